@@ -1,0 +1,219 @@
+/*
+ * mgf.h -- C ABI of the MI355X (gfx950) latent-projection / GANformer-synthesis engine.
+ *
+ * Drop-in boundary for the hot path of nz0001na/MorphGANformer.  Every entry point
+ * takes plain device pointers + sizes + a HIP stream; no torch types.  All functions:
+ *   - return 0 on success, a negative MGF_E* code on failure (mgf_last_error() gives the message,
+ *     thread-local), never throw, never synchronise the device, never allocate device memory;
+ *   - launch on the given stream (NULL = the null stream), outputs are caller-allocated;
+ *   - validate shapes/extents on the host before launching (mirrors the TORCH_CHECKs of the plugins).
+ *
+ * Each declaration cites the reference interface it replaces (file:line under the reference tree).
+ */
+#ifndef MGF_H_
+#define MGF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mgf_stream_t; /* hipStream_t */
+
+enum { MGF_OK = 0, MGF_EINVAL = -1, MGF_EUNSUPPORTED = -2, MGF_ELAUNCH = -3, MGF_ETOOBIG = -4 };
+enum { MGF_F32 = 0, MGF_F64 = 1, MGF_F16 = 2 };
+/* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:15-25) */
+enum { MGF_ACT_LINEAR = 1, MGF_ACT_RELU = 2, MGF_ACT_LRELU = 3, MGF_ACT_TANH = 4, MGF_ACT_SIGMOID = 5,
+       MGF_ACT_ELU = 6, MGF_ACT_SELU = 7, MGF_ACT_SOFTPLUS = 8, MGF_ACT_SWISH = 9 };
+
+const char* mgf_last_error(void);
+int mgf_version(void);
+/* 1 if a gfx950 device is present and usable */
+int mgf_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * bias_act -- replaces bias_act_plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)
+ * (torch_utils/ops/bias_act.cpp:24-82, kernel bias_act.cu:15-139).
+ *   y[i] = F_grad( x[i], b[(i / step_b) % size_b], xref[i], yref[i], dy[i] )
+ * grad 0: y = clamp(act(x+b)*gain); grad 1: first derivative form (x carries dy); grad 2: second derivative form.
+ * NULL pointer = the reference's "empty tensor".  numel <= INT32_MAX (bias_act.cpp:32).
+ */
+int mgf_bias_act(void* y, const void* x, const void* b, const void* xref, const void* yref, const void* dy,
+                 int dtype, int64_t numel, int64_t step_b, int64_t size_b,
+                 int grad, int act, float alpha, float gain, float clamp, mgf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * upfirdn2d -- replaces upfirdn2d_plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1,
+ * flip, gain) (torch_utils/ops/upfirdn2d.cpp:8-86, kernels upfirdn2d.cu:21-333).
+ * x: [n, c, in_h, in_w] with element strides (sn, sc, sh, sw) -> NCHW and channels_last both accepted;
+ * f: float32 [fh, fw] contiguous; y: [n, c, out_h, out_w] with strides (yn, yc, yh, yw), where
+ *   out = (in*up + pad0 + pad1 - fsize + down) / down          (upfirdn2d.cpp:24-25)
+ * Optional fused epilogue (all NULL/0 = plain reference op), applied after the FIR and gain:
+ *   y = lrelu_or_linear( y + noise[n % noise_n, oy, ox] * *noise_strength + bias[c] ) * ep_gain
+ * used by the synthesis engine to fold SynthesisLayer steps 5-6 (training/networks.py:1036-1040) into the
+ * post-transposed-conv blur.
+ */
+typedef struct mgf_epilogue {
+    const float* bias;            /* [c] or NULL */
+    const float* noise;           /* [noise_n, out_h, out_w] or NULL */
+    const float* noise_strength;  /* device scalar or NULL (=1) */
+    int32_t noise_n;              /* 1 = broadcast over batch */
+    int32_t act;                  /* MGF_ACT_LINEAR / MGF_ACT_LRELU / MGF_ACT_RELU */
+    float alpha;
+    float gain;                   /* post-activation gain */
+    const float* residual;        /* same shape/strides as y, or NULL: y += residual after the gain */
+} mgf_epilogue;
+
+int mgf_upfirdn2d(void* y, const void* x, const float* f, int dtype,
+                  int32_t n, int32_t c, int32_t in_h, int32_t in_w,
+                  int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                  int32_t out_h, int32_t out_w, int64_t yn, int64_t yc, int64_t yh, int64_t yw,
+                  int32_t fh, int32_t fw, int32_t upx, int32_t upy, int32_t downx, int32_t downy,
+                  int32_t padx0, int32_t padx1, int32_t pady0, int32_t pady1, int32_t flip, float gain,
+                  const mgf_epilogue* ep, mgf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tap-list convolution on FP32 MFMA (v_mfma_f32_32x32x2_f32) -- the engine's replacement for the cuDNN calls
+ * behind conv2d_resample / modulated_conv2d (torch_utils/ops/conv2d_resample.py:21-46,99-139;
+ * training/networks.py:253-328).
+ *
+ *   acc[n, g, co, ty, tx] = sum_{t in group g} sum_{ci} wp[t][ci][co] *
+ *                           ( x[n, ci, ty*istride + dy[t], tx*istride + dx[t]] * in_scale[n, ci] )   (0 outside x)
+ *   y[n, co, ty*ostride + oy[g], tx*ostride + ox[g]] = epilogue( acc * out_scale[n, co] )
+ *
+ * - a 3x3 'same' correlation is 9 taps in one group (dy,dx in {-1,0,1});
+ * - the stride-2 transposed conv of the up=2 path (conv2d_resample.py:117-130) is 9 taps in 4 parity groups
+ *   with ostride 2, computed at the transposed-conv's own FLOP count;
+ * - in_scale = style modulation, out_scale = demodulation (networks.py:288-293) applied in registers instead of
+ *   materialising per-sample weights.
+ * wp is the packed weight image produced by mgf_pack_conv_weights.  x,y are dense NCHW float32; y has an explicit
+ * row pitch / plane / batch stride (in elements) and a channel offset so that it can be a padded workspace or a
+ * channel slice of a concat buffer.
+ */
+#define MGF_MAX_TAPS 9
+typedef struct mgf_conv_desc {
+    int32_t n, cin, in_h, in_w;          /* input  [n, cin, in_h, in_w] */
+    int32_t cout;                        /* real output channels */
+    int32_t cout_pad;                    /* packed weight channel count (multiple of 32) */
+    int32_t tile_h, tile_w;              /* extent of the (ty,tx) iteration space */
+    int32_t istride, ostride;
+    int32_t ntaps, ngroups;
+    int32_t dy[MGF_MAX_TAPS], dx[MGF_MAX_TAPS], group[MGF_MAX_TAPS];
+    int32_t oy[4], ox[4];
+    int32_t out_h, out_w;                /* valid output extent (stores outside are dropped) */
+    int64_t y_pitch, y_plane, y_batch;   /* element strides of y */
+    int32_t y_choff;                     /* channel offset into y */
+    int32_t out_scale_stride;            /* elements between samples in out_scale (0 = shared) */
+} mgf_conv_desc;
+
+int mgf_conv_taps_f32(float* y, const float* x, const float* wp, const float* in_scale, const float* out_scale,
+                      const mgf_conv_desc* d, const mgf_epilogue* ep, mgf_stream_t stream);
+
+/* Repack [cout, cin, kh, kw] float32 weights (times `gain`) into the [tap][cin][cout_pad] image read by
+ * mgf_conv_taps_f32; `flip` reverses kh,kw (true convolution).  Taps are emitted in (kh, kw) row-major order.
+ * Also emits wsq[cout, cin] = sum_k (w*gain)^2 when wsq != NULL (demodulation table). Device pointers. */
+int mgf_pack_conv_weights(float* wp, float* wsq, const float* w, int32_t cout, int32_t cin, int32_t kh, int32_t kw,
+                          int32_t cout_pad, float gain, int32_t flip, mgf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Styles + demodulation coefficients -- FullyConnectedLayer affine + the `d` of modulated_conv2d
+ * (training/networks.py:131-150, 288-291, 1022, 1056-1059).  For sample n and job j, with
+ * wg = ws[n * ws_stride_n + j.w_offset ...] (the global latent component of that layer's ws slot):
+ *   s[n, ci] = ((sum_k wg[k] * aff_w[ci, k]) * aff_gain + aff_b[ci]) * style_gain
+ *   d[n, co] = rsqrt( sum_ci wsq[co, ci] * s[n, ci]^2 + 1e-8 )                   (if wsq and d are non-NULL)
+ * wsq comes from mgf_pack_conv_weights.  The _multi form takes a DEVICE array of jobs (one launch for all layers).
+ */
+typedef struct mgf_style_job {
+    const float* aff_w;   /* [cin, wdim] */
+    const float* aff_b;   /* [cin] */
+    const float* wsq;     /* [cout, cin] or NULL */
+    float* s;             /* [n, cin] */
+    float* d;             /* [n, cout] or NULL */
+    int32_t cin, cout;
+    int32_t w_offset;
+    float aff_gain, style_gain;
+} mgf_style_job;
+int mgf_style_demod(const mgf_style_job* job, const float* ws, int64_t ws_stride_n, int32_t n, int32_t wdim, mgf_stream_t stream);
+int mgf_style_demod_multi(const mgf_style_job* jobs_dev, int32_t njobs, const float* ws, int64_t ws_stride_n,
+                          int32_t n, int32_t wdim, mgf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Duplex (image <- latents) attention of a SynthesisLayer, k-means/parametric-centroid form, integration "mul",
+ * layer norm -- replaces TransformerLayer.forward + integrate + att_norm (training/networks.py:748-822,657-672,
+ * 341-358) and the noise / bias_act tail of SynthesisLayer.forward (:1036-1040).
+ *
+ * Re-associated (exact in real arithmetic; checked against the oracle to 1e-3 relative):
+ *   S[f,t]  = sum_c x[n,c,f] * wqc[c,t] + spos[f,t]           wqc [c,t], spos [f,t]: checkpoint constants (engine.py)
+ *   P       = softmax_t(S)
+ *   g[f,c]  = sum_t P[f,t] * vwb[n,c,t]                        vwb = (V Wm^T + bm + 1), per sample (mgf_attn_values)
+ *   y[n,c,f]= epilogue( x[n,c,f] * rsqrt(mean_c x^2 + 1e-8) * g[f,c] )
+ * probs (optional) receives P as [n, f, t]; argmax (optional) receives the per-pixel latent assignment [n, f] int32.
+ */
+int mgf_duplex_attention(float* y, const float* x, const float* wqc, const float* spos, const float* vwb,
+                         int32_t n, int32_t c, int32_t f, int32_t t,
+                         const mgf_epilogue* ep, int32_t ep_w, float* probs, int32_t* argmax, mgf_stream_t stream);
+
+/* vwb[n,c,t] = sum_k ycomp[n,t,k] * wmv[c,k] + bmv[c]   (wmv = Wm*Wv folded, bmv = Wm*bv + bm + 1: checkpoint constants;
+ * ycomp[n,t,:] = ws[n*ws_stride_n + t*ws_stride_t + w_offset ...], the local latent components).  t fastest in vwb. */
+typedef struct mgf_attn_job {
+    const float* wmv;     /* [c, wdim] */
+    const float* bmv;     /* [c] */
+    float* vwb;           /* [n, c, t] */
+    int32_t c;
+    int32_t w_offset;
+} mgf_attn_job;
+int mgf_attn_values(const mgf_attn_job* job, const float* ws, int64_t ws_stride_n, int64_t ws_stride_t, int32_t n, int32_t t,
+                    int32_t wdim, mgf_stream_t stream);
+int mgf_attn_values_multi(const mgf_attn_job* jobs_dev, int32_t njobs, const float* ws, int64_t ws_stride_n, int64_t ws_stride_t,
+                          int32_t n, int32_t t, int32_t wdim, mgf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mapping network z -> w  (MappingNetwork.forward, training/networks.py:894-942 with MLP/ResnetLayer :154-221 and the
+ * latent self-attention TransformerLayer :748-822).  One workgroup per sample.
+ * params: packed float32 blob, layout documented in morphganformer_amd/engine.py (pack_mapping_params).
+ * z: [n, k, dim] ; w: [n, k, dim].  dim == 32, k <= 33.
+ */
+int64_t mgf_mapping_param_floats(int32_t k, int32_t dim, int32_t n_res_layers);
+int mgf_mapping_forward(float* w, const float* z, const float* params, int32_t n, int32_t k, int32_t dim,
+                        int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses of the projection loop.
+ * mse:   out[0] (+)= mean((a-b)^2)                 torch.nn.MSELoss, 1024_example_wing_loss_perceptual_sqz_MSE.py:176
+ * wing:  out[0] = WingLoss(pred, target) in f64     wing_loss.py:19-28
+ * lpips layer: out[0] += mean_hw( sum_c lin[c] * (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))^2 )   lpips/networks_basic.py:70-87
+ * All accumulate through a deterministic two-stage reduction (no float atomics) using `scratch`
+ * (>= mgf_reduce_scratch_floats() floats).
+ */
+int64_t mgf_reduce_scratch_floats(void);
+int mgf_mse_f32(float* out, const float* a, const float* b, int64_t numel, float scale, int32_t accumulate,
+                float* scratch, mgf_stream_t stream);
+int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int64_t numel, double omega, double epsilon,
+                      mgf_stream_t stream);
+int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1, const float* lin, int32_t n, int32_t c, int64_t hw,
+                        int32_t accumulate, float* scratch, mgf_stream_t stream);
+/* y = max over a 3x3 window, stride 2, ceil_mode (torchvision SqueezeNet1.1 features[2,5,8]) */
+int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                              mgf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Literal projection step bookkeeping (1024_example_wing_loss_perceptual_sqz_MSE.py:156-157,179,186-189), on device so the
+ * loop never synchronises with the host:
+ *   perturb: latent_n = latent_in + eps[*step] * sigma[*step]      (eps: [steps, numel] injected randn stream, sigma: [steps])
+ *   select:  total = p_loss + lamda*w_loss + beta*mse (float64, as torch promotes it); if total < *min_loss:
+ *            min_loss=total, best_latent=latent_n, best_step=*step.  losses_out[*step] = total (NaN when !valid = "no face",
+ *            ...sqz_MSE.py:165-166).  Finally *step += 1.  All state lives on the device -> graph-replayable.
+ */
+int mgf_latent_perturb(float* latent_n, const float* latent_in, const float* eps, const float* sigma, const int32_t* step,
+                       int64_t numel, mgf_stream_t stream);
+int mgf_select_best(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out,
+                    const float* latent_n, int64_t numel, const float* p_loss, const double* w_loss, const float* mse_loss,
+                    float lamda, float beta, int32_t* step, int32_t valid, mgf_stream_t stream);
+/* uint8 HWC image = clip(rint(x*127.5+127.5), 0, 255) from CHW float (misc.to_pil, misc.py:114-123) */
+int mgf_to_uint8_hwc(uint8_t* out, const float* img, int32_t c, int32_t h, int32_t w, mgf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGF_H_ */

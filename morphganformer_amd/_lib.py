@@ -1,0 +1,126 @@
+"""ctypes binding of the C ABI in include/mgf.h (libmgf_hip.so, built in-tree by morphganformer_amd/build.py).
+
+There is NO CPU fallback: if the shared library is missing, `lib()` raises, and every op checks that its tensors
+live on a HIP device.  (The reference silently falls back to slow torch ops when its plugin build fails,
+torch_utils/ops/bias_act.py:39-43; a drop-in for the GPU hot path must not.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmgf_hip.so")
+
+MGF_F32, MGF_F64, MGF_F16 = 0, 1, 2
+ACT_IDS = {"linear": 1, "relu": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5, "elu": 6, "selu": 7, "softplus": 8, "swish": 9}
+MAX_TAPS = 9
+
+i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("bias", vp), ("noise", vp), ("noise_strength", vp), ("noise_n", i32), ("act", i32), ("alpha", f32),
+                ("gain", f32), ("residual", vp)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("n", i32), ("cin", i32), ("in_h", i32), ("in_w", i32), ("cout", i32), ("cout_pad", i32),
+                ("tile_h", i32), ("tile_w", i32), ("istride", i32), ("ostride", i32), ("ntaps", i32), ("ngroups", i32),
+                ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("group", i32 * MAX_TAPS), ("oy", i32 * 4), ("ox", i32 * 4),
+                ("out_h", i32), ("out_w", i32), ("y_pitch", i64), ("y_plane", i64), ("y_batch", i64), ("y_choff", i32),
+                ("out_scale_stride", i32)]
+
+
+class StyleJob(C.Structure):
+    _fields_ = [("aff_w", vp), ("aff_b", vp), ("wsq", vp), ("s", vp), ("d", vp), ("cin", i32), ("cout", i32),
+                ("w_offset", i32), ("aff_gain", f32), ("style_gain", f32)]
+
+
+class AttnJob(C.Structure):
+    _fields_ = [("wmv", vp), ("bmv", vp), ("vwb", vp), ("c", i32), ("w_offset", i32)]
+
+
+_SIGS = {
+    "mgf_last_error": (C.c_char_p, []),
+    "mgf_version": (C.c_int, []),
+    "mgf_device_ok": (C.c_int, []),
+    "mgf_bias_act": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, i64, i64, i64, C.c_int, C.c_int, f32, f32, f32, vp]),
+    "mgf_upfirdn2d": (C.c_int, [vp, vp, vp, C.c_int, i32, i32, i32, i32, i64, i64, i64, i64, i32, i32, i64, i64, i64, i64,
+                                i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, C.POINTER(Epilogue), vp]),
+    "mgf_conv_taps_f32": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(ConvDesc), C.POINTER(Epilogue), vp]),
+    "mgf_pack_conv_weights": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "mgf_style_demod": (C.c_int, [C.POINTER(StyleJob), vp, i64, i32, i32, vp]),
+    "mgf_style_demod_multi": (C.c_int, [vp, i32, vp, i64, i32, i32, vp]),
+    "mgf_duplex_attention": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(Epilogue), i32, vp, vp, vp]),
+    "mgf_attn_values": (C.c_int, [C.POINTER(AttnJob), vp, i64, i64, i32, i32, i32, vp]),
+    "mgf_attn_values_multi": (C.c_int, [vp, i32, vp, i64, i64, i32, i32, i32, vp]),
+    "mgf_mapping_param_floats": (i64, [i32, i32, i32]),
+    "mgf_mapping_forward": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mgf_reduce_scratch_floats": (i64, []),
+    "mgf_mse_f32": (C.c_int, [vp, vp, vp, i64, f32, i32, vp, vp]),
+    "mgf_wing_loss_f64": (C.c_int, [vp, vp, vp, i64, f64, f64, vp]),
+    "mgf_lpips_layer_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i64, i32, vp, vp]),
+    "mgf_maxpool3x3s2_ceil_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mgf_latent_perturb": (C.c_int, [vp, vp, vp, vp, vp, i64, vp]),
+    "mgf_select_best": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp, vp, f32, f32, vp, i32, vp]),
+    "mgf_to_uint8_hwc": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+}
+
+EXPORTED_SYMBOLS = sorted(_SIGS)
+_lib = None
+
+
+class MgfError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libmgf_hip.so (once).  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MgfError(f"{LIB_PATH} is missing: run `python -m morphganformer_amd.build` (or __graft_entry__.build()). "
+                           "There is no CPU fallback for the HIP path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().mgf_last_error().decode(errors="replace")
+        raise MgfError(f"{what or 'mgf'} failed (code {rc}): {msg}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and t.device.type != "cuda":
+            raise MgfError(f"HIP op received a tensor on '{t.device}'; the MI355X path has no CPU fallback "
+                           "(use impl='ref' only in oracle tests)")
+
+
+def dtype_id(dt: torch.dtype) -> int:
+    try:
+        return {torch.float32: MGF_F32, torch.float64: MGF_F64, torch.float16: MGF_F16}[dt]
+    except KeyError:
+        raise MgfError(f"unsupported dtype {dt}") from None
+
+
+def make_epilogue(bias=None, noise=None, noise_strength=None, noise_n=1, act="linear", alpha=0.2, gain=1.0, residual=None):
+    return Epilogue(ptr(bias), ptr(noise), ptr(noise_strength), int(noise_n), ACT_IDS[act], float(alpha), float(gain),
+                    ptr(residual))

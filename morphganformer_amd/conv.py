@@ -1,0 +1,129 @@
+"""Host wrappers around the FP32-MFMA tap-list convolution (mgf_conv_taps_f32 / mgf_pack_conv_weights, include/mgf.h).
+
+These are the building blocks shared by the reference-compatible operator API (torch_utils/ops/conv2d_resample.py) and
+the synthesis engine (engine.py), which packs weights once per checkpoint instead of per call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+@dataclass
+class PackedConv:
+    wp: torch.Tensor            # [taps, cin, cout_pad]
+    wsq: torch.Tensor | None    # [cout, cin]
+    cout: int
+    cin: int
+    kh: int
+    kw: int
+    cout_pad: int
+
+
+def pack_weights(w: torch.Tensor, gain: float = 1.0, flip: bool = False, want_wsq: bool = False) -> PackedConv:
+    """[cout, cin, kh, kw] -> tap-major image (+ demodulation table).  flip=True reverses kh,kw (true convolution)."""
+    _lib.require_gpu(w)
+    w = w.contiguous().float()
+    cout, cin, kh, kw = w.shape
+    cout_pad = round_up(cout, 32)
+    wp = torch.empty([kh * kw, cin, cout_pad], dtype=torch.float32, device=w.device)
+    wsq = torch.empty([cout, cin], dtype=torch.float32, device=w.device) if want_wsq else None
+    rc = _lib.lib().mgf_pack_conv_weights(wp.data_ptr(), _lib.ptr(wsq), w.data_ptr(), cout, cin, kh, kw, cout_pad,
+                                          float(gain), int(flip), _lib.stream_ptr())
+    _lib.check(rc, "pack_conv_weights")
+    return PackedConv(wp, wsq, cout, cin, kh, kw, cout_pad)
+
+
+def _desc(n, cin, in_h, in_w, cout, cout_pad, tile_h, tile_w, istride, ostride, taps, groups, oy, ox, out_h, out_w,
+          y_pitch, y_plane, y_batch, y_choff=0, out_scale_stride=0):
+    d = _lib.ConvDesc()
+    d.n, d.cin, d.in_h, d.in_w, d.cout, d.cout_pad = n, cin, in_h, in_w, cout, cout_pad
+    d.tile_h, d.tile_w, d.istride, d.ostride = tile_h, tile_w, istride, ostride
+    d.ntaps, d.ngroups = len(taps), (max(groups) + 1 if groups else 1)
+    for i, (dy, dx) in enumerate(taps):
+        d.dy[i], d.dx[i] = dy, dx
+        d.group[i] = groups[i] if groups else 0
+    for i in range(4):
+        d.oy[i] = oy[i] if i < len(oy) else 0
+        d.ox[i] = ox[i] if i < len(ox) else 0
+    d.out_h, d.out_w, d.y_pitch, d.y_plane, d.y_batch = out_h, out_w, y_pitch, y_plane, y_batch
+    d.y_choff, d.out_scale_stride = y_choff, out_scale_stride
+    return d
+
+
+def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_scale=None, epilogue=None, out=None,
+                 out_choff=0):
+    """Correlation with the packed taps: y[oy,ox] = sum w[kh,kw] x[oy*stride + kh - pad_y, ox*stride + kw - pad_x].
+
+    `out` may be a larger [n, C_total, oh, ow] buffer; this conv then writes channels [out_choff, out_choff + cout)."""
+    _lib.require_gpu(x, pc.wp, in_scale, out_scale, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and x.shape[1] == pc.cin
+    n, cin, h, w = x.shape
+    py, px = pad
+    oh = (h + 2 * py - pc.kh) // stride + 1
+    ow = (w + 2 * px - pc.kw) // stride + 1
+    if out is None:
+        out = torch.empty([n, pc.cout, oh, ow], dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and out.shape[0] == n and out.shape[2] == oh and out.shape[3] == ow
+    taps = [(kh - py, kw - px) for kh in range(pc.kh) for kw in range(pc.kw)]
+    d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, oh, ow, stride, 1, taps, None, [0], [0], oh, ow,
+              ow, oh * ow, out.shape[1] * oh * ow, out_choff,
+              0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
+    rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                      C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
+    _lib.check(rc, "conv_taps")
+    return out
+
+
+TCONV_TAPS = [(-1 if kh == 2 else 0, -1 if kw == 2 else 0) for kh in range(3) for kw in range(3)]
+TCONV_GROUPS = [(2 if kh == 1 else 0) + (1 if kw == 1 else 0) for kh in range(3) for kw in range(3)]
+
+
+def tconv_pitch(w: int) -> int:
+    return round_up(2 * w + 1, 4)
+
+
+def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=None):
+    """Stride-2 3x3 transposed convolution t[2i+kh, 2j+kw] += w[kh,kw] x[i,j] -> view [n, cout, 2h+1, 2w+1] of a padded-pitch
+    workspace (row pitch a multiple of 4 floats so the parity pairs are written as aligned float2)."""
+    _lib.require_gpu(x, pc.wp, in_scale, out_scale, out)
+    assert pc.kh == 3 and pc.kw == 3 and x.dtype == torch.float32 and x.is_contiguous()
+    n, cin, h, w = x.shape
+    oh, ow = 2 * h + 1, 2 * w + 1
+    pitch = tconv_pitch(w)
+    if out is None:
+        out = torch.empty([n, pc.cout, oh, pitch], dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and tuple(out.shape) == (n, pc.cout, oh, pitch)
+    d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, h + 1, w + 1, 1, 2, TCONV_TAPS, TCONV_GROUPS, [0, 0, 1, 1], [0, 1, 0, 1],
+              oh, ow, pitch, oh * pitch, pc.cout * oh * pitch, 0,
+              0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
+    rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                      C.byref(d), None, _lib.stream_ptr())
+    _lib.check(rc, "conv_taps(tconv)")
+    return out[:, :, :, :ow]
+
+
+def upfirdn_into(y, x, f2d, up=1, pad=(0, 0, 0, 0), gain=1.0, flip=False, epilogue=None):
+    """mgf_upfirdn2d on arbitrary-stride 4-D views (x may be the padded-pitch transposed-conv workspace), down=1."""
+    _lib.require_gpu(x, y, f2d)
+    n, c, h, w = x.shape
+    fh, fw = f2d.shape
+    px0, px1, py0, py1 = pad
+    oh = h * up + py0 + py1 - fh + 1
+    ow = w * up + px0 + px1 - fw + 1
+    assert tuple(y.shape) == (n, c, oh, ow), (tuple(y.shape), (n, c, oh, ow))
+    sx, sy = x.stride(), y.stride()
+    rc = _lib.lib().mgf_upfirdn2d(y.data_ptr(), x.data_ptr(), f2d.data_ptr(), _lib.MGF_F32, n, c, h, w, sx[0], sx[1], sx[2],
+                                  sx[3], oh, ow, sy[0], sy[1], sy[2], sy[3], fh, fw, up, up, 1, 1, px0, px1, py0, py1,
+                                  int(flip), float(gain), C.byref(epilogue) if epilogue is not None else None,
+                                  _lib.stream_ptr())
+    _lib.check(rc, "upfirdn2d")
+    return y

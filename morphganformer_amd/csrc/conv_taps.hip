@@ -1,0 +1,350 @@
+// Tap-list convolution on the FP32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32, exact f32 fma chains).
+// Contract: include/mgf.h (mgf_conv_taps_f32, mgf_pack_conv_weights).  Replaces the cuDNN conv2d /
+// conv_transpose2d calls behind conv2d_resample (torch_utils/ops/conv2d_resample.py:21-46,99-139) and the
+// per-sample weight modulation of modulated_conv2d (training/networks.py:288-303).
+//
+// GEMM view (per sample):  D[co][pixel] = sum_{tap, ci} W[tap][ci][co] * X[ci][pixel + offset(tap)]
+//   A operand = weights  (M = 32 output channels per MFMA tile, one f32 per lane: A[i = l&31][k = l>>5])
+//   B operand = pixels   (N = 32 consecutive pixels of one tile row:            B[k = l>>5][j = l&31])
+//   D layout  = column (pixel) on the lane, rows (channels) across 16 registers -> every store instruction writes
+//               two 128-byte row segments of the NCHW output.
+// Workgroup = 4 waves.  A workgroup owns CO_T = 32*WM output channels x PX = 128*WN pixels ((PX/TW) rows x TW
+// columns, TW = 32 for feature maps >= 32 wide).  Per K chunk of CK input channels it stages in LDS
+//   Xs[CK][FH][FW]  the input footprint (halo included, zero padded, style-modulated on the way in) and
+//   Ws[T][CK][CO_T] the weight slab,
+// then every wave runs T*CK/2 k-steps of WM*WN MFMAs fed by WM + WN conflict-free ds_read_b32.
+// MODE 1 is the stride-2 transposed convolution: the 9 taps feed 4 output-parity accumulator sets (compile-time
+// tap -> parity map), so it runs at the transposed conv's own FLOP count and writes the parity pairs interleaved.
+#include "mgf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CK = 8;   // input channels per K chunk
+
+struct ConvParams {
+    float* y;
+    const float* x;
+    const float* wp;
+    const float* in_scale;
+    const float* out_scale;
+    mgf_conv_desc d;
+    mgf_epilogue ep;
+    int has_ep;
+    int tw_log2;          // TW = 1 << tw_log2
+    int tiles_x, tiles_y;
+    int fh, fw;           // LDS footprint of a pixel tile
+    int dy_min, dx_min;
+    int co_tiles;
+};
+
+template <int WM, int WN, int MODE>
+struct Tile {
+    static constexpr int CO_T = 32 * WM;
+    static constexpr int PX = 128 * WN;
+    static constexpr int NG = MODE == 1 ? 4 : 1;
+};
+
+__device__ __forceinline__ float epi(const mgf_epilogue& ep, float v, int n, int co, int oy, int ox, int out_h, int out_w,
+                                     int64_t yoff) {
+    if (ep.noise) {
+        float ns = ep.noise_strength ? *ep.noise_strength : 1.0f;
+        int nn = ep.noise_n > 1 ? n : 0;
+        v += ep.noise[((int64_t)nn * out_h + oy) * out_w + ox] * ns;
+    }
+    if (ep.bias) v += ep.bias[co];
+    if (ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * ep.alpha;
+    else if (ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+    v *= ep.gain;
+    if (ep.residual) v += ep.residual[yoff];
+    return v;
+}
+
+// parity group of tap t (t = kh*3 + kw) for the stride-2 transposed conv: kh (kw) == 1 feeds odd rows (cols)
+__host__ __device__ constexpr int tconv_group(int t) { return ((t / 3) == 1 ? 2 : 0) + ((t % 3) == 1 ? 1 : 0); }
+
+template <int WM, int WN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
+    typedef Tile<WM, WN, MODE> TL;
+    constexpr int CO_T = TL::CO_T, PX = TL::PX, NG = TL::NG;
+    extern __shared__ float lds[];
+    const mgf_conv_desc& d = p.d;
+    const int T = d.ntaps;
+    const int chs = p.fh * p.fw;                 // LDS channel stride of Xs
+    float* Xs = lds;
+    float* Ws = lds + CK * chs;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int n = blockIdx.z;
+    const int co0 = blockIdx.y * CO_T;
+    const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
+    const int TW = 1 << p.tw_log2;
+    const int rows = PX >> p.tw_log2;
+    const int ty0 = tile_y * rows, tx0 = tile_x * TW;
+    // top-left input sample of the footprint
+    const int iy0 = ty0 * d.istride + p.dy_min, ix0 = tx0 * d.istride + p.dx_min;
+
+    // per-lane LDS base offset of each of this wave's WN pixel groups, and group validity (wave-uniform)
+    int pbase[WN];
+    bool gvalid[WN];
+#pragma unroll
+    for (int g = 0; g < WN; ++g) {
+        const int pix = (wave * WN + g) * 32 + l31;
+        const int ty = pix >> p.tw_log2, tx = pix & (TW - 1);
+        pbase[g] = ty * d.istride * p.fw + tx * d.istride;
+        const int ty_first = ((wave * WN + g) * 32) >> p.tw_log2;
+        gvalid[g] = (ty0 + ty_first) < d.tile_h;
+    }
+
+    f32x16 acc[NG][WM][WN];
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int g = 0; g < WN; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][m][g][r] = 0.f;
+
+    const float* xn = p.x + (int64_t)n * d.cin * d.in_h * d.in_w;
+    const float* sc = p.in_scale ? p.in_scale + (int64_t)n * d.cin : nullptr;
+    const int fsz = CK * chs;
+    const int wrow4 = CO_T / 4;                       // float4 per weight row
+    const int wsz4 = T * CK * wrow4;
+
+    for (int c0 = 0; c0 < d.cin; c0 += CK) {
+        __syncthreads();                              // previous chunk fully consumed
+        // ---- stage input footprint: Xs[ch][r][q], q fastest (coalesced row segments) ----
+        for (int i = tid; i < fsz; i += 256) {
+            const int ch = i / chs;
+            const int rem = i - ch * chs;
+            const int r = rem / p.fw, q = rem - r * p.fw;
+            const int ci = c0 + ch, iy = iy0 + r, ix = ix0 + q;
+            float v = 0.f;
+            if (ci < d.cin && iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) {
+                v = xn[((int64_t)ci * d.in_h + iy) * d.in_w + ix];
+                if (sc) v *= sc[ci];
+            }
+            Xs[i] = v;
+        }
+        // ---- stage weight slab: Ws[t][ch][co] from wp[t][ci][cout_pad] ----
+        for (int i = tid; i < wsz4; i += 256) {
+            const int c4 = i % wrow4;
+            const int rest = i / wrow4;
+            const int ch = rest % CK, t = rest / CK;
+            const int ci = c0 + ch;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < d.cin) v = *reinterpret_cast<const float4*>(p.wp + ((int64_t)t * d.cin + ci) * d.cout_pad + co0 + c4 * 4);
+            *reinterpret_cast<float4*>(Ws + (t * CK + ch) * CO_T + c4 * 4) = v;
+        }
+        __syncthreads();
+        // ---- MFMA over taps x channel pairs ----
+        if (MODE == 0) {
+            for (int t = 0; t < T; ++t) {
+                const int toff = (d.dy[t] - p.dy_min) * p.fw + (d.dx[t] - p.dx_min);
+#pragma unroll
+                for (int kk = 0; kk < CK / 2; ++kk) {
+                    const int ch = 2 * kk + half;
+                    float a[WM], b[WN];
+#pragma unroll
+                    for (int m = 0; m < WM; ++m) a[m] = Ws[(t * CK + ch) * CO_T + m * 32 + l31];
+#pragma unroll
+                    for (int g = 0; g < WN; ++g) b[g] = Xs[ch * chs + pbase[g] + toff];
+#pragma unroll
+                    for (int m = 0; m < WM; ++m)
+#pragma unroll
+                        for (int g = 0; g < WN; ++g)
+                            if (gvalid[g]) acc[0][m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[g], acc[0][m][g], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                constexpr int dummy = 0; (void)dummy;
+                const int toff = (d.dy[t] - p.dy_min) * p.fw + (d.dx[t] - p.dx_min);
+                const int q = tconv_group(t);
+#pragma unroll
+                for (int kk = 0; kk < CK / 2; ++kk) {
+                    const int ch = 2 * kk + half;
+                    float a[WM], b[WN];
+#pragma unroll
+                    for (int m = 0; m < WM; ++m) a[m] = Ws[(t * CK + ch) * CO_T + m * 32 + l31];
+#pragma unroll
+                    for (int g = 0; g < WN; ++g) b[g] = Xs[ch * chs + pbase[g] + toff];
+#pragma unroll
+                    for (int m = 0; m < WM; ++m)
+#pragma unroll
+                        for (int g = 0; g < WN; ++g)
+                            if (gvalid[g]) acc[NG == 4 ? q : 0][m][g] =
+                                __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[g], acc[NG == 4 ? q : 0][m][g], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: demodulate, noise/bias/activation/gain/residual, store ----
+    float* yn = p.y + (int64_t)n * d.y_batch;
+    const float* osc = p.out_scale ? p.out_scale + (int64_t)n * d.out_scale_stride : nullptr;
+#pragma unroll
+    for (int g = 0; g < WN; ++g) {
+        if (!gvalid[g]) continue;
+        const int pix = (wave * WN + g) * 32 + l31;
+        const int ty = ty0 + (pix >> p.tw_log2), tx = tx0 + (pix & (TW - 1));
+        const bool pvalid = ty < d.tile_h && tx < d.tile_w;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co >= d.cout || !pvalid) continue;
+                const float os = osc ? osc[co] : 1.0f;
+                float* yc = yn + (int64_t)(d.y_choff + co) * d.y_plane;
+                if (MODE == 0) {
+                    const int oy = ty * d.ostride + d.oy[0], ox = tx * d.ostride + d.ox[0];
+                    if (oy < d.out_h && ox < d.out_w) {
+                        const int64_t off = (int64_t)oy * d.y_pitch + ox;
+                        float v = acc[0][m][g][r] * os;
+                        if (p.has_ep) v = epi(p.ep, v, n, co, oy, ox, d.out_h, d.out_w, (yc - p.y) + off);
+                        yc[off] = v;
+                    }
+                } else {
+                    // parity sets: q = 2*a + b -> row 2*ty + a, cols 2*tx + {0,1} written as a pair
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        const int oy = 2 * ty + a2, ox = 2 * tx;
+                        if (oy >= d.out_h || ox >= d.out_w) continue;
+                        const int64_t off = (int64_t)oy * d.y_pitch + ox;
+                        const float v0 = acc[NG == 4 ? 2 * a2 : 0][m][g][r] * os;
+                        const float v1 = acc[NG == 4 ? 2 * a2 + 1 : 0][m][g][r] * os;
+                        if (ox + 1 < d.out_w) *reinterpret_cast<float2*>(yc + off) = make_float2(v0, v1);
+                        else yc[off] = v0;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MODE>
+int launch_conv(const ConvParams& p, hipStream_t st) {
+    typedef Tile<WM, WN, MODE> TL;
+    const size_t lds = ((size_t)CK * p.fh * p.fw + (size_t)p.d.ntaps * CK * TL::CO_T) * sizeof(float);
+    if (lds > 160 * 1024) { mgf_set_error("conv_taps: tile needs %zu bytes of LDS (> 160 KiB)", lds); return MGF_EUNSUPPORTED; }
+    auto kern = conv_taps_kernel<WM, WN, MODE>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { mgf_set_error("conv_taps: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
+    }
+    dim3 grid(p.tiles_x * p.tiles_y, p.co_tiles, p.d.n);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    return MGF_OK;
+}
+
+__global__ void pack_weights_kernel(float* wp, float* wsq, const float* w, int cout, int cin, int kh, int kw, int cout_pad,
+                                    float gain, int flip) {
+    const int T = kh * kw;
+    const int64_t total = (int64_t)T * cin * cout_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout_pad);
+        const int64_t r = i / cout_pad;
+        const int ci = (int)(r % cin);
+        const int t = (int)(r / cin);
+        float v = 0.f;
+        if (co < cout) {
+            int ky = t / kw, kx = t % kw;
+            if (flip) { ky = kh - 1 - ky; kx = kw - 1 - kx; }
+            v = w[(((int64_t)co * cin + ci) * kh + ky) * kw + kx] * gain;
+        }
+        wp[i] = v;
+    }
+    if (wsq) {
+        const int64_t tot2 = (int64_t)cout * cin;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot2; i += (int64_t)gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int t = 0; t < T; ++t) { float v = w[i * T + t] * gain; s += v * v; }
+            wsq[i] = s;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mgf_pack_conv_weights(float* wp, float* wsq, const float* w, int32_t cout, int32_t cin, int32_t kh, int32_t kw,
+                                     int32_t cout_pad, float gain, int32_t flip, mgf_stream_t stream) {
+    MGF_REQUIRE(wp && w, MGF_EINVAL, "pack_conv_weights: null pointer");
+    MGF_REQUIRE(cout >= 1 && cin >= 1 && kh >= 1 && kw >= 1 && kh * kw <= MGF_MAX_TAPS, MGF_EINVAL, "pack_conv_weights: bad shape");
+    MGF_REQUIRE(cout_pad >= cout && cout_pad % 32 == 0, MGF_EINVAL, "pack_conv_weights: cout_pad must be a multiple of 32 >= cout");
+    const int64_t total = (int64_t)kh * kw * cin * cout_pad;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(mgf_stream_grid(total, 256, 4)), dim3(256), 0, (hipStream_t)stream, wp, wsq, w,
+                       cout, cin, kh, kw, cout_pad, gain, flip);
+    MGF_CHECK_LAUNCH("pack_conv_weights");
+    return MGF_OK;
+}
+
+extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, const float* in_scale, const float* out_scale,
+                                 const mgf_conv_desc* dd, const mgf_epilogue* ep, mgf_stream_t stream) {
+    MGF_REQUIRE(y && x && wp && dd, MGF_EINVAL, "conv_taps: null pointer");
+    const mgf_conv_desc& d = *dd;
+    MGF_REQUIRE(d.n >= 1 && d.cin >= 1 && d.cout >= 1 && d.in_h >= 1 && d.in_w >= 1, MGF_EINVAL, "conv_taps: bad shape");
+    MGF_REQUIRE(d.n <= 65535, MGF_ETOOBIG, "conv_taps: batch %d exceeds the grid z limit", d.n);
+    MGF_REQUIRE(d.cout_pad >= d.cout && d.cout_pad % 32 == 0, MGF_EINVAL, "conv_taps: cout_pad must be a multiple of 32 >= cout");
+    MGF_REQUIRE(d.ntaps >= 1 && d.ntaps <= MGF_MAX_TAPS, MGF_EINVAL, "conv_taps: ntaps out of range");
+    MGF_REQUIRE(d.ngroups == 1 || d.ngroups == 4, MGF_EUNSUPPORTED, "conv_taps: ngroups must be 1 or 4");
+    MGF_REQUIRE(d.istride >= 1 && d.ostride >= 1 && d.tile_h >= 1 && d.tile_w >= 1, MGF_EINVAL, "conv_taps: bad strides/tile");
+    MGF_REQUIRE((int64_t)d.cin * d.in_h * d.in_w * d.n <= INT32_MAX, MGF_ETOOBIG, "conv_taps: input too large");
+    MGF_REQUIRE(d.y_pitch >= d.out_w && d.y_plane >= (int64_t)d.out_h * d.y_pitch, MGF_EINVAL, "conv_taps: output strides too small");
+    if (ep) MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU,
+                        MGF_EUNSUPPORTED, "conv_taps: epilogue activation %d unsupported", ep->act);
+    ConvParams p;
+    p.y = y; p.x = x; p.wp = wp; p.in_scale = in_scale; p.out_scale = out_scale; p.d = d;
+    p.has_ep = ep != nullptr;
+    if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
+    int dy_min = d.dy[0], dy_max = d.dy[0], dx_min = d.dx[0], dx_max = d.dx[0];
+    for (int t = 1; t < d.ntaps; ++t) {
+        dy_min = d.dy[t] < dy_min ? d.dy[t] : dy_min; dy_max = d.dy[t] > dy_max ? d.dy[t] : dy_max;
+        dx_min = d.dx[t] < dx_min ? d.dx[t] : dx_min; dx_max = d.dx[t] > dx_max ? d.dx[t] : dx_max;
+    }
+    p.dy_min = dy_min; p.dx_min = dx_min;
+    int mode = 0;
+    if (d.ngroups == 4) {
+        MGF_REQUIRE(d.ntaps == 9 && d.ostride == 2 && d.istride == 1, MGF_EUNSUPPORTED, "conv_taps: 4-group mode is the 3x3 stride-2 transposed conv");
+        for (int t = 0; t < 9; ++t) {
+            MGF_REQUIRE(d.group[t] == tconv_group(t), MGF_EINVAL, "conv_taps: tap %d must belong to parity group %d", t, tconv_group(t));
+        }
+        MGF_REQUIRE(ep == nullptr, MGF_EUNSUPPORTED, "conv_taps: the transposed-conv mode has no fused epilogue (it feeds the FIR pass)");
+        MGF_REQUIRE(d.y_pitch % 2 == 0 && d.y_plane % 2 == 0 && d.y_batch % 2 == 0 && ((uintptr_t)y % 8) == 0, MGF_EINVAL,
+                    "conv_taps: transposed-conv output needs even pitch/plane/batch strides and 8-byte alignment");
+        mode = 1;
+    }
+    // tile geometry
+    int tw_log2 = 5;
+    while (tw_log2 > 2 && (1 << (tw_log2 - 1)) >= d.tile_w) --tw_log2;
+    p.tw_log2 = tw_log2;
+    const int TW = 1 << tw_log2;
+    // pick the workgroup tile: wide channel tiles when there are >= 64 output channels, more pixels per wave otherwise
+    int wm = 1, wn = 2;
+    if (mode == 0) {
+        if (d.cout_pad % 64 == 0 && d.cout > 32) { wm = 2; wn = 2; }
+        else if ((int64_t)d.tile_h * d.tile_w >= 512 * 64) { wm = 1; wn = 4; }
+    }
+    const int PX = 128 * wn;
+    const int rows = PX / TW;
+    p.tiles_x = (int)mgf_cdiv(d.tile_w, TW);
+    p.tiles_y = (int)mgf_cdiv(d.tile_h, rows);
+    p.fh = (rows - 1) * d.istride + (dy_max - dy_min) + 1;
+    p.fw = (TW - 1) * d.istride + (dx_max - dx_min) + 1;
+    p.co_tiles = d.cout_pad / (32 * wm);
+    MGF_REQUIRE((int64_t)p.tiles_x * p.tiles_y <= INT32_MAX && p.co_tiles <= 65535, MGF_ETOOBIG, "conv_taps: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (mode == 1) rc = launch_conv<1, 2, 1>(p, st);
+    else if (wm == 2) rc = launch_conv<2, 2, 0>(p, st);
+    else if (wn == 4) rc = launch_conv<1, 4, 0>(p, st);
+    else rc = launch_conv<1, 2, 0>(p, st);
+    if (rc != MGF_OK) return rc;
+    MGF_CHECK_LAUNCH("conv_taps");
+    return MGF_OK;
+}

@@ -1,0 +1,263 @@
+// Per-iteration latent-side preparation kernels (tiny, launch-latency bound -> batched over layers):
+//   * styles + demodulation coefficients of every modulated conv (training/networks.py:131-150,288-291,1022,1056-1059)
+//   * folded attention value tables vwb = V Wm^T + bm + 1 (networks.py:759,812-814,662-668 re-associated)
+//   * the mapping network z -> w (networks.py:894-942, MLP :179-221, ResnetLayer :154-172, latent self-attention :748-822)
+// Contract: include/mgf.h.
+#include "mgf_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ styles + demod
+// grid = (co_blocks, njobs, n); 256 lanes.  Every block recomputes the (cheap) style vector into LDS, block x == 0
+// publishes it, then the 4 waves walk this block's share of wsq rows: lanes stride over ci (coalesced), wave-reduce.
+__device__ void style_demod_body(const mgf_style_job& j, const float* ws, int64_t ws_stride_n, int wdim, int n, float* s_lds) {
+    const int tid = threadIdx.x;
+    const float* wg = ws + (int64_t)n * ws_stride_n + j.w_offset;
+    for (int ci = tid; ci < j.cin; ci += blockDim.x) {
+        const float* row = j.aff_w + (int64_t)ci * wdim;
+        float acc = 0.f;
+        for (int k = 0; k < wdim; ++k) acc += wg[k] * row[k];
+        float s = (acc * j.aff_gain + j.aff_b[ci]) * j.style_gain;
+        s_lds[ci] = s;
+        if (blockIdx.x == 0) j.s[(int64_t)n * j.cin + ci] = s;
+    }
+    if (!j.wsq || !j.d) return;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int per_block = (j.cout + gridDim.x - 1) / gridDim.x;
+    const int co_begin = blockIdx.x * per_block;
+    const int co_end = min(j.cout, co_begin + per_block);
+    for (int co = co_begin + wave; co < co_end; co += nwaves) {
+        const float* row = j.wsq + (int64_t)co * j.cin;
+        float acc = 0.f;
+        for (int ci = lane; ci < j.cin; ci += 64) { float s = s_lds[ci]; acc += row[ci] * s * s; }
+        acc = wave_sum(acc);
+        if (lane == 0) j.d[(int64_t)n * j.cout + co] = rsqrtf(acc + 1e-8f);
+    }
+}
+
+__global__ __launch_bounds__(256) void style_demod_multi_kernel(const mgf_style_job* jobs, const float* ws, int64_t ws_stride_n, int wdim) {
+    __shared__ float s_lds[2048];
+    const mgf_style_job j = jobs[blockIdx.y];
+    style_demod_body(j, ws, ws_stride_n, wdim, blockIdx.z, s_lds);
+}
+
+__global__ __launch_bounds__(256) void style_demod_single_kernel(mgf_style_job j, const float* ws, int64_t ws_stride_n, int wdim) {
+    __shared__ float s_lds[2048];
+    style_demod_body(j, ws, ws_stride_n, wdim, blockIdx.z, s_lds);
+}
+
+// ------------------------------------------------------------------------------------------ attention value tables
+// vwb[n][c][t] (t fastest: 16 contiguous scalars per channel for the attention kernel's scalar loads)
+//   = sum_j ycomp[n,t,j] * wmv[c,j] + bmv[c]
+__device__ void attn_values_body(const mgf_attn_job& j, const float* ws, int64_t ws_stride_n, int64_t ws_stride_t, int wdim, int t_len, int n) {
+    const int total = j.c * t_len;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int t = i % t_len, c = i / t_len;
+        const float* y = ws + (int64_t)n * ws_stride_n + (int64_t)t * ws_stride_t + j.w_offset;
+        const float* row = j.wmv + (int64_t)c * wdim;
+        float acc = 0.f;
+        for (int k = 0; k < wdim; ++k) acc += y[k] * row[k];
+        j.vwb[((int64_t)n * j.c + c) * t_len + t] = acc + j.bmv[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_values_multi_kernel(const mgf_attn_job* jobs, const float* ws, int64_t sn, int64_t stt, int wdim, int t_len) {
+    const mgf_attn_job j = jobs[blockIdx.y];
+    attn_values_body(j, ws, sn, stt, wdim, t_len, blockIdx.z);
+}
+__global__ __launch_bounds__(256) void attn_values_single_kernel(mgf_attn_job j, const float* ws, int64_t sn, int64_t stt, int wdim, int t_len) {
+    attn_values_body(j, ws, sn, stt, wdim, t_len, blockIdx.z);
+}
+
+// ------------------------------------------------------------------------------------------ mapping network
+// One workgroup (256 lanes) per sample.  All activations live in LDS; every FC is a [rows x 32] . [32 x 32]^T product with the
+// (gain-folded) weight matrix read from the packed parameter blob (L2-resident, 100 KB).
+constexpr int MD = 32;          // latent width handled by this kernel
+constexpr int MT_MAX = 32;      // max local components
+
+struct MapLayout {              // float offsets inside the blob (see engine.py: pack_mapping_params)
+    // global mlp: per res layer {W0,b0,W1,b1}, then {Wout,bout}
+    // local  mlp: per res layer {Wq,bq_pos[T*D],Wk,bk_pos[T*D],Wv,bv,Wm,bm,W0,b0,W1,b1}, then {Wout,bout}
+};
+
+__device__ __forceinline__ float lrelu02(float v) { return v > 0.f ? v : 0.2f * v; }
+
+// out[r][o] = sum_i in[r][i] * W[o][i] + (row_bias ? brow[r*D + o] : b[o]);  rows x 32 outputs spread over the block
+__device__ void fc_rows(float* out, const float* in, const float* W, const float* b, bool row_bias, int rows) {
+    for (int idx = threadIdx.x; idx < rows * MD; idx += blockDim.x) {
+        const int r = idx / MD, o = idx % MD;
+        const float* wr = W + o * MD;
+        const float* xr = in + r * MD;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < MD; ++i) acc += xr[i] * wr[i];
+        out[idx] = acc + (row_bias ? b[r * MD + o] : b[o]);
+    }
+}
+
+__global__ __launch_bounds__(256) void mapping_kernel(float* w, const float* z, const float* P, int k, int n_res, int normalize_global) {
+    __shared__ float X[MT_MAX * MD], Xin[MT_MAX * MD], Q[MT_MAX * MD], K[MT_MAX * MD], V[MT_MAX * MD], H[MT_MAX * MD];
+    __shared__ float Pr[MT_MAX * MT_MAX];
+    __shared__ float G[MD], Gin[MD], GH[MD];
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int T = k - 1;
+    const float* zn = z + (int64_t)n * k * MD;
+    // ---- normalize (networks.py:30-37): joint second moment over the T x D local block; global row separately ----
+    float part = 0.f;
+    for (int i = tid; i < T * MD; i += blockDim.x) { float v = zn[i]; part += v * v; }
+    part = wave_sum(part);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const float fl = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)(T * MD) + 1e-8f);
+    for (int i = tid; i < T * MD; i += blockDim.x) X[i] = zn[i] * fl;
+    __syncthreads();
+    if (tid < 64) {
+        float v = tid < MD ? zn[T * MD + tid] : 0.f;
+        float ss = wave_sum(v * v);
+        float fg = normalize_global ? rsqrtf(ss / (float)MD + 1e-8f) : 1.f;
+        if (tid < MD) G[tid] = v * fg;
+    }
+    __syncthreads();
+
+    const int WSZ = MD * MD;
+    const float* p = P;
+    // ---- global MLP ----
+    for (int l = 0; l < n_res; ++l) {
+        const float *W0 = p, *b0 = p + WSZ, *W1 = b0 + MD, *b1 = W1 + WSZ;
+        p = b1 + MD;
+        if (tid < MD) Gin[tid] = G[tid];
+        __syncthreads();
+        fc_rows(GH, G, W0, b0, false, 1);
+        __syncthreads();
+        if (tid < MD) GH[tid] = lrelu02(GH[tid]) * 1.41421356237309515f;
+        __syncthreads();
+        fc_rows(G, GH, W1, b1, false, 1);
+        __syncthreads();
+        if (tid < MD) G[tid] = lrelu02(G[tid] + Gin[tid]);
+        __syncthreads();
+    }
+    {
+        const float *Wo = p, *bo = p + WSZ;
+        p = bo + MD;
+        fc_rows(GH, G, Wo, bo, false, 1);
+        __syncthreads();
+        if (tid < MD) w[((int64_t)n * k + T) * MD + tid] = lrelu02(GH[tid]) * 1.41421356237309515f;
+    }
+    // ---- local MLP with latent self-attention ----
+    for (int l = 0; l < n_res; ++l) {
+        const float* Wq = p;            const float* bq = Wq + WSZ;
+        const float* Wk = bq + T * MD;  const float* bk = Wk + WSZ;
+        const float* Wv = bk + T * MD;  const float* bv = Wv + WSZ;
+        const float* Wm = bv + MD;      const float* bm = Wm + WSZ;
+        const float* W0 = bm + MD;      const float* b0 = W0 + WSZ;
+        const float* W1 = b0 + MD;      const float* b1 = W1 + WSZ;
+        p = b1 + MD;
+        for (int i = tid; i < T * MD; i += blockDim.x) Xin[i] = X[i];
+        fc_rows(Q, X, Wq, bq, true, T);          // 1/sqrt(D) and the positional term are folded into Wq / bq
+        fc_rows(K, X, Wk, bk, true, T);
+        fc_rows(V, X, Wv, bv, false, T);
+        __syncthreads();
+        for (int idx = tid; idx < T * T; idx += blockDim.x) {
+            const int a = idx / T, b = idx % T;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < MD; ++i) acc += Q[a * MD + i] * K[b * MD + i];
+            Pr[a * MT_MAX + b] = acc;
+        }
+        __syncthreads();
+        if (tid < T) {
+            float m = -3.0e38f;
+            for (int b = 0; b < T; ++b) m = fmaxf(m, Pr[tid * MT_MAX + b]);
+            float s = 0.f;
+            for (int b = 0; b < T; ++b) { float e = expf(Pr[tid * MT_MAX + b] - m); Pr[tid * MT_MAX + b] = e; s += e; }
+            const float inv = 1.f / s;
+            for (int b = 0; b < T; ++b) Pr[tid * MT_MAX + b] *= inv;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < T * MD; idx += blockDim.x) {
+            const int a = idx / MD, o = idx % MD;
+            float acc = 0.f;
+            for (int b = 0; b < T; ++b) acc += Pr[a * MT_MAX + b] * V[b * MD + o];
+            H[idx] = acc;
+        }
+        __syncthreads();
+        fc_rows(Q, H, Wm, bm, false, T);
+        __syncthreads();
+        for (int i = tid; i < T * MD; i += blockDim.x) X[i] += Q[i];        // integration 'add'
+        __syncthreads();
+        fc_rows(H, X, W0, b0, false, T);
+        __syncthreads();
+        for (int i = tid; i < T * MD; i += blockDim.x) H[i] = lrelu02(H[i]) * 1.41421356237309515f;
+        __syncthreads();
+        fc_rows(Q, H, W1, b1, false, T);
+        __syncthreads();
+        for (int i = tid; i < T * MD; i += blockDim.x) X[i] = lrelu02(Q[i] + Xin[i]);
+        __syncthreads();
+    }
+    {
+        const float *Wo = p, *bo = p + WSZ;
+        fc_rows(H, X, Wo, bo, false, T);
+        __syncthreads();
+        for (int i = tid; i < T * MD; i += blockDim.x) w[(int64_t)n * k * MD + i] = lrelu02(H[i]) * 1.41421356237309515f;
+    }
+}
+
+}  // namespace
+
+extern "C" int mgf_style_demod_multi(const mgf_style_job* jobs_dev, int32_t njobs, const float* ws, int64_t ws_stride_n,
+                                     int32_t n, int32_t wdim, mgf_stream_t stream) {
+    MGF_REQUIRE(jobs_dev && ws && njobs >= 1 && n >= 1 && wdim >= 1, MGF_EINVAL, "style_demod_multi: bad arguments");
+    MGF_REQUIRE(njobs <= 65535 && n <= 65535, MGF_ETOOBIG, "style_demod_multi: too many jobs/samples");
+    hipLaunchKernelGGL(style_demod_multi_kernel, dim3(16, njobs, n), dim3(256), 0, (hipStream_t)stream, jobs_dev, ws, ws_stride_n, wdim);
+    MGF_CHECK_LAUNCH("style_demod_multi");
+    return MGF_OK;
+}
+
+extern "C" int mgf_style_demod(const mgf_style_job* job, const float* ws, int64_t ws_stride_n, int32_t n, int32_t wdim,
+                               mgf_stream_t stream) {
+    MGF_REQUIRE(job && ws && n >= 1 && wdim >= 1, MGF_EINVAL, "style_demod: bad arguments");
+    MGF_REQUIRE(job->cin >= 1 && job->cin <= 2048, MGF_EUNSUPPORTED, "style_demod: cin must be in 1..2048 (got %d)", job->cin);
+    MGF_REQUIRE(job->aff_w && job->aff_b && job->s, MGF_EINVAL, "style_demod: null pointer in job");
+    hipLaunchKernelGGL(style_demod_single_kernel, dim3(16, 1, n), dim3(256), 0, (hipStream_t)stream, *job, ws, ws_stride_n, wdim);
+    MGF_CHECK_LAUNCH("style_demod");
+    return MGF_OK;
+}
+
+extern "C" int mgf_attn_values_multi(const mgf_attn_job* jobs_dev, int32_t njobs, const float* ws, int64_t ws_stride_n,
+                                     int64_t ws_stride_t, int32_t n, int32_t t, int32_t wdim, mgf_stream_t stream) {
+    MGF_REQUIRE(jobs_dev && ws && njobs >= 1 && n >= 1 && t >= 1 && wdim >= 1, MGF_EINVAL, "attn_values_multi: bad arguments");
+    hipLaunchKernelGGL(attn_values_multi_kernel, dim3(8, njobs, n), dim3(256), 0, (hipStream_t)stream, jobs_dev, ws, ws_stride_n,
+                       ws_stride_t, wdim, t);
+    MGF_CHECK_LAUNCH("attn_values_multi");
+    return MGF_OK;
+}
+
+extern "C" int mgf_attn_values(const mgf_attn_job* job, const float* ws, int64_t ws_stride_n, int64_t ws_stride_t, int32_t n,
+                               int32_t t, int32_t wdim, mgf_stream_t stream) {
+    MGF_REQUIRE(job && ws && n >= 1 && t >= 1 && wdim >= 1, MGF_EINVAL, "attn_values: bad arguments");
+    MGF_REQUIRE(job->wmv && job->bmv && job->vwb && job->c >= 1, MGF_EINVAL, "attn_values: bad job");
+    hipLaunchKernelGGL(attn_values_single_kernel, dim3(8, 1, n), dim3(256), 0, (hipStream_t)stream, *job, ws, ws_stride_n, ws_stride_t,
+                       wdim, t);
+    MGF_CHECK_LAUNCH("attn_values");
+    return MGF_OK;
+}
+
+extern "C" int64_t mgf_mapping_param_floats(int32_t k, int32_t dim, int32_t n_res_layers) {
+    const int64_t W = (int64_t)dim * dim, T = k - 1;
+    const int64_t glob = n_res_layers * (2 * W + 2 * dim) + W + dim;
+    const int64_t loc = n_res_layers * (6 * W + 2 * T * dim + 4 * dim) + W + dim;
+    return glob + loc;
+}
+
+extern "C" int mgf_mapping_forward(float* w, const float* z, const float* params, int32_t n, int32_t k, int32_t dim,
+                                   int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream) {
+    MGF_REQUIRE(w && z && params, MGF_EINVAL, "mapping_forward: null pointer");
+    MGF_REQUIRE(dim == MD, MGF_EUNSUPPORTED, "mapping_forward: latent width must be %d (got %d)", MD, dim);
+    MGF_REQUIRE(k >= 2 && k - 1 <= MT_MAX, MGF_EUNSUPPORTED, "mapping_forward: k must be in 2..%d (got %d)", MT_MAX + 1, k);
+    MGF_REQUIRE(n >= 1 && n_res_layers >= 0, MGF_EINVAL, "mapping_forward: bad sizes");
+    hipLaunchKernelGGL(mapping_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, w, z, params, k, n_res_layers, normalize_global);
+    MGF_CHECK_LAUNCH("mapping_forward");
+    return MGF_OK;
+}

@@ -1,0 +1,227 @@
+// Losses and bookkeeping of the projection loop, all device-side so an iteration never synchronises with the host.
+// Contract: include/mgf.h.  Reductions are deterministic: fixed grid, per-block partials in `scratch`, a single
+// finishing block sums them in index order (no float atomics -> bit-reproducible run to run).
+#include "mgf_common.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;
+
+__device__ __forceinline__ float block_sum_256(float v, float* sm) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void finish_kernel(float* out, const float* scratch, int nparts, float scale, int accumulate) {
+    __shared__ float sm[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) v += scratch[i];
+    v = block_sum_256(v, sm);
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + v * scale;
+}
+
+__global__ __launch_bounds__(256) void mse_partial_kernel(float* scratch, const float* a, const float* b, int64_t numel) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    const int64_t nvec = numel / 4;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float4 u = a4[i], v = b4[i];
+        float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
+        acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        float d0 = a[i] - b[i];
+        acc += d0 * d0;
+    }
+    acc = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) scratch[blockIdx.x] = acc;
+}
+
+// One lane per pixel: two sweeps over the channels (norms, then the weighted squared difference of the unit vectors).
+__global__ __launch_bounds__(256) void lpips_partial_kernel(float* scratch, const float* f0, const float* f1, const float* lin, int n,
+                                                            int c, int64_t hw) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    const int64_t total = (int64_t)n * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t nn = i / hw, px = i - nn * hw;
+        const float* a = f0 + nn * c * hw + px;
+        const float* b = f1 + nn * c * hw + px;
+        float na = 0.f, nb = 0.f;
+        for (int k = 0; k < c; ++k) { float u = a[(int64_t)k * hw], v = b[(int64_t)k * hw]; na += u * u; nb += v * v; }
+        const float ia = 1.f / (sqrtf(na) + 1e-10f), ib = 1.f / (sqrtf(nb) + 1e-10f);
+        float d = 0.f;
+        for (int k = 0; k < c; ++k) {
+            float u = a[(int64_t)k * hw] * ia - b[(int64_t)k * hw] * ib;
+            d += lin[k] * u * u;
+        }
+        acc += d;
+    }
+    acc = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) scratch[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void wing_kernel(double* out, const double* pred, const double* target, int64_t numel, double omega,
+                                                   double epsilon) {
+    __shared__ double sm[4];
+    const double cc = omega - omega * log(1.0 + omega / epsilon);
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < numel; i += 256) {
+        double dlt = fabs(target[i] - pred[i]);
+        acc += dlt < omega ? omega * log(1.0 + dlt / epsilon) : dlt - cc;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (sm[0] + sm[1] + sm[2] + sm[3]) / (double)numel;
+}
+
+__global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, int nc, int in_h, int in_w, int out_h, int out_w) {
+    const int64_t total = (int64_t)nc * out_h * out_w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % out_w);
+        const int64_t r = i / out_w;
+        const int oy = (int)(r % out_h);
+        const int64_t pl = r / out_h;
+        const float* xp = x + pl * in_h * in_w;
+        float m = -3.0e38f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 + dy;
+            if (iy >= in_h) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 + dx;
+                if (ix < in_w) m = fmaxf(m, xp[(int64_t)iy * in_w + ix]);
+            }
+        }
+        y[i] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void perturb_kernel(float* latent_n, const float* latent_in, const float* eps, const float* sigma,
+                                                      const int32_t* step, int64_t numel) {
+    const int s = *step;
+    const float sg = sigma[s];
+    const float* e = eps + (int64_t)s * numel;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256)
+        latent_n[i] = latent_in[i] + e[i] * sg;
+}
+
+__global__ __launch_bounds__(256) void select_kernel(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out,
+                                                     const float* latent_n, int64_t numel, const float* p_loss, const double* w_loss,
+                                                     const float* mse_loss, float lamda, float beta, int32_t* step, int valid) {
+    __shared__ int take;
+    const int s = *step;
+    if (threadIdx.x == 0) {
+        // same evaluation order as `p_loss + lamda * w_loss + beta * mse_loss` with a float64 wing term
+        double total = 0.0;
+        if (p_loss) total += (double)p_loss[0];
+        if (w_loss) total += (double)lamda * w_loss[0];
+        if (mse_loss) total += (double)(beta * mse_loss[0]);
+        if (losses_out) losses_out[s] = valid ? total : __longlong_as_double(0x7ff8000000000000LL);
+        take = valid && total < min_loss[0];
+        if (take) { min_loss[0] = total; best_step[0] = s; }
+    }
+    __syncthreads();
+    if (take)
+        for (int64_t i = threadIdx.x; i < numel; i += 256) best_latent[i] = latent_n[i];
+    __syncthreads();
+    if (threadIdx.x == 0) *step = s + 1;
+}
+
+__global__ __launch_bounds__(256) void to_uint8_kernel(uint8_t* out, const float* img, int c, int h, int w) {
+    const int64_t hw = (int64_t)h * w, total = hw * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % c);
+        const int64_t px = i / c;
+        float v = img[(int64_t)ch * hw + px] * 127.5f + 127.5f;
+        v = rintf(v);
+        v = fminf(fmaxf(v, 0.f), 255.f);
+        out[i] = (uint8_t)v;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t mgf_reduce_scratch_floats(void) { return RED_BLOCKS; }
+
+extern "C" int mgf_mse_f32(float* out, const float* a, const float* b, int64_t numel, float scale, int32_t accumulate, float* scratch,
+                           mgf_stream_t stream) {
+    MGF_REQUIRE(out && a && b && scratch && numel >= 1, MGF_EINVAL, "mse: bad arguments");
+    MGF_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0), MGF_EINVAL, "mse: inputs must be 16-byte aligned");
+    const int grid = (int)(mgf_cdiv(numel, 256 * 8) < RED_BLOCKS ? mgf_cdiv(numel, 256 * 8) : RED_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(grid), dim3(256), 0, st, scratch, a, b, numel);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, out, scratch, grid, scale / (float)numel, accumulate);
+    MGF_CHECK_LAUNCH("mse");
+    return MGF_OK;
+}
+
+extern "C" int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1, const float* lin, int32_t n, int32_t c, int64_t hw,
+                                   int32_t accumulate, float* scratch, mgf_stream_t stream) {
+    MGF_REQUIRE(out && f0 && f1 && lin && scratch && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer: bad arguments");
+    const int64_t total = (int64_t)n * hw;
+    const int grid = (int)(mgf_cdiv(total, 256) < RED_BLOCKS ? mgf_cdiv(total, 256) : RED_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lpips_partial_kernel, dim3(grid), dim3(256), 0, st, scratch, f0, f1, lin, n, c, hw);
+    // spatial mean per sample, summed over the batch (the loop uses .sum() over N: ...sqz_MSE.py:175)
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, out, scratch, grid, 1.0f / (float)hw, accumulate);
+    MGF_CHECK_LAUNCH("lpips_layer");
+    return MGF_OK;
+}
+
+extern "C" int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int64_t numel, double omega, double epsilon,
+                                 mgf_stream_t stream) {
+    MGF_REQUIRE(out && pred && target && numel >= 1, MGF_EINVAL, "wing_loss: bad arguments");
+    hipLaunchKernelGGL(wing_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, pred, target, numel, omega, epsilon);
+    MGF_CHECK_LAUNCH("wing_loss");
+    return MGF_OK;
+}
+
+extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                                         mgf_stream_t stream) {
+    MGF_REQUIRE(y && x && nc >= 1 && in_h >= 1 && in_w >= 1, MGF_EINVAL, "maxpool: bad arguments");
+    // ceil_mode output size; the last window must start inside the input (torch.nn.MaxPool2d rule)
+    auto osz = [](int in) { int o = (in - 3 + 1) / 2 + 1; if ((o - 1) * 2 >= in) --o; return o; };
+    MGF_REQUIRE(out_h == osz(in_h) && out_w == osz(in_w), MGF_EINVAL, "maxpool: output must be %dx%d (got %dx%d)", osz(in_h), osz(in_w),
+                out_h, out_w);
+    const int64_t total = (int64_t)nc * out_h * out_w;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(mgf_stream_grid(total, 256, 2)), dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w,
+                       out_h, out_w);
+    MGF_CHECK_LAUNCH("maxpool");
+    return MGF_OK;
+}
+
+extern "C" int mgf_latent_perturb(float* latent_n, const float* latent_in, const float* eps, const float* sigma, const int32_t* step,
+                                  int64_t numel, mgf_stream_t stream) {
+    MGF_REQUIRE(latent_n && latent_in && eps && sigma && step && numel >= 1, MGF_EINVAL, "latent_perturb: bad arguments");
+    hipLaunchKernelGGL(perturb_kernel, dim3((unsigned)mgf_cdiv(numel, 256)), dim3(256), 0, (hipStream_t)stream, latent_n, latent_in, eps,
+                       sigma, step, numel);
+    MGF_CHECK_LAUNCH("latent_perturb");
+    return MGF_OK;
+}
+
+extern "C" int mgf_select_best(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out, const float* latent_n,
+                               int64_t numel, const float* p_loss, const double* w_loss, const float* mse_loss, float lamda, float beta,
+                               int32_t* step, int32_t valid, mgf_stream_t stream) {
+    MGF_REQUIRE(min_loss && best_latent && best_step && latent_n && step && numel >= 1, MGF_EINVAL, "select_best: bad arguments");
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, min_loss, best_latent, best_step, losses_out, latent_n,
+                       numel, p_loss, w_loss, mse_loss, lamda, beta, step, valid);
+    MGF_CHECK_LAUNCH("select_best");
+    return MGF_OK;
+}
+
+extern "C" int mgf_to_uint8_hwc(uint8_t* out, const float* img, int32_t c, int32_t h, int32_t w, mgf_stream_t stream) {
+    MGF_REQUIRE(out && img && c >= 1 && h >= 1 && w >= 1, MGF_EINVAL, "to_uint8: bad arguments");
+    const int64_t total = (int64_t)c * h * w;
+    hipLaunchKernelGGL(to_uint8_kernel, dim3(mgf_stream_grid(total, 256, 4)), dim3(256), 0, (hipStream_t)stream, out, img, c, h, w);
+    MGF_CHECK_LAUNCH("to_uint8");
+    return MGF_OK;
+}

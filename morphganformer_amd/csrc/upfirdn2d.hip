@@ -1,0 +1,220 @@
+// upfirdn2d for gfx950: pad -> zero-insert upsample -> 2-D FIR -> decimate, with an optional fused
+// noise/bias/activation/residual epilogue.  Contract: include/mgf.h (mgf_upfirdn2d); reference semantics:
+// torch_utils/ops/upfirdn2d.py:161-200 and upfirdn2d.cu:21-333.
+//
+// Two kernels:
+//  * upfirdn_tiled_f32<UP>: the hot-path shapes (dense NCHW fp32, <=4x4 filter, up in {1,2}, down 1).  A workgroup
+//    stages the input footprint of a 64x16 output tile in LDS (coalesced row reads), every lane produces a 1x4
+//    output column strip from LDS with the polyphase taps unrolled, rows are written as 256-byte segments.
+//  * upfirdn_generic<T>: everything else (any strides incl. channels_last, f16/f64, any up/down/filter): one output
+//    per lane, polyphase tap skipping, filter in LDS.
+#include "mgf_common.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+struct UFParams {
+    void* y;
+    const void* x;
+    const float* f;
+    int n, c, in_h, in_w;
+    int64_t sn, sc, sh, sw;
+    int out_h, out_w;
+    int64_t yn, yc, yh, yw;
+    int fh, fw, upx, upy, downx, downy, padx0, pady0, flip;
+    float gain;
+    mgf_epilogue ep;
+    int has_ep;
+};
+
+__device__ __forceinline__ float apply_epilogue(const mgf_epilogue& ep, float v, int n, int c, int oy, int ox, int out_h,
+                                                int out_w, int64_t yoff) {
+    if (ep.noise) {
+        float ns = ep.noise_strength ? *ep.noise_strength : 1.0f;
+        int nn = ep.noise_n > 1 ? n : 0;
+        v += ep.noise[((int64_t)nn * out_h + oy) * out_w + ox] * ns;
+    }
+    if (ep.bias) v += ep.bias[c];
+    if (ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * ep.alpha;
+    else if (ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+    v *= ep.gain;
+    if (ep.residual) v += ep.residual[yoff];
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ double ld(const T* p) { return (double)*p; }
+template <> __device__ __forceinline__ double ld<__half>(const __half* p) { return (double)__half2float(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, double v) { *p = (T)v; }
+template <> __device__ __forceinline__ void st<__half>(__half* p, double v) { *p = __float2half((float)v); }
+
+// ACC = float for f16/f32, double for f64.
+template <typename T, typename ACC>
+__global__ __launch_bounds__(256) void upfirdn_generic(UFParams p) {
+    extern __shared__ float sfilt[];
+    const int ntaps = p.fh * p.fw;
+    for (int i = threadIdx.x; i < ntaps; i += blockDim.x) {
+        int fy = i / p.fw, fx = i - fy * p.fw;
+        // store the filter so that window offset j multiplies sfilt[j]: true convolution flips the taps
+        int ky = p.flip ? fy : p.fh - 1 - fy, kx = p.flip ? fx : p.fw - 1 - fx;
+        sfilt[i] = p.f[ky * p.fw + kx] * p.gain;
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)p.n * p.c * p.out_h * p.out_w;
+    const T* X = (const T*)p.x;
+    T* Y = (T*)p.y;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int ox = (int)(idx % p.out_w);
+        int64_t r = idx / p.out_w;
+        int oy = (int)(r % p.out_h); r /= p.out_h;
+        int c = (int)(r % p.c);
+        int n = (int)(r / p.c);
+        // window start in upsampled coordinates
+        int uy0 = oy * p.downy - p.pady0, ux0 = ox * p.downx - p.padx0;
+        // first window offset that lands on a real sample (u % up == 0)
+        int jy0 = ((-uy0) % p.upy + p.upy) % p.upy;
+        int jx0 = ((-ux0) % p.upx + p.upx) % p.upx;
+        const T* xb = X + (int64_t)n * p.sn + (int64_t)c * p.sc;
+        ACC acc = 0;
+        for (int jy = jy0; jy < p.fh; jy += p.upy) {
+            int iy = (uy0 + jy) / p.upy;
+            if (iy < 0 || iy >= p.in_h) continue;
+            for (int jx = jx0; jx < p.fw; jx += p.upx) {
+                int ix = (ux0 + jx) / p.upx;
+                if (ix < 0 || ix >= p.in_w) continue;
+                acc += (ACC)ld<T>(xb + (int64_t)iy * p.sh + (int64_t)ix * p.sw) * (ACC)sfilt[jy * p.fw + jx];
+            }
+        }
+        int64_t yoff = (int64_t)n * p.yn + (int64_t)c * p.yc + (int64_t)oy * p.yh + (int64_t)ox * p.yw;
+        if (p.has_ep) acc = (ACC)apply_epilogue(p.ep, (float)acc, n, c, oy, ox, p.out_h, p.out_w, yoff);
+        st<T>(Y + yoff, (double)acc);
+    }
+}
+
+// Hot-path kernel.  Output tile 64 (x) x 16 (y) per workgroup of 256 lanes; lane (lx = tid & 63, ly = tid >> 6)
+// produces outputs (oy0 + 4*ly + {0..3}, ox0 + lx).
+template <int UP>
+__global__ __launch_bounds__(256) void upfirdn_tiled_f32(UFParams p) {
+    constexpr int TW = 64, TH = 16, FMAX = 4;
+    // input footprint of the tile
+    constexpr int IW = (UP == 1) ? TW + FMAX - 1 : TW / 2 + FMAX / 2 + 1;
+    constexpr int IH = (UP == 1) ? TH + FMAX - 1 : TH / 2 + FMAX / 2 + 1;
+    constexpr int IWP = IW + 1;
+    __shared__ float sx[IH][IWP];
+    __shared__ float sf[FMAX][FMAX];
+    const int tid = threadIdx.x;
+    if (tid < FMAX * FMAX) {
+        int jy = tid / FMAX, jx = tid % FMAX;
+        float v = 0.f;
+        if (jy < p.fh && jx < p.fw) {
+            int ky = p.flip ? jy : p.fh - 1 - jy, kx = p.flip ? jx : p.fw - 1 - jx;
+            v = p.f[ky * p.fw + kx] * p.gain;
+        }
+        sf[jy][jx] = v;
+    }
+    const int tiles_x = (p.out_w + TW - 1) / TW;
+    const int tiles_y = (p.out_h + TH - 1) / TH;
+    const int tile = blockIdx.x % (tiles_x * tiles_y);
+    const int plane = blockIdx.x / (tiles_x * tiles_y);          // n * c + c
+    const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
+    const int n = plane / p.c, c = plane - n * p.c;
+    const float* xb = (const float*)p.x + (int64_t)n * p.sn + (int64_t)c * p.sc;
+    // first input sample touched by the tile (floor division, may be negative)
+    const int uy0 = oy0 - p.pady0, ux0 = ox0 - p.padx0;
+    // UP==2: ceil(u0/2) for either sign (C++ division truncates, i.e. rounds negatives up)
+    const int iy0 = (UP == 1) ? uy0 : (uy0 >= 0 ? uy0 + UP - 1 : uy0) / UP;
+    const int ix0 = (UP == 1) ? ux0 : (ux0 >= 0 ? ux0 + UP - 1 : ux0) / UP;
+    for (int i = tid; i < IH * IW; i += 256) {
+        int r = i / IW, q = i - r * IW;
+        int iy = iy0 + r, ix = ix0 + q;
+        float v = 0.f;
+        if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = xb[(int64_t)iy * p.sh + ix];
+        sx[r][q] = v;
+    }
+    __syncthreads();
+    const int lx = tid & 63, ly = tid >> 6;
+    const int ox = ox0 + lx;
+    float* Y = (float*)p.y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int oy = oy0 + ly * 4 + k;
+        float acc = 0.f;
+        const int uy = oy - p.pady0, ux = ox - p.padx0;
+        if (UP == 1) {
+            const int ry = uy - iy0, rx = ux - ix0;
+#pragma unroll
+            for (int jy = 0; jy < FMAX; ++jy)
+#pragma unroll
+                for (int jx = 0; jx < FMAX; ++jx) acc += sx[ry + jy][rx + jx] * sf[jy][jx];
+        } else {
+            // taps jy with (uy + jy) even; input row (uy + jy) / 2
+            const int py = uy & 1, px = ux & 1;   // parity (two's complement & works for negatives)
+#pragma unroll
+            for (int a = 0; a < FMAX / 2; ++a) {
+                const int jy = py + 2 * a;
+                const int ry = ((uy + jy) >> 1) - iy0;
+#pragma unroll
+                for (int b = 0; b < FMAX / 2; ++b) {
+                    const int jx = px + 2 * b;
+                    const int rx = ((ux + jx) >> 1) - ix0;
+                    acc += sx[ry][rx] * sf[jy][jx];
+                }
+            }
+        }
+        if (oy < p.out_h && ox < p.out_w) {
+            int64_t yoff = (int64_t)n * p.yn + (int64_t)c * p.yc + (int64_t)oy * p.yh + ox;
+            if (p.has_ep) acc = apply_epilogue(p.ep, acc, n, c, oy, ox, p.out_h, p.out_w, yoff);
+            Y[yoff] = acc;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mgf_upfirdn2d(void* y, const void* x, const float* f, int dtype, int32_t n, int32_t c, int32_t in_h,
+                             int32_t in_w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int32_t out_h, int32_t out_w,
+                             int64_t yn, int64_t yc, int64_t yh, int64_t yw, int32_t fh, int32_t fw, int32_t upx,
+                             int32_t upy, int32_t downx, int32_t downy, int32_t padx0, int32_t padx1, int32_t pady0,
+                             int32_t pady1, int32_t flip, float gain, const mgf_epilogue* ep, mgf_stream_t stream) {
+    MGF_REQUIRE(dtype == MGF_F32 || dtype == MGF_F64 || dtype == MGF_F16, MGF_EUNSUPPORTED, "upfirdn2d: unsupported dtype %d", dtype);
+    MGF_REQUIRE(n >= 0 && c >= 0 && in_h >= 1 && in_w >= 1, MGF_EINVAL, "upfirdn2d: bad input shape");
+    MGF_REQUIRE(fh >= 1 && fw >= 1 && fh * fw <= 8192, MGF_EINVAL, "upfirdn2d: filter must have 1..8192 taps (got %dx%d)", fh, fw);
+    MGF_REQUIRE(upx >= 1 && upy >= 1 && downx >= 1 && downy >= 1, MGF_EINVAL, "upfirdn2d: up/down factors must be >= 1");
+    const int64_t eh = ((int64_t)in_h * upy + pady0 + pady1 - fh + downy) / downy;
+    const int64_t ew = ((int64_t)in_w * upx + padx0 + padx1 - fw + downx) / downx;
+    MGF_REQUIRE(eh >= 1 && ew >= 1, MGF_EINVAL, "upfirdn2d: output would be empty (%lld x %lld)", (long long)eh, (long long)ew);
+    MGF_REQUIRE(eh == out_h && ew == out_w, MGF_EINVAL, "upfirdn2d: output shape mismatch: expected %lldx%lld, got %dx%d",
+                (long long)eh, (long long)ew, out_h, out_w);
+    MGF_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX && (int64_t)n * c * out_h * out_w <= INT32_MAX, MGF_ETOOBIG,
+                "upfirdn2d: tensor too large");
+    if (n == 0 || c == 0) return MGF_OK;
+    MGF_REQUIRE(x && y && f, MGF_EINVAL, "upfirdn2d: null pointer");
+    if (ep) {
+        MGF_REQUIRE(dtype == MGF_F32, MGF_EUNSUPPORTED, "upfirdn2d: fused epilogue needs float32");
+        MGF_REQUIRE(ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU || ep->act == 0,
+                    MGF_EUNSUPPORTED, "upfirdn2d: epilogue activation %d unsupported", ep->act);
+    }
+    UFParams p;
+    p.y = y; p.x = x; p.f = f; p.n = n; p.c = c; p.in_h = in_h; p.in_w = in_w;
+    p.sn = sn; p.sc = sc; p.sh = sh; p.sw = sw; p.out_h = out_h; p.out_w = out_w;
+    p.yn = yn; p.yc = yc; p.yh = yh; p.yw = yw; p.fh = fh; p.fw = fw;
+    p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
+    p.flip = flip; p.gain = gain; p.has_ep = ep != nullptr;
+    if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
+    hipStream_t stq = (hipStream_t)stream;
+    const bool tiled = dtype == MGF_F32 && sw == 1 && yw == 1 && fh <= 4 && fw <= 4 && upx == upy && (upx == 1 || upx == 2) &&
+                       downx == 1 && downy == 1 && out_w >= 32 && (int64_t)n * c * mgf_cdiv(out_h, 16) * mgf_cdiv(out_w, 64) <= INT32_MAX;
+    if (tiled) {
+        const int blocks = n * c * (int)mgf_cdiv(out_h, 16) * (int)mgf_cdiv(out_w, 64);
+        if (upx == 1) hipLaunchKernelGGL((upfirdn_tiled_f32<1>), dim3(blocks), dim3(256), 0, stq, p);
+        else hipLaunchKernelGGL((upfirdn_tiled_f32<2>), dim3(blocks), dim3(256), 0, stq, p);
+    } else {
+        const int64_t total = (int64_t)n * c * out_h * out_w;
+        const int grid = mgf_stream_grid(total, 256, 4);
+        const size_t lds = (size_t)fh * fw * sizeof(float);
+        if (dtype == MGF_F32) hipLaunchKernelGGL((upfirdn_generic<float, float>), dim3(grid), dim3(256), lds, stq, p);
+        else if (dtype == MGF_F64) hipLaunchKernelGGL((upfirdn_generic<double, double>), dim3(grid), dim3(256), lds, stq, p);
+        else hipLaunchKernelGGL((upfirdn_generic<__half, float>), dim3(grid), dim3(256), lds, stq, p);
+    }
+    MGF_CHECK_LAUNCH("upfirdn2d");
+    return MGF_OK;
+}

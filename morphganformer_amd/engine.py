@@ -1,0 +1,427 @@
+"""GANformer generator forward on MI355X: checkpoint -> device plan -> kernel schedule.
+
+Replaces Generator.forward / MappingNetwork / SynthesisNetwork (training/networks.py:894-942, 1244-1264, 1304-1331) for the
+configuration the projection drivers use (resnet architecture, duplex attention with parametric centroids, integration
+"mul", layer norm).  All arithmetic is float32 on the device; everything that depends only on the
+checkpoint is folded once, in float64, at plan-build time:
+
+  * conv weights -> tap-major images (+ the sum-of-squares table that turns demodulation into a small GEMV),
+  * attention: query projection x positional term x att_weight x centroids x 1/sqrt(C) -> wqc [C,T] and spos [F,T];
+    value projection x modulation FC (+ bias + 1) -> wmv [C,D], bmv [C]          (no F x C x C GEMM is left),
+  * mapping network: learning-rate multipliers, He gains, positional terms and the score scale folded into one blob.
+
+Per call the schedule is: mapping (1 launch) -> styles/demod for all 20 modulated layers (1 launch) -> attention value
+tables for all attention layers (1 launch) -> per block {skip 1x1, skip FIR-up, transposed conv, FIR (+epilogue),
+[attention], conv, [attention]} -> conv_last -> toRGB.  No host synchronisation, no allocation: graph-capturable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import conv as cv
+from .synth_weights import GeneratorConfig
+
+SQRT2 = math.sqrt(2.0)
+SQRT_HALF = math.sqrt(0.5)
+
+
+def pack_mapping_params(sd, cfg: GeneratorConfig) -> np.ndarray:
+    """Flatten the mapping network into the blob read by mgf_mapping_forward (csrc/latent_prep.hip: mapping_kernel).
+
+    Layout (float32, matrices [out][in] row-major, all gains folded):
+      global mlp : n_res x {W0, b0, W1, b1}, Wout, bout
+      local  mlp : n_res x {Wq*, bq_pos[T,D]*, Wk, bk_pos[T,D], Wv, bv, Wm, bm, W0, b0, W1, b1}, Wout, bout
+    (*) pre-multiplied by the 1/sqrt(D) score scale; b?_pos = bias + positional projection of G.pos.
+    """
+    D, T = cfg.w_dim, cfg.k - 1
+    lr = cfg.mapping_lrmul
+    n_res = cfg.mapping_layers // 2
+    g64 = lambda k: np.asarray(sd[k], dtype=np.float64)
+    out = []
+
+    def fc(prefix, lrmul):
+        w = g64(prefix + ".weight")
+        return w * (lrmul / math.sqrt(w.shape[1])), g64(prefix + ".bias") * lrmul
+
+    for i in range(n_res):
+        for j in (0, 1):
+            w, b = fc(f"mapping.global_mlp.l{i}.fc{j}", lr)
+            out += [w, b]
+    out += list(fc("mapping.global_mlp.out_layer", lr))
+    pos = g64("pos")
+    for i in range(n_res):
+        p = f"mapping.mlp.sa{i}"
+        wq, bq = fc(p + ".to_queries", 1.0)
+        wfp, bfp = fc(p + ".from_pos_map", 1.0)
+        wk, bk = fc(p + ".to_keys", 1.0)
+        wtp, btp = fc(p + ".to_pos_map", 1.0)
+        wv, bv = fc(p + ".to_values", 1.0)
+        wm, bm = fc(p + ".modulation", 1.0)
+        sc = 1.0 / math.sqrt(D)
+        out += [wq * sc, (bq[None] + pos @ wfp.T + bfp[None]) * sc, wk, bk[None] + pos @ wtp.T + btp[None], wv, bv, wm, bm]
+        for j in (0, 1):
+            w, b = fc(f"mapping.mlp.l{i}.fc{j}", lr)
+            out += [w, b]
+    out += list(fc("mapping.mlp.out_layer", lr))
+    blob = np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1) for a in out]).astype(np.float32)
+    expect = _lib.lib().mgf_mapping_param_floats(cfg.k, D, n_res)
+    assert blob.size == expect, (blob.size, expect)
+    return blob
+
+
+@dataclass
+class ConvLayerPlan:
+    name: str
+    res: int
+    cin: int
+    cout: int
+    up: int
+    slot: int
+    kind: str                       # "conv3" | "tconv" | "torgb"
+    pc: cv.PackedConv = None
+    aff_w: torch.Tensor = None
+    aff_b: torch.Tensor = None
+    style_gain: float = 1.0
+    demod: bool = True
+    bias: torch.Tensor = None
+    noise_const: torch.Tensor = None
+    noise_strength: torch.Tensor = None
+    act_gain: float = 1.0
+    attn: "AttnPlan" = None
+    s_off: int = 0                  # offsets (floats) into the per-sample style / demod arenas
+    d_off: int = 0
+
+
+@dataclass
+class AttnPlan:
+    c: int
+    f: int
+    wqc: torch.Tensor               # [C, T]
+    spos: torch.Tensor              # [F, T]
+    wmv: torch.Tensor               # [C, D]
+    bmv: torch.Tensor               # [C]
+    v_off: int = 0                  # offset into the per-sample value-table arena
+
+
+class SynthesisPlan:
+    """Device-resident, checkpoint-derived constants of one generator."""
+
+    def __init__(self, sd, cfg: GeneratorConfig, device="cuda"):
+        _lib.lib()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        dev = self.device
+        f64 = lambda k: np.asarray(sd[k], dtype=np.float64)
+        t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+        D, T = cfg.w_dim, cfg.k - 1
+        self.mapping_blob = t32(pack_mapping_params(sd, cfg))
+        self.const = t32(f64("synthesis.b4.const"))
+        self.fir = t32(f64(f"synthesis.b{cfg.block_resolutions[-1]}.resample_kernel"))
+        self.layers: list[ConvLayerPlan] = []
+        self.skips = {}
+        s_off = d_off = v_off = 0
+        for (res, name, cin, cout, up, slot, att, has_nb) in cfg.layer_table():
+            p = f"synthesis.b{res}.{name}"
+            w = f64(p + ".weight")
+            kind = "torgb" if name == "torgb" else ("tconv" if up == 2 else "conv3")
+            lp = ConvLayerPlan(name=p, res=res, cin=cin, cout=cout, up=up, slot=slot, kind=kind)
+            if kind == "torgb":
+                # styles * w_gain instead of weight * w_gain, no demodulation (networks.py:1056-1063)
+                lp.pc = cv.pack_weights(t32(w), gain=1.0, flip=False)
+                lp.style_gain = 1.0 / math.sqrt(cin)
+                lp.demod = False
+            else:
+                wg = 1.0 / math.sqrt(cin * 9)
+                # up=1: correlation (flip_weight=True); up=2: conv_transpose2d on the un-flipped weights
+                lp.pc = cv.pack_weights(t32(w), gain=wg, flip=False, want_wsq=True)
+            lp.aff_w = t32(f64(p + ".affine.weight"))
+            lp.aff_b = t32(f64(p + ".affine.bias"))
+            if (p + ".biasAct.bias") in sd:
+                lp.bias = t32(f64(p + ".biasAct.bias"))
+            if (p + ".noise_strength") in sd:
+                lp.noise_strength = t32(f64(p + ".noise_strength").reshape(1))
+                lp.noise_const = t32(f64(p + ".noise_const"))
+            lp.act_gain = SQRT2 * (SQRT_HALF if (name == "conv1" and res > 4) else 1.0)
+            if att and (p + ".transformer.to_queries.weight") in sd:
+                lp.attn = self._fold_attention(sd, p, cout, res, T, D, t32, f64)
+                lp.attn.v_off = v_off
+                v_off += cout * T
+            lp.s_off, lp.d_off = s_off, d_off
+            s_off += cin
+            d_off += cout
+            self.layers.append(lp)
+        self.s_total, self.d_total, self.v_total = s_off, d_off, v_off
+        for res in cfg.block_resolutions[1:]:
+            w = f64(f"synthesis.b{res}.skip.weight")
+            # 1x1, no modulation; w_gain and the resnet gain sqrt(1/2) (networks.py:1121-1122) folded into the weights
+            self.skips[res] = cv.pack_weights(t32(w), gain=SQRT_HALF / math.sqrt(w.shape[1]), flip=False)
+        torch.cuda.synchronize(dev)
+
+    @staticmethod
+    def _fold_attention(sd, p, C_, res, T, D, t32, f64):
+        tp = p + ".transformer"
+        Fn = res * res
+        wq = f64(tp + ".to_queries.weight") / math.sqrt(C_)
+        bq = f64(tp + ".to_queries.bias")
+        wfp = f64(tp + ".from_pos_map.weight") / math.sqrt(D)
+        bfp = f64(tp + ".from_pos_map.bias")
+        wv = f64(tp + ".to_values.weight") / math.sqrt(D)
+        bv = f64(tp + ".to_values.bias")
+        wm = f64(tp + ".modulation.weight") / math.sqrt(C_)
+        bm = f64(tp + ".modulation.bias")
+        aw = f64(tp + ".att_weight").reshape(2 * C_)
+        cent = f64(tp + ".centroids").reshape(T, 2 * C_)
+        a1 = cent[:, :C_] * aw[None, :C_]                 # [T, C]
+        a2 = cent[:, C_:] * aw[None, C_:]
+        inv = 1.0 / math.sqrt(C_)
+        wqc = (wq.T @ a1.T) * inv                          # [C, T]
+        pos_term = f64(p + ".grid_pos").reshape(Fn, D) @ wfp.T + bfp[None]     # [F, C]
+        spos = (pos_term @ a2.T + (bq @ a1.T)[None]) * inv                      # [F, T]
+        wmv = wm @ wv                                      # [C, D]
+        bmv = wm @ bv + bm + 1.0
+        return AttnPlan(c=C_, f=Fn, wqc=t32(wqc), spos=t32(spos), wmv=t32(wmv), bmv=t32(bmv))
+
+
+class Generator:
+    """Callable mirror of the reference Generator (training/networks.py:1269-1331) backed by the HIP kernels.
+
+    __call__(z=None, c=None, ws=None, truncation_psi=1, ..., noise_mode="random") -> tuple, like the reference.
+    """
+
+    def __init__(self, sd, cfg: GeneratorConfig, device="cuda", max_batch: int = 1):
+        self.cfg = cfg
+        self.plan = SynthesisPlan(sd, cfg, device)
+        self.device = self.plan.device
+        self.input_shape = [None, cfg.k, cfg.z_dim]
+        self.cond_shape = [None, 0]
+        self.z_dim, self.w_dim, self.k, self.c_dim = cfg.z_dim, cfg.w_dim, cfg.k, 0
+        self.img_resolution, self.img_channels = cfg.img_resolution, cfg.img_channels
+        self.num_ws = cfg.num_ws
+        self.w_avg = torch.as_tensor(np.asarray(sd["mapping.w_avg"], dtype=np.float32), device=self.device)
+        self._ws_cache = {}
+        self.taps = None
+        self._alloc(max_batch)
+
+    # ------------------------------------------------------------------ workspace
+    def _alloc(self, n):
+        cfg, dev, P = self.cfg, self.device, self.plan
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        self.n = n
+        self.w_buf = e(n, cfg.k, cfg.w_dim)
+        self.styles = e(n, P.s_total)
+        self.demods = e(n, P.d_total)
+        self.vtabs = e(n, max(P.v_total, 1))
+        self.noise_rand = None
+        self.bufs = {}
+        for res in cfg.block_resolutions:
+            c = cfg.channels(res)
+            b = {"conv1": e(n, c, res, res), "out": e(n, c, res, res)}
+            if res > 4:
+                b["skip_low"] = e(n, c, res // 2, res // 2)
+                b["skip"] = e(n, c, res, res)
+                b["t"] = e(n, c, res + 1, cv.tconv_pitch(res // 2))
+                b["conv0"] = e(n, c, res, res)
+                if cfg.has_attention(res):
+                    b["conv0a"] = e(n, c, res, res)
+            if cfg.has_attention(res):
+                b["conv1a"] = e(n, c, res, res)
+            if res == cfg.img_resolution:
+                b["last"] = e(n, c, res, res)
+            self.bufs[res] = b
+        self.img = e(n, cfg.img_channels, cfg.img_resolution, cfg.img_resolution)
+        self._build_jobs(n)
+
+    def _build_jobs(self, n):
+        """Device job tables for the batched style/demod and attention-value launches (ws layout: [n, k, D]).
+        The style / demod / value arenas are layer-major: [layer][n][channels], so each job sees a dense [n, c] block."""
+        cfg, P = self.cfg, self.plan
+        D = cfg.w_dim
+        sj = (_lib.StyleJob * len(P.layers))()
+        aj = []
+        for i, lp in enumerate(P.layers):
+            sj[i] = _lib.StyleJob(lp.aff_w.data_ptr(), lp.aff_b.data_ptr(), _lib.ptr(lp.pc.wsq) if lp.demod else 0,
+                                  self.styles.data_ptr() + 4 * lp.s_off * n,
+                                  (self.demods.data_ptr() + 4 * lp.d_off * n) if lp.demod else 0,
+                                  lp.cin, lp.cout, (cfg.k - 1) * D, 1.0 / math.sqrt(D), lp.style_gain)
+            if lp.attn is not None:
+                aj.append(_lib.AttnJob(lp.attn.wmv.data_ptr(), lp.attn.bmv.data_ptr(),
+                                       self.vtabs.data_ptr() + 4 * lp.attn.v_off * n, lp.attn.c, 0))
+        self.style_jobs = torch.frombuffer(bytearray(bytes(sj)), dtype=torch.uint8).to(self.device)
+        self.n_style_jobs = len(P.layers)
+        self.attn_jobs = None
+        if aj:
+            arr = (_lib.AttnJob * len(aj))(*aj)
+            self.attn_jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self.n_attn_jobs = len(aj)
+
+    def _s(self, lp):
+        return self.styles.view(-1)[lp.s_off * self.n:(lp.s_off + lp.cin) * self.n].view(self.n, lp.cin)
+
+    def _d(self, lp):
+        return self.demods.view(-1)[lp.d_off * self.n:(lp.d_off + lp.cout) * self.n].view(self.n, lp.cout)
+
+    def _v(self, lp):
+        T = self.cfg.k - 1
+        a = lp.attn
+        return self.vtabs.view(-1)[a.v_off * self.n:(a.v_off + a.c * T) * self.n]
+
+    # ------------------------------------------------------------------ API
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def mapping(self, z, truncation_psi=1, truncation_cutoff=None):
+        """z [n,k,D] -> ws [n,k,num_ws,D] (broadcast view), reference MappingNetwork.forward semantics."""
+        w = self._mapping_into(z)
+        ws = w.unsqueeze(2).expand(-1, -1, self.num_ws, -1)
+        if truncation_psi != 1:
+            ws = self.w_avg.lerp(ws, truncation_psi) if truncation_cutoff is None else torch.cat(
+                [self.w_avg.lerp(ws[:, :, :truncation_cutoff], truncation_psi), ws[:, :, truncation_cutoff:]], dim=2)
+        return ws
+
+    def _mapping_into(self, z):
+        _lib.require_gpu(z)
+        n = z.shape[0]
+        assert tuple(z.shape[1:]) == (self.cfg.k, self.cfg.z_dim), z.shape
+        if n != self.n:
+            self._alloc(n)
+        z = z.contiguous().float()
+        rc = _lib.lib().mgf_mapping_forward(self.w_buf.data_ptr(), z.data_ptr(), self.plan.mapping_blob.data_ptr(), n,
+                                            self.cfg.k, self.cfg.w_dim, self.cfg.mapping_layers // 2,
+                                            int(self.cfg.normalize_global), _lib.stream_ptr())
+        _lib.check(rc, "mapping_forward")
+        return self.w_buf
+
+    def synthesis(self, w, noise_mode="random", noises=None, return_att=False):
+        """w: [n, k, D] (one latent set shared by all layers, as every driver uses it).  Returns img [n,3,R,R]."""
+        cfg, P, L = self.cfg, self.plan, _lib.lib()
+        n = w.shape[0]
+        if n != self.n:
+            raise _lib.MgfError("synthesis: batch size changed; call through __call__ / mapping first")
+        st = _lib.stream_ptr()
+        D, T = cfg.w_dim, cfg.k - 1
+        assert w.is_contiguous() and tuple(w.shape) == (n, cfg.k, D)
+        _lib.check(L.mgf_style_demod_multi(self.style_jobs.data_ptr(), self.n_style_jobs, w.data_ptr(), cfg.k * D, n, D, st),
+                   "style_demod_multi")
+        if self.n_attn_jobs:
+            _lib.check(L.mgf_attn_values_multi(self.attn_jobs.data_ptr(), self.n_attn_jobs, w.data_ptr(), cfg.k * D, D, n, T, D, st),
+                       "attn_values_multi")
+        if noise_mode == "random":
+            noises = self._draw_noise(n)
+        layers = {lp.name: lp for lp in P.layers}
+        self.att_maps = {} if return_att else None
+        x = None
+        for res in cfg.block_resolutions:
+            b = f"synthesis.b{res}"
+            B = self.bufs[res]
+            if res == 4:
+                x_in = self.const.unsqueeze(0).expand(n, -1, -1, -1).contiguous() if n > 1 else self.const.unsqueeze(0)
+                x = self._layer(layers[b + ".conv1"], x_in, B, "conv1", noise_mode, noises, residual=None)
+            else:
+                cv.conv_forward(x, P.skips[res], out=B["skip_low"])
+                cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0)
+                x0 = self._layer(layers[b + ".conv0"], x, B, "conv0", noise_mode, noises, residual=None)
+                x = self._layer(layers[b + ".conv1"], x0, B, "conv1", noise_mode, noises, residual=B["skip"])
+            if self.taps is not None:
+                self.taps[b] = x
+            if res == cfg.img_resolution:
+                lp = layers[b + ".conv_last"]
+                x = cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=self._s(lp), out_scale=self._d(lp), out=B["last"])
+                if self.taps is not None:
+                    self.taps[b] = x
+                lp = layers[b + ".torgb"]
+                ep = _lib.make_epilogue(bias=lp.bias)
+                cv.conv_forward(x, lp.pc, in_scale=self._s(lp), epilogue=ep, out=self.img)
+        return self.img
+
+    def _noise_for(self, lp, noise_mode, noises):
+        if lp.noise_strength is None or noise_mode == "none":
+            return None, 1
+        if noise_mode == "const":
+            return lp.noise_const, 1
+        t = noises[lp.name]
+        return t, t.shape[0]
+
+    def _draw_noise(self, n):
+        """Fresh N(0,1) maps per layer and call (networks.py:1016-1017): one torch.randn launch for all 17 layers."""
+        sizes = [(lp.name, lp.res) for lp in self.plan.layers if lp.noise_strength is not None]
+        total = sum(r * r for _, r in sizes)
+        if self.noise_rand is None or self.noise_rand.shape != (n, total):
+            self.noise_rand = torch.empty([n, total], dtype=torch.float32, device=self.device)
+            self._noise_views = None
+        self.noise_rand.normal_()
+        out, off = {}, 0
+        for name, r in sizes:
+            out[name] = self.noise_rand[:, off:off + r * r]
+            off += r * r
+        # views are [n, r*r] with row stride `total`; kernels want dense [n, r, r] -> only n == 1 is dense
+        if n > 1:
+            out = {k_: v.contiguous() for k_, v in out.items()}
+        return out
+
+    def _layer(self, lp, x, B, key, noise_mode, noises, residual):
+        """One SynthesisLayer (networks.py:1010-1042): modulated conv (+FIR) -> [attention] -> noise -> bias/lrelu."""
+        n = x.shape[0]
+        noise, noise_n = self._noise_for(lp, noise_mode, noises)
+        ep = _lib.make_epilogue(bias=lp.bias, noise=noise, noise_strength=lp.noise_strength if noise is not None else None,
+                                noise_n=noise_n, act="lrelu", alpha=0.2, gain=lp.act_gain, residual=residual)
+        has_att = lp.attn is not None
+        s, d = self._s(lp), self._d(lp)
+        if lp.kind == "tconv":
+            t = cv.tconv3x3s2_forward(x, lp.pc, in_scale=s, out_scale=d, out=B["t"])
+            y = cv.upfirdn_into(B[key], t, self.plan.fir, up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=None if has_att else ep)
+        else:
+            y = cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=s, out_scale=d, epilogue=None if has_att else ep, out=B[key])
+        if self.taps is not None:
+            self.taps[lp.name + ":conv"] = y
+        if has_att:
+            a = lp.attn
+            out = B[key + "a"]
+            probs = argmax = None
+            if self.att_maps is not None:
+                probs = torch.empty([n, a.f, self.cfg.k - 1], dtype=torch.float32, device=self.device)
+                argmax = torch.empty([n, a.f], dtype=torch.int32, device=self.device)
+                self.att_maps[lp.name] = (probs, argmax)
+            rc = _lib.lib().mgf_duplex_attention(out.data_ptr(), y.data_ptr(), a.wqc.data_ptr(), a.spos.data_ptr(),
+                                                 self._v(lp).data_ptr(), n, a.c, a.f, self.cfg.k - 1, C.byref(ep), lp.res,
+                                                 _lib.ptr(probs), _lib.ptr(argmax), _lib.stream_ptr())
+            _lib.check(rc, "duplex_attention")
+            y = out
+        return y
+
+    def __call__(self, z=None, c=None, ws=None, truncation_psi=1, truncation_cutoff=None, return_img=True, return_att=False,
+                 return_ws=False, subnet=None, noise_mode="random", noises=None, fused_modconv=None):
+        return_tensor = False
+        if subnet is not None:
+            return_ws, return_img, return_att, return_tensor = subnet == "mapping", subnet == "synthesis", False, True
+        if ws is None:
+            w = self._mapping_into(z)
+            if truncation_psi != 1:
+                w = self.w_avg.lerp(w, truncation_psi)
+        else:
+            # all drivers pass one latent set broadcast over num_ws (networks.py:932); take slot 0
+            assert ws.ndim == 4 and ws.shape[1] == self.cfg.k
+            if ws.shape[0] != self.n:
+                self._alloc(ws.shape[0])
+            w = ws[:, :, 0].contiguous().float()
+        ret = ()
+        if return_img or return_att:
+            img = self.synthesis(w.contiguous(), noise_mode=noise_mode, noises=noises, return_att=return_att)
+            if return_img:
+                ret += (img,)
+            if return_att:
+                ret += (self.att_maps,)
+        if return_ws:
+            ret += (w.unsqueeze(2).expand(-1, -1, self.num_ws, -1),)
+        return ret[0] if return_tensor else ret

@@ -1,0 +1,172 @@
+"""ORACLE (test infrastructure only) -- CPU restatement of the projection losses and loop.
+
+* wing_loss_ref / adaptive_wing_loss_ref <- wing_loss.py:19-28, adaptive_wing_loss.py:13-44
+* mse_ref                                <- torch.nn.MSELoss as used at 1024_example_wing_loss_perceptual_sqz_MSE.py:176
+* get_lr_ref / noise_strength_ref        <- ...sqz_MSE.py:63-68,156
+* latent_stats_ref                       <- ...sqz_MSE.py:251-255
+* to_uint8_ref                           <- misc.py:114-123 (to_pil rounding contract)
+* squeeze_features_ref / lpips_ref       <- lpips/networks_basic.py:64-101, lpips/__init__.py:44-46,
+                                            lpips/pretrained_networks.py:6-56 (slice boundaries);
+                                            backbone topology = torchvision squeezenet1_1.features
+                                            (third-party, un-vendored: torchvision>=0.9.1, requirements.txt:2)
+* projection_literal_ref                 <- ...sqz_MSE.py:131-208 (literal semantics: best-of-N noisy sampling,
+                                            SURVEY.md section 0.1) with injected epsilon / landmark streams.
+
+Pinned by tests/golden/loss_kats.npz (Wing/AWing/schedule KATs from the reference's own classes) and
+tests/golden/loop_tiny.npz (reference Generator + reference WingLoss driven through the loop).
+LPIPS backbone parity with ImageNet weights: UNPINNED (torchvision and its weights are absent offline);
+pinned only on the vendored 'lin' heads + seeded random backbone weights against torch's own conv ops.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def wing_loss_ref(pred, target, omega=10.0, epsilon=2.0):
+    d = (target - pred).abs()
+    c = omega - omega * math.log(1 + omega / epsilon)
+    small = omega * torch.log(1 + d / epsilon)
+    loss = torch.where(d < omega, small, d - c)
+    return loss.sum() / d.numel()
+
+
+def adaptive_wing_loss_ref(pred, target, omega=14.0, theta=0.5, epsilon=1.0, alpha=2.1):
+    y = target
+    d = (y - pred).abs()
+    p = alpha - y
+    l1 = omega * torch.log(1 + torch.pow(d / omega, p))
+    tp = torch.pow(torch.as_tensor(theta / epsilon, dtype=y.dtype), p)
+    a = omega * (1 / (1 + tp)) * p * torch.pow(torch.as_tensor(theta / epsilon, dtype=y.dtype), p - 1) * (1 / epsilon)
+    c = theta * a - omega * torch.log(1 + tp)
+    loss = torch.where(d < theta, l1, a * d - c)
+    return loss.sum() / d.numel()
+
+
+def mse_ref(a, b):
+    return (a - b).square().mean()
+
+
+def get_lr_ref(t, initial_lr, rampdown=0.25, rampup=0.05):
+    ramp = min(1.0, (1.0 - t) / rampdown)
+    ramp = 0.5 - 0.5 * math.cos(ramp * math.pi)
+    ramp = ramp * min(1.0, t / rampup)
+    return initial_lr * ramp
+
+
+def noise_strength_ref(t, latent_std, noise=0.05, noise_ramp=0.75):
+    return latent_std * noise * max(0.0, 1.0 - t / noise_ramp) ** 2
+
+
+def latent_stats_ref(samples):
+    """samples [N,k,D] -> (latent_mean [k,D], latent_std scalar) exactly as the drivers compute them."""
+    mean = samples.mean(0)
+    std = ((samples - mean).pow(2).sum() / samples.shape[0]) ** 0.5
+    return mean, std
+
+
+def to_uint8_ref(img_chw):
+    """misc.to_pil arithmetic: rint(x*127.5 + 127.5) clipped to [0,255], CHW -> HWC."""
+    a = np.asarray(img_chw, dtype=np.float32)
+    scale = (np.float32(255) - np.float32(0)) / (np.float32(1) - np.float32(-1))
+    bias = np.float32(0) - np.float32(-1) * scale
+    a = a * scale + bias
+    a = np.rint(a).clip(0, 255).astype(np.uint8)
+    return a.transpose(1, 2, 0) if a.ndim == 3 else a
+
+
+# --------------------------------------------------------------------------------------------
+# LPIPS (squeeze)
+
+SQUEEZE_FIRES = {3: (64, 16, 64), 4: (128, 16, 64), 6: (128, 32, 128), 7: (256, 32, 128),
+                 9: (256, 48, 192), 10: (384, 48, 192), 11: (384, 64, 256), 12: (512, 64, 256)}
+SQUEEZE_TAPS_AFTER = [1, 4, 7, 9, 10, 11, 12]       # feature index after which each of the 7 taps is read
+SQUEEZE_POOLS = [2, 5, 8]
+SQUEEZE_CHNS = [64, 128, 256, 384, 384, 512, 512]
+LPIPS_SHIFT = (-0.030, -0.088, -0.188)
+LPIPS_SCALE = (0.458, 0.448, 0.450)
+
+
+def squeeze_backbone_random(seed=0):
+    """Seeded He-scaled random SqueezeNet1.1 feature weights under torchvision's key names."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = torch.from_numpy((rng.standard_normal((co, ci, k, k)) * math.sqrt(2.0 / (ci * k * k))).astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy((rng.standard_normal(co) * 0.05).astype(np.float32))
+
+    conv("features.0", 64, 3, 3)
+    for idx, (ci, sq, ex) in SQUEEZE_FIRES.items():
+        conv(f"features.{idx}.squeeze", sq, ci, 1)
+        conv(f"features.{idx}.expand1x1", ex, sq, 1)
+        conv(f"features.{idx}.expand3x3", ex, sq, 3)
+    return sd
+
+
+def squeeze_features_ref(bb, x):
+    """The 7 LPIPS taps of SqueezeNet1.1 on an already-scaled input."""
+    taps = []
+    h = F.relu(F.conv2d(x, bb["features.0.weight"], bb["features.0.bias"], stride=2))
+    for idx in range(1, 13):
+        if idx == 1:
+            pass
+        elif idx in SQUEEZE_POOLS:
+            h = F.max_pool2d(h, kernel_size=3, stride=2, ceil_mode=True)
+        else:
+            p = f"features.{idx}"
+            s = F.relu(F.conv2d(h, bb[p + ".squeeze.weight"], bb[p + ".squeeze.bias"]))
+            e1 = F.relu(F.conv2d(s, bb[p + ".expand1x1.weight"], bb[p + ".expand1x1.bias"]))
+            e3 = F.relu(F.conv2d(s, bb[p + ".expand3x3.weight"], bb[p + ".expand3x3.bias"], padding=1))
+            h = torch.cat([e1, e3], 1)
+        if idx in SQUEEZE_TAPS_AFTER:
+            taps.append(h)
+    return taps
+
+
+def lpips_ref(bb, lins, img0, img1, per_layer=False):
+    """PNetLin.forward (networks_basic.py:64-92), version 0.1, spatial=False.  lins: list of [C] tensors."""
+    shift = torch.tensor(LPIPS_SHIFT).reshape(1, 3, 1, 1)
+    scale = torch.tensor(LPIPS_SCALE).reshape(1, 3, 1, 1)
+    f0 = squeeze_features_ref(bb, (img0 - shift) / scale)
+    f1 = squeeze_features_ref(bb, (img1 - shift) / scale)
+    vals = []
+    for a, b, lin in zip(f0, f1, lins):
+        na = a / (a.square().sum(1, keepdim=True).sqrt() + 1e-10)
+        nb = b / (b.square().sum(1, keepdim=True).sqrt() + 1e-10)
+        d = (na - nb).square()
+        vals.append((d * lin.reshape(1, -1, 1, 1)).sum(1, keepdim=True).mean([2, 3], keepdim=True))
+    total = vals[0]
+    for v in vals[1:]:
+        total = total + v
+    return (total, vals) if per_layer else total
+
+
+# --------------------------------------------------------------------------------------------
+# Projection loop, literal semantics
+
+def projection_literal_ref(gen_fn, loss_fn, latent_mean, latent_std, eps_stream, steps,
+                           noise=0.05, noise_ramp=0.75, min_loss_init=100.0):
+    """Best-of-N noisy sampling around latent_mean.
+
+    gen_fn(latent [1,k,D]) -> image; loss_fn(step, image) -> python float or None (= 'no face', step skipped);
+    eps_stream[i] is the injected randn_like draw of step i.  Returns (best_latent, best_step, best_loss, losses).
+    """
+    latent_in = latent_mean[None].clone()
+    best, best_step, min_loss = None, -1, float(min_loss_init)
+    losses = []
+    for i in range(steps):
+        t = i / steps
+        sigma = float(noise_strength_ref(t, float(latent_std), noise, noise_ramp))
+        latent_n = latent_in + eps_stream[i] * sigma
+        img = gen_fn(latent_n)
+        val = loss_fn(i, img)
+        losses.append(val)
+        if val is None:
+            continue
+        if val < min_loss:
+            min_loss, best, best_step = val, latent_n.clone(), i
+    return best, best_step, min_loss, losses

@@ -1,0 +1,314 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (CPU, build container only).
+
+Run:  python -m oracle.make_golden            (from the repo root; needs /root/reference)
+
+The reference cannot travel to the GPU box, so only the small input/output vectors emitted here are
+committed.  Harness-side accommodations, none of which alter reference arithmetic:
+  * `termcolor` / `seaborn` are absent cosmetic imports of misc.py -> stub modules;
+  * `TransformerLayer.dim` is read but its assignment is commented out (networks.py:581,616,814)
+    -> property returning to_queries.weight.shape[0].
+Weights are the build's own seeded synthetic tensors (morphganformer_amd/synth_weights.py) loaded through
+`load_state_dict`, since no checkpoint exists offline.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    for name, attrs in (("termcolor", {"colored": lambda s, *a, **k: s}),
+                        ("seaborn", {"color_palette": lambda *a, **k: []})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+    from training import networks
+    from torch_utils.ops import bias_act, upfirdn2d, conv2d_resample
+    import wing_loss
+    import adaptive_wing_loss
+    networks.TransformerLayer.dim = property(lambda s: s.to_queries.weight.shape[0])
+    return types.SimpleNamespace(networks=networks, bias_act=bias_act, upfirdn2d=upfirdn2d,
+                                 conv2d_resample=conv2d_resample, wing_loss=wing_loss,
+                                 adaptive_wing_loss=adaptive_wing_loss)
+
+
+def build_reference_generator(ref, cfg, sd_np):
+    G = ref.networks.Generator(
+        z_dim=cfg.z_dim, c_dim=0, w_dim=cfg.w_dim, k=cfg.k, img_resolution=cfg.img_resolution, img_channels=3,
+        mapping_kwargs=dict(num_heads=1, transformer=True, use_pos=True, resnet=True, ltnt2ltnt=True,
+                            normalize_global=cfg.normalize_global),
+        synthesis_kwargs=dict(channel_base=cfg.channel_base, channel_max=cfg.channel_max, architecture="resnet",
+                              style=True, local_noise=True, transformer=True, use_pos=True, num_heads=1,
+                              start_res=0, end_res=cfg.attn_max_log2res, norm="layer", integration="mul",
+                              kmeans=True, kmeans_iters=1, pos_type="sinus", pos_init="uniform",
+                              pos_directions_num=2)).eval().requires_grad_(False)
+    state = {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+    missing, unexpected = G.load_state_dict(state, strict=False)
+    assert not unexpected, unexpected
+    assert not missing, missing
+    return G
+
+
+def gold_bias_act(ref):
+    from oracle.ops_ref import ACT_NAMES
+    rng = np.random.Generator(np.random.PCG64(11))
+    out = {}
+    x = rng.standard_normal((2, 5, 7, 3)).astype(np.float32) * 2
+    b = rng.standard_normal(5).astype(np.float32)
+    dy = rng.standard_normal((2, 5, 7, 3)).astype(np.float32)
+    ddx = rng.standard_normal((2, 5, 7, 3)).astype(np.float32)
+    out["x"], out["b"], out["dy"], out["ddx"] = x, b, dy, ddx
+    for act in ACT_NAMES:
+        for clamp in (None, 0.5):
+            tag = f"{act}_c{'none' if clamp is None else clamp}"
+            xt = torch.from_numpy(x).requires_grad_(True)
+            y = ref.bias_act.bias_act(xt, torch.from_numpy(b), dim=1, act=act, clamp=clamp, impl="ref")
+            (dx,) = torch.autograd.grad(y, xt, torch.from_numpy(dy), create_graph=True)
+            out[f"y_{tag}"] = y.detach().numpy()
+            out[f"dx_{tag}"] = dx.detach().numpy()
+            if dx.requires_grad:
+                (d2,) = torch.autograd.grad(dx, xt, torch.from_numpy(ddx), allow_unused=True)
+                out[f"d2_{tag}"] = (torch.zeros_like(xt) if d2 is None else d2).detach().numpy()
+            else:
+                out[f"d2_{tag}"] = np.zeros_like(x)
+    # dim=0 bias on a 2-D tensor, and an explicit alpha/gain
+    x2 = rng.standard_normal((3, 7)).astype(np.float32)
+    b2 = rng.standard_normal(3).astype(np.float32)
+    out["x2"], out["b2"] = x2, b2
+    out["y2"] = ref.bias_act.bias_act(torch.from_numpy(x2), torch.from_numpy(b2), dim=0, act="lrelu", alpha=0.3,
+                                      gain=1.7, impl="ref").numpy()
+    np.savez_compressed(os.path.join(OUT, "ops_bias_act.npz"), **out)
+
+
+UPFIRDN_CASES = [
+    # name, shape, filter taps (1-D list => outer product, like the reference for <8 taps), up, down, padding, gain, flip
+    ("up2_4x4_g4", (1, 3, 9, 9), [1, 3, 3, 1], 2, 1, [2, 1, 2, 1], 4.0, False),
+    ("up1_4x4_crop", (2, 3, 11, 11), [1, 3, 3, 1], 1, 1, [1, 1, 1, 1], 4.0, False),
+    ("up2_2x2_nn", (1, 4, 6, 6), [1, 1], 2, 1, [1, 0, 1, 0], 4.0, False),
+    ("down2_4x4", (1, 3, 12, 12), [1, 3, 3, 1], 1, 2, [1, 1, 1, 1], 1.0, False),
+    ("asym_3x5_flip", (1, 2, 8, 10), None, 1, 1, [2, 1, 0, 3], 1.0, True),
+    ("neg_pad", (1, 2, 10, 10), [1, 2, 1], 1, 1, [-1, -2, 0, -1], 1.0, False),
+    ("up3_down2", (1, 2, 7, 5), [1, 4, 6, 4, 1], 3, 2, [3, 2, 1, 4], 2.0, False),
+    ("sep8", (1, 2, 9, 9), [1, 2, 3, 4, 4, 3, 2, 1], 2, 1, [4, 3, 4, 3], 4.0, False),
+]
+
+
+def gold_upfirdn2d(ref):
+    rng = np.random.Generator(np.random.PCG64(12))
+    out = {}
+    for name, shape, taps, up, down, pad, gain, flip in UPFIRDN_CASES:
+        x = rng.standard_normal(shape).astype(np.float32)
+        if taps is None:
+            f = torch.from_numpy(rng.standard_normal((3, 5)).astype(np.float32))
+        else:
+            f = ref.upfirdn2d.setup_filter(taps)
+        y = ref.upfirdn2d.upfirdn2d(torch.from_numpy(x), f, up=up, down=down, padding=pad, flip_filter=flip,
+                                    gain=gain, impl="ref")
+        out[f"x_{name}"], out[f"f_{name}"], out[f"y_{name}"] = x, f.numpy(), y.numpy()
+    np.savez_compressed(os.path.join(OUT, "ops_upfirdn2d.npz"), **out)
+
+
+def gold_modconv(ref):
+    rng = np.random.Generator(np.random.PCG64(13))
+    out = {}
+    f = ref.upfirdn2d.setup_filter([1, 3, 3, 1])
+    x = rng.standard_normal((2, 8, 8, 8)).astype(np.float32)
+    w = (rng.standard_normal((6, 8, 3, 3)) / np.sqrt(72)).astype(np.float32)
+    s = (1 + 0.3 * rng.standard_normal((2, 8))).astype(np.float32)
+    out["x"], out["w"], out["s"], out["f"] = x, w, s, f.numpy()
+    for up in (1, 2):
+        for demod in (True, False):
+            y = ref.networks.modulated_conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(s), up=up,
+                                              padding=1, resample_kernel=f, demodulate=demod, flip_weight=(up == 1),
+                                              fused_modconv=True)
+            out[f"y_up{up}_demod{int(demod)}"] = y.numpy()
+    w1 = (rng.standard_normal((5, 8, 1, 1)) / np.sqrt(8)).astype(np.float32)
+    out["w1"] = w1
+    out["y_skip_up2"] = ref.conv2d_resample.conv2d_resample(torch.from_numpy(x), torch.from_numpy(w1), f=f, up=2,
+                                                            padding=0, flip_weight=False).numpy()
+    np.savez_compressed(os.path.join(OUT, "ops_modconv.npz"), **out)
+
+
+def gold_generator_tiny(ref):
+    from morphganformer_amd.synth_weights import TINY, make_state_dict, synthetic_latents
+    sd = make_state_dict(TINY, seed=0)
+    G = build_reference_generator(ref, TINY, sd)
+    z = torch.from_numpy(synthetic_latents(TINY, 2, seed=1000))
+    out = {"z": z.numpy()}
+    taps = {}
+    hooks = []
+    for res in TINY.block_resolutions:
+        blk = getattr(G.synthesis, f"b{res}")
+        hooks.append(blk.register_forward_hook(lambda m, i, o, r=res: taps.__setitem__(f"b{r}", o[0].detach().clone())))
+    probs = {}
+    for res, name in ((4, "conv1"), (16, "conv0"), (64, "conv1")):
+        tr = getattr(getattr(G.synthesis, f"b{res}"), name).transformer
+        hooks.append(tr.register_forward_hook(lambda m, i, o, k=f"b{res}.{name}": probs.__setitem__(k, o[1].detach().clone())))
+    img, ws = G(z, None, noise_mode="const", return_ws=True)
+    for h in hooks:
+        h.remove()
+    out["img_const"] = img.numpy()
+    out["ws"] = ws[:, :, 0].numpy()
+    assert float((ws - ws[:, :, :1]).abs().max()) == 0.0
+    for k_, v in taps.items():
+        out[f"tap_{k_}"] = v.numpy()
+    for k_, v in probs.items():
+        out[f"probs_{k_}"] = v.reshape(v.shape[0], -1, TINY.k - 1).numpy()
+    out["img_none"] = G(z, None, noise_mode="none")[0].numpy()
+    # injected noise: patch torch.randn inside the reference module namespace with a deterministic queue
+    rng = np.random.Generator(np.random.PCG64(77))
+    inj = {}
+    order = []
+    for res in TINY.block_resolutions:
+        for name in (["conv0"] if res > 4 else []) + ["conv1"]:
+            key = f"synthesis.b{res}.{name}"
+            inj[key] = rng.standard_normal((2, res, res)).astype(np.float32)
+            order.append(key)
+    queue = list(order)
+    real_randn = torch.randn
+
+    def fake_randn(shape, *a, **k):
+        key = queue.pop(0)
+        t = torch.from_numpy(inj[key]).reshape(shape)
+        return t
+
+    ref.networks.torch.randn = fake_randn
+    try:
+        out["img_inject"] = G(z, None, noise_mode="random")[0].numpy()
+    finally:
+        ref.networks.torch.randn = real_randn
+    assert not queue
+    for key, v in inj.items():
+        out["noise_" + key] = v
+    # gradient-mode oracle: d(mean(img^2))/dz through the reference module
+    zg = z.clone().requires_grad_(True)
+    G.requires_grad_(False)
+    loss = G(zg, None, noise_mode="const")[0].square().mean()
+    (gz,) = torch.autograd.grad(loss, zg)
+    out["loss_sq"] = np.float32(loss.item())
+    out["grad_z"] = gz.numpy()
+    np.savez_compressed(os.path.join(OUT, "gen_tiny.npz"), **out)
+    return G, sd
+
+
+def gold_loop_tiny(ref, G):
+    """Literal-mode mini run: 50 steps, MSE + lamda*Wing on injected landmarks."""
+    from morphganformer_amd.synth_weights import TINY, synthetic_latents
+    from oracle.loss_ref import latent_stats_ref, noise_strength_ref
+    torch.manual_seed(0)
+    steps = 50
+    rng = np.random.Generator(np.random.PCG64(5))
+    samples = torch.from_numpy(rng.standard_normal((1000, TINY.k, TINY.z_dim)).astype(np.float32))
+    latent_mean = samples.mean(0)
+    latent_std = ((samples - latent_mean).pow(2).sum() / samples.shape[0]) ** 0.5
+    target = G(torch.from_numpy(synthetic_latents(TINY, 1, seed=1001)), None, noise_mode="const")[0].clamp(-1, 1)
+    eps = rng.standard_normal((steps, 1, TINY.k, TINY.z_dim)).astype(np.float32)
+    lm_target = rng.integers(8, 56, size=(68, 2)).astype(np.float64)
+    lm_steps = lm_target[None] + rng.integers(-6, 7, size=(steps, 68, 2)).astype(np.float64)
+    wing = ref.wing_loss.WingLoss()
+    mse = torch.nn.MSELoss()
+    latent_in = latent_mean[None].clone()
+    min_loss, best, best_step = 100.0, None, -1
+    losses = np.zeros(steps, np.float64)
+    for i in range(steps):
+        t = i / steps
+        sigma = latent_std * 0.05 * max(0, 1 - t / 0.75) ** 2
+        latent_n = latent_in + torch.from_numpy(eps[i]) * sigma.item()
+        img = G(latent_n, 0.7, noise_mode="const")[0]
+        w = wing(torch.from_numpy(lm_steps[i]), torch.from_numpy(lm_target))
+        total = 0.01 * w + 1.0 * mse(img, target)
+        losses[i] = float(total)
+        if float(total) < min_loss:
+            min_loss, best, best_step = float(total), latent_n.clone(), i
+    np.savez_compressed(os.path.join(OUT, "loop_tiny.npz"), latent_mean=latent_mean.numpy(),
+                        latent_std=np.float32(latent_std.item()), target=target.numpy(), eps=eps,
+                        lm_target=lm_target, lm_steps=lm_steps, losses=losses, best_latent=best.numpy(),
+                        best_step=np.int64(best_step), best_loss=np.float64(min_loss))
+
+
+def gold_generator_full(ref):
+    """Full-size 1024^2 generator: 4096 sampled pixels + per-block checksums."""
+    from morphganformer_amd.synth_weights import FULL1024, make_state_dict, synthetic_latents
+    sd = make_state_dict(FULL1024, seed=0)
+    G = build_reference_generator(ref, FULL1024, sd)
+    # the projection loop discards list2tensor's 738 MB output; skip it for speed
+    G.synthesis.list2tensor = lambda att_list, device: torch.zeros([1])
+    z = torch.from_numpy(synthetic_latents(FULL1024, 1, seed=1000))
+    stats = {}
+    hooks = []
+    for res in FULL1024.block_resolutions:
+        blk = getattr(G.synthesis, f"b{res}")
+        hooks.append(blk.register_forward_hook(
+            lambda m, i, o, r=res: stats.__setitem__(r, (float(o[0].double().mean()), float(o[0].double().square().mean().sqrt())))))
+    torch.set_num_threads(8)
+    img = G(z, None, noise_mode="const")[0]
+    for h in hooks:
+        h.remove()
+    rng = np.random.Generator(np.random.PCG64(99))
+    idx = rng.integers(0, 3 * 1024 * 1024, size=4096)
+    flat = img.reshape(-1).numpy()
+    np.savez_compressed(os.path.join(OUT, "gen_full1024.npz"), z=z.numpy(), idx=idx, pixels=flat[idx],
+                        img_mean=np.float64(img.double().mean()), img_rms=np.float64(img.double().square().mean().sqrt()),
+                        img_absmax=np.float32(img.abs().max()),
+                        block_res=np.array(FULL1024.block_resolutions),
+                        block_mean=np.array([stats[r][0] for r in FULL1024.block_resolutions]),
+                        block_rms=np.array([stats[r][1] for r in FULL1024.block_resolutions]),
+                        img_ds=torch.nn.functional.avg_pool2d(img, 16).numpy())
+
+
+def gold_loss_kats(ref):
+    out = {}
+    wing = ref.wing_loss.WingLoss()
+    awing = ref.adaptive_wing_loss.AdaptiveWingLoss()
+    out["wing_ones_zeros"] = np.float64(wing(torch.zeros(2, 68, 64, 64), torch.ones(2, 68, 64, 64)).item())
+    p = torch.tensor([[1.0, 12.0], [3.0, 0.0]], dtype=torch.float64)
+    t = torch.tensor([[0.0, 0.0], [3.0, 20.0]], dtype=torch.float64)
+    out["wing_small_pred"], out["wing_small_target"] = p.numpy(), t.numpy()
+    out["wing_small"] = np.float64(wing(p, t).item())
+    out["awing_ones_zeros"] = np.float64(awing(torch.zeros(68, 2), torch.ones(68, 2)).item())
+    rng = np.random.Generator(np.random.PCG64(21))
+    a = rng.integers(0, 1024, size=(68, 2)).astype(np.float64)
+    b = a + rng.integers(-30, 31, size=(68, 2))
+    out["wing_rand_pred"], out["wing_rand_target"] = a, b
+    out["wing_rand"] = np.float64(wing(torch.from_numpy(a), torch.from_numpy(b)).item())
+    np.savez_compressed(os.path.join(OUT, "loss_kats.npz"), **out)
+
+
+def gold_lin_heads():
+    """The vendored LPIPS 1x1 'lin' heads are data files of the reference (lpips/weights/v0.1/*.pth)."""
+    for net in ("squeeze", "alex", "vgg"):
+        sd = torch.load(os.path.join(REF, "lpips", "weights", "v0.1", net + ".pth"), map_location="cpu")
+        arrs = {k.replace(".model.1.weight", ""): v.reshape(-1).numpy() for k, v in sd.items()}
+        np.savez_compressed(os.path.join(OUT, f"lpips_lin_{net}.npz"), **arrs)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    sys.path.insert(0, ROOT)
+    ref = import_reference()
+    torch.manual_seed(0)
+    gold_bias_act(ref)
+    gold_upfirdn2d(ref)
+    gold_modconv(ref)
+    gold_loss_kats(ref)
+    gold_lin_heads()
+    G, _ = gold_generator_tiny(ref)
+    gold_loop_tiny(ref, G)
+    if "--no-full" not in sys.argv:
+        gold_generator_full(ref)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

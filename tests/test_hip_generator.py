@@ -1,0 +1,109 @@
+"""GPU parity of the HIP generator engine against (a) the reference module's own outputs on seeded synthetic weights
+(tests/golden/gen_tiny.npz, gen_full1024.npz -- produced by oracle/make_golden.py from /root/reference) and (b) the CPU
+oracle on fresh seeded inputs.  Gate (BASELINE.json north_star): generated pixels within 1e-3 of the fp32 CPU path,
+relative to max|img|; per-pixel latent assignment (argmax over the 16 components) exact wherever the reference's top-2
+probabilities are separated by more than float32 re-association noise.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PIX_TOL = 1e-3
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    sd = make_state_dict(TINY, seed=0)
+    return Generator(sd, TINY, "cuda", max_batch=2), sd, TINY
+
+
+def test_mapping_matches_reference(tiny, golden):
+    G, sd, cfg = tiny
+    g = golden("gen_tiny.npz")
+    ws = G(torch.from_numpy(g["z"]).cuda(), None, subnet="mapping")
+    assert tuple(ws.shape) == (2, cfg.k, cfg.num_ws, cfg.w_dim)
+    assert rel(ws[:, :, 0], g["ws"]) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["const", "none", "inject"])
+def test_tiny_generator_matches_reference(tiny, golden, mode):
+    G, sd, cfg = tiny
+    g = golden("gen_tiny.npz")
+    z = torch.from_numpy(g["z"]).cuda()
+    noises = None
+    if mode == "inject":
+        noises = {k[len("noise_"):]: torch.from_numpy(g[k]).cuda() for k in g.files if k.startswith("noise_")}
+    G.taps = {}
+    img = G(z, None, noise_mode=mode, noises=noises)[0]
+    taps, G.taps = G.taps, None
+    assert tuple(img.shape) == (2, 3, 64, 64)
+    if mode == "const":
+        for res in cfg.block_resolutions:
+            assert rel(taps[f"synthesis.b{res}"], g[f"tap_b{res}"]) < PIX_TOL, res
+    assert rel(img, g["img_" + mode]) < PIX_TOL
+
+
+def test_tiny_attention_assignments(tiny, golden):
+    G, sd, cfg = tiny
+    g = golden("gen_tiny.npz")
+    z = torch.from_numpy(g["z"]).cuda()
+    img, att = G(z, None, noise_mode="const", return_att=True)
+    for key in ("b4.conv1", "b16.conv0", "b64.conv1"):
+        probs, argmax = att["synthesis." + key]
+        ref = g["probs_" + key]                      # [n, F, T]
+        assert np.abs(probs.cpu().numpy() - ref).max() < 1e-4, key
+        top2 = np.sort(ref, axis=-1)[..., -2:]
+        decided = (top2[..., 1] - top2[..., 0]) > 1e-4
+        assert decided.mean() > 0.99
+        assert np.array_equal(argmax.cpu().numpy()[decided], ref.argmax(-1)[decided]), key
+
+
+def test_tiny_vs_oracle_fresh_latents(tiny):
+    from oracle.generator_ref import generator_ref, to_torch_state
+    G, sd, cfg = tiny
+    tsd = to_torch_state(sd)
+    torch.manual_seed(123)
+    z = torch.randn(2, cfg.k, cfg.z_dim)
+    ref = generator_ref(tsd, z, cfg, "const")
+    img = G(z.cuda(), None, noise_mode="const")[0]
+    assert rel(img, ref.numpy()) < PIX_TOL
+    # batch of 1 re-allocates the workspace and must agree with the batched run
+    img1 = G(z[:1].cuda(), None, noise_mode="const")[0]
+    assert rel(img1, ref[:1].numpy()) < PIX_TOL
+    # random noise mode is reproducible under a fixed torch seed and differs from const
+    torch.manual_seed(7); a = G(z[:1].cuda(), 0.7)[0].clone()
+    torch.manual_seed(7); b = G(z[:1].cuda(), 0.7)[0].clone()
+    assert torch.equal(a, b) and not torch.equal(a, img1)
+
+
+def test_full_1024_matches_reference_samples(golden):
+    """BASELINE.json full size: 1024^2, k=17, channel_base 32768: 4096 sampled pixels, per-block statistics and a
+    16x down-sampled image, all taken from the reference module on CPU."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import FULL1024, make_state_dict
+    g = golden("gen_full1024.npz")
+    G = Generator(make_state_dict(FULL1024, seed=0), FULL1024, "cuda", max_batch=1)
+    G.taps = {}
+    img = G(torch.from_numpy(g["z"]).cuda(), None, noise_mode="const")[0]
+    taps, G.taps = G.taps, None
+    assert tuple(img.shape) == (1, 3, 1024, 1024)
+    amax = float(g["img_absmax"])
+    pix = img.reshape(-1)[torch.from_numpy(g["idx"]).cuda()].cpu().numpy()
+    assert np.abs(pix - g["pixels"]).max() / amax < PIX_TOL
+    ds = torch.nn.functional.avg_pool2d(img, 16).cpu().numpy()
+    assert np.abs(ds - g["img_ds"]).max() / amax < PIX_TOL
+    for res, m, r in zip(g["block_res"], g["block_mean"], g["block_rms"]):
+        t = taps[f"synthesis.b{int(res)}"].double()
+        assert abs(float(t.mean()) - m) < 1e-3 * r, res
+        assert abs(float(t.square().mean().sqrt()) - r) < 1e-3 * r, res
+    assert abs(float(img.double().mean()) - float(g["img_mean"])) < 1e-3 * float(g["img_rms"])

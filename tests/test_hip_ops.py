@@ -1,0 +1,189 @@
+"""GPU parity of the operator-level HIP kernels (through the C ABI) against the reference's own outputs
+(tests/golden/ops_*.npz, generated from /root/reference by oracle/make_golden.py) and against the CPU oracle on
+seeded inputs.  Tolerances: float32 element-wise ops 1e-5 relative to max|y|; MFMA convs 1e-4 (re-associated f32 sums).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.asarray(a)).cuda()
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_library_loads_and_device_ok():
+    from morphganformer_amd import _lib
+    L = _lib.lib()
+    assert L.mgf_version() >= 100
+    assert L.mgf_device_ok() == 1, L.mgf_last_error()
+
+
+@pytest.mark.parametrize("clamp", [None, 0.5])
+def test_bias_act_golden_fwd_grad(golden, clamp):
+    from morphganformer_amd.torch_utils.ops import bias_act
+    from oracle.ops_ref import ACT_NAMES
+    g = golden("ops_bias_act.npz")
+    for act in ACT_NAMES:
+        tag = f"{act}_c{'none' if clamp is None else clamp}"
+        x = dev(g["x"]).requires_grad_(True)
+        b = dev(g["b"])
+        y = bias_act.bias_act(x, b, dim=1, act=act, clamp=clamp)
+        assert rel_err(y, g[f"y_{tag}"]) < 2e-6, (act, "fwd")
+        (dx,) = torch.autograd.grad(y, x, dev(g["dy"]), create_graph=True)
+        assert rel_err(dx, g[f"dx_{tag}"]) < 5e-6, (act, "grad1")
+        if dx.requires_grad and np.abs(g[f"d2_{tag}"]).max() > 0:
+            (d2,) = torch.autograd.grad(dx, x, dev(g["ddx"]), allow_unused=True)
+            assert d2 is not None and rel_err(d2, g[f"d2_{tag}"]) < 2e-5, (act, "grad2")
+
+
+def test_bias_act_dim0_alpha_gain_and_dtypes(golden):
+    from morphganformer_amd.torch_utils.ops import bias_act
+    from oracle.ops_ref import bias_act_ref
+    g = golden("ops_bias_act.npz")
+    y = bias_act.bias_act(dev(g["x2"]), dev(g["b2"]), dim=0, act="lrelu", alpha=0.3, gain=1.7)
+    assert rel_err(y, g["y2"]) < 2e-6
+    torch.manual_seed(3)
+    for dt, tol in ((torch.float64, 1e-12), (torch.float16, 2e-3)):
+        x = torch.randn(3, 8, 5, 6, dtype=torch.float64).to(dt)
+        b = torch.randn(8, dtype=torch.float64).to(dt)
+        for act in ("lrelu", "swish", "tanh", "softplus"):
+            ref = bias_act_ref(x.double(), b.double(), act=act)
+            out = bias_act.bias_act(x.cuda(), b.cuda(), act=act)
+            assert out.dtype == dt and rel_err(out, ref) < tol, (dt, act)
+    # channels_last input keeps its layout and values
+    x = torch.randn(2, 6, 5, 7).cuda().to(memory_format=torch.channels_last)
+    b = torch.randn(6).cuda()
+    out = bias_act.bias_act(x, b, act="lrelu")
+    assert out.is_contiguous(memory_format=torch.channels_last)
+    assert rel_err(out, bias_act_ref(x.cpu(), b.cpu(), act="lrelu")) < 2e-6
+    # empty tensor and odd sizes (scalar tail path)
+    assert bias_act.bias_act(torch.empty(0, 4).cuda(), None).numel() == 0
+    x = torch.randn(7, 3, 5).cuda()
+    assert rel_err(bias_act.bias_act(x, torch.ones(3).cuda(), act="relu"), bias_act_ref(x.cpu(), torch.ones(3), act="relu")) < 2e-6
+
+
+def test_bias_act_errors():
+    from morphganformer_amd import _lib
+    from morphganformer_amd.torch_utils.ops import bias_act
+    with pytest.raises(_lib.MgfError):
+        bias_act.bias_act(torch.zeros(2, 3), None)                    # CPU tensor: no fallback
+    with pytest.raises(_lib.MgfError):
+        bias_act.bias_act(torch.zeros(2, 3).cuda(), torch.zeros(4).cuda())
+    with pytest.raises(NotImplementedError):
+        bias_act.bias_act(torch.zeros(2, 3).cuda(), None, impl="ref")
+
+
+def test_upfirdn2d_golden(golden):
+    from morphganformer_amd.torch_utils.ops import upfirdn2d
+    from oracle.make_golden import UPFIRDN_CASES
+    g = golden("ops_upfirdn2d.npz")
+    for name, shape, taps, up, down, pad, gain, flip in UPFIRDN_CASES:
+        y = upfirdn2d.upfirdn2d(dev(g[f"x_{name}"]), dev(g[f"f_{name}"]), up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+        assert tuple(y.shape) == g[f"y_{name}"].shape, name
+        assert rel_err(y, g[f"y_{name}"]) < 3e-6, name
+
+
+@pytest.mark.parametrize("up,pad,shape", [(1, [1, 1, 1, 1], (2, 5, 65, 65)), (2, [2, 1, 2, 1], (1, 3, 40, 40)),
+                                           (1, [1, 1, 1, 1], (1, 2, 129, 200)), (2, [2, 1, 2, 1], (2, 2, 33, 70))])
+def test_upfirdn2d_tiled_vs_oracle(up, pad, shape):
+    """The LDS-tiled fast path (>=32 wide, 4x4, up 1/2) incl. ragged tile edges, channels_last and setup_filter."""
+    from morphganformer_amd.torch_utils.ops import upfirdn2d
+    from oracle.ops_ref import setup_filter_ref, upfirdn2d_ref
+    torch.manual_seed(5)
+    x = torch.randn(*shape)
+    f = setup_filter_ref([1, 3, 3, 1])
+    assert torch.equal(upfirdn2d.setup_filter([1, 3, 3, 1]), f)
+    ref = upfirdn2d_ref(x, f, up=up, padding=pad, gain=4.0)
+    out = upfirdn2d.upfirdn2d(x.cuda(), f.cuda(), up=up, padding=pad, gain=4.0)
+    assert rel_err(out, ref) < 3e-6
+    out_cl = upfirdn2d.upfirdn2d(x.cuda().to(memory_format=torch.channels_last), f.cuda(), up=up, padding=pad, gain=4.0)
+    assert rel_err(out_cl, ref) < 3e-6
+    # gradient = self-application with swapped factors
+    xg = x.cuda().requires_grad_(True)
+    (gx,) = torch.autograd.grad(upfirdn2d.upfirdn2d(xg, f.cuda(), up=up, padding=pad, gain=4.0).square().sum(), xg)
+    xr = x.clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad(upfirdn2d_ref(xr, f, up=up, padding=pad, gain=4.0).square().sum(), xr)
+    assert rel_err(gx, gr) < 1e-5
+
+
+def test_upfirdn2d_helpers_vs_oracle():
+    from morphganformer_amd.torch_utils.ops import upfirdn2d
+    from oracle.ops_ref import setup_filter_ref, upfirdn2d_ref
+    torch.manual_seed(6)
+    x = torch.randn(1, 3, 12, 12)
+    f = setup_filter_ref([1, 3, 3, 1])
+    up = upfirdn2d.upsample2d(x.cuda(), f.cuda())
+    assert rel_err(up, upfirdn2d_ref(x, f, up=2, padding=[2, 1, 2, 1], gain=4.0)) < 3e-6
+    dn = upfirdn2d.downsample2d(x.cuda(), f.cuda())
+    assert rel_err(dn, upfirdn2d_ref(x, f, down=2, padding=[1, 1, 1, 1])) < 3e-6
+    fl = upfirdn2d.filter2d(x.cuda(), f.cuda())
+    assert rel_err(fl, upfirdn2d_ref(x, f, padding=[2, 1, 2, 1])) < 3e-6
+    # nearest-neighbour x4 with a separable 4-tap box (the list2tensor pattern, networks.py:1235-1237)
+    box = upfirdn2d.setup_filter([1] * 8)
+    assert box.ndim == 1
+    big = upfirdn2d.upsample2d(x.cuda(), box.cuda(), up=8)
+    ref = upfirdn2d_ref(x, setup_filter_ref([1] * 8), up=8, padding=[7, 0, 7, 0], gain=64.0)
+    assert rel_err(big, ref) < 3e-6
+    with pytest.raises(Exception):
+        upfirdn2d.upfirdn2d(torch.zeros(1, 1, 2, 2).cuda(), torch.ones(5, 5).cuda())      # empty output
+
+
+def test_modulated_conv_golden(golden):
+    from morphganformer_amd.torch_utils.ops import conv2d_resample
+    g = golden("ops_modconv.npz")
+    x, w, s, f = dev(g["x"]), dev(g["w"]), dev(g["s"]), dev(g["f"])
+    for up in (1, 2):
+        for demod in (True, False):
+            y = conv2d_resample.modulated_conv2d(x, w, s, up=up, padding=1, resample_kernel=f, demodulate=demod,
+                                                 flip_weight=(up == 1))
+            ref = g[f"y_up{up}_demod{int(demod)}"]
+            assert tuple(y.shape) == ref.shape
+            assert rel_err(y, ref) < 1e-5, (up, demod)
+    y = conv2d_resample.conv2d_resample(x, dev(g["w1"]), f=f, up=2, padding=0, flip_weight=False)
+    assert rel_err(y, g["y_skip_up2"]) < 1e-5
+
+
+@pytest.mark.parametrize("n,cin,cout,res,k,stride,pad", [
+    (1, 32, 32, 64, 3, 1, 1), (2, 64, 96, 40, 3, 1, 1), (1, 3, 64, 67, 3, 2, 0), (1, 16, 64, 31, 1, 1, 0),
+    (1, 48, 192, 17, 3, 1, 1), (3, 8, 3, 36, 1, 1, 0), (1, 128, 64, 8, 3, 1, 1), (1, 512, 512, 4, 3, 1, 1)])
+def test_conv_taps_vs_torch(n, cin, cout, res, k, stride, pad):
+    """FP32-MFMA tap conv vs torch CPU conv2d on seeded inputs: ragged tiles, channel padding, stride 2, 1x1, tiny maps."""
+    from morphganformer_amd import conv as cv
+    torch.manual_seed(n * 1000 + cin + cout + res)
+    x = torch.randn(n, cin, res, res)
+    w = torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k)
+    b = torch.randn(cout)
+    ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=pad))
+    from morphganformer_amd import _lib
+    pc = cv.pack_weights(w.cuda())
+    ep = _lib.make_epilogue(bias=b.cuda(), act="relu")
+    b_dev = b.cuda()
+    ep = _lib.make_epilogue(bias=b_dev, act="relu")
+    out = cv.conv_forward(x.cuda(), pc, stride=stride, pad=(pad, pad), epilogue=ep)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert rel_err(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("n,cin,cout,res", [(1, 32, 32, 16), (2, 64, 32, 33), (1, 8, 40, 4), (1, 128, 64, 64)])
+def test_tconv_vs_torch(n, cin, cout, res):
+    from morphganformer_amd import conv as cv
+    torch.manual_seed(cin + cout + res)
+    x = torch.randn(n, cin, res, res)
+    w = torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9)
+    s = 1 + 0.2 * torch.randn(n, cin)
+    d = 1 + 0.2 * torch.randn(n, cout)
+    ref = torch.nn.functional.conv_transpose2d(x * s[:, :, None, None], w.transpose(0, 1), stride=2) * d[:, :, None, None]
+    pc = cv.pack_weights(w.cuda())
+    out = cv.tconv3x3s2_forward(x.cuda(), pc, in_scale=s.cuda(), out_scale=d.cuda())
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert rel_err(out, ref) < 2e-5
