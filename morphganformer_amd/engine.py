@@ -235,6 +235,7 @@ class Generator:
                 b["last"] = e(n, c, res, res)
             self.bufs[res] = b
         self.img = e(n, cfg.img_channels, cfg.img_resolution, cfg.img_resolution)
+        self.const_in = P.const.unsqueeze(0).repeat(n, 1, 1, 1).contiguous()            # networks.py:1147
         self._build_jobs(n)
 
     def _build_jobs(self, n):
@@ -326,7 +327,7 @@ class Generator:
             b = f"synthesis.b{res}"
             B = self.bufs[res]
             if res == 4:
-                x_in = self.const.unsqueeze(0).expand(n, -1, -1, -1).contiguous() if n > 1 else self.const.unsqueeze(0)
+                x_in = self.const_in
                 x = self._layer(layers[b + ".conv1"], x_in, B, "conv1", noise_mode, noises, residual=None)
             else:
                 cv.conv_forward(x, P.skips[res], out=B["skip_low"])

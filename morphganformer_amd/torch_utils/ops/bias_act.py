@@ -67,7 +67,7 @@ def _make_op(dim, act, alpha, gain, clamp):
                 y = _launch(x, b, None, None, None, 0, dim, idx, alpha, gain, clamp)
             ctx.save_for_backward(x if "x" in spec.ref or spec.has_2nd_grad else None,
                                   b if "x" in spec.ref or spec.has_2nd_grad else None,
-                                  y if "y" in spec.ref else None)
+                                  y if ("y" in spec.ref or clamp >= 0) else None)   # clamp mask needs y (also for linear)
             ctx.has_b = b is not None
             ctx.memory_format = torch.channels_last if (x.ndim == 4 and x.stride(1) == 1 and x.shape[1] > 1) else torch.contiguous_format
             return y

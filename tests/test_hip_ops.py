@@ -53,7 +53,8 @@ def test_bias_act_dim0_alpha_gain_and_dtypes(golden):
     y = bias_act.bias_act(dev(g["x2"]), dev(g["b2"]), dim=0, act="lrelu", alpha=0.3, gain=1.7)
     assert rel_err(y, g["y2"]) < 2e-6
     torch.manual_seed(3)
-    for dt, tol in ((torch.float64, 1e-12), (torch.float16, 2e-3)):
+    # float64 runs in double but alpha/gain/clamp cross the ABI as float, exactly like the plugin (bias_act.cpp:24)
+    for dt, tol in ((torch.float64, 1e-7), (torch.float16, 2e-3)):
         x = torch.randn(3, 8, 5, 6, dtype=torch.float64).to(dt)
         b = torch.randn(8, dtype=torch.float64).to(dt)
         for act in ("lrelu", "swish", "tanh", "softplus"):
@@ -166,7 +167,6 @@ def test_conv_taps_vs_torch(n, cin, cout, res, k, stride, pad):
     ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=pad))
     from morphganformer_amd import _lib
     pc = cv.pack_weights(w.cuda())
-    ep = _lib.make_epilogue(bias=b.cuda(), act="relu")
     b_dev = b.cuda()
     ep = _lib.make_epilogue(bias=b_dev, act="relu")
     out = cv.conv_forward(x.cuda(), pc, stride=stride, pad=(pad, pad), epilogue=ep)
