@@ -1,0 +1,190 @@
+"""Benchmark of the hot path: latent-projection iterations/sec @1024^2, k=17 (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (config 2 of BASELINE.json): one 1024x1024 synthetic target per GPU, literal-mode projection
+iteration = perturb latent -> GANformer generator forward (noise_mode="random", like the drivers) -> LPIPS(squeeze)
++ lamda*Wing(injected landmarks) + beta*MSE -> best-so-far selection, all resident on the device and replayed as a hipGraph.
+Weights are seeded synthetic tensors (no checkpoint exists offline); inputs are resident in HBM before the timed region.
+N > 1: one independent target per rank (pair-level sharding, no data-path collective) -> "weak" scaling; the only
+collective is the result gather after the timed region.
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, algorithmic FLOPs / measured launch time vs the
+dense FP32-MFMA peak) and "cpu_baseline" (the CPU oracle's port of the same iteration timed on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--res", type=int, default=1024, help="debug only; the reported config is 1024")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    return ap.parse_args()
+
+
+def build(cfg, device, rank, steps_total, use_graph):
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.lpips import PerceptualLoss
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, latent_stats, synthetic_landmarks
+    from morphganformer_amd.synth_weights import make_state_dict, synthetic_latents
+    sd = make_state_dict(cfg, seed=0)
+    G = Generator(sd, cfg, device, max_batch=1)
+    z_t = torch.from_numpy(synthetic_latents(cfg, 1, seed=1000 + rank)).to(device)
+    target = G(z_t, None, noise_mode="const")[0].clamp(-1, 1).clone()
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0)
+    latent_mean, latent_std = latent_stats(G, 10000, device, gen)
+    percept = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device)
+    lm_t, lm_s = synthetic_landmarks(steps_total, cfg.img_resolution, seed=7 + rank)
+    args = ProjectionArgs(step=steps_total)
+    eng = ProjectionEngine(G, target, latent_mean, latent_std, args, percept=percept, use_mse=True, lm_target=lm_t,
+                           lm_steps=lm_s, noise_mode="random", seed=100 + rank, use_graph=use_graph)
+    return sd, G, percept, eng, target, latent_mean, float(latent_std), (lm_t, lm_s)
+
+
+def roofline_leg(eng, iters=3):
+    """Eager (un-graphed) iterations with every MFMA conv launch bracketed by events on the launch stream."""
+    from morphganformer_amd import conv as cv
+    state = [t.clone() for t in (eng.step_ctr, eng.min_loss, eng.best_latent, eng.best_step, eng.losses)]
+    eng._iteration()
+    torch.cuda.synchronize()
+    cv.PROFILE = []
+    for _ in range(iters):
+        eng._iteration()
+    torch.cuda.synchronize()
+    prof, cv.PROFILE = cv.PROFILE, None
+    for dst, src in zip((eng.step_ctr, eng.min_loss, eng.best_latent, eng.best_step, eng.losses), state):
+        dst.copy_(src)
+    agg = {}
+    for variant, flops, e0, e1 in prof:
+        a = agg.setdefault(variant, [0.0, 0.0, 0])
+        a[0] += flops
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    dom = max(agg, key=lambda k_: agg[k_][1])
+    flops, secs, launches = agg[dom]
+    achieved = flops / secs / 1e12
+    per_kernel = {k_: {"launches_per_iter": v[2] // iters, "avg_us": v[1] / v[2] * 1e6, "tflops": v[0] / v[1] / 1e12} for k_, v in agg.items()}
+    total_conv_s = sum(v[1] for v in agg.values()) / iters
+    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(secs / launches * 1e6, 2), "launches_per_iter": launches // iters,
+            "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
+            "all_conv_kernels": per_kernel, "conv_ms_per_iter": round(total_conv_s * 1e3, 3)}
+
+
+def cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, iters):
+    """The oracle's port of one iteration (what the reference computes per step, both LPIPS branches recomputed)."""
+    from oracle.generator_ref import generator_ref, to_torch_state
+    from oracle.loss_ref import lpips_ref, mse_ref, squeeze_backbone_random, wing_loss_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tsd = to_torch_state(sd)
+    bb = squeeze_backbone_random(0)
+    lin = np.load(os.path.join(ROOT, "morphganformer_amd", "weights", "lpips_lin_squeeze.npz"))
+    lins = [torch.from_numpy(lin[f"lin{i}"]) for i in range(7)]
+    tgt = target.cpu()
+    lm_t, lm_s = lms
+    rng = np.random.Generator(np.random.PCG64(1))
+    times = []
+    with torch.no_grad():
+        for i in range(iters + 1):
+            t0 = time.perf_counter()
+            z = latent_mean.cpu()[None] + torch.from_numpy(rng.standard_normal((1, cfg.k, cfg.z_dim)).astype(np.float32)) * (latent_std * 0.05)
+            noises = {}
+            for res in cfg.block_resolutions:
+                for name in (["conv0"] if res > 4 else []) + ["conv1"]:
+                    noises[f"synthesis.b{res}.{name}"] = torch.randn(1, res, res)
+            img = generator_ref(tsd, z, cfg, "inject", noises)
+            total = float(lpips_ref(bb, lins, img, tgt).sum()) + 0.01 * float(wing_loss_ref(torch.from_numpy(lm_s[i]), torch.from_numpy(lm_t))) \
+                + float(mse_ref(img, tgt))
+            times.append(time.perf_counter() - t0)
+    per = float(np.mean(times[1:]))
+    return {"value": round(1.0 / per, 4), "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} timed iterations (+1 warm-up) of the same 1024^2 Wing+LPIPS(squeeze)+MSE step, torch-CPU fp32 oracle, "
+                      f"{cores} threads; {per:.2f} s/iter"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    from morphganformer_amd.synth_weights import GeneratorConfig
+    cfg = GeneratorConfig(img_resolution=a.res)
+    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, a.steps + a.warmup, not a.no_graph)
+
+    eng.run(a.warmup)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(a.steps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # result gather (the only collective of the path): {latent, best loss, best step} per rank
+        from morphganformer_amd.distributed import gather_results
+        lat, bstep, bloss, _ = eng.result()
+        gathered = gather_results(lat.to(device), bloss, bstep)
+        assert gathered["latents"].shape[0] == world
+    else:
+        eng.result()
+
+    out = {
+        "metric": "latent-projection iters/sec @1024^2, k=17 latents", "value": round(world * a.steps / elapsed, 3),
+        "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: single {a.res}x{a.res} face per GPU, Wing+LPIPS(squeeze)+MSE literal-mode projection step, "
+                               "noise_mode=random, seeded synthetic weights/targets/landmarks", "k": cfg.k, "z_dim": cfg.z_dim,
+                   "targets_per_gpu": 1, "parallelism": f"pair-sharded x{world}", "graph_replay": not a.no_graph},
+    }
+    if rank == 0:
+        out["roofline"] = roofline_leg(eng)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, a.cpu_iters)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -189,7 +189,9 @@ int mgf_mapping_forward(float* w, const float* z, const float* params, int32_t n
 int64_t mgf_reduce_scratch_floats(void);
 int mgf_mse_f32(float* out, const float* a, const float* b, int64_t numel, float scale, int32_t accumulate,
                 float* scratch, mgf_stream_t stream);
+/* pred_step (device int32, may be NULL): when given, pred is a [steps, numel] table and row *pred_step is used */
 int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int64_t numel, double omega, double epsilon,
+                      const int32_t* pred_step,
                       mgf_stream_t stream);
 int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1, const float* lin, int32_t n, int32_t c, int64_t hw,
                         int32_t accumulate, float* scratch, mgf_stream_t stream);
@@ -202,14 +204,14 @@ int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, int32_t in_h
  * loop never synchronises with the host:
  *   perturb: latent_n = latent_in + eps[*step] * sigma[*step]      (eps: [steps, numel] injected randn stream, sigma: [steps])
  *   select:  total = p_loss + lamda*w_loss + beta*mse (float64, as torch promotes it); if total < *min_loss:
- *            min_loss=total, best_latent=latent_n, best_step=*step.  losses_out[*step] = total (NaN when !valid = "no face",
+ *            min_loss=total, best_latent=latent_n, best_step=*step.  losses_out[*step] = total (NaN when valid[*step] == 0 = "no face"; valid NULL = always,
  *            ...sqz_MSE.py:165-166).  Finally *step += 1.  All state lives on the device -> graph-replayable.
  */
 int mgf_latent_perturb(float* latent_n, const float* latent_in, const float* eps, const float* sigma, const int32_t* step,
                        int64_t numel, mgf_stream_t stream);
 int mgf_select_best(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out,
                     const float* latent_n, int64_t numel, const float* p_loss, const double* w_loss, const float* mse_loss,
-                    float lamda, float beta, int32_t* step, int32_t valid, mgf_stream_t stream);
+                    float lamda, float beta, int32_t* step, const int32_t* valid, mgf_stream_t stream);
 /* uint8 HWC image = clip(rint(x*127.5+127.5), 0, 255) from CHW float (misc.to_pil, misc.py:114-123) */
 int mgf_to_uint8_hwc(uint8_t* out, const float* img, int32_t c, int32_t h, int32_t w, mgf_stream_t stream);
 

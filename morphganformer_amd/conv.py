@@ -17,6 +17,40 @@ def round_up(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
+# Optional per-launch instrumentation (bench.py roofline leg): when PROFILE is a list, every conv launch is bracketed
+# by events on the launch stream and appended as (kernel_variant, algorithmic_flops, start_event, end_event).
+PROFILE = None
+
+
+def _variant(mode, cout, cout_pad, tile_h, tile_w):
+    """Mirror of the kernel selection in csrc/conv_taps.hip (mgf_conv_taps_f32)."""
+    if mode == 1:
+        return "conv_taps_kernel<1,2,1>"
+    if cout_pad % 64 == 0 and cout > 32:
+        return "conv_taps_kernel<2,2,0>"
+    if tile_h * tile_w >= 512 * 64:
+        return "conv_taps_kernel<1,4,0>"
+    return "conv_taps_kernel<1,2,0>"
+
+
+class _Timed:
+    def __init__(self, variant, flops):
+        self.variant, self.flops = variant, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.variant, self.flops, self.e0, self.e1))
+        return False
+
+
 @dataclass
 class PackedConv:
     wp: torch.Tensor            # [taps, cin, cout_pad]
@@ -77,8 +111,9 @@ def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_sca
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, oh, ow, stride, 1, taps, None, [0], [0], oh, ow,
               ow, oh * ow, out.shape[1] * oh * ow, out_choff,
               0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
-    rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                      C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
+    with _Timed(_variant(0, pc.cout, pc.cout_pad, oh, ow), 2.0 * n * pc.kh * pc.kw * cin * pc.cout * oh * ow):
+        rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                          C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
     _lib.check(rc, "conv_taps")
     return out
 
@@ -105,8 +140,10 @@ def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=Non
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, h + 1, w + 1, 1, 2, TCONV_TAPS, TCONV_GROUPS, [0, 0, 1, 1], [0, 1, 0, 1],
               oh, ow, pitch, oh * pitch, pc.cout * oh * pitch, 0,
               0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
-    rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                      C.byref(d), None, _lib.stream_ptr())
+    # algorithmic FLOPs of a stride-2 transposed conv: 9 taps per INPUT pixel
+    with _Timed(_variant(1, pc.cout, pc.cout_pad, h + 1, w + 1), 2.0 * n * 9 * cin * pc.cout * h * w):
+        rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                          C.byref(d), None, _lib.stream_ptr())
     _lib.check(rc, "conv_taps(tconv)")
     return out[:, :, :, :ow]
 

@@ -68,8 +68,9 @@ __global__ __launch_bounds__(256) void lpips_partial_kernel(float* scratch, cons
 }
 
 __global__ __launch_bounds__(256) void wing_kernel(double* out, const double* pred, const double* target, int64_t numel, double omega,
-                                                   double epsilon) {
+                                                   double epsilon, const int32_t* pred_step) {
     __shared__ double sm[4];
+    if (pred_step) pred += (int64_t)(*pred_step) * numel;      // pred is a [steps, numel] table indexed on the device
     const double cc = omega - omega * log(1.0 + omega / epsilon);
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < numel; i += 256) {
@@ -111,14 +112,15 @@ __global__ __launch_bounds__(256) void perturb_kernel(float* latent_n, const flo
     const float sg = sigma[s];
     const float* e = eps + (int64_t)s * numel;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256)
-        latent_n[i] = latent_in[i] + e[i] * sg;
+        latent_n[i] = __fadd_rn(latent_in[i], __fmul_rn(e[i], sg));   // two roundings like torch (no fma): bit-exact latents
 }
 
 __global__ __launch_bounds__(256) void select_kernel(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out,
                                                      const float* latent_n, int64_t numel, const float* p_loss, const double* w_loss,
-                                                     const float* mse_loss, float lamda, float beta, int32_t* step, int valid) {
+                                                     const float* mse_loss, float lamda, float beta, int32_t* step, const int32_t* valid_tab) {
     __shared__ int take;
     const int s = *step;
+    const int valid = valid_tab ? valid_tab[s] : 1;
     if (threadIdx.x == 0) {
         // same evaluation order as `p_loss + lamda * w_loss + beta * mse_loss` with a float64 wing term
         double total = 0.0;
@@ -178,9 +180,9 @@ extern "C" int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1,
 }
 
 extern "C" int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int64_t numel, double omega, double epsilon,
-                                 mgf_stream_t stream) {
+                                 const int32_t* pred_step, mgf_stream_t stream) {
     MGF_REQUIRE(out && pred && target && numel >= 1, MGF_EINVAL, "wing_loss: bad arguments");
-    hipLaunchKernelGGL(wing_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, pred, target, numel, omega, epsilon);
+    hipLaunchKernelGGL(wing_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, pred, target, numel, omega, epsilon, pred_step);
     MGF_CHECK_LAUNCH("wing_loss");
     return MGF_OK;
 }
@@ -210,7 +212,7 @@ extern "C" int mgf_latent_perturb(float* latent_n, const float* latent_in, const
 
 extern "C" int mgf_select_best(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out, const float* latent_n,
                                int64_t numel, const float* p_loss, const double* w_loss, const float* mse_loss, float lamda, float beta,
-                               int32_t* step, int32_t valid, mgf_stream_t stream) {
+                               int32_t* step, const int32_t* valid, mgf_stream_t stream) {
     MGF_REQUIRE(min_loss && best_latent && best_step && latent_n && step && numel >= 1, MGF_EINVAL, "select_best: bad arguments");
     hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, min_loss, best_latent, best_step, losses_out, latent_n,
                        numel, p_loss, w_loss, mse_loss, lamda, beta, step, valid);

@@ -1,0 +1,64 @@
+"""Multi-GPU layer of the projection path: one process per GPU, independent face pairs sharded across ranks, one
+collective at the end.
+
+The reference has no multi-GPU projection at all: every driver pins one device (`CUDA_VISIBLE_DEVICES`,
+1024_example_wing_loss_perceptual_sqz_MSE.py:213) and walks its image list serially
+(projection_example_v2_percept_morph.py:329-365).  Each target is an independent search with private latent, noise stream
+and best-so-far state, and the generator/LPIPS weights are read-only replicas, so the path shards with NO data-path
+collective; the only exchange is the result gather {latent [k*D] f32, best loss, best step} per item (2.2 KB), done with a
+single all_gather over RCCL/xGMI (backend "nccl" on ROCm) or gloo in CPU tests.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def shard_items(n_items: int, rank: int, world: int):
+    """Static round-robin partition `items[rank::world]`."""
+    return list(range(rank, n_items, world))
+
+
+def pack_result(latent: torch.Tensor, best_loss: float, best_step: int, item: int = 0) -> torch.Tensor:
+    """[k*D + 3] float64 record: latent (exact: f32 embeds in f64), loss, step, item id."""
+    flat = latent.reshape(-1).double()
+    tail = torch.tensor([best_loss, float(best_step), float(item)], dtype=torch.float64, device=flat.device)
+    return torch.cat([flat, tail])
+
+
+def unpack_results(records: torch.Tensor, latent_shape):
+    n = records.shape[0]
+    k = 1
+    for s in latent_shape:
+        k *= s
+    return {"latents": records[:, :k].float().reshape(n, *latent_shape), "losses": records[:, k].clone(),
+            "steps": records[:, k + 1].long(), "items": records[:, k + 2].long()}
+
+
+def gather_results(latent: torch.Tensor, best_loss: float, best_step: int, item: int = 0, group=None):
+    """all_gather of one record per rank; returns the unpacked dict on every rank (works without an initialised
+    process group for world size 1)."""
+    import torch.distributed as dist
+    rec = pack_result(latent, best_loss, best_step, item)
+    if not (dist.is_available() and dist.is_initialized()):
+        return unpack_results(rec[None], tuple(latent.shape[-2:]))
+    world = dist.get_world_size(group)
+    out = torch.empty(world * rec.numel(), dtype=rec.dtype, device=rec.device)      # flat: gloo insists on 1-D in/out
+    dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
+    return unpack_results(out.view(world, rec.numel()), tuple(latent.shape[-2:]))
+
+
+def gather_many(records: torch.Tensor, counts_max: int, group=None):
+    """Ragged gather for several items per rank: records [m, R] padded to counts_max rows with item id -1."""
+    import torch.distributed as dist
+    m, r = records.shape
+    pad = torch.full([counts_max, r], -1.0, dtype=records.dtype, device=records.device)
+    pad[:m] = records
+    if not (dist.is_available() and dist.is_initialized()):
+        return pad[:m]
+    world = dist.get_world_size(group)
+    out = torch.empty(world * counts_max * r, dtype=records.dtype, device=records.device)
+    dist.all_gather_into_tensor(out, pad.reshape(-1), group=group)
+    out = out.view(world * counts_max, r)
+    keep = out[:, -1] >= 0
+    out = out[keep]
+    return out[torch.argsort(out[:, -1])]

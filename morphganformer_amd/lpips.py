@@ -1,0 +1,196 @@
+"""LPIPS v0.1 perceptual distance on MI355X -- same call contract as the reference's lpips.PerceptualLoss
+(lpips/__init__.py:13-41 -> dist_model.py:110-118 -> networks_basic.py:64-92), SqueezeNet1.1 backbone
+(lpips/pretrained_networks.py:6-56; topology = torchvision squeezenet1_1.features, a third-party dependency that is not
+vendored in the reference and whose ImageNet weights are a remote fetch).
+
+  * Backbone weights are injectable (`backbone_state`: torchvision key names `features.N...`); offline they default to
+    seeded He-scaled random tensors -- the same generator the oracle uses (oracle/loss_ref.py).  The learned 1x1 'lin'
+    heads are the reference's own vendored data (lpips/weights/v0.1/squeeze.pth), shipped in weights/.
+  * ScalingLayer (networks_basic.py:94-101) is folded into the first convolution in float64 (it has no padding, so the
+    fold is exact in real arithmetic).
+  * All convolutions run on the FP32-MFMA tap kernel with a fused bias+ReLU epilogue; Fire expand branches write their
+    halves of the concat buffer directly.
+  * The target image's 7 feature maps are computed once (`set_target`) -- the reference recomputes them every iteration.
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import conv as cv
+
+FIRES = {3: (64, 16, 64), 4: (128, 16, 64), 6: (128, 32, 128), 7: (256, 32, 128),
+         9: (256, 48, 192), 10: (384, 48, 192), 11: (384, 64, 256), 12: (512, 64, 256)}
+TAPS_AFTER = [1, 4, 7, 9, 10, 11, 12]
+POOLS = [2, 5, 8]
+CHNS = [64, 128, 256, 384, 384, 512, 512]
+SHIFT = (-0.030, -0.088, -0.188)
+SCALE = (0.458, 0.448, 0.450)
+WEIGHTS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights")
+
+
+def random_squeeze_backbone(seed=0):
+    """Seeded He-scaled SqueezeNet1.1 feature weights (numpy float32) under torchvision's key names."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = (rng.standard_normal((co, ci, k, k)) * math.sqrt(2.0 / (ci * k * k))).astype(np.float32)
+        sd[name + ".bias"] = (rng.standard_normal(co) * 0.05).astype(np.float32)
+
+    conv("features.0", 64, 3, 3)
+    for idx, (ci, sq, ex) in FIRES.items():
+        conv(f"features.{idx}.squeeze", sq, ci, 1)
+        conv(f"features.{idx}.expand1x1", ex, sq, 1)
+        conv(f"features.{idx}.expand3x3", ex, sq, 3)
+    return sd
+
+
+def _pool_out(n):
+    o = (n - 3 + 1) // 2 + 1
+    if (o - 1) * 2 >= n:
+        o -= 1
+    return o
+
+
+class SqueezeFeatures:
+    """The 7 LPIPS taps of SqueezeNet1.1 for a fixed input size, with a preallocated workspace."""
+
+    def __init__(self, backbone_state, n, h, w, device):
+        self.device = torch.device(device)
+        dev = self.device
+        g = lambda k: np.asarray(backbone_state[k], dtype=np.float64)
+        t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+        w0, b0 = g("features.0.weight"), g("features.0.bias")
+        sc, sh = np.asarray(SCALE), np.asarray(SHIFT)
+        w0f = w0 / sc[None, :, None, None]
+        b0f = b0 - (w0 * (sh / sc)[None, :, None, None]).sum(axis=(1, 2, 3))
+        self.c0 = (cv.pack_weights(t32(w0f)), t32(b0f))
+        self.fires = {}
+        for idx in FIRES:
+            p = f"features.{idx}"
+            self.fires[idx] = tuple((cv.pack_weights(t32(g(f"{p}.{nm}.weight"))), t32(g(f"{p}.{nm}.bias")))
+                                    for nm in ("squeeze", "expand1x1", "expand3x3"))
+        self.n = n
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        hh, ww = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        self.shapes = {1: (64, hh, ww)}
+        self.buf = {1: e(n, 64, hh, ww)}
+        self.sq = {}
+        c = 64
+        for idx in range(2, 13):
+            if idx in POOLS:
+                hh, ww = _pool_out(hh), _pool_out(ww)
+                self.buf[idx] = e(n, c, hh, ww)
+            else:
+                ci, sq, ex = FIRES[idx]
+                assert ci == c
+                self.sq[idx] = e(n, sq, hh, ww)
+                c = 2 * ex
+                self.buf[idx] = e(n, c, hh, ww)
+            self.shapes[idx] = (c, hh, ww)
+
+    def __call__(self, x, out=None):
+        """x: [n,3,h,w] in [-1,1] (un-scaled; ScalingLayer is folded).  Returns the list of 7 tap tensors
+        (views of the internal workspace unless `out` -- a list of 7 preallocated tensors -- is given)."""
+        _lib.require_gpu(x)
+        L = _lib.lib()
+        st = _lib.stream_ptr()
+        taps = []
+        k = 0
+
+        def dest(idx):
+            nonlocal k
+            if idx in TAPS_AFTER and out is not None:
+                return out[TAPS_AFTER.index(idx)]
+            return self.buf[idx]
+
+        pc, b = self.c0
+        h = cv.conv_forward(x.contiguous(), pc, stride=2, pad=(0, 0), epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dest(1))
+        taps.append(h)
+        for idx in range(2, 13):
+            if idx in POOLS:
+                y = self.buf[idx]
+                n, c, ih, iw = h.shape
+                _lib.check(L.mgf_maxpool3x3s2_ceil_f32(y.data_ptr(), h.data_ptr(), n * c, ih, iw, y.shape[2], y.shape[3], st), "maxpool")
+                h = y
+            else:
+                (ps, bs), (p1, b1), (p3, b3) = self.fires[idx]
+                s = cv.conv_forward(h, ps, epilogue=_lib.make_epilogue(bias=bs, act="relu"), out=self.sq[idx])
+                y = dest(idx)
+                ex = p1.cout
+                cv.conv_forward(s, p1, epilogue=_lib.make_epilogue(bias=b1, act="relu"), out=y, out_choff=0)
+                cv.conv_forward(s, p3, pad=(1, 1), epilogue=_lib.make_epilogue(bias=b3, act="relu"), out=y, out_choff=ex)
+                h = y
+            if idx in TAPS_AFTER:
+                taps.append(h)
+        return taps
+
+
+class PerceptualLoss(torch.nn.Module):
+    """lpips.PerceptualLoss(model='net-lin', net='squeeze', use_gpu=True)(pred, target, normalize=False) -> [N,1,1,1]."""
+
+    def __init__(self, model="net-lin", net="squeeze", colorspace="rgb", spatial=False, use_gpu=True, gpu_ids=(0,),
+                 backbone_state=None, backbone_seed=0, device="cuda"):
+        super().__init__()
+        if model != "net-lin" or spatial or colorspace != "rgb":
+            raise NotImplementedError("the MI355X path implements model='net-lin', spatial=False, colorspace='rgb'")
+        if net != "squeeze":
+            raise NotImplementedError("only the SqueezeNet1.1 backbone (the one BASELINE config 2 uses) is built so far")
+        if not use_gpu:
+            raise _lib.MgfError("PerceptualLoss(use_gpu=False): the MI355X package has no CPU path")
+        _lib.lib()
+        self.device_ = torch.device(device)
+        self.backbone_state = backbone_state if backbone_state is not None else random_squeeze_backbone(backbone_seed)
+        lin = np.load(os.path.join(WEIGHTS_DIR, f"lpips_lin_{net}.npz"))
+        self.lins = [torch.as_tensor(lin[f"lin{i}"], dtype=torch.float32, device=self.device_) for i in range(len(CHNS))]
+        self._feat = None
+        self._target_taps = None
+        self._scratch = torch.empty(int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=self.device_)
+        self._val = torch.zeros(1, dtype=torch.float32, device=self.device_)
+
+    def _features(self, n, h, w):
+        if self._feat is None or self._feat.n != n or self._feat.buf[1].shape[2:] != ((h - 3) // 2 + 1, (w - 3) // 2 + 1):
+            self._feat = SqueezeFeatures(self.backbone_state, n, h, w, self.device_)
+            self._target_taps = None
+        return self._feat
+
+    def set_target(self, target):
+        """Cache the target's 7 feature maps (they do not change across projection iterations)."""
+        n, _, h, w = target.shape
+        f = self._features(n, h, w)
+        outs = [torch.empty([n, c, *f.shapes[idx][1:]], dtype=torch.float32, device=self.device_)
+                for c, idx in zip(CHNS, TAPS_AFTER)]
+        f(target.float(), out=outs)
+        self._target_taps = outs
+        self._target_id = (target.data_ptr(), tuple(target.shape))
+
+    def distance_into(self, out, pred):
+        """out[0] = sum over taps of the spatial-mean weighted distance between pred and the cached target (batch-summed)."""
+        f = self._features(*[pred.shape[0], pred.shape[2], pred.shape[3]])
+        assert self._target_taps is not None, "call set_target first"
+        taps = f(pred)
+        L, st = _lib.lib(), _lib.stream_ptr()
+        for i, (a, b, lin) in enumerate(zip(taps, self._target_taps, self.lins)):
+            n, c, hh, ww = a.shape
+            _lib.check(L.mgf_lpips_layer_f32(out.data_ptr(), a.data_ptr(), b.data_ptr(), lin.data_ptr(), n, c, hh * ww,
+                                             int(i > 0), self._scratch.data_ptr(), st), "lpips_layer")
+        return out
+
+    def forward(self, pred, target, normalize=False):
+        _lib.require_gpu(pred, target)
+        if normalize:
+            target, pred = 2 * target - 1, 2 * pred - 1
+        n = pred.shape[0]
+        vals = []
+        for i in range(n):      # per-sample values like the reference's [N,1,1,1]; the loop only ever uses N == 1
+            # like the reference, the module-call form recomputes the target features on every call; the projection
+            # engine uses set_target() once + distance_into() per step instead
+            self.set_target(target[i:i + 1].contiguous())
+            self.distance_into(self._val, pred[i:i + 1].contiguous().float())
+            vals.append(self._val.clone())
+        return torch.stack(vals).reshape(n, 1, 1, 1)

@@ -1,0 +1,234 @@
+"""The latent-projection loop of the reference drivers (1024_example_wing_loss_perceptual_sqz_MSE.py:131-208 and its
+MSE / percept / Wing siblings), device-resident on MI355X.
+
+Semantics ("literal" mode = what the reference computes).  Every driver detaches the generator output
+to numpy before any loss, so `latent_in` never receives a gradient and Adam is inert; the loop is a best-of-N noisy search
+around `latent_mean`:
+
+    for i in range(steps):
+        t = i / steps
+        sigma = latent_std * noise * max(0, 1 - t / noise_ramp) ** 2                  (:156)
+        latent_n = latent_in + randn_like(latent_in) * sigma                          (:157, :71-73)
+        img = G(latent_n, 0.7)[0]      # 0.7 lands in `c`; no truncation; noise_mode="random"   (:158)
+        total = LPIPS(img, target) + lamda * Wing(landmarks(img), landmarks(target)) + beta * MSE(img, target)   (:173-179)
+        if total < min_loss: min_loss, best = total, latent_n                         (:186-189)
+
+One iteration is a fixed sequence of HIP kernel launches with all loop state (step counter, best-so-far, loss history)
+on the device, captured once into a hipGraph and replayed: no PCIe copy and no host synchronisation per step (the
+reference makes three crossings of 12.6 MB per step).  Landmark extraction is dlib on the host in the reference
+(:159-170) -- a third-party detector that is not reproducible offline -- so landmarks enter as an injected [steps,68,2]
+float64 table (and a `valid` table for the "no face found -> continue" branch, :165-166).
+
+The gradient-descent reading of the north star (back-propagating into the latent) is NOT implemented yet; see DESIGN.md.
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class ProjectionArgs:
+    """argparse defaults of the reference driver (...sqz_MSE.py:224-245)."""
+    step: int = 5000
+    lamda: float = 0.01
+    beta: float = 1.0
+    lr: float = 0.01
+    lr_rampup: float = 0.05
+    lr_rampdown: float = 0.25
+    noise: float = 0.05
+    noise_ramp: float = 0.75
+    truncation_psi: float = 0.7
+    n_mean_latent: int = 10000
+    min_loss_init: float = 100.0
+
+
+def get_lr(t, initial_lr, rampdown=0.25, rampup=0.05):
+    """Learning-rate schedule of the drivers (:63-68).  Inert in literal mode (the optimizer never sees a gradient)."""
+    lr_ramp = min(1, (1 - t) / rampdown)
+    lr_ramp = 0.5 - 0.5 * math.cos(lr_ramp * math.pi)
+    lr_ramp = lr_ramp * min(1, t / rampup)
+    return initial_lr * lr_ramp
+
+
+def noise_schedule(steps, latent_std, noise, noise_ramp):
+    """sigma_i for i in range(steps), evaluated exactly like the driver: python floats, then float32 on use."""
+    return np.array([float(latent_std) * noise * max(0, 1 - (i / steps) / noise_ramp) ** 2 for i in range(steps)], dtype=np.float64)
+
+
+def latent_stats(G, n_mean_latent=10000, device="cuda", generator=None):
+    """latent_mean [k,D] and latent_std scalar from N(0,I) samples (:251-255)."""
+    samples = torch.randn(n_mean_latent, *G.input_shape[1:], device=device, generator=generator)
+    mean = samples.mean(0)
+    std = ((samples - mean).pow(2).sum() / n_mean_latent) ** 0.5
+    return mean, std
+
+
+class ProjectionEngine:
+    """One target image <-> one latent search, replayable as a hipGraph."""
+
+    def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True,
+                 lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True):
+        self.G, self.args = G, args or ProjectionArgs()
+        a = self.args
+        dev = G.device
+        self.device = dev
+        _lib.require_gpu(target, latent_mean)
+        self.steps = a.step
+        self.target = target.contiguous().float()
+        assert self.target.shape[0] == 1, "one target per engine (the drivers process images serially)"
+        self.percept = percept
+        self.use_mse = use_mse
+        self.use_wing = lm_target is not None
+        self.noise_mode = noise_mode
+        k, D = G.cfg.k, G.cfg.z_dim
+        self.numel = k * D
+        self.latent_in = latent_mean.detach().clone().reshape(1, k, D).contiguous().float()
+        sig = noise_schedule(a.step, float(latent_std), a.noise, a.noise_ramp)
+        self.sigma = torch.as_tensor(sig.astype(np.float32), device=dev)
+        if eps is None:
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(seed)
+            eps = torch.randn(a.step, 1, k, D, device=dev, generator=gen)
+        self.eps = eps.to(dev).contiguous().float()
+        assert self.eps.shape[0] >= a.step
+        if self.use_wing:
+            self.lm_target = torch.as_tensor(lm_target, dtype=torch.float64, device=dev).contiguous()
+            self.lm_steps = torch.as_tensor(lm_steps, dtype=torch.float64, device=dev).contiguous()
+            assert self.lm_steps.shape[0] >= a.step and self.lm_steps.shape[1:] == self.lm_target.shape
+        self.valid = None if lm_valid is None else torch.as_tensor(lm_valid, dtype=torch.int32, device=dev).contiguous()
+        # device-resident loop state
+        self.step_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.min_loss = torch.full([1], float(a.min_loss_init), dtype=torch.float64, device=dev)
+        self.best_latent = torch.zeros(1, k, D, dtype=torch.float32, device=dev)
+        self.best_step = torch.full([1], -1, dtype=torch.int32, device=dev)
+        self.losses = torch.full([a.step], float("nan"), dtype=torch.float64, device=dev)
+        self.latent_n = torch.empty(1, k, D, dtype=torch.float32, device=dev)
+        self.p_loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.mse_loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.w_loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.scratch = torch.empty(int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=dev)
+        if self.percept is not None:
+            self.percept.set_target(self.target)
+        self.use_graph = use_graph
+        self.graph = None
+
+    # ------------------------------------------------------------------ one iteration
+    def _iteration(self):
+        L, st, a = _lib.lib(), _lib.stream_ptr(), self.args
+        _lib.check(L.mgf_latent_perturb(self.latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(),
+                                        self.sigma.data_ptr(), self.step_ctr.data_ptr(), self.numel, st), "latent_perturb")
+        img = self.G(self.latent_n, a.truncation_psi, noise_mode=self.noise_mode)[0]      # psi lands in `c`
+        if self.percept is not None:
+            self.percept.distance_into(self.p_loss, img)
+        if self.use_mse:
+            _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), img.numel(), 1.0, 0,
+                                     self.scratch.data_ptr(), st), "mse")
+        if self.use_wing:
+            _lib.check(L.mgf_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(),
+                                           self.lm_target.numel(), 10.0, 2.0, self.step_ctr.data_ptr(), st), "wing_loss")
+        _lib.check(L.mgf_select_best(self.min_loss.data_ptr(), self.best_latent.data_ptr(), self.best_step.data_ptr(),
+                                     self.losses.data_ptr(), self.latent_n.data_ptr(), self.numel,
+                                     _lib.ptr(self.p_loss if self.percept is not None else None),
+                                     _lib.ptr(self.w_loss if self.use_wing else None),
+                                     _lib.ptr(self.mse_loss if self.use_mse else None), float(a.lamda), float(a.beta),
+                                     self.step_ctr.data_ptr(), _lib.ptr(self.valid), st), "select_best")
+        return img
+
+    def _capture(self):
+        # warm-up on a side stream (allocations, lazy init) before capture, then restore the loop state
+        state = [t.clone() for t in (self.step_ctr, self.min_loss, self.best_latent, self.best_step, self.losses)]
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self._iteration()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._iteration()
+        for dst, src in zip((self.step_ctr, self.min_loss, self.best_latent, self.best_step, self.losses), state):
+            dst.copy_(src)
+        self.graph = g
+
+    def run(self, steps=None):
+        """Advance the loop by `steps` iterations (default: all remaining)."""
+        done = int(self.step_ctr.item()) if steps is None else None
+        n = (self.steps - done) if steps is None else steps
+        if self.use_graph and self.graph is None:
+            self._capture()
+        for _ in range(n):
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._iteration()
+        return self
+
+    def result(self):
+        """(best_latent [1,k,D] cpu, best_step int, best_loss float, losses [steps] float64 numpy).  Raises like the
+        reference (`latent_path[-1]` on an empty list, :208) when no step ever improved on min_loss_init."""
+        torch.cuda.synchronize(self.device)
+        bs = int(self.best_step.item())
+        if bs < 0:
+            raise IndexError("projection: no iteration improved on the initial min_loss (reference: latent_path[-1] on an empty list)")
+        return self.best_latent.cpu().clone(), bs, float(self.min_loss.item()), self.losses.cpu().numpy()
+
+
+def save_best_png(G, latent, path, ratio=1.0, noise_mode="const"):
+    """Write the image of `latent` as the drivers do (misc.to_pil + crop_max_rectangle, misc.py:94-130; :194-195)."""
+    from PIL import Image
+    img = G(latent.to(G.device), None, noise_mode=noise_mode)[0]
+    c, h, w = img.shape[1:]
+    out = torch.empty([h, w, c], dtype=torch.uint8, device=G.device)
+    _lib.check(_lib.lib().mgf_to_uint8_hwc(out.data_ptr(), img.data_ptr(), c, h, w, _lib.stream_ptr()), "to_uint8")
+    im = Image.fromarray(out.cpu().numpy(), "RGB")
+    if ratio is not None:
+        s = min(im.size[0], im.size[1] / ratio)
+        cw, ch = s, ratio * s
+        im = im.crop((int((w - cw) // 2), int((h - ch) // 2), int((w + cw) // 2), int((h + ch) // 2)))
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    im.save(path)
+    return path
+
+
+def synthetic_landmarks(steps, res, seed):
+    """Injected stand-in for the dlib detector: fixed [68,2] grid in the central half + seeded jitter."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    target = rng.integers(res // 4, 3 * res // 4, size=(68, 2)).astype(np.float64)
+    per_step = target[None] + rng.integers(-max(res // 64, 1), max(res // 64, 1) + 1, size=(steps, 68, 2)).astype(np.float64)
+    return target, per_step
+
+
+def smoke_projection():
+    """Tiny literal-mode run on cuda:0 checked against the CPU oracle (used by __graft_entry__.smoke())."""
+    from oracle.generator_ref import generator_ref, to_torch_state
+    from oracle.loss_ref import mse_ref, projection_literal_ref, wing_loss_ref
+    from .engine import Generator
+    from .synth_weights import TINY, make_state_dict, synthetic_latents
+    sd = make_state_dict(TINY, seed=0)
+    tsd = to_torch_state(sd)
+    G = Generator(sd, TINY, "cuda:0", max_batch=1)
+    steps = 8
+    rng = np.random.Generator(np.random.PCG64(3))
+    latent_mean = torch.from_numpy(rng.standard_normal((TINY.k, TINY.z_dim)).astype(np.float32) * 0.1)
+    eps = torch.from_numpy(rng.standard_normal((steps, 1, TINY.k, TINY.z_dim)).astype(np.float32))
+    target = generator_ref(tsd, torch.from_numpy(synthetic_latents(TINY, 1, 1001)), TINY, "const").clamp(-1, 1)
+    lm_t, lm_s = synthetic_landmarks(steps, 64, 9)
+    args = ProjectionArgs(step=steps)
+    eng = ProjectionEngine(G, target.cuda(), latent_mean.cuda(), 23.3, args, percept=None, lm_target=lm_t, lm_steps=lm_s,
+                           eps=eps.cuda(), noise_mode="const", use_graph=True)
+    lat, bstep, bloss, losses = eng.run().result()
+    ref = projection_literal_ref(
+        lambda z: generator_ref(tsd, z, TINY, "const"),
+        lambda i, img: float(0.01 * wing_loss_ref(torch.from_numpy(lm_s[i]), torch.from_numpy(lm_t)) + mse_ref(img, target)),
+        latent_mean, 23.3, eps, steps)
+    assert bstep == ref[1], (bstep, ref[1])
+    assert torch.equal(lat, ref[0]), "best latent must be bit-exact under injected noise"
+    assert abs(bloss - ref[2]) < 1e-3 * abs(ref[2])
+    print(f"[smoke] literal projection (8 steps, graph replay): best step {bstep}, loss {bloss:.6f} (oracle {ref[2]:.6f})")

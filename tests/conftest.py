@@ -11,6 +11,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU test that takes tens of seconds (full 1024^2 oracle forward)")
 
 
 def _has_gpu():
@@ -37,3 +38,7 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name))
     return load
+
+
+def pytest_addoption(parser):
+    parser.addoption("--runslow", action="store_true", default=False, help="also run tests marked slow")

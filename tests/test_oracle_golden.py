@@ -1,0 +1,173 @@
+"""CPU: the oracle (oracle/*.py) is pinned against outputs of the REFERENCE itself (tests/golden/*.npz, produced by
+oracle/make_golden.py from /root/reference in the build container) and against the reference's own known answers
+(SURVEY.md section 8c).  Everything here is float32 torch-CPU; the restatement reproduces the reference bit for bit on
+this container's torch build, so the tolerances below are only slack for other BLAS/oneDNN builds."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from morphganformer_amd.synth_weights import FULL1024, TINY, make_state_dict
+from oracle import loss_ref
+from oracle.generator_ref import generator_ref, mapping_ref, to_torch_state
+from oracle.ops_ref import (ACT_NAMES, bias_act_grad_ref, bias_act_ref, conv2d_resample_ref, modulated_conv2d_ref,
+                            setup_filter_ref, upfirdn2d_ref)
+
+TOL = 2e-6
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("clamp", [None, 0.5])
+def test_bias_act_ref_vs_reference(golden, clamp):
+    g = golden("ops_bias_act.npz")
+    x, b, dy, ddx = (torch.from_numpy(g[k]) for k in ("x", "b", "dy", "ddx"))
+    for act in ACT_NAMES:
+        tag = f"{act}_c{'none' if clamp is None else clamp}"
+        y = bias_act_ref(x, b, dim=1, act=act, clamp=clamp)
+        assert rel(y, g[f"y_{tag}"]) < TOL, act
+        dx = bias_act_grad_ref(dy, x, b, y, dim=1, act=act, clamp=clamp, order=1)
+        assert rel(dx, g[f"dx_{tag}"]) < 5e-6, act
+        d2 = bias_act_grad_ref(dy, x, b, y, dim=1, act=act, clamp=clamp, order=2, ddx=ddx)
+        if np.abs(g[f"d2_{tag}"]).max() > 0:
+            assert rel(d2, g[f"d2_{tag}"]) < 2e-5, act
+        else:
+            assert float(d2.abs().max()) == 0.0
+    assert rel(bias_act_ref(torch.from_numpy(g["x2"]), torch.from_numpy(g["b2"]), dim=0, act="lrelu", alpha=0.3, gain=1.7), g["y2"]) < TOL
+
+
+def test_upfirdn2d_ref_vs_reference(golden):
+    from oracle.make_golden import UPFIRDN_CASES
+    g = golden("ops_upfirdn2d.npz")
+    for name, shape, taps, up, down, pad, gain, flip in UPFIRDN_CASES:
+        if taps is not None:
+            assert torch.equal(setup_filter_ref(taps), torch.from_numpy(g[f"f_{name}"])), name
+        y = upfirdn2d_ref(torch.from_numpy(g[f"x_{name}"]), torch.from_numpy(g[f"f_{name}"]), up=up, down=down, padding=pad,
+                          flip_filter=flip, gain=gain)
+        assert tuple(y.shape) == g[f"y_{name}"].shape and rel(y, g[f"y_{name}"]) < TOL, name
+
+
+def test_modconv_ref_vs_reference(golden):
+    g = golden("ops_modconv.npz")
+    x, w, s, f = (torch.from_numpy(g[k]) for k in ("x", "w", "s", "f"))
+    for up in (1, 2):
+        for demod in (True, False):
+            y = modulated_conv2d_ref(x, w, s, up=up, padding=1, resample_kernel=f, demodulate=demod, flip_weight=(up == 1))
+            assert rel(y, g[f"y_up{up}_demod{int(demod)}"]) < TOL
+    y = conv2d_resample_ref(x, torch.from_numpy(g["w1"]), f=f, up=2, padding=0, flip_weight=False)
+    assert rel(y, g["y_skip_up2"]) < TOL
+
+
+def test_generator_ref_vs_reference_tiny(golden):
+    g = golden("gen_tiny.npz")
+    sd = to_torch_state(make_state_dict(TINY, 0))
+    z = torch.from_numpy(g["z"])
+    taps = {}
+    img = generator_ref(sd, z, TINY, "const", taps=taps)
+    assert rel(taps["ws"], g["ws"]) < TOL
+    for r in TINY.block_resolutions:
+        assert rel(taps[f"synthesis.b{r}"], g[f"tap_b{r}"]) < 1e-5, r
+    assert rel(img, g["img_const"]) < 1e-5
+    assert rel(generator_ref(sd, z, TINY, "none"), g["img_none"]) < 1e-5
+    noises = {k[len("noise_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("noise_")}
+    assert rel(generator_ref(sd, z, TINY, "inject", noises), g["img_inject"]) < 1e-5
+    for key in ("b4.conv1", "b16.conv0", "b64.conv1"):
+        p = taps[f"synthesis.{key}:probs"].numpy()
+        assert rel(p, g["probs_" + key]) < 1e-5
+        assert np.array_equal(p.argmax(-1), g["probs_" + key].argmax(-1))
+    # gradient-mode oracle: d mean(img^2) / dz through the restatement == through the reference module
+    zg = z.clone().requires_grad_(True)
+    loss = generator_ref(sd, zg, TINY, "const").square().mean()
+    (gz,) = torch.autograd.grad(loss, zg)
+    assert abs(float(loss.detach()) - float(g["loss_sq"])) < 1e-5 * float(g["loss_sq"])
+    assert rel(gz, g["grad_z"]) < 1e-4
+
+
+def test_mapping_ref_properties():
+    sd = to_torch_state(make_state_dict(TINY, 0))
+    torch.manual_seed(0)
+    z = torch.randn(3, TINY.k, TINY.z_dim)
+    w = mapping_ref(sd, z, TINY)
+    assert tuple(w.shape) == (3, TINY.k, TINY.w_dim)
+    # samples are independent: evaluating one alone gives the same row
+    assert torch.allclose(mapping_ref(sd, z[1:2], TINY), w[1:2], atol=1e-6)
+    # the joint normalisation makes the local path invariant to a positive rescale of the local components
+    z2 = z.clone(); z2[:, :-1] *= 3.0
+    assert torch.allclose(mapping_ref(sd, z2, TINY)[:, :-1], w[:, :-1], atol=1e-5)
+
+
+def test_loss_kats(golden):
+    g = golden("loss_kats.npz")
+    assert abs(float(loss_ref.wing_loss_ref(torch.zeros(2, 68, 64, 64), torch.ones(2, 68, 64, 64))) - float(g["wing_ones_zeros"])) < 1e-6
+    assert abs(float(g["wing_ones_zeros"]) - 4.054649829864502) < 1e-6            # SURVEY.md 8c [probe]
+    v = loss_ref.wing_loss_ref(torch.from_numpy(g["wing_small_pred"]), torch.from_numpy(g["wing_small_target"]))
+    assert abs(float(v) - float(g["wing_small"])) < 1e-12 and abs(float(v) - 12.972460116410685) < 1e-9
+    v = loss_ref.wing_loss_ref(torch.from_numpy(g["wing_rand_pred"]), torch.from_numpy(g["wing_rand_target"]))
+    assert abs(float(v) - float(g["wing_rand"])) < 1e-10
+    v = loss_ref.adaptive_wing_loss_ref(torch.zeros(68, 2), torch.ones(68, 2))
+    assert abs(float(v) - float(g["awing_ones_zeros"])) < 1e-5 and abs(float(v) - 10.259384155273438) < 1e-4
+
+
+def test_schedule_kats():
+    lr = [loss_ref.get_lr_ref(t, 0.01) for t in (0, .025, .05, .5, .875, .999)]
+    for got, want in zip(lr, (0, .005, .01, .01, .005, 3.9e-07)):
+        assert abs(got - want) < 1e-4 * max(want, 1e-3) + 2e-8
+    ns = [loss_ref.noise_strength_ref(t, 1.0, 1.0, 0.75) for t in (0, .25, .5, .75)]
+    assert np.allclose(ns, (1, 4 / 9, 1 / 9, 0))
+    torch.manual_seed(0)
+    mean, std = loss_ref.latent_stats_ref(torch.randn(10000, 17, 32))
+    assert abs(float(std) - 23.316194534) < 2e-4                                  # SURVEY.md 8c [probe], seed 0 CPU
+    img = np.array([[-1.0, 1.0, 0.0, 0.0039, 2.0, -3.0]], np.float32)          # 2-D (HW) path of to_pil
+    assert loss_ref.to_uint8_ref(img)[0].tolist() == [0, 255, 128, 128, 255, 0]    # rint half-to-even at 127.5
+
+
+def test_projection_literal_ref_vs_reference_run(golden):
+    g = golden("loop_tiny.npz")
+    sd = to_torch_state(make_state_dict(TINY, 0))
+    target = torch.from_numpy(g["target"])
+    lm_t, lm_s = g["lm_target"], g["lm_steps"]
+    steps = int(g["eps"].shape[0])
+
+    def loss_fn(i, img):
+        return float(0.01 * loss_ref.wing_loss_ref(torch.from_numpy(lm_s[i]), torch.from_numpy(lm_t)) + loss_ref.mse_ref(img, target))
+
+    best, bstep, bloss, losses = loss_ref.projection_literal_ref(
+        lambda z: generator_ref(sd, z, TINY, "const"), loss_fn, torch.from_numpy(g["latent_mean"]), float(g["latent_std"]),
+        torch.from_numpy(g["eps"]), steps)
+    assert bstep == int(g["best_step"])
+    assert np.array_equal(best.numpy(), g["best_latent"])
+    assert np.allclose(losses, g["losses"], rtol=1e-5)        # float32 MSE reduction order (nn.MSELoss vs square().mean())
+
+
+def test_lpips_ref_properties():
+    bb = loss_ref.squeeze_backbone_random(0)
+    lin = np.load("morphganformer_amd/weights/lpips_lin_squeeze.npz")
+    lins = [torch.from_numpy(lin[f"lin{i}"]) for i in range(7)]
+    assert all(float(l.min()) >= 0 for l in lins) and [l.numel() for l in lins] == loss_ref.SQUEEZE_CHNS
+    torch.manual_seed(1)
+    a = torch.rand(1, 3, 67, 67) * 2 - 1
+    b = torch.rand(1, 3, 67, 67) * 2 - 1
+    taps = loss_ref.squeeze_features_ref(bb, a)
+    assert [t.shape[1] for t in taps] == loss_ref.SQUEEZE_CHNS
+    assert [t.shape[2] for t in taps] == [33, 16, 8, 4, 4, 4, 4]                   # stride-2 conv then three ceil-mode pools
+    d_ab, d_ba, d_aa = (float(loss_ref.lpips_ref(bb, lins, x, y)) for x, y in ((a, b), (b, a), (a, a)))
+    assert d_aa == 0.0 and d_ab > 0 and abs(d_ab - d_ba) < 1e-6 * d_ab             # identity and symmetry
+
+
+@pytest.mark.slow
+def test_generator_ref_full_vs_reference(golden):
+    """Full 1024^2 forward of the restatement (about 1.5 s on 8 cores, 1 GB peak) vs reference samples/checksums."""
+    g = golden("gen_full1024.npz")
+    sd = to_torch_state(make_state_dict(FULL1024, 0))
+    taps = {}
+    with torch.no_grad():
+        img = generator_ref(sd, torch.from_numpy(g["z"]), FULL1024, "const", taps=taps)
+    assert rel(img.reshape(-1)[torch.from_numpy(g["idx"])], g["pixels"]) < 1e-5
+    assert abs(float(img.double().mean()) - float(g["img_mean"])) < 1e-6
+    for res, m, r in zip(g["block_res"], g["block_mean"], g["block_rms"]):
+        t = taps[f"synthesis.b{int(res)}"].double()
+        assert abs(float(t.mean()) - m) < 1e-5 * r and abs(float(t.square().mean().sqrt()) - r) < 1e-5 * r
