@@ -27,6 +27,19 @@ import numpy as np
 import torch
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line on stdout stays alone)."""
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
 def parse():
@@ -96,8 +109,9 @@ def cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, iters):
     """The oracle's port of one iteration (what the reference computes per step, both LPIPS branches recomputed)."""
     from oracle.generator_ref import generator_ref, to_torch_state
     from oracle.loss_ref import lpips_ref, mse_ref, squeeze_backbone_random, wing_loss_ref
-    cores = os.cpu_count() or 1
+    cores = min(host_cores(), 64)
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads")
     tsd = to_torch_state(sd)
     bb = squeeze_backbone_random(0)
     lin = np.load(os.path.join(ROOT, "morphganformer_amd", "weights", "lpips_lin_squeeze.npz"))
@@ -118,6 +132,7 @@ def cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, iters):
             total = float(lpips_ref(bb, lins, img, tgt).sum()) + 0.01 * float(wing_loss_ref(torch.from_numpy(lm_s[i]), torch.from_numpy(lm_t))) \
                 + float(mse_ref(img, tgt))
             times.append(time.perf_counter() - t0)
+            log(f"cpu_baseline iteration {i}: {times[-1]:.2f} s (loss {total:.4f})")
     per = float(np.mean(times[1:]))
     return {"value": round(1.0 / per, 4), "unit": "iters/s", "cores": cores, "kind": "port",
             "sample": f"{iters} timed iterations (+1 warm-up) of the same 1024^2 Wing+LPIPS(squeeze)+MSE step, torch-CPU fp32 oracle, "
@@ -143,8 +158,10 @@ def main():
     cfg = GeneratorConfig(img_resolution=a.res)
     sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, a.steps + a.warmup, not a.no_graph)
 
+    log(f"built generator/LPIPS/engine on {device}; warm-up {a.warmup} steps (includes graph capture)")
     eng.run(a.warmup)
     torch.cuda.synchronize()
+    log("warm-up done; timing")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -155,6 +172,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    log(f"timed {a.steps} steps in {elapsed:.3f} s")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -178,6 +196,7 @@ def main():
     }
     if rank == 0:
         out["roofline"] = roofline_leg(eng)
+        log(f"roofline leg done: {out['roofline']['kernel']} {out['roofline']['achieved']} TFLOP/s")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, a.cpu_iters)
         print(json.dumps(out), flush=True)

@@ -108,11 +108,16 @@ __global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, 
 
 __global__ __launch_bounds__(256) void perturb_kernel(float* latent_n, const float* latent_in, const float* eps, const float* sigma,
                                                       const int32_t* step, int64_t numel) {
+#pragma clang fp contract(off)      // eps*sigma then +latent with two roundings, like torch: keeps the latents bit-exact
     const int s = *step;
     const float sg = sigma[s];
     const float* e = eps + (int64_t)s * numel;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256)
-        latent_n[i] = __fadd_rn(latent_in[i], __fmul_rn(e[i], sg));   // two roundings like torch (no fma): bit-exact latents
+    {
+        float prod = e[i] * sg;
+        asm volatile("" : "+v"(prod));                 // opaque to the fma combiner: two roundings like torch -> bit-exact latents
+        latent_n[i] = latent_in[i] + prod;
+    }
 }
 
 __global__ __launch_bounds__(256) void select_kernel(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out,
