@@ -105,6 +105,8 @@ typedef struct mgf_conv_desc {
     int64_t y_pitch, y_plane, y_batch;   /* element strides of y */
     int32_t y_choff;                     /* channel offset into y */
     int32_t out_scale_stride;            /* elements between samples in out_scale (0 = shared) */
+    float* workspace;                    /* optional split-K scratch (device); NULL = never split the K dimension */
+    int64_t workspace_floats;            /* capacity of workspace in floats */
 } mgf_conv_desc;
 
 int mgf_conv_taps_f32(float* y, const float* x, const float* wp, const float* in_scale, const float* out_scale,

@@ -22,15 +22,26 @@ def round_up(v: int, m: int) -> int:
 PROFILE = None
 
 
-def _variant(mode, cout, cout_pad, tile_h, tile_w):
-    """Mirror of the kernel selection in csrc/conv_taps.hip (mgf_conv_taps_f32)."""
+def _variant(mode, cout, cout_pad, tile_h, tile_w, ntaps=9, istride=1, span=2):
+    """Mirror of the kernel selection in csrc/conv_taps.hip (mgf_conv_taps_f32 / launch_conv): the demangled kernel name
+    rocprofv3 reports, so bench.py's per-kernel timings can be compared with the committed profile summaries."""
     if mode == 1:
-        return "conv_taps_kernel<1,2,1>"
-    if cout_pad % 64 == 0 and cout > 32:
-        return "conv_taps_kernel<2,2,0>"
-    if tile_h * tile_w >= 512 * 64:
-        return "conv_taps_kernel<1,4,0>"
-    return "conv_taps_kernel<1,2,0>"
+        wm, wn = 1, 2
+    elif cout_pad % 64 == 0 and cout > 32:
+        wm, wn = 2, 2
+    elif tile_h * tile_w >= 512 * 64:
+        wm, wn = 1, 4
+    else:
+        wm, wn = 1, 2
+    tw = 32
+    while tw > 4 and tw // 2 >= tile_w:
+        tw //= 2
+    rows = 128 * wn // tw
+    fh, fw = (rows - 1) * istride + span + 1, (tw - 1) * istride + span + 1
+    xs, ws4 = 8 * fh * fw, ntaps * 8 * 32 * wm // 4
+    buf = 4 * (xs + ntaps * 8 * 32 * wm)
+    pipe = xs <= (20 if wn == 4 else 11) * 256 and ws4 <= (5 if wm == 2 else 3) * 256 and 2 * buf <= 64 * 1024
+    return f"conv_taps_kernel<{wm}, {wn}, {mode}, {'true' if pipe else 'false'}>"
 
 
 class _Timed:
@@ -90,7 +101,22 @@ def _desc(n, cin, in_h, in_w, cout, cout_pad, tile_h, tile_w, istride, ostride, 
         d.ox[i] = ox[i] if i < len(ox) else 0
     d.out_h, d.out_w, d.y_pitch, d.y_plane, d.y_batch = out_h, out_w, y_pitch, y_plane, y_batch
     d.y_choff, d.out_scale_stride = y_choff, out_scale_stride
+    ws = _workspace(torch.cuda.current_device())
+    d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
     return d
+
+
+# Split-K scratch shared by every conv launch of a device (launches are stream-ordered, so one buffer is enough).
+WORKSPACE_FLOATS = 16 << 20
+_WS = {}
+
+
+def _workspace(dev_index):
+    ws = _WS.get(dev_index)
+    if ws is None:
+        ws = torch.empty(WORKSPACE_FLOATS, dtype=torch.float32, device=torch.device("cuda", dev_index))
+        _WS[dev_index] = ws
+    return ws
 
 
 def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_scale=None, epilogue=None, out=None,
@@ -111,7 +137,8 @@ def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_sca
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, oh, ow, stride, 1, taps, None, [0], [0], oh, ow,
               ow, oh * ow, out.shape[1] * oh * ow, out_choff,
               0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
-    with _Timed(_variant(0, pc.cout, pc.cout_pad, oh, ow), 2.0 * n * pc.kh * pc.kw * cin * pc.cout * oh * ow):
+    with _Timed(_variant(0, pc.cout, pc.cout_pad, oh, ow, pc.kh * pc.kw, stride, pc.kh - 1),
+                2.0 * n * pc.kh * pc.kw * cin * pc.cout * oh * ow):
         rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                           C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
     _lib.check(rc, "conv_taps")
@@ -141,7 +168,7 @@ def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=Non
               oh, ow, pitch, oh * pitch, pc.cout * oh * pitch, 0,
               0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
     # algorithmic FLOPs of a stride-2 transposed conv: 9 taps per INPUT pixel
-    with _Timed(_variant(1, pc.cout, pc.cout_pad, h + 1, w + 1), 2.0 * n * 9 * cin * pc.cout * h * w):
+    with _Timed(_variant(1, pc.cout, pc.cout_pad, h + 1, w + 1, 9, 1, 1), 2.0 * n * 9 * cin * pc.cout * h * w):
         rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                           C.byref(d), None, _lib.stream_ptr())
     _lib.check(rc, "conv_taps(tconv)")

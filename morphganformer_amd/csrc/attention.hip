@@ -7,15 +7,18 @@
 //   P      = softmax_t(S)
 //   y[c,f] = epilogue( x[c,f] * rsqrt(mean_c x^2 + 1e-8) * sum_t P[f,t] * vwb[c,t] )   (vwb = V Wm^T + bm + 1 per sample)
 //
-// HBM/L2-bound streaming kernel.  A workgroup owns 64 consecutive pixels (one 256-byte row segment per channel); wave w
-// accumulates the 16 scores and the second moment over channels w, w+4, ...: one coalesced 256-B load + 17 FMAs per
-// channel with the 16 wqc scalars of that channel fetched by scalar loads (wave-uniform).  Partials meet in LDS, every lane
-// finishes the softmax of its own pixel in registers, then the waves sweep their channels again (L2-resident re-read).
+// HBM/L2-bound streaming kernel.  A workgroup (4 waves) owns PXB consecutive pixels and splits the channels over
+// G = 256 / PXB lane groups: PXB = 64 for feature maps >= 32x32 (one 256-byte row segment per channel and wave), PXB = 16
+// below that so that the 4x4 .. 16x16 layers still spread over several workgroups.  The [C,16] tables (wqc, then vwb) are
+// staged in LDS once per workgroup and read back as wave-uniform 16-byte broadcasts; the channel loop is unrolled 4-deep so
+// four independent row loads are in flight per lane.  Score partials meet in LDS, every lane finishes the softmax of its
+// own pixel in registers, then the groups sweep their channels again (L2-resident re-read) and apply the epilogue.
 #include "mgf_common.h"
 
 namespace {
 
 constexpr int TMAX = 16;
+constexpr int UNR = 4;
 
 struct AttnParams {
     float* y;
@@ -24,50 +27,80 @@ struct AttnParams {
     const float* spos;    // [f, t]
     const float* vwb;     // [n, c, t]
     int n, c, f, t;
+    int c_pad;            // c rounded up to a multiple of UNR * G (table rows beyond c are zero)
     mgf_epilogue ep;
     int has_ep;
-    int ep_w;             // image width (noise is indexed [n, f] flat, so only f matters)
     float* probs;         // [n, f, t] or null
     int32_t* argmax;      // [n, f] or null
 };
 
+template <int PXB>
 __global__ __launch_bounds__(256) void duplex_attention_kernel(AttnParams p) {
-    __shared__ float part[4][TMAX + 1][64];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int G = 256 / PXB;                 // channel groups per workgroup
+    extern __shared__ float lds[];
+    float* tab = lds;                             // [c_pad][TMAX]
+    float* part = lds + (size_t)p.c_pad * TMAX;   // [G][TMAX + 1][PXB]
+    const int tid = threadIdx.x;
+    const int px = tid % PXB, grp = tid / PXB;
     const int n = blockIdx.y;
-    const int f0 = blockIdx.x * 64;
-    const int f = f0 + lane;
+    const int f0 = blockIdx.x * PXB;
+    const int f = f0 + px;
     const bool valid = f < p.f;
     const int fc = valid ? f : p.f - 1;
     const float* xn = p.x + (int64_t)n * p.c * p.f;
     const int T = p.t;
 
+    // ---- stage wqc, zero-padded to [c_pad][16] ----
+    for (int i = tid; i < p.c_pad * TMAX; i += 256) {
+        const int c = i / TMAX, t = i % TMAX;
+        tab[i] = (c < p.c && t < T) ? p.wqc[(int64_t)c * T + t] : 0.f;
+    }
+    __syncthreads();
+
     float s[TMAX];
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
     float sq = 0.f;
-    for (int c = wave; c < p.c; c += 4) {
-        const float xv = xn[(int64_t)c * p.f + fc];
-        const float* wr = p.wqc + (int64_t)c * T;       // wave-uniform address -> scalar loads
-        sq += xv * xv;
+    for (int c0 = grp * UNR; c0 < p.c; c0 += G * UNR) {
+        float xv[UNR];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t)
-            if (t < T) s[t] += xv * wr[t];
+        for (int u = 0; u < UNR; ++u) xv[u] = (c0 + u < p.c) ? xn[(int64_t)(c0 + u) * p.f + fc] : 0.f;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const float4* w4 = reinterpret_cast<const float4*>(tab + (c0 + u) * TMAX);
+            sq += xv[u] * xv[u];
+#pragma unroll
+            for (int q = 0; q < TMAX / 4; ++q) {
+                const float4 w = w4[q];
+                s[4 * q + 0] += xv[u] * w.x; s[4 * q + 1] += xv[u] * w.y;
+                s[4 * q + 2] += xv[u] * w.z; s[4 * q + 3] += xv[u] * w.w;
+            }
+        }
     }
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) part[wave][t][lane] = s[t];
-    part[wave][TMAX][lane] = sq;
+    for (int t = 0; t < TMAX; ++t) part[(grp * (TMAX + 1) + t) * PXB + px] = s[t];
+    part[(grp * (TMAX + 1) + TMAX) * PXB + px] = sq;
     __syncthreads();
+
+    // ---- every lane finishes the softmax of its pixel; meanwhile the table is re-staged with this sample's vwb ----
     float m = -3.0e38f;
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
+        float v = 0.f;
+        for (int g = 0; g < G; ++g) v += part[(g * (TMAX + 1) + t) * PXB + px];
         if (t < T) {
-            s[t] = part[0][t][lane] + part[1][t][lane] + part[2][t][lane] + part[3][t][lane] + p.spos[(int64_t)fc * T + t];
-            m = fmaxf(m, s[t]);
+            v += p.spos[(int64_t)fc * T + t];
+            m = fmaxf(m, v);
         }
+        s[t] = v;
     }
-    sq = part[0][TMAX][lane] + part[1][TMAX][lane] + part[2][TMAX][lane] + part[3][TMAX][lane];
+    sq = 0.f;
+    for (int g = 0; g < G; ++g) sq += part[(g * (TMAX + 1) + TMAX) * PXB + px];
+    const float* vn = p.vwb + (int64_t)n * p.c * T;
+    for (int i = tid; i < p.c_pad * TMAX; i += 256) {
+        const int c = i / TMAX, t = i % TMAX;
+        tab[i] = (c < p.c && t < T) ? vn[(int64_t)c * T + t] : 0.f;
+    }
     float den = 0.f;
     int best = 0;
     float bestv = -3.0e38f;
@@ -77,20 +110,22 @@ __global__ __launch_bounds__(256) void duplex_attention_kernel(AttnParams p) {
             if (s[t] > bestv) { bestv = s[t]; best = t; }
             s[t] = __expf(s[t] - m);
             den += s[t];
+        } else {
+            s[t] = 0.f;
         }
     }
     const float inv = 1.f / den;
     const float rs = rsqrtf(sq / (float)p.c + 1e-8f);
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) s[t] = t < T ? s[t] * inv : 0.f;
-    if (wave == 0 && valid) {
+    for (int t = 0; t < TMAX; ++t) s[t] *= inv;
+    if (grp == 0 && valid) {
         if (p.probs)
             for (int t = 0; t < T; ++t) p.probs[((int64_t)n * p.f + f) * T + t] = s[t];
         if (p.argmax) p.argmax[(int64_t)n * p.f + f] = best;
     }
-    // fold the norm into the probabilities once
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) s[t] *= rs;
+    for (int t = 0; t < TMAX; ++t) s[t] *= rs;            // fold the layer norm into the probabilities once
+    __syncthreads();
 
     float nz = 0.f;
     if (p.has_ep && p.ep.noise) {
@@ -98,25 +133,36 @@ __global__ __launch_bounds__(256) void duplex_attention_kernel(AttnParams p) {
         nz = p.ep.noise[(int64_t)(p.ep.noise_n > 1 ? n : 0) * p.f + fc] * ns;
     }
     float* yn = p.y + (int64_t)n * p.c * p.f;
-    const float* vn = p.vwb + (int64_t)n * p.c * T;
     const float* rn = (p.has_ep && p.ep.residual) ? p.ep.residual + (int64_t)n * p.c * p.f : nullptr;
-    for (int c = wave; c < p.c; c += 4) {
-        const float xv = xn[(int64_t)c * p.f + fc];
-        const float* vr = vn + (int64_t)c * T;
-        float g = 0.f;
+    for (int c0 = grp * UNR; c0 < p.c; c0 += G * UNR) {
+        float xv[UNR], rv[UNR];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t)
-            if (t < T) g += s[t] * vr[t];
-        float v = xv * g;
-        if (p.has_ep) {
-            v += nz;
-            if (p.ep.bias) v += p.ep.bias[c];
-            if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
-            else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
-            v *= p.ep.gain;
-            if (rn) v += rn[(int64_t)c * p.f + fc];
+        for (int u = 0; u < UNR; ++u) {
+            const bool ok = c0 + u < p.c;
+            xv[u] = ok ? xn[(int64_t)(c0 + u) * p.f + fc] : 0.f;
+            rv[u] = (ok && rn) ? rn[(int64_t)(c0 + u) * p.f + fc] : 0.f;
         }
-        if (valid) yn[(int64_t)c * p.f + f] = v;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int c = c0 + u;
+            const float4* w4 = reinterpret_cast<const float4*>(tab + c * TMAX);
+            float g = 0.f;
+#pragma unroll
+            for (int q = 0; q < TMAX / 4; ++q) {
+                const float4 w = w4[q];
+                g += s[4 * q + 0] * w.x + s[4 * q + 1] * w.y + s[4 * q + 2] * w.z + s[4 * q + 3] * w.w;
+            }
+            float v = xv[u] * g;
+            if (p.has_ep) {
+                v += nz;
+                if (p.ep.bias && c < p.c) v += p.ep.bias[c];
+                if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
+                else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+                v *= p.ep.gain;
+                v += rv[u];
+            }
+            if (valid && c < p.c) yn[(int64_t)c * p.f + f] = v;
+        }
     }
 }
 
@@ -125,6 +171,7 @@ __global__ __launch_bounds__(256) void duplex_attention_kernel(AttnParams p) {
 extern "C" int mgf_duplex_attention(float* y, const float* x, const float* wqc, const float* spos, const float* vwb, int32_t n,
                                     int32_t c, int32_t f, int32_t t, const mgf_epilogue* ep, int32_t ep_w, float* probs,
                                     int32_t* argmax, mgf_stream_t stream) {
+    (void)ep_w;
     MGF_REQUIRE(y && x && wqc && spos && vwb, MGF_EINVAL, "duplex_attention: null pointer");
     MGF_REQUIRE(n >= 1 && c >= 1 && f >= 1, MGF_EINVAL, "duplex_attention: bad shape");
     MGF_REQUIRE(t >= 1 && t <= TMAX, MGF_EUNSUPPORTED, "duplex_attention: supports 1..%d latent components (got %d)", TMAX, t);
@@ -133,9 +180,16 @@ extern "C" int mgf_duplex_attention(float* y, const float* x, const float* wqc, 
                         MGF_EUNSUPPORTED, "duplex_attention: epilogue activation %d unsupported", ep->act);
     AttnParams p;
     p.y = y; p.x = x; p.wqc = wqc; p.spos = spos; p.vwb = vwb; p.n = n; p.c = c; p.f = f; p.t = t;
-    p.has_ep = ep != nullptr; p.ep_w = ep_w; p.probs = probs; p.argmax = argmax;
+    p.has_ep = ep != nullptr; p.probs = probs; p.argmax = argmax;
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
-    hipLaunchKernelGGL(duplex_attention_kernel, dim3((unsigned)mgf_cdiv(f, 64), n), dim3(256), 0, (hipStream_t)stream, p);
+    const int pxb = f >= 1024 ? 64 : 16;
+    const int g = 256 / pxb;
+    p.c_pad = (int)(mgf_cdiv(c, UNR * g) * UNR * g);
+    const size_t lds = ((size_t)p.c_pad * TMAX + (size_t)g * (TMAX + 1) * pxb) * sizeof(float);
+    MGF_REQUIRE(lds <= 64 * 1024, MGF_EUNSUPPORTED, "duplex_attention: %d channels need %zu bytes of LDS (> 64 KiB)", c, lds);
+    hipStream_t st = (hipStream_t)stream;
+    if (pxb == 64) hipLaunchKernelGGL((duplex_attention_kernel<64>), dim3((unsigned)mgf_cdiv(f, 64), n), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((duplex_attention_kernel<16>), dim3((unsigned)mgf_cdiv(f, 16), n), dim3(256), lds, st, p);
     MGF_CHECK_LAUNCH("duplex_attention");
     return MGF_OK;
 }

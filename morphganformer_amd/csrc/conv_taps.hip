@@ -9,10 +9,20 @@
 //   D layout  = column (pixel) on the lane, rows (channels) across 16 registers -> every store instruction writes
 //               two 128-byte row segments of the NCHW output.
 // Workgroup = 4 waves.  A workgroup owns CO_T = 32*WM output channels x PX = 128*WN pixels ((PX/TW) rows x TW
-// columns, TW = 32 for feature maps >= 32 wide).  Per K chunk of CK input channels it stages in LDS
+// columns, TW = 32 for feature maps >= 32 wide).  The K dimension (taps x input channels) is walked in chunks of CK = 8
+// input channels; per chunk the workgroup holds in LDS
 //   Xs[CK][FH][FW]  the input footprint (halo included, zero padded, style-modulated on the way in) and
 //   Ws[T][CK][CO_T] the weight slab,
-// then every wave runs T*CK/2 k-steps of WM*WN MFMAs fed by WM + WN conflict-free ds_read_b32.
+// and every wave runs T*CK/2 k-steps of WM*WN MFMAs fed by WM + WN conflict-free ds_read_b32.
+//
+// Pipeline: two LDS buffers; the global loads of chunk i+1 are issued into registers before the MFMA phase of chunk i
+// and written to the other buffer after it (one barrier per chunk, loads in flight behind the matrix pipe).  All
+// staging addresses are chunk-invariant and precomputed per lane (no integer division in the loop).
+//
+// Split-K: when a layer has too few output tiles to fill 256 CUs (4x4 .. 64x64 maps with 512 channels) the input
+// channels are split over blockIdx.z; partial tiles go to a caller-provided workspace and a second kernel sums them
+// in a fixed order (deterministic), applies demodulation + epilogue and writes the output.
+//
 // MODE 1 is the stride-2 transposed convolution: the 9 taps feed 4 output-parity accumulator sets (compile-time
 // tap -> parity map), so it runs at the transposed conv's own FLOP count and writes the parity pairs interleaved.
 #include "mgf_common.h"
@@ -21,7 +31,12 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CK = 8;   // input channels per K chunk
+constexpr int CK = 8;          // input channels per K chunk
+// per-lane register staging slots of the pipelined kernels: XS floats of the input footprint, WS float4 of the weight slab
+template <int WM, int WN> struct Slots {
+    static constexpr int XS = WN == 4 ? 20 : 11;      // 16x32 tile: 8*18*34 = 4896 floats; 8x32 tile: 8*10*34 = 2720
+    static constexpr int WS = WM == 2 ? 5 : 3;        // 9*8*64/4 = 1152 float4; 9*8*32/4 = 576
+};
 
 struct ConvParams {
     float* y;
@@ -37,13 +52,9 @@ struct ConvParams {
     int fh, fw;           // LDS footprint of a pixel tile
     int dy_min, dx_min;
     int co_tiles;
-};
-
-template <int WM, int WN, int MODE>
-struct Tile {
-    static constexpr int CO_T = 32 * WM;
-    static constexpr int PX = 128 * WN;
-    static constexpr int NG = MODE == 1 ? 4 : 1;
+    int ksplit;           // number of K slices (1 = direct)
+    int chunks_per_split;
+    float* partial;       // [ksplit][n][cout][out_h][y_pitch] when ksplit > 1
 };
 
 __device__ __forceinline__ float epi(const mgf_epilogue& ep, float v, int n, int co, int oy, int ox, int out_h, int out_w,
@@ -64,28 +75,33 @@ __device__ __forceinline__ float epi(const mgf_epilogue& ep, float v, int n, int
 // parity group of tap t (t = kh*3 + kw) for the stride-2 transposed conv: kh (kw) == 1 feeds odd rows (cols)
 __host__ __device__ constexpr int tconv_group(int t) { return ((t / 3) == 1 ? 2 : 0) + ((t % 3) == 1 ? 1 : 0); }
 
-template <int WM, int WN, int MODE>
+template <int WM, int WN, int MODE, bool PIPE>
 __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
-    typedef Tile<WM, WN, MODE> TL;
-    constexpr int CO_T = TL::CO_T, PX = TL::PX, NG = TL::NG;
+    constexpr int CO_T = 32 * WM, PX = 128 * WN, NG = MODE == 1 ? 4 : 1;
     extern __shared__ float lds[];
     const mgf_conv_desc& d = p.d;
     const int T = d.ntaps;
     const int chs = p.fh * p.fw;                 // LDS channel stride of Xs
-    float* Xs = lds;
-    float* Ws = lds + CK * chs;
+    const int xs_floats = CK * chs;
+    const int ws_floats = T * CK * CO_T;
+    const int buf_floats = xs_floats + ws_floats;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int n = blockIdx.z;
+    const int n = blockIdx.z / p.ksplit, ks = blockIdx.z - n * p.ksplit;
     const int co0 = blockIdx.y * CO_T;
     const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
     const int TW = 1 << p.tw_log2;
     const int rows = PX >> p.tw_log2;
     const int ty0 = tile_y * rows, tx0 = tile_x * TW;
-    // top-left input sample of the footprint
-    const int iy0 = ty0 * d.istride + p.dy_min, ix0 = tx0 * d.istride + p.dx_min;
+    const int iy0 = ty0 * d.istride + p.dy_min, ix0 = tx0 * d.istride + p.dx_min;   // top-left input sample of the footprint
+
+    // channel range of this K slice
+    const int c_begin = ks * p.chunks_per_split * CK;
+    int c_end = c_begin + p.chunks_per_split * CK;
+    if (c_end > d.cin) c_end = d.cin;
+    const int nchunks = (c_end - c_begin + CK - 1) / CK;
 
     // per-lane LDS base offset of each of this wave's WN pixel groups, and group validity (wave-uniform)
     int pbase[WN];
@@ -111,37 +127,88 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
 
     const float* xn = p.x + (int64_t)n * d.cin * d.in_h * d.in_w;
     const float* sc = p.in_scale ? p.in_scale + (int64_t)n * d.cin : nullptr;
-    const int fsz = CK * chs;
+    const int plane = d.in_h * d.in_w;
     const int wrow4 = CO_T / 4;                       // float4 per weight row
     const int wsz4 = T * CK * wrow4;
 
-    for (int c0 = 0; c0 < d.cin; c0 += CK) {
-        __syncthreads();                              // previous chunk fully consumed
-        // ---- stage input footprint: Xs[ch][r][q], q fastest (coalesced row segments) ----
-        for (int i = tid; i < fsz; i += 256) {
+    // ---- chunk-invariant staging slots (pipelined path; full chunks only) ----
+    // X slot j covers LDS element i = tid + 256*j -> (ch, r, q); xoff = offset inside the chunk's channel block,
+    // -1 = zero padding, -2 = no such element.  W slot j covers float4 i = tid + 256*j -> (t, ch, c4) with compile-time divisors.
+    constexpr int XS = Slots<WM, WN>::XS, WS = Slots<WM, WN>::WS;
+    int xoff[XS];
+    if (PIPE) {
+#pragma unroll
+        for (int j = 0; j < XS; ++j) {
+            const int i = tid + 256 * j;
+            xoff[j] = -2;
+            if (i < xs_floats) {
+                const int ch = i / chs;
+                const int rem = i - ch * chs;
+                const int r = rem / p.fw, q = rem - r * p.fw;
+                const int iy = iy0 + r, ix = ix0 + q;
+                xoff[j] = (iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) ? ch * plane + iy * d.in_w + ix : -1;
+            }
+        }
+    }
+    float xr[XS];
+    float4 wr[WS];
+
+    // global -> registers for the (full) chunk starting at channel c0.  The style modulation s[ci] is applied to the weight
+    // rows (exactly the reference's w * s, networks.py:289) because their channel index is a compile-time function of the slot.
+    auto load_chunk = [&](int c0) {
+        const float* xc = xn + (int64_t)c0 * plane;
+#pragma unroll
+        for (int j = 0; j < XS; ++j) xr[j] = xoff[j] >= 0 ? xc[xoff[j]] : 0.f;
+#pragma unroll
+        for (int j = 0; j < WS; ++j) {
+            const int i = tid + 256 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < wsz4) {
+                const int c4 = i % wrow4;
+                const int rest = i / wrow4;
+                const int ch = rest % CK, t = rest / CK;
+                v = *reinterpret_cast<const float4*>(p.wp + ((int64_t)t * d.cin + c0 + ch) * d.cout_pad + co0 + c4 * 4);
+                if (sc) { const float sv = sc[c0 + ch]; v.x *= sv; v.y *= sv; v.z *= sv; v.w *= sv; }
+            }
+            wr[j] = v;
+        }
+    };
+    auto store_chunk = [&](float* buf) {                 // registers -> LDS
+#pragma unroll
+        for (int j = 0; j < XS; ++j)
+            if (xoff[j] != -2) buf[tid + 256 * j] = xr[j];
+        float* Wd = buf + xs_floats;
+#pragma unroll
+        for (int j = 0; j < WS; ++j)
+            if (tid + 256 * j < wsz4) *reinterpret_cast<float4*>(Wd + (tid + 256 * j) * 4) = wr[j];
+    };
+    auto stage_direct = [&](int c0, float* buf) {        // un-pipelined fallback for footprints that exceed the slot budget
+        for (int i = tid; i < xs_floats; i += 256) {
             const int ch = i / chs;
             const int rem = i - ch * chs;
             const int r = rem / p.fw, q = rem - r * p.fw;
             const int ci = c0 + ch, iy = iy0 + r, ix = ix0 + q;
             float v = 0.f;
-            if (ci < d.cin && iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) {
+            if (ci < c_end && iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) {
                 v = xn[((int64_t)ci * d.in_h + iy) * d.in_w + ix];
                 if (sc) v *= sc[ci];
             }
-            Xs[i] = v;
+            buf[i] = v;
         }
-        // ---- stage weight slab: Ws[t][ch][co] from wp[t][ci][cout_pad] ----
+        float* Wd = buf + xs_floats;
         for (int i = tid; i < wsz4; i += 256) {
             const int c4 = i % wrow4;
             const int rest = i / wrow4;
             const int ch = rest % CK, t = rest / CK;
             const int ci = c0 + ch;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < d.cin) v = *reinterpret_cast<const float4*>(p.wp + ((int64_t)t * d.cin + ci) * d.cout_pad + co0 + c4 * 4);
-            *reinterpret_cast<float4*>(Ws + (t * CK + ch) * CO_T + c4 * 4) = v;
+            if (ci < c_end) v = *reinterpret_cast<const float4*>(p.wp + ((int64_t)t * d.cin + ci) * d.cout_pad + co0 + c4 * 4);
+            *reinterpret_cast<float4*>(Wd + i * 4) = v;
         }
-        __syncthreads();
-        // ---- MFMA over taps x channel pairs ----
+    };
+    auto mfma_chunk = [&](const float* buf) {
+        const float* Xs = buf;
+        const float* Ws = buf + xs_floats;
         if (MODE == 0) {
             for (int t = 0; t < T; ++t) {
                 const int toff = (d.dy[t] - p.dy_min) * p.fw + (d.dx[t] - p.dx_min);
@@ -163,7 +230,6 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         } else {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                constexpr int dummy = 0; (void)dummy;
                 const int toff = (d.dy[t] - p.dy_min) * p.fw + (d.dx[t] - p.dx_min);
                 const int q = tconv_group(t);
 #pragma unroll
@@ -183,11 +249,46 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                 }
             }
         }
+    };
+
+    if (PIPE) {
+        // chunks whose 8 channels all exist go through the register pipeline; a ragged last chunk (cin % 8 != 0) is staged directly
+        const int nfull = (c_end - c_begin) / CK;
+        if (nfull > 0) {
+            load_chunk(c_begin);
+            store_chunk(lds);
+        }
+        __syncthreads();
+        for (int c = 0; c < nfull; ++c) {
+            float* cur = lds + (c & 1) * buf_floats;
+            float* nxt = lds + ((c + 1) & 1) * buf_floats;
+            const bool more = c + 1 < nfull;
+            if (more) load_chunk(c_begin + (c + 1) * CK);      // in flight behind the MFMAs below
+            mfma_chunk(cur);
+            if (more) store_chunk(nxt);
+            __syncthreads();
+        }
+        if (nfull < nchunks) {
+            stage_direct(c_begin + nfull * CK, lds);
+            __syncthreads();
+            mfma_chunk(lds);
+        }
+    } else {
+        for (int c = 0; c < nchunks; ++c) {
+            __syncthreads();
+            stage_direct(c_begin + c * CK, lds);
+            __syncthreads();
+            mfma_chunk(lds);
+        }
     }
 
-    // ---- epilogue: demodulate, noise/bias/activation/gain/residual, store ----
-    float* yn = p.y + (int64_t)n * d.y_batch;
-    const float* osc = p.out_scale ? p.out_scale + (int64_t)n * d.out_scale_stride : nullptr;
+    // ---- epilogue: demodulate, noise/bias/activation/gain/residual, store (or raw partial store when split-K) ----
+    const bool partial = p.ksplit > 1;
+    float* yn = partial ? p.partial + ((int64_t)ks * d.n + n) * ((int64_t)d.cout * d.out_h * d.y_pitch) : p.y + (int64_t)n * d.y_batch;
+    const int64_t y_plane = partial ? (int64_t)d.out_h * d.y_pitch : d.y_plane;
+    const int choff = partial ? 0 : d.y_choff;
+    const float* osc = (p.out_scale && !partial) ? p.out_scale + (int64_t)n * d.out_scale_stride : nullptr;
+    const bool do_ep = p.has_ep && !partial;
 #pragma unroll
     for (int g = 0; g < WN; ++g) {
         if (!gvalid[g]) continue;
@@ -201,13 +302,13 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                 const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (co >= d.cout || !pvalid) continue;
                 const float os = osc ? osc[co] : 1.0f;
-                float* yc = yn + (int64_t)(d.y_choff + co) * d.y_plane;
+                float* yc = yn + (int64_t)(choff + co) * y_plane;
                 if (MODE == 0) {
                     const int oy = ty * d.ostride + d.oy[0], ox = tx * d.ostride + d.ox[0];
                     if (oy < d.out_h && ox < d.out_w) {
                         const int64_t off = (int64_t)oy * d.y_pitch + ox;
                         float v = acc[0][m][g][r] * os;
-                        if (p.has_ep) v = epi(p.ep, v, n, co, oy, ox, d.out_h, d.out_w, (yc - p.y) + off);
+                        if (do_ep) v = epi(p.ep, v, n, co, oy, ox, d.out_h, d.out_w, (yc - p.y) + off);
                         yc[off] = v;
                     }
                 } else {
@@ -228,18 +329,52 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     }
 }
 
+// Sum the K slices in index order, demodulate, run the epilogue, write y.  One lane per output element.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvParams p) {
+    const mgf_conv_desc& d = p.d;
+    const int64_t per_n = (int64_t)d.cout * d.out_h * d.out_w;
+    const int64_t total = per_n * d.n;
+    const int64_t pplane = (int64_t)d.out_h * d.y_pitch;
+    const int64_t slice = (int64_t)d.n * d.cout * pplane;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % d.out_w);
+        int64_t r = i / d.out_w;
+        const int oy = (int)(r % d.out_h); r /= d.out_h;
+        const int co = (int)(r % d.cout);
+        const int n = (int)(r / d.cout);
+        const int64_t poff = ((int64_t)n * d.cout + co) * pplane + (int64_t)oy * d.y_pitch + ox;
+        float v = 0.f;
+        for (int s = 0; s < p.ksplit; ++s) v += p.partial[s * slice + poff];
+        if (p.out_scale) v *= p.out_scale[(int64_t)n * d.out_scale_stride + co];
+        const int64_t yoff = (int64_t)n * d.y_batch + (int64_t)(d.y_choff + co) * d.y_plane + (int64_t)oy * d.y_pitch + ox;
+        if (p.has_ep) v = epi(p.ep, v, n, co, oy, ox, d.out_h, d.out_w, yoff);
+        p.y[yoff] = v;
+    }
+}
+
 template <int WM, int WN, int MODE>
 int launch_conv(const ConvParams& p, hipStream_t st) {
-    typedef Tile<WM, WN, MODE> TL;
-    const size_t lds = ((size_t)CK * p.fh * p.fw + (size_t)p.d.ntaps * CK * TL::CO_T) * sizeof(float);
+    constexpr int CO_T = 32 * WM;
+    const size_t buf = ((size_t)CK * p.fh * p.fw + (size_t)p.d.ntaps * CK * CO_T) * sizeof(float);
+    const bool pipe = (size_t)CK * p.fh * p.fw <= (size_t)Slots<WM, WN>::XS * 256 &&
+                      (size_t)p.d.ntaps * CK * CO_T / 4 <= (size_t)Slots<WM, WN>::WS * 256 && 2 * buf <= 64 * 1024;
+    const size_t lds = pipe ? 2 * buf : buf;
     if (lds > 160 * 1024) { mgf_set_error("conv_taps: tile needs %zu bytes of LDS (> 160 KiB)", lds); return MGF_EUNSUPPORTED; }
-    auto kern = conv_taps_kernel<WM, WN, MODE>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { mgf_set_error("conv_taps: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
+    dim3 grid(p.tiles_x * p.tiles_y, p.co_tiles, p.d.n * p.ksplit);
+    if (pipe) {
+        hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE, true>), grid, dim3(256), lds, st, p);
+    } else {
+        auto kern = conv_taps_kernel<WM, WN, MODE, false>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { mgf_set_error("conv_taps: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     }
-    dim3 grid(p.tiles_x * p.tiles_y, p.co_tiles, p.d.n);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    if (p.ksplit > 1) {
+        const int64_t total = (int64_t)p.d.n * p.d.cout * p.d.out_h * p.d.out_w;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(mgf_stream_grid(total, 256, 2)), dim3(256), 0, st, p);
+    }
     return MGF_OK;
 }
 
@@ -289,12 +424,12 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     MGF_REQUIRE(y && x && wp && dd, MGF_EINVAL, "conv_taps: null pointer");
     const mgf_conv_desc& d = *dd;
     MGF_REQUIRE(d.n >= 1 && d.cin >= 1 && d.cout >= 1 && d.in_h >= 1 && d.in_w >= 1, MGF_EINVAL, "conv_taps: bad shape");
-    MGF_REQUIRE(d.n <= 65535, MGF_ETOOBIG, "conv_taps: batch %d exceeds the grid z limit", d.n);
     MGF_REQUIRE(d.cout_pad >= d.cout && d.cout_pad % 32 == 0, MGF_EINVAL, "conv_taps: cout_pad must be a multiple of 32 >= cout");
     MGF_REQUIRE(d.ntaps >= 1 && d.ntaps <= MGF_MAX_TAPS, MGF_EINVAL, "conv_taps: ntaps out of range");
     MGF_REQUIRE(d.ngroups == 1 || d.ngroups == 4, MGF_EUNSUPPORTED, "conv_taps: ngroups must be 1 or 4");
     MGF_REQUIRE(d.istride >= 1 && d.ostride >= 1 && d.tile_h >= 1 && d.tile_w >= 1, MGF_EINVAL, "conv_taps: bad strides/tile");
     MGF_REQUIRE((int64_t)d.cin * d.in_h * d.in_w * d.n <= INT32_MAX, MGF_ETOOBIG, "conv_taps: input too large");
+    MGF_REQUIRE((int64_t)MGF_MAX_TAPS * d.cin * d.cout_pad <= INT32_MAX, MGF_ETOOBIG, "conv_taps: weight image too large");
     MGF_REQUIRE(d.y_pitch >= d.out_w && d.y_plane >= (int64_t)d.out_h * d.y_pitch, MGF_EINVAL, "conv_taps: output strides too small");
     if (ep) MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU,
                         MGF_EUNSUPPORTED, "conv_taps: epilogue activation %d unsupported", ep->act);
@@ -324,7 +459,7 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     while (tw_log2 > 2 && (1 << (tw_log2 - 1)) >= d.tile_w) --tw_log2;
     p.tw_log2 = tw_log2;
     const int TW = 1 << tw_log2;
-    // pick the workgroup tile: wide channel tiles when there are >= 64 output channels, more pixels per wave otherwise
+    // workgroup tile: wide channel tiles when there are >= 64 output channels, more pixels per wave otherwise
     int wm = 1, wn = 2;
     if (mode == 0) {
         if (d.cout_pad % 64 == 0 && d.cout > 32) { wm = 2; wn = 2; }
@@ -337,7 +472,23 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     p.fh = (rows - 1) * d.istride + (dy_max - dy_min) + 1;
     p.fw = (TW - 1) * d.istride + (dx_max - dx_min) + 1;
     p.co_tiles = d.cout_pad / (32 * wm);
-    MGF_REQUIRE((int64_t)p.tiles_x * p.tiles_y <= INT32_MAX && p.co_tiles <= 65535, MGF_ETOOBIG, "conv_taps: grid too large");
+    // split-K when the output tiling alone cannot fill the chip (>= 2 workgroups on each of 256 CUs wanted)
+    const int64_t base_wgs = (int64_t)p.tiles_x * p.tiles_y * p.co_tiles * d.n;
+    const int nchunks = (int)mgf_cdiv(d.cin, CK);
+    int ksplit = 1;
+    if (d.workspace && base_wgs < 512 && nchunks >= 4) {
+        ksplit = (int)mgf_cdiv(1024, base_wgs);
+        if (ksplit > nchunks / 2) ksplit = nchunks / 2;
+        const int64_t slice = (int64_t)d.n * d.cout * d.out_h * d.y_pitch;
+        while (ksplit > 1 && slice * ksplit > d.workspace_floats) --ksplit;
+        if (ksplit < 1) ksplit = 1;
+    }
+    p.chunks_per_split = (int)mgf_cdiv(nchunks, ksplit);
+    ksplit = (int)mgf_cdiv(nchunks, p.chunks_per_split);          // drop empty tail slices
+    p.ksplit = ksplit;
+    p.partial = d.workspace;
+    MGF_REQUIRE((int64_t)p.tiles_x * p.tiles_y <= INT32_MAX && p.co_tiles <= 65535 && (int64_t)d.n * ksplit <= 65535, MGF_ETOOBIG,
+                "conv_taps: grid too large");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (mode == 1) rc = launch_conv<1, 2, 1>(p, st);
