@@ -15,7 +15,9 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmgf_hip.so")
 SOURCES = ["capi.cpp", "bias_act.hip", "upfirdn2d.hip", "conv_taps.hip", "latent_prep.hip", "attention.hip", "losses.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result",
+# -ffp-contract=on: fma only inside one source expression (so `acc += a * b` still fuses) and never across statements --
+# the kernels that must reproduce torch's two-rounding arithmetic bit for bit rely on this.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=on", "-Wno-unused-result",
          "-x", "hip"]
 
 

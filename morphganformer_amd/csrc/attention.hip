@@ -50,11 +50,33 @@ __global__ __launch_bounds__(256) void duplex_attention_kernel(AttnParams p) {
     const float* xn = p.x + (int64_t)n * p.c * p.f;
     const int T = p.t;
 
-    // ---- stage wqc, zero-padded to [c_pad][16] ----
-    for (int i = tid; i < p.c_pad * TMAX; i += 256) {
-        const int c = i / TMAX, t = i % TMAX;
-        tab[i] = (c < p.c && t < T) ? p.wqc[(int64_t)c * T + t] : 0.f;
-    }
+    // ---- stage a [c][T] table zero-padded to [c_pad][16]; T == 16 is a straight 16-byte copy, four loads in flight ----
+    auto stage_table = [&](const float* src) {
+        if (T == TMAX) {
+            const int n4 = p.c * (TMAX / 4), n4_pad = p.c_pad * (TMAX / 4);
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(tab);
+            for (int i0 = tid; i0 < n4_pad; i0 += 256 * 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 256 * u;
+                    v[u] = i < n4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 256 * u;
+                    if (i < n4_pad) d4[i] = v[u];
+                }
+            }
+        } else {
+            for (int i = tid; i < p.c_pad * TMAX; i += 256) {
+                const int c = i / TMAX, t = i % TMAX;
+                tab[i] = (c < p.c && t < T) ? src[(int64_t)c * T + t] : 0.f;
+            }
+        }
+    };
+    stage_table(p.wqc);
     __syncthreads();
 
     float s[TMAX];
@@ -96,11 +118,7 @@ __global__ __launch_bounds__(256) void duplex_attention_kernel(AttnParams p) {
     }
     sq = 0.f;
     for (int g = 0; g < G; ++g) sq += part[(g * (TMAX + 1) + TMAX) * PXB + px];
-    const float* vn = p.vwb + (int64_t)n * p.c * T;
-    for (int i = tid; i < p.c_pad * TMAX; i += 256) {
-        const int c = i / TMAX, t = i % TMAX;
-        tab[i] = (c < p.c && t < T) ? vn[(int64_t)c * T + t] : 0.f;
-    }
+    stage_table(p.vwb + (int64_t)n * p.c * T);
     float den = 0.f;
     int best = 0;
     float bestv = -3.0e38f;
@@ -182,7 +200,8 @@ extern "C" int mgf_duplex_attention(float* y, const float* x, const float* wqc, 
     p.y = y; p.x = x; p.wqc = wqc; p.spos = spos; p.vwb = vwb; p.n = n; p.c = c; p.f = f; p.t = t;
     p.has_ep = ep != nullptr; p.probs = probs; p.argmax = argmax;
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
-    const int pxb = f >= 1024 ? 64 : 16;
+    MGF_REQUIRE(((uintptr_t)wqc % 16 == 0) && ((uintptr_t)vwb % 16 == 0), MGF_EINVAL, "duplex_attention: tables must be 16-byte aligned");
+    const int pxb = f >= 16384 ? 64 : 16;
     const int g = 256 / pxb;
     p.c_pad = (int)(mgf_cdiv(c, UNR * g) * UNR * g);
     const size_t lds = ((size_t)p.c_pad * TMAX + (size_t)g * (TMAX + 1) * pxb) * sizeof(float);

@@ -137,17 +137,20 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     constexpr int XS = Slots<WM, WN>::XS, WS = Slots<WM, WN>::WS;
     int xoff[XS];
     if (PIPE) {
+        // (ch, r, q) of slot 0 by division once, then advanced by 256 elements per slot with carries (no division per slot)
+        int ch = tid / chs;
+        int r = (tid - ch * chs) / p.fw;
+        int q = tid - ch * chs - r * p.fw;
+        const int dr = 256 / p.fw, dq = 256 - dr * p.fw;
 #pragma unroll
         for (int j = 0; j < XS; ++j) {
             const int i = tid + 256 * j;
-            xoff[j] = -2;
-            if (i < xs_floats) {
-                const int ch = i / chs;
-                const int rem = i - ch * chs;
-                const int r = rem / p.fw, q = rem - r * p.fw;
-                const int iy = iy0 + r, ix = ix0 + q;
-                xoff[j] = (iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) ? ch * plane + iy * d.in_w + ix : -1;
-            }
+            const int iy = iy0 + r, ix = ix0 + q;
+            xoff[j] = i >= xs_floats ? -2 : (iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) ? ch * plane + iy * d.in_w + ix : -1;
+            q += dq; r += dr;
+            if (q >= p.fw) { q -= p.fw; ++r; }
+            if (r >= p.fh) { r -= p.fh; ++ch; }
+            if (r >= p.fh) { r -= p.fh; ++ch; }        // 256 / fw + 1 < 2 * fh for every tile geometry the host picks
         }
     }
     float xr[XS];
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                     for (int m = 0; m < WM; ++m)
 #pragma unroll
                         for (int g = 0; g < WN; ++g)
-                            if (gvalid[g]) acc[0][m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[g], acc[0][m][g], 0, 0, 0);
+                            acc[0][m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[g], acc[0][m][g], 0, 0, 0);
                 }
             }
         } else {
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                     for (int m = 0; m < WM; ++m)
 #pragma unroll
                         for (int g = 0; g < WN; ++g)
-                            if (gvalid[g]) acc[NG == 4 ? q : 0][m][g] =
+                            acc[NG == 4 ? q : 0][m][g] =
                                 __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[g], acc[NG == 4 ? q : 0][m][g], 0, 0, 0);
                 }
             }
@@ -344,7 +347,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvParams p) {
         const int n = (int)(r / d.cout);
         const int64_t poff = ((int64_t)n * d.cout + co) * pplane + (int64_t)oy * d.y_pitch + ox;
         float v = 0.f;
-        for (int s = 0; s < p.ksplit; ++s) v += p.partial[s * slice + poff];
+        // fixed summation order (deterministic); loads issued four at a time so their latencies overlap
+        const float* pp = p.partial + poff;
+        int s = 0;
+        for (; s + 4 <= p.ksplit; s += 4) {
+            const float a0 = pp[(int64_t)s * slice], a1 = pp[(int64_t)(s + 1) * slice];
+            const float a2 = pp[(int64_t)(s + 2) * slice], a3 = pp[(int64_t)(s + 3) * slice];
+            v += a0; v += a1; v += a2; v += a3;
+        }
+        for (; s < p.ksplit; ++s) v += pp[(int64_t)s * slice];
         if (p.out_scale) v *= p.out_scale[(int64_t)n * d.out_scale_stride + co];
         const int64_t yoff = (int64_t)n * d.y_batch + (int64_t)(d.y_choff + co) * d.y_plane + (int64_t)oy * d.y_pitch + ox;
         if (p.has_ep) v = epi(p.ep, v, n, co, oy, ox, d.out_h, d.out_w, yoff);
@@ -357,7 +368,8 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     constexpr int CO_T = 32 * WM;
     const size_t buf = ((size_t)CK * p.fh * p.fw + (size_t)p.d.ntaps * CK * CO_T) * sizeof(float);
     const bool pipe = (size_t)CK * p.fh * p.fw <= (size_t)Slots<WM, WN>::XS * 256 &&
-                      (size_t)p.d.ntaps * CK * CO_T / 4 <= (size_t)Slots<WM, WN>::WS * 256 && 2 * buf <= 64 * 1024;
+                      (size_t)p.d.ntaps * CK * CO_T / 4 <= (size_t)Slots<WM, WN>::WS * 256 && 2 * buf <= 64 * 1024 &&
+                      256 / p.fw + 2 <= 2 * p.fh;     // slot walk: at most two row wraps per 256-element step
     const size_t lds = pipe ? 2 * buf : buf;
     if (lds > 160 * 1024) { mgf_set_error("conv_taps: tile needs %zu bytes of LDS (> 160 KiB)", lds); return MGF_EUNSUPPORTED; }
     dim3 grid(p.tiles_x * p.tiles_y, p.co_tiles, p.d.n * p.ksplit);

@@ -5,7 +5,7 @@
 
 namespace {
 
-constexpr int RED_BLOCKS = 1024;
+constexpr int RED_BLOCKS = 16384;
 
 __device__ __forceinline__ float block_sum_256(float v, float* sm) {
     v = wave_sum(v);
@@ -44,27 +44,73 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(float* scratch, const 
 }
 
 // One lane per pixel: two sweeps over the channels (norms, then the weighted squared difference of the unit vectors).
+// A workgroup owns PXB consecutive pixels; its 256 / PXB lane groups split the channels (PXB = 16 for the small deep taps
+// so that a 63x63 map still spreads over ~250 workgroups).  Two sweeps over the channels -- squared norms, then the
+// lin-weighted squared difference of the unit vectors (the second sweep re-reads from L2) -- each unrolled 4-deep; the
+// partial sums meet in LDS in a fixed order, so the result is bit-reproducible.
+template <int PXB>
 __global__ __launch_bounds__(256) void lpips_partial_kernel(float* scratch, const float* f0, const float* f1, const float* lin, int n,
                                                             int c, int64_t hw) {
+    constexpr int G = 256 / PXB;
+    __shared__ float red[2][G][PXB];
     __shared__ float sm[4];
-    float acc = 0.f;
+    const int px = threadIdx.x % PXB, grp = threadIdx.x / PXB;
     const int64_t total = (int64_t)n * hw;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t nn = i / hw, px = i - nn * hw;
-        const float* a = f0 + nn * c * hw + px;
-        const float* b = f1 + nn * c * hw + px;
-        float na = 0.f, nb = 0.f;
-        for (int k = 0; k < c; ++k) { float u = a[(int64_t)k * hw], v = b[(int64_t)k * hw]; na += u * u; nb += v * v; }
-        const float ia = 1.f / (sqrtf(na) + 1e-10f), ib = 1.f / (sqrtf(nb) + 1e-10f);
-        float d = 0.f;
-        for (int k = 0; k < c; ++k) {
-            float u = a[(int64_t)k * hw] * ia - b[(int64_t)k * hw] * ib;
-            d += lin[k] * u * u;
+    const int64_t i = (int64_t)blockIdx.x * PXB + px;
+    const bool valid = i < total;
+    const int64_t ic = valid ? i : total - 1;
+    const int64_t nn = ic / hw, pp = ic - nn * hw;
+    const float* a = f0 + nn * c * hw + pp;
+    const float* b = f1 + nn * c * hw + pp;
+    float na = 0.f, nb = 0.f;
+    for (int k0 = grp * 4; k0 < c; k0 += G * 4) {
+        float u[4], v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = k0 + j < c;
+            u[j] = ok ? a[(int64_t)(k0 + j) * hw] : 0.f;
+            v[j] = ok ? b[(int64_t)(k0 + j) * hw] : 0.f;
         }
-        acc += d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { na += u[j] * u[j]; nb += v[j] * v[j]; }
     }
-    acc = block_sum_256(acc, sm);
+    red[0][grp][px] = na;
+    red[1][grp][px] = nb;
+    __syncthreads();
+    na = 0.f; nb = 0.f;
+    for (int g = 0; g < G; ++g) { na += red[0][g][px]; nb += red[1][g][px]; }
+    const float ia = 1.f / (sqrtf(na) + 1e-10f), ib = 1.f / (sqrtf(nb) + 1e-10f);
+    float d = 0.f;
+    for (int k0 = grp * 4; k0 < c; k0 += G * 4) {
+        float u[4], v[4], w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = k0 + j < c;
+            u[j] = ok ? a[(int64_t)(k0 + j) * hw] : 0.f;
+            v[j] = ok ? b[(int64_t)(k0 + j) * hw] : 0.f;
+            w[j] = ok ? lin[k0 + j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // separate statements: both products are rounded before the subtraction (build uses -ffp-contract=on), so
+            // identical inputs give exactly zero, like the reference's a/|a| - b/|b|
+            const float ua = u[j] * ia;
+            const float vb = v[j] * ib;
+            const float e = ua - vb;
+            d += w[j] * e * e;
+        }
+    }
+    const float acc = block_sum_256(valid ? d : 0.f, sm);
     if (threadIdx.x == 0) scratch[blockIdx.x] = acc;
+}
+
+// scratch[0 .. nparts) -> sum in index order by one workgroup, several rounds of 256-wide partials
+__global__ __launch_bounds__(256) void finish_many_kernel(float* out, const float* scratch, int nparts, float scale, int accumulate) {
+    __shared__ float sm[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) v += scratch[i];
+    v = block_sum_256(v, sm);
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + v * scale;
 }
 
 __global__ __launch_bounds__(256) void wing_kernel(double* out, const double* pred, const double* target, int64_t numel, double omega,
@@ -175,11 +221,16 @@ extern "C" int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1,
                                    int32_t accumulate, float* scratch, mgf_stream_t stream) {
     MGF_REQUIRE(out && f0 && f1 && lin && scratch && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer: bad arguments");
     const int64_t total = (int64_t)n * hw;
-    const int grid = (int)(mgf_cdiv(total, 256) < RED_BLOCKS ? mgf_cdiv(total, 256) : RED_BLOCKS);
+    const int pxb = total >= 65536 ? 64 : 16;
+    const int64_t grid64 = mgf_cdiv(total, pxb);
+    MGF_REQUIRE(grid64 <= mgf_reduce_scratch_floats(), MGF_ETOOBIG, "lpips_layer: %lld pixels need %lld scratch floats (have %lld)",
+                (long long)total, (long long)grid64, (long long)mgf_reduce_scratch_floats());
+    const int grid = (int)grid64;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(lpips_partial_kernel, dim3(grid), dim3(256), 0, st, scratch, f0, f1, lin, n, c, hw);
+    if (pxb == 64) hipLaunchKernelGGL((lpips_partial_kernel<64>), dim3(grid), dim3(256), 0, st, scratch, f0, f1, lin, n, c, hw);
+    else hipLaunchKernelGGL((lpips_partial_kernel<16>), dim3(grid), dim3(256), 0, st, scratch, f0, f1, lin, n, c, hw);
     // spatial mean per sample, summed over the batch (the loop uses .sum() over N: ...sqz_MSE.py:175)
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, out, scratch, grid, 1.0f / (float)hw, accumulate);
+    hipLaunchKernelGGL(finish_many_kernel, dim3(1), dim3(256), 0, st, out, scratch, grid, 1.0f / (float)hw, accumulate);
     MGF_CHECK_LAUNCH("lpips_layer");
     return MGF_OK;
 }
