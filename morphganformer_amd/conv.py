@@ -41,7 +41,10 @@ def _variant(mode, cout, cout_pad, tile_h, tile_w, ntaps=9, istride=1, span=2):
     xs, ws4 = 8 * fh * fw, ntaps * 8 * 32 * wm // 4
     buf = 4 * (xs + ntaps * 8 * 32 * wm)
     pipe = xs <= (20 if wn == 4 else 11) * 256 and ws4 <= (5 if wm == 2 else 3) * 256 and 2 * buf <= 64 * 1024
-    return f"conv_taps_kernel<{wm}, {wn}, {mode}, {'true' if pipe else 'false'}>"
+    if pipe and ntaps not in (1, 9):
+        pipe = False
+    nt = 9 if ntaps == 9 else (1 if (pipe and ntaps == 1) else 0)
+    return f"conv_taps_kernel<{wm}, {wn}, {mode}, {'true' if pipe else 'false'}, {nt}>"
 
 
 class _Timed:

@@ -75,12 +75,16 @@ __device__ __forceinline__ float epi(const mgf_epilogue& ep, float v, int n, int
 // parity group of tap t (t = kh*3 + kw) for the stride-2 transposed conv: kh (kw) == 1 feeds odd rows (cols)
 __host__ __device__ constexpr int tconv_group(int t) { return ((t / 3) == 1 ? 2 : 0) + ((t % 3) == 1 ? 1 : 0); }
 
-template <int WM, int WN, int MODE, bool PIPE>
+// NT = compile-time tap count (9 = 3x3, 1 = 1x1; 0 = any count read from the descriptor at run time)
+template <int WM, int WN, int MODE, bool PIPE, int NT>
 __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     constexpr int CO_T = 32 * WM, PX = 128 * WN, NG = MODE == 1 ? 4 : 1;
     extern __shared__ float lds[];
     const mgf_conv_desc& d = p.d;
-    const int T = d.ntaps;
+    const int T = NT > 0 ? NT : d.ntaps;
+    int toffs[MGF_MAX_TAPS];                         // LDS offset of each tap inside the footprint (wave-uniform)
+#pragma unroll
+    for (int t = 0; t < MGF_MAX_TAPS; ++t) toffs[t] = t < T ? (d.dy[t] - p.dy_min) * p.fw + (d.dx[t] - p.dx_min) : 0;
     const int chs = p.fh * p.fw;                 // LDS channel stride of Xs
     const int xs_floats = CK * chs;
     const int ws_floats = T * CK * CO_T;
@@ -209,46 +213,51 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
             *reinterpret_cast<float4*>(Wd + i * 4) = v;
         }
     };
+    // Operand fragments of one tap (CK/2 k-steps) are fetched from LDS into a register set one tap AHEAD of the MFMAs that
+    // consume them (two sets, statically indexed after unrolling), so the matrix pipe never waits on an LDS round trip.
     auto mfma_chunk = [&](const float* buf) {
-        const float* Xs = buf;
-        const float* Ws = buf + xs_floats;
-        if (MODE == 0) {
-            for (int t = 0; t < T; ++t) {
+        const float* Xs = buf + half * chs;                       // lane halves read channels 2kk and 2kk+1
+        const float* Ws = buf + xs_floats + half * CO_T + l31;
+        float fa[2][CK / 2][WM], fb[2][CK / 2][WN];
+        auto fetch = [&](int t, int set) {
+#pragma unroll
+            for (int kk = 0; kk < CK / 2; ++kk) {
+#pragma unroll
+                for (int m = 0; m < WM; ++m) fa[set][kk][m] = Ws[(t * CK + 2 * kk) * CO_T + m * 32];
+#pragma unroll
+                for (int g = 0; g < WN; ++g) fb[set][kk][g] = Xs[2 * kk * chs + pbase[g] + toffs[t]];
+            }
+        };
+        if (NT > 0) {
+            fetch(0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t + 1 < NT) fetch(t + 1, (t + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);                // keep the next tap's ds_reads ahead of this tap's MFMAs
+                const int q = (MODE == 1 && NG == 4) ? tconv_group(t) : 0;
+#pragma unroll
+                for (int kk = 0; kk < CK / 2; ++kk)
+#pragma unroll
+                    for (int m = 0; m < WM; ++m)
+#pragma unroll
+                        for (int g = 0; g < WN; ++g)
+                            acc[q][m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][kk][m], fb[t & 1][kk][g], acc[q][m][g], 0, 0, 0);
+            }
+        } else {
+            for (int t = 0; t < T; ++t) {                         // generic tap count (e.g. 2x2, 1x3): not pipelined
                 const int toff = (d.dy[t] - p.dy_min) * p.fw + (d.dx[t] - p.dx_min);
 #pragma unroll
                 for (int kk = 0; kk < CK / 2; ++kk) {
-                    const int ch = 2 * kk + half;
                     float a[WM], b[WN];
 #pragma unroll
-                    for (int m = 0; m < WM; ++m) a[m] = Ws[(t * CK + ch) * CO_T + m * 32 + l31];
+                    for (int m = 0; m < WM; ++m) a[m] = Ws[(t * CK + 2 * kk) * CO_T + m * 32];
 #pragma unroll
-                    for (int g = 0; g < WN; ++g) b[g] = Xs[ch * chs + pbase[g] + toff];
+                    for (int g = 0; g < WN; ++g) b[g] = Xs[2 * kk * chs + pbase[g] + toff];
 #pragma unroll
                     for (int m = 0; m < WM; ++m)
 #pragma unroll
                         for (int g = 0; g < WN; ++g)
                             acc[0][m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[g], acc[0][m][g], 0, 0, 0);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int toff = (d.dy[t] - p.dy_min) * p.fw + (d.dx[t] - p.dx_min);
-                const int q = tconv_group(t);
-#pragma unroll
-                for (int kk = 0; kk < CK / 2; ++kk) {
-                    const int ch = 2 * kk + half;
-                    float a[WM], b[WN];
-#pragma unroll
-                    for (int m = 0; m < WM; ++m) a[m] = Ws[(t * CK + ch) * CO_T + m * 32 + l31];
-#pragma unroll
-                    for (int g = 0; g < WN; ++g) b[g] = Xs[ch * chs + pbase[g] + toff];
-#pragma unroll
-                    for (int m = 0; m < WM; ++m)
-#pragma unroll
-                        for (int g = 0; g < WN; ++g)
-                            acc[NG == 4 ? q : 0][m][g] =
-                                __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[g], acc[NG == 4 ? q : 0][m][g], 0, 0, 0);
                 }
             }
         }
@@ -292,12 +301,48 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     const int choff = partial ? 0 : d.y_choff;
     const float* osc = (p.out_scale && !partial) ? p.out_scale + (int64_t)n * d.out_scale_stride : nullptr;
     const bool do_ep = p.has_ep && !partial;
+    const float ep_ns = (do_ep && p.ep.noise) ? (p.ep.noise_strength ? *p.ep.noise_strength : 1.0f) : 0.f;
 #pragma unroll
     for (int g = 0; g < WN; ++g) {
         if (!gvalid[g]) continue;
         const int pix = (wave * WN + g) * 32 + l31;
         const int ty = ty0 + (pix >> p.tw_log2), tx = tx0 + (pix & (TW - 1));
         const bool pvalid = ty < d.tile_h && tx < d.tile_w;
+        if (MODE == 0) {
+            // one output pixel per lane, 16 channels per (m) across the registers: gather every operand of the 16 outputs first
+            // (independent loads in flight together), then compute, then store -- no load ever waits behind a store.
+            const int oy = ty * d.ostride + d.oy[0], ox = tx * d.ostride + d.ox[0];
+            const bool ovalid = pvalid && oy < d.out_h && ox < d.out_w;
+            const int64_t off = (int64_t)oy * d.y_pitch + ox;
+            float nz = 0.f;
+            if (do_ep && p.ep.noise && ovalid) nz = p.ep.noise[((int64_t)(p.ep.noise_n > 1 ? n : 0) * d.out_h + oy) * d.out_w + ox] * ep_ns;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+                float osv[16], bv[16], rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const bool ok = ovalid && co < d.cout;
+                    osv[r] = (osc && co < d.cout) ? osc[co] : 1.0f;
+                    bv[r] = (do_ep && p.ep.bias && co < d.cout) ? p.ep.bias[co] : 0.f;
+                    rv[r] = (do_ep && p.ep.residual && ok) ? p.ep.residual[(int64_t)n * d.y_batch + (int64_t)(choff + co) * y_plane + off] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[0][m][g][r] * osv[r];
+                    if (do_ep) {
+                        v += nz;
+                        v += bv[r];
+                        if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
+                        else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        v = v * p.ep.gain + rv[r];
+                    }
+                    if (ovalid && co < d.cout) yn[(int64_t)(choff + co) * y_plane + off] = v;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int m = 0; m < WM; ++m) {
 #pragma unroll
@@ -306,15 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                 if (co >= d.cout || !pvalid) continue;
                 const float os = osc ? osc[co] : 1.0f;
                 float* yc = yn + (int64_t)(choff + co) * y_plane;
-                if (MODE == 0) {
-                    const int oy = ty * d.ostride + d.oy[0], ox = tx * d.ostride + d.ox[0];
-                    if (oy < d.out_h && ox < d.out_w) {
-                        const int64_t off = (int64_t)oy * d.y_pitch + ox;
-                        float v = acc[0][m][g][r] * os;
-                        if (do_ep) v = epi(p.ep, v, n, co, oy, ox, d.out_h, d.out_w, (yc - p.y) + off);
-                        yc[off] = v;
-                    }
-                } else {
+                {
                     // parity sets: q = 2*a + b -> row 2*ty + a, cols 2*tx + {0,1} written as a pair
 #pragma unroll
                     for (int a2 = 0; a2 < 2; ++a2) {
@@ -373,15 +410,23 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     const size_t lds = pipe ? 2 * buf : buf;
     if (lds > 160 * 1024) { mgf_set_error("conv_taps: tile needs %zu bytes of LDS (> 160 KiB)", lds); return MGF_EUNSUPPORTED; }
     dim3 grid(p.tiles_x * p.tiles_y, p.co_tiles, p.d.n * p.ksplit);
-    if (pipe) {
-        hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE, true>), grid, dim3(256), lds, st, p);
+    const int nt = p.d.ntaps;
+    if (pipe && nt == 9) {
+        hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE, true, 9>), grid, dim3(256), lds, st, p);
+    } else if (pipe && nt == 1 && MODE == 0) {
+        hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE == 1 ? 0 : MODE, true, 1>), grid, dim3(256), lds, st, p);
     } else {
-        auto kern = conv_taps_kernel<WM, WN, MODE, false>;
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { mgf_set_error("conv_taps: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
+        // un-pipelined staging: large footprints (strided convs, 4x4 maps) and unusual tap counts
+        auto kern9 = conv_taps_kernel<WM, WN, MODE, false, 9>;
+        auto kern0 = conv_taps_kernel<WM, WN, MODE == 1 ? 0 : MODE, false, 0>;
+        const size_t lds1 = buf;
+        const void* fn = (nt == 9) ? (const void*)kern9 : (const void*)kern0;
+        if (lds1 > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            if (e != hipSuccess) { mgf_set_error("conv_taps: cannot raise dynamic LDS to %zu: %s", lds1, hipGetErrorString(e)); return MGF_ELAUNCH; }
         }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+        if (nt == 9) hipLaunchKernelGGL(kern9, grid, dim3(256), lds1, st, p);
+        else hipLaunchKernelGGL(kern0, grid, dim3(256), lds1, st, p);
     }
     if (p.ksplit > 1) {
         const int64_t total = (int64_t)p.d.n * p.d.cout * p.d.out_h * p.d.out_w;
