@@ -75,28 +75,30 @@ def build(cfg, device, rank, steps_total, use_graph):
 
 
 def roofline_leg(eng, iters=3):
-    """Eager (un-graphed) iterations with every MFMA conv launch bracketed by events on the launch stream."""
+    """Eager (un-graphed) iterations of the same step with every MFMA conv launch bracketed by HIP events on the launch
+    stream, inside the library (mgf_conv_profile_begin/end): the main kernel only, so durations match rocprofv3's trace."""
     from morphganformer_amd import conv as cv
     state = [t.clone() for t in (eng.step_ctr, eng.min_loss, eng.best_latent, eng.best_step, eng.losses)]
     eng._iteration()
     torch.cuda.synchronize()
-    cv.PROFILE = []
+    cv.profile_begin()
     for _ in range(iters):
         eng._iteration()
     torch.cuda.synchronize()
-    prof, cv.PROFILE = cv.PROFILE, None
+    prof = cv.profile_end()
     for dst, src in zip((eng.step_ctr, eng.min_loss, eng.best_latent, eng.best_step, eng.losses), state):
         dst.copy_(src)
     agg = {}
-    for variant, flops, e0, e1 in prof:
-        a = agg.setdefault(variant, [0.0, 0.0, 0])
+    for kernel, flops, secs, ksplit in prof:
+        a = agg.setdefault(kernel, [0.0, 0.0, 0])
         a[0] += flops
-        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[1] += secs
         a[2] += 1
     dom = max(agg, key=lambda k_: agg[k_][1])
     flops, secs, launches = agg[dom]
     achieved = flops / secs / 1e12
-    per_kernel = {k_: {"launches_per_iter": v[2] // iters, "avg_us": v[1] / v[2] * 1e6, "tflops": v[0] / v[1] / 1e12} for k_, v in agg.items()}
+    per_kernel = {k_: {"launches_per_iter": v[2] // iters, "avg_us": round(v[1] / v[2] * 1e6, 2), "tflops": round(v[0] / v[1] / 1e12, 2)}
+                  for k_, v in agg.items()}
     total_conv_s = sum(v[1] for v in agg.values()) / iters
     return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,

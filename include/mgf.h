@@ -112,6 +112,19 @@ typedef struct mgf_conv_desc {
 int mgf_conv_taps_f32(float* y, const float* x, const float* wp, const float* in_scale, const float* out_scale,
                       const mgf_conv_desc* d, const mgf_epilogue* ep, mgf_stream_t stream);
 
+/* Per-launch instrumentation of mgf_conv_taps_f32 for roofline accounting: between _begin and _end every conv launch is
+ * bracketed by HIP events on its launch stream (main kernel only, not the split-K reduce; do not use during graph capture).
+ * _end waits for the events and fills up to max_recs records in launch order; returns the number of launches seen. */
+typedef struct mgf_conv_prof_rec {
+    char kernel[64];      /* demangled kernel name as rocprofv3 prints it, e.g. "conv_taps_kernel<2, 2, 0, true, 9>" */
+    double flops;         /* algorithmic FLOPs of the launch (transposed conv counted per input pixel) */
+    double seconds;       /* event-to-event duration */
+    int32_t ksplit;       /* K slices used (1 = no split) */
+    int32_t pad_;
+} mgf_conv_prof_rec;
+int mgf_conv_profile_begin(void);
+int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs);
+
 /* Repack [cout, cin, kh, kw] float32 weights (times `gain`) into the [tap][cin][cout_pad] image read by
  * mgf_conv_taps_f32; `flip` reverses kh,kw (true convolution).  Taps are emitted in (kh, kw) row-major order.
  * Also emits wsq[cout, cin] = sum_k (w*gain)^2 when wsq != NULL (demodulation table). Device pointers. */

@@ -34,6 +34,10 @@ class ConvDesc(C.Structure):
                 ("out_scale_stride", i32), ("workspace", vp), ("workspace_floats", i64)]
 
 
+class ConvProfRec(C.Structure):
+    _fields_ = [("kernel", C.c_char * 64), ("flops", f64), ("seconds", f64), ("ksplit", i32), ("pad_", i32)]
+
+
 class StyleJob(C.Structure):
     _fields_ = [("aff_w", vp), ("aff_b", vp), ("wsq", vp), ("s", vp), ("d", vp), ("cin", i32), ("cout", i32),
                 ("w_offset", i32), ("aff_gain", f32), ("style_gain", f32)]
@@ -52,6 +56,8 @@ _SIGS = {
                                 i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, C.POINTER(Epilogue), vp]),
     "mgf_conv_taps_f32": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(ConvDesc), C.POINTER(Epilogue), vp]),
     "mgf_pack_conv_weights": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "mgf_conv_profile_begin": (C.c_int, []),
+    "mgf_conv_profile_end": (C.c_int, [C.POINTER(ConvProfRec), i32]),
     "mgf_style_demod": (C.c_int, [C.POINTER(StyleJob), vp, i64, i32, i32, vp]),
     "mgf_style_demod_multi": (C.c_int, [vp, i32, vp, i64, i32, i32, vp]),
     "mgf_duplex_attention": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(Epilogue), i32, vp, vp, vp]),

@@ -17,52 +17,18 @@ def round_up(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
-# Optional per-launch instrumentation (bench.py roofline leg): when PROFILE is a list, every conv launch is bracketed
-# by events on the launch stream and appended as (kernel_variant, algorithmic_flops, start_event, end_event).
-PROFILE = None
+def profile_begin():
+    """Start bracketing every conv launch with HIP events on its stream (csrc/conv_taps.hip ProfScope); eager mode only."""
+    _lib.check(_lib.lib().mgf_conv_profile_begin(), "conv_profile_begin")
 
 
-def _variant(mode, cout, cout_pad, tile_h, tile_w, ntaps=9, istride=1, span=2):
-    """Mirror of the kernel selection in csrc/conv_taps.hip (mgf_conv_taps_f32 / launch_conv): the demangled kernel name
-    rocprofv3 reports, so bench.py's per-kernel timings can be compared with the committed profile summaries."""
-    if mode == 1:
-        wm, wn = 1, 2
-    elif cout_pad % 64 == 0 and cout > 32:
-        wm, wn = 2, 2
-    elif tile_h * tile_w >= 512 * 64:
-        wm, wn = 1, 4
-    else:
-        wm, wn = 1, 2
-    tw = 32
-    while tw > 4 and tw // 2 >= tile_w:
-        tw //= 2
-    rows = 128 * wn // tw
-    fh, fw = (rows - 1) * istride + span + 1, (tw - 1) * istride + span + 1
-    xs, ws4 = 8 * fh * fw, ntaps * 8 * 32 * wm // 4
-    buf = 4 * (xs + ntaps * 8 * 32 * wm)
-    pipe = xs <= (20 if wn == 4 else 11) * 256 and ws4 <= (5 if wm == 2 else 3) * 256 and 2 * buf <= 64 * 1024
-    if pipe and ntaps not in (1, 9):
-        pipe = False
-    nt = 9 if ntaps == 9 else (1 if (pipe and ntaps == 1) else 0)
-    return f"conv_taps_kernel<{wm}, {wn}, {mode}, {'true' if pipe else 'false'}, {nt}>"
-
-
-class _Timed:
-    def __init__(self, variant, flops):
-        self.variant, self.flops = variant, flops
-
-    def __enter__(self):
-        if PROFILE is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
-        return self
-
-    def __exit__(self, *exc):
-        if PROFILE is not None:
-            self.e1.record()
-            PROFILE.append((self.variant, self.flops, self.e0, self.e1))
-        return False
+def profile_end(max_recs=4096):
+    """-> list of (kernel_name, algorithmic_flops, seconds, ksplit) in launch order."""
+    recs = (_lib.ConvProfRec * max_recs)()
+    n = _lib.lib().mgf_conv_profile_end(recs, max_recs)
+    if n < 0:
+        _lib.check(n, "conv_profile_end")
+    return [(recs[i].kernel.decode(), recs[i].flops, recs[i].seconds, recs[i].ksplit) for i in range(min(n, max_recs))]
 
 
 @dataclass
@@ -140,10 +106,8 @@ def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_sca
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, oh, ow, stride, 1, taps, None, [0], [0], oh, ow,
               ow, oh * ow, out.shape[1] * oh * ow, out_choff,
               0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
-    with _Timed(_variant(0, pc.cout, pc.cout_pad, oh, ow, pc.kh * pc.kw, stride, pc.kh - 1),
-                2.0 * n * pc.kh * pc.kw * cin * pc.cout * oh * ow):
-        rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                          C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
+    rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                      C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
     _lib.check(rc, "conv_taps")
     return out
 
@@ -170,10 +134,8 @@ def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=Non
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, h + 1, w + 1, 1, 2, TCONV_TAPS, TCONV_GROUPS, [0, 0, 1, 1], [0, 1, 0, 1],
               oh, ow, pitch, oh * pitch, pc.cout * oh * pitch, 0,
               0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
-    # algorithmic FLOPs of a stride-2 transposed conv: 9 taps per INPUT pixel
-    with _Timed(_variant(1, pc.cout, pc.cout_pad, h + 1, w + 1, 9, 1, 1), 2.0 * n * 9 * cin * pc.cout * h * w):
-        rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                          C.byref(d), None, _lib.stream_ptr())
+    rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                      C.byref(d), None, _lib.stream_ptr())
     _lib.check(rc, "conv_taps(tconv)")
     return out[:, :, :, :ow]
 

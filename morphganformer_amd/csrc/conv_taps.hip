@@ -26,6 +26,7 @@
 // MODE 1 is the stride-2 transposed convolution: the 9 taps feed 4 output-parity accumulator sets (compile-time
 // tap -> parity map), so it runs at the transposed conv's own FLOP count and writes the parity pairs interleaved.
 #include "mgf_common.h"
+#include <vector>
 
 namespace {
 
@@ -400,6 +401,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvParams p) {
     }
 }
 
+// ---- optional per-launch instrumentation (mgf_conv_profile_begin/end): HIP events on the launch stream around the main
+// kernel only (not the split-K reduce), so the durations line up with rocprofv3's per-kernel trace ----
+struct ProfRec { hipEvent_t e0, e1; int wm, wn, mode, pipe, nt, ksplit; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+    hipStream_t st; bool on;
+    ProfScope(hipStream_t s, int wm, int wn, int mode, int pipe, int nt, const ConvParams& p) : st(s), on(g_prof_on) {
+        if (!on) return;
+        ProfRec r;
+        r.wm = wm; r.wn = wn; r.mode = mode; r.pipe = pipe; r.nt = nt; r.ksplit = p.ksplit;
+        const mgf_conv_desc& d = p.d;
+        // algorithmic FLOPs: conv = 2*taps*cin*cout per output pixel; the stride-2 transposed conv is
+        // counted at its own cost, 2*9*cin*cout per INPUT pixel
+        r.flops = mode == 1 ? 2.0 * 9 * d.cin * (double)d.cout * d.in_h * d.in_w * d.n
+                            : 2.0 * d.ntaps * d.cin * (double)d.cout * d.tile_h * d.tile_w * d.n;
+        hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+        hipEventRecord(r.e0, st);
+        g_prof.push_back(r);
+    }
+    ~ProfScope() { if (on) hipEventRecord(g_prof.back().e1, st); }
+};
+
 template <int WM, int WN, int MODE>
 int launch_conv(const ConvParams& p, hipStream_t st) {
     constexpr int CO_T = 32 * WM;
@@ -412,10 +437,13 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     dim3 grid(p.tiles_x * p.tiles_y, p.co_tiles, p.d.n * p.ksplit);
     const int nt = p.d.ntaps;
     if (pipe && nt == 9) {
+        ProfScope ps(st, WM, WN, MODE, 1, 9, p);
         hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE, true, 9>), grid, dim3(256), lds, st, p);
     } else if (pipe && nt == 1 && MODE == 0) {
+        ProfScope ps(st, WM, WN, MODE, 1, 1, p);
         hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE == 1 ? 0 : MODE, true, 1>), grid, dim3(256), lds, st, p);
     } else {
+        ProfScope ps(st, WM, WN, MODE, 0, nt == 9 ? 9 : 0, p);
         // un-pipelined staging: large footprints (strided convs, 4x4 maps) and unusual tap counts
         auto kern9 = conv_taps_kernel<WM, WN, MODE, false, 9>;
         auto kern0 = conv_taps_kernel<WM, WN, MODE == 1 ? 0 : MODE, false, 0>;
@@ -463,6 +491,32 @@ __global__ void pack_weights_kernel(float* wp, float* wsq, const float* w, int c
 }
 
 }  // namespace
+
+extern "C" int mgf_conv_profile_begin(void) {
+    for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = true;
+    return MGF_OK;
+}
+
+extern "C" int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs) {
+    g_prof_on = false;
+    int n = 0;
+    for (auto& r : g_prof) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) { mgf_set_error("conv_profile_end: event sync failed"); return MGF_ELAUNCH; }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (out && n < max_recs) {
+            mgf_conv_prof_rec& o = out[n];
+            snprintf(o.kernel, sizeof(o.kernel), "conv_taps_kernel<%d, %d, %d, %s, %d>", r.wm, r.wn, r.mode, r.pipe ? "true" : "false", r.nt);
+            o.flops = r.flops; o.seconds = ms * 1e-3; o.ksplit = r.ksplit;
+        }
+        ++n;
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    return n;
+}
 
 extern "C" int mgf_pack_conv_weights(float* wp, float* wsq, const float* w, int32_t cout, int32_t cin, int32_t kh, int32_t kw,
                                      int32_t cout_pad, float gain, int32_t flip, mgf_stream_t stream) {
