@@ -12,7 +12,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmgf_hip.so")
+LIB_PATH = os.environ.get("MGF_LIB_PATH") or os.path.join(HERE, "libmgf_hip.so")     # env override: kernel experiments only
 
 MGF_F32, MGF_F64, MGF_F16 = 0, 1, 2
 ACT_IDS = {"linear": 1, "relu": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5, "elu": 6, "selu": 7, "softplus": 8, "swish": 9}

@@ -39,6 +39,10 @@ template <int WM, int WN> struct Slots {
     static constexpr int WS = WM == 2 ? 5 : 3;        // 9*8*64/4 = 1152 float4; 9*8*32/4 = 576
 };
 
+// table of ones used as the modulation vector when a launch has no in_scale (keeps the staging code branch-free)
+struct Ones { float v[2048]; constexpr Ones() : v() { for (int i = 0; i < 2048; ++i) v[i] = 1.0f; } };
+__device__ const Ones g_ones = Ones();
+
 struct ConvParams {
     float* y;
     const float* x;
@@ -89,7 +93,9 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     const int chs = p.fh * p.fw;                 // LDS channel stride of Xs
     const int xs_floats = CK * chs;
     const int ws_floats = T * CK * CO_T;
-    const int buf_floats = xs_floats + ws_floats;
+    // pipelined mode pads both LDS regions to whole staging slots (branch-free register -> LDS copies)
+    const int xs_region = PIPE ? Slots<WM, WN>::XS * 256 : xs_floats;
+    const int buf_floats = PIPE ? xs_region + Slots<WM, WN>::WS * 1024 : xs_floats + ws_floats;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -141,7 +147,19 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     // -1 = zero padding, -2 = no such element.  W slot j covers float4 i = tid + 256*j -> (t, ch, c4) with compile-time divisors.
     constexpr int XS = Slots<WM, WN>::XS, WS = Slots<WM, WN>::WS;
     int xoff[XS];
+    int woff[WS], wch[WS];
+    const float* scp = sc ? sc : g_ones.v;           // no modulation: multiply by a table of ones (branch-free staging)
+    const int scmask = sc ? ~0 : 2047;
     if (PIPE) {
+#pragma unroll
+        for (int j = 0; j < WS; ++j) {
+            int i = tid + 256 * j;
+            if (i >= wsz4) i = wsz4 - 1;              // surplus slots re-read the last row into the padded LDS tail
+            const int c4 = i % wrow4;
+            const int rest = i / wrow4;
+            wch[j] = rest % CK;
+            woff[j] = ((rest / CK) * d.cin + wch[j]) * d.cout_pad + co0 + c4 * 4;
+        }
         // (ch, r, q) of slot 0 by division once, then advanced by 256 elements per slot with carries (no division per slot)
         int ch = tid / chs;
         int r = (tid - ch * chs) / p.fw;
@@ -151,7 +169,8 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         for (int j = 0; j < XS; ++j) {
             const int i = tid + 256 * j;
             const int iy = iy0 + r, ix = ix0 + q;
-            xoff[j] = i >= xs_floats ? -2 : (iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) ? ch * plane + iy * d.in_w + ix : -1;
+            // -1 = zero padding (also for the surplus slots past the footprint, which land in the padded LDS tail)
+            xoff[j] = (i < xs_floats && iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) ? ch * plane + iy * d.in_w + ix : -1;
             q += dq; r += dr;
             if (q >= p.fw) { q -= p.fw; ++r; }
             if (r >= p.fh) { r -= p.fh; ++ch; }
@@ -163,32 +182,32 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
 
     // global -> registers for the (full) chunk starting at channel c0.  The style modulation s[ci] is applied to the weight
     // rows (exactly the reference's w * s, networks.py:289) because their channel index is a compile-time function of the slot.
+    // load_chunk issues ONLY loads (every address is valid: padding slots read element 0 and are zeroed at store time), so no
+    // instruction that consumes a loaded value -- and hence no s_waitcnt vmcnt -- sits between the loads and the MFMA phase.
+    float wsc[WS];
     auto load_chunk = [&](int c0) {
         const float* xc = xn + (int64_t)c0 * plane;
+        const float* wc = p.wp + (int64_t)c0 * d.cout_pad;
 #pragma unroll
-        for (int j = 0; j < XS; ++j) xr[j] = xoff[j] >= 0 ? xc[xoff[j]] : 0.f;
+        for (int j = 0; j < XS; ++j) xr[j] = xc[xoff[j] > 0 ? xoff[j] : 0];
 #pragma unroll
         for (int j = 0; j < WS; ++j) {
-            const int i = tid + 256 * j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < wsz4) {
-                const int c4 = i % wrow4;
-                const int rest = i / wrow4;
-                const int ch = rest % CK, t = rest / CK;
-                v = *reinterpret_cast<const float4*>(p.wp + ((int64_t)t * d.cin + c0 + ch) * d.cout_pad + co0 + c4 * 4);
-                if (sc) { const float sv = sc[c0 + ch]; v.x *= sv; v.y *= sv; v.z *= sv; v.w *= sv; }
-            }
-            wr[j] = v;
+            wr[j] = *reinterpret_cast<const float4*>(wc + woff[j]);
+            wsc[j] = scp[(c0 + wch[j]) & scmask];
         }
     };
-    auto store_chunk = [&](float* buf) {                 // registers -> LDS
+    // registers -> LDS, branch-free: in pipelined mode the X / W regions are padded to XS*256 floats / WS*256 float4, so every
+    // slot has an address of its own; zero padding and the style modulation are applied here
+    auto store_chunk = [&](float* buf) {
 #pragma unroll
-        for (int j = 0; j < XS; ++j)
-            if (xoff[j] != -2) buf[tid + 256 * j] = xr[j];
-        float* Wd = buf + xs_floats;
+        for (int j = 0; j < XS; ++j) buf[tid + 256 * j] = xoff[j] >= 0 ? xr[j] : 0.f;
+        float* Wd = buf + xs_region;
 #pragma unroll
-        for (int j = 0; j < WS; ++j)
-            if (tid + 256 * j < wsz4) *reinterpret_cast<float4*>(Wd + (tid + 256 * j) * 4) = wr[j];
+        for (int j = 0; j < WS; ++j) {
+            float4 v = wr[j];
+            v.x *= wsc[j]; v.y *= wsc[j]; v.z *= wsc[j]; v.w *= wsc[j];
+            *reinterpret_cast<float4*>(Wd + (tid + 256 * j) * 4) = v;
+        }
     };
     auto stage_direct = [&](int c0, float* buf) {        // un-pipelined fallback for footprints that exceed the slot budget
         for (int i = tid; i < xs_floats; i += 256) {
@@ -203,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
             }
             buf[i] = v;
         }
-        float* Wd = buf + xs_floats;
+        float* Wd = buf + xs_region;
         for (int i = tid; i < wsz4; i += 256) {
             const int c4 = i % wrow4;
             const int rest = i / wrow4;
@@ -218,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     // consume them (two sets, statically indexed after unrolling), so the matrix pipe never waits on an LDS round trip.
     auto mfma_chunk = [&](const float* buf) {
         const float* Xs = buf + half * chs;                       // lane halves read channels 2kk and 2kk+1
-        const float* Ws = buf + xs_floats + half * CO_T + l31;
+        const float* Ws = buf + xs_region + half * CO_T + l31;
         float fa[2][CK / 2][WM], fb[2][CK / 2][WN];
         auto fetch = [&](int t, int set) {
 #pragma unroll
@@ -242,7 +261,16 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                     for (int m = 0; m < WM; ++m)
 #pragma unroll
                         for (int g = 0; g < WN; ++g)
+#if defined(MGF_EXP) && MGF_EXP == 1      // experiment: no matrix work (operands kept live), measures everything else
+                            asm volatile("" ::"v"(fa[t & 1][kk][m]), "v"(fb[t & 1][kk][g]));
+#elif defined(MGF_EXP) && MGF_EXP == 2    // experiment: twice the matrix work
+                        {
                             acc[q][m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][kk][m], fb[t & 1][kk][g], acc[q][m][g], 0, 0, 0);
+                            acc[q][m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][kk][m], fb[t & 1][kk][g], acc[q][m][g], 0, 0, 0);
+                        }
+#else
+                            acc[q][m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][kk][m], fb[t & 1][kk][g], acc[q][m][g], 0, 0, 0);
+#endif
             }
         } else {
             for (int t = 0; t < T; ++t) {                         // generic tap count (e.g. 2x2, 1x3): not pipelined
@@ -418,11 +446,11 @@ struct ProfScope {
         // counted at its own cost, 2*9*cin*cout per INPUT pixel
         r.flops = mode == 1 ? 2.0 * 9 * d.cin * (double)d.cout * d.in_h * d.in_w * d.n
                             : 2.0 * d.ntaps * d.cin * (double)d.cout * d.tile_h * d.tile_w * d.n;
-        hipEventCreate(&r.e0); hipEventCreate(&r.e1);
-        hipEventRecord(r.e0, st);
+        (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+        (void)hipEventRecord(r.e0, st);
         g_prof.push_back(r);
     }
-    ~ProfScope() { if (on) hipEventRecord(g_prof.back().e1, st); }
+    ~ProfScope() { if (on) (void)hipEventRecord(g_prof.back().e1, st); }
 };
 
 template <int WM, int WN, int MODE>
@@ -430,9 +458,9 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     constexpr int CO_T = 32 * WM;
     const size_t buf = ((size_t)CK * p.fh * p.fw + (size_t)p.d.ntaps * CK * CO_T) * sizeof(float);
     const bool pipe = (size_t)CK * p.fh * p.fw <= (size_t)Slots<WM, WN>::XS * 256 &&
-                      (size_t)p.d.ntaps * CK * CO_T / 4 <= (size_t)Slots<WM, WN>::WS * 256 && 2 * buf <= 64 * 1024 &&
+                      (size_t)p.d.ntaps * CK * CO_T / 4 <= (size_t)Slots<WM, WN>::WS * 256 &&
                       256 / p.fw + 2 <= 2 * p.fh;     // slot walk: at most two row wraps per 256-element step
-    const size_t lds = pipe ? 2 * buf : buf;
+    const size_t lds = pipe ? 2 * ((size_t)Slots<WM, WN>::XS * 256 + (size_t)Slots<WM, WN>::WS * 1024) * sizeof(float) : buf;
     if (lds > 160 * 1024) { mgf_set_error("conv_taps: tile needs %zu bytes of LDS (> 160 KiB)", lds); return MGF_EUNSUPPORTED; }
     dim3 grid(p.tiles_x * p.tiles_y, p.co_tiles, p.d.n * p.ksplit);
     const int nt = p.d.ntaps;
@@ -493,7 +521,7 @@ __global__ void pack_weights_kernel(float* wp, float* wsq, const float* w, int c
 }  // namespace
 
 extern "C" int mgf_conv_profile_begin(void) {
-    for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.clear();
     g_prof_on = true;
     return MGF_OK;
@@ -505,14 +533,14 @@ extern "C" int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs) {
     for (auto& r : g_prof) {
         if (hipEventSynchronize(r.e1) != hipSuccess) { mgf_set_error("conv_profile_end: event sync failed"); return MGF_ELAUNCH; }
         float ms = 0.f;
-        hipEventElapsedTime(&ms, r.e0, r.e1);
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
         if (out && n < max_recs) {
             mgf_conv_prof_rec& o = out[n];
             snprintf(o.kernel, sizeof(o.kernel), "conv_taps_kernel<%d, %d, %d, %s, %d>", r.wm, r.wn, r.mode, r.pipe ? "true" : "false", r.nt);
             o.flops = r.flops; o.seconds = ms * 1e-3; o.ksplit = r.ksplit;
         }
         ++n;
-        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
     g_prof.clear();
     return n;
@@ -575,6 +603,12 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     if (mode == 0) {
         if (d.cout_pad % 64 == 0 && d.cout > 32) { wm = 2; wn = 2; }
         else if ((int64_t)d.tile_h * d.tile_w >= 512 * 64) { wm = 1; wn = 4; }
+        // tuning hook (experiments only): MGF_CONV_TILE=wm,wn forces the tile of MODE-0 launches
+        static const char* force = getenv("MGF_CONV_TILE");
+        if (force && force[0] && force[1] == ',' && force[2]) {
+            const int fm = force[0] - '0', fn = force[2] - '0';
+            if ((fm == 2 && fn == 2 && d.cout_pad % 64 == 0) || (fm == 1 && (fn == 2 || fn == 4))) { wm = fm; wn = fn; }
+        }
     }
     const int PX = 128 * wn;
     const int rows = PX / TW;
