@@ -59,6 +59,7 @@ struct ConvParams {
     int co_tiles;
     int ksplit;           // number of K slices (1 = direct)
     int chunks_per_split;
+    int off32_ok;         // one sample of y (and of the split-K slab) spans < 2^30 elements: 32-bit store offsets are safe
     float* partial;       // [ksplit][n][cout][out_h][y_pitch] when ksplit > 1
 };
 
@@ -80,7 +81,14 @@ __device__ __forceinline__ float epi(const mgf_epilogue& ep, float v, int n, int
 // parity group of tap t (t = kh*3 + kw) for the stride-2 transposed conv: kh (kw) == 1 feeds odd rows (cols)
 __host__ __device__ constexpr int tconv_group(int t) { return ((t / 3) == 1 ? 2 : 0) + ((t % 3) == 1 ? 1 : 0); }
 
-// NT = compile-time tap count (9 = 3x3, 1 = 1x1; 0 = any count read from the descriptor at run time)
+struct TileCtx { int n, ks, co0, ty0, tx0, c_begin, c_end; };
+
+// NT = compile-time tap count (9 = 3x3, 1 = 1x1; 0 = any count read from the descriptor at run time).
+// Work items = (sample, K slice, pixel tile, channel tile), channel tile fastest.  PIPE kernels are PERSISTENT: a 1-D grid of
+// at most (workgroups per CU) x 256 workgroups walks the item list with stride gridDim.x, and the register/LDS pipeline runs
+// ACROSS item boundaries -- the first chunk of the next tile is prefetched behind the last MFMA phase of the current one and
+// the epilogue's stores drain while the next tile computes -- so HBM traffic and matrix work overlap chip-wide instead of
+// alternating in lock-step bursts.  Non-PIPE kernels take one item per workgroup and stage synchronously.
 template <int WM, int WN, int MODE, bool PIPE, int NT>
 __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     constexpr int CO_T = 32 * WM, PX = 128 * WN, NG = MODE == 1 ? 4 : 1;
@@ -92,65 +100,70 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     for (int t = 0; t < MGF_MAX_TAPS; ++t) toffs[t] = t < T ? (d.dy[t] - p.dy_min) * p.fw + (d.dx[t] - p.dx_min) : 0;
     const int chs = p.fh * p.fw;                 // LDS channel stride of Xs
     const int xs_floats = CK * chs;
-    const int ws_floats = T * CK * CO_T;
     // pipelined mode pads both LDS regions to whole staging slots (branch-free register -> LDS copies)
     const int xs_region = PIPE ? Slots<WM, WN>::XS * 256 : xs_floats;
-    const int buf_floats = PIPE ? xs_region + Slots<WM, WN>::WS * 1024 : xs_floats + ws_floats;
+    const int buf_floats = PIPE ? xs_region + Slots<WM, WN>::WS * 1024 : xs_floats + T * CK * CO_T;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-
-    const int n = blockIdx.z / p.ksplit, ks = blockIdx.z - n * p.ksplit;
-    const int co0 = blockIdx.y * CO_T;
-    const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
+    const int l31_ = l31, half_ = half;
     const int TW = 1 << p.tw_log2;
     const int rows = PX >> p.tw_log2;
-    const int ty0 = tile_y * rows, tx0 = tile_x * TW;
-    const int iy0 = ty0 * d.istride + p.dy_min, ix0 = tx0 * d.istride + p.dx_min;   // top-left input sample of the footprint
-
-    // channel range of this K slice
-    const int c_begin = ks * p.chunks_per_split * CK;
-    int c_end = c_begin + p.chunks_per_split * CK;
-    if (c_end > d.cin) c_end = d.cin;
-    const int nchunks = (c_end - c_begin + CK - 1) / CK;
-
-    // per-lane LDS base offset of each of this wave's WN pixel groups, and group validity (wave-uniform)
-    int pbase[WN];
-    bool gvalid[WN];
-#pragma unroll
-    for (int g = 0; g < WN; ++g) {
-        const int pix = (wave * WN + g) * 32 + l31;
-        const int ty = pix >> p.tw_log2, tx = pix & (TW - 1);
-        pbase[g] = ty * d.istride * p.fw + tx * d.istride;
-        const int ty_first = ((wave * WN + g) * 32) >> p.tw_log2;
-        gvalid[g] = (ty0 + ty_first) < d.tile_h;
-    }
-
-    f32x16 acc[NG][WM][WN];
-#pragma unroll
-    for (int q = 0; q < NG; ++q)
-#pragma unroll
-        for (int m = 0; m < WM; ++m)
-#pragma unroll
-            for (int g = 0; g < WN; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[q][m][g][r] = 0.f;
-
-    const float* xn = p.x + (int64_t)n * d.cin * d.in_h * d.in_w;
-    const float* sc = p.in_scale ? p.in_scale + (int64_t)n * d.cin : nullptr;
+    const int ptiles = p.tiles_x * p.tiles_y;
+    const int total_items = ptiles * p.co_tiles * d.n * p.ksplit;
     const int plane = d.in_h * d.in_w;
     const int wrow4 = CO_T / 4;                       // float4 per weight row
     const int wsz4 = T * CK * wrow4;
 
-    // ---- chunk-invariant staging slots (pipelined path; full chunks only) ----
-    // X slot j covers LDS element i = tid + 256*j -> (ch, r, q); xoff = offset inside the chunk's channel block,
-    // -1 = zero padding, -2 = no such element.  W slot j covers float4 i = tid + 256*j -> (t, ch, c4) with compile-time divisors.
+    auto decode = [&](int w, TileCtx& c) {
+        const int cot = w % p.co_tiles;
+        int r = w / p.co_tiles;
+        const int pt = r % ptiles;
+        r /= ptiles;
+        c.ks = r % p.ksplit;
+        c.n = r / p.ksplit;
+        c.co0 = cot * CO_T;
+        c.ty0 = (pt / p.tiles_x) * rows;
+        c.tx0 = (pt % p.tiles_x) * TW;
+        c.c_begin = c.ks * p.chunks_per_split * CK;
+        c.c_end = c.c_begin + p.chunks_per_split * CK;
+        if (c.c_end > d.cin) c.c_end = d.cin;
+    };
+
+    // per-lane LDS base offset of each of this wave's WN pixel groups (tile independent)
+    int pbase[WN];
+#pragma unroll
+    for (int g = 0; g < WN; ++g) {
+        const int pix = (wave * WN + g) * 32 + l31;
+        pbase[g] = (pix >> p.tw_log2) * d.istride * p.fw + (pix & (TW - 1)) * d.istride;
+    }
+
+    f32x16 acc[NG][WM][WN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int q = 0; q < NG; ++q)
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int g = 0; g < WN; ++g)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[q][m][g][r] = 0.f;
+    };
+    zero_acc();
+
+    // ---- staging state of the tile being LOADED (pipelined path): chunk-invariant per-lane slots ----
+    // X slot j covers LDS element i = tid + 256*j -> (ch, r, q); xoff = offset inside the chunk's channel block, -1 = zero
+    // padding (also the surplus slots past the footprint, which land in the padded LDS tail).  W slot j covers float4
+    // i = tid + 256*j -> (t, ch, c4).
     constexpr int XS = Slots<WM, WN>::XS, WS = Slots<WM, WN>::WS;
     int xoff[XS];
     int woff[WS], wch[WS];
-    const float* scp = sc ? sc : g_ones.v;           // no modulation: multiply by a table of ones (branch-free staging)
-    const int scmask = sc ? ~0 : 2047;
-    if (PIPE) {
+    const float* xn_l = p.x;
+    const float* scp_l = g_ones.v;                   // no modulation: multiply by a table of ones (branch-free staging)
+    int scmask_l = 2047;
+    auto setup_slots = [&](const TileCtx& c) {
+        xn_l = p.x + (int64_t)c.n * d.cin * plane;
+        if (p.in_scale) { scp_l = p.in_scale + (int64_t)c.n * d.cin; scmask_l = ~0; }
 #pragma unroll
         for (int j = 0; j < WS; ++j) {
             int i = tid + 256 * j;
@@ -158,9 +171,10 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
             const int c4 = i % wrow4;
             const int rest = i / wrow4;
             wch[j] = rest % CK;
-            woff[j] = ((rest / CK) * d.cin + wch[j]) * d.cout_pad + co0 + c4 * 4;
+            woff[j] = ((rest / CK) * d.cin + wch[j]) * d.cout_pad + c.co0 + c4 * 4;
         }
         // (ch, r, q) of slot 0 by division once, then advanced by 256 elements per slot with carries (no division per slot)
+        const int iy0 = c.ty0 * d.istride + p.dy_min, ix0 = c.tx0 * d.istride + p.dx_min;
         int ch = tid / chs;
         int r = (tid - ch * chs) / p.fw;
         int q = tid - ch * chs - r * p.fw;
@@ -169,36 +183,31 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         for (int j = 0; j < XS; ++j) {
             const int i = tid + 256 * j;
             const int iy = iy0 + r, ix = ix0 + q;
-            // -1 = zero padding (also for the surplus slots past the footprint, which land in the padded LDS tail)
             xoff[j] = (i < xs_floats && iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) ? ch * plane + iy * d.in_w + ix : -1;
             q += dq; r += dr;
             if (q >= p.fw) { q -= p.fw; ++r; }
             if (r >= p.fh) { r -= p.fh; ++ch; }
             if (r >= p.fh) { r -= p.fh; ++ch; }        // 256 / fw + 1 < 2 * fh for every tile geometry the host picks
         }
-    }
+    };
     float xr[XS];
     float4 wr[WS];
-
-    // global -> registers for the (full) chunk starting at channel c0.  The style modulation s[ci] is applied to the weight
-    // rows (exactly the reference's w * s, networks.py:289) because their channel index is a compile-time function of the slot.
+    float wsc[WS];
     // load_chunk issues ONLY loads (every address is valid: padding slots read element 0 and are zeroed at store time), so no
     // instruction that consumes a loaded value -- and hence no s_waitcnt vmcnt -- sits between the loads and the MFMA phase.
-    float wsc[WS];
+    // The style modulation s[ci] is applied to the weight rows (the reference's w * s, networks.py:289) at store time.
     auto load_chunk = [&](int c0) {
-        const float* xc = xn + (int64_t)c0 * plane;
+        const float* xc = xn_l + (int64_t)c0 * plane;
         const float* wc = p.wp + (int64_t)c0 * d.cout_pad;
 #pragma unroll
         for (int j = 0; j < XS; ++j) xr[j] = xc[xoff[j] > 0 ? xoff[j] : 0];
 #pragma unroll
         for (int j = 0; j < WS; ++j) {
             wr[j] = *reinterpret_cast<const float4*>(wc + woff[j]);
-            wsc[j] = scp[(c0 + wch[j]) & scmask];
+            wsc[j] = scp_l[(c0 + wch[j]) & scmask_l];
         }
     };
-    // registers -> LDS, branch-free: in pipelined mode the X / W regions are padded to XS*256 floats / WS*256 float4, so every
-    // slot has an address of its own; zero padding and the style modulation are applied here
-    auto store_chunk = [&](float* buf) {
+    auto store_chunk = [&](float* buf) {              // registers -> LDS, branch-free (padded regions)
 #pragma unroll
         for (int j = 0; j < XS; ++j) buf[tid + 256 * j] = xoff[j] >= 0 ? xr[j] : 0.f;
         float* Wd = buf + xs_region;
@@ -209,14 +218,17 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
             *reinterpret_cast<float4*>(Wd + (tid + 256 * j) * 4) = v;
         }
     };
-    auto stage_direct = [&](int c0, float* buf) {        // un-pipelined fallback for footprints that exceed the slot budget
+    auto stage_direct = [&](const TileCtx& c, int c0, float* buf) {   // synchronous staging (non-pipelined kernels)
+        const float* xn = p.x + (int64_t)c.n * d.cin * plane;
+        const float* sc = p.in_scale ? p.in_scale + (int64_t)c.n * d.cin : nullptr;
+        const int iy0 = c.ty0 * d.istride + p.dy_min, ix0 = c.tx0 * d.istride + p.dx_min;
         for (int i = tid; i < xs_floats; i += 256) {
             const int ch = i / chs;
             const int rem = i - ch * chs;
             const int r = rem / p.fw, q = rem - r * p.fw;
             const int ci = c0 + ch, iy = iy0 + r, ix = ix0 + q;
             float v = 0.f;
-            if (ci < c_end && iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) {
+            if (ci < c.c_end && iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) {
                 v = xn[((int64_t)ci * d.in_h + iy) * d.in_w + ix];
                 if (sc) v *= sc[ci];
             }
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
             const int ch = rest % CK, t = rest / CK;
             const int ci = c0 + ch;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < c_end) v = *reinterpret_cast<const float4*>(p.wp + ((int64_t)t * d.cin + ci) * d.cout_pad + co0 + c4 * 4);
+            if (ci < c.c_end) v = *reinterpret_cast<const float4*>(p.wp + ((int64_t)t * d.cin + ci) * d.cout_pad + c.co0 + c4 * 4);
             *reinterpret_cast<float4*>(Wd + i * 4) = v;
         }
     };
@@ -238,17 +250,17 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     auto mfma_chunk = [&](const float* buf) {
         const float* Xs = buf + half * chs;                       // lane halves read channels 2kk and 2kk+1
         const float* Ws = buf + xs_region + half * CO_T + l31;
-        float fa[2][CK / 2][WM], fb[2][CK / 2][WN];
-        auto fetch = [&](int t, int set) {
-#pragma unroll
-            for (int kk = 0; kk < CK / 2; ++kk) {
-#pragma unroll
-                for (int m = 0; m < WM; ++m) fa[set][kk][m] = Ws[(t * CK + 2 * kk) * CO_T + m * 32];
-#pragma unroll
-                for (int g = 0; g < WN; ++g) fb[set][kk][g] = Xs[2 * kk * chs + pbase[g] + toffs[t]];
-            }
-        };
         if (NT > 0) {
+            float fa[2][CK / 2][WM], fb[2][CK / 2][WN];
+            auto fetch = [&](int t, int set) {
+#pragma unroll
+                for (int kk = 0; kk < CK / 2; ++kk) {
+#pragma unroll
+                    for (int m = 0; m < WM; ++m) fa[set][kk][m] = Ws[(t * CK + 2 * kk) * CO_T + m * 32];
+#pragma unroll
+                    for (int g = 0; g < WN; ++g) fb[set][kk][g] = Xs[2 * kk * chs + pbase[g] + toffs[t]];
+                }
+            };
             fetch(0, 0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -292,95 +304,167 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         }
     };
 
-    if (PIPE) {
-        // chunks whose 8 channels all exist go through the register pipeline; a ragged last chunk (cin % 8 != 0) is staged directly
-        const int nfull = (c_end - c_begin) / CK;
-        if (nfull > 0) {
-            load_chunk(c_begin);
-            store_chunk(lds);
-        }
-        __syncthreads();
-        for (int c = 0; c < nfull; ++c) {
-            float* cur = lds + (c & 1) * buf_floats;
-            float* nxt = lds + ((c + 1) & 1) * buf_floats;
-            const bool more = c + 1 < nfull;
-            if (more) load_chunk(c_begin + (c + 1) * CK);      // in flight behind the MFMAs below
-            mfma_chunk(cur);
-            if (more) store_chunk(nxt);
-            __syncthreads();
-        }
-        if (nfull < nchunks) {
-            stage_direct(c_begin + nfull * CK, lds);
-            __syncthreads();
-            mfma_chunk(lds);
-        }
-    } else {
-        for (int c = 0; c < nchunks; ++c) {
-            __syncthreads();
-            stage_direct(c_begin + c * CK, lds);
-            __syncthreads();
-            mfma_chunk(lds);
-        }
-    }
-
-    // ---- epilogue: demodulate, noise/bias/activation/gain/residual, store (or raw partial store when split-K) ----
+    // ---- epilogue of one finished tile: demodulate, noise/bias/activation/gain/residual, store (raw partial store when split-K) ----
     const bool partial = p.ksplit > 1;
-    float* yn = partial ? p.partial + ((int64_t)ks * d.n + n) * ((int64_t)d.cout * d.out_h * d.y_pitch) : p.y + (int64_t)n * d.y_batch;
-    const int64_t y_plane = partial ? (int64_t)d.out_h * d.y_pitch : d.y_plane;
-    const int choff = partial ? 0 : d.y_choff;
-    const float* osc = (p.out_scale && !partial) ? p.out_scale + (int64_t)n * d.out_scale_stride : nullptr;
     const bool do_ep = p.has_ep && !partial;
     const float ep_ns = (do_ep && p.ep.noise) ? (p.ep.noise_strength ? *p.ep.noise_strength : 1.0f) : 0.f;
-#pragma unroll
-    for (int g = 0; g < WN; ++g) {
-        if (!gvalid[g]) continue;
-        const int pix = (wave * WN + g) * 32 + l31;
-        const int ty = ty0 + (pix >> p.tw_log2), tx = tx0 + (pix & (TW - 1));
-        const bool pvalid = ty < d.tile_h && tx < d.tile_w;
-        if (MODE == 0) {
-            // one output pixel per lane, 16 channels per (m) across the registers: gather every operand of the 16 outputs first
-            // (independent loads in flight together), then compute, then store -- no load ever waits behind a store.
-            const int oy = ty * d.ostride + d.oy[0], ox = tx * d.ostride + d.ox[0];
-            const bool ovalid = pvalid && oy < d.out_h && ox < d.out_w;
-            const int64_t off = (int64_t)oy * d.y_pitch + ox;
-            float nz = 0.f;
-            if (do_ep && p.ep.noise && ovalid) nz = p.ep.noise[((int64_t)(p.ep.noise_n > 1 ? n : 0) * d.out_h + oy) * d.out_w + ox] * ep_ns;
+    auto epilogue = [&](const TileCtx& c) {
+        const int n = c.n, co0 = c.co0;
+        // opaque copies of the lane coordinates: keeps the compiler from hoisting the epilogue's per-lane address arithmetic
+        // out of the persistent tile loop, where it would sit in VGPRs across the MFMA phases
+        int half = half_, l31 = l31_;
+        asm volatile("" : "+v"(half), "+v"(l31));
+        float* yn = partial ? p.partial + ((int64_t)c.ks * d.n + n) * ((int64_t)d.cout * d.out_h * d.y_pitch) : p.y + (int64_t)n * d.y_batch;
+        const int64_t y_plane = partial ? (int64_t)d.out_h * d.y_pitch : d.y_plane;
+        const int choff = partial ? 0 : d.y_choff;
+        const float* osc = (p.out_scale && !partial) ? p.out_scale + (int64_t)n * d.out_scale_stride : nullptr;
+        // Fast path (every interior tile of a layer whose channel count fills the tile): no per-element predication and
+        // 32-bit per-lane offsets from wave-uniform base pointers, i.e. one VALU add per global access instead of 64-bit
+        // multiply/add chains -- the epilogue is instruction-issue bound otherwise.
+        const bool fast = p.off32_ok && co0 + CO_T <= d.cout && c.ty0 + rows <= d.tile_h && c.tx0 + TW <= d.tile_w &&
+                          (c.ty0 + rows - 1) * d.ostride + (MODE == 1 ? 1 : d.oy[0]) < d.out_h &&
+                          (c.tx0 + TW - 1) * d.ostride + (MODE == 1 ? 1 : d.ox[0]) < d.out_w;
+        if (fast) {
+            const uint32_t plane32 = (uint32_t)y_plane, pitch32 = (uint32_t)d.y_pitch;
+            float* ybase = yn + (int64_t)(choff + co0) * y_plane;                                   // wave-uniform
+            const float* rbase = (do_ep && p.ep.residual) ? p.ep.residual + (int64_t)n * d.y_batch + (int64_t)(choff + co0) * y_plane : nullptr;
+            const float* obase = osc ? osc + co0 : nullptr;
+            const float* bbase = (do_ep && p.ep.bias) ? p.ep.bias + co0 : nullptr;
+            const float* nbase = (do_ep && p.ep.noise) ? p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * d.out_h * d.out_w : nullptr;
+            const uint32_t hoff = (uint32_t)(4 * half) * plane32;
 #pragma unroll
             for (int m = 0; m < WM; ++m) {
-                float osv[16], bv[16], rv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const bool ok = ovalid && co < d.cout;
-                    osv[r] = (osc && co < d.cout) ? osc[co] : 1.0f;
-                    bv[r] = (do_ep && p.ep.bias && co < d.cout) ? p.ep.bias[co] : 0.f;
-                    rv[r] = (do_ep && p.ep.residual && ok) ? p.ep.residual[(int64_t)n * d.y_batch + (int64_t)(choff + co) * y_plane + off] : 0.f;
-                }
+                for (int hh = 0; hh < 2; ++hh) {
+                    float osv[8], bv[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    float v = acc[0][m][g][r] * osv[r];
-                    if (do_ep) {
-                        v += nz;
-                        v += bv[r];
-                        if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
-                        else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
-                        v = v * p.ep.gain + rv[r];
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int cl = m * 32 + ((hh * 8 + r8) & 3) + 8 * ((hh * 8 + r8) >> 2) + 4 * half;   // channel inside the tile
+                        osv[r8] = obase ? obase[cl] : 1.0f;
+                        bv[r8] = bbase ? bbase[cl] : 0.f;
                     }
-                    if (ovalid && co < d.cout) yn[(int64_t)(choff + co) * y_plane + off] = v;
+#pragma unroll
+                    for (int g = 0; g < WN; ++g) {
+                        const int pix = (wave * WN + g) * 32 + l31;
+                        const uint32_t ty = c.ty0 + (pix >> p.tw_log2), tx = c.tx0 + (pix & (TW - 1));
+                        if (MODE == 0) {
+                            const uint32_t oy = ty * d.ostride + d.oy[0], ox = tx * d.ostride + d.ox[0];
+                            const uint32_t og = oy * pitch32 + ox + hoff;
+                            const float nz = nbase ? nbase[oy * (uint32_t)d.out_w + ox] * ep_ns : 0.f;
+                            float rv[8];
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) {
+                                const uint32_t cu = m * 32 + ((hh * 8 + r8) & 3) + 8 * ((hh * 8 + r8) >> 2);
+                                rv[r8] = rbase ? rbase[og + cu * plane32] : 0.f;
+                            }
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) {
+                                const uint32_t cu = m * 32 + ((hh * 8 + r8) & 3) + 8 * ((hh * 8 + r8) >> 2);
+                                float v = acc[0][m][g][hh * 8 + r8] * osv[r8];
+                                if (do_ep) {
+                                    v += nz;
+                                    v += bv[r8];
+                                    if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
+                                    else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+                                    v = v * p.ep.gain + rv[r8];
+                                }
+                                ybase[og + cu * plane32] = v;
+                            }
+                        } else {
+                            // parity sets: q = 2*a + b -> row 2*ty + a, cols 2*tx + {0,1} written as an aligned pair
+                            const uint32_t og = (2 * ty) * pitch32 + 2 * tx + hoff;
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) {
+                                const uint32_t cu = m * 32 + ((hh * 8 + r8) & 3) + 8 * ((hh * 8 + r8) >> 2);
+#pragma unroll
+                                for (int a2 = 0; a2 < 2; ++a2) {
+                                    const float v0 = acc[NG == 4 ? 2 * a2 : 0][m][g][hh * 8 + r8] * osv[r8];
+                                    const float v1 = acc[NG == 4 ? 2 * a2 + 1 : 0][m][g][hh * 8 + r8] * osv[r8];
+                                    *reinterpret_cast<float2*>(ybase + (og + cu * plane32 + a2 * pitch32)) = make_float2(v0, v1);
+                                }
+                            }
+                        }
+                    }
                 }
             }
-            continue;
+            return;
+        }
+        if (MODE == 0) {
+            // One output pixel per lane, 16 channels per 32-channel tile across the accumulator registers.  Work in half
+            // tiles of 8 registers to bound live temporaries: per-channel operands (demodulation, bias) are fetched once per
+            // half tile, the residual values of the 8 outputs are gathered together (independent loads in flight), then the
+            // 8 results are computed and stored -- no load ever waits behind a store.
+            float nzv[WN];
+            bool ovalid[WN];
+            int64_t offv[WN];
+#pragma unroll
+            for (int g = 0; g < WN; ++g) {
+                const int ty_first = ((wave * WN + g) * 32) >> p.tw_log2;
+                const int pix = (wave * WN + g) * 32 + l31;
+                const int ty = c.ty0 + (pix >> p.tw_log2), tx = c.tx0 + (pix & (TW - 1));
+                const int oy = ty * d.ostride + d.oy[0], ox = tx * d.ostride + d.ox[0];
+                ovalid[g] = (c.ty0 + ty_first < d.tile_h) && ty < d.tile_h && tx < d.tile_w && oy < d.out_h && ox < d.out_w;
+                offv[g] = (int64_t)oy * d.y_pitch + ox;
+                nzv[g] = 0.f;
+                if (do_ep && p.ep.noise && ovalid[g])
+                    nzv[g] = p.ep.noise[((int64_t)(p.ep.noise_n > 1 ? n : 0) * d.out_h + oy) * d.out_w + ox] * ep_ns;
+            }
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    float osv[8], bv[8];
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = hh * 8 + r8;
+                        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        osv[r8] = (osc && co < d.cout) ? osc[co] : 1.0f;
+                        bv[r8] = (do_ep && p.ep.bias && co < d.cout) ? p.ep.bias[co] : 0.f;
+                    }
+#pragma unroll
+                    for (int g = 0; g < WN; ++g) {
+                        float rv[8];
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = hh * 8 + r8;
+                            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            rv[r8] = (do_ep && p.ep.residual && ovalid[g] && co < d.cout)
+                                         ? p.ep.residual[(int64_t)n * d.y_batch + (int64_t)(choff + co) * y_plane + offv[g]] : 0.f;
+                        }
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = hh * 8 + r8;
+                            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            float v = acc[0][m][g][r] * osv[r8];
+                            if (do_ep) {
+                                v += nzv[g];
+                                v += bv[r8];
+                                if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
+                                else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+                                v = v * p.ep.gain + rv[r8];
+                            }
+                            if (ovalid[g] && co < d.cout) yn[(int64_t)(choff + co) * y_plane + offv[g]] = v;
+                        }
+                    }
+                }
+            }
+            return;
         }
 #pragma unroll
-        for (int m = 0; m < WM; ++m) {
+        for (int g = 0; g < WN; ++g) {
+            const int ty_first = ((wave * WN + g) * 32) >> p.tw_log2;
+            if (c.ty0 + ty_first >= d.tile_h) continue;              // whole pixel group below the image (wave-uniform)
+            const int pix = (wave * WN + g) * 32 + l31;
+            const int ty = c.ty0 + (pix >> p.tw_log2), tx = c.tx0 + (pix & (TW - 1));
+            const bool pvalid = ty < d.tile_h && tx < d.tile_w;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co >= d.cout || !pvalid) continue;
-                const float os = osc ? osc[co] : 1.0f;
-                float* yc = yn + (int64_t)(choff + co) * y_plane;
-                {
+            for (int m = 0; m < WM; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co >= d.cout || !pvalid) continue;
+                    const float os = osc ? osc[co] : 1.0f;
+                    float* yc = yn + (int64_t)(choff + co) * y_plane;
                     // parity sets: q = 2*a + b -> row 2*ty + a, cols 2*tx + {0,1} written as a pair
 #pragma unroll
                     for (int a2 = 0; a2 < 2; ++a2) {
@@ -395,6 +479,76 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                 }
             }
         }
+    };
+
+    if (PIPE) {
+        // host guarantees cin % CK == 0 and chunk-aligned K slices: every chunk is full
+        int w = blockIdx.x;
+        if (w >= total_items) return;
+        TileCtx cur;
+        decode(w, cur);
+        int b = 0;
+#if defined(MGF_EXP) && MGF_EXP == 3      // experiment: per-phase shader-clock totals of every workgroup -> workspace
+        unsigned long long tPro = 0, tLoop = 0, tEpi = 0, tMfma = 0, tiles_done = 0;
+#define MGF_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define MGF_STAMP(var)
+#endif
+        for (;;) {
+            // first chunk of this tile: global -> registers -> LDS (latency covered by the co-resident workgroup and by the
+            // previous tile's stores, which are still draining)
+            MGF_STAMP(s0);
+            setup_slots(cur);
+            load_chunk(cur.c_begin);
+            store_chunk(lds + b * buf_floats);
+            __syncthreads();
+            MGF_STAMP(s1);
+            const int nch = (cur.c_end - cur.c_begin) / CK;
+            for (int c = 0; c < nch; ++c) {
+                float* curb = lds + b * buf_floats;
+                float* nxtb = lds + (b ^ 1) * buf_floats;
+                const bool more = c + 1 < nch;
+                if (more) load_chunk(cur.c_begin + (c + 1) * CK);             // in flight behind the MFMAs below
+                MGF_STAMP(m0);
+                mfma_chunk(curb);
+                MGF_STAMP(m1);
+#if defined(MGF_EXP) && MGF_EXP == 3
+                tMfma += m1 - m0;
+#endif
+                if (more) store_chunk(nxtb);
+                __syncthreads();
+                b ^= 1;
+            }
+            MGF_STAMP(s2);
+            epilogue(cur);                                                     // stores drain behind the next tile's work
+            zero_acc();
+            MGF_STAMP(s3);
+#if defined(MGF_EXP) && MGF_EXP == 3
+            tPro += s1 - s0; tLoop += s2 - s1; tEpi += s3 - s2; ++tiles_done;
+#endif
+            w += (int)gridDim.x;
+            if (w >= total_items) break;
+            decode(w, cur);
+        }
+#if defined(MGF_EXP) && MGF_EXP == 3
+        if (tid == 0 && d.workspace) {
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(d.workspace) + (size_t)blockIdx.x * 8;
+            dbg[0] = tPro; dbg[1] = tLoop; dbg[2] = tEpi; dbg[3] = tMfma; dbg[4] = tiles_done;
+        }
+#endif
+    } else {
+        const int w = blockIdx.x;
+        if (w >= total_items) return;
+        TileCtx cur;
+        decode(w, cur);
+        const int nchunks = (cur.c_end - cur.c_begin + CK - 1) / CK;
+        for (int c = 0; c < nchunks; ++c) {
+            __syncthreads();
+            stage_direct(cur, cur.c_begin + c * CK, lds);
+            __syncthreads();
+            mfma_chunk(lds);
+        }
+        epilogue(cur);
     }
 }
 
@@ -459,10 +613,15 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     const size_t buf = ((size_t)CK * p.fh * p.fw + (size_t)p.d.ntaps * CK * CO_T) * sizeof(float);
     const bool pipe = (size_t)CK * p.fh * p.fw <= (size_t)Slots<WM, WN>::XS * 256 &&
                       (size_t)p.d.ntaps * CK * CO_T / 4 <= (size_t)Slots<WM, WN>::WS * 256 &&
-                      256 / p.fw + 2 <= 2 * p.fh;     // slot walk: at most two row wraps per 256-element step
+                      256 / p.fw + 2 <= 2 * p.fh &&   // slot walk: at most two row wraps per 256-element step
+                      p.d.cin % CK == 0;              // the persistent pipeline only moves full chunks
     const size_t lds = pipe ? 2 * ((size_t)Slots<WM, WN>::XS * 256 + (size_t)Slots<WM, WN>::WS * 1024) * sizeof(float) : buf;
     if (lds > 160 * 1024) { mgf_set_error("conv_taps: tile needs %zu bytes of LDS (> 160 KiB)", lds); return MGF_EUNSUPPORTED; }
-    dim3 grid(p.tiles_x * p.tiles_y, p.co_tiles, p.d.n * p.ksplit);
+    const int64_t items = (int64_t)p.tiles_x * p.tiles_y * p.co_tiles * p.d.n * p.ksplit;
+    // persistent kernels: as many workgroups as the chip holds at once (2 per CU; 3 for the small-register variant)
+    static const char* res_env = getenv("MGF_RESIDENT");      // tuning hook (experiments only): workgroups per CU
+    const int64_t resident = (int64_t)MGF_NUM_CU * (res_env ? atoi(res_env) : ((WM == 1 && WN == 2 && MODE == 0) ? 3 : 2));
+    dim3 grid((unsigned)(pipe && (p.d.ntaps == 9 || (p.d.ntaps == 1 && MODE == 0)) ? (items < resident ? items : resident) : items));
     const int nt = p.d.ntaps;
     if (pipe && nt == 9) {
         ProfScope ps(st, WM, WN, MODE, 1, 9, p);
@@ -632,8 +791,8 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     ksplit = (int)mgf_cdiv(nchunks, p.chunks_per_split);          // drop empty tail slices
     p.ksplit = ksplit;
     p.partial = d.workspace;
-    MGF_REQUIRE((int64_t)p.tiles_x * p.tiles_y <= INT32_MAX && p.co_tiles <= 65535 && (int64_t)d.n * ksplit <= 65535, MGF_ETOOBIG,
-                "conv_taps: grid too large");
+    p.off32_ok = ((int64_t)(d.y_choff + d.cout_pad) * d.y_plane < (1LL << 30)) && ((int64_t)d.cout_pad * d.out_h * d.y_pitch < (1LL << 30));
+    MGF_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.co_tiles * d.n * ksplit <= INT32_MAX, MGF_ETOOBIG, "conv_taps: grid too large");
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (mode == 1) rc = launch_conv<1, 2, 1>(p, st);
