@@ -107,6 +107,15 @@ typedef struct mgf_conv_desc {
     int32_t out_scale_stride;            /* elements between samples in out_scale (0 = shared) */
     float* workspace;                    /* optional split-K scratch (device); NULL = never split the K dimension */
     int64_t workspace_floats;            /* capacity of workspace in floats */
+    /* Optional fused 1x1 projection of the conv result (ToRGBLayer, training/networks.py:1054-1065, folded into conv_last):
+     * when rgb_out != NULL the kernel does not write y at all but
+     *   rgb_out[n, c, oy, ox] = sum_co rgb_w[n, c, co] * epilogue(acc)[co] + rgb_bias[c]        c < rgb_channels <= 4
+     * rgb_w carries the per-sample style modulation (W[c,co] * s[n,co]).  Needs cout <= 32, one K slice, dense rgb_out. */
+    const float* rgb_w;                  /* [n, rgb_channels, cout] */
+    const float* rgb_bias;               /* [rgb_channels] or NULL */
+    float* rgb_out;                      /* [n, rgb_channels, out_h, out_w] */
+    int32_t rgb_channels;
+    int32_t pad_;
 } mgf_conv_desc;
 
 int mgf_conv_taps_f32(float* y, const float* x, const float* wp, const float* in_scale, const float* out_scale,

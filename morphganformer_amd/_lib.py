@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ("tile_h", i32), ("tile_w", i32), ("istride", i32), ("ostride", i32), ("ntaps", i32), ("ngroups", i32),
                 ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("group", i32 * MAX_TAPS), ("oy", i32 * 4), ("ox", i32 * 4),
                 ("out_h", i32), ("out_w", i32), ("y_pitch", i64), ("y_plane", i64), ("y_batch", i64), ("y_choff", i32),
-                ("out_scale_stride", i32), ("workspace", vp), ("workspace_floats", i64)]
+                ("out_scale_stride", i32), ("workspace", vp), ("workspace_floats", i64),
+                ("rgb_w", vp), ("rgb_bias", vp), ("rgb_out", vp), ("rgb_channels", i32), ("pad_", i32)]
 
 
 class ConvProfRec(C.Structure):

@@ -89,7 +89,7 @@ def _workspace(dev_index):
 
 
 def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_scale=None, epilogue=None, out=None,
-                 out_choff=0):
+                 out_choff=0, rgb=None):
     """Correlation with the packed taps: y[oy,ox] = sum w[kh,kw] x[oy*stride + kh - pad_y, ox*stride + kw - pad_x].
 
     `out` may be a larger [n, C_total, oh, ow] buffer; this conv then writes channels [out_choff, out_choff + cout)."""
@@ -99,10 +99,23 @@ def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_sca
     py, px = pad
     oh = (h + 2 * py - pc.kh) // stride + 1
     ow = (w + 2 * px - pc.kw) // stride + 1
+    taps = [(kh - py, kw - px) for kh in range(pc.kh) for kw in range(pc.kw)]
+    if rgb is not None:
+        # fused 1x1 projection (ToRGB folded into the conv): rgb = (rgb_w [n,c,cout], rgb_bias [c] | None, rgb_out [n,c,oh,ow]);
+        # the conv result itself is not written
+        rgb_w, rgb_b, rgb_out = rgb
+        _lib.require_gpu(rgb_w, rgb_b, rgb_out)
+        assert rgb_w.is_contiguous() and rgb_out.is_contiguous() and tuple(rgb_out.shape) == (n, rgb_w.shape[1], oh, ow)
+        d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, oh, ow, stride, 1, taps, None, [0], [0], oh, ow, ow, oh * ow,
+                  pc.cout * oh * ow, 0, 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
+        d.rgb_w, d.rgb_bias, d.rgb_out, d.rgb_channels = rgb_w.data_ptr(), _lib.ptr(rgb_b), rgb_out.data_ptr(), rgb_w.shape[1]
+        rc = _lib.lib().mgf_conv_taps_f32(None, x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                          C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
+        _lib.check(rc, "conv_taps(rgb)")
+        return rgb_out
     if out is None:
         out = torch.empty([n, pc.cout, oh, ow], dtype=torch.float32, device=x.device)
     assert out.is_contiguous() and out.shape[0] == n and out.shape[2] == oh and out.shape[3] == ow
-    taps = [(kh - py, kw - px) for kh in range(pc.kh) for kw in range(pc.kw)]
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, oh, ow, stride, 1, taps, None, [0], [0], oh, ow,
               ow, oh * ow, out.shape[1] * oh * ow, out_choff,
               0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)

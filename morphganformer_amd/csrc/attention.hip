@@ -34,7 +34,9 @@ struct AttnParams {
     int32_t* argmax;      // [n, f] or null
 };
 
-template <int PXB>
+// NCH = channels per lane group (C / G) when it is one of 8/16/32/64: the lane then keeps its x values in registers for both
+// sweeps (one batch of independent loads, no re-read); NCH = 0 is the generic two-sweep form for any C.
+template <int PXB, int NCH>
 __global__ __launch_bounds__(256) void duplex_attention_kernel(AttnParams p) {
     constexpr int G = 256 / PXB;                 // channel groups per workgroup
     extern __shared__ float lds[];
@@ -49,6 +51,16 @@ __global__ __launch_bounds__(256) void duplex_attention_kernel(AttnParams p) {
     const int fc = valid ? f : p.f - 1;
     const float* xn = p.x + (int64_t)n * p.c * p.f;
     const int T = p.t;
+
+    // channels of this lane: c = (k / UNR) * G * UNR + grp * UNR + (k % UNR), k = 0 .. NCH-1 (same walk as the generic loop)
+    float xreg[NCH > 0 ? NCH : 1];
+    if (NCH > 0) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
+            xreg[k] = xn[(int64_t)c * p.f + fc];
+        }
+    }
 
     // ---- stage a [c][T] table zero-padded to [c_pad][16]; T == 16 is a straight 16-byte copy, four loads in flight ----
     auto stage_table = [&](const float* src) {
@@ -83,20 +95,26 @@ __global__ __launch_bounds__(256) void duplex_attention_kernel(AttnParams p) {
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
     float sq = 0.f;
-    for (int c0 = grp * UNR; c0 < p.c; c0 += G * UNR) {
-        float xv[UNR];
+    auto accumulate = [&](float xv, int c) {
+        const float4* w4 = reinterpret_cast<const float4*>(tab + c * TMAX);
+        sq += xv * xv;
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) xv[u] = (c0 + u < p.c) ? xn[(int64_t)(c0 + u) * p.f + fc] : 0.f;
+        for (int q = 0; q < TMAX / 4; ++q) {
+            const float4 w = w4[q];
+            s[4 * q + 0] += xv * w.x; s[4 * q + 1] += xv * w.y;
+            s[4 * q + 2] += xv * w.z; s[4 * q + 3] += xv * w.w;
+        }
+    };
+    if (NCH > 0) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const float4* w4 = reinterpret_cast<const float4*>(tab + (c0 + u) * TMAX);
-            sq += xv[u] * xv[u];
+        for (int k = 0; k < NCH; ++k) accumulate(xreg[k], (k / UNR) * G * UNR + grp * UNR + (k % UNR));
+    } else {
+        for (int c0 = grp * UNR; c0 < p.c; c0 += G * UNR) {
+            float xv[UNR];
 #pragma unroll
-            for (int q = 0; q < TMAX / 4; ++q) {
-                const float4 w = w4[q];
-                s[4 * q + 0] += xv[u] * w.x; s[4 * q + 1] += xv[u] * w.y;
-                s[4 * q + 2] += xv[u] * w.z; s[4 * q + 3] += xv[u] * w.w;
-            }
+            for (int u = 0; u < UNR; ++u) xv[u] = (c0 + u < p.c) ? xn[(int64_t)(c0 + u) * p.f + fc] : 0.f;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) accumulate(xv[u], c0 + u);
         }
     }
 #pragma unroll
@@ -152,36 +170,196 @@ __global__ __launch_bounds__(256) void duplex_attention_kernel(AttnParams p) {
     }
     float* yn = p.y + (int64_t)n * p.c * p.f;
     const float* rn = (p.has_ep && p.ep.residual) ? p.ep.residual + (int64_t)n * p.c * p.f : nullptr;
-    for (int c0 = grp * UNR; c0 < p.c; c0 += G * UNR) {
-        float xv[UNR], rv[UNR];
+    auto finish = [&](float xv, float rv, int c) {
+        const float4* w4 = reinterpret_cast<const float4*>(tab + c * TMAX);
+        float g = 0.f;
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const bool ok = c0 + u < p.c;
-            xv[u] = ok ? xn[(int64_t)(c0 + u) * p.f + fc] : 0.f;
-            rv[u] = (ok && rn) ? rn[(int64_t)(c0 + u) * p.f + fc] : 0.f;
+        for (int q = 0; q < TMAX / 4; ++q) {
+            const float4 w = w4[q];
+            g += s[4 * q + 0] * w.x + s[4 * q + 1] * w.y + s[4 * q + 2] * w.z + s[4 * q + 3] * w.w;
         }
+        float v = xv * g;
+        if (p.has_ep) {
+            v += nz;
+            if (p.ep.bias && c < p.c) v += p.ep.bias[c];
+            if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
+            else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+            v *= p.ep.gain;
+            v += rv;
+        }
+        if (valid && c < p.c) yn[(int64_t)c * p.f + f] = v;
+    };
+    if (NCH > 0) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int c = c0 + u;
-            const float4* w4 = reinterpret_cast<const float4*>(tab + c * TMAX);
-            float g = 0.f;
+        for (int k0 = 0; k0 < NCH; k0 += 8) {
+            float rv[8];
 #pragma unroll
-            for (int q = 0; q < TMAX / 4; ++q) {
-                const float4 w = w4[q];
-                g += s[4 * q + 0] * w.x + s[4 * q + 1] * w.y + s[4 * q + 2] * w.z + s[4 * q + 3] * w.w;
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u;
+                const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
+                rv[u] = rn ? rn[(int64_t)c * p.f + fc] : 0.f;
             }
-            float v = xv[u] * g;
-            if (p.has_ep) {
-                v += nz;
-                if (p.ep.bias && c < p.c) v += p.ep.bias[c];
-                if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
-                else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
-                v *= p.ep.gain;
-                v += rv[u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u;
+                finish(xreg[k], rv[u], (k / UNR) * G * UNR + grp * UNR + (k % UNR));
             }
-            if (valid && c < p.c) yn[(int64_t)c * p.f + f] = v;
+        }
+    } else {
+        for (int c0 = grp * UNR; c0 < p.c; c0 += G * UNR) {
+            float xv[UNR], rv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const bool ok = c0 + u < p.c;
+                xv[u] = ok ? xn[(int64_t)(c0 + u) * p.f + fc] : 0.f;
+                rv[u] = (ok && rn) ? rn[(int64_t)(c0 + u) * p.f + fc] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) finish(xv[u], rv[u], c0 + u);
         }
     }
+}
+
+// Register-resident form for C = NCH * G, T == 16: every global operand of the workgroup (x, residual, both tables, spos, noise)
+// is requested up front in one burst of independent loads, so the kernel pays ONE memory round trip instead of ~10 dependent
+// ones -- these layers are 4x4 .. 128x128 maps, i.e. pure latency.
+template <int PXB, int NCH>
+__global__ __launch_bounds__(256) void duplex_attention_reg_kernel(AttnParams p) {
+    constexpr int G = 256 / PXB;
+    constexpr int TV = NCH * G / 64;              // float4 per lane that cover one [C][16] table (C*4 float4 / 256 lanes)
+    extern __shared__ float lds[];
+    float* tab = lds;                             // [C][16]
+    float* part = lds + (size_t)p.c * TMAX;       // [G][17][PXB]
+    const int tid = threadIdx.x;
+    const int px = tid % PXB, grp = tid / PXB;
+    const int n = blockIdx.y;
+    const int f = blockIdx.x * PXB + px;
+    const bool valid = f < p.f;
+    const int fc = valid ? f : p.f - 1;
+    const float* xn = p.x + (int64_t)n * p.c * p.f;
+    const float* rn = (p.has_ep && p.ep.residual) ? p.ep.residual + (int64_t)n * p.c * p.f : nullptr;
+    const float4* wq4 = reinterpret_cast<const float4*>(p.wqc);
+    const float4* vw4 = reinterpret_cast<const float4*>(p.vwb + (int64_t)n * p.c * TMAX);
+
+    // ---- one burst of loads ----
+    float xreg[NCH], rreg[NCH];
+    float4 tq[TV], tv[TV];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
+        xreg[k] = xn[(int64_t)c * p.f + fc];
+        rreg[k] = rn ? rn[(int64_t)c * p.f + fc] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < TV; ++u) { tq[u] = wq4[tid + 256 * u]; tv[u] = vw4[tid + 256 * u]; }
+    float sp[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) sp[t] = p.spos[(int64_t)fc * TMAX + t];
+    float nz = 0.f;
+    if (p.has_ep && p.ep.noise) {
+        const float ns = p.ep.noise_strength ? *p.ep.noise_strength : 1.f;
+        nz = p.ep.noise[(int64_t)(p.ep.noise_n > 1 ? n : 0) * p.f + fc] * ns;
+    }
+
+    float4* t4 = reinterpret_cast<float4*>(tab);
+#pragma unroll
+    for (int u = 0; u < TV; ++u) t4[tid + 256 * u] = tq[u];
+    __syncthreads();
+
+    float s[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
+        const float4* w4 = reinterpret_cast<const float4*>(tab + c * TMAX);
+        const float xv = xreg[k];
+        sq += xv * xv;
+#pragma unroll
+        for (int q = 0; q < TMAX / 4; ++q) {
+            const float4 w = w4[q];
+            s[4 * q + 0] += xv * w.x; s[4 * q + 1] += xv * w.y;
+            s[4 * q + 2] += xv * w.z; s[4 * q + 3] += xv * w.w;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) part[(grp * (TMAX + 1) + t) * PXB + px] = s[t];
+    part[(grp * (TMAX + 1) + TMAX) * PXB + px] = sq;
+    __syncthreads();                               // all reads of the wqc table are done: overwrite it with vwb
+#pragma unroll
+    for (int u = 0; u < TV; ++u) t4[tid + 256 * u] = tv[u];
+
+    float m = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        float v = 0.f;
+        for (int g = 0; g < G; ++g) v += part[(g * (TMAX + 1) + t) * PXB + px];
+        v += sp[t];
+        m = fmaxf(m, v);
+        s[t] = v;
+    }
+    sq = 0.f;
+    for (int g = 0; g < G; ++g) sq += part[(g * (TMAX + 1) + TMAX) * PXB + px];
+    float den = 0.f;
+    int best = 0;
+    float bestv = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        if (s[t] > bestv) { bestv = s[t]; best = t; }
+        s[t] = __expf(s[t] - m);
+        den += s[t];
+    }
+    const float inv = 1.f / den;
+    const float rs = rsqrtf(sq / (float)p.c + 1e-8f);
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) s[t] *= inv;
+    if (grp == 0 && valid) {
+        if (p.probs)
+            for (int t = 0; t < TMAX; ++t) p.probs[((int64_t)n * p.f + f) * TMAX + t] = s[t];
+        if (p.argmax) p.argmax[(int64_t)n * p.f + f] = best;
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) s[t] *= rs;
+    __syncthreads();
+
+    float* yn = p.y + (int64_t)n * p.c * p.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
+        const float4* w4 = reinterpret_cast<const float4*>(tab + c * TMAX);
+        float g = 0.f;
+#pragma unroll
+        for (int q = 0; q < TMAX / 4; ++q) {
+            const float4 w = w4[q];
+            g += s[4 * q + 0] * w.x + s[4 * q + 1] * w.y + s[4 * q + 2] * w.z + s[4 * q + 3] * w.w;
+        }
+        float v = xreg[k] * g;
+        if (p.has_ep) {
+            v += nz;
+            if (p.ep.bias) v += p.ep.bias[c];
+            if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
+            else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+            v *= p.ep.gain;
+            v += rreg[k];
+        }
+        if (valid) yn[(int64_t)c * p.f + f] = v;
+    }
+}
+
+template <int PXB>
+void launch_attention(const AttnParams& p, size_t lds, hipStream_t st) {
+    constexpr int G = 256 / PXB;
+    const dim3 grid((unsigned)mgf_cdiv(p.f, PXB), p.n);
+    const int nch = (p.c % (G * UNR) == 0) ? p.c / G : 0;
+    if (p.t == TMAX && (nch == 16 || nch == 32 || nch == 64) && (nch * G) % 64 == 0) {
+        const size_t lds_r = ((size_t)p.c * TMAX + (size_t)G * (TMAX + 1) * PXB) * sizeof(float);
+        if (nch == 16) hipLaunchKernelGGL((duplex_attention_reg_kernel<PXB, 16>), grid, dim3(256), lds_r, st, p);
+        else if (nch == 32) hipLaunchKernelGGL((duplex_attention_reg_kernel<PXB, 32>), grid, dim3(256), lds_r, st, p);
+        else hipLaunchKernelGGL((duplex_attention_reg_kernel<PXB, 64>), grid, dim3(256), lds_r, st, p);
+        return;
+    }
+    hipLaunchKernelGGL((duplex_attention_kernel<PXB, 0>), grid, dim3(256), lds, st, p);
 }
 
 }  // namespace
@@ -207,8 +385,8 @@ extern "C" int mgf_duplex_attention(float* y, const float* x, const float* wqc, 
     const size_t lds = ((size_t)p.c_pad * TMAX + (size_t)g * (TMAX + 1) * pxb) * sizeof(float);
     MGF_REQUIRE(lds <= 64 * 1024, MGF_EUNSUPPORTED, "duplex_attention: %d channels need %zu bytes of LDS (> 64 KiB)", c, lds);
     hipStream_t st = (hipStream_t)stream;
-    if (pxb == 64) hipLaunchKernelGGL((duplex_attention_kernel<64>), dim3((unsigned)mgf_cdiv(f, 64), n), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((duplex_attention_kernel<16>), dim3((unsigned)mgf_cdiv(f, 16), n), dim3(256), lds, st, p);
+    if (pxb == 64) launch_attention<64>(p, lds, st);
+    else launch_attention<16>(p, lds, st);
     MGF_CHECK_LAUNCH("duplex_attention");
     return MGF_OK;
 }

@@ -318,6 +318,53 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         const int64_t y_plane = partial ? (int64_t)d.out_h * d.y_pitch : d.y_plane;
         const int choff = partial ? 0 : d.y_choff;
         const float* osc = (p.out_scale && !partial) ? p.out_scale + (int64_t)n * d.out_scale_stride : nullptr;
+        if (MODE == 0 && WM == 1 && d.rgb_out) {
+            // Fused ToRGB: this workgroup holds all (<= 32) output channels of its pixels, 16 per lane half.  Each lane forms the
+            // partial 1x1 projection of its channels, the two halves are combined with one cross-lane exchange, and only the
+            // rgb image is written -- the conv result itself never goes to memory.
+            const int rc = d.rgb_channels;
+            const float* wr = d.rgb_w + (int64_t)n * rc * d.cout;
+            float wv[4][16], osv[16], bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const bool ok = co < d.cout;
+                osv[r] = (osc && ok) ? osc[co] : 1.0f;
+                bv[r] = (do_ep && p.ep.bias && ok) ? p.ep.bias[co] : 0.f;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) wv[cc][r] = (cc < rc && ok) ? wr[cc * d.cout + co] : 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < WN; ++g) {
+                const int pix = (wave * WN + g) * 32 + l31;
+                const int ty = c.ty0 + (pix >> p.tw_log2), tx = c.tx0 + (pix & (TW - 1));
+                const int oy = ty * d.ostride + d.oy[0], ox = tx * d.ostride + d.ox[0];
+                const bool ovalid = ty < d.tile_h && tx < d.tile_w && oy < d.out_h && ox < d.out_w;
+                float nz = 0.f;
+                if (do_ep && p.ep.noise && ovalid) nz = p.ep.noise[((int64_t)(p.ep.noise_n > 1 ? n : 0) * d.out_h + oy) * d.out_w + ox] * ep_ns;
+                float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[0][0][g][r] * osv[r];
+                    if (do_ep) {
+                        v += nz;
+                        v += bv[r];
+                        if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
+                        else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        v *= p.ep.gain;
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) sum[cc] += v * wv[cc][r];
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) sum[cc] += __shfl_xor(sum[cc], 32, 64);
+                if (half == 0 && ovalid) {
+                    for (int cc = 0; cc < rc; ++cc)
+                        d.rgb_out[(((int64_t)n * rc + cc) * d.out_h + oy) * d.out_w + ox] = sum[cc] + (d.rgb_bias ? d.rgb_bias[cc] : 0.f);
+                }
+            }
+            return;
+        }
         // Fast path (every interior tile of a layer whose channel count fills the tile): no per-element predication and
         // 32-bit per-lane offsets from wave-uniform base pointers, i.e. one VALU add per global access instead of 64-bit
         // multiply/add chains -- the epilogue is instruction-issue bound otherwise.
@@ -570,6 +617,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvParams p) {
         // fixed summation order (deterministic); loads issued four at a time so their latencies overlap
         const float* pp = p.partial + poff;
         int s = 0;
+        for (; s + 8 <= p.ksplit; s += 8) {
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = pp[(int64_t)(s + u) * slice];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += a[u];
+        }
         for (; s + 4 <= p.ksplit; s += 4) {
             const float a0 = pp[(int64_t)s * slice], a1 = pp[(int64_t)(s + 1) * slice];
             const float a2 = pp[(int64_t)(s + 2) * slice], a3 = pp[(int64_t)(s + 3) * slice];
@@ -719,7 +773,7 @@ extern "C" int mgf_pack_conv_weights(float* wp, float* wsq, const float* w, int3
 
 extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, const float* in_scale, const float* out_scale,
                                  const mgf_conv_desc* dd, const mgf_epilogue* ep, mgf_stream_t stream) {
-    MGF_REQUIRE(y && x && wp && dd, MGF_EINVAL, "conv_taps: null pointer");
+    MGF_REQUIRE(x && wp && dd && (y || dd->rgb_out), MGF_EINVAL, "conv_taps: null pointer");
     const mgf_conv_desc& d = *dd;
     MGF_REQUIRE(d.n >= 1 && d.cin >= 1 && d.cout >= 1 && d.in_h >= 1 && d.in_w >= 1, MGF_EINVAL, "conv_taps: bad shape");
     MGF_REQUIRE(d.cout_pad >= d.cout && d.cout_pad % 32 == 0, MGF_EINVAL, "conv_taps: cout_pad must be a multiple of 32 >= cout");
@@ -729,6 +783,11 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     MGF_REQUIRE((int64_t)d.cin * d.in_h * d.in_w * d.n <= INT32_MAX, MGF_ETOOBIG, "conv_taps: input too large");
     MGF_REQUIRE((int64_t)MGF_MAX_TAPS * d.cin * d.cout_pad <= INT32_MAX, MGF_ETOOBIG, "conv_taps: weight image too large");
     MGF_REQUIRE(d.y_pitch >= d.out_w && d.y_plane >= (int64_t)d.out_h * d.y_pitch, MGF_EINVAL, "conv_taps: output strides too small");
+    if (d.rgb_out) {
+        MGF_REQUIRE(d.rgb_w && d.rgb_channels >= 1 && d.rgb_channels <= 4, MGF_EINVAL, "conv_taps: fused projection needs rgb_w and 1..4 channels");
+        MGF_REQUIRE(d.cout <= 32 && d.ngroups == 1 && (!ep || !ep->residual), MGF_EUNSUPPORTED,
+                    "conv_taps: fused projection needs cout <= 32, a plain conv and no residual");
+    }
     if (ep) MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU,
                         MGF_EUNSUPPORTED, "conv_taps: epilogue activation %d unsupported", ep->act);
     ConvParams p;
@@ -780,7 +839,7 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     const int64_t base_wgs = (int64_t)p.tiles_x * p.tiles_y * p.co_tiles * d.n;
     const int nchunks = (int)mgf_cdiv(d.cin, CK);
     int ksplit = 1;
-    if (d.workspace && base_wgs < 512 && nchunks >= 4) {
+    if (d.workspace && base_wgs < 512 && nchunks >= 4 && !d.rgb_out) {
         ksplit = (int)mgf_cdiv(1024, base_wgs);
         if (ksplit > nchunks / 2) ksplit = nchunks / 2;
         const int64_t slice = (int64_t)d.n * d.cout * d.out_h * d.y_pitch;

@@ -94,6 +94,7 @@ class ConvLayerPlan:
     noise_strength: torch.Tensor = None
     act_gain: float = 1.0
     attn: "AttnPlan" = None
+    w_raw: torch.Tensor = None      # toRGB only: [img_channels, cin] un-packed weights for the fused projection
     s_off: int = 0                  # offsets (floats) into the per-sample style / demod arenas
     d_off: int = 0
 
@@ -134,6 +135,7 @@ class SynthesisPlan:
             if kind == "torgb":
                 # styles * w_gain instead of weight * w_gain, no demodulation (networks.py:1056-1063)
                 lp.pc = cv.pack_weights(t32(w), gain=1.0, flip=False)
+                lp.w_raw = t32(w.reshape(cout, cin))
                 lp.style_gain = 1.0 / math.sqrt(cin)
                 lp.demod = False
             else:
@@ -206,6 +208,7 @@ class Generator:
         self.w_avg = torch.as_tensor(np.asarray(sd["mapping.w_avg"], dtype=np.float32), device=self.device)
         self._ws_cache = {}
         self.taps = None
+        self.fuse_torgb = True
         self._alloc(max_batch)
 
     # ------------------------------------------------------------------ workspace
@@ -236,6 +239,7 @@ class Generator:
             self.bufs[res] = b
         self.img = e(n, cfg.img_channels, cfg.img_resolution, cfg.img_resolution)
         self.const_in = P.const.unsqueeze(0).repeat(n, 1, 1, 1).contiguous()            # networks.py:1147
+        self.rgbw = e(n, cfg.img_channels, cfg.channels(cfg.img_resolution))
         self._build_jobs(n)
 
     def _build_jobs(self, n):
@@ -338,12 +342,18 @@ class Generator:
                 self.taps[b] = x
             if res == cfg.img_resolution:
                 lp = layers[b + ".conv_last"]
-                x = cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=self._s(lp), out_scale=self._d(lp), out=B["last"])
-                if self.taps is not None:
-                    self.taps[b] = x
-                lp = layers[b + ".torgb"]
-                ep = _lib.make_epilogue(bias=lp.bias)
-                cv.conv_forward(x, lp.pc, in_scale=self._s(lp), epilogue=ep, out=self.img)
+                lt = layers[b + ".torgb"]
+                if self.taps is None and self.fuse_torgb and lp.cout <= 32:
+                    # conv_last + ToRGB in one kernel: the [n,32,R,R] conv_last activation never goes to HBM
+                    torch.mul(lt.w_raw.unsqueeze(0), self._s(lt).unsqueeze(1), out=self.rgbw)      # W[c,co] * s[n,co]
+                    cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=self._s(lp), out_scale=self._d(lp),
+                                    rgb=(self.rgbw, lt.bias, self.img))
+                else:
+                    x = cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=self._s(lp), out_scale=self._d(lp), out=B["last"])
+                    if self.taps is not None:
+                        self.taps[b] = x
+                    ep = _lib.make_epilogue(bias=lt.bias)
+                    cv.conv_forward(x, lt.pc, in_scale=self._s(lt), epilogue=ep, out=self.img)
         return self.img
 
     def _noise_for(self, lp, noise_mode, noises):

@@ -107,3 +107,10 @@ def test_full_1024_matches_reference_samples(golden):
         assert abs(float(t.mean()) - m) < 1e-3 * r, res
         assert abs(float(t.square().mean().sqrt()) - r) < 1e-3 * r, res
     assert abs(float(img.double().mean()) - float(g["img_mean"])) < 1e-3 * float(g["img_rms"])
+    # production schedule (no taps requested): conv_last + ToRGB fused into one kernel -- same pixels
+    ref_img = img.clone()
+    assert G.fuse_torgb
+    img2 = G(torch.from_numpy(g["z"]).cuda(), None, noise_mode="const")[0]
+    pix2 = img2.reshape(-1)[torch.from_numpy(g["idx"]).cuda()].cpu().numpy()
+    assert np.abs(pix2 - g["pixels"]).max() / amax < PIX_TOL
+    assert float((img2 - ref_img).abs().max()) / amax < 1e-5
