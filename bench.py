@@ -48,19 +48,21 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", type=int, default=1024, help="debug only; the reported config is 1024")
+    ap.add_argument("--batch", type=int, default=4, help="loop steps evaluated per generator forward (exact in literal mode)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
     return ap.parse_args()
 
 
-def build(cfg, device, rank, steps_total, use_graph):
+def build(cfg, device, rank, steps_total, use_graph, batch):
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.lpips import PerceptualLoss
     from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, latent_stats, synthetic_landmarks
     from morphganformer_amd.synth_weights import make_state_dict, synthetic_latents
     sd = make_state_dict(cfg, seed=0)
     G = Generator(sd, cfg, device, max_batch=1)
+    G.fuse_torgb = True
     z_t = torch.from_numpy(synthetic_latents(cfg, 1, seed=1000 + rank)).to(device)
     target = G(z_t, None, noise_mode="const")[0].clamp(-1, 1).clone()
     gen = torch.Generator(device=device)
@@ -70,7 +72,7 @@ def build(cfg, device, rank, steps_total, use_graph):
     lm_t, lm_s = synthetic_landmarks(steps_total, cfg.img_resolution, seed=7 + rank)
     args = ProjectionArgs(step=steps_total)
     eng = ProjectionEngine(G, target, latent_mean, latent_std, args, percept=percept, use_mse=True, lm_target=lm_t,
-                           lm_steps=lm_s, noise_mode="random", seed=100 + rank, use_graph=use_graph)
+                           lm_steps=lm_s, noise_mode="random", seed=100 + rank, use_graph=use_graph, batch=batch)
     return sd, G, percept, eng, target, latent_mean, float(latent_std), (lm_t, lm_s)
 
 
@@ -158,7 +160,8 @@ def main():
     device = torch.device("cuda", local_rank if world > 1 else 0)
     from morphganformer_amd.synth_weights import GeneratorConfig
     cfg = GeneratorConfig(img_resolution=a.res)
-    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, a.steps + a.warmup, not a.no_graph)
+    assert a.steps % a.batch == 0 and a.warmup % a.batch == 0, "--steps and --warmup must be multiples of --batch"
+    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, a.steps + a.warmup, not a.no_graph, a.batch)
 
     log(f"built generator/LPIPS/engine on {device}; warm-up {a.warmup} steps (includes graph capture)")
     eng.run(a.warmup)
@@ -194,7 +197,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1]: single {a.res}x{a.res} face per GPU, Wing+LPIPS(squeeze)+MSE literal-mode projection step, "
                                "noise_mode=random, seeded synthetic weights/targets/landmarks", "k": cfg.k, "z_dim": cfg.z_dim,
-                   "targets_per_gpu": 1, "parallelism": f"pair-sharded x{world}", "graph_replay": not a.no_graph},
+                   "targets_per_gpu": 1, "parallelism": f"pair-sharded x{world}", "graph_replay": not a.no_graph,
+                   "steps_per_forward": a.batch},
     }
     if rank == 0:
         out["roofline"] = roofline_leg(eng)

@@ -203,39 +203,44 @@ int mgf_mapping_forward(float* w, const float* z, const float* params, int32_t n
                         int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Losses of the projection loop.
- * mse:   out[0] (+)= mean((a-b)^2)                 torch.nn.MSELoss, 1024_example_wing_loss_perceptual_sqz_MSE.py:176
- * wing:  out[0] = WingLoss(pred, target) in f64     wing_loss.py:19-28
- * lpips layer: out[0] += mean_hw( sum_c lin[c] * (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))^2 )   lpips/networks_basic.py:70-87
- * All accumulate through a deterministic two-stage reduction (no float atomics) using `scratch`
- * (>= mgf_reduce_scratch_floats() floats).
+ * Losses of the projection loop, batched over n independent candidates (one generator forward evaluates n steps of the
+ * literal loop; n = 1 is the reference's one-image-per-step form).
+ * mse:   out[i] (+)= scale * mean((a[i] - b[i])^2), a: [n, numel], b: rows b_batch_stride elements apart (0 = one shared
+ *        target)                                      torch.nn.MSELoss, 1024_example_wing_loss_perceptual_sqz_MSE.py:176
+ * wing:  out[i] = WingLoss(pred row (*pred_step + i, clamped to max_row when max_row >= 0), target) in f64   wing_loss.py:19-28
+ *        (pred is a [rows, numel] table; pred_step NULL = rows 0..n-1)
+ * lpips layer: out[i] (+)= mean_hw( sum_c lin[c] * (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))^2 ), f0: [n,c,hw],
+ *        f1 samples f1_batch_stride elements apart (0 = shared target features)      lpips/networks_basic.py:70-87
+ * All reduce through a deterministic two-stage reduction (no float atomics) using `scratch`
+ * (>= n * mgf_reduce_scratch_floats() floats).
  */
 int64_t mgf_reduce_scratch_floats(void);
-int mgf_mse_f32(float* out, const float* a, const float* b, int64_t numel, float scale, int32_t accumulate,
-                float* scratch, mgf_stream_t stream);
-/* pred_step (device int32, may be NULL): when given, pred is a [steps, numel] table and row *pred_step is used */
-int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int64_t numel, double omega, double epsilon,
-                      const int32_t* pred_step,
-                      mgf_stream_t stream);
+int mgf_mse_f32(float* out, const float* a, const float* b, int32_t n, int64_t numel, int64_t b_batch_stride, float scale,
+                int32_t accumulate, float* scratch, mgf_stream_t stream);
+int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int32_t n, int64_t numel, double omega, double epsilon,
+                      const int32_t* pred_step, int32_t max_row, mgf_stream_t stream);
 int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1, const float* lin, int32_t n, int32_t c, int64_t hw,
-                        int32_t accumulate, float* scratch, mgf_stream_t stream);
+                        int64_t f1_batch_stride, int32_t accumulate, float* scratch, mgf_stream_t stream);
 /* y = max over a 3x3 window, stride 2, ceil_mode (torchvision SqueezeNet1.1 features[2,5,8]) */
 int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                               mgf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Literal projection step bookkeeping (1024_example_wing_loss_perceptual_sqz_MSE.py:156-157,179,186-189), on device so the
- * loop never synchronises with the host:
- *   perturb: latent_n = latent_in + eps[*step] * sigma[*step]      (eps: [steps, numel] injected randn stream, sigma: [steps])
- *   select:  total = p_loss + lamda*w_loss + beta*mse (float64, as torch promotes it); if total < *min_loss:
- *            min_loss=total, best_latent=latent_n, best_step=*step.  losses_out[*step] = total (NaN when valid[*step] == 0 = "no face"; valid NULL = always,
- *            ...sqz_MSE.py:165-166).  Finally *step += 1.  All state lives on the device -> graph-replayable.
+ * loop never synchronises with the host.  `batch` consecutive steps are handled per call:
+ *   perturb: latent_n[j] = latent_in + eps[s] * sigma[s],  s = min(*step + j, steps_total - 1)   (eps: [steps, numel] injected
+ *            randn stream, sigma: [steps]); two roundings, like torch
+ *   select:  for j in 0..batch-1 (in step order, s = *step + j < steps_total): total = p_loss[j] + lamda*w_loss[j] + beta*mse[j]
+ *            (float64, as torch promotes it); if total < *min_loss: min_loss=total, best_latent=latent_n[j], best_step=s.
+ *            losses_out[s] = total (NaN when valid[s] == 0 = "no face", ...sqz_MSE.py:165-166; valid NULL = always valid).
+ *            Finally *step = min(*step + batch, steps_total).  All state lives on the device -> graph-replayable.
  */
 int mgf_latent_perturb(float* latent_n, const float* latent_in, const float* eps, const float* sigma, const int32_t* step,
-                       int64_t numel, mgf_stream_t stream);
+                       int32_t batch, int32_t steps_total, int64_t numel, mgf_stream_t stream);
 int mgf_select_best(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out,
                     const float* latent_n, int64_t numel, const float* p_loss, const double* w_loss, const float* mse_loss,
-                    float lamda, float beta, int32_t* step, const int32_t* valid, mgf_stream_t stream);
+                    float lamda, float beta, int32_t* step, const int32_t* valid, int32_t batch, int32_t steps_total,
+                    mgf_stream_t stream);
 /* uint8 HWC image = clip(rint(x*127.5+127.5), 0, 255) from CHW float (misc.to_pil, misc.py:114-123) */
 int mgf_to_uint8_hwc(uint8_t* out, const float* img, int32_t c, int32_t h, int32_t w, mgf_stream_t stream);
 

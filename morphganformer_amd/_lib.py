@@ -67,12 +67,12 @@ _SIGS = {
     "mgf_mapping_param_floats": (i64, [i32, i32, i32]),
     "mgf_mapping_forward": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mgf_reduce_scratch_floats": (i64, []),
-    "mgf_mse_f32": (C.c_int, [vp, vp, vp, i64, f32, i32, vp, vp]),
-    "mgf_wing_loss_f64": (C.c_int, [vp, vp, vp, i64, f64, f64, vp, vp]),
-    "mgf_lpips_layer_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i64, i32, vp, vp]),
+    "mgf_mse_f32": (C.c_int, [vp, vp, vp, i32, i64, i64, f32, i32, vp, vp]),
+    "mgf_wing_loss_f64": (C.c_int, [vp, vp, vp, i32, i64, f64, f64, vp, i32, vp]),
+    "mgf_lpips_layer_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i64, i64, i32, vp, vp]),
     "mgf_maxpool3x3s2_ceil_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
-    "mgf_latent_perturb": (C.c_int, [vp, vp, vp, vp, vp, i64, vp]),
-    "mgf_select_best": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp, vp, f32, f32, vp, vp, vp]),
+    "mgf_latent_perturb": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),
+    "mgf_select_best": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp]),
     "mgf_to_uint8_hwc": (C.c_int, [vp, vp, i32, i32, i32, vp]),
 }
 

@@ -1,11 +1,12 @@
 // Losses and bookkeeping of the projection loop, all device-side so an iteration never synchronises with the host.
-// Contract: include/mgf.h.  Reductions are deterministic: fixed grid, per-block partials in `scratch`, a single
-// finishing block sums them in index order (no float atomics -> bit-reproducible run to run).
+// Contract: include/mgf.h.  Every op is BATCHED over n independent candidates (the literal loop's steps do not depend on each
+// other, so several of them are evaluated per generator forward); reductions are deterministic: fixed grid, per-block
+// partials in `scratch`, one finishing block per sample sums them in index order (no float atomics -> bit-reproducible).
 #include "mgf_common.h"
 
 namespace {
 
-constexpr int RED_BLOCKS = 16384;
+constexpr int RED_BLOCKS = 16384;     // scratch floats per sample
 
 __device__ __forceinline__ float block_sum_256(float v, float* sm) {
     v = wave_sum(v);
@@ -16,52 +17,55 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
     return r;
 }
 
+// out[s] (+)= scale * sum(scratch[s][0 .. nparts))   -- one workgroup per sample
 __global__ __launch_bounds__(256) void finish_kernel(float* out, const float* scratch, int nparts, float scale, int accumulate) {
     __shared__ float sm[4];
+    const float* sc = scratch + (int64_t)blockIdx.x * RED_BLOCKS;
     float v = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += 256) v += scratch[i];
+    for (int i = threadIdx.x; i < nparts; i += 256) v += sc[i];
     v = block_sum_256(v, sm);
-    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + v * scale;
+    if (threadIdx.x == 0) out[blockIdx.x] = (accumulate ? out[blockIdx.x] : 0.f) + v * scale;
 }
 
-__global__ __launch_bounds__(256) void mse_partial_kernel(float* scratch, const float* a, const float* b, int64_t numel) {
+// grid = (blocks, n)
+__global__ __launch_bounds__(256) void mse_partial_kernel(float* scratch, const float* a, const float* b, int64_t numel, int64_t b_stride) {
     __shared__ float sm[4];
+    const float* as = a + (int64_t)blockIdx.y * numel;
+    const float* bs = b + (int64_t)blockIdx.y * b_stride;
     float acc = 0.f;
     const int64_t nvec = numel / 4;
-    const float4* a4 = reinterpret_cast<const float4*>(a);
-    const float4* b4 = reinterpret_cast<const float4*>(b);
+    const float4* a4 = reinterpret_cast<const float4*>(as);
+    const float4* b4 = reinterpret_cast<const float4*>(bs);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
         float4 u = a4[i], v = b4[i];
         float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
         acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
     }
     for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
-        float d0 = a[i] - b[i];
+        float d0 = as[i] - bs[i];
         acc += d0 * d0;
     }
     acc = block_sum_256(acc, sm);
-    if (threadIdx.x == 0) scratch[blockIdx.x] = acc;
+    if (threadIdx.x == 0) scratch[(int64_t)blockIdx.y * RED_BLOCKS + blockIdx.x] = acc;
 }
 
-// One lane per pixel: two sweeps over the channels (norms, then the weighted squared difference of the unit vectors).
-// A workgroup owns PXB consecutive pixels; its 256 / PXB lane groups split the channels (PXB = 16 for the small deep taps
-// so that a 63x63 map still spreads over ~250 workgroups).  Two sweeps over the channels -- squared norms, then the
-// lin-weighted squared difference of the unit vectors (the second sweep re-reads from L2) -- each unrolled 4-deep; the
-// partial sums meet in LDS in a fixed order, so the result is bit-reproducible.
+// grid = (pixel blocks, n).  A workgroup owns PXB consecutive pixels of one sample; its 256 / PXB lane groups split the
+// channels (PXB = 16 for the small deep taps so that a 63x63 map still spreads over ~250 workgroups).  Two sweeps over the
+// channels -- squared norms, then the lin-weighted squared difference of the unit vectors (the second sweep re-reads from
+// L2) -- each unrolled 4-deep; the partial sums meet in LDS in a fixed order, so the result is bit-reproducible.
 template <int PXB>
-__global__ __launch_bounds__(256) void lpips_partial_kernel(float* scratch, const float* f0, const float* f1, const float* lin, int n,
-                                                            int c, int64_t hw) {
+__global__ __launch_bounds__(256) void lpips_partial_kernel(float* scratch, const float* f0, const float* f1, const float* lin, int c,
+                                                            int64_t hw, int64_t f1_stride) {
     constexpr int G = 256 / PXB;
     __shared__ float red[2][G][PXB];
     __shared__ float sm[4];
     const int px = threadIdx.x % PXB, grp = threadIdx.x / PXB;
-    const int64_t total = (int64_t)n * hw;
+    const int nn = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * PXB + px;
-    const bool valid = i < total;
-    const int64_t ic = valid ? i : total - 1;
-    const int64_t nn = ic / hw, pp = ic - nn * hw;
-    const float* a = f0 + nn * c * hw + pp;
-    const float* b = f1 + nn * c * hw + pp;
+    const bool valid = i < hw;
+    const int64_t pp = valid ? i : hw - 1;
+    const float* a = f0 + (int64_t)nn * c * hw + pp;
+    const float* b = f1 + (int64_t)nn * f1_stride + pp;
     float na = 0.f, nb = 0.f;
     for (int k0 = grp * 4; k0 < c; k0 += G * 4) {
         float u[4], v[4];
@@ -101,22 +105,16 @@ __global__ __launch_bounds__(256) void lpips_partial_kernel(float* scratch, cons
         }
     }
     const float acc = block_sum_256(valid ? d : 0.f, sm);
-    if (threadIdx.x == 0) scratch[blockIdx.x] = acc;
+    if (threadIdx.x == 0) scratch[(int64_t)nn * RED_BLOCKS + blockIdx.x] = acc;
 }
 
-// scratch[0 .. nparts) -> sum in index order by one workgroup, several rounds of 256-wide partials
-__global__ __launch_bounds__(256) void finish_many_kernel(float* out, const float* scratch, int nparts, float scale, int accumulate) {
-    __shared__ float sm[4];
-    float v = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += 256) v += scratch[i];
-    v = block_sum_256(v, sm);
-    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + v * scale;
-}
-
+// one workgroup per candidate: out[j] = WingLoss(pred row (*pred_step + j), target) in float64
 __global__ __launch_bounds__(256) void wing_kernel(double* out, const double* pred, const double* target, int64_t numel, double omega,
-                                                   double epsilon, const int32_t* pred_step) {
+                                                   double epsilon, const int32_t* pred_step, int max_row) {
     __shared__ double sm[4];
-    if (pred_step) pred += (int64_t)(*pred_step) * numel;      // pred is a [steps, numel] table indexed on the device
+    int row = (pred_step ? *pred_step : 0) + (int)blockIdx.x;
+    if (max_row >= 0 && row > max_row) row = max_row;
+    pred += (int64_t)row * numel;
     const double cc = omega - omega * log(1.0 + omega / epsilon);
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < numel; i += 256) {
@@ -126,7 +124,7 @@ __global__ __launch_bounds__(256) void wing_kernel(double* out, const double* pr
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = (sm[0] + sm[1] + sm[2] + sm[3]) / (double)numel;
+    if (threadIdx.x == 0) out[blockIdx.x] = (sm[0] + sm[1] + sm[2] + sm[3]) / (double)numel;
 }
 
 __global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, int nc, int in_h, int in_w, int out_h, int out_w) {
@@ -152,41 +150,48 @@ __global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, 
     }
 }
 
+// latent_n[j] = latent_in + eps[s_j] * sigma[s_j], s_j = min(*step + j, steps_total - 1), j < batch
 __global__ __launch_bounds__(256) void perturb_kernel(float* latent_n, const float* latent_in, const float* eps, const float* sigma,
-                                                      const int32_t* step, int64_t numel) {
-#pragma clang fp contract(off)      // eps*sigma then +latent with two roundings, like torch: keeps the latents bit-exact
-    const int s = *step;
-    const float sg = sigma[s];
-    const float* e = eps + (int64_t)s * numel;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256)
-    {
-        float prod = e[i] * sg;
+                                                      const int32_t* step, int batch, int steps_total, int64_t numel) {
+    const int64_t total = (int64_t)batch * numel;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int j = (int)(idx / numel);
+        const int64_t i = idx - (int64_t)j * numel;
+        int s = *step + j;
+        if (s > steps_total - 1) s = steps_total - 1;
+        float prod = eps[(int64_t)s * numel + i] * sigma[s];
         asm volatile("" : "+v"(prod));                 // opaque to the fma combiner: two roundings like torch -> bit-exact latents
-        latent_n[i] = latent_in[i] + prod;
+        latent_n[idx] = latent_in[i] + prod;
     }
 }
 
+// candidates j = 0 .. batch-1 are examined in step order, exactly as the sequential loop would
 __global__ __launch_bounds__(256) void select_kernel(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out,
                                                      const float* latent_n, int64_t numel, const float* p_loss, const double* w_loss,
-                                                     const float* mse_loss, float lamda, float beta, int32_t* step, const int32_t* valid_tab) {
+                                                     const float* mse_loss, float lamda, float beta, int32_t* step, const int32_t* valid_tab,
+                                                     int batch, int steps_total) {
     __shared__ int take;
-    const int s = *step;
-    const int valid = valid_tab ? valid_tab[s] : 1;
-    if (threadIdx.x == 0) {
-        // same evaluation order as `p_loss + lamda * w_loss + beta * mse_loss` with a float64 wing term
-        double total = 0.0;
-        if (p_loss) total += (double)p_loss[0];
-        if (w_loss) total += (double)lamda * w_loss[0];
-        if (mse_loss) total += (double)(beta * mse_loss[0]);
-        if (losses_out) losses_out[s] = valid ? total : __longlong_as_double(0x7ff8000000000000LL);
-        take = valid && total < min_loss[0];
-        if (take) { min_loss[0] = total; best_step[0] = s; }
+    const int s0 = *step;
+    for (int j = 0; j < batch; ++j) {
+        const int s = s0 + j;
+        if (s >= steps_total) break;
+        if (threadIdx.x == 0) {
+            const int valid = valid_tab ? valid_tab[s] : 1;
+            // same evaluation order as `p_loss + lamda * w_loss + beta * mse_loss` with a float64 wing term
+            double total = 0.0;
+            if (p_loss) total += (double)p_loss[j];
+            if (w_loss) total += (double)lamda * w_loss[j];
+            if (mse_loss) total += (double)(beta * mse_loss[j]);
+            if (losses_out) losses_out[s] = valid ? total : __longlong_as_double(0x7ff8000000000000LL);
+            take = valid && total < min_loss[0];
+            if (take) { min_loss[0] = total; best_step[0] = s; }
+        }
+        __syncthreads();
+        if (take)
+            for (int64_t i = threadIdx.x; i < numel; i += 256) best_latent[i] = latent_n[(int64_t)j * numel + i];
+        __syncthreads();
     }
-    __syncthreads();
-    if (take)
-        for (int64_t i = threadIdx.x; i < numel; i += 256) best_latent[i] = latent_n[i];
-    __syncthreads();
-    if (threadIdx.x == 0) *step = s + 1;
+    if (threadIdx.x == 0) *step = s0 + batch < steps_total ? s0 + batch : steps_total;
 }
 
 __global__ __launch_bounds__(256) void to_uint8_kernel(uint8_t* out, const float* img, int c, int h, int w) {
@@ -205,40 +210,40 @@ __global__ __launch_bounds__(256) void to_uint8_kernel(uint8_t* out, const float
 
 extern "C" int64_t mgf_reduce_scratch_floats(void) { return RED_BLOCKS; }
 
-extern "C" int mgf_mse_f32(float* out, const float* a, const float* b, int64_t numel, float scale, int32_t accumulate, float* scratch,
-                           mgf_stream_t stream) {
-    MGF_REQUIRE(out && a && b && scratch && numel >= 1, MGF_EINVAL, "mse: bad arguments");
-    MGF_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0), MGF_EINVAL, "mse: inputs must be 16-byte aligned");
-    const int grid = (int)(mgf_cdiv(numel, 256 * 8) < RED_BLOCKS ? mgf_cdiv(numel, 256 * 8) : RED_BLOCKS);
+extern "C" int mgf_mse_f32(float* out, const float* a, const float* b, int32_t n, int64_t numel, int64_t b_batch_stride, float scale,
+                           int32_t accumulate, float* scratch, mgf_stream_t stream) {
+    MGF_REQUIRE(out && a && b && scratch && numel >= 1 && n >= 1 && n <= 65535, MGF_EINVAL, "mse: bad arguments");
+    MGF_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && (numel % 4 == 0 || n == 1) && b_batch_stride % 4 == 0, MGF_EINVAL,
+                "mse: inputs must be 16-byte aligned per sample");
+    const int grid = (int)(mgf_cdiv(numel, 256 * 8) < 1024 ? mgf_cdiv(numel, 256 * 8) : 1024);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(mse_partial_kernel, dim3(grid), dim3(256), 0, st, scratch, a, b, numel);
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, out, scratch, grid, scale / (float)numel, accumulate);
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(grid, n), dim3(256), 0, st, scratch, a, b, numel, b_batch_stride);
+    hipLaunchKernelGGL(finish_kernel, dim3(n), dim3(256), 0, st, out, scratch, grid, scale / (float)numel, accumulate);
     MGF_CHECK_LAUNCH("mse");
     return MGF_OK;
 }
 
 extern "C" int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1, const float* lin, int32_t n, int32_t c, int64_t hw,
-                                   int32_t accumulate, float* scratch, mgf_stream_t stream) {
-    MGF_REQUIRE(out && f0 && f1 && lin && scratch && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer: bad arguments");
-    const int64_t total = (int64_t)n * hw;
-    const int pxb = total >= 65536 ? 64 : 16;
-    const int64_t grid64 = mgf_cdiv(total, pxb);
-    MGF_REQUIRE(grid64 <= mgf_reduce_scratch_floats(), MGF_ETOOBIG, "lpips_layer: %lld pixels need %lld scratch floats (have %lld)",
-                (long long)total, (long long)grid64, (long long)mgf_reduce_scratch_floats());
+                                   int64_t f1_batch_stride, int32_t accumulate, float* scratch, mgf_stream_t stream) {
+    MGF_REQUIRE(out && f0 && f1 && lin && scratch && n >= 1 && n <= 65535 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer: bad arguments");
+    const int pxb = hw >= 65536 ? 64 : 16;
+    const int64_t grid64 = mgf_cdiv(hw, pxb);
+    MGF_REQUIRE(grid64 <= RED_BLOCKS, MGF_ETOOBIG, "lpips_layer: %lld pixels per sample need %lld scratch floats (have %d per sample)",
+                (long long)hw, (long long)grid64, RED_BLOCKS);
     const int grid = (int)grid64;
     hipStream_t st = (hipStream_t)stream;
-    if (pxb == 64) hipLaunchKernelGGL((lpips_partial_kernel<64>), dim3(grid), dim3(256), 0, st, scratch, f0, f1, lin, n, c, hw);
-    else hipLaunchKernelGGL((lpips_partial_kernel<16>), dim3(grid), dim3(256), 0, st, scratch, f0, f1, lin, n, c, hw);
-    // spatial mean per sample, summed over the batch (the loop uses .sum() over N: ...sqz_MSE.py:175)
-    hipLaunchKernelGGL(finish_many_kernel, dim3(1), dim3(256), 0, st, out, scratch, grid, 1.0f / (float)hw, accumulate);
+    if (pxb == 64) hipLaunchKernelGGL((lpips_partial_kernel<64>), dim3(grid, n), dim3(256), 0, st, scratch, f0, f1, lin, c, hw, f1_batch_stride);
+    else hipLaunchKernelGGL((lpips_partial_kernel<16>), dim3(grid, n), dim3(256), 0, st, scratch, f0, f1, lin, c, hw, f1_batch_stride);
+    // spatial mean per sample (networks_basic.py:85-87)
+    hipLaunchKernelGGL(finish_kernel, dim3(n), dim3(256), 0, st, out, scratch, grid, 1.0f / (float)hw, accumulate);
     MGF_CHECK_LAUNCH("lpips_layer");
     return MGF_OK;
 }
 
-extern "C" int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int64_t numel, double omega, double epsilon,
-                                 const int32_t* pred_step, mgf_stream_t stream) {
-    MGF_REQUIRE(out && pred && target && numel >= 1, MGF_EINVAL, "wing_loss: bad arguments");
-    hipLaunchKernelGGL(wing_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, pred, target, numel, omega, epsilon, pred_step);
+extern "C" int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int32_t n, int64_t numel, double omega,
+                                 double epsilon, const int32_t* pred_step, int32_t max_row, mgf_stream_t stream) {
+    MGF_REQUIRE(out && pred && target && numel >= 1 && n >= 1, MGF_EINVAL, "wing_loss: bad arguments");
+    hipLaunchKernelGGL(wing_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, out, pred, target, numel, omega, epsilon, pred_step, max_row);
     MGF_CHECK_LAUNCH("wing_loss");
     return MGF_OK;
 }
@@ -258,20 +263,22 @@ extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, i
 }
 
 extern "C" int mgf_latent_perturb(float* latent_n, const float* latent_in, const float* eps, const float* sigma, const int32_t* step,
-                                  int64_t numel, mgf_stream_t stream) {
-    MGF_REQUIRE(latent_n && latent_in && eps && sigma && step && numel >= 1, MGF_EINVAL, "latent_perturb: bad arguments");
-    hipLaunchKernelGGL(perturb_kernel, dim3((unsigned)mgf_cdiv(numel, 256)), dim3(256), 0, (hipStream_t)stream, latent_n, latent_in, eps,
-                       sigma, step, numel);
+                                  int32_t batch, int32_t steps_total, int64_t numel, mgf_stream_t stream) {
+    MGF_REQUIRE(latent_n && latent_in && eps && sigma && step && numel >= 1 && batch >= 1 && steps_total >= 1, MGF_EINVAL,
+                "latent_perturb: bad arguments");
+    hipLaunchKernelGGL(perturb_kernel, dim3((unsigned)mgf_cdiv(numel * batch, 256)), dim3(256), 0, (hipStream_t)stream, latent_n, latent_in,
+                       eps, sigma, step, batch, steps_total, numel);
     MGF_CHECK_LAUNCH("latent_perturb");
     return MGF_OK;
 }
 
 extern "C" int mgf_select_best(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out, const float* latent_n,
                                int64_t numel, const float* p_loss, const double* w_loss, const float* mse_loss, float lamda, float beta,
-                               int32_t* step, const int32_t* valid, mgf_stream_t stream) {
-    MGF_REQUIRE(min_loss && best_latent && best_step && latent_n && step && numel >= 1, MGF_EINVAL, "select_best: bad arguments");
+                               int32_t* step, const int32_t* valid, int32_t batch, int32_t steps_total, mgf_stream_t stream) {
+    MGF_REQUIRE(min_loss && best_latent && best_step && latent_n && step && numel >= 1 && batch >= 1 && steps_total >= 1, MGF_EINVAL,
+                "select_best: bad arguments");
     hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, min_loss, best_latent, best_step, losses_out, latent_n,
-                       numel, p_loss, w_loss, mse_loss, lamda, beta, step, valid);
+                       numel, p_loss, w_loss, mse_loss, lamda, beta, step, valid, batch, steps_total);
     MGF_CHECK_LAUNCH("select_best");
     return MGF_OK;
 }

@@ -365,20 +365,17 @@ class Generator:
         return t, t.shape[0]
 
     def _draw_noise(self, n):
-        """Fresh N(0,1) maps per layer and call (networks.py:1016-1017): one torch.randn launch for all 17 layers."""
+        """Fresh N(0,1) maps per layer and call (networks.py:1016-1017): ONE torch.randn launch fills a flat buffer that is
+        laid out layer-major ([layer][n][r*r]), so every layer sees a dense [n, r, r] view without copies."""
         sizes = [(lp.name, lp.res) for lp in self.plan.layers if lp.noise_strength is not None]
         total = sum(r * r for _, r in sizes)
-        if self.noise_rand is None or self.noise_rand.shape != (n, total):
-            self.noise_rand = torch.empty([n, total], dtype=torch.float32, device=self.device)
-            self._noise_views = None
+        if self.noise_rand is None or self.noise_rand.numel() != n * total:
+            self.noise_rand = torch.empty(n * total, dtype=torch.float32, device=self.device)
         self.noise_rand.normal_()
         out, off = {}, 0
         for name, r in sizes:
-            out[name] = self.noise_rand[:, off:off + r * r]
+            out[name] = self.noise_rand[off * n:(off + r * r) * n].view(n, r * r)
             off += r * r
-        # views are [n, r*r] with row stride `total`; kernels want dense [n, r, r] -> only n == 1 is dense
-        if n > 1:
-            out = {k_: v.contiguous() for k_, v in out.items()}
         return out
 
     def _layer(self, lp, x, B, key, noise_mode, noises, residual):

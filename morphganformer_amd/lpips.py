@@ -60,21 +60,24 @@ def _pool_out(n):
 class SqueezeFeatures:
     """The 7 LPIPS taps of SqueezeNet1.1 for a fixed input size, with a preallocated workspace."""
 
-    def __init__(self, backbone_state, n, h, w, device):
+    def __init__(self, backbone_state, n, h, w, device, share=None):
         self.device = torch.device(device)
         dev = self.device
-        g = lambda k: np.asarray(backbone_state[k], dtype=np.float64)
-        t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
-        w0, b0 = g("features.0.weight"), g("features.0.bias")
-        sc, sh = np.asarray(SCALE), np.asarray(SHIFT)
-        w0f = w0 / sc[None, :, None, None]
-        b0f = b0 - (w0 * (sh / sc)[None, :, None, None]).sum(axis=(1, 2, 3))
-        self.c0 = (cv.pack_weights(t32(w0f)), t32(b0f))
-        self.fires = {}
-        for idx in FIRES:
-            p = f"features.{idx}"
-            self.fires[idx] = tuple((cv.pack_weights(t32(g(f"{p}.{nm}.weight"))), t32(g(f"{p}.{nm}.bias")))
-                                    for nm in ("squeeze", "expand1x1", "expand3x3"))
+        if share is not None:
+            self.c0, self.fires = share.c0, share.fires          # packed weights are size independent
+        else:
+            g = lambda k: np.asarray(backbone_state[k], dtype=np.float64)
+            t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+            w0, b0 = g("features.0.weight"), g("features.0.bias")
+            sc, sh = np.asarray(SCALE), np.asarray(SHIFT)
+            w0f = w0 / sc[None, :, None, None]
+            b0f = b0 - (w0 * (sh / sc)[None, :, None, None]).sum(axis=(1, 2, 3))
+            self.c0 = (cv.pack_weights(t32(w0f)), t32(b0f))
+            self.fires = {}
+            for idx in FIRES:
+                p = f"features.{idx}"
+                self.fires[idx] = tuple((cv.pack_weights(t32(g(f"{p}.{nm}.weight"))), t32(g(f"{p}.{nm}.bias")))
+                                        for nm in ("squeeze", "expand1x1", "expand3x3"))
         self.n = n
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         hh, ww = (h - 3) // 2 + 1, (w - 3) // 2 + 1
@@ -148,36 +151,45 @@ class PerceptualLoss(torch.nn.Module):
         self.backbone_state = backbone_state if backbone_state is not None else random_squeeze_backbone(backbone_seed)
         lin = np.load(os.path.join(WEIGHTS_DIR, f"lpips_lin_{net}.npz"))
         self.lins = [torch.as_tensor(lin[f"lin{i}"], dtype=torch.float32, device=self.device_) for i in range(len(CHNS))]
-        self._feat = None
+        self._feats = {}
         self._target_taps = None
         self._scratch = torch.empty(int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=self.device_)
         self._val = torch.zeros(1, dtype=torch.float32, device=self.device_)
 
     def _features(self, n, h, w):
-        if self._feat is None or self._feat.n != n or self._feat.buf[1].shape[2:] != ((h - 3) // 2 + 1, (w - 3) // 2 + 1):
-            self._feat = SqueezeFeatures(self.backbone_state, n, h, w, self.device_)
-            self._target_taps = None
-        return self._feat
+        """Feature extractor (workspace) for a batch/input size; packed weights are shared between instances."""
+        key = (n, h, w)
+        f = self._feats.get(key)
+        if f is None:
+            share = next(iter(self._feats.values()), None)
+            f = SqueezeFeatures(self.backbone_state, n, h, w, self.device_, share=share)
+            self._feats[key] = f
+        return f
 
     def set_target(self, target):
-        """Cache the target's 7 feature maps (they do not change across projection iterations)."""
+        """Cache the (single) target's 7 feature maps (they do not change across projection iterations)."""
         n, _, h, w = target.shape
+        assert n == 1
         f = self._features(n, h, w)
         outs = [torch.empty([n, c, *f.shapes[idx][1:]], dtype=torch.float32, device=self.device_)
                 for c, idx in zip(CHNS, TAPS_AFTER)]
         f(target.float(), out=outs)
         self._target_taps = outs
-        self._target_id = (target.data_ptr(), tuple(target.shape))
 
     def distance_into(self, out, pred):
-        """out[0] = sum over taps of the spatial-mean weighted distance between pred and the cached target (batch-summed)."""
-        f = self._features(*[pred.shape[0], pred.shape[2], pred.shape[3]])
+        """out[i] = sum over taps of the spatial-mean weighted distance between pred[i] and the cached (single) target.
+        pred: [n,3,H,W]; out: float32 [n]."""
+        n = pred.shape[0]
+        f = self._features(n, pred.shape[2], pred.shape[3])
         assert self._target_taps is not None, "call set_target first"
         taps = f(pred)
+        need = n * int(_lib.lib().mgf_reduce_scratch_floats())
+        if self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.float32, device=self.device_)
         L, st = _lib.lib(), _lib.stream_ptr()
         for i, (a, b, lin) in enumerate(zip(taps, self._target_taps, self.lins)):
-            n, c, hh, ww = a.shape
-            _lib.check(L.mgf_lpips_layer_f32(out.data_ptr(), a.data_ptr(), b.data_ptr(), lin.data_ptr(), n, c, hh * ww,
+            _, c, hh, ww = a.shape
+            _lib.check(L.mgf_lpips_layer_f32(out.data_ptr(), a.data_ptr(), b.data_ptr(), lin.data_ptr(), n, c, hh * ww, 0,
                                              int(i > 0), self._scratch.data_ptr(), st), "lpips_layer")
         return out
 

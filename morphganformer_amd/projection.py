@@ -74,8 +74,14 @@ class ProjectionEngine:
     """One target image <-> one latent search, replayable as a hipGraph."""
 
     def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True,
-                 lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True):
+                 lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, batch=1):
+        """batch = number of consecutive loop steps evaluated per generator forward.  In literal mode the steps do not depend
+        on each other (latent_in never changes), so evaluating `batch` candidates at once and examining them in step order
+        gives exactly the sequential loop's result while the small 4x4..64x64 layers, the mapping network and the LPIPS tail
+        get `batch` times more parallel work per launch."""
         self.G, self.args = G, args or ProjectionArgs()
+        self.batch = int(batch)
+        assert self.batch >= 1
         a = self.args
         dev = G.device
         self.device = dev
@@ -109,11 +115,12 @@ class ProjectionEngine:
         self.best_latent = torch.zeros(1, k, D, dtype=torch.float32, device=dev)
         self.best_step = torch.full([1], -1, dtype=torch.int32, device=dev)
         self.losses = torch.full([a.step], float("nan"), dtype=torch.float64, device=dev)
-        self.latent_n = torch.empty(1, k, D, dtype=torch.float32, device=dev)
-        self.p_loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.mse_loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.w_loss = torch.zeros(1, dtype=torch.float64, device=dev)
-        self.scratch = torch.empty(int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=dev)
+        B = self.batch
+        self.latent_n = torch.empty(B, k, D, dtype=torch.float32, device=dev)
+        self.p_loss = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.mse_loss = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.w_loss = torch.zeros(B, dtype=torch.float64, device=dev)
+        self.scratch = torch.empty(B * int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=dev)
         if self.percept is not None:
             self.percept.set_target(self.target)
         self.use_graph = use_graph
@@ -121,24 +128,27 @@ class ProjectionEngine:
 
     # ------------------------------------------------------------------ one iteration
     def _iteration(self):
-        L, st, a = _lib.lib(), _lib.stream_ptr(), self.args
+        """`batch` consecutive steps of the loop: perturb -> generator -> losses -> in-order best-so-far selection."""
+        L, st, a, B = _lib.lib(), _lib.stream_ptr(), self.args, self.batch
         _lib.check(L.mgf_latent_perturb(self.latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(),
-                                        self.sigma.data_ptr(), self.step_ctr.data_ptr(), self.numel, st), "latent_perturb")
+                                        self.sigma.data_ptr(), self.step_ctr.data_ptr(), B, self.steps, self.numel, st), "latent_perturb")
         img = self.G(self.latent_n, a.truncation_psi, noise_mode=self.noise_mode)[0]      # psi lands in `c` (SURVEY 0.2)
         if self.percept is not None:
             self.percept.distance_into(self.p_loss, img)
         if self.use_mse:
-            _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), img.numel(), 1.0, 0,
+            per = img.numel() // B
+            _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), B, per, 0, 1.0, 0,
                                      self.scratch.data_ptr(), st), "mse")
         if self.use_wing:
-            _lib.check(L.mgf_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(),
-                                           self.lm_target.numel(), 10.0, 2.0, self.step_ctr.data_ptr(), st), "wing_loss")
+            _lib.check(L.mgf_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), B,
+                                           self.lm_target.numel(), 10.0, 2.0, self.step_ctr.data_ptr(), self.lm_steps.shape[0] - 1, st),
+                       "wing_loss")
         _lib.check(L.mgf_select_best(self.min_loss.data_ptr(), self.best_latent.data_ptr(), self.best_step.data_ptr(),
                                      self.losses.data_ptr(), self.latent_n.data_ptr(), self.numel,
                                      _lib.ptr(self.p_loss if self.percept is not None else None),
                                      _lib.ptr(self.w_loss if self.use_wing else None),
                                      _lib.ptr(self.mse_loss if self.use_mse else None), float(a.lamda), float(a.beta),
-                                     self.step_ctr.data_ptr(), _lib.ptr(self.valid), st), "select_best")
+                                     self.step_ctr.data_ptr(), _lib.ptr(self.valid), B, self.steps, st), "select_best")
         return img
 
     def _capture(self):
@@ -158,9 +168,10 @@ class ProjectionEngine:
         self.graph = g
 
     def run(self, steps=None):
-        """Advance the loop by `steps` iterations (default: all remaining)."""
+        """Advance the loop by `steps` iterations (default: all remaining), `batch` of them per launch sequence."""
         done = int(self.step_ctr.item()) if steps is None else None
         n = (self.steps - done) if steps is None else steps
+        n = (n + self.batch - 1) // self.batch
         if self.use_graph and self.graph is None:
             self._capture()
         for _ in range(n):

@@ -20,7 +20,7 @@ class WingLoss(torch.nn.Module):
         t = target.contiguous().double()
         assert p.shape == t.shape
         out = torch.empty([], dtype=torch.float64, device=p.device)
-        rc = _lib.lib().mgf_wing_loss_f64(out.data_ptr(), p.data_ptr(), t.data_ptr(), p.numel(), float(self.omega),
-                                          float(self.epsilon), None, _lib.stream_ptr())
+        rc = _lib.lib().mgf_wing_loss_f64(out.data_ptr(), p.data_ptr(), t.data_ptr(), 1, p.numel(), float(self.omega),
+                                          float(self.epsilon), None, -1, _lib.stream_ptr())
         _lib.check(rc, "wing_loss")
         return out

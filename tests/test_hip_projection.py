@@ -30,7 +30,7 @@ def test_wing_and_mse_kats(golden):
     out = torch.zeros(1).cuda()
     scratch = torch.empty(int(_lib.lib().mgf_reduce_scratch_floats())).cuda()
     ad, bd = a.cuda(), b.cuda()
-    _lib.check(_lib.lib().mgf_mse_f32(out.data_ptr(), ad.data_ptr(), bd.data_ptr(), a.numel(), 1.0, 0, scratch.data_ptr(), _lib.stream_ptr()))
+    _lib.check(_lib.lib().mgf_mse_f32(out.data_ptr(), ad.data_ptr(), bd.data_ptr(), 1, a.numel(), 0, 1.0, 0, scratch.data_ptr(), _lib.stream_ptr()))
     ref = float(torch.nn.functional.mse_loss(a.double(), b.double()))
     assert abs(float(out) - ref) < 1e-6 * ref
 
@@ -65,7 +65,7 @@ def test_lpips_squeeze_vs_oracle(res):
     assert float(P(x0.cuda(), x0.cuda())) == 0.0
 
 
-def _engine_from_golden(g, use_graph, steps=None):
+def _engine_from_golden(g, use_graph, steps=None, batch=1):
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
     from morphganformer_amd.synth_weights import TINY, make_state_dict
@@ -74,7 +74,7 @@ def _engine_from_golden(g, use_graph, steps=None):
     args = ProjectionArgs(step=int(g["eps"].shape[0]))
     eng = ProjectionEngine(G, torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]),
                            args, percept=None, use_mse=True, lm_target=g["lm_target"], lm_steps=g["lm_steps"],
-                           eps=torch.from_numpy(g["eps"]).cuda(), noise_mode="const", use_graph=use_graph)
+                           eps=torch.from_numpy(g["eps"]).cuda(), noise_mode="const", use_graph=use_graph, batch=batch)
     return eng
 
 
@@ -90,6 +90,20 @@ def test_literal_loop_matches_reference_run(golden, use_graph):
     # idempotence: a second engine on the same inputs reproduces the loss history bit for bit (deterministic reductions)
     lat2, bstep2, bloss2, losses2 = _engine_from_golden(g, use_graph).run().result()
     assert bstep2 == bstep and bloss2 == bloss and np.array_equal(losses2, losses)
+
+
+@pytest.mark.parametrize("batch", [2, 4, 7])
+def test_batched_steps_equal_sequential_loop(golden, batch):
+    """Evaluating `batch` loop steps per generator forward (in-order selection) reproduces the sequential reference run:
+    same best step, bit-identical best latent, same loss history; 50 steps with batch 4 / 7 also covers a ragged last batch."""
+    g = golden("loop_tiny.npz")
+    lat, bstep, bloss, losses = _engine_from_golden(g, True, batch=batch).run().result()
+    assert bstep == int(g["best_step"])
+    assert np.array_equal(lat.numpy(), g["best_latent"])
+    assert not np.isnan(losses).any()
+    assert np.abs(losses - g["losses"]).max() < 1e-3 * np.abs(g["losses"]).max()
+    lat1, bstep1, bloss1, losses1 = _engine_from_golden(g, False, batch=1).run().result()
+    assert bstep1 == bstep and np.abs(losses1 - losses).max() < 1e-5 * np.abs(losses).max()
 
 
 def test_loop_no_face_and_never_improves(golden):
