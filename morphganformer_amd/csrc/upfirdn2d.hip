@@ -168,6 +168,142 @@ __global__ __launch_bounds__(256) void upfirdn_tiled_f32(UFParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide kernels for the two hot shapes of the synthesis network (4x4 filter, down 1, dense NCHW fp32, 16-byte aligned rows):
+//   fir_up1_wide : the blur after the stride-2 transposed conv (up 1, pad x0 = y0 = 1), optional fused epilogue
+//   fir_up2_wide : the skip-path upsample (up 2, pad x0 = y0 = 2)
+// Output tile 64 x 16 per workgroup; a lane produces a 1x4 strip and stores it as one float4; the input footprint is
+// staged with ALIGNED float4 loads (window starts 4 columns left of the tile) -- 3.4x fewer, 4x wider memory instructions
+// than the scalar tiled kernel, which is what this bandwidth-bound op is limited by.
+template <bool EP>
+__global__ __launch_bounds__(256) void fir_up1_wide(UFParams p) {
+    constexpr int TW = 64, TH = 16, WV = 18, IH = TH + 3;          // window: 18 float4 = 72 columns, 19 rows
+    __shared__ float4 sx[IH][WV + 1];
+    __shared__ float sf[4][4];
+    const int tid = threadIdx.x;
+    if (tid < 16) {
+        const int jy = tid >> 2, jx = tid & 3;
+        float v = 0.f;
+        if (jy < p.fh && jx < p.fw) {
+            const int ky = p.flip ? jy : p.fh - 1 - jy, kx = p.flip ? jx : p.fw - 1 - jx;
+            v = p.f[ky * p.fw + kx] * p.gain;
+        }
+        sf[jy][jx] = v;
+    }
+    const int tiles_x = p.out_w / TW, tiles_y = (p.out_h + TH - 1) / TH;
+    const int tile = blockIdx.x % (tiles_x * tiles_y), plane = blockIdx.x / (tiles_x * tiles_y);
+    const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
+    const int n = plane / p.c, c = plane - n * p.c;
+    const float* xb = (const float*)p.x + (int64_t)n * p.sn + (int64_t)c * p.sc;
+    const int xa = ox0 - 4, iy0 = oy0 - p.pady0;                  // window origin (input coordinates)
+    for (int i = tid; i < IH * WV; i += 256) {
+        const int r = i / WV, v4 = i - r * WV;
+        const int iy = iy0 + r, ix = xa + 4 * v4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
+            v = *reinterpret_cast<const float4*>(xb + (int64_t)iy * p.sh + ix);      // row pitch is padded to a multiple of 4
+            if (ix + 1 >= p.in_w) v.y = 0.f;
+            if (ix + 2 >= p.in_w) v.z = 0.f;
+            if (ix + 3 >= p.in_w) v.w = 0.f;
+        }
+        sx[r][v4] = v;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    const int oy = oy0 + ly;
+    // window column of output (ox0 + 4*lx + e), tap jx:  4 + 4*lx + e - padx0 + jx ; padx0 == 1 -> 4*lx + 3 + e + jx
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jy = 0; jy < 4; ++jy) {
+        const float4 a = sx[ly + jy][lx], b = sx[ly + jy][lx + 1], cc = sx[ly + jy][lx + 2];
+        const float w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, cc.x, cc.y, cc.z, cc.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) acc[e] += w[3 + e + jx] * sf[jy][jx];
+    }
+    if (oy < p.out_h) {
+        const int ox = ox0 + 4 * lx;
+        const int64_t yoff = (int64_t)n * p.yn + (int64_t)c * p.yc + (int64_t)oy * p.yh + ox;
+        if (EP) {
+            float nz[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.ep.noise) {
+                const float ns = p.ep.noise_strength ? *p.ep.noise_strength : 1.0f;
+                const float4 nv = *reinterpret_cast<const float4*>(p.ep.noise + ((int64_t)(p.ep.noise_n > 1 ? n : 0) * p.out_h + oy) * p.out_w + ox);
+                nz[0] = nv.x * ns; nz[1] = nv.y * ns; nz[2] = nv.z * ns; nz[3] = nv.w * ns;
+            }
+            const float bb = p.ep.bias ? p.ep.bias[c] : 0.f;
+            float rr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.ep.residual) {
+                const float4 rv = *reinterpret_cast<const float4*>(p.ep.residual + yoff);
+                rr[0] = rv.x; rr[1] = rv.y; rr[2] = rv.z; rr[3] = rv.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[e] + nz[e];
+                v += bb;
+                if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
+                else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+                acc[e] = v * p.ep.gain + rr[e];
+            }
+        }
+        *reinterpret_cast<float4*>((float*)p.y + yoff) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void fir_up2_wide(UFParams p) {
+    constexpr int TW = 64, TH = 16, WV = 10, IH = TH / 2 + 2;       // window: 10 float4 = 40 input columns, 10 input rows
+    __shared__ float sx[IH][WV * 4 + 4];
+    __shared__ float sf[4][4];
+    const int tid = threadIdx.x;
+    if (tid < 16) {
+        const int jy = tid >> 2, jx = tid & 3;
+        float v = 0.f;
+        if (jy < p.fh && jx < p.fw) {
+            const int ky = p.flip ? jy : p.fh - 1 - jy, kx = p.flip ? jx : p.fw - 1 - jx;
+            v = p.f[ky * p.fw + kx] * p.gain;
+        }
+        sf[jy][jx] = v;
+    }
+    const int tiles_x = p.out_w / TW, tiles_y = (p.out_h + TH - 1) / TH;
+    const int tile = blockIdx.x % (tiles_x * tiles_y), plane = blockIdx.x / (tiles_x * tiles_y);
+    const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
+    const int n = plane / p.c, c = plane - n * p.c;
+    const float* xb = (const float*)p.x + (int64_t)n * p.sn + (int64_t)c * p.sc;
+    // pad (2, 2): output 2m + b reads input columns m - 1 + b (tap jx = b) and m + b (tap jx = b + 2); same for rows
+    const int xa = ox0 / 2 - 4, ya = oy0 / 2 - 1;
+    for (int i = tid; i < IH * WV; i += 256) {
+        const int r = i / WV, v4 = i - r * WV;
+        const int iy = ya + r, ix = xa + 4 * v4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = *reinterpret_cast<const float4*>(xb + (int64_t)iy * p.sh + ix);
+        sx[r][4 * v4 + 0] = v.x; sx[r][4 * v4 + 1] = v.y; sx[r][4 * v4 + 2] = v.z; sx[r][4 * v4 + 3] = v.w;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    const int oy = oy0 + ly;
+    const int a2 = ly & 1;                                           // output row parity (oy0 is even)
+    const int r0 = (ly >> 1) + a2;                                   // window row of input row (oy/2 - 1 + a2)
+    // outputs 4*lx + e, e = 0..3 -> m = 2*lx + (e >> 1), b = e & 1 ; window column of input column j is j - xa = j - ox0/2 + 4
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ry = 0; ry < 2; ++ry) {
+        const int jy = a2 + 2 * ry;
+        float w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = sx[r0 + ry][2 * lx + 3 + q];       // input columns 2*lx - 1 .. 2*lx + 2
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = e >> 1, b = e & 1;
+            acc[e] += w[m + b] * sf[jy][b] + w[m + b + 1] * sf[jy][b + 2];
+        }
+    }
+    if (oy < p.out_h) {
+        const int64_t yoff = (int64_t)n * p.yn + (int64_t)c * p.yc + (int64_t)oy * p.yh + ox0 + 4 * lx;
+        *reinterpret_cast<float4*>((float*)p.y + yoff) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 }  // namespace
 
 extern "C" int mgf_upfirdn2d(void* y, const void* x, const float* f, int dtype, int32_t n, int32_t c, int32_t in_h,
@@ -203,7 +339,18 @@ extern "C" int mgf_upfirdn2d(void* y, const void* x, const float* f, int dtype, 
     hipStream_t stq = (hipStream_t)stream;
     const bool tiled = dtype == MGF_F32 && sw == 1 && yw == 1 && fh <= 4 && fw <= 4 && upx == upy && (upx == 1 || upx == 2) &&
                        downx == 1 && downy == 1 && out_w >= 32 && (int64_t)n * c * mgf_cdiv(out_h, 16) * mgf_cdiv(out_w, 64) <= INT32_MAX;
-    if (tiled) {
+    // wide float4 kernels: 4x4 filter, out_w a multiple of 64, 16-byte aligned rows on both sides
+    const bool wide_ok = tiled && fh == 4 && fw == 4 && out_w % 64 == 0 && sh % 4 == 0 && sc % 4 == 0 && sn % 4 == 0 &&
+                         yh % 4 == 0 && yc % 4 == 0 && yn % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
+                         (!ep || ((!ep->noise || (uintptr_t)ep->noise % 16 == 0) && (!ep->residual || (uintptr_t)ep->residual % 16 == 0)));
+    if (wide_ok && upx == 1 && padx0 == 1 && sh >= (int64_t)((in_w + 3) / 4) * 4 && pady0 >= 0 && pady0 <= 3) {
+        const int blocks = n * c * (int)mgf_cdiv(out_h, 16) * (out_w / 64);
+        if (ep) hipLaunchKernelGGL((fir_up1_wide<true>), dim3(blocks), dim3(256), 0, stq, p);
+        else hipLaunchKernelGGL((fir_up1_wide<false>), dim3(blocks), dim3(256), 0, stq, p);
+    } else if (wide_ok && upx == 2 && padx0 == 2 && pady0 == 2 && !ep && in_w % 4 == 0 && out_h % 2 == 0) {
+        const int blocks = n * c * (int)mgf_cdiv(out_h, 16) * (out_w / 64);
+        hipLaunchKernelGGL(fir_up2_wide, dim3(blocks), dim3(256), 0, stq, p);
+    } else if (tiled) {
         const int blocks = n * c * (int)mgf_cdiv(out_h, 16) * (int)mgf_cdiv(out_w, 64);
         if (upx == 1) hipLaunchKernelGGL((upfirdn_tiled_f32<1>), dim3(blocks), dim3(256), 0, stq, p);
         else hipLaunchKernelGGL((upfirdn_tiled_f32<2>), dim3(blocks), dim3(256), 0, stq, p);

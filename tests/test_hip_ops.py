@@ -117,6 +117,37 @@ def test_upfirdn2d_tiled_vs_oracle(up, pad, shape):
     assert rel_err(gx, gr) < 1e-5
 
 
+@pytest.mark.parametrize("n,c,res", [(1, 3, 64), (2, 5, 128), (1, 2, 192)])
+def test_upfirdn2d_wide_kernels_vs_oracle(n, c, res):
+    """The float4 kernels of the synthesis hot path: (a) blur of a padded-pitch [.., 2h+1, 2w+1] transposed-conv workspace
+    with the fused noise/bias/lrelu/residual epilogue, (b) the x2 skip-path upsample; ragged bottom tiles included."""
+    from morphganformer_amd import _lib, conv as cv
+    from oracle.ops_ref import bias_act_ref, setup_filter_ref, upfirdn2d_ref
+    torch.manual_seed(res + c)
+    f = setup_filter_ref([1, 3, 3, 1])
+    h = res // 2
+    pitch = cv.tconv_pitch(h)
+    t_full = torch.randn(n, c, 2 * h + 1, pitch)                       # pad columns hold garbage on purpose
+    t = t_full[:, :, :, :2 * h + 1]
+    noise, bias, resid = torch.randn(n, res, res), torch.randn(c), torch.randn(n, c, res, res)
+    strength = torch.tensor([0.37])
+    ref = upfirdn2d_ref(t.contiguous(), f, padding=[1, 1, 1, 1], gain=4.0)
+    ref = bias_act_ref(ref + noise[:, None] * strength, bias, act="lrelu", gain=1.3) + resid
+    td = t_full.cuda()[:, :, :, :2 * h + 1]
+    nd, bd, rd, sd_ = noise.cuda(), bias.cuda(), resid.cuda(), strength.cuda()
+    ep = _lib.make_epilogue(bias=bd, noise=nd, noise_strength=sd_, noise_n=n, act="lrelu", gain=1.3, residual=rd)
+    out = torch.empty(n, c, res, res, device="cuda")
+    cv.upfirdn_into(out, td, f.cuda(), up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=ep)
+    assert rel_err(out, ref) < 3e-6
+    out2 = torch.empty(n, c, res, res, device="cuda")
+    cv.upfirdn_into(out2, td, f.cuda(), up=1, pad=(1, 1, 1, 1), gain=4.0)
+    assert rel_err(out2, upfirdn2d_ref(t.contiguous(), f, padding=[1, 1, 1, 1], gain=4.0)) < 3e-6
+    x = torch.randn(n, c, h, h)
+    out3 = torch.empty(n, c, res, res, device="cuda")
+    cv.upfirdn_into(out3, x.cuda(), f.cuda(), up=2, pad=(2, 1, 2, 1), gain=4.0)
+    assert rel_err(out3, upfirdn2d_ref(x, f, up=2, padding=[2, 1, 2, 1], gain=4.0)) < 3e-6
+
+
 def test_upfirdn2d_helpers_vs_oracle():
     from morphganformer_amd.torch_utils.ops import upfirdn2d
     from oracle.ops_ref import setup_filter_ref, upfirdn2d_ref
