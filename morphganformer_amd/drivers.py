@@ -1,0 +1,158 @@
+"""The callers on either side of the projection loop, re-stated as functions:
+
+  image_transform   target image -> [1,3,S,S] in [-1,1]      (1024_example_wing_loss_perceptual_sqz_MSE.py:89-108)
+  save_latent_mat / load_latent_mat    the `.mat` latent exchange format, key 'w'   (1024_merge_morph_2.py:73-92)
+  generate_images   z ~ N(0,1) -> G(z, psi) -> PNG           (1024_generate.py:19-41)
+  merge_morph       (1-a) w1 + a w2 -> G(., psi) -> JPG+.mat (1024_merge_morph_2.py:83-92; the reference hard-codes a = 0.5,
+                    BASELINE config 4 sweeps 11 values)
+  project_image     latent statistics + one ProjectionEngine run + best-of PNG / .mat   (:135-208, :246-268)
+  second_stage      a projection initialised from an earlier result (edit_MSE.py pattern, BASELINE config 5)
+
+Every image is produced by the HIP generator (`engine.Generator`); there is no CPU path here.  Landmark detection (dlib) is a
+closed third-party CPU dependency: landmarks are passed in by the caller (projection.synthetic_landmarks stands in offline).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .projection import ProjectionArgs, ProjectionEngine, latent_stats
+
+
+# ----------------------------------------------------------------------------------------------------------------- image I/O
+def image_transform(src, size=1024, device="cuda"):
+    """Resize(size) (shorter side, bilinear, PIL semantics) -> CenterCrop(size) -> ToTensor -> Normalize(0.5, 0.5).
+    `src`: path or PIL image.  Returns float32 [1,3,size,size] on `device`."""
+    from PIL import Image
+    im = Image.open(src) if not isinstance(src, Image.Image) else src
+    im = im.convert("RGB")
+    w, h = im.size
+    if (w <= h and w != size) or (h < w and h != size):
+        if w <= h:
+            nw, nh = size, int(size * h / w)
+        else:
+            nw, nh = int(size * w / h), size
+        im = im.resize((nw, nh), Image.BILINEAR)
+        w, h = im.size
+    if w < size or h < size:            # CenterCrop pads small images with zeros
+        pl, pt = max((size - w) // 2, 0), max((size - h) // 2, 0)
+        canvas = Image.new("RGB", (max(w, size), max(h, size)))
+        canvas.paste(im, (pl, pt))
+        im, (w, h) = canvas, canvas.size
+    top, left = int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
+    im = im.crop((left, top, left + size, top + size))
+    x = torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)
+    return ((x - 0.5) / 0.5).unsqueeze(0).to(device)
+
+
+def to_uint8_image(G, img):
+    """[1,C,H,W] float32 device image in [-1,1] -> uint8 HWC numpy (misc.to_pil's rint+clip, misc.py:114-130) on the device."""
+    c, h, w = img.shape[1:]
+    out = torch.empty([h, w, c], dtype=torch.uint8, device=img.device)
+    _lib.check(_lib.lib().mgf_to_uint8_hwc(out.data_ptr(), img.contiguous().data_ptr(), c, h, w, _lib.stream_ptr()), "to_uint8")
+    return out.cpu().numpy()
+
+
+def _crop_max_rectangle(im, ratio):
+    if ratio is None:
+        return im
+    w, h = im.size
+    s = min(w, h / ratio)
+    cw, ch = s, ratio * s
+    return im.crop((int((w - cw) // 2), int((h - ch) // 2), int((w + cw) // 2), int((h + ch) // 2)))
+
+
+def save_image(G, img, path, ratio=1.0):
+    from PIL import Image
+    im = _crop_max_rectangle(Image.fromarray(to_uint8_image(G, img), "RGB"), ratio)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    im.save(path)
+    return path
+
+
+def save_latent_mat(path, w):
+    """`{'w': float32 [1,k,D]}` in MATLAB v5 format, like sio.savemat in the drivers (:201-206)."""
+    import scipy.io as sio
+    w = np.asarray(w.detach().cpu() if isinstance(w, torch.Tensor) else w, dtype=np.float32)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    sio.savemat(path, {"w": w})
+    return path
+
+
+def load_latent_mat(path):
+    import scipy.io as sio
+    w = np.asarray(sio.loadmat(path)["w"], dtype=np.float32)
+    if w.ndim != 3:
+        raise ValueError(f"{path}: 'w' has shape {w.shape}, expected [1,k,D]")
+    return w
+
+
+# ----------------------------------------------------------------------------------------------------------------- drivers
+def generate_images(G, images_num=32, truncation_psi=0.7, output_dir=None, ratio=1.0, seed=None, noise_mode="random"):
+    """1024_generate.py:31-41.  Returns the list of z tensors used (and writes sample_%06d.png when `output_dir` is given)."""
+    gen = None
+    if seed is not None:
+        gen = torch.Generator(device=G.device)
+        gen.manual_seed(seed)
+    zs = []
+    for i in range(images_num):
+        z = torch.randn([1, G.cfg.k, G.cfg.z_dim], device=G.device, generator=gen)
+        img = G(z, truncation_psi=truncation_psi, noise_mode=noise_mode)[0]
+        if output_dir is not None:
+            save_image(G, img, os.path.join(output_dir, f"sample_{i:06d}.png"), ratio)
+        zs.append(z.cpu())
+    return zs
+
+
+def merge_morph(G, w1, w2, alphas=(0.5,), truncation_psi=0.7, noise_mode="random", out_prefix=None, ratio=1.0):
+    """Linear latent morphs `dw = (1-a) w1 + a w2` rendered with G(dw, psi) (1024_merge_morph_2.py:83-92).
+    w1/w2: numpy or tensors [1,k,D] (what the `.mat` files hold).  Returns (latents [A,1,k,D] numpy, images [A,3,H,W] device).
+    The blend is done in numpy float32 exactly like the reference (`0.5 * w1 + 0.5 * w2` on loadmat arrays)."""
+    a1 = np.asarray(w1.detach().cpu() if isinstance(w1, torch.Tensor) else w1, dtype=np.float32)
+    a2 = np.asarray(w2.detach().cpu() if isinstance(w2, torch.Tensor) else w2, dtype=np.float32)
+    lat, imgs = [], []
+    for a in alphas:
+        if a == 0.5:
+            dw = 0.5 * a1 + 0.5 * a2
+        else:
+            dw = np.float32(1.0 - a) * a1 + np.float32(a) * a2
+        img = G(torch.from_numpy(dw).to(G.device), truncation_psi, noise_mode=noise_mode)[0]
+        if out_prefix is not None:
+            tag = f"{out_prefix}_a{a:.2f}"
+            save_image(G, img, tag + ".jpg", ratio)
+            save_latent_mat(tag + ".mat", dw)
+        lat.append(dw)
+        imgs.append(img[0].clone())
+    return np.stack(lat), torch.stack(imgs)
+
+
+def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None,
+                  eps=None, out_prefix=None, batch=1, use_graph=True, noise_mode="random", use_mse=True, seed=None):
+    """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and
+    `lm_steps` [steps,68,2] are the (injected) landmark detections.  Returns dict(w, step, loss, losses)."""
+    args = args or ProjectionArgs()
+    if latent_mean is None or latent_std is None:
+        gen = None
+        if seed is not None:
+            gen = torch.Generator(device=G.device)
+            gen.manual_seed(seed)
+        latent_mean, latent_std = latent_stats(G, args.n_mean_latent, G.device, generator=gen)
+    eng = ProjectionEngine(G, target, latent_mean, float(latent_std), args, percept=percept, lm_target=lm_target,
+                           lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse)
+    w, step, loss, losses = eng.run().result()
+    if out_prefix is not None:
+        save_latent_mat(f"{out_prefix}.mat", w)
+        img = G(w.to(G.device), None, noise_mode="const")[0]
+        save_image(G, img, f"{out_prefix}-{loss:.4f}.png", args.ratio)
+    return {"w": w, "step": step, "loss": loss, "losses": losses}
+
+
+def second_stage(G, target, w_init, latent_std, lm_target, lm_steps, **kw):
+    """A second projection whose noisy candidates are drawn around an earlier result instead of the latent mean
+    (edit_MSE.py: `latent_in = w1` pattern; BASELINE config 5)."""
+    w0 = torch.as_tensor(np.asarray(w_init.detach().cpu() if isinstance(w_init, torch.Tensor) else w_init, dtype=np.float32))
+    return project_image(G, target, lm_target, lm_steps, latent_mean=w0.reshape(w0.shape[-2:]).to(G.device),
+                         latent_std=latent_std, **kw)

@@ -46,6 +46,7 @@ class ProjectionArgs:
     noise_ramp: float = 0.75
     truncation_psi: float = 0.7
     n_mean_latent: int = 10000
+    ratio: float = 1.0
     min_loss_init: float = 100.0
 
 

@@ -149,17 +149,19 @@ def lpips_ref(bb, lins, img0, img1, per_layer=False):
 # Projection loop, literal semantics
 
 def projection_literal_ref(gen_fn, loss_fn, latent_mean, latent_std, eps_stream, steps,
-                           noise=0.05, noise_ramp=0.75, min_loss_init=100.0):
+                           noise=0.05, noise_ramp=0.75, min_loss_init=100.0, total_steps=None):
     """Best-of-N noisy sampling around latent_mean.
 
     gen_fn(latent [1,k,D]) -> image; loss_fn(step, image) -> python float or None (= 'no face', step skipped);
     eps_stream[i] is the injected randn_like draw of step i.  Returns (best_latent, best_step, best_loss, losses).
+    `total_steps` (default = steps) is args.step of the schedule when only a prefix of the run is evaluated.
     """
+    total_steps = total_steps or steps
     latent_in = latent_mean[None].clone()
     best, best_step, min_loss = None, -1, float(min_loss_init)
     losses = []
     for i in range(steps):
-        t = i / steps
+        t = i / total_steps
         sigma = float(noise_strength_ref(t, float(latent_std), noise, noise_ramp))
         latent_n = latent_in + eps_stream[i] * sigma
         img = gen_fn(latent_n)

@@ -266,6 +266,59 @@ def gold_generator_full(ref):
                         img_ds=torch.nn.functional.avg_pool2d(img, 16).numpy())
 
 
+def gold_config0_256(ref):
+    """BASELINE configs[0]: one 256x256 face, 50-step MSE-only literal projection (the reference's CPU-runnable case).
+    The target is a uint8 image pushed through ToTensor+Normalize like image_transform (...sqz_MSE.py:89-108)."""
+    from morphganformer_amd.synth_weights import SMALL256, make_state_dict, synthetic_latents
+    cfg = SMALL256
+    sd = make_state_dict(cfg, seed=0)
+    G = build_reference_generator(ref, cfg, sd)
+    G.synthesis.list2tensor = lambda att_list, device: torch.zeros([1])
+    steps = 50
+    rng = np.random.Generator(np.random.PCG64(2560))
+    samples = torch.from_numpy(rng.standard_normal((10000, cfg.k, cfg.z_dim)).astype(np.float32))
+    latent_mean = samples.mean(0)
+    latent_std = ((samples - latent_mean).pow(2).sum() / samples.shape[0]) ** 0.5
+    timg = G(torch.from_numpy(synthetic_latents(cfg, 1, seed=1002)), None, noise_mode="const")[0].clamp(-1, 1)
+    target_u8 = ((timg[0] + 1) * 127.5).round().clamp(0, 255).to(torch.uint8)
+    target = target_u8.float().div(255).sub(0.5).div(0.5)[None]
+    eps = rng.standard_normal((steps, 1, cfg.k, cfg.z_dim)).astype(np.float32)
+    mse = torch.nn.MSELoss()
+    latent_in = latent_mean[None].clone()
+    min_loss, best, best_step = 100.0, None, -1
+    losses = np.zeros(steps, np.float64)
+    for i in range(steps):
+        t = i / steps
+        sigma = latent_std * 0.05 * max(0, 1 - t / 0.75) ** 2
+        latent_n = latent_in + torch.from_numpy(eps[i]) * sigma.item()
+        img = G(latent_n, 0.7, noise_mode="const")[0]
+        total = 1.0 * mse(img, target)
+        losses[i] = float(total)
+        if float(total) < min_loss:
+            min_loss, best, best_step = float(total), latent_n.clone(), i
+    np.savez_compressed(os.path.join(OUT, "loop_config0_256.npz"), latent_mean=latent_mean.numpy(),
+                        latent_std=np.float32(latent_std.item()), target_u8=target_u8.numpy(), eps=eps, losses=losses,
+                        best_latent=best.numpy(), best_step=np.int64(best_step), best_loss=np.float64(min_loss))
+
+
+def gold_morph_tiny(ref, G):
+    """BASELINE config 4's rendering half: 11 linear morphs of two latents through G(dw, psi) (1024_merge_morph_2.py:83-86;
+    psi is passed positionally, i.e. into `c`, so no truncation is applied)."""
+    from morphganformer_amd.synth_weights import TINY, synthetic_latents
+    w1 = synthetic_latents(TINY, 1, seed=2001)
+    w2 = synthetic_latents(TINY, 1, seed=2002)
+    alphas = np.linspace(0.0, 1.0, 11)
+    imgs, lats = [], []
+    for a in alphas:
+        dw = 0.5 * w1 + 0.5 * w2 if a == 0.5 else np.float32(1.0 - a) * w1 + np.float32(a) * w2
+        imgs.append(G(torch.from_numpy(dw), 0.7, noise_mode="const")[0][0].numpy())
+        lats.append(dw)
+    # the keyword form used by 1024_generate.py:35 does apply the truncation
+    img_psi = G(torch.from_numpy(w1), truncation_psi=0.7, noise_mode="const")[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "morph_tiny.npz"), w1=w1, w2=w2, alphas=alphas, latents=np.stack(lats),
+                        images=np.stack(imgs), img_w1_psi07=img_psi)
+
+
 def gold_loss_kats(ref):
     out = {}
     wing = ref.wing_loss.WingLoss()
@@ -297,6 +350,15 @@ def main():
     sys.path.insert(0, ROOT)
     ref = import_reference()
     torch.manual_seed(0)
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+    if only:
+        # regenerate a subset without touching the other fixtures
+        if "config0" in only:
+            gold_config0_256(ref)
+        if "morph" in only:
+            from morphganformer_amd.synth_weights import TINY, make_state_dict
+            gold_morph_tiny(ref, build_reference_generator(ref, TINY, make_state_dict(TINY, seed=0)))
+        return
     gold_bias_act(ref)
     gold_upfirdn2d(ref)
     gold_modconv(ref)
@@ -304,6 +366,8 @@ def main():
     gold_lin_heads()
     G, _ = gold_generator_tiny(ref)
     gold_loop_tiny(ref, G)
+    gold_morph_tiny(ref, G)
+    gold_config0_256(ref)
     if "--no-full" not in sys.argv:
         gold_generator_full(ref)
     for f in sorted(os.listdir(OUT)):

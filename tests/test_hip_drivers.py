@@ -1,0 +1,120 @@
+"""GPU parity for the callers either side of the projection loop and the remaining BASELINE configs:
+
+ * configs[0]  256^2, 50 steps, MSE only            vs tests/golden/loop_config0_256.npz (a run of the REFERENCE modules)
+ * config 4    11 linear morphs through G(dw, psi)  vs tests/golden/morph_tiny.npz (REFERENCE Generator)
+ * config 5    second-stage projection initialised from an earlier result: vs the CPU oracle loop
+ * loader.load_network on a reference-layout pickle -> HIP Generator, generate/project drivers' file outputs
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny_G(seed=0, max_batch=1):
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    return Generator(make_state_dict(TINY, seed=seed), TINY, "cuda", max_batch=max_batch)
+
+
+@pytest.mark.parametrize("batch", [1, 5])
+def test_config0_256_mse_only_matches_reference_run(golden, batch):
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    from morphganformer_amd.synth_weights import SMALL256, make_state_dict
+    g = golden("loop_config0_256.npz")
+    G = Generator(make_state_dict(SMALL256, seed=0), SMALL256, "cuda", max_batch=batch)
+    target = torch.from_numpy(g["target_u8"]).float().div(255).sub(0.5).div(0.5)[None].cuda()
+    eng = ProjectionEngine(G, target, torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]), ProjectionArgs(step=50),
+                           percept=None, use_mse=True, eps=torch.from_numpy(g["eps"]).cuda(), noise_mode="const", batch=batch)
+    lat, bstep, bloss, losses = eng.run().result()
+    assert bstep == int(g["best_step"])
+    assert np.array_equal(lat.numpy(), g["best_latent"])                      # bit-exact under injected noise
+    assert np.abs(losses - g["losses"]).max() < 1e-3 * np.abs(g["losses"]).max()
+    assert abs(bloss - float(g["best_loss"])) < 1e-3 * float(g["best_loss"])
+
+
+def test_merge_morph_matches_reference_renderings(golden, tmp_path):
+    from morphganformer_amd import drivers
+    g = golden("morph_tiny.npz")
+    G = _tiny_G()
+    lat, imgs = drivers.merge_morph(G, g["w1"], torch.from_numpy(g["w2"]), alphas=[float(a) for a in g["alphas"]],
+                                    truncation_psi=0.7, noise_mode="const", out_prefix=str(tmp_path / "m" / "a+b"))
+    assert np.array_equal(lat, g["latents"])                                   # the blend itself: bit-exact
+    err = (imgs.cpu().numpy() - g["images"])
+    assert np.abs(err).max() < 2e-4 * np.abs(g["images"]).max()
+    # psi given by keyword (1024_generate.py:35) really truncates; positionally (merge_morph / the loop) it lands in `c`
+    img_kw = G(torch.from_numpy(g["w1"]).cuda(), truncation_psi=0.7, noise_mode="const")[0].cpu().numpy()
+    assert np.abs(img_kw - g["img_w1_psi07"]).max() < 2e-4 * np.abs(g["img_w1_psi07"]).max()
+    assert np.abs(img_kw - g["images"][0]).max() > 1e-2
+    # files: 11 jpg + 11 mat, the .mat holds the blended latent under 'w'
+    files = sorted(os.listdir(tmp_path / "m"))
+    assert len([f for f in files if f.endswith(".jpg")]) == 11 and len([f for f in files if f.endswith(".mat")]) == 11
+    assert np.array_equal(drivers.load_latent_mat(str(tmp_path / "m" / "a+b_a0.50.mat")), g["latents"][5])
+
+
+def test_second_stage_projection_vs_oracle(golden):
+    """Config 5: candidates are drawn around an earlier projection's result instead of latent_mean."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.projection import ProjectionArgs
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from oracle.generator_ref import generator_ref, to_torch_state
+    from oracle.loss_ref import mse_ref, projection_literal_ref
+    g = golden("loop_tiny.npz")
+    G = _tiny_G()
+    steps = 12
+    w1 = g["best_latent"]                                                      # stage-1 result of the reference run
+    eps = torch.from_numpy(np.random.Generator(np.random.PCG64(8)).standard_normal((steps, 1, TINY.k, TINY.z_dim)).astype(np.float32))
+    target = torch.from_numpy(g["target"])
+    res = drivers.second_stage(G, target.cuda(), w1, float(g["latent_std"]), None, None, args=ProjectionArgs(step=steps),
+                               eps=eps.cuda(), noise_mode="const", batch=4)
+    tsd = to_torch_state(make_state_dict(TINY, seed=0))
+    ref = projection_literal_ref(lambda z: generator_ref(tsd, z, TINY, "const"), lambda i, img: float(mse_ref(img, target)),
+                                 torch.from_numpy(w1[0]), float(g["latent_std"]), eps, steps)
+    assert res["step"] == ref[1]
+    assert torch.equal(res["w"], ref[0])
+    assert np.allclose(res["losses"], np.array(ref[3]), rtol=1e-3)
+
+
+def test_load_network_builds_the_hip_generator(tmp_path):
+    from morphganformer_amd import loader
+    from test_host_and_abi import _tiny_snapshot
+    p = str(tmp_path / "net.pkl")
+    _tiny_snapshot(p, seed=3)
+    nets = loader.load_network(p, device="cuda")
+    G = nets["Gs"]
+    assert isinstance(nets["D"], loader.PersistentStub)                       # never instantiated on this path
+    from morphganformer_amd.synth_weights import TINY, synthetic_latents
+    z = torch.from_numpy(synthetic_latents(TINY, 1, seed=4)).cuda()
+    a = G(z, None, noise_mode="const")[0]
+    b = _tiny_G(seed=3)(z, None, noise_mode="const")[0]
+    assert torch.equal(a, b)
+    assert G.input_shape[1:] == [TINY.k, TINY.z_dim] and G.img_resolution == 64
+
+
+def test_generate_and_project_drivers_write_what_the_reference_writes(tmp_path):
+    from PIL import Image
+    from morphganformer_amd import drivers
+    from morphganformer_amd.projection import ProjectionArgs, synthetic_landmarks
+    G = _tiny_G()
+    zs = drivers.generate_images(G, images_num=3, truncation_psi=0.7, output_dir=str(tmp_path / "gen"), seed=1, noise_mode="const")
+    assert sorted(os.listdir(tmp_path / "gen")) == [f"sample_{i:06d}.png" for i in range(3)]
+    im = np.asarray(Image.open(tmp_path / "gen" / "sample_000001.png"))
+    assert im.shape == (64, 64, 3) and im.dtype == np.uint8
+    ref = G(zs[1].cuda(), truncation_psi=0.7, noise_mode="const")[0][0].cpu().numpy().transpose(1, 2, 0)
+    assert np.array_equal(im, np.rint(ref * 127.5 + 127.5).clip(0, 255).astype(np.uint8))      # misc.to_pil's rounding
+    # project: target image file -> transform -> loop -> .mat + best-of PNG
+    Image.fromarray(im).resize((80, 72)).save(tmp_path / "face.png")
+    target = drivers.image_transform(str(tmp_path / "face.png"), size=64)
+    assert target.shape == (1, 3, 64, 64) and target.is_cuda
+    steps = 8
+    lm_t, lm_s = synthetic_landmarks(steps, 64, 2)
+    out = drivers.project_image(G, target, lm_t, lm_s, args=ProjectionArgs(step=steps, n_mean_latent=500), seed=0,
+                                out_prefix=str(tmp_path / "proj" / "face"), batch=2, noise_mode="const")
+    assert out["w"].shape == (1, 17, 32) and 0 <= out["step"] < steps and out["loss"] == np.nanmin(out["losses"])
+    files = sorted(os.listdir(tmp_path / "proj"))
+    assert files[0].startswith("face-") and files[0].endswith(".png") and files[1] == "face.mat"
+    assert np.array_equal(drivers.load_latent_mat(str(tmp_path / "proj" / "face.mat")), out["w"].numpy())

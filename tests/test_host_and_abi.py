@@ -168,3 +168,95 @@ def test_result_gather_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"ok {r}" in o, o
+
+
+# ----------------------------------------------------------------------------------------------------------------- callers
+def _tiny_snapshot(path, seed=3):
+    from morphganformer_amd import loader
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    sd = make_state_dict(TINY, seed=seed)
+    kw = dict(z_dim=TINY.z_dim, c_dim=0, w_dim=TINY.w_dim, k=TINY.k, img_resolution=TINY.img_resolution, img_channels=3,
+              synthesis_kwargs=dict(channel_base=TINY.channel_base, channel_max=TINY.channel_max, end_res=TINY.attn_max_log2res),
+              mapping_kwargs=dict(num_layers=TINY.mapping_layers))
+    loader.save_snapshot_like_reference(path, {"G": sd, "D": {"b4.fc.weight": np.zeros((2, 3), np.float32)}, "Gs": sd},
+                                        {"G": "Generator", "D": "Discriminator", "Gs": "Generator"}, {"G": kw, "Gs": kw})
+    return sd, kw
+
+
+def test_network_pickle_reader_is_inert_and_complete(tmp_path):
+    """loader.load_network's file format (persistence.py:110-118,171-194) without exec: stubs, state_dict, config."""
+    import pickle
+    from morphganformer_amd import loader
+    from morphganformer_amd.synth_weights import TINY
+    p = str(tmp_path / "net.pkl")
+    sd, kw = _tiny_snapshot(p)
+    stubs = loader.load_network_stubs(p)
+    assert set(stubs) == {"G", "D", "Gs"} and stubs["D"].class_name == "Discriminator"
+    got = stubs["Gs"].state_dict()
+    assert set(got) == set(sd)
+    for k in sd:
+        assert np.array_equal(np.asarray(sd[k]), got[k].numpy()), k
+    assert loader.config_from_stub(stubs["Gs"]) == TINY
+    # anything outside the allow-list is refused before it can run
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+    with open(p, "wb") as f:
+        pickle.dump({"G": Evil(), "D": Evil(), "Gs": Evil()}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        loader.load_network_stubs(p)
+    assert not (tmp_path / "pwned").exists()
+    # a snapshot without the three networks is an error, like the reference's KeyError on ["Gs"]
+    with open(p, "wb") as f:
+        pickle.dump({"G": 1}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        loader.load_network_stubs(p)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/torch_utils"), reason="reference tree not present (GPU box)")
+def test_network_pickle_reader_on_a_real_reference_pickle(tmp_path):
+    """Pickle the REFERENCE Generator with the REFERENCE persistence machinery, read it back with the inert reader."""
+    import pickle
+    from morphganformer_amd import loader
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from oracle.make_golden import build_reference_generator, import_reference
+    ref = import_reference()
+    sd = make_state_dict(TINY, seed=5)
+    G = build_reference_generator(ref, TINY, sd)
+    p = str(tmp_path / "ref.pkl")
+    with open(p, "wb") as f:
+        pickle.dump(dict(G=G, D=G, Gs=G), f)
+    assert b"class Generator" in open(p, "rb").read()           # module source is embedded ... and never executed below
+    stubs = loader.load_network_stubs(p)
+    got = stubs["Gs"].state_dict()
+    want = G.state_dict()
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert torch.equal(v, got[k]), k
+    cfg = loader.config_from_stub(stubs["Gs"])
+    assert cfg == TINY
+
+
+def test_driver_host_helpers(tmp_path):
+    from PIL import Image
+    from morphganformer_amd import drivers
+    # image_transform: shorter side -> size (bilinear), centre crop, [-1,1]
+    rng = np.random.Generator(np.random.PCG64(1))
+    im = Image.fromarray(rng.integers(0, 256, size=(40, 64, 3), dtype=np.uint8), "RGB")
+    x = drivers.image_transform(im, size=32, device="cpu")
+    assert x.shape == (1, 3, 32, 32) and x.dtype == torch.float32 and -1 <= float(x.min()) and float(x.max()) <= 1
+    want = im.resize((int(32 * 64 / 40), 32), Image.BILINEAR)
+    left = int(round((want.size[0] - 32) / 2.0))
+    want = np.asarray(want.crop((left, 0, left + 32, 32)), dtype=np.float32) / 255
+    assert np.array_equal(x[0].permute(1, 2, 0).numpy(), ((torch.from_numpy(want) - 0.5) / 0.5).numpy())
+    same = drivers.image_transform(Image.fromarray(np.full((32, 32, 3), 255, np.uint8)), size=32, device="cpu")
+    assert float(same.min()) == 1.0
+    # .mat latent exchange: key 'w', float32 [1,k,D]
+    w = rng.standard_normal((1, 17, 32)).astype(np.float32)
+    p = drivers.save_latent_mat(str(tmp_path / "a" / "x.mat"), torch.from_numpy(w))
+    assert np.array_equal(drivers.load_latent_mat(p), w)
+    import scipy.io as sio
+    sio.savemat(str(tmp_path / "bad.mat"), {"w": np.zeros(4, np.float32)})
+    with pytest.raises(ValueError):
+        drivers.load_latent_mat(str(tmp_path / "bad.mat"))

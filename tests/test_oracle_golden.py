@@ -171,3 +171,27 @@ def test_generator_ref_full_vs_reference(golden):
     for res, m, r in zip(g["block_res"], g["block_mean"], g["block_rms"]):
         t = taps[f"synthesis.b{int(res)}"].double()
         assert abs(float(t.mean()) - m) < 1e-5 * r and abs(float(t.square().mean().sqrt()) - r) < 1e-5 * r
+
+
+def test_morph_ref_vs_reference(golden):
+    """BASELINE config 4's rendering half: the oracle generator on the 11 blended latents the reference rendered."""
+    g = golden("morph_tiny.npz")
+    sd = to_torch_state(make_state_dict(TINY, 0))
+    for i in (0, 5, 10):
+        img = generator_ref(sd, torch.from_numpy(g["latents"][i]), TINY, "const")
+        assert np.allclose(img[0].numpy(), g["images"][i], atol=2e-5, rtol=0)
+    assert np.array_equal(g["latents"][5], 0.5 * g["w1"] + 0.5 * g["w2"])
+
+
+@pytest.mark.slow
+def test_projection_literal_ref_config0_256(golden):
+    """BASELINE configs[0] (256^2, 50 steps, MSE only) -- the oracle loop against the reference run."""
+    from morphganformer_amd.synth_weights import SMALL256
+    g = golden("loop_config0_256.npz")
+    sd = to_torch_state(make_state_dict(SMALL256, 0))
+    target = torch.from_numpy(g["target_u8"]).float().div(255).sub(0.5).div(0.5)[None]
+    steps = 10          # the first 10 of the 50 recorded steps keep the CPU suite short
+    best, bstep, bloss, losses = loss_ref.projection_literal_ref(
+        lambda z: generator_ref(sd, z, SMALL256, "const"), lambda i, img: float(loss_ref.mse_ref(img, target)),
+        torch.from_numpy(g["latent_mean"]), float(g["latent_std"]), torch.from_numpy(g["eps"]), steps, total_steps=50)
+    assert np.allclose(losses[:steps], g["losses"][:steps], rtol=1e-5)
