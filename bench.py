@@ -6,6 +6,10 @@
 Workload (config 2 of BASELINE.json): one 1024x1024 synthetic target per GPU, literal-mode projection
 iteration = perturb latent -> GANformer generator forward (noise_mode="random", like the drivers) -> LPIPS(squeeze)
 + lamda*Wing(injected landmarks) + beta*MSE -> best-so-far selection, all resident on the device and replayed as a hipGraph.
+In literal mode the loop's steps do not depend on each other (the latent never receives a gradient), so the
+engine evaluates `--batch` consecutive steps per generator forward and examines them in step order: the result (best step,
+best latent, loss history) is the sequential loop's, bit for bit (tests/test_hip_projection.py), and every step's full work --
+its own noise draws, forward, three losses, selection -- is inside the timed region.  `steps` counts loop steps, not launches.
 Weights are seeded synthetic tensors (no checkpoint exists offline); inputs are resident in HBM before the timed region.
 N > 1: one independent target per rank (pair-level sharding, no data-path collective) -> "weak" scaling; the only
 collective is the result gather after the timed region.
@@ -48,7 +52,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", type=int, default=1024, help="debug only; the reported config is 1024")
-    ap.add_argument("--batch", type=int, default=4, help="loop steps evaluated per generator forward (exact in literal mode)")
+    ap.add_argument("--batch", type=int, default=8, help="loop steps evaluated per generator forward (exact in literal mode)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
@@ -160,8 +164,10 @@ def main():
     device = torch.device("cuda", local_rank if world > 1 else 0)
     from morphganformer_amd.synth_weights import GeneratorConfig
     cfg = GeneratorConfig(img_resolution=a.res)
-    assert a.steps % a.batch == 0 and a.warmup % a.batch == 0, "--steps and --warmup must be multiples of --batch"
-    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, a.steps + a.warmup, not a.no_graph, a.batch)
+    # the engine advances `batch` loop steps per launch sequence; K or W that are not multiples are rounded UP to whole
+    # launches (more work inside the timed region, never less) while the reported rate still counts exactly K steps
+    rup = lambda v: -(-v // a.batch) * a.batch
+    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, rup(a.steps) + rup(a.warmup), not a.no_graph, a.batch)
 
     log(f"built generator/LPIPS/engine on {device}; warm-up {a.warmup} steps (includes graph capture)")
     eng.run(a.warmup)

@@ -380,7 +380,7 @@ extern "C" int mgf_duplex_attention(float* y, const float* x, const float* wqc, 
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
     MGF_REQUIRE(((uintptr_t)wqc % 16 == 0) && ((uintptr_t)vwb % 16 == 0), MGF_EINVAL, "duplex_attention: tables must be 16-byte aligned");
     static const char* pxb_env = getenv("MGF_ATTN_PXB");      // tuning hook (experiments only)
-    const int pxb = pxb_env ? atoi(pxb_env) : (f >= 16384 ? 64 : 16);
+    const int pxb = pxb_env ? atoi(pxb_env) : (f > 16384 ? 64 : 16);
     const int g = 256 / pxb;
     p.c_pad = (int)(mgf_cdiv(c, UNR * g) * UNR * g);
     const size_t lds = ((size_t)p.c_pad * TMAX + (size_t)g * (TMAX + 1) * pxb) * sizeof(float);

@@ -1,0 +1,68 @@
+"""Per-kernel HBM traffic from rocprofv3 counter-collection CSVs (one pass per counter: FETCH_SIZE costs 3 of the 4 TCC
+slots and WRITE_SIZE 2, MI355X_MICROARCH.md 'rocprofv3 PMC slots').
+
+    python tools/pmc_traffic.py FETCH_DIR WRITE_DIR [--calib CALIB_FETCH_DIR CALIB_WRITE_DIR] [--match SUBSTR]
+
+Prints, per kernel name, launches and the mean counter value per launch (raw KiB -> bytes), and when --calib is given
+the factors (true bytes / reported bytes) measured on tools/pmc_calib.py's 1 GiB copies.
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def load(d):
+    """{kernel: [values per dispatch]} for the single counter collected in directory tree d."""
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit(f"no *counter_collection.csv under {d}")
+    per = defaultdict(lambda: defaultdict(float))
+    for f in files:
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                key = (f, row.get("Dispatch_Id") or row.get("Correlation_Id"))
+                per[row["Kernel_Name"]][key] += float(row["Counter_Value"])
+    return {k: list(v.values()) for k, v in per.items()}
+
+
+def mean(v):
+    return sum(v) / max(len(v), 1)
+
+
+def main():
+    args = [a for a in sys.argv[1:]]
+    match = None
+    if "--match" in args:
+        i = args.index("--match")
+        match = args[i + 1]
+        del args[i:i + 2]
+    calib = None
+    if "--calib" in args:
+        i = args.index("--calib")
+        calib = (args[i + 1], args[i + 2])
+        del args[i:i + 3]
+    fetch, write = load(args[0]), load(args[1])
+    KIB = 1024.0
+    if calib:
+        cf, cw = load(calib[0]), load(calib[1])
+        true = float(1 << 30)
+        for name in cf:
+            if "elementwise" in name or "copy" in name.lower():
+                r, w = mean(cf[name]) * KIB, mean(cw.get(name, [0])) * KIB
+                if r > 1e8:
+                    print(f"calib {name[:90]}: FETCH {r / 1e6:.1f} MB (true {true / 1e6:.1f}; factor {true / r:.3f}), "
+                          f"WRITE {w / 1e6:.1f} MB (factor {true / max(w, 1):.3f})")
+    print(f"{'kernel':<90} {'launches':>8} {'FETCH_MB':>10} {'WRITE_MB':>10}")
+    rows = []
+    for name in sorted(set(fetch) | set(write)):
+        if match and match not in name:
+            continue
+        rows.append((name, len(fetch.get(name, [])), mean(fetch.get(name, [0])) * KIB / 1e6, mean(write.get(name, [0])) * KIB / 1e6))
+    for name, n, r, w in sorted(rows, key=lambda t: -(t[2] + t[3]) * t[1]):
+        print(f"{name[:90]:<90} {n:>8} {r:>10.2f} {w:>10.2f}")
+
+
+if __name__ == "__main__":
+    main()
