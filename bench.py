@@ -95,22 +95,39 @@ def roofline_leg(eng, iters=3):
     for dst, src in zip((eng.step_ctr, eng.min_loss, eng.best_latent, eng.best_step, eng.losses), state):
         dst.copy_(src)
     agg = {}
-    for kernel, flops, secs, ksplit in prof:
-        a = agg.setdefault(kernel, [0.0, 0.0, 0])
+    for kernel, flops, secs, ksplit, nbytes in prof:
+        a = agg.setdefault(kernel, [0.0, 0.0, 0, 0.0])
         a[0] += flops
         a[1] += secs
         a[2] += 1
+        a[3] += nbytes
     dom = max(agg, key=lambda k_: agg[k_][1])
-    flops, secs, launches = agg[dom]
+    flops, secs, launches, nbytes = agg[dom]
     achieved = flops / secs / 1e12
     per_kernel = {k_: {"launches_per_iter": v[2] // iters, "avg_us": round(v[1] / v[2] * 1e6, 2), "tflops": round(v[0] / v[1] / 1e12, 2)}
                   for k_, v in agg.items()}
     total_conv_s = sum(v[1] for v in agg.values()) / iters
     return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), **pmc_traffic(dom, eng),
+            "algorithmic_bytes_per_launch": round(nbytes / launches),
             "avg_launch_us": round(secs / launches * 1e6, 2), "launches_per_iter": launches // iters,
             "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
             "all_conv_kernels": per_kernel, "conv_ms_per_iter": round(total_conv_s * 1e3, 3)}
+
+
+def pmc_traffic(kernel, eng):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
+    this same workload, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled on gfx950, WRITE_SIZE as read; see
+    profiles/README.md).  Counters cannot be read from inside the process, so the figure is only reported when this run is
+    the configuration the passes were collected on (1024^2, 8 steps per forward); otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if not (os.path.exists(path) and eng.batch == 8 and eng.G.cfg.img_resolution == 1024):
+        return {"traffic": None}
+    with open(path) as fh:
+        rec = json.load(fh).get(kernel)
+    if rec is None:
+        return {"traffic": None}
+    return {"traffic": rec["hbm_bytes"], "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_traffic.json)"}
 
 
 def cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, iters):

@@ -128,6 +128,7 @@ typedef struct mgf_conv_prof_rec {
     char kernel[64];      /* demangled kernel name as rocprofv3 prints it, e.g. "conv_taps_kernel<2, 2, 0, true, 9>" */
     double flops;         /* algorithmic FLOPs of the launch (transposed conv counted per input pixel) */
     double seconds;       /* event-to-event duration */
+    double bytes;         /* algorithmic HBM bytes of the launch: input + output (the RGB image when ToRGB is fused) + weights, each once */
     int32_t ksplit;       /* K slices used (1 = no split) */
     int32_t pad_;
 } mgf_conv_prof_rec;

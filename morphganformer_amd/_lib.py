@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
 
 
 class ConvProfRec(C.Structure):
-    _fields_ = [("kernel", C.c_char * 64), ("flops", f64), ("seconds", f64), ("ksplit", i32), ("pad_", i32)]
+    _fields_ = [("kernel", C.c_char * 64), ("flops", f64), ("seconds", f64), ("bytes", f64), ("ksplit", i32), ("pad_", i32)]
 
 
 class StyleJob(C.Structure):

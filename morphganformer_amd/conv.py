@@ -23,12 +23,12 @@ def profile_begin():
 
 
 def profile_end(max_recs=4096):
-    """-> list of (kernel_name, algorithmic_flops, seconds, ksplit) in launch order."""
+    """-> list of (kernel_name, algorithmic_flops, seconds, ksplit, algorithmic_bytes) in launch order."""
     recs = (_lib.ConvProfRec * max_recs)()
     n = _lib.lib().mgf_conv_profile_end(recs, max_recs)
     if n < 0:
         _lib.check(n, "conv_profile_end")
-    return [(recs[i].kernel.decode(), recs[i].flops, recs[i].seconds, recs[i].ksplit) for i in range(min(n, max_recs))]
+    return [(recs[i].kernel.decode(), recs[i].flops, recs[i].seconds, recs[i].ksplit, recs[i].bytes) for i in range(min(n, max_recs))]
 
 
 @dataclass

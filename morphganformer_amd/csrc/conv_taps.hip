@@ -61,6 +61,9 @@ struct ConvParams {
     int chunks_per_split;
     int off32_ok;         // one sample of y (and of the split-K slab) spans < 2^30 elements: 32-bit store offsets are safe
     float* partial;       // [ksplit][n][cout][out_h][y_pitch] when ksplit > 1
+    int xcd_per;          // > 0: XCD-aware item order -- workgroup b (dispatched round-robin to XCD b % 8) walks the contiguous
+                          // item range [(b % 8) * xcd_per, +xcd_per): neighbouring tiles and the co-tiles of one pixel tile share
+                          // one XCD's L2 instead of being re-fetched by eight of them
 };
 
 __device__ __forceinline__ float epi(const mgf_epilogue& ep, float v, int n, int co, int oy, int ox, int out_h, int out_w,
@@ -530,10 +533,14 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
 
     if (PIPE) {
         // host guarantees cin % CK == 0 and chunk-aligned K slices: every chunk is full
-        int w = blockIdx.x;
-        if (w >= total_items) return;
+        int slot, slot_step, slot_end, wbase;
+        if (p.xcd_per > 0) {
+            slot = (int)(blockIdx.x >> 3); slot_step = (int)(gridDim.x >> 3); wbase = (int)(blockIdx.x & 7) * p.xcd_per;
+            slot_end = total_items - wbase < p.xcd_per ? total_items - wbase : p.xcd_per;
+        } else { slot = (int)blockIdx.x; slot_step = (int)gridDim.x; wbase = 0; slot_end = total_items; }
+        if (slot >= slot_end) return;
         TileCtx cur;
-        decode(w, cur);
+        decode(wbase + slot, cur);
         int b = 0;
 #if defined(MGF_EXP) && MGF_EXP == 3      // experiment: per-phase shader-clock totals of every workgroup -> workspace
         unsigned long long tPro = 0, tLoop = 0, tEpi = 0, tMfma = 0, tiles_done = 0;
@@ -573,9 +580,9 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
 #if defined(MGF_EXP) && MGF_EXP == 3
             tPro += s1 - s0; tLoop += s2 - s1; tEpi += s3 - s2; ++tiles_done;
 #endif
-            w += (int)gridDim.x;
-            if (w >= total_items) break;
-            decode(w, cur);
+            slot += slot_step;
+            if (slot >= slot_end) break;
+            decode(wbase + slot, cur);
         }
 #if defined(MGF_EXP) && MGF_EXP == 3
         if (tid == 0 && d.workspace) {
@@ -584,8 +591,8 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         }
 #endif
     } else {
-        const int w = blockIdx.x;
-        if (w >= total_items) return;
+        const int w = p.xcd_per > 0 ? (int)(blockIdx.x & 7) * p.xcd_per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+        if (w >= total_items || (p.xcd_per > 0 && (int)(blockIdx.x >> 3) >= p.xcd_per)) return;
         TileCtx cur;
         decode(w, cur);
         const int nchunks = (cur.c_end - cur.c_begin + CK - 1) / CK;
@@ -639,7 +646,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvParams p) {
 
 // ---- optional per-launch instrumentation (mgf_conv_profile_begin/end): HIP events on the launch stream around the main
 // kernel only (not the split-K reduce), so the durations line up with rocprofv3's per-kernel trace ----
-struct ProfRec { hipEvent_t e0, e1; int wm, wn, mode, pipe, nt, ksplit; double flops; };
+struct ProfRec { hipEvent_t e0, e1; int wm, wn, mode, pipe, nt, ksplit; double flops, bytes; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 
@@ -654,6 +661,9 @@ struct ProfScope {
         // counted at its own cost, 2*9*cin*cout per INPUT pixel
         r.flops = mode == 1 ? 2.0 * 9 * d.cin * (double)d.cout * d.in_h * d.in_w * d.n
                             : 2.0 * d.ntaps * d.cin * (double)d.cout * d.tile_h * d.tile_w * d.n;
+        // algorithmic HBM bytes: every input, output (the RGB image when ToRGB is fused: y is not written) and weight once
+        r.bytes = 4.0 * ((double)d.n * d.cin * d.in_h * d.in_w + (double)d.ntaps * d.cin * d.cout +
+                         (double)d.n * (d.rgb_out ? d.rgb_channels : d.cout) * d.out_h * d.out_w);
         (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
         (void)hipEventRecord(r.e0, st);
         g_prof.push_back(r);
@@ -662,7 +672,8 @@ struct ProfScope {
 };
 
 template <int WM, int WN, int MODE>
-int launch_conv(const ConvParams& p, hipStream_t st) {
+int launch_conv(const ConvParams& p_in, hipStream_t st) {
+    ConvParams p = p_in;
     constexpr int CO_T = 32 * WM;
     const size_t buf = ((size_t)CK * p.fh * p.fw + (size_t)p.d.ntaps * CK * CO_T) * sizeof(float);
     const bool pipe = (size_t)CK * p.fh * p.fw <= (size_t)Slots<WM, WN>::XS * 256 &&
@@ -676,6 +687,13 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
     static const char* res_env = getenv("MGF_RESIDENT");      // tuning hook (experiments only): workgroups per CU
     const int64_t resident = (int64_t)MGF_NUM_CU * (res_env ? atoi(res_env) : ((WM == 1 && WN == 2 && MODE == 0) ? 3 : 2));
     dim3 grid((unsigned)(pipe && (p.d.ntaps == 9 || (p.d.ntaps == 1 && MODE == 0)) ? (items < resident ? items : resident) : items));
+    // XCD-aware order needs a grid that is a multiple of the 8 XCDs (a grid of ceil(items/8)*8 workgroups otherwise)
+    static const char* xcd_env = getenv("MGF_XCD");            // tuning hook (experiments only): 0 disables the XCD-aware order
+    p.xcd_per = 0;
+    if (!(xcd_env && xcd_env[0] == '0') && items >= 16) {
+        p.xcd_per = (int)((items + 7) / 8);
+        if (grid.x % 8 != 0) grid.x = (grid.x + 7) / 8 * 8;
+    }
     const int nt = p.d.ntaps;
     if (pipe && nt == 9) {
         ProfScope ps(st, WM, WN, MODE, 1, 9, p);
@@ -750,7 +768,7 @@ extern "C" int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs) {
         if (out && n < max_recs) {
             mgf_conv_prof_rec& o = out[n];
             snprintf(o.kernel, sizeof(o.kernel), "conv_taps_kernel<%d, %d, %d, %s, %d>", r.wm, r.wn, r.mode, r.pipe ? "true" : "false", r.nt);
-            o.flops = r.flops; o.seconds = ms * 1e-3; o.ksplit = r.ksplit;
+            o.flops = r.flops; o.bytes = r.bytes; o.seconds = ms * 1e-3; o.ksplit = r.ksplit;
         }
         ++n;
         (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);

@@ -45,6 +45,29 @@ def test_abi_struct_layouts_match_header():
     assert _lib.ConvDesc.y_pitch.offset % 8 == 0
 
 
+def test_abi_struct_layouts_match_a_c_compiler(tmp_path):
+    """include/mgf.h is plain C: compile a probe with gcc and compare every struct's size and field offsets with ctypes."""
+    from morphganformer_amd import _lib
+    structs = {"mgf_epilogue": _lib.Epilogue, "mgf_conv_desc": _lib.ConvDesc, "mgf_conv_prof_rec": _lib.ConvProfRec,
+               "mgf_style_job": _lib.StyleJob, "mgf_attn_job": _lib.AttnJob}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mgf.h"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, *_ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("return 0; }")
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, *_ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
 def test_host_side_validation_without_gpu(lib):
     """Errors raised before any kernel launch (mirrors the TORCH_CHECKs of the plugins) are reachable on CPU."""
     assert lib.mgf_version() >= 100

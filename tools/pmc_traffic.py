@@ -1,7 +1,7 @@
 """Per-kernel HBM traffic from rocprofv3 counter-collection CSVs (one pass per counter: FETCH_SIZE costs 3 of the 4 TCC
 slots and WRITE_SIZE 2, MI355X_MICROARCH.md 'rocprofv3 PMC slots').
 
-    python tools/pmc_traffic.py FETCH_DIR WRITE_DIR [--calib CALIB_FETCH_DIR CALIB_WRITE_DIR] [--match SUBSTR]
+    python tools/pmc_traffic.py FETCH_DIR WRITE_DIR [--calib CALIB_FETCH_DIR CALIB_WRITE_DIR] [--match SUBSTR] [--json OUT]
 
 Prints, per kernel name, launches and the mean counter value per launch (raw KiB -> bytes), and when --calib is given
 the factors (true bytes / reported bytes) measured on tools/pmc_calib.py's 1 GiB copies.
@@ -38,6 +38,11 @@ def main():
         i = args.index("--match")
         match = args[i + 1]
         del args[i:i + 2]
+    json_out = None
+    if "--json" in args:
+        i = args.index("--json")
+        json_out = args[i + 1]
+        del args[i:i + 2]
     calib = None
     if "--calib" in args:
         i = args.index("--calib")
@@ -62,6 +67,20 @@ def main():
         rows.append((name, len(fetch.get(name, [])), mean(fetch.get(name, [0])) * KIB / 1e6, mean(write.get(name, [0])) * KIB / 1e6))
     for name, n, r, w in sorted(rows, key=lambda t: -(t[2] + t[3]) * t[1]):
         print(f"{name[:90]:<90} {n:>8} {r:>10.2f} {w:>10.2f}")
+    if json_out:
+        import json
+        import re
+        table = {}
+        for name, n, r, w in rows:
+            short = re.sub(r"^void ", "", name)
+            short = re.sub(r"\(anonymous namespace\)::", "", short)
+            short = re.sub(r"\(.*$", "", short).strip()
+            # FETCH_SIZE tallies 128-B requests at 64 B on gfx950 (guide + tools/pmc_calib.py: 536.9 MB reported for a 1073.7 MB
+            # read, 559 MB for the dword-wide variant) -> doubled; WRITE_SIZE is exact (1073.7 / 1101 MB reported for 1073.7 MB)
+            table[short] = {"launches": n, "fetch_bytes_reported": round(r * 1e6), "fetch_bytes": round(2 * r * 1e6),
+                            "write_bytes": round(w * 1e6), "hbm_bytes": round((2 * r + w) * 1e6)}
+        with open(json_out, "w") as fh:
+            json.dump(table, fh, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
