@@ -52,7 +52,8 @@ struct ConvParams {
     mgf_conv_desc d;
     mgf_epilogue ep;
     int has_ep;
-    int tw_log2;          // TW = 1 << tw_log2
+    int tw, rows;         // pixel tile = rows x tw lanes (rows * tw <= PX; lanes beyond it idle); tw = 32 for most layers
+    int tw_magic;         // ceil(65536 / tw): pix / tw == (pix * tw_magic) >> 16 for pix < 512, tw <= 64
     int tiles_x, tiles_y;
     int fh, fw;           // LDS footprint of a pixel tile
     int dy_min, dx_min;
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int l31_ = l31, half_ = half;
-    const int TW = 1 << p.tw_log2;
-    const int rows = PX >> p.tw_log2;
+    const int TW = p.tw;
+    const int rows = p.rows;
     const int ptiles = p.tiles_x * p.tiles_y;
     const int total_items = ptiles * p.co_tiles * d.n * p.ksplit;
     const int plane = d.in_h * d.in_w;
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
 #pragma unroll
     for (int g = 0; g < WN; ++g) {
         const int pix = (wave * WN + g) * 32 + l31;
-        pbase[g] = (pix >> p.tw_log2) * d.istride * p.fw + (pix & (TW - 1)) * d.istride;
+        const int pr = (pix * p.tw_magic) >> 16, pc = pix - pr * TW;
+        pbase[g] = pr < rows ? pr * d.istride * p.fw + pc * d.istride : 0;      // idle lanes read a valid LDS address
     }
 
     f32x16 acc[NG][WM][WN];
@@ -340,9 +342,10 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
 #pragma unroll
             for (int g = 0; g < WN; ++g) {
                 const int pix = (wave * WN + g) * 32 + l31;
-                const int ty = c.ty0 + (pix >> p.tw_log2), tx = c.tx0 + (pix & (TW - 1));
+                const int pr = (pix * p.tw_magic) >> 16;
+                const int ty = c.ty0 + pr, tx = c.tx0 + (pix - pr * TW);
                 const int oy = ty * d.ostride + d.oy[0], ox = tx * d.ostride + d.ox[0];
-                const bool ovalid = ty < d.tile_h && tx < d.tile_w && oy < d.out_h && ox < d.out_w;
+                const bool ovalid = pr < rows && ty < d.tile_h && tx < d.tile_w && oy < d.out_h && ox < d.out_w;
                 float nz = 0.f;
                 if (do_ep && p.ep.noise && ovalid) nz = p.ep.noise[((int64_t)(p.ep.noise_n > 1 ? n : 0) * d.out_h + oy) * d.out_w + ox] * ep_ns;
                 float sum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         // Fast path (every interior tile of a layer whose channel count fills the tile): no per-element predication and
         // 32-bit per-lane offsets from wave-uniform base pointers, i.e. one VALU add per global access instead of 64-bit
         // multiply/add chains -- the epilogue is instruction-issue bound otherwise.
-        const bool fast = p.off32_ok && co0 + CO_T <= d.cout && c.ty0 + rows <= d.tile_h && c.tx0 + TW <= d.tile_w &&
+        const bool fast = p.off32_ok && rows * TW == PX && co0 + CO_T <= d.cout && c.ty0 + rows <= d.tile_h && c.tx0 + TW <= d.tile_w &&
                           (c.ty0 + rows - 1) * d.ostride + (MODE == 1 ? 1 : d.oy[0]) < d.out_h &&
                           (c.tx0 + TW - 1) * d.ostride + (MODE == 1 ? 1 : d.ox[0]) < d.out_w;
         if (fast) {
@@ -396,7 +399,8 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
 #pragma unroll
                     for (int g = 0; g < WN; ++g) {
                         const int pix = (wave * WN + g) * 32 + l31;
-                        const uint32_t ty = c.ty0 + (pix >> p.tw_log2), tx = c.tx0 + (pix & (TW - 1));
+                        const uint32_t pr = ((uint32_t)pix * (uint32_t)p.tw_magic) >> 16;
+                        const uint32_t ty = c.ty0 + pr, tx = c.tx0 + ((uint32_t)pix - pr * (uint32_t)TW);
                         if (MODE == 0) {
                             const uint32_t oy = ty * d.ostride + d.oy[0], ox = tx * d.ostride + d.ox[0];
                             const uint32_t og = oy * pitch32 + ox + hoff;
@@ -449,11 +453,12 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
             int64_t offv[WN];
 #pragma unroll
             for (int g = 0; g < WN; ++g) {
-                const int ty_first = ((wave * WN + g) * 32) >> p.tw_log2;
+                const int ty_first = (((wave * WN + g) * 32) * p.tw_magic) >> 16;
                 const int pix = (wave * WN + g) * 32 + l31;
-                const int ty = c.ty0 + (pix >> p.tw_log2), tx = c.tx0 + (pix & (TW - 1));
+                const int pr = (pix * p.tw_magic) >> 16;
+                const int ty = c.ty0 + pr, tx = c.tx0 + (pix - pr * TW);
                 const int oy = ty * d.ostride + d.oy[0], ox = tx * d.ostride + d.ox[0];
-                ovalid[g] = (c.ty0 + ty_first < d.tile_h) && ty < d.tile_h && tx < d.tile_w && oy < d.out_h && ox < d.out_w;
+                ovalid[g] = (c.ty0 + ty_first < d.tile_h) && pr < rows && ty < d.tile_h && tx < d.tile_w && oy < d.out_h && ox < d.out_w;
                 offv[g] = (int64_t)oy * d.y_pitch + ox;
                 nzv[g] = 0.f;
                 if (do_ep && p.ep.noise && ovalid[g])
@@ -502,11 +507,12 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         }
 #pragma unroll
         for (int g = 0; g < WN; ++g) {
-            const int ty_first = ((wave * WN + g) * 32) >> p.tw_log2;
-            if (c.ty0 + ty_first >= d.tile_h) continue;              // whole pixel group below the image (wave-uniform)
+            const int ty_first = (((wave * WN + g) * 32) * p.tw_magic) >> 16;
+            if (c.ty0 + ty_first >= d.tile_h || ty_first >= rows) continue;   // whole pixel group below the image / the tile (wave-uniform)
             const int pix = (wave * WN + g) * 32 + l31;
-            const int ty = c.ty0 + (pix >> p.tw_log2), tx = c.tx0 + (pix & (TW - 1));
-            const bool pvalid = ty < d.tile_h && tx < d.tile_w;
+            const int pr = (pix * p.tw_magic) >> 16;
+            const int ty = c.ty0 + pr, tx = c.tx0 + (pix - pr * TW);
+            const bool pvalid = pr < rows && ty < d.tile_h && tx < d.tile_w;
 #pragma unroll
             for (int m = 0; m < WM; ++m) {
 #pragma unroll
@@ -832,8 +838,7 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     // tile geometry
     int tw_log2 = 5;
     while (tw_log2 > 2 && (1 << (tw_log2 - 1)) >= d.tile_w) --tw_log2;
-    p.tw_log2 = tw_log2;
-    const int TW = 1 << tw_log2;
+    int TW = 1 << tw_log2;
     // workgroup tile: wide channel tiles when there are >= 64 output channels, more pixels per wave otherwise
     int wm = 1, wn = 2;
     if (mode == 0) {
@@ -847,7 +852,23 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
         }
     }
     const int PX = 128 * wn;
-    const int rows = PX / TW;
+    int rows = PX / TW;
+    if (mode == 1) {
+        // The parity grids of the transposed conv are (in+1) wide -- 33, 65, 129 ...: one column more than a whole number of
+        // 32-wide tiles.  Any width works for the lane -> (row, column) map, so take the one that needs the fewest tiles
+        // (rows * tw may leave a few of the 256 pixel lanes idle).
+        static const char* tw_env = getenv("MGF_TCONV_TW");      // tuning hook (experiments only): 0 keeps 32-wide tiles
+        // an odd width costs the predicated epilogue and some idle lanes: it has to save at least 10% of the tiles
+        int64_t best = mgf_cdiv(d.tile_w, TW) * mgf_cdiv(d.tile_h, rows) * 9;       // in tenths of a tile
+        for (int tw = 8; tw <= 64 && !(tw_env && tw_env[0] == '0'); ++tw) {
+            const int r = PX / tw;
+            const int fh_ = r + (dy_max - dy_min), fw_ = tw + (dx_max - dx_min);
+            if (256 / fw_ + 2 > 2 * fh_ || (size_t)CK * fh_ * fw_ > (size_t)Slots<1, 2>::XS * 256) continue;
+            const int64_t tiles = mgf_cdiv(d.tile_w, tw) * mgf_cdiv(d.tile_h, r);
+            if (tiles * 10 < best) { best = tiles * 10; TW = tw; rows = r; }
+        }
+    }
+    p.tw = TW; p.rows = rows; p.tw_magic = (65536 + TW - 1) / TW;
     p.tiles_x = (int)mgf_cdiv(d.tile_w, TW);
     p.tiles_y = (int)mgf_cdiv(d.tile_h, rows);
     p.fh = (rows - 1) * d.istride + (dy_max - dy_min) + 1;

@@ -8,13 +8,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from morphganformer_amd import conv as cv
-from tools.conv_micro import SHAPES
+from tools.conv_micro import N, SHAPES
 
 for name in sys.argv[1:]:
     cin, cout, res, kind = SHAPES[name]
-    x = torch.randn(1, cin, res, res, device="cuda")
-    s = 1 + 0.1 * torch.randn(1, cin, device="cuda")
-    dsc = 1 + 0.1 * torch.randn(1, cout, device="cuda")
+    x = torch.randn(N, cin, res, res, device="cuda")
+    s = 1 + 0.1 * torch.randn(N, cin, device="cuda")
+    dsc = 1 + 0.1 * torch.randn(N, cout, device="cuda")
     k = 1 if kind == "1x1" else 3
     pc = cv.pack_weights(torch.randn(cout, cin, k, k, device="cuda") / math.sqrt(cin * k * k))
     ws = cv._workspace(0)
