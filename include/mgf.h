@@ -222,6 +222,16 @@ int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int
                       const int32_t* pred_step, int32_t max_row, mgf_stream_t stream);
 int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1, const float* lin, int32_t n, int32_t c, int64_t hw,
                         int64_t f1_batch_stride, int32_t accumulate, float* scratch, mgf_stream_t stream);
+/* The LPIPS(squeeze) stem in one pass: features.0 (conv 3->64, 3x3, stride 2, no padding; w: [64,27] in (ci,kh,kw) order and
+ * b: [64], both with the ScalingLayer folded in) -> ReLU (= LPIPS tap 0) -> MaxPool 3x3/2 ceil_mode, written to
+ * pooled [n,64,ph,pw].  Tap 0 itself never goes to memory (lpips/pretrained_networks.py:6-56, networks_basic.py:64-92):
+ *   reference mode (feat_out != NULL): feat_out [n,64,ch,cw] = tap0 / (|tap0|_channels + 1e-10), kept for the target image;
+ *   distance mode  (feat_ref != NULL): out[i] (+)= mean_hw( sum_c lin[c] * (tap0/(|tap0|+1e-10) - feat_ref)^2 ) against ONE
+ *                  shared reference map feat_ref [64,ch,cw]; scratch as for mgf_lpips_layer_f32.
+ * ch = (h-3)/2+1, ph = ceil((ch-3)/2)+1 (torch's ceil_mode rule), same for the widths. */
+int mgf_lpips_stem_f32(float* pooled, const float* x, const float* w, const float* b, float* feat_out, const float* feat_ref,
+                       const float* lin, float* out, int32_t n, int32_t h, int32_t w_in, int32_t accumulate, float* scratch,
+                       mgf_stream_t stream);
 /* y = max over a 3x3 window, stride 2, ceil_mode (torchvision SqueezeNet1.1 features[2,5,8]) */
 int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                               mgf_stream_t stream);

@@ -81,10 +81,12 @@ _WS = {}
 
 
 def _workspace(dev_index):
-    ws = _WS.get(dev_index)
+    """Split-K scratch of the CURRENT stream (launches on different streams may overlap, so each stream has its own slab)."""
+    key = (dev_index, torch.cuda.current_stream(dev_index).cuda_stream)
+    ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(WORKSPACE_FLOATS, dtype=torch.float32, device=torch.device("cuda", dev_index))
-        _WS[dev_index] = ws
+        _WS[key] = ws
     return ws
 
 

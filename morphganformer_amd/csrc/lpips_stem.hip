@@ -1,0 +1,273 @@
+// LPIPS(SqueezeNet1.1) stem in one pass over the image -- contract: include/mgf.h (mgf_lpips_stem_f32).
+//
+//   features.0  conv 3->64, 3x3, stride 2, no padding (+ScalingLayer folded into w/b)   lpips/pretrained_networks.py:6-56
+//   features.1  ReLU                    -> LPIPS tap 0: unit-normalise over channels, squared difference to the reference
+//                                          tap, 1x1 'lin' weights, spatial mean          lpips/networks_basic.py:64-92
+//   features.2  MaxPool 3x3 stride 2, ceil_mode                                          -> written out for the fire modules
+//
+// The 64-channel tap-0 map (67 MB per 1024^2 image) is the largest tensor of the LPIPS branch; unfused it is written by the
+// conv, read by the pool and read again (twice) by the distance kernel.  Here it only ever exists in registers: HBM sees the
+// image (12.6 MB), the reference tap (read, distance mode) and the pooled map (16.6 MB).
+//
+// One wave = one work item = a strip of 32 conv columns x up to 35 conv rows, walked top to bottom:
+//   * conv: FP32 MFMA 32x32x2, M = 64 output channels (2 tiles), N = 32 pixels of one conv row, K = 27 (+1: the bias rides on
+//     the padded k = 27 with a constant-one B operand).  The A operand (weights) lives in 28 registers for the whole kernel;
+//     the B operand comes from a 4-row ring of input rows in LDS, stored de-interleaved (even | odd columns) so the stride-2
+//     taps read consecutive addresses.
+//   * pool: horizontal 3-max with two DPP wave shifts, vertical 3-max carried in registers from row to row -- no LDS, no
+//     cross-wave traffic.  Strips overlap by one conv row/two columns (recomputed, 3%/7%), each conv pixel is OWNED by exactly
+//     one strip for the distance sum.
+//   * distance: deterministic -- per-item partials in `scratch`, one finishing workgroup per sample adds them in index order.
+#include "mgf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int SLOT = 256;            // floats per input-row slot: 3 channels x (36 even + 36 odd columns)
+constexpr int CH_STRIDE = 72, ODD_OFF = 36;
+constexpr int ONE_A = 4 * SLOT, ONE_B = ONE_A ^ (2 * SLOT);     // cells holding 1.0f (reached with and without the odd-row flip)
+constexpr int LIN_OFF = ONE_B + 4;                               // the 64 'lin' weights (distance mode)
+constexpr int LDS_FLOATS = LIN_OFF + 64;
+constexpr int TILE_COLS = 30;        // conv columns owned per item (32 computed)
+constexpr int PR = 17;               // pooled rows per item (2*PR + 1 conv rows computed)
+constexpr int STEM_RED = 16384;      // scratch floats per sample (same slab size as the other loss reductions)
+
+struct StemParams {
+    float* pooled; const float* x; const float* w; const float* b;
+    float* feat_out; const float* feat_ref; const float* lin; float* scratch;
+    int n, h, w_in, ch, cw, ph, pw, tiles_x, strips;
+};
+
+__device__ __forceinline__ float wave_shl1(float v) {      // lane i <- lane i + 1 (DPP wave_shl:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+template <bool FEAT>
+__global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
+    __shared__ float lds[LDS_FLOATS];
+    const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+    int item = blockIdx.x;
+    const int tx = item % p.tiles_x; item /= p.tiles_x;
+    const int st = item % p.strips;
+    const int n = item / p.strips;
+    const int x0 = tx * TILE_COLS, r0 = st * 2 * PR;
+    const int r_end = r0 + 2 * PR < p.ch - 1 ? r0 + 2 * PR : p.ch - 1;        // last conv row of this strip (inclusive)
+    const bool last_tx = tx == p.tiles_x - 1, last_st = st == p.strips - 1;
+
+    // ---- constant operands: weights (A), per-lane LDS offsets of the 14 K steps (B), lin weights ----
+    float a[2][14];
+    int koff[14];
+#pragma unroll
+    for (int kk = 0; kk < 14; ++kk) {
+        const int k = 2 * kk + half;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int co = m * 32 + l31;
+            a[m][kk] = k < 27 ? p.w[co * 27 + k] : (k == 27 ? p.b[co] : 0.f);
+        }
+        const int ci = k / 9, dy = (k % 9) / 3, dx = k % 3;
+        koff[kk] = k < 27 ? dy * SLOT + ci * CH_STRIDE + (dx == 1 ? ODD_OFF : 0) + l31 + (dx == 2 ? 1 : 0) : ONE_A;
+    }
+    if (lane == 0) { lds[ONE_A] = 1.0f; lds[ONE_B] = 1.0f; }
+    if (!FEAT) lds[LIN_OFF + lane] = p.lin[lane];
+    // Channel of accumulator register q of M tile m: m*32 + (q&3) + 8*(q>>2) + 4*half.  The first three terms are wave-uniform,
+    // so every per-channel address below is a scalar base (SGPR) plus ONE per-lane 32-bit offset that carries 4*half planes.
+#define STEM_CH(m, q) ((m) * 32 + ((q) & 3) + 8 * ((q) >> 2))
+
+    // ---- input rows: global -> 4 registers per lane -> LDS ring slot (row & 3), even | odd columns apart ----
+    const float* xn = p.x + (int64_t)n * 3 * p.h * p.w_in;
+    const int64_t plane = (int64_t)p.h * p.w_in;
+    auto load_row = [&](int ir, float (&g)[4]) {
+        const bool rv = ir < p.h;
+        const int c0 = 2 * x0 + lane;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) g[ci] = (rv && c0 < p.w_in) ? xn[ci * plane + (int64_t)ir * p.w_in + c0] : 0.f;
+        g[3] = (rv && lane < 3 && 2 * x0 + 64 < p.w_in) ? xn[lane * plane + (int64_t)ir * p.w_in + 2 * x0 + 64] : 0.f;
+    };
+    auto store_row = [&](int ir, const float (&g)[4]) {
+        const int base = (ir & 3) * SLOT + ((lane & 1) ? ODD_OFF : 0) + (lane >> 1);
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) lds[base + ci * CH_STRIDE] = g[ci];
+        if (lane < 3) lds[(ir & 3) * SLOT + lane * CH_STRIDE + 32] = g[3];
+    };
+    {
+        float g0[4], g1[4], g2[4];
+        load_row(2 * r0, g0); load_row(2 * r0 + 1, g1); load_row(2 * r0 + 2, g2);
+        store_row(2 * r0, g0); store_row(2 * r0 + 1, g1); store_row(2 * r0 + 2, g2);
+    }
+    __syncthreads();
+
+    const int xc = x0 + l31;
+    const bool colvalid = xc < p.cw;
+    const bool colown = colvalid && (l31 < TILE_COLS || last_tx);
+    float P[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) P[m][q] = 0.f;
+    float dsum = 0.f;
+    const int cplane = p.ch * p.cw;                                         // host guarantees 64 * ch * cw < 2^31
+    const int pplane = p.ph * p.pw;
+    const int lane_feat = 4 * half * cplane + (colvalid ? xc : p.cw - 1);    // per-lane part of a tap-0 address
+    const int lane_pool = 4 * half * pplane + (x0 >> 1) + (l31 >> 1);        // per-lane part of a pooled address
+
+    auto emit = [&](int py) {          // pooled row py <- P (lanes on even columns; windows x .. x+2 stay inside the 31 good lanes)
+        const int px = (x0 >> 1) + (l31 >> 1);
+        if (!(l31 & 1) && l31 <= 28 && px < p.pw && py < p.ph) {
+            float* o = p.pooled + (int64_t)n * 64 * pplane + (int64_t)py * p.pw;           // wave-uniform
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) (o + (int64_t)STEM_CH(m, q) * pplane)[lane_pool] = P[m][q];
+        }
+    };
+
+    for (int r = r0; r <= r_end; ++r) {
+        const int rr = r - r0;
+        float gA[4], gB[4];
+        if (r < r_end) { load_row(2 * r + 3, gA); load_row(2 * r + 4, gB); }
+        float t[2][16];
+        if (!FEAT) {
+            const float* tb = p.feat_ref + (int64_t)r * p.cw;                               // wave-uniform
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) t[m][q] = (tb + (int64_t)STEM_CH(m, q) * cplane)[lane_feat];
+        }
+        // conv row r: rows 2r + dy sit in slots (dy + 2 (r & 1)) & 3
+        const int flip = (r & 1) ? 2 * SLOT : 0;
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 14; ++kk) {
+            const float bv = lds[koff[kk] ^ flip];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], bv, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][kk], bv, acc[1], 0, 0, 0);
+        }
+        __syncthreads();                         // (one wave per workgroup: orders the LDS reads above before the overwrites below)
+        if (r < r_end) { store_row(2 * r + 3, gA); store_row(2 * r + 4, gB); }
+        __syncthreads();
+
+        // ReLU (bias is already in), zero outside the map so it is neutral for the pool
+        float v[2][16];
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float u = acc[m][q] > 0.f ? acc[m][q] : 0.f;
+                v[m][q] = colvalid ? u : 0.f;
+                s += v[m][q] * v[m][q];
+            }
+        s += __shfl_xor(s, 32, 64);              // the other 32 channels of this pixel live in the other half of the wave
+        const float inv = 1.f / (sqrtf(s) + 1e-10f);
+        const bool own = colown && (rr < 2 * PR || last_st);
+        if (FEAT) {
+            if (own) {
+                float* fo = p.feat_out + (int64_t)n * 64 * cplane + (int64_t)r * p.cw;     // wave-uniform
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) (fo + (int64_t)STEM_CH(m, q) * cplane)[lane_feat] = v[m][q] * inv;
+            }
+        } else {
+            float d = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    // separate statements: the product is rounded before the subtraction, exactly like the stored reference
+                    // tap (v * inv above), so identical images give exactly zero
+                    const float ua = v[m][q] * inv;
+                    const float e = ua - t[m][q];
+                    d += lds[LIN_OFF + STEM_CH(m, q) + 4 * half] * e * e;
+                }
+            if (own) dsum += d;
+        }
+        // pool: horizontal 3-max, then the vertical window carried in P
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float s1 = wave_shl1(v[m][q]);
+                const float s2 = wave_shl1(s1);
+                float hmx = v[m][q] > s1 ? v[m][q] : s1;
+                hmx = hmx > s2 ? hmx : s2;
+                v[m][q] = hmx;
+            }
+        if ((rr & 1) == 0) {                     // even row: closes window rr/2 - 1, opens window rr/2
+            if (rr > 0) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) P[m][q] = P[m][q] > v[m][q] ? P[m][q] : v[m][q];
+                emit((r0 >> 1) + (rr >> 1) - 1);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) P[m][q] = v[m][q];
+        } else {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) P[m][q] = P[m][q] > v[m][q] ? P[m][q] : v[m][q];
+        }
+    }
+    // ceil_mode: a map with an even number of rows ends on a two-row window
+    if ((r_end - r0) & 1) emit((r0 >> 1) + ((r_end - r0) >> 1));
+
+    if (!FEAT) {
+        dsum = wave_sum(dsum);
+        if (lane == 0) p.scratch[(int64_t)n * STEM_RED + st * p.tiles_x + tx] = dsum;
+    }
+}
+
+__global__ __launch_bounds__(256) void stem_finish_kernel(float* out, const float* scratch, int nparts, float scale, int accumulate) {
+    __shared__ float sm[4];
+    const float* sc = scratch + (int64_t)blockIdx.x * STEM_RED;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) v += sc[i];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (accumulate ? out[blockIdx.x] : 0.f) + (sm[0] + sm[1] + sm[2] + sm[3]) * scale;
+}
+
+int pool_out(int in) { int o = (in - 3 + 1) / 2 + 1; if ((o - 1) * 2 >= in) --o; return o; }
+
+}  // namespace
+
+extern "C" int mgf_lpips_stem_f32(float* pooled, const float* x, const float* w, const float* b, float* feat_out,
+                                  const float* feat_ref, const float* lin, float* out, int32_t n, int32_t h, int32_t w_in,
+                                  int32_t accumulate, float* scratch, mgf_stream_t stream) {
+    MGF_REQUIRE(pooled && x && w && b && n >= 1 && h >= 7 && w_in >= 7, MGF_EINVAL, "lpips_stem: bad arguments");
+    MGF_REQUIRE((feat_out != nullptr) != (feat_ref != nullptr), MGF_EINVAL,
+                "lpips_stem: give feat_out (reference mode) or feat_ref (distance mode), not both or neither");
+    MGF_REQUIRE(feat_out || (lin && out && scratch), MGF_EINVAL, "lpips_stem: distance mode needs lin, out and scratch");
+    StemParams p;
+    p.pooled = pooled; p.x = x; p.w = w; p.b = b; p.feat_out = feat_out; p.feat_ref = feat_ref; p.lin = lin; p.scratch = scratch;
+    p.n = n; p.h = h; p.w_in = w_in;
+    p.ch = (h - 3) / 2 + 1; p.cw = (w_in - 3) / 2 + 1;
+    p.ph = pool_out(p.ch); p.pw = pool_out(p.cw);
+    p.tiles_x = (int)mgf_cdiv(p.pw, TILE_COLS / 2);
+    p.strips = (int)mgf_cdiv(p.ph, PR);
+    const int64_t per_sample = (int64_t)p.tiles_x * p.strips;
+    MGF_REQUIRE(per_sample <= STEM_RED && per_sample * n <= INT32_MAX, MGF_ETOOBIG, "lpips_stem: image too large (%d x %d)", h, w_in);
+    MGF_REQUIRE((int64_t)64 * p.ch * p.cw < (1LL << 31), MGF_ETOOBIG, "lpips_stem: image too large (%d x %d)", h, w_in);
+    hipStream_t stq = (hipStream_t)stream;
+    const dim3 grid((unsigned)(per_sample * n));
+    if (feat_out) {
+        hipLaunchKernelGGL((lpips_stem_kernel<true>), grid, dim3(64), 0, stq, p);
+    } else {
+        hipLaunchKernelGGL((lpips_stem_kernel<false>), grid, dim3(64), 0, stq, p);
+        hipLaunchKernelGGL(stem_finish_kernel, dim3(n), dim3(256), 0, stq, out, scratch, (int)per_sample,
+                           1.0f / ((float)p.ch * (float)p.cw), accumulate);
+    }
+    MGF_CHECK_LAUNCH("lpips_stem");
+    return MGF_OK;
+}

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -209,6 +210,8 @@ class Generator:
         self._ws_cache = {}
         self.taps = None
         self.fuse_torgb = True
+        self.side = torch.cuda.Stream(device=self.device)
+        self.overlap_skip = os.environ.get("MGF_OVERLAP_SKIP", "1") != "0"      # tuning hook: 0 serialises the skip branch
         self._alloc(max_batch)
 
     # ------------------------------------------------------------------ workspace
@@ -334,9 +337,20 @@ class Generator:
                 x_in = self.const_in
                 x = self._layer(layers[b + ".conv1"], x_in, B, "conv1", noise_mode, noises, residual=None)
             else:
-                cv.conv_forward(x, P.skips[res], out=B["skip_low"])
-                cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0)
+                # the resnet skip branch (1x1 conv + 2x FIR upsample: memory bound) runs on a side stream next to conv0's
+                # MFMA-bound transposed conv; both only read x, and conv1 joins them
+                main = torch.cuda.current_stream(self.device)
+                if self.overlap_skip:
+                    self.side.wait_stream(main)
+                    with torch.cuda.stream(self.side):
+                        cv.conv_forward(x, P.skips[res], out=B["skip_low"])
+                        cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0)
+                else:
+                    cv.conv_forward(x, P.skips[res], out=B["skip_low"])
+                    cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0)
                 x0 = self._layer(layers[b + ".conv0"], x, B, "conv0", noise_mode, noises, residual=None)
+                if self.overlap_skip:
+                    main.wait_stream(self.side)
                 x = self._layer(layers[b + ".conv1"], x0, B, "conv1", noise_mode, noises, residual=B["skip"])
             if self.taps is not None:
                 self.taps[b] = x

@@ -65,6 +65,7 @@ class SqueezeFeatures:
         dev = self.device
         if share is not None:
             self.c0, self.fires = share.c0, share.fires          # packed weights are size independent
+            self.stem_w, self.stem_b = share.stem_w, share.stem_b
         else:
             g = lambda k: np.asarray(backbone_state[k], dtype=np.float64)
             t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
@@ -73,6 +74,7 @@ class SqueezeFeatures:
             w0f = w0 / sc[None, :, None, None]
             b0f = b0 - (w0 * (sh / sc)[None, :, None, None]).sum(axis=(1, 2, 3))
             self.c0 = (cv.pack_weights(t32(w0f)), t32(b0f))
+            self.stem_w, self.stem_b = t32(w0f.reshape(64, 27)), t32(b0f)       # operands of the fused stem kernel
             self.fires = {}
             for idx in FIRES:
                 p = f"features.{idx}"
@@ -97,9 +99,21 @@ class SqueezeFeatures:
                 self.buf[idx] = e(n, c, hh, ww)
             self.shapes[idx] = (c, hh, ww)
 
-    def __call__(self, x, out=None):
+    def stem(self, x, feat_out=None, feat_ref=None, lin=None, dist_out=None, scratch=None):
+        """features.0-2 in one kernel (csrc/lpips_stem.hip): writes the pooled map (self.buf[2]) and either the normalised
+        tap-0 map (`feat_out`, reference image) or the tap-0 LPIPS distance against `feat_ref` into `dist_out` [n]."""
+        _lib.require_gpu(x, feat_out, feat_ref, dist_out)
+        n, _, h, w = x.shape
+        assert n == self.n and x.is_contiguous() and x.dtype == torch.float32
+        _lib.check(_lib.lib().mgf_lpips_stem_f32(self.buf[2].data_ptr(), x.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(),
+                                                 _lib.ptr(feat_out), _lib.ptr(feat_ref), _lib.ptr(lin), _lib.ptr(dist_out), n, h, w, 0,
+                                                 _lib.ptr(scratch), _lib.stream_ptr()), "lpips_stem")
+        return self.buf[2]
+
+    def __call__(self, x, out=None, from_pooled=False):
         """x: [n,3,h,w] in [-1,1] (un-scaled; ScalingLayer is folded).  Returns the list of 7 tap tensors
-        (views of the internal workspace unless `out` -- a list of 7 preallocated tensors -- is given)."""
+        (views of the internal workspace unless `out` -- a list of 7 preallocated tensors -- is given).
+        from_pooled=True: `stem()` already produced the first pooled map; tap 0 is not materialised (entry 0 is None)."""
         _lib.require_gpu(x)
         L = _lib.lib()
         st = _lib.stream_ptr()
@@ -112,10 +126,14 @@ class SqueezeFeatures:
                 return out[TAPS_AFTER.index(idx)]
             return self.buf[idx]
 
-        pc, b = self.c0
-        h = cv.conv_forward(x.contiguous(), pc, stride=2, pad=(0, 0), epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dest(1))
-        taps.append(h)
-        for idx in range(2, 13):
+        if from_pooled:
+            h = self.buf[2]
+            taps.append(None)
+        else:
+            pc, b = self.c0
+            h = cv.conv_forward(x.contiguous(), pc, stride=2, pad=(0, 0), epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dest(1))
+            taps.append(h)
+        for idx in range(3 if from_pooled else 2, 13):
             if idx in POOLS:
                 y = self.buf[idx]
                 n, c, ih, iw = h.shape
@@ -153,6 +171,7 @@ class PerceptualLoss(torch.nn.Module):
         self.lins = [torch.as_tensor(lin[f"lin{i}"], dtype=torch.float32, device=self.device_) for i in range(len(CHNS))]
         self._feats = {}
         self._target_taps = None
+        self.fused_stem = os.environ.get("MGF_LPIPS_STEM", "1") != "0"      # tuning hook: 0 = separate conv / pool / distance kernels
         self._scratch = torch.empty(int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=self.device_)
         self._val = torch.zeros(1, dtype=torch.float32, device=self.device_)
 
@@ -173,7 +192,13 @@ class PerceptualLoss(torch.nn.Module):
         f = self._features(n, h, w)
         outs = [torch.empty([n, c, *f.shapes[idx][1:]], dtype=torch.float32, device=self.device_)
                 for c, idx in zip(CHNS, TAPS_AFTER)]
-        f(target.float(), out=outs)
+        if self.fused_stem:
+            # outs[0] holds the NORMALISED tap 0 (what the stem's distance mode compares against); the same kernel arithmetic
+            # runs on both images, so identical images still give exactly zero
+            f.stem(target.float().contiguous(), feat_out=outs[0])
+            f(target.float(), out=outs, from_pooled=True)
+        else:
+            f(target.float(), out=outs)
         self._target_taps = outs
 
     def distance_into(self, out, pred):
@@ -182,12 +207,18 @@ class PerceptualLoss(torch.nn.Module):
         n = pred.shape[0]
         f = self._features(n, pred.shape[2], pred.shape[3])
         assert self._target_taps is not None, "call set_target first"
-        taps = f(pred)
         need = n * int(_lib.lib().mgf_reduce_scratch_floats())
         if self._scratch.numel() < need:
             self._scratch = torch.empty(need, dtype=torch.float32, device=self.device_)
+        if self.fused_stem:
+            f.stem(pred.contiguous(), feat_ref=self._target_taps[0], lin=self.lins[0], dist_out=out, scratch=self._scratch)
+            taps = f(pred, from_pooled=True)
+        else:
+            taps = f(pred)
         L, st = _lib.lib(), _lib.stream_ptr()
         for i, (a, b, lin) in enumerate(zip(taps, self._target_taps, self.lins)):
+            if a is None:
+                continue                            # tap 0 was consumed inside the stem kernel
             _, c, hh, ww = a.shape
             _lib.check(L.mgf_lpips_layer_f32(out.data_ptr(), a.data_ptr(), b.data_ptr(), lin.data_ptr(), n, c, hh * ww, 0,
                                              int(i > 0), self._scratch.data_ptr(), st), "lpips_layer")

@@ -65,6 +65,65 @@ def test_lpips_squeeze_vs_oracle(res):
     assert float(P(x0.cuda(), x0.cuda())) == 0.0
 
 
+@pytest.mark.parametrize("res", [64, 130, 131, 1024])
+def test_lpips_fused_stem_vs_oracle(res):
+    """The one-pass stem (conv 3->64 s2 + ReLU + tap-0 distance + ceil-mode max-pool, csrc/lpips_stem.hip) against the oracle's
+    conv2d / max_pool2d / normalise: pooled map, the normalised reference tap, the tap-0 distance of a batch of 3 images,
+    and agreement of the whole LPIPS value with the unfused kernels."""
+    from morphganformer_amd import _lib
+    from morphganformer_amd.lpips import PerceptualLoss, random_squeeze_backbone
+    from oracle.loss_ref import squeeze_backbone_random, LPIPS_SHIFT, LPIPS_SCALE
+    import torch.nn.functional as F
+    torch.manual_seed(res)
+    n = 3
+    x = (torch.rand(n, 3, res, res) * 2 - 1)
+    tgt = (x[:1] + 0.3 * torch.randn(1, 3, res, res)).clamp(-1, 1)
+    bb = squeeze_backbone_random(0)
+    P = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, backbone_state=random_squeeze_backbone(0))
+    assert P.fused_stem
+    shift = torch.tensor(LPIPS_SHIFT).reshape(1, 3, 1, 1)
+    scale = torch.tensor(LPIPS_SCALE).reshape(1, 3, 1, 1)
+    w0, b0 = bb["features.0.weight"].double(), bb["features.0.bias"].double()
+
+    def tap0(img):
+        return F.relu(F.conv2d(((img - shift) / scale).double(), w0, b0, stride=2))
+
+    def unit(t):
+        return t / (t.square().sum(1, keepdim=True).sqrt() + 1e-10)
+
+    f = P._features(n, res, res)
+    # reference mode: normalised tap 0 + pooled map
+    feat = torch.empty(n, 64, *f.shapes[1][1:], device="cuda")
+    pooled = f.stem(x.cuda(), feat_out=feat).clone()
+    r0 = tap0(x)
+    rp = F.max_pool2d(r0, 3, 2, ceil_mode=True)
+    assert tuple(pooled.shape) == tuple(rp.shape)
+    assert float((pooled.cpu() - rp).abs().max()) < 2e-5 * float(rp.abs().max())
+    assert float((feat.cpu() - unit(r0)).abs().max()) < 2e-5
+    # distance mode against the (single) target's normalised tap 0
+    f1 = P._features(1, res, res)
+    tfeat = torch.empty(1, 64, *f1.shapes[1][1:], device="cuda")
+    f1.stem(tgt.cuda(), feat_out=tfeat)
+    out = torch.full([n], 7.0, device="cuda")
+    scratch = torch.empty(n * int(_lib.lib().mgf_reduce_scratch_floats()), device="cuda")
+    pooled2 = f.stem(x.cuda(), feat_ref=tfeat, lin=P.lins[0], dist_out=out, scratch=scratch)
+    assert torch.equal(pooled2, pooled)
+    lin0 = P.lins[0].cpu().double().reshape(1, 64, 1, 1)
+    want = ((unit(r0) - unit(tap0(tgt))).square() * lin0).sum(1).mean(dim=(1, 2))
+    assert float((out.cpu().double() - want).abs().max()) < 1e-4 * float(want.abs().max())
+    # whole-LPIPS agreement with the separate conv / pool / distance kernels, and the exact zero on identical images
+    P.set_target(tgt.cuda())
+    fused = torch.zeros(n, device="cuda")
+    P.distance_into(fused, x.cuda())
+    Q = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, backbone_state=random_squeeze_backbone(0))
+    Q.fused_stem = False
+    Q.set_target(tgt.cuda())
+    plain = torch.zeros(n, device="cuda")
+    Q.distance_into(plain, x.cuda())
+    assert float((fused - plain).abs().max()) < 1e-4 * float(plain.abs().max())
+    assert float(P(tgt.cuda(), tgt.cuda())) == 0.0
+
+
 def _engine_from_golden(g, use_graph, steps=None, batch=1):
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
