@@ -210,8 +210,12 @@ int mgf_mapping_forward(float* w, const float* z, const float* params, int32_t n
  *        target)                                      torch.nn.MSELoss, 1024_example_wing_loss_perceptual_sqz_MSE.py:176
  * wing:  out[i] = WingLoss(pred row (*pred_step + i, clamped to max_row when max_row >= 0), target) in f64   wing_loss.py:19-28
  *        (pred is a [rows, numel] table; pred_step NULL = rows 0..n-1)
- * lpips layer: out[i] (+)= mean_hw( sum_c lin[c] * (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))^2 ), f0: [n,c,hw],
- *        f1 samples f1_batch_stride elements apart (0 = shared target features)      lpips/networks_basic.py:70-87
+ * lpips unit:  out = f / (|f|_channels + 1e-10), f: [n,c,hw]  (normalize_tensor, lpips/__init__.py / networks_basic.py:70-80);
+ *        run once per target image on each of its taps
+ * lpips layer: out[i] (+)= mean_hw( sum_c lin[c] * (f0/(|f0|+1e-10) - f1_unit)^2 ), f0: [n,c,hw] raw taps of the candidates,
+ *        f1_unit: UNIT-NORMALISED taps of the target (from mgf_lpips_unit_f32; same arithmetic, so identical images give
+ *        exactly 0), samples f1_batch_stride elements apart (0 = one shared target)    lpips/networks_basic.py:70-87
+ *        at most 512 channels per tap
  * All reduce through a deterministic two-stage reduction (no float atomics) using `scratch`
  * (>= n * mgf_reduce_scratch_floats() floats).
  */
@@ -220,7 +224,8 @@ int mgf_mse_f32(float* out, const float* a, const float* b, int32_t n, int64_t n
                 int32_t accumulate, float* scratch, mgf_stream_t stream);
 int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int32_t n, int64_t numel, double omega, double epsilon,
                       const int32_t* pred_step, int32_t max_row, mgf_stream_t stream);
-int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1, const float* lin, int32_t n, int32_t c, int64_t hw,
+int mgf_lpips_unit_f32(float* out, const float* f, int32_t n, int32_t c, int64_t hw, mgf_stream_t stream);
+int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c, int64_t hw,
                         int64_t f1_batch_stride, int32_t accumulate, float* scratch, mgf_stream_t stream);
 /* The LPIPS(squeeze) stem in one pass: features.0 (conv 3->64, 3x3, stride 2, no padding; w: [64,27] in (ci,kh,kw) order and
  * b: [64], both with the ScalingLayer folded in) -> ReLU (= LPIPS tap 0) -> MaxPool 3x3/2 ceil_mode, written to

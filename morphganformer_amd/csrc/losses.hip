@@ -49,15 +49,16 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(float* scratch, const 
     if (threadIdx.x == 0) scratch[(int64_t)blockIdx.y * RED_BLOCKS + blockIdx.x] = acc;
 }
 
-// grid = (pixel blocks, n).  A workgroup owns PXB consecutive pixels of one sample; its 256 / PXB lane groups split the
-// channels (PXB = 16 for the small deep taps so that a 63x63 map still spreads over ~250 workgroups).  Two sweeps over the
-// channels -- squared norms, then the lin-weighted squared difference of the unit vectors (the second sweep re-reads from
-// L2) -- each unrolled 4-deep; the partial sums meet in LDS in a fixed order, so the result is bit-reproducible.
-template <int PXB>
-__global__ __launch_bounds__(256) void lpips_partial_kernel(float* scratch, const float* f0, const float* f1, const float* lin, int c,
-                                                            int64_t hw, int64_t f1_stride) {
+// grid = (pixel blocks, n).  A workgroup owns PXB consecutive pixels of one sample (lanes = consecutive pixels, so a wave reads
+// whole 64/256-byte segments of a channel plane); its G = 256 / PXB lane groups take the channels grp, grp + G, grp + 2G ...
+// ONE sweep over HBM: each thread keeps its <= CPT channel values in registers, the squared norms meet in LDS in a fixed order
+// (bit-reproducible), then the registers are either written back unit-normalised (UNIT_OUT: the reference image's taps, once
+// per target) or compared with the stored unit-normalised reference taps and reduced to one partial per workgroup.
+template <int PXB, int CPT, bool UNIT_OUT>
+__global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float* unit_out, const float* f0, const float* f1u,
+                                                           const float* lin, int c, int64_t hw, int64_t f1_stride) {
     constexpr int G = 256 / PXB;
-    __shared__ float red[2][G][PXB];
+    __shared__ float red[G][PXB];
     __shared__ float sm[4];
     const int px = threadIdx.x % PXB, grp = threadIdx.x / PXB;
     const int nn = blockIdx.y;
@@ -65,47 +66,66 @@ __global__ __launch_bounds__(256) void lpips_partial_kernel(float* scratch, cons
     const bool valid = i < hw;
     const int64_t pp = valid ? i : hw - 1;
     const float* a = f0 + (int64_t)nn * c * hw + pp;
-    const float* b = f1 + (int64_t)nn * f1_stride + pp;
-    float na = 0.f, nb = 0.f;
-    for (int k0 = grp * 4; k0 < c; k0 += G * 4) {
-        float u[4], v[4];
+    float u[CPT];
+    float na = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = k0 + j < c;
-            u[j] = ok ? a[(int64_t)(k0 + j) * hw] : 0.f;
-            v[j] = ok ? b[(int64_t)(k0 + j) * hw] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { na += u[j] * u[j]; nb += v[j] * v[j]; }
+    for (int j = 0; j < CPT; ++j) {
+        const int k = grp + j * G;
+        u[j] = k < c ? a[(int64_t)k * hw] : 0.f;
     }
-    red[0][grp][px] = na;
-    red[1][grp][px] = nb;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) na += u[j] * u[j];
+    red[grp][px] = na;
     __syncthreads();
-    na = 0.f; nb = 0.f;
-    for (int g = 0; g < G; ++g) { na += red[0][g][px]; nb += red[1][g][px]; }
-    const float ia = 1.f / (sqrtf(na) + 1e-10f), ib = 1.f / (sqrtf(nb) + 1e-10f);
-    float d = 0.f;
-    for (int k0 = grp * 4; k0 < c; k0 += G * 4) {
-        float u[4], v[4], w[4];
+    na = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = k0 + j < c;
-            u[j] = ok ? a[(int64_t)(k0 + j) * hw] : 0.f;
-            v[j] = ok ? b[(int64_t)(k0 + j) * hw] : 0.f;
-            w[j] = ok ? lin[k0 + j] : 0.f;
+    for (int g = 0; g < G; ++g) na += red[g][px];
+    const float ia = 1.f / (sqrtf(na) + 1e-10f);
+    if (UNIT_OUT) {
+        float* o = unit_out + (int64_t)nn * c * hw + pp;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int k = grp + j * G;
+            if (valid && k < c) o[(int64_t)k * hw] = u[j] * ia;
         }
+        return;
+    }
+    const float* b = f1u + (int64_t)nn * f1_stride + pp;
+    float d = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // separate statements: both products are rounded before the subtraction (build uses -ffp-contract=on), so
-            // identical inputs give exactly zero, like the reference's a/|a| - b/|b|
+    for (int j = 0; j < CPT; ++j) {
+        const int k = grp + j * G;
+        if (k < c) {
+            // separate statements: the product is rounded before the subtraction (build uses -ffp-contract=on) exactly like the
+            // stored reference taps (u * ia above), so identical images give exactly zero
             const float ua = u[j] * ia;
-            const float vb = v[j] * ib;
-            const float e = ua - vb;
-            d += w[j] * e * e;
+            const float e = ua - b[(int64_t)k * hw];
+            d += lin[k] * e * e;
         }
     }
     const float acc = block_sum_256(valid ? d : 0.f, sm);
     if (threadIdx.x == 0) scratch[(int64_t)nn * RED_BLOCKS + blockIdx.x] = acc;
+}
+
+template <bool UNIT_OUT>
+int launch_lpips_layer(float* scratch, float* unit_out, const float* f0, const float* f1u, const float* lin, int n, int c, int64_t hw,
+                       int64_t f1_stride, hipStream_t st, int* grid_out) {
+    // 64 pixels per workgroup (256-byte segments) whenever that still yields >= 4 workgroups per CU, 16 for the small deep taps
+    const int pxb = (hw >= 65536 || (int64_t)n * mgf_cdiv(hw, 64) >= 1024) ? 64 : 16;
+    const int64_t grid64 = mgf_cdiv(hw, pxb);
+    MGF_REQUIRE(grid64 <= RED_BLOCKS, MGF_ETOOBIG, "lpips_layer: %lld pixels per sample need %lld scratch floats (have %d per sample)",
+                (long long)hw, (long long)grid64, RED_BLOCKS);
+    MGF_REQUIRE(c <= 512, MGF_EUNSUPPORTED, "lpips_layer: at most 512 channels per tap (got %d)", c);
+    const dim3 grid((unsigned)grid64, (unsigned)n);
+    *grid_out = (int)grid64;
+#define MGF_LPIPS_LAUNCH(PXB, CPT) hipLaunchKernelGGL((lpips_layer_kernel<PXB, CPT, UNIT_OUT>), grid, dim3(256), 0, st, scratch, unit_out, f0, f1u, lin, c, hw, f1_stride)
+    if (pxb == 64) {
+        if (c <= 128) MGF_LPIPS_LAUNCH(64, 32); else if (c <= 256) MGF_LPIPS_LAUNCH(64, 64); else MGF_LPIPS_LAUNCH(64, 128);
+    } else {
+        if (c <= 128) MGF_LPIPS_LAUNCH(16, 8); else if (c <= 256) MGF_LPIPS_LAUNCH(16, 16); else MGF_LPIPS_LAUNCH(16, 32);
+    }
+#undef MGF_LPIPS_LAUNCH
+    return MGF_OK;
 }
 
 // one workgroup per candidate: out[j] = WingLoss(pred row (*pred_step + j), target) in float64
@@ -223,17 +243,22 @@ extern "C" int mgf_mse_f32(float* out, const float* a, const float* b, int32_t n
     return MGF_OK;
 }
 
-extern "C" int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1, const float* lin, int32_t n, int32_t c, int64_t hw,
+extern "C" int mgf_lpips_unit_f32(float* out, const float* f, int32_t n, int32_t c, int64_t hw, mgf_stream_t stream) {
+    MGF_REQUIRE(out && f && n >= 1 && n <= 65535 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_unit: bad arguments");
+    int grid = 0;
+    const int rc = launch_lpips_layer<true>(nullptr, out, f, nullptr, nullptr, n, c, hw, 0, (hipStream_t)stream, &grid);
+    if (rc != MGF_OK) return rc;
+    MGF_CHECK_LAUNCH("lpips_unit");
+    return MGF_OK;
+}
+
+extern "C" int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c, int64_t hw,
                                    int64_t f1_batch_stride, int32_t accumulate, float* scratch, mgf_stream_t stream) {
-    MGF_REQUIRE(out && f0 && f1 && lin && scratch && n >= 1 && n <= 65535 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer: bad arguments");
-    const int pxb = hw >= 65536 ? 64 : 16;
-    const int64_t grid64 = mgf_cdiv(hw, pxb);
-    MGF_REQUIRE(grid64 <= RED_BLOCKS, MGF_ETOOBIG, "lpips_layer: %lld pixels per sample need %lld scratch floats (have %d per sample)",
-                (long long)hw, (long long)grid64, RED_BLOCKS);
-    const int grid = (int)grid64;
+    MGF_REQUIRE(out && f0 && f1_unit && lin && scratch && n >= 1 && n <= 65535 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (pxb == 64) hipLaunchKernelGGL((lpips_partial_kernel<64>), dim3(grid, n), dim3(256), 0, st, scratch, f0, f1, lin, c, hw, f1_batch_stride);
-    else hipLaunchKernelGGL((lpips_partial_kernel<16>), dim3(grid, n), dim3(256), 0, st, scratch, f0, f1, lin, c, hw, f1_batch_stride);
+    int grid = 0;
+    const int rc = launch_lpips_layer<false>(scratch, nullptr, f0, f1_unit, lin, n, c, hw, f1_batch_stride, st, &grid);
+    if (rc != MGF_OK) return rc;
     // spatial mean per sample (networks_basic.py:85-87)
     hipLaunchKernelGGL(finish_kernel, dim3(n), dim3(256), 0, st, out, scratch, grid, 1.0f / (float)hw, accumulate);
     MGF_CHECK_LAUNCH("lpips_layer");

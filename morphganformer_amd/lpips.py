@@ -186,7 +186,8 @@ class PerceptualLoss(torch.nn.Module):
         return f
 
     def set_target(self, target):
-        """Cache the (single) target's 7 feature maps (they do not change across projection iterations)."""
+        """Cache the (single) target's 7 feature maps, unit-normalised over channels (they do not change across projection
+        iterations; the reference recomputes and re-normalises them every step)."""
         n, _, h, w = target.shape
         assert n == 1
         f = self._features(n, h, w)
@@ -199,6 +200,11 @@ class PerceptualLoss(torch.nn.Module):
             f(target.float(), out=outs, from_pooled=True)
         else:
             f(target.float(), out=outs)
+        L, st = _lib.lib(), _lib.stream_ptr()
+        for i, t in enumerate(outs):
+            if i == 0 and self.fused_stem:
+                continue                            # the stem already wrote tap 0 normalised
+            _lib.check(L.mgf_lpips_unit_f32(t.data_ptr(), t.data_ptr(), n, t.shape[1], t.shape[2] * t.shape[3], st), "lpips_unit")
         self._target_taps = outs
 
     def distance_into(self, out, pred):
