@@ -115,6 +115,24 @@ def roofline_leg(eng, iters=3):
             "all_conv_kernels": per_kernel, "conv_ms_per_iter": round(total_conv_s * 1e3, 3)}
 
 
+def generator_leg(eng, iters=3):
+    """The 1024^2 generator forward alone (mapping + synthesis of `batch` candidates, noise_mode="random"), HIP-event timed on
+    the launch stream: north-star target ">= 40% of the MFMA roofline on the generator forward"."""
+    G, a = eng.G, eng.args
+    G(eng.latent_n, a.truncation_psi, noise_mode="random")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        G(eng.latent_n, a.truncation_psi, noise_mode="random")
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters / eng.batch
+    gf = G.cfg.conv_gflop()
+    return {"gflop_per_image": round(gf, 1), "ms_per_image": round(ms, 4), "tflops": round(gf / ms, 2),
+            "frac_of_fp32_mfma_peak": round(gf / ms / FP32_MFMA_PEAK_TFLOPS, 4), "images_per_forward": eng.batch}
+
+
 def pmc_traffic(kernel, eng):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
     this same workload, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled on gfx950, WRITE_SIZE as read; see
@@ -225,6 +243,7 @@ def main():
     }
     if rank == 0:
         out["roofline"] = roofline_leg(eng)
+        out["generator_forward"] = generator_leg(eng)
         log(f"roofline leg done: {out['roofline']['kernel']} {out['roofline']['achieved']} TFLOP/s")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, a.cpu_iters)

@@ -1,0 +1,111 @@
+"""Command-line front ends with the reference scripts' arguments and defaults:
+
+    python -m morphganformer_amd.cli generate --model net.pkl --output-dir images --images-num 32 --truncation-psi 0.7
+                                              (1024_generate.py:44-54)
+    python -m morphganformer_amd.cli project  --model net.pkl --image face.png --landmarks lm.npz --path_to_gen out/
+                                              (1024_example_wing_loss_perceptual_sqz_MSE.py:222-268; argparse names kept)
+    python -m morphganformer_amd.cli morph    --model net.pkl --w1 a.mat --w2 b.mat --alphas 0,0.1,...,1 --out out/a+b
+                                              (1024_merge_morph_2.py:25-92)
+
+`--gpus` pins the visible device like the scripts' CUDA_VISIBLE_DEVICES line.  The reference detects landmarks with dlib on the
+target and on every generated image; dlib is a closed third-party dependency, so `project` takes them from `--landmarks`
+(an .npz with `target` [68,2] and `steps` [>=step,68,2], e.g. written by a detector run elsewhere) or, without it, runs the
+MSE(+LPIPS) objective only (the 1024_example_MSE.py / ..._percept.py variants).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(prog="morphganformer_amd", description="MI355X latent-projection / GANformer drivers")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+
+    g = sub.add_parser("generate", help="Generate images using a pretrained network pickle")
+    g.add_argument("--model", type=str, required=True)
+    g.add_argument("--gpus", type=str, default="0")
+    g.add_argument("--output-dir", type=str, default="images")
+    g.add_argument("--images-num", type=int, default=32)
+    g.add_argument("--truncation-psi", type=float, default=0.7)
+    g.add_argument("--ratio", type=float, default=1.0)
+    g.add_argument("--seed", type=int, default=None)
+
+    p = sub.add_parser("project", help="Project one face image into the latent space")
+    p.add_argument("--model", type=str, default="models/ffhq-snapshot-1024_v2.pkl")
+    p.add_argument("--image", type=str, required=True)
+    p.add_argument("--landmarks", type=str, default=None)
+    p.add_argument("--path_to_gen", type=str, default="images/projection/")
+    p.add_argument("--gpus", type=str, default="0")
+    p.add_argument("--size", type=int, default=1024)
+    p.add_argument("--n_mean_latent", type=int, default=10000)
+    p.add_argument("--step", type=int, default=5000)
+    p.add_argument("--lamda", type=float, default=0.01)
+    p.add_argument("--beta", type=float, default=1)
+    p.add_argument("--lr_rampup", type=float, default=0.05)
+    p.add_argument("--lr_rampdown", type=float, default=0.25)
+    p.add_argument("--lr", type=float, default=0.01)
+    p.add_argument("--noise", type=float, default=0.05)
+    p.add_argument("--noise_ramp", type=float, default=0.75)
+    p.add_argument("--ratio", type=float, default=1.0)
+    p.add_argument("--truncation_psi", type=float, default=0.7)
+    p.add_argument("--noise_regularize", type=float, default=1e5)       # accepted and unused, like the reference
+    p.add_argument("--w_plus", action="store_true")                     # accepted and unused, like the reference
+    p.add_argument("--no-lpips", action="store_true", help="MSE(+Wing) only, the 1024_example_MSE.py objective")
+    p.add_argument("--batch", type=int, default=8, help="loop steps evaluated per generator forward (same result)")
+    p.add_argument("--seed", type=int, default=None)
+
+    m = sub.add_parser("morph", help="Render linear morphs of two projected latents")
+    m.add_argument("--model", type=str, required=True)
+    m.add_argument("--w1", type=str, required=True)
+    m.add_argument("--w2", type=str, required=True)
+    m.add_argument("--alphas", type=str, default="0.5")
+    m.add_argument("--out", type=str, required=True, help="output prefix: <out>_a0.50.jpg / .mat")
+    m.add_argument("--gpus", type=str, default="0")
+    m.add_argument("--ratio", type=float, default=1.0)
+    m.add_argument("--truncation_psi", type=float, default=0.7)
+    return ap
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
+    os.environ.setdefault("CUDA_VISIBLE_DEVICES", a.gpus)
+    import numpy as np
+    import torch
+    from . import drivers, loader
+    from .projection import ProjectionArgs
+
+    print("Loading networks...")
+    G = loader.load_network(a.model, device="cuda")["Gs"]
+    if a.cmd == "generate":
+        print("Generate and save images...")
+        drivers.generate_images(G, a.images_num, a.truncation_psi, a.output_dir, a.ratio, seed=a.seed)
+        return 0
+    if a.cmd == "morph":
+        alphas = [float(v) for v in a.alphas.split(",")]
+        drivers.merge_morph(G, drivers.load_latent_mat(a.w1), drivers.load_latent_mat(a.w2), alphas, a.truncation_psi,
+                            out_prefix=a.out, ratio=a.ratio)
+        return 0
+    # project
+    from .lpips import PerceptualLoss
+    args = ProjectionArgs(step=a.step, lamda=a.lamda, beta=a.beta, lr=a.lr, lr_rampup=a.lr_rampup, lr_rampdown=a.lr_rampdown,
+                          noise=a.noise, noise_ramp=a.noise_ramp, truncation_psi=a.truncation_psi, n_mean_latent=a.n_mean_latent,
+                          ratio=a.ratio)
+    target = drivers.image_transform(a.image, size=a.size, device=G.device)
+    lm_t = lm_s = None
+    if a.landmarks:
+        lm = np.load(a.landmarks)
+        lm_t, lm_s = lm["target"], lm["steps"]
+        if lm_s.shape[0] < a.step:
+            raise SystemExit(f"--landmarks holds {lm_s.shape[0]} steps, --step is {a.step}")
+    percept = None if a.no_lpips else PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=G.device)
+    stem = os.path.splitext(os.path.basename(a.image))[0]
+    res = drivers.project_image(G, target, lm_t, lm_s, args=args, percept=percept, batch=a.batch, seed=a.seed,
+                                out_prefix=os.path.join(a.path_to_gen, stem))
+    print(f"best step {res['step']}  loss {res['loss']:.6f}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

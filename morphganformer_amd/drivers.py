@@ -48,6 +48,18 @@ def image_transform(src, size=1024, device="cuda"):
     return ((x - 0.5) / 0.5).unsqueeze(0).to(device)
 
 
+def reference_gray_u8(img_hwc):
+    """The gray uint8 image the drivers hand to dlib (:161-163): cv2.normalize(img, None, 0, 255, NORM_MINMAX, CV_8U) over
+    the whole float image, then cv2.cvtColor(..., COLOR_BGR2GRAY) applied to RGB-ordered data (so channel 0 gets the blue
+    weight) -- restated in numpy with OpenCV's 8-bit fixed-point coefficients (B 1868, G 9617, R 4899, >> 14)."""
+    x = np.asarray(img_hwc, dtype=np.float32)
+    lo, hi = float(x.min()), float(x.max())
+    scale = 255.0 / (hi - lo) if hi > lo else 0.0
+    u8 = np.clip(np.rint((x.astype(np.float64) - lo) * scale), 0, 255).astype(np.uint8)
+    c = u8.astype(np.uint32)
+    return ((c[..., 0] * 1868 + c[..., 1] * 9617 + c[..., 2] * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
 def to_uint8_image(G, img):
     """[1,C,H,W] float32 device image in [-1,1] -> uint8 HWC numpy (misc.to_pil's rint+clip, misc.py:114-130) on the device."""
     c, h, w = img.shape[1:]
@@ -130,9 +142,11 @@ def merge_morph(G, w1, w2, alphas=(0.5,), truncation_psi=0.7, noise_mode="random
 
 
 def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None,
-                  eps=None, out_prefix=None, batch=1, use_graph=True, noise_mode="random", use_mse=True, seed=None):
-    """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and
-    `lm_steps` [steps,68,2] are the (injected) landmark detections.  Returns dict(w, step, loss, losses)."""
+                  eps=None, out_prefix=None, batch=1, use_graph=True, noise_mode="random", use_mse=True, seed=None,
+                  landmark_fn=None):
+    """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and either
+    `lm_steps` [steps,68,2] (injected landmark detections) or `landmark_fn` (host detector called on every generated image,
+    see ProjectionEngine).  Returns dict(w, step, loss, losses)."""
     args = args or ProjectionArgs()
     if latent_mean is None or latent_std is None:
         gen = None
@@ -141,7 +155,8 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
             gen.manual_seed(seed)
         latent_mean, latent_std = latent_stats(G, args.n_mean_latent, G.device, generator=gen)
     eng = ProjectionEngine(G, target, latent_mean, float(latent_std), args, percept=percept, lm_target=lm_target,
-                           lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse)
+                           lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse,
+                           landmark_fn=landmark_fn)
     w, step, loss, losses = eng.run().result()
     if out_prefix is not None:
         save_latent_mat(f"{out_prefix}.mat", w)

@@ -75,11 +75,17 @@ class ProjectionEngine:
     """One target image <-> one latent search, replayable as a hipGraph."""
 
     def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True,
-                 lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, batch=1):
+                 lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, batch=1,
+                 landmark_fn=None):
         """batch = number of consecutive loop steps evaluated per generator forward.  In literal mode the steps do not depend
         on each other (latent_in never changes), so evaluating `batch` candidates at once and examining them in step order
         gives exactly the sequential loop's result while the small 4x4..64x64 layers, the mapping network and the LPIPS tail
-        get `batch` times more parallel work per launch."""
+        get `batch` times more parallel work per launch.
+
+        landmark_fn: optional host callback `f(img_hwc float32 numpy [H,W,3]) -> [68,2] array or None` standing where the
+        drivers call dlib on every generated image (:159-170; `drivers.reference_gray_u8` reproduces their cv2 normalise +
+        gray conversion).  With it the landmark table is filled step by step (None = "no face", the step is skipped) at
+        the price of one device->host image copy and a host call per candidate, and graph replay is off."""
         self.G, self.args = G, args or ProjectionArgs()
         self.batch = int(batch)
         assert self.batch >= 1
@@ -105,6 +111,12 @@ class ProjectionEngine:
             eps = torch.randn(a.step, 1, k, D, device=dev, generator=gen)
         self.eps = eps.to(dev).contiguous().float()
         assert self.eps.shape[0] >= a.step
+        self.landmark_fn = landmark_fn
+        if landmark_fn is not None:
+            assert lm_target is not None, "landmark_fn needs the target image's landmarks (lm_target)"
+            lm_steps = np.zeros((a.step,) + tuple(np.shape(lm_target)), np.float64)
+            lm_valid = np.zeros(a.step, np.int32)
+            use_graph = False
         if self.use_wing:
             self.lm_target = torch.as_tensor(lm_target, dtype=torch.float64, device=dev).contiguous()
             self.lm_steps = torch.as_tensor(lm_steps, dtype=torch.float64, device=dev).contiguous()
@@ -140,6 +152,8 @@ class ProjectionEngine:
             per = img.numel() // B
             _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), B, per, 0, 1.0, 0,
                                      self.scratch.data_ptr(), st), "mse")
+        if self.landmark_fn is not None:
+            self._detect_landmarks(img)
         if self.use_wing:
             _lib.check(L.mgf_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), B,
                                            self.lm_target.numel(), 10.0, 2.0, self.step_ctr.data_ptr(), self.lm_steps.shape[0] - 1, st),
@@ -151,6 +165,17 @@ class ProjectionEngine:
                                      _lib.ptr(self.mse_loss if self.use_mse else None), float(a.lamda), float(a.beta),
                                      self.step_ctr.data_ptr(), _lib.ptr(self.valid), B, self.steps, st), "select_best")
         return img
+
+    def _detect_landmarks(self, img):
+        """Host detour of the callback mode: hand every candidate image of this batch to `landmark_fn`, in step order."""
+        s0 = int(self.step_ctr.item())                                     # host sync (the reference syncs three times per step)
+        host = img.permute(0, 2, 3, 1).contiguous().cpu().numpy()         # [B,H,W,3] float32, what the drivers build at :159-161
+        for j in range(min(self.batch, self.steps - s0)):
+            lm = self.landmark_fn(host[j])
+            if lm is None:
+                continue
+            self.lm_steps[s0 + j].copy_(torch.as_tensor(np.asarray(lm, dtype=np.float64).reshape(self.lm_target.shape)))
+            self.valid[s0 + j] = 1
 
     def _capture(self):
         # warm-up on a side stream (allocations, lazy init) before capture, then restore the loop state

@@ -56,6 +56,14 @@ class GeneratorConfig:
     def num_components(self) -> int:
         return self.k - 1
 
+    def conv_gflop(self):
+        """Algorithmic GFLOP of the convolutions of ONE generator forward: 2*taps*cin*cout per output
+        pixel, the stride-2 transposed conv of conv0 counted per INPUT pixel, plus the 1x1 skip convs at the lower resolution."""
+        rows = self.layer_table()
+        gf = sum(2 * (9 if nm != "torgb" else 1) * ci * co * ((res // up) ** 2) for res, nm, ci, co, up, *_ in rows)
+        gf += sum(2 * self.channels(r // 2) * self.channels(r) * (r // 2) ** 2 for r in self.block_resolutions[1:])
+        return gf / 1e9
+
     def layer_table(self):
         """[(block_res, layer_name, cin, cout, up, ws_slot, has_attention, has_noise_bias)] in execution order."""
         rows = []

@@ -118,3 +118,57 @@ def test_generate_and_project_drivers_write_what_the_reference_writes(tmp_path):
     files = sorted(os.listdir(tmp_path / "proj"))
     assert files[0].startswith("face-") and files[0].endswith(".png") and files[1] == "face.mat"
     assert np.array_equal(drivers.load_latent_mat(str(tmp_path / "proj" / "face.mat")), out["w"].numpy())
+
+
+def test_landmark_callback_mode_equals_injected_table(golden):
+    """A host detector called on every generated image (the drivers' dlib step) gives the same run as the table it produces."""
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    g = golden("loop_tiny.npz")
+    steps = 10
+    seen = []
+
+    def detector(img_hwc):                     # deterministic stand-in: landmarks from image statistics, "no face" now and then
+        assert img_hwc.shape == (64, 64, 3) and img_hwc.dtype == np.float32
+        k = len(seen)
+        seen.append(float(img_hwc.mean()))
+        if k in (2, 5):
+            return None
+        return g["lm_target"] + np.round(40 * img_hwc[:34, :4, 0].astype(np.float64)).reshape(68, 2)
+
+    def make(**kw):
+        return ProjectionEngine(_tiny_G(), torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["latent_mean"]).cuda(),
+                                float(g["latent_std"]), ProjectionArgs(step=steps), use_mse=True, lm_target=g["lm_target"],
+                                eps=torch.from_numpy(g["eps"][:steps]).cuda(), noise_mode="const", **kw)
+    e1 = make(landmark_fn=detector, batch=4)
+    lat1, st1, loss1, hist1 = e1.run().result()
+    assert len(seen) == steps and e1.graph is None
+    table, valid = e1.lm_steps.cpu().numpy(), e1.valid.cpu().numpy()
+    assert valid.tolist() == [1, 1, 0, 1, 1, 0, 1, 1, 1, 1]
+    lat2, st2, loss2, hist2 = make(lm_steps=table, lm_valid=valid, batch=1).run().result()
+    assert st1 == st2 and torch.equal(lat1, lat2) and np.isnan(hist1[2]) and np.isnan(hist1[5])
+    assert np.allclose(np.nan_to_num(hist1), np.nan_to_num(hist2), rtol=1e-6)
+
+
+def test_cli_generate_project_morph(tmp_path):
+    from morphganformer_amd import cli, drivers
+    from morphganformer_amd.projection import synthetic_landmarks
+    from test_host_and_abi import _tiny_snapshot
+    from PIL import Image
+    pkl = str(tmp_path / "net.pkl")
+    _tiny_snapshot(pkl, seed=3)
+    assert cli.main(["generate", "--model", pkl, "--output-dir", str(tmp_path / "g"), "--images-num", "2", "--seed", "1"]) == 0
+    assert sorted(os.listdir(tmp_path / "g")) == ["sample_000000.png", "sample_000001.png"]
+    lm_t, lm_s = synthetic_landmarks(6, 64, 1)
+    np.savez(tmp_path / "lm.npz", target=lm_t, steps=lm_s)
+    for name in ("a", "b"):
+        Image.open(tmp_path / "g" / ("sample_000000.png" if name == "a" else "sample_000001.png")).save(tmp_path / f"{name}.png")
+        assert cli.main(["project", "--model", pkl, "--image", str(tmp_path / f"{name}.png"), "--landmarks", str(tmp_path / "lm.npz"),
+                         "--path_to_gen", str(tmp_path / "p"), "--size", "64", "--step", "6", "--n_mean_latent", "200",
+                         "--batch", "4", "--seed", "0"]) == 0
+    files = sorted(os.listdir(tmp_path / "p"))
+    assert [f for f in files if f.endswith(".mat")] == ["a.mat", "b.mat"] and len([f for f in files if f.endswith(".png")]) == 2
+    assert cli.main(["morph", "--model", pkl, "--w1", str(tmp_path / "p" / "a.mat"), "--w2", str(tmp_path / "p" / "b.mat"),
+                     "--alphas", "0,0.5,1", "--out", str(tmp_path / "m" / "a+b")]) == 0
+    assert len(os.listdir(tmp_path / "m")) == 6
+    w = drivers.load_latent_mat(str(tmp_path / "m" / "a+b_a0.50.mat"))
+    assert np.array_equal(w, 0.5 * drivers.load_latent_mat(str(tmp_path / "p" / "a.mat")) + 0.5 * drivers.load_latent_mat(str(tmp_path / "p" / "b.mat")))

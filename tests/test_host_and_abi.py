@@ -121,7 +121,7 @@ def test_config_tables_and_synth_weights():
     # algorithmic FLOPs of the convs, SURVEY.md 8a row P5 / 8d: 172.7 GFLOP
     gf = sum(2 * (9 if nm != "torgb" else 1) * ci * co * ((res // up) ** 2) for res, nm, ci, co, up, *_ in rows) / 1e9
     gf += sum(2 * FULL1024.channels(r // 2) * FULL1024.channels(r) * (r // 2) ** 2 for r in FULL1024.block_resolutions[1:]) / 1e9
-    assert abs(gf - 172.7) < 0.5
+    assert abs(gf - 172.7) < 0.5 and abs(FULL1024.conv_gflop() - gf) < 1e-9
     a, b = make_state_dict(TINY, 0), make_state_dict(TINY, 0)
     assert list(a) == list(b) and all(np.array_equal(a[k], b[k]) for k in a)
     assert not np.array_equal(a["pos"], make_state_dict(TINY, 1)["pos"])
@@ -283,3 +283,29 @@ def test_driver_host_helpers(tmp_path):
     sio.savemat(str(tmp_path / "bad.mat"), {"w": np.zeros(4, np.float32)})
     with pytest.raises(ValueError):
         drivers.load_latent_mat(str(tmp_path / "bad.mat"))
+
+
+def test_cli_arguments_mirror_the_reference_scripts():
+    """argparse names/defaults of 1024_generate.py:44-54 and 1024_example_wing_loss_perceptual_sqz_MSE.py:222-245."""
+    from morphganformer_amd.cli import build_parser
+    ap = build_parser()
+    g = ap.parse_args(["generate", "--model", "m.pkl"])
+    assert (g.gpus, g.output_dir, g.images_num, g.truncation_psi, g.ratio) == ("0", "images", 32, 0.7, 1.0)
+    p = ap.parse_args(["project", "--image", "x.png"])
+    assert p.model == "models/ffhq-snapshot-1024_v2.pkl"
+    assert (p.size, p.n_mean_latent, p.step, p.lamda, p.beta) == (1024, 10000, 5000, 0.01, 1)
+    assert (p.lr_rampup, p.lr_rampdown, p.lr, p.noise, p.noise_ramp, p.ratio, p.truncation_psi) == (0.05, 0.25, 0.01, 0.05, 0.75, 1.0, 0.7)
+    assert p.noise_regularize == 1e5 and p.w_plus is False
+    m = ap.parse_args(["morph", "--model", "m.pkl", "--w1", "a.mat", "--w2", "b.mat", "--out", "o"])
+    assert m.alphas == "0.5" and m.truncation_psi == 0.7
+
+
+def test_reference_gray_conversion_kat():
+    """cv2.normalize(NORM_MINMAX, CV_8U) + COLOR_BGR2GRAY on RGB-ordered data (...sqz_MSE.py:161-163), hand-checked values."""
+    from morphganformer_amd.drivers import reference_gray_u8
+    img = np.zeros((1, 3, 3), np.float32)
+    img[0, 0] = (-1.0, -1.0, -1.0)          # global minimum -> (0,0,0)   -> 0
+    img[0, 1] = (1.0, 1.0, 1.0)             # global maximum -> (255,..)  -> 255
+    img[0, 2] = (1.0, -1.0, 0.0)            # (255, 0, 128) -> (255*1868 + 128*4899 + 8192) >> 14 = 67
+    assert reference_gray_u8(img).tolist() == [[0, 255, 67]]
+    assert reference_gray_u8(np.full((2, 2, 3), 0.3, np.float32)).tolist() == [[0, 0], [0, 0]]      # flat image: max == min
