@@ -237,6 +237,9 @@ int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1_unit, const
 int mgf_lpips_stem_f32(float* pooled, const float* x, const float* w, const float* b, float* feat_out, const float* feat_ref,
                        const float* lin, float* out, int32_t n, int32_t h, int32_t w_in, int32_t accumulate, float* scratch,
                        mgf_stream_t stream);
+/* y = max over a ksize x ksize window (2 or 3), stride 2, floor mode: out = (in - ksize)/2 + 1
+ * (torchvision vgg16 features[4,9,16,23]: MaxPool2d(2,2); alexnet features[2,5]: MaxPool2d(3,2)) */
+int mgf_maxpool_s2_floor_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t ksize, mgf_stream_t stream);
 /* y = max over a 3x3 window, stride 2, ceil_mode (torchvision SqueezeNet1.1 features[2,5,8]) */
 int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                               mgf_stream_t stream);

@@ -91,7 +91,7 @@ def _workspace(dev_index):
 
 
 def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_scale=None, epilogue=None, out=None,
-                 out_choff=0, rgb=None):
+                 out_choff=0, rgb=None, taps=None, ksize=None):
     """Correlation with the packed taps: y[oy,ox] = sum w[kh,kw] x[oy*stride + kh - pad_y, ox*stride + kw - pad_x].
 
     `out` may be a larger [n, C_total, oh, ow] buffer; this conv then writes channels [out_choff, out_choff + cout)."""
@@ -99,9 +99,12 @@ def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_sca
     assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and x.shape[1] == pc.cin
     n, cin, h, w = x.shape
     py, px = pad
-    oh = (h + 2 * py - pc.kh) // stride + 1
-    ow = (w + 2 * px - pc.kw) // stride + 1
-    taps = [(kh - py, kw - px) for kh in range(pc.kh) for kw in range(pc.kw)]
+    kh_, kw_ = ksize if ksize is not None else (pc.kh, pc.kw)      # ksize/taps: `pc` holds a SUBSET of a larger kernel's taps
+    oh = (h + 2 * py - kh_) // stride + 1
+    ow = (w + 2 * px - kw_) // stride + 1
+    if taps is None:
+        taps = [(kh - py, kw - px) for kh in range(pc.kh) for kw in range(pc.kw)]
+    assert len(taps) == pc.kh * pc.kw
     if rgb is not None:
         # fused 1x1 projection (ToRGB folded into the conv): rgb = (rgb_w [n,c,cout], rgb_bias [c] | None, rgb_out [n,c,oh,ow]);
         # the conv result itself is not written
@@ -124,6 +127,29 @@ def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_sca
     rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                       C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
     _lib.check(rc, "conv_taps")
+    return out
+
+
+def conv_large_forward(x, w, bias, stride, pad, act="relu", out=None):
+    """Convolution with more than 9 taps (AlexNet's 11x11 and 5x5): the tap list is cut into groups of <= 9, each group is one
+    launch accumulating into `out` through the residual port (linear), bias + activation follow in one mgf_bias_act pass."""
+    _lib.require_gpu(x, w, bias)
+    cout, cin, kh, kw = w.shape
+    n, _, h, wd = x.shape
+    oh, ow = (h + 2 * pad - kh) // stride + 1, (wd + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
+    taps = [(a, b) for a in range(kh) for b in range(kw)]
+    wf = w.reshape(cout, cin, kh * kw)
+    for g0 in range(0, len(taps), 9):
+        grp = taps[g0:g0 + 9]
+        pc = pack_weights(wf[:, :, g0:g0 + len(grp)].reshape(cout, cin, 1, len(grp)).contiguous())
+        ep = None if g0 == 0 else _lib.make_epilogue(residual=out)
+        conv_forward(x, pc, stride=stride, pad=(pad, pad), epilogue=ep, out=out, taps=[(a - pad, b - pad) for a, b in grp],
+                     ksize=(kh, kw))
+    act_code = {"linear": 1, "relu": 2}[act]
+    _lib.check(_lib.lib().mgf_bias_act(out.data_ptr(), out.data_ptr(), _lib.ptr(bias), None, None, None, _lib.MGF_F32, out.numel(),
+                                       oh * ow, cout, 0, act_code, 0.0, 1.0, -1.0, _lib.stream_ptr()), "bias_act")
     return out
 
 

@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256) void wing_kernel(double* out, const double* pr
     if (threadIdx.x == 0) out[blockIdx.x] = (sm[0] + sm[1] + sm[2] + sm[3]) / (double)numel;
 }
 
+// K x K window, stride 2, windows clipped at the bottom/right edge (ceil_mode partial windows)
+template <int K>
 __global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, int nc, int in_h, int in_w, int out_h, int out_w) {
     const int64_t total = (int64_t)nc * out_h * out_w;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -157,11 +159,11 @@ __global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, 
         const float* xp = x + pl * in_h * in_w;
         float m = -3.0e38f;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
+        for (int dy = 0; dy < K; ++dy) {
             const int iy = oy * 2 + dy;
             if (iy >= in_h) continue;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
+            for (int dx = 0; dx < K; ++dx) {
                 const int ix = ox * 2 + dx;
                 if (ix < in_w) m = fmaxf(m, xp[(int64_t)iy * in_w + ix]);
             }
@@ -281,9 +283,20 @@ extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, i
     MGF_REQUIRE(out_h == osz(in_h) && out_w == osz(in_w), MGF_EINVAL, "maxpool: output must be %dx%d (got %dx%d)", osz(in_h), osz(in_w),
                 out_h, out_w);
     const int64_t total = (int64_t)nc * out_h * out_w;
-    hipLaunchKernelGGL(maxpool_kernel, dim3(mgf_stream_grid(total, 256, 2)), dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w,
+    hipLaunchKernelGGL(maxpool_kernel<3>, dim3(mgf_stream_grid(total, 256, 2)), dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w,
                        out_h, out_w);
     MGF_CHECK_LAUNCH("maxpool");
+    return MGF_OK;
+}
+
+extern "C" int mgf_maxpool_s2_floor_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t ksize, mgf_stream_t stream) {
+    MGF_REQUIRE(y && x && nc >= 1 && (ksize == 2 || ksize == 3) && in_h >= ksize && in_w >= ksize, MGF_EINVAL, "maxpool_s2_floor: bad arguments");
+    const int out_h = (in_h - ksize) / 2 + 1, out_w = (in_w - ksize) / 2 + 1;
+    const int64_t total = (int64_t)nc * out_h * out_w;
+    const dim3 grid(mgf_stream_grid(total, 256, 2));
+    if (ksize == 2) hipLaunchKernelGGL(maxpool_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w, out_h, out_w);
+    else hipLaunchKernelGGL(maxpool_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w, out_h, out_w);
+    MGF_CHECK_LAUNCH("maxpool_s2_floor");
     return MGF_OK;
 }
 

@@ -50,6 +50,97 @@ def random_squeeze_backbone(seed=0):
     return sd
 
 
+# torchvision vgg16.features / alexnet.features as (kind, ...) rows; every conv is followed by ReLU; "tap" marks an LPIPS tap
+# (lpips/pretrained_networks.py:58-135: alex slices [0:2|2:5|5:8|8:10|10:12], vgg16 slices [0:4|4:9|9:16|16:23|23:30])
+VGG_SPEC = ([("conv", 0, 3, 64, 3, 1, 1), ("conv", 2, 64, 64, 3, 1, 1), ("tap",), ("pool", 2),
+             ("conv", 5, 64, 128, 3, 1, 1), ("conv", 7, 128, 128, 3, 1, 1), ("tap",), ("pool", 2),
+             ("conv", 10, 128, 256, 3, 1, 1), ("conv", 12, 256, 256, 3, 1, 1), ("conv", 14, 256, 256, 3, 1, 1), ("tap",), ("pool", 2),
+             ("conv", 17, 256, 512, 3, 1, 1), ("conv", 19, 512, 512, 3, 1, 1), ("conv", 21, 512, 512, 3, 1, 1), ("tap",), ("pool", 2),
+             ("conv", 24, 512, 512, 3, 1, 1), ("conv", 26, 512, 512, 3, 1, 1), ("conv", 28, 512, 512, 3, 1, 1), ("tap",)])
+ALEX_SPEC = ([("conv", 0, 3, 64, 11, 4, 2), ("tap",), ("pool", 3), ("conv", 3, 64, 192, 5, 1, 2), ("tap",), ("pool", 3),
+              ("conv", 6, 192, 384, 3, 1, 1), ("tap",), ("conv", 8, 384, 256, 3, 1, 1), ("tap",), ("conv", 10, 256, 256, 3, 1, 1), ("tap",)])
+SPECS = {"vgg": VGG_SPEC, "alex": ALEX_SPEC}
+NET_CHNS = {"squeeze": CHNS, "vgg": [64, 128, 256, 512, 512], "alex": [64, 192, 384, 256, 256]}
+
+
+def random_backbone(net, seed=0):
+    """Seeded He-scaled feature weights under torchvision's key names for net in {squeeze, vgg, alex}."""
+    if net == "squeeze":
+        return random_squeeze_backbone(seed)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for row in SPECS[net]:
+        if row[0] == "conv":
+            _, idx, ci, co, k, _, _ = row
+            sd[f"features.{idx}.weight"] = (rng.standard_normal((co, ci, k, k)) * math.sqrt(2.0 / (ci * k * k))).astype(np.float32)
+            sd[f"features.{idx}.bias"] = (rng.standard_normal(co) * 0.05).astype(np.float32)
+    return sd
+
+
+class SequentialFeatures:
+    """LPIPS taps of a plain conv/ReLU/max-pool stack (VGG16, AlexNet) for a fixed input size, preallocated workspace.
+    The ScalingLayer runs as its own element-wise step (these nets zero-pad the SCALED input, so it cannot be folded)."""
+
+    def __init__(self, net, backbone_state, n, h, w, device, share=None):
+        self.device = torch.device(device)
+        dev = self.device
+        self.spec = SPECS[net]
+        self.n = n
+        t32 = lambda a: torch.as_tensor(np.ascontiguousarray(np.asarray(a), dtype=np.float32), device=dev)
+        if share is not None:
+            self.convs, self.shift, self.scale = share.convs, share.shift, share.scale
+        else:
+            self.convs = {}
+            for row in self.spec:
+                if row[0] == "conv":
+                    _, idx, ci, co, k, _, _ = row
+                    wt, b = t32(backbone_state[f"features.{idx}.weight"]), t32(backbone_state[f"features.{idx}.bias"])
+                    self.convs[idx] = (cv.pack_weights(wt) if k == 3 else wt, b)          # > 9 taps: packed per tap group at run time
+            self.shift, self.scale = t32(SHIFT).reshape(1, 3, 1, 1), t32(SCALE).reshape(1, 3, 1, 1)
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        self.xs = e(n, 3, h, w)
+        self.bufs, self.shapes = [], {}
+        c, hh, ww, tap = 3, h, w, 0
+        for row in self.spec:
+            if row[0] == "conv":
+                _, idx, ci, co, k, s, p = row
+                assert ci == c
+                c, hh, ww = co, (hh + 2 * p - k) // s + 1, (ww + 2 * p - k) // s + 1
+                self.bufs.append(e(n, c, hh, ww))
+            elif row[0] == "pool":
+                k = row[1]
+                hh, ww = (hh - k) // 2 + 1, (ww - k) // 2 + 1
+                self.bufs.append(e(n, c, hh, ww))
+            else:
+                self.bufs.append(None)
+                self.shapes[tap] = (c, hh, ww)
+                tap += 1
+
+    def __call__(self, x, out=None):
+        _lib.require_gpu(x)
+        L, st = _lib.lib(), _lib.stream_ptr()
+        torch.sub(x, self.shift, out=self.xs)
+        self.xs.div_(self.scale)
+        h, taps = self.xs, []
+        for pos, (row, buf) in enumerate(zip(self.spec, self.bufs)):
+            if row[0] == "conv":
+                _, idx, ci, co, k, s, p = row
+                wt, b = self.convs[idx]
+                nxt = self.spec[pos + 1]
+                dst = out[len(taps)] if (out is not None and nxt[0] == "tap") else buf
+                if k == 3:
+                    h = cv.conv_forward(h, wt, stride=s, pad=(p, p), epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dst)
+                else:
+                    h = cv.conv_large_forward(h, wt, b, s, p, act="relu", out=dst)
+            elif row[0] == "pool":
+                nn, c, ih, iw = h.shape
+                _lib.check(L.mgf_maxpool_s2_floor_f32(buf.data_ptr(), h.data_ptr(), nn * c, ih, iw, row[1], st), "maxpool")
+                h = buf
+            else:
+                taps.append(h)
+        return taps
+
+
 def _pool_out(n):
     o = (n - 3 + 1) // 2 + 1
     if (o - 1) * 2 >= n:
@@ -160,18 +251,21 @@ class PerceptualLoss(torch.nn.Module):
         super().__init__()
         if model != "net-lin" or spatial or colorspace != "rgb":
             raise NotImplementedError("the MI355X path implements model='net-lin', spatial=False, colorspace='rgb'")
-        if net != "squeeze":
-            raise NotImplementedError("only the SqueezeNet1.1 backbone (the one BASELINE config 2 uses) is built so far")
+        if net not in NET_CHNS:
+            raise NotImplementedError(f"unknown LPIPS backbone {net!r} (squeeze, vgg, alex)")
         if not use_gpu:
             raise _lib.MgfError("PerceptualLoss(use_gpu=False): the MI355X package has no CPU path")
         _lib.lib()
         self.device_ = torch.device(device)
-        self.backbone_state = backbone_state if backbone_state is not None else random_squeeze_backbone(backbone_seed)
+        self.net = net
+        self.chns = NET_CHNS[net]
+        self.backbone_state = backbone_state if backbone_state is not None else random_backbone(net, backbone_seed)
         lin = np.load(os.path.join(WEIGHTS_DIR, f"lpips_lin_{net}.npz"))
-        self.lins = [torch.as_tensor(lin[f"lin{i}"], dtype=torch.float32, device=self.device_) for i in range(len(CHNS))]
+        self.lins = [torch.as_tensor(lin[f"lin{i}"], dtype=torch.float32, device=self.device_) for i in range(len(self.chns))]
         self._feats = {}
         self._target_taps = None
-        self.fused_stem = os.environ.get("MGF_LPIPS_STEM", "1") != "0"      # tuning hook: 0 = separate conv / pool / distance kernels
+        # the one-pass stem exists for SqueezeNet's first three layers; MGF_LPIPS_STEM=0 (tuning hook) keeps them separate
+        self.fused_stem = net == "squeeze" and os.environ.get("MGF_LPIPS_STEM", "1") != "0"
         self._scratch = torch.empty(int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=self.device_)
         self._val = torch.zeros(1, dtype=torch.float32, device=self.device_)
 
@@ -181,7 +275,10 @@ class PerceptualLoss(torch.nn.Module):
         f = self._feats.get(key)
         if f is None:
             share = next(iter(self._feats.values()), None)
-            f = SqueezeFeatures(self.backbone_state, n, h, w, self.device_, share=share)
+            if self.net == "squeeze":
+                f = SqueezeFeatures(self.backbone_state, n, h, w, self.device_, share=share)
+            else:
+                f = SequentialFeatures(self.net, self.backbone_state, n, h, w, self.device_, share=share)
             self._feats[key] = f
         return f
 
@@ -191,8 +288,9 @@ class PerceptualLoss(torch.nn.Module):
         n, _, h, w = target.shape
         assert n == 1
         f = self._features(n, h, w)
+        keys = TAPS_AFTER if self.net == "squeeze" else range(len(self.chns))
         outs = [torch.empty([n, c, *f.shapes[idx][1:]], dtype=torch.float32, device=self.device_)
-                for c, idx in zip(CHNS, TAPS_AFTER)]
+                for c, idx in zip(self.chns, keys)]
         if self.fused_stem:
             # outs[0] holds the NORMALISED tap 0 (what the stem's distance mode compares against); the same kernel arithmetic
             # runs on both images, so identical images still give exactly zero

@@ -127,12 +127,54 @@ def squeeze_features_ref(bb, x):
     return taps
 
 
-def lpips_ref(bb, lins, img0, img1, per_layer=False):
+# torchvision vgg16.features / alexnet.features (third-party, not vendored; topology restated from torchvision >= 0.9.1) with
+# the LPIPS slice boundaries of lpips/pretrained_networks.py:58-135.  Rows: ("conv", features index, cin, cout, k, stride, pad)
+# -- always followed by ReLU --, ("pool", k) = MaxPool2d(k, 2) floor mode, ("tap",) = LPIPS tap.
+VGG_SPEC = ([("conv", 0, 3, 64, 3, 1, 1), ("conv", 2, 64, 64, 3, 1, 1), ("tap",), ("pool", 2),
+             ("conv", 5, 64, 128, 3, 1, 1), ("conv", 7, 128, 128, 3, 1, 1), ("tap",), ("pool", 2),
+             ("conv", 10, 128, 256, 3, 1, 1), ("conv", 12, 256, 256, 3, 1, 1), ("conv", 14, 256, 256, 3, 1, 1), ("tap",), ("pool", 2),
+             ("conv", 17, 256, 512, 3, 1, 1), ("conv", 19, 512, 512, 3, 1, 1), ("conv", 21, 512, 512, 3, 1, 1), ("tap",), ("pool", 2),
+             ("conv", 24, 512, 512, 3, 1, 1), ("conv", 26, 512, 512, 3, 1, 1), ("conv", 28, 512, 512, 3, 1, 1), ("tap",)])
+ALEX_SPEC = ([("conv", 0, 3, 64, 11, 4, 2), ("tap",), ("pool", 3), ("conv", 3, 64, 192, 5, 1, 2), ("tap",), ("pool", 3),
+              ("conv", 6, 192, 384, 3, 1, 1), ("tap",), ("conv", 8, 384, 256, 3, 1, 1), ("tap",), ("conv", 10, 256, 256, 3, 1, 1), ("tap",)])
+NET_SPECS = {"vgg": VGG_SPEC, "alex": ALEX_SPEC}
+
+
+def backbone_random(net, seed=0):
+    """Seeded He-scaled feature weights under torchvision's key names (same generator as the package's random_backbone)."""
+    if net == "squeeze":
+        return squeeze_backbone_random(seed)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for row in NET_SPECS[net]:
+        if row[0] == "conv":
+            _, idx, ci, co, k, _, _ = row
+            sd[f"features.{idx}.weight"] = torch.from_numpy((rng.standard_normal((co, ci, k, k)) * math.sqrt(2.0 / (ci * k * k))).astype(np.float32))
+            sd[f"features.{idx}.bias"] = torch.from_numpy((rng.standard_normal(co) * 0.05).astype(np.float32))
+    return sd
+
+
+def sequential_features_ref(net, bb, x):
+    """The 5 LPIPS taps of vgg16 / alexnet on an already-scaled input."""
+    taps, h = [], x
+    for row in NET_SPECS[net]:
+        if row[0] == "conv":
+            _, idx, ci, co, k, s, p = row
+            h = F.relu(F.conv2d(h, bb[f"features.{idx}.weight"], bb[f"features.{idx}.bias"], stride=s, padding=p))
+        elif row[0] == "pool":
+            h = F.max_pool2d(h, kernel_size=row[1], stride=2)
+        else:
+            taps.append(h)
+    return taps
+
+
+def lpips_ref(bb, lins, img0, img1, per_layer=False, net="squeeze"):
     """PNetLin.forward (networks_basic.py:64-92), version 0.1, spatial=False.  lins: list of [C] tensors."""
     shift = torch.tensor(LPIPS_SHIFT).reshape(1, 3, 1, 1)
     scale = torch.tensor(LPIPS_SCALE).reshape(1, 3, 1, 1)
-    f0 = squeeze_features_ref(bb, (img0 - shift) / scale)
-    f1 = squeeze_features_ref(bb, (img1 - shift) / scale)
+    feats = squeeze_features_ref if net == "squeeze" else (lambda b_, x_: sequential_features_ref(net, b_, x_))
+    f0 = feats(bb, (img0 - shift) / scale)
+    f1 = feats(bb, (img1 - shift) / scale)
     vals = []
     for a, b, lin in zip(f0, f1, lins):
         na = a / (a.square().sum(1, keepdim=True).sqrt() + 1e-10)

@@ -124,6 +124,37 @@ def test_lpips_fused_stem_vs_oracle(res):
     assert float(P(tgt.cuda(), tgt.cuda())) == 0.0
 
 
+@pytest.mark.parametrize("net,res", [("vgg", 64), ("vgg", 75), ("alex", 96), ("alex", 131)])
+def test_lpips_vgg_alex_vs_oracle(net, res):
+    """The other two backbones of lpips.PerceptualLoss (pretrained_networks.py:58-135): taps and distance vs the oracle, seeded
+    random backbone weights + the reference's vendored lin heads.  AlexNet's 11x11/5x5 convs run as chained <=9-tap launches."""
+    from morphganformer_amd.lpips import PerceptualLoss, random_backbone
+    from oracle.loss_ref import backbone_random, lpips_ref, sequential_features_ref, LPIPS_SHIFT, LPIPS_SCALE
+    torch.manual_seed(res)
+    x0 = (torch.rand(2, 3, res, res) * 2 - 1)
+    x1 = (x0[:1] + 0.3 * torch.randn(1, 3, res, res)).clamp(-1, 1)
+    bb_np, bb = random_backbone(net, 0), backbone_random(net, 0)
+    for k in bb:
+        assert np.array_equal(bb[k].numpy(), bb_np[k]), k
+    P = PerceptualLoss(model="net-lin", net=net, use_gpu=True, backbone_state=bb_np)
+    assert len(P.lins) == 5
+    lins = [l.cpu() for l in P.lins]
+    shift = torch.tensor(LPIPS_SHIFT).reshape(1, 3, 1, 1)
+    scale = torch.tensor(LPIPS_SCALE).reshape(1, 3, 1, 1)
+    ref_taps = sequential_features_ref(net, bb, (x0 - shift) / scale)
+    taps = P._features(2, res, res)(x0.cuda())
+    for i, (t, r) in enumerate(zip(taps, ref_taps)):
+        assert tuple(t.shape) == tuple(r.shape), i
+        assert float((t.cpu() - r).abs().max() / r.abs().max()) < 1e-4, i
+    P.set_target(x1.cuda())
+    out = torch.zeros(2, device="cuda")
+    P.distance_into(out, x0.cuda())
+    for i in range(2):
+        ref = float(lpips_ref(bb, lins, x0[i:i + 1], x1, net=net))
+        assert abs(float(out[i]) - ref) < 1e-3 * abs(ref), (i, float(out[i]), ref)
+    assert float(P(x1.cuda(), x1.cuda())) == 0.0
+
+
 def _engine_from_golden(g, use_graph, steps=None, batch=1):
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
