@@ -263,6 +263,21 @@ int mgf_select_best(double* min_loss, float* best_latent, int32_t* best_step, do
 /* uint8 HWC image = clip(rint(x*127.5+127.5), 0, 255) from CHW float (misc.to_pil, misc.py:114-123) */
 int mgf_to_uint8_hwc(uint8_t* out, const float* img, int32_t c, int32_t h, int32_t w, mgf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Biometric branch: the IResNet embedder (backbones/iresnet.py:28-161).  Its convolutions are mgf_conv_taps_f32 launches
+ * (eval-mode BatchNorm folded into out_scale/bias, the identity shortcut into the residual port); these are the rest.
+ *   channel_affine_prelu: y = prelu_c(x * scale[c] + shift[c]) on [n,c,hw]; scale / shift / slope may each be NULL
+ *                         (BatchNorm2d in front of a zero-padded conv, iresnet.py:47-48; nn.PReLU(planes), :50)
+ *   linear:               y[s,o] = b[o] + sum_i w[o,i] x[s,i]   (nn.Linear, :99,158), n <= 16 rows, in_features % 4 == 0
+ *   resize_bilinear:      F.interpolate(x, (out_h,out_w), mode="bilinear", align_corners=False) on nc planes
+ */
+int mgf_channel_affine_prelu_f32(float* y, const float* x, const float* scale, const float* shift, const float* slope,
+                                 int32_t n, int32_t c, int64_t hw, mgf_stream_t stream);
+int mgf_linear_f32(float* y, const float* x, const float* w, const float* b, int32_t n, int32_t in_features, int32_t out_features,
+                   mgf_stream_t stream);
+int mgf_resize_bilinear_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                            mgf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

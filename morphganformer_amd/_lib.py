@@ -72,6 +72,9 @@ _SIGS = {
     "mgf_lpips_unit_f32": (C.c_int, [vp, vp, i32, i32, i64, vp]),
     "mgf_lpips_layer_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i64, i64, i32, vp, vp]),
     "mgf_lpips_stem_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "mgf_channel_affine_prelu_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),
+    "mgf_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mgf_resize_bilinear_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "mgf_maxpool_s2_floor_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mgf_maxpool3x3s2_ceil_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "mgf_latent_perturb": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),

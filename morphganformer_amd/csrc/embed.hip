@@ -1,0 +1,107 @@
+// Small ops of the biometric branch (IResNet embedder, backbones/iresnet.py): contract in include/mgf.h.
+// The 3x3 / 1x1 convolutions of the network run on conv_taps (BatchNorm folded into its out_scale/bias ports, the identity
+// shortcut into its residual port); what is left are three bandwidth-bound element-wise / GEMV steps.
+#include "mgf_common.h"
+
+namespace {
+
+// y = prelu_c(x * scale_c + shift_c); any of scale / shift / slope may be NULL (1 / 0 / no activation).  x, y: [n, c, hw]
+__global__ __launch_bounds__(256) void channel_affine_prelu_kernel(float* y, const float* x, const float* scale, const float* shift,
+                                                                   const float* slope, int c, int64_t hw, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)((i / hw) % c);
+        float v = x[i];
+        if (scale) v = v * scale[ch];
+        if (shift) v = v + shift[ch];
+        if (slope) v = v > 0.f ? v : v * slope[ch];
+        y[i] = v;
+    }
+}
+
+// y[s, o] = b[o] + sum_i w[o, i] * x[s, i]  -- one workgroup per output feature, all samples at once (n <= 16): the weight row
+// is streamed once with float4 loads, the sample vectors are L2 resident.
+constexpr int LIN_MAX_N = 16;
+__global__ __launch_bounds__(256) void linear_kernel(float* y, const float* x, const float* w, const float* b, int n, int in_f, int out_f) {
+    __shared__ float sm[4][LIN_MAX_N];
+    const int o = blockIdx.x;
+    const float* wr = w + (int64_t)o * in_f;
+    float acc[LIN_MAX_N];
+#pragma unroll
+    for (int s = 0; s < LIN_MAX_N; ++s) acc[s] = 0.f;
+    const int nvec = in_f / 4;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+        const float4 wv = reinterpret_cast<const float4*>(wr)[i];
+#pragma unroll
+        for (int s = 0; s < LIN_MAX_N; ++s) {
+            if (s < n) {
+                const float4 xv = reinterpret_cast<const float4*>(x + (int64_t)s * in_f)[i];
+                acc[s] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+            }
+        }
+    }
+    for (int i = nvec * 4 + threadIdx.x; i < in_f; i += 256) {
+#pragma unroll
+        for (int s = 0; s < LIN_MAX_N; ++s)
+            if (s < n) acc[s] += wr[i] * x[(int64_t)s * in_f + i];
+    }
+#pragma unroll
+    for (int s = 0; s < LIN_MAX_N; ++s) {
+        const float v = wave_sum(acc[s]);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][s] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < n) y[(int64_t)threadIdx.x * out_f + o] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x] + (b ? b[o] : 0.f);
+}
+
+// torch.nn.functional.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=False), no antialias
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(float* y, const float* x, int nc, int ih, int iw, int oh, int ow, float sy, float sx) {
+    const int64_t total = (int64_t)nc * oh * ow;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % ow);
+        const int64_t r = i / ow;
+        const int oy = (int)(r % oh);
+        const int64_t pl = r / oh;
+        float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+        fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < ih - 1 ? 1 : 0), x1 = x0 + (x0 < iw - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* xp = x + pl * ih * iw;
+        y[i] = hy * (hx * xp[(int64_t)y0 * iw + x0] + lx * xp[(int64_t)y0 * iw + x1]) +
+               ly * (hx * xp[(int64_t)y1 * iw + x0] + lx * xp[(int64_t)y1 * iw + x1]);
+    }
+}
+
+}  // namespace
+
+extern "C" int mgf_channel_affine_prelu_f32(float* y, const float* x, const float* scale, const float* shift, const float* slope,
+                                            int32_t n, int32_t c, int64_t hw, mgf_stream_t stream) {
+    MGF_REQUIRE(y && x && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "channel_affine_prelu: bad arguments");
+    const int64_t total = (int64_t)n * c * hw;
+    hipLaunchKernelGGL(channel_affine_prelu_kernel, dim3(mgf_stream_grid(total, 256, 4)), dim3(256), 0, (hipStream_t)stream, y, x, scale,
+                       shift, slope, c, hw, total);
+    MGF_CHECK_LAUNCH("channel_affine_prelu");
+    return MGF_OK;
+}
+
+extern "C" int mgf_linear_f32(float* y, const float* x, const float* w, const float* b, int32_t n, int32_t in_features,
+                              int32_t out_features, mgf_stream_t stream) {
+    MGF_REQUIRE(y && x && w && n >= 1 && in_features >= 1 && out_features >= 1, MGF_EINVAL, "linear: bad arguments");
+    MGF_REQUIRE(n <= LIN_MAX_N, MGF_EUNSUPPORTED, "linear: at most %d rows per call (got %d)", LIN_MAX_N, n);
+    MGF_REQUIRE(in_features % 4 == 0, MGF_EUNSUPPORTED, "linear: in_features must be a multiple of 4 (got %d)", in_features);
+    MGF_REQUIRE((((uintptr_t)x | (uintptr_t)w) % 16) == 0, MGF_EINVAL, "linear: x and w must be 16-byte aligned");
+    hipLaunchKernelGGL(linear_kernel, dim3(out_features), dim3(256), 0, (hipStream_t)stream, y, x, w, b, n, in_features, out_features);
+    MGF_CHECK_LAUNCH("linear");
+    return MGF_OK;
+}
+
+extern "C" int mgf_resize_bilinear_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                                       mgf_stream_t stream) {
+    MGF_REQUIRE(y && x && nc >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, MGF_EINVAL, "resize_bilinear: bad arguments");
+    const int64_t total = (int64_t)nc * out_h * out_w;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(mgf_stream_grid(total, 256, 2)), dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h,
+                       in_w, out_h, out_w, (float)in_h / (float)out_h, (float)in_w / (float)out_w);
+    MGF_CHECK_LAUNCH("resize_bilinear");
+    return MGF_OK;
+}

@@ -76,11 +76,14 @@ class ProjectionEngine:
 
     def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True,
                  lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, batch=1,
-                 landmark_fn=None):
+                 landmark_fn=None, biometric=None, gamma=1.0):
         """batch = number of consecutive loop steps evaluated per generator forward.  In literal mode the steps do not depend
         on each other (latent_in never changes), so evaluating `batch` candidates at once and examining them in step order
         gives exactly the sequential loop's result while the small 4x4..64x64 layers, the mapping network and the LPIPS tail
         get `batch` times more parallel work per launch.
+
+        biometric: optional `iresnet.BiometricLoss`; adds gamma * MSE(embed(img), embed(target)) to the objective (the
+        FaceNet term of 1024_example_FaceNet_percept.py:147-158 on the vendored IResNet embedder).
 
         landmark_fn: optional host callback `f(img_hwc float32 numpy [H,W,3]) -> [68,2] array or None` standing where the
         drivers call dlib on every generated image (:159-170; `drivers.reference_gray_u8` reproduces their cv2 normalise +
@@ -136,6 +139,9 @@ class ProjectionEngine:
         self.scratch = torch.empty(B * int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=dev)
         if self.percept is not None:
             self.percept.set_target(self.target)
+        self.biometric, self.gamma = biometric, float(gamma)
+        if biometric is not None:
+            biometric.set_target(self.target)
         self.use_graph = use_graph
         self.graph = None
 
@@ -148,6 +154,8 @@ class ProjectionEngine:
         img = self.G(self.latent_n, a.truncation_psi, noise_mode=self.noise_mode)[0]      # psi lands in `c`
         if self.percept is not None:
             self.percept.distance_into(self.p_loss, img)
+        if self.biometric is not None:      # rides in the p_loss slot: p_loss = LPIPS + gamma * embedding MSE
+            self.biometric.distance_into(self.p_loss, img, scale=self.gamma, accumulate=self.percept is not None)
         if self.use_mse:
             per = img.numel() // B
             _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), B, per, 0, 1.0, 0,
@@ -160,7 +168,7 @@ class ProjectionEngine:
                        "wing_loss")
         _lib.check(L.mgf_select_best(self.min_loss.data_ptr(), self.best_latent.data_ptr(), self.best_step.data_ptr(),
                                      self.losses.data_ptr(), self.latent_n.data_ptr(), self.numel,
-                                     _lib.ptr(self.p_loss if self.percept is not None else None),
+                                     _lib.ptr(self.p_loss if (self.percept is not None or self.biometric is not None) else None),
                                      _lib.ptr(self.w_loss if self.use_wing else None),
                                      _lib.ptr(self.mse_loss if self.use_mse else None), float(a.lamda), float(a.beta),
                                      self.step_ctr.data_ptr(), _lib.ptr(self.valid), B, self.steps, st), "select_best")

@@ -319,6 +319,30 @@ def gold_morph_tiny(ref, G):
                         images=np.stack(imgs), img_w1_psi07=img_psi)
 
 
+def gold_iresnet():
+    """The vendored face embedder (backbones/iresnet.py, pure torch): iresnet18 with the build's seeded state on a seeded
+    112x112 batch -> embedding and per-stage statistics."""
+    sys.path.insert(0, REF)
+    from backbones import iresnet as ref_iresnet
+    from morphganformer_amd.iresnet import random_state
+    sd = random_state(18, seed=0)
+    net = ref_iresnet.iresnet18().eval()
+    missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    rng = np.random.Generator(np.random.PCG64(112))
+    x = rng.uniform(-1, 1, (2, 3, 112, 112)).astype(np.float32)
+    stats = {}
+    hooks = [getattr(net, f"layer{i}").register_forward_hook(
+        lambda m, inp, out, i=i: stats.__setitem__(i, (float(out.double().mean()), float(out.double().square().mean().sqrt()))))
+        for i in range(1, 5)]
+    with torch.no_grad():
+        emb = net(torch.from_numpy(x))
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(OUT, "iresnet18.npz"), x=x, embedding=emb.numpy(),
+                        layer_mean=np.array([stats[i][0] for i in range(1, 5)]), layer_rms=np.array([stats[i][1] for i in range(1, 5)]))
+
+
 def gold_loss_kats(ref):
     out = {}
     wing = ref.wing_loss.WingLoss()
@@ -355,6 +379,8 @@ def main():
         # regenerate a subset without touching the other fixtures
         if "config0" in only:
             gold_config0_256(ref)
+        if "iresnet" in only:
+            gold_iresnet()
         if "morph" in only:
             from morphganformer_amd.synth_weights import TINY, make_state_dict
             gold_morph_tiny(ref, build_reference_generator(ref, TINY, make_state_dict(TINY, seed=0)))
@@ -368,6 +394,7 @@ def main():
     gold_loop_tiny(ref, G)
     gold_morph_tiny(ref, G)
     gold_config0_256(ref)
+    gold_iresnet()
     if "--no-full" not in sys.argv:
         gold_generator_full(ref)
     for f in sorted(os.listdir(OUT)):

@@ -195,3 +195,20 @@ def test_projection_literal_ref_config0_256(golden):
         lambda z: generator_ref(sd, z, SMALL256, "const"), lambda i, img: float(loss_ref.mse_ref(img, target)),
         torch.from_numpy(g["latent_mean"]), float(g["latent_std"]), torch.from_numpy(g["eps"]), steps, total_steps=50)
     assert np.allclose(losses[:steps], g["losses"][:steps], rtol=1e-5)
+
+
+def test_iresnet_ref_vs_reference_module(golden):
+    """oracle/embed_ref.py against backbones/iresnet.py (iresnet18, seeded state, eval mode): bit for bit on this torch build."""
+    from morphganformer_amd.iresnet import block_table, random_state
+    from oracle.embed_ref import iresnet_ref
+    g = golden("iresnet18.npz")
+    sd = {k: torch.from_numpy(v) for k, v in random_state(18, 0).items()}
+    taps = {}
+    with torch.no_grad():
+        e = iresnet_ref(sd, torch.from_numpy(g["x"]), 18, taps)
+    assert np.array_equal(e.numpy(), g["embedding"])
+    rows = block_table(18)
+    assert len(rows) == 8 and [r[3] for r in rows] == [2, 1, 2, 1, 2, 1, 2, 1] and rows[-1][0] == "layer4.1"
+    for i, last in enumerate(("layer1.1", "layer2.1", "layer3.1", "layer4.1")):
+        assert abs(float(taps[last].double().square().mean().sqrt()) - g["layer_rms"][i]) < 1e-9 * g["layer_rms"][i]
+    assert sum(len(v) for v in ([1] * 3,)) == 3 and len(block_table(50)) == 24 and len(block_table(100)) == 49
