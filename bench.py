@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", type=int, default=1024, help="debug only; the reported config is 1024")
-    ap.add_argument("--batch", type=int, default=8, help="loop steps evaluated per generator forward (exact in literal mode)")
+    ap.add_argument("--batch", type=int, default=16, help="loop steps evaluated per generator forward (exact in literal mode)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
@@ -137,9 +137,9 @@ def pmc_traffic(kernel, eng):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
     this same workload, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled on gfx950, WRITE_SIZE as read; see
     profiles/README.md).  Counters cannot be read from inside the process, so the figure is only reported when this run is
-    the configuration the passes were collected on (1024^2, 8 steps per forward); otherwise null."""
+    the configuration the passes were collected on (1024^2, 16 steps per forward); otherwise null."""
     path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if not (os.path.exists(path) and eng.batch == 8 and eng.G.cfg.img_resolution == 1024):
+    if not (os.path.exists(path) and eng.batch == 16 and eng.G.cfg.img_resolution == 1024):
         return {"traffic": None}
     with open(path) as fh:
         rec = json.load(fh).get(kernel)

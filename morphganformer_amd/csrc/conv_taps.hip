@@ -35,7 +35,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CK = 8;          // input channels per K chunk
 // per-lane register staging slots of the pipelined kernels: XS floats of the input footprint, WS float4 of the weight slab
 template <int WM, int WN> struct Slots {
-    static constexpr int XS = WN == 4 ? 20 : 11;      // 16x32 tile: 8*18*34 = 4896 floats; 8x32 tile: 8*10*34 = 2720
+    static constexpr int XS = WN == 4 ? 20 : (WN == 3 ? 15 : 11);      // 16x32 tile: 8*18*34 = 4896 floats; 12x32: 3808; 8x32: 2720
     static constexpr int WS = WM == 2 ? 5 : 3;        // 9*8*64/4 = 1152 float4; 9*8*32/4 = 576
 };
 
@@ -843,12 +843,13 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     int wm = 1, wn = 2;
     if (mode == 0) {
         if (d.cout_pad % 64 == 0 && d.cout > 32) { wm = 2; wn = 2; }
-        else if ((int64_t)d.tile_h * d.tile_w >= 512 * 64) { wm = 1; wn = 4; }
+        // <= 32 output channels on a large map: 12-row tiles for 3x3 (measured 91 vs 87 TFLOP/s at 1024^2), 16-row tiles for 1x1
+        else if ((int64_t)d.tile_h * d.tile_w >= 512 * 64) { wm = 1; wn = d.ntaps == 9 ? 3 : 4; }
         // tuning hook (experiments only): MGF_CONV_TILE=wm,wn forces the tile of MODE-0 launches
         static const char* force = getenv("MGF_CONV_TILE");
         if (force && force[0] && force[1] == ',' && force[2]) {
             const int fm = force[0] - '0', fn = force[2] - '0';
-            if ((fm == 2 && fn == 2 && d.cout_pad % 64 == 0) || (fm == 1 && (fn == 2 || fn == 4))) { wm = fm; wn = fn; }
+            if ((fm == 2 && fn == 2 && d.cout_pad % 64 == 0) || (fm == 1 && (fn == 2 || fn == 3 || fn == 4))) { wm = fm; wn = fn; }
         }
     }
     const int PX = 128 * wn;
@@ -896,6 +897,7 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     if (mode == 1) rc = launch_conv<1, 2, 1>(p, st);
     else if (wm == 2) rc = launch_conv<2, 2, 0>(p, st);
     else if (wn == 4) rc = launch_conv<1, 4, 0>(p, st);
+    else if (wn == 3) rc = launch_conv<1, 3, 0>(p, st);
     else rc = launch_conv<1, 2, 0>(p, st);
     if (rc != MGF_OK) return rc;
     MGF_CHECK_LAUNCH("conv_taps");

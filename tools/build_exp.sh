@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p exp_build/_obj_$1
 C=morphganformer_amd/csrc
-for s in capi.cpp bias_act.hip upfirdn2d.hip latent_prep.hip attention.hip losses.hip; do
+for s in capi.cpp bias_act.hip upfirdn2d.hip latent_prep.hip attention.hip losses.hip lpips_stem.hip embed.hip; do
   cp -u $C/_obj/$s.o exp_build/_obj_$1/$s.o
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=on -Wno-unused-result $2 -x hip -c $C/conv_taps.hip -o exp_build/_obj_$1/conv_taps.hip.o
