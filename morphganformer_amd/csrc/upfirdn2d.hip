@@ -175,6 +175,8 @@ __global__ __launch_bounds__(256) void upfirdn_tiled_f32(UFParams p) {
 // Output tile 64 x 16 per workgroup; a lane produces a 1x4 strip and stores it as one float4; the input footprint is
 // staged with ALIGNED float4 loads (window starts 4 columns left of the tile) -- 3.4x fewer, 4x wider memory instructions
 // than the scalar tiled kernel, which is what this bandwidth-bound op is limited by.
+constexpr int FIR_SUB = 4;       // vertically adjacent tiles per workgroup of the wide FIR kernels
+
 template <bool EP>
 __global__ __launch_bounds__(256) void fir_up1_wide(UFParams p) {
     constexpr int TW = 64, TH = 16, WV = 18, IH = TH + 3;          // window: 18 float4 = 72 columns, 19 rows
@@ -190,11 +192,17 @@ __global__ __launch_bounds__(256) void fir_up1_wide(UFParams p) {
         }
         sf[jy][jx] = v;
     }
-    const int tiles_x = p.out_w / TW, tiles_y = (p.out_h + TH - 1) / TH;
+    // a workgroup walks FIR_SUB vertically adjacent 64x16 tiles: 4x fewer, longer-lived workgroups (filter set-up and index
+    // arithmetic amortised; +1% on the whole iteration)
+    const int tiles_x = p.out_w / TW, tiles_y = (p.out_h + TH * FIR_SUB - 1) / (TH * FIR_SUB);
     const int tile = blockIdx.x % (tiles_x * tiles_y), plane = blockIdx.x / (tiles_x * tiles_y);
-    const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
+    const int ox0 = (tile % tiles_x) * TW;
     const int n = plane / p.c, c = plane - n * p.c;
     const float* xb = (const float*)p.x + (int64_t)n * p.sn + (int64_t)c * p.sc;
+    for (int sub_t = 0; sub_t < FIR_SUB; ++sub_t) {
+    const int oy0 = ((tile / tiles_x) * FIR_SUB + sub_t) * TH;
+    if (oy0 >= p.out_h) break;
+    if (sub_t) __syncthreads();                                    // the previous sub-tile's window reads are done
     const int xa = ox0 - 4, iy0 = oy0 - p.pady0;                  // window origin (input coordinates)
     for (int i = tid; i < IH * WV; i += 256) {
         const int r = i / WV, v4 = i - r * WV;
@@ -249,6 +257,7 @@ __global__ __launch_bounds__(256) void fir_up1_wide(UFParams p) {
         }
         *reinterpret_cast<float4*>((float*)p.y + yoff) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
+    }
 }
 
 __global__ __launch_bounds__(256) void fir_up2_wide(UFParams p) {
@@ -265,11 +274,15 @@ __global__ __launch_bounds__(256) void fir_up2_wide(UFParams p) {
         }
         sf[jy][jx] = v;
     }
-    const int tiles_x = p.out_w / TW, tiles_y = (p.out_h + TH - 1) / TH;
+    const int tiles_x = p.out_w / TW, tiles_y = (p.out_h + TH * FIR_SUB - 1) / (TH * FIR_SUB);
     const int tile = blockIdx.x % (tiles_x * tiles_y), plane = blockIdx.x / (tiles_x * tiles_y);
-    const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
+    const int ox0 = (tile % tiles_x) * TW;
     const int n = plane / p.c, c = plane - n * p.c;
     const float* xb = (const float*)p.x + (int64_t)n * p.sn + (int64_t)c * p.sc;
+    for (int sub_t = 0; sub_t < FIR_SUB; ++sub_t) {
+    const int oy0 = ((tile / tiles_x) * FIR_SUB + sub_t) * TH;
+    if (oy0 >= p.out_h) break;
+    if (sub_t) __syncthreads();
     // pad (2, 2): output 2m + b reads input columns m - 1 + b (tap jx = b) and m + b (tap jx = b + 2); same for rows
     const int xa = ox0 / 2 - 4, ya = oy0 / 2 - 1;
     for (int i = tid; i < IH * WV; i += 256) {
@@ -301,6 +314,7 @@ __global__ __launch_bounds__(256) void fir_up2_wide(UFParams p) {
     if (oy < p.out_h) {
         const int64_t yoff = (int64_t)n * p.yn + (int64_t)c * p.yc + (int64_t)oy * p.yh + ox0 + 4 * lx;
         *reinterpret_cast<float4*>((float*)p.y + yoff) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
     }
 }
 
@@ -344,11 +358,11 @@ extern "C" int mgf_upfirdn2d(void* y, const void* x, const float* f, int dtype, 
                          yh % 4 == 0 && yc % 4 == 0 && yn % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
                          (!ep || ((!ep->noise || (uintptr_t)ep->noise % 16 == 0) && (!ep->residual || (uintptr_t)ep->residual % 16 == 0)));
     if (wide_ok && upx == 1 && padx0 == 1 && sh >= (int64_t)((in_w + 3) / 4) * 4 && pady0 >= 0 && pady0 <= 3) {
-        const int blocks = n * c * (int)mgf_cdiv(out_h, 16) * (out_w / 64);
+        const int blocks = n * c * (int)mgf_cdiv(out_h, 16 * FIR_SUB) * (out_w / 64);
         if (ep) hipLaunchKernelGGL((fir_up1_wide<true>), dim3(blocks), dim3(256), 0, stq, p);
         else hipLaunchKernelGGL((fir_up1_wide<false>), dim3(blocks), dim3(256), 0, stq, p);
     } else if (wide_ok && upx == 2 && padx0 == 2 && pady0 == 2 && !ep && in_w % 4 == 0 && out_h % 2 == 0) {
-        const int blocks = n * c * (int)mgf_cdiv(out_h, 16) * (out_w / 64);
+        const int blocks = n * c * (int)mgf_cdiv(out_h, 16 * FIR_SUB) * (out_w / 64);
         hipLaunchKernelGGL(fir_up2_wide, dim3(blocks), dim3(256), 0, stq, p);
     } else if (tiled) {
         const int blocks = n * c * (int)mgf_cdiv(out_h, 16) * (int)mgf_cdiv(out_w, 64);
