@@ -1,7 +1,7 @@
 """Per-kernel HBM traffic from rocprofv3 counter-collection CSVs (one pass per counter: FETCH_SIZE costs 3 of the 4 TCC
 slots and WRITE_SIZE 2, MI355X_MICROARCH.md 'rocprofv3 PMC slots').
 
-    python tools/pmc_traffic.py FETCH_DIR WRITE_DIR [--calib CALIB_FETCH_DIR CALIB_WRITE_DIR] [--match SUBSTR] [--json OUT]
+    python tools/pmc_traffic.py FETCH_DIR WRITE_DIR [--calib CALIB_FETCH_DIR CALIB_WRITE_DIR] [--match SUBSTR] [--json OUT] [--steps-per-forward B] [--loop-only]
 
 Prints, per kernel name, launches and the mean counter value per launch (raw KiB -> bytes), and when --calib is given
 the factors (true bytes / reported bytes) measured on tools/pmc_calib.py's 1 GiB copies.
@@ -13,17 +13,31 @@ import sys
 from collections import defaultdict
 
 
+LOOP_ONLY = False
+
+
 def load(d):
-    """{kernel: [values per dispatch]} for the single counter collected in directory tree d."""
+    """{kernel: [values per dispatch]} for the single counter collected in directory tree d.  With --loop-only, only the
+    dispatches of whole projection iterations are kept (from a perturb_kernel to the next select_kernel): one-off set-up work
+    at batch 1 and bench.py's generator-only leg would otherwise skew the per-launch means."""
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no *counter_collection.csv under {d}")
     per = defaultdict(lambda: defaultdict(float))
     for f in files:
         with open(f, newline="") as fh:
-            for row in csv.DictReader(fh):
-                key = (f, row.get("Dispatch_Id") or row.get("Correlation_Id"))
-                per[row["Kernel_Name"]][key] += float(row["Counter_Value"])
+            rows = sorted(csv.DictReader(fh), key=lambda r: int(r.get("Dispatch_Id") or r.get("Correlation_Id")))
+        in_loop = False
+        for row in rows:
+            name = row["Kernel_Name"]
+            if "perturb_kernel" in name:
+                in_loop = True
+            if LOOP_ONLY and not in_loop:
+                continue
+            key = (f, row.get("Dispatch_Id") or row.get("Correlation_Id"))
+            per[name][key] += float(row["Counter_Value"])
+            if "select_kernel" in name:
+                in_loop = False
     return {k: list(v.values()) for k, v in per.items()}
 
 
@@ -42,6 +56,15 @@ def main():
     if "--json" in args:
         i = args.index("--json")
         json_out = args[i + 1]
+        del args[i:i + 2]
+    global LOOP_ONLY
+    if "--loop-only" in args:
+        LOOP_ONLY = True
+        args.remove("--loop-only")
+    meta = None
+    if "--steps-per-forward" in args:
+        i = args.index("--steps-per-forward")
+        meta = int(args[i + 1])
         del args[i:i + 2]
     calib = None
     if "--calib" in args:
@@ -79,6 +102,8 @@ def main():
             # read, 559 MB for the dword-wide variant) -> doubled; WRITE_SIZE is exact (1073.7 / 1101 MB reported for 1073.7 MB)
             table[short] = {"launches": n, "fetch_bytes_reported": round(r * 1e6), "fetch_bytes": round(2 * r * 1e6),
                             "write_bytes": round(w * 1e6), "hbm_bytes": round((2 * r + w) * 1e6)}
+        if meta is not None:
+            table["_meta"] = {"steps_per_forward": meta}
         with open(json_out, "w") as fh:
             json.dump(table, fh, indent=1, sort_keys=True)
 

@@ -1,6 +1,9 @@
 """Summarise a rocprofv3 rocpd SQLite database (kernel-trace) into a per-kernel stats table (markdown/CSV-ish text).
 
-    python tools/rocpd_stats.py gpurun_out/prof/x_results.db [--per-launch KERNEL_SUBSTR]
+    python tools/rocpd_stats.py gpurun_out/prof/x_results.db [--per-launch KERNEL_SUBSTR] [--loop-only]
+
+--loop-only keeps the dispatches of whole projection iterations only (from a perturb_kernel to the next select_kernel, in start
+order): that is the population bench.py's in-process event timing averages over (no batch-1 set-up, no generator-only leg).
 """
 import sqlite3
 import sys
@@ -11,7 +14,19 @@ def main():
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by {name_col} order by 3 desc").fetchall()
+    if "--loop-only" in sys.argv:
+        agg, in_loop = {}, False
+        for name, dur in cur.execute(f"select {name_col}, end-start from kernels order by start"):
+            if "perturb_kernel" in name:
+                in_loop = True
+            if in_loop:
+                a = agg.setdefault(name, [0, 0, 1 << 62, 0])
+                a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
+            if "select_kernel" in name:
+                in_loop = False
+        rows = sorted(((k, v[0], v[1], v[1] / v[0], v[2], v[3]) for k, v in agg.items()), key=lambda r: -r[2])
+    else:
+        rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by {name_col} order by 3 desc").fetchall()
     total = sum(r[2] for r in rows)
     print(f"{'kernel':<100} {'calls':>6} {'total_ms':>10} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'pct':>6}")
     for name, n, tot, avg, mn, mx in rows:
