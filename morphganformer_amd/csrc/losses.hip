@@ -111,7 +111,8 @@ template <bool UNIT_OUT>
 int launch_lpips_layer(float* scratch, float* unit_out, const float* f0, const float* f1u, const float* lin, int n, int c, int64_t hw,
                        int64_t f1_stride, hipStream_t st, int* grid_out) {
     // 64 pixels per workgroup (256-byte segments) whenever that still yields >= 4 workgroups per CU, 16 for the small deep taps
-    const int pxb = (hw >= 65536 || (int64_t)n * mgf_cdiv(hw, 64) >= 1024) ? 64 : 16;
+    // (only up to 256 channels: beyond that a thread would hold 128 channel values and occupancy collapses)
+    const int pxb = (hw >= 65536 || (c <= 256 && (int64_t)n * mgf_cdiv(hw, 64) >= 1024)) ? 64 : 16;
     const int64_t grid64 = mgf_cdiv(hw, pxb);
     MGF_REQUIRE(grid64 <= RED_BLOCKS, MGF_ETOOBIG, "lpips_layer: %lld pixels per sample need %lld scratch floats (have %d per sample)",
                 (long long)hw, (long long)grid64, RED_BLOCKS);
