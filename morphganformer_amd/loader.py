@@ -8,13 +8,19 @@ where `state` is the module's `__dict__` (`_parameters`, `_buffers`, `_modules`,
 The reference rebuilds objects by `exec`-ing `module_src`; this reader instead intercepts the reconstruct call, ignores
 `module_src`, and keeps `(class_name, state)` as an inert stub tree that is flattened into a `state_dict`.  The unpickler only
 resolves an allow-list of globals (torch tensor rebuild helpers, numpy array rebuild helpers, OrderedDict, EasyDict); anything
-else raises.  Legacy TensorFlow pickles (loader.py:36-41,91-247) are not converted yet.
+else raises.
+
+Legacy TensorFlow snapshots (loader.py:36-41: a 3-tuple of `dnnlib.tflib.network.Network` objects) are read the same inert way
+(`TFNetworkStub`) and their generator variables renamed / transposed / flipped into the PyTorch state_dict layout by
+`convert_tf_generator` -- the rules of loader.py:91-247 restated as a parser of the TensorFlow variable names.
 """
 from __future__ import annotations
 
 import collections
 import io
+import math
 import pickle
+import re
 from dataclasses import dataclass
 
 import numpy as np
@@ -81,6 +87,14 @@ def _inert_class(name):
     return type(name, (InertModule,), {"class_name": name})
 
 
+class TFNetworkStub(EasyDict):
+    """Inert stand-in for a pickled `dnnlib.tflib.network.Network` (the reference maps it onto an EasyDict too, loader.py:51-58):
+    `__setstate__` only stores version / static_kwargs / variables / components; the build-function source is ignored."""
+
+    def __setstate__(self, state):
+        self.update(state)
+
+
 def _reconstruct_persistent_obj(meta):
     meta = dict(meta)
     if meta.get("type") != "class":
@@ -92,6 +106,7 @@ def _reconstruct_persistent_obj(meta):
 _ALLOWED = {
     ("collections", "OrderedDict"): collections.OrderedDict,
     ("dnnlib.util", "EasyDict"): EasyDict, (__name__, "EasyDict"): EasyDict,
+    ("dnnlib.tflib.network", "Network"): TFNetworkStub, (__name__, "TFNetworkStub"): TFNetworkStub,
     ("torch_utils.persistence", "_reconstruct_persistent_obj"): _reconstruct_persistent_obj,
     ("builtins", "set"): set, ("builtins", "dict"): dict, ("builtins", "list"): list, ("builtins", "tuple"): tuple,
     ("builtins", "slice"): slice, ("builtins", "complex"): complex, ("builtins", "frozenset"): frozenset,
@@ -156,10 +171,163 @@ def config_from_stub(stub: PersistentStub) -> GeneratorConfig:
         normalize_global=bool(mp.get("normalize_global", True)))
 
 
+# ------------------------------------------------------------------------------------------------------ legacy TensorFlow pickles
+def collect_tf_params(tf_net, prefix=""):
+    """Flatten `variables` of a network and of its components into {"comp/sub/name": ndarray} (loader.py:60-68)."""
+    out = {}
+    for name, value in tf_net["variables"]:
+        out[prefix + name] = np.asarray(value)
+    for name, comp in tf_net.get("components", {}).items():
+        out.update(collect_tf_params(comp, prefix + name + "/"))
+    return out
+
+
+def config_from_tf_kwargs(kw) -> GeneratorConfig:
+    """GeneratorConfig from a TF network's static_kwargs (the kwarg translation of loader.py:97-154).  Only the architecture this
+    engine implements is accepted: resnet blocks, duplex (k-means) attention with sinusoidal positions, multiplicative
+    integration -- what the published GANformer snapshots use."""
+    get = lambda k, d: d if kw.get(k, d) is None else kw.get(k, d)
+    need = {"architecture": "resnet", "transformer": True, "style": True, "local_noise": True, "kmeans": True, "use_pos": True,
+            "integration": "mul", "norm": "layer", "mapping_resnet": True, "mapping_ltnt2ltnt": True}
+    for k, v in need.items():
+        if kw.get(k) != v:
+            raise NotImplementedError(f"TensorFlow snapshot built with {k}={kw.get(k)!r}; this engine implements {k}={v!r}")
+    if get("label_size", 0) != 0 or get("num_heads", 1) != 1 or get("start_res", 0) != 0:
+        raise NotImplementedError("conditional / multi-head / start_res > 0 snapshots are not supported")
+    return GeneratorConfig(
+        img_resolution=int(get("resolution", 1024)), img_channels=int(get("num_channels", 3)), z_dim=int(get("latent_size", 512)),
+        w_dim=int(get("dlatent_size", 512)), k=int(get("components_num", 1)) + 1, channel_base=int(get("fmap_base", 16 << 10)) * 2,
+        channel_max=int(get("fmap_max", 512)), attn_max_log2res=int(get("end_res", 8)),
+        mapping_layers=int(get("mapping_layersnum", 8)), mapping_lrmul=float(get("mapping_lrmul", 0.01)), normalize_global=False)
+
+
+_QKV = {"query": "to_queries", "key": "to_keys", "value": "to_values"}
+
+
+def _att_entry(rest):
+    """'weight_query' / 'bias_from_pos' / 'weight_out' / 'toasgn_init' / 'iter_0/st_weights' -> (torch suffix, transpose?)"""
+    if rest == "toasgn_init":
+        return "centroids", False
+    if rest == "iter_0/st_weights":
+        return "att_weight", False
+    kind, _, what = rest.partition("_")
+    if kind not in ("weight", "bias"):
+        return None, False
+    if what in _QKV:
+        mod = _QKV[what]
+    elif what in ("from_pos", "to_pos"):
+        mod = what + "_map"
+    elif what == "out":
+        mod = "modulation"
+    else:
+        return None, False          # key2 (queries2centroids) and friends: not part of the PyTorch module
+    return f"{mod}.{kind}", kind == "weight"
+
+
+def convert_tf_generator(tf_G):
+    """TF generator stub -> (state_dict of numpy float32 arrays under the PyTorch key names, GeneratorConfig).
+    Transforms (loader.py:185-240): dense weights are transposed; conv kernels go HWIO -> OIHW, and the up-sampling conv0 and the
+    skip kernels are additionally flipped in H and W; every style affine bias gets +1; `dlatent_avg` -> mapping.w_avg,
+    `ltnt_emb/emb` -> pos, `synthesis/noise<j>` -> the j-th layer's noise_const; position grids and FIR kernels are rebuilt."""
+    if int(tf_G.get("version", 0)) < 4:
+        raise ValueError("TensorFlow pickle version too low")
+    cfg = config_from_tf_kwargs(dict(tf_G["static_kwargs"]))
+    tfp = collect_tf_params(tf_G)
+    sd = {}
+    f32 = lambda a: np.array(a, dtype=np.float32, order="C")          # (ascontiguousarray would turn 0-d into 1-d)
+    res_out = cfg.img_resolution
+    for name, v in tfp.items():
+        if name == "dlatent_avg":
+            sd["mapping.w_avg"] = f32(v)
+        elif name == "ltnt_emb/emb":
+            sd["pos"] = f32(v)
+        elif name.startswith("mapping/"):
+            rest = name[len("mapping/"):]
+            mlp = "mlp"
+            if rest.startswith("global/"):
+                mlp, rest = "global_mlp", rest[len("global/"):]
+            layer, _, leaf = rest.partition("/")
+            m = re.fullmatch(r"Dense(\d+)_(\d+)", layer)
+            if m and leaf in ("weight", "bias"):
+                sd[f"mapping.{mlp}.l{m.group(1)}.fc{m.group(2)}.{leaf}"] = f32(v.T if leaf == "weight" else v)
+            elif layer == "Dense3" and leaf in ("weight", "bias"):                # the output layer's fixed name (loader.py:195-196)
+                sd[f"mapping.{mlp}.out_layer.{leaf}"] = f32(v.T if leaf == "weight" else v)
+            elif layer.startswith("AttLayer_") and mlp == "mlp":
+                suffix, tr = _att_entry(leaf)
+                if suffix is not None and not suffix.startswith(("centroids", "att_weight")):
+                    sd[f"mapping.mlp.sa{layer[len('AttLayer_'):]}.{suffix}"] = f32(v.T if tr else v)
+        elif name.startswith("synthesis/"):
+            rest = name[len("synthesis/"):]
+            m = re.fullmatch(r"noise(\d+)", rest)
+            if m:
+                j = int(m.group(1))                                               # layer j: res 2^((j+5)//2), conv (j+5) % 2 ... inverse of
+                log2r, i = divmod(j + 5, 2)                                       # j = log2(r)*2 - 5 + i  (loader.py:222)
+                sd[f"synthesis.b{2 ** log2r}.conv{i}.noise_const"] = f32(v[0, 0])
+                continue
+            m = re.fullmatch(r"(\d+)x\1/(.+)", rest)
+            if not m:
+                continue
+            r, leaf = int(m.group(1)), m.group(2)
+            b = f"synthesis.b{r}"
+            if leaf == "Const/const":
+                sd[b + ".const"] = f32(v[0])
+                continue
+            layer, _, what = leaf.partition("/")
+            if layer in ("Conv", "Conv1", "Conv0_up"):
+                conv = "conv0" if layer == "Conv0_up" else "conv1"
+                if what == "weight":
+                    w = v[::-1, ::-1] if conv == "conv0" else v                   # the transposed conv stores the flipped kernel
+                    sd[f"{b}.{conv}.weight"] = f32(w.transpose(3, 2, 0, 1))
+                elif what == "bias":
+                    sd[f"{b}.{conv}.biasAct.bias"] = f32(v)
+                elif what == "noise_strength":
+                    sd[f"{b}.{conv}.noise_strength"] = f32(v)
+                elif what == "mod_weight":
+                    sd[f"{b}.{conv}.affine.weight"] = f32(v.T)
+                elif what == "mod_bias":
+                    sd[f"{b}.{conv}.affine.bias"] = f32(v + 1)
+                elif what.startswith("AttLayer_l2n/"):
+                    suffix, tr = _att_entry(what[len("AttLayer_l2n/"):])
+                    if suffix is not None:
+                        sd[f"{b}.{conv}.transformer.{suffix}"] = f32(v.T if tr else v)
+            elif layer == "Skip" and what == "weight":
+                sd[b + ".skip.weight"] = f32(v[::-1, ::-1].transpose(3, 2, 0, 1))
+            elif layer == "ToRGB" and r == res_out:
+                if what == "weight":
+                    sd[b + ".torgb.weight"] = f32(v.transpose(3, 2, 0, 1))
+                elif what == "bias":
+                    sd[b + ".torgb.biasAct.bias"] = f32(v)
+                elif what == "mod_weight":
+                    sd[b + ".torgb.affine.weight"] = f32(v.T)
+                elif what == "mod_bias":
+                    sd[b + ".torgb.affine.bias"] = f32(v + 1)
+                elif what == "extraLayer/weight":
+                    sd[b + ".conv_last.weight"] = f32(v.transpose(3, 2, 0, 1))
+                elif what == "extraLayer/mod_weight":
+                    sd[b + ".conv_last.affine.weight"] = f32(v.T)
+                elif what == "extraLayer/mod_bias":
+                    sd[b + ".conv_last.affine.bias"] = f32(v + 1)
+    # buffers the TF snapshot does not carry: FIR kernels and sinusoidal position grids are functions of the config
+    from .synth_weights import make_state_dict
+    template = make_state_dict(cfg, seed=0)
+    for k, v in template.items():
+        if k.endswith("resample_kernel") or k.endswith("grid_pos"):
+            sd[k] = v
+    missing = [k for k in template if k not in sd]
+    if missing:
+        raise pickle.UnpicklingError(f"TensorFlow snapshot lacks {len(missing)} generator variables, e.g. {missing[:4]}")
+    for k, v in template.items():
+        if tuple(np.shape(sd[k])) != tuple(np.shape(v)):
+            raise pickle.UnpicklingError(f"{k}: TensorFlow variable has shape {np.shape(sd[k])}, expected {np.shape(v)}")
+    return {k: sd[k] for k in template}, cfg
+
+
 def load_network_stubs(path):
     data = read_pickle(path)
     if isinstance(data, tuple):
-        raise NotImplementedError("legacy TensorFlow network pickles (loader.py:36-41) are not supported yet")
+        if not (len(data) == 3 and all(isinstance(net, TFNetworkStub) for net in data)):
+            raise pickle.UnpicklingError("a tuple snapshot must hold the three TensorFlow networks (G, D, Gs)")
+        return dict(zip(("G", "D", "Gs"), data))
     for key in ("G", "D", "Gs"):
         if key not in data or not isinstance(data[key], PersistentStub):
             raise pickle.UnpicklingError(f"snapshot has no persistent network under key {key!r}")
@@ -174,6 +342,10 @@ def load_network(path, device="cuda", which=("Gs",)):
     out = dict(data)
     for key in which:
         stub = data[key]
+        if isinstance(stub, TFNetworkStub):
+            sd, cfg = convert_tf_generator(stub)
+            out[key] = Generator(sd, cfg, device)
+            continue
         if stub.class_name != "Generator":
             raise pickle.UnpicklingError(f"{key} is a {stub.class_name}, expected Generator")
         sd = {k: v.detach().cpu().numpy() for k, v in stub.state_dict().items()}

@@ -309,3 +309,172 @@ def test_reference_gray_conversion_kat():
     img[0, 2] = (1.0, -1.0, 0.0)            # (255, 0, 128) -> (255*1868 + 128*4899 + 8192) >> 14 = 67
     assert reference_gray_u8(img).tolist() == [[0, 255, 67]]
     assert reference_gray_u8(np.full((2, 2, 3), 0.3, np.float32)).tolist() == [[0, 0], [0, 0]]      # flat image: max == min
+
+
+# ------------------------------------------------------------------------------------------------- legacy TensorFlow snapshots
+def _tf_stub_from_state(sd, cfg):
+    """Build the nested TF-network structure of a legacy snapshot from a PyTorch-layout state_dict (test helper: the inverse
+    of loader.convert_tf_generator's renaming / transposes / flips / +1)."""
+    from morphganformer_amd import loader
+    top, mapping, synthesis = [], [], []
+    qkv = {"to_queries": "query", "to_keys": "key", "to_values": "value"}
+
+    def att(prefix, rest, v):
+        mod, _, kind = rest.rpartition(".")
+        if rest == "centroids":
+            return prefix + "toasgn_init", v
+        if rest == "att_weight":
+            return prefix + "iter_0/st_weights", v
+        what = qkv.get(mod) or {"from_pos_map": "from_pos", "to_pos_map": "to_pos", "modulation": "out"}[mod]
+        return prefix + f"{kind}_{what}", (v.T if kind == "weight" else v)
+
+    for k, v in sd.items():
+        v = np.asarray(v)
+        if k.endswith(("resample_kernel", "grid_pos")):
+            continue
+        if k == "pos":
+            top.append(("ltnt_emb/emb", v)); continue
+        if k == "mapping.w_avg":
+            top.append(("dlatent_avg", v)); continue
+        p = k.split(".")
+        if p[0] == "mapping":
+            g = "global/" if p[1] == "global_mlp" else ""
+            if p[2] == "out_layer":
+                mapping.append((f"{g}Dense3/{p[3]}", v.T if p[3] == "weight" else v))
+            elif p[2].startswith("l"):
+                mapping.append((f"{g}Dense{p[2][1:]}_{p[3][2:]}/{p[4]}", v.T if p[4] == "weight" else v))
+            else:
+                mapping.append(att(f"AttLayer_{p[2][2:]}/", ".".join(p[3:]), v))
+            continue
+        r = int(p[1][1:])
+        base = f"{r}x{r}/"
+        if p[2] == "const":
+            synthesis.append((base + "Const/const", v[None])); continue
+        if p[2] == "skip":
+            synthesis.append((base + "Skip/weight", v.transpose(2, 3, 1, 0)[::-1, ::-1])); continue
+        if p[2] in ("conv0", "conv1"):
+            lay = "Conv0_up" if p[2] == "conv0" else ("Conv" if r == 4 else "Conv1")
+            rest = ".".join(p[3:])
+            if rest == "weight":
+                w = v.transpose(2, 3, 1, 0)
+                synthesis.append((base + lay + "/weight", w[::-1, ::-1] if p[2] == "conv0" else w))
+            elif rest == "biasAct.bias":
+                synthesis.append((base + lay + "/bias", v))
+            elif rest == "noise_strength":
+                synthesis.append((base + lay + "/noise_strength", v))
+            elif rest == "noise_const":
+                synthesis.append((f"noise{int(math.log2(r)) * 2 - 5 + int(p[2][4])}", v[None, None]))
+            elif rest == "affine.weight":
+                synthesis.append((base + lay + "/mod_weight", v.T))
+            elif rest == "affine.bias":
+                synthesis.append((base + lay + "/mod_bias", v - 1))
+            else:
+                synthesis.append(att(base + lay + "/AttLayer_l2n/", rest[len("transformer."):], v))
+            continue
+        rest = ".".join(p[3:])
+        tf = {("torgb", "weight"): "ToRGB/weight", ("torgb", "biasAct.bias"): "ToRGB/bias", ("torgb", "affine.weight"): "ToRGB/mod_weight",
+              ("torgb", "affine.bias"): "ToRGB/mod_bias", ("conv_last", "weight"): "ToRGB/extraLayer/weight",
+              ("conv_last", "affine.weight"): "ToRGB/extraLayer/mod_weight", ("conv_last", "affine.bias"): "ToRGB/extraLayer/mod_bias"}[(p[2], rest)]
+        if rest == "weight":
+            v = v.transpose(2, 3, 1, 0)
+        elif rest == "affine.weight":
+            v = v.T
+        elif rest == "affine.bias":
+            v = v - 1
+        synthesis.append((base + tf, v))
+    kw = dict(latent_size=cfg.z_dim, label_size=0, dlatent_size=cfg.w_dim, components_num=cfg.k - 1, resolution=cfg.img_resolution,
+              num_channels=3, mapping_layersnum=cfg.mapping_layers, mapping_lrmul=cfg.mapping_lrmul, mapping_resnet=True,
+              mapping_ltnt2ltnt=True, transformer=True, num_heads=1, use_pos=True, fmap_base=cfg.channel_base // 2, fmap_max=cfg.channel_max,
+              architecture="resnet", local_noise=True, style=True, start_res=0, end_res=cfg.attn_max_log2res, integration="mul",
+              norm="layer", kmeans=True, kmeans_iters=1, pos_type="sinus", pos_init="uniform", pos_directions_num=2)
+    S = loader.TFNetworkStub
+    return S(version=5, static_kwargs=kw, variables=top,
+             components={"mapping": S(version=5, static_kwargs={}, variables=mapping, components={}),
+                         "synthesis": S(version=5, static_kwargs={}, variables=synthesis, components={})})
+
+
+def _mini256():
+    from morphganformer_amd.synth_weights import GeneratorConfig
+    return GeneratorConfig(img_resolution=256, channel_base=2048, channel_max=32, attn_max_log2res=6, normalize_global=False)
+
+
+def test_legacy_tf_snapshot_conversion_roundtrip(tmp_path):
+    """loader.convert_tf_generator (rules of loader.py:91-247): names, transposes, kernel flips, the +1 on style biases, noise
+    indexing -- against a TF-layout snapshot synthesised from a known state_dict, and through the pickle reader."""
+    import pickle
+    from morphganformer_amd import loader
+    from morphganformer_amd.synth_weights import make_state_dict
+    cfg = _mini256()
+    sd = make_state_dict(cfg, seed=7)
+    stub = _tf_stub_from_state(sd, cfg)
+    names = dict(loader.collect_tf_params(stub))
+    assert "synthesis/4x4/Conv/mod_bias" in names and "synthesis/noise0" in names and "mapping/global/Dense3/weight" in names
+    assert names["synthesis/8x8/Conv0_up/weight"].shape == (3, 3, 32, 32)                        # HWIO
+    got, gcfg = loader.convert_tf_generator(stub)
+    assert gcfg == cfg and list(got) == list(sd)
+    for k in sd:
+        assert np.array_equal(got[k], np.asarray(sd[k], dtype=np.float32)), k
+    # a wrong architecture is refused, not silently mis-loaded
+    bad = _tf_stub_from_state(sd, cfg)
+    bad["static_kwargs"]["architecture"] = "skip"
+    with pytest.raises(NotImplementedError):
+        loader.convert_tf_generator(bad)
+    # through the file format: a 3-tuple of dnnlib.tflib.network.Network objects
+    import sys, types
+    mod = types.ModuleType("dnnlib.tflib.network")
+
+    class Network:
+        def __init__(self, st):
+            self.__dict__.update(st)
+
+        def __getstate__(self):
+            return dict(self.__dict__)
+    Network.__module__, Network.__qualname__ = "dnnlib.tflib.network", "Network"
+    mod.Network = Network
+    saved = {k: sys.modules.get(k) for k in ("dnnlib", "dnnlib.tflib", "dnnlib.tflib.network")}
+    sys.modules.update({"dnnlib": types.ModuleType("dnnlib"), "dnnlib.tflib": types.ModuleType("dnnlib.tflib"), "dnnlib.tflib.network": mod})
+    try:
+        def to_net(s_):
+            return Network(dict(version=s_["version"], static_kwargs=s_["static_kwargs"], variables=s_["variables"],
+                                components={k: to_net(v) for k, v in s_["components"].items()}))
+        with open(tmp_path / "tf.pkl", "wb") as f:
+            pickle.dump((to_net(stub), to_net(stub), to_net(stub)), f)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    nets = loader.load_network_stubs(str(tmp_path / "tf.pkl"))
+    assert set(nets) == {"G", "D", "Gs"} and isinstance(nets["Gs"], loader.TFNetworkStub)
+    got2, _ = loader.convert_tf_generator(nets["Gs"])
+    assert all(np.array_equal(got2[k], got[k]) for k in got)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/torch_utils"), reason="reference tree not present (GPU box)")
+def test_legacy_tf_conversion_matches_the_reference_converter():
+    """The same synthetic TF snapshot through the REFERENCE's convert_tf_generator (loader.py:91-247)."""
+    from morphganformer_amd import loader
+    from morphganformer_amd.synth_weights import make_state_dict
+    from oracle.make_golden import import_reference
+    import_reference()
+    import importlib
+    ref_loader = importlib.import_module("loader")
+    assert ref_loader.__file__.startswith("/root/reference")
+    cfg = _mini256()
+    sd = make_state_dict(cfg, seed=7)
+    stub = _tf_stub_from_state(sd, cfg)
+
+    def to_ref(s_):
+        return ref_loader._TFNetworkStub(version=s_["version"], static_kwargs=dict(s_["static_kwargs"]), variables=list(s_["variables"]),
+                                         components={k: to_ref(v) for k, v in s_["components"].items()})
+    G = ref_loader.convert_tf_generator(to_ref(stub))
+    want = {k: v.detach().numpy() for k, v in G.state_dict().items()}
+    got, gcfg = loader.convert_tf_generator(stub)
+    assert gcfg == cfg
+    for k, v in got.items():
+        if k.endswith("grid_pos"):
+            assert np.allclose(v, want[k], atol=1e-6), k
+        else:
+            assert np.array_equal(v, want[k]), k
+    assert set(want) - set(got) == set() or all("num_batches" in k for k in set(want) - set(got))
