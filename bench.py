@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--biometric", type=int, default=0, metavar="DEPTH",
+                    help="add the IResNet-DEPTH embedding-MSE term (BASELINE config 3's full objective); 0 = the config-2 objective")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank (exercises the N>1 code path)")
     return ap.parse_args()
 
@@ -72,7 +74,7 @@ def auto_batch(steps):
     return min(range(12, 33), key=cost)
 
 
-def build(cfg, device, rank, steps_total, use_graph, batch):
+def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0):
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.lpips import PerceptualLoss
     from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, latent_stats, synthetic_landmarks
@@ -87,9 +89,15 @@ def build(cfg, device, rank, steps_total, use_graph, batch):
     latent_mean, latent_std = latent_stats(G, 10000, device, gen)
     percept = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device)
     lm_t, lm_s = synthetic_landmarks(steps_total, cfg.img_resolution, seed=7 + rank)
-    args = ProjectionArgs(step=steps_total)
+    # (seeded random embedder weights give embedding distances far above the drivers' min_loss start of 100)
+    args = ProjectionArgs(step=steps_total, min_loss_init=1e30 if biometric else 100.0)
+    bio = None
+    if biometric:
+        from morphganformer_amd.iresnet import BiometricLoss, IResNetEmbedder
+        bio = BiometricLoss(IResNetEmbedder(None, depth=biometric, n=batch, device=device, seed=0))
     eng = ProjectionEngine(G, target, latent_mean, latent_std, args, percept=percept, use_mse=True, lm_target=lm_t,
-                           lm_steps=lm_s, noise_mode="random", seed=100 + rank, use_graph=use_graph, batch=batch)
+                           lm_steps=lm_s, noise_mode="random", seed=100 + rank, use_graph=use_graph, batch=batch,
+                           biometric=bio, gamma=1e-6)
     return sd, G, percept, eng, target, latent_mean, float(latent_std), (lm_t, lm_s)
 
 
@@ -218,7 +226,7 @@ def main():
     # the engine advances `batch` loop steps per launch sequence; K or W that are not multiples are rounded UP to whole
     # launches (more work inside the timed region, never less) while the reported rate still counts exactly K steps
     rup = lambda v: -(-v // a.batch) * a.batch
-    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, rup(a.steps) + rup(a.warmup), not a.no_graph, a.batch)
+    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, rup(a.steps) + rup(a.warmup), not a.no_graph, a.batch, a.biometric)
 
     log(f"built generator/LPIPS/engine on {device}; warm-up {a.warmup} steps (includes graph capture)")
     eng.run(a.warmup)
@@ -253,7 +261,8 @@ def main():
         "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1]: single {a.res}x{a.res} face per GPU, Wing+LPIPS(squeeze)+MSE literal-mode projection step, "
-                               "noise_mode=random, seeded synthetic weights/targets/landmarks", "k": cfg.k, "z_dim": cfg.z_dim,
+                               "noise_mode=random, seeded synthetic weights/targets/landmarks"
+                               + (f" + IResNet-{a.biometric} embedding MSE (config 3 objective)" if a.biometric else ""), "k": cfg.k, "z_dim": cfg.z_dim,
                    "targets_per_gpu": 1, "parallelism": f"pair-sharded x{world}", "graph_replay": not a.no_graph,
                    "steps_per_forward": a.batch},
     }

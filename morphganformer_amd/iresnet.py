@@ -146,8 +146,10 @@ class IResNetEmbedder:
                                 epilogue=_lib.make_epilogue(bias=b["bn3"][1], residual=idn), out=B["out"])
         f = self._affine(self.flat, x, *self.bn2)
         out = self.out if out is None else out
-        _lib.check(_lib.lib().mgf_linear_f32(out.data_ptr(), f.data_ptr(), self.fc_w.data_ptr(), self.fc_b.data_ptr(), n, 512 * 49, 512,
-                                             _lib.stream_ptr()), "linear")
+        for r0 in range(0, n, 16):                                   # the GEMV kernel takes at most 16 rows per launch
+            rows = min(16, n - r0)
+            _lib.check(_lib.lib().mgf_linear_f32(out[r0:].data_ptr(), f[r0:].data_ptr(), self.fc_w.data_ptr(), self.fc_b.data_ptr(), rows,
+                                                 512 * 49, 512, _lib.stream_ptr()), "linear")
         return out
 
     def embed_image(self, img, out=None):
