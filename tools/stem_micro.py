@@ -1,0 +1,19 @@
+import sys, torch
+sys.path.insert(0, "/root/repo")
+from morphganformer_amd import _lib
+from morphganformer_amd.lpips import PerceptualLoss
+n = 8
+P = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True)
+x = (torch.rand(n, 3, 1024, 1024, device="cuda") * 2 - 1)
+P.set_target(x[:1].contiguous())
+f = P._features(n, 1024, 1024)
+out = torch.zeros(n, device="cuda")
+sc = torch.empty(n * int(_lib.lib().mgf_reduce_scratch_floats()), device="cuda")
+def run():
+    f.stem(x, feat_ref=P._target_taps[0], lin=P.lins[0], dist_out=out, scratch=sc)
+run(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): run()
+e1.record(); torch.cuda.synchronize()
+print(f"stem n={n}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
