@@ -75,7 +75,7 @@ def _desc(n, cin, in_h, in_w, cout, cout_pad, tile_h, tile_w, istride, ostride, 
     return d
 
 
-# Split-K scratch shared by every conv launch of a device (launches are stream-ordered, so one buffer is enough).
+# Split-K scratch: one slab per (device, stream) -- launches on one stream are ordered, launches on different streams may overlap.
 WORKSPACE_FLOATS = 16 << 20
 _WS = {}
 
