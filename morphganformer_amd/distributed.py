@@ -18,6 +18,33 @@ def shard_items(n_items: int, rank: int, world: int):
     return list(range(rank, n_items, world))
 
 
+class WorkQueue:
+    """Dynamic partition for ragged workloads (targets whose steps are skipped when no face is found, early exits): every rank
+    pulls the next item index from one shared atomic counter in the process group's key-value store.  No
+    tensor collective is involved; with no process group it degenerates to range(n_items)."""
+
+    def __init__(self, n_items: int, name: str = "mgf_queue"):
+        import torch.distributed as dist
+        self.n_items, self.key = n_items, name + "/next"
+        self.store = None
+        self._local = 0
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.store = dist.distributed_c10d._get_default_store()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> int:
+        if self.store is None:
+            i = self._local
+            self._local += 1
+        else:
+            i = self.store.add(self.key, 1) - 1            # atomic fetch-and-add on the rendezvous store
+        if i >= self.n_items:
+            raise StopIteration
+        return i
+
+
 def pack_result(latent: torch.Tensor, best_loss: float, best_step: int, item: int = 0) -> torch.Tensor:
     """[k*D + 3] float64 record: latent (exact: f32 embeds in f64), loss, step, item id."""
     flat = latent.reshape(-1).double()

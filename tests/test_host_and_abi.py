@@ -164,7 +164,7 @@ def _free_port():
 GLOO_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from morphganformer_amd.distributed import shard_items, pack_result, gather_results, gather_many
+from morphganformer_amd.distributed import shard_items, pack_result, gather_results, gather_many, WorkQueue
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
 rank = dist.get_rank()
 mine = shard_items(5, rank, 2)
@@ -177,6 +177,16 @@ assert torch.equal(res["latents"][rank], lat[0])            # f32 -> f64 -> f32 
 recs = torch.stack([pack_result(torch.full((1, 17, 32), float(i)), float(i), i, item=i) for i in mine])
 allr = gather_many(recs, 3)
 assert allr.shape[0] == 5 and allr[:, -1].tolist() == [0, 1, 2, 3, 4] and allr[:, 0].tolist() == [0, 1, 2, 3, 4]
+# dynamic work queue: the two ranks together take every item exactly once, whatever the interleaving
+import time
+taken = []
+for i in WorkQueue(7):
+    taken.append(i)
+    time.sleep(0.01 * (1 + 2 * rank))
+cnt = torch.zeros(7)
+cnt[taken] = 1
+dist.all_reduce(cnt)
+assert cnt.tolist() == [1.0] * 7 and len(taken) >= 1
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 """
