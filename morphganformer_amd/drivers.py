@@ -165,6 +165,30 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
     return {"w": w, "step": step, "loss": loss, "losses": losses}
 
 
+def project_many(G, targets, landmarks=None, dynamic=False, **kw):
+    """Pair-level sharding of BASELINE configs 3/5: rank r projects `targets[r::world]` (or, with dynamic=True, whatever the
+    shared `distributed.WorkQueue` hands it), then ONE all_gather returns every item's {latent, loss, step} to every rank.
+    targets: list of [1,3,S,S] device tensors (or image paths); landmarks: optional list of (lm_target, lm_steps) per item.
+    Returns dict(latents [N,k,D], losses [N], steps [N], items [N]) ordered by item id."""
+    import torch.distributed as dist
+    from .distributed import WorkQueue, gather_many, pack_result, shard_items, unpack_results
+    on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+    order = WorkQueue(len(targets)) if dynamic else shard_items(len(targets), rank, world)
+    recs = []
+    for i in order:
+        t = targets[i]
+        if not isinstance(t, torch.Tensor):
+            t = image_transform(t, size=G.img_resolution, device=G.device)
+        lm_t, lm_s = landmarks[i] if landmarks is not None else (None, None)
+        r = project_image(G, t, lm_t, lm_s, **kw)
+        recs.append(pack_result(r["w"].to(G.device), r["loss"], r["step"], item=i))
+    width = G.cfg.k * G.cfg.z_dim + 3
+    mine = torch.stack(recs) if recs else torch.empty([0, width], dtype=torch.float64, device=G.device)
+    rows = gather_many(mine, len(targets) if dynamic else -(-len(targets) // world))
+    return unpack_results(rows, (G.cfg.k, G.cfg.z_dim))
+
+
 def second_stage(G, target, w_init, latent_std, lm_target, lm_steps, **kw):
     """A second projection whose noisy candidates are drawn around an earlier result instead of the latent mean
     (edit_MSE.py: `latent_in = w1` pattern; BASELINE config 5)."""

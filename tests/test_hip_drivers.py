@@ -172,3 +172,20 @@ def test_cli_generate_project_morph(tmp_path):
     assert len(os.listdir(tmp_path / "m")) == 6
     w = drivers.load_latent_mat(str(tmp_path / "m" / "a+b_a0.50.mat"))
     assert np.array_equal(w, 0.5 * drivers.load_latent_mat(str(tmp_path / "p" / "a.mat")) + 0.5 * drivers.load_latent_mat(str(tmp_path / "p" / "b.mat")))
+
+
+def test_project_many_shards_and_gathers(golden):
+    """Pair-level sharding entry point (one rank here: every item, ordered by id; the N > 1 gather is covered by the gloo test)."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.projection import ProjectionArgs
+    g = golden("loop_tiny.npz")
+    G = _tiny_G()
+    t = torch.from_numpy(g["target"]).cuda()
+    targets = [t, (t * 0.9).contiguous(), (t * 0.8).contiguous()]
+    kw = dict(args=ProjectionArgs(step=6, n_mean_latent=300), seed=0, batch=3, noise_mode="const")
+    res = drivers.project_many(G, targets, **kw)
+    assert res["items"].tolist() == [0, 1, 2] and tuple(res["latents"].shape) == (3, 17, 32)
+    single = drivers.project_image(G, targets[1], None, None, **kw)
+    assert torch.equal(res["latents"][1].cpu(), single["w"][0]) and int(res["steps"][1]) == single["step"]
+    dyn = drivers.project_many(G, targets, dynamic=True, **kw)
+    assert torch.equal(dyn["latents"], res["latents"])
