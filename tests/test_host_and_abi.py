@@ -488,3 +488,22 @@ def test_legacy_tf_conversion_matches_the_reference_converter():
         else:
             assert np.array_equal(v, want[k]), k
     assert set(want) - set(got) == set() or all("num_batches" in k for k in set(want) - set(got))
+
+
+def test_bench_auto_batch_wastes_little():
+    """bench.py works in whole forwards: the automatic steps-per-forward must divide typical step counts (or nearly so)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    for steps in (200, 100, 50, 64, 1000, 5000, 97, 30):
+        b = mod.auto_batch(steps)
+        assert 12 <= b <= 32
+        waste = (-(-steps // b) * b - steps) / steps
+        assert waste <= 0.04, (steps, b, waste)
+    assert mod.auto_batch(200) == 25
