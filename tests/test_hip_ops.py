@@ -218,3 +218,31 @@ def test_tconv_vs_torch(n, cin, cout, res):
     out = cv.tconv3x3s2_forward(x.cuda(), pc, in_scale=s.cuda(), out_scale=d.cuda())
     assert tuple(out.shape) == tuple(ref.shape)
     assert rel_err(out, ref) < 2e-5
+
+
+def test_integration_md_plugin_stub_runs_as_written():
+    """The ctypes binding that INTEGRATION.md tells a maintainer to add to the reference (torch_utils/ops/_mgf_plugin.py) is
+    executed verbatim (only the library path is filled in) and checked against the oracle: the drop-in claim, tested."""
+    import os
+    import re
+    from morphganformer_amd import _lib
+    from oracle.ops_ref import bias_act_ref, upfirdn2d_ref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# torch_utils/ops/_mgf_plugin\.py.*?)```", text, re.S).group(1)
+    code = code.replace("/path/to/morphganformer_amd/libmgf_hip.so", _lib.LIB_PATH)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md:_mgf_plugin.py", "exec"), ns)
+    torch.manual_seed(3)
+    x = torch.randn(2, 5, 9, 7)
+    b = torch.randn(5)
+    empty = torch.empty(0)
+    y = ns["bias_act_plugin"].bias_act(x.cuda(), b.cuda(), empty.cuda(), empty.cuda(), empty.cuda(), 0, 1, 3, 0.2, 2 ** 0.5, -1.0)
+    want = bias_act_ref(x, b, dim=1, act="lrelu", alpha=0.2, gain=2 ** 0.5, clamp=None)
+    assert float((y.cpu() - want).abs().max()) < 5e-6
+    f = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    f2 = (f[:, None] * f[None, :]) / 64
+    xin = torch.randn(1, 3, 10, 12)
+    y2 = ns["upfirdn2d_plugin"].upfirdn2d(xin.cuda(), f2.cuda(), 2, 2, 1, 1, 2, 1, 2, 1, False, 4.0)
+    want2 = upfirdn2d_ref(xin, f2, up=2, down=1, padding=[2, 1, 2, 1], flip_filter=False, gain=4.0)
+    assert tuple(y2.shape) == tuple(want2.shape) and float((y2.cpu() - want2).abs().max()) < 5e-6
