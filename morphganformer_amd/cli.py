@@ -52,6 +52,8 @@ def build_parser():
     p.add_argument("--truncation_psi", type=float, default=0.7)
     p.add_argument("--noise_regularize", type=float, default=1e5)       # accepted and unused, like the reference
     p.add_argument("--w_plus", action="store_true")                     # accepted and unused, like the reference
+    p.add_argument("--percept_weight", type=float, default=1.0, help="coefficient of the LPIPS term (0.5 with --beta 0.5 = 1024_example_percept_MSE.py)")
+    p.add_argument("--net", type=str, default="squeeze", choices=["squeeze", "vgg", "alex"], help="LPIPS backbone")
     p.add_argument("--no-lpips", action="store_true", help="MSE(+Wing) only, the 1024_example_MSE.py objective")
     p.add_argument("--batch", type=int, default=8, help="loop steps evaluated per generator forward (same result)")
     p.add_argument("--seed", type=int, default=None)
@@ -91,7 +93,7 @@ def main(argv=None):
     from .lpips import PerceptualLoss
     args = ProjectionArgs(step=a.step, lamda=a.lamda, beta=a.beta, lr=a.lr, lr_rampup=a.lr_rampup, lr_rampdown=a.lr_rampdown,
                           noise=a.noise, noise_ramp=a.noise_ramp, truncation_psi=a.truncation_psi, n_mean_latent=a.n_mean_latent,
-                          ratio=a.ratio)
+                          ratio=a.ratio, percept_weight=a.percept_weight)
     target = drivers.image_transform(a.image, size=a.size, device=G.device)
     lm_t = lm_s = None
     if a.landmarks:
@@ -99,7 +101,7 @@ def main(argv=None):
         lm_t, lm_s = lm["target"], lm["steps"]
         if lm_s.shape[0] < a.step:
             raise SystemExit(f"--landmarks holds {lm_s.shape[0]} steps, --step is {a.step}")
-    percept = None if a.no_lpips else PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=G.device)
+    percept = None if a.no_lpips else PerceptualLoss(model="net-lin", net=a.net, use_gpu=True, device=G.device)
     stem = os.path.splitext(os.path.basename(a.image))[0]
     res = drivers.project_image(G, target, lm_t, lm_s, args=args, percept=percept, batch=a.batch, seed=a.seed,
                                 out_prefix=os.path.join(a.path_to_gen, stem))

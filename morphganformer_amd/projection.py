@@ -47,6 +47,7 @@ class ProjectionArgs:
     truncation_psi: float = 0.7
     n_mean_latent: int = 10000
     ratio: float = 1.0
+    percept_weight: float = 1.0     # coefficient of the LPIPS term: 1 in the Wing/LPIPS/MSE drivers, 0.5 in 1024_example_percept_MSE.py:147
     min_loss_init: float = 100.0
 
 
@@ -154,6 +155,8 @@ class ProjectionEngine:
         img = self.G(self.latent_n, a.truncation_psi, noise_mode=self.noise_mode)[0]      # psi lands in `c`
         if self.percept is not None:
             self.percept.distance_into(self.p_loss, img)
+            if a.percept_weight != 1.0:
+                self.p_loss.mul_(float(a.percept_weight))
         if self.biometric is not None:      # rides in the p_loss slot: p_loss = LPIPS + gamma * embedding MSE
             self.biometric.distance_into(self.p_loss, img, scale=self.gamma, accumulate=self.percept is not None)
         if self.use_mse:

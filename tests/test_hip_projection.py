@@ -242,3 +242,28 @@ def test_full_size_loop_properties():
     # the selected latent really is eps[bstep]*sigma[bstep] + mean
     expect = eng.latent_in + eng.eps[bstep] * eng.sigma[bstep]
     assert torch.equal(lat.cuda(), expect)
+
+
+def test_percept_mse_objective_variant(golden):
+    """1024_example_percept_MSE.py:147: total = 0.5 * LPIPS(vgg) + 0.5 * MSE -- coefficient on the perceptual term and the VGG backbone
+    inside the loop; every recorded loss equals the separately evaluated terms."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.lpips import PerceptualLoss
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    g = golden("loop_tiny.npz")
+    G = Generator(make_state_dict(TINY, seed=0), TINY, "cuda", max_batch=1)
+    steps = 4
+    tgt = torch.from_numpy(g["target"]).cuda()
+    P = PerceptualLoss(model="net-lin", net="vgg", use_gpu=True)
+    eng = ProjectionEngine(G, tgt, torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]),
+                           ProjectionArgs(step=steps, percept_weight=0.5, beta=0.5), percept=P, use_mse=True,
+                           eps=torch.from_numpy(g["eps"][:steps]).cuda(), noise_mode="const", batch=2)
+    lat, bstep, bloss, losses = eng.run().result()
+    for i in range(steps):
+        sigma = np.float32(float(g["latent_std"]) * 0.05 * max(0, 1 - (i / steps) / 0.75) ** 2)
+        z = torch.from_numpy(g["latent_mean"])[None] + torch.from_numpy(g["eps"][i]) * float(sigma)
+        img = G(z.cuda(), None, noise_mode="const")[0]
+        want = 0.5 * float(P(img, tgt)) + 0.5 * float(torch.nn.functional.mse_loss(img, tgt))
+        assert abs(losses[i] - want) < 1e-5 * abs(want), (i, losses[i], want)
+    assert bstep == int(np.argmin(losses))
