@@ -224,6 +224,9 @@ int mgf_mse_f32(float* out, const float* a, const float* b, int32_t n, int64_t n
                 int32_t accumulate, float* scratch, mgf_stream_t stream);
 int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int32_t n, int64_t numel, double omega, double epsilon,
                       const int32_t* pred_step, int32_t max_row, mgf_stream_t stream);
+/* AdaptiveWingLoss(omega=14, theta=0.5, epsilon=1, alpha=2.1) of adaptive_wing_loss.py:12-39, same row addressing as the wing loss */
+int mgf_adaptive_wing_loss_f64(double* out, const double* pred, const double* target, int32_t n, int64_t numel, double omega, double theta,
+                               double epsilon, double alpha, const int32_t* pred_step, int32_t max_row, mgf_stream_t stream);
 int mgf_lpips_unit_f32(float* out, const float* f, int32_t n, int32_t c, int64_t hw, mgf_stream_t stream);
 int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c, int64_t hw,
                         int64_t f1_batch_stride, int32_t accumulate, float* scratch, mgf_stream_t stream);

@@ -69,6 +69,7 @@ _SIGS = {
     "mgf_reduce_scratch_floats": (i64, []),
     "mgf_mse_f32": (C.c_int, [vp, vp, vp, i32, i64, i64, f32, i32, vp, vp]),
     "mgf_wing_loss_f64": (C.c_int, [vp, vp, vp, i32, i64, f64, f64, vp, i32, vp]),
+    "mgf_adaptive_wing_loss_f64": (C.c_int, [vp, vp, vp, i32, i64, f64, f64, f64, f64, vp, i32, vp]),
     "mgf_lpips_unit_f32": (C.c_int, [vp, vp, i32, i32, i64, vp]),
     "mgf_lpips_layer_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i64, i64, i32, vp, vp]),
     "mgf_lpips_stem_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),

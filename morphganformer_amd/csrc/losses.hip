@@ -148,6 +148,33 @@ __global__ __launch_bounds__(256) void wing_kernel(double* out, const double* pr
     if (threadIdx.x == 0) out[blockIdx.x] = (sm[0] + sm[1] + sm[2] + sm[3]) / (double)numel;
 }
 
+// AdaptiveWingLoss (adaptive_wing_loss.py:20-39): the exponent alpha - y depends on the TARGET value y; mean over all elements
+__global__ __launch_bounds__(256) void awing_kernel(double* out, const double* pred, const double* target, int64_t numel, double omega,
+                                                    double theta, double epsilon, double alpha, const int32_t* pred_step, int max_row) {
+    __shared__ double sm[4];
+    int row = (pred_step ? *pred_step : 0) + (int)blockIdx.x;
+    if (max_row >= 0 && row > max_row) row = max_row;
+    pred += (int64_t)row * numel;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < numel; i += 256) {
+        const double y = target[i];
+        const double dlt = fabs(y - pred[i]);
+        const double pw = alpha - y;
+        if (dlt < theta) {
+            acc += omega * log(1.0 + pow(dlt / omega, pw));
+        } else {
+            const double tp = pow(theta / epsilon, pw);
+            const double A = omega * (1.0 / (1.0 + tp)) * pw * pow(theta / epsilon, pw - 1.0) * (1.0 / epsilon);
+            const double C = theta * A - omega * log(1.0 + tp);
+            acc += A * dlt - C;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (sm[0] + sm[1] + sm[2] + sm[3]) / (double)numel;
+}
+
 // K x K window, stride 2, windows clipped at the bottom/right edge (ceil_mode partial windows)
 template <int K>
 __global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, int nc, int in_h, int in_w, int out_h, int out_w) {
@@ -273,6 +300,16 @@ extern "C" int mgf_wing_loss_f64(double* out, const double* pred, const double* 
     MGF_REQUIRE(out && pred && target && numel >= 1 && n >= 1, MGF_EINVAL, "wing_loss: bad arguments");
     hipLaunchKernelGGL(wing_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, out, pred, target, numel, omega, epsilon, pred_step, max_row);
     MGF_CHECK_LAUNCH("wing_loss");
+    return MGF_OK;
+}
+
+extern "C" int mgf_adaptive_wing_loss_f64(double* out, const double* pred, const double* target, int32_t n, int64_t numel, double omega,
+                                          double theta, double epsilon, double alpha, const int32_t* pred_step, int32_t max_row,
+                                          mgf_stream_t stream) {
+    MGF_REQUIRE(out && pred && target && numel >= 1 && n >= 1, MGF_EINVAL, "adaptive_wing_loss: bad arguments");
+    hipLaunchKernelGGL(awing_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, out, pred, target, numel, omega, theta, epsilon, alpha,
+                       pred_step, max_row);
+    MGF_CHECK_LAUNCH("adaptive_wing_loss");
     return MGF_OK;
 }
 

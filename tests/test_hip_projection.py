@@ -25,6 +25,15 @@ def test_wing_and_mse_kats(golden):
     assert abs(float(v) - float(g["wing_small"])) < 1e-12
     v = w(torch.from_numpy(g["wing_rand_pred"]).cuda(), torch.from_numpy(g["wing_rand_target"]).cuda())
     assert abs(float(v) - float(g["wing_rand"])) < 1e-12 * abs(float(g["wing_rand"])) + 1e-12
+    # AdaptiveWingLoss: the reference's own self-test value + random heat maps vs the oracle
+    from morphganformer_amd.wing_loss import AdaptiveWingLoss
+    from oracle.loss_ref import adaptive_wing_loss_ref
+    aw = AdaptiveWingLoss()
+    v = aw(torch.zeros(68, 2).cuda(), torch.ones(68, 2).cuda())
+    assert abs(float(v) - float(g["awing_ones_zeros"])) < 3e-6                       # float32 KAT
+    torch.manual_seed(1)
+    hp, ht = torch.rand(2, 5, 16, 16, dtype=torch.float64), torch.rand(2, 5, 16, 16, dtype=torch.float64)
+    assert abs(float(aw(hp.cuda(), ht.cuda())) - float(adaptive_wing_loss_ref(hp, ht))) < 1e-12
     torch.manual_seed(0)
     a, b = torch.randn(1, 3, 129, 67), torch.randn(1, 3, 129, 67)
     out = torch.zeros(1).cuda()
