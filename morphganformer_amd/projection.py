@@ -77,11 +77,14 @@ class ProjectionEngine:
 
     def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True,
                  lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, batch=1,
-                 landmark_fn=None, biometric=None, gamma=1.0):
+                 landmark_fn=None, biometric=None, gamma=1.0, wing_kind="wing"):
         """batch = number of consecutive loop steps evaluated per generator forward.  In literal mode the steps do not depend
         on each other (latent_in never changes), so evaluating `batch` candidates at once and examining them in step order
         gives exactly the sequential loop's result while the small 4x4..64x64 layers, the mapping network and the LPIPS tail
         get `batch` times more parallel work per launch.
+
+        wing_kind: "wing" (WingLoss(10, 2), the default drivers) or "awing" (AdaptiveWingLoss(14, 0.5, 1, 2.1) on the same landmark
+        tensors, 1024_example_wing_loss_adaptive.py:176 with lamda = 1e-5).
 
         biometric: optional `iresnet.BiometricLoss`; adds gamma * MSE(embed(img), embed(target)) to the objective (the
         FaceNet term of 1024_example_FaceNet_percept.py:147-158 on the vendored IResNet embedder).
@@ -115,6 +118,8 @@ class ProjectionEngine:
             eps = torch.randn(a.step, 1, k, D, device=dev, generator=gen)
         self.eps = eps.to(dev).contiguous().float()
         assert self.eps.shape[0] >= a.step
+        assert wing_kind in ("wing", "awing")
+        self.wing_kind = wing_kind
         self.landmark_fn = landmark_fn
         if landmark_fn is not None:
             assert lm_target is not None, "landmark_fn needs the target image's landmarks (lm_target)"
@@ -165,10 +170,14 @@ class ProjectionEngine:
                                      self.scratch.data_ptr(), st), "mse")
         if self.landmark_fn is not None:
             self._detect_landmarks(img)
-        if self.use_wing:
+        if self.use_wing and self.wing_kind == "wing":
             _lib.check(L.mgf_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), B,
                                            self.lm_target.numel(), 10.0, 2.0, self.step_ctr.data_ptr(), self.lm_steps.shape[0] - 1, st),
                        "wing_loss")
+        elif self.use_wing:
+            _lib.check(L.mgf_adaptive_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), B,
+                                                    self.lm_target.numel(), 14.0, 0.5, 1.0, 2.1, self.step_ctr.data_ptr(),
+                                                    self.lm_steps.shape[0] - 1, st), "adaptive_wing_loss")
         _lib.check(L.mgf_select_best(self.min_loss.data_ptr(), self.best_latent.data_ptr(), self.best_step.data_ptr(),
                                      self.losses.data_ptr(), self.latent_n.data_ptr(), self.numel,
                                      _lib.ptr(self.p_loss if (self.percept is not None or self.biometric is not None) else None),

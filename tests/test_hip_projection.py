@@ -276,3 +276,26 @@ def test_percept_mse_objective_variant(golden):
         want = 0.5 * float(P(img, tgt)) + 0.5 * float(torch.nn.functional.mse_loss(img, tgt))
         assert abs(losses[i] - want) < 1e-5 * abs(want), (i, losses[i], want)
     assert bstep == int(np.argmin(losses))
+
+
+def test_adaptive_wing_objective_variant(golden):
+    """1024_example_wing_loss_adaptive.py: best-of selection on lamda * AdaptiveWing(landmarks) alone (normalised landmark
+    coordinates so that the exponent alpha - y stays in the loss's working range)."""
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    from oracle.loss_ref import adaptive_wing_loss_ref
+    g = golden("loop_tiny.npz")
+    steps = 9
+    lm_t, lm_s = g["lm_target"] / 64.0, g["lm_steps"][:steps] / 64.0
+    eng = ProjectionEngine(_tiny_gen(), torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["latent_mean"]).cuda(),
+                           float(g["latent_std"]), ProjectionArgs(step=steps, lamda=1e-5, min_loss_init=1e5), percept=None, use_mse=False,
+                           lm_target=lm_t, lm_steps=lm_s, eps=torch.from_numpy(g["eps"][:steps]).cuda(), noise_mode="const", batch=4,
+                           wing_kind="awing")
+    lat, bstep, bloss, losses = eng.run().result()
+    want = np.array([1e-5 * float(adaptive_wing_loss_ref(torch.from_numpy(lm_s[i]), torch.from_numpy(lm_t))) for i in range(steps)])
+    assert np.allclose(losses, want, rtol=1e-12) and bstep == int(np.argmin(want))
+
+
+def _tiny_gen():
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    return Generator(make_state_dict(TINY, seed=0), TINY, "cuda", max_batch=1)
