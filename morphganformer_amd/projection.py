@@ -77,7 +77,7 @@ class ProjectionEngine:
 
     def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True,
                  lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, batch=1,
-                 landmark_fn=None, biometric=None, gamma=1.0, wing_kind="wing"):
+                 landmark_fn=None, biometric=None, gamma=1.0, wing_kind="wing", landmark_model=None):
         """batch = number of consecutive loop steps evaluated per generator forward.  In literal mode the steps do not depend
         on each other (latent_in never changes), so evaluating `batch` candidates at once and examining them in step order
         gives exactly the sequential loop's result while the small 4x4..64x64 layers, the mapping network and the LPIPS tail
@@ -88,6 +88,10 @@ class ProjectionEngine:
 
         biometric: optional `iresnet.BiometricLoss`; adds gamma * MSE(embed(img), embed(target)) to the objective (the
         FaceNet term of 1024_example_FaceNet_percept.py:147-158 on the vendored IResNet embedder).
+
+        landmark_model: optional DEVICE callable `m(img [B,3,H,W]) -> (landmarks [B,68,2] float64, valid [B] int32)` -- the GPU
+        landmark-regressor interface of SURVEY.md 8f row 3.  It runs inside the launch sequence (graph-capturable if the model
+        is), so the loop keeps its no-host-round-trip property; results are scattered into the landmark table on the device.
 
         landmark_fn: optional host callback `f(img_hwc float32 numpy [H,W,3]) -> [68,2] array or None` standing where the
         drivers call dlib on every generated image (:159-170; `drivers.reference_gray_u8` reproduces their cv2 normalise +
@@ -121,6 +125,12 @@ class ProjectionEngine:
         assert wing_kind in ("wing", "awing")
         self.wing_kind = wing_kind
         self.landmark_fn = landmark_fn
+        self.landmark_model = landmark_model
+        if landmark_model is not None:
+            assert lm_target is not None and landmark_fn is None, "landmark_model needs lm_target and excludes landmark_fn"
+            # + batch spare rows: the candidates of a ragged last batch that lie past the final step land there, not on real rows
+            lm_steps = np.zeros((a.step + self.batch,) + tuple(np.shape(lm_target)), np.float64)
+            lm_valid = np.zeros(a.step + self.batch, np.int32)
         if landmark_fn is not None:
             assert lm_target is not None, "landmark_fn needs the target image's landmarks (lm_target)"
             lm_steps = np.zeros((a.step,) + tuple(np.shape(lm_target)), np.float64)
@@ -143,6 +153,7 @@ class ProjectionEngine:
         self.mse_loss = torch.zeros(B, dtype=torch.float32, device=dev)
         self.w_loss = torch.zeros(B, dtype=torch.float64, device=dev)
         self.scratch = torch.empty(B * int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=dev)
+        self._arange = torch.arange(B, dtype=torch.int64, device=dev)
         if self.percept is not None:
             self.percept.set_target(self.target)
         self.biometric, self.gamma = biometric, float(gamma)
@@ -170,6 +181,11 @@ class ProjectionEngine:
                                      self.scratch.data_ptr(), st), "mse")
         if self.landmark_fn is not None:
             self._detect_landmarks(img)
+        if self.landmark_model is not None:
+            lm, ok = self.landmark_model(img)
+            idx = self.step_ctr.long() + self._arange                                    # rows of this batch's steps, on the device
+            self.lm_steps.index_copy_(0, idx, lm.to(torch.float64).reshape(B, *self.lm_target.shape))
+            self.valid.index_copy_(0, idx, ok.to(torch.int32).reshape(B))
         if self.use_wing and self.wing_kind == "wing":
             _lib.check(L.mgf_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), B,
                                            self.lm_target.numel(), 10.0, 2.0, self.step_ctr.data_ptr(), self.lm_steps.shape[0] - 1, st),

@@ -189,3 +189,29 @@ def test_project_many_shards_and_gathers(golden):
     assert torch.equal(res["latents"][1].cpu(), single["w"][0]) and int(res["steps"][1]) == single["step"]
     dyn = drivers.project_many(G, targets, dynamic=True, **kw)
     assert torch.equal(dyn["latents"], res["latents"])
+
+
+def test_device_landmark_model_in_the_graph(golden):
+    """GPU landmark-regressor interface: a device callable produces the landmarks of every candidate inside the captured launch
+    sequence; the run equals the one driven by the table it produced (batch 3 over 8 steps: ragged last batch)."""
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    g = golden("loop_tiny.npz")
+    steps = 8
+    base = torch.from_numpy(g["lm_target"]).cuda()
+
+    def model(img):                          # toy regressor: landmarks move with pooled image statistics; a "no face" rule
+        pooled = torch.nn.functional.adaptive_avg_pool2d(img[:, :1], (68, 2)).reshape(img.shape[0], 68, 2).double()
+        lm = base[None] + torch.round(60 * pooled)
+        ok = (img.mean(dim=(1, 2, 3)) > -10).to(torch.int32)
+        return lm, ok
+
+    def make(**kw):
+        return ProjectionEngine(_tiny_G(), torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["latent_mean"]).cuda(),
+                                float(g["latent_std"]), ProjectionArgs(step=steps), use_mse=True, lm_target=g["lm_target"],
+                                eps=torch.from_numpy(g["eps"][:steps]).cuda(), noise_mode="const", **kw)
+    e1 = make(landmark_model=model, batch=3, use_graph=True)
+    lat1, st1, loss1, hist1 = e1.run().result()
+    assert e1.graph is not None and e1.valid.cpu().tolist()[:steps] == [1] * steps
+    lat2, st2, loss2, hist2 = make(lm_steps=e1.lm_steps.cpu().numpy()[:steps], batch=1).run().result()
+    assert st1 == st2 and torch.equal(lat1, lat2) and np.allclose(hist1, hist2, rtol=1e-6)
+    assert float(e1.lm_steps[:steps].std()) > 0
