@@ -135,6 +135,13 @@ typedef struct mgf_conv_prof_rec {
 int mgf_conv_profile_begin(void);
 int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs);
 
+/* Last row (oy = 2h) and last column (ox = 2w) of the stride-2 transposed 3x3 conv output t [n, cout, 2h+1, pitch] from the same
+ * operands as the 4-group mode of mgf_conv_taps_f32 (x [n,cin,h,w], packed taps, in_scale [n,cin] | NULL, out_scale | NULL).
+ * With it the MFMA launch can tile exactly the h x w grid of 2x2 output quads (desc.tile_h = h, tile_w = w) instead of (h+1) x (w+1). */
+int mgf_tconv3x3s2_border_f32(float* t, const float* x, const float* wp, const float* in_scale, const float* out_scale, int32_t n,
+                              int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t cout_pad, int64_t t_pitch, int64_t t_plane,
+                              int64_t t_batch, int64_t out_scale_stride, mgf_stream_t stream);
+
 /* Repack [cout, cin, kh, kw] float32 weights (times `gain`) into the [tap][cin][cout_pad] image read by
  * mgf_conv_taps_f32; `flip` reverses kh,kw (true convolution).  Taps are emitted in (kh, kw) row-major order.
  * Also emits wsq[cout, cin] = sum_k (w*gain)^2 when wsq != NULL (demodulation table). Device pointers. */

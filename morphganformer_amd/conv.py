@@ -6,6 +6,7 @@ the synthesis engine (engine.py), which packs weights once per checkpoint instea
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -157,6 +158,9 @@ TCONV_TAPS = [(-1 if kh == 2 else 0, -1 if kw == 2 else 0) for kh in range(3) fo
 TCONV_GROUPS = [(2 if kh == 1 else 0) + (1 if kw == 1 else 0) for kh in range(3) for kw in range(3)]
 
 
+SPLIT_TCONV_BORDER = os.environ.get("MGF_TCONV_BORDER", "1") != "0"       # tuning hook: 0 = one launch over the (h+1) x (w+1) grid
+
+
 def tconv_pitch(w: int) -> int:
     return round_up(2 * w + 1, 4)
 
@@ -172,12 +176,21 @@ def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=Non
     if out is None:
         out = torch.empty([n, pc.cout, oh, pitch], dtype=torch.float32, device=x.device)
     assert out.is_contiguous() and tuple(out.shape) == (n, pc.cout, oh, pitch)
-    d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, h + 1, w + 1, 1, 2, TCONV_TAPS, TCONV_GROUPS, [0, 0, 1, 1], [0, 1, 0, 1],
-              oh, ow, pitch, oh * pitch, pc.cout * oh * pitch, 0,
-              0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
+    # The MFMA launch tiles the h x w grid of 2x2 output quads exactly (rows/columns 0 .. 2h-1 / 2w-1); the last row and column
+    # -- 4*in + 1 positions with at most two taps each -- come from a small border kernel.  Tiling (h+1) x (w+1) instead would
+    # spend 7-20 % of the MFMA work on padding (33-wide parity grids over 32-wide tiles).  Maps below 32 px keep the single launch.
+    split = SPLIT_TCONV_BORDER and min(h, w) >= 32
+    os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
+    d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, h if split else h + 1, w if split else w + 1, 1, 2, TCONV_TAPS, TCONV_GROUPS,
+              [0, 0, 1, 1], [0, 1, 0, 1], oh, ow, pitch, oh * pitch, pc.cout * oh * pitch, 0, os_stride)
     rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                       C.byref(d), None, _lib.stream_ptr())
     _lib.check(rc, "conv_taps(tconv)")
+    if split:
+        rc = _lib.lib().mgf_tconv3x3s2_border_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                                  n, cin, h, w, pc.cout, pc.cout_pad, pitch, oh * pitch, pc.cout * oh * pitch, os_stride,
+                                                  _lib.stream_ptr())
+        _lib.check(rc, "tconv3x3s2_border")
     return out[:, :, :, :ow]
 
 

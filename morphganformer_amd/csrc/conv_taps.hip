@@ -783,6 +783,107 @@ extern "C" int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs) {
     return n;
 }
 
+// Last row and last column of the stride-2 transposed 3x3 conv output t[2h+1][2w+1] (t[2i+kh][2j+kw] += w[kh][kw] x[i][j]): the
+// 4*in + 1 positions that do not belong to the in x in grid of 2x2 output quads the MFMA kernel tiles exactly.  The last column only
+// sees the taps kw = 2 (input column w-1), the last row only kh = 2 (input row h-1), so each part is a small GEMM
+//     out[pos][co] = sum_ci sum_{k<3} W[tap_k][ci][co] * X_k[ci][pos]          (X_k = the input sample tap k reads, or 0)
+// done on the VALU: workgroup = 16 positions x 64 output channels, K walked in chunks of 16 input channels staged in LDS (weights
+// coalesced along cout, the style modulation folded into the staged activations).
+constexpr int TB_POS = 16, TB_CK = 32;
+__global__ __launch_bounds__(256) void tconv_border_kernel(float* t, const float* x, const float* wp, const float* in_scale,
+                                                           const float* out_scale, int cin, int h, int w, int cout, int cout_pad,
+                                                           int64_t pitch, int64_t plane, int64_t batch, int64_t os_stride, int col_groups) {
+    __shared__ float Ws[3][TB_CK][64];
+    __shared__ float Xs[TB_CK][3][TB_POS];
+    const int tid = threadIdx.x, n = blockIdx.z, co0 = blockIdx.y * 64;
+    const bool col = (int)blockIdx.x < col_groups;                      // column part (ox = 2w) or row part (oy = 2h)
+    const int p0 = (col ? blockIdx.x : blockIdx.x - col_groups) * TB_POS;
+    const int npos = col ? 2 * h + 1 : 2 * w;
+    const int tap0 = col ? 2 : 6, tapstep = col ? 3 : 1;               // packed tap index of k: (kh = k, kw = 2) or (kh = 2, kw = k)
+    const float* xn = x + (int64_t)n * cin * h * w;
+    const int64_t hw = (int64_t)h * w;
+    // staging role of this thread for X: (ci, k, pos) = 768 entries / 256 threads = 3 each; the source offset (or -1) is fixed
+    int xsrc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int e = tid + 256 * r, pos = e % TB_POS, k = (e / TB_POS) % 3;
+        const int q = p0 + pos;                                         // output coordinate along the part
+        int src = -1;
+        if (q < npos) {
+            const int i2 = q - k;                                       // q = 2*i + k
+            const int lim = col ? h : w;
+            if (i2 >= 0 && !(i2 & 1) && (i2 >> 1) < lim) src = col ? (i2 >> 1) * w + (w - 1) : (h - 1) * w + (i2 >> 1);
+        }
+        xsrc[r] = src;
+    }
+    const int cl = tid & 63, pg = tid >> 6;                             // output channel lane, group of 4 positions
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int WR = 3 * TB_CK * 64 / 256, XR = 3 * TB_CK * TB_POS / 256;
+    float wreg[WR], xreg[XR];
+    auto request = [&](int c0) {                                       // global -> registers for one K chunk (loads only)
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+            const int e = tid + 256 * r, co = e & 63, ci = (e >> 6) % TB_CK, k = e / (64 * TB_CK);
+            const int cg = c0 + ci < cin ? c0 + ci : cin - 1, cc = co0 + co < cout_pad ? co0 + co : cout_pad - 1;
+            wreg[r] = wp[((int64_t)(tap0 + k * tapstep) * cin + cg) * cout_pad + cc];
+        }
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            const int e = tid + 256 * r, ci = e / (3 * TB_POS);
+            const int cg = c0 + ci < cin ? c0 + ci : cin - 1;
+            xreg[r] = xn[cg * hw + (xsrc[r % 3] >= 0 ? xsrc[r % 3] : 0)] * (in_scale ? in_scale[(int64_t)n * cin + cg] : 1.0f);
+        }
+    };
+    request(0);
+    for (int c0 = 0; c0 < cin; c0 += TB_CK) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+            const int e = tid + 256 * r, co = e & 63, ci = (e >> 6) % TB_CK, k = e / (64 * TB_CK);
+            Ws[k][ci][co] = c0 + ci < cin ? wreg[r] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            const int e = tid + 256 * r, pos = e % TB_POS, k = (e / TB_POS) % 3, ci = e / (3 * TB_POS);
+            Xs[ci][k][pos] = (c0 + ci < cin && xsrc[r % 3] >= 0) ? xreg[r] : 0.f;
+        }
+        __syncthreads();
+        if (c0 + TB_CK < cin) request(c0 + TB_CK);                      // next chunk's loads fly during the FMAs below
+#pragma unroll 8
+        for (int ci = 0; ci < TB_CK; ++ci) {
+            const float w0 = Ws[0][ci][cl], w1 = Ws[1][ci][cl], w2 = Ws[2][ci][cl];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pos = pg * 4 + j;
+                acc[j] += w0 * Xs[ci][0][pos] + w1 * Xs[ci][1][pos] + w2 * Xs[ci][2][pos];
+            }
+        }
+    }
+    const int co = co0 + cl;
+    if (co >= cout) return;
+    const float os = out_scale ? out_scale[(int64_t)n * os_stride + co] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = p0 + pg * 4 + j;
+        if (q >= npos) continue;
+        const int oy = col ? q : 2 * h, ox = col ? 2 * w : q;
+        t[(int64_t)n * batch + (int64_t)co * plane + (int64_t)oy * pitch + ox] = acc[j] * os;
+    }
+}
+
+extern "C" int mgf_tconv3x3s2_border_f32(float* t, const float* x, const float* wp, const float* in_scale, const float* out_scale,
+                                         int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t cout_pad, int64_t t_pitch,
+                                         int64_t t_plane, int64_t t_batch, int64_t out_scale_stride, mgf_stream_t stream) {
+    MGF_REQUIRE(t && x && wp && n >= 1 && n <= 65535 && cin >= 1 && h >= 1 && w >= 1 && cout >= 1 && cout_pad >= cout, MGF_EINVAL,
+                "tconv3x3s2_border: bad arguments");
+    MGF_REQUIRE(t_pitch >= 2 * w + 1 && t_plane >= (int64_t)(2 * h + 1) * t_pitch, MGF_EINVAL, "tconv3x3s2_border: output pitch/plane too small");
+    const int col_groups = (int)mgf_cdiv(2 * h + 1, TB_POS), row_groups = (int)mgf_cdiv(2 * w, TB_POS);
+    hipLaunchKernelGGL(tconv_border_kernel, dim3(col_groups + row_groups, (unsigned)mgf_cdiv(cout, 64), n), dim3(256), 0, (hipStream_t)stream,
+                       t, x, wp, in_scale, out_scale, cin, h, w, cout, cout_pad, t_pitch, t_plane, t_batch, out_scale_stride, col_groups);
+    MGF_CHECK_LAUNCH("tconv3x3s2_border");
+    return MGF_OK;
+}
+
 extern "C" int mgf_pack_conv_weights(float* wp, float* wsq, const float* w, int32_t cout, int32_t cin, int32_t kh, int32_t kw,
                                      int32_t cout_pad, float gain, int32_t flip, mgf_stream_t stream) {
     MGF_REQUIRE(wp && w, MGF_EINVAL, "pack_conv_weights: null pointer");
