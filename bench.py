@@ -242,7 +242,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    log(f"timed {a.steps} steps in {elapsed:.3f} s")
+    log(f"timed {a.steps} steps in {elapsed:.3f} s ({a.batch} steps per forward, {torch.cuda.max_memory_allocated(device) / 2 ** 30:.1f} GiB of HBM in use)")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
