@@ -270,7 +270,15 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (t + 1 < NT) fetch(t + 1, (t + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);                // keep the next tap's ds_reads ahead of this tap's MFMAs
+                // interleave: one LDS read of the next tap's operands after each MFMA of this tap (instead of all reads first), so a
+                // wave's MFMA stream has no read-only gaps for the co-resident wave to fill (+1 % on the large layers)
+                if (t + 1 < NT) {
+#pragma unroll
+                    for (int i = 0; i < (CK / 2) * (WM + WN); ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
+                    }
+                }
                 const int q = (MODE == 1 && NG == 4) ? tconv_group(t) : 0;
 #pragma unroll
                 for (int kk = 0; kk < CK / 2; ++kk)
