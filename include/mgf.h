@@ -23,6 +23,10 @@ typedef void* mgf_stream_t; /* hipStream_t */
 
 enum { MGF_OK = 0, MGF_EINVAL = -1, MGF_EUNSUPPORTED = -2, MGF_ELAUNCH = -3, MGF_ETOOBIG = -4 };
 enum { MGF_F32 = 0, MGF_F64 = 1, MGF_F16 = 2 };
+/* OR-ed into mgf_upfirdn2d's `flip` argument by a caller that KNOWS the filter is an outer product fy (x) fx (every filter
+ * upfirdn2d.setup_filter builds from a 1-D tap list is): lets the 4x4 blur take its separable kernel.  Without the hint the
+ * general kernel runs; a wrong hint gives wrong results (the filter lives in device memory and is not inspected). */
+enum { MGF_FILTER_SEPARABLE = 2 };
 /* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:15-25) */
 enum { MGF_ACT_LINEAR = 1, MGF_ACT_RELU = 2, MGF_ACT_LRELU = 3, MGF_ACT_TANH = 4, MGF_ACT_SIGMOID = 5,
        MGF_ACT_ELU = 6, MGF_ACT_SELU = 7, MGF_ACT_SOFTPLUS = 8, MGF_ACT_SWISH = 9 };

@@ -194,8 +194,9 @@ def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=Non
     return out[:, :, :, :ow]
 
 
-def upfirdn_into(y, x, f2d, up=1, pad=(0, 0, 0, 0), gain=1.0, flip=False, epilogue=None):
-    """mgf_upfirdn2d on arbitrary-stride 4-D views (x may be the padded-pitch transposed-conv workspace), down=1."""
+def upfirdn_into(y, x, f2d, up=1, pad=(0, 0, 0, 0), gain=1.0, flip=False, epilogue=None, separable=False):
+    """mgf_upfirdn2d on arbitrary-stride 4-D views (x may be the padded-pitch transposed-conv workspace), down=1.
+    separable=True asserts that f2d is an outer product (every setup_filter([taps]) result is) -> MGF_FILTER_SEPARABLE hint."""
     _lib.require_gpu(x, y, f2d)
     n, c, h, w = x.shape
     fh, fw = f2d.shape
@@ -206,7 +207,7 @@ def upfirdn_into(y, x, f2d, up=1, pad=(0, 0, 0, 0), gain=1.0, flip=False, epilog
     sx, sy = x.stride(), y.stride()
     rc = _lib.lib().mgf_upfirdn2d(y.data_ptr(), x.data_ptr(), f2d.data_ptr(), _lib.MGF_F32, n, c, h, w, sx[0], sx[1], sx[2],
                                   sx[3], oh, ow, sy[0], sy[1], sy[2], sy[3], fh, fw, up, up, 1, 1, px0, px1, py0, py1,
-                                  int(flip), float(gain), C.byref(epilogue) if epilogue is not None else None,
+                                  int(flip) | (2 if separable else 0), float(gain), C.byref(epilogue) if epilogue is not None else None,
                                   _lib.stream_ptr())
     _lib.check(rc, "upfirdn2d")
     return y

@@ -344,10 +344,10 @@ class Generator:
                     self.side.wait_stream(main)
                     with torch.cuda.stream(self.side):
                         cv.conv_forward(x, P.skips[res], out=B["skip_low"])
-                        cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0)
+                        cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0, separable=True)
                 else:
                     cv.conv_forward(x, P.skips[res], out=B["skip_low"])
-                    cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0)
+                    cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0, separable=True)
                 x0 = self._layer(layers[b + ".conv0"], x, B, "conv0", noise_mode, noises, residual=None)
                 if self.overlap_skip:
                     main.wait_stream(self.side)
@@ -402,7 +402,9 @@ class Generator:
         s, d = self._s(lp), self._d(lp)
         if lp.kind == "tconv":
             t = cv.tconv3x3s2_forward(x, lp.pc, in_scale=s, out_scale=d, out=B["t"])
-            y = cv.upfirdn_into(B[key], t, self.plan.fir, up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=None if has_att else ep)
+            # plan.fir is the outer product of the 1-D resample kernel (networks.py:1113 / upfirdn2d.setup_filter): separable
+            y = cv.upfirdn_into(B[key], t, self.plan.fir, up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=None if has_att else ep,
+                                separable=True)
         else:
             y = cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=s, out_scale=d, epilogue=None if has_att else ep, out=B[key])
         if self.taps is not None:

@@ -142,6 +142,17 @@ def test_upfirdn2d_wide_kernels_vs_oracle(n, c, res):
     out2 = torch.empty(n, c, res, res, device="cuda")
     cv.upfirdn_into(out2, td, f.cuda(), up=1, pad=(1, 1, 1, 1), gain=4.0)
     assert rel_err(out2, upfirdn2d_ref(t.contiguous(), f, padding=[1, 1, 1, 1], gain=4.0)) < 3e-6
+    # (c) the separable 4x4-patch form of the blur (MGF_FILTER_SEPARABLE hint), with and without epilogue, an asymmetric 1-D
+    #     tap list so that the fx / fy roles and the flip are really exercised
+    fa = setup_filter_ref([1, 2, 5, 3])
+    for flip in (False, True):
+        refa = upfirdn2d_ref(t.contiguous(), fa, padding=[1, 1, 1, 1], gain=4.0, flip_filter=flip)
+        o = torch.empty(n, c, res, res, device="cuda")
+        cv.upfirdn_into(o, td, fa.cuda(), up=1, pad=(1, 1, 1, 1), gain=4.0, flip=flip, separable=True)
+        assert rel_err(o, refa) < 3e-6
+        o2 = torch.empty(n, c, res, res, device="cuda")
+        cv.upfirdn_into(o2, td, fa.cuda(), up=1, pad=(1, 1, 1, 1), gain=4.0, flip=flip, separable=True, epilogue=ep)
+        assert rel_err(o2, bias_act_ref(refa + noise[:, None] * strength, bias, act="lrelu", gain=1.3) + resid) < 3e-6
     x = torch.randn(n, c, h, h)
     out3 = torch.empty(n, c, res, res, device="cuda")
     cv.upfirdn_into(out3, x.cuda(), f.cuda(), up=2, pad=(2, 1, 2, 1), gain=4.0)

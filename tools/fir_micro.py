@@ -20,7 +20,7 @@ for res in [int(a) for a in sys.argv[1:]] or [256, 512, 1024]:
     ns = torch.ones(1, device="cuda")
     bias = torch.randn(c, device="cuda")
     ep = _lib.make_epilogue(bias=bias, noise=noise, noise_strength=ns, noise_n=N, act="lrelu", alpha=0.2, gain=1.4)
-    us1 = bench(lambda: cv.upfirdn_into(y, t, f2d, up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=ep))
+    us1 = bench(lambda: cv.upfirdn_into(y, t, f2d, up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=ep, separable=True))
     lo = torch.randn(N, c, h, h, device="cuda")
     us2 = bench(lambda: cv.upfirdn_into(y, lo, f2d, up=2, pad=(2, 1, 2, 1), gain=4.0))
     src = torch.randn(N, c, res, res, device="cuda")
