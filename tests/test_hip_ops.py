@@ -257,3 +257,21 @@ def test_integration_md_plugin_stub_runs_as_written():
     y2 = ns["upfirdn2d_plugin"].upfirdn2d(xin.cuda(), f2.cuda(), 2, 2, 1, 1, 2, 1, 2, 1, False, 4.0)
     want2 = upfirdn2d_ref(xin, f2, up=2, down=1, padding=[2, 1, 2, 1], flip_filter=False, gain=4.0)
     assert tuple(y2.shape) == tuple(want2.shape) and float((y2.cpu() - want2).abs().max()) < 5e-6
+
+
+def test_blur_kernels_ragged_height():
+    """Non-square map: the blur kernels tile 64 columns wide, the last tile row is partial (80 = 64 + 16 output rows)."""
+    from morphganformer_amd import conv as cv
+    from oracle.ops_ref import setup_filter_ref, upfirdn2d_ref
+    torch.manual_seed(9)
+    f = setup_filter_ref([1, 3, 3, 1])
+    h, w = 40, 64
+    pitch = cv.tconv_pitch(w)
+    t_full = torch.randn(2, 3, 2 * h + 1, pitch)
+    t = t_full[:, :, :, :2 * w + 1]
+    ref = upfirdn2d_ref(t.contiguous(), f, padding=[1, 1, 1, 1], gain=4.0)
+    td = t_full.cuda()[:, :, :, :2 * w + 1]
+    for sep in (False, True):
+        out = torch.full((2, 3, 2 * h, 2 * w), 7.0, device="cuda")
+        cv.upfirdn_into(out, td, f.cuda(), up=1, pad=(1, 1, 1, 1), gain=4.0, separable=sep)
+        assert rel_err(out, ref) < 3e-6, sep
