@@ -66,12 +66,20 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
     const bool valid = i < hw;
     const int64_t pp = valid ? i : hw - 1;
     const float* a = f0 + (int64_t)nn * c * hw + pp;
-    float u[CPT];
+    float u[CPT], v[UNIT_OUT ? 1 : CPT];
     float na = 0.f;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int k = grp + j * G;
         u[j] = k < c ? a[(int64_t)k * hw] : 0.f;
+    }
+    if (!UNIT_OUT) {                    // the reference taps are requested in the same burst: one memory round trip per workgroup
+        const float* b = f1u + (int64_t)nn * f1_stride + pp;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int k = grp + j * G;
+            v[j] = k < c ? b[(int64_t)k * hw] : 0.f;
+        }
     }
 #pragma unroll
     for (int j = 0; j < CPT; ++j) na += u[j] * u[j];
@@ -90,7 +98,6 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
         }
         return;
     }
-    const float* b = f1u + (int64_t)nn * f1_stride + pp;
     float d = 0.f;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
             // separate statements: the product is rounded before the subtraction (build uses -ffp-contract=on) exactly like the
             // stored reference taps (u * ia above), so identical images give exactly zero
             const float ua = u[j] * ia;
-            const float e = ua - b[(int64_t)k * hw];
+            const float e = ua - v[UNIT_OUT ? 0 : j];
             d += lin[k] * e * e;
         }
     }
