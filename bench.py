@@ -10,6 +10,10 @@ In literal mode the loop's steps do not depend on each other (the latent never r
 engine evaluates `--batch` consecutive steps per generator forward and examines them in step order: the result (best step,
 best latent, loss history) is the sequential loop's, bit for bit (tests/test_hip_projection.py), and every step's full work --
 its own noise draws, forward, three losses, selection -- is inside the timed region.  `steps` counts loop steps, not launches.
+With `--pipeline 1` the losses + selection of one batch run on a second stream while the generator already synthesises the next
+batch (separate buffers; same results; 426 vs 413 iters/s): every timed replay still contains one full generator batch and one
+full loss batch, the one generator batch that is in flight ahead of the losses is produced during warm-up.  It is off by default
+because concurrent kernels stretch each other: per-kernel durations would stop describing a kernel on its own.
 Weights are seeded synthetic tensors (no checkpoint exists offline); inputs are resident in HBM before the timed region.
 N > 1: one independent target per rank (pair-level sharding, no data-path collective) -> "weak" scaling; the only
 collective is the result gather after the timed region.
@@ -60,6 +64,10 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--biometric", type=int, default=0, metavar="DEPTH",
                     help="add the IResNet-DEPTH embedding-MSE term (BASELINE config 3's full objective); 0 = the config-2 objective")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="1 = overlap the losses of batch i with the generator of batch i+1 on two streams (+3 %% iters/s; kernels of the two "
+                         "streams then stretch each other, so per-kernel durations -- and the roofline object -- no longer describe a kernel "
+                         "running alone); 0 = one stream (default: keeps roofline and rocprofv3 per-kernel figures clean)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank (exercises the N>1 code path)")
     return ap.parse_args()
 
@@ -74,7 +82,7 @@ def auto_batch(steps):
     return min(range(12, 33), key=cost)
 
 
-def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0):
+def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0, pipeline=False):
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.lpips import PerceptualLoss
     from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, latent_stats, synthetic_landmarks
@@ -97,7 +105,7 @@ def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0):
         bio = BiometricLoss(IResNetEmbedder(None, depth=biometric, n=batch, device=device, seed=0))
     eng = ProjectionEngine(G, target, latent_mean, latent_std, args, percept=percept, use_mse=True, lm_target=lm_t,
                            lm_steps=lm_s, noise_mode="random", seed=100 + rank, use_graph=use_graph, batch=batch,
-                           biometric=bio, gamma=1e-6)
+                           biometric=bio, gamma=1e-6, pipeline=pipeline)
     return sd, G, percept, eng, target, latent_mean, float(latent_std), (lm_t, lm_s)
 
 
@@ -105,15 +113,18 @@ def roofline_leg(eng, iters=3):
     """Eager (un-graphed) iterations of the same step with every MFMA conv launch bracketed by HIP events on the launch
     stream, inside the library (mgf_conv_profile_begin/end): the main kernel only, so durations match rocprofv3's trace."""
     from morphganformer_amd import conv as cv
-    state = [t.clone() for t in (eng.step_ctr, eng.min_loss, eng.best_latent, eng.best_step, eng.losses)]
-    eng._iteration()
+    tensors = [eng.step_ctr, eng.min_loss, eng.best_latent, eng.best_step, eng.losses] + ([eng.gen_ctr] if eng.pipeline else [])
+    state = [t.clone() for t in tensors]
+    # same schedule as the timed region: in pipelined mode the losses of one batch run on the side stream next to the generator
+    step = (lambda k: eng._pipe_step(k & 1)) if eng.pipeline else (lambda k: eng._iteration())
+    step(0)
     torch.cuda.synchronize()
     cv.profile_begin()
-    for _ in range(iters):
-        eng._iteration()
+    for k in range(iters):
+        step(k + 1)
     torch.cuda.synchronize()
     prof = cv.profile_end()
-    for dst, src in zip((eng.step_ctr, eng.min_loss, eng.best_latent, eng.best_step, eng.losses), state):
+    for dst, src in zip(tensors, state):
         dst.copy_(src)
     agg = {}
     for kernel, flops, secs, ksplit, nbytes in prof:
@@ -226,7 +237,7 @@ def main():
     # the engine advances `batch` loop steps per launch sequence; K or W that are not multiples are rounded UP to whole
     # launches (more work inside the timed region, never less) while the reported rate still counts exactly K steps
     rup = lambda v: -(-v // a.batch) * a.batch
-    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, rup(a.steps) + rup(a.warmup), not a.no_graph, a.batch, a.biometric)
+    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, rup(a.steps) + rup(a.warmup) + a.batch, not a.no_graph, a.batch, a.biometric, bool(a.pipeline))
 
     log(f"built generator/LPIPS/engine on {device}; warm-up {a.warmup} steps (includes graph capture)")
     eng.run(a.warmup)
@@ -264,6 +275,7 @@ def main():
                                "noise_mode=random, seeded synthetic weights/targets/landmarks"
                                + (f" + IResNet-{a.biometric} embedding MSE (config 3 objective)" if a.biometric else ""), "k": cfg.k, "z_dim": cfg.z_dim,
                    "targets_per_gpu": 1, "parallelism": f"pair-sharded x{world}", "graph_replay": not a.no_graph,
+                   "loss_generator_overlap": bool(a.pipeline),
                    "steps_per_forward": a.batch},
     }
     if rank == 0:

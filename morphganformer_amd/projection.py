@@ -77,7 +77,7 @@ class ProjectionEngine:
 
     def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True,
                  lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, batch=1,
-                 landmark_fn=None, biometric=None, gamma=1.0, wing_kind="wing", landmark_model=None):
+                 landmark_fn=None, biometric=None, gamma=1.0, wing_kind="wing", landmark_model=None, pipeline=False):
         """batch = number of consecutive loop steps evaluated per generator forward.  In literal mode the steps do not depend
         on each other (latent_in never changes), so evaluating `batch` candidates at once and examining them in step order
         gives exactly the sequential loop's result while the small 4x4..64x64 layers, the mapping network and the LPIPS tail
@@ -85,6 +85,12 @@ class ProjectionEngine:
 
         wing_kind: "wing" (WingLoss(10, 2), the default drivers) or "awing" (AdaptiveWingLoss(14, 0.5, 1, 2.1) on the same landmark
         tensors, 1024_example_wing_loss_adaptive.py:176 with lamda = 1e-5).
+
+        pipeline: software-pipeline consecutive batches over two streams -- while the losses and the selection of batch i run
+        on a side stream, the generator already synthesises batch i+1 (its own latent / image buffers and step counter).  The
+        literal loop's steps are independent, and selection still happens in step order, so results are unchanged; one extra
+        generator batch is in flight at any time (an engine that is `run()` to its last step has synthesised one batch more
+        than it scored).
 
         biometric: optional `iresnet.BiometricLoss`; adds gamma * MSE(embed(img), embed(target)) to the objective (the
         FaceNet term of 1024_example_FaceNet_percept.py:147-158 on the vendored IResNet embedder).
@@ -161,14 +167,33 @@ class ProjectionEngine:
             biometric.set_target(self.target)
         self.use_graph = use_graph
         self.graph = None
+        self.pipeline = bool(pipeline) and landmark_fn is None
+        if self.pipeline:
+            if G.n != B:
+                G._alloc(B)
+            self.latent_ns = [self.latent_n, torch.empty_like(self.latent_n)]
+            self.imgs = [G.img, torch.empty_like(G.img)]
+            self.gen_ctr = torch.zeros(1, dtype=torch.int32, device=dev)          # step counter of the generator side
+            self.loss_stream = torch.cuda.Stream(device=dev)
+            self.graphs = [None, None]
+            self._parity = 0
+            self._primed = False
 
     # ------------------------------------------------------------------ one iteration
     def _iteration(self):
         """`batch` consecutive steps of the loop: perturb -> generator -> losses -> in-order best-so-far selection."""
+        img = self._gen_phase(self.latent_n, self.step_ctr)
+        self._loss_phase(img, self.latent_n)
+        return img
+
+    def _gen_phase(self, latent_n, ctr):
         L, st, a, B = _lib.lib(), _lib.stream_ptr(), self.args, self.batch
-        _lib.check(L.mgf_latent_perturb(self.latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(),
-                                        self.sigma.data_ptr(), self.step_ctr.data_ptr(), B, self.steps, self.numel, st), "latent_perturb")
-        img = self.G(self.latent_n, a.truncation_psi, noise_mode=self.noise_mode)[0]      # psi lands in `c` (SURVEY 0.2)
+        _lib.check(L.mgf_latent_perturb(latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(),
+                                        self.sigma.data_ptr(), ctr.data_ptr(), B, self.steps, self.numel, st), "latent_perturb")
+        return self.G(latent_n, a.truncation_psi, noise_mode=self.noise_mode)[0]          # psi lands in `c` (SURVEY 0.2)
+
+    def _loss_phase(self, img, latent_n):
+        L, st, a, B = _lib.lib(), _lib.stream_ptr(), self.args, self.batch
         if self.percept is not None:
             self.percept.distance_into(self.p_loss, img)
             if a.percept_weight != 1.0:
@@ -195,12 +220,59 @@ class ProjectionEngine:
                                                     self.lm_target.numel(), 14.0, 0.5, 1.0, 2.1, self.step_ctr.data_ptr(),
                                                     self.lm_steps.shape[0] - 1, st), "adaptive_wing_loss")
         _lib.check(L.mgf_select_best(self.min_loss.data_ptr(), self.best_latent.data_ptr(), self.best_step.data_ptr(),
-                                     self.losses.data_ptr(), self.latent_n.data_ptr(), self.numel,
+                                     self.losses.data_ptr(), latent_n.data_ptr(), self.numel,
                                      _lib.ptr(self.p_loss if (self.percept is not None or self.biometric is not None) else None),
                                      _lib.ptr(self.w_loss if self.use_wing else None),
                                      _lib.ptr(self.mse_loss if self.use_mse else None), float(a.lamda), float(a.beta),
                                      self.step_ctr.data_ptr(), _lib.ptr(self.valid), B, self.steps, st), "select_best")
+
+    # ------------------------------------------------------------------ pipelined mode
+    def _pipe_gen(self, p):
+        """Generator side of batch parity p (own latent / image buffer, own step counter)."""
+        self.G.img = self.imgs[p]
+        img = self._gen_phase(self.latent_ns[p], self.gen_ctr)
+        self.gen_ctr.add_(self.batch).clamp_(max=self.steps)
         return img
+
+    def _pipe_step(self, p):
+        """Steady state: losses + selection of the batch in buffers p on the loss stream, the generator of the next batch in buffers
+        p ^ 1 on the current stream; joined at the end."""
+        main = torch.cuda.current_stream(self.device)
+        self.loss_stream.wait_stream(main)
+        with torch.cuda.stream(self.loss_stream):
+            self._loss_phase(self.imgs[p], self.latent_ns[p])
+        self._pipe_gen(p ^ 1)
+        main.wait_stream(self.loss_stream)
+
+    def _pipe_capture(self):
+        state = [t.clone() for t in (self.step_ctr, self.gen_ctr, self.min_loss, self.best_latent, self.best_step, self.losses)]
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self._pipe_step(0)
+            self._pipe_step(1)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        for p in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._pipe_step(p)
+            self.graphs[p] = g
+        for dst, src in zip((self.step_ctr, self.gen_ctr, self.min_loss, self.best_latent, self.best_step, self.losses), state):
+            dst.copy_(src)
+
+    def _run_pipelined(self, n):
+        if self.use_graph and self.graphs[0] is None:
+            self._pipe_capture()                                          # (its warm-up overwrites both image buffers: capture first)
+        if not self._primed:
+            self._pipe_gen(self._parity)                                  # the first batch has no losses to overlap with
+            self._primed = True
+        for _ in range(n):
+            if self.use_graph:
+                self.graphs[self._parity].replay()
+            else:
+                self._pipe_step(self._parity)
+            self._parity ^= 1
 
     def _detect_landmarks(self, img):
         """Host detour of the callback mode: hand every candidate image of this batch to `landmark_fn`, in step order."""
@@ -234,6 +306,9 @@ class ProjectionEngine:
         done = int(self.step_ctr.item()) if steps is None else None
         n = (self.steps - done) if steps is None else steps
         n = (n + self.batch - 1) // self.batch
+        if self.pipeline:
+            self._run_pipelined(n)
+            return self
         if self.use_graph and self.graph is None:
             self._capture()
         for _ in range(n):

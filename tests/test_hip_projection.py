@@ -299,3 +299,21 @@ def _tiny_gen():
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.synth_weights import TINY, make_state_dict
     return Generator(make_state_dict(TINY, seed=0), TINY, "cuda", max_batch=1)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pipelined_mode_equals_plain_loop(golden, use_graph):
+    """Losses of batch i on a side stream while the generator already runs batch i+1: same best step, bit-identical latent and
+    loss history as the plain loop (and hence as the reference run), also across several run() calls and a ragged last batch."""
+    g = golden("loop_tiny.npz")
+    eng = _engine_from_golden(g, use_graph, batch=4)
+    eng2 = _engine_from_golden(g, use_graph, batch=4)
+    eng2.__init__(eng2.G, eng2.target, torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]), eng2.args, percept=None,
+                  use_mse=True, lm_target=g["lm_target"], lm_steps=g["lm_steps"], eps=torch.from_numpy(g["eps"]).cuda(),
+                  noise_mode="const", use_graph=use_graph, batch=4, pipeline=True)
+    lat, bstep, bloss, losses = eng.run().result()
+    eng2.run(12)
+    eng2.run(38)                                                          # 50 steps in two calls; 50 = 12 * 4 + 2 (ragged tail)
+    lat2, bstep2, bloss2, losses2 = eng2.result()
+    assert bstep2 == bstep == int(g["best_step"]) and torch.equal(lat2, lat) and bloss2 == bloss
+    assert np.array_equal(losses2, losses)

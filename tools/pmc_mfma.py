@@ -3,7 +3,7 @@
     rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d OUT -- python3 bench.py ... --no-graph
     python tools/pmc_mfma.py OUT
 
-Only whole projection iterations are counted (perturb_kernel .. select_kernel).  Normalisation on MI355X: rocprofv3 sums
+Only the projection iterations are counted (first perturb_kernel .. last select_kernel).  Normalisation on MI355X: rocprofv3 sums
 GRBM_GUI_ACTIVE over the 8 XCDs and SQ_VALU_MFMA_BUSY_CYCLES over all SIMDs, so
     clock = GRBM_GUI_ACTIVE / 8 / duration            MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)
 (a kernel that kept every MFMA pipe busy every cycle would read 1.0; achieved TFLOP/s = utilisation x 157.3 x clock / 2.4 GHz).
@@ -27,20 +27,19 @@ def main():
             d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             d["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     agg = defaultdict(lambda: defaultdict(float))
-    in_loop = False
-    for key in sorted(disp):
+    keys = sorted(disp)
+    first = min((k for k in keys if "perturb_kernel" in disp[k]["name"]), default=None)
+    last = max((k for k in keys if "select_kernel" in disp[k]["name"]), default=None)
+    for key in keys:
+        if first is None or last is None or key < first or key > last:
+            continue
         d = disp[key]
         name = d["name"]
-        if "perturb_kernel" in name:
-            in_loop = True
-        if in_loop:
-            short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
-            a = agg[short]
-            for c in ("GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "ns"):
-                a[c] += d.get(c, 0.0)
-            a["launches"] += 1
-        if "select_kernel" in name:
-            in_loop = False
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+        a = agg[short]
+        for c in ("GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "ns"):
+            a[c] += d.get(c, 0.0)
+        a["launches"] += 1
     print(f"{'kernel':<44}{'launches':>9}{'total_ms':>10}{'clock_GHz':>11}{'mfma_util':>11}")
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ns"]):
         if a["ns"] <= 0:

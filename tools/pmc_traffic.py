@@ -18,7 +18,7 @@ LOOP_ONLY = False
 
 def load(d):
     """{kernel: [values per dispatch]} for the single counter collected in directory tree d.  With --loop-only, only the
-    dispatches of whole projection iterations are kept (from a perturb_kernel to the next select_kernel): one-off set-up work
+    dispatches from the first perturb_kernel through the last select_kernel are kept (the projection iterations): one-off set-up work
     at batch 1 and bench.py's generator-only leg would otherwise skew the per-launch means."""
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not files:
@@ -27,17 +27,15 @@ def load(d):
     for f in files:
         with open(f, newline="") as fh:
             rows = sorted(csv.DictReader(fh), key=lambda r: int(r.get("Dispatch_Id") or r.get("Correlation_Id")))
-        in_loop = False
-        for row in rows:
+        ids = [int(r.get("Dispatch_Id") or r.get("Correlation_Id")) for r in rows]
+        first = min((i for i, r in zip(ids, rows) if "perturb_kernel" in r["Kernel_Name"]), default=None)
+        last = max((i for i, r in zip(ids, rows) if "select_kernel" in r["Kernel_Name"]), default=None)
+        for i, row in zip(ids, rows):
             name = row["Kernel_Name"]
-            if "perturb_kernel" in name:
-                in_loop = True
-            if LOOP_ONLY and not in_loop:
+            if LOOP_ONLY and (first is None or last is None or i < first or i > last):
                 continue
             key = (f, row.get("Dispatch_Id") or row.get("Correlation_Id"))
             per[name][key] += float(row["Counter_Value"])
-            if "select_kernel" in name:
-                in_loop = False
     return {k: list(v.values()) for k, v in per.items()}
 
 

@@ -2,8 +2,8 @@
 
     python tools/rocpd_stats.py gpurun_out/prof/x_results.db [--per-launch KERNEL_SUBSTR] [--loop-only]
 
---loop-only keeps the dispatches of whole projection iterations only (from a perturb_kernel to the next select_kernel, in start
-order): that is the population bench.py's in-process event timing averages over (no batch-1 set-up, no generator-only leg).
+--loop-only keeps the dispatches from the first perturb_kernel through the last select_kernel (start order), i.e. the projection
+iterations: that is the population bench.py's in-process event timing averages over (no batch-1 set-up, no generator-only leg).
 """
 import sqlite3
 import sys
@@ -15,15 +15,14 @@ def main():
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     if "--loop-only" in sys.argv:
-        agg, in_loop = {}, False
-        for name, dur in cur.execute(f"select {name_col}, end-start from kernels order by start"):
-            if "perturb_kernel" in name:
-                in_loop = True
-            if in_loop:
+        agg = {}
+        allk = cur.execute(f"select {name_col}, end-start, start from kernels order by start").fetchall()
+        t0 = min((st for nm, _, st in allk if "perturb_kernel" in nm), default=None)
+        t1 = max((st for nm, _, st in allk if "select_kernel" in nm), default=None)
+        for name, dur, st in allk:
+            if t0 is not None and t1 is not None and t0 <= st <= t1:
                 a = agg.setdefault(name, [0, 0, 1 << 62, 0])
                 a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
-            if "select_kernel" in name:
-                in_loop = False
         rows = sorted(((k, v[0], v[1], v[1] / v[0], v[2], v[3]) for k, v in agg.items()), key=lambda r: -r[2])
     else:
         rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by {name_col} order by 3 desc").fetchall()
