@@ -35,7 +35,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CK = 8;          // input channels per K chunk
 // per-lane register staging slots of the pipelined kernels: XS floats of the input footprint, WS float4 of the weight slab
 template <int WM, int WN> struct Slots {
-    static constexpr int XS = WN == 4 ? 20 : (WN == 3 ? 15 : 11);      // 16x32 tile: 8*18*34 = 4896 floats; 12x32: 3808; 8x32: 2720
+    static constexpr int XS = WN == 4 ? 20 : (WN == 3 ? 15 : (WN == 1 ? 7 : 11));   // 16x32 tile: 8*18*34 = 4896 floats; 12x32: 3808; 8x32: 2720; 4x32: 1632
     static constexpr int WS = WM == 2 ? 5 : 3;        // 9*8*64/4 = 1152 float4; 9*8*32/4 = 576
 };
 
@@ -950,8 +950,14 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     int TW = 1 << tw_log2;
     // workgroup tile: wide channel tiles when there are >= 64 output channels, more pixels per wave otherwise
     int wm = 1, wn = 2;
+    // maps of at most 128 positions (4x4, 8x8 and the 5x5 / 9x9 parity grids of the first transposed convs): 128-lane pixel tiles,
+    // half the padded MFMA work of the 256-lane ones
+    static const char* small_env = getenv("MGF_SMALL_TILES");    // tuning hook (experiments only): 0 = always 256-lane tiles
+    const bool small = (int64_t)d.tile_h * d.tile_w <= 128 && !(small_env && small_env[0] == '0');
+    if (mode == 1 && small) wn = 1;
     if (mode == 0) {
-        if (d.cout_pad % 64 == 0 && d.cout > 32) { wm = 2; wn = 2; }
+        if (d.cout_pad % 64 == 0 && d.cout > 32) { wm = 2; wn = small ? 1 : 2; }
+        else if (small) { wm = 1; wn = 1; }
         // <= 32 output channels on a large map: 12-row tiles for 3x3 (measured 91 vs 87 TFLOP/s at 1024^2), 16-row tiles for 1x1
         else if ((int64_t)d.tile_h * d.tile_w >= 512 * 64) { wm = 1; wn = d.ntaps == 9 ? 3 : 4; }
         // tuning hook (experiments only): MGF_CONV_TILE=wm,wn forces the tile of MODE-0 launches
@@ -973,7 +979,7 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
         for (int tw = 8; tw <= 64 && !(tw_env && tw_env[0] == '0'); ++tw) {
             const int r = PX / tw;
             const int fh_ = r + (dy_max - dy_min), fw_ = tw + (dx_max - dx_min);
-            if (256 / fw_ + 2 > 2 * fh_ || (size_t)CK * fh_ * fw_ > (size_t)Slots<1, 2>::XS * 256) continue;
+            if (256 / fw_ + 2 > 2 * fh_ || (size_t)CK * fh_ * fw_ > (size_t)(wn == 1 ? Slots<1, 1>::XS : Slots<1, 2>::XS) * 256) continue;
             const int64_t tiles = mgf_cdiv(d.tile_w, tw) * mgf_cdiv(d.tile_h, r);
             if (tiles * 10 < best) { best = tiles * 10; TW = tw; rows = r; }
         }
@@ -1003,7 +1009,8 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     MGF_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.co_tiles * d.n * ksplit <= INT32_MAX, MGF_ETOOBIG, "conv_taps: grid too large");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (mode == 1) rc = launch_conv<1, 2, 1>(p, st);
+    if (mode == 1) rc = wn == 1 ? launch_conv<1, 1, 1>(p, st) : launch_conv<1, 2, 1>(p, st);
+    else if (wn == 1) rc = wm == 2 ? launch_conv<2, 1, 0>(p, st) : launch_conv<1, 1, 0>(p, st);
     else if (wm == 2) rc = launch_conv<2, 2, 0>(p, st);
     else if (wn == 4) rc = launch_conv<1, 4, 0>(p, st);
     else if (wn == 3) rc = launch_conv<1, 3, 0>(p, st);
