@@ -158,7 +158,8 @@ int mgf_pack_conv_weights(float* wp, float* wsq, const float* w, int32_t cout, i
  * wg = ws[n * ws_stride_n + j.w_offset ...] (the global latent component of that layer's ws slot):
  *   s[n, ci] = ((sum_k wg[k] * aff_w[ci, k]) * aff_gain + aff_b[ci]) * style_gain
  *   d[n, co] = rsqrt( sum_ci wsq[co, ci] * s[n, ci]^2 + 1e-8 )                   (if wsq and d are non-NULL)
- * wsq comes from mgf_pack_conv_weights.  The _multi form takes a DEVICE array of jobs (one launch for all layers).
+ * wsq comes from mgf_pack_conv_weights.  The _multi form takes a DEVICE array of jobs (one launch for all layers); max_cin = the
+ * largest job cin if the caller knows it (lets one workgroup serve all n <= 32 samples and read each wsq table once), else 0.
  */
 typedef struct mgf_style_job {
     const float* aff_w;   /* [cin, wdim] */
@@ -172,7 +173,7 @@ typedef struct mgf_style_job {
 } mgf_style_job;
 int mgf_style_demod(const mgf_style_job* job, const float* ws, int64_t ws_stride_n, int32_t n, int32_t wdim, mgf_stream_t stream);
 int mgf_style_demod_multi(const mgf_style_job* jobs_dev, int32_t njobs, const float* ws, int64_t ws_stride_n,
-                          int32_t n, int32_t wdim, mgf_stream_t stream);
+                          int32_t n, int32_t wdim, int32_t max_cin, mgf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Duplex (image <- latents) attention of a SynthesisLayer, k-means/parametric-centroid form, integration "mul",

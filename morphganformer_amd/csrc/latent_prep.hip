@@ -42,6 +42,51 @@ __global__ __launch_bounds__(256) void style_demod_multi_kernel(const mgf_style_
     style_demod_body(j, ws, ws_stride_n, wdim, blockIdx.z, s_lds);
 }
 
+// Batched form: grid = (co_blocks, njobs); ONE workgroup serves all samples.  The styles of every sample go to LDS ([n][cin]), then
+// each wave streams its rows of wsq ONCE and accumulates the n demodulation sums side by side (the per-sample form re-reads the
+// 1 MB table of a 512-channel layer for every sample).  NB <= 32 samples, n * cin floats of dynamic LDS.
+constexpr int SD_NB = 32;
+__global__ __launch_bounds__(256) void style_demod_batched_kernel(const mgf_style_job* jobs, const float* ws, int64_t ws_stride_n, int wdim, int n) {
+    extern __shared__ float s_all[];                 // [n][cin], squared styles after the publish step
+    const mgf_style_job j = jobs[blockIdx.y];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n * j.cin; i += 256) {
+        const int s_n = i / j.cin, ci = i - s_n * j.cin;
+        const float* wg = ws + (int64_t)s_n * ws_stride_n + j.w_offset;
+        const float* row = j.aff_w + (int64_t)ci * wdim;
+        float acc = 0.f;
+        for (int k = 0; k < wdim; ++k) acc += wg[k] * row[k];
+        const float sv = (acc * j.aff_gain + j.aff_b[ci]) * j.style_gain;
+        if (blockIdx.x == 0) j.s[(int64_t)s_n * j.cin + ci] = sv;
+        s_all[i] = sv * sv;
+    }
+    if (!j.wsq || !j.d) return;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per_block = (j.cout + gridDim.x - 1) / gridDim.x;
+    const int co_begin = blockIdx.x * per_block;
+    const int co_end = min(j.cout, co_begin + per_block);
+    for (int co = co_begin + wave; co < co_end; co += 4) {
+        const float* row = j.wsq + (int64_t)co * j.cin;
+        float acc[SD_NB];
+#pragma unroll
+        for (int q = 0; q < SD_NB; ++q) acc[q] = 0.f;
+        for (int ci = lane; ci < j.cin; ci += 64) {
+            const float wv = row[ci];
+#pragma unroll
+            for (int q = 0; q < SD_NB; ++q)
+                if (q < n) acc[q] += wv * s_all[q * j.cin + ci];
+        }
+#pragma unroll
+        for (int q = 0; q < SD_NB; ++q) {
+            if (q < n) {
+                const float v = wave_sum(acc[q]);
+                if (lane == 0) j.d[(int64_t)q * j.cout + co] = rsqrtf(v + 1e-8f);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void style_demod_single_kernel(mgf_style_job j, const float* ws, int64_t ws_stride_n, int wdim) {
     __shared__ float s_lds[2048];
     style_demod_body(j, ws, ws_stride_n, wdim, blockIdx.z, s_lds);
@@ -207,10 +252,21 @@ __global__ __launch_bounds__(256) void mapping_kernel(float* w, const float* z, 
 }  // namespace
 
 extern "C" int mgf_style_demod_multi(const mgf_style_job* jobs_dev, int32_t njobs, const float* ws, int64_t ws_stride_n,
-                                     int32_t n, int32_t wdim, mgf_stream_t stream) {
+                                     int32_t n, int32_t wdim, int32_t max_cin, mgf_stream_t stream) {
     MGF_REQUIRE(jobs_dev && ws && njobs >= 1 && n >= 1 && wdim >= 1, MGF_EINVAL, "style_demod_multi: bad arguments");
     MGF_REQUIRE(njobs <= 65535 && n <= 65535, MGF_ETOOBIG, "style_demod_multi: too many jobs/samples");
-    hipLaunchKernelGGL(style_demod_multi_kernel, dim3(16, njobs, n), dim3(256), 0, (hipStream_t)stream, jobs_dev, ws, ws_stride_n, wdim);
+    // all samples in one workgroup when their styles fit in LDS: the wsq tables are read once instead of once per sample
+    MGF_REQUIRE(max_cin >= 0 && max_cin <= 2048, MGF_EINVAL, "style_demod_multi: max_cin must be 0 (unknown) or the largest job cin (<= 2048)");
+    if (n > 1 && n <= SD_NB && max_cin > 0 && (size_t)n * max_cin * sizeof(float) <= 128 * 1024) {
+        const size_t lds = (size_t)n * max_cin * sizeof(float);
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)style_demod_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { mgf_set_error("style_demod_multi: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
+        }
+        hipLaunchKernelGGL(style_demod_batched_kernel, dim3(16, njobs), dim3(256), lds, (hipStream_t)stream, jobs_dev, ws, ws_stride_n, wdim, n);
+    } else {
+        hipLaunchKernelGGL(style_demod_multi_kernel, dim3(16, njobs, n), dim3(256), 0, (hipStream_t)stream, jobs_dev, ws, ws_stride_n, wdim);
+    }
     MGF_CHECK_LAUNCH("style_demod_multi");
     return MGF_OK;
 }

@@ -262,6 +262,7 @@ class Generator:
                                        self.vtabs.data_ptr() + 4 * lp.attn.v_off * n, lp.attn.c, 0))
         self.style_jobs = torch.frombuffer(bytearray(bytes(sj)), dtype=torch.uint8).to(self.device)
         self.n_style_jobs = len(P.layers)
+        self.max_style_cin = max(lp.cin for lp in P.layers)
         self.attn_jobs = None
         if aj:
             arr = (_lib.AttnJob * len(aj))(*aj)
@@ -320,7 +321,8 @@ class Generator:
         st = _lib.stream_ptr()
         D, T = cfg.w_dim, cfg.k - 1
         assert w.is_contiguous() and tuple(w.shape) == (n, cfg.k, D)
-        _lib.check(L.mgf_style_demod_multi(self.style_jobs.data_ptr(), self.n_style_jobs, w.data_ptr(), cfg.k * D, n, D, st),
+        _lib.check(L.mgf_style_demod_multi(self.style_jobs.data_ptr(), self.n_style_jobs, w.data_ptr(), cfg.k * D, n, D,
+                                           self.max_style_cin, st),
                    "style_demod_multi")
         if self.n_attn_jobs:
             _lib.check(L.mgf_attn_values_multi(self.attn_jobs.data_ptr(), self.n_attn_jobs, w.data_ptr(), cfg.k * D, D, n, T, D, st),
