@@ -10,7 +10,8 @@ namespace {
 // ------------------------------------------------------------------------------------------ styles + demod
 // grid = (co_blocks, njobs, n); 256 lanes.  Every block recomputes the (cheap) style vector into LDS, block x == 0
 // publishes it, then the 4 waves walk this block's share of wsq rows: lanes stride over ci (coalesced), wave-reduce.
-__device__ void style_demod_body(const mgf_style_job& j, const float* ws, int64_t ws_stride_n, int wdim, int n, float* s_lds) {
+__device__ void style_demod_body(const mgf_style_job& j, const float* ws, int64_t ws_stride_n, int wdim, int n, float* s_lds,
+                                 bool styles_only = false) {
     const int tid = threadIdx.x;
     const float* wg = ws + (int64_t)n * ws_stride_n + j.w_offset;
     for (int ci = tid; ci < j.cin; ci += blockDim.x) {
@@ -21,7 +22,7 @@ __device__ void style_demod_body(const mgf_style_job& j, const float* ws, int64_
         s_lds[ci] = s;
         if (blockIdx.x == 0) j.s[(int64_t)n * j.cin + ci] = s;
     }
-    if (!j.wsq || !j.d) return;
+    if (!j.wsq || !j.d || styles_only) return;
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int per_block = (j.cout + gridDim.x - 1) / gridDim.x;
@@ -36,13 +37,15 @@ __device__ void style_demod_body(const mgf_style_job& j, const float* ws, int64_
     }
 }
 
-__global__ __launch_bounds__(256) void style_demod_multi_kernel(const mgf_style_job* jobs, const float* ws, int64_t ws_stride_n, int wdim) {
+__global__ __launch_bounds__(256) void style_demod_multi_kernel(const mgf_style_job* jobs, const float* ws, int64_t ws_stride_n, int wdim,
+                                                                int styles_only) {
     __shared__ float s_lds[2048];
     const mgf_style_job j = jobs[blockIdx.y];
-    style_demod_body(j, ws, ws_stride_n, wdim, blockIdx.z, s_lds);
+    style_demod_body(j, ws, ws_stride_n, wdim, blockIdx.z, s_lds, styles_only != 0);
 }
 
-// Batched form: grid = (co_blocks, njobs); ONE workgroup serves all samples.  The styles of every sample go to LDS ([n][cin]), then
+// Batched demodulation: grid = (co_blocks, njobs); ONE workgroup serves all samples.  The styles of every sample (computed by a
+// styles-only launch just before) go to LDS ([n][cin]), then
 // each wave streams its rows of wsq ONCE and accumulates the n demodulation sums side by side (the per-sample form re-reads the
 // 1 MB table of a 512-channel layer for every sample).  NB <= 32 samples, n * cin floats of dynamic LDS.
 constexpr int SD_NB = 32;
@@ -50,17 +53,11 @@ __global__ __launch_bounds__(256) void style_demod_batched_kernel(const mgf_styl
     extern __shared__ float s_all[];                 // [n][cin], squared styles after the publish step
     const mgf_style_job j = jobs[blockIdx.y];
     const int tid = threadIdx.x;
-    for (int i = tid; i < n * j.cin; i += 256) {
-        const int s_n = i / j.cin, ci = i - s_n * j.cin;
-        const float* wg = ws + (int64_t)s_n * ws_stride_n + j.w_offset;
-        const float* row = j.aff_w + (int64_t)ci * wdim;
-        float acc = 0.f;
-        for (int k = 0; k < wdim; ++k) acc += wg[k] * row[k];
-        const float sv = (acc * j.aff_gain + j.aff_b[ci]) * j.style_gain;
-        if (blockIdx.x == 0) j.s[(int64_t)s_n * j.cin + ci] = sv;
+    if (!j.wsq || !j.d) return;
+    for (int i = tid; i < n * j.cin; i += 256) {                  // styles were published by the preceding styles-only launch
+        const float sv = j.s[i];
         s_all[i] = sv * sv;
     }
-    if (!j.wsq || !j.d) return;
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int per_block = (j.cout + gridDim.x - 1) / gridDim.x;
@@ -96,14 +93,44 @@ __global__ __launch_bounds__(256) void style_demod_single_kernel(mgf_style_job j
 // vwb[n][c][t] (t fastest: 16 contiguous scalars per channel for the attention kernel's scalar loads)
 //   = sum_j ycomp[n,t,j] * wmv[c,j] + bmv[c]
 __device__ void attn_values_body(const mgf_attn_job& j, const float* ws, int64_t ws_stride_n, int64_t ws_stride_t, int wdim, int t_len, int n) {
-    const int total = j.c * t_len;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int t = i % t_len, c = i / t_len;
-        const float* y = ws + (int64_t)n * ws_stride_n + (int64_t)t * ws_stride_t + j.w_offset;
-        const float* row = j.wmv + (int64_t)c * wdim;
-        float acc = 0.f;
-        for (int k = 0; k < wdim; ++k) acc += y[k] * row[k];
-        j.vwb[((int64_t)n * j.c + c) * t_len + t] = acc + j.bmv[c];
+    // the sample's latent components go to LDS once; a thread then owns one channel: its weight row is read once (float4 when
+    // aligned) and reused for all t_len components, the t_len results are contiguous in vwb
+    __shared__ float ys[16 * 64];
+    const bool fast = t_len <= 16 && wdim <= 64 && wdim % 4 == 0 && ((uintptr_t)j.wmv % 16) == 0;
+    if (!fast) {
+        const int total = j.c * t_len;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            const int t = i % t_len, c = i / t_len;
+            const float* y = ws + (int64_t)n * ws_stride_n + (int64_t)t * ws_stride_t + j.w_offset;
+            const float* row = j.wmv + (int64_t)c * wdim;
+            float acc = 0.f;
+            for (int k = 0; k < wdim; ++k) acc += y[k] * row[k];
+            j.vwb[((int64_t)n * j.c + c) * t_len + t] = acc + j.bmv[c];
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < t_len * wdim; i += blockDim.x)
+        ys[i] = ws[(int64_t)n * ws_stride_n + (int64_t)(i / wdim) * ws_stride_t + j.w_offset + i % wdim];
+    __syncthreads();
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < j.c; c += gridDim.x * blockDim.x) {
+        const float4* row = reinterpret_cast<const float4*>(j.wmv + (int64_t)c * wdim);
+        float acc[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+        for (int k4 = 0; k4 < wdim / 4; ++k4) {
+            const float4 wv = row[k4];
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (t < t_len) {
+                    const float* y = ys + t * wdim + 4 * k4;
+                    acc[t] += y[0] * wv.x + y[1] * wv.y + y[2] * wv.z + y[3] * wv.w;
+                }
+        }
+        const float bb = j.bmv[c];
+        float* o = j.vwb + ((int64_t)n * j.c + c) * t_len;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t < t_len) o[t] = acc[t] + bb;
     }
 }
 
@@ -263,9 +290,10 @@ extern "C" int mgf_style_demod_multi(const mgf_style_job* jobs_dev, int32_t njob
             hipError_t e = hipFuncSetAttribute((const void*)style_demod_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { mgf_set_error("style_demod_multi: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
         }
+        hipLaunchKernelGGL(style_demod_multi_kernel, dim3(1, njobs, n), dim3(256), 0, (hipStream_t)stream, jobs_dev, ws, ws_stride_n, wdim, 1);
         hipLaunchKernelGGL(style_demod_batched_kernel, dim3(16, njobs), dim3(256), lds, (hipStream_t)stream, jobs_dev, ws, ws_stride_n, wdim, n);
     } else {
-        hipLaunchKernelGGL(style_demod_multi_kernel, dim3(16, njobs, n), dim3(256), 0, (hipStream_t)stream, jobs_dev, ws, ws_stride_n, wdim);
+        hipLaunchKernelGGL(style_demod_multi_kernel, dim3(16, njobs, n), dim3(256), 0, (hipStream_t)stream, jobs_dev, ws, ws_stride_n, wdim, 0);
     }
     MGF_CHECK_LAUNCH("style_demod_multi");
     return MGF_OK;
