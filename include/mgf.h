@@ -293,6 +293,72 @@ int mgf_linear_f32(float* y, const float* x, const float* w, const float* b, int
 int mgf_resize_bilinear_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                             mgf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Gradient mode: dLoss/dlatent through the synthesis network -- what torch autograd does for the reference when the loss is
+ * differentiated with respect to the latent (the north-star reading of the projection loop; bias_act.py:137-198,
+ * upfirdn2d.py:237-256, networks.py:253-328, 748-822).  Weights are constants, so a layer needs
+ *   - the activation gradient: a forward mgf_conv_taps_f32 launch on channel-transposed taps (dgrad) and mgf_upfirdn2d with up/down
+ *     swapped;
+ *   - the style gradient of  c_o = d_o * sum_i s_i (W_oi * x_i):   dL/ds_i = <x_i, g_i> - s_i * sum_o <dc_o, c_o> d_o^2 wsq[o,i]
+ *     with g_i = sum_o W_oi^T * (d_o dc_o) the un-modulated dgrad result;
+ *   - the gradients of the duplex attention with respect to its input and its value table.
+ * All per-channel reductions are deterministic two-stage sums: a launch writes `mgf_bwd_chunks(hw)` partials per (sample, channel),
+ * the consumer (mgf_style_demod_bwd_multi) adds them in order.
+ *
+ * layer_act_bwd: for y = lrelu_alpha(c + noise * strength + bias) * gain (+ residual), given dy:
+ *     dz = dy * gain * (y - residual > 0 ? 1 : alpha)                              (may alias dy)
+ *     dot_part[n, ch, chunk] = sum dz * c   with c recovered from y by inverting the activation     (skipped when dot_part == NULL)
+ * channel_dot:   dot_part[n, ch, chunk] = sum a * b
+ * style_grad:    dot_part[n, ch, chunk] = sum x * g;   dx (+)= s[n, ch] * g      (s NULL = 1; accumulate != 0 adds to dx)
+ */
+int32_t mgf_bwd_chunks(int64_t hw);
+int mgf_layer_act_bwd_f32(float* dz, float* dot_part, const float* dy, const float* y, const float* residual, const float* bias,
+                          const float* noise, const float* noise_strength, int32_t noise_n, int32_t n, int32_t c, int64_t hw,
+                          float alpha, float gain, mgf_stream_t stream);
+int mgf_channel_dot_f32(float* dot_part, const float* a, const float* b, int32_t n, int32_t c, int64_t hw, mgf_stream_t stream);
+int mgf_style_grad_f32(float* dot_part, float* dx, const float* x, const float* g, const float* s, int32_t n, int32_t c, int64_t hw,
+                       int32_t accumulate, mgf_stream_t stream);
+/* Backward of mgf_duplex_attention without its epilogue (apply mgf_layer_act_bwd_f32 first), same operands as the forward:
+ *   dx[n,c,f]    gradient with respect to the attention input x
+ *   dg[n,c,f]    = da * x * rsqrt(mean_c x^2 + 1e-8), scratch consumed by mgf_attn_values_grad (may be NULL)
+ *   probs[n,f,t] the recomputed softmax (may be NULL)
+ * attn_values_grad: dvwb[n,c,t] = sum_f dg[n,c,f] * probs[n,f,t], the gradient of the per-sample value table. */
+int mgf_duplex_attention_bwd(float* dx, float* dg, float* probs, const float* da, const float* x, const float* wqc, const float* spos,
+                             const float* vwb, int32_t n, int32_t c, int32_t f, int32_t t, mgf_stream_t stream);
+int mgf_attn_values_grad(float* dvwb, const float* dg, const float* probs, int32_t n, int32_t c, int32_t f, int32_t t, mgf_stream_t stream);
+/* Latent side.  style_demod_bwd_multi: per job (= modulated layer) and sample, from the partial dots above,
+ *   ds[i]  = sum_chunks ds_part[n,i,:] - s[n,i] * sum_o (sum_chunks dc_part[n,o,:]) d[n,o]^2 wsq[o,i]      (second term only with demod)
+ *   dwg[n, job, k] = aff_gain * style_gain * sum_i ds[i] * aff_w[i, k]          gradient wrt the global latent component
+ * attn_values_bwd_multi: dyc[n, job, t, k] = sum_c dvwb[n,c,t] * wmv[c,k]       gradient wrt the local latent components
+ * latent_grad_gather:    dw[n, t < k-1, :] = scale * sum_jobs dyc,  dw[n, k-1, :] = scale * sum_jobs dwg      (w layout [n, k, wdim]) */
+typedef struct mgf_style_bwd_job {
+    const float* aff_w;    /* [cin, wdim] */
+    const float* wsq;      /* [cout, cin] or NULL */
+    const float* s;        /* [n, cin] */
+    const float* d;        /* [n, cout] or NULL */
+    const float* ds_part;  /* [n, cin, s_chunks] */
+    const float* dc_part;  /* [n, cout, d_chunks] or NULL */
+    int32_t cin, cout, s_chunks, d_chunks;
+    float aff_gain, style_gain;
+} mgf_style_bwd_job;
+typedef struct mgf_attn_bwd_job {
+    const float* wmv;      /* [c, wdim] */
+    const float* dvwb;     /* [n, c, t] */
+    int32_t c;
+    int32_t pad_;
+} mgf_attn_bwd_job;
+int mgf_style_demod_bwd_multi(float* dwg, const mgf_style_bwd_job* jobs_dev, int32_t njobs, int32_t n, int32_t wdim, int32_t max_channels,
+                              mgf_stream_t stream);
+int mgf_attn_values_bwd_multi(float* dyc, const mgf_attn_bwd_job* jobs_dev, int32_t njobs, int32_t n, int32_t t, int32_t wdim,
+                              mgf_stream_t stream);
+int mgf_latent_grad_gather(float* dw, const float* dwg, int32_t n_style_jobs, const float* dyc, int32_t n_attn_jobs, int32_t n, int32_t k,
+                           int32_t wdim, float scale, mgf_stream_t stream);
+/* Backward of mgf_mapping_forward: dz[n,k,dim] from dw[n,k,dim].  The forward is recomputed; its per-layer activations go to
+ * `scratch` (>= n * mgf_mapping_bwd_scratch_floats(k, dim, n_res_layers) floats). */
+int64_t mgf_mapping_bwd_scratch_floats(int32_t k, int32_t dim, int32_t n_res_layers);
+int mgf_mapping_backward(float* dz, const float* dw, const float* z, const float* params, float* scratch, int32_t n, int32_t k,
+                         int32_t dim, int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

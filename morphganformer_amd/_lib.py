@@ -48,6 +48,15 @@ class AttnJob(C.Structure):
     _fields_ = [("wmv", vp), ("bmv", vp), ("vwb", vp), ("c", i32), ("w_offset", i32)]
 
 
+class StyleBwdJob(C.Structure):
+    _fields_ = [("aff_w", vp), ("wsq", vp), ("s", vp), ("d", vp), ("ds_part", vp), ("dc_part", vp), ("cin", i32), ("cout", i32),
+                ("s_chunks", i32), ("d_chunks", i32), ("aff_gain", f32), ("style_gain", f32)]
+
+
+class AttnBwdJob(C.Structure):
+    _fields_ = [("wmv", vp), ("dvwb", vp), ("c", i32), ("pad_", i32)]
+
+
 _SIGS = {
     "mgf_last_error": (C.c_char_p, []),
     "mgf_version": (C.c_int, []),
@@ -82,6 +91,17 @@ _SIGS = {
     "mgf_latent_perturb": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),
     "mgf_select_best": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp]),
     "mgf_to_uint8_hwc": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "mgf_bwd_chunks": (i32, [i64]),
+    "mgf_layer_act_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, f32, f32, vp]),
+    "mgf_channel_dot_f32": (C.c_int, [vp, vp, vp, i32, i32, i64, vp]),
+    "mgf_style_grad_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, i32, vp]),
+    "mgf_duplex_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mgf_attn_values_grad": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mgf_style_demod_bwd_multi": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "mgf_attn_values_bwd_multi": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "mgf_latent_grad_gather": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, i32, f32, vp]),
+    "mgf_mapping_bwd_scratch_floats": (i64, [i32, i32, i32]),
+    "mgf_mapping_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
 }
 
 EXPORTED_SYMBOLS = sorted(_SIGS)

@@ -131,6 +131,18 @@ def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_sca
     return out
 
 
+def transpose_packed(pc: PackedConv, flip: bool) -> PackedConv:
+    """The packed taps of the data-gradient convolution: channels swapped ([tap][cout][cin_pad], gain kept), tap order reversed
+    when `flip` (the gradient of a correlation is a true convolution with the same kernel)."""
+    t = pc.wp[:, :, :pc.cout].permute(0, 2, 1)
+    if flip:
+        t = t.flip(0)
+    cpad = round_up(pc.cin, 32)
+    wp = torch.zeros([pc.kh * pc.kw, pc.cout, cpad], dtype=torch.float32, device=pc.wp.device)
+    wp[:, :, :pc.cin] = t
+    return PackedConv(wp.contiguous(), None, pc.cin, pc.cout, pc.kh, pc.kw, cpad)
+
+
 def conv_large_forward(x, w, bias, stride, pad, act="relu", out=None):
     """Convolution with more than 9 taps (AlexNet's 11x11 and 5x5): the tap list is cut into groups of <= 9, each group is one
     launch accumulating into `out` through the residual port (linear), bias + activation follow in one mgf_bias_act pass."""
@@ -194,19 +206,19 @@ def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=Non
     return out[:, :, :, :ow]
 
 
-def upfirdn_into(y, x, f2d, up=1, pad=(0, 0, 0, 0), gain=1.0, flip=False, epilogue=None, separable=False):
-    """mgf_upfirdn2d on arbitrary-stride 4-D views (x may be the padded-pitch transposed-conv workspace), down=1.
+def upfirdn_into(y, x, f2d, up=1, pad=(0, 0, 0, 0), gain=1.0, flip=False, epilogue=None, separable=False, down=1):
+    """mgf_upfirdn2d on arbitrary-stride 4-D views (x may be the padded-pitch transposed-conv workspace).
     separable=True asserts that f2d is an outer product (every setup_filter([taps]) result is) -> MGF_FILTER_SEPARABLE hint."""
     _lib.require_gpu(x, y, f2d)
     n, c, h, w = x.shape
     fh, fw = f2d.shape
     px0, px1, py0, py1 = pad
-    oh = h * up + py0 + py1 - fh + 1
-    ow = w * up + px0 + px1 - fw + 1
+    oh = (h * up + py0 + py1 - fh + down) // down
+    ow = (w * up + px0 + px1 - fw + down) // down
     assert tuple(y.shape) == (n, c, oh, ow), (tuple(y.shape), (n, c, oh, ow))
     sx, sy = x.stride(), y.stride()
     rc = _lib.lib().mgf_upfirdn2d(y.data_ptr(), x.data_ptr(), f2d.data_ptr(), _lib.MGF_F32, n, c, h, w, sx[0], sx[1], sx[2],
-                                  sx[3], oh, ow, sy[0], sy[1], sy[2], sy[3], fh, fw, up, up, 1, 1, px0, px1, py0, py1,
+                                  sx[3], oh, ow, sy[0], sy[1], sy[2], sy[3], fh, fw, up, up, down, down, px0, px1, py0, py1,
                                   int(flip) | (2 if separable else 0), float(gain), C.byref(epilogue) if epilogue is not None else None,
                                   _lib.stream_ptr())
     _lib.check(rc, "upfirdn2d")

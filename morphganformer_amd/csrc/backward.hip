@@ -1,0 +1,442 @@
+// Gradient mode: dLoss/dlatent through the synthesis network (SURVEY.md section 8a row P0 "gradient mode"; the ops the reference
+// differentiates with autograd: bias_act.py:137-198, upfirdn2d.py:237-256, modulated_conv2d networks.py:253-328,
+// TransformerLayer.forward :748-822).  Weights are constants, so per layer only three things are needed:
+//   * d(input activation): a "dgrad" convolution -- the forward tap-list kernel with channel-transposed taps (conv_taps.hip);
+//   * d(style):   y_o = d_o * sum_i s_i (W_oi * x_i)   =>   dL/ds_i = <x_i, g_i> - s_i * sum_o <dc_o, c_o> d_o^2 Wsq_oi
+//                 with g_i = sum_o W_oi^T * (d_o dc_o) the un-modulated dgrad result -- two per-channel dot products instead of a
+//                 per-sample weight-gradient GEMM;
+//   * d(attention value table) and d(x) through the duplex attention.
+// Every reduction is two-stage and deterministic (per-chunk partials, summed in a fixed order by the consumer).
+// Contract: include/mgf.h ("Gradient mode").
+#include "mgf_common.h"
+
+namespace {
+
+constexpr int BWD_CHUNK = 4096;          // elements of one (sample, channel) plane handled by one workgroup
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------------------------------ activation backward
+struct ActBwdParams {
+    float* dz;
+    float* part;
+    const float* dy;
+    const float* y;
+    const float* res;
+    const float* bias;
+    const float* noise;
+    const float* nstr;
+    int noise_n, c, nchunk;
+    int64_t hw;
+    float alpha, gain;
+};
+
+// grid (nchunk, c, n).  y = lrelu(z) * gain + res  with  z = cval + noise * strength + bias:
+//   dz = dy * gain * (y - res > 0 ? 1 : alpha);    part[n,c,chunk] = sum dz * cval   (cval recovered by inverting the activation)
+__global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdParams p) {
+    __shared__ float red[4];
+    const int chunk = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
+    const int64_t base = ((int64_t)n * p.c + ch) * p.hw;
+    const int64_t i0 = (int64_t)chunk * BWD_CHUNK;
+    const int64_t i1 = min(p.hw, i0 + (int64_t)BWD_CHUNK);
+    const float b = p.bias ? p.bias[ch] : 0.f;
+    const float ns = p.noise ? (p.nstr ? *p.nstr : 1.f) : 0.f;
+    const float* nz = p.noise ? p.noise + (int64_t)(p.noise_n > 1 ? n : 0) * p.hw : nullptr;
+    const float inv_gain = 1.f / p.gain, inv_alpha = 1.f / p.alpha;
+    float acc = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        float v = p.y[base + i];
+        if (p.res) v -= p.res[base + i];
+        const bool pos = v > 0.f;
+        const float dzv = p.dy[base + i] * p.gain * (pos ? 1.f : p.alpha);
+        p.dz[base + i] = dzv;
+        if (p.part) {
+            const float zv = (pos ? v : v * inv_alpha) * inv_gain;
+            acc += dzv * (zv - b - (nz ? nz[i] * ns : 0.f));
+        }
+    }
+    if (p.part) {
+        const float tot = block_sum(acc, red);
+        if (threadIdx.x == 0) p.part[((int64_t)n * p.c + ch) * p.nchunk + chunk] = tot;
+    }
+}
+
+// part[n,c,chunk] = sum a * b over the chunk
+__global__ __launch_bounds__(256) void channel_dot_kernel(float* part, const float* a, const float* b, int c, int64_t hw, int nchunk) {
+    __shared__ float red[4];
+    const int chunk = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
+    const int64_t base = ((int64_t)n * c + ch) * hw;
+    const int64_t i0 = (int64_t)chunk * BWD_CHUNK;
+    const int64_t i1 = min(hw, i0 + (int64_t)BWD_CHUNK);
+    float acc = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) acc += a[base + i] * b[base + i];
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) part[((int64_t)n * c + ch) * nchunk + chunk] = tot;
+}
+
+// part[n,c,chunk] = sum x * g ;  dx (+)= s[n,c] * g
+__global__ __launch_bounds__(256) void style_grad_kernel(float* part, float* dx, const float* x, const float* g, const float* s, int c,
+                                                         int64_t hw, int nchunk, int accumulate) {
+    __shared__ float red[4];
+    const int chunk = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
+    const int64_t base = ((int64_t)n * c + ch) * hw;
+    const int64_t i0 = (int64_t)chunk * BWD_CHUNK;
+    const int64_t i1 = min(hw, i0 + (int64_t)BWD_CHUNK);
+    const float sv = s ? s[(int64_t)n * c + ch] : 1.f;
+    float acc = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float gv = g[base + i];
+        acc += x[base + i] * gv;
+        const float o = sv * gv;
+        dx[base + i] = accumulate ? dx[base + i] + o : o;
+    }
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) part[((int64_t)n * c + ch) * nchunk + chunk] = tot;
+}
+
+// ------------------------------------------------------------------------------------------ duplex attention backward
+// Forward (attention.hip):  S = x^T wqc + spos;  P = softmax_t(S);  r = rsqrt(mean_c x^2 + 1e-8);  g[c] = sum_t P[t] vwb[c,t];
+//                           a[c] = x[c] * r * g[c]
+// Backward per pixel, given da:
+//   dg[c] = da[c] x[c] r                  (-> dvwb[c,t] = sum_f dg[c,f] P[f,t], second kernel)
+//   dP[t] = sum_c dg[c] vwb[c,t];   PdP = sum_t P[t] dP[t]  ( = r * sum_c da[c] x[c] g[c], i.e. the norm term for free )
+//   dS[t] = P[t] (dP[t] - PdP)
+//   dx[c] = da[c] r g[c]  -  (PdP r^2 / C) x[c]  +  sum_t dS[t] wqc[c,t]
+constexpr int TMAX = 16;
+struct AttnBwdParams {
+    float* dx;
+    float* dg;
+    float* probs;
+    const float* da;
+    const float* x;
+    const float* wqc;
+    const float* spos;
+    const float* vwb;
+    int n, c, f, t, c_pad;
+};
+
+template <int PXB>
+__global__ __launch_bounds__(256) void duplex_attention_bwd_kernel(AttnBwdParams p) {
+    constexpr int G = 256 / PXB;
+    extern __shared__ float lds[];
+    float* tq = lds;                                  // [c_pad][16]
+    float* tv = tq + (size_t)p.c_pad * TMAX;          // [c_pad][16]
+    float* part = tv + (size_t)p.c_pad * TMAX;        // [G][17][PXB]
+    const int tid = threadIdx.x;
+    const int px = tid % PXB, grp = tid / PXB;
+    const int n = blockIdx.y;
+    const int f = blockIdx.x * PXB + px;
+    const bool valid = f < p.f;
+    const int fc = valid ? f : p.f - 1;
+    const int T = p.t;
+    const int64_t plane = (int64_t)n * p.c * p.f;
+    const float* xn = p.x + plane;
+    const float* dan = p.da + plane;
+    const float* vw = p.vwb + (int64_t)n * p.c * T;
+    for (int i = tid; i < p.c_pad * TMAX; i += 256) {
+        const int c = i / TMAX, t = i % TMAX;
+        const bool ok = c < p.c && t < T;
+        tq[i] = ok ? p.wqc[(int64_t)c * T + t] : 0.f;
+        tv[i] = ok ? vw[(int64_t)c * T + t] : 0.f;
+    }
+    __syncthreads();
+
+    float s[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
+    float sq = 0.f;
+    for (int c = grp; c < p.c; c += G) {
+        const float xv = xn[(int64_t)c * p.f + fc];
+        const float4* w4 = reinterpret_cast<const float4*>(tq + c * TMAX);
+        sq += xv * xv;
+#pragma unroll
+        for (int q = 0; q < TMAX / 4; ++q) {
+            const float4 w = w4[q];
+            s[4 * q + 0] += xv * w.x; s[4 * q + 1] += xv * w.y; s[4 * q + 2] += xv * w.z; s[4 * q + 3] += xv * w.w;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) part[(grp * (TMAX + 1) + t) * PXB + px] = s[t];
+    part[(grp * (TMAX + 1) + TMAX) * PXB + px] = sq;
+    __syncthreads();
+    float P[TMAX];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        float v = 0.f;
+        for (int g = 0; g < G; ++g) v += part[(g * (TMAX + 1) + t) * PXB + px];
+        if (t < T) { v += p.spos[(int64_t)fc * T + t]; m = fmaxf(m, v); }
+        P[t] = v;
+    }
+    sq = 0.f;
+    for (int g = 0; g < G; ++g) sq += part[(g * (TMAX + 1) + TMAX) * PXB + px];
+    float den = 0.f;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        P[t] = t < T ? __expf(P[t] - m) : 0.f;
+        den += P[t];
+    }
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) P[t] *= inv;
+    const float r = rsqrtf(sq / (float)p.c + 1e-8f);
+    if (grp == 0 && valid && p.probs)
+        for (int t = 0; t < T; ++t) p.probs[((int64_t)n * p.f + f) * T + t] = P[t];
+    __syncthreads();
+
+    // ---- pass 2: dP ----
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
+    for (int c = grp; c < p.c; c += G) {
+        const int64_t o = (int64_t)c * p.f + fc;
+        const float dgv = dan[o] * xn[o] * r;
+        if (valid && p.dg) p.dg[plane + (int64_t)c * p.f + f] = dgv;
+        const float4* w4 = reinterpret_cast<const float4*>(tv + c * TMAX);
+#pragma unroll
+        for (int q = 0; q < TMAX / 4; ++q) {
+            const float4 w = w4[q];
+            s[4 * q + 0] += dgv * w.x; s[4 * q + 1] += dgv * w.y; s[4 * q + 2] += dgv * w.z; s[4 * q + 3] += dgv * w.w;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) part[(grp * (TMAX + 1) + t) * PXB + px] = s[t];
+    __syncthreads();
+    float pdp = 0.f;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        float v = 0.f;
+        for (int g = 0; g < G; ++g) v += part[(g * (TMAX + 1) + t) * PXB + px];
+        s[t] = v;
+        pdp += P[t] * v;
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) s[t] = P[t] * (s[t] - pdp);          // dS
+    const float coef = pdp * r * r / (float)p.c;
+
+    // ---- pass 3: dx ----
+    float* dxn = p.dx + plane;
+    for (int c = grp; c < p.c; c += G) {
+        const int64_t o = (int64_t)c * p.f + fc;
+        const float4* v4 = reinterpret_cast<const float4*>(tv + c * TMAX);
+        const float4* q4 = reinterpret_cast<const float4*>(tq + c * TMAX);
+        float g = 0.f, qs = 0.f;
+#pragma unroll
+        for (int q = 0; q < TMAX / 4; ++q) {
+            const float4 a = v4[q], b = q4[q];
+            g += P[4 * q + 0] * a.x + P[4 * q + 1] * a.y + P[4 * q + 2] * a.z + P[4 * q + 3] * a.w;
+            qs += s[4 * q + 0] * b.x + s[4 * q + 1] * b.y + s[4 * q + 2] * b.z + s[4 * q + 3] * b.w;
+        }
+        const float v = dan[o] * r * g - coef * xn[o] + qs;
+        if (valid) dxn[(int64_t)c * p.f + f] = v;
+    }
+}
+
+// dvwb[n,c,t] = sum_f dg[n,c,f] * P[n,f,t]; grid (cdiv(c,4), n): a workgroup owns 4 channels and streams all pixels once
+__global__ __launch_bounds__(256) void attn_values_grad_kernel(float* dvwb, const float* dg, const float* probs, int c, int f, int T) {
+    __shared__ float red[4][4 * TMAX];
+    const int c0 = blockIdx.x * 4, n = blockIdx.y, tid = threadIdx.x;
+    float acc[4][TMAX];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) acc[u][t] = 0.f;
+    const float* pn = probs + (int64_t)n * f * T;
+    const float* dgn = dg + (int64_t)n * c * f;
+    for (int i = tid; i < f; i += 256) {
+        float pv[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) pv[t] = t < T ? pn[(int64_t)i * T + t] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float dv = (c0 + u < c) ? dgn[(int64_t)(c0 + u) * f + i] : 0.f;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) acc[u][t] += dv * pv[t];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            const float v = wave_sum(acc[u][t]);
+            if ((tid & 63) == 0) red[tid >> 6][u * TMAX + t] = v;
+        }
+    __syncthreads();
+    if (tid < 4 * TMAX) {
+        const int u = tid / TMAX, t = tid % TMAX;
+        if (c0 + u < c && t < T) dvwb[((int64_t)n * c + c0 + u) * T + t] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ latent-side backward
+// grid (njobs, n): d(style) -> d(global latent component) for one modulated layer (see the header comment)
+__global__ __launch_bounds__(256) void style_demod_bwd_kernel(float* dwg, const mgf_style_bwd_job* jobs, int njobs, int wdim) {
+    __shared__ float tl[2048];
+    __shared__ float dst[2048];
+    __shared__ float red[256];
+    const mgf_style_bwd_job j = jobs[blockIdx.x];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const bool demod = j.wsq && j.d && j.dc_part;
+    if (demod) {
+        for (int o = tid; o < j.cout; o += 256) {
+            const float* pp = j.dc_part + ((int64_t)n * j.cout + o) * j.d_chunks;
+            float acc = 0.f;
+            for (int q = 0; q < j.d_chunks; ++q) acc += pp[q];
+            const float dv = j.d[(int64_t)n * j.cout + o];
+            tl[o] = acc * dv * dv;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < j.cin; i += 256) {
+        const float* pp = j.ds_part + ((int64_t)n * j.cin + i) * j.s_chunks;
+        float acc = 0.f;
+        for (int q = 0; q < j.s_chunks; ++q) acc += pp[q];
+        if (demod) {
+            float dem = 0.f;
+            for (int o = 0; o < j.cout; ++o) dem += tl[o] * j.wsq[(int64_t)o * j.cin + i];
+            acc -= j.s[(int64_t)n * j.cin + i] * dem;
+        }
+        dst[i] = acc;
+    }
+    __syncthreads();
+    const int k = tid % wdim, sl = tid / wdim, nsl = 256 / wdim;
+    float acc = 0.f;
+    for (int i = sl; i < j.cin; i += nsl) acc += dst[i] * j.aff_w[(int64_t)i * wdim + k];
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < wdim) {
+        float v = 0.f;
+        for (int q = 0; q < nsl; ++q) v += red[q * wdim + tid];
+        dwg[((int64_t)n * njobs + blockIdx.x) * wdim + tid] = v * j.aff_gain * j.style_gain;
+    }
+}
+
+// grid (njobs, n): dyc[n, job, t, k] = sum_c dvwb[n,c,t] * wmv[c,k]
+__global__ __launch_bounds__(256) void attn_values_bwd_kernel(float* dyc, const mgf_attn_bwd_job* jobs, int njobs, int T, int wdim) {
+    const mgf_attn_bwd_job j = jobs[blockIdx.x];
+    const int n = blockIdx.y;
+    const float* dv = j.dvwb + (int64_t)n * j.c * T;
+    for (int idx = threadIdx.x; idx < T * wdim; idx += 256) {
+        const int t = idx / wdim, k = idx % wdim;
+        float acc = 0.f;
+        for (int c = 0; c < j.c; ++c) acc += dv[(int64_t)c * T + t] * j.wmv[(int64_t)c * wdim + k];
+        dyc[(((int64_t)n * njobs + blockIdx.x) * T + t) * wdim + k] = acc;
+    }
+}
+
+// dw[n, t < T, :] = sum_jobs dyc ; dw[n, T, :] = sum_jobs dwg       (k = T + 1 rows), times `scale`
+__global__ __launch_bounds__(256) void latent_grad_gather_kernel(float* dw, const float* dwg, int njs, const float* dyc, int nja, int k,
+                                                                 int wdim, float scale) {
+    const int n = blockIdx.x, T = k - 1;
+    for (int idx = threadIdx.x; idx < k * wdim; idx += 256) {
+        const int row = idx / wdim, col = idx % wdim;
+        float acc = 0.f;
+        if (row < T) {
+            for (int q = 0; q < nja; ++q) acc += dyc[(((int64_t)n * nja + q) * T + row) * wdim + col];
+        } else {
+            for (int q = 0; q < njs; ++q) acc += dwg[((int64_t)n * njs + q) * wdim + col];
+        }
+        dw[(int64_t)n * k * wdim + idx] = acc * scale;
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t mgf_bwd_chunks(int64_t hw) { return (int32_t)mgf_cdiv(hw, BWD_CHUNK); }
+
+extern "C" int mgf_layer_act_bwd_f32(float* dz, float* dot_part, const float* dy, const float* y, const float* residual, const float* bias,
+                                     const float* noise, const float* noise_strength, int32_t noise_n, int32_t n, int32_t c, int64_t hw,
+                                     float alpha, float gain, mgf_stream_t stream) {
+    MGF_REQUIRE(dz && dy && y && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "layer_act_bwd: bad arguments");
+    MGF_REQUIRE(alpha != 0.f && gain != 0.f, MGF_EINVAL, "layer_act_bwd: alpha and gain must be non-zero (the activation is inverted)");
+    MGF_REQUIRE(n <= 65535 && c <= 65535, MGF_ETOOBIG, "layer_act_bwd: n and c must be <= 65535");
+    ActBwdParams p{dz, dot_part, dy, y, residual, bias, noise, noise_strength, noise_n, c, (int)mgf_cdiv(hw, BWD_CHUNK), hw, alpha, gain};
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
+    MGF_CHECK_LAUNCH("layer_act_bwd");
+    return MGF_OK;
+}
+
+extern "C" int mgf_channel_dot_f32(float* dot_part, const float* a, const float* b, int32_t n, int32_t c, int64_t hw, mgf_stream_t stream) {
+    MGF_REQUIRE(dot_part && a && b && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "channel_dot: bad arguments");
+    MGF_REQUIRE(n <= 65535 && c <= 65535, MGF_ETOOBIG, "channel_dot: n and c must be <= 65535");
+    const int nchunk = (int)mgf_cdiv(hw, BWD_CHUNK);
+    hipLaunchKernelGGL(channel_dot_kernel, dim3(nchunk, c, n), dim3(256), 0, (hipStream_t)stream, dot_part, a, b, c, hw, nchunk);
+    MGF_CHECK_LAUNCH("channel_dot");
+    return MGF_OK;
+}
+
+extern "C" int mgf_style_grad_f32(float* dot_part, float* dx, const float* x, const float* g, const float* s, int32_t n, int32_t c,
+                                  int64_t hw, int32_t accumulate, mgf_stream_t stream) {
+    MGF_REQUIRE(dot_part && dx && x && g && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "style_grad: bad arguments");
+    MGF_REQUIRE(n <= 65535 && c <= 65535, MGF_ETOOBIG, "style_grad: n and c must be <= 65535");
+    const int nchunk = (int)mgf_cdiv(hw, BWD_CHUNK);
+    hipLaunchKernelGGL(style_grad_kernel, dim3(nchunk, c, n), dim3(256), 0, (hipStream_t)stream, dot_part, dx, x, g, s, c, hw, nchunk,
+                       accumulate);
+    MGF_CHECK_LAUNCH("style_grad");
+    return MGF_OK;
+}
+
+extern "C" int mgf_duplex_attention_bwd(float* dx, float* dg, float* probs, const float* da, const float* x, const float* wqc,
+                                        const float* spos, const float* vwb, int32_t n, int32_t c, int32_t f, int32_t t,
+                                        mgf_stream_t stream) {
+    MGF_REQUIRE(dx && da && x && wqc && spos && vwb, MGF_EINVAL, "duplex_attention_bwd: null pointer");
+    MGF_REQUIRE(n >= 1 && c >= 1 && f >= 1, MGF_EINVAL, "duplex_attention_bwd: bad shape");
+    MGF_REQUIRE(t >= 1 && t <= TMAX, MGF_EUNSUPPORTED, "duplex_attention_bwd: supports 1..%d latent components (got %d)", TMAX, t);
+    MGF_REQUIRE(n <= 65535 && (int64_t)n * c * f <= INT32_MAX, MGF_ETOOBIG, "duplex_attention_bwd: tensor too large");
+    constexpr int PXB = 16, G = 256 / PXB;
+    AttnBwdParams p{dx, dg, probs, da, x, wqc, spos, vwb, n, c, f, t, (int)(mgf_cdiv(c, 4) * 4)};
+    const size_t lds = ((size_t)2 * p.c_pad * TMAX + (size_t)G * (TMAX + 1) * PXB) * sizeof(float);
+    MGF_REQUIRE(lds <= 150 * 1024, MGF_EUNSUPPORTED, "duplex_attention_bwd: %d channels need %zu bytes of LDS", c, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)duplex_attention_bwd_kernel<PXB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { mgf_set_error("duplex_attention_bwd: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
+    }
+    hipLaunchKernelGGL(duplex_attention_bwd_kernel<PXB>, dim3((unsigned)mgf_cdiv(f, PXB), n), dim3(256), lds, (hipStream_t)stream, p);
+    MGF_CHECK_LAUNCH("duplex_attention_bwd");
+    return MGF_OK;
+}
+
+extern "C" int mgf_attn_values_grad(float* dvwb, const float* dg, const float* probs, int32_t n, int32_t c, int32_t f, int32_t t,
+                                    mgf_stream_t stream) {
+    MGF_REQUIRE(dvwb && dg && probs && n >= 1 && c >= 1 && f >= 1, MGF_EINVAL, "attn_values_grad: bad arguments");
+    MGF_REQUIRE(t >= 1 && t <= TMAX, MGF_EUNSUPPORTED, "attn_values_grad: supports 1..%d latent components (got %d)", TMAX, t);
+    MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "attn_values_grad: n must be <= 65535");
+    hipLaunchKernelGGL(attn_values_grad_kernel, dim3((unsigned)mgf_cdiv(c, 4), n), dim3(256), 0, (hipStream_t)stream, dvwb, dg, probs, c, f, t);
+    MGF_CHECK_LAUNCH("attn_values_grad");
+    return MGF_OK;
+}
+
+extern "C" int mgf_style_demod_bwd_multi(float* dwg, const mgf_style_bwd_job* jobs_dev, int32_t njobs, int32_t n, int32_t wdim,
+                                         int32_t max_channels, mgf_stream_t stream) {
+    MGF_REQUIRE(dwg && jobs_dev && njobs >= 1 && n >= 1, MGF_EINVAL, "style_demod_bwd_multi: bad arguments");
+    MGF_REQUIRE(wdim >= 1 && wdim <= 256 && 256 % wdim == 0, MGF_EUNSUPPORTED, "style_demod_bwd_multi: wdim must divide 256 (got %d)", wdim);
+    MGF_REQUIRE(max_channels >= 1 && max_channels <= 2048, MGF_EUNSUPPORTED, "style_demod_bwd_multi: at most 2048 channels per layer (got %d)", max_channels);
+    MGF_REQUIRE(njobs <= 65535 && n <= 65535, MGF_ETOOBIG, "style_demod_bwd_multi: too many jobs/samples");
+    hipLaunchKernelGGL(style_demod_bwd_kernel, dim3(njobs, n), dim3(256), 0, (hipStream_t)stream, dwg, jobs_dev, njobs, wdim);
+    MGF_CHECK_LAUNCH("style_demod_bwd_multi");
+    return MGF_OK;
+}
+
+extern "C" int mgf_attn_values_bwd_multi(float* dyc, const mgf_attn_bwd_job* jobs_dev, int32_t njobs, int32_t n, int32_t t, int32_t wdim,
+                                         mgf_stream_t stream) {
+    MGF_REQUIRE(dyc && jobs_dev && njobs >= 1 && n >= 1 && t >= 1 && wdim >= 1, MGF_EINVAL, "attn_values_bwd_multi: bad arguments");
+    MGF_REQUIRE(njobs <= 65535 && n <= 65535, MGF_ETOOBIG, "attn_values_bwd_multi: too many jobs/samples");
+    hipLaunchKernelGGL(attn_values_bwd_kernel, dim3(njobs, n), dim3(256), 0, (hipStream_t)stream, dyc, jobs_dev, njobs, t, wdim);
+    MGF_CHECK_LAUNCH("attn_values_bwd_multi");
+    return MGF_OK;
+}
+
+extern "C" int mgf_latent_grad_gather(float* dw, const float* dwg, int32_t n_style_jobs, const float* dyc, int32_t n_attn_jobs, int32_t n,
+                                      int32_t k, int32_t wdim, float scale, mgf_stream_t stream) {
+    MGF_REQUIRE(dw && n >= 1 && k >= 2 && wdim >= 1, MGF_EINVAL, "latent_grad_gather: bad arguments");
+    MGF_REQUIRE((dwg || n_style_jobs == 0) && (dyc || n_attn_jobs == 0), MGF_EINVAL, "latent_grad_gather: null partials");
+    hipLaunchKernelGGL(latent_grad_gather_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dw, dwg, n_style_jobs, dyc, n_attn_jobs, k, wdim,
+                       scale);
+    MGF_CHECK_LAUNCH("latent_grad_gather");
+    return MGF_OK;
+}

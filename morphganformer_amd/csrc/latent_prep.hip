@@ -168,14 +168,46 @@ __device__ void fc_rows(float* out, const float* in, const float* W, const float
     }
 }
 
-__global__ __launch_bounds__(256) void mapping_kernel(float* w, const float* z, const float* P, int k, int n_res, int normalize_global) {
-    __shared__ float X[MT_MAX * MD], Xin[MT_MAX * MD], Q[MT_MAX * MD], K[MT_MAX * MD], V[MT_MAX * MD], H[MT_MAX * MD];
-    __shared__ float Pr[MT_MAX * MT_MAX];
-    __shared__ float G[MD], Gin[MD], GH[MD];
-    __shared__ float red[4];
-    const int n = blockIdx.x, tid = threadIdx.x;
+// out[r][i] = sum_o in[r][o] * W[o][i]   (the transposed product of the backward pass)
+__device__ void fc_rows_t(float* out, const float* in, const float* W, int rows, bool accumulate) {
+    for (int idx = threadIdx.x; idx < rows * MD; idx += blockDim.x) {
+        const int r = idx / MD, i = idx % MD;
+        const float* xr = in + r * MD;
+        float acc = 0.f;
+#pragma unroll
+        for (int o = 0; o < MD; ++o) acc += xr[o] * W[o * MD + i];
+        out[idx] = accumulate ? out[idx] + acc : acc;
+    }
+}
+
+struct MapShared {
+    float X[MT_MAX * MD], Xin[MT_MAX * MD], Q[MT_MAX * MD], K[MT_MAX * MD], V[MT_MAX * MD], H[MT_MAX * MD];
+    float Pr[MT_MAX * MT_MAX];
+    float G[MD], Gin[MD], GH[MD];
+    float red[4];
+};
+
+// Per-sample scratch of the backward pass (floats): what the recomputed forward leaves behind.
+//   global path, per res layer: {H0 (post-lrelu fc0), Xo (layer output)} = 2 D
+//   local  path, per res layer: {Q, K, V, H0, Xo} (T D each), P (T T)
+struct MapSave {
+    int T, n_res;
+    __host__ __device__ int64_t glayer(int l) const { return (int64_t)l * 2 * MD; }
+    __host__ __device__ int64_t lbase() const { return (int64_t)n_res * 2 * MD; }
+    __host__ __device__ int64_t lstride() const { return (int64_t)5 * T * MD + (int64_t)T * T; }
+    __host__ __device__ int64_t llayer(int l) const { return lbase() + l * lstride(); }
+    __host__ __device__ int64_t total() const { return lbase() + n_res * lstride(); }
+};
+
+// Forward of one sample; SAVE additionally stores the per-layer activations the backward pass needs into `sv`.
+template <bool SAVE>
+__device__ void mapping_forward_body(MapShared& sh, float* w_n, const float* zn, const float* P, int k, int n_res, int normalize_global,
+                                     float* sv, float* norm_out) {
+    float *X = sh.X, *Xin = sh.Xin, *Q = sh.Q, *K = sh.K, *V = sh.V, *H = sh.H, *Pr = sh.Pr, *G = sh.G, *Gin = sh.Gin, *GH = sh.GH;
+    float* red = sh.red;
+    const int tid = threadIdx.x;
     const int T = k - 1;
-    const float* zn = z + (int64_t)n * k * MD;
+    const MapSave ms{T, n_res};
     // ---- normalize (networks.py:30-37): joint second moment over the T x D local block; global row separately ----
     float part = 0.f;
     for (int i = tid; i < T * MD; i += blockDim.x) { float v = zn[i]; part += v * v; }
@@ -190,6 +222,7 @@ __global__ __launch_bounds__(256) void mapping_kernel(float* w, const float* z, 
         float ss = wave_sum(v * v);
         float fg = normalize_global ? rsqrtf(ss / (float)MD + 1e-8f) : 1.f;
         if (tid < MD) G[tid] = v * fg;
+        if (SAVE && tid == 0) { norm_out[0] = fl; norm_out[1] = fg; }
     }
     __syncthreads();
 
@@ -203,11 +236,17 @@ __global__ __launch_bounds__(256) void mapping_kernel(float* w, const float* z, 
         __syncthreads();
         fc_rows(GH, G, W0, b0, false, 1);
         __syncthreads();
-        if (tid < MD) GH[tid] = lrelu02(GH[tid]) * 1.41421356237309515f;
+        if (tid < MD) {
+            GH[tid] = lrelu02(GH[tid]) * 1.41421356237309515f;
+            if (SAVE) sv[ms.glayer(l) + tid] = GH[tid];
+        }
         __syncthreads();
         fc_rows(G, GH, W1, b1, false, 1);
         __syncthreads();
-        if (tid < MD) G[tid] = lrelu02(G[tid] + Gin[tid]);
+        if (tid < MD) {
+            G[tid] = lrelu02(G[tid] + Gin[tid]);
+            if (SAVE) sv[ms.glayer(l) + MD + tid] = G[tid];
+        }
         __syncthreads();
     }
     {
@@ -215,7 +254,7 @@ __global__ __launch_bounds__(256) void mapping_kernel(float* w, const float* z, 
         p = bo + MD;
         fc_rows(GH, G, Wo, bo, false, 1);
         __syncthreads();
-        if (tid < MD) w[((int64_t)n * k + T) * MD + tid] = lrelu02(GH[tid]) * 1.41421356237309515f;
+        if (tid < MD) w_n[T * MD + tid] = lrelu02(GH[tid]) * 1.41421356237309515f;
     }
     // ---- local MLP with latent self-attention ----
     for (int l = 0; l < n_res; ++l) {
@@ -226,11 +265,15 @@ __global__ __launch_bounds__(256) void mapping_kernel(float* w, const float* z, 
         const float* W0 = bm + MD;      const float* b0 = W0 + WSZ;
         const float* W1 = b0 + MD;      const float* b1 = W1 + WSZ;
         p = b1 + MD;
+        float* svl = SAVE ? sv + ms.llayer(l) : nullptr;
+        const int TD = T * MD;
         for (int i = tid; i < T * MD; i += blockDim.x) Xin[i] = X[i];
         fc_rows(Q, X, Wq, bq, true, T);          // 1/sqrt(D) and the positional term are folded into Wq / bq
         fc_rows(K, X, Wk, bk, true, T);
         fc_rows(V, X, Wv, bv, false, T);
         __syncthreads();
+        if (SAVE)
+            for (int i = tid; i < TD; i += blockDim.x) { svl[i] = Q[i]; svl[TD + i] = K[i]; svl[2 * TD + i] = V[i]; }
         for (int idx = tid; idx < T * T; idx += blockDim.x) {
             const int a = idx / T, b = idx % T;
             float acc = 0.f;
@@ -245,7 +288,10 @@ __global__ __launch_bounds__(256) void mapping_kernel(float* w, const float* z, 
             float s = 0.f;
             for (int b = 0; b < T; ++b) { float e = expf(Pr[tid * MT_MAX + b] - m); Pr[tid * MT_MAX + b] = e; s += e; }
             const float inv = 1.f / s;
-            for (int b = 0; b < T; ++b) Pr[tid * MT_MAX + b] *= inv;
+            for (int b = 0; b < T; ++b) {
+                Pr[tid * MT_MAX + b] *= inv;
+                if (SAVE) svl[5 * TD + tid * T + b] = Pr[tid * MT_MAX + b];
+            }
         }
         __syncthreads();
         for (int idx = tid; idx < T * MD; idx += blockDim.x) {
@@ -261,18 +307,174 @@ __global__ __launch_bounds__(256) void mapping_kernel(float* w, const float* z, 
         __syncthreads();
         fc_rows(H, X, W0, b0, false, T);
         __syncthreads();
-        for (int i = tid; i < T * MD; i += blockDim.x) H[i] = lrelu02(H[i]) * 1.41421356237309515f;
+        for (int i = tid; i < T * MD; i += blockDim.x) {
+            H[i] = lrelu02(H[i]) * 1.41421356237309515f;
+            if (SAVE) svl[3 * TD + i] = H[i];
+        }
         __syncthreads();
         fc_rows(Q, H, W1, b1, false, T);
         __syncthreads();
-        for (int i = tid; i < T * MD; i += blockDim.x) X[i] = lrelu02(Q[i] + Xin[i]);
+        for (int i = tid; i < T * MD; i += blockDim.x) {
+            X[i] = lrelu02(Q[i] + Xin[i]);
+            if (SAVE) svl[4 * TD + i] = X[i];
+        }
         __syncthreads();
     }
     {
         const float *Wo = p, *bo = p + WSZ;
         fc_rows(H, X, Wo, bo, false, T);
         __syncthreads();
-        for (int i = tid; i < T * MD; i += blockDim.x) w[(int64_t)n * k * MD + i] = lrelu02(H[i]) * 1.41421356237309515f;
+        for (int i = tid; i < T * MD; i += blockDim.x) w_n[i] = lrelu02(H[i]) * 1.41421356237309515f;
+    }
+}
+
+__global__ __launch_bounds__(256) void mapping_kernel(float* w, const float* z, const float* P, int k, int n_res, int normalize_global) {
+    __shared__ MapShared sh;
+    const int n = blockIdx.x;
+    mapping_forward_body<false>(sh, w + (int64_t)n * k * MD, z + (int64_t)n * k * MD, P, k, n_res, normalize_global, nullptr, nullptr);
+}
+
+__device__ __forceinline__ float dlrelu02(float y) { return y > 0.f ? 1.f : 0.2f; }
+
+// dz from dw: the forward is recomputed with SAVE into this sample's scratch slab, then the layers are walked in reverse.
+// Scratch slab: [MapSave::total() activations][k*D recomputed w][2 normalisation factors].
+__global__ __launch_bounds__(256) void mapping_backward_kernel(float* dz, const float* dw, const float* z, const float* P, float* scratch,
+                                                               int64_t slab, int k, int n_res, int normalize_global) {
+    __shared__ MapShared sh;
+    __shared__ float dX[MT_MAX * MD], A[MT_MAX * MD];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int T = k - 1, TD = T * MD, WSZ = MD * MD;
+    const MapSave ms{T, n_res};
+    float* sv = scratch + (int64_t)n * slab;
+    float* wrec = sv + ms.total();
+    float* nrm = wrec + (int64_t)k * MD;
+    const float* zn = z + (int64_t)n * k * MD;
+    const float* dwn = dw + (int64_t)n * k * MD;
+    float* dzn = dz + (int64_t)n * k * MD;
+    mapping_forward_body<true>(sh, wrec, zn, P, k, n_res, normalize_global, sv, nrm);
+    __syncthreads();                                 // the slab was written by this workgroup: visible after the barrier
+    const float SQ2 = 1.41421356237309515f;
+    const int64_t gstride = 2 * WSZ + 2 * MD;
+    const float* Pg_out = P + n_res * gstride;
+    const float* Pl = Pg_out + WSZ + MD;
+    const int64_t lstride = 6 * (int64_t)WSZ + 2 * (int64_t)TD + 4 * MD;
+    const float* Pl_out = Pl + n_res * lstride;
+    float *B = sh.H, *Cx = sh.X, *Dh = sh.Xin, *dQ = sh.Q, *dK = sh.K, *dV = sh.V, *Pr = sh.Pr;
+
+    // ---- local path ----
+    for (int i = tid; i < TD; i += blockDim.x) A[i] = dwn[i] * SQ2 * dlrelu02(wrec[i]);
+    __syncthreads();
+    fc_rows_t(dX, A, Pl_out, T, false);              // through the out layer
+    __syncthreads();
+    for (int l = n_res - 1; l >= 0; --l) {
+        const float* p = Pl + l * lstride;
+        const float* Wq = p;            const float* bq = Wq + WSZ;
+        const float* Wk = bq + TD;      const float* bk = Wk + WSZ;
+        const float* Wv = bk + TD;      const float* bv = Wv + WSZ;
+        const float* Wm = bv + MD;      const float* bm = Wm + WSZ;
+        const float* W0 = bm + MD;      const float* b0 = W0 + WSZ;
+        const float* W1 = b0 + MD;
+        const float* svl = sv + ms.llayer(l);
+        const float *sQ = svl, *sK = svl + TD, *sV = svl + 2 * TD, *sH0 = svl + 3 * TD, *sXo = svl + 4 * TD, *sP = svl + 5 * TD;
+        for (int i = tid; i < TD; i += blockDim.x) A[i] = dX[i] * dlrelu02(sXo[i]);           // d(F1 + Xin)
+        __syncthreads();
+        fc_rows_t(B, A, W1, T, false);
+        __syncthreads();
+        for (int i = tid; i < TD; i += blockDim.x) B[i] *= SQ2 * dlrelu02(sH0[i]);
+        __syncthreads();
+        fc_rows_t(Cx, B, W0, T, false);              // dXs (= dM, and the direct path into X)
+        __syncthreads();
+        fc_rows_t(Dh, Cx, Wm, T, false);             // d(P V)
+        __syncthreads();
+        for (int idx = tid; idx < T * T; idx += blockDim.x) {
+            const int a = idx / T, b = idx % T;
+            float acc = 0.f;
+#pragma unroll
+            for (int o = 0; o < MD; ++o) acc += Dh[a * MD + o] * sV[b * MD + o];
+            Pr[a * MT_MAX + b] = acc;                // dP
+        }
+        for (int idx = tid; idx < TD; idx += blockDim.x) {
+            const int b = idx / MD, o = idx % MD;
+            float acc = 0.f;
+            for (int a = 0; a < T; ++a) acc += sP[a * T + b] * Dh[a * MD + o];
+            dV[idx] = acc;
+        }
+        __syncthreads();
+        if (tid < T) {
+            float pdp = 0.f;
+            for (int b = 0; b < T; ++b) pdp += sP[tid * T + b] * Pr[tid * MT_MAX + b];
+            for (int b = 0; b < T; ++b) Pr[tid * MT_MAX + b] = sP[tid * T + b] * (Pr[tid * MT_MAX + b] - pdp);     // dScores
+        }
+        __syncthreads();
+        for (int idx = tid; idx < TD; idx += blockDim.x) {
+            const int r = idx / MD, i = idx % MD;
+            float aq = 0.f, ak = 0.f;
+            for (int b = 0; b < T; ++b) {
+                aq += Pr[r * MT_MAX + b] * sK[b * MD + i];
+                ak += Pr[b * MT_MAX + r] * sQ[b * MD + i];
+            }
+            dQ[idx] = aq;
+            dK[idx] = ak;
+        }
+        __syncthreads();
+        for (int i = tid; i < TD; i += blockDim.x) dX[i] = Cx[i] + A[i];
+        __syncthreads();
+        fc_rows_t(dX, dQ, Wq, T, true);
+        __syncthreads();
+        fc_rows_t(dX, dK, Wk, T, true);
+        __syncthreads();
+        fc_rows_t(dX, dV, Wv, T, true);
+        __syncthreads();
+    }
+    // normalize backward: X0 = z * fl,  fl = rsqrt(mean z^2 + eps)  =>  dz = fl dX0 - z fl^3 <dX0, z> / (T D)
+    {
+        float part = 0.f;
+        for (int i = tid; i < TD; i += blockDim.x) part += dX[i] * zn[i];
+        part = wave_sum(part);
+        __syncthreads();
+        if ((tid & 63) == 0) sh.red[tid >> 6] = part;
+        __syncthreads();
+        const float dot = sh.red[0] + sh.red[1] + sh.red[2] + sh.red[3];
+        const float fl = nrm[0];
+        const float coef = fl * fl * fl * dot / (float)TD;
+        for (int i = tid; i < TD; i += blockDim.x) dzn[i] = fl * dX[i] - zn[i] * coef;
+    }
+    __syncthreads();
+    // ---- global path (one row) ----
+    float* dG = sh.G;
+    float* tA = sh.Gin;
+    float* tB = sh.GH;
+    if (tid < MD) tA[tid] = dwn[TD + tid] * SQ2 * dlrelu02(wrec[TD + tid]);
+    __syncthreads();
+    fc_rows_t(dG, tA, Pg_out, 1, false);
+    __syncthreads();
+    for (int l = n_res - 1; l >= 0; --l) {
+        const float* p = P + l * gstride;
+        const float *W0 = p, *b0 = p + WSZ, *W1 = b0 + MD;
+        const float* svl = sv + ms.glayer(l);
+        if (tid < MD) tA[tid] = dG[tid] * dlrelu02(svl[MD + tid]);
+        __syncthreads();
+        fc_rows_t(tB, tA, W1, 1, false);
+        __syncthreads();
+        if (tid < MD) tB[tid] *= SQ2 * dlrelu02(svl[tid]);
+        __syncthreads();
+        fc_rows_t(dG, tB, W0, 1, false);
+        __syncthreads();
+        if (tid < MD) dG[tid] += tA[tid];
+        __syncthreads();
+    }
+    if (tid < 64) {
+        const float zv = tid < MD ? zn[TD + tid] : 0.f;
+        const float gv = tid < MD ? dG[tid] : 0.f;
+        const float dot = wave_sum(zv * gv);
+        if (tid < MD) {
+            if (normalize_global) {
+                const float fg = nrm[1];
+                dzn[TD + tid] = fg * gv - zv * fg * fg * fg * dot / (float)MD;
+            } else {
+                dzn[TD + tid] = gv;
+            }
+        }
     }
 }
 
@@ -333,6 +535,24 @@ extern "C" int64_t mgf_mapping_param_floats(int32_t k, int32_t dim, int32_t n_re
     const int64_t glob = n_res_layers * (2 * W + 2 * dim) + W + dim;
     const int64_t loc = n_res_layers * (6 * W + 2 * T * dim + 4 * dim) + W + dim;
     return glob + loc;
+}
+
+extern "C" int64_t mgf_mapping_bwd_scratch_floats(int32_t k, int32_t dim, int32_t n_res_layers) {
+    if (dim != MD || k < 2) return -1;
+    const MapSave ms{k - 1, n_res_layers};
+    return ms.total() + (int64_t)k * MD + 2;
+}
+
+extern "C" int mgf_mapping_backward(float* dz, const float* dw, const float* z, const float* params, float* scratch, int32_t n, int32_t k,
+                                    int32_t dim, int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream) {
+    MGF_REQUIRE(dz && dw && z && params && scratch, MGF_EINVAL, "mapping_backward: null pointer");
+    MGF_REQUIRE(dim == MD, MGF_EUNSUPPORTED, "mapping_backward: latent width must be %d (got %d)", MD, dim);
+    MGF_REQUIRE(k >= 2 && k - 1 <= MT_MAX, MGF_EUNSUPPORTED, "mapping_backward: k must be in 2..%d (got %d)", MT_MAX + 1, k);
+    MGF_REQUIRE(n >= 1 && n_res_layers >= 0, MGF_EINVAL, "mapping_backward: bad sizes");
+    hipLaunchKernelGGL(mapping_backward_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dz, dw, z, params, scratch,
+                       mgf_mapping_bwd_scratch_floats(k, dim, n_res_layers), k, n_res_layers, normalize_global);
+    MGF_CHECK_LAUNCH("mapping_backward");
+    return MGF_OK;
 }
 
 extern "C" int mgf_mapping_forward(float* w, const float* z, const float* params, int32_t n, int32_t k, int32_t dim,

@@ -210,6 +210,7 @@ class Generator:
         self._ws_cache = {}
         self.taps = None
         self.fuse_torgb = True
+        self.last_noise = ("none", None)      # (noise_mode, noises) of the latest synthesis call, read by grad.SynthesisGrad
         self.side = torch.cuda.Stream(device=self.device)
         self.overlap_skip = os.environ.get("MGF_OVERLAP_SKIP", "1") != "0"      # tuning hook: 0 serialises the skip branch
         self._alloc(max_batch)
@@ -329,6 +330,7 @@ class Generator:
                        "attn_values_multi")
         if noise_mode == "random":
             noises = self._draw_noise(n)
+        self.last_noise = (noise_mode, noises)
         layers = {lp.name: lp for lp in P.layers}
         self.att_maps = {} if return_att else None
         x = None

@@ -1,0 +1,212 @@
+"""Gradient mode: d(loss)/d(latent) through the HIP generator -- the backward pass torch autograd runs for the reference when a
+projection driver differentiates its loss with respect to the latent (the north-star reading of the loop, SURVEY.md section 8a
+row P0; the literal reference loop severs this gradient, section 0.1, so gradient mode is an extension whose oracle is autograd
+through oracle/generator_ref.py, itself pinned on the reference module's own autograd by the `grad_z` vector of tests/golden/gen_tiny.npz).
+
+    gg = GeneratorGrad(G)
+    img = gg.forward(z, noise_mode="const")            # G(z)[0], keeping what the backward pass needs
+    dz = gg.backward(dimg)                              # [n, k, D] = d<img, dimg>/dz
+
+Weights are constants.  Per modulated layer  c_o = d_o * sum_i s_i (W_oi * x_i)  the pass needs (csrc/backward.hip):
+  * dx_i = s_i g_i with g_i = sum_o W_oi^T * (d_o dc_o): the forward tap-list MFMA kernel on channel-transposed taps, the
+    demodulation coefficients riding on its input-scale port (the stride-2 transposed conv's gradient is a stride-2 conv);
+  * ds_i = <x_i, g_i> - s_i sum_o <dc_o, c_o> d_o^2 wsq[o,i]: two per-channel dot products, no per-sample weight-gradient GEMM;
+  * FIR gradients = mgf_upfirdn2d with up/down swapped (upfirdn2d.py:237-256); the duplex attention has its own backward kernel.
+Activations are the forward's own buffers (nothing is stored twice); the pre-activation of a fused conv+bias+lrelu layer is
+recovered by inverting the leaky ReLU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from . import conv as cv
+from .engine import Generator
+
+
+class GeneratorGrad:
+    def __init__(self, G: Generator):
+        self.G = G
+        P = G.plan
+        self.T = {}
+        for lp in P.layers:
+            # 3x3 stride-1 correlation -> true convolution (taps reversed); the transposed conv's gradient is a plain stride-2
+            # correlation with the same taps; 1x1 needs no flip
+            self.T[lp.name] = cv.transpose_packed(lp.pc, flip=(lp.kind == "conv3"))
+        self.Tskip = {res: cv.transpose_packed(pc, flip=False) for res, pc in P.skips.items()}
+        self._bufs = {}
+        self._n = None
+        self.z = None
+        self.psi = 1.0
+        self.debug = None                 # dict -> clones of the intermediate gradients (tests / tools only)
+
+    # ------------------------------------------------------------------ workspace
+    def buf(self, role, shape):
+        key = (role, tuple(shape))
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=torch.float32, device=self.G.device)
+            self._bufs[key] = t
+        return t
+
+    def _alloc(self, n):
+        """Per-batch-size reduction buffers and the device job tables of the latent-side kernels."""
+        G, P, cfg, L = self.G, self.G.plan, self.G.cfg, _lib.lib()
+        D, T = cfg.w_dim, cfg.k - 1
+        self._n = n
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=G.device)
+        self.ds_part, self.dc_part, self.dvwb = {}, {}, {}
+        sj, aj = [], []
+        for lp in P.layers:
+            in_res = lp.res // lp.up
+            sc, dc = int(L.mgf_bwd_chunks(in_res * in_res)), int(L.mgf_bwd_chunks(lp.res * lp.res))
+            self.ds_part[lp.name] = e(n, lp.cin, sc)
+            if lp.demod:
+                self.dc_part[lp.name] = e(n, lp.cout, dc)
+            sj.append(_lib.StyleBwdJob(lp.aff_w.data_ptr(), _lib.ptr(lp.pc.wsq) if lp.demod else 0, G._s(lp).data_ptr(),
+                                       G._d(lp).data_ptr() if lp.demod else 0, self.ds_part[lp.name].data_ptr(),
+                                       self.dc_part[lp.name].data_ptr() if lp.demod else 0, lp.cin, lp.cout, sc, dc,
+                                       1.0 / math.sqrt(D), lp.style_gain))
+            if lp.attn is not None:
+                self.dvwb[lp.name] = e(n, lp.attn.c, T)
+                aj.append(_lib.AttnBwdJob(lp.attn.wmv.data_ptr(), self.dvwb[lp.name].data_ptr(), lp.attn.c, 0))
+        arr = (_lib.StyleBwdJob * len(sj))(*sj)
+        self.style_jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(G.device)
+        self.n_style_jobs = len(sj)
+        self.attn_jobs, self.n_attn_jobs = None, len(aj)
+        if aj:
+            arr = (_lib.AttnBwdJob * len(aj))(*aj)
+            self.attn_jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(G.device)
+        self.dwg = e(n, len(sj), D)
+        self.dyc = e(n, max(len(aj), 1), T, D)
+        self.dw = e(n, cfg.k, D)
+        self.dz = e(n, cfg.k, D)
+        self.map_scratch = e(n * int(L.mgf_mapping_bwd_scratch_floats(cfg.k, D, cfg.mapping_layers // 2)))
+        self.max_channels = max(max(lp.cin, lp.cout) for lp in P.layers)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, z=None, ws=None, truncation_psi=1, noise_mode="const", noises=None):
+        """G(z)[0] (or G(ws=...)) with conv_last kept in memory (the fused conv_last+ToRGB kernel never writes it)."""
+        G = self.G
+        G.fuse_torgb = False
+        try:
+            img = G(z, None, ws=ws, truncation_psi=truncation_psi, noise_mode=noise_mode, noises=noises)[0]
+        finally:
+            G.fuse_torgb = True
+        self.z = None if z is None else z.contiguous().float()
+        self.psi = float(truncation_psi) if ws is None else 1.0
+        if self._n != G.n:            # after G: its style / demod arenas (pointed to by the job tables) are sized by then
+            self._alloc(G.n)
+        return img
+
+    # ------------------------------------------------------------------ backward
+    def _layer_bwd(self, lp, dy, y_out, c_pre, residual, x_in, dx_role):
+        """One SynthesisLayer.  dy: gradient wrt the layer output y_out (= lrelu(c [attention] + noise + bias) * gain + residual);
+        c_pre: the stored demodulated conv output when the layer has attention; x_in: the layer input.  Returns d(x_in)."""
+        G, L, st = self.G, _lib.lib(), _lib.stream_ptr()
+        n, c, h, w = y_out.shape
+        hw = h * w
+        mode, noises = G.last_noise
+        noise, noise_n = G._noise_for(lp, mode, noises)
+        has_att = lp.attn is not None
+        dz = self.buf("dz", y_out.shape)
+        want_dot = lp.demod and not has_att
+        # conv_last carries neither noise nor bias/activation (engine.synthesis): alpha = gain = 1 makes the kernel a plain copy + dot
+        alpha, gain = (0.2, lp.act_gain) if lp.bias is not None else (1.0, 1.0)
+        _lib.check(L.mgf_layer_act_bwd_f32(dz.data_ptr(), self.dc_part[lp.name].data_ptr() if want_dot else None, dy.data_ptr(),
+                                           y_out.data_ptr(), _lib.ptr(residual), _lib.ptr(lp.bias), _lib.ptr(noise),
+                                           _lib.ptr(lp.noise_strength) if noise is not None else None, noise_n, n, c, hw, alpha,
+                                           gain, st), "layer_act_bwd")
+        dc = dz
+        if has_att:
+            a = lp.attn
+            T = G.cfg.k - 1
+            dc, dg, probs = self.buf("dc", y_out.shape), self.buf("dg", y_out.shape), self.buf("probs", (n, a.f, T))
+            _lib.check(L.mgf_duplex_attention_bwd(dc.data_ptr(), dg.data_ptr(), probs.data_ptr(), dz.data_ptr(), c_pre.data_ptr(),
+                                                  a.wqc.data_ptr(), a.spos.data_ptr(), G._v(lp).data_ptr(), n, a.c, a.f, T, st),
+                       "duplex_attention_bwd")
+            _lib.check(L.mgf_attn_values_grad(self.dvwb[lp.name].data_ptr(), dg.data_ptr(), probs.data_ptr(), n, a.c, a.f, T, st),
+                       "attn_values_grad")
+            if lp.demod:
+                _lib.check(L.mgf_channel_dot_f32(self.dc_part[lp.name].data_ptr(), dc.data_ptr(), c_pre.data_ptr(), n, c, hw, st),
+                           "channel_dot")
+        if self.debug is not None:
+            self.debug[lp.name + ":dc"] = dc.clone()
+        d = G._d(lp) if lp.demod else None
+        if lp.kind == "tconv":
+            dT = self.buf("dT", (n, c, h + 1, w + 1))
+            cv.upfirdn_into(dT, dc, G.plan.fir, up=1, pad=(2, 2, 2, 2), gain=4.0, flip=True)
+            g = cv.conv_forward(dT, self.T[lp.name], stride=2, pad=(0, 0), in_scale=d, out=self.buf("g", x_in.shape))
+        else:
+            pad = (1, 1) if lp.kind == "conv3" else (0, 0)
+            g = cv.conv_forward(dc, self.T[lp.name], pad=pad, in_scale=d, out=self.buf("g", x_in.shape))
+        dx = self.buf(dx_role, x_in.shape)
+        ci, hi = x_in.shape[1], x_in.shape[2] * x_in.shape[3]
+        _lib.check(L.mgf_style_grad_f32(self.ds_part[lp.name].data_ptr(), dx.data_ptr(), x_in.data_ptr(), g.data_ptr(),
+                                        G._s(lp).data_ptr(), n, ci, hi, 0, st), "style_grad")
+        return dx
+
+    def backward_w(self, dimg):
+        """dimg [n,3,R,R] -> dw [n,k,D]: gradient of <img, dimg> with respect to the intermediate latent w."""
+        G, P, cfg, L = self.G, self.G.plan, self.G.cfg, _lib.lib()
+        _lib.require_gpu(dimg)
+        n = G.n
+        assert self._n == n, "call forward() first"
+        assert tuple(dimg.shape) == tuple(G.img.shape) and dimg.dtype == torch.float32
+        dimg = dimg.contiguous()
+        st = _lib.stream_ptr()
+        D, T = cfg.w_dim, cfg.k - 1
+        layers = {lp.name: lp for lp in P.layers}
+        R = cfg.img_resolution
+        out_of = lambda res: G.bufs[res]["conv1a" if cfg.has_attention(res) else "conv1"]
+        b = f"synthesis.b{R}"
+        lt, ll = layers[b + ".torgb"], layers[b + ".conv_last"]
+        h = G.bufs[R]["last"]
+        # ToRGB: img = sum_co W[c,co] s[co] h[co] + bias (no demodulation, no activation)
+        g = cv.conv_forward(dimg, self.T[lt.name], out=self.buf("g", h.shape))
+        dh = self.buf("dh", h.shape)
+        _lib.check(L.mgf_style_grad_f32(self.ds_part[lt.name].data_ptr(), dh.data_ptr(), h.data_ptr(), g.data_ptr(),
+                                        G._s(lt).data_ptr(), n, h.shape[1], h.shape[2] * h.shape[3], 0, st), "style_grad(torgb)")
+        dx = self._layer_bwd(ll, dh, h, None, None, out_of(R), "dxin")
+        for res in reversed(cfg.block_resolutions):
+            B = G.bufs[res]
+            att = cfg.has_attention(res)
+            l1 = layers[f"synthesis.b{res}.conv1"]
+            y1 = B["conv1a"] if att else B["conv1"]
+            if res == 4:
+                self._layer_bwd(l1, dx, y1, B["conv1"] if att else None, None, G.const_in, "dxin")
+                break
+            l0 = layers[f"synthesis.b{res}.conv0"]
+            y0 = B["conv0a"] if att else B["conv0"]
+            x_prev = out_of(res // 2)
+            d_out = dx
+            if self.debug is not None:
+                self.debug[f"synthesis.b{res}:dout"] = d_out.clone()
+            dmid = self._layer_bwd(l1, d_out, y1, B["conv1"] if att else None, B["skip"], y0, "dmid")
+            dxin = self._layer_bwd(l0, dmid, y0, B["conv0"] if att else None, None, x_prev, "dxin")
+            # skip branch: y = upfirdn(conv1x1(x), up=2, pad (2,1,2,1), gain 4)  ->  conv1x1^T(upfirdn(dy, down=2, pad (1,1,1,1)))
+            dlow = self.buf("dlow", B["skip_low"].shape)
+            cv.upfirdn_into(dlow, d_out, P.fir, up=1, down=2, pad=(1, 1, 1, 1), gain=4.0, flip=True)
+            cv.conv_forward(dlow, self.Tskip[res], epilogue=_lib.make_epilogue(residual=dxin), out=dxin)
+            dx = dxin
+        _lib.check(L.mgf_style_demod_bwd_multi(self.dwg.data_ptr(), self.style_jobs.data_ptr(), self.n_style_jobs, n, D,
+                                               self.max_channels, st), "style_demod_bwd_multi")
+        if self.n_attn_jobs:
+            _lib.check(L.mgf_attn_values_bwd_multi(self.dyc.data_ptr(), self.attn_jobs.data_ptr(), self.n_attn_jobs, n, T, D, st),
+                       "attn_values_bwd_multi")
+        _lib.check(L.mgf_latent_grad_gather(self.dw.data_ptr(), self.dwg.data_ptr(), self.n_style_jobs, self.dyc.data_ptr(),
+                                            self.n_attn_jobs, n, cfg.k, D, self.psi, st), "latent_grad_gather")
+        return self.dw
+
+    def backward(self, dimg):
+        """dimg -> dz [n,k,D] (through the mapping network; forward() must have been called with z)."""
+        G, cfg, L = self.G, self.G.cfg, _lib.lib()
+        assert self.z is not None, "forward() was called with ws=...: use backward_w"
+        dw = self.backward_w(dimg)
+        _lib.check(L.mgf_mapping_backward(self.dz.data_ptr(), dw.data_ptr(), self.z.data_ptr(), G.plan.mapping_blob.data_ptr(),
+                                          self.map_scratch.data_ptr(), G.n, cfg.k, cfg.w_dim, cfg.mapping_layers // 2,
+                                          int(cfg.normalize_global), _lib.stream_ptr()), "mapping_backward")
+        return self.dz

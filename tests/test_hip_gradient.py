@@ -1,0 +1,166 @@
+"""Gradient mode: d(loss)/d(latent) through the HIP generator against torch autograd through the CPU
+oracle (oracle/generator_ref.py), which tests/test_oracle_golden.py pins on the reference module's own autograd
+(the `grad_z` vector of tests/golden/gen_tiny.npz).  Gate: max |difference| <= 1e-3 of max |gradient| (the north-star pixel tolerance, applied to
+gradients)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GRAD_TOL = 1e-3
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.grad import GeneratorGrad
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from oracle.generator_ref import to_torch_state
+    sd = make_state_dict(TINY, seed=0)
+    G = Generator(sd, TINY, "cuda", max_batch=2)
+    return GeneratorGrad(G), to_torch_state(sd), TINY
+
+
+def test_mapping_backward_matches_autograd(tiny):
+    from morphganformer_amd import _lib
+    from oracle.generator_ref import mapping_ref
+    gg, tsd, cfg = tiny
+    torch.manual_seed(5)
+    z = torch.randn(3, cfg.k, cfg.z_dim, requires_grad=True)
+    dw = torch.randn(3, cfg.k, cfg.w_dim)
+    w = mapping_ref(tsd, z, cfg)
+    (ref,) = torch.autograd.grad(w, z, dw)
+    L = _lib.lib()
+    zc, dwc = z.detach().cuda(), dw.cuda()
+    dz = torch.empty_like(zc)
+    scratch = torch.empty(3 * int(L.mgf_mapping_bwd_scratch_floats(cfg.k, cfg.w_dim, cfg.mapping_layers // 2)), device="cuda")
+    _lib.check(L.mgf_mapping_backward(dz.data_ptr(), dwc.data_ptr(), zc.data_ptr(), gg.G.plan.mapping_blob.data_ptr(), scratch.data_ptr(),
+                                      3, cfg.k, cfg.w_dim, cfg.mapping_layers // 2, int(cfg.normalize_global), _lib.stream_ptr()))
+    assert rel(dz, ref) < GRAD_TOL
+
+
+def test_layer_act_bwd_and_dots():
+    from morphganformer_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(1)
+    n, c, hw = 2, 5, 5000                               # two chunks per plane, ragged tail
+    cpre = torch.randn(n, c, hw, dtype=torch.float64)
+    noise = torch.randn(n, hw, dtype=torch.float64)
+    bias = torch.randn(c, dtype=torch.float64)
+    res = torch.randn(n, c, hw, dtype=torch.float64)
+    dy = torch.randn(n, c, hw, dtype=torch.float64)
+    ns, gain = 0.3, 0.9
+    z = cpre + noise[:, None] * ns + bias[None, :, None]
+    y = torch.nn.functional.leaky_relu(z, 0.2) * gain + res
+    dz_ref = dy * gain * torch.where(z > 0, 1.0, 0.2)
+    dot_ref = (dz_ref * cpre).sum(-1)
+    f = lambda t: t.float().cuda().contiguous()
+    yd, rd, dyd, nd, bd = f(y), f(res), f(dy), f(noise), f(bias)
+    nsd = torch.tensor([ns], device="cuda")
+    chunks = int(L.mgf_bwd_chunks(hw))
+    assert chunks == 2
+    dz = torch.empty_like(yd)
+    part = torch.empty(n, c, chunks, device="cuda")
+    _lib.check(L.mgf_layer_act_bwd_f32(dz.data_ptr(), part.data_ptr(), dyd.data_ptr(), yd.data_ptr(), rd.data_ptr(), bd.data_ptr(),
+                                       nd.data_ptr(), nsd.data_ptr(), n, n, c, hw, 0.2, gain, _lib.stream_ptr()))
+    # elements whose pre-activation is within float32 noise of zero may take either slope
+    decided = (z.abs() > 1e-5).cuda()
+    assert torch.allclose(dz[decided], f(dz_ref)[decided], rtol=1e-5, atol=1e-6)
+    assert rel(part.sum(-1), dot_ref) < 1e-4
+    # channel_dot / style_grad
+    a, b, s = f(torch.randn(n, c, hw)), f(torch.randn(n, c, hw)), f(torch.randn(n, c))
+    _lib.check(L.mgf_channel_dot_f32(part.data_ptr(), a.data_ptr(), b.data_ptr(), n, c, hw, _lib.stream_ptr()))
+    assert rel(part.sum(-1), (a.double() * b.double()).sum(-1)) < 1e-5
+    dx = torch.full_like(a, 2.0)
+    _lib.check(L.mgf_style_grad_f32(part.data_ptr(), dx.data_ptr(), a.data_ptr(), b.data_ptr(), s.data_ptr(), n, c, hw, 1, _lib.stream_ptr()))
+    assert rel(part.sum(-1), (a.double() * b.double()).sum(-1)) < 1e-5
+    assert torch.allclose(dx, 2.0 + s[:, :, None] * b, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("c,res", [(32, 8), (512, 4), (20, 6)])
+def test_duplex_attention_bwd_matches_autograd(c, res):
+    from morphganformer_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(c)
+    n, T, f = 2, 16, res * res
+    x = torch.randn(n, c, f, dtype=torch.float64, requires_grad=True)
+    wqc = torch.randn(c, T, dtype=torch.float64) / math.sqrt(c)
+    spos = torch.randn(f, T, dtype=torch.float64)
+    vwb = (1 + 0.3 * torch.randn(n, c, T, dtype=torch.float64)).requires_grad_(True)
+    da = torch.randn(n, c, f, dtype=torch.float64)
+    S = torch.einsum("ncf,ct->nft", x, wqc) + spos[None]
+    P = torch.softmax(S, -1)
+    r = torch.rsqrt(x.square().mean(1, keepdim=True) + 1e-8)
+    g = torch.einsum("nft,nct->ncf", P, vwb)
+    a = x * r * g
+    dx_ref, dv_ref = torch.autograd.grad(a, (x, vwb), da)
+    fl = lambda t: t.detach().float().cuda().contiguous()
+    xd, wq, sp, vw, dad = fl(x), fl(wqc), fl(spos), fl(vwb), fl(da)
+    dx, dg, probs = torch.empty_like(xd), torch.empty_like(xd), torch.empty(n, f, T, device="cuda")
+    _lib.check(L.mgf_duplex_attention_bwd(dx.data_ptr(), dg.data_ptr(), probs.data_ptr(), dad.data_ptr(), xd.data_ptr(), wq.data_ptr(),
+                                          sp.data_ptr(), vw.data_ptr(), n, c, f, T, _lib.stream_ptr()))
+    dv = torch.empty(n, c, T, device="cuda")
+    _lib.check(L.mgf_attn_values_grad(dv.data_ptr(), dg.data_ptr(), probs.data_ptr(), n, c, f, T, _lib.stream_ptr()))
+    assert rel(probs, P) < 1e-4
+    assert rel(dx, dx_ref) < GRAD_TOL
+    assert rel(dv, dv_ref) < GRAD_TOL
+
+
+@pytest.mark.parametrize("mode", ["const", "inject"])
+def test_tiny_synthesis_gradient_wrt_w(tiny, mode):
+    from oracle.generator_ref import mapping_ref, synthesis_ref
+    gg, tsd, cfg = tiny
+    torch.manual_seed(11)
+    z = torch.randn(2, cfg.k, cfg.z_dim)
+    dimg = torch.randn(2, 3, cfg.img_resolution, cfg.img_resolution)
+    noises_cpu = noises = None
+    if mode == "inject":
+        noises_cpu = {lp.name: torch.randn(2, lp.res, lp.res) for lp in gg.G.plan.layers if lp.noise_strength is not None}
+        noises = {k: v.cuda().reshape(2, -1) for k, v in noises_cpu.items()}
+    w = mapping_ref(tsd, z, cfg).detach().requires_grad_(True)
+    img_ref = synthesis_ref(tsd, w, cfg, mode, noises_cpu)
+    (dw_ref,) = torch.autograd.grad(img_ref, w, dimg)
+    ws = w.detach().cuda().unsqueeze(2).expand(-1, -1, cfg.num_ws, -1)
+    img = gg.forward(ws=ws, noise_mode=mode, noises=noises)
+    assert rel(img, img_ref) < 1e-3
+    dw = gg.backward_w(dimg.cuda())
+    assert rel(dw, dw_ref) < GRAD_TOL
+
+
+def test_tiny_generator_gradient_wrt_z(tiny):
+    from oracle.generator_ref import generator_ref
+    gg, tsd, cfg = tiny
+    torch.manual_seed(12)
+    z = torch.randn(2, cfg.k, cfg.z_dim, requires_grad=True)
+    target = torch.randn(2, 3, cfg.img_resolution, cfg.img_resolution) * 0.5
+    img_ref = generator_ref(tsd, z, cfg, "const")
+    loss = (img_ref - target).square().mean(dim=(1, 2, 3)).sum()
+    (dz_ref,) = torch.autograd.grad(loss, z)
+    img = gg.forward(z.detach().cuda(), noise_mode="const")
+    dimg = 2.0 * (img - target.cuda()) / target[0].numel()
+    dz = gg.backward(dimg)
+    assert rel(dz, dz_ref) < GRAD_TOL
+    # batch of one re-allocates the workspaces and must agree with the batched run
+    img1 = gg.forward(z.detach()[:1].cuda(), noise_mode="const")
+    dz1 = gg.backward(2.0 * (img1 - target[:1].cuda()) / target[0].numel())
+    assert rel(dz1, dz_ref[:1]) < GRAD_TOL
+
+
+def test_tiny_gradient_matches_reference_module(tiny, golden):
+    """d mean(img^2)/dz computed by the REFERENCE module's autograd (gen_tiny.npz, oracle/make_golden.py) vs the HIP backward."""
+    gg, tsd, cfg = tiny
+    g = golden("gen_tiny.npz")
+    z = torch.from_numpy(g["z"]).cuda()
+    img = gg.forward(z, noise_mode="const")
+    assert abs(float(img.square().mean()) - float(g["loss_sq"])) < 1e-3 * float(g["loss_sq"])
+    dz = gg.backward(2.0 * img / img.numel())
+    assert rel(dz, g["grad_z"]) < GRAD_TOL
