@@ -359,6 +359,22 @@ int64_t mgf_mapping_bwd_scratch_floats(int32_t k, int32_t dim, int32_t n_res_lay
 int mgf_mapping_backward(float* dz, const float* dw, const float* z, const float* params, float* scratch, int32_t n, int32_t k,
                          int32_t dim, int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream);
 
+/* Loss side of gradient mode (what autograd does through lpips/networks_basic.py:64-92 and torch.nn.MSELoss):
+ *   lpips_layer_bwd:   df0 (+)= d/df0 [ scale * mean_hw sum_c lin[c] (f0/(|f0|+1e-10) - f1_unit)^2 ], operands as mgf_lpips_layer_f32;
+ *                      a pixel whose channels are all zero gets a zero gradient (autograd: NaN)
+ *   relu_bwd_split:    dz = (y > 0 ? dy : 0); channels [0, c_split) go to dz_a [n, c_split, hw], the rest to dz_b [n, c - c_split, hw]
+ *                      (the two halves of a SqueezeNet Fire concat; c_split == c and dz_a == dy is the plain in-place ReLU backward)
+ *   maxpool3x3s2_ceil_bwd: dx of mgf_maxpool3x3s2_ceil_f32; a window's gradient goes to its first maximum in row-major order (torch)
+ *   mse_grad:          d (+)= scale * 2 (a - b) / numel, operands as mgf_mse_f32 */
+int mgf_lpips_layer_bwd_f32(float* df0, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c, int64_t hw,
+                            int64_t f1_batch_stride, float scale, int32_t accumulate, mgf_stream_t stream);
+int mgf_relu_bwd_split_f32(float* dz_a, float* dz_b, const float* dy, const float* y, int32_t n, int32_t c, int32_t c_split, int64_t hw,
+                           mgf_stream_t stream);
+int mgf_maxpool3x3s2_ceil_bwd_f32(float* dx, const float* dy, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h,
+                                  int32_t out_w, mgf_stream_t stream);
+int mgf_mse_grad_f32(float* d, const float* a, const float* b, int32_t n, int64_t numel, int64_t b_batch_stride, float scale,
+                     int32_t accumulate, mgf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -345,6 +345,94 @@ __global__ __launch_bounds__(256) void latent_grad_gather_kernel(float* dw, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------ loss-side backward
+// LPIPS tap (networks_basic.py:70-87): l = (scale / hw) * sum_p sum_c lin[c] (f0[c] q - u1[c])^2 with q = 1 / (|f0| + 1e-10).
+// One lane per pixel, two sweeps over the channels:  A = sum f0^2, B = sum lin f0^2, Cc = sum lin u1 f0  give
+//   <du0, f0> = k (q B - Cc),   df0[c] = q k lin[c] (f0[c] q - u1[c]) - <du0, f0> q^2 / |f0| * f0[c],   k = 2 scale / hw.
+// An all-zero pixel (|f0| = 0) gets a zero gradient (torch autograd yields NaN there: sqrt'(0) * 0).
+__global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* df0, const float* f0, const float* f1u, const float* lin, int c,
+                                                              int64_t hw, int64_t f1_bs, float k, int accumulate) {
+    const int n = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const float* a = f0 + (int64_t)n * c * hw + p;
+    const float* b = f1u + (int64_t)n * f1_bs + p;
+    float* o = df0 + (int64_t)n * c * hw + p;
+    float A = 0.f, B = 0.f, Cc = 0.f;
+    for (int ch = 0; ch < c; ++ch) {
+        const float v = a[(int64_t)ch * hw], l = lin[ch];
+        A += v * v;
+        B += l * v * v;
+        Cc += l * b[(int64_t)ch * hw] * v;
+    }
+    const float nrm = sqrtf(A);
+    const float q = 1.f / (nrm + 1e-10f);
+    const float dot = k * (q * B - Cc);
+    const float coef = nrm > 0.f ? dot * q * q / nrm : 0.f;
+    for (int ch = 0; ch < c; ++ch) {
+        const float v = a[(int64_t)ch * hw];
+        const float g = q * k * lin[ch] * (v * q - b[(int64_t)ch * hw]) - coef * v;
+        o[(int64_t)ch * hw] = accumulate ? o[(int64_t)ch * hw] + g : g;
+    }
+}
+
+// dz = dy where y > 0 else 0, channels [0, cs) to dz_a [n, cs, hw] and [cs, c) to dz_b [n, c - cs, hw] (Fire concat halves)
+__global__ __launch_bounds__(256) void relu_bwd_split_kernel(float* dz_a, float* dz_b, const float* dy, const float* y, int c, int cs,
+                                                             int64_t hw, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i % hw, r = i / hw;
+        const int ch = (int)(r % c);
+        const int64_t nn = r / c;
+        const float v = y[i] > 0.f ? dy[i] : 0.f;
+        if (ch < cs) dz_a[(nn * cs + ch) * hw + p] = v;
+        else dz_b[(nn * (c - cs) + (ch - cs)) * hw + p] = v;
+    }
+}
+
+// MaxPool2d(3, 2, ceil_mode=True) backward: the gradient of a window goes to its FIRST maximum in row-major order (torch's argmax rule)
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(float* dx, const float* dy, const float* x, int ih, int iw, int oh, int ow,
+                                                               int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ix = (int)(i % iw);
+        const int64_t r = i / iw;
+        const int iy = (int)(r % ih);
+        const int64_t pl = r / ih;
+        const float* xp = x + pl * ih * iw;
+        const float* dp = dy + pl * oh * ow;
+        float acc = 0.f;
+        for (int oy = max(0, (iy - 1) / 2); oy <= min(oh - 1, iy / 2); ++oy) {
+            if (2 * oy > iy || 2 * oy + 2 < iy) continue;
+            for (int ox = max(0, (ix - 1) / 2); ox <= min(ow - 1, ix / 2); ++ox) {
+                if (2 * ox > ix || 2 * ox + 2 < ix) continue;
+                float best = -3.4e38f;
+                int by = -1, bx = -1;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = 2 * oy + ky;
+                    if (yy >= ih) break;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = 2 * ox + kx;
+                        if (xx >= iw) break;
+                        const float v = xp[(int64_t)yy * iw + xx];
+                        if (v > best || by < 0) { best = v; by = yy; bx = xx; }
+                    }
+                }
+                if (by == iy && bx == ix) acc += dp[(int64_t)oy * ow + ox];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+// dimg (+)= scale * 2 (a - b) / numel    (gradient of scale * mean((a - b)^2) per sample)
+__global__ __launch_bounds__(256) void mse_grad_kernel(float* d, const float* a, const float* b, int64_t numel, int64_t b_bs, float k,
+                                                       int accumulate, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t nn = i / numel, p = i % numel;
+        const float g = k * (a[i] - b[nn * b_bs + p]);
+        d[i] = accumulate ? d[i] + g : g;
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t mgf_bwd_chunks(int64_t hw) { return (int32_t)mgf_cdiv(hw, BWD_CHUNK); }
@@ -438,5 +526,47 @@ extern "C" int mgf_latent_grad_gather(float* dw, const float* dwg, int32_t n_sty
     hipLaunchKernelGGL(latent_grad_gather_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dw, dwg, n_style_jobs, dyc, n_attn_jobs, k, wdim,
                        scale);
     MGF_CHECK_LAUNCH("latent_grad_gather");
+    return MGF_OK;
+}
+
+extern "C" int mgf_lpips_layer_bwd_f32(float* df0, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c, int64_t hw,
+                                       int64_t f1_batch_stride, float scale, int32_t accumulate, mgf_stream_t stream) {
+    MGF_REQUIRE(df0 && f0 && f1_unit && lin && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer_bwd: bad arguments");
+    MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "lpips_layer_bwd: n must be <= 65535");
+    hipLaunchKernelGGL(lpips_layer_bwd_kernel, dim3((unsigned)mgf_cdiv(hw, 256), n), dim3(256), 0, (hipStream_t)stream, df0, f0, f1_unit, lin, c,
+                       hw, f1_batch_stride, 2.f * scale / (float)hw, accumulate);
+    MGF_CHECK_LAUNCH("lpips_layer_bwd");
+    return MGF_OK;
+}
+
+extern "C" int mgf_relu_bwd_split_f32(float* dz_a, float* dz_b, const float* dy, const float* y, int32_t n, int32_t c, int32_t c_split,
+                                      int64_t hw, mgf_stream_t stream) {
+    MGF_REQUIRE(dz_a && dy && y && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "relu_bwd_split: bad arguments");
+    MGF_REQUIRE(c_split >= 1 && c_split <= c && (dz_b || c_split == c), MGF_EINVAL, "relu_bwd_split: bad split %d of %d channels", c_split, c);
+    const int64_t total = (int64_t)n * c * hw;
+    hipLaunchKernelGGL(relu_bwd_split_kernel, dim3(mgf_stream_grid(total, 256, 4)), dim3(256), 0, (hipStream_t)stream, dz_a, dz_b, dy, y, c,
+                       c_split, hw, total);
+    MGF_CHECK_LAUNCH("relu_bwd_split");
+    return MGF_OK;
+}
+
+extern "C" int mgf_maxpool3x3s2_ceil_bwd_f32(float* dx, const float* dy, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h,
+                                             int32_t out_w, mgf_stream_t stream) {
+    MGF_REQUIRE(dx && dy && x && nc >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, MGF_EINVAL, "maxpool3x3s2_ceil_bwd: bad arguments");
+    MGF_REQUIRE(2 * (out_h - 1) < in_h && 2 * (out_w - 1) < in_w, MGF_EINVAL, "maxpool3x3s2_ceil_bwd: output extent does not match the input");
+    const int64_t total = (int64_t)nc * in_h * in_w;
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(mgf_stream_grid(total, 256, 2)), dim3(256), 0, (hipStream_t)stream, dx, dy, x, in_h, in_w,
+                       out_h, out_w, total);
+    MGF_CHECK_LAUNCH("maxpool3x3s2_ceil_bwd");
+    return MGF_OK;
+}
+
+extern "C" int mgf_mse_grad_f32(float* d, const float* a, const float* b, int32_t n, int64_t numel, int64_t b_batch_stride, float scale,
+                                int32_t accumulate, mgf_stream_t stream) {
+    MGF_REQUIRE(d && a && b && n >= 1 && numel >= 1, MGF_EINVAL, "mse_grad: bad arguments");
+    const int64_t total = (int64_t)n * numel;
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(mgf_stream_grid(total, 256, 4)), dim3(256), 0, (hipStream_t)stream, d, a, b, numel, b_batch_stride,
+                       2.f * scale / (float)numel, accumulate, total);
+    MGF_CHECK_LAUNCH("mse_grad");
     return MGF_OK;
 }

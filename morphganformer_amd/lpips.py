@@ -157,7 +157,9 @@ class SqueezeFeatures:
         if share is not None:
             self.c0, self.fires = share.c0, share.fires          # packed weights are size independent
             self.stem_w, self.stem_b = share.stem_w, share.stem_b
+            self.gp = share.gp
         else:
+            self.gp = {}                                          # channel-transposed packs of the backward pass, built on first use
             g = lambda k: np.asarray(backbone_state[k], dtype=np.float64)
             t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
             w0, b0 = g("features.0.weight"), g("features.0.bias")
@@ -189,6 +191,55 @@ class SqueezeFeatures:
                 c = 2 * ex
                 self.buf[idx] = e(n, c, hh, ww)
             self.shapes[idx] = (c, hh, ww)
+
+    def _grad_ws(self):
+        """Workspace + transposed taps of `backward` (gradient mode only, allocated on first use)."""
+        if not self.gp:
+            self.gp["c0"] = cv.transpose_packed(self.c0[0], flip=False)       # stride-2 conv -> stride-2 transposed conv, same taps
+            for idx, ((ps, _), (p1, _), (p3, _)) in self.fires.items():
+                self.gp[idx] = (cv.transpose_packed(ps, False), cv.transpose_packed(p1, False), cv.transpose_packed(p3, True))
+        if getattr(self, "gbuf", None) is None:
+            e = lambda t: torch.empty_like(t)
+            self.gbuf = {idx: e(t) for idx, t in self.buf.items()}
+            self.gsq = {idx: e(t) for idx, t in self.sq.items()}
+            self.gex = {idx: (e(self.buf[idx][:, :FIRES[idx][2]].contiguous()), e(self.buf[idx][:, FIRES[idx][2]:].contiguous()))
+                        for idx in FIRES}
+            n, _, h1, w1 = self.buf[1].shape
+            self.gimg = torch.empty([n, 3, 2 * h1 + 1, cv.tconv_pitch(w1)], dtype=torch.float32, device=self.device)
+
+    def backward(self, target_taps, lins, scale):
+        """Gradient of  scale * sum_taps lpips_layer(tap, target_tap)  with respect to the input image of the latest __call__
+        (un-fused path: all 7 taps are in the workspace).  Returns a [n,3,2*h1+1,2*w1+1] view (rows/columns beyond it get no
+        gradient: the stride-2 stem never reads them)."""
+        self._grad_ws()
+        L, st = _lib.lib(), _lib.stream_ptr()
+        n = self.n
+        for idx in range(12, 0, -1):
+            h, gh = self.buf[idx], self.gbuf[idx]
+            c, hh, ww = h.shape[1:]
+            if idx in TAPS_AFTER:
+                k = TAPS_AFTER.index(idx)
+                _lib.check(L.mgf_lpips_layer_bwd_f32(gh.data_ptr(), h.data_ptr(), target_taps[k].data_ptr(), lins[k].data_ptr(), n, c,
+                                                     hh * ww, 0, float(scale), int(idx != 12), st), "lpips_layer_bwd")
+            if idx == 1:
+                _lib.check(L.mgf_relu_bwd_split_f32(gh.data_ptr(), None, gh.data_ptr(), h.data_ptr(), n, c, c, hh * ww, st), "relu_bwd")
+                return cv.tconv3x3s2_forward(gh, self.gp["c0"], out=self.gimg)
+            if idx in POOLS:
+                x = self.buf[idx - 1]
+                _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_f32(self.gbuf[idx - 1].data_ptr(), gh.data_ptr(), x.data_ptr(), n * c, x.shape[2],
+                                                           x.shape[3], hh, ww, st), "maxpool_bwd")
+                continue
+            sqT, e1T, e3T = self.gp[idx]
+            ex = FIRES[idx][2]
+            da, db = self.gex[idx]
+            _lib.check(L.mgf_relu_bwd_split_f32(da.data_ptr(), db.data_ptr(), gh.data_ptr(), h.data_ptr(), n, c, ex, hh * ww, st), "relu_bwd_split")
+            s, gs = self.sq[idx], self.gsq[idx]
+            cv.conv_forward(da, e1T, out=gs)
+            cv.conv_forward(db, e3T, pad=(1, 1), epilogue=_lib.make_epilogue(residual=gs), out=gs)
+            _lib.check(L.mgf_relu_bwd_split_f32(gs.data_ptr(), None, gs.data_ptr(), s.data_ptr(), n, s.shape[1], s.shape[1], hh * ww, st),
+                       "relu_bwd")
+            cv.conv_forward(gs, sqT, out=self.gbuf[idx - 1])
+        raise AssertionError("unreachable")
 
     def stem(self, x, feat_out=None, feat_ref=None, lin=None, dist_out=None, scratch=None):
         """features.0-2 in one kernel (csrc/lpips_stem.hip): writes the pooled map (self.buf[2]) and either the normalised
@@ -264,6 +315,7 @@ class PerceptualLoss(torch.nn.Module):
         self.lins = [torch.as_tensor(lin[f"lin{i}"], dtype=torch.float32, device=self.device_) for i in range(len(self.chns))]
         self._feats = {}
         self._target_taps = None
+        self._last, self._last_hw = None, None
         # the one-pass stem exists for SqueezeNet's first three layers; MGF_LPIPS_STEM=0 (tuning hook) keeps them separate
         self.fused_stem = net == "squeeze" and os.environ.get("MGF_LPIPS_STEM", "1") != "0"
         self._scratch = torch.empty(int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=self.device_)
@@ -305,16 +357,31 @@ class PerceptualLoss(torch.nn.Module):
             _lib.check(L.mgf_lpips_unit_f32(t.data_ptr(), t.data_ptr(), n, t.shape[1], t.shape[2] * t.shape[3], st), "lpips_unit")
         self._target_taps = outs
 
-    def distance_into(self, out, pred):
+    def grad_into(self, dimg, scale=1.0, accumulate=False):
+        """dimg (+)= d(scale * distance)/d(pred) for the pred of the latest `distance_into(..., keep_taps=True)` call
+        (what autograd computes through networks_basic.py:64-92 and the backbone).  SqueezeNet backbone only."""
+        if self.net != "squeeze":
+            raise NotImplementedError("gradient mode is implemented for the SqueezeNet LPIPS backbone")
+        f = self._last
+        assert f is not None and tuple(dimg.shape) == (f.n, 3, *self._last_hw), "call distance_into(..., keep_taps=True) first"
+        g = f.backward(self._target_taps, self.lins, scale)
+        if not accumulate:
+            dimg.zero_()
+        dimg[:, :, :g.shape[2], :g.shape[3]].add_(g)
+        return dimg
+
+    def distance_into(self, out, pred, keep_taps=False):
         """out[i] = sum over taps of the spatial-mean weighted distance between pred[i] and the cached (single) target.
-        pred: [n,3,H,W]; out: float32 [n]."""
+        pred: [n,3,H,W]; out: float32 [n].  keep_taps=True takes the un-fused path so that every tap stays in the workspace
+        for `grad_into`."""
         n = pred.shape[0]
         f = self._features(n, pred.shape[2], pred.shape[3])
         assert self._target_taps is not None, "call set_target first"
         need = n * int(_lib.lib().mgf_reduce_scratch_floats())
         if self._scratch.numel() < need:
             self._scratch = torch.empty(need, dtype=torch.float32, device=self.device_)
-        if self.fused_stem:
+        self._last, self._last_hw = (f, tuple(pred.shape[2:])) if keep_taps else (None, None)
+        if self.fused_stem and not keep_taps:
             f.stem(pred.contiguous(), feat_ref=self._target_taps[0], lin=self.lins[0], dist_out=out, scratch=self._scratch)
             taps = f(pred, from_pooled=True)
         else:

@@ -164,3 +164,49 @@ def test_tiny_gradient_matches_reference_module(tiny, golden):
     assert abs(float(img.square().mean()) - float(g["loss_sq"])) < 1e-3 * float(g["loss_sq"])
     dz = gg.backward(2.0 * img / img.numel())
     assert rel(dz, g["grad_z"]) < GRAD_TOL
+
+
+@pytest.mark.parametrize("size", [65, 128])
+def test_lpips_squeeze_gradient_matches_autograd(size):
+    from morphganformer_amd.lpips import PerceptualLoss, random_backbone, WEIGHTS_DIR
+    from oracle.loss_ref import backbone_random, lpips_ref
+    import os
+    torch.manual_seed(size)
+    n = 2
+    pred = (torch.rand(n, 3, size, size) * 2 - 1).requires_grad_(True)
+    target = torch.rand(1, 3, size, size) * 2 - 1
+    bb = backbone_random("squeeze", 0)
+    lin = np.load(os.path.join(WEIGHTS_DIR, "lpips_lin_squeeze.npz"))
+    lins = [torch.from_numpy(lin[f"lin{i}"]).float().reshape(-1) for i in range(7)]
+    val = lpips_ref(bb, lins, pred, target.expand(n, -1, -1, -1))
+    (ref,) = torch.autograd.grad(val.sum() * 0.7, pred)
+    pl = PerceptualLoss(net="squeeze")
+    pl.set_target(target.cuda())
+    out = torch.empty(n, device="cuda")
+    pl.distance_into(out, pred.detach().cuda(), keep_taps=True)
+    assert rel(out, val.reshape(n)) < 1e-4
+    dimg = torch.full((n, 3, size, size), 0.25, device="cuda")
+    pl.grad_into(dimg, scale=0.7, accumulate=True)
+    assert rel(dimg - 0.25, ref) < GRAD_TOL
+    pl.grad_into(dimg, scale=0.7)
+    assert rel(dimg, ref) < GRAD_TOL
+
+
+def test_mse_grad_and_pool_bwd():
+    from morphganformer_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(3)
+    a, b = torch.randn(2, 3, 9, 9), torch.randn(1, 3, 9, 9)
+    ad, bd = a.cuda(), b.cuda()
+    d = torch.ones_like(ad)
+    _lib.check(L.mgf_mse_grad_f32(d.data_ptr(), ad.data_ptr(), bd.data_ptr(), 2, 243, 0, 0.5, 1, _lib.stream_ptr()))
+    assert torch.allclose(d.cpu(), 1 + 0.5 * 2 * (a - b) / 243, rtol=1e-6, atol=1e-7)
+    # ceil-mode pooling with ties (ReLU zeros): the gradient must follow torch's first-maximum rule
+    x = torch.relu(torch.randn(2, 4, 15, 12)).requires_grad_(True)
+    y = torch.nn.functional.max_pool2d(x, 3, 2, ceil_mode=True)
+    dy = torch.randn_like(y)
+    (ref,) = torch.autograd.grad(y, x, dy)
+    xd, dyd = x.detach().cuda(), dy.cuda()
+    dx = torch.empty_like(xd)
+    _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_f32(dx.data_ptr(), dyd.data_ptr(), xd.data_ptr(), 8, 15, 12, y.shape[2], y.shape[3], _lib.stream_ptr()))
+    assert torch.equal(dx.cpu(), ref)
