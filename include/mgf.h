@@ -375,6 +375,14 @@ int mgf_maxpool3x3s2_ceil_bwd_f32(float* dx, const float* dy, const float* x, in
 int mgf_mse_grad_f32(float* d, const float* a, const float* b, int32_t n, int64_t numel, int64_t b_batch_stride, float scale,
                      int32_t accumulate, mgf_stream_t stream);
 
+/* torch.optim.Adam.step() on the latent (1024_example_wing_loss_perceptual_sqz_MSE.py:146,181-184; defaults betas (0.9, 0.999),
+ * eps 1e-8; weight_decay 1e-4 in 1024_example_MSE.py:117), device-resident: lr = lr_table[*step] (the get_lr schedule, :63-68),
+ * nothing happens when valid[*step] == 0 (the "no face" `continue`, :165-166) or *step >= steps_total; *adam_t is the optimizer's own
+ * step count (bias corrections 1 - beta^t in double, like torch). */
+int mgf_adam_step_f32(float* param, float* exp_avg, float* exp_avg_sq, int32_t* adam_t, const float* grad, const float* lr_table,
+                      const int32_t* step, const int32_t* valid, int64_t numel, int32_t steps_total, float beta1, float beta2, float eps,
+                      float weight_decay, mgf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

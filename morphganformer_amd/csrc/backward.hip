@@ -433,6 +433,30 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(float* d, const float* a,
     }
 }
 
+// torch.optim.Adam (single tensor, amsgrad off, weight_decay optional as L2 like torch) on a small parameter, one workgroup;
+// the optimizer's own step count lives on the device (it only advances when a step is taken, like optimizer.step()).
+__global__ __launch_bounds__(256) void adam_step_kernel(float* param, float* m, float* v, int32_t* t_ctr, const float* grad, const float* lr_table,
+                                                        const int32_t* step, const int32_t* valid, int64_t numel, int steps_total, float beta1,
+                                                        float beta2, float eps, float weight_decay) {
+    const int s = *step;
+    if (s >= steps_total || (valid && valid[s] == 0)) return;               // past the end / "no face": `continue` before optimizer.step()
+    const int t = *t_ctr + 1;
+    __syncthreads();
+    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    const float step_size = (float)((double)lr_table[s] / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    for (int64_t i = threadIdx.x; i < numel; i += 256) {
+        float g = grad[i];
+        if (weight_decay != 0.f) g += weight_decay * param[i];
+        const float mi = m[i] + (g - m[i]) * (1.f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * beta2 + (1.f - beta2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        param[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+    if (threadIdx.x == 0) *t_ctr = t;
+}
+
 }  // namespace
 
 extern "C" int32_t mgf_bwd_chunks(int64_t hw) { return (int32_t)mgf_cdiv(hw, BWD_CHUNK); }
@@ -568,5 +592,17 @@ extern "C" int mgf_mse_grad_f32(float* d, const float* a, const float* b, int32_
     hipLaunchKernelGGL(mse_grad_kernel, dim3(mgf_stream_grid(total, 256, 4)), dim3(256), 0, (hipStream_t)stream, d, a, b, numel, b_batch_stride,
                        2.f * scale / (float)numel, accumulate, total);
     MGF_CHECK_LAUNCH("mse_grad");
+    return MGF_OK;
+}
+
+extern "C" int mgf_adam_step_f32(float* param, float* exp_avg, float* exp_avg_sq, int32_t* adam_t, const float* grad, const float* lr_table,
+                                 const int32_t* step, const int32_t* valid, int64_t numel, int32_t steps_total, float beta1, float beta2,
+                                 float eps, float weight_decay, mgf_stream_t stream) {
+    MGF_REQUIRE(param && exp_avg && exp_avg_sq && adam_t && grad && lr_table && step, MGF_EINVAL, "adam_step: null pointer");
+    MGF_REQUIRE(numel >= 1 && steps_total >= 1, MGF_EINVAL, "adam_step: bad sizes");
+    MGF_REQUIRE(numel <= (1 << 20), MGF_EUNSUPPORTED, "adam_step: single-workgroup kernel for latent-sized parameters (numel <= 2^20)");
+    hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, param, exp_avg, exp_avg_sq, adam_t, grad, lr_table, step,
+                       valid, numel, steps_total, beta1, beta2, eps, weight_decay);
+    MGF_CHECK_LAUNCH("adam_step");
     return MGF_OK;
 }

@@ -19,7 +19,8 @@ reference makes three crossings of 12.6 MB per step).  Landmark extraction is dl
 (:159-170) -- a third-party detector that is not reproducible offline -- so landmarks enter as an injected [steps,68,2]
 float64 table (and a `valid` table for the "no face found -> continue" branch, :165-166).
 
-The gradient-descent reading of the north star (back-propagating into the latent) is NOT implemented yet; see DESIGN.md.
+`GradientProjectionEngine` below is the gradient-descent reading of the north star (the loss is back-propagated into the
+latent and Adam moves it) -- the loop the drivers set up (optimizer, lr schedule) but never get (the detach severs it).
 """
 from __future__ import annotations
 
@@ -285,9 +286,13 @@ class ProjectionEngine:
             self.lm_steps[s0 + j].copy_(torch.as_tensor(np.asarray(lm, dtype=np.float64).reshape(self.lm_target.shape)))
             self.valid[s0 + j] = 1
 
+    def _state(self):
+        """Device tensors that make up the loop state (saved and restored around the capture warm-up)."""
+        return (self.step_ctr, self.min_loss, self.best_latent, self.best_step, self.losses)
+
     def _capture(self):
         # warm-up on a side stream (allocations, lazy init) before capture, then restore the loop state
-        state = [t.clone() for t in (self.step_ctr, self.min_loss, self.best_latent, self.best_step, self.losses)]
+        state = [t.clone() for t in self._state()]
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
@@ -297,7 +302,7 @@ class ProjectionEngine:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._iteration()
-        for dst, src in zip((self.step_ctr, self.min_loss, self.best_latent, self.best_step, self.losses), state):
+        for dst, src in zip(self._state(), state):
             dst.copy_(src)
         self.graph = g
 
@@ -326,6 +331,80 @@ class ProjectionEngine:
         if bs < 0:
             raise IndexError("projection: no iteration improved on the initial min_loss (reference: latent_path[-1] on an empty list)")
         return self.best_latent.cpu().clone(), bs, float(self.min_loss.item()), self.losses.cpu().numpy()
+
+
+class GradientProjectionEngine(ProjectionEngine):
+    """Gradient mode: the same loop with the loss back-propagated into the latent.
+
+        latent_n = latent_in + eps_i * sigma_i;  img = G(latent_n)
+        total = percept_weight * LPIPS + lamda * Wing + beta * MSE          (Wing's landmarks come from a detector: no gradient)
+        latent_in <- Adam(lr_i = get_lr(i / steps)).step(d total / d latent_in);  keep (latent_n, i) if total < min_loss
+
+    i.e. the drivers' loop (...sqz_MSE.py:143-189) with the `.cpu().detach().numpy()` at :158 removed.  One candidate per step
+    (the steps now depend on each other); forward, losses, backward (grad.GeneratorGrad, LPIPS backward), Adam and the best-of
+    bookkeeping are one device-resident launch sequence, replayed as a hipGraph.  The oracle is torch autograd + torch.optim.Adam
+    through the CPU restatement (oracle/loss_ref.py: projection_gradient_ref)."""
+
+    def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, betas=(0.9, 0.999), adam_eps=1e-8,
+                 weight_decay=0.0, **kw):
+        from .grad import GeneratorGrad
+        kw.pop("batch", None)
+        kw.pop("pipeline", None)
+        super().__init__(G, target, latent_mean, latent_std, args, batch=1, pipeline=False, **kw)
+        assert self.biometric is None, "gradient mode: the biometric term has no backward pass yet"
+        assert self.percept is None or self.percept.net == "squeeze", "gradient mode: LPIPS backward exists for the SqueezeNet backbone"
+        a, dev = self.args, self.device
+        self.gg = GeneratorGrad(G)
+        self.betas, self.adam_eps, self.weight_decay = betas, float(adam_eps), float(weight_decay)
+        self.lr_table = torch.as_tensor(np.array([get_lr(i / a.step, a.lr, a.lr_rampdown, a.lr_rampup) for i in range(a.step)],
+                                                 dtype=np.float32), device=dev)
+        self.exp_avg = torch.zeros_like(self.latent_in)
+        self.exp_avg_sq = torch.zeros_like(self.latent_in)
+        self.adam_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.dimg = torch.zeros_like(self.target)
+
+    def _state(self):
+        return super()._state() + (self.latent_in, self.exp_avg, self.exp_avg_sq, self.adam_t)
+
+    def _iteration(self):
+        L, st, a = _lib.lib(), _lib.stream_ptr(), self.args
+        _lib.check(L.mgf_latent_perturb(self.latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(), self.sigma.data_ptr(),
+                                        self.step_ctr.data_ptr(), 1, self.steps, self.numel, st), "latent_perturb")
+        img = self.gg.forward(self.latent_n, noise_mode=self.noise_mode)          # psi lands in `c` in the drivers: no truncation
+        per = img.numel()
+        if self.use_mse:
+            _lib.check(L.mgf_mse_grad_f32(self.dimg.data_ptr(), img.data_ptr(), self.target.data_ptr(), 1, per, 0, float(a.beta), 0, st),
+                       "mse_grad")
+        else:
+            self.dimg.zero_()
+        if self.percept is not None:
+            self.percept.distance_into(self.p_loss, img, keep_taps=True)
+            self.percept.grad_into(self.dimg, scale=float(a.percept_weight), accumulate=True)
+            if a.percept_weight != 1.0:
+                self.p_loss.mul_(float(a.percept_weight))
+        if self.use_mse:
+            _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), 1, per, 0, 1.0, 0,
+                                     self.scratch.data_ptr(), st), "mse")
+        dz = self.gg.backward(self.dimg)
+        _lib.check(L.mgf_adam_step_f32(self.latent_in.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.adam_t.data_ptr(),
+                                       dz.data_ptr(), self.lr_table.data_ptr(), self.step_ctr.data_ptr(), _lib.ptr(self.valid), self.numel,
+                                       self.steps, float(self.betas[0]), float(self.betas[1]), self.adam_eps, self.weight_decay, st),
+                   "adam_step")
+        if self.use_wing and self.wing_kind == "wing":
+            _lib.check(L.mgf_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), 1,
+                                           self.lm_target.numel(), 10.0, 2.0, self.step_ctr.data_ptr(), self.lm_steps.shape[0] - 1, st),
+                       "wing_loss")
+        elif self.use_wing:
+            _lib.check(L.mgf_adaptive_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), 1,
+                                                    self.lm_target.numel(), 14.0, 0.5, 1.0, 2.1, self.step_ctr.data_ptr(),
+                                                    self.lm_steps.shape[0] - 1, st), "adaptive_wing_loss")
+        _lib.check(L.mgf_select_best(self.min_loss.data_ptr(), self.best_latent.data_ptr(), self.best_step.data_ptr(),
+                                     self.losses.data_ptr(), self.latent_n.data_ptr(), self.numel,
+                                     _lib.ptr(self.p_loss if self.percept is not None else None),
+                                     _lib.ptr(self.w_loss if self.use_wing else None),
+                                     _lib.ptr(self.mse_loss if self.use_mse else None), float(a.lamda), float(a.beta),
+                                     self.step_ctr.data_ptr(), _lib.ptr(self.valid), 1, self.steps, st), "select_best")
+        return img
 
 
 def save_best_png(G, latent, path, ratio=1.0, noise_mode="const"):

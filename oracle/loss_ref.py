@@ -214,3 +214,37 @@ def projection_literal_ref(gen_fn, loss_fn, latent_mean, latent_std, eps_stream,
         if val < min_loss:
             min_loss, best, best_step = val, latent_n.clone(), i
     return best, best_step, min_loss, losses
+
+
+# --------------------------------------------------------------------------------------------
+# Projection loop, gradient mode (the loop the drivers set up at :143-184 with the detach at :158 removed)
+
+def projection_gradient_ref(gen_fn, loss_fn, latent_mean, latent_std, eps_stream, steps, lr=0.01, rampdown=0.25, rampup=0.05,
+                            noise=0.05, noise_ramp=0.75, min_loss_init=100.0, total_steps=None, weight_decay=0.0):
+    """torch autograd + torch.optim.Adam through gen_fn / loss_fn.  loss_fn(step, image) -> scalar tensor or None ('no face':
+    the step is skipped before optimizer.step()).  Returns (best_latent, best_step, best_loss, losses, trajectory) where
+    trajectory[i] is latent_in after step i."""
+    total_steps = total_steps or steps
+    latent_in = latent_mean[None].clone().requires_grad_(True)
+    opt = torch.optim.Adam([latent_in], lr=lr, weight_decay=weight_decay)
+    best, best_step, min_loss = None, -1, float(min_loss_init)
+    losses, traj = [], []
+    for i in range(steps):
+        t = i / total_steps
+        opt.param_groups[0]["lr"] = get_lr_ref(t, lr, rampdown, rampup)
+        sigma = float(noise_strength_ref(t, float(latent_std), noise, noise_ramp))
+        latent_n = latent_in + eps_stream[i] * sigma
+        val = loss_fn(i, gen_fn(latent_n))
+        if val is None:
+            losses.append(None)
+            traj.append(latent_in.detach().clone())
+            continue
+        opt.zero_grad()
+        val.backward()
+        opt.step()
+        num = float(val.detach())
+        losses.append(num)
+        traj.append(latent_in.detach().clone())
+        if num < min_loss:
+            min_loss, best, best_step = num, latent_n.detach().clone(), i
+    return best, best_step, min_loss, losses, traj

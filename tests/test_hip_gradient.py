@@ -210,3 +210,56 @@ def test_mse_grad_and_pool_bwd():
     dx = torch.empty_like(xd)
     _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_f32(dx.data_ptr(), dyd.data_ptr(), xd.data_ptr(), 8, 15, 12, y.shape[2], y.shape[3], _lib.stream_ptr()))
     assert torch.equal(dx.cpu(), ref)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_gradient_projection_matches_autograd_adam(tiny, use_graph):
+    """Gradient-mode loop vs torch autograd + torch.optim.Adam through the CPU oracle: LPIPS + lamda Wing + beta MSE, a skipped
+    ("no face") step, injected noise streams."""
+    import os
+    from morphganformer_amd.lpips import PerceptualLoss, WEIGHTS_DIR
+    from morphganformer_amd.projection import GradientProjectionEngine, ProjectionArgs, synthetic_landmarks
+    from morphganformer_amd.synth_weights import synthetic_latents
+    from oracle.generator_ref import generator_ref
+    from oracle.loss_ref import backbone_random, lpips_ref, mse_ref, projection_gradient_ref, wing_loss_ref
+    gg, tsd, cfg = tiny
+    steps = 10
+    rng = np.random.Generator(np.random.PCG64(4))
+    latent_mean = torch.from_numpy(rng.standard_normal((cfg.k, cfg.z_dim)).astype(np.float32))
+    eps = torch.from_numpy(rng.standard_normal((steps, 1, cfg.k, cfg.z_dim)).astype(np.float32))
+    target = generator_ref(tsd, torch.from_numpy(synthetic_latents(cfg, 1, 1001)), cfg, "const").clamp(-1, 1)
+    lm_t, lm_s = synthetic_landmarks(steps, 64, 9)
+    valid = np.ones(steps, np.int32)
+    valid[3] = 0
+    args = ProjectionArgs(step=steps, lr=0.05, lr_rampup=0.2)
+    bb = backbone_random("squeeze", 0)
+    lin = np.load(os.path.join(WEIGHTS_DIR, "lpips_lin_squeeze.npz"))
+    lins = [torch.from_numpy(lin[f"lin{i}"]).float().reshape(-1) for i in range(7)]
+
+    def loss_fn(i, img):
+        if not valid[i]:
+            return None
+        w = wing_loss_ref(torch.from_numpy(lm_s[i]), torch.from_numpy(lm_t))
+        return lpips_ref(bb, lins, img, target).sum() + args.lamda * w + args.beta * mse_ref(img, target)
+
+    ref = projection_gradient_ref(lambda z: generator_ref(tsd, z, cfg, "const"), loss_fn, latent_mean, 1.0, eps, steps, lr=args.lr,
+                                  rampdown=args.lr_rampdown, rampup=args.lr_rampup)
+    pl = PerceptualLoss(net="squeeze")
+    eng = GradientProjectionEngine(gg.G, target.cuda(), latent_mean.cuda(), 1.0, args, percept=pl, lm_target=lm_t, lm_steps=lm_s,
+                                   lm_valid=valid, eps=eps.cuda(), noise_mode="const", use_graph=use_graph)
+    traj = []
+    for i in range(steps):
+        eng.run(1)
+        traj.append(eng.latent_in.cpu().clone())
+    lat, bstep, bloss, losses = eng.result()
+    moved = float((ref[4][-1] - latent_mean).abs().max())
+    assert moved > 5 * args.lr * 0.2, "the oracle run must actually move the latent"
+    for i in range(steps):
+        # Adam normalises the gradient, so an element whose gradient is ~0 can differ by a fraction of one lr step
+        assert float((traj[i] - ref[4][i]).abs().max()) < 0.05 * args.lr * (i + 1), i
+    got = np.array([v for v in losses if not np.isnan(v)])
+    want = np.array([v for v in ref[3] if v is not None])
+    assert np.isnan(losses[3]) and ref[3][3] is None
+    assert np.abs(got - want).max() < 1e-3 * np.abs(want).max()
+    assert bstep == ref[1]
+    assert float((lat - ref[0]).abs().max()) < 0.05 * args.lr * steps
