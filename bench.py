@@ -68,6 +68,8 @@ def parse():
                     help="1 = overlap the losses of batch i with the generator of batch i+1 on two streams (+3 %% iters/s; kernels of the two "
                          "streams then stretch each other, so per-kernel durations -- and the roofline object -- no longer describe a kernel "
                          "running alone); 0 = one stream (default: keeps roofline and rocprofv3 per-kernel figures clean)")
+    ap.add_argument("--gradient-steps", type=int, default=20,
+                    help="steps of the extra gradient-mode leg (loss back-propagated into the latent, Adam; rank 0, N=1 only); 0 = skip")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank (exercises the N>1 code path)")
     return ap.parse_args()
 
@@ -163,6 +165,44 @@ def generator_leg(eng, iters=3):
     gf = G.cfg.conv_gflop()
     return {"gflop_per_image": round(gf, 1), "ms_per_image": round(ms, 4), "tflops": round(gf / ms, 2),
             "frac_of_fp32_mfma_peak": round(gf / ms / FP32_MFMA_PEAK_TFLOPS, 4), "images_per_forward": eng.batch}
+
+
+def gradient_leg(sd, cfg, device, eng, steps):
+    """Extra (not the headline metric): the same objective with the loss back-propagated into the latent and Adam moving it
+    (projection.GradientProjectionEngine) -- one candidate per step, forward + LPIPS + backward + Adam as one hipGraph."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.projection import GradientProjectionEngine, ProjectionArgs
+    G1 = Generator(sd, cfg, device, max_batch=1)
+    total = steps + 8
+    ge = GradientProjectionEngine(G1, eng.target, eng.latent_in[0], 1.0, ProjectionArgs(step=total), percept=eng.percept, use_mse=True,
+                                  lm_target=eng.lm_target.cpu().numpy(), lm_steps=eng.lm_steps[:total].cpu().numpy(), noise_mode="random",
+                                  seed=5, use_graph=True)
+    ge.sigma.copy_(eng.sigma[:1].expand(total))                    # the run's initial noise level at every step of this short leg
+    ge.run(4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ge.run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # phase split, eager, HIP events on the current stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    img = ge.gg.forward(ge.latent_n, noise_mode="random")
+    ev[0].record()
+    img = ge.gg.forward(ge.latent_n, noise_mode="random")
+    ev[1].record()
+    ge.percept.distance_into(ge.p_loss, img, keep_taps=True)
+    ge.percept.grad_into(ge.dimg, scale=1.0, accumulate=False)
+    ev[2].record()
+    ge.gg.backward(ge.dimg)
+    ev[3].record()
+    torch.cuda.synchronize()
+    conv_gf = cfg.conv_gflop()
+    return {"value": round(steps / dt, 2), "unit": "iters/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+            "candidates_per_step": 1, "generator_forward_ms": round(ev[0].elapsed_time(ev[1]), 3),
+            "lpips_forward_backward_ms": round(ev[1].elapsed_time(ev[2]), 3), "generator_backward_ms": round(ev[2].elapsed_time(ev[3]), 3),
+            "conv_gflop_forward_plus_dgrad": round(2 * conv_gf, 1),
+            "note": "loss back-propagated into the latent (grad.GeneratorGrad + LPIPS backward + Adam), hipGraph replay; "
+                    "the reference loop severs this gradient, so the headline metric stays the literal loop"}
 
 
 def pmc_traffic(kernel, eng):
@@ -282,6 +322,9 @@ def main():
         out["roofline"] = roofline_leg(eng)
         out["generator_forward"] = generator_leg(eng)
         log(f"roofline leg done: {out['roofline']['kernel']} {out['roofline']['achieved']} TFLOP/s")
+        if world == 1 and a.gradient_steps > 0 and not a.biometric:
+            out["gradient_mode"] = gradient_leg(sd, cfg, device, eng, a.gradient_steps)
+            log(f"gradient-mode leg done: {out['gradient_mode']['value']} iters/s")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, a.cpu_iters)
         print(json.dumps(out), flush=True)

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256) void style_demod_bwd_kernel(float* dwg, const 
         for (int q = 0; q < j.s_chunks; ++q) acc += pp[q];
         if (demod) {
             float dem = 0.f;
+#pragma unroll 8
             for (int o = 0; o < j.cout; ++o) dem += tl[o] * j.wsq[(int64_t)o * j.cin + i];
             acc -= j.s[(int64_t)n * j.cin + i] * dem;
         }
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(256) void attn_values_bwd_kernel(float* dyc, const 
     for (int idx = threadIdx.x; idx < T * wdim; idx += 256) {
         const int t = idx / wdim, k = idx % wdim;
         float acc = 0.f;
+#pragma unroll 8
         for (int c = 0; c < j.c; ++c) acc += dv[(int64_t)c * T + t] * j.wmv[(int64_t)c * wdim + k];
         dyc[(((int64_t)n * njobs + blockIdx.x) * T + t) * wdim + k] = acc;
     }
@@ -350,26 +352,39 @@ __global__ __launch_bounds__(256) void latent_grad_gather_kernel(float* dw, cons
 // One lane per pixel, two sweeps over the channels:  A = sum f0^2, B = sum lin f0^2, Cc = sum lin u1 f0  give
 //   <du0, f0> = k (q B - Cc),   df0[c] = q k lin[c] (f0[c] q - u1[c]) - <du0, f0> q^2 / |f0| * f0[c],   k = 2 scale / hw.
 // An all-zero pixel (|f0| = 0) gets a zero gradient (torch autograd yields NaN there: sqrt'(0) * 0).
+template <int PXB>
 __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* df0, const float* f0, const float* f1u, const float* lin, int c,
                                                               int64_t hw, int64_t f1_bs, float k, int accumulate) {
-    const int n = blockIdx.y;
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= hw) return;
-    const float* a = f0 + (int64_t)n * c * hw + p;
-    const float* b = f1u + (int64_t)n * f1_bs + p;
-    float* o = df0 + (int64_t)n * c * hw + p;
+    // a workgroup owns PXB consecutive pixels; its G = 256 / PXB lane groups split the channels and meet in LDS
+    constexpr int G = 256 / PXB;
+    __shared__ float part[3][G][PXB];
+    const int n = blockIdx.y, px = threadIdx.x % PXB, grp = threadIdx.x / PXB;
+    const int64_t p = (int64_t)blockIdx.x * PXB + px;
+    const bool valid = p < hw;
+    const int64_t pc = valid ? p : hw - 1;
+    const float* a = f0 + (int64_t)n * c * hw + pc;
+    const float* b = f1u + (int64_t)n * f1_bs + pc;
+    float* o = df0 + (int64_t)n * c * hw + pc;
     float A = 0.f, B = 0.f, Cc = 0.f;
-    for (int ch = 0; ch < c; ++ch) {
+#pragma unroll 4
+    for (int ch = grp; ch < c; ch += G) {
         const float v = a[(int64_t)ch * hw], l = lin[ch];
         A += v * v;
         B += l * v * v;
         Cc += l * b[(int64_t)ch * hw] * v;
     }
+    part[0][grp][px] = A; part[1][grp][px] = B; part[2][grp][px] = Cc;
+    __syncthreads();
+    A = B = Cc = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) { A += part[0][g][px]; B += part[1][g][px]; Cc += part[2][g][px]; }
     const float nrm = sqrtf(A);
     const float q = 1.f / (nrm + 1e-10f);
     const float dot = k * (q * B - Cc);
     const float coef = nrm > 0.f ? dot * q * q / nrm : 0.f;
-    for (int ch = 0; ch < c; ++ch) {
+    if (!valid) return;
+#pragma unroll 4
+    for (int ch = grp; ch < c; ch += G) {
         const float v = a[(int64_t)ch * hw];
         const float g = q * k * lin[ch] * (v * q - b[(int64_t)ch * hw]) - coef * v;
         o[(int64_t)ch * hw] = accumulate ? o[(int64_t)ch * hw] + g : g;
@@ -389,37 +404,73 @@ __global__ __launch_bounds__(256) void relu_bwd_split_kernel(float* dz_a, float*
     }
 }
 
-// MaxPool2d(3, 2, ceil_mode=True) backward: the gradient of a window goes to its FIRST maximum in row-major order (torch's argmax rule)
+// MaxPool2d(3, 2, ceil_mode=True) backward: the gradient of a window goes to its FIRST maximum in row-major order (torch's argmax rule).
+// A workgroup owns a 32 x 32 tile of INPUT elements of one plane.  The 17 x 17 windows that touch it (one row / column of them
+// belongs to the neighbouring tile and is recomputed) read a 35 x 35 input patch from LDS; every window's argmax (as a patch offset)
+// and gradient are computed once, then each input element collects from the <= 4 windows that cover it.
+constexpr int MPT = 32, MPW = MPT / 2 + 1, MPI = MPT + 3;
 __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(float* dx, const float* dy, const float* x, int ih, int iw, int oh, int ow,
-                                                               int64_t total) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int ix = (int)(i % iw);
-        const int64_t r = i / iw;
-        const int iy = (int)(r % ih);
-        const int64_t pl = r / ih;
-        const float* xp = x + pl * ih * iw;
-        const float* dp = dy + pl * oh * ow;
-        float acc = 0.f;
-        for (int oy = max(0, (iy - 1) / 2); oy <= min(oh - 1, iy / 2); ++oy) {
-            if (2 * oy > iy || 2 * oy + 2 < iy) continue;
-            for (int ox = max(0, (ix - 1) / 2); ox <= min(ow - 1, ix / 2); ++ox) {
-                if (2 * ox > ix || 2 * ox + 2 < ix) continue;
-                float best = -3.4e38f;
-                int by = -1, bx = -1;
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int yy = 2 * oy + ky;
-                    if (yy >= ih) break;
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int xx = 2 * ox + kx;
-                        if (xx >= iw) break;
-                        const float v = xp[(int64_t)yy * iw + xx];
-                        if (v > best || by < 0) { best = v; by = yy; bx = xx; }
+                                                               int tiles_x, int tiles_y) {
+    __shared__ float patch[MPI][MPI + 1];
+    __shared__ int16_t arg[MPW][MPW];
+    __shared__ float gw[MPW][MPW];
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
+    const int64_t pl = blockIdx.x / ((int64_t)tiles_x * tiles_y);
+    const int iy0 = ty * MPT, ix0 = tx * MPT;            // first owned input row / column
+    const int py0 = iy0 - 2, px0 = ix0 - 2;              // patch origin
+    const int wy0 = iy0 / 2 - 1, wx0 = ix0 / 2 - 1;      // first window row / column (may be -1)
+    const float* xp = x + pl * ih * iw;
+    const float* dp = dy + pl * oh * ow;
+    for (int i = threadIdx.x; i < MPI * MPI; i += 256) {
+        const int r = i / MPI, cc = i % MPI;
+        const int yy = py0 + r, xx = px0 + cc;
+        patch[r][cc] = (yy >= 0 && xx >= 0 && yy < ih && xx < iw) ? xp[(int64_t)yy * iw + xx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MPW * MPW; i += 256) {
+        const int wy = i / MPW, wx = i % MPW;
+        const int oy = wy0 + wy, ox = wx0 + wx;
+        int best = -1;
+        float bv = 0.f;
+        if (oy >= 0 && ox >= 0 && oy < oh && ox < ow) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int yy = 2 * oy + ky, xx = 2 * ox + kx;
+                    if (yy < ih && xx < iw) {
+                        const int r = yy - py0, cc = xx - px0;
+                        const float v = patch[r][cc];
+                        if (best < 0 || v > bv) { bv = v; best = r * MPI + cc; }
                     }
                 }
-                if (by == iy && bx == ix) acc += dp[(int64_t)oy * ow + ox];
+        }
+        arg[wy][wx] = (int16_t)best;
+        gw[wy][wx] = best >= 0 ? dp[(int64_t)oy * ow + ox] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MPT * MPT; i += 256) {
+        const int r = i / MPT, cc = i % MPT;
+        const int yy = iy0 + r, xx = ix0 + cc;
+        if (yy >= ih || xx >= iw) continue;
+        const int me = (yy - py0) * MPI + (xx - px0);
+        float acc = 0.f;
+        // windows oy with 2 oy <= yy <= 2 oy + 2:  oy in {(yy - 1) / 2 (only when yy is even, = yy / 2 - 1), yy / 2}
+        const int oyb = yy / 2, oxb = xx / 2;
+#pragma unroll
+        for (int a = 1; a >= 0; --a) {               // ascending window order, like the reference's accumulation
+            const int oy = oyb - a;
+            if (a == 1 && (yy & 1)) continue;
+            if (oy < 0 || oy >= oh) continue;
+#pragma unroll
+            for (int b = 1; b >= 0; --b) {
+                const int ox = oxb - b;
+                if (b == 1 && (xx & 1)) continue;
+                if (ox < 0 || ox >= ow) continue;
+                if (arg[oy - wy0][ox - wx0] == me) acc += gw[oy - wy0][ox - wx0];
             }
         }
-        dx[i] = acc;
+        dx[pl * ih * iw + (int64_t)yy * iw + xx] = acc;
     }
 }
 
@@ -557,8 +608,13 @@ extern "C" int mgf_lpips_layer_bwd_f32(float* df0, const float* f0, const float*
                                        int64_t f1_batch_stride, float scale, int32_t accumulate, mgf_stream_t stream) {
     MGF_REQUIRE(df0 && f0 && f1_unit && lin && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer_bwd: bad arguments");
     MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "lpips_layer_bwd: n must be <= 65535");
-    hipLaunchKernelGGL(lpips_layer_bwd_kernel, dim3((unsigned)mgf_cdiv(hw, 256), n), dim3(256), 0, (hipStream_t)stream, df0, f0, f1_unit, lin, c,
-                       hw, f1_batch_stride, 2.f * scale / (float)hw, accumulate);
+    const float kk = 2.f * scale / (float)hw;
+    if (hw >= 16384)
+        hipLaunchKernelGGL(lpips_layer_bwd_kernel<64>, dim3((unsigned)mgf_cdiv(hw, 64), n), dim3(256), 0, (hipStream_t)stream, df0, f0, f1_unit, lin,
+                           c, hw, f1_batch_stride, kk, accumulate);
+    else
+        hipLaunchKernelGGL(lpips_layer_bwd_kernel<16>, dim3((unsigned)mgf_cdiv(hw, 16), n), dim3(256), 0, (hipStream_t)stream, df0, f0, f1_unit, lin,
+                           c, hw, f1_batch_stride, kk, accumulate);
     MGF_CHECK_LAUNCH("lpips_layer_bwd");
     return MGF_OK;
 }
@@ -578,9 +634,10 @@ extern "C" int mgf_maxpool3x3s2_ceil_bwd_f32(float* dx, const float* dy, const f
                                              int32_t out_w, mgf_stream_t stream) {
     MGF_REQUIRE(dx && dy && x && nc >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, MGF_EINVAL, "maxpool3x3s2_ceil_bwd: bad arguments");
     MGF_REQUIRE(2 * (out_h - 1) < in_h && 2 * (out_w - 1) < in_w, MGF_EINVAL, "maxpool3x3s2_ceil_bwd: output extent does not match the input");
-    const int64_t total = (int64_t)nc * in_h * in_w;
-    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(mgf_stream_grid(total, 256, 2)), dim3(256), 0, (hipStream_t)stream, dx, dy, x, in_h, in_w,
-                       out_h, out_w, total);
+    const int tiles_x = (int)mgf_cdiv(in_w, MPT), tiles_y = (int)mgf_cdiv(in_h, MPT);
+    MGF_REQUIRE((int64_t)nc * tiles_x * tiles_y <= INT32_MAX, MGF_ETOOBIG, "maxpool3x3s2_ceil_bwd: too many tiles");
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((unsigned)((int64_t)nc * tiles_x * tiles_y)), dim3(256), 0, (hipStream_t)stream, dx, dy, x,
+                       in_h, in_w, out_h, out_w, tiles_x, tiles_y);
     MGF_CHECK_LAUNCH("maxpool3x3s2_ceil_bwd");
     return MGF_OK;
 }
