@@ -56,6 +56,9 @@ def build_parser():
     p.add_argument("--net", type=str, default="squeeze", choices=["squeeze", "vgg", "alex"], help="LPIPS backbone")
     p.add_argument("--no-lpips", action="store_true", help="MSE(+Wing) only, the 1024_example_MSE.py objective")
     p.add_argument("--batch", type=int, default=8, help="loop steps evaluated per generator forward (same result)")
+    p.add_argument("--mode", type=str, default="literal", choices=["literal", "gradient"],
+                   help="literal = the loop as the reference executes it (best-of-N noisy sampling); gradient = back-propagate the loss "
+                        "into the latent and let Adam move it")
     p.add_argument("--seed", type=int, default=None)
 
     m = sub.add_parser("morph", help="Render linear morphs of two projected latents")
@@ -104,7 +107,7 @@ def main(argv=None):
     percept = None if a.no_lpips else PerceptualLoss(model="net-lin", net=a.net, use_gpu=True, device=G.device)
     stem = os.path.splitext(os.path.basename(a.image))[0]
     res = drivers.project_image(G, target, lm_t, lm_s, args=args, percept=percept, batch=a.batch, seed=a.seed,
-                                out_prefix=os.path.join(a.path_to_gen, stem))
+                                out_prefix=os.path.join(a.path_to_gen, stem), mode=a.mode)
     print(f"best step {res['step']}  loss {res['loss']:.6f}")
     return 0
 

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .projection import ProjectionArgs, ProjectionEngine, latent_stats
+from .projection import GradientProjectionEngine, ProjectionArgs, ProjectionEngine, latent_stats
 
 
 # ----------------------------------------------------------------------------------------------------------------- image I/O
@@ -143,10 +143,12 @@ def merge_morph(G, w1, w2, alphas=(0.5,), truncation_psi=0.7, noise_mode="random
 
 def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None,
                   eps=None, out_prefix=None, batch=1, use_graph=True, noise_mode="random", use_mse=True, seed=None,
-                  landmark_fn=None):
+                  landmark_fn=None, mode="literal", weight_decay=0.0):
     """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and either
     `lm_steps` [steps,68,2] (injected landmark detections) or `landmark_fn` (host detector called on every generated image,
-    see ProjectionEngine).  Returns dict(w, step, loss, losses)."""
+    see ProjectionEngine).  mode="literal" is the loop as the reference executes it (best-of-N noisy sampling, `batch` steps per
+    forward); mode="gradient" back-propagates the loss into the latent and lets Adam move it (GradientProjectionEngine; one
+    candidate per step; weight_decay=1e-4 is the 1024_example_MSE.py:117 optimizer).  Returns dict(w, step, loss, losses)."""
     args = args or ProjectionArgs()
     if latent_mean is None or latent_std is None:
         gen = None
@@ -154,9 +156,16 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
             gen = torch.Generator(device=G.device)
             gen.manual_seed(seed)
         latent_mean, latent_std = latent_stats(G, args.n_mean_latent, G.device, generator=gen)
-    eng = ProjectionEngine(G, target, latent_mean, float(latent_std), args, percept=percept, lm_target=lm_target,
-                           lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse,
-                           landmark_fn=landmark_fn)
+    if mode not in ("literal", "gradient"):
+        raise ValueError(f"mode must be 'literal' or 'gradient' (got {mode!r})")
+    if mode == "gradient":
+        eng = GradientProjectionEngine(G, target, latent_mean, float(latent_std), args, weight_decay=weight_decay, percept=percept,
+                                       lm_target=lm_target, lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph,
+                                       use_mse=use_mse, landmark_fn=landmark_fn)
+    else:
+        eng = ProjectionEngine(G, target, latent_mean, float(latent_std), args, percept=percept, lm_target=lm_target,
+                               lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse,
+                               landmark_fn=landmark_fn)
     w, step, loss, losses = eng.run().result()
     if out_prefix is not None:
         save_latent_mat(f"{out_prefix}.mat", w)

@@ -205,13 +205,7 @@ class ProjectionEngine:
             per = img.numel() // B
             _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), B, per, 0, 1.0, 0,
                                      self.scratch.data_ptr(), st), "mse")
-        if self.landmark_fn is not None:
-            self._detect_landmarks(img)
-        if self.landmark_model is not None:
-            lm, ok = self.landmark_model(img)
-            idx = self.step_ctr.long() + self._arange                                    # rows of this batch's steps, on the device
-            self.lm_steps.index_copy_(0, idx, lm.to(torch.float64).reshape(B, *self.lm_target.shape))
-            self.valid.index_copy_(0, idx, ok.to(torch.int32).reshape(B))
+        self._landmarks(img)
         if self.use_wing and self.wing_kind == "wing":
             _lib.check(L.mgf_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), B,
                                            self.lm_target.numel(), 10.0, 2.0, self.step_ctr.data_ptr(), self.lm_steps.shape[0] - 1, st),
@@ -226,6 +220,17 @@ class ProjectionEngine:
                                      _lib.ptr(self.w_loss if self.use_wing else None),
                                      _lib.ptr(self.mse_loss if self.use_mse else None), float(a.lamda), float(a.beta),
                                      self.step_ctr.data_ptr(), _lib.ptr(self.valid), B, self.steps, st), "select_best")
+
+    def _landmarks(self, img):
+        """Fill this batch's rows of the landmark / valid tables when a detector is attached (host callback or device model)."""
+        B = self.batch
+        if self.landmark_fn is not None:
+            self._detect_landmarks(img)
+        if self.landmark_model is not None:
+            lm, ok = self.landmark_model(img)
+            idx = self.step_ctr.long() + self._arange                                    # rows of this batch's steps, on the device
+            self.lm_steps.index_copy_(0, idx, lm.to(torch.float64).reshape(B, *self.lm_target.shape))
+            self.valid.index_copy_(0, idx, ok.to(torch.int32).reshape(B))
 
     # ------------------------------------------------------------------ pipelined mode
     def _pipe_gen(self, p):
@@ -371,6 +376,7 @@ class GradientProjectionEngine(ProjectionEngine):
         _lib.check(L.mgf_latent_perturb(self.latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(), self.sigma.data_ptr(),
                                         self.step_ctr.data_ptr(), 1, self.steps, self.numel, st), "latent_perturb")
         img = self.gg.forward(self.latent_n, noise_mode=self.noise_mode)          # psi lands in `c` in the drivers: no truncation
+        self._landmarks(img)                                                      # before Adam: a "no face" step must not move the latent
         per = img.numel()
         if self.use_mse:
             _lib.check(L.mgf_mse_grad_f32(self.dimg.data_ptr(), img.data_ptr(), self.target.data_ptr(), 1, per, 0, float(a.beta), 0, st),

@@ -266,6 +266,27 @@ def gold_generator_full(ref):
                         img_ds=torch.nn.functional.avg_pool2d(img, 16).numpy())
 
 
+def grad_full_target(res=1024):
+    """Deterministic smooth target of the full-size gradient fixture (formula shared with tests/test_hip_gradient.py)."""
+    y, x = np.meshgrid(np.arange(res, dtype=np.float64), np.arange(res, dtype=np.float64), indexing="ij")
+    return np.stack([0.5 * np.sin(2 * np.pi * (x * (c + 1) + y) / res) for c in range(3)])[None].astype(np.float32)
+
+
+def gold_grad_full(ref):
+    """Gradient-mode fixture at full size: d MSE(G(z), target) / dz through the REFERENCE module's autograd at 1024^2."""
+    from morphganformer_amd.synth_weights import FULL1024, make_state_dict, synthetic_latents
+    sd = make_state_dict(FULL1024, seed=0)
+    G = build_reference_generator(ref, FULL1024, sd)
+    G.synthesis.list2tensor = lambda att_list, device: torch.zeros([1])
+    torch.set_num_threads(8)
+    z = torch.from_numpy(synthetic_latents(FULL1024, 1, seed=1000)).requires_grad_(True)
+    target = torch.from_numpy(grad_full_target(1024))
+    loss = (G(z, None, noise_mode="const")[0] - target).square().mean()
+    (gz,) = torch.autograd.grad(loss, z)
+    np.savez_compressed(os.path.join(OUT, "grad_full1024.npz"), z=z.detach().numpy(), loss=np.float64(loss.item()), grad_z=gz.numpy())
+    print("grad_full1024: loss", loss.item(), "|grad|max", float(gz.abs().max()))
+
+
 def gold_config0_256(ref):
     """BASELINE configs[0]: one 256x256 face, 50-step MSE-only literal projection (the reference's CPU-runnable case).
     The target is a uint8 image pushed through ToTensor+Normalize like image_transform (...sqz_MSE.py:89-108)."""
@@ -379,6 +400,8 @@ def main():
         # regenerate a subset without touching the other fixtures
         if "config0" in only:
             gold_config0_256(ref)
+        if "gradfull" in only:
+            gold_grad_full(ref)
         if "iresnet" in only:
             gold_iresnet()
         if "morph" in only:
@@ -397,6 +420,7 @@ def main():
     gold_iresnet()
     if "--no-full" not in sys.argv:
         gold_generator_full(ref)
+        gold_grad_full(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -263,3 +263,20 @@ def test_gradient_projection_matches_autograd_adam(tiny, use_graph):
     assert np.abs(got - want).max() < 1e-3 * np.abs(want).max()
     assert bstep == ref[1]
     assert float((lat - ref[0]).abs().max()) < 0.05 * args.lr * steps
+
+
+def test_full1024_gradient_matches_reference_module(golden):
+    """Full size: d MSE(G(z), target)/dz at 1024^2 by the REFERENCE module's autograd (tests/golden/grad_full1024.npz,
+    oracle/make_golden.py: gold_grad_full) vs the HIP forward + backward."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.grad import GeneratorGrad
+    from morphganformer_amd.synth_weights import FULL1024, make_state_dict
+    from oracle.make_golden import grad_full_target
+    g = golden("grad_full1024.npz")
+    gg = GeneratorGrad(Generator(make_state_dict(FULL1024, seed=0), FULL1024, "cuda", max_batch=1))
+    target = torch.from_numpy(grad_full_target(1024)).cuda()
+    img = gg.forward(torch.from_numpy(g["z"]).cuda(), noise_mode="const")
+    loss = float((img - target).square().mean())
+    assert abs(loss - float(g["loss"])) < 1e-4 * float(g["loss"])
+    dz = gg.backward(2.0 * (img - target) / img.numel())
+    assert rel(dz, g["grad_z"]) < GRAD_TOL

@@ -306,6 +306,7 @@ def test_cli_arguments_mirror_the_reference_scripts():
     assert (p.size, p.n_mean_latent, p.step, p.lamda, p.beta) == (1024, 10000, 5000, 0.01, 1)
     assert (p.lr_rampup, p.lr_rampdown, p.lr, p.noise, p.noise_ramp, p.ratio, p.truncation_psi) == (0.05, 0.25, 0.01, 0.05, 0.75, 1.0, 0.7)
     assert p.noise_regularize == 1e5 and p.w_plus is False
+    assert p.mode == "literal" and ap.parse_args(["project", "--image", "x.png", "--mode", "gradient"]).mode == "gradient"
     m = ap.parse_args(["morph", "--model", "m.pkl", "--w1", "a.mat", "--w2", "b.mat", "--out", "o"])
     assert m.alphas == "0.5" and m.truncation_psi == 0.7
 

@@ -212,3 +212,16 @@ def test_iresnet_ref_vs_reference_module(golden):
     for i, last in enumerate(("layer1.1", "layer2.1", "layer3.1", "layer4.1")):
         assert abs(float(taps[last].double().square().mean().sqrt()) - g["layer_rms"][i]) < 1e-9 * g["layer_rms"][i]
     assert sum(len(v) for v in ([1] * 3,)) == 3 and len(block_table(50)) == 24 and len(block_table(100)) == 49
+
+
+def test_generator_ref_gradient_full_vs_reference(golden):
+    """The restatement's autograd at full size against the reference module's (tests/golden/grad_full1024.npz)."""
+    from oracle.make_golden import grad_full_target
+    g = golden("grad_full1024.npz")
+    sd = to_torch_state(make_state_dict(FULL1024, 0))
+    z = torch.from_numpy(g["z"]).requires_grad_(True)
+    target = torch.from_numpy(grad_full_target(1024))
+    loss = (generator_ref(sd, z, FULL1024, "const") - target).square().mean()
+    (gz,) = torch.autograd.grad(loss, z)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    assert rel(gz, g["grad_z"]) < 1e-4
