@@ -191,6 +191,12 @@ int mgf_duplex_attention(float* y, const float* x, const float* wqc, const float
                          int32_t n, int32_t c, int32_t f, int32_t t,
                          const mgf_epilogue* ep, int32_t ep_w, float* probs, int32_t* argmax, mgf_stream_t stream);
 
+/* SynthesisNetwork.list2tensor (training/networks.py:1222-1242) for one layer: probs [n, side*side, t] (what mgf_duplex_attention
+ * writes) replicated nearest-neighbour to out_res x out_res (upsample2d with the all-ones kernel) into slice `layer` of the
+ * stacked tensor out [n, t, n_layers, 1, out_res, out_res].  Only needed with return_att=True; the projection loop discards it. */
+int mgf_att_map_upsample_f32(float* out, const float* probs, int32_t n, int32_t side, int32_t t, int32_t out_res, int32_t layer,
+                             int32_t n_layers, mgf_stream_t stream);
+
 /* vwb[n,c,t] = sum_k ycomp[n,t,k] * wmv[c,k] + bmv[c]   (wmv = Wm*Wv folded, bmv = Wm*bv + bm + 1: checkpoint constants;
  * ycomp[n,t,:] = ws[n*ws_stride_n + t*ws_stride_t + w_offset ...], the local latent components).  t fastest in vwb. */
 typedef struct mgf_attn_job {

@@ -72,6 +72,7 @@ _SIGS = {
     "mgf_style_demod": (C.c_int, [C.POINTER(StyleJob), vp, i64, i32, i32, vp]),
     "mgf_style_demod_multi": (C.c_int, [vp, i32, vp, i64, i32, i32, i32, vp]),
     "mgf_duplex_attention": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(Epilogue), i32, vp, vp, vp]),
+    "mgf_att_map_upsample_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mgf_attn_values": (C.c_int, [C.POINTER(AttnJob), vp, i64, i64, i32, i32, i32, vp]),
     "mgf_attn_values_multi": (C.c_int, [vp, i32, vp, i64, i64, i32, i32, i32, vp]),
     "mgf_mapping_param_floats": (i64, [i32, i32, i32]),

@@ -347,6 +347,22 @@ __global__ __launch_bounds__(256) void duplex_attention_reg_kernel(AttnParams p)
     }
 }
 
+// list2tensor (networks.py:1222-1242): one layer's attention map [n, s*s, t] replicated (nearest neighbour = upsample2d with the
+// all-ones kernel) to the image resolution, written as slice `layer` of the stacked tensor [n, t, layers, 1, R, R]
+__global__ __launch_bounds__(256) void att_map_upsample_kernel(float* out, const float* probs, int t, int s, int R, int layer, int layers,
+                                                               int64_t total) {
+    const int f = R / s;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % R);
+        int64_t r = i / R;
+        const int y = (int)(r % R);
+        r /= R;
+        const int tt = (int)(r % t);
+        const int64_t n = r / t;
+        out[(((n * t + tt) * layers + layer) * R + y) * (int64_t)R + x] = probs[(n * s * s + (int64_t)(y / f) * s + x / f) * t + tt];
+    }
+}
+
 template <int PXB>
 void launch_attention(const AttnParams& p, size_t lds, hipStream_t st) {
     constexpr int G = 256 / PXB;
@@ -389,5 +405,17 @@ extern "C" int mgf_duplex_attention(float* y, const float* x, const float* wqc, 
     if (pxb == 64) launch_attention<64>(p, lds, st);
     else launch_attention<16>(p, lds, st);
     MGF_CHECK_LAUNCH("duplex_attention");
+    return MGF_OK;
+}
+
+extern "C" int mgf_att_map_upsample_f32(float* out, const float* probs, int32_t n, int32_t side, int32_t t, int32_t out_res, int32_t layer,
+                                        int32_t n_layers, mgf_stream_t stream) {
+    MGF_REQUIRE(out && probs && n >= 1 && side >= 1 && t >= 1 && n_layers >= 1, MGF_EINVAL, "att_map_upsample: bad arguments");
+    MGF_REQUIRE(layer >= 0 && layer < n_layers, MGF_EINVAL, "att_map_upsample: layer %d outside 0..%d", layer, n_layers - 1);
+    MGF_REQUIRE(out_res >= side && out_res % side == 0, MGF_EINVAL, "att_map_upsample: the image resolution %d must be a multiple of the map side %d", out_res, side);
+    const int64_t total = (int64_t)n * t * out_res * out_res;
+    hipLaunchKernelGGL(att_map_upsample_kernel, dim3(mgf_stream_grid(total, 256, 4)), dim3(256), 0, (hipStream_t)stream, out, probs, t, side,
+                       out_res, layer, n_layers, total);
+    MGF_CHECK_LAUNCH("att_map_upsample");
     return MGF_OK;
 }

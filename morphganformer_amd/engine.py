@@ -374,6 +374,24 @@ class Generator:
                     cv.conv_forward(x, lt.pc, in_scale=self._s(lt), epilogue=ep, out=self.img)
         return self.img
 
+    def list2tensor(self, att_maps=None):
+        """SynthesisNetwork.list2tensor (networks.py:1222-1242): the per-layer attention maps of the latest return_att=True call,
+        nearest-neighbour replicated to the image resolution and stacked -> [n, k-1, layers, 1, R, R] (738 MB at 1024^2, n=1;
+        the projection drivers discard it, so it is only built on request)."""
+        att_maps = self.att_maps if att_maps is None else att_maps
+        if not att_maps:
+            return torch.zeros([1], device=self.device)
+        T, R = self.cfg.k - 1, self.cfg.img_resolution
+        names = [lp.name for lp in self.plan.layers if lp.name in att_maps]
+        n = att_maps[names[0]][0].shape[0]
+        out = torch.empty([n, T, len(names), 1, R, R], dtype=torch.float32, device=self.device)
+        for i, name in enumerate(names):
+            probs = att_maps[name][0]
+            side = math.isqrt(probs.shape[1])
+            _lib.check(_lib.lib().mgf_att_map_upsample_f32(out.data_ptr(), probs.data_ptr(), n, side, T, R, i, len(names),
+                                                           _lib.stream_ptr()), "att_map_upsample")
+        return out
+
     def _noise_for(self, lp, noise_mode, noises):
         if lp.noise_strength is None or noise_mode == "none":
             return None, 1

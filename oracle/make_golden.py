@@ -266,6 +266,16 @@ def gold_generator_full(ref):
                         img_ds=torch.nn.functional.avg_pool2d(img, 16).numpy())
 
 
+def gold_att_tiny(ref):
+    """list2tensor fixture: the stacked attention-map tensor of G(z, return_att=True) on the tiny generator, sub-sampled 8x."""
+    from morphganformer_amd.synth_weights import TINY, make_state_dict, synthetic_latents
+    G = build_reference_generator(ref, TINY, make_state_dict(TINY, seed=0))
+    z = torch.from_numpy(synthetic_latents(TINY, 2, seed=1000))
+    img, att = G(z, None, noise_mode="const", return_att=True)
+    np.savez_compressed(os.path.join(OUT, "att_tiny.npz"), z=z.numpy(), shape=np.array(att.shape), att_sub=att[:, :, :, 0, 3::8, 5::8].numpy())
+    print("att_tiny", tuple(att.shape))
+
+
 def grad_full_target(res=1024):
     """Deterministic smooth target of the full-size gradient fixture (formula shared with tests/test_hip_gradient.py)."""
     y, x = np.meshgrid(np.arange(res, dtype=np.float64), np.arange(res, dtype=np.float64), indexing="ij")
@@ -400,6 +410,8 @@ def main():
         # regenerate a subset without touching the other fixtures
         if "config0" in only:
             gold_config0_256(ref)
+        if "att" in only:
+            gold_att_tiny(ref)
         if "gradfull" in only:
             gold_grad_full(ref)
         if "iresnet" in only:
@@ -416,6 +428,7 @@ def main():
     G, _ = gold_generator_tiny(ref)
     gold_loop_tiny(ref, G)
     gold_morph_tiny(ref, G)
+    gold_att_tiny(ref)
     gold_config0_256(ref)
     gold_iresnet()
     if "--no-full" not in sys.argv:

@@ -114,3 +114,17 @@ def test_full_1024_matches_reference_samples(golden):
     pix2 = img2.reshape(-1)[torch.from_numpy(g["idx"]).cuda()].cpu().numpy()
     assert np.abs(pix2 - g["pixels"]).max() / amax < PIX_TOL
     assert float((img2 - ref_img).abs().max()) / amax < 1e-5
+
+
+def test_list2tensor_matches_reference(tiny, golden):
+    """SynthesisNetwork.list2tensor (networks.py:1222-1242): stacked, nearest-neighbour upsampled attention maps of return_att=True."""
+    G, sd, cfg = tiny
+    g = golden("att_tiny.npz")
+    img, att = G(torch.from_numpy(g["z"]).cuda(), None, noise_mode="const", return_att=True)
+    t = G.list2tensor(att)
+    assert tuple(t.shape) == tuple(g["shape"])
+    assert np.abs(t[:, :, :, 0, 3::8, 5::8].cpu().numpy() - g["att_sub"]).max() < 1e-4
+    # layer 0 is the 4x4 map: constant over 16x16 pixel blocks
+    blk = t[:, :, 0, 0].reshape(2, cfg.k - 1, 4, 16, 4, 16)
+    assert torch.equal(blk, blk[:, :, :, :1, :, :1].expand_as(blk))
+    assert abs(float(t.sum(1).mean()) - 1.0) < 1e-5          # probabilities over the latent components
