@@ -378,6 +378,9 @@ int mgf_relu_bwd_split_f32(float* dz_a, float* dz_b, const float* dy, const floa
                            mgf_stream_t stream);
 int mgf_maxpool3x3s2_ceil_bwd_f32(float* dx, const float* dy, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h,
                                   int32_t out_w, mgf_stream_t stream);
+/* dx of mgf_maxpool_s2_floor_f32 (ksize 2 or 3), first-maximum rule */
+int mgf_maxpool_s2_floor_bwd_f32(float* dx, const float* dy, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t ksize,
+                                 mgf_stream_t stream);
 int mgf_mse_grad_f32(float* d, const float* a, const float* b, int32_t n, int64_t numel, int64_t b_batch_stride, float scale,
                      int32_t accumulate, mgf_stream_t stream);
 

@@ -474,6 +474,30 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(float* dx, const 
     }
 }
 
+// MaxPool2d(2, 2) backward (VGG): windows do not overlap, an input element belongs to at most one
+__global__ __launch_bounds__(256) void maxpool2x2s2_bwd_kernel(float* dx, const float* dy, const float* x, int ih, int iw, int oh, int ow,
+                                                               int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ix = (int)(i % iw);
+        const int64_t r = i / iw;
+        const int iy = (int)(r % ih);
+        const int64_t pl = r / ih;
+        const int oy = iy / 2, ox = ix / 2;
+        float g = 0.f;
+        if (oy < oh && ox < ow) {
+            const float* xp = x + pl * ih * iw + (int64_t)(2 * oy) * iw + 2 * ox;
+            const float v00 = xp[0], v01 = xp[1], v10 = xp[iw], v11 = xp[iw + 1];
+            int best = 0;
+            float bv = v00;
+            if (v01 > bv) { bv = v01; best = 1; }
+            if (v10 > bv) { bv = v10; best = 2; }
+            if (v11 > bv) { bv = v11; best = 3; }
+            if (best == (iy & 1) * 2 + (ix & 1)) g = dy[pl * oh * ow + (int64_t)oy * ow + ox];
+        }
+        dx[i] = g;
+    }
+}
+
 // dimg (+)= scale * 2 (a - b) / numel    (gradient of scale * mean((a - b)^2) per sample)
 __global__ __launch_bounds__(256) void mse_grad_kernel(float* d, const float* a, const float* b, int64_t numel, int64_t b_bs, float k,
                                                        int accumulate, int64_t total) {
@@ -661,5 +685,17 @@ extern "C" int mgf_adam_step_f32(float* param, float* exp_avg, float* exp_avg_sq
     hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, param, exp_avg, exp_avg_sq, adam_t, grad, lr_table, step,
                        valid, numel, steps_total, beta1, beta2, eps, weight_decay);
     MGF_CHECK_LAUNCH("adam_step");
+    return MGF_OK;
+}
+
+extern "C" int mgf_maxpool_s2_floor_bwd_f32(float* dx, const float* dy, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t ksize,
+                                            mgf_stream_t stream) {
+    MGF_REQUIRE(dx && dy && x && nc >= 1 && (ksize == 2 || ksize == 3) && in_h >= ksize && in_w >= ksize, MGF_EINVAL, "maxpool_s2_floor_bwd: bad arguments");
+    const int out_h = (in_h - ksize) / 2 + 1, out_w = (in_w - ksize) / 2 + 1;
+    if (ksize == 3) return mgf_maxpool3x3s2_ceil_bwd_f32(dx, dy, x, nc, in_h, in_w, out_h, out_w, stream);      // same rule, fewer windows
+    const int64_t total = (int64_t)nc * in_h * in_w;
+    hipLaunchKernelGGL(maxpool2x2s2_bwd_kernel, dim3(mgf_stream_grid(total, 256, 2)), dim3(256), 0, (hipStream_t)stream, dx, dy, x, in_h, in_w,
+                       out_h, out_w, total);
+    MGF_CHECK_LAUNCH("maxpool_s2_floor_bwd");
     return MGF_OK;
 }

@@ -88,8 +88,9 @@ class SequentialFeatures:
         self.n = n
         t32 = lambda a: torch.as_tensor(np.ascontiguousarray(np.asarray(a), dtype=np.float32), device=dev)
         if share is not None:
-            self.convs, self.shift, self.scale = share.convs, share.shift, share.scale
+            self.convs, self.shift, self.scale, self.gp = share.convs, share.shift, share.scale, share.gp
         else:
+            self.gp = {}                                   # channel-transposed packs of the backward pass, built on first use
             self.convs = {}
             for row in self.spec:
                 if row[0] == "conv":
@@ -139,6 +140,47 @@ class SequentialFeatures:
             else:
                 taps.append(h)
         return taps
+
+
+    def backward(self, target_taps, lins, scale):
+        """Gradient of  scale * sum_taps lpips_layer(tap, target_tap)  with respect to the input image of the latest __call__
+        (taps in the internal workspace).  3x3 / stride-1 stacks only (VGG16): AlexNet's 11x11 stride-4 stem has no dgrad kernel."""
+        L, st = _lib.lib(), _lib.stream_ptr()
+        rows = [(row, buf) for row, buf in zip(self.spec, self.bufs)]
+        if any(r[0] == "conv" and (r[4] != 3 or r[5] != 1) for r, _ in rows):
+            raise NotImplementedError("LPIPS backward: only 3x3 stride-1 backbones (squeeze, vgg)")
+        if not self.gp:
+            for row in self.spec:
+                if row[0] == "conv":
+                    self.gp[row[1]] = cv.transpose_packed(self.convs[row[1]][0], flip=True)
+        if getattr(self, "gbufs", None) is None:
+            self.gbufs = [None if b is None else torch.empty_like(b) for b in self.bufs]
+            self.gxs = torch.empty_like(self.xs)
+        n = self.n
+        nodes = [i for i, (row, _) in enumerate(rows) if row[0] != "tap"]
+        tap_of, k = {}, 0
+        for i, (row, _) in enumerate(rows):
+            if row[0] == "tap":
+                tap_of[[j for j in nodes if j < i][-1]] = k          # a tap reads the output of the row in front of it
+                k += 1
+        for pos in range(len(nodes) - 1, -1, -1):
+            i = nodes[pos]
+            row, h = rows[i]
+            gh = self.gbufs[i]
+            c, hh, ww = h.shape[1:]
+            if i in tap_of:
+                kk = tap_of[i]
+                _lib.check(L.mgf_lpips_layer_bwd_f32(gh.data_ptr(), h.data_ptr(), target_taps[kk].data_ptr(), lins[kk].data_ptr(), n, c,
+                                                     hh * ww, 0, float(scale), int(pos != len(nodes) - 1), st), "lpips_layer_bwd")
+            prev = self.bufs[nodes[pos - 1]] if pos > 0 else self.xs
+            gprev = self.gbufs[nodes[pos - 1]] if pos > 0 else self.gxs
+            if row[0] == "conv":
+                _lib.check(L.mgf_relu_bwd_split_f32(gh.data_ptr(), None, gh.data_ptr(), h.data_ptr(), n, c, c, hh * ww, st), "relu_bwd")
+                cv.conv_forward(gh, self.gp[row[1]], pad=(1, 1), out=gprev)
+            else:
+                _lib.check(L.mgf_maxpool_s2_floor_bwd_f32(gprev.data_ptr(), gh.data_ptr(), prev.data_ptr(), n * c, prev.shape[2],
+                                                          prev.shape[3], row[1], st), "maxpool_bwd")
+        return self.gxs.div_(self.scale)                   # through the ScalingLayer (x - shift) / scale
 
 
 def _pool_out(n):
@@ -359,9 +401,9 @@ class PerceptualLoss(torch.nn.Module):
 
     def grad_into(self, dimg, scale=1.0, accumulate=False):
         """dimg (+)= d(scale * distance)/d(pred) for the pred of the latest `distance_into(..., keep_taps=True)` call
-        (what autograd computes through networks_basic.py:64-92 and the backbone).  SqueezeNet backbone only."""
-        if self.net != "squeeze":
-            raise NotImplementedError("gradient mode is implemented for the SqueezeNet LPIPS backbone")
+        (what autograd computes through networks_basic.py:64-92 and the backbone).  SqueezeNet and VGG16 backbones."""
+        if self.net == "alex":
+            raise NotImplementedError("gradient mode: AlexNet's 11x11 stride-4 stem has no dgrad kernel (squeeze and vgg do)")
         f = self._last
         assert f is not None and tuple(dimg.shape) == (f.n, 3, *self._last_hw), "call distance_into(..., keep_taps=True) first"
         g = f.backward(self._target_taps, self.lins, scale)

@@ -357,7 +357,7 @@ class GradientProjectionEngine(ProjectionEngine):
         kw.pop("pipeline", None)
         super().__init__(G, target, latent_mean, latent_std, args, batch=1, pipeline=False, **kw)
         assert self.biometric is None, "gradient mode: the biometric term has no backward pass yet"
-        assert self.percept is None or self.percept.net == "squeeze", "gradient mode: LPIPS backward exists for the SqueezeNet backbone"
+        assert self.percept is None or self.percept.net in ("squeeze", "vgg"), "gradient mode: LPIPS backward exists for squeeze and vgg"
         a, dev = self.args, self.device
         self.gg = GeneratorGrad(G)
         self.betas, self.adam_eps, self.weight_decay = betas, float(adam_eps), float(weight_decay)

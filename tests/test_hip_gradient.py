@@ -166,8 +166,8 @@ def test_tiny_gradient_matches_reference_module(tiny, golden):
     assert rel(dz, g["grad_z"]) < GRAD_TOL
 
 
-@pytest.mark.parametrize("size", [65, 128])
-def test_lpips_squeeze_gradient_matches_autograd(size):
+@pytest.mark.parametrize("net,size", [("squeeze", 65), ("squeeze", 128), ("vgg", 48), ("vgg", 70)])
+def test_lpips_gradient_matches_autograd(net, size):
     from morphganformer_amd.lpips import PerceptualLoss, random_backbone, WEIGHTS_DIR
     from oracle.loss_ref import backbone_random, lpips_ref
     import os
@@ -175,12 +175,12 @@ def test_lpips_squeeze_gradient_matches_autograd(size):
     n = 2
     pred = (torch.rand(n, 3, size, size) * 2 - 1).requires_grad_(True)
     target = torch.rand(1, 3, size, size) * 2 - 1
-    bb = backbone_random("squeeze", 0)
-    lin = np.load(os.path.join(WEIGHTS_DIR, "lpips_lin_squeeze.npz"))
-    lins = [torch.from_numpy(lin[f"lin{i}"]).float().reshape(-1) for i in range(7)]
-    val = lpips_ref(bb, lins, pred, target.expand(n, -1, -1, -1))
+    bb = backbone_random(net, 0)
+    lin = np.load(os.path.join(WEIGHTS_DIR, f"lpips_lin_{net}.npz"))
+    lins = [torch.from_numpy(lin[f"lin{i}"]).float().reshape(-1) for i in range(len(lin.files))]
+    val = lpips_ref(bb, lins, pred, target.expand(n, -1, -1, -1), net=net)
     (ref,) = torch.autograd.grad(val.sum() * 0.7, pred)
-    pl = PerceptualLoss(net="squeeze")
+    pl = PerceptualLoss(net=net)
     pl.set_target(target.cuda())
     out = torch.empty(n, device="cuda")
     pl.distance_into(out, pred.detach().cuda(), keep_taps=True)
