@@ -384,6 +384,17 @@ int mgf_maxpool_s2_floor_bwd_f32(float* dx, const float* dy, const float* x, int
 int mgf_mse_grad_f32(float* d, const float* a, const float* b, int32_t n, int64_t numel, int64_t b_batch_stride, float scale,
                      int32_t accumulate, mgf_stream_t stream);
 
+/* Gradient mode of the biometric branch (autograd through backbones/iresnet.py:46-58,145-160 and F.interpolate); its convolution
+ * gradients are mgf_conv_taps_f32 launches on transposed taps, BatchNorm gradients are mgf_channel_affine_prelu_f32 with the scale only.
+ *   prelu_bwd:           dx = dy * (y > 0 ? 1 : slope[c]) from the PReLU OUTPUT y -- needs positive slopes (sign(y) = sign(input))
+ *   linear_bwd:          dx[s,i] = sum_o dy[s,o] w[o,i]                        (n <= 16 rows, n * out_features floats <= 64 KiB)
+ *   resize_bilinear_bwd: dx += adjoint of mgf_resize_bilinear_f32 applied to dy; dx [nc,in_h,in_w] must be zeroed (or hold the sum to
+ *                        add to) beforehand; deterministic when the map is shrunk by >= 2x (no two outputs share a source pixel) */
+int mgf_prelu_bwd_f32(float* dx, const float* dy, const float* y, const float* slope, int32_t n, int32_t c, int64_t hw, mgf_stream_t stream);
+int mgf_linear_bwd_f32(float* dx, const float* dy, const float* w, int32_t n, int32_t in_features, int32_t out_features, mgf_stream_t stream);
+int mgf_resize_bilinear_bwd_f32(float* dx, const float* dy, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                                mgf_stream_t stream);
+
 /* torch.optim.Adam.step() on the latent (1024_example_wing_loss_perceptual_sqz_MSE.py:146,181-184; defaults betas (0.9, 0.999),
  * eps 1e-8; weight_decay 1e-4 in 1024_example_MSE.py:117), device-resident: lr = lr_table[*step] (the get_lr schedule, :63-68),
  * nothing happens when valid[*step] == 0 (the "no face" `continue`, :165-166) or *step >= steps_total; *adam_t is the optimizer's own

@@ -73,7 +73,94 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(float* y, const fl
     }
 }
 
+// ---- gradient mode ----
+// dx = dy * (y > 0 ? 1 : slope[c]) from the PReLU OUTPUT y (valid for positive slopes: sign(y) = sign(pre-activation))
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(float* dx, const float* dy, const float* y, const float* slope, int c, int64_t hw,
+                                                        int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)((i / hw) % c);
+        dx[i] = dy[i] * (y[i] > 0.f ? 1.f : slope[ch]);
+    }
+}
+
+// dx[s, i] = sum_o dy[s, o] * w[o, i]: one lane per input feature (coalesced rows of w), all samples at once
+__global__ __launch_bounds__(256) void linear_bwd_kernel(float* dx, const float* dy, const float* w, int n, int in_f, int out_f) {
+    extern __shared__ float dys[];                 // [n][out_f]
+    for (int i = threadIdx.x; i < n * out_f; i += 256) dys[i] = dy[i];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= in_f) return;
+    float acc[LIN_MAX_N];
+#pragma unroll
+    for (int s = 0; s < LIN_MAX_N; ++s) acc[s] = 0.f;
+#pragma unroll 4
+    for (int o = 0; o < out_f; ++o) {
+        const float wv = w[(int64_t)o * in_f + i];
+#pragma unroll
+        for (int s = 0; s < LIN_MAX_N; ++s)
+            if (s < n) acc[s] += wv * dys[s * out_f + o];
+    }
+#pragma unroll
+    for (int s = 0; s < LIN_MAX_N; ++s)
+        if (s < n) dx[(int64_t)s * in_f + i] = acc[s];
+}
+
+// adjoint of resize_bilinear_kernel: every output pixel's gradient is scattered to its four source pixels (dx pre-zeroed by the
+// caller).  When the map is shrunk by >= 2x no two output pixels share a source pixel, so the atomics never race on an address.
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(float* dx, const float* dy, int nc, int ih, int iw, int oh, int ow, float sy, float sx) {
+    const int64_t total = (int64_t)nc * oh * ow;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % ow);
+        const int64_t r = i / ow;
+        const int oy = (int)(r % oh);
+        const int64_t pl = r / oh;
+        float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+        fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < ih - 1 ? 1 : 0), x1 = x0 + (x0 < iw - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        float* xp = dx + pl * ih * iw;
+        const float g = dy[i];
+        atomicAdd(xp + (int64_t)y0 * iw + x0, hy * hx * g);
+        atomicAdd(xp + (int64_t)y0 * iw + x1, hy * lx * g);
+        atomicAdd(xp + (int64_t)y1 * iw + x0, ly * hx * g);
+        atomicAdd(xp + (int64_t)y1 * iw + x1, ly * lx * g);
+    }
+}
+
 }  // namespace
+
+extern "C" int mgf_prelu_bwd_f32(float* dx, const float* dy, const float* y, const float* slope, int32_t n, int32_t c, int64_t hw,
+                                 mgf_stream_t stream) {
+    MGF_REQUIRE(dx && dy && y && slope && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "prelu_bwd: bad arguments");
+    const int64_t total = (int64_t)n * c * hw;
+    hipLaunchKernelGGL(prelu_bwd_kernel, dim3(mgf_stream_grid(total, 256, 4)), dim3(256), 0, (hipStream_t)stream, dx, dy, y, slope, c, hw, total);
+    MGF_CHECK_LAUNCH("prelu_bwd");
+    return MGF_OK;
+}
+
+extern "C" int mgf_linear_bwd_f32(float* dx, const float* dy, const float* w, int32_t n, int32_t in_features, int32_t out_features,
+                                  mgf_stream_t stream) {
+    MGF_REQUIRE(dx && dy && w && n >= 1 && in_features >= 1 && out_features >= 1, MGF_EINVAL, "linear_bwd: bad arguments");
+    MGF_REQUIRE(n <= LIN_MAX_N, MGF_EUNSUPPORTED, "linear_bwd: at most %d rows per call (got %d)", LIN_MAX_N, n);
+    const size_t lds = (size_t)n * out_features * sizeof(float);
+    MGF_REQUIRE(lds <= 64 * 1024, MGF_EUNSUPPORTED, "linear_bwd: n * out_features = %d floats exceed 64 KiB of LDS", n * out_features);
+    hipLaunchKernelGGL(linear_bwd_kernel, dim3((unsigned)mgf_cdiv(in_features, 256)), dim3(256), lds, (hipStream_t)stream, dx, dy, w, n,
+                       in_features, out_features);
+    MGF_CHECK_LAUNCH("linear_bwd");
+    return MGF_OK;
+}
+
+extern "C" int mgf_resize_bilinear_bwd_f32(float* dx, const float* dy, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                                           mgf_stream_t stream) {
+    MGF_REQUIRE(dx && dy && nc >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, MGF_EINVAL, "resize_bilinear_bwd: bad arguments");
+    const int64_t total = (int64_t)nc * out_h * out_w;
+    hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(mgf_stream_grid(total, 256, 1)), dim3(256), 0, (hipStream_t)stream, dx, dy, nc, in_h,
+                       in_w, out_h, out_w, (float)in_h / (float)out_h, (float)in_w / (float)out_w);
+    MGF_CHECK_LAUNCH("resize_bilinear_bwd");
+    return MGF_OK;
+}
 
 extern "C" int mgf_channel_affine_prelu_f32(float* y, const float* x, const float* scale, const float* shift, const float* slope,
                                             int32_t n, int32_t c, int64_t hw, mgf_stream_t stream) {

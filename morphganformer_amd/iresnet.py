@@ -152,6 +152,83 @@ class IResNetEmbedder:
                                                  512 * 49, 512, _lib.stream_ptr()), "linear")
         return out
 
+    # ------------------------------------------------------------------ gradient mode
+    def _grad_ws(self):
+        """Transposed taps + workspace of `backward` (built on first use).  BatchNorm scales ride on the dgrad convs' input-scale
+        port, which is per sample: they are expanded to [n, c] once."""
+        n = self.n
+        if getattr(self, "_gp", None) is None:
+            self._gp = {"stem": cv.transpose_packed(self.stem[0], flip=True), "blocks": []}
+            for b in self.blocks:
+                if bool((b["slope"] <= 0).any()):
+                    raise _lib.MgfError("IResNet backward: PReLU slopes must be positive (the pre-activation sign is read off the output)")
+                self._gp["blocks"].append(dict(
+                    c1=cv.transpose_packed(b["conv1"], flip=True),
+                    c2=cv.transpose_packed(b["conv2"], flip=(b["stride"] == 1)),      # stride 2: gradient = transposed conv, same taps
+                    down=cv.transpose_packed(b["down"][0], flip=False) if b["down"] is not None else None))
+            if bool((self.stem[3] <= 0).any()):
+                raise _lib.MgfError("IResNet backward: PReLU slopes must be positive")
+        if getattr(self, "_gn", None) != n:
+            self._gn = n
+            ex = lambda t: t.reshape(1, -1).expand(n, -1).contiguous()
+            self._gs = dict(stem=ex(self.stem[1]), blocks=[dict(bn2=ex(b["bn2"][0]), bn3=ex(b["bn3"][0]),
+                                                                down=ex(b["down"][1]) if b["down"] is not None else None)
+                                                           for b in self.blocks])
+            e = lambda t: torch.empty_like(t)
+            self._gb = [dict(dh=e(B["h"]), dpre=e(B["h"]), da=e(B["a"]), dx=e(B["a"]),
+                             t=torch.empty([n, B["h"].shape[1], B["h"].shape[2] + 1, cv.tconv_pitch(B["out"].shape[3])], dtype=torch.float32,
+                                           device=self.device) if b["stride"] == 2 else None,
+                             dlow=torch.empty([n, B["a"].shape[1], B["out"].shape[2], B["out"].shape[3]], dtype=torch.float32,
+                                              device=self.device) if b["down"] is not None else None)
+                        for b, B in zip(self.blocks, self.bufs)]
+            self._gflat, self._gtop = e(self.flat), e(self.flat)
+            self._gstem, self._gx112 = e(self.stem_out), e(self.x112)
+
+    def backward(self, demb, dimg=None, accumulate=False):
+        """demb [n,512] -> gradient wrt the image of the latest embed_image()/embed() call.  With `dimg` [n,3,H,W] the result is
+        scattered through the bilinear resize into it (added when `accumulate`); otherwise the [n,3,112,112] gradient is returned."""
+        _lib.require_gpu(demb, dimg)
+        self._grad_ws()
+        L, st, n = _lib.lib(), _lib.stream_ptr(), self.n
+        for r0 in range(0, n, 16):
+            rows = min(16, n - r0)
+            _lib.check(L.mgf_linear_bwd_f32(self._gflat[r0:].data_ptr(), demb[r0:].data_ptr(), self.fc_w.data_ptr(), rows, 512 * 49, 512, st),
+                       "linear_bwd")
+        dx = self._affine(self._gtop, self._gflat, scale=self.bn2[0])
+        for b, B, gp, gs, gb in reversed(list(zip(self.blocks, self.bufs, self._gp["blocks"], self._gs["blocks"], self._gb))):
+            dxo = dx
+            if b["stride"] == 1:
+                dh = cv.conv_forward(dxo, gp["c2"], pad=(1, 1), in_scale=gs["bn3"], out=gb["dh"])
+            else:
+                t = cv.tconv3x3s2_forward(dxo, gp["c2"], in_scale=gs["bn3"], out=gb["t"])      # T[q + 1] = d h[q]: drop row/column 0
+                gb["dh"].copy_(t[:, :, 1:, 1:])
+                dh = gb["dh"]
+            c, hw = dh.shape[1], dh.shape[2] * dh.shape[3]
+            _lib.check(L.mgf_prelu_bwd_f32(gb["dpre"].data_ptr(), dh.data_ptr(), B["h"].data_ptr(), b["slope"].data_ptr(), n, c, hw, st),
+                       "prelu_bwd")
+            da = cv.conv_forward(gb["dpre"], gp["c1"], pad=(1, 1), in_scale=gs["bn2"], out=gb["da"])
+            dxi = self._affine(gb["dx"], da, scale=b["bn1"][0])
+            if b["down"] is not None:
+                low = cv.conv_forward(dxo, gp["down"], in_scale=gs["down"], out=gb["dlow"])
+                dxi[:, :, ::b["stride"], ::b["stride"]] += low
+            else:
+                dxi += dxo
+            dx = dxi
+        c, hw = dx.shape[1], dx.shape[2] * dx.shape[3]
+        _lib.check(L.mgf_prelu_bwd_f32(self._gstem.data_ptr(), dx.data_ptr(), self.stem_out.data_ptr(), self.stem[3].data_ptr(), n, c, hw, st),
+                   "prelu_bwd")
+        d112 = cv.conv_forward(self._gstem, self._gp["stem"], pad=(1, 1), in_scale=self._gs["stem"], out=self._gx112)
+        if dimg is None:
+            return d112
+        if not accumulate:
+            dimg.zero_()
+        h, w = dimg.shape[2:]
+        if (h, w) == (112, 112):
+            dimg += d112
+        else:
+            _lib.check(L.mgf_resize_bilinear_bwd_f32(dimg.data_ptr(), d112.data_ptr(), n * 3, h, w, 112, 112, st), "resize_bilinear_bwd")
+        return dimg
+
     def embed_image(self, img, out=None):
         """img [n,3,H,W] in [-1,1] -> embedding; bilinear resize (align_corners=False) to the 112x112 ArcFace input."""
         _lib.require_gpu(img)
@@ -196,6 +273,16 @@ class BiometricLoss:
         _lib.check(_lib.lib().mgf_mse_f32(out.data_ptr(), emb.data_ptr(), self._target.data_ptr(), n, 512, 0, float(scale),
                                           int(accumulate), self._scratch.data_ptr(), _lib.stream_ptr()), "mse(embedding)")
         return out
+
+    def grad_into(self, dimg, scale=1.0, accumulate=False):
+        """dimg (+)= d(scale * distance)/d(pred) for the pred of the latest distance_into call (gradient mode)."""
+        e = self.embedder
+        n = e.n
+        if getattr(self, "_demb", None) is None or self._demb.shape[0] != n:
+            self._demb = torch.empty(n, 512, dtype=torch.float32, device=dimg.device)
+        _lib.check(_lib.lib().mgf_mse_grad_f32(self._demb.data_ptr(), e.out.data_ptr(), self._target.data_ptr(), n, 512, 0, float(scale), 0,
+                                               _lib.stream_ptr()), "mse_grad(embedding)")
+        return e.backward(self._demb, dimg, accumulate)
 
     def __call__(self, pred, target):
         self.set_target(target)

@@ -356,7 +356,6 @@ class GradientProjectionEngine(ProjectionEngine):
         kw.pop("batch", None)
         kw.pop("pipeline", None)
         super().__init__(G, target, latent_mean, latent_std, args, batch=1, pipeline=False, **kw)
-        assert self.biometric is None, "gradient mode: the biometric term has no backward pass yet"
         assert self.percept is None or self.percept.net in ("squeeze", "vgg"), "gradient mode: LPIPS backward exists for squeeze and vgg"
         a, dev = self.args, self.device
         self.gg = GeneratorGrad(G)
@@ -388,6 +387,9 @@ class GradientProjectionEngine(ProjectionEngine):
             self.percept.grad_into(self.dimg, scale=float(a.percept_weight), accumulate=True)
             if a.percept_weight != 1.0:
                 self.p_loss.mul_(float(a.percept_weight))
+        if self.biometric is not None:      # rides in the p_loss slot, like the literal loop
+            self.biometric.distance_into(self.p_loss, img, scale=self.gamma, accumulate=self.percept is not None)
+            self.biometric.grad_into(self.dimg, scale=self.gamma, accumulate=True)
         if self.use_mse:
             _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), 1, per, 0, 1.0, 0,
                                      self.scratch.data_ptr(), st), "mse")
@@ -406,7 +408,7 @@ class GradientProjectionEngine(ProjectionEngine):
                                                     self.lm_steps.shape[0] - 1, st), "adaptive_wing_loss")
         _lib.check(L.mgf_select_best(self.min_loss.data_ptr(), self.best_latent.data_ptr(), self.best_step.data_ptr(),
                                      self.losses.data_ptr(), self.latent_n.data_ptr(), self.numel,
-                                     _lib.ptr(self.p_loss if self.percept is not None else None),
+                                     _lib.ptr(self.p_loss if (self.percept is not None or self.biometric is not None) else None),
                                      _lib.ptr(self.w_loss if self.use_wing else None),
                                      _lib.ptr(self.mse_loss if self.use_mse else None), float(a.lamda), float(a.beta),
                                      self.step_ctr.data_ptr(), _lib.ptr(self.valid), 1, self.steps, st), "select_best")
