@@ -4,7 +4,7 @@
 set -e
 D=$1; B=${2:-25}
 cd "$(dirname "$0")/.."
-DB=$(ls $D/trace/runc/*_results.db)
+DB=$(find $D/trace -name "*_results.db" | head -1)
 python tools/rocpd_stats.py $DB > profiles/r1_bench_kernel_stats.txt
 python tools/rocpd_stats.py $DB --loop-only > profiles/r1_bench_kernel_stats_loop.txt
 python tools/iter_trace.py $DB > profiles/r1_iteration_trace.txt 2>&1
