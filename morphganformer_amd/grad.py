@@ -17,7 +17,6 @@ recovered by inverting the leaky ReLU.
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 
 import torch

@@ -215,3 +215,22 @@ def test_device_landmark_model_in_the_graph(golden):
     lat2, st2, loss2, hist2 = make(lm_steps=e1.lm_steps.cpu().numpy()[:steps], batch=1).run().result()
     assert st1 == st2 and torch.equal(lat1, lat2) and np.allclose(hist1, hist2, rtol=1e-6)
     assert float(e1.lm_steps[:steps].std()) > 0
+
+
+def test_project_image_gradient_mode_beats_literal_sampling(golden, tmp_path):
+    """configs[0] shape (256^2, MSE only, the 1024_example_MSE.py optimizer incl. weight_decay=1e-4) through the driver in both
+    modes on the same noise stream: descending the gradient must end below the best of the literal loop's noisy samples."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.projection import ProjectionArgs
+    from morphganformer_amd.synth_weights import SMALL256, make_state_dict
+    g = golden("loop_config0_256.npz")
+    G = Generator(make_state_dict(SMALL256, seed=0), SMALL256, "cuda", max_batch=1)
+    target = torch.from_numpy(g["target_u8"]).float().div(255).sub(0.5).div(0.5)[None].cuda()
+    kw = dict(args=ProjectionArgs(step=50, lr=0.05), percept=None, latent_mean=torch.from_numpy(g["latent_mean"]).cuda(),
+              latent_std=float(g["latent_std"]), eps=torch.from_numpy(g["eps"]).cuda(), noise_mode="const")
+    lit = drivers.project_image(G, target, None, None, batch=5, **kw)
+    grad = drivers.project_image(G, target, None, None, mode="gradient", weight_decay=1e-4, out_prefix=str(tmp_path / "g"), **kw)
+    assert lit["step"] == int(g["best_step"])
+    assert grad["loss"] < 0.9 * lit["loss"], (grad["loss"], lit["loss"])
+    assert np.isfinite(grad["losses"]).all() and os.path.exists(tmp_path / "g.mat")
