@@ -70,6 +70,7 @@ def parse():
                          "running alone); 0 = one stream (default: keeps roofline and rocprofv3 per-kernel figures clean)")
     ap.add_argument("--gradient-steps", type=int, default=20,
                     help="steps of the extra gradient-mode leg (loss back-propagated into the latent, Adam; rank 0, N=1 only); 0 = skip")
+    ap.add_argument("--gradient-lockstep", type=int, default=8, help="targets advanced in lockstep in the second half of the gradient-mode leg")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank (exercises the N>1 code path)")
     return ap.parse_args()
 
@@ -167,7 +168,7 @@ def generator_leg(eng, iters=3):
             "frac_of_fp32_mfma_peak": round(gf / ms / FP32_MFMA_PEAK_TFLOPS, 4), "images_per_forward": eng.batch}
 
 
-def gradient_leg(sd, cfg, device, eng, steps):
+def gradient_leg(sd, cfg, device, eng, steps, lockstep=8):
     """Extra (not the headline metric): the same objective with the loss back-propagated into the latent and Adam moving it
     (projection.GradientProjectionEngine) -- one candidate per step, forward + LPIPS + backward + Adam as one hipGraph."""
     from morphganformer_amd.engine import Generator
@@ -197,8 +198,31 @@ def gradient_leg(sd, cfg, device, eng, steps):
     ev[3].record()
     torch.cuda.synchronize()
     conv_gf = cfg.conv_gflop()
+    # B independent targets advanced in lockstep through one generator forward/backward per step
+    lock = None
+    if lockstep > 1:
+        from morphganformer_amd.lpips import PerceptualLoss
+        from morphganformer_amd.projection import synthetic_landmarks
+        from morphganformer_amd.synth_weights import synthetic_latents
+        B = lockstep
+        GB = Generator(sd, cfg, device, max_batch=B)
+        zt = torch.from_numpy(synthetic_latents(cfg, B, seed=2000)).to(device)
+        tg = GB(zt, None, noise_mode="const")[0].clamp(-1, 1).clone()
+        lm = [synthetic_landmarks(total, cfg.img_resolution, seed=50 + j) for j in range(B)]
+        gb = GradientProjectionEngine(GB, tg, eng.latent_in[0], 1.0, ProjectionArgs(step=total),
+                                      percept=PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device), use_mse=True,
+                                      lm_target=np.stack([l[0] for l in lm]), lm_steps=np.stack([l[1] for l in lm]), noise_mode="random",
+                                      seed=6, use_graph=True)
+        gb.sigma.copy_(eng.sigma[:1].expand(total))
+        gb.run(4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gb.run(steps)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+        lock = {"targets": B, "value": round(B * steps / dtb, 2), "unit": "iters/s (all targets)", "ms_per_step": round(dtb / steps * 1e3, 3)}
     return {"value": round(steps / dt, 2), "unit": "iters/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
-            "candidates_per_step": 1, "generator_forward_ms": round(ev[0].elapsed_time(ev[1]), 3),
+            "candidates_per_step": 1, "lockstep": lock, "generator_forward_ms": round(ev[0].elapsed_time(ev[1]), 3),
             "lpips_forward_backward_ms": round(ev[1].elapsed_time(ev[2]), 3), "generator_backward_ms": round(ev[2].elapsed_time(ev[3]), 3),
             "conv_gflop_forward_plus_dgrad": round(2 * conv_gf, 1),
             "note": "loss back-propagated into the latent (grad.GeneratorGrad + LPIPS backward + Adam), hipGraph replay; "
@@ -323,7 +347,7 @@ def main():
         out["generator_forward"] = generator_leg(eng)
         log(f"roofline leg done: {out['roofline']['kernel']} {out['roofline']['achieved']} TFLOP/s")
         if world == 1 and a.gradient_steps > 0 and not a.biometric:
-            out["gradient_mode"] = gradient_leg(sd, cfg, device, eng, a.gradient_steps)
+            out["gradient_mode"] = gradient_leg(sd, cfg, device, eng, a.gradient_steps, a.gradient_lockstep)
             log(f"gradient-mode leg done: {out['gradient_mode']['value']} iters/s")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, a.cpu_iters)

@@ -142,9 +142,10 @@ class SequentialFeatures:
         return taps
 
 
-    def backward(self, target_taps, lins, scale):
+    def backward(self, target_taps, lins, scale, per_sample=False):
         """Gradient of  scale * sum_taps lpips_layer(tap, target_tap)  with respect to the input image of the latest __call__
-        (taps in the internal workspace).  3x3 / stride-1 stacks only (VGG16): AlexNet's 11x11 stride-4 stem has no dgrad kernel."""
+        (taps in the internal workspace); per_sample: target_taps hold one target per sample instead of one shared target.
+        3x3 / stride-1 stacks only (VGG16): AlexNet's 11x11 stride-4 stem has no dgrad kernel."""
         L, st = _lib.lib(), _lib.stream_ptr()
         rows = [(row, buf) for row, buf in zip(self.spec, self.bufs)]
         if any(r[0] == "conv" and (r[4] != 3 or r[5] != 1) for r, _ in rows):
@@ -171,7 +172,8 @@ class SequentialFeatures:
             if i in tap_of:
                 kk = tap_of[i]
                 _lib.check(L.mgf_lpips_layer_bwd_f32(gh.data_ptr(), h.data_ptr(), target_taps[kk].data_ptr(), lins[kk].data_ptr(), n, c,
-                                                     hh * ww, 0, float(scale), int(pos != len(nodes) - 1), st), "lpips_layer_bwd")
+                                                     hh * ww, c * hh * ww if per_sample else 0, float(scale), int(pos != len(nodes) - 1), st),
+                           "lpips_layer_bwd")
             prev = self.bufs[nodes[pos - 1]] if pos > 0 else self.xs
             gprev = self.gbufs[nodes[pos - 1]] if pos > 0 else self.gxs
             if row[0] == "conv":
@@ -249,9 +251,9 @@ class SqueezeFeatures:
             n, _, h1, w1 = self.buf[1].shape
             self.gimg = torch.empty([n, 3, 2 * h1 + 1, cv.tconv_pitch(w1)], dtype=torch.float32, device=self.device)
 
-    def backward(self, target_taps, lins, scale):
+    def backward(self, target_taps, lins, scale, per_sample=False):
         """Gradient of  scale * sum_taps lpips_layer(tap, target_tap)  with respect to the input image of the latest __call__
-        (un-fused path: all 7 taps are in the workspace).  Returns a [n,3,2*h1+1,2*w1+1] view (rows/columns beyond it get no
+        (un-fused path: all 7 taps are in the workspace; per_sample: one target per sample instead of one shared target).  Returns a [n,3,2*h1+1,2*w1+1] view (rows/columns beyond it get no
         gradient: the stride-2 stem never reads them)."""
         self._grad_ws()
         L, st = _lib.lib(), _lib.stream_ptr()
@@ -262,7 +264,8 @@ class SqueezeFeatures:
             if idx in TAPS_AFTER:
                 k = TAPS_AFTER.index(idx)
                 _lib.check(L.mgf_lpips_layer_bwd_f32(gh.data_ptr(), h.data_ptr(), target_taps[k].data_ptr(), lins[k].data_ptr(), n, c,
-                                                     hh * ww, 0, float(scale), int(idx != 12), st), "lpips_layer_bwd")
+                                                     hh * ww, c * hh * ww if per_sample else 0, float(scale), int(idx != 12), st),
+                           "lpips_layer_bwd")
             if idx == 1:
                 _lib.check(L.mgf_relu_bwd_split_f32(gh.data_ptr(), None, gh.data_ptr(), h.data_ptr(), n, c, c, hh * ww, st), "relu_bwd")
                 return cv.tconv3x3s2_forward(gh, self.gp["c0"], out=self.gimg)
@@ -357,6 +360,7 @@ class PerceptualLoss(torch.nn.Module):
         self.lins = [torch.as_tensor(lin[f"lin{i}"], dtype=torch.float32, device=self.device_) for i in range(len(self.chns))]
         self._feats = {}
         self._target_taps = None
+        self._target_n = 1
         self._last, self._last_hw = None, None
         # the one-pass stem exists for SqueezeNet's first three layers; MGF_LPIPS_STEM=0 (tuning hook) keeps them separate
         self.fused_stem = net == "squeeze" and os.environ.get("MGF_LPIPS_STEM", "1") != "0"
@@ -377,15 +381,16 @@ class PerceptualLoss(torch.nn.Module):
         return f
 
     def set_target(self, target):
-        """Cache the (single) target's 7 feature maps, unit-normalised over channels (they do not change across projection
-        iterations; the reference recomputes and re-normalises them every step)."""
+        """Cache the target's feature maps, unit-normalised over channels (they do not change across projection iterations; the
+        reference recomputes and re-normalises them every step).  One target [1,3,H,W] is shared by every candidate of
+        `distance_into`; n targets pair up with n candidates (independent projections advanced in lockstep)."""
         n, _, h, w = target.shape
-        assert n == 1
+        self._target_n = n
         f = self._features(n, h, w)
         keys = TAPS_AFTER if self.net == "squeeze" else range(len(self.chns))
         outs = [torch.empty([n, c, *f.shapes[idx][1:]], dtype=torch.float32, device=self.device_)
                 for c, idx in zip(self.chns, keys)]
-        if self.fused_stem:
+        if self.fused_stem and n == 1:
             # outs[0] holds the NORMALISED tap 0 (what the stem's distance mode compares against); the same kernel arithmetic
             # runs on both images, so identical images still give exactly zero
             f.stem(target.float().contiguous(), feat_out=outs[0])
@@ -394,7 +399,7 @@ class PerceptualLoss(torch.nn.Module):
             f(target.float(), out=outs)
         L, st = _lib.lib(), _lib.stream_ptr()
         for i, t in enumerate(outs):
-            if i == 0 and self.fused_stem:
+            if i == 0 and self.fused_stem and n == 1:
                 continue                            # the stem already wrote tap 0 normalised
             _lib.check(L.mgf_lpips_unit_f32(t.data_ptr(), t.data_ptr(), n, t.shape[1], t.shape[2] * t.shape[3], st), "lpips_unit")
         self._target_taps = outs
@@ -406,7 +411,7 @@ class PerceptualLoss(torch.nn.Module):
             raise NotImplementedError("gradient mode: AlexNet's 11x11 stride-4 stem has no dgrad kernel (squeeze and vgg do)")
         f = self._last
         assert f is not None and tuple(dimg.shape) == (f.n, 3, *self._last_hw), "call distance_into(..., keep_taps=True) first"
-        g = f.backward(self._target_taps, self.lins, scale)
+        g = f.backward(self._target_taps, self.lins, scale, per_sample=self._target_n > 1)
         if not accumulate:
             dimg.zero_()
         dimg[:, :, :g.shape[2], :g.shape[3]].add_(g)
@@ -419,11 +424,13 @@ class PerceptualLoss(torch.nn.Module):
         n = pred.shape[0]
         f = self._features(n, pred.shape[2], pred.shape[3])
         assert self._target_taps is not None, "call set_target first"
+        per_sample = self._target_n > 1
+        assert not per_sample or self._target_n == n, f"{self._target_n} targets cannot pair with {n} candidates"
         need = n * int(_lib.lib().mgf_reduce_scratch_floats())
         if self._scratch.numel() < need:
             self._scratch = torch.empty(need, dtype=torch.float32, device=self.device_)
         self._last, self._last_hw = (f, tuple(pred.shape[2:])) if keep_taps else (None, None)
-        if self.fused_stem and not keep_taps:
+        if self.fused_stem and not keep_taps and not per_sample:
             f.stem(pred.contiguous(), feat_ref=self._target_taps[0], lin=self.lins[0], dist_out=out, scratch=self._scratch)
             taps = f(pred, from_pooled=True)
         else:
@@ -433,7 +440,8 @@ class PerceptualLoss(torch.nn.Module):
             if a is None:
                 continue                            # tap 0 was consumed inside the stem kernel
             _, c, hh, ww = a.shape
-            _lib.check(L.mgf_lpips_layer_f32(out.data_ptr(), a.data_ptr(), b.data_ptr(), lin.data_ptr(), n, c, hh * ww, 0,
+            _lib.check(L.mgf_lpips_layer_f32(out.data_ptr(), a.data_ptr(), b.data_ptr(), lin.data_ptr(), n, c, hh * ww,
+                                             c * hh * ww if per_sample else 0,
                                              int(i > 0), self._scratch.data_ptr(), st), "lpips_layer")
         return out
 

@@ -342,20 +342,36 @@ class GradientProjectionEngine(ProjectionEngine):
     """Gradient mode: the same loop with the loss back-propagated into the latent.
 
         latent_n = latent_in + eps_i * sigma_i;  img = G(latent_n)
-        total = percept_weight * LPIPS + lamda * Wing + beta * MSE          (Wing's landmarks come from a detector: no gradient)
+        total = percept_weight * LPIPS + lamda * Wing + beta * MSE [+ gamma * embedding MSE]     (Wing's landmarks come from a
+                                                                                                 detector: no gradient)
         latent_in <- Adam(lr_i = get_lr(i / steps)).step(d total / d latent_in);  keep (latent_n, i) if total < min_loss
 
-    i.e. the drivers' loop (...sqz_MSE.py:143-189) with the `.cpu().detach().numpy()` at :158 removed.  One candidate per step
-    (the steps now depend on each other); forward, losses, backward (grad.GeneratorGrad, LPIPS backward), Adam and the best-of
-    bookkeeping are one device-resident launch sequence, replayed as a hipGraph.  The oracle is torch autograd + torch.optim.Adam
-    through the CPU restatement (oracle/loss_ref.py: projection_gradient_ref)."""
+    i.e. the drivers' loop (...sqz_MSE.py:143-189) with the `.cpu().detach().numpy()` at :158 removed.  One candidate per target
+    and step (the steps now depend on each other); forward, losses, backward (grad.GeneratorGrad, LPIPS / embedder backward),
+    Adam and the best-of bookkeeping are one device-resident launch sequence, replayed as a hipGraph.  The oracle is torch
+    autograd + torch.optim.Adam through the CPU restatement (oracle/loss_ref.py: projection_gradient_ref).
 
-    def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, betas=(0.9, 0.999), adam_eps=1e-8,
-                 weight_decay=0.0, **kw):
+    `target` may hold B > 1 images: B independent projections (own latent, Adam state, noise stream, landmarks, best-so-far)
+    advance in lockstep through ONE generator forward/backward per step -- the batch that lifts the 4x4..64x64 layers off
+    their batch-1 latency floor (BASELINE configs 3 and 5 are batches of independent targets).  lm_target is then [B,68,2],
+    lm_steps [B,steps,68,2], lm_valid [B,steps], eps [steps,B,k,D]; `result()` returns per-target lists."""
+
+    def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True, lm_target=None,
+                 lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, landmark_fn=None, biometric=None,
+                 gamma=1.0, wing_kind="wing", landmark_model=None, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=0.0, **ignored):
         from .grad import GeneratorGrad
-        kw.pop("batch", None)
-        kw.pop("pipeline", None)
-        super().__init__(G, target, latent_mean, latent_std, args, batch=1, pipeline=False, **kw)
+        B = int(target.shape[0])
+        if B == 1:
+            super().__init__(G, target, latent_mean, latent_std, args, percept=percept, use_mse=use_mse, lm_target=lm_target,
+                             lm_steps=lm_steps, lm_valid=lm_valid, eps=eps, noise_mode=noise_mode, seed=seed, use_graph=use_graph, batch=1,
+                             landmark_fn=landmark_fn, biometric=biometric, gamma=gamma, wing_kind=wing_kind,
+                             landmark_model=landmark_model, pipeline=False)
+            self.lm_tables = [self.lm_steps] if self.use_wing else None
+        else:
+            self._init_multi(G, target, latent_mean, latent_std, args, percept, use_mse, lm_target, lm_steps, lm_valid, eps, noise_mode,
+                             seed, use_graph, biometric, gamma, wing_kind)
+            assert landmark_fn is None and landmark_model is None, "landmark detectors are wired for one target per engine"
+        self.targets = B
         assert self.percept is None or self.percept.net in ("squeeze", "vgg"), "gradient mode: LPIPS backward exists for squeeze and vgg"
         a, dev = self.args, self.device
         self.gg = GeneratorGrad(G)
@@ -364,22 +380,72 @@ class GradientProjectionEngine(ProjectionEngine):
                                                  dtype=np.float32), device=dev)
         self.exp_avg = torch.zeros_like(self.latent_in)
         self.exp_avg_sq = torch.zeros_like(self.latent_in)
-        self.adam_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.adam_t = torch.zeros(B, dtype=torch.int32, device=dev)
         self.dimg = torch.zeros_like(self.target)
+
+    def _init_multi(self, G, target, latent_mean, latent_std, args, percept, use_mse, lm_target, lm_steps, lm_valid, eps, noise_mode,
+                    seed, use_graph, biometric, gamma, wing_kind):
+        """Loop state of B lockstep projections (the single-target layout of ProjectionEngine with a leading B axis)."""
+        self.G, self.args = G, args or ProjectionArgs()
+        a, dev = self.args, G.device
+        B = int(target.shape[0])
+        self.device, self.batch, self.steps = dev, 1, a.step
+        _lib.require_gpu(target, latent_mean)
+        self.target = target.contiguous().float()
+        self.percept, self.use_mse, self.use_wing, self.noise_mode = percept, use_mse, lm_target is not None, noise_mode
+        k, D = G.cfg.k, G.cfg.z_dim
+        self.numel = k * D
+        lm0 = latent_mean.detach().float().reshape(-1, k, D)
+        self.latent_in = (lm0 if lm0.shape[0] == B else lm0.expand(B, -1, -1)).contiguous().clone()
+        self.sigma = torch.as_tensor(noise_schedule(a.step, float(latent_std), a.noise, a.noise_ramp).astype(np.float32), device=dev)
+        if eps is None:
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(seed)
+            eps = torch.randn(a.step, B, k, D, device=dev, generator=gen)
+        self.eps = eps.to(dev).contiguous().float()
+        assert tuple(self.eps.shape) == (self.eps.shape[0], B, k, D) and self.eps.shape[0] >= a.step
+        assert wing_kind in ("wing", "awing")
+        self.wing_kind, self.landmark_fn, self.landmark_model = wing_kind, None, None
+        if self.use_wing:
+            self.lm_target = torch.as_tensor(lm_target, dtype=torch.float64, device=dev).contiguous()           # [B,68,2]
+            self.lm_steps = torch.as_tensor(lm_steps, dtype=torch.float64, device=dev).contiguous()             # [B,steps,68,2]
+            assert self.lm_target.shape[0] == B and self.lm_steps.shape[:2] == (B, self.lm_steps.shape[1]) and self.lm_steps.shape[1] >= a.step
+            self.lm_tables = [self.lm_steps[j] for j in range(B)]
+        else:
+            self.lm_tables = None
+        self.valid = None if lm_valid is None else torch.as_tensor(lm_valid, dtype=torch.int32, device=dev).reshape(B, -1).contiguous()
+        self.step_ctr = torch.zeros(B, dtype=torch.int32, device=dev)              # one copy per target (select advances its own)
+        self.min_loss = torch.full([B], float(a.min_loss_init), dtype=torch.float64, device=dev)
+        self.best_latent = torch.zeros(B, k, D, dtype=torch.float32, device=dev)
+        self.best_step = torch.full([B], -1, dtype=torch.int32, device=dev)
+        self.losses = torch.full([B, a.step], float("nan"), dtype=torch.float64, device=dev)
+        self.latent_n = torch.empty(B, k, D, dtype=torch.float32, device=dev)
+        self.p_loss = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.mse_loss = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.w_loss = torch.zeros(B, dtype=torch.float64, device=dev)
+        self.scratch = torch.empty(B * int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=dev)
+        if percept is not None:
+            percept.set_target(self.target)
+        self.biometric, self.gamma = biometric, float(gamma)
+        assert biometric is None, "several targets per engine: the biometric term keeps one target embedding (use one engine per target)"
+        self.use_graph, self.graph, self.pipeline = use_graph, None, False
 
     def _state(self):
         return super()._state() + (self.latent_in, self.exp_avg, self.exp_avg_sq, self.adam_t)
 
     def _iteration(self):
-        L, st, a = _lib.lib(), _lib.stream_ptr(), self.args
+        L, st, a, B = _lib.lib(), _lib.stream_ptr(), self.args, self.targets
+        # B targets: one flat parameter of B * numel floats, one noise row [B * numel] per step
         _lib.check(L.mgf_latent_perturb(self.latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(), self.sigma.data_ptr(),
-                                        self.step_ctr.data_ptr(), 1, self.steps, self.numel, st), "latent_perturb")
+                                        self.step_ctr.data_ptr(), 1, self.steps, B * self.numel, st), "latent_perturb")
         img = self.gg.forward(self.latent_n, noise_mode=self.noise_mode)          # psi lands in `c` in the drivers: no truncation
-        self._landmarks(img)                                                      # before Adam: a "no face" step must not move the latent
-        per = img.numel()
+        if B == 1:
+            self._landmarks(img)                                                  # before Adam: a "no face" step must not move the latent
+        per = img.numel() // B
+        tstride = per if B > 1 else 0
         if self.use_mse:
-            _lib.check(L.mgf_mse_grad_f32(self.dimg.data_ptr(), img.data_ptr(), self.target.data_ptr(), 1, per, 0, float(a.beta), 0, st),
-                       "mse_grad")
+            _lib.check(L.mgf_mse_grad_f32(self.dimg.data_ptr(), img.data_ptr(), self.target.data_ptr(), B, per, tstride, float(a.beta), 0,
+                                          st), "mse_grad")
         else:
             self.dimg.zero_()
         if self.percept is not None:
@@ -391,28 +457,54 @@ class GradientProjectionEngine(ProjectionEngine):
             self.biometric.distance_into(self.p_loss, img, scale=self.gamma, accumulate=self.percept is not None)
             self.biometric.grad_into(self.dimg, scale=self.gamma, accumulate=True)
         if self.use_mse:
-            _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), 1, per, 0, 1.0, 0,
+            _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), B, per, tstride, 1.0, 0,
                                      self.scratch.data_ptr(), st), "mse")
         dz = self.gg.backward(self.dimg)
-        _lib.check(L.mgf_adam_step_f32(self.latent_in.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.adam_t.data_ptr(),
-                                       dz.data_ptr(), self.lr_table.data_ptr(), self.step_ctr.data_ptr(), _lib.ptr(self.valid), self.numel,
-                                       self.steps, float(self.betas[0]), float(self.betas[1]), self.adam_eps, self.weight_decay, st),
-                   "adam_step")
-        if self.use_wing and self.wing_kind == "wing":
-            _lib.check(L.mgf_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), 1,
-                                           self.lm_target.numel(), 10.0, 2.0, self.step_ctr.data_ptr(), self.lm_steps.shape[0] - 1, st),
-                       "wing_loss")
-        elif self.use_wing:
-            _lib.check(L.mgf_adaptive_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), 1,
-                                                    self.lm_target.numel(), 14.0, 0.5, 1.0, 2.1, self.step_ctr.data_ptr(),
-                                                    self.lm_steps.shape[0] - 1, st), "adaptive_wing_loss")
-        _lib.check(L.mgf_select_best(self.min_loss.data_ptr(), self.best_latent.data_ptr(), self.best_step.data_ptr(),
-                                     self.losses.data_ptr(), self.latent_n.data_ptr(), self.numel,
-                                     _lib.ptr(self.p_loss if (self.percept is not None or self.biometric is not None) else None),
-                                     _lib.ptr(self.w_loss if self.use_wing else None),
-                                     _lib.ptr(self.mse_loss if self.use_mse else None), float(a.lamda), float(a.beta),
-                                     self.step_ctr.data_ptr(), _lib.ptr(self.valid), 1, self.steps, st), "select_best")
+        has_p = self.percept is not None or self.biometric is not None
+        for j in range(B):                   # per-target optimizer step, Wing term and best-of bookkeeping (tiny launches)
+            ctr = self.step_ctr[j:]
+            valid = None if self.valid is None else (self.valid[j] if B > 1 else self.valid)
+            _lib.check(L.mgf_adam_step_f32(self.latent_in[j:].data_ptr(), self.exp_avg[j:].data_ptr(), self.exp_avg_sq[j:].data_ptr(),
+                                           self.adam_t[j:].data_ptr(), dz[j:].data_ptr(), self.lr_table.data_ptr(), ctr.data_ptr(),
+                                           _lib.ptr(valid), self.numel, self.steps, float(self.betas[0]), float(self.betas[1]),
+                                           self.adam_eps, self.weight_decay, st), "adam_step")
+            if self.use_wing:
+                tab, tgt = self.lm_tables[j], (self.lm_target[j] if B > 1 else self.lm_target)
+                if self.wing_kind == "wing":
+                    _lib.check(L.mgf_wing_loss_f64(self.w_loss[j:].data_ptr(), tab.data_ptr(), tgt.data_ptr(), 1, tgt.numel(), 10.0, 2.0,
+                                                   ctr.data_ptr(), tab.shape[0] - 1, st), "wing_loss")
+                else:
+                    _lib.check(L.mgf_adaptive_wing_loss_f64(self.w_loss[j:].data_ptr(), tab.data_ptr(), tgt.data_ptr(), 1, tgt.numel(),
+                                                            14.0, 0.5, 1.0, 2.1, ctr.data_ptr(), tab.shape[0] - 1, st), "adaptive_wing_loss")
+            _lib.check(L.mgf_select_best(self.min_loss[j:].data_ptr(), self.best_latent[j:].data_ptr(), self.best_step[j:].data_ptr(),
+                                         self.losses.reshape(B, -1)[j].data_ptr(), self.latent_n[j:].data_ptr(), self.numel,
+                                         _lib.ptr(self.p_loss[j:] if has_p else None), _lib.ptr(self.w_loss[j:] if self.use_wing else None),
+                                         _lib.ptr(self.mse_loss[j:] if self.use_mse else None), float(a.lamda), float(a.beta),
+                                         ctr.data_ptr(), _lib.ptr(valid), 1, self.steps, st), "select_best")
         return img
+
+    def run(self, steps=None):
+        done = int(self.step_ctr[0].item()) if steps is None else None
+        n = (self.steps - done) if steps is None else steps
+        if self.use_graph and self.graph is None:
+            self._capture()
+        for _ in range(n):
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._iteration()
+        return self
+
+    def result(self):
+        """One target: like ProjectionEngine.result().  B targets: (best_latents [B,k,D] cpu, best_steps [B], best_losses [B],
+        losses [B,steps]) as numpy / tensors; a target that never improved on min_loss_init raises like the reference."""
+        if self.targets == 1:
+            return super().result()
+        torch.cuda.synchronize(self.device)
+        bs = self.best_step.cpu().numpy()
+        if (bs < 0).any():
+            raise IndexError(f"projection: targets {np.nonzero(bs < 0)[0].tolist()} never improved on the initial min_loss")
+        return self.best_latent.cpu().clone(), bs, self.min_loss.cpu().numpy(), self.losses.cpu().numpy()
 
 
 def save_best_png(G, latent, path, ratio=1.0, noise_mode="const"):

@@ -339,3 +339,40 @@ def test_gradient_projection_with_vgg_and_biometric_terms(tiny):
     assert np.isfinite(losses).all()
     assert abs(losses[0] - first_literal) < 1e-4 * abs(first_literal)       # step 0: lr = 0, same candidate, same objective
     assert float((eng.latent_in[0] - latent_mean).abs().max()) > 0.01
+
+
+def test_gradient_projection_lockstep_targets_equal_single_runs(tiny):
+    """B = 2 targets in one engine (one generator forward/backward per step for both) against two single-target engines on the
+    same noise streams: same losses, same latent trajectories, same best steps; a "no face" step of one target leaves the other
+    untouched."""
+    from morphganformer_amd.lpips import PerceptualLoss
+    from morphganformer_amd.projection import GradientProjectionEngine, ProjectionArgs, synthetic_landmarks
+    gg, tsd, cfg = tiny
+    G = gg.G
+    steps, B = 8, 2
+    torch.manual_seed(21)
+    latent_mean = torch.randn(cfg.k, cfg.z_dim, device="cuda")
+    eps = torch.randn(steps, B, cfg.k, cfg.z_dim, device="cuda")
+    targets = G(torch.randn(B, cfg.k, cfg.z_dim, device="cuda"), None, noise_mode="const")[0].clamp(-1, 1).clone()
+    lms = [synthetic_landmarks(steps, 64, 9 + j) for j in range(B)]
+    valid = np.ones((B, steps), np.int32)
+    valid[1, 2] = 0
+    args = ProjectionArgs(step=steps, lr=0.05, lr_rampup=0.25)
+    singles = []
+    for j in range(B):
+        e = GradientProjectionEngine(G, targets[j:j + 1].contiguous(), latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze"),
+                                     lm_target=lms[j][0], lm_steps=lms[j][1], lm_valid=valid[j], eps=eps[:, j:j + 1].contiguous(),
+                                     noise_mode="const", use_graph=False).run()
+        singles.append((e.result(), e.latent_in.cpu().clone()))
+    multi = GradientProjectionEngine(G, targets, latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze"),
+                                     lm_target=np.stack([l[0] for l in lms]), lm_steps=np.stack([l[1] for l in lms]), lm_valid=valid,
+                                     eps=eps, noise_mode="const", use_graph=True).run()
+    lat, bstep, bloss, losses = multi.result()
+    for j in range(B):
+        (slat, sstep, sloss, slosses), sfinal = singles[j]
+        ok = ~np.isnan(slosses)
+        assert np.array_equal(np.isnan(losses[j]), np.isnan(slosses))
+        assert np.abs(losses[j][ok] - slosses[ok]).max() < 1e-4 * np.abs(slosses[ok]).max()
+        assert int(bstep[j]) == sstep
+        assert float((multi.latent_in[j].cpu() - sfinal[0]).abs().max()) < 0.05 * args.lr * steps
+    assert np.isnan(losses[1, 2]) and not np.isnan(losses[0, 2])
