@@ -39,6 +39,7 @@ struct ActBwdParams {
 
 // grid (nchunk, c, n).  y = lrelu(z) * gain + res  with  z = cval + noise * strength + bias:
 //   dz = dy * gain * (y - res > 0 ? 1 : alpha);    part[n,c,chunk] = sum dz * cval   (cval recovered by inverting the activation)
+template <bool VEC>
 __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdParams p) {
     __shared__ float red[4];
     const int chunk = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
@@ -50,15 +51,31 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdParams p) {
     const float* nz = p.noise ? p.noise + (int64_t)(p.noise_n > 1 ? n : 0) * p.hw : nullptr;
     const float inv_gain = 1.f / p.gain, inv_alpha = 1.f / p.alpha;
     float acc = 0.f;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        float v = p.y[base + i];
-        if (p.res) v -= p.res[base + i];
+    auto one = [&](float yv, float rv, float dyv, float nv, float& dzv) {
+        const float v = yv - rv;
         const bool pos = v > 0.f;
-        const float dzv = p.dy[base + i] * p.gain * (pos ? 1.f : p.alpha);
-        p.dz[base + i] = dzv;
+        dzv = dyv * p.gain * (pos ? 1.f : p.alpha);
         if (p.part) {
             const float zv = (pos ? v : v * inv_alpha) * inv_gain;
-            acc += dzv * (zv - b - (nz ? nz[i] * ns : 0.f));
+            acc += dzv * (zv - b - nv * ns);
+        }
+    };
+    if (VEC) {          // hw % 4 == 0 and 16-byte aligned operands: four elements per lane and access
+        for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
+            const float4 yv = *reinterpret_cast<const float4*>(p.y + base + i);
+            const float4 dv = *reinterpret_cast<const float4*>(p.dy + base + i);
+            const float4 rv = p.res ? *reinterpret_cast<const float4*>(p.res + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 nv = nz ? *reinterpret_cast<const float4*>(nz + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o;
+            one(yv.x, rv.x, dv.x, nv.x, o.x); one(yv.y, rv.y, dv.y, nv.y, o.y);
+            one(yv.z, rv.z, dv.z, nv.z, o.z); one(yv.w, rv.w, dv.w, nv.w, o.w);
+            *reinterpret_cast<float4*>(p.dz + base + i) = o;
+        }
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            float o;
+            one(p.y[base + i], p.res ? p.res[base + i] : 0.f, p.dy[base + i], nz ? nz[i] : 0.f, o);
+            p.dz[base + i] = o;
         }
     }
     if (p.part) {
@@ -81,6 +98,7 @@ __global__ __launch_bounds__(256) void channel_dot_kernel(float* part, const flo
 }
 
 // part[n,c,chunk] = sum x * g ;  dx (+)= s[n,c] * g
+template <bool VEC>
 __global__ __launch_bounds__(256) void style_grad_kernel(float* part, float* dx, const float* x, const float* g, const float* s, int c,
                                                          int64_t hw, int nchunk, int accumulate) {
     __shared__ float red[4];
@@ -90,11 +108,25 @@ __global__ __launch_bounds__(256) void style_grad_kernel(float* part, float* dx,
     const int64_t i1 = min(hw, i0 + (int64_t)BWD_CHUNK);
     const float sv = s ? s[(int64_t)n * c + ch] : 1.f;
     float acc = 0.f;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        const float gv = g[base + i];
-        acc += x[base + i] * gv;
-        const float o = sv * gv;
-        dx[base + i] = accumulate ? dx[base + i] + o : o;
+    if (VEC) {
+        for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
+            const float4 gv = *reinterpret_cast<const float4*>(g + base + i);
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+            acc += xv.x * gv.x + xv.y * gv.y + xv.z * gv.z + xv.w * gv.w;
+            float4 o = make_float4(sv * gv.x, sv * gv.y, sv * gv.z, sv * gv.w);
+            if (accumulate) {
+                const float4 d = *reinterpret_cast<const float4*>(dx + base + i);
+                o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
+            }
+            *reinterpret_cast<float4*>(dx + base + i) = o;
+        }
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            const float gv = g[base + i];
+            acc += x[base + i] * gv;
+            const float o = sv * gv;
+            dx[base + i] = accumulate ? dx[base + i] + o : o;
+        }
     }
     const float tot = block_sum(acc, red);
     if (threadIdx.x == 0) part[((int64_t)n * c + ch) * nchunk + chunk] = tot;
@@ -543,7 +575,10 @@ extern "C" int mgf_layer_act_bwd_f32(float* dz, float* dot_part, const float* dy
     MGF_REQUIRE(alpha != 0.f && gain != 0.f, MGF_EINVAL, "layer_act_bwd: alpha and gain must be non-zero (the activation is inverted)");
     MGF_REQUIRE(n <= 65535 && c <= 65535, MGF_ETOOBIG, "layer_act_bwd: n and c must be <= 65535");
     ActBwdParams p{dz, dot_part, dy, y, residual, bias, noise, noise_strength, noise_n, c, (int)mgf_cdiv(hw, BWD_CHUNK), hw, alpha, gain};
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
+    auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
+    const bool vec = hw % 4 == 0 && al16(dz) && al16(dy) && al16(y) && al16(residual) && al16(noise);
+    if (vec) hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
     MGF_CHECK_LAUNCH("layer_act_bwd");
     return MGF_OK;
 }
@@ -562,8 +597,11 @@ extern "C" int mgf_style_grad_f32(float* dot_part, float* dx, const float* x, co
     MGF_REQUIRE(dot_part && dx && x && g && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "style_grad: bad arguments");
     MGF_REQUIRE(n <= 65535 && c <= 65535, MGF_ETOOBIG, "style_grad: n and c must be <= 65535");
     const int nchunk = (int)mgf_cdiv(hw, BWD_CHUNK);
-    hipLaunchKernelGGL(style_grad_kernel, dim3(nchunk, c, n), dim3(256), 0, (hipStream_t)stream, dot_part, dx, x, g, s, c, hw, nchunk,
-                       accumulate);
+    const bool vec = hw % 4 == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)g % 16) == 0;
+    if (vec) hipLaunchKernelGGL(style_grad_kernel<true>, dim3(nchunk, c, n), dim3(256), 0, (hipStream_t)stream, dot_part, dx, x, g, s, c, hw,
+                                nchunk, accumulate);
+    else hipLaunchKernelGGL(style_grad_kernel<false>, dim3(nchunk, c, n), dim3(256), 0, (hipStream_t)stream, dot_part, dx, x, g, s, c, hw,
+                            nchunk, accumulate);
     MGF_CHECK_LAUNCH("style_grad");
     return MGF_OK;
 }

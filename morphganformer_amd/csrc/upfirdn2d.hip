@@ -91,6 +91,54 @@ __global__ __launch_bounds__(256) void upfirdn_generic(UFParams p) {
     }
 }
 
+
+// down = 2, up = 1, filter <= 4x4, dense rows (the gradient of the 2x FIR upsampling of the resnet skip branch, gradient mode).
+// Output tile 64 (x) x 16 (y) per workgroup; its (2*64+2) x (2*16+2) input footprint goes through LDS once, lane (lx, ly) then
+// produces outputs (oy0 + 4*ly + {0..3}, ox0 + lx) from 16 LDS reads each.
+__global__ __launch_bounds__(256) void fir_down2_tiled(UFParams p) {
+    constexpr int TW = 64, TH = 16, FMAX = 4;
+    constexpr int IW = 2 * (TW - 1) + FMAX, IH = 2 * (TH - 1) + FMAX;
+    __shared__ float sx[IH][IW + 1];
+    __shared__ float sf[FMAX][FMAX];
+    const int tid = threadIdx.x;
+    if (tid < FMAX * FMAX) {
+        const int jy = tid / FMAX, jx = tid % FMAX;
+        float v = 0.f;
+        if (jy < p.fh && jx < p.fw) {
+            const int ky = p.flip ? jy : p.fh - 1 - jy, kx = p.flip ? jx : p.fw - 1 - jx;
+            v = p.f[ky * p.fw + kx] * p.gain;
+        }
+        sf[jy][jx] = v;
+    }
+    const int tiles_x = (p.out_w + TW - 1) / TW, tiles_y = (p.out_h + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; b /= tiles_y;
+    const int c = b % p.c, n = b / p.c;
+    const int ox0 = tx * TW, oy0 = ty * TH;
+    const int ix0 = 2 * ox0 - p.padx0, iy0 = 2 * oy0 - p.pady0;
+    const float* xb = (const float*)p.x + (int64_t)n * p.sn + (int64_t)c * p.sc;
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int r = i / IW, cc = i - r * IW;
+        const int iy = iy0 + r, ix = ix0 + cc;
+        sx[r][cc] = (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) ? xb[(int64_t)iy * p.sh + ix] : 0.f;
+    }
+    __syncthreads();
+    const int lx = tid & 63, ly = tid >> 6;
+    float* yb = (float*)p.y + (int64_t)n * p.yn + (int64_t)c * p.yc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int wy = 4 * ly + q;
+        const int oy = oy0 + wy, ox = ox0 + lx;
+        float acc = 0.f;
+#pragma unroll
+        for (int jy = 0; jy < FMAX; ++jy)
+#pragma unroll
+            for (int jx = 0; jx < FMAX; ++jx) acc += sx[2 * wy + jy][2 * lx + jx] * sf[jy][jx];
+        if (oy < p.out_h && ox < p.out_w) yb[(int64_t)oy * p.yh + ox] = acc;
+    }
+}
+
 // Hot-path kernel.  Output tile 64 (x) x 16 (y) per workgroup of 256 lanes; lane (lx = tid & 63, ly = tid >> 6)
 // produces outputs (oy0 + 4*ly + {0..3}, ox0 + lx).
 template <int UP>
@@ -448,6 +496,10 @@ extern "C" int mgf_upfirdn2d(void* y, const void* x, const float* f, int dtype, 
     } else if (wide_ok && upx == 2 && padx0 == 2 && pady0 == 2 && !ep && in_w % 4 == 0 && out_h % 2 == 0) {
         const int blocks = n * c * (int)mgf_cdiv(out_h, 16 * FIR_SUB) * (out_w / 64);
         hipLaunchKernelGGL(fir_up2_wide, dim3(blocks), dim3(256), 0, stq, p);
+    } else if (dtype == MGF_F32 && sw == 1 && yw == 1 && fh <= 4 && fw <= 4 && upx == 1 && upy == 1 && downx == 2 && downy == 2 && !ep &&
+               out_w >= 32 && (int64_t)n * c * mgf_cdiv(out_h, 16) * mgf_cdiv(out_w, 64) <= INT32_MAX) {
+        const int blocks = n * c * (int)mgf_cdiv(out_h, 16) * (int)mgf_cdiv(out_w, 64);
+        hipLaunchKernelGGL(fir_down2_tiled, dim3(blocks), dim3(256), 0, stq, p);
     } else if (tiled) {
         const int blocks = n * c * (int)mgf_cdiv(out_h, 16) * (int)mgf_cdiv(out_w, 64);
         if (upx == 1) hipLaunchKernelGGL((upfirdn_tiled_f32<1>), dim3(blocks), dim3(256), 0, stq, p);

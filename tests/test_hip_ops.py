@@ -275,3 +275,19 @@ def test_blur_kernels_ragged_height():
         out = torch.full((2, 3, 2 * h, 2 * w), 7.0, device="cuda")
         cv.upfirdn_into(out, td, f.cuda(), up=1, pad=(1, 1, 1, 1), gain=4.0, separable=sep)
         assert rel_err(out, ref) < 3e-6, sep
+
+
+@pytest.mark.parametrize("shape,pad,taps,flip", [((2, 3, 70, 130), [1, 1, 1, 1], [1, 3, 3, 1], False), ((1, 2, 129, 201), [2, 1, 0, 3], None, True),
+                                                 ((1, 4, 256, 256), [1, 1, 1, 1], [1, 3, 3, 1], True)])
+def test_upfirdn2d_down2_tiled_vs_oracle(shape, pad, taps, flip):
+    """The LDS-tiled decimating kernel (down 2, <= 4x4 filter, >= 32 outputs per row): the gradient of the skip branch's 2x
+    upsampling in gradient mode; ragged tiles, asymmetric padding and a non-separable filter included."""
+    from morphganformer_amd.torch_utils.ops import upfirdn2d
+    from oracle.ops_ref import setup_filter_ref, upfirdn2d_ref
+    torch.manual_seed(17)
+    x = torch.randn(*shape)
+    f = setup_filter_ref(taps) if taps is not None else torch.randn(3, 4)
+    ref = upfirdn2d_ref(x, f, down=2, padding=pad, gain=4.0, flip_filter=flip)
+    out = upfirdn2d.upfirdn2d(x.cuda(), f.cuda(), down=2, padding=pad, gain=4.0, flip_filter=flip)
+    assert tuple(out.shape) == tuple(ref.shape) and out.shape[-1] >= 32
+    assert rel_err(out, ref) < 3e-6
