@@ -174,28 +174,62 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
     return {"w": w, "step": step, "loss": loss, "losses": losses}
 
 
-def project_many(G, targets, landmarks=None, dynamic=False, **kw):
+def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):
     """Pair-level sharding of BASELINE configs 3/5: rank r projects `targets[r::world]` (or, with dynamic=True, whatever the
     shared `distributed.WorkQueue` hands it), then ONE all_gather returns every item's {latent, loss, step} to every rank.
     targets: list of [1,3,S,S] device tensors (or image paths); landmarks: optional list of (lm_target, lm_steps) per item.
+    lockstep > 1 (gradient mode, static sharding): a rank advances that many of its items through one generator
+    forward/backward per step (GradientProjectionEngine with B targets) instead of one after the other.
     Returns dict(latents [N,k,D], losses [N], steps [N], items [N]) ordered by item id."""
     import torch.distributed as dist
     from .distributed import WorkQueue, gather_many, pack_result, shard_items, unpack_results
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
     order = WorkQueue(len(targets)) if dynamic else shard_items(len(targets), rank, world)
+    load = lambda t: t if isinstance(t, torch.Tensor) else image_transform(t, size=G.img_resolution, device=G.device)
     recs = []
-    for i in order:
-        t = targets[i]
-        if not isinstance(t, torch.Tensor):
-            t = image_transform(t, size=G.img_resolution, device=G.device)
-        lm_t, lm_s = landmarks[i] if landmarks is not None else (None, None)
-        r = project_image(G, t, lm_t, lm_s, **kw)
-        recs.append(pack_result(r["w"].to(G.device), r["loss"], r["step"], item=i))
+    if lockstep > 1:
+        if dynamic or kw.get("mode") != "gradient":
+            raise ValueError("lockstep groups need mode='gradient' and static sharding")
+        mine = list(order)
+        for g0 in range(0, len(mine), lockstep):
+            ids = mine[g0:g0 + lockstep]
+            res = _project_group(G, [load(targets[i]) for i in ids], [landmarks[i] for i in ids] if landmarks is not None else None, **kw)
+            recs += [pack_result(res["w"][j:j + 1].to(G.device), float(res["loss"][j]), int(res["step"][j]), item=i) for j, i in enumerate(ids)]
+    else:
+        for i in order:
+            lm_t, lm_s = landmarks[i] if landmarks is not None else (None, None)
+            r = project_image(G, load(targets[i]), lm_t, lm_s, **kw)
+            recs.append(pack_result(r["w"].to(G.device), r["loss"], r["step"], item=i))
     width = G.cfg.k * G.cfg.z_dim + 3
     mine = torch.stack(recs) if recs else torch.empty([0, width], dtype=torch.float64, device=G.device)
     rows = gather_many(mine, len(targets) if dynamic else -(-len(targets) // world))
     return unpack_results(rows, (G.cfg.k, G.cfg.z_dim))
+
+
+def _project_group(G, targets, landmarks, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None, eps=None,
+                   use_graph=True, noise_mode="random", use_mse=True, seed=None, weight_decay=0.0, mode="gradient", **unused):
+    """B targets through one lockstep GradientProjectionEngine; returns dict(w [B,k,D], step [B], loss [B], losses [B,steps])."""
+    args = args or ProjectionArgs()
+    if latent_mean is None or latent_std is None:
+        gen = None
+        if seed is not None:
+            gen = torch.Generator(device=G.device)
+            gen.manual_seed(seed)
+        latent_mean, latent_std = latent_stats(G, args.n_mean_latent, G.device, generator=gen)
+    tg = torch.cat([t.reshape(1, *t.shape[-3:]) for t in targets]).contiguous()
+    lm_t = lm_s = None
+    if landmarks is not None:
+        lm_t, lm_s = np.stack([np.asarray(l[0]) for l in landmarks]), np.stack([np.asarray(l[1]) for l in landmarks])
+    if len(targets) == 1 and lm_t is not None:
+        lm_t, lm_s = lm_t[0], lm_s[0]
+    eng = GradientProjectionEngine(G, tg, latent_mean, float(latent_std), args, weight_decay=weight_decay, percept=percept,
+                                   lm_target=lm_t, lm_steps=lm_s, eps=eps, noise_mode=noise_mode, use_graph=use_graph, use_mse=use_mse,
+                                   seed=0 if seed is None else seed)
+    w, step, loss, losses = eng.run().result()
+    if len(targets) == 1:
+        return {"w": w, "step": np.array([step]), "loss": np.array([loss]), "losses": losses[None]}
+    return {"w": w, "step": step, "loss": loss, "losses": losses}
 
 
 def second_stage(G, target, w_init, latent_std, lm_target, lm_steps, **kw):

@@ -234,3 +234,51 @@ def test_project_image_gradient_mode_beats_literal_sampling(golden, tmp_path):
     assert lit["step"] == int(g["best_step"])
     assert grad["loss"] < 0.9 * lit["loss"], (grad["loss"], lit["loss"])
     assert np.isfinite(grad["losses"]).all() and os.path.exists(tmp_path / "g.mat")
+
+
+def test_project_many_gradient_lockstep_groups(golden):
+    """project_many(mode='gradient', lockstep=2): a rank's items go through one generator pass per step two at a time; every item
+    still gets its own record, and an item's result does not depend on which group it travelled in (same noise stream)."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.projection import ProjectionArgs
+    g = golden("loop_tiny.npz")
+    G = _tiny_G()
+    t = torch.from_numpy(g["target"]).cuda()
+    targets = [t, (t * 0.9).contiguous(), (t * 0.8).contiguous()]
+    torch.manual_seed(3)
+    mean, std = torch.randn(17, 32, device="cuda"), 1.0
+    eps2 = torch.randn(6, 2, 17, 32, device="cuda")
+    kw = dict(args=ProjectionArgs(step=6, lr=0.05, lr_rampup=0.3), latent_mean=mean, latent_std=std, noise_mode="const", mode="gradient")
+    res = drivers.project_many(G, targets[:2], lockstep=2, eps=eps2, **kw)
+    assert res["items"].tolist() == [0, 1] and tuple(res["latents"].shape) == (2, 17, 32)
+    for j in range(2):
+        single = drivers.project_image(G, targets[j], None, None, eps=eps2[:, j:j + 1].contiguous(), **kw)
+        assert int(res["steps"][j]) == single["step"]
+        assert abs(float(res["losses"][j]) - single["loss"]) < 1e-4 * abs(single["loss"])
+    odd = drivers.project_many(G, targets, lockstep=2, seed=1, **kw)             # 3 items: a group of two and a group of one
+    assert odd["items"].tolist() == [0, 1, 2]
+    with pytest.raises(ValueError):
+        drivers.project_many(G, targets, lockstep=2, args=ProjectionArgs(step=6))
+
+
+def test_gradient_entry_points_reject_bad_arguments():
+    """The new C-ABI entry points validate on the host and report through mgf_last_error (no launch on bad input)."""
+    from morphganformer_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(64, device="cuda")
+    with pytest.raises(_lib.MgfError, match="alpha and gain"):
+        _lib.check(L.mgf_layer_act_bwd_f32(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), None, None, None, None, 1, 1, 1, 64, 0.0, 1.0, None))
+    with pytest.raises(_lib.MgfError, match="latent components"):
+        _lib.check(L.mgf_duplex_attention_bwd(x.data_ptr(), None, None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                                              1, 2, 2, 17, None))
+    with pytest.raises(_lib.MgfError, match="wdim must divide 256"):
+        _lib.check(L.mgf_style_demod_bwd_multi(x.data_ptr(), x.data_ptr(), 1, 1, 48, 64, None))
+    with pytest.raises(_lib.MgfError, match="bad split"):
+        _lib.check(L.mgf_relu_bwd_split_f32(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), 1, 4, 2, 16, None))
+    with pytest.raises(_lib.MgfError, match="output extent"):
+        _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 8, 8, 5, 4, None))
+    with pytest.raises(_lib.MgfError, match="null pointer"):
+        _lib.check(L.mgf_adam_step_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), None, x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 4, 2,
+                                       0.9, 0.999, 1e-8, 0.0, None))
+    with pytest.raises(_lib.MgfError, match="at most 16 rows"):
+        _lib.check(L.mgf_linear_bwd_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), 17, 4, 4, None))
