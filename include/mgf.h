@@ -139,6 +139,17 @@ typedef struct mgf_conv_prof_rec {
 int mgf_conv_profile_begin(void);
 int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs);
 
+/* Winograd F(2x2,3x3) form of the 3x3 / stride-1 / pad-1 correlation (same operands and result as the 9-tap mgf_conv_taps_f32 launch
+ * behind modulated_conv2d, training/networks.py:288-303, with 2.25x fewer matrix operations; results differ from the direct form
+ * by float32 rounding only).
+ *   winograd_weights: u[xi][ci][co] = gain * (G g G^T)[xi] for w [cout, cin, 3, 3] (xi = 0..15), once per checkpoint
+ *   conv3x3_winograd: y[n, co] = epilogue( out_scale[n, co] * sum_ci (in_scale[n, ci] * w[co, ci]) (*) x[n, ci] ), dense NCHW,
+ *                     cin % 8 == 0, cout % 64 == 0, h and w even; in_scale / out_scale / ep may be NULL */
+int mgf_winograd_weights_f32(float* u, const float* w, int32_t cout, int32_t cin, float gain, mgf_stream_t stream);
+int mgf_conv3x3_winograd_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
+                             int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
+                             mgf_stream_t stream);
+
 /* Last row (oy = 2h) and last column (ox = 2w) of the stride-2 transposed 3x3 conv output t [n, cout, 2h+1, pitch] from the same
  * operands as the 4-group mode of mgf_conv_taps_f32 (x [n,cin,h,w], packed taps, in_scale [n,cin] | NULL, out_scale | NULL).
  * With it the MFMA launch can tile exactly the h x w grid of 2x2 output quads (desc.tile_h = h, tile_w = w) instead of (h+1) x (w+1). */

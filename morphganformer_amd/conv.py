@@ -143,6 +143,38 @@ def transpose_packed(pc: PackedConv, flip: bool) -> PackedConv:
     return PackedConv(wp.contiguous(), None, pc.cin, pc.cout, pc.kh, pc.kw, cpad)
 
 
+def winograd_weights(w: torch.Tensor, gain: float = 1.0) -> torch.Tensor:
+    """[cout, cin, 3, 3] -> the 16 transformed weight planes u [16, cin, cout] of mgf_conv3x3_winograd_f32 (once per checkpoint)."""
+    _lib.require_gpu(w)
+    w = w.contiguous().float()
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) == (3, 3)
+    u = torch.empty([16, cin, cout], dtype=torch.float32, device=w.device)
+    _lib.check(_lib.lib().mgf_winograd_weights_f32(u.data_ptr(), w.data_ptr(), cout, cin, float(gain), _lib.stream_ptr()), "winograd_weights")
+    return u
+
+
+def winograd_ok(cin, cout, h, w):
+    """Shapes the Winograd kernel takes (and where it pays: >= 16x16 maps, whole 64-channel output tiles)."""
+    return cin % 8 == 0 and cout % 64 == 0 and h % 2 == 0 and w % 2 == 0 and min(h, w) >= 16
+
+
+def winograd_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None):
+    """3x3 / stride 1 / pad 1 correlation through the Winograd F(2x2,3x3) kernel; same contract as conv_forward(pad=(1, 1))."""
+    _lib.require_gpu(x, u, in_scale, out_scale, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and x.shape[1] == u.shape[1]
+    n, cin, h, w = x.shape
+    cout = u.shape[2]
+    if out is None:
+        out = torch.empty([n, cout, h, w], dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and tuple(out.shape) == (n, cout, h, w)
+    os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
+    rc = _lib.lib().mgf_conv3x3_winograd_f32(out.data_ptr(), x.data_ptr(), u.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale), n, cin, h, w,
+                                             cout, os_stride, C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
+    _lib.check(rc, "conv3x3_winograd")
+    return out
+
+
 def conv_large_forward(x, w, bias, stride, pad, act="relu", out=None):
     """Convolution with more than 9 taps (AlexNet's 11x11 and 5x5): the tap list is cut into groups of <= 9, each group is one
     launch accumulating into `out` through the residual port (linear), bias + activation follow in one mgf_bias_act pass."""

@@ -1,0 +1,319 @@
+// Winograd F(2x2, 3x3) form of the modulated 3x3 / stride-1 / pad-1 convolution on the FP32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32).  Contract: include/mgf.h (mgf_conv3x3_winograd_f32).  Same arithmetic role as the 9-tap launch of
+// mgf_conv_taps_f32 behind modulated_conv2d (training/networks.py:288-303, conv2d_resample.py:21-46) with 2.25x fewer matrix
+// operations:
+//   Y(2x2) = A^T [ (G g G^T) (.) (B^T d B) ] A        d: 4x4 input patch, g: 3x3 kernel            (Lavin & Gray 2016)
+// The 16 transformed weight planes U[xi][ci][co] = (G g G^T)[xi] are a checkpoint constant (host, once); the style modulation
+// s[ci] is applied to them on the way into LDS and the demodulation d[co] to the transformed-back outputs, exactly as in the
+// tap-list kernel (both commute with the transforms, which act on the spatial axes only).
+//
+// Workgroup (4 waves, one per SIMD, 256 accumulator registers each) = 64 output channels x one 16x16 output tile (8x8 Winograd
+// tiles) of one sample.  K is walked in chunks of 8 input channels; per chunk
+//   raw[8][18][18]    the input footprint (zero padded),
+//   V[16][8][64]      its transform B^T d B, one plane per Winograd position xi,
+//   U[16][8][64]      the (modulated) weight planes,
+// live in LDS and wave (m, g) runs 16 x 4 MFMAs: D_xi[32 co of half m][32 tiles of half g] += U_xi^T V_xi.
+// Pipeline: while the matrix pipe works on chunk i the same waves transform chunk i+1 (VALU/LDS work between the MFMAs) and the
+// global loads of chunk i+2 (input) / i+1 (weights) are in flight into registers.
+#include "mgf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WCK = 8;                 // input channels per chunk
+constexpr int WCO = 64;                // output channels per workgroup
+constexpr int WTS = 8;                 // Winograd tiles per side of the 16x16 output tile
+constexpr int WNT = WTS * WTS;         // 64 tiles
+constexpr int RAW_H = 2 * WTS + 2;     // 18
+constexpr int RAW_P = RAW_H + 2;       // row pitch 20: rows of a patch start 8-byte aligned
+constexpr int RAW_FLOATS = WCK * RAW_H * RAW_P;
+constexpr int PLANE_FLOATS = 16 * WCK * 64;          // one U or V buffer
+constexpr int XS = 11;                 // ceil(8*18*18 / 256)
+constexpr int US = 8;                  // 16*8*16 float4 / 256
+
+struct WinoParams {
+    float* y;
+    const float* x;
+    const float* u;           // [16][cin][cout]
+    const float* in_scale;    // [n][cin] or null
+    const float* out_scale;   // [n or 1][cout] or null
+    int n, cin, h, w, cout, os_stride;
+    int tiles_x, tiles_y, co_tiles;
+    mgf_epilogue ep;
+    int has_ep;
+};
+
+__global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
+    extern __shared__ float lds[];
+    float* raw = lds;
+    float* Us = raw + RAW_FLOATS;                    // [2][16][8][64]
+    float* Vs = Us + 2 * PLANE_FLOATS;               // [2][16][8][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave & 1, wg = wave >> 1;
+
+    int b = blockIdx.x;
+    const int cot = b % p.co_tiles; b /= p.co_tiles;
+    const int ptx = b % p.tiles_x; b /= p.tiles_x;
+    const int pty = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int co0 = cot * WCO, oy0 = pty * 2 * WTS, ox0 = ptx * 2 * WTS;
+    const int plane = p.h * p.w;
+    const float* xn = p.x + (int64_t)n * p.cin * plane;
+    const float* sc = p.in_scale ? p.in_scale + (int64_t)n * p.cin : nullptr;
+
+    // ---- chunk-invariant staging slots ----
+    int xoff[XS], xdst[XS];
+#pragma unroll
+    for (int j = 0; j < XS; ++j) {
+        const int e = tid + 256 * j;
+        const int ch = e / (RAW_H * RAW_H), rem = e - ch * (RAW_H * RAW_H);
+        const int r = rem / RAW_H, q = rem - r * RAW_H;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
+        const bool in_patch = e < WCK * RAW_H * RAW_H;
+        xdst[j] = in_patch ? (ch * RAW_H + r) * RAW_P + q : -1;
+        xoff[j] = (in_patch && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? ch * plane + iy * p.w + ix : -1;
+    }
+    int uoff[US], uch[US];
+#pragma unroll
+    for (int j = 0; j < US; ++j) {
+        const int e = tid + 256 * j;
+        const int c4 = e & 15, rest = e >> 4;
+        uch[j] = rest & 7;
+        uoff[j] = ((rest >> 3) * p.cin + uch[j]) * p.cout + co0 + c4 * 4;
+    }
+    float xr[XS];
+    float4 ur[US];
+    float usc[US];
+    auto load_x = [&](int c0) {
+        const float* xc = xn + (int64_t)c0 * plane;
+#pragma unroll
+        for (int j = 0; j < XS; ++j) xr[j] = xc[xoff[j] > 0 ? xoff[j] : 0];
+    };
+    auto load_u = [&](int c0) {
+        const float* uc = p.u + (int64_t)c0 * p.cout;
+#pragma unroll
+        for (int j = 0; j < US; ++j) {
+            ur[j] = *reinterpret_cast<const float4*>(uc + uoff[j]);
+            usc[j] = sc ? sc[c0 + uch[j]] : 1.f;
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int j = 0; j < XS; ++j)
+            if (xdst[j] >= 0) raw[xdst[j]] = xoff[j] >= 0 ? xr[j] : 0.f;
+    };
+    auto store_u = [&](float* U) {
+#pragma unroll
+        for (int j = 0; j < US; ++j) {
+            float4 v = ur[j];
+            v.x *= usc[j]; v.y *= usc[j]; v.z *= usc[j]; v.w *= usc[j];
+            *reinterpret_cast<float4*>(U + (tid + 256 * j) * 4) = v;
+        }
+    };
+    // B^T d B of the two (channel, tile) patches this lane owns
+    auto transform = [&](float* V) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 256 * q;
+            const int ch = e >> 6, tile = e & 63;
+            const int ty = tile >> 3, tx = tile & 7;
+            const float* src = raw + (ch * RAW_H + 2 * ty) * RAW_P + 2 * tx;
+            float d[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float2 a = *reinterpret_cast<const float2*>(src + u * RAW_P);
+                const float2 c = *reinterpret_cast<const float2*>(src + u * RAW_P + 2);
+                d[u][0] = a.x; d[u][1] = a.y; d[u][2] = c.x; d[u][3] = c.y;
+            }
+            float t[4][4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                t[0][v] = d[0][v] - d[2][v];
+                t[1][v] = d[1][v] + d[2][v];
+                t[2][v] = d[2][v] - d[1][v];
+                t[3][v] = d[1][v] - d[3][v];
+            }
+            float* dst = V + ch * 64 + tile;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                dst[(a * 4 + 0) * (WCK * 64)] = t[a][0] - t[a][2];
+                dst[(a * 4 + 1) * (WCK * 64)] = t[a][1] + t[a][2];
+                dst[(a * 4 + 2) * (WCK * 64)] = t[a][2] - t[a][1];
+                dst[(a * 4 + 3) * (WCK * 64)] = t[a][1] - t[a][3];
+            }
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+
+    auto mfma_chunk = [&](const float* U, const float* V) {
+        const float* ua = U + half * 64 + wm * 32 + l31;
+        const float* vb = V + half * 64 + wg * 32 + l31;
+        float fa[2][WCK / 2], fb[2][WCK / 2];
+        auto fetch = [&](int xi, int set) {
+#pragma unroll
+            for (int kk = 0; kk < WCK / 2; ++kk) {
+                fa[set][kk] = ua[(xi * WCK + 2 * kk) * 64];
+                fb[set][kk] = vb[(xi * WCK + 2 * kk) * 64];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            if (xi + 1 < 16) fetch(xi + 1, (xi + 1) & 1);
+#pragma unroll
+            for (int kk = 0; kk < WCK / 2; ++kk)
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[xi & 1][kk], fb[xi & 1][kk], acc[xi], 0, 0, 0);
+        }
+    };
+
+    const int nchunks = p.cin / WCK;
+    // ---- prologue: chunk 0 transformed, chunk 1 raw ----
+    load_x(0);
+    load_u(0);
+    store_x();
+    store_u(Us);
+    __syncthreads();
+    transform(Vs);
+    __syncthreads();
+    if (nchunks > 1) {
+        load_x(WCK);
+        store_x();
+    }
+    __syncthreads();
+    for (int i = 0; i < nchunks; ++i) {
+        const int cur = i & 1, nxt = cur ^ 1;
+        if (i + 2 < nchunks) load_x((i + 2) * WCK);
+        if (i + 1 < nchunks) load_u((i + 1) * WCK);
+        mfma_chunk(Us + cur * PLANE_FLOATS, Vs + cur * PLANE_FLOATS);
+        if (i + 1 < nchunks) transform(Vs + nxt * PLANE_FLOATS);
+        __syncthreads();
+        if (i + 2 < nchunks) store_x();
+        if (i + 1 < nchunks) store_u(Us + nxt * PLANE_FLOATS);
+        __syncthreads();
+    }
+
+    // ---- output transform A^T m A per (channel, tile), demodulation, epilogue, store ----
+    const int tile = wg * 32 + l31;
+    const int ty = tile >> 3, tx = tile & 7;
+    const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
+    const bool ok_px = oy < p.h && ox < p.w;           // h, w even: the whole 2x2 quad is inside whenever its corner is
+    const float* osc = p.out_scale ? p.out_scale + (int64_t)n * p.os_stride : nullptr;
+    const bool do_ep = p.has_ep != 0;
+    const float ns = (do_ep && p.ep.noise) ? (p.ep.noise_strength ? *p.ep.noise_strength : 1.f) : 0.f;
+    float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (do_ep && p.ep.noise && ok_px) {
+        const float* np_ = p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane + (int64_t)oy * p.w + ox;
+        nz[0][0] = np_[0] * ns; nz[0][1] = np_[1] * ns; nz[1][0] = np_[p.w] * ns; nz[1][1] = np_[p.w + 1] * ns;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float s0[4], s1[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            s0[bb] = acc[0 + bb][r] + acc[4 + bb][r] + acc[8 + bb][r];
+            s1[bb] = acc[4 + bb][r] - acc[8 + bb][r] - acc[12 + bb][r];
+        }
+        float yv[2][2];
+        yv[0][0] = s0[0] + s0[1] + s0[2];
+        yv[0][1] = s0[1] - s0[2] - s0[3];
+        yv[1][0] = s1[0] + s1[1] + s1[2];
+        yv[1][1] = s1[1] - s1[2] - s1[3];
+        if (!ok_px || co >= p.cout) continue;
+        const float os = osc ? osc[co] : 1.f;
+        const float bv = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
+        const int64_t off = ((int64_t)n * p.cout + co) * plane + (int64_t)oy * p.w + ox;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float v[2];
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                float t = yv[a][bb] * os;
+                if (do_ep) {
+                    t += nz[a][bb];
+                    t += bv;
+                    if (p.ep.act == MGF_ACT_LRELU) t = t > 0.f ? t : t * p.ep.alpha;
+                    else if (p.ep.act == MGF_ACT_RELU) t = t > 0.f ? t : 0.f;
+                    t *= p.ep.gain;
+                    if (p.ep.residual) t += p.ep.residual[off + a * p.w + bb];
+                }
+                v[bb] = t;
+            }
+            *reinterpret_cast<float2*>(p.y + off + a * p.w) = make_float2(v[0], v[1]);
+        }
+    }
+}
+
+// U[xi = 4a + b][ci][co] = gain * (G g G^T)[a][b] from w [cout][cin][3][3]; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ __launch_bounds__(256) void wino_weights_kernel(float* u, const float* w, int cout, int cin, float gain) {
+    const int64_t total = (int64_t)cout * cin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % cout), ci = (int)(i / cout);
+        const float* g = w + ((int64_t)co * cin + ci) * 9;
+        float t[4][3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            t[0][v] = g[v];
+            t[1][v] = 0.5f * (g[v] + g[3 + v] + g[6 + v]);
+            t[2][v] = 0.5f * (g[v] - g[3 + v] + g[6 + v]);
+            t[3][v] = g[6 + v];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float o0 = t[a][0], o1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), o2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), o3 = t[a][2];
+            float* dst = u + ((int64_t)(a * 4) * cin + ci) * cout + co;
+            dst[0] = o0 * gain;
+            dst[(int64_t)cin * cout] = o1 * gain;
+            dst[(int64_t)2 * cin * cout] = o2 * gain;
+            dst[(int64_t)3 * cin * cout] = o3 * gain;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mgf_winograd_weights_f32(float* u, const float* w, int32_t cout, int32_t cin, float gain, mgf_stream_t stream) {
+    MGF_REQUIRE(u && w && cout >= 1 && cin >= 1, MGF_EINVAL, "winograd_weights: bad arguments");
+    hipLaunchKernelGGL(wino_weights_kernel, dim3(mgf_stream_grid((int64_t)cout * cin, 256, 1)), dim3(256), 0, (hipStream_t)stream, u, w, cout, cin,
+                       gain);
+    MGF_CHECK_LAUNCH("winograd_weights");
+    return MGF_OK;
+}
+
+extern "C" int mgf_conv3x3_winograd_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
+                                        int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
+                                        mgf_stream_t stream) {
+    MGF_REQUIRE(y && x && u && n >= 1 && cin >= 1 && cout >= 1 && h >= 2 && w >= 2, MGF_EINVAL, "conv3x3_winograd: bad arguments");
+    MGF_REQUIRE(cin % WCK == 0 && cout % WCO == 0, MGF_EUNSUPPORTED, "conv3x3_winograd: cin must be a multiple of %d and cout of %d (got %d, %d)",
+                WCK, WCO, cin, cout);
+    MGF_REQUIRE(h % 2 == 0 && w % 2 == 0, MGF_EUNSUPPORTED, "conv3x3_winograd: even feature-map sides only (got %dx%d)", h, w);
+    MGF_REQUIRE((int64_t)cin * h * w <= INT32_MAX / 2 && (int64_t)16 * cin * cout <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd: tensor too large");
+    MGF_REQUIRE(((uintptr_t)u % 16) == 0 && ((uintptr_t)y % 8) == 0, MGF_EINVAL, "conv3x3_winograd: u must be 16-byte and y 8-byte aligned");
+    if (ep) MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU, MGF_EUNSUPPORTED,
+                        "conv3x3_winograd: epilogue activation %d unsupported", ep->act);
+    WinoParams p;
+    p.y = y; p.x = x; p.u = u; p.in_scale = in_scale; p.out_scale = out_scale;
+    p.n = n; p.cin = cin; p.h = h; p.w = w; p.cout = cout; p.os_stride = out_scale_stride;
+    p.tiles_x = (int)mgf_cdiv(w, 2 * WTS); p.tiles_y = (int)mgf_cdiv(h, 2 * WTS); p.co_tiles = cout / WCO;
+    p.has_ep = ep != nullptr;
+    if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
+    const int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
+    MGF_REQUIRE(blocks <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd: too many workgroups");
+    const size_t lds = (size_t)(RAW_FLOATS + 4 * PLANE_FLOATS) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { mgf_set_error("conv3x3_winograd: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    MGF_CHECK_LAUNCH("conv3x3_winograd");
+    return MGF_OK;
+}

@@ -291,3 +291,32 @@ def test_upfirdn2d_down2_tiled_vs_oracle(shape, pad, taps, flip):
     out = upfirdn2d.upfirdn2d(x.cuda(), f.cuda(), down=2, padding=pad, gain=4.0, flip_filter=flip)
     assert tuple(out.shape) == tuple(ref.shape) and out.shape[-1] >= 32
     assert rel_err(out, ref) < 3e-6
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 32), (1, 16, 128, 24, 40), (3, 72, 64, 18, 34), (1, 512, 512, 16, 16)])
+def test_winograd_conv_matches_direct_conv_and_oracle(n, cin, cout, h, w):
+    """Winograd F(2x2,3x3) kernel vs the 9-tap MFMA kernel and the CPU oracle: style modulation, demodulation, fused
+    noise/bias/lrelu/residual epilogue, ragged 16x16 tiles (maps that are not multiples of 16)."""
+    from morphganformer_amd import _lib, conv as cv
+    from oracle.ops_ref import bias_act_ref
+    torch.manual_seed(cin + h)
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+    s, d = 1 + 0.3 * torch.randn(n, cin), 0.5 + torch.rand(n, cout)
+    noise, bias, resid = torch.randn(n, h, w), torch.randn(cout), torch.randn(n, cout, h, w)
+    strength = torch.tensor([0.37])
+    ref = torch.nn.functional.conv2d((x * s[:, :, None, None]).double(), wt.double(), padding=1) * d[:, :, None, None].double()
+    ref_ep = bias_act_ref(ref.float() + noise[:, None] * strength, bias, act="lrelu", gain=1.3) + resid
+    f = lambda t: t.cuda().contiguous()
+    xd, sd, dd = f(x), f(s), f(d)
+    u = cv.winograd_weights(f(wt), gain=1.0)
+    pc = cv.pack_weights(f(wt))
+    plain = cv.winograd_forward(xd, u, in_scale=sd, out_scale=dd)
+    direct = cv.conv_forward(xd, pc, pad=(1, 1), in_scale=sd, out_scale=dd)
+    assert rel_err(plain, ref) < 2e-5
+    assert rel_err(plain, direct) < 2e-5
+    nd, bd, rd, st = f(noise), f(bias), f(resid), strength.cuda()
+    ep = _lib.make_epilogue(bias=bd, noise=nd, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.3, residual=rd)
+    out = cv.winograd_forward(xd, u, in_scale=sd, out_scale=dd, epilogue=ep)
+    assert rel_err(out, ref_ep) < 2e-5
+    assert rel_err(cv.winograd_forward(xd, u), torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)) < 2e-5
