@@ -142,7 +142,8 @@ int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs);
 /* Winograd F(2x2,3x3) form of the 3x3 / stride-1 / pad-1 correlation (same operands and result as the 9-tap mgf_conv_taps_f32 launch
  * behind modulated_conv2d, training/networks.py:288-303, with 2.25x fewer matrix operations; results differ from the direct form
  * by float32 rounding only).
- *   winograd_weights: u[xi][ci][co] = gain * (G g G^T)[xi] for w [cout, cin, 3, 3] (xi = 0..15), once per checkpoint
+ *   winograd_weights: u[xi][ci / 8][co][slot] = gain * (G g G^T)[xi] for w [cout, cin, 3, 3] (xi = 0..15; the 8 channels of a chunk
+ *                     are stored in MFMA operand order, slot 4*(c%2) + (c%8)/2), once per checkpoint; 16*cin*cout floats
  *   conv3x3_winograd: y[n, co] = epilogue( out_scale[n, co] * sum_ci (in_scale[n, ci] * w[co, ci]) (*) x[n, ci] ), dense NCHW,
  *                     cin % 8 == 0, cout % 64 == 0, h and w even; in_scale / out_scale / ep may be NULL */
 int mgf_winograd_weights_f32(float* u, const float* w, int32_t cout, int32_t cin, float gain, mgf_stream_t stream);

@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvParams p) {
 
 // ---- optional per-launch instrumentation (mgf_conv_profile_begin/end): HIP events on the launch stream around the main
 // kernel only (not the split-K reduce), so the durations line up with rocprofv3's per-kernel trace ----
-struct ProfRec { hipEvent_t e0, e1; int wm, wn, mode, pipe, nt, ksplit; double flops, bytes; };
+struct ProfRec { hipEvent_t e0, e1; int wm, wn, mode, pipe, nt, ksplit; double flops, bytes; const char* name; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 
@@ -669,6 +669,7 @@ struct ProfScope {
     ProfScope(hipStream_t s, int wm, int wn, int mode, int pipe, int nt, const ConvParams& p) : st(s), on(g_prof_on) {
         if (!on) return;
         ProfRec r;
+        r.name = nullptr;
         r.wm = wm; r.wn = wn; r.mode = mode; r.pipe = pipe; r.nt = nt; r.ksplit = p.ksplit;
         const mgf_conv_desc& d = p.d;
         // algorithmic FLOPs: conv = 2*taps*cin*cout per output pixel; the stride-2 transposed conv is
@@ -772,6 +773,19 @@ extern "C" int mgf_conv_profile_begin(void) {
     return MGF_OK;
 }
 
+// the other convolution kernels of the library (csrc/wino.hip) report through the same instrumentation
+void mgf_prof_external_begin(hipStream_t st, const char* name, double flops, double bytes) {
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.name = name; r.wm = r.wn = r.mode = r.pipe = r.nt = 0; r.ksplit = 1; r.flops = flops; r.bytes = bytes;
+    (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, st);
+    g_prof.push_back(r);
+}
+void mgf_prof_external_end(hipStream_t st) {
+    if (g_prof_on && !g_prof.empty()) (void)hipEventRecord(g_prof.back().e1, st);
+}
+
 extern "C" int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs) {
     g_prof_on = false;
     int n = 0;
@@ -781,7 +795,8 @@ extern "C" int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs) {
         (void)hipEventElapsedTime(&ms, r.e0, r.e1);
         if (out && n < max_recs) {
             mgf_conv_prof_rec& o = out[n];
-            snprintf(o.kernel, sizeof(o.kernel), "conv_taps_kernel<%d, %d, %d, %s, %d>", r.wm, r.wn, r.mode, r.pipe ? "true" : "false", r.nt);
+            if (r.name) snprintf(o.kernel, sizeof(o.kernel), "%s", r.name);
+            else snprintf(o.kernel, sizeof(o.kernel), "conv_taps_kernel<%d, %d, %d, %s, %d>", r.wm, r.wn, r.mode, r.pipe ? "true" : "false", r.nt);
             o.flops = r.flops; o.bytes = r.bytes; o.seconds = ms * 1e-3; o.ksplit = r.ksplit;
         }
         ++n;

@@ -40,6 +40,10 @@ static inline int mgf_stream_grid(int64_t work_items, int block, int per_thread)
     return (int)g;
 }
 
+// instrumentation hooks of mgf_conv_profile_begin/end for convolution kernels outside conv_taps.hip (no-ops unless profiling is on)
+void mgf_prof_external_begin(hipStream_t st, const char* name, double flops, double bytes);
+void mgf_prof_external_end(hipStream_t st);
+
 #ifdef __HIPCC__
 // Sum over the 64 lanes of a wave (DPP/bpermute butterflies emitted by the compiler for __shfl_xor).
 template <typename T>

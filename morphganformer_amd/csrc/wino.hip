@@ -13,8 +13,8 @@
 //   V[16][8][64]      its transform B^T d B, one plane per Winograd position xi,
 //   U[16][8][64]      the (modulated) weight planes,
 // live in LDS and wave (m, g) runs 16 x 4 MFMAs: D_xi[32 co of half m][32 tiles of half g] += U_xi^T V_xi.
-// Pipeline: while the matrix pipe works on chunk i the same waves transform chunk i+1 (VALU/LDS work between the MFMAs) and the
-// global loads of chunk i+2 (input) / i+1 (weights) are in flight into registers.
+// Pipeline (one barrier per chunk): the registers holding X(i+2) / U(i+1) are parked in LDS, the global loads of X(i+3) / U(i+2)
+// are issued, chunk i+1 is transformed, then the 64 MFMAs of chunk i run while those loads are in flight.
 #include "mgf_common.h"
 
 namespace {
@@ -32,6 +32,8 @@ constexpr int PLANE_FLOATS = 16 * WCK * 64;          // one U or V buffer
 constexpr int XS = 11;                 // ceil(8*18*18 / 256)
 constexpr int US = 8;                  // 16*8*16 float4 / 256
 
+__device__ const float g_wino_ones[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+
 struct WinoParams {
     float* y;
     const float* x;
@@ -46,8 +48,8 @@ struct WinoParams {
 
 __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
     extern __shared__ float lds[];
-    float* raw = lds;
-    float* Us = raw + RAW_FLOATS;                    // [2][16][8][64]
+    float* raw = lds;                                // [2][8][18][20]
+    float* Us = raw + 2 * RAW_FLOATS;                // [2][16][8][64]
     float* Vs = Us + 2 * PLANE_FLOATS;               // [2][16][8][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
         const int r = rem / RAW_H, q = rem - r * RAW_H;
         const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
         const bool in_patch = e < WCK * RAW_H * RAW_H;
-        xdst[j] = in_patch ? (ch * RAW_H + r) * RAW_P + q : -1;
+        xdst[j] = in_patch ? (ch * RAW_H + r) * RAW_P + q : RAW_FLOATS - 1;     // surplus slots land in a pad column (never read)
         xoff[j] = (in_patch && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? ch * plane + iy * p.w + ix : -1;
     }
     int uoff[US], uch[US];
@@ -86,6 +88,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
     float xr[XS];
     float4 ur[US];
     float usc[US];
+    const float* scp = sc ? sc : g_wino_ones;        // no modulation: a table of ones keeps the staging code branch-free
+    const int scmask = sc ? ~0 : 7;
     auto load_x = [&](int c0) {
         const float* xc = xn + (int64_t)c0 * plane;
 #pragma unroll
@@ -96,13 +100,12 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
 #pragma unroll
         for (int j = 0; j < US; ++j) {
             ur[j] = *reinterpret_cast<const float4*>(uc + uoff[j]);
-            usc[j] = sc ? sc[c0 + uch[j]] : 1.f;
+            usc[j] = scp[(c0 + uch[j]) & scmask];
         }
     };
-    auto store_x = [&]() {
+    auto store_x = [&](float* R) {
 #pragma unroll
-        for (int j = 0; j < XS; ++j)
-            if (xdst[j] >= 0) raw[xdst[j]] = xoff[j] >= 0 ? xr[j] : 0.f;
+        for (int j = 0; j < XS; ++j) R[xdst[j]] = xoff[j] >= 0 ? xr[j] : 0.f;
     };
     auto store_u = [&](float* U) {
 #pragma unroll
@@ -113,13 +116,13 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
         }
     };
     // B^T d B of the two (channel, tile) patches this lane owns
-    auto transform = [&](float* V) {
+    auto transform = [&](const float* R, float* V) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = tid + 256 * q;
             const int ch = e >> 6, tile = e & 63;
             const int ty = tile >> 3, tx = tile & 7;
-            const float* src = raw + (ch * RAW_H + 2 * ty) * RAW_P + 2 * tx;
+            const float* src = R + (ch * RAW_H + 2 * ty) * RAW_P + 2 * tx;
             float d[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -174,28 +177,33 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
     };
 
     const int nchunks = p.cin / WCK;
-    // ---- prologue: chunk 0 transformed, chunk 1 raw ----
+    const int last = nchunks - 1;
+    auto chunk0 = [&](int i) { return (i < last ? i : last) * WCK; };      // tail iterations re-load the last chunk (never consumed)
+    // ---- prologue: chunk 0 transformed (U in Us[0], V in Vs[0]), chunk 1 raw in raw[1]; registers hold X(2) and U(1) ----
+    float* raw1 = raw + RAW_FLOATS;
     load_x(0);
     load_u(0);
-    store_x();
+    store_x(raw);
     store_u(Us);
+    load_x(chunk0(1));
     __syncthreads();
-    transform(Vs);
+    transform(raw, Vs);
+    store_x(raw1);
+    load_x(chunk0(2));
+    load_u(chunk0(1));
     __syncthreads();
-    if (nchunks > 1) {
-        load_x(WCK);
-        store_x();
-    }
-    __syncthreads();
+    // ---- steady state: ONE basic block and one barrier per chunk: park the registers loaded last iteration in LDS (X of chunk
+    // i+2, U of chunk i+1), issue the global loads of X(i+3) / U(i+2), transform chunk i+1, run the 64 MFMAs of chunk i ----
     for (int i = 0; i < nchunks; ++i) {
         const int cur = i & 1, nxt = cur ^ 1;
-        if (i + 2 < nchunks) load_x((i + 2) * WCK);
-        if (i + 1 < nchunks) load_u((i + 1) * WCK);
+        float* raw_in = cur ? raw : raw1;                 // holds chunk i+1 (written during iteration i-1)
+        float* raw_out = cur ? raw1 : raw;                // receives chunk i+2
+        store_x(raw_out);
+        store_u(Us + nxt * PLANE_FLOATS);
+        load_x(chunk0(i + 3));
+        load_u(chunk0(i + 2));
+        transform(raw_in, Vs + nxt * PLANE_FLOATS);
         mfma_chunk(Us + cur * PLANE_FLOATS, Vs + cur * PLANE_FLOATS);
-        if (i + 1 < nchunks) transform(Vs + nxt * PLANE_FLOATS);
-        __syncthreads();
-        if (i + 2 < nchunks) store_x();
-        if (i + 1 < nchunks) store_u(Us + nxt * PLANE_FLOATS);
         __syncthreads();
     }
 
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
         yv[0][1] = s0[1] - s0[2] - s0[3];
         yv[1][0] = s1[0] + s1[1] + s1[2];
         yv[1][1] = s1[1] - s1[2] - s1[3];
-        if (!ok_px || co >= p.cout) continue;
+        if (!ok_px || co >= p.cout) { __builtin_amdgcn_sched_barrier(0); continue; }
         const float os = osc ? osc[co] : 1.f;
         const float bv = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
         const int64_t off = ((int64_t)n * p.cout + co) * plane + (int64_t)oy * p.w + ox;
@@ -248,6 +256,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
             }
             *reinterpret_cast<float2*>(p.y + off + a * p.w) = make_float2(v[0], v[1]);
         }
+        __builtin_amdgcn_sched_barrier(0);           // one channel row at a time: keeps the accumulator read-out (256 registers) from being hoisted into VGPRs at once
     }
 }
 
@@ -306,14 +315,18 @@ extern "C" int mgf_conv3x3_winograd_f32(float* y, const float* x, const float* u
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
     const int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
     MGF_REQUIRE(blocks <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd: too many workgroups");
-    const size_t lds = (size_t)(RAW_FLOATS + 4 * PLANE_FLOATS) * sizeof(float);
+    const size_t lds = (size_t)(2 * RAW_FLOATS + 4 * PLANE_FLOATS) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)wino_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { mgf_set_error("conv3x3_winograd: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
         attr_set = true;
     }
+    // algorithmic accounting of the direct form (what the launch replaces): 2*9*cin*cout FLOPs per output pixel; x, y, weights once
+    mgf_prof_external_begin((hipStream_t)stream, "wino_conv_kernel", 2.0 * 9 * cin * (double)cout * h * w * n,
+                            4.0 * ((double)n * cin * h * w + 9.0 * cin * cout + (double)n * cout * h * w));
     hipLaunchKernelGGL(wino_conv_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    mgf_prof_external_end((hipStream_t)stream);
     MGF_CHECK_LAUNCH("conv3x3_winograd");
     return MGF_OK;
 }

@@ -30,6 +30,7 @@ from .synth_weights import GeneratorConfig
 
 SQRT2 = math.sqrt(2.0)
 SQRT_HALF = math.sqrt(0.5)
+USE_WINOGRAD = os.environ.get("MGF_WINOGRAD", "1") != "0"
 
 
 def pack_mapping_params(sd, cfg: GeneratorConfig) -> np.ndarray:
@@ -96,6 +97,7 @@ class ConvLayerPlan:
     act_gain: float = 1.0
     attn: "AttnPlan" = None
     w_raw: torch.Tensor = None      # toRGB only: [img_channels, cin] un-packed weights for the fused projection
+    wino_u: torch.Tensor = None     # 3x3 stride-1 layers on 16^2 .. 256^2 maps: Winograd-transformed weights (csrc/wino.hip)
     s_off: int = 0                  # offsets (floats) into the per-sample style / demod arenas
     d_off: int = 0
 
@@ -143,6 +145,10 @@ class SynthesisPlan:
                 wg = 1.0 / math.sqrt(cin * 9)
                 # up=1: correlation (flip_weight=True); up=2: conv_transpose2d on the un-flipped weights
                 lp.pc = cv.pack_weights(t32(w), gain=wg, flip=False, want_wsq=True)
+                # Winograd F(2x2,3x3) where it beats the 9-tap kernel (measured, tools/wino_micro.py): 3x3 stride-1 layers with
+                # >= 128 channels on 16^2 .. 256^2 maps; MGF_WINOGRAD=0 (tuning hook) keeps the direct kernel everywhere
+                if kind == "conv3" and USE_WINOGRAD and cv.winograd_ok(cin, cout, res, res) and res <= 256 and name != "conv_last":
+                    lp.wino_u = cv.winograd_weights(t32(w), gain=wg)
             lp.aff_w = t32(f64(p + ".affine.weight"))
             lp.aff_b = t32(f64(p + ".affine.bias"))
             if (p + ".biasAct.bias") in sd:
@@ -427,6 +433,8 @@ class Generator:
             # plan.fir is the outer product of the 1-D resample kernel (networks.py:1113 / upfirdn2d.setup_filter): separable
             y = cv.upfirdn_into(B[key], t, self.plan.fir, up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=None if has_att else ep,
                                 separable=True)
+        elif lp.wino_u is not None:
+            y = cv.winograd_forward(x, lp.wino_u, in_scale=s, out_scale=d, epilogue=None if has_att else ep, out=B[key])
         else:
             y = cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=s, out_scale=d, epilogue=None if has_att else ep, out=B[key])
         if self.taps is not None:
