@@ -159,6 +159,12 @@ def winograd_ok(cin, cout, h, w):
     return cin % 8 == 0 and cout % 64 == 0 and h % 2 == 0 and w % 2 == 0 and min(h, w) >= 16
 
 
+def winograd_fills_chip(n, cout, h, w):
+    """The Winograd kernel has no split-K: one workgroup per (sample, 16x16 tile, 64 channels), one workgroup per CU.  Below two
+    waves of workgroups (2 x 256) the tap-list kernel with its split-K path is faster (a single 1024^2 projection, n = 1)."""
+    return n * -(-h // 16) * -(-w // 16) * (cout // 64) >= 512
+
+
 def winograd_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None):
     """3x3 / stride 1 / pad 1 correlation through the Winograd F(2x2,3x3) kernel; same contract as conv_forward(pad=(1, 1))."""
     _lib.require_gpu(x, u, in_scale, out_scale, out)

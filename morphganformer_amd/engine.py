@@ -433,7 +433,7 @@ class Generator:
             # plan.fir is the outer product of the 1-D resample kernel (networks.py:1113 / upfirdn2d.setup_filter): separable
             y = cv.upfirdn_into(B[key], t, self.plan.fir, up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=None if has_att else ep,
                                 separable=True)
-        elif lp.wino_u is not None:
+        elif lp.wino_u is not None and cv.winograd_fills_chip(n, lp.cout, lp.res, lp.res):
             y = cv.winograd_forward(x, lp.wino_u, in_scale=s, out_scale=d, epilogue=None if has_att else ep, out=B[key])
         else:
             y = cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=s, out_scale=d, epilogue=None if has_att else ep, out=B[key])

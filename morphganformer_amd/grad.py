@@ -36,6 +36,13 @@ class GeneratorGrad:
             # correlation with the same taps; 1x1 needs no flip
             self.T[lp.name] = cv.transpose_packed(lp.pc, flip=(lp.kind == "conv3"))
         self.Tskip = {res: cv.transpose_packed(pc, flip=False) for res, pc in P.skips.items()}
+        # layers the forward runs through the Winograd kernel take it for their data gradient too: the transposed, flipped kernel
+        # is rebuilt from the packed taps (gain already folded in) and transformed once
+        self.Tw = {}
+        for lp in P.layers:
+            if lp.wino_u is not None:
+                w = lp.pc.wp[:, :, :lp.cout].reshape(3, 3, lp.cin, lp.cout).permute(3, 2, 0, 1)        # [cout, cin, kh, kw]
+                self.Tw[lp.name] = cv.winograd_weights(w.permute(1, 0, 2, 3).flip(2, 3).contiguous())
         self._bufs = {}
         self._n = None
         self.z = None
@@ -141,7 +148,10 @@ class GeneratorGrad:
             g = cv.conv_forward(dT, self.T[lp.name], stride=2, pad=(0, 0), in_scale=d, out=self.buf("g", x_in.shape))
         else:
             pad = (1, 1) if lp.kind == "conv3" else (0, 0)
-            g = cv.conv_forward(dc, self.T[lp.name], pad=pad, in_scale=d, out=self.buf("g", x_in.shape))
+            if lp.name in self.Tw and cv.winograd_fills_chip(n, x_in.shape[1], h, w):
+                g = cv.winograd_forward(dc, self.Tw[lp.name], in_scale=d, out=self.buf("g", x_in.shape))
+            else:
+                g = cv.conv_forward(dc, self.T[lp.name], pad=pad, in_scale=d, out=self.buf("g", x_in.shape))
         dx = self.buf(dx_role, x_in.shape)
         ci, hi = x_in.shape[1], x_in.shape[2] * x_in.shape[3]
         _lib.check(L.mgf_style_grad_f32(self.ds_part[lp.name].data_ptr(), dx.data_ptr(), x_in.data_ptr(), g.data_ptr(),
