@@ -147,6 +147,12 @@ int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs);
  *   conv3x3_winograd: y[n, co] = epilogue( out_scale[n, co] * sum_ci (in_scale[n, ci] * w[co, ci]) (*) x[n, ci] ), dense NCHW,
  *                     cin % 8 == 0, cout % 64 == 0, h and w even; in_scale / out_scale / ep may be NULL */
 int mgf_winograd_weights_f32(float* u, const float* w, int32_t cout, int32_t cin, float gain, mgf_stream_t stream);
+/* Second form of the same operation (two 4-wave workgroups per CU, 32 output channels x 16x16 outputs each, 4-channel chunks):
+ * u[xi][ci / 4][co][slot] with the 4 channels of a chunk in MFMA operand order (slot 2*(c%2) + (c%4)/2); cin % 4 == 0, cout % 32 == 0 */
+int mgf_winograd2_weights_f32(float* u, const float* w, int32_t cout, int32_t cin, float gain, mgf_stream_t stream);
+int mgf_conv3x3_winograd2_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
+                              int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
+                              mgf_stream_t stream);
 int mgf_conv3x3_winograd_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
                              int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
                              mgf_stream_t stream);

@@ -154,6 +154,32 @@ def winograd_weights(w: torch.Tensor, gain: float = 1.0) -> torch.Tensor:
     return u
 
 
+def winograd2_weights(w: torch.Tensor, gain: float = 1.0) -> torch.Tensor:
+    """Weight planes of the second kernel form (mgf_conv3x3_winograd2_f32): [16, cin / 4, cout, 4]."""
+    _lib.require_gpu(w)
+    w = w.contiguous().float()
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and cin % 4 == 0
+    u = torch.empty([16, cin // 4, cout, 4], dtype=torch.float32, device=w.device)
+    _lib.check(_lib.lib().mgf_winograd2_weights_f32(u.data_ptr(), w.data_ptr(), cout, cin, float(gain), _lib.stream_ptr()), "winograd2_weights")
+    return u
+
+
+def winograd2_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None):
+    _lib.require_gpu(x, u, in_scale, out_scale, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and u.ndim == 4 and x.shape[1] == u.shape[1] * 4
+    n, cin, h, w = x.shape
+    cout = u.shape[2]
+    if out is None:
+        out = torch.empty([n, cout, h, w], dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and tuple(out.shape) == (n, cout, h, w)
+    os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
+    rc = _lib.lib().mgf_conv3x3_winograd2_f32(out.data_ptr(), x.data_ptr(), u.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale), n, cin, h, w,
+                                              cout, os_stride, C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
+    _lib.check(rc, "conv3x3_winograd2")
+    return out
+
+
 def winograd_ok(cin, cout, h, w):
     """Shapes the Winograd kernel takes (and where it pays: >= 16x16 maps, whole 64-channel output tiles)."""
     return cin % 8 == 0 and cout % 64 == 0 and h % 2 == 0 and w % 2 == 0 and min(h, w) >= 16
@@ -165,8 +191,17 @@ def winograd_fills_chip(n, cout, h, w):
     return n * -(-h // 16) * -(-w // 16) * (cout // 64) >= 512
 
 
+def winograd_pack(w: torch.Tensor, gain: float, res: int) -> torch.Tensor:
+    """Transformed weights in the layout of the kernel form that is faster at this map size (tools/wino_micro.py): the
+    one-workgroup-per-CU form on 16x16 maps, the two-workgroups-per-CU form above.  winograd_forward dispatches on the layout."""
+    return winograd_weights(w, gain) if res <= 16 else winograd2_weights(w, gain)
+
+
 def winograd_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None):
-    """3x3 / stride 1 / pad 1 correlation through the Winograd F(2x2,3x3) kernel; same contract as conv_forward(pad=(1, 1))."""
+    """3x3 / stride 1 / pad 1 correlation through the Winograd F(2x2,3x3) kernels; same contract as conv_forward(pad=(1, 1)).
+    u: [16, cin, cout] (winograd_weights) or [16, cin / 4, cout, 4] (winograd2_weights)."""
+    if u.ndim == 4:
+        return winograd2_forward(x, u, in_scale, out_scale, epilogue, out)
     _lib.require_gpu(x, u, in_scale, out_scale, out)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and x.shape[1] == u.shape[1]
     n, cin, h, w = x.shape

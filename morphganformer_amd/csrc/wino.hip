@@ -260,6 +260,245 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Second form: TWO workgroups per CU.  A workgroup owns 32 output channels x the same 16x16 output tile; its four waves split the
+// 64 Winograd tiles in two halves (g) and the 16 positions xi in two halves (h2), so a wave carries 8 x 16 = 128 accumulator
+// registers and two workgroups (8 waves, 2 per SIMD) fit in a CU's register file and LDS: while one workgroup transforms / parks
+// its next chunk, the matrix pipes run the other one's MFMAs -- the overlap the one-wave-per-SIMD form above has to get from
+// instruction interleaving.  Chunks are 4 input channels; U [16][32][4] and V [16][64][4] keep the chunk's channels in MFMA slot
+// order (slot 2*half + kk <-> channel 2*kk + half) so an operand of both k-steps is one 8-byte LDS read.  The two xi halves of a
+// tile meet once, at the end: the output transform is linear, each wave reduces its 8 planes to a 2x2 partial, the partner's half
+// goes through LDS.
+constexpr int W2CK = 4;
+constexpr int W2CO = 32;
+constexpr int W2_RAW = 256 * 6;                      // 4 * 18 * 18 = 1296 floats rounded up to whole staging slots
+constexpr int W2_U = 16 * W2CO * W2CK;               // 2048 floats
+constexpr int W2_V = 16 * WNT * W2CK;                // 4096 floats
+constexpr int W2_XS = 6, W2_US = 2;
+
+__global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
+    extern __shared__ float lds[];
+    float* const raw0 = lds;
+    float* const raw1 = raw0 + W2_RAW;
+    float* const U0 = raw1 + W2_RAW;
+    float* const U1 = U0 + W2_U;
+    float* const V0 = U1 + W2_U;
+    float* const V1 = V0 + W2_V;
+    float* const Ss = V1 + W2_V;                     // [cin]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wg = wave & 1, h2 = wave >> 1;
+
+    int b = blockIdx.x;
+    const int cot = b % p.co_tiles; b /= p.co_tiles;
+    const int ptx = b % p.tiles_x; b /= p.tiles_x;
+    const int pty = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int co0 = cot * W2CO, oy0 = pty * 2 * WTS, ox0 = ptx * 2 * WTS;
+    const int plane = p.h * p.w;
+    const float* xn = p.x + (int64_t)n * p.cin * plane;
+    const float* sc = p.in_scale ? p.in_scale + (int64_t)n * p.cin : nullptr;
+
+    int xoff[W2_XS];
+#pragma unroll
+    for (int j = 0; j < W2_XS; ++j) {
+        const int e = tid + 256 * j;
+        const int ch = e / (RAW_H * RAW_H), rem = e - ch * (RAW_H * RAW_H);
+        const int r = rem / RAW_H, q = rem - r * RAW_H;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
+        xoff[j] = (e < W2CK * RAW_H * RAW_H && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? ch * plane + iy * p.w + ix : -1;
+    }
+    // U slot j: float4 e = tid + 256 j of the chunk slab [16 xi][32 co][4 slots]: xi = e >> 5, float4 (e & 31) of 128 contiguous floats
+    const int nck = p.cin / W2CK;
+    int uoff[W2_US];
+#pragma unroll
+    for (int j = 0; j < W2_US; ++j) {
+        const int e = tid + 256 * j;
+        uoff[j] = ((e >> 5) * nck * p.cout + co0) * W2CK + (e & 31) * 4;
+    }
+    float xr[W2_XS];
+    float4 ur[W2_US];
+    auto load_x = [&](int c0) {
+        const float* xc = xn + (int64_t)c0 * plane;
+#pragma unroll
+        for (int j = 0; j < W2_XS; ++j) xr[j] = xc[xoff[j] > 0 ? xoff[j] : 0];
+    };
+    auto load_u = [&](int c0) {
+        const float* uc = p.u + (int64_t)c0 * p.cout;            // chunk c0 / 4 starts (c0 / 4) * cout * 4 floats into a plane
+#pragma unroll
+        for (int j = 0; j < W2_US; ++j) ur[j] = *reinterpret_cast<const float4*>(uc + uoff[j]);
+    };
+    auto store_x = [&](float* R) {
+#pragma unroll
+        for (int j = 0; j < W2_XS; ++j) R[tid + 256 * j] = xoff[j] >= 0 ? xr[j] : 0.f;
+    };
+    auto store_u = [&](float* U) {
+#pragma unroll
+        for (int j = 0; j < W2_US; ++j) *reinterpret_cast<float4*>(U + (tid + 256 * j) * 4) = ur[j];
+    };
+    // one (channel, tile) patch per lane: lane <-> (tile = tid >> 2, channel = tid & 3)
+    const int t_tile = tid >> 2, t_ch = tid & 3;
+    const int t_slot = 2 * (t_ch & 1) + (t_ch >> 1);
+    auto transform = [&](const float* R, float* V, int c0) {
+        const int ty = t_tile >> 3, tx = t_tile & 7;
+        const float* src = R + (t_ch * RAW_H + 2 * ty) * RAW_H + 2 * tx;
+        const float sv = Ss[c0 + t_ch];
+        float d[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float2 a = *reinterpret_cast<const float2*>(src + u * RAW_H);
+            const float2 c = *reinterpret_cast<const float2*>(src + u * RAW_H + 2);
+            d[u][0] = a.x * sv; d[u][1] = a.y * sv; d[u][2] = c.x * sv; d[u][3] = c.y * sv;
+        }
+        float* dst = V + t_tile * W2CK + t_slot;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float t[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                t[v] = a == 0 ? d[0][v] - d[2][v] : a == 1 ? d[1][v] + d[2][v] : a == 2 ? d[2][v] - d[1][v] : d[1][v] - d[3][v];
+            dst[(a * 4 + 0) * (WNT * W2CK)] = t[0] - t[2];
+            dst[(a * 4 + 1) * (WNT * W2CK)] = t[1] + t[2];
+            dst[(a * 4 + 2) * (WNT * W2CK)] = t[2] - t[1];
+            dst[(a * 4 + 3) * (WNT * W2CK)] = t[1] - t[3];
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+    auto mfma_chunk = [&](const float* U, const float* V) {
+        const float2* ua = reinterpret_cast<const float2*>(U + (8 * h2 * W2CO + l31) * W2CK + half * 2);
+        const float2* vb = reinterpret_cast<const float2*>(V + (8 * h2 * WNT + wg * 32 + l31) * W2CK + half * 2);
+        float2 fa[8], fb[8];
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) { fa[xi] = ua[xi * (W2CO * W2CK / 2)]; fb[xi] = vb[xi * (WNT * W2CK / 2)]; }
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) {
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[xi].x, fb[xi].x, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[xi].y, fb[xi].y, acc[xi], 0, 0, 0);
+        }
+    };
+
+    const int nchunks = nck;
+    const int last = nchunks - 1;
+    auto chunk0 = [&](int i) { return (i < last ? i : last) * W2CK; };
+    for (int i = tid; i < p.cin; i += 256) Ss[i] = sc ? sc[i] : 1.f;
+    load_x(0);
+    load_u(0);
+    store_x(raw0);
+    store_u(U0);
+    load_x(chunk0(1));
+    __syncthreads();
+    transform(raw0, V0, 0);
+    store_x(raw1);
+    load_x(chunk0(2));
+    load_u(chunk0(1));
+    __syncthreads();
+    auto body = [&](int i, float* Ucur, float* Vcur, float* Unxt, float* Vnxt, float* raw_in, float* raw_out) {
+#if !defined(MGF_W2EXP) || MGF_W2EXP != 3         // experiment 3: no global loads / register parking
+        store_x(raw_out);                            // X(i+2), loaded during the previous chunk
+        store_u(Unxt);                               // U(i+1)
+        load_x(chunk0(i + 3));
+        load_u(chunk0(i + 2));
+#endif
+#if !defined(MGF_W2EXP) || MGF_W2EXP != 2         // experiment 2: no input transform
+        transform(raw_in, Vnxt, chunk0(i + 1));
+#endif
+#if !defined(MGF_W2EXP) || MGF_W2EXP != 1         // experiment 1: no matrix work
+        mfma_chunk(Ucur, Vcur);
+#endif
+        __syncthreads();
+    };
+    for (int i = 0; i < nchunks; i += 2) {
+        body(i, U0, V0, U1, V1, raw1, raw0);
+        if (i + 1 < nchunks) body(i + 1, U1, V1, U0, V0, raw0, raw1);
+    }
+
+    // ---- output transform.  Rows a of this wave: {2 h2, 2 h2 + 1}.  A^T: s0 = m0 + m1 + m2, s1 = m1 - m2 - m3 ->
+    //   h2 = 0: (m0 + m1, m1);   h2 = 1: (m2, m2 + m3);   Y0 = P0 + Q0, Y1 = P1 - Q1 after the (linear) column transform. ----
+    float part[2][2][16];                            // [output row i][output col j][register r]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float r0[4], r1[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            r0[bb] = h2 == 0 ? acc[bb][r] + acc[4 + bb][r] : acc[bb][r];
+            r1[bb] = h2 == 0 ? acc[4 + bb][r] : acc[bb][r] + acc[4 + bb][r];
+        }
+        part[0][0][r] = r0[0] + r0[1] + r0[2];
+        part[0][1][r] = r0[1] - r0[2] - r0[3];
+        part[1][0][r] = r1[0] + r1[1] + r1[2];
+        part[1][1][r] = r1[1] - r1[2] - r1[3];
+    }
+    // exchange: each wave keeps the 8 registers r with (r >> 3) == h2 and hands the other 8 to its partner (same g, other h2);
+    // register arrays are indexed with compile-time constants only (selects on h2), so nothing spills to scratch
+    float* xch = lds;                                // [2 g][2 h2 (writer)][32 values][64 lanes] = 32 KB, the staging buffers are dead
+    float keep[8][4];
+    {
+        float* mine = xch + ((wg * 2 + h2) * 32) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int ij = 0; ij < 4; ++ij) {
+                const float lo = part[ij >> 1][ij & 1][k], hi = part[ij >> 1][ij & 1][8 + k];
+                mine[(k * 4 + ij) * 64] = h2 == 0 ? hi : lo;          // rows the partner finishes
+                keep[k][ij] = h2 == 0 ? lo : hi;
+            }
+    }
+    __syncthreads();
+    const float* theirs = xch + ((wg * 2 + (1 - h2)) * 32) * 64 + lane;
+    const int tile = wg * 32 + l31;
+    const int ty = tile >> 3, tx = tile & 7;
+    const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
+    const bool ok_px = oy < p.h && ox < p.w;
+    const float* osc = p.out_scale ? p.out_scale + (int64_t)n * p.os_stride : nullptr;
+    const bool do_ep = p.has_ep != 0;
+    const float ns = (do_ep && p.ep.noise) ? (p.ep.noise_strength ? *p.ep.noise_strength : 1.f) : 0.f;
+    float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (do_ep && p.ep.noise && ok_px) {
+        const float* np_ = p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane + (int64_t)oy * p.w + ox;
+        nz[0][0] = np_[0] * ns; nz[0][1] = np_[1] * ns; nz[1][0] = np_[p.w] * ns; nz[1][1] = np_[p.w + 1] * ns;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = h2 * 8 + k;
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float yv[2][2];
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+            const float o = theirs[(k * 4 + ij) * 64];
+            const float m = keep[k][ij];
+            // row 0: P0 + Q0; row 1: P1 - Q1 (P from the h2 = 0 wave, Q from the h2 = 1 wave)
+            yv[ij >> 1][ij & 1] = (ij >> 1) == 0 ? m + o : (h2 == 0 ? m - o : o - m);
+        }
+        if (!ok_px || co >= p.cout) continue;
+        const float os = osc ? osc[co] : 1.f;
+        const float bv = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
+        const int64_t off = ((int64_t)n * p.cout + co) * plane + (int64_t)oy * p.w + ox;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float v[2];
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                float t = yv[a][bb] * os;
+                if (do_ep) {
+                    t += nz[a][bb];
+                    t += bv;
+                    if (p.ep.act == MGF_ACT_LRELU) t = t > 0.f ? t : t * p.ep.alpha;
+                    else if (p.ep.act == MGF_ACT_RELU) t = t > 0.f ? t : 0.f;
+                    t *= p.ep.gain;
+                    if (p.ep.residual) t += p.ep.residual[off + a * p.w + bb];
+                }
+                v[bb] = t;
+            }
+            *reinterpret_cast<float2*>(p.y + off + a * p.w) = make_float2(v[0], v[1]);
+        }
+    }
+}
+
 // U[xi = 4a + b][ci][co] = gain * (G g G^T)[a][b] from w [cout][cin][3][3]; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 __global__ __launch_bounds__(256) void wino_weights_kernel(float* u, const float* w, int cout, int cin, float gain) {
     const int64_t total = (int64_t)cout * cin;
@@ -286,7 +525,79 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(float* u, const float
     }
 }
 
+// form 2: U[xi][ci / 4][co][slot], the 4 channels of a chunk in MFMA slot order (slot 2*(c%2) + (c%4)/2)
+__global__ __launch_bounds__(256) void wino2_weights_kernel(float* u, const float* w, int cout, int cin, float gain) {
+    const int64_t total = (int64_t)cout * cin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % cout), ci = (int)(i / cout);
+        const float* g = w + ((int64_t)co * cin + ci) * 9;
+        float t[4][3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            t[0][v] = g[v];
+            t[1][v] = 0.5f * (g[v] + g[3 + v] + g[6 + v]);
+            t[2][v] = 0.5f * (g[v] - g[3 + v] + g[6 + v]);
+            t[3][v] = g[6 + v];
+        }
+        const int cl = ci & 3, slot = 2 * (cl & 1) + (cl >> 1);
+        const int64_t pl = (int64_t)cin * cout;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float o0 = t[a][0], o1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), o2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), o3 = t[a][2];
+            float* dst = u + (((int64_t)(a * 4) * (cin / 4) + (ci >> 2)) * cout + co) * 4 + slot;
+            dst[0] = o0 * gain;
+            dst[pl] = o1 * gain;
+            dst[2 * pl] = o2 * gain;
+            dst[3 * pl] = o3 * gain;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int mgf_winograd2_weights_f32(float* u, const float* w, int32_t cout, int32_t cin, float gain, mgf_stream_t stream) {
+    MGF_REQUIRE(u && w && cout >= 1 && cin >= 1, MGF_EINVAL, "winograd2_weights: bad arguments");
+    MGF_REQUIRE(cin % 4 == 0, MGF_EUNSUPPORTED, "winograd2_weights: cin must be a multiple of 4 (got %d)", cin);
+    hipLaunchKernelGGL(wino2_weights_kernel, dim3(mgf_stream_grid((int64_t)cout * cin, 256, 1)), dim3(256), 0, (hipStream_t)stream, u, w, cout, cin,
+                       gain);
+    MGF_CHECK_LAUNCH("winograd2_weights");
+    return MGF_OK;
+}
+
+extern "C" int mgf_conv3x3_winograd2_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
+                                         int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
+                                         mgf_stream_t stream) {
+    MGF_REQUIRE(y && x && u && n >= 1 && cin >= 1 && cout >= 1 && h >= 2 && w >= 2, MGF_EINVAL, "conv3x3_winograd2: bad arguments");
+    MGF_REQUIRE(cin % W2CK == 0 && cout % W2CO == 0, MGF_EUNSUPPORTED, "conv3x3_winograd2: cin must be a multiple of %d and cout of %d (got %d, %d)",
+                W2CK, W2CO, cin, cout);
+    MGF_REQUIRE(cin <= 1024, MGF_EUNSUPPORTED, "conv3x3_winograd2: at most 1024 input channels (got %d)", cin);
+    MGF_REQUIRE(h % 2 == 0 && w % 2 == 0, MGF_EUNSUPPORTED, "conv3x3_winograd2: even feature-map sides only (got %dx%d)", h, w);
+    MGF_REQUIRE((int64_t)cin * h * w <= INT32_MAX / 2 && (int64_t)16 * cin * cout <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd2: tensor too large");
+    MGF_REQUIRE(((uintptr_t)u % 16) == 0 && ((uintptr_t)y % 8) == 0, MGF_EINVAL, "conv3x3_winograd2: u must be 16-byte and y 8-byte aligned");
+    if (ep) MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU, MGF_EUNSUPPORTED,
+                        "conv3x3_winograd2: epilogue activation %d unsupported", ep->act);
+    WinoParams p;
+    p.y = y; p.x = x; p.u = u; p.in_scale = in_scale; p.out_scale = out_scale;
+    p.n = n; p.cin = cin; p.h = h; p.w = w; p.cout = cout; p.os_stride = out_scale_stride;
+    p.tiles_x = (int)mgf_cdiv(w, 2 * WTS); p.tiles_y = (int)mgf_cdiv(h, 2 * WTS); p.co_tiles = cout / W2CO;
+    p.has_ep = ep != nullptr;
+    if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
+    const int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
+    MGF_REQUIRE(blocks <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd2: too many workgroups");
+    const size_t lds = (size_t)(2 * W2_RAW + 2 * W2_U + 2 * W2_V + 1024) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino2_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { mgf_set_error("conv3x3_winograd2: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
+        attr_set = true;
+    }
+    mgf_prof_external_begin((hipStream_t)stream, "wino2_conv_kernel", 2.0 * 9 * cin * (double)cout * h * w * n,
+                            4.0 * ((double)n * cin * h * w + 9.0 * cin * cout + (double)n * cout * h * w));
+    hipLaunchKernelGGL(wino2_conv_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    mgf_prof_external_end((hipStream_t)stream);
+    MGF_CHECK_LAUNCH("conv3x3_winograd2");
+    return MGF_OK;
+}
 
 extern "C" int mgf_winograd_weights_f32(float* u, const float* w, int32_t cout, int32_t cin, float gain, mgf_stream_t stream) {
     MGF_REQUIRE(u && w && cout >= 1 && cin >= 1, MGF_EINVAL, "winograd_weights: bad arguments");

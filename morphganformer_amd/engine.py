@@ -148,7 +148,7 @@ class SynthesisPlan:
                 # Winograd F(2x2,3x3) where it beats the 9-tap kernel (measured, tools/wino_micro.py): 3x3 stride-1 layers with
                 # >= 128 channels on 16^2 .. 256^2 maps; MGF_WINOGRAD=0 (tuning hook) keeps the direct kernel everywhere
                 if kind == "conv3" and USE_WINOGRAD and cv.winograd_ok(cin, cout, res, res) and res <= 256 and name != "conv_last":
-                    lp.wino_u = cv.winograd_weights(t32(w), gain=wg)
+                    lp.wino_u = cv.winograd_pack(t32(w), wg, res)
             lp.aff_w = t32(f64(p + ".affine.weight"))
             lp.aff_b = t32(f64(p + ".affine.bias"))
             if (p + ".biasAct.bias") in sd:

@@ -42,7 +42,7 @@ class GeneratorGrad:
         for lp in P.layers:
             if lp.wino_u is not None:
                 w = lp.pc.wp[:, :, :lp.cout].reshape(3, 3, lp.cin, lp.cout).permute(3, 2, 0, 1)        # [cout, cin, kh, kw]
-                self.Tw[lp.name] = cv.winograd_weights(w.permute(1, 0, 2, 3).flip(2, 3).contiguous())
+                self.Tw[lp.name] = cv.winograd_pack(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), 1.0, lp.res)
         self._bufs = {}
         self._n = None
         self.z = None

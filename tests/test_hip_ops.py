@@ -293,10 +293,12 @@ def test_upfirdn2d_down2_tiled_vs_oracle(shape, pad, taps, flip):
     assert rel_err(out, ref) < 3e-6
 
 
+@pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 32), (1, 16, 128, 24, 40), (3, 72, 64, 18, 34), (1, 512, 512, 16, 16)])
-def test_winograd_conv_matches_direct_conv_and_oracle(n, cin, cout, h, w):
-    """Winograd F(2x2,3x3) kernel vs the 9-tap MFMA kernel and the CPU oracle: style modulation, demodulation, fused
-    noise/bias/lrelu/residual epilogue, ragged 16x16 tiles (maps that are not multiples of 16)."""
+def test_winograd_conv_matches_direct_conv_and_oracle(n, cin, cout, h, w, form):
+    """Winograd F(2x2,3x3) kernels (form 1: one workgroup per CU, 64 channels x 16x16 outputs, 8-channel chunks; form 2: two
+    workgroups per CU, 32 channels, 4-channel chunks, the position halves meeting through LDS) vs the 9-tap MFMA kernel and the
+    CPU oracle: style modulation, demodulation, fused noise/bias/lrelu/residual epilogue, ragged 16x16 tiles."""
     from morphganformer_amd import _lib, conv as cv
     from oracle.ops_ref import bias_act_ref
     torch.manual_seed(cin + h)
@@ -309,7 +311,7 @@ def test_winograd_conv_matches_direct_conv_and_oracle(n, cin, cout, h, w):
     ref_ep = bias_act_ref(ref.float() + noise[:, None] * strength, bias, act="lrelu", gain=1.3) + resid
     f = lambda t: t.cuda().contiguous()
     xd, sd, dd = f(x), f(s), f(d)
-    u = cv.winograd_weights(f(wt), gain=1.0)
+    u = cv.winograd_weights(f(wt), gain=1.0) if form == 1 else cv.winograd2_weights(f(wt), gain=1.0)
     pc = cv.pack_weights(f(wt))
     plain = cv.winograd_forward(xd, u, in_scale=sd, out_scale=dd)
     direct = cv.conv_forward(xd, pc, pad=(1, 1), in_scale=sd, out_scale=dd)

@@ -12,12 +12,13 @@ for res, c in ((16, 512), (32, 512), (64, 512), (128, 256), (256, 128), (512, 64
     noise, bias = torch.randn(n, res * res, device="cuda"), torch.randn(c, device="cuda")
     st = torch.tensor([0.1], device="cuda")
     ep = _lib.make_epilogue(bias=bias, noise=noise, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.4)
-    u, pc = cv.winograd_weights(w), cv.pack_weights(w)
-    out_w, out_d = torch.empty_like(x), torch.empty_like(x)
+    u, u2, pc = cv.winograd_weights(w), cv.winograd2_weights(w), cv.pack_weights(w)
+    out_w, out_d, out_2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
     fw = lambda: cv.winograd_forward(x, u, in_scale=s, out_scale=d, epilogue=ep, out=out_w)
     fd = lambda: cv.conv_forward(x, pc, pad=(1, 1), in_scale=s, out_scale=d, epilogue=ep, out=out_d)
+    f2 = lambda: cv.winograd2_forward(x, u2, in_scale=s, out_scale=d, epilogue=ep, out=out_2)
     res_t = []
-    for fn in (fw, fd):
+    for fn in (fw, fd, f2):
         fn(); fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,4 +30,6 @@ for res, c in ((16, 512), (32, 512), (64, 512), (128, 256), (256, 128), (512, 64
         res_t.append(e0.elapsed_time(e1) / 5)
     gf = 2 * 9 * c * c * res * res * n / 1e9
     err = float((out_w - out_d).abs().max() / out_d.abs().max())
-    print(f"res {res:4d} c {c:4d}: winograd {res_t[0]*1e3:8.1f} us ({gf/res_t[0]:6.1f} TF alg)  direct {res_t[1]*1e3:8.1f} us ({gf/res_t[1]:6.1f} TF)  rel diff {err:.1e}", flush=True)
+    err2 = float((out_2 - out_d).abs().max() / out_d.abs().max())
+    print(f"res {res:4d} c {c:4d}: winograd {res_t[0]*1e3:8.1f} us ({gf/res_t[0]:6.1f} TF alg)  direct {res_t[1]*1e3:8.1f} us ({gf/res_t[1]:6.1f} TF)  rel diff {err:.1e}"
+          f" | form2 {res_t[2]*1e3:8.1f} us ({gf/res_t[2]:6.1f} TF) diff {err2:.1e}", flush=True)
