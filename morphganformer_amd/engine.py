@@ -218,7 +218,10 @@ class Generator:
         self.fuse_torgb = True
         self.last_noise = ("none", None)      # (noise_mode, noises) of the latest synthesis call, read by grad.SynthesisGrad
         self.side = torch.cuda.Stream(device=self.device)
-        self.overlap_skip = os.environ.get("MGF_OVERLAP_SKIP", "1") != "0"      # tuning hook: 0 serialises the skip branch
+        # MGF_OVERLAP_SKIP=1 forks the skip branch onto the side stream (+0.9 % iterations/s).  Off by default for the same reason
+        # as the loss/generator pipeline: concurrent kernels stretch each other -- differently under graph replay than in the eager
+        # roofline leg -- so per-kernel durations would no longer agree between bench.py and a rocprofv3 trace.
+        self.overlap_skip = os.environ.get("MGF_OVERLAP_SKIP", "0") != "0"
         self._alloc(max_batch)
 
     # ------------------------------------------------------------------ workspace

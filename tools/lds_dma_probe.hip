@@ -1,3 +1,4 @@
+// Probe of global_load_lds on gfx950 (lane l of a wave writes its element to LDS base + l * size; 4- and 16-byte forms): hipcc --offload-arch=gfx950 -O2 tools/lds_dma_probe.hip -o /tmp/p && /tmp/p
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 __global__ void k(const float* g, float* out) {

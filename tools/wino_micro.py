@@ -5,16 +5,16 @@ import torch
 from morphganformer_amd import _lib, conv as cv
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 25
-for res, c in ((16, 512), (32, 512), (64, 512), (128, 256), (256, 128), (512, 64)):
+for res, c in ((16, 512), (32, 512), (64, 512), (128, 256), (256, 128), (512, 64), (1024, 32))[int(os.environ.get("WM_FIRST", "0")):]:
     x = torch.randn(n, c, res, res, device="cuda")
     w = torch.randn(c, c, 3, 3, device="cuda") / (3 * c ** 0.5)
     s, d = torch.rand(n, c, device="cuda") + 0.5, torch.rand(n, c, device="cuda") + 0.5
     noise, bias = torch.randn(n, res * res, device="cuda"), torch.randn(c, device="cuda")
     st = torch.tensor([0.1], device="cuda")
     ep = _lib.make_epilogue(bias=bias, noise=noise, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.4)
-    u, u2, pc = cv.winograd_weights(w), cv.winograd2_weights(w), cv.pack_weights(w)
+    u, u2, pc = (cv.winograd_weights(w) if c % 64 == 0 else None), cv.winograd2_weights(w), cv.pack_weights(w)
     out_w, out_d, out_2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-    fw = lambda: cv.winograd_forward(x, u, in_scale=s, out_scale=d, epilogue=ep, out=out_w)
+    fw = (lambda: cv.winograd_forward(x, u, in_scale=s, out_scale=d, epilogue=ep, out=out_w)) if u is not None else (lambda: out_w.copy_(out_d))
     fd = lambda: cv.conv_forward(x, pc, pad=(1, 1), in_scale=s, out_scale=d, epilogue=ep, out=out_d)
     f2 = lambda: cv.winograd2_forward(x, u2, in_scale=s, out_scale=d, epilogue=ep, out=out_2)
     res_t = []
