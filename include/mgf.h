@@ -413,6 +413,15 @@ int mgf_linear_bwd_f32(float* dx, const float* dy, const float* w, int32_t n, in
 int mgf_resize_bilinear_bwd_f32(float* dx, const float* dy, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                                 mgf_stream_t stream);
 
+/* Landmark-Delaunay warp post-process (1024_warp_morphs.py:78-113,163-210): every output pixel takes the LAST triangle of the list whose
+ * integer polygon tri_xy[t] = {x0,y0,x1,y1,x2,y2} (the floor of the averaged-landmark mesh vertices, boundary included, as
+ * cv2.fillConvexPoly(np.int32(...)) fills it) covers it, maps its coordinates through dst_to_src[t] = {a,b,tx, c,d,ty} (the inverse
+ * of cv2.getAffineTransform(srcTri, dstTri)) and samples src [c,h,w] bilinearly with BORDER_REFLECT_101; pixels outside every
+ * triangle get `background`.  Not reproduced (OpenCV is absent offline, parity with it is unpinned): warpAffine's 1/32-pixel fixed-point
+ * coordinates, the LINE_AA blend along triangle edges, and the reflection at the per-triangle PATCH border instead of the image border. */
+int mgf_piecewise_affine_warp_f32(float* out, const float* src, const int32_t* tri_xy, const float* dst_to_src, int32_t ntri, int32_t c,
+                                  int32_t h, int32_t w, float background, mgf_stream_t stream);
+
 /* torch.optim.Adam.step() on the latent (1024_example_wing_loss_perceptual_sqz_MSE.py:146,181-184; defaults betas (0.9, 0.999),
  * eps 1e-8; weight_decay 1e-4 in 1024_example_MSE.py:117), device-resident: lr = lr_table[*step] (the get_lr schedule, :63-68),
  * nothing happens when valid[*step] == 0 (the "no face" `continue`, :165-166) or *step >= steps_total; *adam_t is the optimizer's own

@@ -7,6 +7,7 @@
                     BASELINE config 4 sweeps 11 values)
   project_image     latent statistics + one ProjectionEngine run + best-of PNG / .mat   (:135-208, :246-268)
   second_stage      a projection initialised from an earlier result (edit_MSE.py pattern, BASELINE config 5)
+  warp_morph        landmark-Delaunay warp of a morph onto the averaged landmarks (1024_warp_morphs.py:78-113,163-210)
 
 Every image is produced by the HIP generator (`engine.Generator`); there is no CPU path here.  Landmark detection (dlib) is a
 closed third-party CPU dependency: landmarks are passed in by the caller (projection.synthetic_landmarks stands in offline).
@@ -230,6 +231,47 @@ def _project_group(G, targets, landmarks, args: ProjectionArgs = None, percept=N
     if len(targets) == 1:
         return {"w": w, "step": np.array([step]), "loss": np.array([loss]), "losses": losses[None]}
     return {"w": w, "step": step, "loss": loss, "losses": losses}
+
+
+# the 12 frame points the reference adds to the 68 landmarks before triangulating (1024_warp_morphs.py:130-132)
+WARP_EXTRA_POINTS = [[0, 0], [0, 341], [0, 682], [0, 1023], [341, 0], [682, 0], [1023, 0], [1023, 341], [1023, 682], [1023, 1023],
+                     [341, 1023], [682, 1023]]
+
+
+def warp_mesh(points_src, points_dst):
+    """Host side of the Delaunay warp (1024_warp_morphs.py:163-201): triangulate the DESTINATION points with scipy (as the reference
+    does), and per triangle return the integer polygon np.int32(dst triangle) that cv2.fillConvexPoly would fill and the affine map
+    destination -> source (the inverse of cv2.getAffineTransform(srcTri, dstTri)), solved in float64.
+    Returns (tri_xy int32 [T,6], dst_to_src float32 [T,6], simplices [T,3])."""
+    from scipy.spatial import Delaunay
+    ps, pd = np.asarray(points_src, np.float64), np.asarray(points_dst, np.float64)
+    simplices = Delaunay(pd).simplices
+    tri_xy = np.zeros((len(simplices), 6), np.int32)
+    maps = np.zeros((len(simplices), 6), np.float64)
+    for t, idx in enumerate(simplices):
+        d, s_ = pd[idx], ps[idx]
+        tri_xy[t] = np.int32(d).reshape(-1)                               # truncation, like np.int32(tRect) (:101)
+        a = np.concatenate([d, np.ones((3, 1))], axis=1)                  # [x y 1] @ M^T = src
+        maps[t] = np.linalg.solve(a, s_).T.reshape(-1)
+    return tri_xy, maps.astype(np.float32), simplices
+
+
+def warp_morph(img, points_G, points_avg, background=0.0):
+    """Warp the generated morph so that its landmarks `points_G` land on the averaged landmarks `points_avg` (both [P,2] in pixel
+    coordinates, frame points included), the post-process of 1024_warp_morphs.py:163-210 as one gather kernel.
+    img: [1,C,H,W] or [C,H,W] float32 device tensor in ANY value range (the reference works on the 0..255 float BGR image it reads
+    back from the PNG); returns a tensor of the same shape."""
+    _lib.require_gpu(img)
+    x = img.reshape(-1, *img.shape[-2:]).contiguous().float()
+    c, h, w = x.shape
+    tri_xy, maps, _ = warp_mesh(points_G, points_avg)
+    dev = x.device
+    t_d = torch.as_tensor(tri_xy, device=dev).contiguous()
+    m_d = torch.as_tensor(maps, device=dev).contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().mgf_piecewise_affine_warp_f32(out.data_ptr(), x.data_ptr(), t_d.data_ptr(), m_d.data_ptr(), len(tri_xy), c, h, w,
+                                                        float(background), _lib.stream_ptr()), "piecewise_affine_warp")
+    return out.reshape(img.shape)
 
 
 def second_stage(G, target, w_init, latent_std, lm_target, lm_steps, **kw):

@@ -248,3 +248,32 @@ def projection_gradient_ref(gen_fn, loss_fn, latent_mean, latent_std, eps_stream
         if num < min_loss:
             min_loss, best, best_step = num, latent_n.detach().clone(), i
     return best, best_step, min_loss, losses, traj
+
+
+# --------------------------------------------------------------------------------------------
+# Landmark-Delaunay warp (1024_warp_morphs.py:78-113,163-210).  PARITY UNPINNED: the reference's arithmetic lives in OpenCV
+# (cv2.getAffineTransform / warpAffine / fillConvexPoly, absent offline).  Restated from the documented semantics: per triangle of
+# the destination mesh (in list order, later triangles overwrite), pixels of the integer polygon np.int32(dst triangle), boundary
+# included, take the bilinear sample (BORDER_REFLECT_101) of the source at the affine pre-image of their coordinates.  Not
+# restated: warpAffine's 1/32-pixel fixed-point coordinate grid, the LINE_AA blend on triangle edges, reflection at the patch border.
+
+def piecewise_affine_warp_ref(src, tri_xy, dst_to_src, background=0.0):
+    """src [C,H,W] float64 numpy; tri_xy [T,6] int; dst_to_src [T,6].  Pure numpy, one triangle at a time like the reference."""
+    c, h, w = src.shape
+    out = np.full((c, h, w), float(background))
+    ys, xs = np.mgrid[0:h, 0:w]
+    refl = lambda i, n: np.abs(((i + (n - 1)) % (2 * (n - 1))) - (n - 1)) if n > 1 else np.zeros_like(i)
+    for q, a in zip(np.asarray(tri_xy, np.int64), np.asarray(dst_to_src, np.float64)):
+        e0 = (q[2] - q[0]) * (ys - q[1]) - (q[3] - q[1]) * (xs - q[0])
+        e1 = (q[4] - q[2]) * (ys - q[3]) - (q[5] - q[3]) * (xs - q[2])
+        e2 = (q[0] - q[4]) * (ys - q[5]) - (q[1] - q[5]) * (xs - q[4])
+        m = ((e0 >= 0) & (e1 >= 0) & (e2 >= 0)) | ((e0 <= 0) & (e1 <= 0) & (e2 <= 0))
+        sx = a[0] * xs + a[1] * ys + a[2]
+        sy = a[3] * xs + a[4] * ys + a[5]
+        fx, fy = np.floor(sx), np.floor(sy)
+        lx, ly = sx - fx, sy - fy
+        x0, x1 = refl(fx.astype(np.int64), w), refl(fx.astype(np.int64) + 1, w)
+        y0, y1 = refl(fy.astype(np.int64), h), refl(fy.astype(np.int64) + 1, h)
+        val = (1 - ly) * ((1 - lx) * src[:, y0, x0] + lx * src[:, y0, x1]) + ly * ((1 - lx) * src[:, y1, x0] + lx * src[:, y1, x1])
+        out[:, m] = val[:, m]
+    return out

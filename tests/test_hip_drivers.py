@@ -282,3 +282,29 @@ def test_gradient_entry_points_reject_bad_arguments():
                                        0.9, 0.999, 1e-8, 0.0, None))
     with pytest.raises(_lib.MgfError, match="at most 16 rows"):
         _lib.check(L.mgf_linear_bwd_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), 17, 4, 4, None))
+
+
+def test_landmark_delaunay_warp_vs_oracle():
+    """the morph warp of 1024_warp_morphs.py as one gather kernel vs the numpy restatement (parity with OpenCV
+    itself is unpinned: cv2 is absent offline, see oracle/loss_ref.py).  Properties: identical point sets give the identity; every
+    pixel is covered (the frame points span the image)."""
+    from morphganformer_amd import drivers
+    from oracle.loss_ref import piecewise_affine_warp_ref
+    rng = np.random.Generator(np.random.PCG64(5))
+    h = w = 96
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([127 + 100 * np.sin(xx / 7 + c) * np.cos(yy / 9 - c) for c in range(3)])[None].astype(np.float32)      # smooth, 0..255
+    frame = np.array([[0, 0], [0, 47], [0, 95], [47, 0], [95, 0], [95, 47], [95, 95], [47, 95]], np.float64)
+    inner_avg = rng.uniform(12, 84, (20, 2))
+    inner_G = inner_avg + rng.uniform(-4, 4, (20, 2))
+    p_avg, p_G = np.concatenate([inner_avg, frame]), np.concatenate([inner_G, frame])
+    out = drivers.warp_morph(torch.from_numpy(img).cuda(), p_G, p_avg, background=-1.0)
+    tri_xy, maps, simp = drivers.warp_mesh(p_G, p_avg)
+    ref = piecewise_affine_warp_ref(img[0].astype(np.float64), tri_xy, maps, background=-1.0)
+    assert out.shape == (1, 3, h, w)
+    assert np.abs(out[0].cpu().numpy() - ref).max() < 2e-2                   # float32 vs float64 coordinates on 0..255 data
+    assert float(out.min()) >= 0.0                                           # no background pixel: the mesh covers the frame
+    assert np.abs(out[0].cpu().numpy() - img[0]).max() > 5.0                 # ... and it did move something
+    same = drivers.warp_morph(torch.from_numpy(img).cuda(), p_avg, p_avg)
+    assert np.abs(same.cpu().numpy() - img).max() < 2e-2
+    assert len(drivers.WARP_EXTRA_POINTS) == 12 and tri_xy.shape == (len(simp), 6)
