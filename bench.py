@@ -11,15 +11,18 @@ engine evaluates `--batch` consecutive steps per generator forward and examines 
 best latent, loss history) is the sequential loop's, bit for bit (tests/test_hip_projection.py), and every step's full work --
 its own noise draws, forward, three losses, selection -- is inside the timed region.  `steps` counts loop steps, not launches.
 With `--pipeline 1` the losses + selection of one batch run on a second stream while the generator already synthesises the next
-batch (separate buffers; same results; 426 vs 413 iters/s): every timed replay still contains one full generator batch and one
+batch (separate buffers; same results; 446 vs 435 iters/s): every timed replay still contains one full generator batch and one
 full loss batch, the one generator batch that is in flight ahead of the losses is produced during warm-up.  It is off by default
 because concurrent kernels stretch each other: per-kernel durations would stop describing a kernel on its own.
 Weights are seeded synthetic tensors (no checkpoint exists offline); inputs are resident in HBM before the timed region.
 N > 1: one independent target per rank (pair-level sharding, no data-path collective) -> "weak" scaling; the only
 collective is the result gather after the timed region.
 
-Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, algorithmic FLOPs / measured launch time vs the
-dense FP32-MFMA peak) and "cpu_baseline" (the CPU oracle's port of the same iteration timed on the host cores, N=1 only).
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (the convolution kernel with the largest total time, algorithmic FLOPs /
+measured launch time vs the dense FP32-MFMA peak; Winograd launches are counted at the direct form's FLOPs), "generator_forward",
+"cpu_baseline" (the CPU oracle's port of the same iteration timed on the host cores, N=1 only) and "gradient_mode" (N=1 only,
+--gradient-steps 0 skips it): the same objective with the loss back-propagated into the latent and Adam moving it, one target and
+--gradient-lockstep targets per generator pass -- reported beside the metric, never in `value`.
 """
 import argparse
 import json
