@@ -181,14 +181,17 @@ def winograd2_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=No
 
 
 def winograd_ok(cin, cout, h, w):
-    """Shapes the Winograd kernel takes (and where it pays: >= 16x16 maps, whole 64-channel output tiles)."""
-    return cin % 8 == 0 and cout % 64 == 0 and h % 2 == 0 and w % 2 == 0 and min(h, w) >= 16
+    """Shapes the Winograd kernels take (winograd_pack picks the form by map size): >= 16x16 maps with even sides; form 1 (16x16 maps)
+    whole 64-channel output tiles and 8-channel chunks, form 2 whole 32-channel tiles and 4-channel chunks."""
+    if h % 2 or w % 2 or min(h, w) < 16:
+        return False
+    return (cin % 8 == 0 and cout % 64 == 0) if min(h, w) <= 16 else (cin % 4 == 0 and cout % 32 == 0)
 
 
 def winograd_fills_chip(n, cout, h, w):
     """The Winograd kernel has no split-K: one workgroup per (sample, 16x16 tile, 64 channels), one workgroup per CU.  Below two
     waves of workgroups (2 x 256) the tap-list kernel with its split-K path is faster (a single 1024^2 projection, n = 1)."""
-    return n * -(-h // 16) * -(-w // 16) * (cout // 64) >= 512
+    return n * -(-h // 16) * -(-w // 16) * (cout // (64 if min(h, w) <= 16 else 32)) >= 512
 
 
 def winograd_pack(w: torch.Tensor, gain: float, res: int) -> torch.Tensor:

@@ -398,6 +398,11 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     load_u(chunk0(1));
     __syncthreads();
     auto body = [&](int i, float* Ucur, float* Vcur, float* Unxt, float* Vnxt, float* raw_in, float* raw_out) {
+        // matrix work first in program order: its operands are ready, so the wave's MFMAs start at once and the parking /
+        // transform instructions below issue in the slots between them (all five LDS regions are distinct compile-time buffers)
+#if !defined(MGF_W2EXP) || MGF_W2EXP != 1         // experiment 1: no matrix work
+        mfma_chunk(Ucur, Vcur);
+#endif
 #if !defined(MGF_W2EXP) || MGF_W2EXP != 3         // experiment 3: no global loads / register parking
         store_x(raw_out);                            // X(i+2), loaded during the previous chunk
         store_u(Unxt);                               // U(i+1)
@@ -406,9 +411,6 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
 #endif
 #if !defined(MGF_W2EXP) || MGF_W2EXP != 2         // experiment 2: no input transform
         transform(raw_in, Vnxt, chunk0(i + 1));
-#endif
-#if !defined(MGF_W2EXP) || MGF_W2EXP != 1         // experiment 1: no matrix work
-        mfma_chunk(Ucur, Vcur);
 #endif
         __syncthreads();
     };
