@@ -145,7 +145,13 @@ def roofline_leg(eng, iters=3):
     per_kernel = {k_: {"launches_per_iter": v[2] // iters, "avg_us": round(v[1] / v[2] * 1e6, 2), "tflops": round(v[0] / v[1] / 1e12, 2)}
                   for k_, v in agg.items()}
     total_conv_s = sum(v[1] for v in agg.values()) / iters
-    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+    extra = {}
+    if dom.startswith("wino"):
+        # the contract counts ALGORITHMIC FLOPs (the direct 3x3 form's); the Winograd kernel executes 16/36 of them on the matrix cores
+        extra = {"executed_mfma_frac": round(achieved * 16 / 36 / FP32_MFMA_PEAK_TFLOPS, 4),
+                 "note": "Winograd F(2x2,3x3): achieved/frac count the direct form's algorithmic FLOPs; the kernel issues 4/9 of them as MFMA work "
+                         "(executed_mfma_frac; cf. SQ_VALU_MFMA_BUSY_CYCLES in profiles/r1_pmc_mfma.txt)"}
+    return {"bound": "mfma", "kernel": dom, **extra, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), **pmc_traffic(dom, eng),
             "algorithmic_bytes_per_launch": round(nbytes / launches),
             "avg_launch_us": round(secs / launches * 1e6, 2), "launches_per_iter": launches // iters,

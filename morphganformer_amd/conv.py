@@ -191,7 +191,9 @@ def winograd_ok(cin, cout, h, w):
 def winograd_fills_chip(n, cout, h, w):
     """The Winograd kernel has no split-K: one workgroup per (sample, 16x16 tile, 64 channels), one workgroup per CU.  Below two
     waves of workgroups (2 x 256) the tap-list kernel with its split-K path is faster (a single 1024^2 projection, n = 1)."""
-    return n * -(-h // 16) * -(-w // 16) * (cout // (64 if min(h, w) <= 16 else 32)) >= 512
+    if min(h, w) <= 16:
+        return n * -(-h // 16) * -(-w // 16) * (cout // 64) >= 512
+    return n * -(-h // 8) * -(-w // 32) * (cout // 32) >= 512
 
 
 def winograd_pack(w: torch.Tensor, gain: float, res: int) -> torch.Tensor:

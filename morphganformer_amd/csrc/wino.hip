@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Second form: TWO workgroups per CU.  A workgroup owns 32 output channels x the same 16x16 output tile; its four waves split the
+// Second form: TWO workgroups per CU.  A workgroup owns 32 output channels x a 32 (x) x 8 (y) output tile; its four waves split the
 // 64 Winograd tiles in two halves (g) and the 16 positions xi in two halves (h2), so a wave carries 8 x 16 = 128 accumulator
 // registers and two workgroups (8 waves, 2 per SIMD) fit in a CU's register file and LDS: while one workgroup transforms / parks
 // its next chunk, the matrix pipes run the other one's MFMAs -- the overlap the one-wave-per-SIMD form above has to get from
@@ -271,7 +271,10 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
 // goes through LDS.
 constexpr int W2CK = 4;
 constexpr int W2CO = 32;
-constexpr int W2_RAW = 256 * 6;                      // 4 * 18 * 18 = 1296 floats rounded up to whole staging slots
+constexpr int W2TX = 16, W2TY = 4;                   // Winograd tiles of a workgroup: 16 wide x 4 tall = 32 x 8 outputs, so that a
+                                                     // wave's 32 tiles are two rows of 16 and its stores / residual loads cover 128-byte row segments
+constexpr int W2RW = 2 * W2TX + 2, W2RH = 2 * W2TY + 2;   // input footprint 34 x 10
+constexpr int W2_RAW = 256 * 6;                      // 4 * 10 * 34 = 1360 floats rounded up to whole staging slots
 constexpr int W2_U = 16 * W2CO * W2CK;               // 2048 floats
 constexpr int W2_V = 16 * WNT * W2CK;                // 4096 floats
 constexpr int W2_XS = 6, W2_US = 2;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     const int ptx = b % p.tiles_x; b /= p.tiles_x;
     const int pty = b % p.tiles_y;
     const int n = b / p.tiles_y;
-    const int co0 = cot * W2CO, oy0 = pty * 2 * WTS, ox0 = ptx * 2 * WTS;
+    const int co0 = cot * W2CO, oy0 = pty * 2 * W2TY, ox0 = ptx * 2 * W2TX;
     const int plane = p.h * p.w;
     const float* xn = p.x + (int64_t)n * p.cin * plane;
     const float* sc = p.in_scale ? p.in_scale + (int64_t)n * p.cin : nullptr;
@@ -303,10 +306,10 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
 #pragma unroll
     for (int j = 0; j < W2_XS; ++j) {
         const int e = tid + 256 * j;
-        const int ch = e / (RAW_H * RAW_H), rem = e - ch * (RAW_H * RAW_H);
-        const int r = rem / RAW_H, q = rem - r * RAW_H;
+        const int ch = e / (W2RH * W2RW), rem = e - ch * (W2RH * W2RW);
+        const int r = rem / W2RW, q = rem - r * W2RW;
         const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
-        xoff[j] = (e < W2CK * RAW_H * RAW_H && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? ch * plane + iy * p.w + ix : -1;
+        xoff[j] = (e < W2CK * W2RH * W2RW && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? ch * plane + iy * p.w + ix : -1;
     }
     // U slot j: float4 e = tid + 256 j of the chunk slab [16 xi][32 co][4 slots]: xi = e >> 5, float4 (e & 31) of 128 contiguous floats
     const int nck = p.cin / W2CK;
@@ -340,14 +343,14 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     const int t_tile = tid >> 2, t_ch = tid & 3;
     const int t_slot = 2 * (t_ch & 1) + (t_ch >> 1);
     auto transform = [&](const float* R, float* V, int c0) {
-        const int ty = t_tile >> 3, tx = t_tile & 7;
-        const float* src = R + (t_ch * RAW_H + 2 * ty) * RAW_H + 2 * tx;
+        const int ty = t_tile / W2TX, tx = t_tile % W2TX;
+        const float* src = R + (t_ch * W2RH + 2 * ty) * W2RW + 2 * tx;
         const float sv = Ss[c0 + t_ch];
         float d[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float2 a = *reinterpret_cast<const float2*>(src + u * RAW_H);
-            const float2 c = *reinterpret_cast<const float2*>(src + u * RAW_H + 2);
+            const float2 a = *reinterpret_cast<const float2*>(src + u * W2RW);
+            const float2 c = *reinterpret_cast<const float2*>(src + u * W2RW + 2);
             d[u][0] = a.x * sv; d[u][1] = a.y * sv; d[u][2] = c.x * sv; d[u][3] = c.y * sv;
         }
         float* dst = V + t_tile * W2CK + t_slot;
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     __syncthreads();
     const float* theirs = xch + ((wg * 2 + (1 - h2)) * 32) * 64 + lane;
     const int tile = wg * 32 + l31;
-    const int ty = tile >> 3, tx = tile & 7;
+    const int ty = tile / W2TX, tx = tile % W2TX;
     const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
     const bool ok_px = oy < p.h && ox < p.w;
     const float* osc = p.out_scale ? p.out_scale + (int64_t)n * p.os_stride : nullptr;
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float v[2];
+            const float2 rr = (do_ep && p.ep.residual) ? *reinterpret_cast<const float2*>(p.ep.residual + off + a * p.w) : make_float2(0.f, 0.f);
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 float t = yv[a][bb] * os;
@@ -491,8 +495,7 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
                     t += bv;
                     if (p.ep.act == MGF_ACT_LRELU) t = t > 0.f ? t : t * p.ep.alpha;
                     else if (p.ep.act == MGF_ACT_RELU) t = t > 0.f ? t : 0.f;
-                    t *= p.ep.gain;
-                    if (p.ep.residual) t += p.ep.residual[off + a * p.w + bb];
+                    t = t * p.ep.gain + (bb ? rr.y : rr.x);
                 }
                 v[bb] = t;
             }
@@ -581,7 +584,7 @@ extern "C" int mgf_conv3x3_winograd2_f32(float* y, const float* x, const float* 
     WinoParams p;
     p.y = y; p.x = x; p.u = u; p.in_scale = in_scale; p.out_scale = out_scale;
     p.n = n; p.cin = cin; p.h = h; p.w = w; p.cout = cout; p.os_stride = out_scale_stride;
-    p.tiles_x = (int)mgf_cdiv(w, 2 * WTS); p.tiles_y = (int)mgf_cdiv(h, 2 * WTS); p.co_tiles = cout / W2CO;
+    p.tiles_x = (int)mgf_cdiv(w, 2 * W2TX); p.tiles_y = (int)mgf_cdiv(h, 2 * W2TY); p.co_tiles = cout / W2CO;
     p.has_ep = ep != nullptr;
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
     const int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
