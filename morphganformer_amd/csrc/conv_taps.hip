@@ -204,8 +204,14 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     auto load_chunk = [&](int c0) {
         const float* xc = xn_l + (int64_t)c0 * plane;
         const float* wc = p.wp + (int64_t)c0 * d.cout_pad;
+#if defined(MGF_EXP) && (MGF_EXP == 4 || MGF_EXP == 6)      // experiment: no activation loads (everything else as is)
+#pragma unroll
+        for (int j = 0; j < XS; ++j) xr[j] = (float)xoff[j];
+        (void)xc;
+#else
 #pragma unroll
         for (int j = 0; j < XS; ++j) xr[j] = xc[xoff[j] > 0 ? xoff[j] : 0];
+#endif
 #pragma unroll
         for (int j = 0; j < WS; ++j) {
             wr[j] = *reinterpret_cast<const float4*>(wc + woff[j]);
@@ -430,7 +436,11 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                                     else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
                                     v = v * p.ep.gain + rv[r8];
                                 }
+#if defined(MGF_EXP) && (MGF_EXP == 5 || MGF_EXP == 6)      // experiment: no output stores (one lane keeps the value alive)
+                                if (v == 12345.678f) ybase[og + cu * plane32] = v;
+#else
                                 ybase[og + cu * plane32] = v;
+#endif
                             }
                         } else {
                             // parity sets: q = 2*a + b -> row 2*ty + a, cols 2*tx + {0,1} written as an aligned pair
