@@ -225,3 +225,17 @@ def test_generator_ref_gradient_full_vs_reference(golden):
     (gz,) = torch.autograd.grad(loss, z)
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * float(g["loss"])
     assert rel(gz, g["grad_z"]) < 1e-4
+
+
+def test_winograd_f2x2_3x3_identity():
+    """The transform matrices csrc/wino.hip hard-codes (Lavin & Gray F(2x2,3x3)): A^T [(G g G^T) . (B^T d B)] A equals the 3x3
+    correlation of a 4x4 patch, in float64, for random data -- pins the algebra the HIP kernels implement."""
+    rng = np.random.Generator(np.random.PCG64(1))
+    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+    G = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], np.float64)
+    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+    for _ in range(5):
+        d, g = rng.standard_normal((4, 4)), rng.standard_normal((3, 3))
+        y = At @ ((G @ g @ G.T) * (Bt @ d @ Bt.T)) @ At.T
+        ref = np.array([[(g * d[i:i + 3, j:j + 3]).sum() for j in range(2)] for i in range(2)])
+        assert np.abs(y - ref).max() < 1e-12
