@@ -10,27 +10,33 @@ import torch
 from ... import _lib
 
 
+def _as_ints(value, counts, what):
+    """An int or a sequence whose length is one of `counts`, as a list of Python ints (error behaviour of the reference: assert)."""
+    seq = [value] if isinstance(value, int) else list(value)
+    assert len(seq) in counts and all(isinstance(v, int) for v in seq), f"bad {what}: {value!r}"
+    return seq
+
+
 def _parse_scaling(scaling):
-    if isinstance(scaling, int):
-        scaling = [scaling, scaling]
-    sx, sy = scaling
-    assert isinstance(sx, int) and isinstance(sy, int) and sx >= 1 and sy >= 1
+    """up / down factor: k or (kx, ky), each >= 1."""
+    seq = _as_ints(scaling, (1, 2), "scaling")
+    sx, sy = seq * 2 if len(seq) == 1 else seq
+    assert sx >= 1 and sy >= 1
     return sx, sy
 
 
 def _parse_padding(padding):
-    if isinstance(padding, int):
-        padding = [padding, padding]
-    padding = list(padding)
-    assert all(isinstance(v, int) for v in padding)
-    if len(padding) == 2:
-        px, py = padding
-        padding = [px, px, py, py]
-    px0, px1, py0, py1 = padding
-    return px0, px1, py0, py1
+    """padding: p | (px, py) | (px0, px1, py0, py1) -> (px0, px1, py0, py1); negative values crop."""
+    seq = _as_ints(padding, (1, 2, 4), "padding")
+    if len(seq) == 1:
+        seq = seq * 4
+    elif len(seq) == 2:
+        seq = [seq[0], seq[0], seq[1], seq[1]]
+    return tuple(seq)
 
 
 def _get_filter_size(f):
+    """(width, height) of a prepared filter; None stands for the 1x1 identity."""
     if f is None:
         return 1, 1
     assert isinstance(f, torch.Tensor) and f.ndim in (1, 2)
