@@ -356,10 +356,18 @@ def main():
         out["generator_forward"] = generator_leg(eng)
         log(f"roofline leg done: {out['roofline']['kernel']} {out['roofline']['achieved']} TFLOP/s")
         if world == 1 and a.gradient_steps > 0 and not a.biometric:
-            out["gradient_mode"] = gradient_leg(sd, cfg, device, eng, a.gradient_steps, a.gradient_lockstep)
-            log(f"gradient-mode leg done: {out['gradient_mode']['value']} iters/s")
+            try:            # an extra beside the metric: never let it take the JSON line down
+                out["gradient_mode"] = gradient_leg(sd, cfg, device, eng, a.gradient_steps, a.gradient_lockstep)
+                log(f"gradient-mode leg done: {out['gradient_mode']['value']} iters/s")
+            except Exception as exc:        # noqa: BLE001 -- reported in the line instead
+                out["gradient_mode"] = {"error": f"{type(exc).__name__}: {exc}"}
+                log(f"gradient-mode leg failed: {exc}")
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, a.cpu_iters)
+            try:
+                out["cpu_baseline"] = cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, a.cpu_iters)
+            except Exception as exc:        # noqa: BLE001 -- the measured GPU line is still printed, with the failure recorded
+                out["cpu_baseline"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
+                log(f"cpu baseline leg failed: {exc}")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
