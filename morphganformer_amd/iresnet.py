@@ -251,26 +251,32 @@ class BiometricLoss:
     def __init__(self, embedder: IResNetEmbedder):
         self.embedder = embedder
         self._target = None
+        self._target_stride = 0
         self._tgt_net = None
         self._scratch = None
 
     def set_target(self, target):
-        if self._tgt_net is None:       # a batch-1 instance sharing nothing mutable with the candidates' workspace
+        """One target [1,3,H,W] shared by every candidate, or B targets that pair up with B candidates (lockstep projections)."""
+        nt = int(target.shape[0])
+        if self._tgt_net is None or self._tgt_net.n != nt:       # an instance sharing nothing mutable with the candidates' workspace
             e = self.embedder
             self._tgt_net = IResNetEmbedder.__new__(IResNetEmbedder)
-            self._tgt_net.__dict__.update({k: v for k, v in e.__dict__.items() if k not in ("bufs", "x112", "stem_out", "flat", "out")})
-            self._tgt_net._alloc(1)
+            self._tgt_net.__dict__.update({k: v for k, v in e.__dict__.items()
+                                           if k not in ("bufs", "x112", "stem_out", "flat", "out") and not k.startswith("_g")})
+            self._tgt_net._alloc(nt)
         self._target = self._tgt_net.embed_image(target.float()).clone()
+        self._target_stride = 512 if nt > 1 else 0
 
     def distance_into(self, out, pred, scale=1.0, accumulate=False):
         """out[i] (+)= scale * mean((embed(pred[i]) - embed(target))^2);  out: float32 [n]."""
         assert self._target is not None, "call set_target first"
         n = pred.shape[0]
+        assert self._target_stride == 0 or self._target.shape[0] == n, "B targets pair up with B candidates"
         emb = self.embedder.embed_image(pred)
         need = n * int(_lib.lib().mgf_reduce_scratch_floats())
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = torch.empty(need, dtype=torch.float32, device=emb.device)
-        _lib.check(_lib.lib().mgf_mse_f32(out.data_ptr(), emb.data_ptr(), self._target.data_ptr(), n, 512, 0, float(scale),
+        _lib.check(_lib.lib().mgf_mse_f32(out.data_ptr(), emb.data_ptr(), self._target.data_ptr(), n, 512, self._target_stride, float(scale),
                                           int(accumulate), self._scratch.data_ptr(), _lib.stream_ptr()), "mse(embedding)")
         return out
 
@@ -280,7 +286,7 @@ class BiometricLoss:
         n = e.n
         if getattr(self, "_demb", None) is None or self._demb.shape[0] != n:
             self._demb = torch.empty(n, 512, dtype=torch.float32, device=dimg.device)
-        _lib.check(_lib.lib().mgf_mse_grad_f32(self._demb.data_ptr(), e.out.data_ptr(), self._target.data_ptr(), n, 512, 0, float(scale), 0,
+        _lib.check(_lib.lib().mgf_mse_grad_f32(self._demb.data_ptr(), e.out.data_ptr(), self._target.data_ptr(), n, 512, self._target_stride, float(scale), 0,
                                                _lib.stream_ptr()), "mse_grad(embedding)")
         return e.backward(self._demb, dimg, accumulate)
 

@@ -427,7 +427,8 @@ class GradientProjectionEngine(ProjectionEngine):
         if percept is not None:
             percept.set_target(self.target)
         self.biometric, self.gamma = biometric, float(gamma)
-        assert biometric is None, "several targets per engine: the biometric term keeps one target embedding (use one engine per target)"
+        if biometric is not None:
+            biometric.set_target(self.target)                 # one embedding per target
         self.use_graph, self.graph, self.pipeline = use_graph, None, False
 
     def _state(self):

@@ -376,3 +376,33 @@ def test_gradient_projection_lockstep_targets_equal_single_runs(tiny):
         assert int(bstep[j]) == sstep
         assert float((multi.latent_in[j].cpu() - sfinal[0]).abs().max()) < 0.05 * args.lr * steps
     assert np.isnan(losses[1, 2]) and not np.isnan(losses[0, 2])
+
+
+def test_lockstep_targets_with_the_biometric_term(tiny):
+    """B = 2 targets with the full objective (LPIPS + Wing + MSE + embedding MSE, one target embedding each): first-step losses equal
+    those of two single-target engines."""
+    from morphganformer_amd.iresnet import BiometricLoss, IResNetEmbedder
+    from morphganformer_amd.lpips import PerceptualLoss
+    from morphganformer_amd.projection import GradientProjectionEngine, ProjectionArgs, synthetic_landmarks
+    gg, tsd, cfg = tiny
+    G = gg.G
+    steps, B = 4, 2
+    torch.manual_seed(31)
+    latent_mean = torch.randn(cfg.k, cfg.z_dim, device="cuda")
+    eps = torch.randn(steps, B, cfg.k, cfg.z_dim, device="cuda")
+    targets = G(torch.randn(B, cfg.k, cfg.z_dim, device="cuda"), None, noise_mode="const")[0].clamp(-1, 1).clone()
+    lms = [synthetic_landmarks(steps, 64, 9 + j) for j in range(B)]
+    args = ProjectionArgs(step=steps, lr=0.05, lr_rampup=0.25, min_loss_init=1e30)
+    firsts = []
+    for j in range(B):
+        e = GradientProjectionEngine(G, targets[j:j + 1].contiguous(), latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze"),
+                                     lm_target=lms[j][0], lm_steps=lms[j][1], eps=eps[:, j:j + 1].contiguous(), noise_mode="const", use_graph=False,
+                                     biometric=BiometricLoss(IResNetEmbedder(None, depth=18, n=1, device="cuda")), gamma=1e-3).run(2)
+        firsts.append(e.losses.cpu().numpy()[:2])
+    multi = GradientProjectionEngine(G, targets, latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze"),
+                                     lm_target=np.stack([l[0] for l in lms]), lm_steps=np.stack([l[1] for l in lms]), eps=eps,
+                                     noise_mode="const", use_graph=True,
+                                     biometric=BiometricLoss(IResNetEmbedder(None, depth=18, n=B, device="cuda")), gamma=1e-3).run(2)
+    got = multi.losses.cpu().numpy()
+    for j in range(B):
+        assert np.abs(got[j, :2] - firsts[j]).max() < 1e-3 * np.abs(firsts[j]).max()
