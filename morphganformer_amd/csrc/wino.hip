@@ -335,23 +335,29 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
 #pragma unroll
         for (int j = 0; j < W2_XS; ++j) R[tid + 256 * j] = xoff[j] >= 0 ? xr[j] : 0.f;
     };
-    auto store_u = [&](float* U) {
+    // the style modulation rides on the weight slab (the reference's w * s, networks.py:289): a float4 holds one output channel's
+    // four slots = channels c0 + {0, 2, 1, 3}, so the chunk's four styles are one wave-uniform 16-byte LDS read
+    auto store_u = [&](float* U, int c0) {
+        const float4 sv = *reinterpret_cast<const float4*>(Ss + c0);
 #pragma unroll
-        for (int j = 0; j < W2_US; ++j) *reinterpret_cast<float4*>(U + (tid + 256 * j) * 4) = ur[j];
+        for (int j = 0; j < W2_US; ++j) {
+            float4 v = ur[j];
+            v.x *= sv.x; v.y *= sv.z; v.z *= sv.y; v.w *= sv.w;
+            *reinterpret_cast<float4*>(U + (tid + 256 * j) * 4) = v;
+        }
     };
     // one (channel, tile) patch per lane: lane <-> (tile = tid >> 2, channel = tid & 3)
     const int t_tile = tid >> 2, t_ch = tid & 3;
     const int t_slot = 2 * (t_ch & 1) + (t_ch >> 1);
-    auto transform = [&](const float* R, float* V, int c0) {
+    auto transform = [&](const float* R, float* V) {
         const int ty = t_tile / W2TX, tx = t_tile % W2TX;
         const float* src = R + (t_ch * W2RH + 2 * ty) * W2RW + 2 * tx;
-        const float sv = Ss[c0 + t_ch];
         float d[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float2 a = *reinterpret_cast<const float2*>(src + u * W2RW);
             const float2 c = *reinterpret_cast<const float2*>(src + u * W2RW + 2);
-            d[u][0] = a.x * sv; d[u][1] = a.y * sv; d[u][2] = c.x * sv; d[u][3] = c.y * sv;
+            d[u][0] = a.x; d[u][1] = a.y; d[u][2] = c.x; d[u][3] = c.y;
         }
         float* dst = V + t_tile * W2CK + t_slot;
 #pragma unroll
@@ -392,10 +398,11 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     load_x(0);
     load_u(0);
     store_x(raw0);
-    store_u(U0);
+    __syncthreads();                                 // Ss is read by store_u
+    store_u(U0, 0);
     load_x(chunk0(1));
     __syncthreads();
-    transform(raw0, V0, 0);
+    transform(raw0, V0);
     store_x(raw1);
     load_x(chunk0(2));
     load_u(chunk0(1));
@@ -408,12 +415,12 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
 #endif
 #if !defined(MGF_W2EXP) || MGF_W2EXP != 3         // experiment 3: no global loads / register parking
         store_x(raw_out);                            // X(i+2), loaded during the previous chunk
-        store_u(Unxt);                               // U(i+1)
+        store_u(Unxt, chunk0(i + 1));                // U(i+1)
         load_x(chunk0(i + 3));
         load_u(chunk0(i + 2));
 #endif
 #if !defined(MGF_W2EXP) || MGF_W2EXP != 2         // experiment 2: no input transform
-        transform(raw_in, Vnxt, chunk0(i + 1));
+        transform(raw_in, Vnxt);
 #endif
         __syncthreads();
     };
