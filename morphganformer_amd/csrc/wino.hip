@@ -20,6 +20,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int WCK = 8;                 // input channels per chunk
 constexpr int WCO = 64;                // output channels per workgroup
@@ -352,24 +353,22 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     auto transform = [&](const float* R, float* V) {
         const int ty = t_tile / W2TX, tx = t_tile % W2TX;
         const float* src = R + (t_ch * W2RH + 2 * ty) * W2RW + 2 * tx;
-        float d[4][4];
+        // row pass on packed pairs (v_pk_add_f32: two columns per instruction), column pass on scalars
+        v2f lo[4], hi[4];                            // d[u][0..1], d[u][2..3]
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float2 a = *reinterpret_cast<const float2*>(src + u * W2RW);
-            const float2 c = *reinterpret_cast<const float2*>(src + u * W2RW + 2);
-            d[u][0] = a.x; d[u][1] = a.y; d[u][2] = c.x; d[u][3] = c.y;
+            lo[u] = *reinterpret_cast<const v2f*>(src + u * W2RW);
+            hi[u] = *reinterpret_cast<const v2f*>(src + u * W2RW + 2);
         }
+        const v2f tl[4] = {lo[0] - lo[2], lo[1] + lo[2], lo[2] - lo[1], lo[1] - lo[3]};
+        const v2f th[4] = {hi[0] - hi[2], hi[1] + hi[2], hi[2] - hi[1], hi[1] - hi[3]};
         float* dst = V + t_tile * W2CK + t_slot;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            float t[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                t[v] = a == 0 ? d[0][v] - d[2][v] : a == 1 ? d[1][v] + d[2][v] : a == 2 ? d[2][v] - d[1][v] : d[1][v] - d[3][v];
-            dst[(a * 4 + 0) * (WNT * W2CK)] = t[0] - t[2];
-            dst[(a * 4 + 1) * (WNT * W2CK)] = t[1] + t[2];
-            dst[(a * 4 + 2) * (WNT * W2CK)] = t[2] - t[1];
-            dst[(a * 4 + 3) * (WNT * W2CK)] = t[1] - t[3];
+            dst[(a * 4 + 0) * (WNT * W2CK)] = tl[a].x - th[a].x;
+            dst[(a * 4 + 1) * (WNT * W2CK)] = tl[a].y + th[a].x;
+            dst[(a * 4 + 2) * (WNT * W2CK)] = th[a].x - tl[a].y;
+            dst[(a * 4 + 3) * (WNT * W2CK)] = tl[a].y - th[a].y;
         }
     };
 
