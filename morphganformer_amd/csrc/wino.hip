@@ -303,38 +303,42 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     const float* xn = p.x + (int64_t)n * p.cin * plane;
     const float* sc = p.in_scale ? p.in_scale + (int64_t)n * p.cin : nullptr;
 
-    int xoff[W2_XS];
+    // Staging loads are raw BUFFER loads: a scalar resource (base + size) plus a 32-bit lane offset -- no 64-bit address arithmetic
+    // per load -- and an out-of-range offset returns 0, which is the zero padding of the footprint (no select when parking).
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, p.cin * plane * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, 16 * p.cin * p.cout * 4, 0x00020000);
+    unsigned xoff[W2_XS];                            // byte offset inside the chunk's channel block; 0xFFFFFFF0 = outside the image
 #pragma unroll
     for (int j = 0; j < W2_XS; ++j) {
         const int e = tid + 256 * j;
         const int ch = e / (W2RH * W2RW), rem = e - ch * (W2RH * W2RW);
         const int r = rem / W2RW, q = rem - r * W2RW;
         const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
-        xoff[j] = (e < W2CK * W2RH * W2RW && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? ch * plane + iy * p.w + ix : -1;
+        xoff[j] = (e < W2CK * W2RH * W2RW && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? (unsigned)(ch * plane + iy * p.w + ix) * 4u : 0xFFFFFFF0u;
     }
     // U slot j: float4 e = tid + 256 j of the chunk slab [16 xi][32 co][4 slots]: xi = e >> 5, float4 (e & 31) of 128 contiguous floats
     const int nck = p.cin / W2CK;
-    int uoff[W2_US];
+    unsigned uoff[W2_US];
 #pragma unroll
     for (int j = 0; j < W2_US; ++j) {
         const int e = tid + 256 * j;
-        uoff[j] = ((e >> 5) * nck * p.cout + co0) * W2CK + (e & 31) * 4;
+        uoff[j] = (unsigned)(((e >> 5) * nck * p.cout + co0) * W2CK + (e & 31) * 4) * 4u;
     }
     float xr[W2_XS];
     float4 ur[W2_US];
     auto load_x = [&](int c0) {
-        const float* xc = xn + (int64_t)c0 * plane;
+        const int soff = c0 * plane * 4;
 #pragma unroll
-        for (int j = 0; j < W2_XS; ++j) xr[j] = xc[xoff[j] > 0 ? xoff[j] : 0];
+        for (int j = 0; j < W2_XS; ++j) xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff[j], soff, 0));
     };
     auto load_u = [&](int c0) {
-        const float* uc = p.u + (int64_t)c0 * p.cout;            // chunk c0 / 4 starts (c0 / 4) * cout * 4 floats into a plane
+        const int soff = c0 * p.cout * 4;            // chunk c0 / 4 starts (c0 / 4) * cout * 4 floats into a plane
 #pragma unroll
-        for (int j = 0; j < W2_US; ++j) ur[j] = *reinterpret_cast<const float4*>(uc + uoff[j]);
+        for (int j = 0; j < W2_US; ++j) ur[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, uoff[j], soff, 0));
     };
     auto store_x = [&](float* R) {
 #pragma unroll
-        for (int j = 0; j < W2_XS; ++j) R[tid + 256 * j] = xoff[j] >= 0 ? xr[j] : 0.f;
+        for (int j = 0; j < W2_XS; ++j) R[tid + 256 * j] = xr[j];
     };
     // the style modulation rides on the weight slab (the reference's w * s, networks.py:289): a float4 holds one output channel's
     // four slots = channels c0 + {0, 2, 1, 3}, so the chunk's four styles are one wave-uniform 16-byte LDS read
@@ -583,7 +587,8 @@ extern "C" int mgf_conv3x3_winograd2_f32(float* y, const float* x, const float* 
                 W2CK, W2CO, cin, cout);
     MGF_REQUIRE(cin <= 1024, MGF_EUNSUPPORTED, "conv3x3_winograd2: at most 1024 input channels (got %d)", cin);
     MGF_REQUIRE(h % 2 == 0 && w % 2 == 0, MGF_EUNSUPPORTED, "conv3x3_winograd2: even feature-map sides only (got %dx%d)", h, w);
-    MGF_REQUIRE((int64_t)cin * h * w <= INT32_MAX / 2 && (int64_t)16 * cin * cout <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd2: tensor too large");
+    MGF_REQUIRE((int64_t)cin * h * w <= INT32_MAX / 4 && (int64_t)16 * cin * cout <= INT32_MAX / 4, MGF_ETOOBIG,
+                "conv3x3_winograd2: one sample / the weight planes must stay below 2 GiB (32-bit buffer offsets)");
     MGF_REQUIRE(((uintptr_t)u % 16) == 0 && ((uintptr_t)y % 8) == 0, MGF_EINVAL, "conv3x3_winograd2: u must be 16-byte and y 8-byte aligned");
     if (ep) MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU, MGF_EUNSUPPORTED,
                         "conv3x3_winograd2: epilogue activation %d unsupported", ep->act);
