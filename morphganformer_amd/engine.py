@@ -31,7 +31,7 @@ from .synth_weights import GeneratorConfig
 SQRT2 = math.sqrt(2.0)
 SQRT_HALF = math.sqrt(0.5)
 USE_WINOGRAD = os.environ.get("MGF_WINOGRAD", "1") != "0"
-WINOGRAD_MAX_RES = int(os.environ.get("MGF_WINOGRAD_MAX_RES", "512"))
+WINOGRAD_MAX_RES = int(os.environ.get("MGF_WINOGRAD_MAX_RES", "1024"))
 
 
 def pack_mapping_params(sd, cfg: GeneratorConfig) -> np.ndarray:
@@ -147,9 +147,9 @@ class SynthesisPlan:
                 # up=1: correlation (flip_weight=True); up=2: conv_transpose2d on the un-flipped weights
                 lp.pc = cv.pack_weights(t32(w), gain=wg, flip=False, want_wsq=True)
                 # Winograd F(2x2,3x3) where it beats the 9-tap kernel IN the iteration (rocprofv3 trace, conv1 layers with their residual
-                # epilogue): 3x3 stride-1 layers on 16^2 .. 512^2 maps (512^2: 4.2 vs 4.7 ms; 1024^2 is a tie at 6.1 ms and stays on the
-                # tap-list kernel); conv_last stays on the tap-list launch that also carries the fused ToRGB projection.
-                # MGF_WINOGRAD=0 (tuning hook) = direct kernel everywhere
+                # epilogue): every 3x3 stride-1 layer from 32^2 up (1024^2: +1 % iterations/s, the smallest margin); conv_last stays on
+                # the tap-list launch that also carries the fused ToRGB projection.  MGF_WINOGRAD=0 (tuning hook) = direct kernel
+                # everywhere, MGF_WINOGRAD_MAX_RES limits the map size
                 if kind == "conv3" and USE_WINOGRAD and cv.winograd_ok(cin, cout, res, res) and res <= WINOGRAD_MAX_RES and name != "conv_last":
                     lp.wino_u = cv.winograd_pack(t32(w), wg, res)
             lp.aff_w = t32(f64(p + ".affine.weight"))
