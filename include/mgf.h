@@ -150,6 +150,11 @@ int mgf_winograd_weights_f32(float* u, const float* w, int32_t cout, int32_t cin
 /* Second form of the same operation (two 4-wave workgroups per CU, 32 output channels x 16x16 outputs each, 4-channel chunks):
  * u[xi][ci / 4][co][slot] with the 4 channels of a chunk in MFMA operand order (slot 2*(c%2) + (c%4)/2); cin % 4 == 0, cout % 32 == 0 */
 int mgf_winograd2_weights_f32(float* u, const float* w, int32_t cout, int32_t cin, float gain, mgf_stream_t stream);
+/* form 2 with the fused 1x1 projection of mgf_conv_desc.rgb_* (ToRGB folded into conv_last, training/networks.py:1054-1065): needs
+ * cout == 32; writes only rgb_out[n, c, h, w] = sum_co rgb_w[n, c, co] * (out_scale[n, co] * conv)[co] + rgb_bias[c], c < rgb_channels <= 4 */
+int mgf_conv3x3_winograd2_rgb_f32(float* rgb_out, const float* x, const float* u, const float* in_scale, const float* out_scale,
+                                  const float* rgb_w, const float* rgb_bias, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                                  int32_t out_scale_stride, int32_t rgb_channels, mgf_stream_t stream);
 int mgf_conv3x3_winograd2_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
                               int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
                               mgf_stream_t stream);

@@ -180,6 +180,20 @@ def winograd2_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=No
     return out
 
 
+def winograd2_rgb_forward(x, u, rgb_w, rgb_bias, rgb_out, in_scale=None, out_scale=None):
+    """conv_last + ToRGB in one Winograd launch (cout == 32): rgb_out [n,c,h,w] = rgb_w [n,c,cout] . (out_scale * conv3x3(x)) + rgb_bias."""
+    _lib.require_gpu(x, u, rgb_w, rgb_bias, rgb_out, in_scale, out_scale)
+    n, cin, h, w = x.shape
+    cout = u.shape[2]
+    assert x.is_contiguous() and u.ndim == 4 and u.shape[3] == 4 and rgb_w.is_contiguous() and rgb_out.is_contiguous()
+    assert tuple(rgb_out.shape) == (n, rgb_w.shape[1], h, w) and rgb_w.shape[2] == cout
+    os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
+    _lib.check(_lib.lib().mgf_conv3x3_winograd2_rgb_f32(rgb_out.data_ptr(), x.data_ptr(), u.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                                        rgb_w.data_ptr(), _lib.ptr(rgb_bias), n, cin, h, w, cout, os_stride, rgb_w.shape[1],
+                                                        _lib.stream_ptr()), "conv3x3_winograd2_rgb")
+    return rgb_out
+
+
 def winograd_ok(cin, cout, h, w):
     """Shapes the Winograd kernels take (winograd_pack picks the form by map size): >= 16x16 maps with even sides; form 1 (16x16 maps)
     whole 64-channel output tiles and 8-channel chunks, form 2 whole 32-channel tiles and 4-channel chunks."""

@@ -45,6 +45,11 @@ struct WinoParams {
     int tiles_x, tiles_y, co_tiles;
     mgf_epilogue ep;
     int has_ep;
+    // fused 1x1 projection of the result (ToRGB folded into conv_last, like mgf_conv_desc.rgb_*): form 2 with cout == 32 only
+    const float* rgb_w;       // [n][rgb_channels][cout]
+    const float* rgb_bias;    // [rgb_channels] or null
+    float* rgb_out;           // [n][rgb_channels][h][w]
+    int rgb_channels;
 };
 
 __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoParams p) {
@@ -280,6 +285,7 @@ constexpr int W2_U = 16 * W2CO * W2CK;               // 2048 floats
 constexpr int W2_V = 16 * WNT * W2CK;                // 4096 floats
 constexpr int W2_XS = 6, W2_US = 2;
 
+template <bool RGB>
 __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     extern __shared__ float lds[];
     float* const raw0 = lds;
@@ -477,6 +483,57 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
         const float* np_ = p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane + (int64_t)oy * p.w + ox;
         nz[0][0] = np_[0] * ns; nz[0][1] = np_[1] * ns; nz[1][0] = np_[p.w] * ns; nz[1][1] = np_[p.w + 1] * ns;
     }
+    if (RGB) {
+        // Fused ToRGB (the conv result itself never goes to memory): this workgroup holds all 32 channels of its pixels -- 8 per lane
+        // in each of the two lane halves of the two position-half waves.  Every lane forms the partial 1x1 projection of its 8
+        // channels, the lane halves meet with one cross-lane exchange, the two waves through LDS (the exchange block is dead by then).
+        const int rc = p.rgb_channels;
+        const float* wr = p.rgb_w + (int64_t)n * rc * p.cout;
+        float sum[4][4];                             // [rgb channel][2x2 position]
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int ij = 0; ij < 4; ++ij) sum[cc][ij] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = h2 * 8 + k;
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float os = osc ? osc[co] : 1.f;
+            float wv[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) wv[cc] = cc < rc ? wr[cc * p.cout + co] : 0.f;
+#pragma unroll
+            for (int ij = 0; ij < 4; ++ij) {
+                const float o = theirs[(k * 4 + ij) * 64];
+                const float m = keep[k][ij];
+                const float v = ((ij >> 1) == 0 ? m + o : (h2 == 0 ? m - o : o - m)) * os;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) sum[cc][ij] += v * wv[cc];
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int ij = 0; ij < 4; ++ij) sum[cc][ij] += __shfl_xor(sum[cc][ij], 32, 64);
+        __syncthreads();                             // every wave has read its partner's block
+        float* rx = xch + (wg * 16) * 64 + l31;      // [2 g][16 values][32 lanes]
+        if (h2 == 1 && half == 0) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int ij = 0; ij < 4; ++ij) rx[(cc * 4 + ij) * 64] = sum[cc][ij];
+        }
+        __syncthreads();
+        if (h2 == 0 && half == 0 && ok_px) {
+            for (int cc = 0; cc < rc; ++cc) {
+                const float bb = p.rgb_bias ? p.rgb_bias[cc] : 0.f;
+                float* o = p.rgb_out + ((int64_t)n * rc + cc) * plane + (int64_t)oy * p.w + ox;
+                *reinterpret_cast<float2*>(o) = make_float2(sum[cc][0] + rx[(cc * 4 + 0) * 64] + bb, sum[cc][1] + rx[(cc * 4 + 1) * 64] + bb);
+                *reinterpret_cast<float2*>(o + p.w) = make_float2(sum[cc][2] + rx[(cc * 4 + 2) * 64] + bb, sum[cc][3] + rx[(cc * 4 + 3) * 64] + bb);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = h2 * 8 + k;
@@ -579,40 +636,61 @@ extern "C" int mgf_winograd2_weights_f32(float* u, const float* w, int32_t cout,
     return MGF_OK;
 }
 
-extern "C" int mgf_conv3x3_winograd2_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
-                                         int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
-                                         mgf_stream_t stream) {
-    MGF_REQUIRE(y && x && u && n >= 1 && cin >= 1 && cout >= 1 && h >= 2 && w >= 2, MGF_EINVAL, "conv3x3_winograd2: bad arguments");
+static int launch_wino2(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n, int32_t cin, int32_t h,
+                       int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep, const float* rgb_w, const float* rgb_bias,
+                       float* rgb_out, int32_t rgb_channels, mgf_stream_t stream) {
+    const bool rgb = rgb_out != nullptr;
+    MGF_REQUIRE((y || rgb) && x && u && n >= 1 && cin >= 1 && cout >= 1 && h >= 2 && w >= 2, MGF_EINVAL, "conv3x3_winograd2: bad arguments");
     MGF_REQUIRE(cin % W2CK == 0 && cout % W2CO == 0, MGF_EUNSUPPORTED, "conv3x3_winograd2: cin must be a multiple of %d and cout of %d (got %d, %d)",
                 W2CK, W2CO, cin, cout);
     MGF_REQUIRE(cin <= 1024, MGF_EUNSUPPORTED, "conv3x3_winograd2: at most 1024 input channels (got %d)", cin);
     MGF_REQUIRE(h % 2 == 0 && w % 2 == 0, MGF_EUNSUPPORTED, "conv3x3_winograd2: even feature-map sides only (got %dx%d)", h, w);
     MGF_REQUIRE((int64_t)cin * h * w <= INT32_MAX / 4 && (int64_t)16 * cin * cout <= INT32_MAX / 4, MGF_ETOOBIG,
                 "conv3x3_winograd2: one sample / the weight planes must stay below 2 GiB (32-bit buffer offsets)");
-    MGF_REQUIRE(((uintptr_t)u % 16) == 0 && ((uintptr_t)y % 8) == 0, MGF_EINVAL, "conv3x3_winograd2: u must be 16-byte and y 8-byte aligned");
+    MGF_REQUIRE(((uintptr_t)u % 16) == 0 && ((uintptr_t)(rgb ? rgb_out : y) % 8) == 0, MGF_EINVAL, "conv3x3_winograd2: u must be 16-byte and the output 8-byte aligned");
     if (ep) MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU, MGF_EUNSUPPORTED,
                         "conv3x3_winograd2: epilogue activation %d unsupported", ep->act);
+    if (rgb) {
+        MGF_REQUIRE(cout == W2CO && rgb_w && rgb_channels >= 1 && rgb_channels <= 4 && !ep, MGF_EUNSUPPORTED,
+                    "conv3x3_winograd2_rgb: needs cout == %d, 1..4 projected channels and no epilogue (got cout %d, %d channels)", W2CO, cout, rgb_channels);
+    }
     WinoParams p;
     p.y = y; p.x = x; p.u = u; p.in_scale = in_scale; p.out_scale = out_scale;
     p.n = n; p.cin = cin; p.h = h; p.w = w; p.cout = cout; p.os_stride = out_scale_stride;
     p.tiles_x = (int)mgf_cdiv(w, 2 * W2TX); p.tiles_y = (int)mgf_cdiv(h, 2 * W2TY); p.co_tiles = cout / W2CO;
     p.has_ep = ep != nullptr;
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
+    p.rgb_w = rgb_w; p.rgb_bias = rgb_bias; p.rgb_out = rgb_out; p.rgb_channels = rgb_channels;
     const int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
     MGF_REQUIRE(blocks <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd2: too many workgroups");
     const size_t lds = (size_t)(2 * W2_RAW + 2 * W2_U + 2 * W2_V + 1024) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino2_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)wino2_conv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino2_conv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { mgf_set_error("conv3x3_winograd2: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
         attr_set = true;
     }
     mgf_prof_external_begin((hipStream_t)stream, "wino2_conv_kernel", 2.0 * 9 * cin * (double)cout * h * w * n,
-                            4.0 * ((double)n * cin * h * w + 9.0 * cin * cout + (double)n * cout * h * w));
-    hipLaunchKernelGGL(wino2_conv_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+                            4.0 * ((double)n * cin * h * w + 9.0 * cin * cout + (double)n * (rgb ? rgb_channels : cout) * h * w));
+    if (rgb) hipLaunchKernelGGL(wino2_conv_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wino2_conv_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     mgf_prof_external_end((hipStream_t)stream);
     MGF_CHECK_LAUNCH("conv3x3_winograd2");
     return MGF_OK;
+}
+
+extern "C" int mgf_conv3x3_winograd2_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
+                                         int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
+                                         mgf_stream_t stream) {
+    return launch_wino2(y, x, u, in_scale, out_scale, n, cin, h, w, cout, out_scale_stride, ep, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mgf_conv3x3_winograd2_rgb_f32(float* rgb_out, const float* x, const float* u, const float* in_scale, const float* out_scale,
+                                             const float* rgb_w, const float* rgb_bias, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                                             int32_t out_scale_stride, int32_t rgb_channels, mgf_stream_t stream) {
+    MGF_REQUIRE(rgb_out, MGF_EINVAL, "conv3x3_winograd2_rgb: null output");
+    return launch_wino2(nullptr, x, u, in_scale, out_scale, n, cin, h, w, cout, out_scale_stride, nullptr, rgb_w, rgb_bias, rgb_out, rgb_channels, stream);
 }
 
 extern "C" int mgf_winograd_weights_f32(float* u, const float* w, int32_t cout, int32_t cin, float gain, mgf_stream_t stream) {

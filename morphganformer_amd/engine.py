@@ -147,10 +147,10 @@ class SynthesisPlan:
                 # up=1: correlation (flip_weight=True); up=2: conv_transpose2d on the un-flipped weights
                 lp.pc = cv.pack_weights(t32(w), gain=wg, flip=False, want_wsq=True)
                 # Winograd F(2x2,3x3) where it beats the 9-tap kernel IN the iteration (rocprofv3 trace, conv1 layers with their residual
-                # epilogue): every 3x3 stride-1 layer from 32^2 up (1024^2: +1 % iterations/s, the smallest margin); conv_last stays on
-                # the tap-list launch that also carries the fused ToRGB projection.  MGF_WINOGRAD=0 (tuning hook) = direct kernel
+                # epilogue): every 3x3 stride-1 layer from 32^2 up (1024^2: +1 % iterations/s, the smallest margin), conv_last with the
+                # ToRGB projection fused into its epilogue like the tap-list launch.  MGF_WINOGRAD=0 (tuning hook) = direct kernel
                 # everywhere, MGF_WINOGRAD_MAX_RES limits the map size
-                if kind == "conv3" and USE_WINOGRAD and cv.winograd_ok(cin, cout, res, res) and res <= WINOGRAD_MAX_RES and name != "conv_last":
+                if kind == "conv3" and USE_WINOGRAD and cv.winograd_ok(cin, cout, res, res) and res <= WINOGRAD_MAX_RES:
                     lp.wino_u = cv.winograd_pack(t32(w), wg, res)
             lp.aff_w = t32(f64(p + ".affine.weight"))
             lp.aff_b = t32(f64(p + ".affine.bias"))
@@ -376,10 +376,16 @@ class Generator:
                 if self.taps is None and self.fuse_torgb and lp.cout <= 32:
                     # conv_last + ToRGB in one kernel: the [n,32,R,R] conv_last activation never goes to HBM
                     torch.mul(lt.w_raw.unsqueeze(0), self._s(lt).unsqueeze(1), out=self.rgbw)      # W[c,co] * s[n,co]
-                    cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=self._s(lp), out_scale=self._d(lp),
-                                    rgb=(self.rgbw, lt.bias, self.img))
+                    if lp.wino_u is not None and lp.wino_u.ndim == 4 and lp.cout == 32 and cv.winograd_fills_chip(n, lp.cout, res, res):
+                        cv.winograd2_rgb_forward(x, lp.wino_u, self.rgbw, lt.bias, self.img, in_scale=self._s(lp), out_scale=self._d(lp))
+                    else:
+                        cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=self._s(lp), out_scale=self._d(lp),
+                                        rgb=(self.rgbw, lt.bias, self.img))
                 else:
-                    x = cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=self._s(lp), out_scale=self._d(lp), out=B["last"])
+                    if lp.wino_u is not None and cv.winograd_fills_chip(n, lp.cout, res, res):
+                        x = cv.winograd_forward(x, lp.wino_u, in_scale=self._s(lp), out_scale=self._d(lp), out=B["last"])
+                    else:
+                        x = cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=self._s(lp), out_scale=self._d(lp), out=B["last"])
                     if self.taps is not None:
                         self.taps[b] = x
                     ep = _lib.make_epilogue(bias=lt.bias)

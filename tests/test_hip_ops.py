@@ -322,3 +322,24 @@ def test_winograd_conv_matches_direct_conv_and_oracle(n, cin, cout, h, w, form):
     out = cv.winograd_forward(xd, u, in_scale=sd, out_scale=dd, epilogue=ep)
     assert rel_err(out, ref_ep) < 2e-5
     assert rel_err(cv.winograd_forward(xd, u), torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)) < 2e-5
+
+
+@pytest.mark.parametrize("n,cin,h,w", [(2, 32, 64, 64), (1, 16, 24, 40)])
+def test_winograd_fused_torgb_matches_tap_list_launch(n, cin, h, w):
+    """conv_last + ToRGB in one Winograd launch vs the tap-list kernel's fused projection and vs torch."""
+    from morphganformer_amd import conv as cv
+    torch.manual_seed(h + cin)
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(32, cin, 3, 3) / (3 * cin ** 0.5)
+    s, d = 1 + 0.3 * torch.randn(n, cin), 0.5 + torch.rand(n, 32)
+    rgbw, rgbb = torch.randn(n, 3, 32), torch.randn(3)
+    conv = torch.nn.functional.conv2d((x * s[:, :, None, None]).double(), wt.double(), padding=1) * d[:, :, None, None].double()
+    ref = torch.einsum("nkc,nchw->nkhw", rgbw.double(), conv) + rgbb.double()[None, :, None, None]
+    f = lambda t: t.cuda().contiguous()
+    xd, sd, dd, rw, rb = f(x), f(s), f(d), f(rgbw), f(rgbb)
+    out = torch.empty(n, 3, h, w, device="cuda")
+    cv.winograd2_rgb_forward(xd, cv.winograd2_weights(f(wt)), rw, rb, out, in_scale=sd, out_scale=dd)
+    assert rel_err(out, ref) < 2e-5
+    direct = torch.empty_like(out)
+    cv.conv_forward(xd, cv.pack_weights(f(wt)), pad=(1, 1), in_scale=sd, out_scale=dd, rgb=(rw, rb, direct))
+    assert rel_err(out, direct) < 2e-5
