@@ -145,11 +145,17 @@ int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs);
  *   winograd_weights: u[xi][ci / 8][co][slot] = gain * (G g G^T)[xi] for w [cout, cin, 3, 3] (xi = 0..15; the 8 channels of a chunk
  *                     are stored in MFMA operand order, slot 4*(c%2) + (c%8)/2), once per checkpoint; 16*cin*cout floats
  *   conv3x3_winograd: y[n, co] = epilogue( out_scale[n, co] * sum_ci (in_scale[n, ci] * w[co, ci]) (*) x[n, ci] ), dense NCHW,
- *                     cin % 8 == 0, cout % 64 == 0, h and w even; in_scale / out_scale / ep may be NULL */
+ *                     cin % 8 == 0, cout % 64 == 0, h and w even (form 1); in_scale / out_scale / ep may be NULL */
 int mgf_winograd_weights_f32(float* u, const float* w, int32_t cout, int32_t cin, float gain, mgf_stream_t stream);
 /* Second form of the same operation (two 4-wave workgroups per CU, 32 output channels x 16x16 outputs each, 4-channel chunks):
  * u[xi][ci / 4][co][slot] with the 4 channels of a chunk in MFMA operand order (slot 2*(c%2) + (c%4)/2); cin % 4 == 0, cout % 32 == 0 */
 int mgf_winograd2_weights_f32(float* u, const float* w, int32_t cout, int32_t cin, float gain, mgf_stream_t stream);
+/* form 2 writing a channel slice of a wider output (y [n, C_total, h, w] with y_batch = C_total*h*w elements between samples, channels
+ * [y_choff, y_choff + cout)) -- a SqueezeNet Fire module's expand3x3 half of the concat buffer; odd map sides are accepted here and in
+ * mgf_conv3x3_winograd2_f32 (element-wise stores of the partial last quads) */
+int mgf_conv3x3_winograd2_slice_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
+                                    int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, int64_t y_batch,
+                                    int32_t y_choff, const mgf_epilogue* ep, mgf_stream_t stream);
 /* form 2 with the fused 1x1 projection of mgf_conv_desc.rgb_* (ToRGB folded into conv_last, training/networks.py:1054-1065): needs
  * cout == 32; writes only rgb_out[n, c, h, w] = sum_co rgb_w[n, c, co] * (out_scale[n, co] * conv)[co] + rgb_bias[c], c < rgb_channels <= 4 */
 int mgf_conv3x3_winograd2_rgb_f32(float* rgb_out, const float* x, const float* u, const float* in_scale, const float* out_scale,

@@ -165,17 +165,19 @@ def winograd2_weights(w: torch.Tensor, gain: float = 1.0) -> torch.Tensor:
     return u
 
 
-def winograd2_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None):
+def winograd2_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None, out_choff=0):
+    """Form 2 (and only it) may write channels [out_choff, out_choff + cout) of a wider `out` and takes odd map sides."""
     _lib.require_gpu(x, u, in_scale, out_scale, out)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and u.ndim == 4 and x.shape[1] == u.shape[1] * 4
     n, cin, h, w = x.shape
     cout = u.shape[2]
     if out is None:
         out = torch.empty([n, cout, h, w], dtype=torch.float32, device=x.device)
-    assert out.is_contiguous() and tuple(out.shape) == (n, cout, h, w)
+    assert out.is_contiguous() and out.shape[0] == n and tuple(out.shape[2:]) == (h, w) and out_choff + cout <= out.shape[1]
     os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
-    rc = _lib.lib().mgf_conv3x3_winograd2_f32(out.data_ptr(), x.data_ptr(), u.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale), n, cin, h, w,
-                                              cout, os_stride, C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
+    rc = _lib.lib().mgf_conv3x3_winograd2_slice_f32(out.data_ptr(), x.data_ptr(), u.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale), n, cin, h,
+                                                    w, cout, os_stride, out.shape[1] * h * w, out_choff,
+                                                    C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
     _lib.check(rc, "conv3x3_winograd2")
     return out
 

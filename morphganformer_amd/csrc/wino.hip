@@ -46,6 +46,9 @@ struct WinoParams {
     mgf_epilogue ep;
     int has_ep;
     // fused 1x1 projection of the result (ToRGB folded into conv_last, like mgf_conv_desc.rgb_*): form 2 with cout == 32 only
+    int64_t y_batch;          // elements between samples of y (form 2: y may be a channel slice of a wider concat buffer)
+    int y_choff;              // channel offset into y
+    int odd;                  // h or w odd: 2x2 output quads are stored element-wise with bounds checks
     const float* rgb_w;       // [n][rgb_channels][cout]
     const float* rgb_bias;    // [rgb_channels] or null
     float* rgb_out;           // [n][rgb_channels][h][w]
@@ -481,7 +484,8 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     if (do_ep && p.ep.noise && ok_px) {
         const float* np_ = p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane + (int64_t)oy * p.w + ox;
-        nz[0][0] = np_[0] * ns; nz[0][1] = np_[1] * ns; nz[1][0] = np_[p.w] * ns; nz[1][1] = np_[p.w + 1] * ns;
+        const bool r1 = oy + 1 < p.h, c1 = ox + 1 < p.w;
+        nz[0][0] = np_[0] * ns; nz[0][1] = c1 ? np_[1] * ns : 0.f; nz[1][0] = r1 ? np_[p.w] * ns : 0.f; nz[1][1] = (r1 && c1) ? np_[p.w + 1] * ns : 0.f;
     }
     if (RGB) {
         // Fused ToRGB (the conv result itself never goes to memory): this workgroup holds all 32 channels of its pixels -- 8 per lane
@@ -549,11 +553,15 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
         if (!ok_px || co >= p.cout) continue;
         const float os = osc ? osc[co] : 1.f;
         const float bv = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
-        const int64_t off = ((int64_t)n * p.cout + co) * plane + (int64_t)oy * p.w + ox;
+        const int64_t off = (int64_t)n * p.y_batch + (int64_t)(p.y_choff + co) * plane + (int64_t)oy * p.w + ox;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float v[2];
-            const float2 rr = (do_ep && p.ep.residual) ? *reinterpret_cast<const float2*>(p.ep.residual + off + a * p.w) : make_float2(0.f, 0.f);
+            float2 rr = make_float2(0.f, 0.f);
+            if (do_ep && p.ep.residual) {
+                if (!p.odd) rr = *reinterpret_cast<const float2*>(p.ep.residual + off + a * p.w);
+                else if (oy + a < p.h) { rr.x = p.ep.residual[off + a * p.w]; if (ox + 1 < p.w) rr.y = p.ep.residual[off + a * p.w + 1]; }
+            }
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 float t = yv[a][bb] * os;
@@ -566,7 +574,12 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
                 }
                 v[bb] = t;
             }
-            *reinterpret_cast<float2*>(p.y + off + a * p.w) = make_float2(v[0], v[1]);
+            if (!p.odd) {
+                *reinterpret_cast<float2*>(p.y + off + a * p.w) = make_float2(v[0], v[1]);
+            } else if (oy + a < p.h) {                 // odd map sides (LPIPS backbones): rows are not 8-byte aligned, the last quad is partial
+                p.y[off + a * p.w] = v[0];
+                if (ox + 1 < p.w) p.y[off + a * p.w + 1] = v[1];
+            }
         }
     }
 }
@@ -638,16 +651,19 @@ extern "C" int mgf_winograd2_weights_f32(float* u, const float* w, int32_t cout,
 
 static int launch_wino2(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n, int32_t cin, int32_t h,
                        int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep, const float* rgb_w, const float* rgb_bias,
-                       float* rgb_out, int32_t rgb_channels, mgf_stream_t stream) {
+                       float* rgb_out, int32_t rgb_channels, mgf_stream_t stream, int64_t y_batch = 0, int32_t y_choff = 0) {
     const bool rgb = rgb_out != nullptr;
     MGF_REQUIRE((y || rgb) && x && u && n >= 1 && cin >= 1 && cout >= 1 && h >= 2 && w >= 2, MGF_EINVAL, "conv3x3_winograd2: bad arguments");
     MGF_REQUIRE(cin % W2CK == 0 && cout % W2CO == 0, MGF_EUNSUPPORTED, "conv3x3_winograd2: cin must be a multiple of %d and cout of %d (got %d, %d)",
                 W2CK, W2CO, cin, cout);
     MGF_REQUIRE(cin <= 1024, MGF_EUNSUPPORTED, "conv3x3_winograd2: at most 1024 input channels (got %d)", cin);
-    MGF_REQUIRE(h % 2 == 0 && w % 2 == 0, MGF_EUNSUPPORTED, "conv3x3_winograd2: even feature-map sides only (got %dx%d)", h, w);
+    const bool odd = (h % 2) || (w % 2);
+    MGF_REQUIRE(!(odd && rgb), MGF_EUNSUPPORTED, "conv3x3_winograd2_rgb: even feature-map sides only (got %dx%d)", h, w);
     MGF_REQUIRE((int64_t)cin * h * w <= INT32_MAX / 4 && (int64_t)16 * cin * cout <= INT32_MAX / 4, MGF_ETOOBIG,
                 "conv3x3_winograd2: one sample / the weight planes must stay below 2 GiB (32-bit buffer offsets)");
-    MGF_REQUIRE(((uintptr_t)u % 16) == 0 && ((uintptr_t)(rgb ? rgb_out : y) % 8) == 0, MGF_EINVAL, "conv3x3_winograd2: u must be 16-byte and the output 8-byte aligned");
+    MGF_REQUIRE(((uintptr_t)u % 16) == 0 && (odd || ((uintptr_t)(rgb ? rgb_out : y) % 8) == 0), MGF_EINVAL, "conv3x3_winograd2: u must be 16-byte and the output 8-byte aligned");
+    MGF_REQUIRE(y_choff >= 0 && (y_batch == 0 || y_batch >= (int64_t)(y_choff + cout) * h * w), MGF_EINVAL, "conv3x3_winograd2: bad output slice");
+    MGF_REQUIRE(odd || (y_batch % 2 == 0), MGF_EINVAL, "conv3x3_winograd2: y_batch must keep rows 8-byte aligned");
     if (ep) MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU, MGF_EUNSUPPORTED,
                         "conv3x3_winograd2: epilogue activation %d unsupported", ep->act);
     if (rgb) {
@@ -661,6 +677,7 @@ static int launch_wino2(float* y, const float* x, const float* u, const float* i
     p.has_ep = ep != nullptr;
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
     p.rgb_w = rgb_w; p.rgb_bias = rgb_bias; p.rgb_out = rgb_out; p.rgb_channels = rgb_channels;
+    p.y_batch = y_batch ? y_batch : (int64_t)cout * h * w; p.y_choff = y_choff; p.odd = odd;
     const int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
     MGF_REQUIRE(blocks <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd2: too many workgroups");
     const size_t lds = (size_t)(2 * W2_RAW + 2 * W2_U + 2 * W2_V + 1024) * sizeof(float);
@@ -684,6 +701,12 @@ extern "C" int mgf_conv3x3_winograd2_f32(float* y, const float* x, const float* 
                                          int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
                                          mgf_stream_t stream) {
     return launch_wino2(y, x, u, in_scale, out_scale, n, cin, h, w, cout, out_scale_stride, ep, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mgf_conv3x3_winograd2_slice_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
+                                               int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, int64_t y_batch,
+                                               int32_t y_choff, const mgf_epilogue* ep, mgf_stream_t stream) {
+    return launch_wino2(y, x, u, in_scale, out_scale, n, cin, h, w, cout, out_scale_stride, ep, nullptr, nullptr, nullptr, 0, stream, y_batch, y_choff);
 }
 
 extern "C" int mgf_conv3x3_winograd2_rgb_f32(float* rgb_out, const float* x, const float* u, const float* in_scale, const float* out_scale,

@@ -31,6 +31,9 @@ CHNS = [64, 128, 256, 384, 384, 512, 512]
 SHIFT = (-0.030, -0.088, -0.188)
 SCALE = (0.458, 0.448, 0.450)
 WEIGHTS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights")
+# Tuning hook: 1 runs the Fire expand3x3 convs on the Winograd kernel (odd maps, concat slices).  Measured slower in the iteration
+# (481 vs 486 iters/s: 16..64 input channels are 4..16 chunks deep and the odd maps take the element-wise store path), so off.
+USE_WINOGRAD_LPIPS = os.environ.get("MGF_WINOGRAD_LPIPS", "0") != "0"
 
 
 def random_squeeze_backbone(seed=0):
@@ -199,7 +202,7 @@ class SqueezeFeatures:
         self.device = torch.device(device)
         dev = self.device
         if share is not None:
-            self.c0, self.fires = share.c0, share.fires          # packed weights are size independent
+            self.c0, self.fires, self.wino3 = share.c0, share.fires, share.wino3          # packed weights are size independent
             self.stem_w, self.stem_b = share.stem_w, share.stem_b
             self.gp = share.gp
         else:
@@ -213,10 +216,13 @@ class SqueezeFeatures:
             self.c0 = (cv.pack_weights(t32(w0f)), t32(b0f))
             self.stem_w, self.stem_b = t32(w0f.reshape(64, 27)), t32(b0f)       # operands of the fused stem kernel
             self.fires = {}
+            self.wino3 = {}                                       # expand3x3 in Winograd form (csrc/wino.hip form 2: odd maps, concat slice)
             for idx in FIRES:
                 p = f"features.{idx}"
                 self.fires[idx] = tuple((cv.pack_weights(t32(g(f"{p}.{nm}.weight"))), t32(g(f"{p}.{nm}.bias")))
                                         for nm in ("squeeze", "expand1x1", "expand3x3"))
+                if USE_WINOGRAD_LPIPS:
+                    self.wino3[idx] = cv.winograd2_weights(t32(g(f"{p}.expand3x3.weight")))
         self.n = n
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         hh, ww = (h - 3) // 2 + 1, (w - 3) // 2 + 1
@@ -332,7 +338,11 @@ class SqueezeFeatures:
                 y = dest(idx)
                 ex = p1.cout
                 cv.conv_forward(s, p1, epilogue=_lib.make_epilogue(bias=b1, act="relu"), out=y, out_choff=0)
-                cv.conv_forward(s, p3, pad=(1, 1), epilogue=_lib.make_epilogue(bias=b3, act="relu"), out=y, out_choff=ex)
+                # Winograd when its grid (no split-K) gives every CU two workgroups: the 25-candidate literal iteration, not a single image
+                if idx in self.wino3 and min(s.shape[2:]) > 16 and s.shape[0] * -(-s.shape[2] // 8) * -(-s.shape[3] // 32) * (ex // 32) >= 512:
+                    cv.winograd2_forward(s, self.wino3[idx], epilogue=_lib.make_epilogue(bias=b3, act="relu"), out=y, out_choff=ex)
+                else:
+                    cv.conv_forward(s, p3, pad=(1, 1), epilogue=_lib.make_epilogue(bias=b3, act="relu"), out=y, out_choff=ex)
                 h = y
             if idx in TAPS_AFTER:
                 taps.append(h)

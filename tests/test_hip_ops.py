@@ -343,3 +343,23 @@ def test_winograd_fused_torgb_matches_tap_list_launch(n, cin, h, w):
     direct = torch.empty_like(out)
     cv.conv_forward(xd, cv.pack_weights(f(wt)), pad=(1, 1), in_scale=sd, out_scale=dd, rgb=(rw, rb, direct))
     assert rel_err(out, direct) < 2e-5
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,ctotal,choff", [(2, 16, 64, 63, 63, 128, 64), (1, 32, 32, 31, 45, 96, 32), (2, 48, 64, 40, 33, 64, 0)])
+def test_winograd_odd_maps_and_channel_slices(n, cin, cout, h, w, ctotal, choff):
+    """Form 2 on odd map sides writing a channel slice of a wider buffer (the Fire expand3x3 half of a concat buffer) with the
+    bias+ReLU epilogue; the rest of the buffer must stay untouched."""
+    from morphganformer_amd import _lib, conv as cv
+    torch.manual_seed(h * w)
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+    bias = torch.randn(cout)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1))
+    f = lambda t: t.cuda().contiguous()
+    out = torch.full((n, ctotal, h, w), 7.0, device="cuda")
+    bd = f(bias)
+    cv.winograd2_forward(f(x), cv.winograd2_weights(f(wt)), epilogue=_lib.make_epilogue(bias=bd, act="relu"), out=out, out_choff=choff)
+    assert rel_err(out[:, choff:choff + cout], ref) < 2e-5
+    mask = torch.ones(ctotal, dtype=torch.bool)
+    mask[choff:choff + cout] = False
+    assert bool((out[:, mask.cuda()] == 7.0).all())
