@@ -11,7 +11,7 @@ engine evaluates `--batch` consecutive steps per generator forward and examines 
 best latent, loss history) is the sequential loop's, bit for bit (tests/test_hip_projection.py), and every step's full work --
 its own noise draws, forward, three losses, selection -- is inside the timed region.  `steps` counts loop steps, not launches.
 With `--pipeline 1` the losses + selection of one batch run on a second stream while the generator already synthesises the next
-batch (separate buffers; same results; 471 vs 455 iters/s): every timed replay still contains one full generator batch and one
+batch (separate buffers; same results; 496 vs 480 iters/s): every timed replay still contains one full generator batch and one
 full loss batch, the one generator batch that is in flight ahead of the losses is produced during warm-up.  It is off by default
 because concurrent kernels stretch each other: per-kernel durations would stop describing a kernel on its own.
 Weights are seeded synthetic tensors (no checkpoint exists offline); inputs are resident in HBM before the timed region.
@@ -146,7 +146,7 @@ def roofline_leg(eng, iters=3):
                   for k_, v in agg.items()}
     total_conv_s = sum(v[1] for v in agg.values()) / iters
     extra = {}
-    if dom.startswith("wino"):
+    if dom.startswith("wino"):          # both Winograd instantiations
         # the contract counts ALGORITHMIC FLOPs (the direct 3x3 form's); the Winograd kernel executes 16/36 of them on the matrix cores
         extra = {"executed_mfma_frac": round(achieved * 16 / 36 / FP32_MFMA_PEAK_TFLOPS, 4),
                  "note": "Winograd F(2x2,3x3): achieved/frac count the direct form's algorithmic FLOPs; the kernel issues 4/9 of them as MFMA work "

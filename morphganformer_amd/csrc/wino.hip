@@ -688,7 +688,8 @@ static int launch_wino2(float* y, const float* x, const float* u, const float* i
         if (e != hipSuccess) { mgf_set_error("conv3x3_winograd2: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return MGF_ELAUNCH; }
         attr_set = true;
     }
-    mgf_prof_external_begin((hipStream_t)stream, "wino2_conv_kernel", 2.0 * 9 * cin * (double)cout * h * w * n,
+    // names as rocprofv3 prints the two instantiations
+    mgf_prof_external_begin((hipStream_t)stream, rgb ? "wino2_conv_kernel<true>" : "wino2_conv_kernel<false>", 2.0 * 9 * cin * (double)cout * h * w * n,
                             4.0 * ((double)n * cin * h * w + 9.0 * cin * cout + (double)n * (rgb ? rgb_channels : cout) * h * w));
     if (rgb) hipLaunchKernelGGL(wino2_conv_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wino2_conv_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
