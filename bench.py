@@ -101,7 +101,7 @@ def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0, pipelin
     gen = torch.Generator(device=device)
     gen.manual_seed(0)
     latent_mean, latent_std = latent_stats(G, 10000, device, gen)
-    percept = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device)
+    percept = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device, allow_random_backbone=True)
     lm_t, lm_s = synthetic_landmarks(steps_total, cfg.img_resolution, seed=7 + rank)
     # (seeded random embedder weights give embedding distances far above the drivers' min_loss start of 100)
     args = ProjectionArgs(step=steps_total, min_loss_init=1e30 if biometric else 100.0)
@@ -163,12 +163,12 @@ def generator_leg(eng, iters=3):
     """The 1024^2 generator forward alone (mapping + synthesis of `batch` candidates, noise_mode="random"), HIP-event timed on
     the launch stream: north-star target ">= 40% of the MFMA roofline on the generator forward"."""
     G, a = eng.G, eng.args
-    G(eng.latent_n, a.truncation_psi, noise_mode="random")
+    G.forward_workspace(eng.latent_n, a.truncation_psi, noise_mode="random")
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        G(eng.latent_n, a.truncation_psi, noise_mode="random")
+        G.forward_workspace(eng.latent_n, a.truncation_psi, noise_mode="random")
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters / eng.batch
@@ -219,7 +219,7 @@ def gradient_leg(sd, cfg, device, eng, steps, lockstep=8):
         tg = GB(zt, None, noise_mode="const")[0].clamp(-1, 1).clone()
         lm = [synthetic_landmarks(total, cfg.img_resolution, seed=50 + j) for j in range(B)]
         gb = GradientProjectionEngine(GB, tg, eng.latent_in[0], 1.0, ProjectionArgs(step=total),
-                                      percept=PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device), use_mse=True,
+                                      percept=PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device, allow_random_backbone=True), use_mse=True,
                                       lm_target=np.stack([l[0] for l in lm]), lm_steps=np.stack([l[1] for l in lm]), noise_mode="random",
                                       seed=6, use_graph=True)
         gb.sigma.copy_(eng.sigma[:1].expand(total))

@@ -299,17 +299,29 @@ int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, int32_t in_h
  * loop never synchronises with the host.  `batch` consecutive steps are handled per call:
  *   perturb: latent_n[j] = latent_in + eps[s] * sigma[s],  s = min(*step + j, steps_total - 1)   (eps: [steps, numel] injected
  *            randn stream, sigma: [steps]); two roundings, like torch
- *   select:  for j in 0..batch-1 (in step order, s = *step + j < steps_total): total = p_loss[j] + lamda*w_loss[j] + beta*mse[j]
- *            (float64, as torch promotes it); if total < *min_loss: min_loss=total, best_latent=latent_n[j], best_step=s.
+ *   select:  for j in 0..batch-1 (in step order, s = *step + j < steps_total):
+ *              total = (double)p_loss[j] + lamda * w_loss[j] + (double)(beta * mse[j])
+ *            -- torch's promotion of `p_loss + args.lamda * w_loss + args.beta * mse_loss` (:179): lamda is a python double times a
+ *            float64 tensor, beta a python scalar times a float32 tensor (float32 product) --
+ *            if total < *min_loss: min_loss=total, best_latent=latent_n[j], best_step=s.
  *            losses_out[s] = total (NaN when valid[s] == 0 = "no face", ...sqz_MSE.py:165-166; valid NULL = always valid).
  *            Finally *step = min(*step + batch, steps_total).  All state lives on the device -> graph-replayable.
+ *            Improvement trail (optional; the drivers save a PNG of the scored image at every improvement, :186-195): when
+ *            `take_slot` != NULL, take_slot[j] = the trail slot candidate j's image belongs in (-1 = not an improvement), and
+ *            trail_steps/trail_losses[slot] record the step and the loss; *trail_count counts improvements.  Slots run 0, 1, ...,
+ *            capacity-1; once full, further improvements overwrite the LAST slot (the best-so-far is always kept).
+ *   keep_improvements: trail_imgs[take_slot[j]] = imgs[j] for every j with take_slot[j] >= 0 (imgs: [batch, numel], the scored
+ *            images of this batch; trail_imgs: [capacity, numel]).
  */
 int mgf_latent_perturb(float* latent_n, const float* latent_in, const float* eps, const float* sigma, const int32_t* step,
                        int32_t batch, int32_t steps_total, int64_t numel, mgf_stream_t stream);
 int mgf_select_best(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out,
                     const float* latent_n, int64_t numel, const float* p_loss, const double* w_loss, const float* mse_loss,
-                    float lamda, float beta, int32_t* step, const int32_t* valid, int32_t batch, int32_t steps_total,
+                    double lamda, float beta, int32_t* step, const int32_t* valid, int32_t batch, int32_t steps_total,
+                    int32_t* take_slot, int32_t* trail_count, int32_t trail_capacity, int32_t* trail_steps, double* trail_losses,
                     mgf_stream_t stream);
+int mgf_keep_improvements(float* trail_imgs, const float* imgs, int64_t numel, const int32_t* take_slot, int32_t batch,
+                          mgf_stream_t stream);
 /* uint8 HWC image = clip(rint(x*127.5+127.5), 0, 255) from CHW float (misc.to_pil, misc.py:114-123) */
 int mgf_to_uint8_hwc(uint8_t* out, const float* img, int32_t c, int32_t h, int32_t w, mgf_stream_t stream);
 

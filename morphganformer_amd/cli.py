@@ -55,6 +55,11 @@ def build_parser():
     p.add_argument("--percept_weight", type=float, default=1.0, help="coefficient of the LPIPS term (0.5 with --beta 0.5 = 1024_example_percept_MSE.py)")
     p.add_argument("--net", type=str, default="squeeze", choices=["squeeze", "vgg", "alex"], help="LPIPS backbone")
     p.add_argument("--no-lpips", action="store_true", help="MSE(+Wing) only, the 1024_example_MSE.py objective")
+    p.add_argument("--lpips-backbone", type=str, default=None, metavar="STATE_DICT",
+                   help="torchvision feature weights of --net (.pth state dict or .npz with `features.N...` keys) -- what the reference "
+                        "fetches with pretrained=True; required unless --no-lpips or --lpips-random-backbone")
+    p.add_argument("--lpips-random-backbone", action="store_true",
+                   help="score with SEEDED RANDOM backbone features (smoke runs only: the LPIPS term is then not a perceptual distance)")
     p.add_argument("--batch", type=int, default=8, help="loop steps evaluated per generator forward (same result)")
     p.add_argument("--mode", type=str, default="literal", choices=["literal", "gradient"],
                    help="literal = the loop as the reference executes it (best-of-N noisy sampling); gradient = back-propagate the loss "
@@ -104,10 +109,21 @@ def main(argv=None):
         lm_t, lm_s = lm["target"], lm["steps"]
         if lm_s.shape[0] < a.step:
             raise SystemExit(f"--landmarks holds {lm_s.shape[0]} steps, --step is {a.step}")
-    percept = None if a.no_lpips else PerceptualLoss(model="net-lin", net=a.net, use_gpu=True, device=G.device)
+    percept = None
+    if not a.no_lpips:
+        if a.lpips_backbone is None and not a.lpips_random_backbone:
+            raise SystemExit("project: the LPIPS term needs the torchvision backbone weights: --lpips-backbone <state dict> "
+                             "(or --no-lpips / --lpips-random-backbone)")
+        from .lpips import load_backbone_state
+        state = load_backbone_state(a.lpips_backbone) if a.lpips_backbone else None
+        if state is None:
+            print("WARNING: LPIPS runs on seeded random backbone weights (--lpips-random-backbone); the term is not a perceptual distance")
+        percept = PerceptualLoss(model="net-lin", net=a.net, use_gpu=True, device=G.device, backbone_state=state,
+                                 allow_random_backbone=state is None)
     stem = os.path.splitext(os.path.basename(a.image))[0]
     res = drivers.project_image(G, target, lm_t, lm_s, args=args, percept=percept, batch=a.batch, seed=a.seed,
-                                out_prefix=os.path.join(a.path_to_gen, stem), mode=a.mode)
+                                out_prefix=os.path.join(a.path_to_gen, stem), mode=a.mode,
+                                path_to_gen=a.path_to_gen if a.mode == "literal" else None)
     print(f"best step {res['step']}  loss {res['loss']:.6f}")
     return 0
 

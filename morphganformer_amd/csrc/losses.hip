@@ -225,23 +225,43 @@ __global__ __launch_bounds__(256) void perturb_kernel(float* latent_n, const flo
 // candidates j = 0 .. batch-1 are examined in step order, exactly as the sequential loop would
 __global__ __launch_bounds__(256) void select_kernel(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out,
                                                      const float* latent_n, int64_t numel, const float* p_loss, const double* w_loss,
-                                                     const float* mse_loss, float lamda, float beta, int32_t* step, const int32_t* valid_tab,
-                                                     int batch, int steps_total) {
+                                                     const float* mse_loss, double lamda, float beta, int32_t* step, const int32_t* valid_tab,
+                                                     int batch, int steps_total, int32_t* take_slot, int32_t* trail_count, int trail_capacity,
+                                                     int32_t* trail_steps, double* trail_losses) {
     __shared__ int take;
     const int s0 = *step;
+    int last_full_j = -1;            // (thread 0) candidate of this batch that already sits in the last trail slot
     for (int j = 0; j < batch; ++j) {
         const int s = s0 + j;
-        if (s >= steps_total) break;
+        if (s >= steps_total) {
+            if (take_slot && threadIdx.x == 0) take_slot[j] = -1;
+            continue;
+        }
         if (threadIdx.x == 0) {
             const int valid = valid_tab ? valid_tab[s] : 1;
-            // same evaluation order as `p_loss + lamda * w_loss + beta * mse_loss` with a float64 wing term
+            // same evaluation order and promotions as `p_loss + lamda * w_loss + beta * mse_loss` with a float64 wing term
             double total = 0.0;
             if (p_loss) total += (double)p_loss[j];
-            if (w_loss) total += (double)lamda * w_loss[j];
+            if (w_loss) total += lamda * w_loss[j];
             if (mse_loss) total += (double)(beta * mse_loss[j]);
             if (losses_out) losses_out[s] = valid ? total : __longlong_as_double(0x7ff8000000000000LL);
             take = valid && total < min_loss[0];
             if (take) { min_loss[0] = total; best_step[0] = s; }
+            if (take_slot) {
+                int slot = -1;
+                if (take) {
+                    const int cnt = *trail_count;
+                    slot = cnt < trail_capacity ? cnt : trail_capacity - 1;
+                    if (slot == trail_capacity - 1) {            // two candidates of one batch must not both be copied into the last slot
+                        if (last_full_j >= 0) take_slot[last_full_j] = -1;
+                        last_full_j = j;
+                    }
+                    trail_steps[slot] = s;
+                    trail_losses[slot] = total;
+                    *trail_count = cnt + 1;
+                }
+                take_slot[j] = slot;
+            }
         }
         __syncthreads();
         if (take)
@@ -249,6 +269,24 @@ __global__ __launch_bounds__(256) void select_kernel(double* min_loss, float* be
         __syncthreads();
     }
     if (threadIdx.x == 0) *step = s0 + batch < steps_total ? s0 + batch : steps_total;
+}
+
+// trail_imgs[take_slot[j]] = imgs[j] for the improving candidates of a batch; grid (blocks, batch), float4 body + scalar tail
+__global__ __launch_bounds__(256) void keep_improvements_kernel(float* __restrict__ trail, const float* __restrict__ imgs, int64_t numel,
+                                                                const int32_t* __restrict__ take_slot) {
+    const int j = blockIdx.y;
+    const int slot = take_slot[j];
+    if (slot < 0) return;
+    const float* src = imgs + (int64_t)j * numel;
+    float* dst = trail + (int64_t)slot * numel;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if ((numel & 3) == 0) {
+        const int64_t n4 = numel >> 2;
+        for (int64_t i = tid; i < n4; i += stride) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+        for (int64_t i = tid; i < numel; i += stride) dst[i] = src[i];
+    }
 }
 
 __global__ __launch_bounds__(256) void to_uint8_kernel(uint8_t* out, const float* img, int c, int h, int w) {
@@ -356,13 +394,28 @@ extern "C" int mgf_latent_perturb(float* latent_n, const float* latent_in, const
 }
 
 extern "C" int mgf_select_best(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out, const float* latent_n,
-                               int64_t numel, const float* p_loss, const double* w_loss, const float* mse_loss, float lamda, float beta,
-                               int32_t* step, const int32_t* valid, int32_t batch, int32_t steps_total, mgf_stream_t stream) {
+                               int64_t numel, const float* p_loss, const double* w_loss, const float* mse_loss, double lamda, float beta,
+                               int32_t* step, const int32_t* valid, int32_t batch, int32_t steps_total, int32_t* take_slot,
+                               int32_t* trail_count, int32_t trail_capacity, int32_t* trail_steps, double* trail_losses, mgf_stream_t stream) {
     MGF_REQUIRE(min_loss && best_latent && best_step && latent_n && step && numel >= 1 && batch >= 1 && steps_total >= 1, MGF_EINVAL,
                 "select_best: bad arguments");
+    MGF_REQUIRE(!take_slot || (trail_count && trail_steps && trail_losses && trail_capacity >= 1), MGF_EINVAL,
+                "select_best: take_slot needs trail_count, trail_steps, trail_losses and a capacity >= 1");
     hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, min_loss, best_latent, best_step, losses_out, latent_n,
-                       numel, p_loss, w_loss, mse_loss, lamda, beta, step, valid, batch, steps_total);
+                       numel, p_loss, w_loss, mse_loss, lamda, beta, step, valid, batch, steps_total, take_slot, trail_count, trail_capacity,
+                       trail_steps, trail_losses);
     MGF_CHECK_LAUNCH("select_best");
+    return MGF_OK;
+}
+
+extern "C" int mgf_keep_improvements(float* trail_imgs, const float* imgs, int64_t numel, const int32_t* take_slot, int32_t batch,
+                                     mgf_stream_t stream) {
+    MGF_REQUIRE(trail_imgs && imgs && take_slot && numel >= 1 && batch >= 1 && batch <= 65535, MGF_EINVAL, "keep_improvements: bad arguments");
+    MGF_REQUIRE((numel & 3) != 0 || ((((uintptr_t)trail_imgs | (uintptr_t)imgs) & 15) == 0), MGF_EINVAL, "keep_improvements: buffers must be 16-byte aligned");
+    const int64_t want = (numel / 4 + 255) / 256 + 1;
+    const int blocks = (int)(want < 512 ? want : 512);
+    hipLaunchKernelGGL(keep_improvements_kernel, dim3(blocks, batch), dim3(256), 0, (hipStream_t)stream, trail_imgs, imgs, numel, take_slot);
+    MGF_CHECK_LAUNCH("keep_improvements");
     return MGF_OK;
 }
 

@@ -144,12 +144,17 @@ def merge_morph(G, w1, w2, alphas=(0.5,), truncation_psi=0.7, noise_mode="random
 
 def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None,
                   eps=None, out_prefix=None, batch=1, use_graph=True, noise_mode="random", use_mse=True, seed=None,
-                  landmark_fn=None, mode="literal", weight_decay=0.0):
+                  landmark_fn=None, mode="literal", weight_decay=0.0, path_to_gen=None, keep_images=32):
     """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and either
     `lm_steps` [steps,68,2] (injected landmark detections) or `landmark_fn` (host detector called on every generated image,
     see ProjectionEngine).  mode="literal" is the loop as the reference executes it (best-of-N noisy sampling, `batch` steps per
     forward); mode="gradient" back-propagates the loss into the latent and lets Adam move it (GradientProjectionEngine; one
-    candidate per step; weight_decay=1e-4 is the 1024_example_MSE.py:117 optimizer).  Returns dict(w, step, loss, losses)."""
+    candidate per step; weight_decay=1e-4 is the 1024_example_MSE.py:117 optimizer).  Returns dict(w, step, loss, losses).
+
+    Outputs, like the drivers: with `path_to_gen` (literal mode) the SCORED image of every improvement -- the candidate as it was
+    generated and ranked, its random per-layer noise included -- is written as `{path_to_gen}/{step:06d}_{loss:04f}.png` (:190-195;
+    the images are kept on the device during the run, up to `keep_images` of them, and written afterwards).  `out_prefix` adds the
+    latent as `{out_prefix}.mat` (key 'w', :201-206 of the morph drivers)."""
     args = args or ProjectionArgs()
     if latent_mean is None or latent_std is None:
         gen = None
@@ -166,13 +171,16 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
     else:
         eng = ProjectionEngine(G, target, latent_mean, float(latent_std), args, percept=percept, lm_target=lm_target,
                                lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse,
-                               landmark_fn=landmark_fn)
+                               landmark_fn=landmark_fn, keep_images=keep_images if path_to_gen is not None else 0)
     w, step, loss, losses = eng.run().result()
+    out = {"w": w, "step": step, "loss": loss, "losses": losses}
     if out_prefix is not None:
         save_latent_mat(f"{out_prefix}.mat", w)
-        img = G(w.to(G.device), None, noise_mode="const")[0]
-        save_image(G, img, f"{out_prefix}-{loss:.4f}.png", args.ratio)
-    return {"w": w, "step": step, "loss": loss, "losses": losses}
+    if path_to_gen is not None:
+        if mode != "literal":
+            raise ValueError("path_to_gen (the per-improvement PNG trail) is kept by the literal-mode engine")
+        out["images"] = eng.save_improvements(path_to_gen, args.ratio)
+    return out
 
 
 def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):

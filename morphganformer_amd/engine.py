@@ -225,10 +225,62 @@ class Generator:
         # as the loss/generator pipeline: concurrent kernels stretch each other -- differently under graph replay than in the eager
         # roofline leg -- so per-kernel durations would no longer agree between bench.py and a rocprofv3 trace.
         self.overlap_skip = os.environ.get("MGF_OVERLAP_SKIP", "0") != "0"
+        self._workspaces, self._pins = {}, {}
         self._alloc(max_batch)
 
     # ------------------------------------------------------------------ workspace
+    # One workspace (activations, style / demod / value arenas, device job tables) per batch size, kept for the life of the
+    # generator: hipGraphs captured by the projection engines bake these pointers in, so a call with another batch size must never
+    # free them (it used to).  Engines `pin` the batch size they captured; only un-pinned workspaces are ever dropped, and only when
+    # the total exceeds MGF_WORKSPACE_GB (default 160 of the 288 GB).
+    _WS_FIELDS = ("n", "w_buf", "styles", "demods", "vtabs", "noise_rand", "bufs", "img", "const_in", "rgbw", "style_jobs", "n_style_jobs",
+                  "max_style_cin", "attn_jobs", "n_attn_jobs", "style_jobs_pl", "attn_jobs_pl", "ws_bytes")
+
     def _alloc(self, n):
+        """Make the workspace of batch size n current (created on first use)."""
+        cur = getattr(self, "n", None)
+        if cur is not None and cur in self._workspaces:
+            self._workspaces[cur]["noise_rand"] = self.noise_rand              # lazily allocated: remember it with its workspace
+        ws = self._workspaces.pop(n, None)
+        if ws is None:
+            self._evict_for(n)
+            self._create(n)
+            ws = {k: getattr(self, k) for k in self._WS_FIELDS}
+        self._workspaces[n] = ws                                               # most recently used last
+        for k, v in ws.items():
+            setattr(self, k, v)
+
+    def pin(self, n=None):
+        """Declare that a captured hipGraph references the workspace of batch size n (default: the current one)."""
+        n = self.n if n is None else n
+        self._pins[n] = self._pins.get(n, 0) + 1
+        return n
+
+    def unpin(self, n):
+        if self._pins.get(n, 0) > 0:
+            self._pins[n] -= 1
+
+    def _evict_for(self, n):
+        budget = float(os.environ.get("MGF_WORKSPACE_GB", "160")) * 2 ** 30
+        need = self._workspace_bytes(n)
+        total = sum(w["ws_bytes"] for w in self._workspaces.values())
+        for m in list(self._workspaces):                                       # least recently used first
+            if total + need <= budget:
+                break
+            if self._pins.get(m, 0) == 0 and m != getattr(self, "n", None):
+                total -= self._workspaces.pop(m)["ws_bytes"]
+
+    def _workspace_bytes(self, n):
+        cfg = self.cfg
+        per = 0
+        for res in cfg.block_resolutions:
+            c = cfg.channels(res)
+            planes = 2 + (4 if res > 4 else 0) + (1 if res > 4 and cfg.has_attention(res) else 0) + (1 if cfg.has_attention(res) else 0) \
+                + (1 if res == cfg.img_resolution else 0)
+            per += planes * c * res * res
+        return 4 * n * (per + cfg.img_channels * cfg.img_resolution ** 2)
+
+    def _create(self, n):
         cfg, dev, P = self.cfg, self.device, self.plan
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         self.n = n
@@ -256,31 +308,40 @@ class Generator:
         self.img = e(n, cfg.img_channels, cfg.img_resolution, cfg.img_resolution)
         self.const_in = P.const.unsqueeze(0).repeat(n, 1, 1, 1).contiguous()            # networks.py:1147
         self.rgbw = e(n, cfg.img_channels, cfg.channels(cfg.img_resolution))
+        self.ws_bytes = self._workspace_bytes(n)
         self._build_jobs(n)
 
     def _build_jobs(self, n):
-        """Device job tables for the batched style/demod and attention-value launches (ws layout: [n, k, D]).
-        The style / demod / value arenas are layer-major: [layer][n][channels], so each job sees a dense [n, c] block."""
+        """Device job tables for the batched style/demod and attention-value launches.  The style / demod / value arenas are
+        layer-major: [layer][n][channels], so each job sees a dense [n, c] block.  Two tables each: for one latent set shared by all
+        layers (w [n, k, D]: what mapping() broadcasts and every driver uses) and for per-layer latents (ws [n, k, num_ws, D],
+        networks.py:1252-1253: layer `slot` reads ws[:, :, slot]) -- same kernels, different offsets into the latent tensor."""
         cfg, P = self.cfg, self.plan
-        D = cfg.w_dim
-        sj = (_lib.StyleJob * len(P.layers))()
-        aj = []
-        for i, lp in enumerate(P.layers):
-            sj[i] = _lib.StyleJob(lp.aff_w.data_ptr(), lp.aff_b.data_ptr(), _lib.ptr(lp.pc.wsq) if lp.demod else 0,
-                                  self.styles.data_ptr() + 4 * lp.s_off * n,
-                                  (self.demods.data_ptr() + 4 * lp.d_off * n) if lp.demod else 0,
-                                  lp.cin, lp.cout, (cfg.k - 1) * D, 1.0 / math.sqrt(D), lp.style_gain)
-            if lp.attn is not None:
-                aj.append(_lib.AttnJob(lp.attn.wmv.data_ptr(), lp.attn.bmv.data_ptr(),
-                                       self.vtabs.data_ptr() + 4 * lp.attn.v_off * n, lp.attn.c, 0))
-        self.style_jobs = torch.frombuffer(bytearray(bytes(sj)), dtype=torch.uint8).to(self.device)
+        D, NW = cfg.w_dim, cfg.num_ws
+
+        def tables(per_layer):
+            sj = (_lib.StyleJob * len(P.layers))()
+            aj = []
+            for i, lp in enumerate(P.layers):
+                g_off = ((cfg.k - 1) * NW + lp.slot) * D if per_layer else (cfg.k - 1) * D          # the global component (get_global)
+                sj[i] = _lib.StyleJob(lp.aff_w.data_ptr(), lp.aff_b.data_ptr(), _lib.ptr(lp.pc.wsq) if lp.demod else 0,
+                                      self.styles.data_ptr() + 4 * lp.s_off * n,
+                                      (self.demods.data_ptr() + 4 * lp.d_off * n) if lp.demod else 0,
+                                      lp.cin, lp.cout, g_off, 1.0 / math.sqrt(D), lp.style_gain)
+                if lp.attn is not None:
+                    aj.append(_lib.AttnJob(lp.attn.wmv.data_ptr(), lp.attn.bmv.data_ptr(),
+                                           self.vtabs.data_ptr() + 4 * lp.attn.v_off * n, lp.attn.c, lp.slot * D if per_layer else 0))
+            sjt = torch.frombuffer(bytearray(bytes(sj)), dtype=torch.uint8).to(self.device)
+            ajt = None
+            if aj:
+                arr = (_lib.AttnJob * len(aj))(*aj)
+                ajt = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            return sjt, ajt, len(aj)
+
+        self.style_jobs, self.attn_jobs, self.n_attn_jobs = tables(False)
+        self.style_jobs_pl, self.attn_jobs_pl, _ = tables(True)
         self.n_style_jobs = len(P.layers)
         self.max_style_cin = max(lp.cin for lp in P.layers)
-        self.attn_jobs = None
-        if aj:
-            arr = (_lib.AttnJob * len(aj))(*aj)
-            self.attn_jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-        self.n_attn_jobs = len(aj)
 
     def _s(self, lp):
         return self.styles.view(-1)[lp.s_off * self.n:(lp.s_off + lp.cin) * self.n].view(self.n, lp.cin)
@@ -304,12 +365,17 @@ class Generator:
         return self
 
     def mapping(self, z, truncation_psi=1, truncation_cutoff=None):
-        """z [n,k,D] -> ws [n,k,num_ws,D] (broadcast view), reference MappingNetwork.forward semantics."""
-        w = self._mapping_into(z)
+        """z [n,k,D] -> ws [n,k,num_ws,D], reference MappingNetwork.forward semantics (networks.py:929-941): broadcast over the
+        layer slots, then `w_avg.lerp(x, psi)` on all slots or, with a cutoff, on slots [0, cutoff) only."""
+        return self._truncate(self._mapping_into(z), truncation_psi, truncation_cutoff)
+
+    def _truncate(self, w, truncation_psi, truncation_cutoff):
         ws = w.unsqueeze(2).expand(-1, -1, self.num_ws, -1)
         if truncation_psi != 1:
-            ws = self.w_avg.lerp(ws, truncation_psi) if truncation_cutoff is None else torch.cat(
-                [self.w_avg.lerp(ws[:, :, :truncation_cutoff], truncation_psi), ws[:, :, truncation_cutoff:]], dim=2)
+            if truncation_cutoff is None:
+                ws = self.w_avg.lerp(ws, truncation_psi)
+            else:
+                ws = torch.cat([self.w_avg.lerp(ws[:, :, :truncation_cutoff], truncation_psi), ws[:, :, truncation_cutoff:]], dim=2)
         return ws
 
     def _mapping_into(self, z):
@@ -326,19 +392,32 @@ class Generator:
         return self.w_buf
 
     def synthesis(self, w, noise_mode="random", noises=None, return_att=False):
-        """w: [n, k, D] (one latent set shared by all layers, as every driver uses it).  Returns img [n,3,R,R]."""
+        """w: [n, k, D] -- one latent set shared by all layers, as every driver uses it -- or ws [n, k, num_ws, D] with per-layer
+        latents (W+; layer `slot` reads ws[:, :, slot] for its style AND its attention values, networks.py:1022-1031,1252-1253).
+        Returns img [n,3,R,R] (the workspace buffer: valid until the next call with this batch size)."""
         cfg, P, L = self.cfg, self.plan, _lib.lib()
         n = w.shape[0]
         if n != self.n:
             raise _lib.MgfError("synthesis: batch size changed; call through __call__ / mapping first")
         st = _lib.stream_ptr()
         D, T = cfg.w_dim, cfg.k - 1
-        assert w.is_contiguous() and tuple(w.shape) == (n, cfg.k, D)
-        _lib.check(L.mgf_style_demod_multi(self.style_jobs.data_ptr(), self.n_style_jobs, w.data_ptr(), cfg.k * D, n, D,
-                                           self.max_style_cin, st),
+        _lib.require_gpu(w)
+        per_layer = w.ndim == 4
+        if per_layer:
+            if tuple(w.shape) != (n, cfg.k, cfg.num_ws, D):
+                raise _lib.MgfError(f"synthesis: ws must be [n, {cfg.k}, {cfg.num_ws}, {D}] (got {tuple(w.shape)})")
+            w = w.contiguous().float()
+            stride_n, stride_t = cfg.k * cfg.num_ws * D, cfg.num_ws * D
+            sjobs, ajobs = self.style_jobs_pl, self.attn_jobs_pl
+        else:
+            assert w.is_contiguous() and tuple(w.shape) == (n, cfg.k, D)
+            stride_n, stride_t = cfg.k * D, D
+            sjobs, ajobs = self.style_jobs, self.attn_jobs
+        self.last_w = w                                                            # kept alive for the asynchronous launches below
+        _lib.check(L.mgf_style_demod_multi(sjobs.data_ptr(), self.n_style_jobs, w.data_ptr(), stride_n, n, D, self.max_style_cin, st),
                    "style_demod_multi")
         if self.n_attn_jobs:
-            _lib.check(L.mgf_attn_values_multi(self.attn_jobs.data_ptr(), self.n_attn_jobs, w.data_ptr(), cfg.k * D, D, n, T, D, st),
+            _lib.check(L.mgf_attn_values_multi(ajobs.data_ptr(), self.n_attn_jobs, w.data_ptr(), stride_n, stride_t, n, T, D, st),
                        "attn_values_multi")
         if noise_mode == "random":
             noises = self._draw_noise(n)
@@ -466,28 +545,50 @@ class Generator:
             y = out
         return y
 
-    def __call__(self, z=None, c=None, ws=None, truncation_psi=1, truncation_cutoff=None, return_img=True, return_att=False,
-                 return_ws=False, subnet=None, noise_mode="random", noises=None, fused_modconv=None):
+    def forward_workspace(self, z=None, c=None, ws=None, truncation_psi=1, truncation_cutoff=None, return_img=True, return_att=False,
+                          return_ws=False, subnet=None, noise_mode="random", noises=None, fused_modconv=None, att_format="tensor"):
+        """Generator.forward (networks.py:1304-1331), zero-copy: the returned image IS the workspace buffer of this batch size and is
+        overwritten by the next call (what the projection engines want; `__call__` hands out copies).
+
+        ws [n, k, num_ws, D]: per-layer latents are honoured (every layer reads its own slot, :1252-1253).  truncation_psi /
+        truncation_cutoff act in the mapping network only, i.e. when `z` is given (:1317, :935-941).  return_att=True returns the
+        stacked attention tensor [n, k-1, layers, 1, R, R] of list2tensor (:1262,1222-1242); att_format="maps" returns the per-layer
+        dict {layer: (probs [n,F,k-1], argmax [n,F])} instead (the cheap form: the stacked tensor is 738 MB per image at 1024^2)."""
         return_tensor = False
         if subnet is not None:
             return_ws, return_img, return_att, return_tensor = subnet == "mapping", subnet == "synthesis", False, True
+        if att_format not in ("tensor", "maps"):
+            raise ValueError(f"att_format must be 'tensor' or 'maps' (got {att_format!r})")
+        ws_out = None
         if ws is None:
+            if z is None:
+                raise _lib.MgfError("Generator: pass z or ws")
             w = self._mapping_into(z)
-            if truncation_psi != 1:
-                w = self.w_avg.lerp(w, truncation_psi)
+            if truncation_psi != 1 and truncation_cutoff is not None:
+                w_in = ws_out = self._truncate(w, truncation_psi, truncation_cutoff).contiguous()    # slots differ -> per-layer path
+            else:
+                w_in = self.w_avg.lerp(w, truncation_psi) if truncation_psi != 1 else w
         else:
-            # all drivers pass one latent set broadcast over num_ws (networks.py:932); take slot 0
-            assert ws.ndim == 4 and ws.shape[1] == self.cfg.k
+            _lib.require_gpu(ws)
+            if ws.ndim != 4 or tuple(ws.shape[1:]) != (self.cfg.k, self.num_ws, self.cfg.w_dim):
+                raise _lib.MgfError(f"Generator: ws must be [n, {self.cfg.k}, {self.num_ws}, {self.cfg.w_dim}] (got {tuple(ws.shape)})")
             if ws.shape[0] != self.n:
                 self._alloc(ws.shape[0])
-            w = ws[:, :, 0].contiguous().float()
+            w_in = ws_out = ws.contiguous().float()
         ret = ()
         if return_img or return_att:
-            img = self.synthesis(w.contiguous(), noise_mode=noise_mode, noises=noises, return_att=return_att)
+            img = self.synthesis(w_in if w_in.ndim == 4 else w_in.contiguous(), noise_mode=noise_mode, noises=noises, return_att=return_att)
             if return_img:
                 ret += (img,)
             if return_att:
-                ret += (self.att_maps,)
+                ret += (self.att_maps if att_format == "maps" else self.list2tensor(self.att_maps),)
         if return_ws:
-            ret += (w.unsqueeze(2).expand(-1, -1, self.num_ws, -1),)
+            ret += (ws_out if ws_out is not None else w_in.unsqueeze(2).expand(-1, -1, self.num_ws, -1),)
         return ret[0] if return_tensor else ret
+
+    def __call__(self, *args, **kwargs):
+        """Generator.forward with the reference's ownership: every returned tensor is the caller's own (`a = G(z1)[0]; b = G(z2)[0]` do
+        not alias).  The projection engines use `forward_workspace` (no copy)."""
+        ret = self.forward_workspace(*args, **kwargs)
+        own = lambda t: t.clone() if isinstance(t, torch.Tensor) else t
+        return own(ret) if not isinstance(ret, tuple) else tuple(own(t) for t in ret)

@@ -97,9 +97,20 @@ class GeneratorGrad:
     def forward(self, z=None, ws=None, truncation_psi=1, noise_mode="const", noises=None):
         """G(z)[0] (or G(ws=...)) with conv_last kept in memory (the fused conv_last+ToRGB kernel never writes it)."""
         G = self.G
+        if ws is not None:
+            # the backward pass sums the layers' latent gradients into ONE latent set: a broadcast ws (what mapping() returns, an
+            # expanded view) is fine, distinct per-layer latents are not supported here
+            if ws.ndim == 4 and ws.stride(2) != 0:
+                raise _lib.MgfError("GeneratorGrad: per-layer ws (W+) has no backward pass; pass z, or a ws broadcast over the layer axis")
+            w = (ws[:, :, 0] if ws.ndim == 4 else ws).contiguous().float()
         G.fuse_torgb = False
         try:
-            img = G(z, None, ws=ws, truncation_psi=truncation_psi, noise_mode=noise_mode, noises=noises)[0]
+            if ws is not None:
+                if w.shape[0] != G.n:
+                    G._alloc(w.shape[0])
+                img = G.synthesis(w, noise_mode=noise_mode, noises=noises)
+            else:
+                img = G.forward_workspace(z, None, truncation_psi=truncation_psi, noise_mode=noise_mode, noises=noises)[0]
         finally:
             G.fuse_torgb = True
         self.z = None if z is None else z.contiguous().float()

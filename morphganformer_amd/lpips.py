@@ -80,6 +80,22 @@ def random_backbone(net, seed=0):
     return sd
 
 
+def load_backbone_state(path):
+    """torchvision-keyed feature weights from a state_dict file (.pth/.pt: torch.load with weights_only=True; .npz: numpy).  Accepts a
+    whole-model state dict (`features.0.weight`, `classifier...`: the classifier entries are ignored) -> {key: float32 numpy}."""
+    if str(path).endswith(".npz"):
+        raw = dict(np.load(path))
+    else:
+        raw = torch.load(path, map_location="cpu", weights_only=True)
+        if "state_dict" in raw and not any(k.startswith("features.") for k in raw):
+            raw = raw["state_dict"]
+    out = {k: np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
+           for k, v in raw.items() if k.startswith("features.")}
+    if not out:
+        raise _lib.MgfError(f"{path}: no `features.*` entries (expected a torchvision squeezenet1_1 / vgg16 / alexnet state dict)")
+    return out
+
+
 class SequentialFeatures:
     """LPIPS taps of a plain conv/ReLU/max-pool stack (VGG16, AlexNet) for a fixed input size, preallocated workspace.
     The ScalingLayer runs as its own element-wise step (these nets zero-pad the SCALED input, so it cannot be folded)."""
@@ -353,7 +369,12 @@ class PerceptualLoss(torch.nn.Module):
     """lpips.PerceptualLoss(model='net-lin', net='squeeze', use_gpu=True)(pred, target, normalize=False) -> [N,1,1,1]."""
 
     def __init__(self, model="net-lin", net="squeeze", colorspace="rgb", spatial=False, use_gpu=True, gpu_ids=(0,),
-                 backbone_state=None, backbone_seed=0, device="cuda"):
+                 backbone_state=None, backbone_seed=None, allow_random_backbone=False, device="cuda"):
+        """backbone_state: the torchvision feature weights (`features.N...` keys, tensors or arrays; `load_backbone_state` reads a
+        .pth / .npz) -- what the reference obtains with tv.<net>(pretrained=True) (pretrained_networks.py:9,60,100).  Without it
+        the distance would be computed on meaningless features, so that is an ERROR unless the caller opts in to the seeded random
+        backbone (allow_random_backbone=True or an explicit backbone_seed: benchmarks and parity tests, where only the arithmetic
+        matters)."""
         super().__init__()
         if model != "net-lin" or spatial or colorspace != "rgb":
             raise NotImplementedError("the MI355X path implements model='net-lin', spatial=False, colorspace='rgb'")
@@ -361,11 +382,20 @@ class PerceptualLoss(torch.nn.Module):
             raise NotImplementedError(f"unknown LPIPS backbone {net!r} (squeeze, vgg, alex)")
         if not use_gpu:
             raise _lib.MgfError("PerceptualLoss(use_gpu=False): the MI355X package has no CPU path")
+        if backbone_state is None:
+            if not allow_random_backbone and backbone_seed is None:
+                raise _lib.MgfError(
+                    f"PerceptualLoss(net={net!r}): no backbone weights.  Pass backbone_state= (torchvision `{net}` feature weights, see "
+                    "lpips.load_backbone_state) or opt in to seeded random features with allow_random_backbone=True / backbone_seed=")
+            backbone_state = random_backbone(net, 0 if backbone_seed is None else backbone_seed)
+            self.random_backbone = True
+        else:
+            self.random_backbone = False
+        self.backbone_state = backbone_state
         _lib.lib()
         self.device_ = torch.device(device)
         self.net = net
         self.chns = NET_CHNS[net]
-        self.backbone_state = backbone_state if backbone_state is not None else random_backbone(net, backbone_seed)
         lin = np.load(os.path.join(WEIGHTS_DIR, f"lpips_lin_{net}.npz"))
         self.lins = [torch.as_tensor(lin[f"lin{i}"], dtype=torch.float32, device=self.device_) for i in range(len(self.chns))]
         self._feats = {}

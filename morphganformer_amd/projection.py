@@ -61,8 +61,11 @@ def get_lr(t, initial_lr, rampdown=0.25, rampup=0.05):
 
 
 def noise_schedule(steps, latent_std, noise, noise_ramp):
-    """sigma_i for i in range(steps), evaluated exactly like the driver: python floats, then float32 on use."""
-    return np.array([float(latent_std) * noise * max(0, 1 - (i / steps) / noise_ramp) ** 2 for i in range(steps)], dtype=np.float64)
+    """sigma_i for i in range(steps) as float32, with the driver's roundings (:156): `latent_std` is a 0-d float32 TENSOR there, so
+    `latent_std * args.noise` rounds to float32, the multiplication by the python-float ramp factor rounds to float32 again, and
+    `.item()` hands that value to latent_noise (:157, :71-73), where `noise * strength` multiplies a float32 tensor by it."""
+    base = np.float32(latent_std) * np.float32(noise)                                   # float32 x float32 -> float32, like the tensor op
+    return np.array([base * np.float32(max(0, 1 - (i / steps) / noise_ramp) ** 2) for i in range(steps)], dtype=np.float32)
 
 
 def latent_stats(G, n_mean_latent=10000, device="cuda", generator=None):
@@ -78,7 +81,7 @@ class ProjectionEngine:
 
     def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True,
                  lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, batch=1,
-                 landmark_fn=None, biometric=None, gamma=1.0, wing_kind="wing", landmark_model=None, pipeline=False):
+                 landmark_fn=None, biometric=None, gamma=1.0, wing_kind="wing", landmark_model=None, pipeline=False, keep_images=0):
         """batch = number of consecutive loop steps evaluated per generator forward.  In literal mode the steps do not depend
         on each other (latent_in never changes), so evaluating `batch` candidates at once and examining them in step order
         gives exactly the sequential loop's result while the small 4x4..64x64 layers, the mapping network and the LPIPS tail
@@ -92,6 +95,12 @@ class ProjectionEngine:
         literal loop's steps are independent, and selection still happens in step order, so results are unchanged; one extra
         generator batch is in flight at any time (an engine that is `run()` to its last step has synthesised one batch more
         than it scored).
+
+        keep_images: K > 0 keeps the SCORED image of every improvement on the device (the drivers write `{step:06d}_{loss:04f}.png`
+        of exactly that image -- random per-layer noise included -- at every improvement, :186-195): a trail of up to K images with
+        their steps and losses, filled inside the launch sequence (no host round trip); after K improvements the last slot is
+        overwritten, so the best-so-far image is always there.  `improvements()` returns the trail, `save_improvements()` writes it
+        under the reference's file names.
 
         biometric: optional `iresnet.BiometricLoss`; adds gamma * MSE(embed(img), embed(target)) to the objective (the
         FaceNet term of 1024_example_FaceNet_percept.py:147-158 on the vendored IResNet embedder).
@@ -122,7 +131,7 @@ class ProjectionEngine:
         self.numel = k * D
         self.latent_in = latent_mean.detach().clone().reshape(1, k, D).contiguous().float()
         sig = noise_schedule(a.step, float(latent_std), a.noise, a.noise_ramp)
-        self.sigma = torch.as_tensor(sig.astype(np.float32), device=dev)
+        self.sigma = torch.as_tensor(sig, device=dev)
         if eps is None:
             gen = torch.Generator(device=dev)
             gen.manual_seed(seed)
@@ -166,6 +175,14 @@ class ProjectionEngine:
         self.biometric, self.gamma = biometric, float(gamma)
         if biometric is not None:
             biometric.set_target(self.target)
+        self.keep_images = int(keep_images)
+        if self.keep_images > 0:
+            per = G.cfg.img_channels * G.cfg.img_resolution ** 2
+            self.trail_imgs = torch.empty(self.keep_images, per, dtype=torch.float32, device=dev)
+            self.trail_steps = torch.full([self.keep_images], -1, dtype=torch.int32, device=dev)
+            self.trail_losses = torch.zeros(self.keep_images, dtype=torch.float64, device=dev)
+            self.trail_count = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.take_slot = torch.full([B], -1, dtype=torch.int32, device=dev)
         self.use_graph = use_graph
         self.graph = None
         self.pipeline = bool(pipeline) and landmark_fn is None
@@ -191,7 +208,7 @@ class ProjectionEngine:
         L, st, a, B = _lib.lib(), _lib.stream_ptr(), self.args, self.batch
         _lib.check(L.mgf_latent_perturb(latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(),
                                         self.sigma.data_ptr(), ctr.data_ptr(), B, self.steps, self.numel, st), "latent_perturb")
-        return self.G(latent_n, a.truncation_psi, noise_mode=self.noise_mode)[0]          # psi lands in `c`
+        return self.G.forward_workspace(latent_n, a.truncation_psi, noise_mode=self.noise_mode)[0]      # psi lands in `c`
 
     def _loss_phase(self, img, latent_n):
         L, st, a, B = _lib.lib(), _lib.stream_ptr(), self.args, self.batch
@@ -214,12 +231,19 @@ class ProjectionEngine:
             _lib.check(L.mgf_adaptive_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), B,
                                                     self.lm_target.numel(), 14.0, 0.5, 1.0, 2.1, self.step_ctr.data_ptr(),
                                                     self.lm_steps.shape[0] - 1, st), "adaptive_wing_loss")
+        keep = self.keep_images > 0
         _lib.check(L.mgf_select_best(self.min_loss.data_ptr(), self.best_latent.data_ptr(), self.best_step.data_ptr(),
                                      self.losses.data_ptr(), latent_n.data_ptr(), self.numel,
                                      _lib.ptr(self.p_loss if (self.percept is not None or self.biometric is not None) else None),
                                      _lib.ptr(self.w_loss if self.use_wing else None),
                                      _lib.ptr(self.mse_loss if self.use_mse else None), float(a.lamda), float(a.beta),
-                                     self.step_ctr.data_ptr(), _lib.ptr(self.valid), B, self.steps, st), "select_best")
+                                     self.step_ctr.data_ptr(), _lib.ptr(self.valid), B, self.steps,
+                                     _lib.ptr(self.take_slot if keep else None), _lib.ptr(self.trail_count if keep else None),
+                                     self.keep_images, _lib.ptr(self.trail_steps if keep else None),
+                                     _lib.ptr(self.trail_losses if keep else None), st), "select_best")
+        if keep:
+            _lib.check(L.mgf_keep_improvements(self.trail_imgs.data_ptr(), img.data_ptr(), self.trail_imgs.shape[1],
+                                               self.take_slot.data_ptr(), B, st), "keep_improvements")
 
     def _landmarks(self, img):
         """Fill this batch's rows of the landmark / valid tables when a detector is attached (host callback or device model)."""
@@ -251,7 +275,8 @@ class ProjectionEngine:
         main.wait_stream(self.loss_stream)
 
     def _pipe_capture(self):
-        state = [t.clone() for t in (self.step_ctr, self.gen_ctr, self.min_loss, self.best_latent, self.best_step, self.losses)]
+        tensors = self._state() + (self.gen_ctr,)
+        state = [t.clone() for t in tensors]
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
@@ -264,8 +289,9 @@ class ProjectionEngine:
             with torch.cuda.graph(g):
                 self._pipe_step(p)
             self.graphs[p] = g
-        for dst, src in zip((self.step_ctr, self.gen_ctr, self.min_loss, self.best_latent, self.best_step, self.losses), state):
+        for dst, src in zip(tensors, state):
             dst.copy_(src)
+        self._pin_workspace()
 
     def _run_pipelined(self, n):
         if self.use_graph and self.graphs[0] is None:
@@ -293,7 +319,29 @@ class ProjectionEngine:
 
     def _state(self):
         """Device tensors that make up the loop state (saved and restored around the capture warm-up)."""
-        return (self.step_ctr, self.min_loss, self.best_latent, self.best_step, self.losses)
+        st = (self.step_ctr, self.min_loss, self.best_latent, self.best_step, self.losses)
+        if self.keep_images > 0:
+            st += (self.trail_count, self.trail_steps, self.trail_losses)
+        return st
+
+    def improvements(self):
+        """The improvement trail of a keep_images=K engine: list of (step, loss, image [C,H,W] device tensor) in the order the
+        improvements happened -- the (step, min_loss, img_gen_raw) triples the drivers turn into PNG files (:186-195).  With more
+        than K improvements the list holds the first K-1 and the latest."""
+        assert self.keep_images > 0, "construct the engine with keep_images=K"
+        torch.cuda.synchronize(self.device)
+        n = min(int(self.trail_count.item()), self.keep_images)
+        c, r = self.G.cfg.img_channels, self.G.cfg.img_resolution
+        steps, losses = self.trail_steps.cpu().numpy(), self.trail_losses.cpu().numpy()
+        return [(int(steps[i]), float(losses[i]), self.trail_imgs[i].view(c, r, r)) for i in range(n)]
+
+    def save_improvements(self, output_dir, ratio=1.0):
+        """Write the trail as the drivers do: `{output_dir}/{step:06d}_{loss:04f}.png` of crop(to_pil(img), ratio) (:190-195)."""
+        from .drivers import save_image
+        paths = []
+        for step, loss, img in self.improvements():
+            paths.append(save_image(self.G, img.unsqueeze(0), os.path.join(output_dir, "{:06d}_{:04f}.png".format(step, loss)), ratio))
+        return paths
 
     def _capture(self):
         # warm-up on a side stream (allocations, lazy init) before capture, then restore the loop state
@@ -310,6 +358,13 @@ class ProjectionEngine:
         for dst, src in zip(self._state(), state):
             dst.copy_(src)
         self.graph = g
+        self._pin_workspace()
+
+    def _pin_workspace(self):
+        """The captured graph references the generator's workspace of this batch size: keep it alive as long as this engine lives."""
+        import weakref
+        G = self.G
+        weakref.finalize(self, G.unpin, G.pin())
 
     def run(self, steps=None):
         """Advance the loop by `steps` iterations (default: all remaining), `batch` of them per launch sequence."""
@@ -397,7 +452,7 @@ class GradientProjectionEngine(ProjectionEngine):
         self.numel = k * D
         lm0 = latent_mean.detach().float().reshape(-1, k, D)
         self.latent_in = (lm0 if lm0.shape[0] == B else lm0.expand(B, -1, -1)).contiguous().clone()
-        self.sigma = torch.as_tensor(noise_schedule(a.step, float(latent_std), a.noise, a.noise_ramp).astype(np.float32), device=dev)
+        self.sigma = torch.as_tensor(noise_schedule(a.step, float(latent_std), a.noise, a.noise_ramp), device=dev)
         if eps is None:
             gen = torch.Generator(device=dev)
             gen.manual_seed(seed)
@@ -429,7 +484,7 @@ class GradientProjectionEngine(ProjectionEngine):
         self.biometric, self.gamma = biometric, float(gamma)
         if biometric is not None:
             biometric.set_target(self.target)                 # one embedding per target
-        self.use_graph, self.graph, self.pipeline = use_graph, None, False
+        self.use_graph, self.graph, self.pipeline, self.keep_images = use_graph, None, False, 0
 
     def _state(self):
         return super()._state() + (self.latent_in, self.exp_avg, self.exp_avg_sq, self.adam_t)
@@ -481,7 +536,7 @@ class GradientProjectionEngine(ProjectionEngine):
                                          self.losses.reshape(B, -1)[j].data_ptr(), self.latent_n[j:].data_ptr(), self.numel,
                                          _lib.ptr(self.p_loss[j:] if has_p else None), _lib.ptr(self.w_loss[j:] if self.use_wing else None),
                                          _lib.ptr(self.mse_loss[j:] if self.use_mse else None), float(a.lamda), float(a.beta),
-                                         ctr.data_ptr(), _lib.ptr(valid), 1, self.steps, st), "select_best")
+                                         ctr.data_ptr(), _lib.ptr(valid), 1, self.steps, None, None, 0, None, None, st), "select_best")
         return img
 
     def run(self, steps=None):
@@ -511,7 +566,7 @@ class GradientProjectionEngine(ProjectionEngine):
 def save_best_png(G, latent, path, ratio=1.0, noise_mode="const"):
     """Write the image of `latent` as the drivers do (misc.to_pil + crop_max_rectangle, misc.py:94-130; :194-195)."""
     from PIL import Image
-    img = G(latent.to(G.device), None, noise_mode=noise_mode)[0]
+    img = G.forward_workspace(latent.to(G.device), None, noise_mode=noise_mode)[0]
     c, h, w = img.shape[1:]
     out = torch.empty([h, w, c], dtype=torch.uint8, device=G.device)
     _lib.check(_lib.lib().mgf_to_uint8_hwc(out.data_ptr(), img.data_ptr(), c, h, w, _lib.stream_ptr()), "to_uint8")
@@ -531,32 +586,3 @@ def synthetic_landmarks(steps, res, seed):
     target = rng.integers(res // 4, 3 * res // 4, size=(68, 2)).astype(np.float64)
     per_step = target[None] + rng.integers(-max(res // 64, 1), max(res // 64, 1) + 1, size=(steps, 68, 2)).astype(np.float64)
     return target, per_step
-
-
-def smoke_projection():
-    """Tiny literal-mode run on cuda:0 checked against the CPU oracle (used by __graft_entry__.smoke())."""
-    from oracle.generator_ref import generator_ref, to_torch_state
-    from oracle.loss_ref import mse_ref, projection_literal_ref, wing_loss_ref
-    from .engine import Generator
-    from .synth_weights import TINY, make_state_dict, synthetic_latents
-    sd = make_state_dict(TINY, seed=0)
-    tsd = to_torch_state(sd)
-    G = Generator(sd, TINY, "cuda:0", max_batch=1)
-    steps = 8
-    rng = np.random.Generator(np.random.PCG64(3))
-    latent_mean = torch.from_numpy(rng.standard_normal((TINY.k, TINY.z_dim)).astype(np.float32) * 0.1)
-    eps = torch.from_numpy(rng.standard_normal((steps, 1, TINY.k, TINY.z_dim)).astype(np.float32))
-    target = generator_ref(tsd, torch.from_numpy(synthetic_latents(TINY, 1, 1001)), TINY, "const").clamp(-1, 1)
-    lm_t, lm_s = synthetic_landmarks(steps, 64, 9)
-    args = ProjectionArgs(step=steps)
-    eng = ProjectionEngine(G, target.cuda(), latent_mean.cuda(), 23.3, args, percept=None, lm_target=lm_t, lm_steps=lm_s,
-                           eps=eps.cuda(), noise_mode="const", use_graph=True)
-    lat, bstep, bloss, losses = eng.run().result()
-    ref = projection_literal_ref(
-        lambda z: generator_ref(tsd, z, TINY, "const"),
-        lambda i, img: float(0.01 * wing_loss_ref(torch.from_numpy(lm_s[i]), torch.from_numpy(lm_t)) + mse_ref(img, target)),
-        latent_mean, 23.3, eps, steps)
-    assert bstep == ref[1], (bstep, ref[1])
-    assert torch.equal(lat, ref[0]), "best latent must be bit-exact under injected noise"
-    assert abs(bloss - ref[2]) < 1e-3 * abs(ref[2])
-    print(f"[smoke] literal projection (8 steps, graph replay): best step {bstep}, loss {bloss:.6f} (oracle {ref[2]:.6f})")

@@ -139,6 +139,15 @@ def synthesis_ref(sd, w, cfg, noise_mode="const", noises=None, taps=None):
     """
     B = w.shape[0]
     x = None
+    slots = {f"synthesis.b{res}.{name}": slot for res, name, _ci, _co, _up, slot, *_ in cfg.layer_table()}
+    if w.ndim == 4:
+        # per-layer latents ws [B,k,num_ws,D]: block r sees ws.narrow(2, w_idx, ...) and hands its layers next(w_iter)
+        # (networks.py:1134,1158-1173,1249-1253) -> layer `slot` reads ws[:, :, slot]
+        ws4, w = w, None
+        pick = lambda prefix: ws4[:, :, slots[prefix]]
+    else:
+        w3 = w
+        pick = lambda prefix: w3
     for res in cfg.block_resolutions:
         b = f"synthesis.b{res}"
 
@@ -151,31 +160,57 @@ def synthesis_ref(sd, w, cfg, noise_mode="const", noises=None, taps=None):
 
         if res == 4:
             x = sd[b + ".const"][None].repeat(B, 1, 1, 1)                              # :1147
-            x = synthesis_layer_ref(sd, b + ".conv1", x, w, cfg, res, 1, nz("conv1"), 1.0, taps)
+            x = synthesis_layer_ref(sd, b + ".conv1", x, pick(b + ".conv1"), cfg, res, 1, nz("conv1"), 1.0, taps)
         else:
             ws_ = sd[b + ".skip.weight"]
             y = conv2d_resample_ref(x, ws_ * (1.0 / math.sqrt(ws_.shape[1])), f=sd[b + ".skip.resample_kernel"],
                                     up=2, padding=0, flip_weight=False)                # :245-250
             y = y * SQRT_HALF
-            x = synthesis_layer_ref(sd, b + ".conv0", x, w, cfg, res, 2, nz("conv0"), 1.0, taps)
-            x = synthesis_layer_ref(sd, b + ".conv1", x, w, cfg, res, 1, nz("conv1"), SQRT_HALF, taps)
+            x = synthesis_layer_ref(sd, b + ".conv0", x, pick(b + ".conv0"), cfg, res, 2, nz("conv0"), 1.0, taps)
+            x = synthesis_layer_ref(sd, b + ".conv1", x, pick(b + ".conv1"), cfg, res, 1, nz("conv1"), SQRT_HALF, taps)
             x = y + x                                                                  # :1160
         if res == cfg.img_resolution:
-            x = synthesis_layer_ref(sd, b + ".conv_last", x, w, cfg, res, 1, None, 1.0, taps)   # :1170
+            x = synthesis_layer_ref(sd, b + ".conv_last", x, pick(b + ".conv_last"), cfg, res, 1, None, 1.0, taps)   # :1170
         if taps is not None:
             taps[b] = x                       # what SynthesisBlock.forward returns as x (:1174)
         if res == cfg.img_resolution:
             tw = sd[b + ".torgb.weight"]
-            styles = _fc(sd, b + ".torgb.affine", w[:, -1]) * (1.0 / math.sqrt(tw.shape[1]))    # :1056-1059
+            styles = _fc(sd, b + ".torgb.affine", pick(b + ".torgb")[:, -1]) * (1.0 / math.sqrt(tw.shape[1]))    # :1056-1059
             img = modulated_conv2d_ref(x, tw, styles, demodulate=False)
             img = bias_act_ref(img, sd[b + ".torgb.biasAct.bias"])
             return img
     raise AssertionError("unreachable")
 
 
-def generator_ref(sd, z, cfg, noise_mode="const", noises=None, taps=None):
-    """Generator.forward(z)[0] (networks.py:1304-1331) with truncation_psi=1."""
+def truncate_ref(sd, w, cfg, truncation_psi=1, truncation_cutoff=None):
+    """Broadcast + truncation of MappingNetwork.forward (networks.py:929-941): w [B,k,D] -> ws [B,k,num_ws,D]."""
+    ws = w.unsqueeze(2).repeat(1, 1, cfg.num_ws, 1)
+    if truncation_psi != 1:
+        if truncation_cutoff is None:
+            ws = sd["mapping.w_avg"].lerp(ws, truncation_psi)
+        else:
+            ws[:, :, :truncation_cutoff] = sd["mapping.w_avg"].lerp(ws[:, :, :truncation_cutoff], truncation_psi)
+    return ws
+
+
+def list2tensor_ref(probs_by_layer, cfg):
+    """SynthesisNetwork.list2tensor (networks.py:1222-1242): the layers' attention maps [B,F,T] (in network order), each
+    nearest-neighbour replicated to the image resolution, stacked to [B, T, layers, 1, R, R]."""
+    R, T = cfg.img_resolution, cfg.k - 1
+    out = []
+    for p in probs_by_layer:
+        B, Fn, _ = p.shape
+        r = math.isqrt(Fn)
+        m = p.reshape(B, r, r, T).permute(0, 3, 1, 2)                                  # [B,T,r,r]
+        out.append(m.repeat_interleave(R // r, dim=2).repeat_interleave(R // r, dim=3))
+    return torch.stack(out, dim=2).unsqueeze(3)
+
+
+def generator_ref(sd, z, cfg, noise_mode="const", noises=None, taps=None, truncation_psi=1, truncation_cutoff=None):
+    """Generator.forward(z)[0] (networks.py:1304-1331); truncation_psi=1 in the projection drivers."""
     w = mapping_ref(sd, z, cfg)
     if taps is not None:
         taps["ws"] = w
+    if truncation_psi != 1:
+        w = truncate_ref(sd, w, cfg, truncation_psi, truncation_cutoff)
     return synthesis_ref(sd, w, cfg, noise_mode, noises, taps)

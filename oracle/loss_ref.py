@@ -14,8 +14,10 @@
 
 Pinned by tests/golden/loss_kats.npz (Wing/AWing/schedule KATs from the reference's own classes) and
 tests/golden/loop_tiny.npz (reference Generator + reference WingLoss driven through the loop).
-LPIPS backbone parity with ImageNet weights: UNPINNED (torchvision and its weights are absent offline);
-pinned only on the vendored 'lin' heads + seeded random backbone weights against torch's own conv ops.
+LPIPS: the DISTANCE half (ScalingLayer, normalize_tensor, squared difference, lin heads, spatial average, sum) is pinned by
+tests/golden/lpips_dist.npz = the reference's own lpips/networks_basic.py PNetLin.forward / lpips.PerceptualLoss.forward run on
+injected tap tensors and vendored lin weights.  The BACKBONE half with ImageNet weights stays UNPINNED (torchvision and its
+weights are absent offline): topology restated, checked on seeded random weights against torch's own conv ops.
 """
 from __future__ import annotations
 
@@ -58,7 +60,9 @@ def get_lr_ref(t, initial_lr, rampdown=0.25, rampup=0.05):
 
 
 def noise_strength_ref(t, latent_std, noise=0.05, noise_ramp=0.75):
-    return latent_std * noise * max(0.0, 1.0 - t / noise_ramp) ** 2
+    """...sqz_MSE.py:156 with its dtypes: latent_std is a 0-d float32 tensor, so both multiplications are float32 tensor x python
+    scalar ops (each rounds to float32); `.item()` returns that value as a python float."""
+    return (torch.as_tensor(float(latent_std), dtype=torch.float32) * noise * max(0.0, 1.0 - t / noise_ramp) ** 2).item()
 
 
 def latent_stats_ref(samples):
@@ -168,23 +172,34 @@ def sequential_features_ref(net, bb, x):
     return taps
 
 
-def lpips_ref(bb, lins, img0, img1, per_layer=False, net="squeeze"):
-    """PNetLin.forward (networks_basic.py:64-92), version 0.1, spatial=False.  lins: list of [C] tensors."""
-    shift = torch.tensor(LPIPS_SHIFT).reshape(1, 3, 1, 1)
-    scale = torch.tensor(LPIPS_SCALE).reshape(1, 3, 1, 1)
-    feats = squeeze_features_ref if net == "squeeze" else (lambda b_, x_: sequential_features_ref(net, b_, x_))
-    f0 = feats(bb, (img0 - shift) / scale)
-    f1 = feats(bb, (img1 - shift) / scale)
+def scaling_layer_ref(x):
+    """ScalingLayer.forward (networks_basic.py:94-101)."""
+    return (x - torch.tensor(LPIPS_SHIFT).reshape(1, 3, 1, 1)) / torch.tensor(LPIPS_SCALE).reshape(1, 3, 1, 1)
+
+
+def normalize_tensor_ref(f, eps=1e-10):
+    """lpips.normalize_tensor (lpips/__init__.py:44-46)."""
+    return f / (f.square().sum(1, keepdim=True).sqrt() + eps)
+
+
+def lpips_distance_ref(taps0, taps1, lins, per_layer=False):
+    """The distance half of PNetLin.forward (networks_basic.py:70-92, lpips=True, spatial=False): unit-normalise each tap over
+    channels, squared difference, 1x1 lin head (dropout = identity in eval), spatial mean, sum over taps.
+    Pinned by tests/golden/lpips_dist.npz (the reference's own PNetLin.forward on injected tap tensors)."""
     vals = []
-    for a, b, lin in zip(f0, f1, lins):
-        na = a / (a.square().sum(1, keepdim=True).sqrt() + 1e-10)
-        nb = b / (b.square().sum(1, keepdim=True).sqrt() + 1e-10)
-        d = (na - nb).square()
+    for a, b, lin in zip(taps0, taps1, lins):
+        d = (normalize_tensor_ref(a) - normalize_tensor_ref(b)).square()
         vals.append((d * lin.reshape(1, -1, 1, 1)).sum(1, keepdim=True).mean([2, 3], keepdim=True))
     total = vals[0]
     for v in vals[1:]:
         total = total + v
     return (total, vals) if per_layer else total
+
+
+def lpips_ref(bb, lins, img0, img1, per_layer=False, net="squeeze"):
+    """PNetLin.forward (networks_basic.py:64-92), version 0.1, spatial=False.  lins: list of [C] tensors."""
+    feats = squeeze_features_ref if net == "squeeze" else (lambda b_, x_: sequential_features_ref(net, b_, x_))
+    return lpips_distance_ref(feats(bb, scaling_layer_ref(img0)), feats(bb, scaling_layer_ref(img1)), lins, per_layer)
 
 
 # --------------------------------------------------------------------------------------------

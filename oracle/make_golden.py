@@ -220,10 +220,12 @@ def gold_loop_tiny(ref, G):
     latent_in = latent_mean[None].clone()
     min_loss, best, best_step = 100.0, None, -1
     losses = np.zeros(steps, np.float64)
+    sigmas, latents_n = [], []
     for i in range(steps):
         t = i / steps
         sigma = latent_std * 0.05 * max(0, 1 - t / 0.75) ** 2
         latent_n = latent_in + torch.from_numpy(eps[i]) * sigma.item()
+        sigmas.append(sigma.item()); latents_n.append(latent_n.numpy().copy())
         img = G(latent_n, 0.7, noise_mode="const")[0]
         w = wing(torch.from_numpy(lm_steps[i]), torch.from_numpy(lm_target))
         total = 0.01 * w + 1.0 * mse(img, target)
@@ -233,7 +235,8 @@ def gold_loop_tiny(ref, G):
     np.savez_compressed(os.path.join(OUT, "loop_tiny.npz"), latent_mean=latent_mean.numpy(),
                         latent_std=np.float32(latent_std.item()), target=target.numpy(), eps=eps,
                         lm_target=lm_target, lm_steps=lm_steps, losses=losses, best_latent=best.numpy(),
-                        best_step=np.int64(best_step), best_loss=np.float64(min_loss))
+                        best_step=np.int64(best_step), best_loss=np.float64(min_loss), sigmas=np.array(sigmas, np.float64),
+                        latents_n=np.stack(latents_n))
 
 
 def gold_generator_full(ref):
@@ -274,6 +277,26 @@ def gold_att_tiny(ref):
     img, att = G(z, None, noise_mode="const", return_att=True)
     np.savez_compressed(os.path.join(OUT, "att_tiny.npz"), z=z.numpy(), shape=np.array(att.shape), att_sub=att[:, :, :, 0, 3::8, 5::8].numpy())
     print("att_tiny", tuple(att.shape))
+
+
+def gold_wplus_tiny(ref):
+    """Boundary fixture for Generator.forward's less-travelled arguments (networks.py:1304-1331) on the tiny generator:
+    distinct per-layer latents through `ws=`, truncation with a cutoff (mapping, :935-941), and the return_att tensor."""
+    from morphganformer_amd.synth_weights import TINY, make_state_dict, synthetic_latents
+    G = build_reference_generator(ref, TINY, make_state_dict(TINY, seed=0))
+    z = torch.from_numpy(synthetic_latents(TINY, 2, seed=1000))
+    rng = np.random.Generator(np.random.PCG64(4242))
+    ws0 = G(z, None, noise_mode="const", subnet="mapping")
+    ws = (ws0 + torch.from_numpy(rng.standard_normal(tuple(ws0.shape)).astype(np.float32)) * 0.5 * ws0.std()).contiguous()
+    assert float((ws - ws[:, :, :1]).abs().max()) > 0
+    img_ws, att_ws = G(ws=ws, noise_mode="const", return_att=True)
+    img_cut, ws_cut = G(z, None, truncation_psi=0.6, truncation_cutoff=5, noise_mode="const", return_ws=True)
+    img_psi, ws_psi = G(z, None, truncation_psi=0.6, noise_mode="const", return_ws=True)
+    np.savez_compressed(os.path.join(OUT, "wplus_tiny.npz"), z=z.numpy(), ws=ws.numpy(), img_ws=img_ws.numpy(),
+                        att_shape=np.array(att_ws.shape), att_sub=att_ws[:, :, :, 0, 3::8, 5::8].numpy(),
+                        img_cut=img_cut.numpy(), ws_cut=ws_cut.numpy(), img_psi=img_psi.numpy(), ws_psi=ws_psi.numpy(),
+                        img_synthesis_subnet=G(ws=ws, noise_mode="const", subnet="synthesis").numpy())
+    print("wplus_tiny", tuple(att_ws.shape))
 
 
 def grad_full_target(res=1024):
@@ -318,10 +341,12 @@ def gold_config0_256(ref):
     latent_in = latent_mean[None].clone()
     min_loss, best, best_step = 100.0, None, -1
     losses = np.zeros(steps, np.float64)
+    sigmas, latents_n = [], []
     for i in range(steps):
         t = i / steps
         sigma = latent_std * 0.05 * max(0, 1 - t / 0.75) ** 2
         latent_n = latent_in + torch.from_numpy(eps[i]) * sigma.item()
+        sigmas.append(sigma.item()); latents_n.append(latent_n.numpy().copy())
         img = G(latent_n, 0.7, noise_mode="const")[0]
         total = 1.0 * mse(img, target)
         losses[i] = float(total)
@@ -329,7 +354,8 @@ def gold_config0_256(ref):
             min_loss, best, best_step = float(total), latent_n.clone(), i
     np.savez_compressed(os.path.join(OUT, "loop_config0_256.npz"), latent_mean=latent_mean.numpy(),
                         latent_std=np.float32(latent_std.item()), target_u8=target_u8.numpy(), eps=eps, losses=losses,
-                        best_latent=best.numpy(), best_step=np.int64(best_step), best_loss=np.float64(min_loss))
+                        best_latent=best.numpy(), best_step=np.int64(best_step), best_loss=np.float64(min_loss),
+                        sigmas=np.array(sigmas, np.float64), latents_n=np.stack(latents_n))
 
 
 def gold_morph_tiny(ref, G):
@@ -400,18 +426,145 @@ def gold_lin_heads():
         np.savez_compressed(os.path.join(OUT, f"lpips_lin_{net}.npz"), **arrs)
 
 
+def import_reference_lpips():
+    """Import the reference's `lpips` package.  Its modules import three absent third-party packages at module scope
+    (skimage: lpips/__init__.py:7, networks_basic.py:11, dist_model.py:16; IPython: networks_basic.py:12 ...; torchvision:
+    pretrained_networks.py:3) -> IMPORT-ONLY stub modules, exactly like termcolor/seaborn above: they define the imported names and
+    nothing else, and none of them is ever called (the torchvision backbones are never constructed here)."""
+    sys.path.insert(0, REF)
+
+    def stub(name, **attrs):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+        return sys.modules[name]
+
+    def absent(*a, **k):
+        raise RuntimeError("import-only stub: this third-party function is not available offline")
+
+    sk = stub("skimage")
+    sk.measure = stub("skimage.measure", compare_ssim=absent)
+    sk.color = stub("skimage.color")
+    sk.transform = stub("skimage.transform")
+    stub("IPython", embed=absent)
+    tvm = stub("torchvision")
+    tvm.models = stub("torchvision.models")
+    import lpips
+    from lpips import networks_basic
+    return lpips, networks_basic
+
+
+class _TapSource(torch.nn.Module):
+    """Stands where PNetLin keeps its torchvision backbone (`self.net`, networks_basic.py:52): returns pre-computed tap tensors, keyed by
+    the identity of the (scaled) input, so that the reference's PNetLin.forward runs verbatim on injected feature maps."""
+
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        return self.fn(x)
+
+
+def _reference_pnetlin(nb, net, feat_fn):
+    """A reference PNetLin (networks_basic.py:26-92) with the vendored lin heads loaded the way DistModel.initialize does
+    (dist_model.py:63-75: use_dropout=True, load_state_dict(strict=False), eval) and `feat_fn` in place of the torchvision
+    backbone.  PNetLin.__init__ would construct tv.<net>(pretrained=...) -- absent offline -- so the attributes its forward reads
+    are set here to the values __init__ gives them (:29-62); forward, ScalingLayer, NetLinLayer are the reference's own code."""
+    chns = {"squeeze": [64, 128, 256, 384, 384, 512, 512], "vgg": [64, 128, 256, 512, 512], "alex": [64, 192, 384, 256, 256]}[net]
+    m = nb.PNetLin.__new__(nb.PNetLin)
+    torch.nn.Module.__init__(m)
+    m.pnet_type, m.pnet_tune, m.pnet_rand, m.spatial, m.lpips, m.version = net, False, False, False, True, "0.1"
+    m.scaling_layer = nb.ScalingLayer()
+    m.chns, m.L = chns, len(chns)
+    m.net = _TapSource(feat_fn)
+    m.lins = []
+    for i, c in enumerate(chns):
+        lin = nb.NetLinLayer(c, use_dropout=True)
+        setattr(m, f"lin{i}", lin)
+        m.lins.append(lin)
+    state = torch.load(os.path.join(REF, "lpips", "weights", "v0.1", net + ".pth"), map_location="cpu")
+    missing, unexpected = m.load_state_dict(state, strict=False)
+    assert not unexpected and not [k for k in missing if k.startswith("lin")], (missing, unexpected)
+    return m.eval()
+
+
+def gold_lpips_dist():
+    """LPIPS distance half run through the REFERENCE's own code (lpips/networks_basic.py:64-111, lpips/__init__.py:44-46):
+      (1) per net in {squeeze, vgg, alex}: seeded tap tensors (one pair per tap, the net's channel counts) -> reference
+          normalize_tensor, squared difference, NetLinLayer (vendored weights, eval => dropout is identity), spatial_average, sum:
+          `PNetLin.forward(retPerLayer=True)` with the tap tensors standing where the backbone output would be;
+      (2) ScalingLayer on a seeded image;
+      (3) squeeze: the whole PNetLin.forward on two seeded 64x64 images with the ORACLE's restated SqueezeNet1.1 topology + seeded
+          random weights as the injected backbone (the torchvision backbone itself stays unpinned)."""
+    lp, nb = import_reference_lpips()
+    from oracle.loss_ref import squeeze_backbone_random, squeeze_features_ref
+    rng = np.random.Generator(np.random.PCG64(314))
+    out = {}
+    sizes = {"squeeze": [(9, 9), (5, 5), (3, 3), (2, 2), (2, 2), (2, 2), (2, 2)], "vgg": [(8, 8), (4, 4), (4, 4), (2, 2), (2, 2)],
+             "alex": [(7, 7), (3, 3), (3, 3), (3, 3), (3, 3)]}
+    with torch.no_grad():
+        for net, hw in sizes.items():
+            chns = {"squeeze": [64, 128, 256, 384, 384, 512, 512], "vgg": [64, 128, 256, 512, 512], "alex": [64, 192, 384, 256, 256]}[net]
+            # post-ReLU-like taps: non-negative, some all-zero pixels (exercises the eps of normalize_tensor), n = 2 samples
+            t0 = [np.maximum(rng.standard_normal((2, c, h, w)), 0).astype(np.float32) for c, (h, w) in zip(chns, hw)]
+            t1 = [np.maximum(rng.standard_normal((2, c, h, w)), 0).astype(np.float32) for c, (h, w) in zip(chns, hw)]
+            for t in t0 + t1:
+                t[:, :, 0, 0] = 0
+            seq = iter([t0, t1])
+            m = _reference_pnetlin(nb, net, lambda x: [torch.from_numpy(a) for a in next(seq)])
+            img = torch.zeros(2, 3, 8, 8)
+            val, res = m.forward(img, img, retPerLayer=True)
+            for i in range(len(chns)):
+                out[f"{net}_tap0_{i}"], out[f"{net}_tap1_{i}"] = t0[i], t1[i]
+                out[f"{net}_res_{i}"] = res[i].numpy()
+            out[f"{net}_unit0_1"] = lp.normalize_tensor(torch.from_numpy(t0[1])).numpy()
+            out[f"{net}_val"] = val.numpy()
+        x = rng.uniform(-1, 1, (2, 3, 5, 7)).astype(np.float32)
+        out["scale_in"], out["scale_out"] = x, nb.ScalingLayer()(torch.from_numpy(x)).numpy()
+        # (3) full forward, oracle topology injected
+        bb = squeeze_backbone_random(0)
+        m = _reference_pnetlin(nb, "squeeze", lambda xs: squeeze_features_ref(bb, xs))
+        a = rng.uniform(-1, 1, (2, 3, 64, 64)).astype(np.float32)
+        b = np.clip(a + 0.3 * rng.standard_normal(a.shape), -1, 1).astype(np.float32)
+        val, res = m.forward(torch.from_numpy(a), torch.from_numpy(b), retPerLayer=True)
+        out["full_in0"], out["full_in1"], out["full_val"] = a, b, val.numpy()
+        out["full_res"] = np.stack([r.numpy().reshape(-1) for r in res])
+        # the module-level entry the drivers call: PerceptualLoss.forward -> DistModel.forward -> PNetLin.forward (lpips/__init__.py:26-41,
+        # dist_model.py:110-118), with normalize=True mapping [0,1] images to [-1,1]
+        pl = lp.PerceptualLoss.__new__(lp.PerceptualLoss)
+        torch.nn.Module.__init__(pl)
+        dm = lp.dist_model.DistModel()
+        dm.net = m
+        pl.model, pl.use_gpu, pl.spatial, pl.gpu_ids = dm, False, False, [0]
+        out["full_val_normalize"] = pl.forward(torch.from_numpy((a + 1) / 2), torch.from_numpy((b + 1) / 2), normalize=True).numpy()
+    np.savez_compressed(os.path.join(OUT, "lpips_dist.npz"), **out)
+    print("lpips_dist: full val", out["full_val"].reshape(-1))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.path.insert(0, ROOT)
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+    if only == ["lpips"]:
+        gold_lpips_dist()
+        return
     ref = import_reference()
     torch.manual_seed(0)
-    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     if only:
+        if "lpips" in only:
+            gold_lpips_dist()
         # regenerate a subset without touching the other fixtures
         if "config0" in only:
             gold_config0_256(ref)
+        if "loop" in only:
+            from morphganformer_amd.synth_weights import TINY, make_state_dict
+            gold_loop_tiny(ref, build_reference_generator(ref, TINY, make_state_dict(TINY, seed=0)))
         if "att" in only:
             gold_att_tiny(ref)
+        if "wplus" in only:
+            gold_wplus_tiny(ref)
         if "gradfull" in only:
             gold_grad_full(ref)
         if "iresnet" in only:
@@ -429,8 +582,10 @@ def main():
     gold_loop_tiny(ref, G)
     gold_morph_tiny(ref, G)
     gold_att_tiny(ref)
+    gold_wplus_tiny(ref)
     gold_config0_256(ref)
     gold_iresnet()
+    gold_lpips_dist()
     if "--no-full" not in sys.argv:
         gold_generator_full(ref)
         gold_grad_full(ref)

@@ -113,11 +113,54 @@ def test_generate_and_project_drivers_write_what_the_reference_writes(tmp_path):
     steps = 8
     lm_t, lm_s = synthetic_landmarks(steps, 64, 2)
     out = drivers.project_image(G, target, lm_t, lm_s, args=ProjectionArgs(step=steps, n_mean_latent=500), seed=0,
-                                out_prefix=str(tmp_path / "proj" / "face"), batch=2, noise_mode="const")
+                                out_prefix=str(tmp_path / "proj" / "face"), path_to_gen=str(tmp_path / "proj"), batch=3, noise_mode="random")
     assert out["w"].shape == (1, 17, 32) and 0 <= out["step"] < steps and out["loss"] == np.nanmin(out["losses"])
-    files = sorted(os.listdir(tmp_path / "proj"))
-    assert files[0].startswith("face-") and files[0].endswith(".png") and files[1] == "face.mat"
     assert np.array_equal(drivers.load_latent_mat(str(tmp_path / "proj" / "face.mat")), out["w"].numpy())
+    # the drivers write `{step:06d}_{loss:04f}.png` of the scored image at EVERY improvement (...sqz_MSE.py:186-195): one file per
+    # running-minimum step of the loss history, named with that step and loss
+    hist, best, want = out["losses"], 100.0, []
+    for i, v in enumerate(hist):
+        if v < best:
+            best = v
+            want.append("{:06d}_{:04f}.png".format(i, v))
+    pngs = sorted(f for f in os.listdir(tmp_path / "proj") if f.endswith(".png"))
+    assert pngs == sorted(want) and want[-1].startswith(f"{out['step']:06d}_")
+    assert np.asarray(Image.open(tmp_path / "proj" / want[-1])).shape == (64, 64, 3)
+
+
+def test_improvement_trail_keeps_the_scored_images(golden):
+    """keep_images: the image kept for every improvement is the candidate that was scored (bit-equal to a fresh const-noise rendering of
+    that step's latent), in improvement order; with fewer slots than improvements the last slot holds the final best."""
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    g = golden("loop_tiny.npz")
+    steps = 50
+    G = _tiny_G()
+
+    def make(keep, batch):
+        return ProjectionEngine(G, torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]),
+                                ProjectionArgs(step=steps), use_mse=True, lm_target=g["lm_target"], lm_steps=g["lm_steps"],
+                                eps=torch.from_numpy(g["eps"]).cuda(), noise_mode="const", batch=batch, keep_images=keep)
+    want, best = [], 100.0
+    for i, v in enumerate(g["losses"]):
+        if v < best:
+            best = v
+            want.append(i)
+    assert len(want) >= 3 and want[-1] == int(g["best_step"])
+    for batch in (1, 7):
+        eng = make(16, batch)
+        lat, bstep, bloss, losses = eng.run().result()
+        trail = eng.improvements()
+        assert [t[0] for t in trail] == want and trail[-1][1] == bloss
+        for step, loss, img in trail:
+            assert loss == losses[step]
+            fresh = G(torch.from_numpy(g["latents_n"][step]).cuda(), None, noise_mode="const")[0]
+            assert torch.equal(img, fresh[0])
+    # two slots, more improvements: first improvement in slot 0, the final best in slot 1 (also when several improve in one batch)
+    eng = make(2, 50)
+    eng.run()
+    trail = eng.improvements()
+    assert [t[0] for t in trail] == [want[0], want[-1]]
+    assert torch.equal(trail[1][2], G(torch.from_numpy(g["latents_n"][want[-1]]).cuda(), None, noise_mode="const")[0][0])
 
 
 def test_landmark_callback_mode_equals_injected_table(golden):
@@ -160,18 +203,28 @@ def test_cli_generate_project_morph(tmp_path):
     assert sorted(os.listdir(tmp_path / "g")) == ["sample_000000.png", "sample_000001.png"]
     lm_t, lm_s = synthetic_landmarks(6, 64, 1)
     np.savez(tmp_path / "lm.npz", target=lm_t, steps=lm_s)
+    import re
     for name in ("a", "b"):
         Image.open(tmp_path / "g" / ("sample_000000.png" if name == "a" else "sample_000001.png")).save(tmp_path / f"{name}.png")
-        assert cli.main(["project", "--model", pkl, "--image", str(tmp_path / f"{name}.png"), "--landmarks", str(tmp_path / "lm.npz"),
-                         "--path_to_gen", str(tmp_path / "p"), "--size", "64", "--step", "6", "--n_mean_latent", "200",
-                         "--batch", "4", "--seed", "0"]) == 0
-    files = sorted(os.listdir(tmp_path / "p"))
-    assert [f for f in files if f.endswith(".mat")] == ["a.mat", "b.mat"] and len([f for f in files if f.endswith(".png")]) == 2
-    assert cli.main(["morph", "--model", pkl, "--w1", str(tmp_path / "p" / "a.mat"), "--w2", str(tmp_path / "p" / "b.mat"),
+        argv = ["project", "--model", pkl, "--image", str(tmp_path / f"{name}.png"), "--landmarks", str(tmp_path / "lm.npz"),
+                "--path_to_gen", str(tmp_path / "p" / name), "--size", "64", "--step", "6", "--n_mean_latent", "200", "--batch", "4", "--seed", "0"]
+        with pytest.raises(SystemExit, match="lpips-backbone"):      # the LPIPS term needs real backbone weights unless opted out
+            cli.main(argv)
+        assert cli.main(argv + ["--lpips-random-backbone"]) == 0
+        files = sorted(os.listdir(tmp_path / "p" / name))
+        pngs = [f for f in files if f.endswith(".png")]
+        assert [f for f in files if f.endswith(".mat")] == [f"{name}.mat"] and len(pngs) >= 1
+        assert all(re.fullmatch(r"\d{6}_\d+\.\d{6}\.png", f) for f in pngs), pngs        # {:06d}_{:04f}.png (...sqz_MSE.py:193)
+    # a state-dict file of torchvision-keyed weights is accepted in place of the random backbone
+    from morphganformer_amd.lpips import random_squeeze_backbone
+    np.savez(tmp_path / "sq.npz", **random_squeeze_backbone(0))
+    assert cli.main(["project", "--model", pkl, "--image", str(tmp_path / "a.png"), "--path_to_gen", str(tmp_path / "p" / "c"), "--size", "64",
+                     "--step", "4", "--n_mean_latent", "200", "--batch", "2", "--seed", "0", "--lpips-backbone", str(tmp_path / "sq.npz")]) == 0
+    assert cli.main(["morph", "--model", pkl, "--w1", str(tmp_path / "p" / "a" / "a.mat"), "--w2", str(tmp_path / "p" / "b" / "b.mat"),
                      "--alphas", "0,0.5,1", "--out", str(tmp_path / "m" / "a+b")]) == 0
     assert len(os.listdir(tmp_path / "m")) == 6
     w = drivers.load_latent_mat(str(tmp_path / "m" / "a+b_a0.50.mat"))
-    assert np.array_equal(w, 0.5 * drivers.load_latent_mat(str(tmp_path / "p" / "a.mat")) + 0.5 * drivers.load_latent_mat(str(tmp_path / "p" / "b.mat")))
+    assert np.array_equal(w, 0.5 * drivers.load_latent_mat(str(tmp_path / "p" / "a" / "a.mat")) + 0.5 * drivers.load_latent_mat(str(tmp_path / "p" / "b" / "b.mat")))
 
 
 def test_project_many_shards_and_gathers(golden):

@@ -57,7 +57,7 @@ def test_tiny_attention_assignments(tiny, golden):
     G, sd, cfg = tiny
     g = golden("gen_tiny.npz")
     z = torch.from_numpy(g["z"]).cuda()
-    img, att = G(z, None, noise_mode="const", return_att=True)
+    img, att = G(z, None, noise_mode="const", return_att=True, att_format="maps")
     for key in ("b4.conv1", "b16.conv0", "b64.conv1"):
         probs, argmax = att["synthesis." + key]
         ref = g["probs_" + key]                      # [n, F, T]
@@ -120,11 +120,68 @@ def test_list2tensor_matches_reference(tiny, golden):
     """SynthesisNetwork.list2tensor (networks.py:1222-1242): stacked, nearest-neighbour upsampled attention maps of return_att=True."""
     G, sd, cfg = tiny
     g = golden("att_tiny.npz")
-    img, att = G(torch.from_numpy(g["z"]).cuda(), None, noise_mode="const", return_att=True)
-    t = G.list2tensor(att)
+    img, t = G(torch.from_numpy(g["z"]).cuda(), None, noise_mode="const", return_att=True)       # the reference's return contract
     assert tuple(t.shape) == tuple(g["shape"])
+    _img, att = G(torch.from_numpy(g["z"]).cuda(), None, noise_mode="const", return_att=True, att_format="maps")
+    assert torch.equal(G.list2tensor(att), t)
     assert np.abs(t[:, :, :, 0, 3::8, 5::8].cpu().numpy() - g["att_sub"]).max() < 1e-4
     # layer 0 is the 4x4 map: constant over 16x16 pixel blocks
     blk = t[:, :, 0, 0].reshape(2, cfg.k - 1, 4, 16, 4, 16)
     assert torch.equal(blk, blk[:, :, :, :1, :, :1].expand_as(blk))
     assert abs(float(t.sum(1).mean()) - 1.0) < 1e-5          # probabilities over the latent components
+
+
+def test_generator_forward_boundary_arguments_vs_reference(tiny, golden):
+    """Generator.forward(ws=per-layer latents), truncation_psi + truncation_cutoff, return_ws, subnet="synthesis" and the stacked
+    return_att tensor (networks.py:1304-1331, 935-941, 1252-1253) against the reference module (tests/golden/wplus_tiny.npz); plus
+    the ownership contract: results of two calls do not alias, and a call with another batch size leaves earlier workspaces intact."""
+    from morphganformer_amd import _lib
+    G, sd, cfg = tiny
+    g = golden("wplus_tiny.npz")
+    z, ws = torch.from_numpy(g["z"]).cuda(), torch.from_numpy(g["ws"]).cuda()
+    img, att = G(ws=ws, noise_mode="const", return_att=True)
+    assert rel(img, g["img_ws"]) < PIX_TOL
+    assert tuple(att.shape) == tuple(g["att_shape"]) and np.abs(att[:, :, :, 0, 3::8, 5::8].cpu().numpy() - g["att_sub"]).max() < 1e-4
+    assert rel(G(ws=ws, noise_mode="const", subnet="synthesis"), g["img_synthesis_subnet"]) < PIX_TOL
+    # a broadcast ws is the ordinary path: same pixels as z
+    gt = golden("gen_tiny.npz")
+    wsb = G(torch.from_numpy(gt["z"]).cuda(), None, subnet="mapping")
+    assert rel(G(ws=wsb, noise_mode="const")[0], gt["img_const"]) < PIX_TOL
+    for psi, cut, kimg, kws in ((0.6, 5, "img_cut", "ws_cut"), (0.6, None, "img_psi", "ws_psi")):
+        im, wso = G(z, None, truncation_psi=psi, truncation_cutoff=cut, noise_mode="const", return_ws=True)
+        assert tuple(wso.shape) == g[kws].shape and rel(wso, g[kws]) < 1e-5, kws
+        assert rel(im, g[kimg]) < PIX_TOL, kimg
+        assert rel(G.mapping(z, psi, cut), g[kws]) < 1e-5
+    with pytest.raises(_lib.MgfError):
+        G(ws=ws[:, :, :3], noise_mode="const")                   # wrong number of layer slots: refuse, never guess
+    # ownership: the reference returns fresh tensors
+    a = G(z[:1], None, noise_mode="const")[0]
+    keep = a.clone()
+    b = G(z[1:], None, noise_mode="const")[0]
+    assert a.data_ptr() != b.data_ptr() and torch.equal(a, keep) and not torch.equal(a, b)
+    # workspaces are per batch size and survive calls with other sizes (hipGraphs of the engines hold their pointers)
+    p2 = G.forward_workspace(z, None, noise_mode="const")[0].data_ptr()
+    G(z[:1], None, noise_mode="const")
+    assert G.forward_workspace(z, None, noise_mode="const")[0].data_ptr() == p2
+
+
+def test_graph_replay_survives_other_batch_sizes(golden):
+    """eng.run(k); G(w) with another batch size (the drivers render a preview at every improvement); eng.run(k) -- the captured graph
+    keeps running on its own workspace and the run equals an undisturbed one."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    g = golden("loop_tiny.npz")
+    res = []
+    for disturb in (False, True):
+        G = Generator(make_state_dict(TINY, seed=0), TINY, "cuda", max_batch=1)
+        eng = ProjectionEngine(G, torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]),
+                               ProjectionArgs(step=48), use_mse=True, lm_target=g["lm_target"], lm_steps=g["lm_steps"],
+                               eps=torch.from_numpy(g["eps"]).cuda(), noise_mode="const", batch=4, use_graph=True)
+        eng.run(24)
+        if disturb:
+            junk = [G(torch.randn(n, TINY.k, TINY.z_dim, device="cuda"), None, noise_mode="const")[0] for n in (1, 7, 2)]
+            assert G._pins.get(4) == 1
+        eng.run(24)
+        res.append(eng.result())
+    assert res[0][1] == res[1][1] and torch.equal(res[0][0], res[1][0]) and np.array_equal(res[0][3], res[1][3])

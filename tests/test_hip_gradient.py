@@ -180,7 +180,7 @@ def test_lpips_gradient_matches_autograd(net, size):
     lins = [torch.from_numpy(lin[f"lin{i}"]).float().reshape(-1) for i in range(len(lin.files))]
     val = lpips_ref(bb, lins, pred, target.expand(n, -1, -1, -1), net=net)
     (ref,) = torch.autograd.grad(val.sum() * 0.7, pred)
-    pl = PerceptualLoss(net=net)
+    pl = PerceptualLoss(net=net, allow_random_backbone=True)
     pl.set_target(target.cuda())
     out = torch.empty(n, device="cuda")
     pl.distance_into(out, pred.detach().cuda(), keep_taps=True)
@@ -244,7 +244,7 @@ def test_gradient_projection_matches_autograd_adam(tiny, use_graph):
 
     ref = projection_gradient_ref(lambda z: generator_ref(tsd, z, cfg, "const"), loss_fn, latent_mean, 1.0, eps, steps, lr=args.lr,
                                   rampdown=args.lr_rampdown, rampup=args.lr_rampup)
-    pl = PerceptualLoss(net="squeeze")
+    pl = PerceptualLoss(net="squeeze", allow_random_backbone=True)
     eng = GradientProjectionEngine(gg.G, target.cuda(), latent_mean.cuda(), 1.0, args, percept=pl, lm_target=lm_t, lm_steps=lm_s,
                                    lm_valid=valid, eps=eps.cuda(), noise_mode="const", use_graph=use_graph)
     traj = []
@@ -329,7 +329,7 @@ def test_gradient_projection_with_vgg_and_biometric_terms(tiny):
     target = G(torch.randn(1, cfg.k, cfg.z_dim, device="cuda"), None, noise_mode="const")[0].clamp(-1, 1).clone()
     lm_t, lm_s = synthetic_landmarks(steps, 64, 9)
     args = ProjectionArgs(step=steps, lr=0.05, lr_rampup=0.2, min_loss_init=1e30)
-    mk = lambda cls, **kw: cls(G, target, latent_mean, 1.0, args, percept=PerceptualLoss(net="vgg"), lm_target=lm_t, lm_steps=lm_s,
+    mk = lambda cls, **kw: cls(G, target, latent_mean, 1.0, args, percept=PerceptualLoss(net="vgg", allow_random_backbone=True), lm_target=lm_t, lm_steps=lm_s,
                                eps=eps, noise_mode="const", biometric=BiometricLoss(IResNetEmbedder(None, depth=18, n=1, device="cuda")),
                                gamma=1e-3, **kw)
     lit = mk(ProjectionEngine, batch=1, use_graph=False).run(1)
@@ -360,11 +360,11 @@ def test_gradient_projection_lockstep_targets_equal_single_runs(tiny):
     args = ProjectionArgs(step=steps, lr=0.05, lr_rampup=0.25)
     singles = []
     for j in range(B):
-        e = GradientProjectionEngine(G, targets[j:j + 1].contiguous(), latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze"),
+        e = GradientProjectionEngine(G, targets[j:j + 1].contiguous(), latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze", allow_random_backbone=True),
                                      lm_target=lms[j][0], lm_steps=lms[j][1], lm_valid=valid[j], eps=eps[:, j:j + 1].contiguous(),
                                      noise_mode="const", use_graph=False).run()
         singles.append((e.result(), e.latent_in.cpu().clone()))
-    multi = GradientProjectionEngine(G, targets, latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze"),
+    multi = GradientProjectionEngine(G, targets, latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze", allow_random_backbone=True),
                                      lm_target=np.stack([l[0] for l in lms]), lm_steps=np.stack([l[1] for l in lms]), lm_valid=valid,
                                      eps=eps, noise_mode="const", use_graph=True).run()
     lat, bstep, bloss, losses = multi.result()
@@ -395,11 +395,11 @@ def test_lockstep_targets_with_the_biometric_term(tiny):
     args = ProjectionArgs(step=steps, lr=0.05, lr_rampup=0.25, min_loss_init=1e30)
     firsts = []
     for j in range(B):
-        e = GradientProjectionEngine(G, targets[j:j + 1].contiguous(), latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze"),
+        e = GradientProjectionEngine(G, targets[j:j + 1].contiguous(), latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze", allow_random_backbone=True),
                                      lm_target=lms[j][0], lm_steps=lms[j][1], eps=eps[:, j:j + 1].contiguous(), noise_mode="const", use_graph=False,
                                      biometric=BiometricLoss(IResNetEmbedder(None, depth=18, n=1, device="cuda")), gamma=1e-3).run(2)
         firsts.append(e.losses.cpu().numpy()[:2])
-    multi = GradientProjectionEngine(G, targets, latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze"),
+    multi = GradientProjectionEngine(G, targets, latent_mean, 1.0, args, percept=PerceptualLoss(net="squeeze", allow_random_backbone=True),
                                      lm_target=np.stack([l[0] for l in lms]), lm_steps=np.stack([l[1] for l in lms]), eps=eps,
                                      noise_mode="const", use_graph=True,
                                      biometric=BiometricLoss(IResNetEmbedder(None, depth=18, n=B, device="cuda")), gamma=1e-3).run(2)

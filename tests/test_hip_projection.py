@@ -240,7 +240,7 @@ def test_full_size_loop_properties():
     lm_t, lm_s = synthetic_landmarks(steps, 1024, 7)
     hist = []
     for _ in range(2):
-        P = PerceptualLoss(net="squeeze")
+        P = PerceptualLoss(net="squeeze", allow_random_backbone=True)
         eng = ProjectionEngine(G, target, mean, std, ProjectionArgs(step=steps), percept=P, lm_target=lm_t, lm_steps=lm_s,
                                noise_mode="const", seed=5, use_graph=True)
         lat, bstep, bloss, losses = eng.run().result()
@@ -264,7 +264,7 @@ def test_percept_mse_objective_variant(golden):
     G = Generator(make_state_dict(TINY, seed=0), TINY, "cuda", max_batch=1)
     steps = 4
     tgt = torch.from_numpy(g["target"]).cuda()
-    P = PerceptualLoss(model="net-lin", net="vgg", use_gpu=True)
+    P = PerceptualLoss(model="net-lin", net="vgg", use_gpu=True, allow_random_backbone=True)
     eng = ProjectionEngine(G, tgt, torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]),
                            ProjectionArgs(step=steps, percept_weight=0.5, beta=0.5), percept=P, use_mse=True,
                            eps=torch.from_numpy(g["eps"][:steps]).cuda(), noise_mode="const", batch=2)
@@ -317,3 +317,140 @@ def test_pipelined_mode_equals_plain_loop(golden, use_graph):
     lat2, bstep2, bloss2, losses2 = eng2.result()
     assert bstep2 == bstep == int(g["best_step"]) and torch.equal(lat2, lat) and bloss2 == bloss
     assert np.array_equal(losses2, losses)
+
+
+LPIPS_CHNS = {"squeeze": [64, 128, 256, 384, 384, 512, 512], "vgg": [64, 128, 256, 512, 512], "alex": [64, 192, 384, 256, 256]}
+
+
+def test_lpips_distance_half_vs_reference_fixture(golden):
+    """tests/golden/lpips_dist.npz = the REFERENCE's own lpips code (PNetLin.forward, ScalingLayer, NetLinLayer with the vendored weights,
+    normalize_tensor, spatial_average: networks_basic.py:64-111, lpips/__init__.py:26-46) run on injected tap tensors.  The HIP
+    distance kernels (mgf_lpips_unit_f32 / mgf_lpips_layer_f32, the lin heads shipped in weights/) against those outputs, for all
+    three nets; then the whole PerceptualLoss.forward (HIP SqueezeNet backbone on seeded weights + HIP distance) against the
+    reference forward with the same backbone injected."""
+    from morphganformer_amd import _lib
+    from morphganformer_amd.lpips import PerceptualLoss, random_squeeze_backbone
+    g = golden("lpips_dist.npz")
+    L, st = _lib.lib(), _lib.stream_ptr()
+    scratch = torch.empty(2 * int(L.mgf_reduce_scratch_floats()), device="cuda")
+    for net, chns in LPIPS_CHNS.items():
+        P = PerceptualLoss(model="net-lin", net=net, use_gpu=True, allow_random_backbone=True)
+        ref_lin = golden(f"lpips_lin_{net}.npz")
+        out = torch.zeros(2, device="cuda")
+        per_layer = []
+        for i, c in enumerate(chns):
+            assert np.array_equal(P.lins[i].cpu().numpy(), ref_lin[f"lin{i}"])          # shipped heads == the reference's vendored data
+            a, b = torch.from_numpy(g[f"{net}_tap0_{i}"]).cuda(), torch.from_numpy(g[f"{net}_tap1_{i}"]).cuda()
+            n, _, h, w = a.shape
+            bu = torch.empty_like(b)
+            _lib.check(L.mgf_lpips_unit_f32(bu.data_ptr(), b.data_ptr(), n, c, h * w, st), "lpips_unit")
+            if i == 1:
+                au = torch.empty_like(a)
+                _lib.check(L.mgf_lpips_unit_f32(au.data_ptr(), a.data_ptr(), n, c, h * w, st), "lpips_unit")
+                assert float((au.cpu() - torch.from_numpy(g[f"{net}_unit0_1"])).abs().max()) < 2e-6
+                assert float(au[:, :, 0, 0].abs().max()) == 0.0                          # all-zero pixel: 0 / (0 + 1e-10)
+            one = torch.zeros(2, device="cuda")
+            _lib.check(L.mgf_lpips_layer_f32(one.data_ptr(), a.data_ptr(), bu.data_ptr(), P.lins[i].data_ptr(), n, c, h * w, c * h * w, 0,
+                                             scratch.data_ptr(), st), "lpips_layer")
+            _lib.check(L.mgf_lpips_layer_f32(out.data_ptr(), a.data_ptr(), bu.data_ptr(), P.lins[i].data_ptr(), n, c, h * w, c * h * w, 1,
+                                             scratch.data_ptr(), st), "lpips_layer")
+            per_layer.append(one.cpu().numpy())
+            if i > 0:        # (the reference's res[0] is aliased to the running total: networks_basic.py:85-87)
+                want = g[f"{net}_res_{i}"].reshape(-1)
+                assert np.abs(per_layer[-1] - want).max() < 1e-5 * np.abs(want).max(), (net, i)
+        want = g[f"{net}_val"].reshape(-1)
+        assert np.abs(out.cpu().numpy() - want).max() < 1e-5 * np.abs(want).max(), net
+    P = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, backbone_state=random_squeeze_backbone(0))
+    a, b = torch.from_numpy(g["full_in0"]).cuda(), torch.from_numpy(g["full_in1"]).cuda()
+    got = P(a, b).cpu().numpy()
+    assert got.shape == g["full_val"].shape and np.abs(got - g["full_val"]).max() < 1e-3 * np.abs(g["full_val"]).max()
+    got = P((a + 1) / 2, (b + 1) / 2, normalize=True).cpu().numpy()
+    assert np.abs(got - g["full_val_normalize"]).max() < 1e-3 * np.abs(g["full_val_normalize"]).max()
+
+
+def _config3_objective(G, target, cfg, steps, batch, lm, eps, mean, std, depth=18, gamma=1e-4, noise_mode="const", seed=0):
+    """BASELINE config 3's objective: Wing + IResNet embedding MSE + LPIPS(squeeze) + MSE."""
+    from morphganformer_amd.iresnet import BiometricLoss, IResNetEmbedder, random_state
+    from morphganformer_amd.lpips import PerceptualLoss, random_squeeze_backbone
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    bio_sd = random_state(depth, 1)
+    P = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, backbone_state=random_squeeze_backbone(0))
+    bio = BiometricLoss(IResNetEmbedder(bio_sd, depth=depth, n=batch))
+    eng = ProjectionEngine(G, target, mean, std, ProjectionArgs(step=steps, min_loss_init=1e30), percept=P, use_mse=True, lm_target=lm[0],
+                           lm_steps=lm[1], eps=eps, noise_mode=noise_mode, batch=batch, biometric=bio, gamma=gamma, seed=seed)
+    return eng, bio_sd
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_config3_four_term_objective_vs_oracle(golden, batch):
+    """Config 3 of BASELINE.json (Wing + biometric + LPIPS + MSE) on the tiny generator against the CPU oracle's literal loop with the
+    same four terms: best step exact, best latent bit-exact, every loss of the history to 1e-3 (sequential and batched steps)."""
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from oracle.embed_ref import biometric_loss_ref
+    from oracle.generator_ref import generator_ref, to_torch_state
+    from oracle.loss_ref import lpips_ref, mse_ref, projection_literal_ref, squeeze_backbone_random, wing_loss_ref
+    g = golden("loop_tiny.npz")
+    steps, gamma = 8, 1e-4
+    sd = make_state_dict(TINY, seed=0)
+    tsd = to_torch_state(sd)
+    G = _tiny_gen()
+    target = torch.from_numpy(g["target"])
+    mean, std = torch.from_numpy(g["latent_mean"]), float(g["latent_std"])
+    eps = torch.from_numpy(g["eps"][:steps])
+    lm = (g["lm_target"], g["lm_steps"][:steps])
+    eng, bio_sd = _config3_objective(G, target.cuda(), TINY, steps, batch, lm, eps.cuda(), mean.cuda(), std, gamma=gamma)
+    lat, bstep, bloss, losses = eng.run().result()
+    bb = squeeze_backbone_random(0)
+    lin = golden("lpips_lin_squeeze.npz")
+    lins = [torch.from_numpy(lin[f"lin{i}"]) for i in range(7)]
+    bsd = {k: torch.from_numpy(v) for k, v in bio_sd.items()}
+
+    def loss_fn(i, img):
+        with torch.no_grad():
+            p = float(lpips_ref(bb, lins, img, target).sum())
+            w = float(wing_loss_ref(torch.from_numpy(lm[1][i]), torch.from_numpy(lm[0])))
+            b = float(biometric_loss_ref(bsd, img, target, 18))
+            return p + gamma * b + 0.01 * w + 1.0 * float(mse_ref(img, target))
+
+    with torch.no_grad():
+        ref = projection_literal_ref(lambda z: generator_ref(tsd, z, TINY, "const"), loss_fn, mean, std, eps, steps, min_loss_init=1e30)
+    want = np.array(ref[3], np.float64)
+    assert np.abs(losses - want).max() < 1e-3 * np.abs(want).max(), (losses, want)
+    assert bstep == ref[1]
+    assert torch.equal(lat, ref[0]), "best latent must be bit-exact under injected noise"
+    assert abs(bloss - ref[2]) < 1e-3 * abs(ref[2])
+
+
+def test_config3_full_size_properties():
+    """Config 3's four-term objective at the full 1024^2 size, IResNet-50 embedder: size-independent properties of a 12-step run --
+    best loss == min of the history, best step == argmin, reproducible history, the selected latent is mean + eps*sigma, and the
+    biometric term really is in the total (history minus the three-term history is positive and equals gamma * the embedding MSE)."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.lpips import PerceptualLoss, random_squeeze_backbone
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, latent_stats, synthetic_landmarks
+    from morphganformer_amd.synth_weights import FULL1024, make_state_dict, synthetic_latents
+    G = Generator(make_state_dict(FULL1024, seed=0), FULL1024, "cuda", max_batch=1)
+    target = G(torch.from_numpy(synthetic_latents(FULL1024, 1, 1000)).cuda(), None, noise_mode="const")[0].clamp(-1, 1).clone()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    mean, std = latent_stats(G, 10000, "cuda", gen)
+    steps, batch, gamma = 12, 4, 1e-6
+    lm = synthetic_landmarks(steps, 1024, 7)
+    gen.manual_seed(5)
+    eps = torch.randn(steps, 1, FULL1024.k, FULL1024.z_dim, device="cuda", generator=gen)
+    hist = []
+    for _ in range(2):
+        eng, _sd = _config3_objective(G, target, FULL1024, steps, batch, lm, eps, mean, std, depth=50, gamma=gamma)
+        lat, bstep, bloss, losses = eng.run().result()
+        hist.append(losses)
+        assert not np.isnan(losses).any()
+        assert bstep == int(np.argmin(losses)) and bloss == float(losses.min())
+    assert np.array_equal(hist[0], hist[1])
+    assert torch.equal(lat.cuda(), eng.latent_in + eng.eps[bstep] * eng.sigma[bstep])
+    P = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, backbone_state=random_squeeze_backbone(0))
+    three = ProjectionEngine(G, target, mean, std, ProjectionArgs(step=steps, min_loss_init=1e30), percept=P, lm_target=lm[0], lm_steps=lm[1],
+                             eps=eps, noise_mode="const", batch=batch).run().result()[3]
+    extra = hist[0] - three
+    assert (extra > 0).all()
+    img = G((eng.latent_in + eng.eps[bstep] * eng.sigma[bstep]), None, noise_mode="const")[0]
+    want = gamma * float(eng.biometric(img[:1], target))
+    assert abs(extra[bstep] - want) < 1e-3 * want + 1e-6 * abs(hist[0][bstep]), (extra[bstep], want)

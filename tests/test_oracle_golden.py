@@ -239,3 +239,83 @@ def test_winograd_f2x2_3x3_identity():
         y = At @ ((G @ g @ G.T) * (Bt @ d @ Bt.T)) @ At.T
         ref = np.array([[(g * d[i:i + 3, j:j + 3]).sum() for j in range(2)] for i in range(2)])
         assert np.abs(y - ref).max() < 1e-12
+
+
+LPIPS_CHNS = {"squeeze": [64, 128, 256, 384, 384, 512, 512], "vgg": [64, 128, 256, 512, 512], "alex": [64, 192, 384, 256, 256]}
+
+
+def test_lpips_distance_half_vs_reference(golden):
+    """tests/golden/lpips_dist.npz holds outputs of the reference's own lpips code (networks_basic.py:64-111 PNetLin.forward,
+    ScalingLayer, NetLinLayer with the vendored weights, lpips/__init__.py:26-46) on injected tap tensors: the oracle's distance
+    half, its ScalingLayer and the whole lpips_ref (restated SqueezeNet topology, same seeded weights) must reproduce them."""
+    g = golden("lpips_dist.npz")
+    for net, chns in LPIPS_CHNS.items():
+        lin = golden(f"lpips_lin_{net}.npz")
+        lins = [torch.from_numpy(lin[f"lin{i}"]) for i in range(len(chns))]
+        t0 = [torch.from_numpy(g[f"{net}_tap0_{i}"]) for i in range(len(chns))]
+        t1 = [torch.from_numpy(g[f"{net}_tap1_{i}"]) for i in range(len(chns))]
+        assert [t.shape[1] for t in t0] == chns
+        total, vals = loss_ref.lpips_distance_ref(t0, t1, lins, per_layer=True)
+        # reference quirk: `val = res[0]; val += res[l]` (networks_basic.py:85-87) accumulates IN PLACE, so the res[0] that
+        # retPerLayer=True hands back is the total, not tap 0's term
+        assert np.array_equal(g[f"{net}_res_0"], g[f"{net}_val"])
+        for i, v in enumerate(vals):
+            if i > 0:
+                assert tuple(v.shape) == g[f"{net}_res_{i}"].shape and rel(v, g[f"{net}_res_{i}"]) < TOL, (net, i)
+        assert rel(total, g[f"{net}_val"]) < TOL, net
+        rest = sum(g[f"{net}_res_{i}"].astype(np.float64) for i in range(1, len(chns)))
+        assert np.abs(vals[0].numpy() - (g[f"{net}_val"] - rest)).max() < 1e-6 * np.abs(g[f"{net}_val"]).max(), net
+        assert rel(loss_ref.normalize_tensor_ref(t0[1]), g[f"{net}_unit0_1"]) < TOL
+        assert float(loss_ref.normalize_tensor_ref(t0[1])[:, :, 0, 0].abs().max()) == 0.0        # all-zero pixel: 0 / (0 + eps)
+    assert rel(loss_ref.scaling_layer_ref(torch.from_numpy(g["scale_in"])), g["scale_out"]) < TOL
+    lin = golden("lpips_lin_squeeze.npz")
+    lins = [torch.from_numpy(lin[f"lin{i}"]) for i in range(7)]
+    bb = loss_ref.squeeze_backbone_random(0)
+    a, b = torch.from_numpy(g["full_in0"]), torch.from_numpy(g["full_in1"])
+    total, vals = loss_ref.lpips_ref(bb, lins, a, b, per_layer=True)
+    assert tuple(total.shape) == (2, 1, 1, 1) and rel(total, g["full_val"]) < TOL
+    assert rel(torch.stack([v.reshape(-1) for v in vals[1:]]), g["full_res"][1:]) < TOL and np.array_equal(g["full_res"][0], g["full_val"].reshape(-1))
+    # PerceptualLoss.forward(normalize=True) maps [0,1] inputs to [-1,1] first (lpips/__init__.py:36-38)
+    assert rel(loss_ref.lpips_ref(bb, lins, 2 * ((a + 1) / 2) - 1, 2 * ((b + 1) / 2) - 1), g["full_val_normalize"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["loop_tiny.npz", "loop_config0_256.npz"])
+def test_every_step_sigma_and_latent_vs_reference_run(golden, name):
+    """All 50 noise strengths and all 50 perturbed latents of the reference-driven runs (not only the selected step): the
+    oracle's schedule and the package's host-side schedule table reproduce `latent_std * noise * ramp` (float32 tensor x python
+    scalars, ...sqz_MSE.py:156) and `latent_in + randn * strength` (:71-73,157) bit for bit."""
+    from morphganformer_amd.projection import noise_schedule
+    g = golden(name)
+    steps = g["eps"].shape[0]
+    sig_pkg = noise_schedule(steps, float(g["latent_std"]), 0.05, 0.75)
+    assert sig_pkg.dtype == np.float32
+    mean = torch.from_numpy(g["latent_mean"])[None]
+    for i in range(steps):
+        s = loss_ref.noise_strength_ref(i / steps, float(g["latent_std"]))
+        assert s == float(g["sigmas"][i]) and float(sig_pkg[i]) == float(g["sigmas"][i]), i
+        lat = mean + torch.from_numpy(g["eps"][i]) * s
+        assert np.array_equal(lat.numpy(), g["latents_n"][i]), i
+        # the device kernel multiplies float32 eps by the float32 table entry and adds with two roundings: same numbers
+        lat32 = (g["latent_mean"][None] + g["eps"][i] * sig_pkg[i]).astype(np.float32)
+        assert np.array_equal(lat32, g["latents_n"][i]), i
+
+
+def test_per_layer_ws_truncation_cutoff_and_att_tensor_vs_reference(golden):
+    """Generator.forward's W+ / truncation_cutoff / return_att paths (networks.py:1304-1331, 935-941, 1222-1262) of the restatement
+    against the reference module's outputs (tests/golden/wplus_tiny.npz)."""
+    from oracle.generator_ref import list2tensor_ref, synthesis_ref, truncate_ref
+    g = golden("wplus_tiny.npz")
+    sd = to_torch_state(make_state_dict(TINY, 0))
+    z, ws = torch.from_numpy(g["z"]), torch.from_numpy(g["ws"])
+    taps = {}
+    img = synthesis_ref(sd, ws, TINY, "const", taps=taps)
+    assert rel(img, g["img_ws"]) < 1e-5 and rel(img, g["img_synthesis_subnet"]) < 1e-5
+    order = [f"synthesis.b{res}.{name}" for res, name, *_rest, att, _nb in TINY.layer_table() if att]
+    att = list2tensor_ref([taps[k + ":probs"] for k in order], TINY)
+    assert tuple(att.shape) == tuple(g["att_shape"]) and rel(att[:, :, :, 0, 3::8, 5::8], g["att_sub"]) < 1e-5
+    w = mapping_ref(sd, z, TINY)
+    for psi, cut, kimg, kws in ((0.6, 5, "img_cut", "ws_cut"), (0.6, None, "img_psi", "ws_psi")):
+        wst = truncate_ref(sd, w, TINY, psi, cut)
+        assert rel(wst, g[kws]) < TOL
+        assert rel(generator_ref(sd, z, TINY, "const", truncation_psi=psi, truncation_cutoff=cut), g[kimg]) < 1e-5
+    assert float((torch.from_numpy(g["ws_cut"])[:, :, 5:] - w[:, :, None]).abs().max()) < 1e-6          # slots >= cutoff untouched

@@ -22,7 +22,7 @@ if B > 1:
     lm_t, lm_s = np.stack([lms[0]] * B), np.stack([lms[1][:total]] * B)
 else:
     lm_t, lm_s = lms[0], lms[1][:total]
-ge = GradientProjectionEngine(GB, target, latent_mean, latent_std, ProjectionArgs(step=total), percept=PerceptualLoss(net="squeeze", device=dev),
+ge = GradientProjectionEngine(GB, target, latent_mean, latent_std, ProjectionArgs(step=total), percept=PerceptualLoss(net="squeeze", device=dev, allow_random_backbone=True),
                               use_mse=True, lm_target=lm_t, lm_steps=lm_s, noise_mode="random", seed=5, use_graph=False)
 ge.run(2)
 torch.cuda.synchronize()

@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 from morphganformer_amd import _lib
 from morphganformer_amd.lpips import PerceptualLoss
 n = 8
-P = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True)
+P = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, allow_random_backbone=True)
 x = (torch.rand(n, 3, 1024, 1024, device="cuda") * 2 - 1)
 P.set_target(x[:1].contiguous())
 f = P._features(n, 1024, 1024)
