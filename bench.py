@@ -1,6 +1,7 @@
 """Benchmark of the hot path: latent-projection iterations/sec @1024^2, k=17 (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W           (N > 1 without a launcher: bench.py starts the N ranks itself, as
+                                                             children of a parent that never touches the GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workload (config 2 of BASELINE.json): one 1024x1024 synthetic target per GPU, literal-mode projection
@@ -10,6 +11,9 @@ In literal mode the loop's steps do not depend on each other (the latent never r
 engine evaluates `--batch` consecutive steps per generator forward and examines them in step order: the result (best step,
 best latent, loss history) is the sequential loop's, bit for bit (tests/test_hip_projection.py), and every step's full work --
 its own noise draws, forward, three losses, selection -- is inside the timed region.  `steps` counts loop steps, not launches.
+The engine works in whole launch sequences of `--batch` (25) steps, and one sequence takes ~0.05 s, so the timed region is K rounded up
+to whole sequences and extended to at least `--min-seconds` (1 s): the line's `steps` is the number of steps that were really timed
+(`ms_per_step` and `value` are computed from it), `steps_requested` echoes K.
 With `--pipeline 1` the losses + selection of one batch run on a second stream while the generator already synthesises the next
 batch (separate buffers; same results; 496 vs 480 iters/s): every timed replay still contains one full generator batch and one
 full loss batch, the one generator batch that is in flight ahead of the losses is produced during warm-up.  It is off by default
@@ -34,8 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
+np = torch = None          # imported in main(), AFTER the launcher decision: the parent of a self-launched N-rank run must not touch the GPU
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 _T0 = time.perf_counter()
@@ -59,9 +62,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", type=int, default=1024, help="debug only; the reported config is 1024")
-    ap.add_argument("--batch", type=int, default=0,
-                    help="loop steps evaluated per generator forward (exact in literal mode); 0 = pick 12..32 so that --steps is a whole "
-                         "number of forwards")
+    ap.add_argument("--batch", type=int, default=25,
+                    help="loop steps evaluated per generator forward (exact in literal mode).  Fixed (not derived from --steps) so that every "
+                         "run -- the driver's, the rocprofv3 trace, the PMC passes in profiles/ -- launches the same kernels on the same shapes")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="the timed region is extended to at least this long (whole forwards; the line reports the real step count in `steps` "
+                         "and the request in `steps_requested`): one graph replay is 0.05 s, too short to time")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
@@ -75,17 +81,9 @@ def parse():
                     help="steps of the extra gradient-mode leg (loss back-propagated into the latent, Adam; rank 0, N=1 only); 0 = skip")
     ap.add_argument("--gradient-lockstep", type=int, default=8, help="targets advanced in lockstep in the second half of the gradient-mode leg")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank (exercises the N>1 code path)")
+    ap.add_argument("--force-launch", action="store_true", help="self-launch through torch.distributed.run even for --gpus 1 (exercises the launcher)")
+    ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)      # CPU/gloo dry run of the launcher (tests/)
     return ap.parse_args()
-
-
-def auto_batch(steps):
-    """Steps per forward for a run of `steps` loop steps: the engine works in whole forwards, so a ragged last forward evaluates
-    candidates nobody counts.  Pick b in 12..32 minimising that waste, discounted by the measured efficiency of the batch size
-    (8: 0.94, 16: 1.00, 32: 1.01 of the 16-step rate on MI355X)."""
-    def cost(b):
-        eff = 1.0 - 0.0075 * max(0, 16 - b) + 0.01 * min(max(b - 16, 0), 16) / 16
-        return (-(-steps // b) * b) / steps / eff
-    return min(range(12, 33), key=cost)
 
 
 def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0, pipeline=False):
@@ -145,14 +143,15 @@ def roofline_leg(eng, iters=3):
     per_kernel = {k_: {"launches_per_iter": v[2] // iters, "avg_us": round(v[1] / v[2] * 1e6, 2), "tflops": round(v[0] / v[1] / 1e12, 2)}
                   for k_, v in agg.items()}
     total_conv_s = sum(v[1] for v in agg.values()) / iters
-    extra = {}
-    if dom.startswith("wino"):          # both Winograd instantiations
-        # the contract counts ALGORITHMIC FLOPs (the direct 3x3 form's); the Winograd kernel executes 16/36 of them on the matrix cores
-        extra = {"executed_mfma_frac": round(achieved * 16 / 36 / FP32_MFMA_PEAK_TFLOPS, 4),
-                 "note": "Winograd F(2x2,3x3): achieved/frac count the direct form's algorithmic FLOPs; the kernel issues 4/9 of them as MFMA work "
-                         "(executed_mfma_frac; cf. SQ_VALU_MFMA_BUSY_CYCLES in profiles/r1_pmc_mfma.txt)"}
+    # the contract counts ALGORITHMIC FLOPs (the direct 3x3 form's); a Winograd F(2x2,3x3) kernel executes 16/36 of them on the matrix
+    # cores.  executed_mfma_frac is what the MFMA pipes actually do -- the number to judge the kernel by; `frac` follows the contract.
+    executed = achieved * (16 / 36 if dom.startswith("wino") else 1.0)
+    extra = {"executed_mfma_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4)}
+    if dom.startswith("wino"):
+        extra["note"] = ("Winograd F(2x2,3x3): achieved/frac count the direct form's algorithmic FLOPs; the kernel issues 4/9 of them as MFMA "
+                         "work (executed_mfma_frac; cf. mfma_busy)")
     return {"bound": "mfma", "kernel": dom, **extra, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), **pmc_traffic(dom, eng),
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), **pmc_fields(dom, eng),
             "algorithmic_bytes_per_launch": round(nbytes / launches),
             "avg_launch_us": round(secs / launches * 1e6, 2), "launches_per_iter": launches // iters,
             "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
@@ -238,20 +237,49 @@ def gradient_leg(sd, cfg, device, eng, steps, lockstep=8):
                     "the reference loop severs this gradient, so the headline metric stays the literal loop"}
 
 
-def pmc_traffic(kernel, eng):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
-    this same workload, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled on gfx950, WRITE_SIZE as read; see
-    profiles/README.md).  Counters cannot be read from inside the process, so the figure is only reported when this run is
-    the configuration the passes were collected on (1024^2, same steps per forward as recorded in the file); otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if not (os.path.exists(path) and eng.G.cfg.img_resolution == 1024):
-        return {"traffic": None}
-    with open(path) as fh:
-        table = json.load(fh)
-    rec = table.get(kernel)
-    if rec is None or table.get("_meta", {}).get("steps_per_forward") != eng.batch:
-        return {"traffic": None}
-    return {"traffic": rec["hbm_bytes"], "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_traffic.json)"}
+def pmc_tables():
+    """The committed counter summaries of this workload (profiles/, newest round first): HBM-side bytes per launch and MFMA-pipe
+    utilisation per kernel.  Counters cannot be read from inside the process (rocprofv3 --pmc is a separate run, and gpurun forbids
+    mixing it with tracing), so bench.py reports the figures of the committed passes and says which file they come from."""
+    out = {"traffic": None, "mfma": None}
+    for rnd in ("r2", "r1"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+        if out["traffic"] is None and os.path.exists(path):
+            with open(path) as fh:
+                out["traffic"] = (f"profiles/{rnd}_pmc_traffic.json", json.load(fh))
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_mfma.json")
+        if out["mfma"] is None and os.path.exists(path):
+            with open(path) as fh:
+                out["mfma"] = (f"profiles/{rnd}_pmc_mfma.json", json.load(fh))
+    return out
+
+
+def pmc_fields(kernel, eng):
+    """`traffic` = HBM-side bytes per launch of `kernel` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this same
+    workload, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled on gfx950, WRITE_SIZE as read; profiles/README.md).
+    The passes are taken at `steps_per_forward` candidates per launch; for another count the bytes are scaled by the ratio (every
+    operand of these kernels except the weights -- < 1 % of the bytes -- is per candidate) and the line says so.
+    `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x SIMDs) of the same kernel from the committed MFMA pass."""
+    t = pmc_tables()
+    out = {"traffic": None}
+    if eng.G.cfg.img_resolution != 1024:
+        return out
+    if t["traffic"] is not None:
+        src, table = t["traffic"]
+        rec = table.get(kernel)
+        b0 = table.get("_meta", {}).get("steps_per_forward")
+        if rec is not None and b0:
+            scale = eng.batch / b0
+            out["traffic"] = round(rec["hbm_bytes"] * scale)
+            out["traffic_unit"] = f"bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, {src}, collected at {b0} steps per forward" + \
+                                  ("" if scale == 1 else f", scaled x{scale:.3f} to {eng.batch}") + ")"
+    if t["mfma"] is not None:
+        src, table = t["mfma"]
+        rec = table.get(kernel)
+        if rec is not None:
+            out["mfma_busy"] = rec["mfma_busy"]
+            out["mfma_busy_source"] = f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs), {src}"
+    return out
 
 
 def cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, iters):
@@ -288,12 +316,71 @@ def cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, iters):
                       f"{cores} threads; {per:.2f} s/iter"}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- `python -m torch.distributed.run` as a CHILD
+    process, from a parent that has made no GPU call (nothing here imports torch; re-exec'ing a process that initialised HIP is what
+    this pool forbids) -- pass rank 0's JSON line through, and fail if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MGF_BENCH_SELF_LAUNCHED="1")
+    argv = [x for x in sys.argv[1:] if x != "--force-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log(f"self-launch: {' '.join(cmd)}")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for line in proc.stdout:                       # rank 0 prints exactly one line on stdout; everything else goes to stderr
+        lines.append(line)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc != 0:
+        log(f"self-launch: torch.distributed.run exited with {rc}")
+        return rc
+    if not any(ln.lstrip().startswith("{") for ln in lines):
+        log("self-launch: no JSON line came back from rank 0")
+        return 1
+    return 0
+
+
+def launch_selftest(a):
+    """CPU dry run of the launcher path (tests/): every rank joins a gloo group, the ranks all_gather their ids, rank 0 prints a
+    line shaped like the real one.  MGF_SELFTEST_FAIL_RANK makes that rank exit non-zero (the parent must notice)."""
+    import torch as th
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if os.environ.get("MGF_SELFTEST_FAIL_RANK") == str(rank):
+        sys.exit(3)
+    got = [th.zeros(1, dtype=th.int64) for _ in range(world)]
+    dist.all_gather(got, th.tensor([rank]))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest", "n_gpus": world, "rccl_ranks": world, "ranks": [int(t) for t in got]}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     a = parse()
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not launched and (a.gpus > 1 or a.force_launch):
+        return self_launch(a)
+    if a.selftest_launch:
+        return launch_selftest(a)
+    global np, torch
+    import numpy as np
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or a.force_dist:
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} ranks")
+    rccl_ranks = None
+    if world > 1 or a.force_dist or os.environ.get("MGF_BENCH_SELF_LAUNCHED"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -303,30 +390,49 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     device = torch.device("cuda", local_rank if world > 1 else 0)
+    if dist is not None:
+        # one RCCL collective before anything is timed: every rank contributes its rank id; the count that comes back is what the line reports
+        ids = torch.empty(world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=device))
+        assert ids.tolist() == list(range(world)), ids.tolist()
+        rccl_ranks = dist.get_world_size()
     from morphganformer_amd.synth_weights import GeneratorConfig
     cfg = GeneratorConfig(img_resolution=a.res)
-    if a.batch <= 0:
-        a.batch = auto_batch(a.steps)
-    # the engine advances `batch` loop steps per launch sequence; K or W that are not multiples are rounded UP to whole
-    # launches (more work inside the timed region, never less) while the reported rate still counts exactly K steps
+    assert a.batch >= 1
+    # the engine advances `batch` loop steps per launch sequence: K and W are rounded UP to whole launches (more work inside the
+    # timed region, never less), and the line reports the number of steps that were really timed
     rup = lambda v: -(-v // a.batch) * a.batch
-    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, rup(a.steps) + rup(a.warmup) + a.batch, not a.no_graph, a.batch, a.biometric, bool(a.pipeline))
+    cap = max(rup(a.steps), 8192 if a.min_seconds > 0 else 0)            # room to extend the timed region to --min-seconds
+    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, cap + rup(a.warmup) + 3 * a.batch, not a.no_graph, a.batch,
+                                                                      a.biometric, bool(a.pipeline))
 
     log(f"built generator/LPIPS/engine on {device}; warm-up {a.warmup} steps (includes graph capture)")
     eng.run(a.warmup)
     torch.cuda.synchronize()
-    log("warm-up done; timing")
+    # calibration (part of the warm-up): one more launch sequence, timed, to size the timed region
+    t0 = time.perf_counter()
+    eng.run(a.batch)
+    torch.cuda.synchronize()
+    per_launch = time.perf_counter() - t0
+    steps = rup(a.steps)
+    if a.min_seconds > 0:
+        steps = min(max(steps, rup(int(a.min_seconds / per_launch * a.batch) + 1)), cap)
+    if dist is not None:                               # every rank times the same number of steps
+        t = torch.tensor([steps], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        steps = int(t.item())
+    log(f"warm-up done ({per_launch * 1e3:.1f} ms per launch sequence of {a.batch} steps); timing {steps} steps (requested {a.steps})")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    eng.run(a.steps)
+    eng.run(steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    log(f"timed {a.steps} steps in {elapsed:.3f} s ({a.batch} steps per forward, {torch.cuda.max_memory_allocated(device) / 2 ** 30:.1f} GiB of HBM in use)")
+    log(f"timed {steps} steps in {elapsed:.3f} s ({a.batch} steps per forward, {torch.cuda.max_memory_allocated(device) / 2 ** 30:.1f} GiB of HBM in use)")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -340,16 +446,17 @@ def main():
         eng.result()
 
     out = {
-        "metric": "latent-projection iters/sec @1024^2, k=17 latents", "value": round(world * a.steps / elapsed, 3),
-        "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "metric": "latent-projection iters/sec @1024^2, k=17 latents", "value": round(world * steps / elapsed, 3),
+        "unit": "iters/s", "n_gpus": world, "steps": steps, "steps_requested": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks, "timed_seconds": round(elapsed, 4),
         "config": {"workload": f"configs[1]: single {a.res}x{a.res} face per GPU, Wing+LPIPS(squeeze)+MSE literal-mode projection step, "
                                "noise_mode=random, seeded synthetic weights/targets/landmarks"
                                + (f" + IResNet-{a.biometric} embedding MSE (config 3 objective)" if a.biometric else ""), "k": cfg.k, "z_dim": cfg.z_dim,
                    "targets_per_gpu": 1, "parallelism": f"pair-sharded x{world}", "graph_replay": not a.no_graph,
-                   "loss_generator_overlap": bool(a.pipeline),
-                   "steps_per_forward": a.batch},
+                   "loss_generator_overlap": bool(a.pipeline), "steps_per_forward": a.batch,
+                   "lpips_backbone": "seeded random SqueezeNet1.1 weights (torchvision's are a remote fetch) + the reference's vendored lin heads",
+                   "timed_region": f"{steps} steps = {steps // a.batch} graph replays (>= --min-seconds {a.min_seconds}; requested --steps {a.steps})"},
     }
     if rank == 0:
         out["roofline"] = roofline_leg(eng)
@@ -372,7 +479,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

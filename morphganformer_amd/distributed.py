@@ -21,11 +21,19 @@ def shard_items(n_items: int, rank: int, world: int):
 class WorkQueue:
     """Dynamic partition for ragged workloads (targets whose steps are skipped when no face is found, early exits): every rank
     pulls the next item index from one shared atomic counter in the process group's key-value store.  No
-    tensor collective is involved; with no process group it degenerates to range(n_items)."""
+    tensor collective is involved; with no process group it degenerates to range(n_items).
+
+    Every queue has its own counter key: `name` plus an epoch that counts the queues of that name created in this process.  Ranks
+    create their queues in the same order (project_many is called collectively), so the epoch -- and the key -- agree across ranks,
+    and a second queue in the same process group (the second stage of a two-stage run) starts from zero again."""
+
+    _epochs: dict = {}
 
     def __init__(self, n_items: int, name: str = "mgf_queue"):
         import torch.distributed as dist
-        self.n_items, self.key = n_items, name + "/next"
+        epoch = WorkQueue._epochs.get(name, 0)
+        WorkQueue._epochs[name] = epoch + 1
+        self.n_items, self.key = n_items, f"{name}/{epoch}/next"
         self.store = None
         self._local = 0
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -191,6 +191,14 @@ cnt = torch.zeros(7)
 cnt[taken] = 1
 dist.all_reduce(cnt)
 assert cnt.tolist() == [1.0] * 7 and len(taken) >= 1
+# a second and a third queue in the same process group start from zero again (two-stage runs), also under another name
+for n_items, kw in ((5, {}), (4, {"name": "stage2"})):
+    dist.barrier()
+    taken = list(WorkQueue(n_items, **kw))
+    cnt = torch.zeros(n_items)
+    cnt[taken] = 1
+    dist.all_reduce(cnt)
+    assert cnt.tolist() == [1.0] * n_items, (n_items, cnt.tolist())
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 """
@@ -205,6 +213,26 @@ def test_result_gather_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"ok {r}" in o, o
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (torch.distributed.run as a child of a parent that never
+    imports torch), hands rank 0's JSON line through and fails when a rank fails -- rehearsed on CPU with the gloo dry-run leg."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch"]
+    ok = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert ok.returncode == 0, ok.stderr.decode()[-2000:]
+    lines = [ln for ln in ok.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2 and json.loads(lines[0])["ranks"] == [0, 1]
+    bad = subprocess.run(cmd, env=dict(env, MGF_SELFTEST_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert bad.returncode != 0
+    # the parent decides to launch before anything GPU-related is imported
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def main():")]
+    assert not re.search(r"^(import|from) (torch|numpy)", head, re.M)
 
 
 # ----------------------------------------------------------------------------------------------------------------- callers
