@@ -154,13 +154,15 @@ def test_improvement_trail_keeps_the_scored_images(golden):
         for step, loss, img in trail:
             assert loss == losses[step]
             fresh = G(torch.from_numpy(g["latents_n"][step]).cuda(), None, noise_mode="const")[0]
-            assert torch.equal(img, fresh[0])
+            # (a fresh single-image rendering may take other kernel paths than the batch -- split-K, tile shapes: float32 rounding only)
+            assert float((img - fresh[0]).abs().max()) < 1e-5 * float(fresh.abs().max())
     # two slots, more improvements: first improvement in slot 0, the final best in slot 1 (also when several improve in one batch)
     eng = make(2, 50)
     eng.run()
     trail = eng.improvements()
     assert [t[0] for t in trail] == [want[0], want[-1]]
-    assert torch.equal(trail[1][2], G(torch.from_numpy(g["latents_n"][want[-1]]).cuda(), None, noise_mode="const")[0][0])
+    fresh = G(torch.from_numpy(g["latents_n"][want[-1]]).cuda(), None, noise_mode="const")[0][0]
+    assert float((trail[1][2] - fresh).abs().max()) < 1e-5 * float(fresh.abs().max())
 
 
 def test_landmark_callback_mode_equals_injected_table(golden):
