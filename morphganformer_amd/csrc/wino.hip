@@ -335,31 +335,35 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     }
     float xr[W2_XS];
     float4 ur[W2_US];
-    auto load_x = [&](int c0) {
+    auto load_x_to = [&](float (&dst)[W2_XS], int c0) {
         const int soff = c0 * plane * 4;
 #pragma unroll
-        for (int j = 0; j < W2_XS; ++j) xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff[j], soff, 0));
+        for (int j = 0; j < W2_XS; ++j) dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff[j], soff, 0));
     };
-    auto load_u = [&](int c0) {
+    auto load_u_to = [&](float4 (&dst)[W2_US], int c0) {
         const int soff = c0 * p.cout * 4;            // chunk c0 / 4 starts (c0 / 4) * cout * 4 floats into a plane
 #pragma unroll
-        for (int j = 0; j < W2_US; ++j) ur[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, uoff[j], soff, 0));
+        for (int j = 0; j < W2_US; ++j) dst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, uoff[j], soff, 0));
     };
-    auto store_x = [&](float* R) {
+    auto load_x = [&](int c0) { load_x_to(xr, c0); };
+    auto load_u = [&](int c0) { load_u_to(ur, c0); };
+    auto store_x_from = [&](float* R, const float (&src)[W2_XS]) {
 #pragma unroll
-        for (int j = 0; j < W2_XS; ++j) R[tid + 256 * j] = xr[j];
+        for (int j = 0; j < W2_XS; ++j) R[tid + 256 * j] = src[j];
     };
+    auto store_x = [&](float* R) { store_x_from(R, xr); };
     // the style modulation rides on the weight slab (the reference's w * s, networks.py:289): a float4 holds one output channel's
     // four slots = channels c0 + {0, 2, 1, 3}, so the chunk's four styles are one wave-uniform 16-byte LDS read
-    auto store_u = [&](float* U, int c0) {
+    auto store_u_from = [&](float* U, const float4 (&src)[W2_US], int c0) {
         const float4 sv = *reinterpret_cast<const float4*>(Ss + c0);
 #pragma unroll
         for (int j = 0; j < W2_US; ++j) {
-            float4 v = ur[j];
+            float4 v = src[j];
             v.x *= sv.x; v.y *= sv.z; v.z *= sv.y; v.w *= sv.w;
             *reinterpret_cast<float4*>(U + (tid + 256 * j) * 4) = v;
         }
     };
+    auto store_u = [&](float* U, int c0) { store_u_from(U, ur, c0); };
     // one (channel, tile) patch per lane: lane <-> (tile = tid >> 2, channel = tid & 3)
     const int t_tile = tid >> 2, t_ch = tid & 3;
     const int t_slot = 2 * (t_ch & 1) + (t_ch >> 1);
@@ -406,20 +410,28 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     const int nchunks = nck;
     const int last = nchunks - 1;
     auto chunk0 = [&](int i) { return (i < last ? i : last) * W2CK; };
-    for (int i = tid; i < p.cin; i += 256) Ss[i] = sc ? sc[i] : 1.f;
-    load_x(0);
-    load_u(0);
-    store_x(raw0);
-    __syncthreads();                                 // Ss is read by store_u
-    store_u(U0, 0);
-    load_x(chunk0(1));
-    __syncthreads();
-    transform(raw0, V0);
-    store_x(raw1);
-    load_x(chunk0(2));
-    load_u(chunk0(1));
-    __syncthreads();
-    auto body = [&](int i, float* Ucur, float* Vcur, float* Unxt, float* Vnxt, float* raw_in, float* raw_out) {
+    // prologue: the loads of chunks 0, 1 and 2 are all in flight before the first wait -- one memory round trip instead of three
+    // (a workgroup of a 32-channel layer runs only 8 chunks: its prologue and epilogue latencies are what the other workgroup of
+    // the CU has to cover with its matrix work)
+    {
+        float xa[W2_XS], xb[W2_XS];
+        float4 ua[W2_US];
+        load_x_to(xa, 0);
+        load_u_to(ua, 0);
+        load_x_to(xb, chunk0(1));
+        load_u(chunk0(1));
+        load_x(chunk0(2));
+        for (int i = tid; i < p.cin; i += 256) Ss[i] = sc ? sc[i] : 1.f;
+        store_x_from(raw0, xa);
+        __syncthreads();                             // Ss is read by store_u
+        store_u_from(U0, ua, 0);
+        store_x_from(raw1, xb);
+        transform(raw0, V0);
+        __syncthreads();
+    }
+    // lx / lu: whether chunks i+3 / i+2 exist.  The steady-state loop passes literal `true`s (one basic block, as before); the last
+    // iterations skip the loads nobody would consume (a 32-channel layer runs 8 chunks per workgroup: 3 of 8 x-loads were wasted)
+    auto body = [&](int i, float* Ucur, float* Vcur, float* Unxt, float* Vnxt, float* raw_in, float* raw_out, bool lx, bool lu) {
         // matrix work first in program order: its operands are ready, so the wave's MFMAs start at once and the parking /
         // transform instructions below issue in the slots between them (all five LDS regions are distinct compile-time buffers)
 #if !defined(MGF_W2EXP) || MGF_W2EXP != 1         // experiment 1: no matrix work
@@ -428,17 +440,17 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
 #if !defined(MGF_W2EXP) || MGF_W2EXP != 3         // experiment 3: no global loads / register parking
         store_x(raw_out);                            // X(i+2), loaded during the previous chunk
         store_u(Unxt, chunk0(i + 1));                // U(i+1)
-        load_x(chunk0(i + 3));
-        load_u(chunk0(i + 2));
+        if (lx) load_x(chunk0(i + 3));
+        if (lu) load_u(chunk0(i + 2));
 #endif
 #if !defined(MGF_W2EXP) || MGF_W2EXP != 2         // experiment 2: no input transform
         transform(raw_in, Vnxt);
 #endif
         __syncthreads();
     };
-    for (int i = 0; i < nchunks; i += 2) {
-        body(i, U0, V0, U1, V1, raw1, raw0);
-        if (i + 1 < nchunks) body(i + 1, U1, V1, U0, V0, raw0, raw1);
+    for (int it = 0; it < nchunks; it += 2) {
+        body(it, U0, V0, U1, V1, raw1, raw0, it + 3 < nchunks, it + 2 < nchunks);
+        if (it + 1 < nchunks) body(it + 1, U1, V1, U0, V0, raw0, raw1, it + 4 < nchunks, it + 3 < nchunks);
     }
 
     // ---- output transform.  Rows a of this wave: {2 h2, 2 h2 + 1}.  A^T: s0 = m0 + m1 + m2, s1 = m1 - m2 - m3 ->
@@ -472,8 +484,11 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
                 keep[k][ij] = h2 == 0 ? lo : hi;
             }
     }
-    __syncthreads();
-    const float* theirs = xch + ((wg * 2 + (1 - h2)) * 32) * 64 + lane;
+    __builtin_amdgcn_sched_barrier(0);               // (the burst below must not be hoisted to where the 128 accumulators are still live)
+    // Every global operand of the epilogue (demodulation, bias, noise, the residual tile, the ToRGB weights) is requested HERE, in one
+    // burst in front of the exchange barrier, and consumed after it: one memory round trip per workgroup.  (Loaded where they are
+    // used -- inside the per-channel loop, behind per-lane conditions -- they cost eight serialised round trips, ~11 us per workgroup
+    // against 11 us of matrix work in a 32-channel layer.)
     const int tile = wg * 32 + l31;
     const int ty = tile / W2TX, tx = tile % W2TX;
     const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
@@ -487,12 +502,29 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
         const bool r1 = oy + 1 < p.h, c1 = ox + 1 < p.w;
         nz[0][0] = np_[0] * ns; nz[0][1] = c1 ? np_[1] * ns : 0.f; nz[1][0] = r1 ? np_[p.w] * ns : 0.f; nz[1][1] = (r1 && c1) ? np_[p.w + 1] * ns : 0.f;
     }
+    float osv[8];                                    // (co < cout always: cout is a whole number of 32-channel tiles)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = h2 * 8 + k;
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        osv[k] = osc ? osc[co] : 1.f;
+    }
     if (RGB) {
         // Fused ToRGB (the conv result itself never goes to memory): this workgroup holds all 32 channels of its pixels -- 8 per lane
         // in each of the two lane halves of the two position-half waves.  Every lane forms the partial 1x1 projection of its 8
         // channels, the lane halves meet with one cross-lane exchange, the two waves through LDS (the exchange block is dead by then).
         const int rc = p.rgb_channels;
         const float* wr = p.rgb_w + (int64_t)n * rc * p.cout;
+        float wv[8][4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = h2 * 8 + k;
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) wv[k][cc] = cc < rc ? wr[cc * p.cout + co] : 0.f;
+        }
+        __syncthreads();
+        const float* theirs = xch + ((wg * 2 + (1 - h2)) * 32) * 64 + lane;
         float sum[4][4];                             // [rgb channel][2x2 position]
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
@@ -500,19 +532,13 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
             for (int ij = 0; ij < 4; ++ij) sum[cc][ij] = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int r = h2 * 8 + k;
-            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float os = osc ? osc[co] : 1.f;
-            float wv[4];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) wv[cc] = cc < rc ? wr[cc * p.cout + co] : 0.f;
 #pragma unroll
             for (int ij = 0; ij < 4; ++ij) {
                 const float o = theirs[(k * 4 + ij) * 64];
                 const float m = keep[k][ij];
-                const float v = ((ij >> 1) == 0 ? m + o : (h2 == 0 ? m - o : o - m)) * os;
+                const float v = ((ij >> 1) == 0 ? m + o : (h2 == 0 ? m - o : o - m)) * osv[k];
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) sum[cc][ij] += v * wv[cc];
+                for (int cc = 0; cc < 4; ++cc) sum[cc][ij] += v * wv[k][cc];
             }
         }
 #pragma unroll
@@ -538,6 +564,49 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
         }
         return;
     }
+    float bvv[8];
+    float2 rr[8][2];
+    const bool has_res = do_ep && p.ep.residual != nullptr;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = h2 * 8 + k;
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bvv[k] = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
+        rr[k][0] = rr[k][1] = make_float2(0.f, 0.f);
+    }
+    if (has_res) {
+        // buffer loads: ONE scalar resource over this sample's residual slice, the channel of register k in the scalar offset (it is
+        // wave-uniform up to the lane half), one 32-bit lane offset per output row -- no 64-bit address pair per load -- and lanes
+        // outside the map read out of range (= 0)
+        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.ep.residual + (int64_t)n * p.y_batch + (int64_t)p.y_choff * plane), 0, p.cout * plane * 4, 0x00020000);
+        const unsigned v0 = ok_px ? (unsigned)((co0 + 4 * half) * plane + oy * p.w + ox) * 4u : 0xFFFFFFF0u;
+        if (!p.odd) {
+            const unsigned v1 = ok_px ? v0 + (unsigned)p.w * 4u : 0xFFFFFFF0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = h2 * 8 + k;
+                const int soff = ((r & 3) + 8 * (r >> 2)) * plane * 4;
+                rr[k][0] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rres, v0, soff, 0));
+                rr[k][1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rres, v1, soff, 0));
+            }
+        } else {                                      // odd map sides: rows are not 8-byte aligned, the last quad is partial
+            const bool r1 = ok_px && oy + 1 < p.h, c1 = ok_px && ox + 1 < p.w;
+            const unsigned o01 = c1 ? v0 + 4u : 0xFFFFFFF0u, o10 = r1 ? v0 + (unsigned)p.w * 4u : 0xFFFFFFF0u;
+            const unsigned o11 = (r1 && c1) ? o10 + 4u : 0xFFFFFFF0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = h2 * 8 + k;
+                const int soff = ((r & 3) + 8 * (r >> 2)) * plane * 4;
+                rr[k][0].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, v0, soff, 0));
+                rr[k][0].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, o01, soff, 0));
+                rr[k][1].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, o10, soff, 0));
+                rr[k][1].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, o11, soff, 0));
+            }
+        }
+    }
+    __syncthreads();
+    const float* theirs = xch + ((wg * 2 + (1 - h2)) * 32) * 64 + lane;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = h2 * 8 + k;
@@ -550,18 +619,12 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
             // row 0: P0 + Q0; row 1: P1 - Q1 (P from the h2 = 0 wave, Q from the h2 = 1 wave)
             yv[ij >> 1][ij & 1] = (ij >> 1) == 0 ? m + o : (h2 == 0 ? m - o : o - m);
         }
-        if (!ok_px || co >= p.cout) continue;
-        const float os = osc ? osc[co] : 1.f;
-        const float bv = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
+        if (!ok_px) continue;
+        const float os = osv[k], bv = bvv[k];
         const int64_t off = (int64_t)n * p.y_batch + (int64_t)(p.y_choff + co) * plane + (int64_t)oy * p.w + ox;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float v[2];
-            float2 rr = make_float2(0.f, 0.f);
-            if (do_ep && p.ep.residual) {
-                if (!p.odd) rr = *reinterpret_cast<const float2*>(p.ep.residual + off + a * p.w);
-                else if (oy + a < p.h) { rr.x = p.ep.residual[off + a * p.w]; if (ox + 1 < p.w) rr.y = p.ep.residual[off + a * p.w + 1]; }
-            }
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 float t = yv[a][bb] * os;
@@ -570,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
                     t += bv;
                     if (p.ep.act == MGF_ACT_LRELU) t = t > 0.f ? t : t * p.ep.alpha;
                     else if (p.ep.act == MGF_ACT_RELU) t = t > 0.f ? t : 0.f;
-                    t = t * p.ep.gain + (bb ? rr.y : rr.x);
+                    t = t * p.ep.gain + (bb ? rr[k][a].y : rr[k][a].x);
                 }
                 v[bb] = t;
             }

@@ -11,7 +11,8 @@ for res, c in ((16, 512), (32, 512), (64, 512), (128, 256), (256, 128), (512, 64
     s, d = torch.rand(n, c, device="cuda") + 0.5, torch.rand(n, c, device="cuda") + 0.5
     noise, bias = torch.randn(n, res * res, device="cuda"), torch.randn(c, device="cuda")
     st = torch.tensor([0.1], device="cuda")
-    ep = _lib.make_epilogue(bias=bias, noise=noise, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.4)
+    resid = torch.randn(n, c, res, res, device="cuda") if os.environ.get("WM_RES", "1") != "0" else None     # conv1 layers add the skip branch
+    ep = _lib.make_epilogue(bias=bias, noise=noise, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.4, residual=resid)
     u, u2, pc = (cv.winograd_weights(w) if c % 64 == 0 else None), cv.winograd2_weights(w), cv.pack_weights(w)
     out_w, out_d, out_2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
     fw = (lambda: cv.winograd_forward(x, u, in_scale=s, out_scale=d, epilogue=ep, out=out_w)) if u is not None else (lambda: out_w.copy_(out_d))
