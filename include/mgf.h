@@ -164,6 +164,21 @@ int mgf_conv3x3_winograd2_rgb_f32(float* rgb_out, const float* x, const float* u
 int mgf_conv3x3_winograd2_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
                               int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
                               mgf_stream_t stream);
+/* Third form of the same operation (csrc/wino3.hip), the one the engine uses for 32x32 maps and larger: the four rows of the transformed
+ * patch go to the four waves of a workgroup, a lane computes exactly the transformed-input values of its own MFMA operand slots (no
+ * LDS round trip of the transformed input), the weight operands come straight from L2, the style multiplies the input footprint.
+ * u in the layout of mgf_winograd2_weights_f32; cin % 4 == 0, cout % 32 == 0 (64 output channels per workgroup when cout % 64 == 0),
+ * even map sides; dense y [n, cout, h, w]; epilogue as mgf_conv_taps_f32 (noise and residual 8-byte aligned).
+ * _rgb: the fused 1x1 projection of mgf_conv3x3_winograd2_rgb_f32 (cout == 32, rgb_channels <= 3). */
+int mgf_conv3x3_winograd3_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
+                              int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
+                              mgf_stream_t stream);
+/* tuning / test hook: pin the workgroup shape of the form-3 launches (0 = automatic choice; 21 = 64 channels x 32 tiles, 12 = 32 x 64,
+ * 11 = 32 x 32 with three workgroups per CU); a shape that does not fit the call (21 with cout % 64 != 0) falls back to the automatic one */
+int mgf_winograd3_force_shape(int32_t shape);
+int mgf_conv3x3_winograd3_rgb_f32(float* rgb_out, const float* x, const float* u, const float* in_scale, const float* out_scale,
+                                  const float* rgb_w, const float* rgb_bias, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                                  int32_t out_scale_stride, int32_t rgb_channels, mgf_stream_t stream);
 int mgf_conv3x3_winograd_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
                              int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
                              mgf_stream_t stream);

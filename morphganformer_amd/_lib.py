@@ -71,6 +71,9 @@ _SIGS = {
     "mgf_winograd2_weights_f32": (C.c_int, [vp, vp, i32, i32, f32, vp]),
     "mgf_conv3x3_winograd2_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(Epilogue), vp]),
     "mgf_conv3x3_winograd2_rgb_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "mgf_conv3x3_winograd3_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(Epilogue), vp]),
+    "mgf_winograd3_force_shape": (C.c_int, [i32]),
+    "mgf_conv3x3_winograd3_rgb_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "mgf_conv3x3_winograd2_slice_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, C.POINTER(Epilogue), vp]),
     "mgf_pack_conv_weights": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
     "mgf_conv_profile_begin": (C.c_int, []),

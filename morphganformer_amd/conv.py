@@ -165,9 +165,32 @@ def winograd2_weights(w: torch.Tensor, gain: float = 1.0) -> torch.Tensor:
     return u
 
 
+# Which kernel serves the [16, cin/4, cout, 4] weight layout on even maps: form 3 (csrc/wino3.hip, the transformed input stays in
+# registers) unless MGF_WINOGRAD_FORM=2 (tuning hook: form 2, csrc/wino.hip, which also takes odd maps and channel slices)
+WINOGRAD_FORM = int(os.environ.get("MGF_WINOGRAD_FORM", "3"))
+
+
+def winograd3_ok(x, out, out_choff):
+    return (WINOGRAD_FORM == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and out_choff == 0 and
+            (out is None or out.shape[1] == out.shape[1] and out.is_contiguous()))
+
+
 def winograd2_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None, out_choff=0):
-    """Form 2 (and only it) may write channels [out_choff, out_choff + cout) of a wider `out` and takes odd map sides."""
+    """3x3 / stride 1 / pad 1 correlation on weights in the [16, cin/4, cout, 4] layout.  Form 3 serves dense outputs on even maps;
+    form 2 (and only it) may write channels [out_choff, out_choff + cout) of a wider `out` and takes odd map sides."""
     _lib.require_gpu(x, u, in_scale, out_scale, out)
+    if winograd3_ok(x, out, out_choff) and (out is None or out.shape[1] == u.shape[2]):
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and u.ndim == 4 and x.shape[1] == u.shape[1] * 4
+        n, cin, h, w = x.shape
+        cout = u.shape[2]
+        if out is None:
+            out = torch.empty([n, cout, h, w], dtype=torch.float32, device=x.device)
+        assert out.is_contiguous() and tuple(out.shape) == (n, cout, h, w)
+        os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
+        rc = _lib.lib().mgf_conv3x3_winograd3_f32(out.data_ptr(), x.data_ptr(), u.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale), n, cin, h, w,
+                                                  cout, os_stride, C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
+        _lib.check(rc, "conv3x3_winograd3")
+        return out
     assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and u.ndim == 4 and x.shape[1] == u.shape[1] * 4
     n, cin, h, w = x.shape
     cout = u.shape[2]
@@ -190,6 +213,11 @@ def winograd2_rgb_forward(x, u, rgb_w, rgb_bias, rgb_out, in_scale=None, out_sca
     assert x.is_contiguous() and u.ndim == 4 and u.shape[3] == 4 and rgb_w.is_contiguous() and rgb_out.is_contiguous()
     assert tuple(rgb_out.shape) == (n, rgb_w.shape[1], h, w) and rgb_w.shape[2] == cout
     os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
+    if WINOGRAD_FORM == 3 and h % 2 == 0 and w % 2 == 0 and rgb_w.shape[1] <= 3:
+        _lib.check(_lib.lib().mgf_conv3x3_winograd3_rgb_f32(rgb_out.data_ptr(), x.data_ptr(), u.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                                            rgb_w.data_ptr(), _lib.ptr(rgb_bias), n, cin, h, w, cout, os_stride, rgb_w.shape[1],
+                                                            _lib.stream_ptr()), "conv3x3_winograd3_rgb")
+        return rgb_out
     _lib.check(_lib.lib().mgf_conv3x3_winograd2_rgb_f32(rgb_out.data_ptr(), x.data_ptr(), u.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                                         rgb_w.data_ptr(), _lib.ptr(rgb_bias), n, cin, h, w, cout, os_stride, rgb_w.shape[1],
                                                         _lib.stream_ptr()), "conv3x3_winograd2_rgb")
@@ -209,6 +237,8 @@ def winograd_fills_chip(n, cout, h, w):
     waves of workgroups (2 x 256) the tap-list kernel with its split-K path is faster (a single 1024^2 projection, n = 1)."""
     if min(h, w) <= 16:
         return n * -(-h // 16) * -(-w // 16) * (cout // 64) >= 512
+    if WINOGRAD_FORM == 3:                              # form 3: 32 channels x (32 x 4 outputs) per workgroup, four workgroups per CU
+        return n * -(-h // 4) * -(-w // 32) * (cout // 32) >= 1024
     return n * -(-h // 8) * -(-w // 32) * (cout // 32) >= 512
 
 

@@ -1,0 +1,436 @@
+// Winograd F(2x2, 3x3), third kernel form: the transformed input never touches LDS.
+// Contract: include/mgf.h (mgf_conv3x3_winograd3_f32 / _rgb_f32); weights in the layout of mgf_winograd2_weights_f32.
+// Same arithmetic role as wino.hip (modulated 3x3 / stride-1 / pad-1 convolution, training/networks.py:288-303).
+//
+// What bounds a Winograd kernel on gfx950's FP32 matrix cores (tools/probes/mfma_lds.hip, mfma_coexec.hip): v_mfma_f32_32x32x2_f32
+// holds its SIMD for 64 cycles and NOTHING else of that SIMD overlaps with it to speak of -- a VALU instruction costs ~4 cycles of
+// matrix time (2 with two waves per SIMD), an LDS store ~8 cycles PER DWORD whatever its width (4 CU-wide cycles: the VGPR -> LDS path
+// is shared by the CU), while LDS loads of up to four per MFMA are free.  Form 2 (wino.hip) stores 30 dwords per lane and chunk to LDS
+// (input footprint 6, modulated weights 8, transformed input 16) and issues ~40 VALU instructions for 16 MFMAs.  This form:
+//   * splits the 16 Winograd positions of a tile FOUR ways, by row `a` of the transformed patch, one row per wave.  Row a of B^T d B
+//     needs two rows of the patch (a=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3) and 8 additions per (tile, channel), and a lane computes
+//     exactly the values its own MFMA B-operand slots hold -- (tile = lane % 32, channels {half, half + 2} of the chunk) -- so the
+//     transformed input goes from VALU registers straight into the MFMAs: no LDS store, no LDS buffer, no second barrier phase;
+//   * reads the weight operand (A) for its 4 positions straight from L2 into registers (one 8-byte buffer load per position and
+//     32-channel block: the two k-steps of a chunk), one chunk ahead: no LDS staging of weights either;
+//   * folds the style modulation into the INPUT when the footprint is parked in LDS (x * s, 4-6 multiplies per lane and chunk,
+//     instead of scaling the 16/9-times larger transformed weight slab): sum_i (W_oi s_i) * x_i = sum_i W_oi * (s_i x_i).
+// Per lane and chunk of 4 input channels that leaves 4-6 LDS dword stores, 16-38 VALU instructions, 8-16 LDS reads and 16 MFMAs.
+//
+// Workgroup: 4 waves (wave = row a), 4 positions x NB blocks of 32x32 accumulators per wave.
+//   <CB=2, TB=1>: 64 output channels x 32 tiles (16 x 2 Winograd tiles = 32 x 4 outputs), 128 accumulators, 2 workgroups per CU
+//                 -- layers deep enough in K (>= 128 input channels) to be bound by the matrix pipe
+//   <CB=1, TB=2>: 32 output channels x 64 tiles (32 x 8 outputs), 128 accumulators
+//   <CB=1, TB=1>: 32 output channels x 32 tiles (32 x 4 outputs), 64 accumulators, 3 workgroups per CU, optional fused ToRGB
+//                 -- the 512^2 / 1024^2 layers (8-16 chunks per workgroup): their time is the prologue / epilogue memory latency of a
+//                 workgroup, which more resident workgroups hide
+// The four rows meet once, at the end: Y = A^T M A is linear in M, every wave reduces its row to R[a][j] (2 values per accumulator
+// register), the rows are exchanged through LDS so that wave w finishes output row (w >> 1) of block (w & 1).
+#include "mgf_common.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct Wino3Params {
+    float* y;
+    const float* x;
+    const float* u;           // [16][cin / 4][cout][4 slots] (mgf_winograd2_weights_f32)
+    const float* in_scale;    // [n][cin] or null
+    const float* out_scale;   // [n or 1][cout] or null
+    int n, cin, h, w, cout, os_stride;
+    int tiles_x, tiles_y, co_tiles;
+    mgf_epilogue ep;
+    int has_ep;
+    const float* rgb_w;       // [n][rgb_channels][cout]
+    const float* rgb_bias;    // [rgb_channels] or null
+    float* rgb_out;           // [n][rgb_channels][h][w]
+    int rgb_channels;
+};
+
+#ifndef W3_OCC1
+#define W3_OCC1 4                        // workgroups per CU the one-block shapes are compiled for (3 -> 4: conv_last + ToRGB 3.64 -> 3.26 ms)
+#endif
+constexpr int W3CK = 4;                    // input channels per chunk
+constexpr int W3FW = 34;                   // footprint width: 16 tiles x 2 + 2
+
+template <int CB, int TB, bool RGB>
+__global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_kernel(Wino3Params p) {
+    constexpr int NB = CB * TB;                                    // 32x32 blocks per position and wave: 2 (128 accumulators) or 1 (64)
+    static_assert(NB == 1 || NB == 2, "a wave carries one or two 32x32 blocks per position");
+    constexpr int FH = 4 * TB + 2, FP = FH * W3FW;                 // footprint rows / pixels per channel
+    constexpr int XS = (W3CK * FP + 255) / 256;                    // staging slots per lane: 4 (TB = 1) or 6 (TB = 2)
+    constexpr int RAW = 256 * XS;
+    extern __shared__ float lds[];
+    float* const raw0 = lds;
+    float* const raw1 = raw0 + RAW;
+    float* const Ss = raw1 + RAW;                                  // [cin] styles
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int a = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave = row of the transformed patch (wave-uniform)
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tx = l31 & 15, ty = l31 >> 4;
+
+    int b_ = blockIdx.x;
+    const int cot = b_ % p.co_tiles; b_ /= p.co_tiles;
+    const int ptx = b_ % p.tiles_x; b_ /= p.tiles_x;
+    const int pty = b_ % p.tiles_y;
+    const int n = b_ / p.tiles_y;
+    const int co0 = cot * 32 * CB, oy0 = pty * 4 * TB, ox0 = ptx * 32;
+    const int plane = p.h * p.w;
+    const float* xn = p.x + (int64_t)n * p.cin * plane;
+    const float* sc = p.in_scale ? p.in_scale + (int64_t)n * p.cin : nullptr;
+    const int nck = p.cin / W3CK;
+
+    // raw BUFFER loads: scalar resource + 32-bit lane offset, out of range = 0 = the zero padding of the footprint
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, p.cin * plane * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, 16 * p.cin * p.cout * 4, 0x00020000);
+    // a resource of ZERO records: every access through it is out of range = returns 0 without touching memory.  The loop's tail
+    // iterations load through it instead of branching around their loads: the instruction stream -- and with it the compiler's vmcnt
+    // bookkeeping -- stays identical in every iteration (behind `if (more) load` the waits are merged conservatively over both paths
+    // and drain the loads issued a moment ago, i.e. expose one L2 round trip per chunk)
+    const __amdgpu_buffer_rsrc_t rnull = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, 0, 0x00020000);
+    unsigned xoff[XS];
+    int sidx[XS];                                                  // channel of the slot (which style multiplies it)
+#pragma unroll
+    for (int j = 0; j < XS; ++j) {
+        const int e = tid + 256 * j;
+        const int ch = e / FP, rem = e - ch * FP;
+        const int r = rem / W3FW, q = rem - r * W3FW;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
+        xoff[j] = (e < W3CK * FP && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? (unsigned)(ch * plane + iy * p.w + ix) * 4u : 0xFFFFFFF0u;
+        sidx[j] = ch < W3CK ? ch : W3CK - 1;
+    }
+    // A operand of lane (l31, half) for position 4a + b, block cb: 8 bytes = slots {2 half, 2 half + 1} = channels {half, half + 2} of
+    // output channel co0 + 32 cb + l31.  The position / chunk part of the address is wave-uniform and rides in the scalar offset.
+    const unsigned aoff = (unsigned)(((co0 + l31) * W3CK + half * 2) * 4);
+    const int upos = nck * p.cout * W3CK * 4;                      // bytes between two positions
+    const int ubase = 4 * a * upos;
+
+    float xr[XS];
+    auto load_x = [&](float (&dst)[XS], int c0, bool live = true) {
+        const int soff = c0 * plane * 4;
+        const __amdgpu_buffer_rsrc_t r = live ? rx : rnull;
+#pragma unroll
+        for (int j = 0; j < XS; ++j) dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff[j], soff, 0));
+    };
+    auto park_x = [&](float* R, const float (&src)[XS], int c0) {
+#pragma unroll
+        for (int j = 0; j < XS; ++j) R[tid + 256 * j] = src[j] * Ss[c0 + sidx[j]];       // the style modulation rides on the input
+    };
+    auto load_a = [&](v2f (&dst)[4][CB], int c0, bool live = true) {
+        const int soff = ubase + c0 * p.cout * 4;                  // chunk c0 / 4 starts (c0 / 4) * cout * 4 floats into a position plane
+        const __amdgpu_buffer_rsrc_t r = live ? ru : rnull;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+                dst[b][cb] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, aoff + cb * (32 * W3CK * 4), soff + b * upos, 0));
+    };
+    // row a of B^T d B for this lane's (tile, channel) pairs: t = d[pr] + sg * d[qr] over the 4 columns, then the row pass
+    const int pr = a == 0 ? 0 : (a == 2 ? 2 : 1);
+    const int qr = a == 2 ? 1 : (a == 3 ? 3 : 2);
+    const float sg = a == 1 ? 1.f : -1.f;
+    auto transform = [&](float (&B)[TB][2][4], const float* R) {
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const float* src = R + ((half + 2 * kk) * FH + 2 * (tb * 2 + ty)) * W3FW + 2 * tx;
+                const v2f p01 = *reinterpret_cast<const v2f*>(src + pr * W3FW), p23 = *reinterpret_cast<const v2f*>(src + pr * W3FW + 2);
+                const v2f q01 = *reinterpret_cast<const v2f*>(src + qr * W3FW), q23 = *reinterpret_cast<const v2f*>(src + qr * W3FW + 2);
+                const float t0 = p01.x + sg * q01.x, t1 = p01.y + sg * q01.y, t2 = p23.x + sg * q23.x, t3 = p23.y + sg * q23.y;
+                B[tb][kk][0] = t0 - t2;
+                B[tb][kk][1] = t1 + t2;
+                B[tb][kk][2] = t2 - t1;
+                B[tb][kk][3] = t1 - t3;
+            }
+    };
+
+    f32x16 acc[4][CB][TB];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][cb][tb][r] = 0.f;
+    auto mfma_chunk = [&](const v2f (&A)[4][CB], const float (&B)[TB][2][4]) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) {
+                    acc[b][cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[b][cb].x, B[tb][0][b], acc[b][cb][tb], 0, 0, 0);
+                    acc[b][cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[b][cb].y, B[tb][1][b], acc[b][cb][tb], 0, 0, 0);
+                }
+    };
+
+    // ---- prologue: every load of chunks 0..2 is in flight before the first wait ----
+    const int nchunks = nck;
+    const int last = nchunks - 1;
+    auto chunk0 = [&](int i) { return (i < last ? i : last) * W3CK; };
+    v2f A0[4][CB], A1[4][CB];
+    float B0[TB][2][4], B1[TB][2][4];
+    {
+        float xa[XS], xb[XS];
+        load_x(xa, 0);
+        load_a(A0, 0);
+        load_x(xb, chunk0(1));
+        load_x(xr, chunk0(2));
+        for (int i = tid; i < p.cin; i += 256) Ss[i] = sc ? sc[i] : 1.f;
+        __syncthreads();                             // Ss is read when parking
+        park_x(raw0, xa, 0);
+        park_x(raw1, xb, chunk0(1));
+        __syncthreads();
+        transform(B0, raw0);
+    }
+    // ---- steady state, one barrier per chunk.  body(i): request A(i+1); transform chunk i+1 (parked during body(i-1)) into the other
+    // B registers; the 16 MFMAs of chunk i; park x(i+2) -- loaded during body(i-1) -- over chunk i's footprint (its transform is
+    // done and every wave passed the barrier since); request x(i+3). ----
+    auto body = [&](int i, v2f (&Acur)[4][CB], v2f (&Anxt)[4][CB], float (&Bcur)[TB][2][4], float (&Bnxt)[TB][2][4], float* raw_nxt, float* raw_park) {
+        // ONE basic block: nothing here is conditional (past the last chunk the loads go through the null resource, the transform and
+        // the parking work on values nobody reads)
+        load_a(Anxt, chunk0(i + 1), i + 1 < nchunks);
+#if !defined(MGF_W3EXP) || MGF_W3EXP != 2         // experiment 2: no input transform
+        transform(Bnxt, raw_nxt);
+#endif
+#if !defined(MGF_W3EXP) || MGF_W3EXP != 1         // experiment 1: no matrix work
+        mfma_chunk(Acur, Bcur);
+#endif
+#if !defined(MGF_W3EXP) || MGF_W3EXP != 3         // experiment 3: no footprint staging
+        park_x(raw_park, xr, chunk0(i + 2));
+        load_x(xr, chunk0(i + 3), i + 3 < nchunks);
+#endif
+        __syncthreads();
+    };
+    for (int it = 0; it < nchunks; it += 2) {
+        body(it, A0, A1, B0, B1, raw1, raw0);
+        if (it + 1 < nchunks) body(it + 1, A1, A0, B1, B0, raw0, raw1);
+    }
+
+    // ---- output transform.  R[j] = row a of M times A: R0 = M0 + M1 + M2, R1 = M1 - M2 - M3 per accumulator register; then over the
+    // rows (= waves): Y0 = R[0] + R[1] + R[2], Y1 = R[1] - R[2] - R[3].  The work is cut in two UNITS and wave w finishes output row
+    // (w >> 1) of unit (w & 1):
+    //   w0: Y0 u0 = own + s1 + s3     w1: Y0 u1 = s0 + own + s4     w2: Y1 u0 = s1 - own - s5     w3: Y1 u1 = s2 - s4 - own
+    // with the exchange slots  s0 = R[0] u1, s1 = R[1] u0, s2 = R[1] u1, s3 = R[2] u0, s4 = R[2] u1, s5 = R[3] u0.
+    // A unit is: one of the wave's two 32x32 blocks (NB = 2); a half of the block's 16 registers, i.e. 16 of its 32 channels (NB = 1);
+    // or, for the fused ToRGB with one block, an output COLUMN j (the wave then holds one pixel of every quad for all 32 channels). ----
+    constexpr int UMODE = NB == 2 ? 0 : (RGB ? 2 : 1);
+    constexpr int NV = UMODE == 0 ? 32 : 16;         // values per lane and exchange slot
+    float own[NV];
+    float* xch = lds;                                // [6 slots][NV values][64 lanes]; the staging buffers are dead
+    const int blk = a & 1, orow = a >> 1;
+    {
+        const int w0 = a == 1 ? 1 : (a == 2 ? 3 : (a == 3 ? 5 : -1));     // slot receiving my unit 0
+        const int w1 = a == 0 ? 0 : (a == 1 ? 2 : (a == 2 ? 4 : -1));     // slot receiving my unit 1
+#pragma unroll
+        for (int un = 0; un < 2; ++un) {
+            const int ws = un == 0 ? w0 : w1;
+            float* dst = xch + (ws < 0 ? 0 : ws) * (NV * 64) + lane;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int r = UMODE == 0 ? (v >> 1) : (UMODE == 1 ? un * 8 + (v >> 1) : v);
+                const int jj = UMODE == 2 ? un : (v & 1);
+                const int cb = (UMODE == 0 && CB == 2) ? un : 0, tb = (UMODE == 0 && TB == 2) ? un : 0;
+                const float m0 = acc[0][cb][tb][r], m1 = acc[1][cb][tb][r], m2 = acc[2][cb][tb][r], m3 = acc[3][cb][tb][r];
+                const float val = jj == 0 ? m0 + m1 + m2 : m1 - m2 - m3;
+                if (un == blk) own[v] = val;
+                if (ws >= 0) dst[v * 64] = val;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);               // (the operand burst below must not move to where the accumulators are still live)
+    // every global operand of the epilogue is requested here, in one burst in front of the exchange barrier
+    const int trow = (UMODE == 0 && TB == 2 ? blk * 2 : 0) + ty;   // tile row inside the workgroup's tile
+    const int oy = oy0 + 2 * trow + orow, ox = ox0 + 2 * tx + (UMODE == 2 ? blk : 0);
+    const bool ok_px = oy < p.h && ox < p.w;         // h, w even: a pixel pair is inside whenever its first pixel is
+    // channel of the wave's k-th channel row: cob + (k & 3) + 8 (k >> 2)
+    const int cob = co0 + (UMODE == 0 && CB == 2 ? blk * 32 : 0) + (UMODE == 1 ? blk * 16 : 0) + 4 * half;
+    const float* osc = p.out_scale ? p.out_scale + (int64_t)n * p.os_stride : nullptr;
+    const bool do_ep = p.has_ep != 0;
+    const int sa = a == 0 ? 1 : (a == 1 ? 0 : (a == 2 ? 1 : 2)), sb = a == 0 ? 3 : (a == 2 ? 5 : 4);
+    const float sgn = a < 2 ? 1.f : -1.f;
+    const float* pa = xch + sa * (NV * 64) + lane;
+    const float* pb = xch + sb * (NV * 64) + lane;
+    if (RGB) {
+        // fused ToRGB: the wave holds, for all 32 channels (16 per lane half), row `orow` of its tiles' quads (UMODE 0: both columns)
+        // or pixel (orow, blk) of them (UMODE 2).  The projection weights times the demodulation go through LDS once per workgroup.
+        const int rc = p.rgb_channels;
+        float* wvs = lds + 6 * NV * 64;              // [3][32]
+        if (tid < 96) {
+            const int cc = tid >> 5, co = tid & 31;
+            wvs[tid] = cc < rc ? p.rgb_w[((int64_t)n * rc + cc) * p.cout + co0 + co] * (osc ? osc[co0 + co] : 1.f) : 0.f;
+        }
+        __syncthreads();
+        constexpr int NC = UMODE == 0 ? 2 : 1;       // output columns this wave produces
+        float sum[3][NC];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) sum[cc][q] = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int k = UMODE == 0 ? (v >> 1) : v, q = UMODE == 0 ? (v & 1) : 0;
+            const float yv = pa[v * 64] + sgn * (own[v] + pb[v * 64]);
+            const int cl = 4 * half + (k & 3) + 8 * (k >> 2);
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) sum[cc][q] += yv * wvs[cc * 32 + cl];
+        }
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) sum[cc][q] += __shfl_xor(sum[cc][q], 32, 64);
+        if (half == 0 && ok_px) {
+            for (int cc = 0; cc < rc; ++cc) {
+                const float bb = p.rgb_bias ? p.rgb_bias[cc] : 0.f;
+                float* o = p.rgb_out + ((int64_t)n * rc + cc) * plane + (int64_t)oy * p.w + ox;
+                if (NC == 2) *reinterpret_cast<float2*>(o) = make_float2(sum[cc][0] + bb, sum[cc][NC - 1] + bb);
+                else o[0] = sum[cc][0] + bb;
+            }
+        }
+        return;
+    }
+    constexpr int NR = NV / 2;                       // channel rows this wave finishes (both columns of each)
+    float osv[NR], bvv[NR];
+    float2 rr[NR];
+    float nz0 = 0.f, nz1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int co = cob + (k & 3) + 8 * (k >> 2);
+        osv[k] = osc ? osc[co] : 1.f;
+        bvv[k] = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
+        rr[k] = make_float2(0.f, 0.f);
+    }
+    const unsigned voff = ok_px ? (unsigned)(cob * plane + oy * p.w + ox) * 4u : 0xFFFFFFF0u;
+    if (do_ep && p.ep.residual) {
+        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ep.residual + (int64_t)n * p.cout * plane), 0,
+                                                                              p.cout * plane * 4, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            rr[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rres, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0));
+    }
+    if (do_ep && p.ep.noise && ok_px) {
+        const float ns = p.ep.noise_strength ? *p.ep.noise_strength : 1.f;
+        const float2 nv = *reinterpret_cast<const float2*>(p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane + (int64_t)oy * p.w + ox);
+        nz0 = nv.x * ns; nz1 = nv.y * ns;
+    }
+    __syncthreads();
+    {
+        float* yb = p.y + (int64_t)n * p.cout * plane;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            float v[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float t = (pa[(2 * k + q) * 64] + sgn * (own[2 * k + q] + pb[(2 * k + q) * 64])) * osv[k];
+                if (do_ep) {
+                    t += q ? nz1 : nz0;
+                    t += bvv[k];
+                    if (p.ep.act == MGF_ACT_LRELU) t = t > 0.f ? t : t * p.ep.alpha;
+                    else if (p.ep.act == MGF_ACT_RELU) t = t > 0.f ? t : 0.f;
+                    t = t * p.ep.gain + (q ? rr[k].y : rr[k].x);
+                }
+                v[q] = t;
+            }
+            if (ok_px)
+                *reinterpret_cast<float2*>(yb + (int64_t)(cob + (k & 3) + 8 * (k >> 2)) * plane + (int64_t)oy * p.w + ox) = make_float2(v[0], v[1]);
+        }
+    }
+}
+
+}  // namespace
+
+static int g_w3_forced_shape = 0;
+
+extern "C" int mgf_winograd3_force_shape(int32_t shape) {
+    MGF_REQUIRE(shape == 0 || shape == 21 || shape == 12 || shape == 11, MGF_EINVAL, "winograd3_force_shape: 0 (auto), 21, 12 or 11 (got %d)", shape);
+    g_w3_forced_shape = shape;
+    return MGF_OK;
+}
+
+static int launch_wino3(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n, int32_t cin, int32_t h,
+                        int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep, const float* rgb_w, const float* rgb_bias,
+                        float* rgb_out, int32_t rgb_channels, mgf_stream_t stream) {
+    const bool rgb = rgb_out != nullptr;
+    MGF_REQUIRE((y || rgb) && x && u && n >= 1 && cin >= 1 && cout >= 1 && h >= 2 && w >= 2, MGF_EINVAL, "conv3x3_winograd3: bad arguments");
+    MGF_REQUIRE(cin % W3CK == 0 && cout % 32 == 0, MGF_EUNSUPPORTED, "conv3x3_winograd3: cin must be a multiple of %d and cout of 32 (got %d, %d)",
+                W3CK, cin, cout);
+    MGF_REQUIRE(cin <= 1024, MGF_EUNSUPPORTED, "conv3x3_winograd3: at most 1024 input channels (got %d)", cin);
+    MGF_REQUIRE(h % 2 == 0 && w % 2 == 0, MGF_EUNSUPPORTED, "conv3x3_winograd3: even feature-map sides only (got %dx%d)", h, w);
+    MGF_REQUIRE((int64_t)cin * h * w <= INT32_MAX / 4 && (int64_t)16 * cin * cout <= INT32_MAX / 4 && (int64_t)cout * h * w <= INT32_MAX / 4,
+                MGF_ETOOBIG, "conv3x3_winograd3: one sample / the weight planes must stay below 2 GiB (32-bit buffer offsets)");
+    MGF_REQUIRE(((uintptr_t)u % 16) == 0 && ((uintptr_t)(rgb ? rgb_out : y) % 8) == 0, MGF_EINVAL, "conv3x3_winograd3: u must be 16-byte and the output 8-byte aligned");
+    if (ep) {
+        MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU, MGF_EUNSUPPORTED,
+                    "conv3x3_winograd3: epilogue activation %d unsupported", ep->act);
+        MGF_REQUIRE(!ep->residual || ((uintptr_t)ep->residual % 8) == 0, MGF_EINVAL, "conv3x3_winograd3: the residual must be 8-byte aligned");
+        MGF_REQUIRE(!ep->noise || ((uintptr_t)ep->noise % 8) == 0, MGF_EINVAL, "conv3x3_winograd3: the noise map must be 8-byte aligned");
+    }
+    if (rgb) {
+        MGF_REQUIRE(cout == 32 && rgb_w && rgb_channels >= 1 && rgb_channels <= 3 && !ep, MGF_EUNSUPPORTED,
+                    "conv3x3_winograd3_rgb: needs cout == 32, 1..3 projected channels and no epilogue (got cout %d, %d channels)", cout, rgb_channels);
+    }
+    // Shape: 32 channels x 32 tiles with 64 accumulators per wave and FOUR workgroups per CU.  Measured on the generator's conv1 layers
+    // at 25 samples (tools/w3_phases.py; shapes 21 / 12 / 11, us): 64^2 2412 / 2297 / 2138, 128^2 2273 / 2408 / 2254, 256^2 2543 /
+    // 2681 / 2525, 512^2 3078 / 3303 / 3011, 1024^2 - / 4376 / 3940 -- residency (latency hiding across workgroups) is worth more than
+    // the instructions the wider shapes save.  MGF_W3_SHAPE = 21 | 12 | 11 or mgf_winograd3_force_shape pin a shape (tuning, tests).
+    static const int env_forced = [] { const char* e = getenv("MGF_W3_SHAPE"); return e ? atoi(e) : 0; }();
+    const int forced = g_w3_forced_shape ? g_w3_forced_shape : env_forced;
+    int shape = 11;
+    if (forced == 21 && cout % 64 == 0 && !rgb) shape = 21;
+    if (forced == 12 || forced == 11) shape = forced;
+    const int cb = shape == 21 ? 2 : 1, tb = shape == 12 ? 2 : 1;
+    Wino3Params p;
+    p.y = y; p.x = x; p.u = u; p.in_scale = in_scale; p.out_scale = out_scale;
+    p.n = n; p.cin = cin; p.h = h; p.w = w; p.cout = cout; p.os_stride = out_scale_stride;
+    p.tiles_x = (int)mgf_cdiv(w, 32); p.tiles_y = (int)mgf_cdiv(h, 4 * tb); p.co_tiles = cout / (32 * cb);
+    p.has_ep = ep != nullptr;
+    if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
+    p.rgb_w = rgb_w; p.rgb_bias = rgb_bias; p.rgb_out = rgb_out; p.rgb_channels = rgb_channels;
+    const int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
+    MGF_REQUIRE(blocks <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd3: too many workgroups");
+    // main loop: two footprint buffers + the styles; epilogue: 6 exchange slots (+ the ToRGB weights) over the same memory
+    const size_t nv = cb * tb == 2 ? 32 : 16;
+    const size_t lds = std::max<size_t>((size_t)(2 * 256 * (tb == 2 ? 6 : 4) + cin) * sizeof(float), (size_t)(6 * nv * 64 + 96) * sizeof(float));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino3_conv_kernel<2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino3_conv_kernel<1, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino3_conv_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e != hipSuccess) { mgf_set_error("conv3x3_winograd3: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MGF_ELAUNCH; }
+        attr_set = true;
+    }
+    // names as rocprofv3 prints the instantiations; algorithmic accounting of the direct form (what the launch replaces)
+    const char* name = rgb ? (shape == 12 ? "wino3_conv_kernel<1, 2, true>" : "wino3_conv_kernel<1, 1, true>")
+                           : (shape == 21 ? "wino3_conv_kernel<2, 1, false>" : (shape == 12 ? "wino3_conv_kernel<1, 2, false>" : "wino3_conv_kernel<1, 1, false>"));
+    mgf_prof_external_begin((hipStream_t)stream, name, 2.0 * 9 * cin * (double)cout * h * w * n,
+                            4.0 * ((double)n * cin * h * w + 9.0 * cin * cout + (double)n * (rgb ? rgb_channels : cout) * h * w));
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (rgb && shape == 12) hipLaunchKernelGGL((wino3_conv_kernel<1, 2, true>), grid, blk, lds, st, p);
+    else if (rgb) hipLaunchKernelGGL((wino3_conv_kernel<1, 1, true>), grid, blk, lds, st, p);
+    else if (shape == 21) hipLaunchKernelGGL((wino3_conv_kernel<2, 1, false>), grid, blk, lds, st, p);
+    else if (shape == 12) hipLaunchKernelGGL((wino3_conv_kernel<1, 2, false>), grid, blk, lds, st, p);
+    else hipLaunchKernelGGL((wino3_conv_kernel<1, 1, false>), grid, blk, lds, st, p);
+    mgf_prof_external_end((hipStream_t)stream);
+    MGF_CHECK_LAUNCH("conv3x3_winograd3");
+    return MGF_OK;
+}
+
+extern "C" int mgf_conv3x3_winograd3_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
+                                         int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
+                                         mgf_stream_t stream) {
+    return launch_wino3(y, x, u, in_scale, out_scale, n, cin, h, w, cout, out_scale_stride, ep, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mgf_conv3x3_winograd3_rgb_f32(float* rgb_out, const float* x, const float* u, const float* in_scale, const float* out_scale,
+                                             const float* rgb_w, const float* rgb_bias, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                                             int32_t out_scale_stride, int32_t rgb_channels, mgf_stream_t stream) {
+    MGF_REQUIRE(rgb_out, MGF_EINVAL, "conv3x3_winograd3_rgb: null output");
+    return launch_wino3(nullptr, x, u, in_scale, out_scale, n, cin, h, w, cout, out_scale_stride, nullptr, rgb_w, rgb_bias, rgb_out, rgb_channels, stream);
+}

@@ -293,14 +293,22 @@ def test_upfirdn2d_down2_tiled_vs_oracle(shape, pad, taps, flip):
     assert rel_err(out, ref) < 3e-6
 
 
-@pytest.mark.parametrize("form", [1, 2])
-@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 32), (1, 16, 128, 24, 40), (3, 72, 64, 18, 34), (1, 512, 512, 16, 16)])
-def test_winograd_conv_matches_direct_conv_and_oracle(n, cin, cout, h, w, form):
+@pytest.mark.parametrize("form", [1, 2, 3, 21, 12, 11])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 32), (1, 16, 128, 24, 40), (3, 72, 64, 18, 34), (1, 512, 512, 16, 16), (2, 32, 32, 40, 64),
+                                            (1, 20, 96, 6, 2)])
+def test_winograd_conv_matches_direct_conv_and_oracle(n, cin, cout, h, w, form, monkeypatch, request):
     """Winograd F(2x2,3x3) kernels (form 1: one workgroup per CU, 64 channels x 16x16 outputs, 8-channel chunks; form 2: two
-    workgroups per CU, 32 channels, 4-channel chunks, the position halves meeting through LDS) vs the 9-tap MFMA kernel and the
-    CPU oracle: style modulation, demodulation, fused noise/bias/lrelu/residual epilogue, ragged 16x16 tiles."""
+    workgroups per CU, 32 channels, 4-channel chunks, the position halves meeting through LDS; form 3: one row of the transformed
+    patch per wave, transformed input kept in registers, 64 or 32 channels per workgroup) vs the 9-tap MFMA kernel and the CPU
+    oracle: style modulation, demodulation, fused noise/bias/lrelu/residual epilogue, ragged tiles."""
     from morphganformer_amd import _lib, conv as cv
     from oracle.ops_ref import bias_act_ref
+    if form == 1 and (cin % 8 or cout % 64):
+        pytest.skip("form 1 takes 8-channel chunks and 64-channel tiles")
+    monkeypatch.setattr(cv, "WINOGRAD_FORM", 3 if form >= 3 else 2)
+    if form > 3:                                  # form 3 with a pinned workgroup shape (21 falls back to the automatic one when cout % 64)
+        _lib.check(_lib.lib().mgf_winograd3_force_shape(form))
+        request.addfinalizer(lambda: _lib.lib().mgf_winograd3_force_shape(0))
     torch.manual_seed(cin + h)
     x = torch.randn(n, cin, h, w)
     wt = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
@@ -324,10 +332,16 @@ def test_winograd_conv_matches_direct_conv_and_oracle(n, cin, cout, h, w, form):
     assert rel_err(cv.winograd_forward(xd, u), torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)) < 2e-5
 
 
-@pytest.mark.parametrize("n,cin,h,w", [(2, 32, 64, 64), (1, 16, 24, 40)])
-def test_winograd_fused_torgb_matches_tap_list_launch(n, cin, h, w):
-    """conv_last + ToRGB in one Winograd launch vs the tap-list kernel's fused projection and vs torch."""
-    from morphganformer_amd import conv as cv
+@pytest.mark.parametrize("form", [2, 3, 12])
+@pytest.mark.parametrize("n,cin,h,w", [(2, 32, 64, 64), (1, 16, 24, 40), (3, 32, 20, 34)])
+def test_winograd_fused_torgb_matches_tap_list_launch(n, cin, h, w, form, monkeypatch, request):
+    """conv_last + ToRGB in one Winograd launch (form 2; form 3 in its 32x32-tile and 32x64-tile shapes) vs the tap-list kernel's fused
+    projection and vs torch."""
+    from morphganformer_amd import _lib, conv as cv
+    monkeypatch.setattr(cv, "WINOGRAD_FORM", 3 if form >= 3 else 2)
+    if form > 3:
+        _lib.check(_lib.lib().mgf_winograd3_force_shape(form))
+        request.addfinalizer(lambda: _lib.lib().mgf_winograd3_force_shape(0))
     torch.manual_seed(h + cin)
     x = torch.randn(n, cin, h, w)
     wt = torch.randn(32, cin, 3, 3) / (3 * cin ** 0.5)

@@ -17,9 +17,17 @@ for res, c in ((16, 512), (32, 512), (64, 512), (128, 256), (256, 128), (512, 64
     out_w, out_d, out_2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
     fw = (lambda: cv.winograd_forward(x, u, in_scale=s, out_scale=d, epilogue=ep, out=out_w)) if u is not None else (lambda: out_w.copy_(out_d))
     fd = lambda: cv.conv_forward(x, pc, pad=(1, 1), in_scale=s, out_scale=d, epilogue=ep, out=out_d)
-    f2 = lambda: cv.winograd2_forward(x, u2, in_scale=s, out_scale=d, epilogue=ep, out=out_2)
+    out_3 = torch.empty_like(x)
+
+    def f2():
+        cv.WINOGRAD_FORM = 2
+        cv.winograd2_forward(x, u2, in_scale=s, out_scale=d, epilogue=ep, out=out_2)
+
+    def f3():
+        cv.WINOGRAD_FORM = 3
+        cv.winograd2_forward(x, u2, in_scale=s, out_scale=d, epilogue=ep, out=out_3)
     res_t = []
-    for fn in (fw, fd, f2):
+    for fn in (fw, fd, f2, f3):
         fn(); fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,4 +41,5 @@ for res, c in ((16, 512), (32, 512), (64, 512), (128, 256), (256, 128), (512, 64
     err = float((out_w - out_d).abs().max() / out_d.abs().max())
     err2 = float((out_2 - out_d).abs().max() / out_d.abs().max())
     print(f"res {res:4d} c {c:4d}: winograd {res_t[0]*1e3:8.1f} us ({gf/res_t[0]:6.1f} TF alg)  direct {res_t[1]*1e3:8.1f} us ({gf/res_t[1]:6.1f} TF)  rel diff {err:.1e}"
-          f" | form2 {res_t[2]*1e3:8.1f} us ({gf/res_t[2]:6.1f} TF) diff {err2:.1e}", flush=True)
+          f" | form2 {res_t[2]*1e3:8.1f} us ({gf/res_t[2]:6.1f} TF) diff {err2:.1e} | form3 {res_t[3]*1e3:8.1f} us ({gf/res_t[3]:6.1f} TF) diff "
+          f"{float((out_3 - out_d).abs().max() / out_d.abs().max()):.1e}", flush=True)
