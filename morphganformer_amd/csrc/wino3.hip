@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         park_x(raw1, xb, chunk0(1));
         __syncthreads();
         transform(B0, raw0);
+        __syncthreads();                             // body(0) parks chunk 2 over raw0: every wave must have read chunk 0 from it
     }
     // ---- steady state, one barrier per chunk.  body(i): request A(i+1); transform chunk i+1 (parked during body(i-1)) into the other
     // B registers; the 16 MFMAs of chunk i; park x(i+2) -- loaded during body(i-1) -- over chunk i's footprint (its transform is
