@@ -86,7 +86,17 @@ def parse():
     return ap.parse_args()
 
 
+def _late_imports():
+    """numpy / torch enter the module only on the worker side (main() after the launcher decision, or a tool importing build())."""
+    global np, torch
+    if torch is None:
+        import numpy
+        import torch as _torch
+        np, torch = numpy, _torch
+
+
 def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0, pipeline=False):
+    _late_imports()
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.lpips import PerceptualLoss
     from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, latent_stats, synthetic_landmarks
@@ -371,9 +381,7 @@ def main():
         return self_launch(a)
     if a.selftest_launch:
         return launch_selftest(a)
-    global np, torch
-    import numpy as np
-    import torch
+    _late_imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -237,8 +237,10 @@ def winograd_fills_chip(n, cout, h, w):
     waves of workgroups (2 x 256) the tap-list kernel with its split-K path is faster (a single 1024^2 projection, n = 1)."""
     if min(h, w) <= 16:
         return n * -(-h // 16) * -(-w // 16) * (cout // 64) >= 512
-    if WINOGRAD_FORM == 3:                              # form 3: 32 channels x (32 x 4 outputs) per workgroup, four workgroups per CU
-        return n * -(-h // 4) * -(-w // 32) * (cout // 32) >= 1024
+    if WINOGRAD_FORM == 3:
+        # form 3: 32 channels x (32 x 4 outputs) per workgroup, four workgroups per CU.  Half a wave of workgroups (512 of the 1024 the
+        # chip holds: a single 64x64 x 512-channel image, gradient mode) is still faster than the split-K tap-list launch + its reduce
+        return n * -(-h // 4) * -(-w // 32) * (cout // 32) >= 512
     return n * -(-h // 8) * -(-w // 32) * (cout // 32) >= 512
 
 

@@ -985,6 +985,12 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
         else if (small) { wm = 1; wn = 1; }
         // <= 32 output channels on a large map: 12-row tiles for 3x3 (measured 91 vs 87 TFLOP/s at 1024^2), 16-row tiles for 1x1
         else if ((int64_t)d.tile_h * d.tile_w >= 512 * 64) { wm = 1; wn = d.ntaps == 9 ? 3 : 4; }
+        // stride-2 convolutions (the data gradient of the up-sampling layers, IResNet's down-sampling convs): the footprint of a tile is
+        // four times that of a stride-1 tile and does not fit the pipeline's register slots, so these launches stage synchronously --
+        // with 128-lane tiles (4 x 32 outputs, 9 x 65 footprint: 37 KB of LDS, four workgroups per CU instead of two) the workgroups
+        // cover each other's staging phases
+        static const char* s2_env = getenv("MGF_S2_SMALL");          // tuning hook (experiments only): 0 keeps the 256-lane tile
+        if (d.istride == 2 && !(s2_env && s2_env[0] == '0')) wn = 1;
         // tuning hook (experiments only): MGF_CONV_TILE=wm,wn forces the tile of MODE-0 launches
         static const char* force = getenv("MGF_CONV_TILE");
         if (force && force[0] && force[1] == ',' && force[2]) {
