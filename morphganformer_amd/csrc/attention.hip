@@ -347,6 +347,151 @@ __global__ __launch_bounds__(256) void duplex_attention_reg_kernel(AttnParams p)
     }
 }
 
+// Multi-block variant of the kernel above (the 128x128 layers: 16384 pixels x 256 channels per sample): a workgroup walks NBLK consecutive pixel blocks with BOTH
+// [C][16] tables resident in LDS.  With one block per workgroup the two tables (32 KB from L2, 8 LDS stores of 16 bytes per lane)
+// were twice the bytes of the 16 KB of activations they served; the loads of block b+1 are issued before block b is finished.
+template <int PXB, int NCH, int NBLK>
+__global__ __launch_bounds__(256) void duplex_attention_blocks_kernel(AttnParams p) {
+    constexpr int G = 256 / PXB;
+    constexpr int TV = NCH * G / 64;              // float4 per lane that cover one [C][16] table (C*4 float4 / 256 lanes)
+    constexpr bool TWO = NBLK > 1;                // both tables resident
+    extern __shared__ float lds[];
+    float* tab = lds;                             // [C][16] wqc (then vwb when !TWO)
+    float* tabv = TWO ? lds + (size_t)p.c * TMAX : lds;                       // [C][16] vwb
+    float* part = lds + (size_t)p.c * TMAX * (TWO ? 2 : 1);                   // [G][17][PXB]
+    const int tid = threadIdx.x;
+    const int px = tid % PXB, grp = tid / PXB;
+    const int n = blockIdx.y;
+    const float* xn = p.x + (int64_t)n * p.c * p.f;
+    const float* rn = (p.has_ep && p.ep.residual) ? p.ep.residual + (int64_t)n * p.c * p.f : nullptr;
+    const float4* wq4 = reinterpret_cast<const float4*>(p.wqc);
+    const float4* vw4 = reinterpret_cast<const float4*>(p.vwb + (int64_t)n * p.c * TMAX);
+    const float ns = (p.has_ep && p.ep.noise) ? (p.ep.noise_strength ? *p.ep.noise_strength : 1.f) : 0.f;
+
+    float xreg[NCH], rreg[NCH], sp[TMAX];
+    float nz = 0.f;
+    auto load_block = [&](int blk) {               // one burst of independent loads
+        const int f = (blockIdx.x * NBLK + blk) * PXB + px;
+        const int fc = f < p.f ? f : p.f - 1;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
+            xreg[k] = xn[(int64_t)c * p.f + fc];
+            rreg[k] = rn ? rn[(int64_t)c * p.f + fc] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) sp[t] = p.spos[(int64_t)fc * TMAX + t];
+        if (p.has_ep && p.ep.noise) nz = p.ep.noise[(int64_t)(p.ep.noise_n > 1 ? n : 0) * p.f + fc] * ns;
+    };
+    float4 tq[TV], tv[TV];
+    load_block(0);
+#pragma unroll
+    for (int u = 0; u < TV; ++u) { tq[u] = wq4[tid + 256 * u]; tv[u] = vw4[tid + 256 * u]; }
+    float4* t4 = reinterpret_cast<float4*>(tab);
+    float4* t4v = reinterpret_cast<float4*>(tabv);
+#pragma unroll
+    for (int u = 0; u < TV; ++u) t4[tid + 256 * u] = tq[u];
+    if (TWO) {
+#pragma unroll
+        for (int u = 0; u < TV; ++u) t4v[tid + 256 * u] = tv[u];
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int blk = 0; blk < NBLK; ++blk) {
+        const int f = (blockIdx.x * NBLK + blk) * PXB + px;
+        const bool valid = f < p.f;
+        float s[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
+        float sq = 0.f;
+        float xk[NCH], rk[NCH];                    // this block's values; the registers of load_block go to the next block
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) { xk[k] = xreg[k]; rk[k] = rreg[k]; }
+        float spk[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) spk[t] = sp[t];
+        const float nzk = nz;
+        if (TWO && blk + 1 < NBLK) load_block(blk + 1);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
+            const float4* w4 = reinterpret_cast<const float4*>(tab + c * TMAX);
+            const float xv = xk[k];
+            sq += xv * xv;
+#pragma unroll
+            for (int q = 0; q < TMAX / 4; ++q) {
+                const float4 w = w4[q];
+                s[4 * q + 0] += xv * w.x; s[4 * q + 1] += xv * w.y;
+                s[4 * q + 2] += xv * w.z; s[4 * q + 3] += xv * w.w;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) part[(grp * (TMAX + 1) + t) * PXB + px] = s[t];
+        part[(grp * (TMAX + 1) + TMAX) * PXB + px] = sq;
+        __syncthreads();                           // (one table: all reads of the wqc table are done, overwrite it with vwb)
+        if (!TWO) {
+#pragma unroll
+            for (int u = 0; u < TV; ++u) t4[tid + 256 * u] = tv[u];
+        }
+        float m = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            float v = 0.f;
+            for (int g = 0; g < G; ++g) v += part[(g * (TMAX + 1) + t) * PXB + px];
+            v += spk[t];
+            m = fmaxf(m, v);
+            s[t] = v;
+        }
+        sq = 0.f;
+        for (int g = 0; g < G; ++g) sq += part[(g * (TMAX + 1) + TMAX) * PXB + px];
+        float den = 0.f;
+        int best = 0;
+        float bestv = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            if (s[t] > bestv) { bestv = s[t]; best = t; }
+            s[t] = __expf(s[t] - m);
+            den += s[t];
+        }
+        const float inv = 1.f / den;
+        const float rs = rsqrtf(sq / (float)p.c + 1e-8f);
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) s[t] *= inv;
+        if (grp == 0 && valid) {
+            if (p.probs)
+                for (int t = 0; t < TMAX; ++t) p.probs[((int64_t)n * p.f + f) * TMAX + t] = s[t];
+            if (p.argmax) p.argmax[(int64_t)n * p.f + f] = best;
+        }
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) s[t] *= rs;
+        __syncthreads();                           // `part` is free for the next block (one table: vwb is in place)
+
+        float* yn = p.y + (int64_t)n * p.c * p.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
+            const float4* w4 = reinterpret_cast<const float4*>(tabv + c * TMAX);
+            float g = 0.f;
+#pragma unroll
+            for (int q = 0; q < TMAX / 4; ++q) {
+                const float4 w = w4[q];
+                g += s[4 * q + 0] * w.x + s[4 * q + 1] * w.y + s[4 * q + 2] * w.z + s[4 * q + 3] * w.w;
+            }
+            float v = xk[k] * g;
+            if (p.has_ep) {
+                v += nzk;
+                if (p.ep.bias) v += p.ep.bias[c];
+                if (p.ep.act == MGF_ACT_LRELU) v = v > 0.f ? v : v * p.ep.alpha;
+                else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+                v *= p.ep.gain;
+                v += rk[k];
+            }
+            if (valid) yn[(int64_t)c * p.f + f] = v;
+        }
+    }
+}
+
 // list2tensor (networks.py:1222-1242): one layer's attention map [n, s*s, t] replicated (nearest neighbour = upsample2d with the
 // all-ones kernel) to the image resolution, written as slice `layer` of the stacked tensor [n, t, layers, 1, R, R]
 __global__ __launch_bounds__(256) void att_map_upsample_kernel(float* out, const float* probs, int t, int s, int R, int layer, int layers,
@@ -366,15 +511,24 @@ __global__ __launch_bounds__(256) void att_map_upsample_kernel(float* out, const
 template <int PXB>
 void launch_attention(const AttnParams& p, size_t lds, hipStream_t st) {
     constexpr int G = 256 / PXB;
-    const dim3 grid((unsigned)mgf_cdiv(p.f, PXB), p.n);
     const int nch = (p.c % (G * UNR) == 0) ? p.c / G : 0;
     if (p.t == TMAX && (nch == 16 || nch == 32 || nch == 64) && (nch * G) % 64 == 0) {
         const size_t lds_r = ((size_t)p.c * TMAX + (size_t)G * (TMAX + 1) * PXB) * sizeof(float);
+        // large maps with few channels (the 128x128 x 256 layers): 4 pixel blocks per workgroup, both tables resident
+        static const char* nb_env = getenv("MGF_ATTN_NBLK");      // tuning hook (experiments only): 1 = one block per workgroup
+        constexpr int NBLK = 4;
+        if (PXB == 16 && nch == 16 && p.f >= 4096 && p.f % (PXB * NBLK) == 0 && !(nb_env && nb_env[0] == '1')) {
+            const size_t lds_2 = ((size_t)2 * p.c * TMAX + (size_t)G * (TMAX + 1) * PXB) * sizeof(float);
+            hipLaunchKernelGGL((duplex_attention_blocks_kernel<PXB, 16, NBLK>), dim3((unsigned)(p.f / (PXB * NBLK)), p.n), dim3(256), lds_2, st, p);
+            return;
+        }
+        const dim3 grid((unsigned)mgf_cdiv(p.f, PXB), p.n);
         if (nch == 16) hipLaunchKernelGGL((duplex_attention_reg_kernel<PXB, 16>), grid, dim3(256), lds_r, st, p);
         else if (nch == 32) hipLaunchKernelGGL((duplex_attention_reg_kernel<PXB, 32>), grid, dim3(256), lds_r, st, p);
         else hipLaunchKernelGGL((duplex_attention_reg_kernel<PXB, 64>), grid, dim3(256), lds_r, st, p);
         return;
     }
+    const dim3 grid((unsigned)mgf_cdiv(p.f, PXB), p.n);
     hipLaunchKernelGGL((duplex_attention_kernel<PXB, 0>), grid, dim3(256), lds, st, p);
 }
 
