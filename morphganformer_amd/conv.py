@@ -286,10 +286,65 @@ def conv_large_forward(x, w, bias, stride, pad, act="relu", out=None):
         ep = None if g0 == 0 else _lib.make_epilogue(residual=out)
         conv_forward(x, pc, stride=stride, pad=(pad, pad), epilogue=ep, out=out, taps=[(a - pad, b - pad) for a, b in grp],
                      ksize=(kh, kw))
+    if bias is None and act == "linear":
+        return out
     act_code = {"linear": 1, "relu": 2}[act]
     _lib.check(_lib.lib().mgf_bias_act(out.data_ptr(), out.data_ptr(), _lib.ptr(bias), None, None, None, _lib.MGF_F32, out.numel(),
                                        oh * ow, cout, 0, act_code, 0.0, 1.0, -1.0, _lib.stream_ptr()), "bias_act")
     return out
+
+
+def conv_large_dgrad(dy, w, pad, out=None):
+    """Data gradient of a stride-1 convolution with more than 9 taps (AlexNet's 5x5): dx = correlation of dy with the spatially
+    flipped, channel-transposed kernel, padding k - 1 - pad -- the same chained <= 9-tap launches as conv_large_forward."""
+    cout, cin, kh, kw = w.shape
+    wt = w.permute(1, 0, 2, 3).flip(2, 3).contiguous()             # [cin, cout, kh, kw]
+    assert kh == kw and kh - 1 - pad >= 0
+    return conv_large_forward(dy, wt, None, 1, kh - 1 - pad, act="linear", out=out)
+
+
+def conv_strided_dgrad(dy, w, stride, pad, in_hw, out=None):
+    """Data gradient of a strided convolution y = conv(x, w, stride, pad) with a large kernel (AlexNet's 11x11 / stride 4 stem):
+    dx[s i + kh - pad] += w[co, ci, kh, kw] dy[co, i].  The stride^2 output phases are independent stride-1 correlations of dy with the
+    sub-kernels w[.., r + s t, r' + s u] (<= 9 taps each for 11x11 / 4), run as tap-list launches into a phase-planar buffer that one
+    strided copy interleaves into dx [n, cin, H, W]."""
+    _lib.require_gpu(dy, w)
+    cout, cin, kh, kw = w.shape
+    n, _, hy, wy = dy.shape
+    H, W = in_hw
+    s = stride
+    hq, wq = -(-H // s), -(-W // s)
+    if out is None:
+        out = torch.empty([n, cin, H, W], dtype=torch.float32, device=dy.device)
+    phase = torch.empty([n, cin, hq, wq], dtype=torch.float32, device=dy.device)
+
+    def geom(diff):                 # (pad, ksize) that make conv_forward's output hq = hy + diff long (the taps are given explicitly)
+        assert diff >= 0
+        return ((diff + 1) // 2, 2) if diff % 2 else (diff // 2, 1)
+
+    (py_, ky_), (px_, kx_) = geom(hq - hy), geom(wq - wy)
+    key = (w.data_ptr(), tuple(w.shape), s, pad)
+    plan = _STRIDED_PLANS.get(key)
+    if plan is None:                # the phase sub-kernels are a checkpoint constant: packed once
+        plan = []
+        for a in range(s):
+            ry, qy = (a + pad) % s, (a + pad) // s
+            ts = [t for t in range(-(-kh // s)) if ry + s * t < kh]
+            for b in range(s):
+                rx, qx = (b + pad) % s, (b + pad) // s
+                us = [u for u in range(-(-kw // s)) if rx + s * u < kw]
+                sub = torch.stack([w[:, :, ry + s * t, rx + s * u] for t in ts for u in us], dim=-1)        # [cout, cin, taps]
+                pc = pack_weights(sub.permute(1, 0, 2).reshape(cin, cout, 1, len(ts) * len(us)).contiguous())
+                plan.append((a, b, pc, [(qy - t, qx - u) for t in ts for u in us]))
+        _STRIDED_PLANS[key] = plan
+    for a, b, pc, taps in plan:
+        conv_forward(dy, pc, pad=(py_, px_), taps=taps, ksize=(ky_, kx_), out=phase)
+        dst = out[:, :, a::s, b::s]
+        dst.copy_(phase[:, :, :dst.shape[2], :dst.shape[3]])
+    return out
+
+
+_STRIDED_PLANS = {}
 
 
 TCONV_TAPS = [(-1 if kh == 2 else 0, -1 if kw == 2 else 0) for kh in range(3) for kw in range(3)]

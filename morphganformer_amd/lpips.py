@@ -164,14 +164,13 @@ class SequentialFeatures:
     def backward(self, target_taps, lins, scale, per_sample=False):
         """Gradient of  scale * sum_taps lpips_layer(tap, target_tap)  with respect to the input image of the latest __call__
         (taps in the internal workspace); per_sample: target_taps hold one target per sample instead of one shared target.
-        3x3 / stride-1 stacks only (VGG16): AlexNet's 11x11 stride-4 stem has no dgrad kernel."""
+        3x3 / stride-1 layers take the tap-list kernel on transposed, flipped taps; AlexNet's 5x5 runs as chained <= 9-tap launches
+        (conv.conv_large_dgrad) and its 11x11 / stride-4 stem as 16 phase launches (conv.conv_strided_dgrad)."""
         L, st = _lib.lib(), _lib.stream_ptr()
         rows = [(row, buf) for row, buf in zip(self.spec, self.bufs)]
-        if any(r[0] == "conv" and (r[4] != 3 or r[5] != 1) for r, _ in rows):
-            raise NotImplementedError("LPIPS backward: only 3x3 stride-1 backbones (squeeze, vgg)")
         if not self.gp:
             for row in self.spec:
-                if row[0] == "conv":
+                if row[0] == "conv" and row[4] == 3:
                     self.gp[row[1]] = cv.transpose_packed(self.convs[row[1]][0], flip=True)
         if getattr(self, "gbufs", None) is None:
             self.gbufs = [None if b is None else torch.empty_like(b) for b in self.bufs]
@@ -197,7 +196,13 @@ class SequentialFeatures:
             gprev = self.gbufs[nodes[pos - 1]] if pos > 0 else self.gxs
             if row[0] == "conv":
                 _lib.check(L.mgf_relu_bwd_split_f32(gh.data_ptr(), None, gh.data_ptr(), h.data_ptr(), n, c, c, hh * ww, st), "relu_bwd")
-                cv.conv_forward(gh, self.gp[row[1]], pad=(1, 1), out=gprev)
+                _, idx, _ci, _co, k, stride, pad = row
+                if k == 3 and stride == 1:
+                    cv.conv_forward(gh, self.gp[idx], pad=(1, 1), out=gprev)
+                elif stride == 1:
+                    cv.conv_large_dgrad(gh, self.convs[idx][0], pad, out=gprev)
+                else:
+                    cv.conv_strided_dgrad(gh, self.convs[idx][0], stride, pad, tuple(prev.shape[2:]), out=gprev)
             else:
                 _lib.check(L.mgf_maxpool_s2_floor_bwd_f32(gprev.data_ptr(), gh.data_ptr(), prev.data_ptr(), n * c, prev.shape[2],
                                                           prev.shape[3], row[1], st), "maxpool_bwd")
@@ -447,8 +452,6 @@ class PerceptualLoss(torch.nn.Module):
     def grad_into(self, dimg, scale=1.0, accumulate=False):
         """dimg (+)= d(scale * distance)/d(pred) for the pred of the latest `distance_into(..., keep_taps=True)` call
         (what autograd computes through networks_basic.py:64-92 and the backbone).  SqueezeNet and VGG16 backbones."""
-        if self.net == "alex":
-            raise NotImplementedError("gradient mode: AlexNet's 11x11 stride-4 stem has no dgrad kernel (squeeze and vgg do)")
         f = self._last
         assert f is not None and tuple(dimg.shape) == (f.n, 3, *self._last_hw), "call distance_into(..., keep_taps=True) first"
         g = f.backward(self._target_taps, self.lins, scale, per_sample=self._target_n > 1)

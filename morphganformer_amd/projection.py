@@ -427,7 +427,6 @@ class GradientProjectionEngine(ProjectionEngine):
                              seed, use_graph, biometric, gamma, wing_kind)
             assert landmark_fn is None and landmark_model is None, "landmark detectors are wired for one target per engine"
         self.targets = B
-        assert self.percept is None or self.percept.net in ("squeeze", "vgg"), "gradient mode: LPIPS backward exists for squeeze and vgg"
         a, dev = self.args, self.device
         self.gg = GeneratorGrad(G)
         self.betas, self.adam_eps, self.weight_decay = betas, float(adam_eps), float(weight_decay)

@@ -166,7 +166,7 @@ def test_tiny_gradient_matches_reference_module(tiny, golden):
     assert rel(dz, g["grad_z"]) < GRAD_TOL
 
 
-@pytest.mark.parametrize("net,size", [("squeeze", 65), ("squeeze", 128), ("vgg", 48), ("vgg", 70)])
+@pytest.mark.parametrize("net,size", [("squeeze", 65), ("squeeze", 128), ("vgg", 48), ("vgg", 70), ("alex", 96), ("alex", 131), ("alex", 224)])
 def test_lpips_gradient_matches_autograd(net, size):
     from morphganformer_amd.lpips import PerceptualLoss, random_backbone, WEIGHTS_DIR
     from oracle.loss_ref import backbone_random, lpips_ref
@@ -314,8 +314,9 @@ def test_biometric_gradient_matches_autograd(size):
     assert float(err.median()) < 1e-5 and float(err.square().mean().sqrt()) < 1e-3
 
 
-def test_gradient_projection_with_vgg_and_biometric_terms(tiny):
-    """The full north-star objective in gradient mode (LPIPS(vgg) + lamda Wing + beta MSE + gamma embedding MSE): runs as a
+@pytest.mark.parametrize("net", ["vgg", "alex"])
+def test_gradient_projection_with_vgg_and_biometric_terms(tiny, net):
+    """The full north-star objective in gradient mode (LPIPS(vgg | alex) + lamda Wing + beta MSE + gamma embedding MSE): runs as a
     replayed graph, moves the latent, and its first loss equals the literal engine's loss of the same candidate."""
     from morphganformer_amd.iresnet import BiometricLoss, IResNetEmbedder
     from morphganformer_amd.lpips import PerceptualLoss
@@ -329,7 +330,7 @@ def test_gradient_projection_with_vgg_and_biometric_terms(tiny):
     target = G(torch.randn(1, cfg.k, cfg.z_dim, device="cuda"), None, noise_mode="const")[0].clamp(-1, 1).clone()
     lm_t, lm_s = synthetic_landmarks(steps, 64, 9)
     args = ProjectionArgs(step=steps, lr=0.05, lr_rampup=0.2, min_loss_init=1e30)
-    mk = lambda cls, **kw: cls(G, target, latent_mean, 1.0, args, percept=PerceptualLoss(net="vgg", allow_random_backbone=True), lm_target=lm_t, lm_steps=lm_s,
+    mk = lambda cls, **kw: cls(G, target, latent_mean, 1.0, args, percept=PerceptualLoss(net=net, allow_random_backbone=True), lm_target=lm_t, lm_steps=lm_s,
                                eps=eps, noise_mode="const", biometric=BiometricLoss(IResNetEmbedder(None, depth=18, n=1, device="cuda")),
                                gamma=1e-3, **kw)
     lit = mk(ProjectionEngine, batch=1, use_graph=False).run(1)
