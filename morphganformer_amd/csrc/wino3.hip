@@ -43,6 +43,7 @@ struct Wino3Params {
     const float* out_scale;   // [n or 1][cout] or null
     int n, cin, h, w, cout, os_stride;
     int tiles_x, tiles_y, co_tiles;
+    int xcd_per;              // > 0: XCD-aware work order (see the kernel); 0: work item = blockIdx.x
     mgf_epilogue ep;
     int has_ep;
     const float* rgb_w;       // [n][rgb_channels][cout]
@@ -73,7 +74,16 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     const int l31 = lane & 31, half = lane >> 5;
     const int tx = l31 & 15, ty = l31 >> 4;
 
+    // Work item -> (channel tile fastest, pixel tile, sample).  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one),
+    // each with its own L2.  With xcd_per > 0, XCD (b % 8) walks the CONTIGUOUS item range [(b % 8) * xcd_per, +xcd_per): all channel
+    // tiles of a pixel tile -- which read the same input footprint -- and its neighbours run on one XCD, so the footprint comes from
+    // fabric once instead of once per XCD.  Used when the layer's transformed weights (16 * cin * cout floats, then read by every
+    // workgroup of the XCD) fit its 4 MB L2; for the 512-channel layers the plain order (two channel tiles per XCD) moves fewer bytes.
     int b_ = blockIdx.x;
+    if (p.xcd_per > 0) {
+        b_ = (b_ & 7) * p.xcd_per + (b_ >> 3);
+        if (b_ >= p.n * p.tiles_x * p.tiles_y * p.co_tiles) return;
+    }
     const int cot = b_ % p.co_tiles; b_ /= p.co_tiles;
     const int ptx = b_ % p.tiles_x; b_ /= p.tiles_x;
     const int pty = b_ % p.tiles_y;
@@ -393,8 +403,14 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     p.has_ep = ep != nullptr;
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
     p.rgb_w = rgb_w; p.rgb_bias = rgb_bias; p.rgb_out = rgb_out; p.rgb_channels = rgb_channels;
-    const int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
-    MGF_REQUIRE(blocks <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd3: too many workgroups");
+    int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
+    MGF_REQUIRE(blocks <= INT32_MAX - 8, MGF_ETOOBIG, "conv3x3_winograd3: too many workgroups");
+    static const char* xcd_env = getenv("MGF_XCD");             // tuning hook (experiments only): 0 disables the XCD-aware order
+    p.xcd_per = 0;
+    if (p.co_tiles > 1 && (int64_t)16 * cin * cout * 4 <= (4 << 20) && blocks >= 16 && !(xcd_env && xcd_env[0] == '0')) {
+        p.xcd_per = (int)((blocks + 7) / 8);
+        blocks = (int64_t)p.xcd_per * 8;
+    }
     // main loop: two footprint buffers + the styles; epilogue: 6 exchange slots (+ the ToRGB weights) over the same memory
     const size_t nv = cb * tb == 2 ? 32 : 16;
     const size_t lds = std::max<size_t>((size_t)(2 * 256 * (tb == 2 ? 6 : 4) + cin) * sizeof(float), (size_t)(6 * nv * 64 + 96) * sizeof(float));
