@@ -35,7 +35,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CK = 8;          // input channels per K chunk
 // per-lane register staging slots of the pipelined kernels: XS floats of the input footprint, WS float4 of the weight slab
 template <int WM, int WN> struct Slots {
-    static constexpr int XS = WN == 4 ? 20 : (WN == 3 ? 15 : (WN == 1 ? 7 : 11));   // 16x32 tile: 8*18*34 = 4896 floats; 12x32: 3808; 8x32: 2720; 4x32: 1632
+    // 16x32 tile: 8*18*34 = 4896 floats; 12x32: 3808; 8x32: 2720; 4x32: 1632 -- and 8*9*65 = 4680 for the 4x32 tile of a STRIDE-2 3x3
+    // conv (the data gradient of the up-sampling layers), which makes the 128-lane tile's slot count 19 instead of 7
+    static constexpr int XS = WN == 4 ? 20 : (WN == 3 ? 15 : (WN == 1 ? 19 : 11));
     static constexpr int WS = WM == 2 ? 5 : 3;        // 9*8*64/4 = 1152 float4; 9*8*32/4 = 576
 };
 
