@@ -173,6 +173,13 @@ int mgf_conv3x3_winograd2_f32(float* y, const float* x, const float* u, const fl
 int mgf_conv3x3_winograd3_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
                               int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
                               mgf_stream_t stream);
+/* form 3 with the epilogue's residual given at HALF resolution: residual_low [n, cout, h/2, w/2] is up-sampled 2x inside the epilogue with the
+ * [1,3,3,1] (x) [1,3,3,1] / 16 filter of upfirdn2d.upsample2d(x, f, up=2) (padding [2,1,2,1], gain 4; torch_utils/ops/upfirdn2d.py:300-336) and
+ * added after the gain, i.e. y = act(...) * gain + upsample2d(residual_low).  This is the resnet skip branch of a SynthesisBlock
+ * (training/networks.py:1157-1160, 245-250, conv2d_resample.py:105-108) without its full-resolution tensor.  ep->residual must be NULL. */
+int mgf_conv3x3_winograd3_up2res_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale,
+                                     const float* residual_low, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                                     int32_t out_scale_stride, const mgf_epilogue* ep, mgf_stream_t stream);
 /* tuning / test hook: pin the workgroup shape of the form-3 launches (0 = automatic choice; 21 = 64 channels x 32 tiles, 12 = 32 x 64,
  * 11 = 32 x 32 with three workgroups per CU); a shape that does not fit the call (21 with cout % 64 != 0) falls back to the automatic one */
 int mgf_winograd3_force_shape(int32_t shape);

@@ -175,10 +175,25 @@ def winograd3_ok(x, out, out_choff):
             (out is None or out.shape[1] == out.shape[1] and out.is_contiguous()))
 
 
-def winograd2_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None, out_choff=0):
+def winograd2_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None, out_choff=0, residual_low=None):
     """3x3 / stride 1 / pad 1 correlation on weights in the [16, cin/4, cout, 4] layout.  Form 3 serves dense outputs on even maps;
-    form 2 (and only it) may write channels [out_choff, out_choff + cout) of a wider `out` and takes odd map sides."""
-    _lib.require_gpu(x, u, in_scale, out_scale, out)
+    form 2 (and only it) may write channels [out_choff, out_choff + cout) of a wider `out` and takes odd map sides.
+    residual_low [n, cout, h/2, w/2] (form 3 only): the epilogue adds upsample2d(residual_low, [1,3,3,1], up=2) -- the resnet skip branch
+    without its full-resolution tensor (mgf_conv3x3_winograd3_up2res_f32)."""
+    _lib.require_gpu(x, u, in_scale, out_scale, out, residual_low)
+    if residual_low is not None:
+        n, cin, h, w = x.shape
+        cout = u.shape[2]
+        assert winograd3_ok(x, out, out_choff) and epilogue is not None, "residual_low needs the form-3 kernel and an epilogue"
+        assert residual_low.is_contiguous() and tuple(residual_low.shape) == (n, cout, h // 2, w // 2) and residual_low.dtype == torch.float32
+        if out is None:
+            out = torch.empty([n, cout, h, w], dtype=torch.float32, device=x.device)
+        assert out.is_contiguous() and tuple(out.shape) == (n, cout, h, w)
+        os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
+        _lib.check(_lib.lib().mgf_conv3x3_winograd3_up2res_f32(out.data_ptr(), x.data_ptr(), u.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                                               residual_low.data_ptr(), n, cin, h, w, cout, os_stride, C.byref(epilogue),
+                                                               _lib.stream_ptr()), "conv3x3_winograd3_up2res")
+        return out
     if winograd3_ok(x, out, out_choff) and (out is None or out.shape[1] == u.shape[2]):
         assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and u.ndim == 4 and x.shape[1] == u.shape[1] * 4
         n, cin, h, w = x.shape
@@ -250,11 +265,12 @@ def winograd_pack(w: torch.Tensor, gain: float, res: int) -> torch.Tensor:
     return winograd_weights(w, gain) if res <= 16 else winograd2_weights(w, gain)
 
 
-def winograd_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None):
+def winograd_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None, residual_low=None):
     """3x3 / stride 1 / pad 1 correlation through the Winograd F(2x2,3x3) kernels; same contract as conv_forward(pad=(1, 1)).
     u: [16, cin, cout] (winograd_weights) or [16, cin / 4, cout, 4] (winograd2_weights)."""
     if u.ndim == 4:
-        return winograd2_forward(x, u, in_scale, out_scale, epilogue, out)
+        return winograd2_forward(x, u, in_scale, out_scale, epilogue, out, residual_low=residual_low)
+    assert residual_low is None
     _lib.require_gpu(x, u, in_scale, out_scale, out)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and x.shape[1] == u.shape[1]
     n, cin, h, w = x.shape

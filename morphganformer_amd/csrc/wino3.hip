@@ -50,6 +50,7 @@ struct Wino3Params {
     const float* rgb_bias;    // [rgb_channels] or null
     float* rgb_out;           // [n][rgb_channels][h][w]
     int rgb_channels;
+    const float* res_low;     // [n][cout][h/2][w/2] or null: the residual at HALF resolution, 2x up-sampled in the epilogue
 };
 
 #ifndef W3_OCC1
@@ -325,12 +326,49 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         for (int k = 0; k < NR; ++k)
             rr[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rres, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0));
     }
+    // The residual at half resolution (the resnet skip branch: 1x1 conv at the block's INPUT resolution, networks.py:1157,245-250), 2x
+    // up-sampled here with the [1,3,3,1] (x) [1,3,3,1] / 16 filter of upfirdn2d.upsample2d (up = 2, padding [2,1,2,1], gain 4):
+    //   out[2m] = x[m-1] / 4 + 3 x[m] / 4,   out[2m+1] = 3 x[m] / 4 + x[m+1] / 4   per axis, zeros outside the map.
+    // The workgroup's 4 x 18 low-resolution window of its 32 channels (9 KB) goes through LDS, behind the exchange slots: the full
+    // resolution skip tensor -- one write and one read of the largest activation of the block -- never exists.
+    float* lowt = lds + 6 * NV * 64;                 // [32 channels][4 rows][18 columns]
+    if (UMODE == 1 && p.res_low) {
+        const int hl = p.h >> 1, wl = p.w >> 1, pl = hl * wl;
+        const __amdgpu_buffer_rsrc_t rlow = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res_low + ((int64_t)n * p.cout + co0) * pl), 0, 32 * pl * 4, 0x00020000);
+        const int m0 = (oy0 >> 1) - 1, n0 = (ox0 >> 1) - 1;
+        float lv[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int e = tid + 256 * j;
+            const int ch = e / 72, rem = e - ch * 72;
+            const int r = rem / 18, c = rem - r * 18;
+            const int my = m0 + r, nx = n0 + c;
+            const unsigned off = (my >= 0 && my < hl && nx >= 0 && nx < wl) ? (unsigned)(ch * pl + my * wl + nx) * 4u : 0xFFFFFFF0u;
+            lv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rlow, off, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) lowt[tid + 256 * j] = lv[j];
+    }
     if (do_ep && p.ep.noise && ok_px) {
         const float ns = p.ep.noise_strength ? *p.ep.noise_strength : 1.f;
         const float2 nv = *reinterpret_cast<const float2*>(p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane + (int64_t)oy * p.w + ox);
         nz0 = nv.x * ns; nz1 = nv.y * ns;
     }
     __syncthreads();
+    if (UMODE == 1 && p.res_low) {
+        // this wave's output row is oy = oy0 + 2 trow + orow: low rows (m-1, m) with weights (1/4, 3/4) for orow = 0, (m, m+1) with
+        // (3/4, 1/4) for orow = 1, i.e. window rows trow + orow and trow + orow + 1; window columns tx, tx + 1, tx + 2
+        const float wa = orow ? 0.75f : 0.25f, wb = 1.f - wa;
+        const int chl = cob - co0;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const float* lp = lowt + (chl + (k & 3) + 8 * (k >> 2)) * 72 + (trow + orow) * 18 + tx;
+            const float a0 = lp[0], a1 = lp[1], a2 = lp[2], b0 = lp[18], b1 = lp[19], b2 = lp[20];
+            const float c0 = wa * a0 + wb * b0, c1 = wa * a1 + wb * b1, c2 = wa * a2 + wb * b2;
+            rr[k].x = 0.25f * c0 + 0.75f * c1;
+            rr[k].y = 0.75f * c1 + 0.25f * c2;
+        }
+    }
     {
         float* yb = p.y + (int64_t)n * p.cout * plane;
 #pragma unroll
@@ -366,7 +404,7 @@ extern "C" int mgf_winograd3_force_shape(int32_t shape) {
 
 static int launch_wino3(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n, int32_t cin, int32_t h,
                         int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep, const float* rgb_w, const float* rgb_bias,
-                        float* rgb_out, int32_t rgb_channels, mgf_stream_t stream) {
+                        float* rgb_out, int32_t rgb_channels, mgf_stream_t stream, const float* res_low = nullptr) {
     const bool rgb = rgb_out != nullptr;
     MGF_REQUIRE((y || rgb) && x && u && n >= 1 && cin >= 1 && cout >= 1 && h >= 2 && w >= 2, MGF_EINVAL, "conv3x3_winograd3: bad arguments");
     MGF_REQUIRE(cin % W3CK == 0 && cout % 32 == 0, MGF_EUNSUPPORTED, "conv3x3_winograd3: cin must be a multiple of %d and cout of 32 (got %d, %d)",
@@ -403,6 +441,12 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     p.has_ep = ep != nullptr;
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
     p.rgb_w = rgb_w; p.rgb_bias = rgb_bias; p.rgb_out = rgb_out; p.rgb_channels = rgb_channels;
+    p.res_low = res_low;
+    if (res_low) {
+        MGF_REQUIRE(ep && !ep->residual && !rgb, MGF_EINVAL, "conv3x3_winograd3_up2res: needs an epilogue without a full-resolution residual");
+        MGF_REQUIRE(shape == 11, MGF_EUNSUPPORTED, "conv3x3_winograd3_up2res: only the 32x32-tile shape takes the half-resolution residual");
+        MGF_REQUIRE((int64_t)32 * (h / 2) * (w / 2) * 4 <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd3_up2res: map too large");
+    }
     int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
     MGF_REQUIRE(blocks <= INT32_MAX - 8, MGF_ETOOBIG, "conv3x3_winograd3: too many workgroups");
     static const char* xcd_env = getenv("MGF_XCD");             // tuning hook (experiments only): 0 disables the XCD-aware order
@@ -413,7 +457,8 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     }
     // main loop: two footprint buffers + the styles; epilogue: 6 exchange slots (+ the ToRGB weights) over the same memory
     const size_t nv = cb * tb == 2 ? 32 : 16;
-    const size_t lds = std::max<size_t>((size_t)(2 * 256 * (tb == 2 ? 6 : 4) + cin) * sizeof(float), (size_t)(6 * nv * 64 + 96) * sizeof(float));
+    const size_t lds = std::max<size_t>((size_t)(2 * 256 * (tb == 2 ? 6 : 4) + cin) * sizeof(float),
+                                        (size_t)(6 * nv * 64 + (res_low ? 2304 : 96)) * sizeof(float));
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)wino3_conv_kernel<2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -443,6 +488,13 @@ extern "C" int mgf_conv3x3_winograd3_f32(float* y, const float* x, const float* 
                                          int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
                                          mgf_stream_t stream) {
     return launch_wino3(y, x, u, in_scale, out_scale, n, cin, h, w, cout, out_scale_stride, ep, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mgf_conv3x3_winograd3_up2res_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale,
+                                                const float* residual_low, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                                                int32_t out_scale_stride, const mgf_epilogue* ep, mgf_stream_t stream) {
+    MGF_REQUIRE(residual_low, MGF_EINVAL, "conv3x3_winograd3_up2res: null residual");
+    return launch_wino3(y, x, u, in_scale, out_scale, n, cin, h, w, cout, out_scale_stride, ep, nullptr, nullptr, nullptr, 0, stream, residual_low);
 }
 
 extern "C" int mgf_conv3x3_winograd3_rgb_f32(float* rgb_out, const float* x, const float* u, const float* in_scale, const float* out_scale,

@@ -128,6 +128,10 @@ class SynthesisPlan:
         self.mapping_blob = t32(pack_mapping_params(sd, cfg))
         self.const = t32(f64("synthesis.b4.const"))
         self.fir = t32(f64(f"synthesis.b{cfg.block_resolutions[-1]}.resample_kernel"))
+        # the resample filter every checkpoint of the reference has (networks.py:1113, resample_kernel = [1,3,3,1]): the form-3 Winograd
+        # epilogue up-samples the resnet skip branch with it in place (hard-wired taps), any other filter keeps the separate FIR pass
+        self.fir_is_1331 = bool(np.allclose(f64(f"synthesis.b{cfg.block_resolutions[-1]}.resample_kernel"),
+                                            np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0, rtol=0, atol=1e-7))
         self.layers: list[ConvLayerPlan] = []
         self.skips = {}
         s_off = d_off = v_off = 0
@@ -219,6 +223,7 @@ class Generator:
         self._ws_cache = {}
         self.taps = None
         self.fuse_torgb = True
+        self.fuse_skip_up = os.environ.get("MGF_FUSE_SKIP_UP", "1") != "0"      # tuning hook: 0 = the skip branch's own 2x FIR pass everywhere
         self.last_noise = ("none", None)      # (noise_mode, noises) of the latest synthesis call, read by grad.SynthesisGrad
         self.side = torch.cuda.Stream(device=self.device)
         # MGF_OVERLAP_SKIP=1 forks the skip branch onto the side stream (+0.9 % iterations/s).  Off by default for the same reason
@@ -434,19 +439,29 @@ class Generator:
             else:
                 # the resnet skip branch (1x1 conv + 2x FIR upsample: memory bound) runs on a side stream next to conv0's
                 # MFMA-bound transposed conv; both only read x, and conv1 joins them
+                l1 = layers[b + ".conv1"]
+                # conv1 on the form-3 Winograd kernel without attention (256^2 and larger): its epilogue up-samples the half-resolution
+                # skip output itself -- no fir_up2 pass, no full-resolution skip tensor (one write + one read of the block's largest map)
+                fuse_up = (self.fuse_skip_up and P.fir_is_1331 and cv.WINOGRAD_FORM == 3 and l1.attn is None and l1.wino_u is not None
+                           and l1.wino_u.ndim == 4 and res % 2 == 0 and cv.winograd_fills_chip(n, l1.cout, res, res))
                 main = torch.cuda.current_stream(self.device)
                 if self.overlap_skip:
                     self.side.wait_stream(main)
                     with torch.cuda.stream(self.side):
                         cv.conv_forward(x, P.skips[res], out=B["skip_low"])
-                        cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0, separable=True)
+                        if not fuse_up:
+                            cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0, separable=True)
                 else:
                     cv.conv_forward(x, P.skips[res], out=B["skip_low"])
-                    cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0, separable=True)
+                    if not fuse_up:
+                        cv.upfirdn_into(B["skip"], B["skip_low"], P.fir, up=2, pad=(2, 1, 2, 1), gain=4.0, separable=True)
                 x0 = self._layer(layers[b + ".conv0"], x, B, "conv0", noise_mode, noises, residual=None)
                 if self.overlap_skip:
                     main.wait_stream(self.side)
-                x = self._layer(layers[b + ".conv1"], x0, B, "conv1", noise_mode, noises, residual=B["skip"])
+                if fuse_up:
+                    x = self._layer(l1, x0, B, "conv1", noise_mode, noises, residual=None, residual_low=B["skip_low"])
+                else:
+                    x = self._layer(l1, x0, B, "conv1", noise_mode, noises, residual=B["skip"])
             if self.taps is not None:
                 self.taps[b] = x
             if res == cfg.img_resolution:
@@ -511,7 +526,7 @@ class Generator:
             off += r * r
         return out
 
-    def _layer(self, lp, x, B, key, noise_mode, noises, residual):
+    def _layer(self, lp, x, B, key, noise_mode, noises, residual, residual_low=None):
         """One SynthesisLayer (networks.py:1010-1042): modulated conv (+FIR) -> [attention] -> noise -> bias/lrelu."""
         n = x.shape[0]
         noise, noise_n = self._noise_for(lp, noise_mode, noises)
@@ -525,7 +540,8 @@ class Generator:
             y = cv.upfirdn_into(B[key], t, self.plan.fir, up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=None if has_att else ep,
                                 separable=True)
         elif lp.wino_u is not None and cv.winograd_fills_chip(n, lp.cout, lp.res, lp.res):
-            y = cv.winograd_forward(x, lp.wino_u, in_scale=s, out_scale=d, epilogue=None if has_att else ep, out=B[key])
+            y = cv.winograd_forward(x, lp.wino_u, in_scale=s, out_scale=d, epilogue=None if has_att else ep, out=B[key],
+                                    residual_low=residual_low)
         else:
             y = cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=s, out_scale=d, epilogue=None if has_att else ep, out=B[key])
         if self.taps is not None:

@@ -103,7 +103,8 @@ class GeneratorGrad:
             if ws.ndim == 4 and ws.stride(2) != 0:
                 raise _lib.MgfError("GeneratorGrad: per-layer ws (W+) has no backward pass; pass z, or a ws broadcast over the layer axis")
             w = (ws[:, :, 0] if ws.ndim == 4 else ws).contiguous().float()
-        G.fuse_torgb = False
+        # the backward pass reads conv_last's activation and the full-resolution skip tensors: both fusions off for this forward
+        G.fuse_torgb, keep_up, G.fuse_skip_up = False, G.fuse_skip_up, False
         try:
             if ws is not None:
                 if w.shape[0] != G.n:
@@ -112,7 +113,7 @@ class GeneratorGrad:
             else:
                 img = G.forward_workspace(z, None, truncation_psi=truncation_psi, noise_mode=noise_mode, noises=noises)[0]
         finally:
-            G.fuse_torgb = True
+            G.fuse_torgb, G.fuse_skip_up = True, keep_up
         self.z = None if z is None else z.contiguous().float()
         self.psi = float(truncation_psi) if ws is None else 1.0
         if self._n != G.n:            # after G: its style / demod arenas (pointed to by the job tables) are sized by then

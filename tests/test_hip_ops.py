@@ -377,3 +377,32 @@ def test_winograd_odd_maps_and_channel_slices(n, cin, cout, h, w, ctotal, choff)
     mask = torch.ones(ctotal, dtype=torch.bool)
     mask[choff:choff + cout] = False
     assert bool((out[:, mask.cuda()] == 7.0).all())
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 32, 32, 64, 64), (1, 16, 64, 20, 36), (3, 8, 96, 8, 2)])
+def test_winograd3_half_resolution_residual(n, cin, cout, h, w):
+    """Form 3 with the resnet skip branch given at half resolution: the epilogue's in-place 2x up-sampling ([1,3,3,1] filter, padding
+    [2,1,2,1], gain 4) against the reference-pinned upfirdn2d oracle, and against the two-launch path (FIR pass + full-size residual)."""
+    from morphganformer_amd import _lib, conv as cv
+    from oracle.ops_ref import bias_act_ref, setup_filter_ref, upfirdn2d_ref
+    torch.manual_seed(cout + h)
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+    s, d = 1 + 0.3 * torch.randn(n, cin), 0.5 + torch.rand(n, cout)
+    noise, bias, low = torch.randn(n, h, w), torch.randn(cout), torch.randn(n, cout, h // 2, w // 2)
+    strength = torch.tensor([0.37])
+    f = setup_filter_ref([1, 3, 3, 1])
+    skip = upfirdn2d_ref(low, f, up=2, padding=[2, 1, 2, 1], gain=4.0)
+    ref = torch.nn.functional.conv2d((x * s[:, :, None, None]).double(), wt.double(), padding=1) * d[:, :, None, None].double()
+    ref = bias_act_ref(ref.float() + noise[:, None] * strength, bias, act="lrelu", gain=1.3) + skip
+    g = lambda t: t.cuda().contiguous()
+    xd, sd, dd, nd, bd, ld, st = g(x), g(s), g(d), g(noise), g(bias), g(low), strength.cuda()
+    u = cv.winograd2_weights(g(wt), gain=1.0)
+    ep = _lib.make_epilogue(bias=bd, noise=nd, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.3)
+    out = cv.winograd_forward(xd, u, in_scale=sd, out_scale=dd, epilogue=ep, residual_low=ld)
+    assert rel_err(out, ref) < 2e-5
+    full = torch.empty(n, cout, h, w, device="cuda")
+    cv.upfirdn_into(full, ld, g(f), up=2, pad=(2, 1, 2, 1), gain=4.0, separable=True)
+    ep2 = _lib.make_epilogue(bias=bd, noise=nd, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.3, residual=full)
+    two = cv.winograd_forward(xd, u, in_scale=sd, out_scale=dd, epilogue=ep2)
+    assert rel_err(out, two) < 2e-6
