@@ -451,7 +451,9 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     MGF_REQUIRE(blocks <= INT32_MAX - 8, MGF_ETOOBIG, "conv3x3_winograd3: too many workgroups");
     static const char* xcd_env = getenv("MGF_XCD");             // tuning hook (experiments only): 0 disables the XCD-aware order
     p.xcd_per = 0;
-    if (p.co_tiles > 1 && (int64_t)16 * cin * cout * 4 <= (4 << 20) && blocks >= 16 && !(xcd_env && xcd_env[0] == '0')) {
+    // (also with ONE channel tile: a footprint row is 34 floats around a 32-float = 128-byte line, so its two halo floats pull in the
+    // neighbours' lines; with horizontally adjacent tiles on one XCD those are L2 hits instead of a 3x fetch from fabric)
+    if ((int64_t)16 * cin * cout * 4 <= (4 << 20) && blocks >= 16 && !(xcd_env && xcd_env[0] == '0')) {
         p.xcd_per = (int)((blocks + 7) / 8);
         blocks = (int64_t)p.xcd_per * 8;
     }
