@@ -168,11 +168,18 @@ int mgf_conv3x3_winograd2_f32(float* y, const float* x, const float* u, const fl
  * patch go to the four waves of a workgroup, a lane computes exactly the transformed-input values of its own MFMA operand slots (no
  * LDS round trip of the transformed input), the weight operands come straight from L2, the style multiplies the input footprint.
  * u in the layout of mgf_winograd2_weights_f32; cin % 4 == 0, cout % 32 == 0 (64 output channels per workgroup when cout % 64 == 0),
- * even map sides; dense y [n, cout, h, w]; epilogue as mgf_conv_taps_f32 (noise and residual 8-byte aligned).
+ * dense y [n, cout, h, w] (odd map sides are accepted here too, with element-wise stores); epilogue as mgf_conv_taps_f32 (noise and
+ * residual 8-byte aligned on even maps).
  * _rgb: the fused 1x1 projection of mgf_conv3x3_winograd2_rgb_f32 (cout == 32, rgb_channels <= 3). */
 int mgf_conv3x3_winograd3_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
                               int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
                               mgf_stream_t stream);
+/* form 3 writing a channel slice of a wider output (y [n, C_total, h, w] with y_batch = C_total*h*w elements between samples, channels
+ * [y_choff, y_choff + cout); the residual, when given, has the same layout) and/or on ODD map sides (element-wise stores of the pixel pairs):
+ * a SqueezeNet Fire module's expand3x3 half of the concat buffer on the 255 / 127 / 63 px LPIPS maps */
+int mgf_conv3x3_winograd3_slice_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
+                                    int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, int64_t y_batch,
+                                    int32_t y_choff, const mgf_epilogue* ep, mgf_stream_t stream);
 /* form 3 with the epilogue's residual given at HALF resolution: residual_low [n, cout, h/2, w/2] is up-sampled 2x inside the epilogue with the
  * [1,3,3,1] (x) [1,3,3,1] / 16 filter of upfirdn2d.upsample2d(x, f, up=2) (padding [2,1,2,1], gain 4; torch_utils/ops/upfirdn2d.py:300-336) and
  * added after the gain, i.e. y = act(...) * gain + upsample2d(residual_low).  This is the resnet skip branch of a SynthesisBlock

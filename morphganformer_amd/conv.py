@@ -171,8 +171,8 @@ WINOGRAD_FORM = int(os.environ.get("MGF_WINOGRAD_FORM", "3"))
 
 
 def winograd3_ok(x, out, out_choff):
-    return (WINOGRAD_FORM == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and out_choff == 0 and
-            (out is None or out.shape[1] == out.shape[1] and out.is_contiguous()))
+    """Form 3 serves every call of the [16, cin/4, cout, 4] weight layout (odd maps and channel slices included) unless pinned off."""
+    return WINOGRAD_FORM == 3 and min(x.shape[2], x.shape[3]) >= 2
 
 
 def winograd2_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=None, out_choff=0, residual_low=None):
@@ -194,16 +194,17 @@ def winograd2_forward(x, u, in_scale=None, out_scale=None, epilogue=None, out=No
                                                                residual_low.data_ptr(), n, cin, h, w, cout, os_stride, C.byref(epilogue),
                                                                _lib.stream_ptr()), "conv3x3_winograd3_up2res")
         return out
-    if winograd3_ok(x, out, out_choff) and (out is None or out.shape[1] == u.shape[2]):
+    if winograd3_ok(x, out, out_choff):
         assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and u.ndim == 4 and x.shape[1] == u.shape[1] * 4
         n, cin, h, w = x.shape
         cout = u.shape[2]
         if out is None:
             out = torch.empty([n, cout, h, w], dtype=torch.float32, device=x.device)
-        assert out.is_contiguous() and tuple(out.shape) == (n, cout, h, w)
+        assert out.is_contiguous() and out.shape[0] == n and tuple(out.shape[2:]) == (h, w) and out_choff + cout <= out.shape[1]
         os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
-        rc = _lib.lib().mgf_conv3x3_winograd3_f32(out.data_ptr(), x.data_ptr(), u.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale), n, cin, h, w,
-                                                  cout, os_stride, C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
+        rc = _lib.lib().mgf_conv3x3_winograd3_slice_f32(out.data_ptr(), x.data_ptr(), u.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale), n, cin, h,
+                                                        w, cout, os_stride, out.shape[1] * h * w, out_choff,
+                                                        C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
         _lib.check(rc, "conv3x3_winograd3")
         return out
     assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and u.ndim == 4 and x.shape[1] == u.shape[1] * 4

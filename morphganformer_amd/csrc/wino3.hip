@@ -51,6 +51,9 @@ struct Wino3Params {
     float* rgb_out;           // [n][rgb_channels][h][w]
     int rgb_channels;
     const float* res_low;     // [n][cout][h/2][w/2] or null: the residual at HALF resolution, 2x up-sampled in the epilogue
+    int64_t y_batch;          // elements between samples of y (y may be a channel slice of a wider concat buffer; residual likewise)
+    int y_choff;              // channel offset into y
+    int odd;                  // h or w odd: pixel pairs are stored / loaded element-wise with bounds checks
 };
 
 #ifndef W3_OCC1
@@ -319,12 +322,22 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         rr[k] = make_float2(0.f, 0.f);
     }
     const unsigned voff = ok_px ? (unsigned)(cob * plane + oy * p.w + ox) * 4u : 0xFFFFFFF0u;
+    const bool pair_ok = ox + 1 < p.w;               // (always true on even maps)
     if (do_ep && p.ep.residual) {
-        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ep.residual + (int64_t)n * p.cout * plane), 0,
-                                                                              p.cout * plane * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.ep.residual + (int64_t)n * p.y_batch + (int64_t)p.y_choff * plane), 0, p.cout * plane * 4, 0x00020000);
+        if (!p.odd) {
 #pragma unroll
-        for (int k = 0; k < NR; ++k)
-            rr[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rres, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0));
+            for (int k = 0; k < NR; ++k)
+                rr[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rres, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0));
+        } else {                                      // odd map sides: rows are not 8-byte aligned
+            const unsigned voff1 = (ok_px && pair_ok) ? voff + 4u : 0xFFFFFFF0u;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                rr[k].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0));
+                rr[k].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, voff1, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0));
+            }
+        }
     }
     // The residual at half resolution (the resnet skip branch: 1x1 conv at the block's INPUT resolution, networks.py:1157,245-250), 2x
     // up-sampled here with the [1,3,3,1] (x) [1,3,3,1] / 16 filter of upfirdn2d.upsample2d (up = 2, padding [2,1,2,1], gain 4):
@@ -351,8 +364,14 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     }
     if (do_ep && p.ep.noise && ok_px) {
         const float ns = p.ep.noise_strength ? *p.ep.noise_strength : 1.f;
-        const float2 nv = *reinterpret_cast<const float2*>(p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane + (int64_t)oy * p.w + ox);
-        nz0 = nv.x * ns; nz1 = nv.y * ns;
+        const float* np_ = p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane + (int64_t)oy * p.w + ox;
+        if (!p.odd) {
+            const float2 nv = *reinterpret_cast<const float2*>(np_);
+            nz0 = nv.x * ns; nz1 = nv.y * ns;
+        } else {
+            nz0 = np_[0] * ns;
+            nz1 = pair_ok ? np_[1] * ns : 0.f;
+        }
     }
     __syncthreads();
     if (UMODE == 1 && p.res_low) {
@@ -370,7 +389,7 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         }
     }
     {
-        float* yb = p.y + (int64_t)n * p.cout * plane;
+        float* yb = p.y + (int64_t)n * p.y_batch + (int64_t)p.y_choff * plane;
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             float v[2];
@@ -386,8 +405,11 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
                 }
                 v[q] = t;
             }
-            if (ok_px)
-                *reinterpret_cast<float2*>(yb + (int64_t)(cob + (k & 3) + 8 * (k >> 2)) * plane + (int64_t)oy * p.w + ox) = make_float2(v[0], v[1]);
+            if (ok_px) {
+                float* dst = yb + (int64_t)(cob + (k & 3) + 8 * (k >> 2)) * plane + (int64_t)oy * p.w + ox;
+                if (!p.odd) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+                else { dst[0] = v[0]; if (pair_ok) dst[1] = v[1]; }
+            }
         }
     }
 }
@@ -404,21 +426,26 @@ extern "C" int mgf_winograd3_force_shape(int32_t shape) {
 
 static int launch_wino3(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n, int32_t cin, int32_t h,
                         int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep, const float* rgb_w, const float* rgb_bias,
-                        float* rgb_out, int32_t rgb_channels, mgf_stream_t stream, const float* res_low = nullptr) {
+                        float* rgb_out, int32_t rgb_channels, mgf_stream_t stream, const float* res_low = nullptr, int64_t y_batch = 0,
+                        int32_t y_choff = 0) {
     const bool rgb = rgb_out != nullptr;
     MGF_REQUIRE((y || rgb) && x && u && n >= 1 && cin >= 1 && cout >= 1 && h >= 2 && w >= 2, MGF_EINVAL, "conv3x3_winograd3: bad arguments");
     MGF_REQUIRE(cin % W3CK == 0 && cout % 32 == 0, MGF_EUNSUPPORTED, "conv3x3_winograd3: cin must be a multiple of %d and cout of 32 (got %d, %d)",
                 W3CK, cin, cout);
     MGF_REQUIRE(cin <= 1024, MGF_EUNSUPPORTED, "conv3x3_winograd3: at most 1024 input channels (got %d)", cin);
-    MGF_REQUIRE(h % 2 == 0 && w % 2 == 0, MGF_EUNSUPPORTED, "conv3x3_winograd3: even feature-map sides only (got %dx%d)", h, w);
-    MGF_REQUIRE((int64_t)cin * h * w <= INT32_MAX / 4 && (int64_t)16 * cin * cout <= INT32_MAX / 4 && (int64_t)cout * h * w <= INT32_MAX / 4,
+    const bool odd = (h % 2) || (w % 2);
+    MGF_REQUIRE(!(odd && (rgb || res_low)), MGF_EUNSUPPORTED, "conv3x3_winograd3: the fused ToRGB / half-resolution residual need even map sides (got %dx%d)", h, w);
+    MGF_REQUIRE(y_choff >= 0 && (y_batch == 0 || y_batch >= (int64_t)(y_choff + cout) * h * w), MGF_EINVAL, "conv3x3_winograd3: bad output slice");
+    MGF_REQUIRE(odd || (y_batch % 2 == 0), MGF_EINVAL, "conv3x3_winograd3: y_batch must keep rows 8-byte aligned");
+    MGF_REQUIRE(!(y_batch || y_choff) || !(rgb || res_low), MGF_EUNSUPPORTED, "conv3x3_winograd3: channel-slice outputs are for the plain launch");
+    MGF_REQUIRE((int64_t)cin * h * w <= INT32_MAX / 4 && (int64_t)16 * cin * cout <= INT32_MAX / 4 && (int64_t)(y_choff + cout) * h * w <= INT32_MAX / 4,
                 MGF_ETOOBIG, "conv3x3_winograd3: one sample / the weight planes must stay below 2 GiB (32-bit buffer offsets)");
-    MGF_REQUIRE(((uintptr_t)u % 16) == 0 && ((uintptr_t)(rgb ? rgb_out : y) % 8) == 0, MGF_EINVAL, "conv3x3_winograd3: u must be 16-byte and the output 8-byte aligned");
+    MGF_REQUIRE(((uintptr_t)u % 16) == 0 && (odd || ((uintptr_t)(rgb ? rgb_out : y) % 8) == 0), MGF_EINVAL, "conv3x3_winograd3: u must be 16-byte and the output 8-byte aligned");
     if (ep) {
         MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU, MGF_EUNSUPPORTED,
                     "conv3x3_winograd3: epilogue activation %d unsupported", ep->act);
-        MGF_REQUIRE(!ep->residual || ((uintptr_t)ep->residual % 8) == 0, MGF_EINVAL, "conv3x3_winograd3: the residual must be 8-byte aligned");
-        MGF_REQUIRE(!ep->noise || ((uintptr_t)ep->noise % 8) == 0, MGF_EINVAL, "conv3x3_winograd3: the noise map must be 8-byte aligned");
+        MGF_REQUIRE(odd || !ep->residual || ((uintptr_t)ep->residual % 8) == 0, MGF_EINVAL, "conv3x3_winograd3: the residual must be 8-byte aligned");
+        MGF_REQUIRE(odd || !ep->noise || ((uintptr_t)ep->noise % 8) == 0, MGF_EINVAL, "conv3x3_winograd3: the noise map must be 8-byte aligned");
     }
     if (rgb) {
         MGF_REQUIRE(cout == 32 && rgb_w && rgb_channels >= 1 && rgb_channels <= 3 && !ep, MGF_EUNSUPPORTED,
@@ -442,6 +469,7 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
     p.rgb_w = rgb_w; p.rgb_bias = rgb_bias; p.rgb_out = rgb_out; p.rgb_channels = rgb_channels;
     p.res_low = res_low;
+    p.y_batch = y_batch ? y_batch : (int64_t)cout * h * w; p.y_choff = y_choff; p.odd = odd;
     if (res_low) {
         MGF_REQUIRE(ep && !ep->residual && !rgb, MGF_EINVAL, "conv3x3_winograd3_up2res: needs an epilogue without a full-resolution residual");
         MGF_REQUIRE(shape == 11, MGF_EUNSUPPORTED, "conv3x3_winograd3_up2res: only the 32x32-tile shape takes the half-resolution residual");
@@ -490,6 +518,13 @@ extern "C" int mgf_conv3x3_winograd3_f32(float* y, const float* x, const float* 
                                          int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, const mgf_epilogue* ep,
                                          mgf_stream_t stream) {
     return launch_wino3(y, x, u, in_scale, out_scale, n, cin, h, w, cout, out_scale_stride, ep, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mgf_conv3x3_winograd3_slice_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale, int32_t n,
+                                               int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t out_scale_stride, int64_t y_batch,
+                                               int32_t y_choff, const mgf_epilogue* ep, mgf_stream_t stream) {
+    return launch_wino3(y, x, u, in_scale, out_scale, n, cin, h, w, cout, out_scale_stride, ep, nullptr, nullptr, nullptr, 0, stream, nullptr, y_batch,
+                        y_choff);
 }
 
 extern "C" int mgf_conv3x3_winograd3_up2res_f32(float* y, const float* x, const float* u, const float* in_scale, const float* out_scale,

@@ -31,9 +31,10 @@ CHNS = [64, 128, 256, 384, 384, 512, 512]
 SHIFT = (-0.030, -0.088, -0.188)
 SCALE = (0.458, 0.448, 0.450)
 WEIGHTS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights")
-# Tuning hook: 1 runs the Fire expand3x3 convs on the Winograd kernel (odd maps, concat slices).  Measured slower in the iteration
-# (481 vs 486 iters/s: 16..64 input channels are 4..16 chunks deep and the odd maps take the element-wise store path), so off.
-USE_WINOGRAD_LPIPS = os.environ.get("MGF_WINOGRAD_LPIPS", "0") != "0"
+# The Fire expand3x3 convs (16..64 input channels, 255 / 127 / 63 px maps, output = a channel slice of the concat buffer) run on the form-3
+# Winograd kernel: few chunks per tile is exactly where its 32x32-tile shape with four workgroups per CU pays (with form 2 they were
+# slower than the tap-list kernel, 481 vs 486 iters/s).  MGF_WINOGRAD_LPIPS=0 (tuning hook) puts them back on the tap-list kernel.
+USE_WINOGRAD_LPIPS = os.environ.get("MGF_WINOGRAD_LPIPS", "1") != "0"
 
 
 def random_squeeze_backbone(seed=0):
@@ -359,8 +360,8 @@ class SqueezeFeatures:
                 y = dest(idx)
                 ex = p1.cout
                 cv.conv_forward(s, p1, epilogue=_lib.make_epilogue(bias=b1, act="relu"), out=y, out_choff=0)
-                # Winograd when its grid (no split-K) gives every CU two workgroups: the 25-candidate literal iteration, not a single image
-                if idx in self.wino3 and min(s.shape[2:]) > 16 and s.shape[0] * -(-s.shape[2] // 8) * -(-s.shape[3] // 32) * (ex // 32) >= 512:
+                # Winograd when its grid (no split-K) fills the chip: the 25-candidate literal iteration, not a single small image
+                if idx in self.wino3 and min(s.shape[2:]) > 16 and cv.winograd_fills_chip(s.shape[0], ex, s.shape[2], s.shape[3]):
                     cv.winograd2_forward(s, self.wino3[idx], epilogue=_lib.make_epilogue(bias=b3, act="relu"), out=y, out_choff=ex)
                 else:
                     cv.conv_forward(s, p3, pad=(1, 1), epilogue=_lib.make_epilogue(bias=b3, act="relu"), out=y, out_choff=ex)

@@ -359,11 +359,14 @@ def test_winograd_fused_torgb_matches_tap_list_launch(n, cin, h, w, form, monkey
     assert rel_err(out, direct) < 2e-5
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w,ctotal,choff", [(2, 16, 64, 63, 63, 128, 64), (1, 32, 32, 31, 45, 96, 32), (2, 48, 64, 40, 33, 64, 0)])
-def test_winograd_odd_maps_and_channel_slices(n, cin, cout, h, w, ctotal, choff):
-    """Form 2 on odd map sides writing a channel slice of a wider buffer (the Fire expand3x3 half of a concat buffer) with the
+@pytest.mark.parametrize("form", [2, 3])
+@pytest.mark.parametrize("n,cin,cout,h,w,ctotal,choff", [(2, 16, 64, 63, 63, 128, 64), (1, 32, 32, 31, 45, 96, 32), (2, 48, 64, 40, 33, 64, 0),
+                                                         (1, 16, 64, 255, 255, 128, 64)])
+def test_winograd_odd_maps_and_channel_slices(n, cin, cout, h, w, ctotal, choff, form, monkeypatch):
+    """Forms 2 and 3 on odd map sides writing a channel slice of a wider buffer (the Fire expand3x3 half of a concat buffer) with the
     bias+ReLU epilogue; the rest of the buffer must stay untouched."""
     from morphganformer_amd import _lib, conv as cv
+    monkeypatch.setattr(cv, "WINOGRAD_FORM", form)
     torch.manual_seed(h * w)
     x = torch.randn(n, cin, h, w)
     wt = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
