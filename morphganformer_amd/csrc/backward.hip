@@ -183,14 +183,28 @@ __global__ __launch_bounds__(256) void duplex_attention_bwd_kernel(AttnBwdParams
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
     float sq = 0.f;
-    for (int c = grp; c < p.c; c += G) {
-        const float xv = xn[(int64_t)c * p.f + fc];
-        const float4* w4 = reinterpret_cast<const float4*>(tq + c * TMAX);
-        sq += xv * xv;
+    // the channel sweeps issue ABU independent row loads before the first use: these layers are 4x4 .. 128x128 maps, i.e. latency --
+    // one load per iteration made every sweep a chain of C / G dependent memory round trips (55 us per launch whatever the grid)
+    constexpr int ABU = 8;
+    for (int c0 = grp; c0 < p.c; c0 += G * ABU) {
+        float xv[ABU];
 #pragma unroll
-        for (int q = 0; q < TMAX / 4; ++q) {
-            const float4 w = w4[q];
-            s[4 * q + 0] += xv * w.x; s[4 * q + 1] += xv * w.y; s[4 * q + 2] += xv * w.z; s[4 * q + 3] += xv * w.w;
+        for (int u = 0; u < ABU; ++u) {
+            const int c = c0 + u * G;
+            xv[u] = c < p.c ? xn[(int64_t)c * p.f + fc] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < ABU; ++u) {
+            const int c = c0 + u * G;
+            if (c < p.c) {
+                const float4* w4 = reinterpret_cast<const float4*>(tq + c * TMAX);
+                sq += xv[u] * xv[u];
+#pragma unroll
+                for (int q = 0; q < TMAX / 4; ++q) {
+                    const float4 w = w4[q];
+                    s[4 * q + 0] += xv[u] * w.x; s[4 * q + 1] += xv[u] * w.y; s[4 * q + 2] += xv[u] * w.z; s[4 * q + 3] += xv[u] * w.w;
+                }
+            }
         }
     }
 #pragma unroll
@@ -225,15 +239,27 @@ __global__ __launch_bounds__(256) void duplex_attention_bwd_kernel(AttnBwdParams
     // ---- pass 2: dP ----
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
-    for (int c = grp; c < p.c; c += G) {
-        const int64_t o = (int64_t)c * p.f + fc;
-        const float dgv = dan[o] * xn[o] * r;
-        if (valid && p.dg) p.dg[plane + (int64_t)c * p.f + f] = dgv;
-        const float4* w4 = reinterpret_cast<const float4*>(tv + c * TMAX);
+    for (int c0 = grp; c0 < p.c; c0 += G * ABU) {
+        float dv[ABU], xv[ABU];
 #pragma unroll
-        for (int q = 0; q < TMAX / 4; ++q) {
-            const float4 w = w4[q];
-            s[4 * q + 0] += dgv * w.x; s[4 * q + 1] += dgv * w.y; s[4 * q + 2] += dgv * w.z; s[4 * q + 3] += dgv * w.w;
+        for (int u = 0; u < ABU; ++u) {
+            const int c = c0 + u * G;
+            const int64_t o = (int64_t)(c < p.c ? c : 0) * p.f + fc;
+            dv[u] = dan[o]; xv[u] = xn[o];
+        }
+#pragma unroll
+        for (int u = 0; u < ABU; ++u) {
+            const int c = c0 + u * G;
+            if (c < p.c) {
+                const float dgv = dv[u] * xv[u] * r;
+                if (valid && p.dg) p.dg[plane + (int64_t)c * p.f + f] = dgv;
+                const float4* w4 = reinterpret_cast<const float4*>(tv + c * TMAX);
+#pragma unroll
+                for (int q = 0; q < TMAX / 4; ++q) {
+                    const float4 w = w4[q];
+                    s[4 * q + 0] += dgv * w.x; s[4 * q + 1] += dgv * w.y; s[4 * q + 2] += dgv * w.z; s[4 * q + 3] += dgv * w.w;
+                }
+            }
         }
     }
 #pragma unroll
@@ -253,19 +279,31 @@ __global__ __launch_bounds__(256) void duplex_attention_bwd_kernel(AttnBwdParams
 
     // ---- pass 3: dx ----
     float* dxn = p.dx + plane;
-    for (int c = grp; c < p.c; c += G) {
-        const int64_t o = (int64_t)c * p.f + fc;
-        const float4* v4 = reinterpret_cast<const float4*>(tv + c * TMAX);
-        const float4* q4 = reinterpret_cast<const float4*>(tq + c * TMAX);
-        float g = 0.f, qs = 0.f;
+    for (int c0 = grp; c0 < p.c; c0 += G * ABU) {
+        float dv[ABU], xv[ABU];
 #pragma unroll
-        for (int q = 0; q < TMAX / 4; ++q) {
-            const float4 a = v4[q], b = q4[q];
-            g += P[4 * q + 0] * a.x + P[4 * q + 1] * a.y + P[4 * q + 2] * a.z + P[4 * q + 3] * a.w;
-            qs += s[4 * q + 0] * b.x + s[4 * q + 1] * b.y + s[4 * q + 2] * b.z + s[4 * q + 3] * b.w;
+        for (int u = 0; u < ABU; ++u) {
+            const int c = c0 + u * G;
+            const int64_t o = (int64_t)(c < p.c ? c : 0) * p.f + fc;
+            dv[u] = dan[o]; xv[u] = xn[o];
         }
-        const float v = dan[o] * r * g - coef * xn[o] + qs;
-        if (valid) dxn[(int64_t)c * p.f + f] = v;
+#pragma unroll
+        for (int u = 0; u < ABU; ++u) {
+            const int c = c0 + u * G;
+            if (c < p.c) {
+                const float4* v4 = reinterpret_cast<const float4*>(tv + c * TMAX);
+                const float4* q4 = reinterpret_cast<const float4*>(tq + c * TMAX);
+                float g = 0.f, qs = 0.f;
+#pragma unroll
+                for (int q = 0; q < TMAX / 4; ++q) {
+                    const float4 a = v4[q], b = q4[q];
+                    g += P[4 * q + 0] * a.x + P[4 * q + 1] * a.y + P[4 * q + 2] * a.z + P[4 * q + 3] * a.w;
+                    qs += s[4 * q + 0] * b.x + s[4 * q + 1] * b.y + s[4 * q + 2] * b.z + s[4 * q + 3] * b.w;
+                }
+                const float v = dv[u] * r * g - coef * xv[u] + qs;
+                if (valid) dxn[(int64_t)c * p.f + f] = v;
+            }
+        }
     }
 }
 
@@ -280,16 +318,25 @@ __global__ __launch_bounds__(256) void attn_values_grad_kernel(float* dvwb, cons
         for (int t = 0; t < TMAX; ++t) acc[u][t] = 0.f;
     const float* pn = probs + (int64_t)n * f * T;
     const float* dgn = dg + (int64_t)n * c * f;
-    for (int i = tid; i < f; i += 256) {
-        float pv[TMAX];
+    // two pixel slices per trip: their loads are independent, so twice the bytes are in flight per round trip of this latency-bound sweep
+    for (int i0 = tid; i0 < f; i0 += 512) {
+        float pv[2][TMAX], dv[2][4];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) pv[t] = t < T ? pn[(int64_t)i * T + t] : 0.f;
+        for (int h = 0; h < 2; ++h) {
+            const int i = i0 + 256 * h;
+            const bool ok = i < f;
+            const int ic = ok ? i : 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float dv = (c0 + u < c) ? dgn[(int64_t)(c0 + u) * f + i] : 0.f;
+            for (int t = 0; t < TMAX; ++t) pv[h][t] = (ok && t < T) ? pn[(int64_t)ic * T + t] : 0.f;
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) acc[u][t] += dv * pv[t];
+            for (int u = 0; u < 4; ++u) dv[h][u] = (ok && c0 + u < c) ? dgn[(int64_t)(c0 + u) * f + ic] : 0.f;
         }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t) acc[u][t] += dv[h][u] * pv[h][t];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
