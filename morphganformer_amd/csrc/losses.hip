@@ -182,28 +182,32 @@ __global__ __launch_bounds__(256) void awing_kernel(double* out, const double* p
     if (threadIdx.x == 0) out[blockIdx.x] = (sm[0] + sm[1] + sm[2] + sm[3]) / (double)numel;
 }
 
-// K x K window, stride 2, windows clipped at the bottom/right edge (ceil_mode partial windows)
+// K x K window, stride 2, windows clipped at the bottom/right edge (ceil_mode partial windows).  A workgroup covers 4 output rows of one
+// plane; a thread produces TWO adjacent outputs from a K x (K + 2) input window, so a wave reads 3 contiguous row segments (every byte
+// of them used) and no index needs a division per element (one per workgroup row).  HBM-bound: in + out bytes once.
 template <int K>
 __global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, int nc, int in_h, int in_w, int out_h, int out_w) {
-    const int64_t total = (int64_t)nc * out_h * out_w;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int ox = (int)(i % out_w);
-        const int64_t r = i / out_w;
-        const int oy = (int)(r % out_h);
-        const int64_t pl = r / out_h;
-        const float* xp = x + pl * in_h * in_w;
-        float m = -3.0e38f;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);              // (plane, output row) flattened
+    if (row >= nc * out_h) return;
+    const int pl = row / out_h, oy = row - pl * out_h;
+    const float* xp = x + (int64_t)pl * in_h * in_w;
+    float* yp = y + ((int64_t)pl * out_h + oy) * out_w;
+    const int lane = threadIdx.x & 63;
+    for (int ox = 2 * lane; ox < out_w; ox += 128) {
+        float m0 = -3.0e38f, m1 = -3.0e38f;
 #pragma unroll
         for (int dy = 0; dy < K; ++dy) {
             const int iy = oy * 2 + dy;
             if (iy >= in_h) continue;
+            const float* rp = xp + (int64_t)iy * in_w + 2 * ox;
+            float v[K + 2];
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) {
-                const int ix = ox * 2 + dx;
-                if (ix < in_w) m = fmaxf(m, xp[(int64_t)iy * in_w + ix]);
-            }
+            for (int dx = 0; dx < K + 2; ++dx) v[dx] = (2 * ox + dx < in_w) ? rp[dx] : -3.0e38f;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) { m0 = fmaxf(m0, v[dx]); m1 = fmaxf(m1, v[dx + 2]); }
         }
-        y[i] = m;
+        yp[ox] = m0;
+        if (ox + 1 < out_w) yp[ox + 1] = m1;
     }
 }
 
@@ -365,8 +369,8 @@ extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, i
     auto osz = [](int in) { int o = (in - 3 + 1) / 2 + 1; if ((o - 1) * 2 >= in) --o; return o; };
     MGF_REQUIRE(out_h == osz(in_h) && out_w == osz(in_w), MGF_EINVAL, "maxpool: output must be %dx%d (got %dx%d)", osz(in_h), osz(in_w),
                 out_h, out_w);
-    const int64_t total = (int64_t)nc * out_h * out_w;
-    hipLaunchKernelGGL(maxpool_kernel<3>, dim3(mgf_stream_grid(total, 256, 2)), dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w,
+    MGF_REQUIRE((int64_t)nc * out_h <= INT32_MAX - 4, MGF_ETOOBIG, "maxpool: too many rows");
+    hipLaunchKernelGGL(maxpool_kernel<3>, dim3((unsigned)mgf_cdiv((int64_t)nc * out_h, 4)), dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w,
                        out_h, out_w);
     MGF_CHECK_LAUNCH("maxpool");
     return MGF_OK;
@@ -375,8 +379,8 @@ extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, i
 extern "C" int mgf_maxpool_s2_floor_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t ksize, mgf_stream_t stream) {
     MGF_REQUIRE(y && x && nc >= 1 && (ksize == 2 || ksize == 3) && in_h >= ksize && in_w >= ksize, MGF_EINVAL, "maxpool_s2_floor: bad arguments");
     const int out_h = (in_h - ksize) / 2 + 1, out_w = (in_w - ksize) / 2 + 1;
-    const int64_t total = (int64_t)nc * out_h * out_w;
-    const dim3 grid(mgf_stream_grid(total, 256, 2));
+    MGF_REQUIRE((int64_t)nc * out_h <= INT32_MAX - 4, MGF_ETOOBIG, "maxpool_s2_floor: too many rows");
+    const dim3 grid((unsigned)mgf_cdiv((int64_t)nc * out_h, 4));
     if (ksize == 2) hipLaunchKernelGGL(maxpool_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w, out_h, out_w);
     else hipLaunchKernelGGL(maxpool_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w, out_h, out_w);
     MGF_CHECK_LAUNCH("maxpool_s2_floor");

@@ -210,6 +210,20 @@ def test_mse_grad_and_pool_bwd():
     dx = torch.empty_like(xd)
     _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_f32(dx.data_ptr(), dyd.data_ptr(), xd.data_ptr(), 8, 15, 12, y.shape[2], y.shape[3], _lib.stream_ptr()))
     assert torch.equal(dx.cpu(), ref)
+    # forward pooling, both entries, odd and even sides, wider than one wave's 128 columns: bit-exact
+    for (c, hh, ww) in ((3, 15, 12), (2, 31, 301), (1, 8, 257), (5, 2, 3)):
+        xf = torch.randn(2, c, hh, ww)
+        want = torch.nn.functional.max_pool2d(xf, 3, 2, ceil_mode=True)
+        got = torch.empty_like(want).cuda()
+        _lib.check(L.mgf_maxpool3x3s2_ceil_f32(got.data_ptr(), xf.cuda().data_ptr(), 2 * c, hh, ww, want.shape[2], want.shape[3], _lib.stream_ptr()))
+        assert torch.equal(got.cpu(), want)
+        for k in (2, 3):
+            if hh < k or ww < k:
+                continue
+            want = torch.nn.functional.max_pool2d(xf, k, 2)
+            got = torch.empty_like(want).cuda()
+            _lib.check(L.mgf_maxpool_s2_floor_f32(got.data_ptr(), xf.cuda().data_ptr(), 2 * c, hh, ww, k, _lib.stream_ptr()))
+            assert torch.equal(got.cpu(), want)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
