@@ -76,6 +76,8 @@ def _desc(n, cin, in_h, in_w, cout, cout_pad, tile_h, tile_w, istride, ostride, 
     return d
 
 
+POINTWISE = os.environ.get("MGF_POINTWISE", "1") != "0"                   # tuning hook: 0 = 1x1 layers on the tap-list kernel
+
 # Split-K scratch: one slab per (device, stream) -- launches on one stream are ordered, launches on different streams may overlap.
 WORKSPACE_FLOATS = 16 << 20
 _WS = {}
@@ -122,6 +124,14 @@ def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_sca
     if out is None:
         out = torch.empty([n, pc.cout, oh, ow], dtype=torch.float32, device=x.device)
     assert out.is_contiguous() and out.shape[0] == n and out.shape[2] == oh and out.shape[3] == ow
+    if (POINTWISE and pc.kh == 1 and pc.kw == 1 and stride == 1 and pad == (0, 0) and in_scale is None and out_scale is None
+            and taps == [(0, 0)] and (epilogue is None or not epilogue.noise)):
+        # un-modulated 1x1 layer: the register-operand GEMM (csrc/pointwise.hip) instead of the LDS-staged tap-list kernel
+        rc = _lib.lib().mgf_conv1x1_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), n, cin, h * w, pc.cout, pc.cout_pad,
+                                        out.shape[1] * oh * ow, out_choff, C.byref(epilogue) if epilogue is not None else None,
+                                        _lib.stream_ptr())
+        _lib.check(rc, "conv1x1")
+        return out
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, oh, ow, stride, 1, taps, None, [0], [0], oh, ow,
               ow, oh * ow, out.shape[1] * oh * ow, out_choff,
               0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)

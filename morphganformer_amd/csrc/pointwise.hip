@@ -1,0 +1,250 @@
+// 1x1 convolution (a plain GEMM per sample) with both MFMA operands loaded straight into registers: no LDS, no barrier.
+// Contract: include/mgf.h (mgf_conv1x1_f32).  Replaces the tap-list kernel for the un-modulated 1x1 layers: the resnet skip
+// projections of the synthesis blocks (training/networks.py:1102-1105, conv2d_resample with a 1x1 kernel) and the SqueezeNet Fire
+// squeeze / expand1x1 layers of LPIPS (lpips/pretrained_networks.py:7-44).
+//
+// Why not the tap-list kernel: it stages every input element in LDS and reuses it for `taps x cout` multiplies; with ONE tap the
+// staging (an LDS store costs ~8 matrix-pipe cycles per dword, tools/probes/mfma_lds.hip) is as expensive as the arithmetic, and the
+// Fire layers (16..64 channels on one side) are HBM streams that its two workgroups per CU cannot keep in flight.  Here
+//   y[n, co, p] = epilogue( sum_ci w[ci][co] * x[n, ci, p] ),        p = flattened pixel
+// is tiled [32 CB output channels] x [128 pixels] per WAVE: v_mfma_f32_32x32x2_f32 takes A[32 co][2 ci] as one dword per lane
+// (lane -> co = lane % 32, ci = lane / 32: two 128-byte rows of the [cin][cout_pad] weight image, L2-resident) and B[2 ci][32 px] as
+// one dword per lane -- so a lane loads exactly its own operand slots, 4 pixel blocks per k-step, and 4 CB MFMAs follow from 4 + CB
+// loaded dwords (one 16-byte load + CB dwords when the map is 4-pixel aligned: lane -> 4 CONSECUTIVE pixels, the four pixel blocks are
+// an interleaving of the tile, and the accumulators of a row leave as one 16-byte store).  Loads run one group of 8 channels ahead in a
+// second register set; reads past the last channel fall outside the buffer resources and return 0, so the loop has no tail code.
+#include "mgf_common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PwParams {
+    float* y;
+    const float* x;           // [n][cin][hw]
+    const float* w;           // [cin][cout_pad] (mgf_pack_conv_weights of a 1x1 kernel)
+    int n, cin, hw, cout, cout_pad;
+    int px_tiles, co_tiles;   // workgroup tiles per sample / over the output channels
+    int xcd_per;              // > 0: XCD-aware work order (all channel tiles of a pixel tile on one XCD)
+    int64_t y_batch;          // elements between samples of y (y may be a channel slice of a concat buffer; the residual likewise)
+    int y_choff;
+    mgf_epilogue ep;
+    int has_ep;
+};
+
+constexpr int PWKU = 4;       // k-steps (of 2 channels) per load group
+
+// WK = 4: the four waves of a workgroup share ONE tile and split the input channels (layers with too few tiles to fill the chip, where a
+// wave's serial walk over K at one load group in flight is the whole run time); their accumulators meet in LDS and wave 0 stores.
+template <int CB, int WCO, int WK, bool VEC>
+__global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_kernel(PwParams p) {
+    static_assert(WK == 1 || (WK == 4 && WCO == 1), "split-K workgroups put all four waves on one tile");
+    constexpr int WPX = 4 / (WCO * WK);
+    __shared__ float red[WK > 1 ? 3 * 64 * CB * 64 : 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    int b_ = blockIdx.x;
+    if (p.xcd_per > 0) {
+        b_ = (b_ & 7) * p.xcd_per + (b_ >> 3);
+        if (b_ >= p.n * p.px_tiles * p.co_tiles) return;
+    }
+    const int cot = b_ % p.co_tiles; b_ /= p.co_tiles;
+    const int pt = b_ % p.px_tiles;
+    const int n = b_ / p.px_tiles;
+    const int co0 = (cot * WCO + wv % WCO) * 32 * CB;
+    const int p0 = (pt * WPX + (WK > 1 ? 0 : wv / WCO)) * 128;
+    if (p0 >= p.hw || co0 >= p.cout) return;                       // wave-uniform (workgroup-uniform with WK > 1: its barrier is safe)
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.cin * p.hw), 0, p.cin * p.hw * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.cin * p.cout_pad * 4, 0x00020000);
+    // the channel part of every address rides in the VECTOR offset: the range check of a raw buffer access ignores the scalar offset
+    const unsigned xo = (unsigned)(half * p.hw + p0 + (VEC ? 4 * l31 : l31)) * 4u;
+    const unsigned wo = (unsigned)(half * p.cout_pad + co0 + l31) * 4u;
+    const unsigned xstep = (unsigned)p.hw * 8u, wstep = (unsigned)p.cout_pad * 8u;      // one k-step = 2 channels
+
+    f32x16 acc[CB][4];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][j][r] = 0.f;
+
+    float Ba[PWKU][4], Aa[PWKU][CB], Bb[PWKU][4], Ab[PWKU][CB];
+    auto load = [&](float (&B)[PWKU][4], float (&A)[PWKU][CB], int it) {
+#pragma unroll
+        for (int ks = 0; ks < PWKU; ++ks) {
+            const unsigned xv = xo + (unsigned)(it * PWKU + ks) * xstep, wvo = wo + (unsigned)(it * PWKU + ks) * wstep;
+            if (VEC) {
+                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, xv, 0, 0));
+                B[ks][0] = v.x; B[ks][1] = v.y; B[ks][2] = v.z; B[ks][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) B[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xv + 128u * j, 0, 0));
+            }
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) A[ks][cb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wvo + 128u * cb, 0, 0));
+        }
+    };
+    auto mm = [&](const float (&B)[PWKU][4], const float (&A)[PWKU][CB]) {
+#pragma unroll
+        for (int ks = 0; ks < PWKU; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[cb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[ks][cb], B[ks][j], acc[cb][j], 0, 0, 0);
+    };
+    int nit = (p.cin + 2 * PWKU - 1) / (2 * PWKU), it0 = 0;
+    // (an EVEN number of groups per wave: the loop below consumes them in pairs, and the odd one out would be the next wave's first;
+    // groups past cin read zeros)
+    if (WK > 1) { const int per = 2 * ((nit + 2 * WK - 1) / (2 * WK)); it0 = wv * per; nit = it0 + per; }
+    // (scheduling fences: left alone, the compiler sinks each load group to just above its first use and waits for it there)
+    load(Ba, Aa, it0);
+    for (int it = it0; it < nit; it += 2) {
+        load(Bb, Ab, it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(Ba, Aa);
+        __builtin_amdgcn_sched_barrier(0);
+        load(Ba, Aa, it + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(Bb, Ab);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (WK > 1) {
+        if (wv > 0) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(((wv - 1) * CB + cb) * 64 + j * 16 + r) * 64 + lane] = acc[cb][j][r];
+        }
+        __syncthreads();
+        if (wv > 0) return;
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k)                                 // (not unrolled: 192 LDS reads in flight would spill)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[cb][j][r] += red[((k * CB + cb) * 64 + j * 16 + r) * 64 + lane];
+    }
+    // accumulator register r of a 32x32 block = output channel (r & 3) + 8 (r >> 2) + 4 half of the block, pixel column l31
+    const bool do_ep = p.has_ep != 0;
+    const int act = p.ep.act;
+    const float alpha = p.ep.alpha, gain = do_ep ? p.ep.gain : 1.f;
+    float* yb = p.y + (int64_t)n * p.y_batch + (int64_t)p.y_choff * p.hw;
+    const float* rb = (do_ep && p.ep.residual) ? p.ep.residual + (int64_t)n * p.y_batch + (int64_t)p.y_choff * p.hw : nullptr;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co >= p.cout) continue;
+            const float bv = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = acc[cb][j][r] + bv;
+                if (act == MGF_ACT_LRELU) t = t > 0.f ? t : t * alpha;
+                else if (act == MGF_ACT_RELU) t = t > 0.f ? t : 0.f;
+                v[j] = t * gain;
+            }
+            const int64_t row = (int64_t)co * p.hw;
+            if (VEC) {
+                const int px = p0 + 4 * l31;
+                if (px < p.hw) {
+                    if (rb) { const float4 q = *reinterpret_cast<const float4*>(rb + row + px); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+                    *reinterpret_cast<float4*>(yb + row + px) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int px = p0 + l31 + 32 * j;
+                    if (px < p.hw) yb[row + px] = v[j] + (rb ? rb[row + px] : 0.f);
+                }
+            }
+        }
+    }
+}
+
+template <int CB, int WCO, int WK = 1>
+void pw_launch(const PwParams& p, bool vec, dim3 grid, hipStream_t st) {
+    if (vec) hipLaunchKernelGGL((pw_conv_kernel<CB, WCO, WK, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pw_conv_kernel<CB, WCO, WK, false>), grid, dim3(256), 0, st, p);
+}
+
+}  // namespace
+
+static int g_pw_forced_cb = 0;
+
+extern "C" int mgf_conv1x1_force_shape(int32_t channel_blocks) {
+    MGF_REQUIRE(channel_blocks >= 0 && channel_blocks <= 2, MGF_EINVAL, "conv1x1_force_shape: 0 (auto), 1 or 2 channel blocks per wave (got %d)", channel_blocks);
+    g_pw_forced_cb = channel_blocks;
+    return MGF_OK;
+}
+
+extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, int32_t n, int32_t cin, int32_t hw, int32_t cout, int32_t cout_pad,
+                               int64_t y_batch, int32_t y_choff, const mgf_epilogue* ep, mgf_stream_t stream) {
+    MGF_REQUIRE(y && x && w && n >= 1 && cin >= 1 && hw >= 1 && cout >= 1, MGF_EINVAL, "conv1x1: bad arguments");
+    MGF_REQUIRE(cout_pad >= cout && cout_pad % 32 == 0, MGF_EINVAL, "conv1x1: the weight image must be [cin][cout_pad], cout_pad a multiple of 32 (got %d for %d)",
+                cout_pad, cout);
+    MGF_REQUIRE(y_choff >= 0 && (y_batch == 0 || y_batch >= (int64_t)(y_choff + cout) * hw), MGF_EINVAL, "conv1x1: bad output slice");
+    // 32-bit byte offsets inside one sample / the weight image, with room for the reads past the last channel (they must not wrap)
+    MGF_REQUIRE(((int64_t)cin + 4 * PWKU) * hw * 4 + 4096 <= (int64_t)UINT32_MAX && ((int64_t)cin + 4 * PWKU) * cout_pad * 4 + 4096 <= (int64_t)UINT32_MAX,
+                MGF_ETOOBIG, "conv1x1: one sample / the weight image must stay below 4 GiB (32-bit buffer offsets)");
+    if (ep) {
+        MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU, MGF_EUNSUPPORTED,
+                    "conv1x1: epilogue activation %d unsupported", ep->act);
+        MGF_REQUIRE(!ep->noise, MGF_EUNSUPPORTED, "conv1x1: no noise input (the tap-list kernel has it)");
+    }
+    PwParams p;
+    p.y = y; p.x = x; p.w = w; p.n = n; p.cin = cin; p.hw = hw; p.cout = cout; p.cout_pad = cout_pad;
+    p.y_batch = y_batch ? y_batch : (int64_t)cout * hw; p.y_choff = y_choff;
+    p.has_ep = ep != nullptr;
+    if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; p.ep.act = MGF_ACT_LINEAR; }
+    // 16-byte accesses: every row of x, y and the residual starts 16-byte aligned
+    const bool vec = hw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (p.y_batch % 4) == 0 &&
+                     (!ep || !ep->residual || ((uintptr_t)ep->residual % 16) == 0);
+    // Shape: ONE 32-channel block per wave (64 accumulators, 4 workgroups per CU).  Two blocks per wave (128 accumulators, 2 workgroups
+    // per CU) halve the B-operand loads but were never faster (tools/pw_micro.py, 25 samples, us for 1 / 2 blocks: skip 512->512 at
+    // 32^2 142 / 145, 512->256 at 64^2 242 / 266, 256->128 at 128^2 250 / 272, Fire expand 16->64 at 255^2 152 / 192): residency hides
+    // the load latency, the operand loads are L1 hits.  MGF_PW_CB = 2 or mgf_conv1x1_force_shape(2) select the wide shape (tuning, tests).
+    static const int env_cb = [] { const char* e = getenv("MGF_PW_CB"); return e ? atoi(e) : 0; }();
+    int cb = 1;
+    const int forced = g_pw_forced_cb ? g_pw_forced_cb : env_cb;
+    if ((forced == 1) || (forced == 2 && cout_pad % 64 == 0)) cb = forced;
+    const int cw = cout_pad / (32 * cb);                           // wave columns needed
+    // Few tiles (the 4^2..16^2 skips, most layers at one sample): all four waves on one tile, K split four ways.  Measured
+    // (tools/pw_micro.py, 1 / 8 / 25 samples): a gain below ~800 waves (512 -> 512 at 4^2, 25 samples: 39 -> 26 us; 512 -> 64 at 63^2,
+    // one sample: 49 -> 24 us), a loss above (512 -> 512 at 16^2, 25 samples = 800 waves: 42 -> 50 us).
+    // MGF_PW_SPLITK_WAVES = the wave count below which it is used (tuning; 0 = never).
+    static const int64_t splitk_below = [] { const char* e = getenv("MGF_PW_SPLITK_WAVES"); return e ? atoll(e) : (int64_t)768; }();
+    const bool splitk = cb == 1 && cin >= 32 && (int64_t)n * mgf_cdiv(hw, 128) * cw < splitk_below;
+    const int wco = splitk ? 1 : (cw >= 3 ? 4 : cw);               // 1, 2 or 4 waves of a workgroup side by side over the channels
+    p.co_tiles = (cw + wco - 1) / wco;
+    p.px_tiles = (int)mgf_cdiv(hw, splitk ? 128 : 128 * (4 / wco));
+    int64_t blocks = (int64_t)n * p.px_tiles * p.co_tiles;
+    MGF_REQUIRE(blocks <= INT32_MAX - 8, MGF_ETOOBIG, "conv1x1: too many workgroups");
+    p.xcd_per = 0;
+    if (p.co_tiles > 1 && blocks >= 16) { p.xcd_per = (int)((blocks + 7) / 8); blocks = (int64_t)p.xcd_per * 8; }
+    static const char* names[2][3] = {{"pw_conv_kernel<1, 1>", "pw_conv_kernel<1, 2>", "pw_conv_kernel<1, 4>"},
+                                      {"pw_conv_kernel<2, 1>", "pw_conv_kernel<2, 2>", "pw_conv_kernel<2, 4>"}};
+    hipStream_t st = (hipStream_t)stream;
+    mgf_prof_external_begin(st, splitk ? "pw_conv_kernel<1, 1, 4>" : names[cb - 1][wco == 4 ? 2 : wco - 1], 2.0 * cin * (double)cout * hw * n,
+                            4.0 * ((double)n * cin * hw + (double)cin * cout + (double)n * cout * hw * ((ep && ep->residual) ? 2 : 1)));
+    const dim3 grid((unsigned)blocks);
+    if (splitk) pw_launch<1, 1, 4>(p, vec, grid, st);
+    else if (cb == 2) {
+        if (wco == 4) pw_launch<2, 4>(p, vec, grid, st); else if (wco == 2) pw_launch<2, 2>(p, vec, grid, st); else pw_launch<2, 1>(p, vec, grid, st);
+    } else {
+        if (wco == 4) pw_launch<1, 4>(p, vec, grid, st); else if (wco == 2) pw_launch<1, 2>(p, vec, grid, st); else pw_launch<1, 1>(p, vec, grid, st);
+    }
+    mgf_prof_external_end(st);
+    MGF_CHECK_LAUNCH("conv1x1");
+    return MGF_OK;
+}

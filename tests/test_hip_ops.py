@@ -216,6 +216,49 @@ def test_conv_taps_vs_torch(n, cin, cout, res, k, stride, pad):
     assert rel_err(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,ctotal,choff,act,res", [
+    (2, 64, 16, 31, 31, 16, 0, "relu", False),        # Fire squeeze: odd map, 16 of 32 padded channels
+    (3, 16, 64, 63, 63, 128, 64, "relu", False),      # Fire expand1x1 into the second half of the concat buffer
+    (1, 48, 192, 15, 17, 384, 0, "relu", False),      # 3 wave columns (one idle wave)
+    (2, 512, 512, 32, 32, 512, 0, "linear", False),   # resnet skip 512 -> 512: two channel tiles, XCD order, 16-byte path
+    (2, 128, 64, 64, 64, 64, 0, "lrelu", True),       # residual, aligned
+    (1, 6, 40, 9, 13, 50, 7, "linear", True),         # ragged everything: cin not a multiple of 8, residual on an odd slice
+    (1, 2, 3, 1, 1, 3, 0, "linear", False),           # one pixel
+    (2, 32, 32, 8, 8, 32, 0, "linear", False),        # split-K workgroups with fewer channel groups than waves
+    (1, 72, 40, 16, 12, 40, 0, "relu", True),         # ... and with an odd number of groups per wave
+    (1, 256, 128, 128, 128, 128, 0, "linear", False)])
+def test_conv1x1_register_gemm_vs_torch_and_tap_list(n, cin, cout, h, w, ctotal, choff, act, res, monkeypatch):
+    """csrc/pointwise.hip (what conv_forward runs for un-modulated 1x1 layers) vs torch CPU conv2d and vs the tap-list kernel."""
+    from morphganformer_amd import _lib, conv as cv
+    torch.manual_seed(cin * 7 + cout + h)
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(cout, cin, 1, 1) / math.sqrt(cin)
+    b = torch.randn(cout)
+    r = torch.randn(n, ctotal, h, w)
+    ref = torch.nn.functional.conv2d(x, wt, b)
+    ref = {"relu": torch.relu, "lrelu": lambda t: torch.nn.functional.leaky_relu(t, 0.2), "linear": lambda t: t}[act](ref) * 1.5
+    if res:
+        ref = ref + r[:, choff:choff + cout]
+    pc = cv.pack_weights(wt.cuda())
+    b_dev, r_dev = b.cuda(), r.cuda()
+    outs = []
+    for pointwise in (True, False):
+        monkeypatch.setattr(cv, "POINTWISE", pointwise)
+        ep = _lib.make_epilogue(bias=b_dev, act=act, alpha=0.2, gain=1.5, residual=r_dev if res else None)
+        out = torch.full([n, ctotal, h, w], 7.0, device="cuda")
+        got = cv.conv_forward(x.cuda(), pc, epilogue=ep, out=out, out_choff=choff)
+        assert got is out
+        assert rel_err(out[:, choff:choff + cout], ref) < 2e-5
+        keep = torch.ones(ctotal, dtype=torch.bool)
+        keep[choff:choff + cout] = False
+        assert bool((out[:, keep.cuda()] == 7.0).all())                 # nothing outside the slice is written
+        outs.append(out)
+    assert rel_err(outs[0], outs[1]) < 2e-6
+    # no epilogue at all
+    monkeypatch.setattr(cv, "POINTWISE", True)
+    assert rel_err(cv.conv_forward(x.cuda(), pc), torch.nn.functional.conv2d(x, wt)) < 2e-5
+
+
 @pytest.mark.parametrize("n,cin,cout,res", [(1, 32, 32, 16), (2, 64, 32, 33), (1, 8, 40, 4), (1, 128, 64, 64)])
 def test_tconv_vs_torch(n, cin, cout, res):
     from morphganformer_amd import conv as cv
