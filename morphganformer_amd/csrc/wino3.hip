@@ -61,18 +61,20 @@ struct Wino3Params {
 #endif
 constexpr int W3CK = 4;                    // input channels per chunk
 constexpr int W3FW = 34;                   // footprint width: 16 tiles x 2 + 2
+__constant__ float w3_ones[W3CK] = {1.f, 1.f, 1.f, 1.f};          // the "styles" of an un-modulated launch (read with stride 0)
 
 template <int CB, int TB, bool RGB>
 __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_kernel(Wino3Params p) {
     constexpr int NB = CB * TB;                                    // 32x32 blocks per position and wave: 2 (128 accumulators) or 1 (64)
     static_assert(NB == 1 || NB == 2, "a wave carries one or two 32x32 blocks per position");
     constexpr int FH = 4 * TB + 2, FP = FH * W3FW;                 // footprint rows / pixels per channel
-    constexpr int XS = (W3CK * FP + 255) / 256;                    // staging slots per lane: 4 (TB = 1) or 6 (TB = 2)
-    constexpr int RAW = 256 * XS;
+    constexpr int SPC = (FP + 255) / 256;                          // staging slots per lane and CHANNEL: 1 (TB = 1) or 2 (TB = 2)
+    constexpr int XS = W3CK * SPC;                                 // staging slots per lane
+    constexpr int CST = 256 * SPC;                                 // floats between the channels of a staging buffer
+    constexpr int RAW = W3CK * CST;
     extern __shared__ float lds[];
     float* const raw0 = lds;
     float* const raw1 = raw0 + RAW;
-    float* const Ss = raw1 + RAW;                                  // [cin] styles
     const int tid = threadIdx.x, lane = tid & 63;
     const int a = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave = row of the transformed patch (wave-uniform)
     const int l31 = lane & 31, half = lane >> 5;
@@ -106,16 +108,16 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     // bookkeeping -- stays identical in every iteration (behind `if (more) load` the waits are merged conservatively over both paths
     // and drain the loads issued a moment ago, i.e. expose one L2 round trip per chunk)
     const __amdgpu_buffer_rsrc_t rnull = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, 0, 0x00020000);
-    unsigned xoff[XS];
-    int sidx[XS];                                                  // channel of the slot (which style multiplies it)
+    // A staging slot is ONE channel: slot j = channel j / SPC of the chunk, footprint pixel tid + 256 (j % SPC).  The pixel part of the
+    // address is the same for all channels (one VGPR per pixel slot; the channel rides in the scalar offset, which the range check ignores:
+    // a pixel outside the map stays out of range) and the style of a slot is wave-uniform: a scalar load, no LDS table.
+    unsigned xoff[SPC];
 #pragma unroll
-    for (int j = 0; j < XS; ++j) {
-        const int e = tid + 256 * j;
-        const int ch = e / FP, rem = e - ch * FP;
-        const int r = rem / W3FW, q = rem - r * W3FW;
+    for (int s = 0; s < SPC; ++s) {
+        const int e = tid + 256 * s;
+        const int r = e / W3FW, q = e - r * W3FW;
         const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
-        xoff[j] = (e < W3CK * FP && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? (unsigned)(ch * plane + iy * p.w + ix) * 4u : 0xFFFFFFF0u;
-        sidx[j] = ch < W3CK ? ch : W3CK - 1;
+        xoff[s] = (e < FP && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? (unsigned)(iy * p.w + ix) * 4u : 0xFFFFFFF0u;
     }
     // A operand of lane (l31, half) for position 4a + b, block cb: 8 bytes = slots {2 half, 2 half + 1} = channels {half, half + 2} of
     // output channel co0 + 32 cb + l31.  The position / chunk part of the address is wave-uniform and rides in the scalar offset.
@@ -125,14 +127,23 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
 
     float xr[XS];
     auto load_x = [&](float (&dst)[XS], int c0, bool live = true) {
-        const int soff = c0 * plane * 4;
         const __amdgpu_buffer_rsrc_t r = live ? rx : rnull;
 #pragma unroll
-        for (int j = 0; j < XS; ++j) dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff[j], soff, 0));
+        for (int j = 0; j < XS; ++j)
+            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, xoff[j % SPC], (c0 + j / SPC) * plane * 4, 0));
     };
-    auto park_x = [&](float* R, const float (&src)[XS], int c0) {
+    // (constant address space: the compiler then emits s_load for these uniform addresses -- through a generic pointer it falls back to
+    // flat vector loads, which also poison the vmcnt bookkeeping; no branch in the loop: an un-modulated launch re-reads four ones)
+    typedef const float __attribute__((address_space(4)))* cfp4;
+    const cfp4 sbase = sc ? (cfp4)sc : (cfp4)w3_ones;
+    const int sstep = sc ? 1 : 0;
+    auto load_s = [&](float (&dst)[W3CK], int c0) {                // the chunk's styles (uniform addresses: scalar loads)
 #pragma unroll
-        for (int j = 0; j < XS; ++j) R[tid + 256 * j] = src[j] * Ss[c0 + sidx[j]];       // the style modulation rides on the input
+        for (int j = 0; j < W3CK; ++j) dst[j] = sbase[c0 * sstep + j];
+    };
+    auto park_x = [&](float* R, const float (&src)[XS], const float (&sv)[W3CK]) {
+#pragma unroll
+        for (int j = 0; j < XS; ++j) R[(j / SPC) * CST + tid + 256 * (j % SPC)] = src[j] * sv[j / SPC];      // the style modulation rides on the input
     };
     auto load_a = [&](v2f (&dst)[4][CB], int c0, bool live = true) {
         const int soff = ubase + c0 * p.cout * 4;                  // chunk c0 / 4 starts (c0 / 4) * cout * 4 floats into a position plane
@@ -147,19 +158,27 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     const int pr = a == 0 ? 0 : (a == 2 ? 2 : 1);
     const int qr = a == 2 ? 1 : (a == 3 ? 3 : 2);
     const float sg = a == 1 ? 1.f : -1.f;
+    const v2f sg2 = {sg, sg}, pm = {-1.f, 1.f}, sgpm = {-sg, sg};
     auto transform = [&](float (&B)[TB][2][4], const float* R) {
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const float* src = R + ((half + 2 * kk) * FH + 2 * (tb * 2 + ty)) * W3FW + 2 * tx;
+                const float* src = R + (half + 2 * kk) * CST + 2 * (tb * 2 + ty) * W3FW + 2 * tx;
                 const v2f p01 = *reinterpret_cast<const v2f*>(src + pr * W3FW), p23 = *reinterpret_cast<const v2f*>(src + pr * W3FW + 2);
                 const v2f q01 = *reinterpret_cast<const v2f*>(src + qr * W3FW), q23 = *reinterpret_cast<const v2f*>(src + qr * W3FW + 2);
-                const float t0 = p01.x + sg * q01.x, t1 = p01.y + sg * q01.y, t2 = p23.x + sg * q23.x, t3 = p23.y + sg * q23.y;
-                B[tb][kk][0] = t0 - t2;
-                B[tb][kk][1] = t1 + t2;
-                B[tb][kk][2] = t2 - t1;
-                B[tb][kk][3] = t1 - t3;
+                // PACKED fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes of math per issue slot), written so that every operand is a register
+                // pair or a broadcast of one half of a pair (op_sel) -- 5 instructions for the 4 values instead of 8:
+                //   t = p + sg q;  (B0, B1) = (t0 - t2, t1 + t2) = t01 + p2 (-1, 1) + q2 (-sg, sg);  (B2, -B3) = t23 - (t1, t1).
+                // Position 3 of the row thus carries -B3, i.e. its accumulator -M3: the output transform below ADDS it.
+                const v2f t01 = p01 + sg2 * q01, t23 = p23 + sg2 * q23;
+                const v2f p2b = {p23.x, p23.x}, q2b = {q23.x, q23.x}, t1b = {t01.y, t01.y};
+                const v2f b01 = q2b * sgpm + (p2b * pm + t01);
+                const v2f b23 = t23 - t1b;
+                B[tb][kk][0] = b01.x;
+                B[tb][kk][1] = b01.y;
+                B[tb][kk][2] = b23.x;
+                B[tb][kk][3] = b23.y;
             }
     };
 
@@ -190,16 +209,18 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     auto chunk0 = [&](int i) { return (i < last ? i : last) * W3CK; };
     v2f A0[4][CB], A1[4][CB];
     float B0[TB][2][4], B1[TB][2][4];
+    float sv[W3CK];                                  // styles of the chunk parked next (scalar registers)
     {
-        float xa[XS], xb[XS];
+        float xa[XS], xb[XS], sa_[W3CK], sb_[W3CK];
+        load_s(sv, chunk0(2));
         load_x(xa, 0);
         load_a(A0, 0);
         load_x(xb, chunk0(1));
         load_x(xr, chunk0(2));
-        for (int i = tid; i < p.cin; i += 256) Ss[i] = sc ? sc[i] : 1.f;
-        __syncthreads();                             // Ss is read when parking
-        park_x(raw0, xa, 0);
-        park_x(raw1, xb, chunk0(1));
+        load_s(sa_, 0);
+        load_s(sb_, chunk0(1));
+        park_x(raw0, xa, sa_);
+        park_x(raw1, xb, sb_);
         __syncthreads();
         transform(B0, raw0);
         __syncthreads();                             // body(0) parks chunk 2 over raw0: every wave must have read chunk 0 from it
@@ -210,17 +231,16 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     auto body = [&](int i, v2f (&Acur)[4][CB], v2f (&Anxt)[4][CB], float (&Bcur)[TB][2][4], float (&Bnxt)[TB][2][4], float* raw_nxt, float* raw_park) {
         // ONE basic block: nothing here is conditional (past the last chunk the loads go through the null resource, the transform and
         // the parking work on values nobody reads)
+        // the fences keep the order written here: left alone, the scheduler hoists the parking -- and with it the wait for x(i+2),
+        // requested only one chunk ago -- in front of the MFMAs
         load_a(Anxt, chunk0(i + 1), i + 1 < nchunks);
-#if !defined(MGF_W3EXP) || MGF_W3EXP != 2         // experiment 2: no input transform
+        __builtin_amdgcn_sched_barrier(0);
         transform(Bnxt, raw_nxt);
-#endif
-#if !defined(MGF_W3EXP) || MGF_W3EXP != 1         // experiment 1: no matrix work
         mfma_chunk(Acur, Bcur);
-#endif
-#if !defined(MGF_W3EXP) || MGF_W3EXP != 3         // experiment 3: no footprint staging
-        park_x(raw_park, xr, chunk0(i + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        park_x(raw_park, xr, sv);
         load_x(xr, chunk0(i + 3), i + 3 < nchunks);
-#endif
+        load_s(sv, chunk0(i + 3));                   // (requested here, a whole chunk before their use: scalar loads share the LDS counter)
         __syncthreads();
     };
     for (int it = 0; it < nchunks; it += 2) {
@@ -253,7 +273,7 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
                 const int jj = UMODE == 2 ? un : (v & 1);
                 const int cb = (UMODE == 0 && CB == 2) ? un : 0, tb = (UMODE == 0 && TB == 2) ? un : 0;
                 const float m0 = acc[0][cb][tb][r], m1 = acc[1][cb][tb][r], m2 = acc[2][cb][tb][r], m3 = acc[3][cb][tb][r];
-                const float val = jj == 0 ? m0 + m1 + m2 : m1 - m2 - m3;
+                const float val = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;        // (m3 = -M3, see transform)
                 if (un == blk) own[v] = val;
                 if (ws >= 0) dst[v * 64] = val;
             }
@@ -487,8 +507,9 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     }
     // main loop: two footprint buffers + the styles; epilogue: 6 exchange slots (+ the ToRGB weights) over the same memory
     const size_t nv = cb * tb == 2 ? 32 : 16;
-    const size_t lds = std::max<size_t>((size_t)(2 * 256 * (tb == 2 ? 6 : 4) + cin) * sizeof(float),
-                                        (size_t)(6 * nv * 64 + (res_low ? 2304 : 96)) * sizeof(float));
+    static const size_t lds_pad = [] { const char* e = getenv("MGF_W3_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();   // tuning: fewer workgroups per CU
+    const size_t lds = std::max<size_t>((size_t)(2 * 256 * (tb == 2 ? 8 : 4)) * sizeof(float),
+                                        (size_t)(6 * nv * 64 + (res_low ? 2304 : 96)) * sizeof(float)) + lds_pad;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)wino3_conv_kernel<2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
