@@ -56,6 +56,9 @@ struct Wino3Params {
     int odd;                  // h or w odd: pixel pairs are stored / loaded element-wise with bounds checks
 };
 
+#ifndef MGF_W3X
+#define MGF_W3X 0
+#endif
 #ifndef W3_OCC1
 #define W3_OCC1 4                        // workgroups per CU the one-block shapes are compiled for (3 -> 4: conv_last + ToRGB 3.64 -> 3.26 ms)
 #endif
@@ -210,6 +213,45 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     v2f A0[4][CB], A1[4][CB];
     float B0[TB][2][4], B1[TB][2][4];
     float sv[W3CK];                                  // styles of the chunk parked next (scalar registers)
+    // Epilogue operands of the one-block shape -- the half-resolution residual window, the noise rows, the demodulation and bias of the 32
+    // channels -- are requested NOW, as LDS-DMA loads (buffer_load ... lds: no register holds them across the main loop) into LDS
+    // behind the exchange slots, which the staging buffers do not reach: the epilogue then has no global load between the last MFMA and
+    // its stores (it used to request them there and sit out an HBM round trip per workgroup -- with four workgroups per CU the kernel is
+    // bound by the length of a workgroup's dependency chain, not by any throughput).  Lane l of a wave writes LDS base + 4 l; out-of-range
+    // lanes write zeros.  These are the oldest loads in flight, so the first ordinary wait below retires them too.
+    constexpr int UMODE = NB == 2 ? 0 : (RGB ? 2 : 1);
+    constexpr int NV = UMODE == 0 ? 32 : 16;         // values per lane and exchange slot
+    float* const lowt = lds + 6 * NV * 64;           // [32 channels][4 rows][18 columns] half-resolution residual window (2304 floats)
+    float* const nzs = lowt + (p.res_low ? 2304 : 0);    // [4 rows][64]: noise of the tile's rows (32 px used)
+    float* const obs = nzs + 256;                    // [2][64]: out_scale, bias of the 32 channels
+    const bool pre_ep = UMODE == 1 && !p.odd;        // (uniform)
+    if (pre_ep) {
+        if (p.res_low) {
+            const int hl = p.h >> 1, wl = p.w >> 1, pl = hl * wl;
+            const __amdgpu_buffer_rsrc_t rlow = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res_low + ((int64_t)n * p.cout + co0) * pl), 0, 32 * pl * 4, 0x00020000);
+            const int m0 = (oy0 >> 1) - 1, n0 = (ox0 >> 1) - 1;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int e = tid + 256 * j;
+                const int ch = e / 72, rem = e - ch * 72;
+                const int r = rem / 18, c = rem - r * 18;
+                const int my = m0 + r, nx = n0 + c;
+                const unsigned off = (my >= 0 && my < hl && nx >= 0 && nx < wl) ? (unsigned)(ch * pl + my * wl + nx) * 4u : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rlow, lowt + 256 * j + 64 * a, 4, off, 0, 0, 0);
+            }
+        }
+        if (p.has_ep && p.ep.noise) {                // wave a: row a of the tile, lanes 0..31 its 32 pixels
+            const __amdgpu_buffer_rsrc_t rnz = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane), 0, plane * 4, 0x00020000);
+            const int ny = oy0 + a, nx = ox0 + lane;
+            const unsigned off = (lane < 32 && ny < p.h && nx < p.w) ? (unsigned)(ny * p.w + nx) * 4u : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rnz, nzs + 64 * a, 4, off, 0, 0, 0);
+        }
+        if (a < 2) {                                 // wave 0: out_scale, wave 1: bias (a null pointer gets a zero-size resource: zeros)
+            const float* src = a == 0 ? (p.out_scale ? p.out_scale + (int64_t)n * p.os_stride + co0 : nullptr) : ((p.has_ep && p.ep.bias) ? p.ep.bias + co0 : nullptr);
+            const __amdgpu_buffer_rsrc_t rob = __builtin_amdgcn_make_buffer_rsrc((void*)(src ? src : p.x), 0, src ? 32 * 4 : 0, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rob, obs + 64 * a, 4, (unsigned)lane * 4u, 0, 0, 0);
+        }
+    }
     {
         float xa[XS], xb[XS], sa_[W3CK], sb_[W3CK];
         load_s(sv, chunk0(2));
@@ -233,21 +275,37 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         // the parking work on values nobody reads)
         // the fences keep the order written here: left alone, the scheduler hoists the parking -- and with it the wait for x(i+2),
         // requested only one chunk ago -- in front of the MFMAs
+        // (MGF_W3X: bit mask of timing ablations built by tools/build_exp.sh, results wrong by construction -- 1 no matrix work, 2 no
+        // input transform, 4 no footprint staging, 8 no weight loads, 16 no barrier, 32 no epilogue at all)
+#if !(MGF_W3X & 8)
         load_a(Anxt, chunk0(i + 1), i + 1 < nchunks);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+#if !(MGF_W3X & 2)
         transform(Bnxt, raw_nxt);
+#endif
+#if !(MGF_W3X & 1)
         mfma_chunk(Acur, Bcur);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+#if !(MGF_W3X & 4)
         park_x(raw_park, xr, sv);
         load_x(xr, chunk0(i + 3), i + 3 < nchunks);
         load_s(sv, chunk0(i + 3));                   // (requested here, a whole chunk before their use: scalar loads share the LDS counter)
+#endif
+#if !(MGF_W3X & 16)
         __syncthreads();
+#endif
     };
     for (int it = 0; it < nchunks; it += 2) {
         body(it, A0, A1, B0, B1, raw1, raw0);
         if (it + 1 < nchunks) body(it + 1, A1, A0, B1, B0, raw0, raw1);
     }
 
+#if MGF_W3X & 32
+    if (acc[0][0][0][0] + acc[1][0][0][1] + acc[2][0][0][2] + acc[3][0][0][3] == 12345.f) p.y[tid] = B0[0][0][0] + A0[0][0].x;
+    return;
+#endif
     // ---- output transform.  R[j] = row a of M times A: R0 = M0 + M1 + M2, R1 = M1 - M2 - M3 per accumulator register; then over the
     // rows (= waves): Y0 = R[0] + R[1] + R[2], Y1 = R[1] - R[2] - R[3].  The work is cut in two UNITS and wave w finishes output row
     // (w >> 1) of unit (w & 1):
@@ -255,8 +313,6 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     // with the exchange slots  s0 = R[0] u1, s1 = R[1] u0, s2 = R[1] u1, s3 = R[2] u0, s4 = R[2] u1, s5 = R[3] u0.
     // A unit is: one of the wave's two 32x32 blocks (NB = 2); a half of the block's 16 registers, i.e. 16 of its 32 channels (NB = 1);
     // or, for the fused ToRGB with one block, an output COLUMN j (the wave then holds one pixel of every quad for all 32 channels). ----
-    constexpr int UMODE = NB == 2 ? 0 : (RGB ? 2 : 1);
-    constexpr int NV = UMODE == 0 ? 32 : 16;         // values per lane and exchange slot
     float own[NV];
     float* xch = lds;                                // [6 slots][NV values][64 lanes]; the staging buffers are dead
     const int blk = a & 1, orow = a >> 1;
@@ -337,8 +393,10 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const int co = cob + (k & 3) + 8 * (k >> 2);
-        osv[k] = osc ? osc[co] : 1.f;
-        bvv[k] = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
+        if (!pre_ep) {
+            osv[k] = osc ? osc[co] : 1.f;
+            bvv[k] = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
+        }
         rr[k] = make_float2(0.f, 0.f);
     }
     const unsigned voff = ok_px ? (unsigned)(cob * plane + oy * p.w + ox) * 4u : 0xFFFFFFF0u;
@@ -364,25 +422,8 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     //   out[2m] = x[m-1] / 4 + 3 x[m] / 4,   out[2m+1] = 3 x[m] / 4 + x[m+1] / 4   per axis, zeros outside the map.
     // The workgroup's 4 x 18 low-resolution window of its 32 channels (9 KB) goes through LDS, behind the exchange slots: the full
     // resolution skip tensor -- one write and one read of the largest activation of the block -- never exists.
-    float* lowt = lds + 6 * NV * 64;                 // [32 channels][4 rows][18 columns]
-    if (UMODE == 1 && p.res_low) {
-        const int hl = p.h >> 1, wl = p.w >> 1, pl = hl * wl;
-        const __amdgpu_buffer_rsrc_t rlow = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res_low + ((int64_t)n * p.cout + co0) * pl), 0, 32 * pl * 4, 0x00020000);
-        const int m0 = (oy0 >> 1) - 1, n0 = (ox0 >> 1) - 1;
-        float lv[9];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const int e = tid + 256 * j;
-            const int ch = e / 72, rem = e - ch * 72;
-            const int r = rem / 18, c = rem - r * 18;
-            const int my = m0 + r, nx = n0 + c;
-            const unsigned off = (my >= 0 && my < hl && nx >= 0 && nx < wl) ? (unsigned)(ch * pl + my * wl + nx) * 4u : 0xFFFFFFF0u;
-            lv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rlow, off, 0, 0));
-        }
-#pragma unroll
-        for (int j = 0; j < 9; ++j) lowt[tid + 256 * j] = lv[j];
-    }
-    if (do_ep && p.ep.noise && ok_px) {
+    // (the window itself was requested in the prologue, see there)
+    if (do_ep && p.ep.noise && ok_px && !pre_ep) {
         const float ns = p.ep.noise_strength ? *p.ep.noise_strength : 1.f;
         const float* np_ = p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane + (int64_t)oy * p.w + ox;
         if (!p.odd) {
@@ -394,6 +435,20 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         }
     }
     __syncthreads();
+    if (pre_ep) {
+        const int chl = cob - co0;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int cl = chl + (k & 3) + 8 * (k >> 2);
+            osv[k] = p.out_scale ? obs[cl] : 1.f;
+            bvv[k] = obs[64 + cl];
+        }
+        if (do_ep && p.ep.noise) {
+            const float ns = p.ep.noise_strength ? *p.ep.noise_strength : 1.f;
+            const float2 nv = *reinterpret_cast<const float2*>(nzs + 64 * (2 * trow + orow) + 2 * tx);
+            nz0 = nv.x * ns; nz1 = nv.y * ns;
+        }
+    }
     if (UMODE == 1 && p.res_low) {
         // this wave's output row is oy = oy0 + 2 trow + orow: low rows (m-1, m) with weights (1/4, 3/4) for orow = 0, (m, m+1) with
         // (3/4, 1/4) for orow = 1, i.e. window rows trow + orow and trow + orow + 1; window columns tx, tx + 1, tx + 2
@@ -509,7 +564,7 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     const size_t nv = cb * tb == 2 ? 32 : 16;
     static const size_t lds_pad = [] { const char* e = getenv("MGF_W3_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();   // tuning: fewer workgroups per CU
     const size_t lds = std::max<size_t>((size_t)(2 * 256 * (tb == 2 ? 8 : 4)) * sizeof(float),
-                                        (size_t)(6 * nv * 64 + (res_low ? 2304 : 96)) * sizeof(float)) + lds_pad;
+                                        (size_t)(6 * nv * 64 + (res_low ? 2304 : 0) + 256 + 128) * sizeof(float)) + lds_pad;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)wino3_conv_kernel<2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);

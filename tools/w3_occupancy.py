@@ -9,11 +9,12 @@ for res, c in ((64, 512), (256, 128), (512, 64), (1024, 32)):
     s, d = torch.rand(n, c, device="cuda") + 0.5, torch.rand(n, c, device="cuda") + 0.5
     noise, bias = torch.randn(n, res * res, device="cuda"), torch.randn(c, device="cuda")
     st = torch.tensor([0.1], device="cuda")
-    resid = torch.randn(n, c, res, res, device="cuda")
-    ep = _lib.make_epilogue(bias=bias, noise=noise, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.4, residual=resid)
+    low = os.environ.get("W3_LOW", "0") == "1" and res >= 256       # the engine's fused skip up-sample (256^2 and larger)
+    resid = torch.randn(n, c, res // 2, res // 2, device="cuda") if low else torch.randn(n, c, res, res, device="cuda")
+    ep = _lib.make_epilogue(bias=bias, noise=noise, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.4, residual=None if low else resid)
     u2 = cv.winograd2_weights(w)
     out = torch.empty_like(x)
-    fn = lambda: cv.winograd2_forward(x, u2, in_scale=s, out_scale=d, epilogue=ep, out=out)
+    fn = lambda: cv.winograd2_forward(x, u2, in_scale=s, out_scale=d, epilogue=ep, out=out, residual_low=resid if low else None)
     fn(); fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
