@@ -252,6 +252,13 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rob, obs + 64 * a, 4, (unsigned)lane * 4u, 0, 0, 0);
         }
     }
+    // (fused ToRGB: the projection weights times the demodulation, [3][32] behind the exchange slots, likewise fetched up front)
+    float wv_pre = 0.f;
+    if (RGB && tid < 96) {
+        const int cc = tid >> 5, co = tid & 31;
+        if (cc < p.rgb_channels)
+            wv_pre = p.rgb_w[((int64_t)n * p.rgb_channels + cc) * p.cout + co0 + co] * (p.out_scale ? p.out_scale[(int64_t)n * p.os_stride + co0 + co] : 1.f);
+    }
     {
         float xa[XS], xb[XS], sa_[W3CK], sb_[W3CK];
         load_s(sv, chunk0(2));
@@ -263,6 +270,7 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         load_s(sb_, chunk0(1));
         park_x(raw0, xa, sa_);
         park_x(raw1, xb, sb_);
+        if (RGB && tid < 96) lowt[tid] = wv_pre;     // (= wvs of the epilogue)
         __syncthreads();
         transform(B0, raw0);
         __syncthreads();                             // body(0) parks chunk 2 over raw0: every wave must have read chunk 0 from it
@@ -352,12 +360,8 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         // fused ToRGB: the wave holds, for all 32 channels (16 per lane half), row `orow` of its tiles' quads (UMODE 0: both columns)
         // or pixel (orow, blk) of them (UMODE 2).  The projection weights times the demodulation go through LDS once per workgroup.
         const int rc = p.rgb_channels;
-        float* wvs = lds + 6 * NV * 64;              // [3][32]
-        if (tid < 96) {
-            const int cc = tid >> 5, co = tid & 31;
-            wvs[tid] = cc < rc ? p.rgb_w[((int64_t)n * rc + cc) * p.cout + co0 + co] * (osc ? osc[co0 + co] : 1.f) : 0.f;
-        }
-        __syncthreads();
+        const float* wvs = lowt;                     // [3][32], written in the prologue
+        __syncthreads();                             // the exchange slots are complete
         constexpr int NC = UMODE == 0 ? 2 : 1;       // output columns this wave produces
         float sum[3][NC];
 #pragma unroll
