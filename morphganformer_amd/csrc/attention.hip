@@ -17,6 +17,40 @@
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+// The two 16-wide inner products of the register kernels in PACKED fp32 (v_pk_fma_f32: two lanes of math per issue slot; the scalar form
+// issued 16 v_fmac per channel and phase): scores  s[0..15] += x * row,  gain  g = <s, row>.  `row` = 16 floats of an LDS table.
+#ifndef MGF_ATTX
+#define MGF_ATTX 0          // timing ablations (tools/build_exp.sh; results wrong by construction): 1 no score FMAs, 2 no gain dot product,
+#endif                      // 4 both read ONE table row (LDS reads hoisted out of the channel loops)
+__device__ __forceinline__ void att_fma_row(v2f (&s2)[8], float xv, const float4* w4) {
+#if MGF_ATTX & 1
+    s2[0] += v2f{xv, xv}; return;
+#endif
+    const v2f x2 = {xv, xv};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 w = w4[q];
+        const v2f lo = {w.x, w.y}, hi = {w.z, w.w};
+        s2[2 * q] += x2 * lo;
+        s2[2 * q + 1] += x2 * hi;
+    }
+}
+__device__ __forceinline__ float att_dot_row(const v2f (&s2)[8], const float4* w4) {
+#if MGF_ATTX & 2
+    return s2[0].x + w4[0].x;
+#endif
+    v2f g2 = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 w = w4[q];
+        const v2f lo = {w.x, w.y}, hi = {w.z, w.w};
+        g2 += s2[2 * q] * lo;
+        g2 += s2[2 * q + 1] * hi;
+    }
+    return g2.x + g2.y;
+}
+
 constexpr int TMAX = 16;
 constexpr int UNR = 4;
 
@@ -270,37 +304,41 @@ __global__ __launch_bounds__(256) void duplex_attention_reg_kernel(AttnParams p)
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
     float sq = 0.f;
+    v2f s2[TMAX / 2];
+#pragma unroll
+    for (int q = 0; q < TMAX / 2; ++q) s2[q] = v2f{0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
-        const float4* w4 = reinterpret_cast<const float4*>(tab + c * TMAX);
         const float xv = xreg[k];
         sq += xv * xv;
-#pragma unroll
-        for (int q = 0; q < TMAX / 4; ++q) {
-            const float4 w = w4[q];
-            s[4 * q + 0] += xv * w.x; s[4 * q + 1] += xv * w.y;
-            s[4 * q + 2] += xv * w.z; s[4 * q + 3] += xv * w.w;
-        }
+        att_fma_row(s2, xv, reinterpret_cast<const float4*>(tab + ((MGF_ATTX & 4) ? 0 : c) * TMAX));
     }
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) part[(grp * (TMAX + 1) + t) * PXB + px] = s[t];
+    for (int t = 0; t < TMAX; ++t) part[(grp * (TMAX + 1) + t) * PXB + px] = (t & 1) ? s2[t >> 1].y : s2[t >> 1].x;
     part[(grp * (TMAX + 1) + TMAX) * PXB + px] = sq;
     __syncthreads();                               // all reads of the wqc table are done: overwrite it with vwb
 #pragma unroll
     for (int u = 0; u < TV; ++u) t4[tid + 256 * u] = tv[u];
 
+    // the G partial sums of the 17 values of a pixel: group g totals value t = g (+ G, ...) and publishes it -- every group summing
+    // all 17 itself was 272 LDS reads + adds per thread where 33 + 16 do
+    float* fin = part + G * (TMAX + 1) * PXB;      // [17][PXB]
+    for (int t = grp; t < TMAX + 1; t += G) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) v += part[(g * (TMAX + 1) + t) * PXB + px];
+        fin[t * PXB + px] = v;
+    }
+    __syncthreads();
     float m = -3.0e38f;
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
-        float v = 0.f;
-        for (int g = 0; g < G; ++g) v += part[(g * (TMAX + 1) + t) * PXB + px];
-        v += sp[t];
+        const float v = fin[t * PXB + px] + sp[t];
         m = fmaxf(m, v);
         s[t] = v;
     }
-    sq = 0.f;
-    for (int g = 0; g < G; ++g) sq += part[(g * (TMAX + 1) + TMAX) * PXB + px];
+    sq = fin[TMAX * PXB + px];
     float den = 0.f;
     int best = 0;
     float bestv = -3.0e38f;
@@ -320,20 +358,14 @@ __global__ __launch_bounds__(256) void duplex_attention_reg_kernel(AttnParams p)
         if (p.argmax) p.argmax[(int64_t)n * p.f + f] = best;
     }
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) s[t] *= rs;
-    __syncthreads();
+    for (int q = 0; q < TMAX / 2; ++q) s2[q] = v2f{s[2 * q] * rs, s[2 * q + 1] * rs};
+    // (the barrier behind the totals also ordered the vwb table: no further barrier)
 
     float* yn = p.y + (int64_t)n * p.c * p.f;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
-        const float4* w4 = reinterpret_cast<const float4*>(tab + c * TMAX);
-        float g = 0.f;
-#pragma unroll
-        for (int q = 0; q < TMAX / 4; ++q) {
-            const float4 w = w4[q];
-            g += s[4 * q + 0] * w.x + s[4 * q + 1] * w.y + s[4 * q + 2] * w.z + s[4 * q + 3] * w.w;
-        }
+        const float g = att_dot_row(s2, reinterpret_cast<const float4*>(tab + ((MGF_ATTX & 4) ? 0 : c) * TMAX));
         float v = xreg[k] * g;
         if (p.has_ep) {
             v += nz;
@@ -413,38 +445,40 @@ __global__ __launch_bounds__(256) void duplex_attention_blocks_kernel(AttnParams
         for (int t = 0; t < TMAX; ++t) spk[t] = sp[t];
         const float nzk = nz;
         if (TWO && blk + 1 < NBLK) load_block(blk + 1);
+        v2f s2[TMAX / 2];
+#pragma unroll
+        for (int q = 0; q < TMAX / 2; ++q) s2[q] = v2f{0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
-            const float4* w4 = reinterpret_cast<const float4*>(tab + c * TMAX);
             const float xv = xk[k];
             sq += xv * xv;
-#pragma unroll
-            for (int q = 0; q < TMAX / 4; ++q) {
-                const float4 w = w4[q];
-                s[4 * q + 0] += xv * w.x; s[4 * q + 1] += xv * w.y;
-                s[4 * q + 2] += xv * w.z; s[4 * q + 3] += xv * w.w;
-            }
+            att_fma_row(s2, xv, reinterpret_cast<const float4*>(tab + ((MGF_ATTX & 4) ? 0 : c) * TMAX));
         }
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) part[(grp * (TMAX + 1) + t) * PXB + px] = s[t];
+        for (int t = 0; t < TMAX; ++t) part[(grp * (TMAX + 1) + t) * PXB + px] = (t & 1) ? s2[t >> 1].y : s2[t >> 1].x;
         part[(grp * (TMAX + 1) + TMAX) * PXB + px] = sq;
         __syncthreads();                           // (one table: all reads of the wqc table are done, overwrite it with vwb)
         if (!TWO) {
 #pragma unroll
             for (int u = 0; u < TV; ++u) t4[tid + 256 * u] = tv[u];
         }
+        float* fin = part + G * (TMAX + 1) * PXB;  // [17][PXB]: group g totals value t = g (+ G, ...) of its pixel (see the kernel above)
+        for (int t = grp; t < TMAX + 1; t += G) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) v += part[(g * (TMAX + 1) + t) * PXB + px];
+            fin[t * PXB + px] = v;
+        }
+        __syncthreads();
         float m = -3.0e38f;
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
-            float v = 0.f;
-            for (int g = 0; g < G; ++g) v += part[(g * (TMAX + 1) + t) * PXB + px];
-            v += spk[t];
+            const float v = fin[t * PXB + px] + spk[t];
             m = fmaxf(m, v);
             s[t] = v;
         }
-        sq = 0.f;
-        for (int g = 0; g < G; ++g) sq += part[(g * (TMAX + 1) + TMAX) * PXB + px];
+        sq = fin[TMAX * PXB + px];
         float den = 0.f;
         int best = 0;
         float bestv = -3.0e38f;
@@ -464,20 +498,14 @@ __global__ __launch_bounds__(256) void duplex_attention_blocks_kernel(AttnParams
             if (p.argmax) p.argmax[(int64_t)n * p.f + f] = best;
         }
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) s[t] *= rs;
-        __syncthreads();                           // `part` is free for the next block (one table: vwb is in place)
+        for (int q = 0; q < TMAX / 2; ++q) s2[q] = v2f{s[2 * q] * rs, s[2 * q + 1] * rs};
+        // (no barrier here: `part` and `fin` of the next block are written behind barriers every wave passes after its reads)
 
         float* yn = p.y + (int64_t)n * p.c * p.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
-            const float4* w4 = reinterpret_cast<const float4*>(tabv + c * TMAX);
-            float g = 0.f;
-#pragma unroll
-            for (int q = 0; q < TMAX / 4; ++q) {
-                const float4 w = w4[q];
-                g += s[4 * q + 0] * w.x + s[4 * q + 1] * w.y + s[4 * q + 2] * w.z + s[4 * q + 3] * w.w;
-            }
+            const float g = att_dot_row(s2, reinterpret_cast<const float4*>(tabv + ((MGF_ATTX & 4) ? 0 : c) * TMAX));
             float v = xk[k] * g;
             if (p.has_ep) {
                 v += nzk;
@@ -488,6 +516,157 @@ __global__ __launch_bounds__(256) void duplex_attention_blocks_kernel(AttnParams
                 v += rk[k];
             }
             if (valid) yn[(int64_t)c * p.f + f] = v;
+        }
+    }
+}
+
+// MFMA form of the register kernels for the generator's attention layers (C = 256 or 512, 16 latents; F a multiple of 32): both small
+// products of the layer are 1x1 convolutions -- scores[t][px] = sum_c wqc[c][t] x[c][px] (C -> 16 channels) and gain[c][px] = sum_t
+// vwb[c][t] p[t][px] (16 -> C) -- and run on v_mfma_f32_32x32x2_f32 with register operands like csrc/pointwise.hip.  A workgroup takes
+// 32 pixels (every global access of a wave is two 128-byte row segments), wave w the channels [64 w, 64 w + 64):
+//   * a lane loads x for the 32 channel/pixel pairs that are BOTH its B-operand slots of the score GEMM and its accumulator slots of the
+//     gain GEMM: the k-steps walk the channels in accumulator order -- k-step r of block cb = channels 32 cb + (r & 3) + 8 (r >> 2) +
+//     {0, 4} for the lane halves -- so x is read once, stays in 32 registers, and meets the gain without any data movement;
+//   * the partial scores of the waves (rows t of a 32x32 accumulator: 8 registers per lane) and sum x^2 meet in LDS (one barrier);
+//   * the softmax over 16 latents is 8 values in the lane + 8 in lane ^ 32 (two cross-lane exchanges);
+//   * the probabilities (times the layer-norm factor) are exactly the B-operand slots of the gain GEMM when its k-steps pair the latents
+//     as the accumulator rows pair them: k-step j = latents (j & 3) + 8 (j >> 2) + {0, 4}.
+// No LDS tables, no per-channel LDS reads, 17 + 16 FMAs per element replaced by 1/32 + 1/4 MFMA.  HBM-bound: x and residual in, y out.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void duplex_attention_mfma_kernel(AttnParams p) {
+    __shared__ float red[NW][9][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n = blockIdx.y, f0 = blockIdx.x * 32;
+    const int cw0 = wv * 64;
+    const int64_t nb = (int64_t)n * p.c * p.f;
+    const bool ep = p.has_ep != 0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + nb), 0, p.c * p.f * 4, 0x00020000);
+    const float* resp = (ep && p.ep.residual) ? p.ep.residual + nb : nullptr;          // (absent operands: zero-size resources read zeros)
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(resp ? resp : p.x), 0, resp ? p.c * p.f * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)p.wqc, 0, p.c * TMAX * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vwb + (int64_t)n * p.c * TMAX), 0, p.c * TMAX * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc((void*)p.spos, 0, p.f * TMAX * 4, 0x00020000);
+    const float* biasp = (ep && p.ep.bias) ? p.ep.bias : nullptr;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(biasp ? biasp : p.x), 0, biasp ? p.c * 4 : 0, 0x00020000);
+    auto rowof = [](int r) { return (r & 3) + 8 * (r >> 2); };         // accumulator register -> row of the 32x32 block (+ 4 half)
+
+    // ---- one burst of loads: x (kept), the score weights, the positional scores, the noise ----
+    const unsigned xo = (unsigned)((cw0 + 4 * half) * p.f + f0 + l31) * 4u;
+    const unsigned qo = l31 < TMAX ? (unsigned)((cw0 + 4 * half) * TMAX + l31) * 4u : 0xFFFFFFF0u;    // rows t >= 16 of the A operand are zero
+    float xr[2][16], a1[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = 32 * cb + rowof(r);
+            xr[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xo, ch * p.f * 4, 0));
+            a1[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, qo, ch * TMAX * 4, 0));
+        }
+    float sp[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        sp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsp, (unsigned)((f0 + l31) * TMAX + 4 * half) * 4u, rowof(r) * 4, 0));
+    float nz = 0.f;
+    if (ep && p.ep.noise) nz = p.ep.noise[(int64_t)(p.ep.noise_n > 1 ? n : 0) * p.f + f0 + l31] * (p.ep.noise_strength ? *p.ep.noise_strength : 1.f);
+
+    // ---- scores of this wave's 64 channels, sum x^2 ----
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float sq = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cb][r], xr[cb][r], acc, 0, 0, 0);
+            sq += xr[cb][r] * xr[cb][r];
+        }
+    // the residual rows are requested now: their latency runs behind the reduction and the softmax
+    float rr[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            rr[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, xo, (32 * cb + rowof(r)) * p.f * 4, 0));
+#pragma unroll
+    for (int r = 0; r < 8; ++r) red[wv][r][lane] = acc[r];
+    red[wv][8][lane] = sq;
+    __syncthreads();
+    float s[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float v = sp[r];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][r][lane];
+        s[r] = v;
+    }
+    sq = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sq += red[w][8][lane];
+    sq += __shfl_xor(sq, 32, 64);                  // the lane halves hold different channels
+    // ---- softmax over the 16 latents: 8 here (t = rowof(r) + 4 half), 8 in lane ^ 32 ----
+    float m = s[0];
+    int best = 4 * half;
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+        if (s[r] > m) { m = s[r]; best = rowof(r) + 4 * half; }
+    }
+    {
+        const float om = __shfl_xor(m, 32, 64);
+        const int ob = __shfl_xor(best, 32, 64);
+        if (om > m || (om == m && ob < best)) { m = om; best = ob; }      // first maximum, like the sequential scan
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { s[r] = __expf(s[r] - m); den += s[r]; }
+    den += __shfl_xor(den, 32, 64);
+    const float inv = 1.f / den;
+    const float rs = rsqrtf(sq / (float)p.c + 1e-8f);
+    if (wv == 0) {
+        if (p.probs) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) p.probs[((int64_t)n * p.f + f0 + l31) * TMAX + rowof(r) + 4 * half] = s[r] * inv;
+        }
+        if (p.argmax && half == 0) p.argmax[(int64_t)n * p.f + f0 + l31] = best;
+    }
+    const float ps = inv * rs;                      // the layer norm folded into the probabilities
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s[r] *= ps;
+
+    // ---- gain = vwb . p per 32-channel block, y = x * gain, epilogue ----
+    float* yn = p.y + nb;
+    const int act = p.ep.act;
+    const float alpha = p.ep.alpha, gain = p.ep.gain;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        // A operand of k-step j: vwb[channel cw0 + 32 cb + l31][latent rowof(j) + 4 half] = two 16-byte pieces of the channel's row
+        const unsigned vo = (unsigned)((cw0 + 32 * cb + l31) * TMAX + 4 * half) * 4u;
+        const float4 va = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 0));
+        const float4 vb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rv, vo + 32u, 0, 0));
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(cw0 + 32 * cb + 4 * half) * 4u, rowof(r) * 4, 0));
+        const float a2[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        f32x16 g;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[j], s[j], g, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = xr[cb][r] * g[r];
+            if (ep) {
+                v += nz;
+                v += bv[r];
+                if (act == MGF_ACT_LRELU) v = v > 0.f ? v : v * alpha;
+                else if (act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
+                v = v * gain + rr[cb][r];
+            }
+            yn[(int64_t)(cw0 + 32 * cb + rowof(r) + 4 * half) * p.f + f0 + l31] = v;
         }
     }
 }
@@ -513,12 +692,12 @@ void launch_attention(const AttnParams& p, size_t lds, hipStream_t st) {
     constexpr int G = 256 / PXB;
     const int nch = (p.c % (G * UNR) == 0) ? p.c / G : 0;
     if (p.t == TMAX && (nch == 16 || nch == 32 || nch == 64) && (nch * G) % 64 == 0) {
-        const size_t lds_r = ((size_t)p.c * TMAX + (size_t)G * (TMAX + 1) * PXB) * sizeof(float);
+        const size_t lds_r = ((size_t)p.c * TMAX + (size_t)(G + 1) * (TMAX + 1) * PXB) * sizeof(float);
         // large maps with few channels (the 128x128 x 256 layers): 4 pixel blocks per workgroup, both tables resident
         static const char* nb_env = getenv("MGF_ATTN_NBLK");      // tuning hook (experiments only): 1 = one block per workgroup
         constexpr int NBLK = 4;
         if (PXB == 16 && nch == 16 && p.f >= 4096 && p.f % (PXB * NBLK) == 0 && !(nb_env && nb_env[0] == '1')) {
-            const size_t lds_2 = ((size_t)2 * p.c * TMAX + (size_t)G * (TMAX + 1) * PXB) * sizeof(float);
+            const size_t lds_2 = ((size_t)2 * p.c * TMAX + (size_t)(G + 1) * (TMAX + 1) * PXB) * sizeof(float);
             hipLaunchKernelGGL((duplex_attention_blocks_kernel<PXB, 16, NBLK>), dim3((unsigned)(p.f / (PXB * NBLK)), p.n), dim3(256), lds_2, st, p);
             return;
         }
@@ -549,6 +728,16 @@ extern "C" int mgf_duplex_attention(float* y, const float* x, const float* wqc, 
     p.has_ep = ep != nullptr; p.probs = probs; p.argmax = argmax;
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
     MGF_REQUIRE(((uintptr_t)wqc % 16 == 0) && ((uintptr_t)vwb % 16 == 0), MGF_EINVAL, "duplex_attention: tables must be 16-byte aligned");
+    // the generator's layers (256 / 512 channels, 16 latents, whole 32-pixel tiles): the MFMA form.  MGF_ATTN_MFMA=0 keeps the register
+    // kernels (tuning hook, tests).
+    static const char* mf_env = getenv("MGF_ATTN_MFMA");
+    if (t == TMAX && (c == 256 || c == 512) && f % 32 == 0 && !(mf_env && mf_env[0] == '0')) {
+        hipStream_t st0 = (hipStream_t)stream;
+        if (c == 256) hipLaunchKernelGGL((duplex_attention_mfma_kernel<4>), dim3((unsigned)(f / 32), n), dim3(256), 0, st0, p);
+        else hipLaunchKernelGGL((duplex_attention_mfma_kernel<8>), dim3((unsigned)(f / 32), n), dim3(512), 0, st0, p);
+        MGF_CHECK_LAUNCH("duplex_attention");
+        return MGF_OK;
+    }
     static const char* pxb_env = getenv("MGF_ATTN_PXB");      // tuning hook (experiments only)
     const int pxb = pxb_env ? atoi(pxb_env) : (f > 16384 ? 64 : 16);
     const int g = 256 / pxb;
@@ -557,6 +746,7 @@ extern "C" int mgf_duplex_attention(float* y, const float* x, const float* wqc, 
     MGF_REQUIRE(lds <= 64 * 1024, MGF_EUNSUPPORTED, "duplex_attention: %d channels need %zu bytes of LDS (> 64 KiB)", c, lds);
     hipStream_t st = (hipStream_t)stream;
     if (pxb == 64) launch_attention<64>(p, lds, st);
+    else if (pxb == 32) launch_attention<32>(p, lds, st);
     else launch_attention<16>(p, lds, st);
     MGF_CHECK_LAUNCH("duplex_attention");
     return MGF_OK;

@@ -452,3 +452,46 @@ def test_winograd3_half_resolution_residual(n, cin, cout, h, w):
     ep2 = _lib.make_epilogue(bias=bd, noise=nd, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.3, residual=full)
     two = cv.winograd_forward(xd, u, in_scale=sd, out_scale=dd, epilogue=ep2)
     assert rel_err(out, two) < 2e-6
+
+
+@pytest.mark.parametrize("n,c,f,with_ep", [(2, 256, 128, True), (1, 512, 96, True), (2, 256, 64, False), (3, 64, 80, True), (1, 512, 1024, True)])
+def test_duplex_attention_forward_all_kernel_forms_vs_float64(n, c, f, with_ep):
+    """mgf_duplex_attention against the folded layer written out in float64: S = x^T wqc + spos, P = softmax(S), y = x rsqrt(mean_c x^2
+    + 1e-8) (P vwb^T) -> noise, bias, lrelu, gain, residual; probabilities and first-maximum assignments.  256 / 512 channels with whole
+    32-pixel tiles run the MFMA kernel, the rest the register kernels."""
+    import ctypes as C
+    from morphganformer_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(c + f)
+    T = 16
+    x = torch.randn(n, c, f, dtype=torch.float64)
+    wqc = torch.randn(c, T, dtype=torch.float64) / math.sqrt(c)
+    spos = torch.randn(f, T, dtype=torch.float64)
+    vwb = 1 + 0.3 * torch.randn(n, c, T, dtype=torch.float64)
+    noise, bias, res = torch.randn(n, f, dtype=torch.float64), torch.randn(c, dtype=torch.float64), torch.randn(n, c, f, dtype=torch.float64)
+    S = torch.einsum("ncf,ct->nft", x, wqc) + spos[None]
+    P = torch.softmax(S, -1)
+    r = torch.rsqrt(x.square().mean(1, keepdim=True) + 1e-8)
+    y = x * r * torch.einsum("nft,nct->ncf", P, vwb)
+    if with_ep:
+        y = torch.nn.functional.leaky_relu(y + 0.37 * noise[:, None] + bias[None, :, None], 0.2) * 1.3 + res
+    fl = lambda t: t.float().cuda().contiguous()
+    xd, wd, sd_, vd, nd, bd, rd = fl(x), fl(wqc), fl(spos), fl(vwb), fl(noise), fl(bias), fl(res)
+    st = torch.tensor([0.37], device="cuda")
+    ep = _lib.make_epilogue(bias=bd, noise=nd, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.3, residual=rd) if with_ep else None
+    out = torch.empty_like(xd)
+    probs = torch.empty(n, f, T, device="cuda")
+    amax = torch.empty(n, f, dtype=torch.int32, device="cuda")
+    _lib.check(L.mgf_duplex_attention(out.data_ptr(), xd.data_ptr(), wd.data_ptr(), sd_.data_ptr(), vd.data_ptr(), n, c, f, T,
+                                      C.byref(ep) if ep is not None else None, 0, probs.data_ptr(), amax.data_ptr(), _lib.stream_ptr()))
+    assert rel_err(out, y) < 2e-5
+    assert float((probs.double().cpu() - P).abs().max()) < 1e-5
+    # assignments: equal to the float64 argmax wherever the two best scores are not within rounding of each other
+    top2 = S.topk(2, -1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-4
+    assert bool((amax.cpu().long()[clear] == S.argmax(-1)[clear]).all())
+    # without the optional outputs
+    out2 = torch.empty_like(xd)
+    _lib.check(L.mgf_duplex_attention(out2.data_ptr(), xd.data_ptr(), wd.data_ptr(), sd_.data_ptr(), vd.data_ptr(), n, c, f, T,
+                                      C.byref(ep) if ep is not None else None, 0, None, None, _lib.stream_ptr()))
+    assert torch.equal(out, out2)
