@@ -56,13 +56,20 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(float* scratch, const 
 // per target) or compared with the stored unit-normalised reference taps and reduced to one partial per workgroup.
 template <int PXB, int CPT, bool UNIT_OUT>
 __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float* unit_out, const float* f0, const float* f1u,
-                                                           const float* lin, int c, int64_t hw, int64_t f1_stride) {
+                                                           const float* lin, int c, int64_t hw, int64_t f1_stride, int nsamp, int nblk,
+                                                           int xcd_per) {
     constexpr int G = 256 / PXB;
     __shared__ float red[G][PXB];
     __shared__ float sm[4];
     const int px = threadIdx.x % PXB, grp = threadIdx.x / PXB;
-    const int nn = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * PXB + px;
+    // work order: XCD b % 8 walks a contiguous item range with the SAMPLE as the fastest index -- the n candidates of a pixel block read
+    // the same block of the target's stored taps and now share it through one L2 (it came from the Infinity Cache once per candidate:
+    // as many bytes again as the candidates' own taps)
+    int item = (blockIdx.x & 7) * xcd_per + (blockIdx.x >> 3);
+    if (item >= nsamp * nblk) return;
+    const int nn = item % nsamp;
+    const int blk = item / nsamp;
+    const int64_t i = (int64_t)blk * PXB + px;
     const bool valid = i < hw;
     const int64_t pp = valid ? i : hw - 1;
     const float* a = f0 + (int64_t)nn * c * hw + pp;
@@ -111,22 +118,26 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
         }
     }
     const float acc = block_sum_256(valid ? d : 0.f, sm);
-    if (threadIdx.x == 0) scratch[(int64_t)nn * RED_BLOCKS + blockIdx.x] = acc;
+    if (threadIdx.x == 0) scratch[(int64_t)nn * RED_BLOCKS + blk] = acc;
 }
 
 template <bool UNIT_OUT>
 int launch_lpips_layer(float* scratch, float* unit_out, const float* f0, const float* f1u, const float* lin, int n, int c, int64_t hw,
                        int64_t f1_stride, hipStream_t st, int* grid_out) {
     // 64 pixels per workgroup (256-byte segments) whenever that still yields >= 4 workgroups per CU, 16 for the small deep taps
-    // (only up to 256 channels: beyond that a thread would hold 128 channel values and occupancy collapses)
-    const int pxb = (hw >= 65536 || (c <= 256 && (int64_t)n * mgf_cdiv(hw, 64) >= 1024)) ? 64 : 16;
+    static const int pxb_env = [] { const char* e = getenv("MGF_LPIPS_PXB"); return e ? atoi(e) : 0; }();      // tuning hook: 16 | 64
+    // (64-pixel blocks only up to 128 channels = 32 values per thread: with 64 values per thread the 256-channel tap at 127^2 ran at
+    // 1.6 TB/s, 2.35 TB/s on 16-pixel blocks -- tools/lpips_layer_micro.py)
+    const int pxb = pxb_env ? pxb_env : ((c <= 128 && (hw >= 65536 || (int64_t)n * mgf_cdiv(hw, 64) >= 1024)) ? 64 : 16);
     const int64_t grid64 = mgf_cdiv(hw, pxb);
     MGF_REQUIRE(grid64 <= RED_BLOCKS, MGF_ETOOBIG, "lpips_layer: %lld pixels per sample need %lld scratch floats (have %d per sample)",
                 (long long)hw, (long long)grid64, RED_BLOCKS);
     MGF_REQUIRE(c <= 512, MGF_EUNSUPPORTED, "lpips_layer: at most 512 channels per tap (got %d)", c);
-    const dim3 grid((unsigned)grid64, (unsigned)n);
+    MGF_REQUIRE(grid64 * n <= INT32_MAX - 8, MGF_ETOOBIG, "lpips_layer: too many workgroups");
+    const int xcd_per = (int)mgf_cdiv(grid64 * n, 8);
+    const dim3 grid((unsigned)(xcd_per * 8));
     *grid_out = (int)grid64;
-#define MGF_LPIPS_LAUNCH(PXB, CPT) hipLaunchKernelGGL((lpips_layer_kernel<PXB, CPT, UNIT_OUT>), grid, dim3(256), 0, st, scratch, unit_out, f0, f1u, lin, c, hw, f1_stride)
+#define MGF_LPIPS_LAUNCH(PXB, CPT) hipLaunchKernelGGL((lpips_layer_kernel<PXB, CPT, UNIT_OUT>), grid, dim3(256), 0, st, scratch, unit_out, f0, f1u, lin, c, hw, f1_stride, n, (int)grid64, xcd_per)
     if (pxb == 64) {
         if (c <= 128) MGF_LPIPS_LAUNCH(64, 32); else if (c <= 256) MGF_LPIPS_LAUNCH(64, 64); else MGF_LPIPS_LAUNCH(64, 128);
     } else {

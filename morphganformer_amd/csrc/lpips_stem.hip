@@ -36,7 +36,7 @@ constexpr int STEM_RED = 16384;      // scratch floats per sample (same slab siz
 struct StemParams {
     float* pooled; const float* x; const float* w; const float* b;
     float* feat_out; const float* feat_ref; const float* lin; float* scratch;
-    int n, h, w_in, ch, cw, ph, pw, tiles_x, strips;
+    int n, h, w_in, ch, cw, ph, pw, tiles_x, strips, xcd_per;
 };
 
 __device__ __forceinline__ float wave_shl1(float v) {      // lane i <- lane i + 1 (DPP wave_shl:1)
@@ -47,10 +47,15 @@ template <bool FEAT>
 __global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
     __shared__ float lds[LDS_FLOATS];
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
-    int item = blockIdx.x;
-    const int tx = item % p.tiles_x; item /= p.tiles_x;
-    const int st = item % p.strips;
-    const int n = item / p.strips;
+    // Work order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2); XCD b % 8 walks the contiguous item range
+    // [(b % 8) * xcd_per, +xcd_per) with the SAMPLE as the fastest index, so the n candidates of one strip -- which all read the same
+    // strip of the target's stored tap (67 MB per target at 1024^2: 25 candidates used to pull it from the Infinity Cache 25 times, more
+    // bytes than the kernel's own image + pooled map) -- run on one XCD back to back and share it through that L2.
+    int item = (blockIdx.x & 7) * p.xcd_per + (blockIdx.x >> 3);
+    if (item >= p.n * p.tiles_x * p.strips) return;
+    const int n = item % p.n; item /= p.n;
+    const int tx = item % p.tiles_x;
+    const int st = item / p.tiles_x;
     const int x0 = tx * TILE_COLS, r0 = st * 2 * PR;
     const int r_end = r0 + 2 * PR < p.ch - 1 ? r0 + 2 * PR : p.ch - 1;        // last conv row of this strip (inclusive)
     const bool last_tx = tx == p.tiles_x - 1, last_st = st == p.strips - 1;
@@ -260,7 +265,8 @@ extern "C" int mgf_lpips_stem_f32(float* pooled, const float* x, const float* w,
     MGF_REQUIRE(per_sample <= STEM_RED && per_sample * n <= INT32_MAX, MGF_ETOOBIG, "lpips_stem: image too large (%d x %d)", h, w_in);
     MGF_REQUIRE((int64_t)64 * p.ch * p.cw < (1LL << 31), MGF_ETOOBIG, "lpips_stem: image too large (%d x %d)", h, w_in);
     hipStream_t stq = (hipStream_t)stream;
-    const dim3 grid((unsigned)(per_sample * n));
+    p.xcd_per = (int)mgf_cdiv(per_sample * n, 8);
+    const dim3 grid((unsigned)(p.xcd_per * 8));
     if (feat_out) {
         hipLaunchKernelGGL((lpips_stem_kernel<true>), grid, dim3(64), 0, stq, p);
     } else {
