@@ -259,7 +259,7 @@ def test_conv1x1_register_gemm_vs_torch_and_tap_list(n, cin, cout, h, w, ctotal,
     assert rel_err(cv.conv_forward(x.cuda(), pc), torch.nn.functional.conv2d(x, wt)) < 2e-5
 
 
-@pytest.mark.parametrize("n,cin,cout,res", [(1, 32, 32, 16), (2, 64, 32, 33), (1, 8, 40, 4), (1, 128, 64, 64)])
+@pytest.mark.parametrize("n,cin,cout,res", [(1, 32, 32, 16), (2, 64, 32, 33), (1, 8, 40, 4), (1, 128, 64, 64), (3, 48, 96, 40), (1, 6, 20, 130)])
 def test_tconv_vs_torch(n, cin, cout, res):
     from morphganformer_amd import conv as cv
     torch.manual_seed(cin + cout + res)
