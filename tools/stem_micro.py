@@ -1,8 +1,8 @@
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from morphganformer_amd import _lib
 from morphganformer_amd.lpips import PerceptualLoss
-n = 8
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 25
 P = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, allow_random_backbone=True)
 x = (torch.rand(n, 3, 1024, 1024, device="cuda") * 2 - 1)
 P.set_target(x[:1].contiguous())
