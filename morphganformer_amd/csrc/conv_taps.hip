@@ -64,6 +64,7 @@ struct ConvParams {
     int chunks_per_split;
     int off32_ok;         // one sample of y (and of the split-K slab) spans < 2^30 elements: 32-bit store offsets are safe
     float* partial;       // [ksplit][n][cout][out_h][y_pitch] when ksplit > 1
+    int fixed_geo;        // transposed conv on its usual tile (8 x 32 quads: footprint 9 x 33, canonical taps): instantiation NTP = 10
     int xcd_per;          // > 0: XCD-aware item order -- workgroup b (dispatched round-robin to XCD b % 8) walks the contiguous
                           // item range [(b % 8) * xcd_per, +xcd_per): neighbouring tiles and the co-tiles of one pixel tile share
                           // one XCD's L2 instead of being re-fetched by eight of them
@@ -89,14 +90,17 @@ __host__ __device__ constexpr int tconv_group(int t) { return ((t / 3) == 1 ? 2 
 
 struct TileCtx { int n, ks, co0, ty0, tx0, c_begin, c_end; };
 
-// NT = compile-time tap count (9 = 3x3, 1 = 1x1; 0 = any count read from the descriptor at run time).
+// NTP = compile-time tap count (9 = 3x3, 1 = 1x1; 0 = any count read from the descriptor at run time; 10 = the 9 taps of the transposed
+// conv on its usual 8 x 32-quad tile -- footprint 9 x 33, canonical tap offsets -- whose operand reads take compile-time LDS offsets).
 // Work items = (sample, K slice, pixel tile, channel tile), channel tile fastest.  PIPE kernels are PERSISTENT: a 1-D grid of
 // at most (workgroups per CU) x 256 workgroups walks the item list with stride gridDim.x, and the register/LDS pipeline runs
 // ACROSS item boundaries -- the first chunk of the next tile is prefetched behind the last MFMA phase of the current one and
 // the epilogue's stores drain while the next tile computes -- so HBM traffic and matrix work overlap chip-wide instead of
 // alternating in lock-step bursts.  Non-PIPE kernels take one item per workgroup and stage synchronously.
-template <int WM, int WN, int MODE, bool PIPE, int NT>
+template <int WM, int WN, int MODE, bool PIPE, int NTP>
 __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
+    constexpr bool FX = NTP == 10;                   // fixed transposed-conv geometry
+    constexpr int NT = FX ? 9 : NTP;
     constexpr int CO_T = 32 * WM, PX = 128 * WN, NG = MODE == 1 ? 4 : 1;
     extern __shared__ float lds[];
     const mgf_conv_desc& d = p.d;
@@ -261,6 +265,10 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     // Operand fragments of one tap (CK/2 k-steps) are fetched from LDS into a register set one tap AHEAD of the MFMAs that
     // consume them (two sets, statically indexed after unrolling), so the matrix pipe never waits on an LDS round trip.
     auto mfma_chunk = [&](const float* buf) {
+        // FX: footprint geometry and tap offsets are compile-time constants, so every B-operand read is `ds_read_b32 v, base offset:imm`;
+        // with run-time geometry each read carries its own v_add_u32 (72 per chunk of 72 MFMAs, ~4 matrix-pipe cycles each)
+        const int chs = FX ? 9 * 33 : p.fh * p.fw;
+        auto toff = [&](int t) { return FX ? ((t / 3) == 2 ? 0 : 33) + ((t % 3) == 2 ? 0 : 1) : toffs[t]; };
         const float* Xs = buf + half * chs;                       // lane halves read channels 2kk and 2kk+1
         const float* Ws = buf + xs_region + half * CO_T + l31;
         if (NT > 0) {
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
 #pragma unroll
                     for (int m = 0; m < WM; ++m) fa[set][kk][m] = Ws[(t * CK + 2 * kk) * CO_T + m * 32];
 #pragma unroll
-                    for (int g = 0; g < WN; ++g) fb[set][kk][g] = Xs[2 * kk * chs + pbase[g] + toffs[t]];
+                    for (int g = 0; g < WN; ++g) fb[set][kk][g] = Xs[2 * kk * chs + pbase[g] + toff(t)];
                 }
             };
             fetch(0, 0);
@@ -722,7 +730,10 @@ int launch_conv(const ConvParams& p_in, hipStream_t st) {
         if (grid.x % 8 != 0) grid.x = (grid.x + 7) / 8 * 8;
     }
     const int nt = p.d.ntaps;
-    if (pipe && nt == 9) {
+    if (pipe && nt == 9 && MODE == 1 && WN == 2 && p.fixed_geo) {
+        ProfScope ps(st, WM, WN, MODE, 1, 10, p);
+        hipLaunchKernelGGL((conv_taps_kernel<WM, (MODE == 1 ? 2 : WN), MODE, true, (MODE == 1 ? 10 : 9)>), grid, dim3(256), lds, st, p);
+    } else if (pipe && nt == 9) {
         ProfScope ps(st, WM, WN, MODE, 1, 9, p);
         hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE, true, 9>), grid, dim3(256), lds, st, p);
     } else if (pipe && nt == 1 && MODE == 0) {
@@ -1022,6 +1033,14 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     p.tiles_y = (int)mgf_cdiv(d.tile_h, rows);
     p.fh = (rows - 1) * d.istride + (dy_max - dy_min) + 1;
     p.fw = (TW - 1) * d.istride + (dx_max - dx_min) + 1;
+    p.fixed_geo = 0;
+    if (mode == 1 && p.fh == 9 && p.fw == 33) {
+        p.fixed_geo = 1;
+        for (int t = 0; t < 9; ++t)
+            if (d.dy[t] != ((t / 3) == 2 ? -1 : 0) || d.dx[t] != ((t % 3) == 2 ? -1 : 0)) p.fixed_geo = 0;
+        static const char* fg_env = getenv("MGF_TCONV_FIXED");       // tuning hook (experiments only): 0 = run-time geometry
+        if (fg_env && fg_env[0] == '0') p.fixed_geo = 0;
+    }
     p.co_tiles = d.cout_pad / (32 * wm);
     // split-K when the output tiling alone cannot fill the chip (>= 2 workgroups on each of 256 CUs wanted)
     const int64_t base_wgs = (int64_t)p.tiles_x * p.tiles_y * p.co_tiles * d.n;
