@@ -327,20 +327,32 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     {
         const int w0 = a == 1 ? 1 : (a == 2 ? 3 : (a == 3 ? 5 : -1));     // slot receiving my unit 0
         const int w1 = a == 0 ? 0 : (a == 1 ? 2 : (a == 2 ? 4 : -1));     // slot receiving my unit 1
+        // (values first, then at most two wave-uniform branches: with the slot test around every store this was one basic block per value)
+        float val[2][NV];
 #pragma unroll
-        for (int un = 0; un < 2; ++un) {
-            const int ws = un == 0 ? w0 : w1;
-            float* dst = xch + (ws < 0 ? 0 : ws) * (NV * 64) + lane;
+        for (int un = 0; un < 2; ++un)
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int r = UMODE == 0 ? (v >> 1) : (UMODE == 1 ? un * 8 + (v >> 1) : v);
                 const int jj = UMODE == 2 ? un : (v & 1);
                 const int cb = (UMODE == 0 && CB == 2) ? un : 0, tb = (UMODE == 0 && TB == 2) ? un : 0;
                 const float m0 = acc[0][cb][tb][r], m1 = acc[1][cb][tb][r], m2 = acc[2][cb][tb][r], m3 = acc[3][cb][tb][r];
-                const float val = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;        // (m3 = -M3, see transform)
-                if (un == blk) own[v] = val;
-                if (ws >= 0) dst[v * 64] = val;
+                val[un][v] = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;        // (m3 = -M3, see transform)
             }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {               // own = unit `blk`, as a bit select (a ?: here becomes an indexed read of a stack array)
+            const unsigned m = 0u - (unsigned)blk, b0 = __builtin_bit_cast(unsigned, val[0][v]), b1 = __builtin_bit_cast(unsigned, val[1][v]);
+            own[v] = __builtin_bit_cast(float, (b1 & m) | (b0 & ~m));
+        }
+        if (w0 >= 0) {
+            float* dst = xch + w0 * (NV * 64) + lane;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) dst[v * 64] = val[0][v];
+        }
+        if (w1 >= 0) {
+            float* dst = xch + w1 * (NV * 64) + lane;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) dst[v * 64] = val[1][v];
         }
     }
     __builtin_amdgcn_sched_barrier(0);               // (the operand burst below must not move to where the accumulators are still live)
@@ -395,13 +407,16 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     float2 rr[NR];
     float nz0 = 0.f, nz1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        const int co = cob + (k & 3) + 8 * (k >> 2);
-        if (!pre_ep) {
-            osv[k] = osc ? osc[co] : 1.f;
-            bvv[k] = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
+    for (int k = 0; k < NR; ++k) { osv[k] = 1.f; bvv[k] = 0.f; rr[k] = make_float2(0.f, 0.f); }
+    if (!pre_ep) {
+        if (osc) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) osv[k] = osc[cob + (k & 3) + 8 * (k >> 2)];
         }
-        rr[k] = make_float2(0.f, 0.f);
+        if (do_ep && p.ep.bias) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) bvv[k] = p.ep.bias[cob + (k & 3) + 8 * (k >> 2)];
+        }
     }
     const unsigned voff = ok_px ? (unsigned)(cob * plane + oy * p.w + ox) * 4u : 0xFFFFFFF0u;
     const bool pair_ok = ox + 1 < p.w;               // (always true on even maps)
@@ -468,26 +483,41 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         }
     }
     {
-        float* yb = p.y + (int64_t)n * p.y_batch + (int64_t)p.y_choff * plane;
+        // Branch-free: absent epilogue pieces take their neutral values (noise / bias / residual 0, slope and gain 1) and pixels outside
+        // the map an out-of-range store offset, so the 16 outputs of a lane are straight-line code the compiler can batch -- written with
+        // `if (do_ep)`, `if (act == ...)`, `if (ok_px)` around every element it became ~400 basic blocks, each an LDS read, a full wait
+        // and a branch.
+        const float slope = !do_ep ? 1.f : (p.ep.act == MGF_ACT_LRELU ? p.ep.alpha : (p.ep.act == MGF_ACT_RELU ? 0.f : 1.f));
+        const float gain = do_ep ? p.ep.gain : 1.f;
+        const float nzq[2] = {do_ep ? nz0 : 0.f, do_ep ? nz1 : 0.f};
+        float2 vout[NR];
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             float v[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float t = (pa[(2 * k + q) * 64] + sgn * (own[2 * k + q] + pb[(2 * k + q) * 64])) * osv[k];
-                if (do_ep) {
-                    t += q ? nz1 : nz0;
-                    t += bvv[k];
-                    if (p.ep.act == MGF_ACT_LRELU) t = t > 0.f ? t : t * p.ep.alpha;
-                    else if (p.ep.act == MGF_ACT_RELU) t = t > 0.f ? t : 0.f;
-                    t = t * p.ep.gain + (q ? rr[k].y : rr[k].x);
-                }
+                t += nzq[q];
+                t += do_ep ? bvv[k] : 0.f;
+                t = t > 0.f ? t : t * slope;
+                t = t * gain + (q ? rr[k].y : rr[k].x);
                 v[q] = t;
             }
-            if (ok_px) {
-                float* dst = yb + (int64_t)(cob + (k & 3) + 8 * (k >> 2)) * plane + (int64_t)oy * p.w + ox;
-                if (!p.odd) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
-                else { dst[0] = v[0]; if (pair_ok) dst[1] = v[1]; }
+            vout[k] = make_float2(v[0], v[1]);
+        }
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.y + (int64_t)n * p.y_batch + (int64_t)p.y_choff * plane), 0, p.cout * plane * 4, 0x00020000);
+        if (!p.odd) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vout[k]), ry, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0);
+        } else {                                      // odd map sides: rows are not 8-byte aligned, the last pair of a row may be half outside
+            const unsigned voff1 = (ok_px && pair_ok) ? voff + 4u : 0xFFFFFFF0u;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vout[k].x), ry, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vout[k].y), ry, voff1, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0);
             }
         }
     }
