@@ -133,39 +133,64 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[cb][j][r] += red[((k * CB + cb) * 64 + j * 16 + r) * 64 + lane];
     }
-    // accumulator register r of a 32x32 block = output channel (r & 3) + 8 (r >> 2) + 4 half of the block, pixel column l31
+    // accumulator register r of a 32x32 block = output channel (r & 3) + 8 (r >> 2) + 4 half of the block, pixel column l31.
+    // Branch-free (with `if (co < cout)`, `if (px < hw)`, `if (residual)` around every element this was > 1000 basic blocks): the operands
+    // and the result go through buffer resources -- an absent bias / residual is a zero-size resource (reads 0), a channel row past cout
+    // selects the zero-size resource for its loads and stores (wave-uniform, scalar select; needs cout % 8 == 0 so that the two lane
+    // halves of a row are valid together, otherwise the per-lane half test rides in the vector offset), a pixel past hw an out-of-range
+    // vector offset.
     const bool do_ep = p.has_ep != 0;
-    const int act = p.ep.act;
-    const float alpha = p.ep.alpha, gain = do_ep ? p.ep.gain : 1.f;
-    float* yb = p.y + (int64_t)n * p.y_batch + (int64_t)p.y_choff * p.hw;
-    const float* rb = (do_ep && p.ep.residual) ? p.ep.residual + (int64_t)n * p.y_batch + (int64_t)p.y_choff * p.hw : nullptr;
+    const float slope = !do_ep ? 1.f : (p.ep.act == MGF_ACT_LRELU ? p.ep.alpha : (p.ep.act == MGF_ACT_RELU ? 0.f : 1.f));
+    const float gain = do_ep ? p.ep.gain : 1.f;
+    const int64_t ybase = (int64_t)n * p.y_batch + (int64_t)p.y_choff * p.hw;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + ybase), 0, p.cout * p.hw * 4, 0x00020000);
+    const float* resp = (do_ep && p.ep.residual) ? p.ep.residual + ybase : nullptr;
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(resp ? resp : p.x), 0, resp ? p.cout * p.hw * 4 : 0, 0x00020000);
+    const float* biasp = (do_ep && p.ep.bias) ? p.ep.bias : nullptr;
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)(biasp ? biasp : p.x), 0, biasp ? p.cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rnone = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
+    const bool rows8 = (p.cout & 7) == 0;             // rows of both lane halves are inside / outside together
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    // per-lane pixel offsets (bytes) inside a channel row; the half's 4 rows ride along
+    unsigned pvo[4];
+    if (VEC) {
+        const int px = p0 + 4 * l31;
+        pvo[0] = px < p.hw ? (unsigned)(4 * half * p.hw + px) * 4u : 0xFFFFFFF0u;
+        pvo[1] = pvo[2] = pvo[3] = 0xFFFFFFF0u;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int px = p0 + l31 + 32 * j;
+            pvo[j] = px < p.hw ? (unsigned)(4 * half * p.hw + px) * 4u : 0xFFFFFFF0u;
+        }
+    }
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = co0 + 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co >= p.cout) continue;
-            const float bv = (do_ep && p.ep.bias) ? p.ep.bias[co] : 0.f;
+            const int cor = co0 + 32 * cb + (r & 3) + 8 * (r >> 2);          // row of lane half 0 (wave-uniform); half 1: + 4
+            const bool in = rows8 ? cor < p.cout : cor + 4 * half < p.cout;    // (uniform when rows8)
+            const bool any = cor < p.cout;                                      // some lane of the row is inside (uniform)
+            const __amdgpu_buffer_rsrc_t ryr = any ? ry : rnone, rrr = any ? rres : rnone, rbr = any ? rbias : rnone;
+            const int soff = cor * p.hw * 4;
+            const unsigned lane_ok = (rows8 || in) ? 0u : 0xFFFFFFF0u;         // (per-lane only for ragged channel counts)
+            const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbr, (unsigned)(4 * half) * 4u | lane_ok, cor * 4, 0));
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float t = acc[cb][j][r] + bv;
-                if (act == MGF_ACT_LRELU) t = t > 0.f ? t : t * alpha;
-                else if (act == MGF_ACT_RELU) t = t > 0.f ? t : 0.f;
+                t = t > 0.f ? t : t * slope;
                 v[j] = t * gain;
             }
-            const int64_t row = (int64_t)co * p.hw;
             if (VEC) {
-                const int px = p0 + 4 * l31;
-                if (px < p.hw) {
-                    if (rb) { const float4 q = *reinterpret_cast<const float4*>(rb + row + px); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
-                    *reinterpret_cast<float4*>(yb + row + px) = make_float4(v[0], v[1], v[2], v[3]);
-                }
+                const float4 q = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrr, pvo[0] | lane_ok, soff, 0));
+                const float4 o = make_float4(v[0] + q.x, v[1] + q.y, v[2] + q.z, v[3] + q.w);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), ryr, pvo[0] | lane_ok, soff, 0);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int px = p0 + l31 + 32 * j;
-                    if (px < p.hw) yb[row + px] = v[j] + (rb ? rb[row + px] : 0.f);
+                    const float q = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrr, pvo[j] | lane_ok, soff, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j] + q), ryr, pvo[j] | lane_ok, soff, 0);
                 }
             }
         }
