@@ -638,8 +638,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void duplex_attention_mfm
 
     // ---- gain = vwb . p per 32-channel block, y = x * gain, epilogue ----
     float* yn = p.y + nb;
-    const int act = p.ep.act;
-    const float alpha = p.ep.alpha, gain = p.ep.gain;
+    // (branch-free epilogue: no epilogue = noise / bias / residual read as zeros above, slope and gain 1)
+    const float slope = !ep ? 1.f : (p.ep.act == MGF_ACT_LRELU ? p.ep.alpha : (p.ep.act == MGF_ACT_RELU ? 0.f : 1.f));
+    const float gain = ep ? p.ep.gain : 1.f;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         // A operand of k-step j: vwb[channel cw0 + 32 cb + l31][latent rowof(j) + 4 half] = two 16-byte pieces of the channel's row
@@ -659,13 +660,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 4 : 2) void duplex_attention_mfm
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = xr[cb][r] * g[r];
-            if (ep) {
-                v += nz;
-                v += bv[r];
-                if (act == MGF_ACT_LRELU) v = v > 0.f ? v : v * alpha;
-                else if (act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
-                v = v * gain + rr[cb][r];
-            }
+            v += nz;
+            v += bv[r];
+            v = v > 0.f ? v : v * slope;
+            v = v * gain + rr[cb][r];
             yn[(int64_t)(cw0 + 32 * cb + rowof(r) + 4 * half) * p.f + f0 + l31] = v;
         }
     }
