@@ -91,7 +91,8 @@ __host__ __device__ constexpr int tconv_group(int t) { return ((t / 3) == 1 ? 2 
 struct TileCtx { int n, ks, co0, ty0, tx0, c_begin, c_end; };
 
 // NTP = compile-time tap count (9 = 3x3, 1 = 1x1; 0 = any count read from the descriptor at run time; 10 = the 9 taps of the transposed
-// conv on its usual 8 x 32-quad tile -- footprint 9 x 33, canonical tap offsets -- whose operand reads take compile-time LDS offsets).
+// conv on its usual 8 x 32-quad tile -- footprint 9 x 33, canonical tap offsets -- whose operand reads take compile-time LDS offsets;
+// 11 = likewise the 3x3 stride-2 conv on its 4 x 32 tile -- footprint 9 x 65, row-major taps: the data gradient of an up-sampling layer).
 // Work items = (sample, K slice, pixel tile, channel tile), channel tile fastest.  PIPE kernels are PERSISTENT: a 1-D grid of
 // at most (workgroups per CU) x 256 workgroups walks the item list with stride gridDim.x, and the register/LDS pipeline runs
 // ACROSS item boundaries -- the first chunk of the next tile is prefetched behind the last MFMA phase of the current one and
@@ -99,7 +100,8 @@ struct TileCtx { int n, ks, co0, ty0, tx0, c_begin, c_end; };
 // alternating in lock-step bursts.  Non-PIPE kernels take one item per workgroup and stage synchronously.
 template <int WM, int WN, int MODE, bool PIPE, int NTP>
 __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
-    constexpr bool FX = NTP == 10;                   // fixed transposed-conv geometry
+    constexpr bool FX = NTP == 10 || NTP == 11;      // fixed geometry: transposed conv (10), stride-2 conv (11)
+    constexpr int FXW = NTP == 10 ? 33 : 65;         // footprint width (height 9 in both)
     constexpr int NT = FX ? 9 : NTP;
     constexpr int CO_T = 32 * WM, PX = 128 * WN, NG = MODE == 1 ? 4 : 1;
     extern __shared__ float lds[];
@@ -267,8 +269,10 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     auto mfma_chunk = [&](const float* buf) {
         // FX: footprint geometry and tap offsets are compile-time constants, so every B-operand read is `ds_read_b32 v, base offset:imm`;
         // with run-time geometry each read carries its own v_add_u32 (72 per chunk of 72 MFMAs, ~4 matrix-pipe cycles each)
-        const int chs = FX ? 9 * 33 : p.fh * p.fw;
-        auto toff = [&](int t) { return FX ? ((t / 3) == 2 ? 0 : 33) + ((t % 3) == 2 ? 0 : 1) : toffs[t]; };
+        const int chs = FX ? 9 * FXW : p.fh * p.fw;
+        auto toff = [&](int t) {
+            return NTP == 10 ? ((t / 3) == 2 ? 0 : 33) + ((t % 3) == 2 ? 0 : 1) : (NTP == 11 ? (t / 3) * 65 + (t % 3) : toffs[t]);
+        };
         const float* Xs = buf + half * chs;                       // lane halves read channels 2kk and 2kk+1
         const float* Ws = buf + xs_region + half * CO_T + l31;
         if (NT > 0) {
@@ -733,6 +737,9 @@ int launch_conv(const ConvParams& p_in, hipStream_t st) {
     if (pipe && nt == 9 && MODE == 1 && WN == 2 && p.fixed_geo) {
         ProfScope ps(st, WM, WN, MODE, 1, 10, p);
         hipLaunchKernelGGL((conv_taps_kernel<WM, (MODE == 1 ? 2 : WN), MODE, true, (MODE == 1 ? 10 : 9)>), grid, dim3(256), lds, st, p);
+    } else if (pipe && nt == 9 && MODE == 0 && WN == 1 && p.fixed_geo == 2) {
+        ProfScope ps(st, WM, WN, MODE, 1, 11, p);
+        hipLaunchKernelGGL((conv_taps_kernel<WM, (MODE == 0 ? 1 : WN), MODE, true, (MODE == 0 ? 11 : 9)>), grid, dim3(256), lds, st, p);
     } else if (pipe && nt == 9) {
         ProfScope ps(st, WM, WN, MODE, 1, 9, p);
         hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE, true, 9>), grid, dim3(256), lds, st, p);
@@ -1039,6 +1046,13 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
         for (int t = 0; t < 9; ++t)
             if (d.dy[t] != ((t / 3) == 2 ? -1 : 0) || d.dx[t] != ((t % 3) == 2 ? -1 : 0)) p.fixed_geo = 0;
         static const char* fg_env = getenv("MGF_TCONV_FIXED");       // tuning hook (experiments only): 0 = run-time geometry
+        if (fg_env && fg_env[0] == '0') p.fixed_geo = 0;
+    }
+    if (mode == 0 && d.ntaps == 9 && d.istride == 2 && p.fh == 9 && p.fw == 65) {
+        p.fixed_geo = 2;
+        for (int t = 0; t < 9; ++t)
+            if (d.dy[t] - dy_min != t / 3 || d.dx[t] - dx_min != t % 3) p.fixed_geo = 0;
+        static const char* fg_env = getenv("MGF_TCONV_FIXED");
         if (fg_env && fg_env[0] == '0') p.fixed_geo = 0;
     }
     p.co_tiles = d.cout_pad / (32 * wm);
