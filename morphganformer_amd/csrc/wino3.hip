@@ -567,6 +567,10 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     static const int env_forced = [] { const char* e = getenv("MGF_W3_SHAPE"); return e ? atoi(e) : 0; }();
     const int forced = g_w3_forced_shape ? g_w3_forced_shape : env_forced;
     int shape = 11;
+    // ... except where the 64-channel shape measures faster: deep K with enough workgroups left to fill the chip (the 128^2 x 256-channel
+    // conv1 at 25 samples: 1969 vs 2097 us; at 64^2 x 512 its 6400 workgroups lose to 12800 of the small shape, 2151 vs 1998 us)
+    if (!forced && !rgb && !res_low && !odd && y_choff == 0 && cout % 64 == 0 && cin >= 256 &&
+        (int64_t)n * mgf_cdiv(w, 32) * mgf_cdiv(h, 4) * (cout / 64) >= 8192) shape = 21;
     if (forced == 21 && cout % 64 == 0 && !rgb) shape = 21;
     if (forced == 12 || forced == 11) shape = forced;
     const int cb = shape == 21 ? 2 : 1, tb = shape == 12 ? 2 : 1;
