@@ -412,6 +412,12 @@ int mgf_style_grad_f32(float* dot_part, float* dx, const float* x, const float* 
 int mgf_duplex_attention_bwd(float* dx, float* dg, float* probs, const float* da, const float* x, const float* wqc, const float* spos,
                              const float* vwb, int32_t n, int32_t c, int32_t f, int32_t t, mgf_stream_t stream);
 int mgf_attn_values_grad(float* dvwb, const float* dg, const float* probs, int32_t n, int32_t c, int32_t f, int32_t t, mgf_stream_t stream);
+/* the same result through a register-operand MFMA GEMM over pixel slices + a fixed-order reduce (csrc/backward.hip); `workspace` holds the
+ * per-slice partial sums (mgf_attn_values_grad_workspace_floats(n, c) floats, 16-byte aligned).  Falls back to the kernel above when
+ * t != 16, the pixel count is not a multiple of 8 or the workspace is missing / too small. */
+int64_t mgf_attn_values_grad_workspace_floats(int32_t n, int32_t c);
+int mgf_attn_values_grad_ws(float* dvwb, const float* dg, const float* probs, int32_t n, int32_t c, int32_t f, int32_t t, float* workspace,
+                            int64_t workspace_floats, mgf_stream_t stream);
 /* Latent side.  style_demod_bwd_multi: per job (= modulated layer) and sample, from the partial dots above,
  *   ds[i]  = sum_chunks ds_part[n,i,:] - s[n,i] * sum_o (sum_chunks dc_part[n,o,:]) d[n,o]^2 wsq[o,i]      (second term only with demod)
  *   dwg[n, job, k] = aff_gain * style_gain * sum_i ds[i] * aff_w[i, k]          gradient wrt the global latent component

@@ -112,6 +112,8 @@ _SIGS = {
     "mgf_style_grad_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, i32, vp]),
     "mgf_duplex_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mgf_attn_values_grad": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mgf_attn_values_grad_workspace_floats": (C.c_int64, [i32, i32]),
+    "mgf_attn_values_grad_ws": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp, i64, vp]),
     "mgf_style_demod_bwd_multi": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mgf_attn_values_bwd_multi": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mgf_latent_grad_gather": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, i32, f32, vp]),

@@ -352,6 +352,71 @@ __global__ __launch_bounds__(256) void attn_values_grad_kernel(float* dvwb, cons
     }
 }
 
+// The same sum as a register-operand MFMA GEMM (cf. csrc/pointwise.hip): out[t][c] = sum_f P[f][t] dg[c][f] with M = the 16 latents (half
+// of a 32-row tile), N = 32 channels per wave, K = pixels.  Lane (l31, half) holds A = P[f][t = l31] and B = dg[c = l31][f] for the pixel
+// f = f0 + 4 half + ks of k-step ks: four k-steps per 16-byte load of its own dg row (each lane walks ONE row: 32 rows per load
+// instruction, but 16 consecutive k-steps stay inside a row's 128-byte line) and four 64-byte-coalesced dword loads of P.  The pixel axis
+// is cut into `slices` (grid.x) so that one sample still fills the chip: partial sums go to a workspace [n][slices][c][16], and
+// attn_values_reduce_kernel adds the slices in index order (bit-reproducible).  The VALU kernel above gave every workgroup 4 channels and
+// ALL pixels: 64 workgroups for a 128^2 x 256-channel layer at one sample, each re-reading the 1 MB probability map: 150 us.
+typedef float avg_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void attn_values_grad_mfma_kernel(float* part, const float* dg, const float* probs, int c, int f, int slices) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int sl = blockIdx.x, cb = blockIdx.y * 4 + wv, n = blockIdx.z;
+    if (cb * 32 >= c) return;
+    const int fs = f / slices, f0 = sl * fs;                      // pixels of this slice (host: a multiple of 8)
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dg + (int64_t)n * c * f), 0, c * f * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(probs + (int64_t)n * f * TMAX), 0, f * TMAX * 4, 0x00020000);
+    const int crow = cb * 32 + l31;
+    const unsigned dvo = crow < c ? (unsigned)(crow * f + f0 + 4 * half) * 4u : 0xFFFFFFF0u;
+    const unsigned pvo = l31 < TMAX ? (unsigned)((f0 + 4 * half) * TMAX + l31) * 4u : 0xFFFFFFF0u;     // rows t >= 16 of the A operand are zero
+    avg_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int groups = fs / 8;                                     // 8 pixels (4 k-steps x 2 halves) per group
+    auto load = [&](float4& dv, float (&pa)[4], int g) {
+        const __amdgpu_buffer_rsrc_t d_ = g < groups ? rd : __builtin_amdgcn_make_buffer_rsrc((void*)dg, 0, 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t p_ = g < groups ? rp : __builtin_amdgcn_make_buffer_rsrc((void*)dg, 0, 0, 0x00020000);
+        dv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d_, dvo, g * 32, 0));
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)          // (the k-step rides in the SCALAR offset: added to the vector offset it would wrap the out-of-range mark)
+            pa[ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(p_, pvo, (g * 8 + ks) * TMAX * 4, 0));
+    };
+    auto mm = [&](const float4& dv, const float (&pa)[4]) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[0], dv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[1], dv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2], dv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[3], dv.w, acc, 0, 0, 0);
+    };
+    float4 d0, d1, d2, d3;
+    float p0[4], p1[4], p2[4], p3[4];
+    load(d0, p0, 0); load(d1, p1, 1); load(d2, p2, 2);             // three groups in flight (the sweep is latency-bound, not MFMA-bound)
+    for (int g = 0; g < groups; g += 4) {
+        load(d3, p3, g + 3); __builtin_amdgcn_sched_barrier(0); mm(d0, p0); __builtin_amdgcn_sched_barrier(0);
+        load(d0, p0, g + 4); __builtin_amdgcn_sched_barrier(0); mm(d1, p1); __builtin_amdgcn_sched_barrier(0);
+        load(d1, p1, g + 5); __builtin_amdgcn_sched_barrier(0); mm(d2, p2); __builtin_amdgcn_sched_barrier(0);
+        load(d2, p2, g + 6); __builtin_amdgcn_sched_barrier(0); mm(d3, p3); __builtin_amdgcn_sched_barrier(0);
+    }
+    // accumulator register r = latent (r & 3) + 8 (r >> 2) + 4 half (rows >= 16 are padding), column = channel crow
+    if (crow < c) {
+        float* o = part + (((int64_t)n * slices + sl) * c + crow) * TMAX;
+        *reinterpret_cast<float4*>(o + 4 * half) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(o + 8 + 4 * half) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_values_reduce_kernel(float* dvwb, const float* part, int64_t per_sample, int slices) {
+    const int n = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+        const float* pp = part + (int64_t)n * slices * per_sample + i;
+        float a = 0.f;
+        for (int s = 0; s < slices; ++s) a += pp[(int64_t)s * per_sample];
+        dvwb[(int64_t)n * per_sample + i] = a;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ latent-side backward
 // grid (njobs, n): d(style) -> d(global latent component) for one modulated layer (see the header comment)
 __global__ __launch_bounds__(256) void style_demod_bwd_kernel(float* dwg, const mgf_style_bwd_job* jobs, int njobs, int wdim) {
@@ -679,6 +744,31 @@ extern "C" int mgf_attn_values_grad(float* dvwb, const float* dg, const float* p
     MGF_REQUIRE(t >= 1 && t <= TMAX, MGF_EUNSUPPORTED, "attn_values_grad: supports 1..%d latent components (got %d)", TMAX, t);
     MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "attn_values_grad: n must be <= 65535");
     hipLaunchKernelGGL(attn_values_grad_kernel, dim3((unsigned)mgf_cdiv(c, 4), n), dim3(256), 0, (hipStream_t)stream, dvwb, dg, probs, c, f, t);
+    MGF_CHECK_LAUNCH("attn_values_grad");
+    return MGF_OK;
+}
+
+extern "C" int64_t mgf_attn_values_grad_workspace_floats(int32_t n, int32_t c) {
+    return (int64_t)128 * (n > 0 ? n : 1) * (c > 0 ? c : 1) * TMAX;         // at most 128 pixel slices
+}
+
+extern "C" int mgf_attn_values_grad_ws(float* dvwb, const float* dg, const float* probs, int32_t n, int32_t c, int32_t f, int32_t t,
+                                       float* workspace, int64_t workspace_floats, mgf_stream_t stream) {
+    MGF_REQUIRE(dvwb && dg && probs && n >= 1 && c >= 1 && f >= 1, MGF_EINVAL, "attn_values_grad: bad arguments");
+    MGF_REQUIRE(t >= 1 && t <= TMAX, MGF_EUNSUPPORTED, "attn_values_grad: supports 1..%d latent components (got %d)", TMAX, t);
+    MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "attn_values_grad: n must be <= 65535");
+    // the MFMA form: 16 latents, pixel count a multiple of 8, 32-bit offsets inside a sample; pixel slices so that ~1024 waves run
+    int slices = 1;
+    const int cblocks = (int)mgf_cdiv(c, 32);
+    while (slices < 128 && (int64_t)n * slices * cblocks < 1024 && f % (slices * 2 * 8) == 0 && f / (slices * 2) >= 32) slices *= 2;
+    const bool ok = t == TMAX && f % (8 * slices) == 0 && (int64_t)c * f * 4 < (1LL << 31) && workspace &&
+                    workspace_floats >= (int64_t)n * slices * c * TMAX && ((uintptr_t)workspace % 16) == 0;
+    static const char* mf_env = getenv("MGF_ATTN_GRAD_MFMA");     // tuning hook (experiments, tests): 0 = the VALU kernel
+    if (!ok || (mf_env && mf_env[0] == '0')) return mgf_attn_values_grad(dvwb, dg, probs, n, c, f, t, stream);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_values_grad_mfma_kernel, dim3(slices, (unsigned)mgf_cdiv(cblocks, 4), n), dim3(256), 0, st, workspace, dg, probs, c, f, slices);
+    const int64_t per_sample = (int64_t)c * TMAX;
+    hipLaunchKernelGGL(attn_values_reduce_kernel, dim3((unsigned)mgf_cdiv(per_sample, 256), n), dim3(256), 0, st, dvwb, workspace, per_sample, slices);
     MGF_CHECK_LAUNCH("attn_values_grad");
     return MGF_OK;
 }

@@ -63,6 +63,9 @@ class GeneratorGrad:
         G, P, cfg, L = self.G, self.G.plan, self.G.cfg, _lib.lib()
         D, T = cfg.w_dim, cfg.k - 1
         self._n = n
+        # per-slice partial sums of mgf_attn_values_grad_ws (allocated here, not at first use: never inside a captured launch sequence)
+        cmax = max([lp.attn.c for lp in P.layers if lp.attn is not None] or [1])
+        self.avg_ws = torch.empty(int(L.mgf_attn_values_grad_workspace_floats(n, cmax)), dtype=torch.float32, device=G.device)
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=G.device)
         self.ds_part, self.dc_part, self.dvwb = {}, {}, {}
         sj, aj = [], []
@@ -146,8 +149,9 @@ class GeneratorGrad:
             _lib.check(L.mgf_duplex_attention_bwd(dc.data_ptr(), dg.data_ptr(), probs.data_ptr(), dz.data_ptr(), c_pre.data_ptr(),
                                                   a.wqc.data_ptr(), a.spos.data_ptr(), G._v(lp).data_ptr(), n, a.c, a.f, T, st),
                        "duplex_attention_bwd")
-            _lib.check(L.mgf_attn_values_grad(self.dvwb[lp.name].data_ptr(), dg.data_ptr(), probs.data_ptr(), n, a.c, a.f, T, st),
-                       "attn_values_grad")
+            ws = self.avg_ws
+            _lib.check(L.mgf_attn_values_grad_ws(self.dvwb[lp.name].data_ptr(), dg.data_ptr(), probs.data_ptr(), n, a.c, a.f, T,
+                                                 ws.data_ptr(), ws.numel(), st), "attn_values_grad")
             if lp.demod:
                 _lib.check(L.mgf_channel_dot_f32(self.dc_part[lp.name].data_ptr(), dc.data_ptr(), c_pre.data_ptr(), n, c, hw, st),
                            "channel_dot")

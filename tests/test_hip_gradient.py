@@ -86,7 +86,7 @@ def test_layer_act_bwd_and_dots():
     assert torch.allclose(dx, 2.0 + s[:, :, None] * b, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("c,res", [(32, 8), (512, 4), (20, 6)])
+@pytest.mark.parametrize("c,res", [(32, 8), (512, 4), (20, 6), (256, 32), (64, 16)])
 def test_duplex_attention_bwd_matches_autograd(c, res):
     from morphganformer_amd import _lib
     L = _lib.lib()
@@ -113,6 +113,12 @@ def test_duplex_attention_bwd_matches_autograd(c, res):
     assert rel(probs, P) < 1e-4
     assert rel(dx, dx_ref) < GRAD_TOL
     assert rel(dv, dv_ref) < GRAD_TOL
+    # the MFMA form (pixel slices + fixed-order reduce) of the value gradient: same numbers, bit-reproducible
+    ws = torch.empty(int(L.mgf_attn_values_grad_workspace_floats(n, c)), device="cuda")
+    dv2, dv3 = torch.full_like(dv, 7.0), torch.full_like(dv, 9.0)
+    for out in (dv2, dv3):
+        _lib.check(L.mgf_attn_values_grad_ws(out.data_ptr(), dg.data_ptr(), probs.data_ptr(), n, c, f, T, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    assert rel(dv2, dv_ref) < GRAD_TOL and torch.equal(dv2, dv3)
 
 
 @pytest.mark.parametrize("mode", ["const", "inject"])
