@@ -307,6 +307,151 @@ __global__ __launch_bounds__(256) void duplex_attention_bwd_kernel(AttnBwdParams
     }
 }
 
+// MFMA form of the kernel above for the generator's layers (C = 256 / 512, 16 latents, whole 32-pixel tiles) -- the backward twin of
+// duplex_attention_mfma_kernel (csrc/attention.hip), same tiling: a workgroup = 32 pixels, wave w = channels [64 w, 64 w + 64), x and da
+// read ONCE into the 32 + 32 registers that are the lane's B-operand slots of the C -> 16 GEMMs and its accumulator slots of the 16 -> C
+// GEMMs (k-steps walk the channels in accumulator order).  Four small GEMMs on v_mfma_f32_32x32x2_f32:
+//   scores S = wqc^T x (+ spos) -> softmax P, r = rsqrt(mean x^2 + eps)        [partials + sum x^2 meet in LDS]
+//   dP = vwb^T dg,  dg = da x r                                                [partials meet in LDS]
+//   dS = P (dP - <P, dP>),   coef = <P, dP> r^2 / C   (the layer-norm term: sum_c dg g = <P, dP>)
+//   per 32-channel block:  G = vwb P,  Q = wqc dS,  dx = da r G + Q - coef x
+typedef float adb_f32x16 __attribute__((ext_vector_type(16)));
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 1) void duplex_attention_bwd_mfma_kernel(AttnBwdParams p) {
+    __shared__ float red[2][NW][9][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n = blockIdx.y, f0 = blockIdx.x * 32;
+    const int cw0 = wv * 64;
+    const int64_t nb = (int64_t)n * p.c * p.f;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + nb), 0, p.c * p.f * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rda = __builtin_amdgcn_make_buffer_rsrc((void*)(p.da + nb), 0, p.c * p.f * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)p.wqc, 0, p.c * TMAX * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vwb + (int64_t)n * p.c * TMAX), 0, p.c * TMAX * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc((void*)p.spos, 0, p.f * TMAX * 4, 0x00020000);
+    auto rowof = [](int r) { return (r & 3) + 8 * (r >> 2); };         // accumulator register -> row of the 32x32 block (+ 4 half)
+
+    const unsigned xo = (unsigned)((cw0 + 4 * half) * p.f + f0 + l31) * 4u;
+    const unsigned to = l31 < TMAX ? (unsigned)((cw0 + 4 * half) * TMAX + l31) * 4u : 0xFFFFFFF0u;     // [c][t] table, transposed operand (t = lane)
+    float xr[2][16], dar[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = 32 * cb + rowof(r);
+            xr[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xo, ch * p.f * 4, 0));
+            dar[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rda, xo, ch * p.f * 4, 0));
+        }
+    float sp[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        sp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsp, (unsigned)((f0 + l31) * TMAX + 4 * half) * 4u, rowof(r) * 4, 0));
+
+    // ---- scores and sum x^2 ----
+    adb_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float sq = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, to, (32 * cb + rowof(r)) * TMAX * 4, 0));
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xr[cb][r], acc, 0, 0, 0);
+            sq += xr[cb][r] * xr[cb][r];
+        }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) red[0][wv][r][lane] = acc[r];
+    red[0][wv][8][lane] = sq;
+    __syncthreads();
+    float P[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float v = sp[r];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[0][w][r][lane];
+        P[r] = v;
+    }
+    sq = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sq += red[0][w][8][lane];
+    sq += __shfl_xor(sq, 32, 64);
+    float m = P[0];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) m = fmaxf(m, P[r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float den = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { P[r] = __expf(P[r] - m); den += P[r]; }
+    den += __shfl_xor(den, 32, 64);
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) P[r] *= inv;
+    const float rn = rsqrtf(sq / (float)p.c + 1e-8f);
+    if (wv == 0 && p.probs) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p.probs[((int64_t)n * p.f + f0 + l31) * TMAX + rowof(r) + 4 * half] = P[r];
+    }
+
+    // ---- dg = da x r (written out for the value gradient), dP = vwb^T dg ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float* dgn = p.dg ? p.dg + nb : nullptr;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = 32 * cb + rowof(r);
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, to, ch * TMAX * 4, 0));
+            const float dgv = dar[cb][r] * xr[cb][r] * rn;
+            if (dgn) dgn[(int64_t)(cw0 + ch + 4 * half) * p.f + f0 + l31] = dgv;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dgv, acc, 0, 0, 0);
+        }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) red[1][wv][r][lane] = acc[r];
+    __syncthreads();
+    float dS[8], pdp = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[1][w][r][lane];
+        dS[r] = v;                                   // dP
+        pdp += P[r] * v;
+    }
+    pdp += __shfl_xor(pdp, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dS[r] = P[r] * (dS[r] - pdp);
+    const float coef = pdp * rn * rn / (float)p.c;
+
+    // ---- per 32-channel block: G = vwb P, Q = wqc dS, dx = da r G + Q - coef x ----
+    float* dxn = p.dx + nb;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const unsigned vo = (unsigned)((cw0 + 32 * cb + l31) * TMAX + 4 * half) * 4u;      // row of channel l31 of the block, my half's latents
+        const float4 va = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rv, vo, 0, 0));
+        const float4 vb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rv, vo + 32u, 0, 0));
+        const float4 qa = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rq, vo, 0, 0));
+        const float4 qb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rq, vo + 32u, 0, 0));
+        const float av[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        const float aq[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        adb_f32x16 g, q;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g[r] = 0.f; q[r] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            g = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], P[j], g, 0, 0, 0);
+            q = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j], dS[j], q, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = dar[cb][r] * rn * g[r] - coef * xr[cb][r] + q[r];
+            dxn[(int64_t)(cw0 + 32 * cb + rowof(r) + 4 * half) * p.f + f0 + l31] = v;
+        }
+    }
+}
+
 // dvwb[n,c,t] = sum_f dg[n,c,f] * P[n,f,t]; grid (cdiv(c,4), n): a workgroup owns 4 channels and streams all pixels once
 __global__ __launch_bounds__(256) void attn_values_grad_kernel(float* dvwb, const float* dg, const float* probs, int c, int f, int T) {
     __shared__ float red[4][4 * TMAX];
@@ -727,6 +872,14 @@ extern "C" int mgf_duplex_attention_bwd(float* dx, float* dg, float* probs, cons
     MGF_REQUIRE(n <= 65535 && (int64_t)n * c * f <= INT32_MAX, MGF_ETOOBIG, "duplex_attention_bwd: tensor too large");
     constexpr int PXB = 16, G = 256 / PXB;
     AttnBwdParams p{dx, dg, probs, da, x, wqc, spos, vwb, n, c, f, t, (int)(mgf_cdiv(c, 4) * 4)};
+    // the generator's layers: the MFMA form (MGF_ATTN_BWD_MFMA=0 keeps the register kernel: tuning hook, tests)
+    static const char* mf_env = getenv("MGF_ATTN_BWD_MFMA");
+    if (t == TMAX && (c == 256 || c == 512) && f % 32 == 0 && !(mf_env && mf_env[0] == '0')) {
+        if (c == 256) hipLaunchKernelGGL((duplex_attention_bwd_mfma_kernel<4>), dim3((unsigned)(f / 32), n), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((duplex_attention_bwd_mfma_kernel<8>), dim3((unsigned)(f / 32), n), dim3(512), 0, (hipStream_t)stream, p);
+        MGF_CHECK_LAUNCH("duplex_attention_bwd");
+        return MGF_OK;
+    }
     const size_t lds = ((size_t)2 * p.c_pad * TMAX + (size_t)G * (TMAX + 1) * PXB) * sizeof(float);
     MGF_REQUIRE(lds <= 150 * 1024, MGF_EUNSUPPORTED, "duplex_attention_bwd: %d channels need %zu bytes of LDS", c, lds);
     if (lds > 64 * 1024) {

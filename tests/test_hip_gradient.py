@@ -86,7 +86,7 @@ def test_layer_act_bwd_and_dots():
     assert torch.allclose(dx, 2.0 + s[:, :, None] * b, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("c,res", [(32, 8), (512, 4), (20, 6), (256, 32), (64, 16)])
+@pytest.mark.parametrize("c,res", [(32, 8), (512, 4), (20, 6), (256, 32), (64, 16), (512, 8), (256, 8)])
 def test_duplex_attention_bwd_matches_autograd(c, res):
     from morphganformer_amd import _lib
     L = _lib.lib()
