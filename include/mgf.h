@@ -183,11 +183,12 @@ int mgf_conv3x3_winograd3_slice_f32(float* y, const float* x, const float* u, co
 /* 1x1 convolution without modulation -- the resnet skip projection of a SynthesisBlock (training/networks.py:1102-1105: Conv2dLayer with
  * kernel_size 1 -> conv2d_resample.py:99-103 -> F.conv2d) and the SqueezeNet Fire squeeze / expand1x1 layers of LPIPS
  * (lpips/pretrained_networks.py:7-44, torchvision Fire) -- as a register-operand MFMA GEMM (csrc/pointwise.hip: no LDS staging):
- *   y[n, y_choff + co, p] = epilogue( sum_ci w[ci][co] * x[n, ci, p] ),  p in [0, hw)
+ *   y[n, y_choff + co, p] = epilogue( sum_ci w[ci][co] * in_scale[n, ci] * x[n, ci, p] ),  p in [0, hw)
+ * (in_scale may be NULL; with it this is the modulated, un-demodulated 1x1 conv of ToRGBLayer, training/networks.py:1054-1065)
  * w is the [cin][cout_pad] image mgf_pack_conv_weights makes of a 1x1 kernel; y may be a channel slice of a wider buffer (y_batch elements
  * between samples, 0 = dense; the epilogue's residual then has the same layout); epilogue as mgf_conv_taps_f32 minus the noise input. */
-int mgf_conv1x1_f32(float* y, const float* x, const float* w, int32_t n, int32_t cin, int32_t hw, int32_t cout, int32_t cout_pad,
-                    int64_t y_batch, int32_t y_choff, const mgf_epilogue* ep, mgf_stream_t stream);
+int mgf_conv1x1_f32(float* y, const float* x, const float* w, const float* in_scale, int32_t n, int32_t cin, int32_t hw, int32_t cout,
+                    int32_t cout_pad, int64_t y_batch, int32_t y_choff, const mgf_epilogue* ep, mgf_stream_t stream);
 /* tuning / tests: pin the 32-channel blocks a wave of mgf_conv1x1_f32 carries (1 or 2; 0 = by layer shape) */
 int mgf_conv1x1_force_shape(int32_t channel_blocks);
 /* form 3 with the epilogue's residual given at HALF resolution: residual_low [n, cout, h/2, w/2] is up-sampled 2x inside the epilogue with the

@@ -124,10 +124,11 @@ def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_sca
     if out is None:
         out = torch.empty([n, pc.cout, oh, ow], dtype=torch.float32, device=x.device)
     assert out.is_contiguous() and out.shape[0] == n and out.shape[2] == oh and out.shape[3] == ow
-    if (POINTWISE and pc.kh == 1 and pc.kw == 1 and stride == 1 and pad == (0, 0) and in_scale is None and out_scale is None
+    if (POINTWISE and pc.kh == 1 and pc.kw == 1 and stride == 1 and pad == (0, 0) and out_scale is None
+            and (in_scale is None or (in_scale.is_contiguous() and tuple(in_scale.shape) == (n, cin)))
             and taps == [(0, 0)] and (epilogue is None or not epilogue.noise)):
-        # un-modulated 1x1 layer: the register-operand GEMM (csrc/pointwise.hip) instead of the LDS-staged tap-list kernel
-        rc = _lib.lib().mgf_conv1x1_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), n, cin, h * w, pc.cout, pc.cout_pad,
+        # 1x1 layer without demodulation: the register-operand GEMM (csrc/pointwise.hip) instead of the LDS-staged tap-list kernel
+        rc = _lib.lib().mgf_conv1x1_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), n, cin, h * w, pc.cout, pc.cout_pad,
                                         out.shape[1] * oh * ow, out_choff, C.byref(epilogue) if epilogue is not None else None,
                                         _lib.stream_ptr())
         _lib.check(rc, "conv1x1")

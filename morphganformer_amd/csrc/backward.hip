@@ -557,7 +557,15 @@ __global__ __launch_bounds__(256) void attn_values_reduce_kernel(float* dvwb, co
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
         const float* pp = part + (int64_t)n * slices * per_sample + i;
         float a = 0.f;
-        for (int s = 0; s < slices; ++s) a += pp[(int64_t)s * per_sample];
+        int s = 0;
+        for (; s + 8 <= slices; s += 8) {            // eight independent loads per trip, summed in index order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(s + u) * per_sample];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; s < slices; ++s) a += pp[(int64_t)s * per_sample];
         dvwb[(int64_t)n * per_sample + i] = a;
     }
 }

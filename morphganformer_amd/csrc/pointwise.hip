@@ -24,6 +24,7 @@ struct PwParams {
     float* y;
     const float* x;           // [n][cin][hw]
     const float* w;           // [cin][cout_pad] (mgf_pack_conv_weights of a 1x1 kernel)
+    const float* in_scale;    // [n][cin] or null: per-sample style on the input channels (ToRGB: modulated 1x1, no demodulation)
     int n, cin, hw, cout, cout_pad;
     int px_tiles, co_tiles;   // workgroup tiles per sample / over the output channels
     int xcd_per;              // > 0: XCD-aware work order (all channel tiles of a pixel tile on one XCD)
@@ -59,6 +60,9 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.cin * p.hw), 0, p.cin * p.hw * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.cin * p.cout_pad * 4, 0x00020000);
+    // the style multiplies the WEIGHT operand (one dword per lane and k-step, next to the weight's own): w[ci][co] s[n][ci]
+    const bool has_s = p.in_scale != nullptr;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(has_s ? p.in_scale + (int64_t)n * p.cin : p.x), 0, has_s ? p.cin * 4 : 0, 0x00020000);
     // the channel part of every address rides in the VECTOR offset: the range check of a raw buffer access ignores the scalar offset
     const unsigned xo = (unsigned)(half * p.hw + p0 + (VEC ? 4 * l31 : l31)) * 4u;
     const unsigned wo = (unsigned)(half * p.cout_pad + co0 + l31) * 4u;
@@ -86,6 +90,11 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
             }
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) A[ks][cb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wvo + 128u * cb, 0, 0));
+            if (has_s) {
+                const float sv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)((it * PWKU + ks) * 2 + half) * 4u, 0, 0));
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) A[ks][cb] *= sv;
+            }
         }
     };
     auto mm = [&](const float (&B)[PWKU][4], const float (&A)[PWKU][CB]) {
@@ -213,8 +222,8 @@ extern "C" int mgf_conv1x1_force_shape(int32_t channel_blocks) {
     return MGF_OK;
 }
 
-extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, int32_t n, int32_t cin, int32_t hw, int32_t cout, int32_t cout_pad,
-                               int64_t y_batch, int32_t y_choff, const mgf_epilogue* ep, mgf_stream_t stream) {
+extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const float* in_scale, int32_t n, int32_t cin, int32_t hw, int32_t cout,
+                               int32_t cout_pad, int64_t y_batch, int32_t y_choff, const mgf_epilogue* ep, mgf_stream_t stream) {
     MGF_REQUIRE(y && x && w && n >= 1 && cin >= 1 && hw >= 1 && cout >= 1, MGF_EINVAL, "conv1x1: bad arguments");
     MGF_REQUIRE(cout_pad >= cout && cout_pad % 32 == 0, MGF_EINVAL, "conv1x1: the weight image must be [cin][cout_pad], cout_pad a multiple of 32 (got %d for %d)",
                 cout_pad, cout);
@@ -228,7 +237,7 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, int32_t
         MGF_REQUIRE(!ep->noise, MGF_EUNSUPPORTED, "conv1x1: no noise input (the tap-list kernel has it)");
     }
     PwParams p;
-    p.y = y; p.x = x; p.w = w; p.n = n; p.cin = cin; p.hw = hw; p.cout = cout; p.cout_pad = cout_pad;
+    p.y = y; p.x = x; p.w = w; p.in_scale = in_scale; p.n = n; p.cin = cin; p.hw = hw; p.cout = cout; p.cout_pad = cout_pad;
     p.y_batch = y_batch ? y_batch : (int64_t)cout * hw; p.y_choff = y_choff;
     p.has_ep = ep != nullptr;
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; p.ep.act = MGF_ACT_LINEAR; }

@@ -257,6 +257,13 @@ def test_conv1x1_register_gemm_vs_torch_and_tap_list(n, cin, cout, h, w, ctotal,
     # no epilogue at all
     monkeypatch.setattr(cv, "POINTWISE", True)
     assert rel_err(cv.conv_forward(x.cuda(), pc), torch.nn.functional.conv2d(x, wt)) < 2e-5
+    # per-sample style on the input channels (ToRGB: modulated, not demodulated), both kernels
+    sty = 1 + 0.3 * torch.randn(n, cin)
+    ref_m = torch.nn.functional.conv2d(x * sty[:, :, None, None], wt, b)
+    for pointwise in (True, False):
+        monkeypatch.setattr(cv, "POINTWISE", pointwise)
+        got = cv.conv_forward(x.cuda(), pc, in_scale=sty.cuda(), epilogue=_lib.make_epilogue(bias=b_dev))
+        assert rel_err(got, ref_m) < 2e-5
 
 
 @pytest.mark.parametrize("n,cin,cout,res", [(1, 32, 32, 16), (2, 64, 32, 33), (1, 8, 40, 4), (1, 128, 64, 64), (3, 48, 96, 40), (1, 6, 20, 130)])
