@@ -380,6 +380,7 @@ TCONV_GROUPS = [(2 if kh == 1 else 0) + (1 if kw == 1 else 0) for kh in range(3)
 
 
 SPLIT_TCONV_BORDER = os.environ.get("MGF_TCONV_BORDER", "1") != "0"       # tuning hook: 0 = one launch over the (h+1) x (w+1) grid
+TCONV_SPLIT_MIN = int(os.environ.get("MGF_TCONV_SPLIT_MIN", "16"))         # smallest map side that takes the split (tuning hook)
 
 
 def tconv_pitch(w: int) -> int:
@@ -399,8 +400,10 @@ def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=Non
     assert out.is_contiguous() and tuple(out.shape) == (n, pc.cout, oh, pitch)
     # The MFMA launch tiles the h x w grid of 2x2 output quads exactly (rows/columns 0 .. 2h-1 / 2w-1); the last row and column
     # -- 4*in + 1 positions with at most two taps each -- come from a small border kernel.  Tiling (h+1) x (w+1) instead would
-    # spend 7-20 % of the MFMA work on padding (33-wide parity grids over 32-wide tiles).  Maps below 32 px keep the single launch.
-    split = SPLIT_TCONV_BORDER and min(h, w) >= 32
+    # spend 7-20 % of the MFMA work on padding (33-wide parity grids over 32-wide tiles) -- and half of it on a 16 px map, whose 17 x 17
+    # parity grid needs two 256-lane tiles where the 16 x 16 quads fill exactly one (727 -> 503 us for the 16 -> 32 layer at 25 samples).
+    # Maps below 16 px keep the single launch (8 px: 212 vs 302 us with the split).
+    split = SPLIT_TCONV_BORDER and min(h, w) >= TCONV_SPLIT_MIN
     os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, h if split else h + 1, w if split else w + 1, 1, 2, TCONV_TAPS, TCONV_GROUPS,
               [0, 0, 1, 1], [0, 1, 0, 1], oh, ow, pitch, oh * pitch, pc.cout * oh * pitch, 0, os_stride)
