@@ -405,6 +405,13 @@ int mgf_layer_act_bwd_f32(float* dz, float* dot_part, const float* dy, const flo
 int mgf_channel_dot_f32(float* dot_part, const float* a, const float* b, int32_t n, int32_t c, int64_t hw, mgf_stream_t stream);
 int mgf_style_grad_f32(float* dot_part, float* dx, const float* x, const float* g, const float* s, int32_t n, int32_t c, int64_t hw,
                        int32_t accumulate, mgf_stream_t stream);
+/* mgf_style_grad_f32 of a layer fused with mgf_layer_act_bwd_f32 of the layer BEFORE it, whose output y is this layer's input x (conv1 ->
+ * conv0 of a SynthesisBlock; the earlier layer must have no residual): style_part = <x, g> per (n, c, chunk), dz = (s g) gain
+ * (x > 0 ? 1 : alpha), dot_part (may be NULL) = <dz, c> as in mgf_layer_act_bwd_f32 -- bit-identical to the two calls in sequence,
+ * without the intermediate s g ever reaching memory. */
+int mgf_style_grad_act_bwd_f32(float* style_part, float* dot_part, float* dz, const float* x, const float* g, const float* s,
+                               const float* bias, const float* noise, const float* noise_strength, int32_t noise_n, int32_t n, int32_t c,
+                               int64_t hw, float alpha, float gain, mgf_stream_t stream);
 /* Backward of mgf_duplex_attention without its epilogue (apply mgf_layer_act_bwd_f32 first), same operands as the forward:
  *   dx[n,c,f]    gradient with respect to the attention input x
  *   dg[n,c,f]    = da * x * rsqrt(mean_c x^2 + 1e-8), scratch consumed by mgf_attn_values_grad (may be NULL)

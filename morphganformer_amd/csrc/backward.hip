@@ -871,6 +871,84 @@ extern "C" int mgf_style_grad_f32(float* dot_part, float* dx, const float* x, co
     return MGF_OK;
 }
 
+// style_grad of layer L+1 fused with the activation backward of layer L, whose OUTPUT is layer L+1's input x (the conv1 -> conv0 pair of a
+// synthesis block): one pass over (x, g) gives  part_s = <x, g>,  d = s g (never stored),  dz = d gain (x > 0 ? 1 : alpha)  and, when
+// part_dc is given,  part_dc = <dz, c>  with c recovered by inverting the activation -- exactly the arithmetic of the two kernels run one
+// after the other (d is rounded to float32 before it is used), at 3 tensor passes instead of 6.  Layer L must have no residual.
+struct StyleActParams {
+    float* part_s; float* part_dc; float* dz;
+    const float* x; const float* g; const float* s; const float* bias; const float* noise; const float* nstr;
+    int noise_n, c, nchunk;
+    int64_t hw;
+    float alpha, gain;
+};
+namespace {
+template <bool VEC>
+__global__ __launch_bounds__(256) void style_grad_act_bwd_kernel(StyleActParams p) {
+    __shared__ float red[4];
+    const int chunk = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
+    const int64_t base = ((int64_t)n * p.c + ch) * p.hw;
+    const int64_t i0 = (int64_t)chunk * BWD_CHUNK;
+    const int64_t i1 = min(p.hw, i0 + (int64_t)BWD_CHUNK);
+    const float sv = p.s ? p.s[(int64_t)n * p.c + ch] : 1.f;
+    const float b = p.bias ? p.bias[ch] : 0.f;
+    const float ns = p.noise ? (p.nstr ? *p.nstr : 1.f) : 0.f;
+    const float* nz = p.noise ? p.noise + (int64_t)(p.noise_n > 1 ? n : 0) * p.hw : nullptr;
+    const float inv_gain = 1.f / p.gain, inv_alpha = 1.f / p.alpha;
+    float acc_s = 0.f, acc_c = 0.f;
+    auto one = [&](float xv, float gv, float nv, float& dzv) {
+        const float d = sv * gv;                     // (the value style_grad would have stored)
+        const bool pos = xv > 0.f;
+        dzv = d * p.gain * (pos ? 1.f : p.alpha);
+        if (p.part_dc) {
+            const float zv = (pos ? xv : xv * inv_alpha) * inv_gain;
+            acc_c += dzv * (zv - b - nv * ns);
+        }
+    };
+    if (VEC) {
+        for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
+            const float4 gv = *reinterpret_cast<const float4*>(p.g + base + i);
+            const float4 xv = *reinterpret_cast<const float4*>(p.x + base + i);
+            const float4 nv = nz ? *reinterpret_cast<const float4*>(nz + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc_s += xv.x * gv.x + xv.y * gv.y + xv.z * gv.z + xv.w * gv.w;       // (the association of style_grad_kernel: bit-identical partials)
+            float4 o;
+            one(xv.x, gv.x, nv.x, o.x); one(xv.y, gv.y, nv.y, o.y); one(xv.z, gv.z, nv.z, o.z); one(xv.w, gv.w, nv.w, o.w);
+            *reinterpret_cast<float4*>(p.dz + base + i) = o;
+        }
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            float o;
+            const float xs = p.x[base + i], gs = p.g[base + i];
+            acc_s += xs * gs;
+            one(xs, gs, nz ? nz[i] : 0.f, o);
+            p.dz[base + i] = o;
+        }
+    }
+    const float ts = block_sum(acc_s, red);
+    if (threadIdx.x == 0) p.part_s[((int64_t)n * p.c + ch) * p.nchunk + chunk] = ts;
+    if (p.part_dc) {
+        __syncthreads();
+        const float tc = block_sum(acc_c, red);
+        if (threadIdx.x == 0) p.part_dc[((int64_t)n * p.c + ch) * p.nchunk + chunk] = tc;
+    }
+}
+}  // namespace
+
+extern "C" int mgf_style_grad_act_bwd_f32(float* style_part, float* dot_part, float* dz, const float* x, const float* g, const float* s,
+                                          const float* bias, const float* noise, const float* noise_strength, int32_t noise_n, int32_t n,
+                                          int32_t c, int64_t hw, float alpha, float gain, mgf_stream_t stream) {
+    MGF_REQUIRE(style_part && dz && x && g && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "style_grad_act_bwd: bad arguments");
+    MGF_REQUIRE(alpha != 0.f && gain != 0.f, MGF_EINVAL, "style_grad_act_bwd: alpha and gain must be non-zero (the activation is inverted)");
+    MGF_REQUIRE(n <= 65535 && c <= 65535, MGF_ETOOBIG, "style_grad_act_bwd: n and c must be <= 65535");
+    StyleActParams p{style_part, dot_part, dz, x, g, s, bias, noise, noise_strength, noise_n, c, (int)mgf_cdiv(hw, BWD_CHUNK), hw, alpha, gain};
+    auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
+    const bool vec = hw % 4 == 0 && al16(dz) && al16(x) && al16(g) && al16(noise);
+    if (vec) hipLaunchKernelGGL(style_grad_act_bwd_kernel<true>, dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(style_grad_act_bwd_kernel<false>, dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
+    MGF_CHECK_LAUNCH("style_grad_act_bwd");
+    return MGF_OK;
+}
+
 extern "C" int mgf_duplex_attention_bwd(float* dx, float* dg, float* probs, const float* da, const float* x, const float* wqc,
                                         const float* spos, const float* vwb, int32_t n, int32_t c, int32_t f, int32_t t,
                                         mgf_stream_t stream) {

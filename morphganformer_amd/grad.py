@@ -18,12 +18,15 @@ recovered by inverting the leaky ReLU.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
 from . import _lib
 from . import conv as cv
 from .engine import Generator
+
+FUSE_STYLE_ACT = os.environ.get("MGF_FUSE_STYLE_ACT", "1") != "0"      # tuning / test hook: 0 = style_grad and act_bwd as two launches
 
 
 class GeneratorGrad:
@@ -124,25 +127,31 @@ class GeneratorGrad:
         return img
 
     # ------------------------------------------------------------------ backward
-    def _layer_bwd(self, lp, dy, y_out, c_pre, residual, x_in, dx_role):
-        """One SynthesisLayer.  dy: gradient wrt the layer output y_out (= lrelu(c [attention] + noise + bias) * gain + residual);
-        c_pre: the stored demodulated conv output when the layer has attention; x_in: the layer input.  Returns d(x_in)."""
+    def _act_bwd(self, lp, dy, y_out, residual):
+        """d(pre-activation) of one SynthesisLayer from the gradient dy of its output y_out = lrelu(c [attention] + noise + bias) * gain
+        + residual (and, for a demodulated layer without attention, the <dz, c> partials of the demodulation gradient)."""
         G, L, st = self.G, _lib.lib(), _lib.stream_ptr()
         n, c, h, w = y_out.shape
-        hw = h * w
         mode, noises = G.last_noise
         noise, noise_n = G._noise_for(lp, mode, noises)
-        has_att = lp.attn is not None
         dz = self.buf("dz", y_out.shape)
-        want_dot = lp.demod and not has_att
+        want_dot = lp.demod and lp.attn is None
         # conv_last carries neither noise nor bias/activation (engine.synthesis): alpha = gain = 1 makes the kernel a plain copy + dot
         alpha, gain = (0.2, lp.act_gain) if lp.bias is not None else (1.0, 1.0)
         _lib.check(L.mgf_layer_act_bwd_f32(dz.data_ptr(), self.dc_part[lp.name].data_ptr() if want_dot else None, dy.data_ptr(),
                                            y_out.data_ptr(), _lib.ptr(residual), _lib.ptr(lp.bias), _lib.ptr(noise),
-                                           _lib.ptr(lp.noise_strength) if noise is not None else None, noise_n, n, c, hw, alpha,
+                                           _lib.ptr(lp.noise_strength) if noise is not None else None, noise_n, n, c, h * w, alpha,
                                            gain, st), "layer_act_bwd")
+        return dz
+
+    def _conv_bwd(self, lp, dz, y_out, c_pre, x_in):
+        """dz -> g = the data gradient of the layer's convolution BEFORE the style scale (d(x_in) = s * g): attention backward when the
+        layer has one, then the convolution on the transposed taps."""
+        G, L, st = self.G, _lib.lib(), _lib.stream_ptr()
+        n, c, h, w = y_out.shape
+        hw = h * w
         dc = dz
-        if has_att:
+        if lp.attn is not None:
             a = lp.attn
             T = G.cfg.k - 1
             dc, dg, probs = self.buf("dc", y_out.shape), self.buf("dg", y_out.shape), self.buf("probs", (n, a.f, T))
@@ -161,18 +170,44 @@ class GeneratorGrad:
         if lp.kind == "tconv":
             dT = self.buf("dT", (n, c, h + 1, w + 1))
             cv.upfirdn_into(dT, dc, G.plan.fir, up=1, pad=(2, 2, 2, 2), gain=4.0, flip=True)
-            g = cv.conv_forward(dT, self.T[lp.name], stride=2, pad=(0, 0), in_scale=d, out=self.buf("g", x_in.shape))
-        else:
-            pad = (1, 1) if lp.kind == "conv3" else (0, 0)
-            if lp.name in self.Tw and cv.winograd_fills_chip(n, x_in.shape[1], h, w):
-                g = cv.winograd_forward(dc, self.Tw[lp.name], in_scale=d, out=self.buf("g", x_in.shape))
-            else:
-                g = cv.conv_forward(dc, self.T[lp.name], pad=pad, in_scale=d, out=self.buf("g", x_in.shape))
+            return cv.conv_forward(dT, self.T[lp.name], stride=2, pad=(0, 0), in_scale=d, out=self.buf("g", x_in.shape))
+        pad = (1, 1) if lp.kind == "conv3" else (0, 0)
+        if lp.name in self.Tw and cv.winograd_fills_chip(n, x_in.shape[1], h, w):
+            return cv.winograd_forward(dc, self.Tw[lp.name], in_scale=d, out=self.buf("g", x_in.shape))
+        return cv.conv_forward(dc, self.T[lp.name], pad=pad, in_scale=d, out=self.buf("g", x_in.shape))
+
+    def _style_bwd(self, lp, g, x_in, dx_role):
+        """<x_in, g> partials of the style gradient and d(x_in) = s * g."""
+        G, L, st = self.G, _lib.lib(), _lib.stream_ptr()
+        n = x_in.shape[0]
         dx = self.buf(dx_role, x_in.shape)
         ci, hi = x_in.shape[1], x_in.shape[2] * x_in.shape[3]
         _lib.check(L.mgf_style_grad_f32(self.ds_part[lp.name].data_ptr(), dx.data_ptr(), x_in.data_ptr(), g.data_ptr(),
                                         G._s(lp).data_ptr(), n, ci, hi, 0, st), "style_grad")
         return dx
+
+    def _style_act_bwd(self, lp, g, prev, y_prev):
+        """_style_bwd of `lp` fused with _act_bwd of the layer `prev` whose output y_prev is lp's input (conv1 -> conv0 of a block: prev has
+        no residual): one pass over (y_prev, g), the intermediate s * g never reaches memory (mgf_style_grad_act_bwd_f32)."""
+        G, L, st = self.G, _lib.lib(), _lib.stream_ptr()
+        n, c, h, w = y_prev.shape
+        mode, noises = G.last_noise
+        noise, noise_n = G._noise_for(prev, mode, noises)
+        dz = self.buf("dz", y_prev.shape)
+        want_dot = prev.demod and prev.attn is None
+        alpha, gain = (0.2, prev.act_gain) if prev.bias is not None else (1.0, 1.0)
+        _lib.check(L.mgf_style_grad_act_bwd_f32(self.ds_part[lp.name].data_ptr(), self.dc_part[prev.name].data_ptr() if want_dot else None,
+                                                dz.data_ptr(), y_prev.data_ptr(), g.data_ptr(), G._s(lp).data_ptr(), _lib.ptr(prev.bias),
+                                                _lib.ptr(noise), _lib.ptr(prev.noise_strength) if noise is not None else None, noise_n,
+                                                n, c, h * w, alpha, gain, st), "style_grad_act_bwd")
+        return dz
+
+    def _layer_bwd(self, lp, dy, y_out, c_pre, residual, x_in, dx_role):
+        """One SynthesisLayer.  dy: gradient wrt the layer output y_out (= lrelu(c [attention] + noise + bias) * gain + residual);
+        c_pre: the stored demodulated conv output when the layer has attention; x_in: the layer input.  Returns d(x_in)."""
+        dz = self._act_bwd(lp, dy, y_out, residual)
+        g = self._conv_bwd(lp, dz, y_out, c_pre, x_in)
+        return self._style_bwd(lp, g, x_in, dx_role)
 
     def backward_w(self, dimg):
         """dimg [n,3,R,R] -> dw [n,k,D]: gradient of <img, dimg> with respect to the intermediate latent w."""
@@ -210,8 +245,19 @@ class GeneratorGrad:
             d_out = dx
             if self.debug is not None:
                 self.debug[f"synthesis.b{res}:dout"] = d_out.clone()
-            dmid = self._layer_bwd(l1, d_out, y1, B["conv1"] if att else None, B["skip"], y0, "dmid")
-            dxin = self._layer_bwd(l0, dmid, y0, B["conv0"] if att else None, None, x_prev, "dxin")
+            # conv1 then conv0: conv1's input IS conv0's output y0, so conv1's style gradient and conv0's activation backward are one
+            # pass over (y0, g) -- d(y0) = s g is never stored (MGF_FUSE_STYLE_ACT=0: the two kernels in sequence, bit-identical)
+            dz1 = self._act_bwd(l1, d_out, y1, B["skip"])
+            g1 = self._conv_bwd(l1, dz1, y1, B["conv1"] if att else None, y0)
+            if FUSE_STYLE_ACT and self.debug is None:
+                dz0 = self._style_act_bwd(l1, g1, l0, y0)
+            else:
+                dmid = self._style_bwd(l1, g1, y0, "dmid")
+                if self.debug is not None:
+                    self.debug[f"synthesis.b{res}:dmid"] = dmid.clone()
+                dz0 = self._act_bwd(l0, dmid, y0, None)
+            g0 = self._conv_bwd(l0, dz0, y0, B["conv0"] if att else None, x_prev)
+            dxin = self._style_bwd(l0, g0, x_prev, "dxin")
             # skip branch: y = upfirdn(conv1x1(x), up=2, pad (2,1,2,1), gain 4)  ->  conv1x1^T(upfirdn(dy, down=2, pad (1,1,1,1)))
             dlow = self.buf("dlow", B["skip_low"].shape)
             cv.upfirdn_into(dlow, d_out, P.fir, up=1, down=2, pad=(1, 1, 1, 1), gain=4.0, flip=True)

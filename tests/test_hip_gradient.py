@@ -86,6 +86,34 @@ def test_layer_act_bwd_and_dots():
     assert torch.allclose(dx, 2.0 + s[:, :, None] * b, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("hw,with_dot", [(5000, True), (4096, False), (37, True)])
+def test_style_grad_fused_with_act_bwd_is_the_two_kernels_in_sequence(hw, with_dot):
+    """mgf_style_grad_act_bwd_f32 (conv1's style gradient + conv0's activation backward in one pass) == mgf_style_grad_f32 followed by
+    mgf_layer_act_bwd_f32, bit for bit: same partial sums, same dz."""
+    from morphganformer_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(hw)
+    n, c = 2, 5
+    y = torch.randn(n, c, hw, device="cuda")                       # conv0's output = conv1's input
+    g = torch.randn(n, c, hw, device="cuda")
+    s = torch.rand(n, c, device="cuda") + 0.5
+    bias, noise = torch.randn(c, device="cuda"), torch.randn(n, hw, device="cuda")
+    nstr = torch.tensor([0.3], device="cuda")
+    chunks = int(L.mgf_bwd_chunks(hw))
+    st = _lib.stream_ptr()
+    ps_a, pd_a = torch.empty(n, c, chunks, device="cuda"), torch.empty(n, c, chunks, device="cuda")
+    dmid, dz_a = torch.empty_like(y), torch.empty_like(y)
+    _lib.check(L.mgf_style_grad_f32(ps_a.data_ptr(), dmid.data_ptr(), y.data_ptr(), g.data_ptr(), s.data_ptr(), n, c, hw, 0, st))
+    _lib.check(L.mgf_layer_act_bwd_f32(dz_a.data_ptr(), pd_a.data_ptr() if with_dot else None, dmid.data_ptr(), y.data_ptr(), None,
+                                       bias.data_ptr(), noise.data_ptr(), nstr.data_ptr(), n, n, c, hw, 0.2, 1.3, st))
+    ps_b, pd_b, dz_b = torch.empty_like(ps_a), torch.empty_like(pd_a), torch.empty_like(y)
+    _lib.check(L.mgf_style_grad_act_bwd_f32(ps_b.data_ptr(), pd_b.data_ptr() if with_dot else None, dz_b.data_ptr(), y.data_ptr(), g.data_ptr(),
+                                            s.data_ptr(), bias.data_ptr(), noise.data_ptr(), nstr.data_ptr(), n, n, c, hw, 0.2, 1.3, st))
+    assert torch.equal(dz_a, dz_b) and torch.equal(ps_a, ps_b)
+    if with_dot:
+        assert torch.equal(pd_a, pd_b)
+
+
 @pytest.mark.parametrize("c,res", [(32, 8), (512, 4), (20, 6), (256, 32), (64, 16), (512, 8), (256, 8)])
 def test_duplex_attention_bwd_matches_autograd(c, res):
     from morphganformer_amd import _lib
