@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void fir_up1_wide(UFParams p) {
 // thread produces a 4x4 output patch from a 7-row x 12-column register window -- horizontal pass on the 7 rows (4 taps), vertical
 // pass on the 4x4 patch (4 taps): 11 FMAs and 1.3 LDS reads per output instead of 16 and 3.  Workgroup = 64x64 outputs, window of
 // 67 rows x 18 float4 staged once (read amplification 1.18 instead of 1.33).
-template <bool EP>
+template <bool EP, int PADX = 1, bool RAGGED = false>
 __global__ __launch_bounds__(256) void fir_up1_sep(UFParams p) {
     constexpr int T = 64, WV = 18, IH = T + 3;
     __shared__ float4 sx[IH][WV + 1];
@@ -325,7 +325,9 @@ __global__ __launch_bounds__(256) void fir_up1_sep(UFParams p) {
         sfx[tid] = p.f[k] / f00;                                     // row 0 normalised
         sfy[tid] = p.f[k * p.fw] * p.gain;                           // column 0 (carries f00)
     }
-    const int tiles_x = p.out_w / T, tiles_y = (p.out_h + T - 1) / T;
+    // PADX = 2 / RAGGED: the blur's own gradient (pad 2 on every side, output one wider than the input and of any width: rows are not
+    // 16-byte aligned, so the last stage stores element-wise) -- the backward pass of gradient mode ran on the generic tiled kernel
+    const int tiles_x = RAGGED ? (p.out_w + T - 1) / T : p.out_w / T, tiles_y = (p.out_h + T - 1) / T;
     const int tile = blockIdx.x % (tiles_x * tiles_y), plane = blockIdx.x / (tiles_x * tiles_y);
     const int ox0 = (tile % tiles_x) * T, oy0 = (tile / tiles_x) * T;
     const int n = plane / p.c, c = plane - n * p.c;
@@ -352,7 +354,8 @@ __global__ __launch_bounds__(256) void fir_up1_sep(UFParams p) {
         const float4 a = sx[4 * ly + r][lx], b = sx[4 * ly + r][lx + 1], cc = sx[4 * ly + r][lx + 2];
         const float w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, cc.x, cc.y, cc.z, cc.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hz[r][e] = w[3 + e] * fx0 + w[4 + e] * fx1 + w[5 + e] * fx2 + w[6 + e] * fx3;   // padx0 == 1
+        for (int e = 0; e < 4; ++e)                                  // input column of tap k: ox + e - PADX + k = window slot 4 - PADX + e + k
+            hz[r][e] = w[4 - PADX + e] * fx0 + w[5 - PADX + e] * fx1 + w[6 - PADX + e] * fx2 + w[7 - PADX + e] * fx3;
     }
     const float fy0 = sfy[0], fy1 = sfy[1], fy2 = sfy[2], fy3 = sfy[3];
     const float ns = (EP && p.ep.noise && p.ep.noise_strength) ? *p.ep.noise_strength : 1.0f;
@@ -381,7 +384,13 @@ __global__ __launch_bounds__(256) void fir_up1_sep(UFParams p) {
                 acc[e] = v * p.ep.gain + rr[e];
             }
         }
-        *reinterpret_cast<float4*>((float*)p.y + yoff) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (RAGGED) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ox + e < p.out_w) ((float*)p.y)[yoff + e] = acc[e];
+        } else {
+            *reinterpret_cast<float4*>((float*)p.y + yoff) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
     }
 }
 
@@ -493,6 +502,12 @@ extern "C" int mgf_upfirdn2d(void* y, const void* x, const float* f, int dtype, 
         if (ep) hipLaunchKernelGGL((fir_up1_wide<true>), dim3(blocks), dim3(256), 0, stq, p);
         else hipLaunchKernelGGL((fir_up1_wide<false>), dim3(blocks), dim3(256), 0, stq, p);
         }
+    } else if (tiled && fh == 4 && fw == 4 && upx == 1 && padx0 == 2 && pady0 >= 0 && pady0 <= 3 && !ep && p.sep_ok && in_w % 4 == 0 &&
+               sh % 4 == 0 && sc % 4 == 0 && sn % 4 == 0 && ((uintptr_t)x % 16 == 0) && sh >= in_w &&
+               (int64_t)n * c * mgf_cdiv(out_h, 64) * mgf_cdiv(out_w, 64) <= INT32_MAX) {
+        // the gradient of the post-transposed-conv blur: separable kernel, pad 2, element-wise stores into rows of any width
+        const int blocks = n * c * (int)mgf_cdiv(out_h, 64) * (int)mgf_cdiv(out_w, 64);
+        hipLaunchKernelGGL((fir_up1_sep<false, 2, true>), dim3(blocks), dim3(256), 0, stq, p);
     } else if (wide_ok && upx == 2 && padx0 == 2 && pady0 == 2 && !ep && in_w % 4 == 0 && out_h % 2 == 0) {
         const int blocks = n * c * (int)mgf_cdiv(out_h, 16 * FIR_SUB) * (out_w / 64);
         hipLaunchKernelGGL(fir_up2_wide, dim3(blocks), dim3(256), 0, stq, p);

@@ -169,7 +169,7 @@ class GeneratorGrad:
         d = G._d(lp) if lp.demod else None
         if lp.kind == "tconv":
             dT = self.buf("dT", (n, c, h + 1, w + 1))
-            cv.upfirdn_into(dT, dc, G.plan.fir, up=1, pad=(2, 2, 2, 2), gain=4.0, flip=True)
+            cv.upfirdn_into(dT, dc, G.plan.fir, up=1, pad=(2, 2, 2, 2), gain=4.0, flip=True, separable=True)    # (plan.fir is an outer product, cf. engine._layer)
             return cv.conv_forward(dT, self.T[lp.name], stride=2, pad=(0, 0), in_scale=d, out=self.buf("g", x_in.shape))
         pad = (1, 1) if lp.kind == "conv3" else (0, 0)
         if lp.name in self.Tw and cv.winograd_fills_chip(n, x_in.shape[1], h, w):

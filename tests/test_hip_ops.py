@@ -117,6 +117,22 @@ def test_upfirdn2d_tiled_vs_oracle(up, pad, shape):
     assert rel_err(gx, gr) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 64), (1, 2, 128, 200), (1, 1, 36, 40), (2, 2, 200, 132)])
+def test_blur_gradient_geometry_on_the_separable_kernel(shape):
+    """The gradient of the post-transposed-conv blur is the same filter with pad 2 on every side and an output one larger than the input
+    (odd width: rows are not 16-byte aligned) -- the separable kernel's PADX = 2 / ragged instantiation, vs the oracle."""
+    from morphganformer_amd import conv as cv
+    from oracle.ops_ref import setup_filter_ref, upfirdn2d_ref
+    torch.manual_seed(shape[2] + shape[3])
+    f = setup_filter_ref([1, 3, 3, 1])
+    x = torch.randn(*shape)
+    ref = upfirdn2d_ref(x, f, padding=[2, 2, 2, 2], gain=4.0, flip_filter=True)
+    out = torch.full([shape[0], shape[1], shape[2] + 1, shape[3] + 1], 7.0, device="cuda")
+    cv.upfirdn_into(out, x.cuda(), f.cuda(), up=1, pad=(2, 2, 2, 2), gain=4.0, flip=True, separable=True)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert rel_err(out, ref) < 3e-6
+
+
 @pytest.mark.parametrize("n,c,res", [(1, 3, 64), (2, 5, 128), (1, 2, 192)])
 def test_upfirdn2d_wide_kernels_vs_oracle(n, c, res):
     """The float4 kernels of the synthesis hot path: (a) blur of a padded-pitch [.., 2h+1, 2w+1] transposed-conv workspace
