@@ -227,10 +227,15 @@ class GeneratorGrad:
         h = G.bufs[R]["last"]
         # ToRGB: img = sum_co W[c,co] s[co] h[co] + bias (no demodulation, no activation)
         g = cv.conv_forward(dimg, self.T[lt.name], out=self.buf("g", h.shape))
-        dh = self.buf("dh", h.shape)
-        _lib.check(L.mgf_style_grad_f32(self.ds_part[lt.name].data_ptr(), dh.data_ptr(), h.data_ptr(), g.data_ptr(),
-                                        G._s(lt).data_ptr(), n, h.shape[1], h.shape[2] * h.shape[3], 0, st), "style_grad(torgb)")
-        dx = self._layer_bwd(ll, dh, h, None, None, out_of(R), "dxin")
+        if FUSE_STYLE_ACT and self.debug is None:
+            # ToRGB's input IS conv_last's output h: its style gradient and conv_last's (linear) activation backward in one pass over (h, g)
+            dzl = self._style_act_bwd(lt, g, ll, h)
+            dx = self._style_bwd(ll, self._conv_bwd(ll, dzl, h, None, out_of(R)), out_of(R), "dxin")
+        else:
+            dh = self.buf("dh", h.shape)
+            _lib.check(L.mgf_style_grad_f32(self.ds_part[lt.name].data_ptr(), dh.data_ptr(), h.data_ptr(), g.data_ptr(),
+                                            G._s(lt).data_ptr(), n, h.shape[1], h.shape[2] * h.shape[3], 0, st), "style_grad(torgb)")
+            dx = self._layer_bwd(ll, dh, h, None, None, out_of(R), "dxin")
         for res in reversed(cfg.block_resolutions):
             B = G.bufs[res]
             att = cfg.has_attention(res)
