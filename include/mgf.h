@@ -458,6 +458,12 @@ int mgf_latent_grad_gather(float* dw, const float* dwg, int32_t n_style_jobs, co
 int64_t mgf_mapping_bwd_scratch_floats(int32_t k, int32_t dim, int32_t n_res_layers);
 int mgf_mapping_backward(float* dz, const float* dw, const float* z, const float* params, float* scratch, int32_t n, int32_t k,
                          int32_t dim, int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream);
+/* The same pair without the recomputation: mgf_mapping_forward_save is mgf_mapping_forward that also fills `scratch` (same size
+ * and layout) with the activations; mgf_mapping_backward_saved reads them for the same z. */
+int mgf_mapping_forward_save(float* w, const float* z, const float* params, float* scratch, int32_t n, int32_t k, int32_t dim,
+                             int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream);
+int mgf_mapping_backward_saved(float* dz, const float* dw, const float* z, const float* params, float* scratch, int32_t n, int32_t k,
+                               int32_t dim, int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream);
 
 /* Loss side of gradient mode (what autograd does through lpips/networks_basic.py:64-92 and torch.nn.MSELoss):
  *   lpips_layer_bwd:   df0 (+)= d/df0 [ scale * mean_hw sum_c lin[c] (f0/(|f0|+1e-10) - f1_unit)^2 ], operands as mgf_lpips_layer_f32;

@@ -130,6 +130,8 @@ _SIGS = {
     "mgf_adam_step_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, vp]),
     "mgf_mapping_bwd_scratch_floats": (i64, [i32, i32, i32]),
     "mgf_mapping_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mgf_mapping_forward_save": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mgf_mapping_backward_saved": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
 }
 
 EXPORTED_SYMBOLS = sorted(_SIGS)

@@ -572,34 +572,72 @@ __global__ __launch_bounds__(256) void attn_values_reduce_kernel(float* dvwb, co
 
 // ------------------------------------------------------------------------------------------ latent-side backward
 // grid (njobs, n): d(style) -> d(global latent component) for one modulated layer (see the header comment)
+// Sum the per-chunk partials of `rows` rows ([rows][chunks], contiguous) and hand each total to emit(row, sum).  Many chunks (the
+// large maps): one wave per row, lanes across the chunks; few: one thread per row.  Fixed order either way.
+template <class F>
+__device__ __forceinline__ void sum_chunk_partials(const float* part, int rows, int chunks, F&& emit) {
+    const int tid = threadIdx.x;
+    if (chunks >= 16) {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int r = wv; r < rows; r += 4) {
+            float a = 0.f;
+            for (int q = lane; q < chunks; q += 64) a += part[(int64_t)r * chunks + q];
+#pragma unroll
+            for (int o = 32; o; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0) emit(r, a);
+        }
+    } else {
+        for (int r = tid; r < rows; r += 256) {
+            float a = 0.f;
+            for (int q = 0; q < chunks; ++q) a += part[(int64_t)r * chunks + q];
+            emit(r, a);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void style_demod_bwd_kernel(float* dwg, const mgf_style_bwd_job* jobs, int njobs, int wdim) {
     __shared__ float tl[2048];
     __shared__ float dst[2048];
-    __shared__ float red[256];
+    __shared__ float red[1024];
     const mgf_style_bwd_job j = jobs[blockIdx.x];
     const int n = blockIdx.y, tid = threadIdx.x;
     const bool demod = j.wsq && j.d && j.dc_part;
-    if (demod) {
-        for (int o = tid; o < j.cout; o += 256) {
-            const float* pp = j.dc_part + ((int64_t)n * j.cout + o) * j.d_chunks;
-            float acc = 0.f;
-            for (int q = 0; q < j.d_chunks; ++q) acc += pp[q];
+    if (demod)
+        sum_chunk_partials(j.dc_part + (int64_t)n * j.cout * j.d_chunks, j.cout, j.d_chunks, [&](int o, float a) {
             const float dv = j.d[(int64_t)n * j.cout + o];
-            tl[o] = acc * dv * dv;
-        }
-    }
+            tl[o] = a * dv * dv;
+        });
+    sum_chunk_partials(j.ds_part + (int64_t)n * j.cin * j.s_chunks, j.cin, j.s_chunks, [&](int i, float a) { dst[i] = a; });
     __syncthreads();
-    for (int i = tid; i < j.cin; i += 256) {
-        const float* pp = j.ds_part + ((int64_t)n * j.cin + i) * j.s_chunks;
-        float acc = 0.f;
-        for (int q = 0; q < j.s_chunks; ++q) acc += pp[q];
-        if (demod) {
-            float dem = 0.f;
+    if (demod) {
+        // dem[i] = sum_o tl[o] * wsq[o][i]: the [cout x cin] table is read once, four input channels per lane, the output channels
+        // split over as many slices as 256 lanes allow; the slices meet in LDS
+        const int q4 = j.cin >> 2;
+        if ((j.cin & 3) == 0 && q4 <= 256 && 256 % q4 == 0) {
+            const int i4 = tid % q4, sl = tid / q4, nsl = 256 / q4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4* wq = (const float4*)j.wsq + i4;
 #pragma unroll 8
-            for (int o = 0; o < j.cout; ++o) dem += tl[o] * j.wsq[(int64_t)o * j.cin + i];
-            acc -= j.s[(int64_t)n * j.cin + i] * dem;
+            for (int o = sl; o < j.cout; o += nsl) {
+                const float4 w = wq[(int64_t)o * q4];
+                const float t = tl[o];
+                a.x += t * w.x; a.y += t * w.y; a.z += t * w.z; a.w += t * w.w;
+            }
+            ((float4*)red)[tid] = a;                 // [nsl][q4] float4
+            __syncthreads();
+            for (int i = tid; i < j.cin; i += 256) {
+                float dem = 0.f;
+                for (int q = 0; q < nsl; ++q) dem += red[(q * q4 + (i >> 2)) * 4 + (i & 3)];
+                dst[i] -= j.s[(int64_t)n * j.cin + i] * dem;
+            }
+        } else {
+            for (int i = tid; i < j.cin; i += 256) {
+                float dem = 0.f;
+#pragma unroll 8
+                for (int o = 0; o < j.cout; ++o) dem += tl[o] * j.wsq[(int64_t)o * j.cin + i];
+                dst[i] -= j.s[(int64_t)n * j.cin + i] * dem;
+            }
         }
-        dst[i] = acc;
     }
     __syncthreads();
     const int k = tid % wdim, sl = tid / wdim, nsl = 256 / wdim;

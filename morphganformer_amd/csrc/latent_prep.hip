@@ -155,29 +155,57 @@ struct MapLayout {              // float offsets inside the blob (see engine.py:
 
 __device__ __forceinline__ float lrelu02(float v) { return v > 0.f ? v : 0.2f * v; }
 
-// out[r][o] = sum_i in[r][i] * W[o][i] + (row_bias ? brow[r*D + o] : b[o]);  rows x 32 outputs spread over the block
-__device__ void fc_rows(float* out, const float* in, const float* W, const float* b, bool row_bias, int rows) {
-    for (int idx = threadIdx.x; idx < rows * MD; idx += blockDim.x) {
-        const int r = idx / MD, o = idx % MD;
-        const float* wr = W + o * MD;
-        const float* xr = in + r * MD;
-        float acc = 0.f;
+// One D x D layer the way the thread that uses it holds it: row o of W for the forward product out[r][o] = <in[r], W[o]> + b, or
+// column i for the backward product out[r][i] = sum_o in[r][o] W[o][i], with o / i = tid % D -- the same for each of the thread's
+// outputs (rows tid/D, tid/D + 8, ...) -- and those outputs' biases.  A layer's matrices are all loaded at its top, ahead of use:
+// the network is a chain of ~50 tiny dependent products run by one workgroup, and this leaves one exposed memory latency per
+// layer instead of one per product.  Sums run i = 0..D-1 from zero and the bias is added last, in every form of these kernels.
+constexpr int MAP_BLOCK = 256;
+constexpr int MAP_PASSES = MT_MAX * MD / MAP_BLOCK;       // outputs per thread of a [T x D] product
+constexpr int MAP_MAX_RES = 7;                            // the global path keeps its 2 n_res + 1 weights in 8 groups x 2 register sets
+struct FcW { float w[MD]; float b[MAP_PASSES]; };
+
+__device__ __forceinline__ void load_fc_row(FcW& f, const float* W, const float* b, bool row_bias, int rows) {
+    const int o = threadIdx.x & (MD - 1), r0 = threadIdx.x / MD;
+    const float4* p = (const float4*)(W + o * MD);
 #pragma unroll
-        for (int i = 0; i < MD; ++i) acc += xr[i] * wr[i];
-        out[idx] = acc + (row_bias ? b[r * MD + o] : b[o]);
+    for (int j = 0; j < MD / 4; ++j) {
+        const float4 q = p[j];
+        f.w[4 * j] = q.x; f.w[4 * j + 1] = q.y; f.w[4 * j + 2] = q.z; f.w[4 * j + 3] = q.w;
+    }
+#pragma unroll
+    for (int j = 0; j < MAP_PASSES; ++j) {
+        const int r = r0 + (MAP_BLOCK / MD) * j;
+        f.b[j] = row_bias ? (r < rows ? b[r * MD + o] : 0.f) : b[o];
     }
 }
-
-// out[r][i] = sum_o in[r][o] * W[o][i]   (the transposed product of the backward pass)
-__device__ void fc_rows_t(float* out, const float* in, const float* W, int rows, bool accumulate) {
-    for (int idx = threadIdx.x; idx < rows * MD; idx += blockDim.x) {
-        const int r = idx / MD, i = idx % MD;
-        const float* xr = in + r * MD;
-        float acc = 0.f;
+__device__ __forceinline__ void load_fc_col(FcW& f, const float* W) {
+    const int i = threadIdx.x & (MD - 1);
 #pragma unroll
-        for (int o = 0; o < MD; ++o) acc += xr[o] * W[o * MD + i];
-        out[idx] = accumulate ? out[idx] + acc : acc;
+    for (int o = 0; o < MD; ++o) f.w[o] = W[o * MD + i];
+}
+
+// emit(idx, j, <in[idx / D], f.w> (+ bias)) for the thread's outputs idx = tid + 256 j < rows * D
+template <bool BIAS, class F>
+__device__ __forceinline__ void fc_apply(const float* in, const FcW& f, int rows, F&& emit) {
+#pragma unroll
+    for (int j = 0; j < MAP_PASSES; ++j) {
+        const int idx = threadIdx.x + MAP_BLOCK * j;
+        if (idx < rows * MD) {
+            const float* xr = in + (idx / MD) * MD;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < MD; ++i) acc += xr[i] * f.w[i];
+            emit(idx, j, BIAS ? acc + f.b[j] : acc);
+        }
     }
+}
+// one row (the global component): the 32 lanes of one group
+__device__ __forceinline__ float fc_row1(const float* in, const FcW& f) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MD; ++i) acc += in[i] * f.w[i];
+    return acc;
 }
 
 struct MapShared {
@@ -187,7 +215,7 @@ struct MapShared {
     float red[4];
 };
 
-// Per-sample scratch of the backward pass (floats): what the recomputed forward leaves behind.
+// Per-sample scratch of the backward pass (floats): what the saving forward leaves behind.
 //   global path, per res layer: {H0 (post-lrelu fc0), Xo (layer output)} = 2 D
 //   local  path, per res layer: {Q, K, V, H0, Xo} (T D each), P (T T)
 struct MapSave {
@@ -199,82 +227,109 @@ struct MapSave {
     __host__ __device__ int64_t total() const { return lbase() + n_res * lstride(); }
 };
 
-// Forward of one sample; SAVE additionally stores the per-layer activations the backward pass needs into `sv`.
+constexpr float MAP_SQ2 = 1.41421356237309515f;
+constexpr int MAP_WSZ = MD * MD;
+constexpr int MAP_GSTRIDE = 2 * MAP_WSZ + 2 * MD;                          // global res layer {W0,b0,W1,b1}
+__device__ __forceinline__ int64_t map_lstride(int T) { return 6 * (int64_t)MAP_WSZ + 2 * (int64_t)T * MD + 4 * MD; }
+__device__ __forceinline__ const float* map_local_params(const float* P, int n_res) { return P + n_res * MAP_GSTRIDE + MAP_WSZ + MD; }
+
+// The global component and the T local components never meet inside the mapping network: each sample runs as two workgroups
+// (blockIdx.y: 0 = local MLP with latent self-attention, 1 = global MLP), forward and backward.
+//
+// Global path, forward.  Its 2 n_res + 1 products have one row each: group g (32 lanes) of the workgroup keeps the weights of
+// products g and g + 8 in registers (loaded at the start, all in flight together) and runs them; the row travels through LDS.
+// SAVE additionally stores the per-layer activations the backward pass needs into `sv` and the normalisation factor.
 template <bool SAVE>
-__device__ void mapping_forward_body(MapShared& sh, float* w_n, const float* zn, const float* P, int k, int n_res, int normalize_global,
-                                     float* sv, float* norm_out) {
-    float *X = sh.X, *Xin = sh.Xin, *Q = sh.Q, *K = sh.K, *V = sh.V, *H = sh.H, *Pr = sh.Pr, *G = sh.G, *Gin = sh.Gin, *GH = sh.GH;
-    float* red = sh.red;
-    const int tid = threadIdx.x;
-    const int T = k - 1;
+__device__ __forceinline__ void mapping_forward_global(MapShared& sh, float* w_n, float* w_copy, const float* zn, const float* P, int k, int n_res,
+                                       int normalize_global, float* sv, float* norm_out) {
+    float *G = sh.G, *GH = sh.GH;
+    const int tid = threadIdx.x, g = tid / MD, o = tid & (MD - 1);
+    const int T = k - 1, nfc = 2 * n_res + 1;
     const MapSave ms{T, n_res};
-    // ---- normalize (networks.py:30-37): joint second moment over the T x D local block; global row separately ----
-    float part = 0.f;
-    for (int i = tid; i < T * MD; i += blockDim.x) { float v = zn[i]; part += v * v; }
-    part = wave_sum(part);
-    if ((tid & 63) == 0) red[tid >> 6] = part;
-    __syncthreads();
-    const float fl = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)(T * MD) + 1e-8f);
-    for (int i = tid; i < T * MD; i += blockDim.x) X[i] = zn[i] * fl;
-    __syncthreads();
+    auto fcw = [&](int j) { return j < 2 * n_res ? P + (j >> 1) * MAP_GSTRIDE + (j & 1) * (MAP_WSZ + MD) : P + n_res * MAP_GSTRIDE; };
+    FcW s0, s1;
+    if (g < nfc) load_fc_row(s0, fcw(g), fcw(g) + MAP_WSZ, false, 1);
+    if (g + 8 < nfc) load_fc_row(s1, fcw(g + 8), fcw(g + 8) + MAP_WSZ, false, 1);
     if (tid < 64) {
         float v = tid < MD ? zn[T * MD + tid] : 0.f;
         float ss = wave_sum(v * v);
         float fg = normalize_global ? rsqrtf(ss / (float)MD + 1e-8f) : 1.f;
         if (tid < MD) G[tid] = v * fg;
-        if (SAVE && tid == 0) { norm_out[0] = fl; norm_out[1] = fg; }
+        if (SAVE && tid == 0) norm_out[1] = fg;
     }
     __syncthreads();
-
-    const int WSZ = MD * MD;
-    const float* p = P;
-    // ---- global MLP ----
     for (int l = 0; l < n_res; ++l) {
-        const float *W0 = p, *b0 = p + WSZ, *W1 = b0 + MD, *b1 = W1 + WSZ;
-        p = b1 + MD;
-        if (tid < MD) Gin[tid] = G[tid];
-        __syncthreads();
-        fc_rows(GH, G, W0, b0, false, 1);
-        __syncthreads();
-        if (tid < MD) {
-            GH[tid] = lrelu02(GH[tid]) * 1.41421356237309515f;
-            if (SAVE) sv[ms.glayer(l) + tid] = GH[tid];
+        int j = 2 * l;
+        if (g == (j & 7)) {
+            const float v = (j >> 3) ? fc_row1(G, s1) + s1.b[0] : fc_row1(G, s0) + s0.b[0];
+            const float h = lrelu02(v) * MAP_SQ2;
+            GH[o] = h;
+            if (SAVE) sv[ms.glayer(l) + o] = h;
         }
         __syncthreads();
-        fc_rows(G, GH, W1, b1, false, 1);
-        __syncthreads();
-        if (tid < MD) {
-            G[tid] = lrelu02(G[tid] + Gin[tid]);
-            if (SAVE) sv[ms.glayer(l) + MD + tid] = G[tid];
+        j = 2 * l + 1;
+        if (g == (j & 7)) {
+            const float v = (j >> 3) ? fc_row1(GH, s1) + s1.b[0] : fc_row1(GH, s0) + s0.b[0];
+            const float x = lrelu02(v + G[o]);       // the product reads GH; G[o] is this lane's own element
+            G[o] = x;
+            if (SAVE) sv[ms.glayer(l) + MD + o] = x;
         }
         __syncthreads();
     }
     {
-        const float *Wo = p, *bo = p + WSZ;
-        p = bo + MD;
-        fc_rows(GH, G, Wo, bo, false, 1);
-        __syncthreads();
-        if (tid < MD) w_n[T * MD + tid] = lrelu02(GH[tid]) * 1.41421356237309515f;
+        const int j = 2 * n_res;
+        if (g == (j & 7)) {
+            const float v = (j >> 3) ? fc_row1(G, s1) + s1.b[0] : fc_row1(G, s0) + s0.b[0];
+            const float w = lrelu02(v) * MAP_SQ2;
+            w_n[T * MD + o] = w;
+            if (w_copy) w_copy[T * MD + o] = w;
+        }
     }
-    // ---- local MLP with latent self-attention ----
+}
+
+// Local path, forward.
+template <bool SAVE>
+__device__ __forceinline__ void mapping_forward_local(MapShared& sh, float* w_n, float* w_copy, const float* zn, const float* P, int k, int n_res,
+                                      float* sv, float* norm_out) {
+    float *X = sh.X, *Xin = sh.Xin, *Q = sh.Q, *K = sh.K, *V = sh.V, *H = sh.H, *Pr = sh.Pr;
+    float* red = sh.red;
+    const int tid = threadIdx.x;
+    const int T = k - 1, TD = T * MD;
+    const MapSave ms{T, n_res};
+    const float* p = map_local_params(P, n_res);
+    // ---- normalize (networks.py:30-37): joint second moment over the T x D local block ----
+    float part = 0.f;
+    for (int i = tid; i < TD; i += MAP_BLOCK) { float v = zn[i]; part += v * v; }
+    part = wave_sum(part);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const float fl = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)TD + 1e-8f);
+    for (int i = tid; i < TD; i += MAP_BLOCK) X[i] = zn[i] * fl;
+    if (SAVE && tid == 0) norm_out[0] = fl;
+    __syncthreads();
+    // ---- res layers: latent self-attention, then two dense layers ----
     for (int l = 0; l < n_res; ++l) {
-        const float* Wq = p;            const float* bq = Wq + WSZ;
-        const float* Wk = bq + T * MD;  const float* bk = Wk + WSZ;
-        const float* Wv = bk + T * MD;  const float* bv = Wv + WSZ;
-        const float* Wm = bv + MD;      const float* bm = Wm + WSZ;
-        const float* W0 = bm + MD;      const float* b0 = W0 + WSZ;
-        const float* W1 = b0 + MD;      const float* b1 = W1 + WSZ;
+        const float* Wq = p;            const float* bq = Wq + MAP_WSZ;
+        const float* Wk = bq + TD;      const float* bk = Wk + MAP_WSZ;
+        const float* Wv = bk + TD;      const float* bv = Wv + MAP_WSZ;
+        const float* Wm = bv + MD;      const float* bm = Wm + MAP_WSZ;
+        const float* W0 = bm + MD;      const float* b0 = W0 + MAP_WSZ;
+        const float* W1 = b0 + MD;      const float* b1 = W1 + MAP_WSZ;
         p = b1 + MD;
+        FcW fq, fk, fv, fm, f0, f1;
+        load_fc_row(fq, Wq, bq, true, T);            // 1/sqrt(D) and the positional term are folded into Wq / bq
+        load_fc_row(fk, Wk, bk, true, T);
+        load_fc_row(fv, Wv, bv, false, T);
+        load_fc_row(fm, Wm, bm, false, T);
+        load_fc_row(f0, W0, b0, false, T);
+        load_fc_row(f1, W1, b1, false, T);
         float* svl = SAVE ? sv + ms.llayer(l) : nullptr;
-        const int TD = T * MD;
-        for (int i = tid; i < T * MD; i += blockDim.x) Xin[i] = X[i];
-        fc_rows(Q, X, Wq, bq, true, T);          // 1/sqrt(D) and the positional term are folded into Wq / bq
-        fc_rows(K, X, Wk, bk, true, T);
-        fc_rows(V, X, Wv, bv, false, T);
+        for (int i = tid; i < TD; i += MAP_BLOCK) Xin[i] = X[i];
+        fc_apply<true>(X, fq, T, [&](int i, int, float v) { Q[i] = v; if (SAVE) svl[i] = v; });
+        fc_apply<true>(X, fk, T, [&](int i, int, float v) { K[i] = v; if (SAVE) svl[TD + i] = v; });
+        fc_apply<true>(X, fv, T, [&](int i, int, float v) { V[i] = v; if (SAVE) svl[2 * TD + i] = v; });
         __syncthreads();
-        if (SAVE)
-            for (int i = tid; i < TD; i += blockDim.x) { svl[i] = Q[i]; svl[TD + i] = K[i]; svl[2 * TD + i] = V[i]; }
-        for (int idx = tid; idx < T * T; idx += blockDim.x) {
+        for (int idx = tid; idx < T * T; idx += MAP_BLOCK) {
             const int a = idx / T, b = idx % T;
             float acc = 0.f;
 #pragma unroll
@@ -294,173 +349,116 @@ __device__ void mapping_forward_body(MapShared& sh, float* w_n, const float* zn,
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < T * MD; idx += blockDim.x) {
+        for (int idx = tid; idx < TD; idx += MAP_BLOCK) {
             const int a = idx / MD, o = idx % MD;
             float acc = 0.f;
             for (int b = 0; b < T; ++b) acc += Pr[a * MT_MAX + b] * V[b * MD + o];
             H[idx] = acc;
         }
         __syncthreads();
-        fc_rows(Q, H, Wm, bm, false, T);
+        fc_apply<true>(H, fm, T, [&](int i, int, float v) { X[i] += v; });                   // integration 'add'
         __syncthreads();
-        for (int i = tid; i < T * MD; i += blockDim.x) X[i] += Q[i];        // integration 'add'
+        fc_apply<true>(X, f0, T, [&](int i, int, float v) {
+            const float h = lrelu02(v) * MAP_SQ2;
+            H[i] = h;
+            if (SAVE) svl[3 * TD + i] = h;
+        });
         __syncthreads();
-        fc_rows(H, X, W0, b0, false, T);
-        __syncthreads();
-        for (int i = tid; i < T * MD; i += blockDim.x) {
-            H[i] = lrelu02(H[i]) * 1.41421356237309515f;
-            if (SAVE) svl[3 * TD + i] = H[i];
-        }
-        __syncthreads();
-        fc_rows(Q, H, W1, b1, false, T);
-        __syncthreads();
-        for (int i = tid; i < T * MD; i += blockDim.x) {
-            X[i] = lrelu02(Q[i] + Xin[i]);
-            if (SAVE) svl[4 * TD + i] = X[i];
-        }
+        fc_apply<true>(H, f1, T, [&](int i, int, float v) {
+            const float x = lrelu02(v + Xin[i]);
+            X[i] = x;
+            if (SAVE) svl[4 * TD + i] = x;
+        });
         __syncthreads();
     }
     {
-        const float *Wo = p, *bo = p + WSZ;
-        fc_rows(H, X, Wo, bo, false, T);
-        __syncthreads();
-        for (int i = tid; i < T * MD; i += blockDim.x) w_n[i] = lrelu02(H[i]) * 1.41421356237309515f;
+        const float *Wo = p, *bo = p + MAP_WSZ;
+        FcW fo;
+        load_fc_row(fo, Wo, bo, false, T);
+        fc_apply<true>(X, fo, T, [&](int i, int, float v) {
+            const float w = lrelu02(v) * MAP_SQ2;
+            w_n[i] = w;
+            if (w_copy) w_copy[i] = w;
+        });
     }
 }
 
-__global__ __launch_bounds__(256) void mapping_kernel(float* w, const float* z, const float* P, int k, int n_res, int normalize_global) {
+__global__ __launch_bounds__(MAP_BLOCK) void mapping_kernel(float* w, const float* z, const float* P, int k, int n_res, int normalize_global) {
     __shared__ MapShared sh;
     const int n = blockIdx.x;
-    mapping_forward_body<false>(sh, w + (int64_t)n * k * MD, z + (int64_t)n * k * MD, P, k, n_res, normalize_global, nullptr, nullptr);
+    float* wn = w + (int64_t)n * k * MD;
+    const float* zn = z + (int64_t)n * k * MD;
+    if (blockIdx.y) mapping_forward_global<false>(sh, wn, nullptr, zn, P, k, n_res, normalize_global, nullptr, nullptr);
+    else mapping_forward_local<false>(sh, wn, nullptr, zn, P, k, n_res, nullptr, nullptr);
+}
+
+// The forward with its per-layer activations kept in the backward kernel's scratch slab, so that the backward need not recompute
+// it.  Scratch slab: [MapSave::total() activations][k*D copy of w][2 normalisation factors].
+__global__ __launch_bounds__(MAP_BLOCK) void mapping_save_kernel(float* w, const float* z, const float* P, float* scratch, int64_t slab,
+                                                                 int k, int n_res, int normalize_global) {
+    __shared__ MapShared sh;
+    const int n = blockIdx.x;
+    const MapSave ms{k - 1, n_res};
+    float* sv = scratch + (int64_t)n * slab;
+    float* wrec = sv + ms.total();
+    float* nrm = wrec + (int64_t)k * MD;
+    float* wn = w + (int64_t)n * k * MD;
+    const float* zn = z + (int64_t)n * k * MD;
+    if (blockIdx.y) mapping_forward_global<true>(sh, wn, wrec, zn, P, k, n_res, normalize_global, sv, nrm);
+    else mapping_forward_local<true>(sh, wn, wrec, zn, P, k, n_res, sv, nrm);
 }
 
 __device__ __forceinline__ float dlrelu02(float y) { return y > 0.f ? 1.f : 0.2f; }
 
-// dz from dw: the forward is recomputed with SAVE into this sample's scratch slab, then the layers are walked in reverse.
-// Scratch slab: [MapSave::total() activations][k*D recomputed w][2 normalisation factors].
-__global__ __launch_bounds__(256) void mapping_backward_kernel(float* dz, const float* dw, const float* z, const float* P, float* scratch,
-                                                               int64_t slab, int k, int n_res, int normalize_global) {
-    __shared__ MapShared sh;
-    __shared__ float dX[MT_MAX * MD], A[MT_MAX * MD];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int T = k - 1, TD = T * MD, WSZ = MD * MD;
-    const MapSave ms{T, n_res};
-    float* sv = scratch + (int64_t)n * slab;
-    float* wrec = sv + ms.total();
-    float* nrm = wrec + (int64_t)k * MD;
-    const float* zn = z + (int64_t)n * k * MD;
-    const float* dwn = dw + (int64_t)n * k * MD;
-    float* dzn = dz + (int64_t)n * k * MD;
-    mapping_forward_body<true>(sh, wrec, zn, P, k, n_res, normalize_global, sv, nrm);
-    __syncthreads();                                 // the slab was written by this workgroup: visible after the barrier
-    const float SQ2 = 1.41421356237309515f;
-    const int64_t gstride = 2 * WSZ + 2 * MD;
-    const float* Pg_out = P + n_res * gstride;
-    const float* Pl = Pg_out + WSZ + MD;
-    const int64_t lstride = 6 * (int64_t)WSZ + 2 * (int64_t)TD + 4 * MD;
-    const float* Pl_out = Pl + n_res * lstride;
-    float *B = sh.H, *Cx = sh.X, *Dh = sh.Xin, *dQ = sh.Q, *dK = sh.K, *dV = sh.V, *Pr = sh.Pr;
+struct MapBwdShared {
+    float dX[MT_MAX * MD], A[MT_MAX * MD], sQ[MT_MAX * MD], sK[MT_MAX * MD], sV[MT_MAX * MD], sP[MT_MAX * MT_MAX];
+};
 
-    // ---- local path ----
-    for (int i = tid; i < TD; i += blockDim.x) A[i] = dwn[i] * SQ2 * dlrelu02(wrec[i]);
+// Global path, backward: the 2 n_res + 1 transposed products in reverse, held by the groups as in the forward (product jj = 0 is
+// the out layer, then W1 and W0 of the res layers from the last to the first), each with the one saved activation its stage needs.
+__device__ __forceinline__ void mapping_backward_global(MapShared& sh, float* dzn, const float* dwn, const float* zn, const float* P, const float* sv,
+                                        const float* wrec, const float* nrm, int k, int n_res, int normalize_global) {
+    float *dG = sh.G, *tA = sh.Gin, *tB = sh.GH;
+    const int tid = threadIdx.x, g = tid / MD, o = tid & (MD - 1);
+    const int T = k - 1, TD = T * MD, nfc = 2 * n_res + 1;
+    const MapSave ms{T, n_res};
+    // product jj: its weight, and the saved activation whose lrelu slope multiplies what the stage hands on
+    auto fcw = [&](int jj) {
+        if (jj == 0) return P + n_res * MAP_GSTRIDE;
+        const int l = n_res - 1 - ((jj - 1) >> 1);
+        return P + l * MAP_GSTRIDE + ((jj - 1) & 1 ? 0 : MAP_WSZ + MD);                  // odd jj: W1, even: W0
+    };
+    auto aux = [&](int jj) {
+        if (jj == 0) return n_res > 0 ? sv[ms.glayer(n_res - 1) + MD + o] : 1.f;         // Xo of the last layer
+        const int l = n_res - 1 - ((jj - 1) >> 1);
+        if ((jj - 1) & 1) return l > 0 ? sv[ms.glayer(l - 1) + MD + o] : 1.f;            // after W0_l: Xo of layer l-1
+        return sv[ms.glayer(l) + o];                                                     // after W1_l: H0 of layer l
+    };
+    FcW s0, s1;
+    float a0 = 1.f, a1 = 1.f;
+    if (g < nfc) { load_fc_col(s0, fcw(g)); a0 = aux(g); }
+    if (g + 8 < nfc) { load_fc_col(s1, fcw(g + 8)); a1 = aux(g + 8); }
+    if (tid < MD) tA[tid] = dwn[TD + tid] * MAP_SQ2 * dlrelu02(wrec[TD + tid]);
     __syncthreads();
-    fc_rows_t(dX, A, Pl_out, T, false);              // through the out layer
-    __syncthreads();
-    for (int l = n_res - 1; l >= 0; --l) {
-        const float* p = Pl + l * lstride;
-        const float* Wq = p;            const float* bq = Wq + WSZ;
-        const float* Wk = bq + TD;      const float* bk = Wk + WSZ;
-        const float* Wv = bk + TD;      const float* bv = Wv + WSZ;
-        const float* Wm = bv + MD;      const float* bm = Wm + WSZ;
-        const float* W0 = bm + MD;      const float* b0 = W0 + WSZ;
-        const float* W1 = b0 + MD;
-        const float* svl = sv + ms.llayer(l);
-        const float *sQ = svl, *sK = svl + TD, *sV = svl + 2 * TD, *sH0 = svl + 3 * TD, *sXo = svl + 4 * TD, *sP = svl + 5 * TD;
-        for (int i = tid; i < TD; i += blockDim.x) A[i] = dX[i] * dlrelu02(sXo[i]);           // d(F1 + Xin)
-        __syncthreads();
-        fc_rows_t(B, A, W1, T, false);
-        __syncthreads();
-        for (int i = tid; i < TD; i += blockDim.x) B[i] *= SQ2 * dlrelu02(sH0[i]);
-        __syncthreads();
-        fc_rows_t(Cx, B, W0, T, false);              // dXs (= dM, and the direct path into X)
-        __syncthreads();
-        fc_rows_t(Dh, Cx, Wm, T, false);             // d(P V)
-        __syncthreads();
-        for (int idx = tid; idx < T * T; idx += blockDim.x) {
-            const int a = idx / T, b = idx % T;
-            float acc = 0.f;
-#pragma unroll
-            for (int o = 0; o < MD; ++o) acc += Dh[a * MD + o] * sV[b * MD + o];
-            Pr[a * MT_MAX + b] = acc;                // dP
-        }
-        for (int idx = tid; idx < TD; idx += blockDim.x) {
-            const int b = idx / MD, o = idx % MD;
-            float acc = 0.f;
-            for (int a = 0; a < T; ++a) acc += sP[a * T + b] * Dh[a * MD + o];
-            dV[idx] = acc;
-        }
-        __syncthreads();
-        if (tid < T) {
-            float pdp = 0.f;
-            for (int b = 0; b < T; ++b) pdp += sP[tid * T + b] * Pr[tid * MT_MAX + b];
-            for (int b = 0; b < T; ++b) Pr[tid * MT_MAX + b] = sP[tid * T + b] * (Pr[tid * MT_MAX + b] - pdp);     // dScores
-        }
-        __syncthreads();
-        for (int idx = tid; idx < TD; idx += blockDim.x) {
-            const int r = idx / MD, i = idx % MD;
-            float aq = 0.f, ak = 0.f;
-            for (int b = 0; b < T; ++b) {
-                aq += Pr[r * MT_MAX + b] * sK[b * MD + i];
-                ak += Pr[b * MT_MAX + r] * sQ[b * MD + i];
-            }
-            dQ[idx] = aq;
-            dK[idx] = ak;
-        }
-        __syncthreads();
-        for (int i = tid; i < TD; i += blockDim.x) dX[i] = Cx[i] + A[i];
-        __syncthreads();
-        fc_rows_t(dX, dQ, Wq, T, true);
-        __syncthreads();
-        fc_rows_t(dX, dK, Wk, T, true);
-        __syncthreads();
-        fc_rows_t(dX, dV, Wv, T, true);
-        __syncthreads();
-    }
-    // normalize backward: X0 = z * fl,  fl = rsqrt(mean z^2 + eps)  =>  dz = fl dX0 - z fl^3 <dX0, z> / (T D)
-    {
-        float part = 0.f;
-        for (int i = tid; i < TD; i += blockDim.x) part += dX[i] * zn[i];
-        part = wave_sum(part);
-        __syncthreads();
-        if ((tid & 63) == 0) sh.red[tid >> 6] = part;
-        __syncthreads();
-        const float dot = sh.red[0] + sh.red[1] + sh.red[2] + sh.red[3];
-        const float fl = nrm[0];
-        const float coef = fl * fl * fl * dot / (float)TD;
-        for (int i = tid; i < TD; i += blockDim.x) dzn[i] = fl * dX[i] - zn[i] * coef;
+    // stage 0: dG = tA . Wout; what the next stage reads (dG times the slope at the last layer's output) goes to tB
+    if (g == 0) {
+        const float v = fc_row1(tA, s0);
+        dG[o] = v;
+        tB[o] = v * dlrelu02(a0);
     }
     __syncthreads();
-    // ---- global path (one row) ----
-    float* dG = sh.G;
-    float* tA = sh.Gin;
-    float* tB = sh.GH;
-    if (tid < MD) tA[tid] = dwn[TD + tid] * SQ2 * dlrelu02(wrec[TD + tid]);
-    __syncthreads();
-    fc_rows_t(dG, tA, Pg_out, 1, false);
-    __syncthreads();
-    for (int l = n_res - 1; l >= 0; --l) {
-        const float* p = P + l * gstride;
-        const float *W0 = p, *b0 = p + WSZ, *W1 = b0 + MD;
-        const float* svl = sv + ms.glayer(l);
-        if (tid < MD) tA[tid] = dG[tid] * dlrelu02(svl[MD + tid]);
+    for (int l = n_res - 1, jj = 1; l >= 0; --l, jj += 2) {
+        if (g == (jj & 7)) {                         // tB through W1, times the slope at H0 -> tA
+            const float v = (jj >> 3) ? fc_row1(tB, s1) : fc_row1(tB, s0);
+            tA[o] = v * (MAP_SQ2 * dlrelu02((jj >> 3) ? a1 : a0));
+        }
         __syncthreads();
-        fc_rows_t(tB, tA, W1, 1, false);
-        __syncthreads();
-        if (tid < MD) tB[tid] *= SQ2 * dlrelu02(svl[tid]);
-        __syncthreads();
-        fc_rows_t(dG, tB, W0, 1, false);
-        __syncthreads();
-        if (tid < MD) dG[tid] += tA[tid];
+        const int j2 = jj + 1;
+        if (g == (j2 & 7)) {                         // tA through W0, plus the skip path (tB[o]: this lane's own element) -> dG
+            const float v = ((j2 >> 3) ? fc_row1(tA, s1) : fc_row1(tA, s0)) + tB[o];
+            dG[o] = v;
+            tB[o] = v * dlrelu02((j2 >> 3) ? a1 : a0);                                   // the previous layer's slope (1 at l = 0: unused)
+        }
         __syncthreads();
     }
     if (tid < 64) {
@@ -475,6 +473,144 @@ __global__ __launch_bounds__(256) void mapping_backward_kernel(float* dz, const 
                 dzn[TD + tid] = gv;
             }
         }
+    }
+}
+
+// Local path, backward.
+__device__ __forceinline__ void mapping_backward_local(MapShared& sh, MapBwdShared& bs, float* dzn, const float* dwn, const float* zn, const float* P,
+                                       const float* sv, const float* wrec, const float* nrm, int k, int n_res) {
+    const int tid = threadIdx.x;
+    const int T = k - 1, TD = T * MD;
+    const MapSave ms{T, n_res};
+    const int64_t lstride = map_lstride(T);
+    const float* Pl = map_local_params(P, n_res);
+    const float* Pl_out = Pl + n_res * lstride;
+    float *B = sh.H, *Cx = sh.X, *Dh = sh.Xin, *dQ = sh.Q, *dK = sh.K, *dV = sh.V, *Pr = sh.Pr;
+    float *dX = bs.dX, *A = bs.A, *sQ = bs.sQ, *sK = bs.sK, *sV = bs.sV, *sP = bs.sP;
+    {
+        FcW fo;
+        load_fc_col(fo, Pl_out);
+        for (int i = tid; i < TD; i += MAP_BLOCK) A[i] = dwn[i] * MAP_SQ2 * dlrelu02(wrec[i]);
+        __syncthreads();
+        fc_apply<false>(A, fo, T, [&](int i, int, float v) { dX[i] = v; });                   // through the out layer
+        __syncthreads();
+    }
+    for (int l = n_res - 1; l >= 0; --l) {
+        const float* p = Pl + l * lstride;
+        const float* Wq = p;            const float* bq = Wq + MAP_WSZ;
+        const float* Wk = bq + TD;      const float* bk = Wk + MAP_WSZ;
+        const float* Wv = bk + TD;      const float* bv = Wv + MAP_WSZ;
+        const float* Wm = bv + MD;      const float* bm = Wm + MAP_WSZ;
+        const float* W0 = bm + MD;      const float* b0 = W0 + MAP_WSZ;
+        const float* W1 = b0 + MD;
+        const float* svl = sv + ms.llayer(l);
+        // everything this layer reads from memory, issued together: six weight columns, and the saved activations (the two used
+        // element-wise stay in registers, the four used as matrices go to LDS)
+        FcW f1, f0, fm, fq, fk, fv;
+        load_fc_col(f1, W1); load_fc_col(f0, W0); load_fc_col(fm, Wm);
+        load_fc_col(fq, Wq); load_fc_col(fk, Wk); load_fc_col(fv, Wv);
+        float xo[MAP_PASSES], h0[MAP_PASSES];
+#pragma unroll
+        for (int j = 0; j < MAP_PASSES; ++j) {
+            const int i = tid + MAP_BLOCK * j;
+            const bool in = i < TD;
+            xo[j] = in ? svl[4 * TD + i] : 0.f;
+            h0[j] = in ? svl[3 * TD + i] : 0.f;
+            if (in) { sQ[i] = svl[i]; sK[i] = svl[TD + i]; sV[i] = svl[2 * TD + i]; }
+            if (i < T * T) sP[i] = svl[5 * TD + i];
+        }
+#pragma unroll
+        for (int j = 0; j < MAP_PASSES; ++j) {
+            const int i = tid + MAP_BLOCK * j;
+            if (i < TD) A[i] = dX[i] * dlrelu02(xo[j]);                                  // d(F1 + Xin)
+        }
+        __syncthreads();
+        fc_apply<false>(A, f1, T, [&](int i, int j, float v) { B[i] = v * (MAP_SQ2 * dlrelu02(h0[j])); });
+        __syncthreads();
+        fc_apply<false>(B, f0, T, [&](int i, int, float v) { Cx[i] = v; });                   // dXs (= dM, and the direct path into X)
+        __syncthreads();
+        fc_apply<false>(Cx, fm, T, [&](int i, int, float v) { Dh[i] = v; });                  // d(P V)
+        __syncthreads();
+        for (int idx = tid; idx < T * T; idx += MAP_BLOCK) {
+            const int a = idx / T, b = idx % T;
+            float acc = 0.f;
+#pragma unroll
+            for (int o = 0; o < MD; ++o) acc += Dh[a * MD + o] * sV[b * MD + o];
+            Pr[a * MT_MAX + b] = acc;                // dP
+        }
+        for (int idx = tid; idx < TD; idx += MAP_BLOCK) {
+            const int b = idx / MD, o = idx % MD;
+            float acc = 0.f;
+            for (int a = 0; a < T; ++a) acc += sP[a * T + b] * Dh[a * MD + o];
+            dV[idx] = acc;
+        }
+        __syncthreads();
+        if (tid < T) {
+            float pdp = 0.f;
+            for (int b = 0; b < T; ++b) pdp += sP[tid * T + b] * Pr[tid * MT_MAX + b];
+            for (int b = 0; b < T; ++b) Pr[tid * MT_MAX + b] = sP[tid * T + b] * (Pr[tid * MT_MAX + b] - pdp);     // dScores
+        }
+        __syncthreads();
+        for (int idx = tid; idx < TD; idx += MAP_BLOCK) {
+            const int r = idx / MD, i = idx % MD;
+            float aq = 0.f, ak = 0.f;
+            for (int b = 0; b < T; ++b) {
+                aq += Pr[r * MT_MAX + b] * sK[b * MD + i];
+                ak += Pr[b * MT_MAX + r] * sQ[b * MD + i];
+            }
+            dQ[idx] = aq;
+            dK[idx] = ak;
+        }
+        __syncthreads();
+        // dX = ((Cx + A) + dQ . Wq) + dK . Wk) + dV . Wv, each output by its own thread
+        float acc[MAP_PASSES];
+        fc_apply<false>(dQ, fq, T, [&](int i, int j, float v) { acc[j] = (Cx[i] + A[i]) + v; });
+        fc_apply<false>(dK, fk, T, [&](int, int j, float v) { acc[j] += v; });
+        fc_apply<false>(dV, fv, T, [&](int i, int j, float v) { dX[i] = acc[j] + v; });
+        __syncthreads();
+    }
+    // normalize backward: X0 = z * fl,  fl = rsqrt(mean z^2 + eps)  =>  dz = fl dX0 - z fl^3 <dX0, z> / (T D)
+    {
+        float part = 0.f;
+        for (int i = tid; i < TD; i += MAP_BLOCK) part += dX[i] * zn[i];
+        part = wave_sum(part);
+        if ((tid & 63) == 0) sh.red[tid >> 6] = part;
+        __syncthreads();
+        const float dot = sh.red[0] + sh.red[1] + sh.red[2] + sh.red[3];
+        const float fl = nrm[0];
+        const float coef = fl * fl * fl * dot / (float)TD;
+        for (int i = tid; i < TD; i += MAP_BLOCK) dzn[i] = fl * dX[i] - zn[i] * coef;
+    }
+}
+
+// dz from dw.  RECOMPUTE: the forward is run again with SAVE into this sample's scratch slab first; otherwise the slab is the one
+// mapping_save_kernel filled for the same z.  Two workgroups per sample, as in the forward.
+template <bool RECOMPUTE>
+__global__ __launch_bounds__(MAP_BLOCK) void mapping_backward_kernel(float* dz, const float* dw, const float* z, const float* P,
+                                                                     float* scratch, int64_t slab, int k, int n_res,
+                                                                     int normalize_global) {
+    __shared__ MapShared sh;
+    __shared__ MapBwdShared bs;
+    const int n = blockIdx.x;
+    const MapSave ms{k - 1, n_res};
+    float* sv = scratch + (int64_t)n * slab;
+    float* wrec = sv + ms.total();
+    float* nrm = wrec + (int64_t)k * MD;
+    const float* zn = z + (int64_t)n * k * MD;
+    const float* dwn = dw + (int64_t)n * k * MD;
+    float* dzn = dz + (int64_t)n * k * MD;
+    if (blockIdx.y) {
+        if (RECOMPUTE) {
+            mapping_forward_global<true>(sh, wrec, nullptr, zn, P, k, n_res, normalize_global, sv, nrm);
+            __syncthreads();                         // the slab was written by this workgroup: visible after the barrier
+        }
+        mapping_backward_global(sh, dzn, dwn, zn, P, sv, wrec, nrm, k, n_res, normalize_global);
+    } else {
+        if (RECOMPUTE) {
+            mapping_forward_local<true>(sh, wrec, nullptr, zn, P, k, n_res, sv, nrm);
+            __syncthreads();
+        }
+        mapping_backward_local(sh, bs, dzn, dwn, zn, P, sv, wrec, nrm, k, n_res);
     }
 }
 
@@ -549,9 +685,36 @@ extern "C" int mgf_mapping_backward(float* dz, const float* dw, const float* z, 
     MGF_REQUIRE(dim == MD, MGF_EUNSUPPORTED, "mapping_backward: latent width must be %d (got %d)", MD, dim);
     MGF_REQUIRE(k >= 2 && k - 1 <= MT_MAX, MGF_EUNSUPPORTED, "mapping_backward: k must be in 2..%d (got %d)", MT_MAX + 1, k);
     MGF_REQUIRE(n >= 1 && n_res_layers >= 0, MGF_EINVAL, "mapping_backward: bad sizes");
-    hipLaunchKernelGGL(mapping_backward_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dz, dw, z, params, scratch,
+    MGF_REQUIRE(n_res_layers <= MAP_MAX_RES, MGF_EUNSUPPORTED, "mapping_backward: at most %d residual layers (got %d)", MAP_MAX_RES, n_res_layers);
+    hipLaunchKernelGGL(mapping_backward_kernel<true>, dim3(n, 2), dim3(MAP_BLOCK), 0, (hipStream_t)stream, dz, dw, z, params, scratch,
                        mgf_mapping_bwd_scratch_floats(k, dim, n_res_layers), k, n_res_layers, normalize_global);
     MGF_CHECK_LAUNCH("mapping_backward");
+    return MGF_OK;
+}
+
+extern "C" int mgf_mapping_forward_save(float* w, const float* z, const float* params, float* scratch, int32_t n, int32_t k, int32_t dim,
+                                        int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream) {
+    MGF_REQUIRE(w && z && params && scratch, MGF_EINVAL, "mapping_forward_save: null pointer");
+    MGF_REQUIRE(dim == MD, MGF_EUNSUPPORTED, "mapping_forward_save: latent width must be %d (got %d)", MD, dim);
+    MGF_REQUIRE(k >= 2 && k - 1 <= MT_MAX, MGF_EUNSUPPORTED, "mapping_forward_save: k must be in 2..%d (got %d)", MT_MAX + 1, k);
+    MGF_REQUIRE(n >= 1 && n_res_layers >= 0, MGF_EINVAL, "mapping_forward_save: bad sizes");
+    MGF_REQUIRE(n_res_layers <= MAP_MAX_RES, MGF_EUNSUPPORTED, "mapping_forward_save: at most %d residual layers (got %d)", MAP_MAX_RES, n_res_layers);
+    hipLaunchKernelGGL(mapping_save_kernel, dim3(n, 2), dim3(MAP_BLOCK), 0, (hipStream_t)stream, w, z, params, scratch,
+                       mgf_mapping_bwd_scratch_floats(k, dim, n_res_layers), k, n_res_layers, normalize_global);
+    MGF_CHECK_LAUNCH("mapping_forward_save");
+    return MGF_OK;
+}
+
+extern "C" int mgf_mapping_backward_saved(float* dz, const float* dw, const float* z, const float* params, float* scratch, int32_t n,
+                                          int32_t k, int32_t dim, int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream) {
+    MGF_REQUIRE(dz && dw && z && params && scratch, MGF_EINVAL, "mapping_backward_saved: null pointer");
+    MGF_REQUIRE(dim == MD, MGF_EUNSUPPORTED, "mapping_backward_saved: latent width must be %d (got %d)", MD, dim);
+    MGF_REQUIRE(k >= 2 && k - 1 <= MT_MAX, MGF_EUNSUPPORTED, "mapping_backward_saved: k must be in 2..%d (got %d)", MT_MAX + 1, k);
+    MGF_REQUIRE(n >= 1 && n_res_layers >= 0, MGF_EINVAL, "mapping_backward_saved: bad sizes");
+    MGF_REQUIRE(n_res_layers <= MAP_MAX_RES, MGF_EUNSUPPORTED, "mapping_backward_saved: at most %d residual layers (got %d)", MAP_MAX_RES, n_res_layers);
+    hipLaunchKernelGGL(mapping_backward_kernel<false>, dim3(n, 2), dim3(MAP_BLOCK), 0, (hipStream_t)stream, dz, dw, z, params, scratch,
+                       mgf_mapping_bwd_scratch_floats(k, dim, n_res_layers), k, n_res_layers, normalize_global);
+    MGF_CHECK_LAUNCH("mapping_backward_saved");
     return MGF_OK;
 }
 
@@ -561,7 +724,8 @@ extern "C" int mgf_mapping_forward(float* w, const float* z, const float* params
     MGF_REQUIRE(dim == MD, MGF_EUNSUPPORTED, "mapping_forward: latent width must be %d (got %d)", MD, dim);
     MGF_REQUIRE(k >= 2 && k - 1 <= MT_MAX, MGF_EUNSUPPORTED, "mapping_forward: k must be in 2..%d (got %d)", MT_MAX + 1, k);
     MGF_REQUIRE(n >= 1 && n_res_layers >= 0, MGF_EINVAL, "mapping_forward: bad sizes");
-    hipLaunchKernelGGL(mapping_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, w, z, params, k, n_res_layers, normalize_global);
+    MGF_REQUIRE(n_res_layers <= MAP_MAX_RES, MGF_EUNSUPPORTED, "mapping_forward: at most %d residual layers (got %d)", MAP_MAX_RES, n_res_layers);
+    hipLaunchKernelGGL(mapping_kernel, dim3(n, 2), dim3(MAP_BLOCK), 0, (hipStream_t)stream, w, z, params, k, n_res_layers, normalize_global);
     MGF_CHECK_LAUNCH("mapping_forward");
     return MGF_OK;
 }

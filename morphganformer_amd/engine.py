@@ -390,9 +390,15 @@ class Generator:
         if n != self.n:
             self._alloc(n)
         z = z.contiguous().float()
-        rc = _lib.lib().mgf_mapping_forward(self.w_buf.data_ptr(), z.data_ptr(), self.plan.mapping_blob.data_ptr(), n,
-                                            self.cfg.k, self.cfg.w_dim, self.cfg.mapping_layers // 2,
-                                            int(self.cfg.normalize_global), _lib.stream_ptr())
+        save = getattr(self, "map_save", None)       # gradient mode (grad.GeneratorGrad) keeps the mapping activations for its backward
+        if save is not None:
+            rc = _lib.lib().mgf_mapping_forward_save(self.w_buf.data_ptr(), z.data_ptr(), self.plan.mapping_blob.data_ptr(),
+                                                     save.data_ptr(), n, self.cfg.k, self.cfg.w_dim, self.cfg.mapping_layers // 2,
+                                                     int(self.cfg.normalize_global), _lib.stream_ptr())
+        else:
+            rc = _lib.lib().mgf_mapping_forward(self.w_buf.data_ptr(), z.data_ptr(), self.plan.mapping_blob.data_ptr(), n,
+                                                self.cfg.k, self.cfg.w_dim, self.cfg.mapping_layers // 2,
+                                                int(self.cfg.normalize_global), _lib.stream_ptr())
         _lib.check(rc, "mapping_forward")
         return self.w_buf
 

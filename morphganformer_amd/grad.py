@@ -48,6 +48,7 @@ class GeneratorGrad:
                 self.Tw[lp.name] = cv.winograd_pack(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), 1.0, lp.res)
         self._bufs = {}
         self._n = None
+        self.map_scratch = None
         self.z = None
         self.psi = 1.0
         self.debug = None                 # dict -> clones of the intermediate gradients (tests / tools only)
@@ -96,7 +97,6 @@ class GeneratorGrad:
         self.dyc = e(n, max(len(aj), 1), T, D)
         self.dw = e(n, cfg.k, D)
         self.dz = e(n, cfg.k, D)
-        self.map_scratch = e(n * int(L.mgf_mapping_bwd_scratch_floats(cfg.k, D, cfg.mapping_layers // 2)))
         self.max_channels = max(max(lp.cin, lp.cout) for lp in P.layers)
 
     # ------------------------------------------------------------------ forward
@@ -111,6 +111,12 @@ class GeneratorGrad:
             w = (ws[:, :, 0] if ws.ndim == 4 else ws).contiguous().float()
         # the backward pass reads conv_last's activation and the full-resolution skip tensors: both fusions off for this forward
         G.fuse_torgb, keep_up, G.fuse_skip_up = False, G.fuse_skip_up, False
+        if z is not None:
+            # the mapping network's activations are kept for backward() (mgf_mapping_backward_saved) rather than recomputed there
+            need = z.shape[0] * int(_lib.lib().mgf_mapping_bwd_scratch_floats(G.cfg.k, G.cfg.w_dim, G.cfg.mapping_layers // 2))
+            if self.map_scratch is None or self.map_scratch.numel() != need:
+                self.map_scratch = torch.empty(need, device=G.device, dtype=torch.float32)
+            G.map_save = self.map_scratch
         try:
             if ws is not None:
                 if w.shape[0] != G.n:
@@ -119,7 +125,7 @@ class GeneratorGrad:
             else:
                 img = G.forward_workspace(z, None, truncation_psi=truncation_psi, noise_mode=noise_mode, noises=noises)[0]
         finally:
-            G.fuse_torgb, G.fuse_skip_up = True, keep_up
+            G.fuse_torgb, G.fuse_skip_up, G.map_save = True, keep_up, None
         self.z = None if z is None else z.contiguous().float()
         self.psi = float(truncation_psi) if ws is None else 1.0
         if self._n != G.n:            # after G: its style / demod arenas (pointed to by the job tables) are sized by then
@@ -282,7 +288,7 @@ class GeneratorGrad:
         G, cfg, L = self.G, self.G.cfg, _lib.lib()
         assert self.z is not None, "forward() was called with ws=...: use backward_w"
         dw = self.backward_w(dimg)
-        _lib.check(L.mgf_mapping_backward(self.dz.data_ptr(), dw.data_ptr(), self.z.data_ptr(), G.plan.mapping_blob.data_ptr(),
+        _lib.check(L.mgf_mapping_backward_saved(self.dz.data_ptr(), dw.data_ptr(), self.z.data_ptr(), G.plan.mapping_blob.data_ptr(),
                                           self.map_scratch.data_ptr(), G.n, cfg.k, cfg.w_dim, cfg.mapping_layers // 2,
-                                          int(cfg.normalize_global), _lib.stream_ptr()), "mapping_backward")
+                                          int(cfg.normalize_global), _lib.stream_ptr()), "mapping_backward_saved")
         return self.dz

@@ -46,6 +46,46 @@ def test_mapping_backward_matches_autograd(tiny):
     _lib.check(L.mgf_mapping_backward(dz.data_ptr(), dwc.data_ptr(), zc.data_ptr(), gg.G.plan.mapping_blob.data_ptr(), scratch.data_ptr(),
                                       3, cfg.k, cfg.w_dim, cfg.mapping_layers // 2, int(cfg.normalize_global), _lib.stream_ptr()))
     assert rel(dz, ref) < GRAD_TOL
+    # the saving forward + the backward that reads its slab: the same w as the plain forward and the same dz, bit for bit
+    scratch2 = torch.full_like(scratch, float("nan"))
+    w0, w1, dz2 = torch.empty_like(zc), torch.empty_like(zc), torch.empty_like(zc)
+    margs = (3, cfg.k, cfg.w_dim, cfg.mapping_layers // 2, int(cfg.normalize_global), _lib.stream_ptr())
+    _lib.check(L.mgf_mapping_forward(w0.data_ptr(), zc.data_ptr(), gg.G.plan.mapping_blob.data_ptr(), *margs))
+    _lib.check(L.mgf_mapping_forward_save(w1.data_ptr(), zc.data_ptr(), gg.G.plan.mapping_blob.data_ptr(), scratch2.data_ptr(), *margs))
+    _lib.check(L.mgf_mapping_backward_saved(dz2.data_ptr(), dwc.data_ptr(), zc.data_ptr(), gg.G.plan.mapping_blob.data_ptr(),
+                                            scratch2.data_ptr(), *margs))
+    assert torch.equal(w0, w1) and torch.equal(dz, dz2)
+
+
+@pytest.mark.parametrize("k,layers", [(6, 4), (12, 14), (33, 2), (2, 0)])
+def test_mapping_forward_and_backward_other_shapes(k, layers):
+    """Component counts that leave the last pass of the [T x D] products ragged (T = 5, 11), the largest T (32), the smallest
+    (1), and residual-layer counts that fill one / both register sets of the global path's groups (2 n_res + 1 = 5, 15, 3, 1)."""
+    import dataclasses
+    from morphganformer_amd import _lib
+    from morphganformer_amd.engine import pack_mapping_params
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from oracle.generator_ref import mapping_ref, to_torch_state
+    cfg = dataclasses.replace(TINY, k=k, mapping_layers=layers)
+    sd = make_state_dict(cfg, seed=3)
+    blob = torch.from_numpy(pack_mapping_params(sd, cfg)).cuda()
+    torch.manual_seed(k)
+    z = torch.randn(2, k, cfg.z_dim, requires_grad=True)
+    dw = torch.randn(2, k, cfg.w_dim)
+    w_ref = mapping_ref(to_torch_state(sd), z, cfg)
+    (dz_ref,) = torch.autograd.grad(w_ref, z, dw)
+    L = _lib.lib()
+    zc, dwc = z.detach().cuda(), dw.cuda()
+    w0, w1, dz0, dz1 = (torch.empty_like(zc) for _ in range(4))
+    scr = [torch.full((2 * int(L.mgf_mapping_bwd_scratch_floats(k, cfg.w_dim, layers // 2)),), float("nan"), device="cuda") for _ in range(2)]
+    margs = (2, k, cfg.w_dim, layers // 2, int(cfg.normalize_global), _lib.stream_ptr())
+    _lib.check(L.mgf_mapping_forward(w0.data_ptr(), zc.data_ptr(), blob.data_ptr(), *margs))
+    _lib.check(L.mgf_mapping_forward_save(w1.data_ptr(), zc.data_ptr(), blob.data_ptr(), scr[0].data_ptr(), *margs))
+    _lib.check(L.mgf_mapping_backward_saved(dz0.data_ptr(), dwc.data_ptr(), zc.data_ptr(), blob.data_ptr(), scr[0].data_ptr(), *margs))
+    _lib.check(L.mgf_mapping_backward(dz1.data_ptr(), dwc.data_ptr(), zc.data_ptr(), blob.data_ptr(), scr[1].data_ptr(), *margs))
+    assert rel(w0, w_ref) < 1e-5 and torch.equal(w0, w1)
+    assert rel(dz0, dz_ref) < GRAD_TOL and torch.equal(dz0, dz1)
+    assert L.mgf_mapping_forward(w0.data_ptr(), zc.data_ptr(), blob.data_ptr(), 2, k, cfg.w_dim, 8, 1, _lib.stream_ptr()) != 0      # > 7 res layers
 
 
 def test_layer_act_bwd_and_dots():
