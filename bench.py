@@ -186,6 +186,34 @@ def generator_leg(eng, iters=3):
             "frac_of_fp32_mfma_peak": round(gf / ms / FP32_MFMA_PEAK_TFLOPS, 4), "images_per_forward": eng.batch}
 
 
+def gradient_roofline(ge):
+    """One eager forward + LPIPS + backward of a gradient-mode engine with every MFMA conv launch (forward and dgrad) bracketed by
+    HIP events inside the library, as in roofline_leg: the dominant kernel, its algorithmic TFLOP/s and fraction of the FP32-MFMA peak."""
+    from morphganformer_amd import conv as cv
+    cv.profile_begin()
+    img = ge.gg.forward(ge.latent_n, noise_mode="random")
+    ge.percept.distance_into(ge.p_loss, img, keep_taps=True)
+    ge.percept.grad_into(ge.dimg, scale=1.0, accumulate=False)
+    ge.gg.backward(ge.dimg)
+    torch.cuda.synchronize()
+    agg = {}
+    for kernel, flops, secs, ksplit, nbytes in cv.profile_end():
+        a = agg.setdefault(kernel, [0.0, 0.0, 0])
+        a[0] += flops
+        a[1] += secs
+        a[2] += 1
+    dom = max(agg, key=lambda k_: agg[k_][1])
+    flops, secs, launches = agg[dom]
+    achieved = flops / secs / 1e12
+    conv_s = sum(v[1] for v in agg.values())
+    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "executed_mfma_frac": round(achieved * (16 / 36 if dom.startswith("wino") else 1.0) / FP32_MFMA_PEAK_TFLOPS, 4),
+            "launches_per_step": launches, "avg_launch_us": round(secs / launches * 1e6, 2),
+            "conv_ms_per_step": round(conv_s * 1e3, 3),
+            "all_convs_tflops": round(sum(v[0] for v in agg.values()) / conv_s / 1e12, 2)}
+
+
 def gradient_leg(sd, cfg, device, eng, steps, lockstep=8):
     """Extra (not the headline metric): the same objective with the loss back-propagated into the latent and Adam moving it
     (projection.GradientProjectionEngine) -- one candidate per step, forward + LPIPS + backward + Adam as one hipGraph."""
@@ -216,6 +244,7 @@ def gradient_leg(sd, cfg, device, eng, steps, lockstep=8):
     ev[3].record()
     torch.cuda.synchronize()
     conv_gf = cfg.conv_gflop()
+    roof = gradient_roofline(ge)
     # B independent targets advanced in lockstep through one generator forward/backward per step
     lock = None
     if lockstep > 1:
@@ -238,11 +267,14 @@ def gradient_leg(sd, cfg, device, eng, steps, lockstep=8):
         gb.run(steps)
         torch.cuda.synchronize()
         dtb = time.perf_counter() - t0
-        lock = {"targets": B, "value": round(B * steps / dtb, 2), "unit": "iters/s (all targets)", "ms_per_step": round(dtb / steps * 1e3, 3)}
+        lock = {"targets": B, "value": round(B * steps / dtb, 2), "unit": "iters/s (all targets)", "ms_per_step": round(dtb / steps * 1e3, 3),
+                "step_tflops": round(2 * conv_gf * B * steps / dtb / 1e3, 2), "roofline": gradient_roofline(gb)}
     return {"value": round(steps / dt, 2), "unit": "iters/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
             "candidates_per_step": 1, "lockstep": lock, "generator_forward_ms": round(ev[0].elapsed_time(ev[1]), 3),
             "lpips_forward_backward_ms": round(ev[1].elapsed_time(ev[2]), 3), "generator_backward_ms": round(ev[2].elapsed_time(ev[3]), 3),
             "conv_gflop_forward_plus_dgrad": round(2 * conv_gf, 1),
+            "generator_forward_frac_of_fp32_mfma_peak": round(conv_gf / ev[0].elapsed_time(ev[1]) / FP32_MFMA_PEAK_TFLOPS, 4),
+            "step_tflops": round(2 * conv_gf * steps / dt / 1e3, 2), "roofline": roof,
             "note": "loss back-propagated into the latent (grad.GeneratorGrad + LPIPS backward + Adam), hipGraph replay; "
                     "the reference loop severs this gradient, so the headline metric stays the literal loop"}
 

@@ -408,10 +408,12 @@ int mgf_style_grad_f32(float* dot_part, float* dx, const float* x, const float* 
 /* mgf_style_grad_f32 of a layer fused with mgf_layer_act_bwd_f32 of the layer BEFORE it, whose output y is this layer's input x (conv1 ->
  * conv0 of a SynthesisBlock; the earlier layer must have no residual): style_part = <x, g> per (n, c, chunk), dz = (s g) gain
  * (x > 0 ? 1 : alpha), dot_part (may be NULL) = <dz, c> as in mgf_layer_act_bwd_f32 -- bit-identical to the two calls in sequence,
- * without the intermediate s g ever reaching memory. */
-int mgf_style_grad_act_bwd_f32(float* style_part, float* dot_part, float* dz, const float* x, const float* g, const float* s,
-                               const float* bias, const float* noise, const float* noise_strength, int32_t noise_n, int32_t n, int32_t c,
-                               int64_t hw, float alpha, float gain, mgf_stream_t stream);
+ * without the intermediate s g ever reaching memory.  `residual` and `dx` (both or neither) cover an earlier layer WITH a residual
+ * (conv_last -> conv1 of the last block): the activation is inverted on x - residual and s g is also written to dx, which the block's
+ * skip branch reads. */
+int mgf_style_grad_act_bwd_f32(float* style_part, float* dot_part, float* dz, float* dx, const float* x, const float* g, const float* s,
+                               const float* residual, const float* bias, const float* noise, const float* noise_strength, int32_t noise_n,
+                               int32_t n, int32_t c, int64_t hw, float alpha, float gain, mgf_stream_t stream);
 /* Backward of mgf_duplex_attention without its epilogue (apply mgf_layer_act_bwd_f32 first), same operands as the forward:
  *   dx[n,c,f]    gradient with respect to the attention input x
  *   dg[n,c,f]    = da * x * rsqrt(mean_c x^2 + 1e-8), scratch consumed by mgf_attn_values_grad (may be NULL)
@@ -474,6 +476,12 @@ int mgf_mapping_backward_saved(float* dz, const float* dw, const float* z, const
  *   mse_grad:          d (+)= scale * 2 (a - b) / numel, operands as mgf_mse_f32 */
 int mgf_lpips_layer_bwd_f32(float* df0, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c, int64_t hw,
                             int64_t f1_batch_stride, float scale, int32_t accumulate, mgf_stream_t stream);
+/* mgf_lpips_layer_bwd_f32 followed by mgf_relu_bwd_split_f32 on the same tap (every LPIPS tap is a ReLU output f0) in one pass:
+ * dz = f0 > 0 ? dy + d/df0[...] : 0 with dy the gradient arriving from the layers behind the tap (NULL: none), split like
+ * relu_bwd_split (dz_b NULL with c_split == c: no split; dz_a == dy: in place). */
+int mgf_lpips_layer_bwd_relu_f32(float* dz_a, float* dz_b, const float* dy, const float* f0, const float* f1_unit, const float* lin,
+                                 int32_t n, int32_t c, int32_t c_split, int64_t hw, int64_t f1_batch_stride, float scale,
+                                 mgf_stream_t stream);
 int mgf_relu_bwd_split_f32(float* dz_a, float* dz_b, const float* dy, const float* y, int32_t n, int32_t c, int32_t c_split, int64_t hw,
                            mgf_stream_t stream);
 int mgf_maxpool3x3s2_ceil_bwd_f32(float* dx, const float* dy, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h,

@@ -110,7 +110,7 @@ _SIGS = {
     "mgf_layer_act_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, f32, f32, vp]),
     "mgf_channel_dot_f32": (C.c_int, [vp, vp, vp, i32, i32, i64, vp]),
     "mgf_style_grad_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, i32, vp]),
-    "mgf_style_grad_act_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, f32, f32, vp]),
+    "mgf_style_grad_act_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, f32, f32, vp]),
     "mgf_duplex_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mgf_attn_values_grad": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "mgf_attn_values_grad_workspace_floats": (C.c_int64, [i32, i32]),
@@ -119,6 +119,7 @@ _SIGS = {
     "mgf_attn_values_bwd_multi": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mgf_latent_grad_gather": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, i32, f32, vp]),
     "mgf_lpips_layer_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i64, i64, f32, i32, vp]),
+    "mgf_lpips_layer_bwd_relu_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, f32, vp]),
     "mgf_relu_bwd_split_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i64, vp]),
     "mgf_maxpool3x3s2_ceil_bwd_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mgf_maxpool_s2_floor_bwd_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -687,9 +687,13 @@ __global__ __launch_bounds__(256) void latent_grad_gather_kernel(float* dw, cons
 // One lane per pixel, two sweeps over the channels:  A = sum f0^2, B = sum lin f0^2, Cc = sum lin u1 f0  give
 //   <du0, f0> = k (q B - Cc),   df0[c] = q k lin[c] (f0[c] q - u1[c]) - <du0, f0> q^2 / |f0| * f0[c],   k = 2 scale / hw.
 // An all-zero pixel (|f0| = 0) gets a zero gradient (torch autograd yields NaN there: sqrt'(0) * 0).
-template <int PXB>
-__global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* df0, const float* f0, const float* f1u, const float* lin, int c,
-                                                              int64_t hw, int64_t f1_bs, float k, int accumulate) {
+// RELU: the tap is a ReLU output (all of them are) and the ReLU's backward rides along: dz = f0 > 0 ? din + df0 : 0 (din may be
+// null), channels [0, c_split) to oa [n, c_split, hw], the rest to ob [n, c - c_split, hw] (mgf_relu_bwd_split_f32's layout); without
+// RELU oa is df0 [n, c, hw] and `accumulate` adds to it.
+template <int PXB, bool RELU>
+__global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* oa, float* ob, const float* din, const float* f0, const float* f1u,
+                                                              const float* lin, int c, int c_split, int64_t hw, int64_t f1_bs, float k,
+                                                              int accumulate) {
     // a workgroup owns PXB consecutive pixels; its G = 256 / PXB lane groups split the channels and meet in LDS
     constexpr int G = 256 / PXB;
     __shared__ float part[3][G][PXB];
@@ -699,7 +703,6 @@ __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* df0, const 
     const int64_t pc = valid ? p : hw - 1;
     const float* a = f0 + (int64_t)n * c * hw + pc;
     const float* b = f1u + (int64_t)n * f1_bs + pc;
-    float* o = df0 + (int64_t)n * c * hw + pc;
     float A = 0.f, B = 0.f, Cc = 0.f;
 #pragma unroll 4
     for (int ch = grp; ch < c; ch += G) {
@@ -718,11 +721,27 @@ __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* df0, const 
     const float dot = k * (q * B - Cc);
     const float coef = nrm > 0.f ? dot * q * q / nrm : 0.f;
     if (!valid) return;
+    if (RELU) {
+        const float* di = din ? din + (int64_t)n * c * hw + pc : nullptr;
+        float* da = oa + (int64_t)n * c_split * hw + pc;
+        float* db = ob ? ob + (int64_t)n * (c - c_split) * hw + pc : nullptr;
 #pragma unroll 4
-    for (int ch = grp; ch < c; ch += G) {
-        const float v = a[(int64_t)ch * hw];
-        const float g = q * k * lin[ch] * (v * q - b[(int64_t)ch * hw]) - coef * v;
-        o[(int64_t)ch * hw] = accumulate ? o[(int64_t)ch * hw] + g : g;
+        for (int ch = grp; ch < c; ch += G) {
+            const float v = a[(int64_t)ch * hw];
+            float g = q * k * lin[ch] * (v * q - b[(int64_t)ch * hw]) - coef * v;
+            if (di) g = di[(int64_t)ch * hw] + g;
+            g = v > 0.f ? g : 0.f;
+            if (ch < c_split) da[(int64_t)ch * hw] = g;
+            else db[(int64_t)(ch - c_split) * hw] = g;
+        }
+    } else {
+        float* o = oa + (int64_t)n * c * hw + pc;
+#pragma unroll 4
+        for (int ch = grp; ch < c; ch += G) {
+            const float v = a[(int64_t)ch * hw];
+            const float g = q * k * lin[ch] * (v * q - b[(int64_t)ch * hw]) - coef * v;
+            o[(int64_t)ch * hw] = accumulate ? o[(int64_t)ch * hw] + g : g;
+        }
     }
 }
 
@@ -914,14 +933,16 @@ extern "C" int mgf_style_grad_f32(float* dot_part, float* dx, const float* x, co
 // part_dc is given,  part_dc = <dz, c>  with c recovered by inverting the activation -- exactly the arithmetic of the two kernels run one
 // after the other (d is rounded to float32 before it is used), at 3 tensor passes instead of 6.  Layer L must have no residual.
 struct StyleActParams {
-    float* part_s; float* part_dc; float* dz;
-    const float* x; const float* g; const float* s; const float* bias; const float* noise; const float* nstr;
+    float* part_s; float* part_dc; float* dz; float* dx;
+    const float* x; const float* g; const float* s; const float* res; const float* bias; const float* noise; const float* nstr;
     int noise_n, c, nchunk;
     int64_t hw;
     float alpha, gain;
 };
 namespace {
-template <bool VEC>
+// RES: the earlier layer's output carries a residual (x = lrelu(..) gain + res: the activation is inverted on x - res) and s g is
+// also stored (dx: the block's skip branch reads it).
+template <bool VEC, bool RES>
 __global__ __launch_bounds__(256) void style_grad_act_bwd_kernel(StyleActParams p) {
     __shared__ float red[4];
     const int chunk = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
@@ -934,12 +955,13 @@ __global__ __launch_bounds__(256) void style_grad_act_bwd_kernel(StyleActParams 
     const float* nz = p.noise ? p.noise + (int64_t)(p.noise_n > 1 ? n : 0) * p.hw : nullptr;
     const float inv_gain = 1.f / p.gain, inv_alpha = 1.f / p.alpha;
     float acc_s = 0.f, acc_c = 0.f;
-    auto one = [&](float xv, float gv, float nv, float& dzv) {
-        const float d = sv * gv;                     // (the value style_grad would have stored)
-        const bool pos = xv > 0.f;
-        dzv = d * p.gain * (pos ? 1.f : p.alpha);
+    auto one = [&](float xv, float rv, float gv, float nv, float& dv, float& dzv) {
+        dv = sv * gv;                                // (the value style_grad would have stored)
+        const float v = RES ? xv - rv : xv;
+        const bool pos = v > 0.f;
+        dzv = dv * p.gain * (pos ? 1.f : p.alpha);
         if (p.part_dc) {
-            const float zv = (pos ? xv : xv * inv_alpha) * inv_gain;
+            const float zv = (pos ? v : v * inv_alpha) * inv_gain;
             acc_c += dzv * (zv - b - nv * ns);
         }
     };
@@ -948,18 +970,23 @@ __global__ __launch_bounds__(256) void style_grad_act_bwd_kernel(StyleActParams 
             const float4 gv = *reinterpret_cast<const float4*>(p.g + base + i);
             const float4 xv = *reinterpret_cast<const float4*>(p.x + base + i);
             const float4 nv = nz ? *reinterpret_cast<const float4*>(nz + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (RES) rv = *reinterpret_cast<const float4*>(p.res + base + i);
             acc_s += xv.x * gv.x + xv.y * gv.y + xv.z * gv.z + xv.w * gv.w;       // (the association of style_grad_kernel: bit-identical partials)
-            float4 o;
-            one(xv.x, gv.x, nv.x, o.x); one(xv.y, gv.y, nv.y, o.y); one(xv.z, gv.z, nv.z, o.z); one(xv.w, gv.w, nv.w, o.w);
+            float4 o, d;
+            one(xv.x, rv.x, gv.x, nv.x, d.x, o.x); one(xv.y, rv.y, gv.y, nv.y, d.y, o.y);
+            one(xv.z, rv.z, gv.z, nv.z, d.z, o.z); one(xv.w, rv.w, gv.w, nv.w, d.w, o.w);
             *reinterpret_cast<float4*>(p.dz + base + i) = o;
+            if (RES) *reinterpret_cast<float4*>(p.dx + base + i) = d;
         }
     } else {
         for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-            float o;
+            float o, d;
             const float xs = p.x[base + i], gs = p.g[base + i];
             acc_s += xs * gs;
-            one(xs, gs, nz ? nz[i] : 0.f, o);
+            one(xs, RES ? p.res[base + i] : 0.f, gs, nz ? nz[i] : 0.f, d, o);
             p.dz[base + i] = o;
+            if (RES) p.dx[base + i] = d;
         }
     }
     const float ts = block_sum(acc_s, red);
@@ -972,17 +999,26 @@ __global__ __launch_bounds__(256) void style_grad_act_bwd_kernel(StyleActParams 
 }
 }  // namespace
 
-extern "C" int mgf_style_grad_act_bwd_f32(float* style_part, float* dot_part, float* dz, const float* x, const float* g, const float* s,
-                                          const float* bias, const float* noise, const float* noise_strength, int32_t noise_n, int32_t n,
-                                          int32_t c, int64_t hw, float alpha, float gain, mgf_stream_t stream) {
+extern "C" int mgf_style_grad_act_bwd_f32(float* style_part, float* dot_part, float* dz, float* dx, const float* x, const float* g,
+                                          const float* s, const float* residual, const float* bias, const float* noise,
+                                          const float* noise_strength, int32_t noise_n, int32_t n, int32_t c, int64_t hw, float alpha,
+                                          float gain, mgf_stream_t stream) {
     MGF_REQUIRE(style_part && dz && x && g && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "style_grad_act_bwd: bad arguments");
+    MGF_REQUIRE((dx != nullptr) == (residual != nullptr), MGF_EINVAL, "style_grad_act_bwd: dx and residual go together (both or neither)");
     MGF_REQUIRE(alpha != 0.f && gain != 0.f, MGF_EINVAL, "style_grad_act_bwd: alpha and gain must be non-zero (the activation is inverted)");
     MGF_REQUIRE(n <= 65535 && c <= 65535, MGF_ETOOBIG, "style_grad_act_bwd: n and c must be <= 65535");
-    StyleActParams p{style_part, dot_part, dz, x, g, s, bias, noise, noise_strength, noise_n, c, (int)mgf_cdiv(hw, BWD_CHUNK), hw, alpha, gain};
+    StyleActParams p{style_part, dot_part, dz, dx, x, g, s, residual, bias, noise, noise_strength, noise_n, c, (int)mgf_cdiv(hw, BWD_CHUNK),
+                     hw, alpha, gain};
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
-    const bool vec = hw % 4 == 0 && al16(dz) && al16(x) && al16(g) && al16(noise);
-    if (vec) hipLaunchKernelGGL(style_grad_act_bwd_kernel<true>, dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(style_grad_act_bwd_kernel<false>, dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
+    const bool vec = hw % 4 == 0 && al16(dz) && al16(x) && al16(g) && al16(noise) && al16(dx) && al16(residual);
+    const dim3 grid(p.nchunk, c, n);
+    if (residual) {
+        if (vec) hipLaunchKernelGGL((style_grad_act_bwd_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((style_grad_act_bwd_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((style_grad_act_bwd_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((style_grad_act_bwd_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     MGF_CHECK_LAUNCH("style_grad_act_bwd");
     return MGF_OK;
 }
@@ -1086,12 +1122,29 @@ extern "C" int mgf_lpips_layer_bwd_f32(float* df0, const float* f0, const float*
     MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "lpips_layer_bwd: n must be <= 65535");
     const float kk = 2.f * scale / (float)hw;
     if (hw >= 16384)
-        hipLaunchKernelGGL(lpips_layer_bwd_kernel<64>, dim3((unsigned)mgf_cdiv(hw, 64), n), dim3(256), 0, (hipStream_t)stream, df0, f0, f1_unit, lin,
-                           c, hw, f1_batch_stride, kk, accumulate);
+        hipLaunchKernelGGL((lpips_layer_bwd_kernel<64, false>), dim3((unsigned)mgf_cdiv(hw, 64), n), dim3(256), 0, (hipStream_t)stream, df0,
+                           nullptr, nullptr, f0, f1_unit, lin, c, c, hw, f1_batch_stride, kk, accumulate);
     else
-        hipLaunchKernelGGL(lpips_layer_bwd_kernel<16>, dim3((unsigned)mgf_cdiv(hw, 16), n), dim3(256), 0, (hipStream_t)stream, df0, f0, f1_unit, lin,
-                           c, hw, f1_batch_stride, kk, accumulate);
+        hipLaunchKernelGGL((lpips_layer_bwd_kernel<16, false>), dim3((unsigned)mgf_cdiv(hw, 16), n), dim3(256), 0, (hipStream_t)stream, df0,
+                           nullptr, nullptr, f0, f1_unit, lin, c, c, hw, f1_batch_stride, kk, accumulate);
     MGF_CHECK_LAUNCH("lpips_layer_bwd");
+    return MGF_OK;
+}
+
+extern "C" int mgf_lpips_layer_bwd_relu_f32(float* dz_a, float* dz_b, const float* dy, const float* f0, const float* f1_unit,
+                                            const float* lin, int32_t n, int32_t c, int32_t c_split, int64_t hw, int64_t f1_batch_stride,
+                                            float scale, mgf_stream_t stream) {
+    MGF_REQUIRE(dz_a && f0 && f1_unit && lin && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer_bwd_relu: bad arguments");
+    MGF_REQUIRE(c_split >= 1 && c_split <= c && (dz_b || c_split == c), MGF_EINVAL, "lpips_layer_bwd_relu: bad split %d of %d channels", c_split, c);
+    MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "lpips_layer_bwd_relu: n must be <= 65535");
+    const float kk = 2.f * scale / (float)hw;
+    if (hw >= 16384)
+        hipLaunchKernelGGL((lpips_layer_bwd_kernel<64, true>), dim3((unsigned)mgf_cdiv(hw, 64), n), dim3(256), 0, (hipStream_t)stream, dz_a,
+                           dz_b, dy, f0, f1_unit, lin, c, c_split, hw, f1_batch_stride, kk, 0);
+    else
+        hipLaunchKernelGGL((lpips_layer_bwd_kernel<16, true>), dim3((unsigned)mgf_cdiv(hw, 16), n), dim3(256), 0, (hipStream_t)stream, dz_a,
+                           dz_b, dy, f0, f1_unit, lin, c, c_split, hw, f1_batch_stride, kk, 0);
+    MGF_CHECK_LAUNCH("lpips_layer_bwd_relu");
     return MGF_OK;
 }
 

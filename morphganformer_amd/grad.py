@@ -192,9 +192,11 @@ class GeneratorGrad:
                                         G._s(lp).data_ptr(), n, ci, hi, 0, st), "style_grad")
         return dx
 
-    def _style_act_bwd(self, lp, g, prev, y_prev):
-        """_style_bwd of `lp` fused with _act_bwd of the layer `prev` whose output y_prev is lp's input (conv1 -> conv0 of a block: prev has
-        no residual): one pass over (y_prev, g), the intermediate s * g never reaches memory (mgf_style_grad_act_bwd_f32)."""
+    def _style_act_bwd(self, lp, g, prev, y_prev, residual=None, dx_role=None):
+        """_style_bwd of `lp` fused with _act_bwd of the layer `prev` whose output y_prev is lp's input: one pass over (y_prev, g)
+        (mgf_style_grad_act_bwd_f32).  conv1 -> conv0 of a block: prev has no residual and the intermediate s * g never reaches memory.
+        conv_last -> conv1 of the last block: prev's residual is the block's skip tensor and s * g is stored too (dx_role: the skip
+        branch's backward reads it).  Returns dz, or (dz, dx) with a residual."""
         G, L, st = self.G, _lib.lib(), _lib.stream_ptr()
         n, c, h, w = y_prev.shape
         mode, noises = G.last_noise
@@ -202,11 +204,13 @@ class GeneratorGrad:
         dz = self.buf("dz", y_prev.shape)
         want_dot = prev.demod and prev.attn is None
         alpha, gain = (0.2, prev.act_gain) if prev.bias is not None else (1.0, 1.0)
+        dx = self.buf(dx_role, y_prev.shape) if residual is not None else None
         _lib.check(L.mgf_style_grad_act_bwd_f32(self.ds_part[lp.name].data_ptr(), self.dc_part[prev.name].data_ptr() if want_dot else None,
-                                                dz.data_ptr(), y_prev.data_ptr(), g.data_ptr(), G._s(lp).data_ptr(), _lib.ptr(prev.bias),
-                                                _lib.ptr(noise), _lib.ptr(prev.noise_strength) if noise is not None else None, noise_n,
+                                                dz.data_ptr(), _lib.ptr(dx), y_prev.data_ptr(), g.data_ptr(), G._s(lp).data_ptr(),
+                                                _lib.ptr(residual), _lib.ptr(prev.bias), _lib.ptr(noise),
+                                                _lib.ptr(prev.noise_strength) if noise is not None else None, noise_n,
                                                 n, c, h * w, alpha, gain, st), "style_grad_act_bwd")
-        return dz
+        return dz if residual is None else (dz, dx)
 
     def _layer_bwd(self, lp, dy, y_out, c_pre, residual, x_in, dx_role):
         """One SynthesisLayer.  dy: gradient wrt the layer output y_out (= lrelu(c [attention] + noise + bias) * gain + residual);
@@ -231,12 +235,19 @@ class GeneratorGrad:
         b = f"synthesis.b{R}"
         lt, ll = layers[b + ".torgb"], layers[b + ".conv_last"]
         h = G.bufs[R]["last"]
+        dz1_top = None
         # ToRGB: img = sum_co W[c,co] s[co] h[co] + bias (no demodulation, no activation)
         g = cv.conv_forward(dimg, self.T[lt.name], out=self.buf("g", h.shape))
         if FUSE_STYLE_ACT and self.debug is None:
             # ToRGB's input IS conv_last's output h: its style gradient and conv_last's (linear) activation backward in one pass over (h, g)
             dzl = self._style_act_bwd(lt, g, ll, h)
-            dx = self._style_bwd(ll, self._conv_bwd(ll, dzl, h, None, out_of(R)), out_of(R), "dxin")
+            gl = self._conv_bwd(ll, dzl, h, None, out_of(R))
+            if R > 4:
+                # conv_last's input IS the last block's output (conv1's activation + the skip tensor): conv_last's style gradient and
+                # conv1's activation backward in one pass as well; s g is still stored, the skip branch's backward reads it
+                dz1_top, dx = self._style_act_bwd(ll, gl, layers[b + ".conv1"], out_of(R), residual=G.bufs[R]["skip"], dx_role="dxin")
+            else:
+                dx = self._style_bwd(ll, gl, out_of(R), "dxin")
         else:
             dh = self.buf("dh", h.shape)
             _lib.check(L.mgf_style_grad_f32(self.ds_part[lt.name].data_ptr(), dh.data_ptr(), h.data_ptr(), g.data_ptr(),
@@ -258,7 +269,7 @@ class GeneratorGrad:
                 self.debug[f"synthesis.b{res}:dout"] = d_out.clone()
             # conv1 then conv0: conv1's input IS conv0's output y0, so conv1's style gradient and conv0's activation backward are one
             # pass over (y0, g) -- d(y0) = s g is never stored (MGF_FUSE_STYLE_ACT=0: the two kernels in sequence, bit-identical)
-            dz1 = self._act_bwd(l1, d_out, y1, B["skip"])
+            dz1 = dz1_top if res == R and dz1_top is not None else self._act_bwd(l1, d_out, y1, B["skip"])
             g1 = self._conv_bwd(l1, dz1, y1, B["conv1"] if att else None, y0)
             if FUSE_STYLE_ACT and self.debug is None:
                 dz0 = self._style_act_bwd(l1, g1, l0, y0)

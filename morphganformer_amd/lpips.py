@@ -35,6 +35,9 @@ WEIGHTS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights"
 # Winograd kernel: few chunks per tile is exactly where its 32x32-tile shape with four workgroups per CU pays (with form 2 they were
 # slower than the tap-list kernel, 481 vs 486 iters/s).  MGF_WINOGRAD_LPIPS=0 (tuning hook) puts them back on the tap-list kernel.
 USE_WINOGRAD_LPIPS = os.environ.get("MGF_WINOGRAD_LPIPS", "1") != "0"
+# a tap's distance gradient and the backward of the ReLU whose output the tap is, in one pass (mgf_lpips_layer_bwd_relu_f32);
+# 0: the two kernels in sequence (experiments / the equivalence test)
+FUSE_TAP_RELU = os.environ.get("MGF_FUSE_TAP_RELU", "1") != "0"
 
 
 def random_squeeze_backbone(seed=0):
@@ -188,15 +191,23 @@ class SequentialFeatures:
             row, h = rows[i]
             gh = self.gbufs[i]
             c, hh, ww = h.shape[1:]
-            if i in tap_of:
+            behind = pos != len(nodes) - 1                     # a gradient from the rows behind this one is already in gh
+            fused = FUSE_TAP_RELU and i in tap_of and row[0] == "conv"
+            if fused:
+                kk = tap_of[i]
+                _lib.check(L.mgf_lpips_layer_bwd_relu_f32(gh.data_ptr(), None, gh.data_ptr() if behind else None, h.data_ptr(),
+                                                          target_taps[kk].data_ptr(), lins[kk].data_ptr(), n, c, c, hh * ww,
+                                                          c * hh * ww if per_sample else 0, float(scale), st), "lpips_layer_bwd_relu")
+            elif i in tap_of:
                 kk = tap_of[i]
                 _lib.check(L.mgf_lpips_layer_bwd_f32(gh.data_ptr(), h.data_ptr(), target_taps[kk].data_ptr(), lins[kk].data_ptr(), n, c,
-                                                     hh * ww, c * hh * ww if per_sample else 0, float(scale), int(pos != len(nodes) - 1), st),
+                                                     hh * ww, c * hh * ww if per_sample else 0, float(scale), int(behind), st),
                            "lpips_layer_bwd")
             prev = self.bufs[nodes[pos - 1]] if pos > 0 else self.xs
             gprev = self.gbufs[nodes[pos - 1]] if pos > 0 else self.gxs
             if row[0] == "conv":
-                _lib.check(L.mgf_relu_bwd_split_f32(gh.data_ptr(), None, gh.data_ptr(), h.data_ptr(), n, c, c, hh * ww, st), "relu_bwd")
+                if not fused:
+                    _lib.check(L.mgf_relu_bwd_split_f32(gh.data_ptr(), None, gh.data_ptr(), h.data_ptr(), n, c, c, hh * ww, st), "relu_bwd")
                 _, idx, _ci, _co, k, stride, pad = row
                 if k == 3 and stride == 1:
                     cv.conv_forward(gh, self.gp[idx], pad=(1, 1), out=gprev)
@@ -289,13 +300,23 @@ class SqueezeFeatures:
         for idx in range(12, 0, -1):
             h, gh = self.buf[idx], self.gbuf[idx]
             c, hh, ww = h.shape[1:]
-            if idx in TAPS_AFTER:
+            # every tap is a ReLU output (the stem's, or a Fire's concat): its distance gradient and that ReLU's backward (with the
+            # Fire's split into the two expand branches) are one pass
+            fused = FUSE_TAP_RELU and idx in TAPS_AFTER and idx not in POOLS
+            if fused:
+                k = TAPS_AFTER.index(idx)
+                da, db, ex = (gh, None, c) if idx == 1 else (*self.gex[idx], FIRES[idx][2])
+                _lib.check(L.mgf_lpips_layer_bwd_relu_f32(da.data_ptr(), _lib.ptr(db), gh.data_ptr() if idx != 12 else None, h.data_ptr(),
+                                                          target_taps[k].data_ptr(), lins[k].data_ptr(), n, c, ex, hh * ww,
+                                                          c * hh * ww if per_sample else 0, float(scale), st), "lpips_layer_bwd_relu")
+            elif idx in TAPS_AFTER:
                 k = TAPS_AFTER.index(idx)
                 _lib.check(L.mgf_lpips_layer_bwd_f32(gh.data_ptr(), h.data_ptr(), target_taps[k].data_ptr(), lins[k].data_ptr(), n, c,
                                                      hh * ww, c * hh * ww if per_sample else 0, float(scale), int(idx != 12), st),
                            "lpips_layer_bwd")
             if idx == 1:
-                _lib.check(L.mgf_relu_bwd_split_f32(gh.data_ptr(), None, gh.data_ptr(), h.data_ptr(), n, c, c, hh * ww, st), "relu_bwd")
+                if not fused:
+                    _lib.check(L.mgf_relu_bwd_split_f32(gh.data_ptr(), None, gh.data_ptr(), h.data_ptr(), n, c, c, hh * ww, st), "relu_bwd")
                 return cv.tconv3x3s2_forward(gh, self.gp["c0"], out=self.gimg)
             if idx in POOLS:
                 x = self.buf[idx - 1]
@@ -305,7 +326,9 @@ class SqueezeFeatures:
             sqT, e1T, e3T = self.gp[idx]
             ex = FIRES[idx][2]
             da, db = self.gex[idx]
-            _lib.check(L.mgf_relu_bwd_split_f32(da.data_ptr(), db.data_ptr(), gh.data_ptr(), h.data_ptr(), n, c, ex, hh * ww, st), "relu_bwd_split")
+            if not fused:
+                _lib.check(L.mgf_relu_bwd_split_f32(da.data_ptr(), db.data_ptr(), gh.data_ptr(), h.data_ptr(), n, c, ex, hh * ww, st),
+                           "relu_bwd_split")
             s, gs = self.sq[idx], self.gsq[idx]
             cv.conv_forward(da, e1T, out=gs)
             cv.conv_forward(db, e3T, pad=(1, 1), epilogue=_lib.make_epilogue(residual=gs), out=gs)

@@ -126,10 +126,12 @@ def test_layer_act_bwd_and_dots():
     assert torch.allclose(dx, 2.0 + s[:, :, None] * b, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("hw,with_dot", [(5000, True), (4096, False), (37, True)])
-def test_style_grad_fused_with_act_bwd_is_the_two_kernels_in_sequence(hw, with_dot):
-    """mgf_style_grad_act_bwd_f32 (conv1's style gradient + conv0's activation backward in one pass) == mgf_style_grad_f32 followed by
-    mgf_layer_act_bwd_f32, bit for bit: same partial sums, same dz."""
+@pytest.mark.parametrize("hw,with_dot,with_res", [(5000, True, False), (4096, False, False), (37, True, False),
+                                                  (5000, True, True), (4096, False, True), (37, True, True)])
+def test_style_grad_fused_with_act_bwd_is_the_two_kernels_in_sequence(hw, with_dot, with_res):
+    """mgf_style_grad_act_bwd_f32 (conv1's style gradient + conv0's activation backward in one pass; with a residual and the stored s g:
+    conv_last's style gradient + conv1's activation backward) == mgf_style_grad_f32 followed by mgf_layer_act_bwd_f32, bit for bit:
+    same partial sums, same dz, same dx."""
     from morphganformer_amd import _lib
     L = _lib.lib()
     torch.manual_seed(hw)
@@ -139,17 +141,24 @@ def test_style_grad_fused_with_act_bwd_is_the_two_kernels_in_sequence(hw, with_d
     s = torch.rand(n, c, device="cuda") + 0.5
     bias, noise = torch.randn(c, device="cuda"), torch.randn(n, hw, device="cuda")
     nstr = torch.tensor([0.3], device="cuda")
+    res = torch.randn(n, c, hw, device="cuda") if with_res else None
+    rp = res.data_ptr() if with_res else None
     chunks = int(L.mgf_bwd_chunks(hw))
     st = _lib.stream_ptr()
     ps_a, pd_a = torch.empty(n, c, chunks, device="cuda"), torch.empty(n, c, chunks, device="cuda")
     dmid, dz_a = torch.empty_like(y), torch.empty_like(y)
     _lib.check(L.mgf_style_grad_f32(ps_a.data_ptr(), dmid.data_ptr(), y.data_ptr(), g.data_ptr(), s.data_ptr(), n, c, hw, 0, st))
-    _lib.check(L.mgf_layer_act_bwd_f32(dz_a.data_ptr(), pd_a.data_ptr() if with_dot else None, dmid.data_ptr(), y.data_ptr(), None,
+    _lib.check(L.mgf_layer_act_bwd_f32(dz_a.data_ptr(), pd_a.data_ptr() if with_dot else None, dmid.data_ptr(), y.data_ptr(), rp,
                                        bias.data_ptr(), noise.data_ptr(), nstr.data_ptr(), n, n, c, hw, 0.2, 1.3, st))
-    ps_b, pd_b, dz_b = torch.empty_like(ps_a), torch.empty_like(pd_a), torch.empty_like(y)
-    _lib.check(L.mgf_style_grad_act_bwd_f32(ps_b.data_ptr(), pd_b.data_ptr() if with_dot else None, dz_b.data_ptr(), y.data_ptr(), g.data_ptr(),
-                                            s.data_ptr(), bias.data_ptr(), noise.data_ptr(), nstr.data_ptr(), n, n, c, hw, 0.2, 1.3, st))
+    ps_b, pd_b, dz_b, dx_b = torch.empty_like(ps_a), torch.empty_like(pd_a), torch.empty_like(y), torch.empty_like(y)
+    _lib.check(L.mgf_style_grad_act_bwd_f32(ps_b.data_ptr(), pd_b.data_ptr() if with_dot else None, dz_b.data_ptr(),
+                                            dx_b.data_ptr() if with_res else None, y.data_ptr(), g.data_ptr(), s.data_ptr(), rp,
+                                            bias.data_ptr(), noise.data_ptr(), nstr.data_ptr(), n, n, c, hw, 0.2, 1.3, st))
     assert torch.equal(dz_a, dz_b) and torch.equal(ps_a, ps_b)
+    if with_res:
+        assert torch.equal(dmid, dx_b)
+        assert L.mgf_style_grad_act_bwd_f32(ps_b.data_ptr(), None, dz_b.data_ptr(), dx_b.data_ptr(), y.data_ptr(), g.data_ptr(), s.data_ptr(),
+                                            None, None, None, None, 0, n, c, hw, 0.2, 1.3, st) != 0        # dx without residual
     if with_dot:
         assert torch.equal(pd_a, pd_b)
 
@@ -264,6 +273,34 @@ def test_lpips_gradient_matches_autograd(net, size):
     assert rel(dimg - 0.25, ref) < GRAD_TOL
     pl.grad_into(dimg, scale=0.7)
     assert rel(dimg, ref) < GRAD_TOL
+
+
+@pytest.mark.parametrize("c,split,hw,behind", [(128, 64, 20000, True), (64, 64, 17000, True), (48, 16, 300, True), (512, 256, 49, False)])
+def test_lpips_tap_gradient_fused_with_relu_bwd_is_the_two_kernels_in_sequence(c, split, hw, behind):
+    """mgf_lpips_layer_bwd_relu_f32 == mgf_lpips_layer_bwd_f32 (accumulating into the gradient from behind the tap) followed by
+    mgf_relu_bwd_split_f32, bit for bit; both pixel-block sizes, with and without a split, one target per sample."""
+    from morphganformer_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(c + hw)
+    n = 2
+    f0 = torch.relu(torch.randn(n, c, hw, device="cuda"))          # a ReLU output: about half zeros
+    f1 = torch.nn.functional.normalize(torch.rand(n, c, hw, device="cuda"), dim=1)
+    lin = torch.rand(c, device="cuda")
+    dy = torch.randn(n, c, hw, device="cuda")
+    st = _lib.stream_ptr()
+    acc = dy.clone()
+    _lib.check(L.mgf_lpips_layer_bwd_f32(acc.data_ptr(), f0.data_ptr(), f1.data_ptr(), lin.data_ptr(), n, c, hw, c * hw, 0.7, int(behind), st))
+    a0, b0 = torch.empty(n, split, hw, device="cuda"), torch.empty(n, max(c - split, 1), hw, device="cuda")
+    a1, b1 = torch.empty_like(a0), torch.empty_like(b0)
+    bp = lambda t: t.data_ptr() if split < c else None
+    _lib.check(L.mgf_relu_bwd_split_f32(a0.data_ptr(), bp(b0), acc.data_ptr(), f0.data_ptr(), n, c, split, hw, st))
+    _lib.check(L.mgf_lpips_layer_bwd_relu_f32(a1.data_ptr(), bp(b1), dy.data_ptr() if behind else None, f0.data_ptr(), f1.data_ptr(),
+                                              lin.data_ptr(), n, c, split, hw, c * hw, 0.7, st))
+    assert torch.equal(a0, a1) and (split == c or torch.equal(b0, b1))
+    if split == c:                                                 # in place, as the sequential backbones call it
+        _lib.check(L.mgf_lpips_layer_bwd_relu_f32(dy.data_ptr(), None, dy.data_ptr(), f0.data_ptr(), f1.data_ptr(), lin.data_ptr(), n, c, c, hw,
+                                                  c * hw, 0.7, st))
+        assert torch.equal(dy, a0) or not behind
 
 
 def test_mse_grad_and_pool_bwd():
