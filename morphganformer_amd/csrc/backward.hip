@@ -762,69 +762,92 @@ __global__ __launch_bounds__(256) void relu_bwd_split_kernel(float* dz_a, float*
 // A workgroup owns a 32 x 32 tile of INPUT elements of one plane.  The 17 x 17 windows that touch it (one row / column of them
 // belongs to the neighbouring tile and is recomputed) read a 35 x 35 input patch from LDS; every window's argmax (as a patch offset)
 // and gradient are computed once, then each input element collects from the <= 4 windows that cover it.
-constexpr int MPT = 32, MPW = MPT / 2 + 1, MPI = MPT + 3;
+// Input tile owned by a workgroup: 64 columns x 32 rows (both even: windows start on even rows / columns), the (32/2 + 1) x (64/2 + 1)
+// windows that touch it, and their (32 + 3) x (64 + 3) input patch.  The kernel is bound by its instruction count, not by memory
+// (2.1 TB/s in its first form): no coordinates are divided, the patch is padded with -inf so the window scan needs no bounds tests,
+// and a lane scatters the windows' gradients to one 2 x 2 block of inputs (whose four window memberships are fixed by parity).
+constexpr int MPTX = 64, MPTY = 32, MPWX = MPTX / 2 + 1, MPWY = MPTY / 2 + 1, MPIX = MPTX + 3, MPIY = MPTY + 3, MPS = MPIX + 1;
 __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(float* dx, const float* dy, const float* x, int ih, int iw, int oh, int ow,
                                                                int tiles_x, int tiles_y) {
-    __shared__ float patch[MPI][MPI + 1];
-    __shared__ int16_t arg[MPW][MPW];
-    __shared__ float gw[MPW][MPW];
+    __shared__ float patch[MPIY * MPS];
+    __shared__ int16_t arg[MPWY][MPWX + 1];
+    __shared__ float gw[MPWY][MPWX + 1];
+    const int tid = threadIdx.x;
     const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
     const int64_t pl = blockIdx.x / ((int64_t)tiles_x * tiles_y);
-    const int iy0 = ty * MPT, ix0 = tx * MPT;            // first owned input row / column
-    const int py0 = iy0 - 2, px0 = ix0 - 2;              // patch origin
+    const int iy0 = ty * MPTY, ix0 = tx * MPTX;          // first owned input row / column
+    const int py0 = iy0 - 2, px0 = ix0 - 2;              // patch origin: patch[2 wy + ky][2 wx + kx] is tap (ky, kx) of local window (wy, wx)
     const int wy0 = iy0 / 2 - 1, wx0 = ix0 / 2 - 1;      // first window row / column (may be -1)
     const float* xp = x + pl * ih * iw;
     const float* dp = dy + pl * oh * ow;
-    for (int i = threadIdx.x; i < MPI * MPI; i += 256) {
-        const int r = i / MPI, cc = i % MPI;
-        const int yy = py0 + r, xx = px0 + cc;
-        patch[r][cc] = (yy >= 0 && xx >= 0 && yy < ih && xx < iw) ? xp[(int64_t)yy * iw + xx] : 0.f;
+    const float NEG = -__builtin_inff();
+    {
+        const int cc = tid & 63, r0 = tid >> 6;
+        const int xx = px0 + cc;
+        const bool xin = xx >= 0 && xx < iw;
+#pragma unroll
+        for (int r = r0; r < MPIY; r += 4) {
+            const int yy = py0 + r;
+            patch[r * MPS + cc] = (xin && yy >= 0 && yy < ih) ? xp[(int64_t)yy * iw + xx] : NEG;
+        }
+        if (tid < 3 * MPIY) {                            // the three columns past the 64th
+            const int r = tid / 3, c3 = 64 + tid - 3 * r;
+            const int yy = py0 + r, x3 = px0 + c3;
+            patch[r * MPS + c3] = (x3 < iw && yy >= 0 && yy < ih) ? xp[(int64_t)yy * iw + x3] : NEG;
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < MPW * MPW; i += 256) {
-        const int wy = i / MPW, wx = i % MPW;
+    for (int i = tid; i < MPWY * MPWX; i += 256) {
+        const int wy = i / MPWX, wx = i - wy * MPWX;
         const int oy = wy0 + wy, ox = wx0 + wx;
         int best = -1;
-        float bv = 0.f;
-        if (oy >= 0 && ox >= 0 && oy < oh && ox < ow) {
+        float g = 0.f;
+        if (oy >= 0 && ox >= 0 && oy < oh && ox < ow) {  // tap (0, 0) of a window that exists is inside the input
+            const int base = 2 * wy * MPS + 2 * wx;
+            float bv = patch[base];
+            best = base;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int yy = 2 * oy + ky, xx = 2 * ox + kx;
-                    if (yy < ih && xx < iw) {
-                        const int r = yy - py0, cc = xx - px0;
-                        const float v = patch[r][cc];
-                        if (best < 0 || v > bv) { bv = v; best = r * MPI + cc; }
-                    }
+                    if (ky == 0 && kx == 0) continue;
+                    const float v = patch[base + ky * MPS + kx];
+                    if (v > bv) { bv = v; best = base + ky * MPS + kx; }       // first maximum in row-major order (torch)
                 }
+            g = dp[(int64_t)oy * ow + ox];
         }
         arg[wy][wx] = (int16_t)best;
-        gw[wy][wx] = best >= 0 ? dp[(int64_t)oy * ow + ox] : 0.f;
+        gw[wy][wx] = g;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < MPT * MPT; i += 256) {
-        const int r = i / MPT, cc = i % MPT;
-        const int yy = iy0 + r, xx = ix0 + cc;
+    // input block (2 br, 2 bc) + {0,1}^2 of the tile: windows (br, bc) .. (br + 1, bc + 1) in local indices; element (0,0) is in
+    // all four, (0,1) in the right two, (1,0) in the lower two, (1,1) in the last -- summed in ascending window order like torch
+#pragma unroll
+    for (int i = tid; i < (MPTY / 2) * (MPTX / 2); i += 256) {
+        const int br = i / (MPTX / 2), bc = i - br * (MPTX / 2);
+        const int yy = iy0 + 2 * br, xx = ix0 + 2 * bc;
         if (yy >= ih || xx >= iw) continue;
-        const int me = (yy - py0) * MPI + (xx - px0);
-        float acc = 0.f;
-        // windows oy with 2 oy <= yy <= 2 oy + 2:  oy in {(yy - 1) / 2 (only when yy is even, = yy / 2 - 1), yy / 2}
-        const int oyb = yy / 2, oxb = xx / 2;
-#pragma unroll
-        for (int a = 1; a >= 0; --a) {               // ascending window order, like the reference's accumulation
-            const int oy = oyb - a;
-            if (a == 1 && (yy & 1)) continue;
-            if (oy < 0 || oy >= oh) continue;
-#pragma unroll
-            for (int b = 1; b >= 0; --b) {
-                const int ox = oxb - b;
-                if (b == 1 && (xx & 1)) continue;
-                if (ox < 0 || ox >= ow) continue;
-                if (arg[oy - wy0][ox - wx0] == me) acc += gw[oy - wy0][ox - wx0];
-            }
+        const int me = (2 * br + 2) * MPS + 2 * bc + 2;
+        const int a00 = arg[br][bc], a01 = arg[br][bc + 1], a10 = arg[br + 1][bc], a11 = arg[br + 1][bc + 1];
+        const float g00 = gw[br][bc], g01 = gw[br][bc + 1], g10 = gw[br + 1][bc], g11 = gw[br + 1][bc + 1];
+        float e00 = 0.f, e01 = 0.f, e10 = 0.f, e11 = 0.f;
+        if (a00 == me) e00 += g00;
+        if (a01 == me) e00 += g01;
+        if (a10 == me) e00 += g10;
+        if (a11 == me) e00 += g11;
+        if (a01 == me + 1) e01 += g01;
+        if (a11 == me + 1) e01 += g11;
+        if (a10 == me + MPS) e10 += g10;
+        if (a11 == me + MPS) e10 += g11;
+        if (a11 == me + MPS + 1) e11 += g11;
+        float* o = dx + pl * ih * iw + (int64_t)yy * iw + xx;
+        const bool x1 = xx + 1 < iw;
+        o[0] = e00;
+        if (x1) o[1] = e01;
+        if (yy + 1 < ih) {
+            o[iw] = e10;
+            if (x1) o[iw + 1] = e11;
         }
-        dx[pl * ih * iw + (int64_t)yy * iw + xx] = acc;
     }
 }
 
@@ -1163,7 +1186,7 @@ extern "C" int mgf_maxpool3x3s2_ceil_bwd_f32(float* dx, const float* dy, const f
                                              int32_t out_w, mgf_stream_t stream) {
     MGF_REQUIRE(dx && dy && x && nc >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, MGF_EINVAL, "maxpool3x3s2_ceil_bwd: bad arguments");
     MGF_REQUIRE(2 * (out_h - 1) < in_h && 2 * (out_w - 1) < in_w, MGF_EINVAL, "maxpool3x3s2_ceil_bwd: output extent does not match the input");
-    const int tiles_x = (int)mgf_cdiv(in_w, MPT), tiles_y = (int)mgf_cdiv(in_h, MPT);
+    const int tiles_x = (int)mgf_cdiv(in_w, MPTX), tiles_y = (int)mgf_cdiv(in_h, MPTY);
     MGF_REQUIRE((int64_t)nc * tiles_x * tiles_y <= INT32_MAX, MGF_ETOOBIG, "maxpool3x3s2_ceil_bwd: too many tiles");
     hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((unsigned)((int64_t)nc * tiles_x * tiles_y)), dim3(256), 0, (hipStream_t)stream, dx, dy, x,
                        in_h, in_w, out_h, out_w, tiles_x, tiles_y);

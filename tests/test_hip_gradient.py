@@ -313,14 +313,18 @@ def test_mse_grad_and_pool_bwd():
     _lib.check(L.mgf_mse_grad_f32(d.data_ptr(), ad.data_ptr(), bd.data_ptr(), 2, 243, 0, 0.5, 1, _lib.stream_ptr()))
     assert torch.allclose(d.cpu(), 1 + 0.5 * 2 * (a - b) / 243, rtol=1e-6, atol=1e-7)
     # ceil-mode pooling with ties (ReLU zeros): the gradient must follow torch's first-maximum rule
-    x = torch.relu(torch.randn(2, 4, 15, 12)).requires_grad_(True)
-    y = torch.nn.functional.max_pool2d(x, 3, 2, ceil_mode=True)
-    dy = torch.randn_like(y)
-    (ref,) = torch.autograd.grad(y, x, dy)
-    xd, dyd = x.detach().cuda(), dy.cuda()
-    dx = torch.empty_like(xd)
-    _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_f32(dx.data_ptr(), dyd.data_ptr(), xd.data_ptr(), 8, 15, 12, y.shape[2], y.shape[3], _lib.stream_ptr()))
-    assert torch.equal(dx.cpu(), ref)
+    # (one tile; several 64 x 32 tiles with ragged edges, odd and even sides; all-negative inputs: the -inf padding must never win)
+    for shape, neg in (((2, 4, 15, 12), False), ((1, 3, 70, 131), False), ((2, 1, 65, 64), False), ((1, 2, 33, 129), True)):
+        x = torch.relu(torch.randn(*shape))
+        x = (x - 5.0 if neg else x).requires_grad_(True)
+        y = torch.nn.functional.max_pool2d(x, 3, 2, ceil_mode=True)
+        dy = torch.randn_like(y)
+        (ref,) = torch.autograd.grad(y, x, dy)
+        xd, dyd = x.detach().cuda(), dy.cuda()
+        dx = torch.full_like(xd, float("nan"))
+        _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_f32(dx.data_ptr(), dyd.data_ptr(), xd.data_ptr(), shape[0] * shape[1], shape[2], shape[3],
+                                                   y.shape[2], y.shape[3], _lib.stream_ptr()))
+        assert torch.equal(dx.cpu(), ref), shape
     # forward pooling, both entries, odd and even sides, wider than one wave's 128 columns: bit-exact
     for (c, hh, ww) in ((3, 15, 12), (2, 31, 301), (1, 8, 257), (5, 2, 3)):
         xf = torch.randn(2, c, hh, ww)
