@@ -690,12 +690,16 @@ __global__ __launch_bounds__(256) void latent_grad_gather_kernel(float* dw, cons
 // RELU: the tap is a ReLU output (all of them are) and the ReLU's backward rides along: dz = f0 > 0 ? din + df0 : 0 (din may be
 // null), channels [0, c_split) to oa [n, c_split, hw], the rest to ob [n, c - c_split, hw] (mgf_relu_bwd_split_f32's layout); without
 // RELU oa is df0 [n, c, hw] and `accumulate` adds to it.
-template <int PXB, bool RELU>
+// CPT > 0: c <= CPT * (256 / PXB), and the lane keeps its CPT channels of f0 and f1 in registers between the two sweeps: 629 -> 588 us
+// at 8 x 64 x 511^2 with 16 channels per lane; with 32 (128 channels) the registers cost more residency than the second sweep's
+// mostly cache-resident reads (321 -> 435 us), so only CPT = 16 is built.  Wider pixel blocks (128, 256) measured no faster than 64.
+template <int PXB, bool RELU, int CPT>
 __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* oa, float* ob, const float* din, const float* f0, const float* f1u,
                                                               const float* lin, int c, int c_split, int64_t hw, int64_t f1_bs, float k,
                                                               int accumulate) {
     // a workgroup owns PXB consecutive pixels; its G = 256 / PXB lane groups split the channels and meet in LDS
     constexpr int G = 256 / PXB;
+    constexpr int NV = CPT > 0 ? CPT : 1;
     __shared__ float part[3][G][PXB];
     const int n = blockIdx.y, px = threadIdx.x % PXB, grp = threadIdx.x / PXB;
     const int64_t p = (int64_t)blockIdx.x * PXB + px;
@@ -703,13 +707,31 @@ __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* oa, float* 
     const int64_t pc = valid ? p : hw - 1;
     const float* a = f0 + (int64_t)n * c * hw + pc;
     const float* b = f1u + (int64_t)n * f1_bs + pc;
+    float va[NV], vb[NV];
     float A = 0.f, B = 0.f, Cc = 0.f;
+    if (CPT > 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int ch = grp + j * G;
+            va[j] = ch < c ? a[(int64_t)ch * hw] : 0.f;
+            vb[j] = ch < c ? b[(int64_t)ch * hw] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int ch = grp + j * G;
+            const float l = ch < c ? lin[ch] : 0.f;
+            A += va[j] * va[j];
+            B += l * va[j] * va[j];
+            Cc += l * vb[j] * va[j];
+        }
+    } else {
 #pragma unroll 4
-    for (int ch = grp; ch < c; ch += G) {
-        const float v = a[(int64_t)ch * hw], l = lin[ch];
-        A += v * v;
-        B += l * v * v;
-        Cc += l * b[(int64_t)ch * hw] * v;
+        for (int ch = grp; ch < c; ch += G) {
+            const float v = a[(int64_t)ch * hw], l = lin[ch];
+            A += v * v;
+            B += l * v * v;
+            Cc += l * b[(int64_t)ch * hw] * v;
+        }
     }
     part[0][grp][px] = A; part[1][grp][px] = B; part[2][grp][px] = Cc;
     __syncthreads();
@@ -721,27 +743,29 @@ __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* oa, float* 
     const float dot = k * (q * B - Cc);
     const float coef = nrm > 0.f ? dot * q * q / nrm : 0.f;
     if (!valid) return;
-    if (RELU) {
-        const float* di = din ? din + (int64_t)n * c * hw + pc : nullptr;
-        float* da = oa + (int64_t)n * c_split * hw + pc;
-        float* db = ob ? ob + (int64_t)n * (c - c_split) * hw + pc : nullptr;
-#pragma unroll 4
-        for (int ch = grp; ch < c; ch += G) {
-            const float v = a[(int64_t)ch * hw];
-            float g = q * k * lin[ch] * (v * q - b[(int64_t)ch * hw]) - coef * v;
+    const float* di = (RELU && din) ? din + (int64_t)n * c * hw + pc : nullptr;
+    float* da = oa + (int64_t)n * (RELU ? c_split : c) * hw + pc;
+    float* db = (RELU && ob) ? ob + (int64_t)n * (c - c_split) * hw + pc : nullptr;
+    auto one = [&](int ch, float v, float u) {
+        float g = q * k * lin[ch] * (v * q - u) - coef * v;
+        if (RELU) {
             if (di) g = di[(int64_t)ch * hw] + g;
             g = v > 0.f ? g : 0.f;
             if (ch < c_split) da[(int64_t)ch * hw] = g;
             else db[(int64_t)(ch - c_split) * hw] = g;
+        } else {
+            da[(int64_t)ch * hw] = accumulate ? da[(int64_t)ch * hw] + g : g;
+        }
+    };
+    if (CPT > 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int ch = grp + j * G;
+            if (ch < c) one(ch, va[j], vb[j]);
         }
     } else {
-        float* o = oa + (int64_t)n * c * hw + pc;
 #pragma unroll 4
-        for (int ch = grp; ch < c; ch += G) {
-            const float v = a[(int64_t)ch * hw];
-            const float g = q * k * lin[ch] * (v * q - b[(int64_t)ch * hw]) - coef * v;
-            o[(int64_t)ch * hw] = accumulate ? o[(int64_t)ch * hw] + g : g;
-        }
+        for (int ch = grp; ch < c; ch += G) one(ch, a[(int64_t)ch * hw], b[(int64_t)ch * hw]);
     }
 }
 
@@ -1139,17 +1163,34 @@ extern "C" int mgf_latent_grad_gather(float* dw, const float* dwg, int32_t n_sty
     return MGF_OK;
 }
 
+// Pixels per workgroup: 64 (256-byte row segments per channel) while that leaves >= 512 workgroups, else 32 while >= 256, else 16 -- the
+// 16-pixel form moves 64-byte segments and streams at half the rate (1.7 vs 3.4 TB/s at 8 x 256 x 127^2).  MGF_LPIPS_BWD_PXB pins one,
+// MGF_LPIPS_BWD_CACHE=0 turns the register-resident second sweep off (tuning).
+template <bool RELU>
+static void lpips_bwd_launch(float* oa, float* ob, const float* din, const float* f0, const float* f1u, const float* lin, int n, int c,
+                             int c_split, int64_t hw, int64_t f1_bs, float k, int accumulate, hipStream_t st) {
+    static const int env_pxb = [] { const char* e = getenv("MGF_LPIPS_BWD_PXB"); return e ? atoi(e) : 0; }();
+    int pxb = mgf_cdiv(hw, 64) * n >= 512 ? 64 : mgf_cdiv(hw, 32) * n >= 256 ? 32 : 16;
+    if (env_pxb == 16 || env_pxb == 32 || env_pxb == 64) pxb = env_pxb;
+    static const bool no_cache = [] { const char* e = getenv("MGF_LPIPS_BWD_CACHE"); return e && e[0] == '0'; }();
+    const dim3 grid((unsigned)mgf_cdiv(hw, pxb), n);
+#define MGF_LPB_LAUNCH(PX, CP) hipLaunchKernelGGL((lpips_layer_bwd_kernel<PX, RELU, CP>), grid, dim3(256), 0, st, oa, ob, din, f0, f1u, lin, c, c_split, hw, f1_bs, k, accumulate)
+    if (pxb == 64) {
+        if (c <= 64 && !no_cache) MGF_LPB_LAUNCH(64, 16);
+        else MGF_LPB_LAUNCH(64, 0);
+    } else if (pxb == 32) {
+        if (c <= 128 && !no_cache) MGF_LPB_LAUNCH(32, 16);
+        else MGF_LPB_LAUNCH(32, 0);
+    } else MGF_LPB_LAUNCH(16, 0);
+#undef MGF_LPB_LAUNCH
+}
+
 extern "C" int mgf_lpips_layer_bwd_f32(float* df0, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c, int64_t hw,
                                        int64_t f1_batch_stride, float scale, int32_t accumulate, mgf_stream_t stream) {
     MGF_REQUIRE(df0 && f0 && f1_unit && lin && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer_bwd: bad arguments");
     MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "lpips_layer_bwd: n must be <= 65535");
     const float kk = 2.f * scale / (float)hw;
-    if (hw >= 16384)
-        hipLaunchKernelGGL((lpips_layer_bwd_kernel<64, false>), dim3((unsigned)mgf_cdiv(hw, 64), n), dim3(256), 0, (hipStream_t)stream, df0,
-                           nullptr, nullptr, f0, f1_unit, lin, c, c, hw, f1_batch_stride, kk, accumulate);
-    else
-        hipLaunchKernelGGL((lpips_layer_bwd_kernel<16, false>), dim3((unsigned)mgf_cdiv(hw, 16), n), dim3(256), 0, (hipStream_t)stream, df0,
-                           nullptr, nullptr, f0, f1_unit, lin, c, c, hw, f1_batch_stride, kk, accumulate);
+    lpips_bwd_launch<false>(df0, nullptr, nullptr, f0, f1_unit, lin, n, c, c, hw, f1_batch_stride, kk, accumulate, (hipStream_t)stream);
     MGF_CHECK_LAUNCH("lpips_layer_bwd");
     return MGF_OK;
 }
@@ -1161,12 +1202,7 @@ extern "C" int mgf_lpips_layer_bwd_relu_f32(float* dz_a, float* dz_b, const floa
     MGF_REQUIRE(c_split >= 1 && c_split <= c && (dz_b || c_split == c), MGF_EINVAL, "lpips_layer_bwd_relu: bad split %d of %d channels", c_split, c);
     MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "lpips_layer_bwd_relu: n must be <= 65535");
     const float kk = 2.f * scale / (float)hw;
-    if (hw >= 16384)
-        hipLaunchKernelGGL((lpips_layer_bwd_kernel<64, true>), dim3((unsigned)mgf_cdiv(hw, 64), n), dim3(256), 0, (hipStream_t)stream, dz_a,
-                           dz_b, dy, f0, f1_unit, lin, c, c_split, hw, f1_batch_stride, kk, 0);
-    else
-        hipLaunchKernelGGL((lpips_layer_bwd_kernel<16, true>), dim3((unsigned)mgf_cdiv(hw, 16), n), dim3(256), 0, (hipStream_t)stream, dz_a,
-                           dz_b, dy, f0, f1_unit, lin, c, c_split, hw, f1_batch_stride, kk, 0);
+    lpips_bwd_launch<true>(dz_a, dz_b, dy, f0, f1_unit, lin, n, c, c_split, hw, f1_batch_stride, kk, 0, (hipStream_t)stream);
     MGF_CHECK_LAUNCH("lpips_layer_bwd_relu");
     return MGF_OK;
 }

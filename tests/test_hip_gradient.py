@@ -275,10 +275,12 @@ def test_lpips_gradient_matches_autograd(net, size):
     assert rel(dimg, ref) < GRAD_TOL
 
 
-@pytest.mark.parametrize("c,split,hw,behind", [(128, 64, 20000, True), (64, 64, 17000, True), (48, 16, 300, True), (512, 256, 49, False)])
+@pytest.mark.parametrize("c,split,hw,behind", [(128, 64, 20000, True), (64, 64, 17000, True), (48, 16, 300, True), (512, 256, 49, False),
+                                                 (100, 40, 5000, True), (130, 130, 4999, False)])
 def test_lpips_tap_gradient_fused_with_relu_bwd_is_the_two_kernels_in_sequence(c, split, hw, behind):
     """mgf_lpips_layer_bwd_relu_f32 == mgf_lpips_layer_bwd_f32 (accumulating into the gradient from behind the tap) followed by
-    mgf_relu_bwd_split_f32, bit for bit; both pixel-block sizes, with and without a split, one target per sample."""
+    mgf_relu_bwd_split_f32, bit for bit; the three pixel-block sizes (64 / 32 / 16 per workgroup), channels cached in registers or not,
+    with and without a split, one target per sample."""
     from morphganformer_amd import _lib
     L = _lib.lib()
     torch.manual_seed(c + hw)
