@@ -125,10 +125,13 @@ template <bool UNIT_OUT>
 int launch_lpips_layer(float* scratch, float* unit_out, const float* f0, const float* f1u, const float* lin, int n, int c, int64_t hw,
                        int64_t f1_stride, hipStream_t st, int* grid_out) {
     // 64 pixels per workgroup (256-byte segments) whenever that still yields >= 4 workgroups per CU, 16 for the small deep taps
-    static const int pxb_env = [] { const char* e = getenv("MGF_LPIPS_PXB"); return e ? atoi(e) : 0; }();      // tuning hook: 16 | 64
+    static const int pxb_env = [] { const char* e = getenv("MGF_LPIPS_PXB"); return e ? atoi(e) : 0; }();      // tuning hook: 16 | 32 | 64
     // (64-pixel blocks only up to 128 channels = 32 values per thread: with 64 values per thread the 256-channel tap at 127^2 ran at
     // 1.6 TB/s, 2.35 TB/s on 16-pixel blocks -- tools/lpips_layer_micro.py)
-    const int pxb = pxb_env ? pxb_env : ((c <= 128 && (hw >= 65536 || (int64_t)n * mgf_cdiv(hw, 64) >= 1024)) ? 64 : 16);
+    // (32-pixel blocks for the 256-channel tap: 151 vs 176 us at 25 x 127^2; slower than 16 on the 384 / 512-channel taps at 63^2)
+    const int pxb = pxb_env ? pxb_env
+                  : (c <= 128 && (hw >= 65536 || (int64_t)n * mgf_cdiv(hw, 64) >= 1024)) ? 64
+                  : (c > 128 && c <= 256 && (int64_t)n * mgf_cdiv(hw, 32) >= 1024) ? 32 : 16;
     const int64_t grid64 = mgf_cdiv(hw, pxb);
     MGF_REQUIRE(grid64 <= RED_BLOCKS, MGF_ETOOBIG, "lpips_layer: %lld pixels per sample need %lld scratch floats (have %d per sample)",
                 (long long)hw, (long long)grid64, RED_BLOCKS);
@@ -140,6 +143,8 @@ int launch_lpips_layer(float* scratch, float* unit_out, const float* f0, const f
 #define MGF_LPIPS_LAUNCH(PXB, CPT) hipLaunchKernelGGL((lpips_layer_kernel<PXB, CPT, UNIT_OUT>), grid, dim3(256), 0, st, scratch, unit_out, f0, f1u, lin, c, hw, f1_stride, n, (int)grid64, xcd_per)
     if (pxb == 64) {
         if (c <= 128) MGF_LPIPS_LAUNCH(64, 32); else if (c <= 256) MGF_LPIPS_LAUNCH(64, 64); else MGF_LPIPS_LAUNCH(64, 128);
+    } else if (pxb == 32) {
+        if (c <= 128) MGF_LPIPS_LAUNCH(32, 16); else if (c <= 256) MGF_LPIPS_LAUNCH(32, 32); else MGF_LPIPS_LAUNCH(32, 64);
     } else {
         if (c <= 128) MGF_LPIPS_LAUNCH(16, 8); else if (c <= 256) MGF_LPIPS_LAUNCH(16, 16); else MGF_LPIPS_LAUNCH(16, 32);
     }

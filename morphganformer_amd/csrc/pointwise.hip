@@ -206,6 +206,73 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
     }
 }
 
+// cout <= 4 (ToRGB outside the fused conv_last launch: gradient mode, odd sizes): the layer is a weighted sum of the channel rows,
+// 0.1 FLOP per byte -- a streaming VALU kernel, PX pixels per lane, eight channel rows in flight per lane, weights and styles through
+// the scalar cache.  (On the GEMM kernel a 32-row tile with 3 live rows and a K loop of 32 ran at 2.8 TB/s: 380 us for 8 x 32 x 1024^2.)
+template <bool VEC>
+__global__ __launch_bounds__(256) void pw_narrow_kernel(PwParams p) {
+    constexpr int PX = VEC ? 4 : 1;
+    const int n = blockIdx.y;
+    const int64_t px0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PX;
+    if (px0 >= p.hw) return;
+    const float* __restrict__ xb = p.x + (int64_t)n * p.cin * p.hw + px0;
+    const float* __restrict__ w = p.w;
+    const float* __restrict__ sc = p.in_scale ? p.in_scale + (int64_t)n * p.cin : nullptr;
+    float acc[4][PX];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int e = 0; e < PX; ++e) acc[o][e] = 0.f;
+    for (int k0 = 0; k0 < p.cin; k0 += 8) {
+        float v[8][PX];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = min(k0 + u, p.cin - 1);                    // (rows past the last one re-read it with a zero weight)
+            if (VEC) {
+                const float4 q = *reinterpret_cast<const float4*>(xb + (int64_t)k * p.hw);
+                v[u][0] = q.x; v[u][PX > 1 ? 1 : 0] = q.y; v[u][PX > 2 ? 2 : 0] = q.z; v[u][PX > 3 ? 3 : 0] = q.w;
+            } else {
+                v[u][0] = xb[(int64_t)k * p.hw];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u;
+            const bool in = k < p.cin;
+            const int kc = in ? k : p.cin - 1;
+            const float s = !in ? 0.f : (sc ? sc[kc] : 1.f);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const float wv = o < p.cout ? w[(int64_t)kc * p.cout_pad + o] * s : 0.f;
+#pragma unroll
+                for (int e = 0; e < PX; ++e) acc[o][e] += wv * v[u][e];
+            }
+        }
+    }
+    const bool do_ep = p.has_ep != 0;
+    const float slope = !do_ep ? 1.f : (p.ep.act == MGF_ACT_LRELU ? p.ep.alpha : (p.ep.act == MGF_ACT_RELU ? 0.f : 1.f));
+    const float gain = do_ep ? p.ep.gain : 1.f;
+    const int64_t ybase = (int64_t)n * p.y_batch + (int64_t)p.y_choff * p.hw + px0;
+    for (int o = 0; o < p.cout; ++o) {
+        const float bv = (do_ep && p.ep.bias) ? p.ep.bias[o] : 0.f;
+        float r[PX];
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+            float t = (o == 0 ? acc[0][e] : o == 1 ? acc[1][e] : o == 2 ? acc[2][e] : acc[3][e]) + bv;
+            t = t > 0.f ? t : t * slope;
+            r[e] = t * gain;
+        }
+        float* yo = p.y + ybase + (int64_t)o * p.hw;
+        if (VEC) {
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (do_ep && p.ep.residual) q = *reinterpret_cast<const float4*>(p.ep.residual + ybase + (int64_t)o * p.hw);
+            *reinterpret_cast<float4*>(yo) = make_float4(r[0] + q.x, r[PX > 1 ? 1 : 0] + q.y, r[PX > 2 ? 2 : 0] + q.z, r[PX > 3 ? 3 : 0] + q.w);
+        } else {
+            yo[0] = r[0] + ((do_ep && p.ep.residual) ? p.ep.residual[ybase + (int64_t)o * p.hw] : 0.f);
+        }
+    }
+}
+
 template <int CB, int WCO, int WK = 1>
 void pw_launch(const PwParams& p, bool vec, dim3 grid, hipStream_t st) {
     if (vec) hipLaunchKernelGGL((pw_conv_kernel<CB, WCO, WK, true>), grid, dim3(256), 0, st, p);
@@ -244,6 +311,18 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
     // 16-byte accesses: every row of x, y and the residual starts 16-byte aligned
     const bool vec = hw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (p.y_batch % 4) == 0 &&
                      (!ep || !ep->residual || ((uintptr_t)ep->residual % 16) == 0);
+    static const bool narrow_off = [] { const char* e = getenv("MGF_PW_NARROW"); return e && e[0] == '0'; }();
+    if (cout <= 4 && !narrow_off && n <= 65535) {
+        hipStream_t st = (hipStream_t)stream;
+        mgf_prof_external_begin(st, "pw_narrow_kernel", 2.0 * cin * (double)cout * hw * n,
+                                4.0 * ((double)n * cin * hw + (double)cin * cout + (double)n * cout * hw * ((ep && ep->residual) ? 2 : 1)));
+        const dim3 grid((unsigned)mgf_cdiv(hw, vec ? 1024 : 256), n);
+        if (vec) hipLaunchKernelGGL(pw_narrow_kernel<true>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(pw_narrow_kernel<false>, grid, dim3(256), 0, st, p);
+        mgf_prof_external_end(st);
+        MGF_CHECK_LAUNCH("conv1x1");
+        return MGF_OK;
+    }
     // Shape: ONE 32-channel block per wave (64 accumulators, 4 workgroups per CU).  Two blocks per wave (128 accumulators, 2 workgroups
     // per CU) halve the B-operand loads but were never faster (tools/pw_micro.py, 25 samples, us for 1 / 2 blocks: skip 512->512 at
     // 32^2 142 / 145, 512->256 at 64^2 242 / 266, 256->128 at 128^2 250 / 272, Fire expand 16->64 at 255^2 152 / 192): residency hides

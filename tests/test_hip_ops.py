@@ -242,7 +242,10 @@ def test_conv_taps_vs_torch(n, cin, cout, res, k, stride, pad):
     (1, 2, 3, 1, 1, 3, 0, "linear", False),           # one pixel
     (2, 32, 32, 8, 8, 32, 0, "linear", False),        # split-K workgroups with fewer channel groups than waves
     (1, 72, 40, 16, 12, 40, 0, "relu", True),         # ... and with an odd number of groups per wave
-    (1, 256, 128, 128, 128, 128, 0, "linear", False)])
+    (1, 256, 128, 128, 128, 128, 0, "linear", False),
+    (2, 32, 3, 64, 64, 3, 0, "linear", False),        # ToRGB outside the fused launch: the narrow-output streaming kernel, 16-byte path
+    (2, 13, 3, 9, 13, 8, 2, "lrelu", True),           # ... scalar path, cin not a multiple of its 8-row sweep, residual on a slice
+    (1, 64, 4, 32, 36, 4, 0, "relu", True)])          # ... four outputs
 def test_conv1x1_register_gemm_vs_torch_and_tap_list(n, cin, cout, h, w, ctotal, choff, act, res, monkeypatch):
     """csrc/pointwise.hip (what conv_forward runs for un-modulated 1x1 layers) vs torch CPU conv2d and vs the tap-list kernel."""
     from morphganformer_amd import _lib, conv as cv
