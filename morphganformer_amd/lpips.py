@@ -237,9 +237,9 @@ class SqueezeFeatures:
         if share is not None:
             self.c0, self.fires, self.wino3 = share.c0, share.fires, share.wino3          # packed weights are size independent
             self.stem_w, self.stem_b = share.stem_w, share.stem_b
-            self.gp = share.gp
+            self.gp, self.gpw = share.gp, share.gpw
         else:
-            self.gp = {}                                          # channel-transposed packs of the backward pass, built on first use
+            self.gp, self.gpw = {}, {}                            # channel-transposed packs of the backward pass (+ Winograd images), built on first use
             g = lambda k: np.asarray(backbone_state[k], dtype=np.float64)
             t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
             w0, b0 = g("features.0.weight"), g("features.0.bias")
@@ -281,6 +281,11 @@ class SqueezeFeatures:
             self.gp["c0"] = cv.transpose_packed(self.c0[0], flip=False)       # stride-2 conv -> stride-2 transposed conv, same taps
             for idx, ((ps, _), (p1, _), (p3, _)) in self.fires.items():
                 self.gp[idx] = (cv.transpose_packed(ps, False), cv.transpose_packed(p1, False), cv.transpose_packed(p3, True))
+                if USE_WINOGRAD_LPIPS and p3.cin % 32 == 0:
+                    # the expand-3x3 data gradient (E -> S channels) on the Winograd kernel where S is a multiple of its 32-channel tile
+                    w = p3.wp[:, :, :p3.cout].reshape(3, 3, p3.cin, p3.cout).permute(3, 2, 0, 1)        # [E, S, kh, kw]
+                    # (the form-3 image whatever this instance's map size: the packs are shared between sizes)
+                    self.gpw[idx] = cv.winograd2_weights(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), 1.0)
         if getattr(self, "gbuf", None) is None:
             e = lambda t: torch.empty_like(t)
             self.gbuf = {idx: e(t) for idx, t in self.buf.items()}
@@ -331,7 +336,10 @@ class SqueezeFeatures:
                            "relu_bwd_split")
             s, gs = self.sq[idx], self.gsq[idx]
             cv.conv_forward(da, e1T, out=gs)
-            cv.conv_forward(db, e3T, pad=(1, 1), epilogue=_lib.make_epilogue(residual=gs), out=gs)
+            if idx in self.gpw and cv.winograd_fills_chip(n, gs.shape[1], hh, ww):
+                cv.winograd_forward(db, self.gpw[idx], epilogue=_lib.make_epilogue(residual=gs), out=gs)
+            else:
+                cv.conv_forward(db, e3T, pad=(1, 1), epilogue=_lib.make_epilogue(residual=gs), out=gs)
             _lib.check(L.mgf_relu_bwd_split_f32(gs.data_ptr(), None, gs.data_ptr(), s.data_ptr(), n, s.shape[1], s.shape[1], hh * ww, st),
                        "relu_bwd")
             cv.conv_forward(gs, sqT, out=self.gbuf[idx - 1])

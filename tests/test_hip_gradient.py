@@ -275,6 +275,30 @@ def test_lpips_gradient_matches_autograd(net, size):
     assert rel(dimg, ref) < GRAD_TOL
 
 
+def test_lpips_squeeze_gradient_with_winograd_data_gradients(monkeypatch):
+    """The expand-3x3 data gradients of the Fire modules whose squeeze width is a multiple of 32 run on the Winograd kernel once the
+    launch fills the chip (8 targets at 1024^2; odd 127^2 and 63^2 maps, residual added in place).  Forced here at a small size: the same
+    backward from the same forward with and without them (against autograd a near-tie in a deep max-pool can differ between CPU
+    and GPU forwards at an arbitrary size, which says nothing about these kernels; test_lpips_gradient_matches_autograd pins the rest)."""
+    from morphganformer_amd import conv as cv
+    from morphganformer_amd.lpips import PerceptualLoss
+    monkeypatch.setattr(cv, "winograd_fills_chip", lambda *a: True)
+    torch.manual_seed(11)
+    n, size = 2, 140                                               # maps 69, 34, 17 (odd) and 8
+    pred = torch.rand(n, 3, size, size, device="cuda") * 2 - 1
+    pl = PerceptualLoss(net="squeeze", allow_random_backbone=True)
+    pl.set_target(torch.rand(1, 3, size, size, device="cuda") * 2 - 1)
+    out = torch.empty(n, device="cuda")
+    pl.distance_into(out, pred, keep_taps=True)
+    g_wino, g_taps = torch.empty_like(pred), torch.empty_like(pred)
+    pl.grad_into(g_wino, scale=1.0)
+    feat = pl._features(n, size, size)
+    assert sorted(feat.gpw) == [6, 7, 11, 12]                      # Fire modules with 32 / 64 squeeze channels
+    feat.gpw.clear()
+    pl.grad_into(g_taps, scale=1.0)
+    assert float(g_taps.abs().max()) > 0 and rel(g_wino, g_taps) < 1e-5
+
+
 @pytest.mark.parametrize("c,split,hw,behind", [(128, 64, 20000, True), (64, 64, 17000, True), (48, 16, 300, True), (512, 256, 49, False),
                                                  (100, 40, 5000, True), (130, 130, 4999, False)])
 def test_lpips_tap_gradient_fused_with_relu_bwd_is_the_two_kernels_in_sequence(c, split, hw, behind):
