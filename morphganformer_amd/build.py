@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmgf_hip.so")
-SOURCES = ["capi.cpp", "bias_act.hip", "upfirdn2d.hip", "conv_taps.hip", "latent_prep.hip", "attention.hip", "losses.hip", "lpips_stem.hip", "embed.hip", "backward.hip", "wino.hip", "wino3.hip", "pointwise.hip", "warp.hip"]
+SOURCES = ["capi.cpp", "bias_act.hip", "upfirdn2d.hip", "conv_taps.hip", "latent_prep.hip", "attention.hip", "losses.hip", "lpips_stem.hip", "embed.hip", "backward.hip", "wino.hip", "wino3.hip", "pointwise.hip", "narrow_conv.hip", "warp.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=on: fma only inside one source expression (so `acc += a * b` still fuses) and never across statements --
 # the kernels that must reproduce torch's two-rounding arithmetic bit for bit rely on this.

@@ -76,6 +76,8 @@ def _desc(n, cin, in_h, in_w, cout, cout_pad, tile_h, tile_w, istride, ostride, 
     return d
 
 
+# the <= 4-channel ends of the LPIPS stem on the streaming kernels of csrc/narrow_conv.hip (0: the MFMA tap-list kernel; experiments, tests)
+NARROW_CONV = os.environ.get("MGF_NARROW_CONV", "1") != "0"
 POINTWISE = os.environ.get("MGF_POINTWISE", "1") != "0"                   # tuning hook: 0 = 1x1 layers on the tap-list kernel
 
 # Split-K scratch: one slab per (device, stream) -- launches on one stream are ordered, launches on different streams may overlap.
@@ -387,6 +389,21 @@ def tconv_pitch(w: int) -> int:
     return round_up(2 * w + 1, 4)
 
 
+def conv3x3s2_few_inputs(x, pc: PackedConv, bias=None, relu=False, out=None):
+    """3x3 / stride-2 / unpadded convolution of a map with <= 4 channels (+ bias, ReLU): the LPIPS stem outside the fused stem kernel."""
+    _lib.require_gpu(x, pc.wp, bias, out)
+    assert pc.kh == 3 and pc.kw == 3 and pc.cin <= 4 and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == pc.cin
+    n, cin, h, w = x.shape
+    oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    if out is None:
+        out = torch.empty([n, pc.cout, oh, ow], dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and tuple(out.shape) == (n, pc.cout, oh, ow)
+    rc = _lib.lib().mgf_conv3x3s2_few_inputs_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(bias), n, cin, h, w, pc.cout,
+                                                 pc.cout_pad, int(relu), _lib.stream_ptr())
+    _lib.check(rc, "conv3x3s2_few_inputs")
+    return out
+
+
 def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=None):
     """Stride-2 3x3 transposed convolution t[2i+kh, 2j+kw] += w[kh,kw] x[i,j] -> view [n, cout, 2h+1, 2w+1] of a padded-pitch
     workspace (row pitch a multiple of 4 floats so the parity pairs are written as aligned float2)."""
@@ -403,6 +420,12 @@ def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=Non
     # spend 7-20 % of the MFMA work on padding (33-wide parity grids over 32-wide tiles) -- and half of it on a 16 px map, whose 17 x 17
     # parity grid needs two 256-lane tiles where the 16 x 16 quads fill exactly one (727 -> 503 us for the 16 -> 32 layer at 25 samples).
     # Maps below 16 px keep the single launch (8 px: 212 vs 302 us with the split).
+    if NARROW_CONV and pc.cout <= 4 and in_scale is None and out_scale is None:
+        # <= 4 output channels (the LPIPS stem's data gradient): a stream over x, not a GEMM (csrc/narrow_conv.hip)
+        rc = _lib.lib().mgf_tconv3x3s2_few_outputs_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), n, cin, h, w, pc.cout, pc.cout_pad,
+                                                       pitch, oh * pitch, pc.cout * oh * pitch, _lib.stream_ptr())
+        _lib.check(rc, "tconv3x3s2_few_outputs")
+        return out[:, :, :, :ow]
     split = SPLIT_TCONV_BORDER and min(h, w) >= TCONV_SPLIT_MIN
     os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, h if split else h + 1, w if split else w + 1, 1, 2, TCONV_TAPS, TCONV_GROUPS,

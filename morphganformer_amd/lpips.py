@@ -377,7 +377,10 @@ class SqueezeFeatures:
             taps.append(None)
         else:
             pc, b = self.c0
-            h = cv.conv_forward(x.contiguous(), pc, stride=2, pad=(0, 0), epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dest(1))
+            if cv.NARROW_CONV and pc.cin <= 4:
+                h = cv.conv3x3s2_few_inputs(x.contiguous(), pc, bias=b, relu=True, out=dest(1))
+            else:
+                h = cv.conv_forward(x.contiguous(), pc, stride=2, pad=(0, 0), epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dest(1))
             taps.append(h)
         for idx in range(3 if from_pooled else 2, 13):
             if idx in POOLS:

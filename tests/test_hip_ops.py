@@ -285,6 +285,37 @@ def test_conv1x1_register_gemm_vs_torch_and_tap_list(n, cin, cout, h, w, ctotal,
         assert rel_err(got, ref_m) < 2e-5
 
 
+@pytest.mark.parametrize("n,narrow,wide,h,w", [(2, 3, 64, 67, 131), (1, 3, 64, 8, 9), (2, 1, 20, 33, 64), (1, 4, 70, 130, 66), (1, 2, 5, 3, 3)])
+def test_narrow_stride2_convs_vs_torch_and_tap_list(n, narrow, wide, h, w, monkeypatch):
+    """csrc/narrow_conv.hip: the 3x3 / stride-2 conv with <= 4 INPUT channels (LPIPS stem forward) and the 3x3 / stride-2 transposed
+    conv with <= 4 OUTPUT channels (its data gradient) against torch CPU and against the MFMA tap-list kernel they replace."""
+    from morphganformer_amd import _lib, conv as cv
+    torch.manual_seed(h * 7 + w)
+    x = torch.randn(n, narrow, h, w)
+    wt = torch.randn(wide, narrow, 3, 3) / 3
+    b = torch.randn(wide)
+    ref = torch.relu(torch.nn.functional.conv2d(x, wt, b, stride=2))
+    pc = cv.pack_weights(wt.cuda())
+    got = cv.conv3x3s2_few_inputs(x.cuda(), pc, bias=b.cuda(), relu=True)
+    assert tuple(got.shape) == tuple(ref.shape) and rel_err(got, ref) < 2e-5
+    taps = cv.conv_forward(x.cuda(), pc, stride=2, pad=(0, 0), epilogue=_lib.make_epilogue(bias=b.cuda(), act="relu"))
+    assert rel_err(got, taps) < 2e-6
+    lin = cv.conv3x3s2_few_inputs(x.cuda(), pc)                    # no bias, no activation
+    assert rel_err(lin, torch.nn.functional.conv2d(x, wt, stride=2)) < 2e-5
+    # the data gradient: dy [n, wide, oh, ow] -> dx on the (2 oh + 1) x (2 ow + 1) grid the transposed conv writes
+    dy = torch.randn_like(ref)
+    ref_t = torch.nn.functional.conv_transpose2d(dy, wt, stride=2)
+    pt = cv.transpose_packed(pc, flip=False)
+    outs = []
+    for narrow_on in (True, False):
+        monkeypatch.setattr(cv, "NARROW_CONV", narrow_on)
+        buf = torch.full([n, narrow, 2 * ref.shape[2] + 1, cv.tconv_pitch(ref.shape[3])], 7.0, device="cuda")
+        got_t = cv.tconv3x3s2_forward(dy.cuda(), pt, out=buf)
+        assert tuple(got_t.shape) == tuple(ref_t.shape) and rel_err(got_t, ref_t) < 2e-5
+        outs.append(got_t.clone())
+    assert rel_err(outs[0], outs[1]) < 2e-6
+
+
 @pytest.mark.parametrize("n,cin,cout,res", [(1, 32, 32, 16), (2, 64, 32, 33), (1, 8, 40, 4), (1, 128, 64, 64), (3, 48, 96, 40), (1, 6, 20, 130)])
 def test_tconv_vs_torch(n, cin, cout, res):
     from morphganformer_amd import conv as cv

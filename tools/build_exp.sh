@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p exp_build/_obj_$1
 C=morphganformer_amd/csrc
-for s in capi.cpp bias_act.hip upfirdn2d.hip latent_prep.hip attention.hip losses.hip lpips_stem.hip embed.hip backward.hip conv_taps.hip wino.hip wino3.hip pointwise.hip warp.hip; do
+for s in capi.cpp bias_act.hip upfirdn2d.hip latent_prep.hip attention.hip losses.hip lpips_stem.hip embed.hip backward.hip conv_taps.hip wino.hip wino3.hip pointwise.hip narrow_conv.hip warp.hip; do
   cp -u $C/_obj/$s.o exp_build/_obj_$1/$s.o
 done
 SRC=${3:-conv_taps.hip}      # third argument: the source the flags apply to
