@@ -193,12 +193,14 @@ int mgf_conv1x1_f32(float* y, const float* x, const float* w, const float* in_sc
 int mgf_conv1x1_force_shape(int32_t channel_blocks);
 
 /* The narrow ends of the LPIPS(squeeze) stem outside the fused stem kernel (lpips/pretrained_networks.py:7-44, features.0), as
- * streaming VALU kernels (csrc/narrow_conv.hip); weights in mgf_pack_conv_weights' [tap][cin][cout_pad] layout.
- *   conv3x3s2_few_inputs:   y[n,cout,oh,ow] = act(bias + conv3x3 / stride 2 / no padding of x[n,cin<=4,in_h,in_w]), oh = (in_h-3)/2+1
+ * streaming VALU kernels (csrc/narrow_conv.hip).
+ *   conv3x3s2_few_inputs:   y[n,cout,oh,ow] = act(bias + conv3x3 / stride 2 / no padding of x[n,cin<=4,in_h,in_w]), oh = (in_h-3)/2+1;
+ *                           w in the torch layout [cout][cin][3][3]
  *   tconv3x3s2_few_outputs: t[n,co<=4, 2i+kh, 2j+kw] += w[kh,kw][ci][co] x[n,ci,i,j] over the whole [2h+1] x [2w+1] output (row pitch
- *                           `pitch`, even; the layout mgf_conv_taps_f32 + mgf_tconv3x3s2_border_f32 write) */
-int mgf_conv3x3s2_few_inputs_f32(float* y, const float* x, const float* wp, const float* bias, int32_t n, int32_t cin, int32_t in_h,
-                                 int32_t in_w, int32_t cout, int32_t cout_pad, int32_t relu, mgf_stream_t stream);
+ *                           `pitch`, even; the layout mgf_conv_taps_f32 + mgf_tconv3x3s2_border_f32 write); wp in
+ *                           mgf_pack_conv_weights' [tap][cin][cout_pad] layout, cout_pad >= 4 */
+int mgf_conv3x3s2_few_inputs_f32(float* y, const float* x, const float* w, const float* bias, int32_t n, int32_t cin, int32_t in_h,
+                                 int32_t in_w, int32_t cout, int32_t relu, mgf_stream_t stream);
 int mgf_tconv3x3s2_few_outputs_f32(float* y, const float* x, const float* wp, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
                                    int32_t cout_pad, int32_t pitch, int64_t y_plane, int64_t y_batch, mgf_stream_t stream);
 /* form 3 with the epilogue's residual given at HALF resolution: residual_low [n, cout, h/2, w/2] is up-sampled 2x inside the epilogue with the

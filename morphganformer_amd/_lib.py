@@ -73,7 +73,7 @@ _SIGS = {
     "mgf_conv3x3_winograd2_rgb_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "mgf_conv3x3_winograd3_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(Epilogue), vp]),
     "mgf_conv1x1_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, C.POINTER(Epilogue), vp]),
-    "mgf_conv3x3s2_few_inputs_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "mgf_conv3x3s2_few_inputs_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mgf_tconv3x3s2_few_outputs_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, vp]),
     "mgf_conv1x1_force_shape": (C.c_int, [i32]),
     "mgf_conv3x3_winograd3_slice_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, C.POINTER(Epilogue), vp]),

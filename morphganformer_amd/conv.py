@@ -389,17 +389,20 @@ def tconv_pitch(w: int) -> int:
     return round_up(2 * w + 1, 4)
 
 
-def conv3x3s2_few_inputs(x, pc: PackedConv, bias=None, relu=False, out=None):
-    """3x3 / stride-2 / unpadded convolution of a map with <= 4 channels (+ bias, ReLU): the LPIPS stem outside the fused stem kernel."""
-    _lib.require_gpu(x, pc.wp, bias, out)
-    assert pc.kh == 3 and pc.kw == 3 and pc.cin <= 4 and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == pc.cin
-    n, cin, h, w = x.shape
-    oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+def conv3x3s2_few_inputs(x, w, bias=None, relu=False, out=None):
+    """3x3 / stride-2 / unpadded convolution of a map with <= 4 channels (+ bias, ReLU): the LPIPS stem outside the fused stem kernel.
+    w: [cout, cin, 3, 3] (the torch layout, not a PackedConv)."""
+    _lib.require_gpu(x, w, bias, out)
+    cout, cin = w.shape[:2]
+    assert tuple(w.shape[2:]) == (3, 3) and cin <= 4 and w.is_contiguous() and w.dtype == torch.float32
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == cin
+    n, _, h, wd = x.shape
+    oh, ow = (h - 3) // 2 + 1, (wd - 3) // 2 + 1
     if out is None:
-        out = torch.empty([n, pc.cout, oh, ow], dtype=torch.float32, device=x.device)
-    assert out.is_contiguous() and tuple(out.shape) == (n, pc.cout, oh, ow)
-    rc = _lib.lib().mgf_conv3x3s2_few_inputs_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(bias), n, cin, h, w, pc.cout,
-                                                 pc.cout_pad, int(relu), _lib.stream_ptr())
+        out = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and tuple(out.shape) == (n, cout, oh, ow)
+    rc = _lib.lib().mgf_conv3x3s2_few_inputs_f32(out.data_ptr(), x.data_ptr(), w.data_ptr(), _lib.ptr(bias), n, cin, h, wd, cout, int(relu),
+                                                 _lib.stream_ptr())
     _lib.check(rc, "conv3x3s2_few_inputs")
     return out
 

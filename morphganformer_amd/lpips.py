@@ -377,8 +377,8 @@ class SqueezeFeatures:
             taps.append(None)
         else:
             pc, b = self.c0
-            if cv.NARROW_CONV and pc.cin <= 4:
-                h = cv.conv3x3s2_few_inputs(x.contiguous(), pc, bias=b, relu=True, out=dest(1))
+            if cv.NARROW_CONV:
+                h = cv.conv3x3s2_few_inputs(x.contiguous(), self.stem_w.view(64, 3, 3, 3), bias=b, relu=True, out=dest(1))
             else:
                 h = cv.conv_forward(x.contiguous(), pc, stride=2, pad=(0, 0), epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dest(1))
             taps.append(h)

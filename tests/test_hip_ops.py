@@ -296,11 +296,11 @@ def test_narrow_stride2_convs_vs_torch_and_tap_list(n, narrow, wide, h, w, monke
     b = torch.randn(wide)
     ref = torch.relu(torch.nn.functional.conv2d(x, wt, b, stride=2))
     pc = cv.pack_weights(wt.cuda())
-    got = cv.conv3x3s2_few_inputs(x.cuda(), pc, bias=b.cuda(), relu=True)
+    got = cv.conv3x3s2_few_inputs(x.cuda(), wt.cuda(), bias=b.cuda(), relu=True)
     assert tuple(got.shape) == tuple(ref.shape) and rel_err(got, ref) < 2e-5
     taps = cv.conv_forward(x.cuda(), pc, stride=2, pad=(0, 0), epilogue=_lib.make_epilogue(bias=b.cuda(), act="relu"))
     assert rel_err(got, taps) < 2e-6
-    lin = cv.conv3x3s2_few_inputs(x.cuda(), pc)                    # no bias, no activation
+    lin = cv.conv3x3s2_few_inputs(x.cuda(), wt.cuda())            # no bias, no activation
     assert rel_err(lin, torch.nn.functional.conv2d(x, wt, stride=2)) < 2e-5
     # the data gradient: dy [n, wide, oh, ow] -> dx on the (2 oh + 1) x (2 ow + 1) grid the transposed conv writes
     dy = torch.randn_like(ref)
