@@ -378,7 +378,10 @@ def test_blur_kernels_ragged_height():
 
 
 @pytest.mark.parametrize("shape,pad,taps,flip", [((2, 3, 70, 130), [1, 1, 1, 1], [1, 3, 3, 1], False), ((1, 2, 129, 201), [2, 1, 0, 3], None, True),
-                                                 ((1, 4, 256, 256), [1, 1, 1, 1], [1, 3, 3, 1], True)])
+                                                 ((1, 4, 256, 256), [1, 1, 1, 1], [1, 3, 3, 1], True),
+                                                 # rows readable with 16-byte loads, the patch starting 2 / 3 / 0 columns off a 4-column boundary
+                                                 ((1, 2, 132, 200), [2, 1, 0, 3], None, True), ((2, 1, 66, 260), [3, 0, 1, 2], None, False),
+                                                 ((1, 3, 40, 128), [0, 2, 2, 0], [1, 3, 3, 1], False)])
 def test_upfirdn2d_down2_tiled_vs_oracle(shape, pad, taps, flip):
     """The LDS-tiled decimating kernel (down 2, <= 4x4 filter, >= 32 outputs per row): the gradient of the skip branch's 2x
     upsampling in gradient mode; ragged tiles, asymmetric padding and a non-separable filter included."""
