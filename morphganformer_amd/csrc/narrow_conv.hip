@@ -63,40 +63,57 @@ __global__ __launch_bounds__(256) void tconv3x3s2_few_outputs_kernel(float* __re
         ws[i] = o < CO ? wp[((int64_t)t * cin + c) * cout_pad + o] : 0.f;
     }
     __syncthreads();
-    const int n = blockIdx.z, i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;       // 256 x 1 quads: 1 KB pieces of every input plane
+    // 256 x 2 quads per workgroup (1 KB pieces of every input plane), a lane takes quads (i, j) and (i + 1, j): three input rows serve
+    // both and the weight image is read once per channel for the two (its broadcast reads are what bounds the kernel)
+    const int n = blockIdx.z, i = 2 * blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     if (j > w) return;
-    const bool r0 = i < h, r1 = i > 0, c0 = j < w, c1 = j > 0;         // x[i][.], x[i-1][.], x[.][j], x[.][j-1] exist
+    const bool c0 = j < w, c1 = j > 0;                                 // x[.][j], x[.][j-1] exist
+    const bool ra = i > 0, rb = i < h, rc = i + 1 < h;                 // rows i-1, i, i+1 of x exist
+    const bool q1 = i + 1 <= h;                                        // the second quad row exists
     const float* xb = x + (int64_t)n * cin * h * w + (int64_t)i * w + j;
     const int64_t plane = (int64_t)h * w;
-    float a00[CO], a01[CO], a10[CO], a11[CO];
+    float a00[2][CO], a01[2][CO], a10[2][CO], a11[2][CO];
 #pragma unroll
-    for (int o = 0; o < CO; ++o) a00[o] = a01[o] = a10[o] = a11[o] = 0.f;
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int o = 0; o < CO; ++o) a00[u][o] = a01[u][o] = a10[u][o] = a11[u][o] = 0.f;
 #pragma unroll 2
     for (int c = 0; c < cin; ++c) {
         const float* xc = xb + c * plane;
-        const float p = (r0 && c0) ? xc[0] : 0.f, q = (r0 && c1) ? xc[-1] : 0.f;              // x[i][j], x[i][j-1]
-        const float r = (r1 && c0) ? xc[-w] : 0.f, s = (r1 && c1) ? xc[-w - 1] : 0.f;         // x[i-1][j], x[i-1][j-1]
+        float xr[3][2];                                                // rows i-1, i, i+1; columns j, j-1
+        xr[0][0] = (ra && c0) ? xc[-w] : 0.f;    xr[0][1] = (ra && c1) ? xc[-w - 1] : 0.f;
+        xr[1][0] = (rb && c0) ? xc[0] : 0.f;     xr[1][1] = (rb && c1) ? xc[-1] : 0.f;
+        xr[2][0] = (rc && c0) ? xc[w] : 0.f;     xr[2][1] = (rc && c1) ? xc[w - 1] : 0.f;
         const float4* wc = reinterpret_cast<const float4*>(ws + c * 36);
         float wt[9][4];
 #pragma unroll
         for (int t = 0; t < 9; ++t) { const float4 f = wc[t]; wt[t][0] = f.x; wt[t][1] = f.y; wt[t][2] = f.z; wt[t][3] = f.w; }
 #pragma unroll
-        for (int o = 0; o < CO; ++o) {
-            a00[o] += wt[0][o] * p + wt[2][o] * q + wt[6][o] * r + wt[8][o] * s;
-            a01[o] += wt[1][o] * p + wt[7][o] * r;
-            a10[o] += wt[3][o] * p + wt[5][o] * q;
-            a11[o] += wt[4][o] * p;
+        for (int u = 0; u < 2; ++u) {
+            const float p = xr[u + 1][0], q = xr[u + 1][1], r = xr[u][0], s = xr[u][1];      // x[i'][j], x[i'][j-1], x[i'-1][j], x[i'-1][j-1]
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                a00[u][o] += wt[0][o] * p + wt[2][o] * q + wt[6][o] * r + wt[8][o] * s;
+                a01[u][o] += wt[1][o] * p + wt[7][o] * r;
+                a10[u][o] += wt[3][o] * p + wt[5][o] * q;
+                a11[u][o] += wt[4][o] * p;
+            }
         }
     }
-    float* yb = y + (int64_t)n * y_batch + (int64_t)(2 * i) * pitch + 2 * j;
 #pragma unroll
-    for (int o = 0; o < CO; ++o) {
-        float* yo = yb + o * y_plane;
-        if (c0) *reinterpret_cast<float2*>(yo) = make_float2(a00[o], a01[o]);
-        else yo[0] = a00[o];
-        if (r0) {
-            if (c0) *reinterpret_cast<float2*>(yo + pitch) = make_float2(a10[o], a11[o]);
-            else yo[pitch] = a10[o];
+    for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !q1) break;
+        const bool r0 = i + u < h;                                     // the quad's second output row exists
+        float* yb = y + (int64_t)n * y_batch + (int64_t)(2 * (i + u)) * pitch + 2 * j;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            float* yo = yb + o * y_plane;
+            if (c0) *reinterpret_cast<float2*>(yo) = make_float2(a00[u][o], a01[u][o]);
+            else yo[0] = a00[u][o];
+            if (r0) {
+                if (c0) *reinterpret_cast<float2*>(yo + pitch) = make_float2(a10[u][o], a11[u][o]);
+                else yo[pitch] = a10[u][o];
+            }
         }
     }
 }
@@ -134,7 +151,7 @@ extern "C" int mgf_tconv3x3s2_few_outputs_f32(float* y, const float* x, const fl
                 "tconv3x3s2_few_outputs: the output needs an even row pitch >= 2w+1, even plane / sample strides and an 8-byte aligned base");
     MGF_REQUIRE(n <= 65535 && (int64_t)cin * h * w <= INT32_MAX, MGF_ETOOBIG, "tconv3x3s2_few_outputs: tensor too large");
     MGF_REQUIRE(h < 65535, MGF_ETOOBIG, "tconv3x3s2_few_outputs: at most 65534 input rows");
-    const dim3 grid((unsigned)mgf_cdiv(w + 1, 256), (unsigned)(h + 1), n);
+    const dim3 grid((unsigned)mgf_cdiv(w + 1, 256), (unsigned)mgf_cdiv(h + 1, 2), n);
     hipStream_t st = (hipStream_t)stream;
 #define MGF_TCF_LAUNCH(CO) \
     hipLaunchKernelGGL(tconv3x3s2_few_outputs_kernel<CO>, grid, dim3(256), (size_t)cin * 36 * sizeof(float), st, y, x, wp, cin, h, w, cout_pad, pitch, y_plane, y_batch)
