@@ -273,6 +273,56 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(PwParams p) {
     }
 }
 
+// cin <= 4 (ToRGB's data gradient: 3 -> 32 channels): every output row is a combination of <= 4 input rows held in registers -- a
+// stream of stores, PX pixels per lane.
+template <bool VEC>
+__global__ __launch_bounds__(256) void pw_few_inputs_kernel(PwParams p) {
+    constexpr int PX = VEC ? 4 : 1;
+    const int n = blockIdx.y;
+    const int64_t px0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PX;
+    if (px0 >= p.hw) return;
+    const float* __restrict__ xb = p.x + (int64_t)n * p.cin * p.hw + px0;
+    typedef const float __attribute__((address_space(4)))* cfp;
+    const cfp w = (cfp)p.w;
+    float v[4][PX];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int kc = min(k, p.cin - 1);
+        const float s = k < p.cin ? (p.in_scale ? p.in_scale[(int64_t)n * p.cin + kc] : 1.f) : 0.f;
+        if (VEC) {
+            const float4 q = *reinterpret_cast<const float4*>(xb + (int64_t)kc * p.hw);
+            v[k][0] = q.x * s; v[k][PX > 1 ? 1 : 0] = q.y * s; v[k][PX > 2 ? 2 : 0] = q.z * s; v[k][PX > 3 ? 3 : 0] = q.w * s;
+        } else {
+            v[k][0] = xb[(int64_t)kc * p.hw] * s;
+        }
+    }
+    const bool do_ep = p.has_ep != 0;
+    const float slope = !do_ep ? 1.f : (p.ep.act == MGF_ACT_LRELU ? p.ep.alpha : (p.ep.act == MGF_ACT_RELU ? 0.f : 1.f));
+    const float gain = do_ep ? p.ep.gain : 1.f;
+    const int64_t ybase = (int64_t)n * p.y_batch + (int64_t)p.y_choff * p.hw + px0;
+    const int k1 = p.cin > 1 ? p.cout_pad : 0, k2 = p.cin > 2 ? 2 * p.cout_pad : 0, k3 = p.cin > 3 ? 3 * p.cout_pad : 0;
+#pragma unroll 4
+    for (int o = 0; o < p.cout; ++o) {
+        const float w0 = w[o], w1 = w[k1 + o], w2 = w[k2 + o], w3 = w[k3 + o];          // (rows past cin carry zeros in v)
+        const float bv = (do_ep && p.ep.bias) ? p.ep.bias[o] : 0.f;
+        float r[PX];
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+            float t = ((w0 * v[0][e] + w1 * v[1][e]) + w2 * v[2][e]) + w3 * v[3][e] + bv;
+            t = t > 0.f ? t : t * slope;
+            r[e] = t * gain;
+        }
+        float* yo = p.y + ybase + (int64_t)o * p.hw;
+        if (VEC) {
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (do_ep && p.ep.residual) q = *reinterpret_cast<const float4*>(p.ep.residual + ybase + (int64_t)o * p.hw);
+            *reinterpret_cast<float4*>(yo) = make_float4(r[0] + q.x, r[PX > 1 ? 1 : 0] + q.y, r[PX > 2 ? 2 : 0] + q.z, r[PX > 3 ? 3 : 0] + q.w);
+        } else {
+            yo[0] = r[0] + ((do_ep && p.ep.residual) ? p.ep.residual[ybase + (int64_t)o * p.hw] : 0.f);
+        }
+    }
+}
+
 template <int CB, int WCO, int WK = 1>
 void pw_launch(const PwParams& p, bool vec, dim3 grid, hipStream_t st) {
     if (vec) hipLaunchKernelGGL((pw_conv_kernel<CB, WCO, WK, true>), grid, dim3(256), 0, st, p);
@@ -319,6 +369,17 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
         const dim3 grid((unsigned)mgf_cdiv(hw, vec ? 1024 : 256), n);
         if (vec) hipLaunchKernelGGL(pw_narrow_kernel<true>, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(pw_narrow_kernel<false>, grid, dim3(256), 0, st, p);
+        mgf_prof_external_end(st);
+        MGF_CHECK_LAUNCH("conv1x1");
+        return MGF_OK;
+    }
+    if (cin <= 4 && cout > 4 && !narrow_off && n <= 65535) {
+        hipStream_t st = (hipStream_t)stream;
+        mgf_prof_external_begin(st, "pw_few_inputs_kernel", 2.0 * cin * (double)cout * hw * n,
+                                4.0 * ((double)n * cin * hw + (double)cin * cout + (double)n * cout * hw * ((ep && ep->residual) ? 2 : 1)));
+        const dim3 grid((unsigned)mgf_cdiv(hw, vec ? 1024 : 256), n);
+        if (vec) hipLaunchKernelGGL(pw_few_inputs_kernel<true>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(pw_few_inputs_kernel<false>, grid, dim3(256), 0, st, p);
         mgf_prof_external_end(st);
         MGF_CHECK_LAUNCH("conv1x1");
         return MGF_OK;

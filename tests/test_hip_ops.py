@@ -245,7 +245,10 @@ def test_conv_taps_vs_torch(n, cin, cout, res, k, stride, pad):
     (1, 256, 128, 128, 128, 128, 0, "linear", False),
     (2, 32, 3, 64, 64, 3, 0, "linear", False),        # ToRGB outside the fused launch: the narrow-output streaming kernel, 16-byte path
     (2, 13, 3, 9, 13, 8, 2, "lrelu", True),           # ... scalar path, cin not a multiple of its 8-row sweep, residual on a slice
-    (1, 64, 4, 32, 36, 4, 0, "relu", True)])          # ... four outputs
+    (1, 64, 4, 32, 36, 4, 0, "relu", True),           # ... four outputs
+    (2, 3, 32, 64, 64, 32, 0, "linear", False),       # ToRGB's data gradient: the few-inputs streaming kernel, 16-byte path
+    (1, 4, 37, 9, 13, 50, 5, "lrelu", True),          # ... scalar path, four inputs, ragged outputs into a slice with a residual
+    (2, 1, 8, 16, 16, 8, 0, "relu", False)])          # ... one input
 def test_conv1x1_register_gemm_vs_torch_and_tap_list(n, cin, cout, h, w, ctotal, choff, act, res, monkeypatch):
     """csrc/pointwise.hip (what conv_forward runs for un-modulated 1x1 layers) vs torch CPU conv2d and vs the tap-list kernel."""
     from morphganformer_amd import _lib, conv as cv
