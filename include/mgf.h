@@ -496,6 +496,12 @@ int mgf_lpips_layer_bwd_relu_f32(float* dz_a, float* dz_b, const float* dy, cons
                                  mgf_stream_t stream);
 int mgf_relu_bwd_split_f32(float* dz_a, float* dz_b, const float* dy, const float* y, int32_t n, int32_t c, int32_t c_split, int64_t hw,
                            mgf_stream_t stream);
+/* The same gradient from tap indices stored by the forward (mgf_maxpool3x3s2_ceil_idx_f32: y as mgf_maxpool3x3s2_ceil_f32 plus, per
+ * output, the row-major index 0..8 of the window's first maximum): neither the input map nor the window scan is needed. */
+int mgf_maxpool3x3s2_ceil_idx_f32(float* y, uint8_t* idx, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h,
+                                  int32_t out_w, mgf_stream_t stream);
+int mgf_maxpool3x3s2_ceil_bwd_idx_f32(float* dx, const float* dy, const uint8_t* idx, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h,
+                                      int32_t out_w, mgf_stream_t stream);
 int mgf_maxpool3x3s2_ceil_bwd_f32(float* dx, const float* dy, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h,
                                   int32_t out_w, mgf_stream_t stream);
 /* dx of mgf_maxpool_s2_floor_f32 (ksize 2 or 3), first-maximum rule */

@@ -1218,6 +1218,62 @@ extern "C" int mgf_relu_bwd_split_f32(float* dz_a, float* dz_b, const float* dy,
     return MGF_OK;
 }
 
+namespace {
+// dx of the 3x3 / stride-2 ceil-mode pool from the forward's stored tap indices: one lane per 2 x 2 input block (2 bi, 2 bj) + {0,1}^2,
+// whose elements sit at fixed taps of the <= 4 windows around it -- (0,0): tap 8 of window (bi-1, bj-1), 6 of (bi-1, bj), 2 of
+// (bi, bj-1), 0 of (bi, bj); (0,1): 7 of (bi-1, bj), 1 of (bi, bj); (1,0): 5 of (bi, bj-1), 3 of (bi, bj); (1,1): 4 of (bi, bj) --
+// summed in ascending window order like torch.  No LDS, no input map: a stream of stores.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_idx_kernel(float* __restrict__ dx, const float* __restrict__ dy,
+                                                                   const uint8_t* __restrict__ idx, int ih, int iw, int oh, int ow) {
+    const int bj = blockIdx.x * 256 + threadIdx.x, bi = blockIdx.y;
+    const int64_t pl = blockIdx.z;
+    const int yy = 2 * bi, xx = 2 * bj;
+    if (xx >= iw) return;
+    const float* dp = dy + pl * oh * ow;
+    const uint8_t* ip = idx + pl * oh * ow;
+    float g[2][2];
+    int t[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int oy = bi - 1 + a, ox = bj - 1 + b;
+            const bool in = oy >= 0 && ox >= 0 && oy < oh && ox < ow;
+            g[a][b] = in ? dp[(int64_t)oy * ow + ox] : 0.f;
+            t[a][b] = in ? (int)ip[(int64_t)oy * ow + ox] : -1;
+        }
+    float e00 = 0.f, e01 = 0.f, e10 = 0.f, e11 = 0.f;
+    if (t[0][0] == 8) e00 += g[0][0];
+    if (t[0][1] == 6) e00 += g[0][1];
+    if (t[1][0] == 2) e00 += g[1][0];
+    if (t[1][1] == 0) e00 += g[1][1];
+    if (t[0][1] == 7) e01 += g[0][1];
+    if (t[1][1] == 1) e01 += g[1][1];
+    if (t[1][0] == 5) e10 += g[1][0];
+    if (t[1][1] == 3) e10 += g[1][1];
+    if (t[1][1] == 4) e11 += g[1][1];
+    float* o = dx + pl * ih * iw + (int64_t)yy * iw + xx;
+    const bool x1 = xx + 1 < iw;
+    o[0] = e00;
+    if (x1) o[1] = e01;
+    if (yy + 1 < ih) {
+        o[iw] = e10;
+        if (x1) o[iw + 1] = e11;
+    }
+}
+}  // namespace
+
+extern "C" int mgf_maxpool3x3s2_ceil_bwd_idx_f32(float* dx, const float* dy, const uint8_t* idx, int32_t nc, int32_t in_h, int32_t in_w,
+                                                 int32_t out_h, int32_t out_w, mgf_stream_t stream) {
+    MGF_REQUIRE(dx && dy && idx && nc >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, MGF_EINVAL, "maxpool3x3s2_ceil_bwd_idx: bad arguments");
+    MGF_REQUIRE(2 * (out_h - 1) < in_h && 2 * (out_w - 1) < in_w, MGF_EINVAL, "maxpool3x3s2_ceil_bwd_idx: output extent does not match the input");
+    MGF_REQUIRE(nc <= 65535 && (in_h + 1) / 2 <= 65535, MGF_ETOOBIG, "maxpool3x3s2_ceil_bwd_idx: at most 65535 planes and 131070 rows");
+    const dim3 grid((unsigned)mgf_cdiv((in_w + 1) / 2, 256), (unsigned)((in_h + 1) / 2), nc);
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_idx_kernel, grid, dim3(256), 0, (hipStream_t)stream, dx, dy, idx, in_h, in_w, out_h, out_w);
+    MGF_CHECK_LAUNCH("maxpool3x3s2_ceil_bwd_idx");
+    return MGF_OK;
+}
+
 extern "C" int mgf_maxpool3x3s2_ceil_bwd_f32(float* dx, const float* dy, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h,
                                              int32_t out_w, mgf_stream_t stream) {
     MGF_REQUIRE(dx && dy && x && nc >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, MGF_EINVAL, "maxpool3x3s2_ceil_bwd: bad arguments");

@@ -201,8 +201,11 @@ __global__ __launch_bounds__(256) void awing_kernel(double* out, const double* p
 // K x K window, stride 2, windows clipped at the bottom/right edge (ceil_mode partial windows).  A workgroup covers 4 output rows of one
 // plane; a thread produces TWO adjacent outputs from a K x (K + 2) input window, so a wave reads 3 contiguous row segments (every byte
 // of them used) and no index needs a division per element (one per workgroup row).  HBM-bound: in + out bytes once.
-template <int K>
-__global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, int nc, int in_h, int in_w, int out_h, int out_w) {
+// IDX (K = 3): also the window's first maximum in row-major order as a tap index 0..8 (torch's rule for the gradient), one byte per
+// output -- gradient mode's backward then needs neither the input map nor the 9-tap scan (mgf_maxpool3x3s2_ceil_bwd_idx_f32).
+template <int K, bool IDX = false>
+__global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, int nc, int in_h, int in_w, int out_h, int out_w,
+                                                      uint8_t* idx = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);              // (plane, output row) flattened
     if (row >= nc * out_h) return;
     const int pl = row / out_h, oy = row - pl * out_h;
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, 
     const int lane = threadIdx.x & 63;
     for (int ox = 2 * lane; ox < out_w; ox += 128) {
         float m0 = -3.0e38f, m1 = -3.0e38f;
+        int t0 = 0, t1 = 0;
 #pragma unroll
         for (int dy = 0; dy < K; ++dy) {
             const int iy = oy * 2 + dy;
@@ -220,10 +224,21 @@ __global__ __launch_bounds__(256) void maxpool_kernel(float* y, const float* x, 
 #pragma unroll
             for (int dx = 0; dx < K + 2; ++dx) v[dx] = (2 * ox + dx < in_w) ? rp[dx] : -3.0e38f;
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) { m0 = fmaxf(m0, v[dx]); m1 = fmaxf(m1, v[dx + 2]); }
+            for (int dx = 0; dx < K; ++dx) {
+                if (IDX) {                                               // strict >: the first maximum wins; tap (0, 0) always exists
+                    if (v[dx] > m0) { m0 = v[dx]; t0 = dy * K + dx; }
+                    if (v[dx + 2] > m1) { m1 = v[dx + 2]; t1 = dy * K + dx; }
+                } else {
+                    m0 = fmaxf(m0, v[dx]); m1 = fmaxf(m1, v[dx + 2]);
+                }
+            }
         }
         yp[ox] = m0;
-        if (ox + 1 < out_w) yp[ox + 1] = m1;
+        if (IDX) idx[((int64_t)pl * out_h + oy) * out_w + ox] = (uint8_t)t0;
+        if (ox + 1 < out_w) {
+            yp[ox + 1] = m1;
+            if (IDX) idx[((int64_t)pl * out_h + oy) * out_w + ox + 1] = (uint8_t)t1;
+        }
     }
 }
 
@@ -389,6 +404,19 @@ extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, i
     hipLaunchKernelGGL(maxpool_kernel<3>, dim3((unsigned)mgf_cdiv((int64_t)nc * out_h, 4)), dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w,
                        out_h, out_w);
     MGF_CHECK_LAUNCH("maxpool");
+    return MGF_OK;
+}
+
+extern "C" int mgf_maxpool3x3s2_ceil_idx_f32(float* y, uint8_t* idx, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h,
+                                             int32_t out_w, mgf_stream_t stream) {
+    MGF_REQUIRE(y && idx && x && nc >= 1 && in_h >= 1 && in_w >= 1, MGF_EINVAL, "maxpool_idx: bad arguments");
+    auto osz = [](int in) { int o = (in - 3 + 1) / 2 + 1; if ((o - 1) * 2 >= in) --o; return o; };
+    MGF_REQUIRE(out_h == osz(in_h) && out_w == osz(in_w), MGF_EINVAL, "maxpool_idx: output must be %dx%d (got %dx%d)", osz(in_h), osz(in_w),
+                out_h, out_w);
+    MGF_REQUIRE((int64_t)nc * out_h <= INT32_MAX - 4, MGF_ETOOBIG, "maxpool_idx: too many rows");
+    hipLaunchKernelGGL((maxpool_kernel<3, true>), dim3((unsigned)mgf_cdiv((int64_t)nc * out_h, 4)), dim3(256), 0, (hipStream_t)stream, y, x, nc,
+                       in_h, in_w, out_h, out_w, idx);
+    MGF_CHECK_LAUNCH("maxpool_idx");
     return MGF_OK;
 }
 

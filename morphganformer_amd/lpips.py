@@ -38,6 +38,9 @@ USE_WINOGRAD_LPIPS = os.environ.get("MGF_WINOGRAD_LPIPS", "1") != "0"
 # a tap's distance gradient and the backward of the ReLU whose output the tap is, in one pass (mgf_lpips_layer_bwd_relu_f32);
 # 0: the two kernels in sequence (experiments / the equivalence test)
 FUSE_TAP_RELU = os.environ.get("MGF_FUSE_TAP_RELU", "1") != "0"
+# gradient mode: SqueezeNet's pools store their winning taps in the forward and the backward reads those (0: argmax recomputed from the
+# input map in the backward; experiments / the equivalence test)
+POOL_ARGMAX = os.environ.get("MGF_POOL_ARGMAX", "1") != "0"
 
 
 def random_squeeze_backbone(seed=0):
@@ -262,6 +265,7 @@ class SqueezeFeatures:
         self.shapes = {1: (64, hh, ww)}
         self.buf = {1: e(n, 64, hh, ww)}
         self.sq = {}
+        self.pidx, self.have_argmax = {}, False          # winning taps of the pools (uint8), kept by forwards run with argmax=True
         c = 64
         for idx in range(2, 13):
             if idx in POOLS:
@@ -325,8 +329,12 @@ class SqueezeFeatures:
                 return cv.tconv3x3s2_forward(gh, self.gp["c0"], out=self.gimg)
             if idx in POOLS:
                 x = self.buf[idx - 1]
-                _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_f32(self.gbuf[idx - 1].data_ptr(), gh.data_ptr(), x.data_ptr(), n * c, x.shape[2],
-                                                           x.shape[3], hh, ww, st), "maxpool_bwd")
+                if self.have_argmax:
+                    _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_idx_f32(self.gbuf[idx - 1].data_ptr(), gh.data_ptr(), self.pidx[idx].data_ptr(), n * c,
+                                                                   x.shape[2], x.shape[3], hh, ww, st), "maxpool_bwd_idx")
+                else:
+                    _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_f32(self.gbuf[idx - 1].data_ptr(), gh.data_ptr(), x.data_ptr(), n * c, x.shape[2],
+                                                               x.shape[3], hh, ww, st), "maxpool_bwd")
                 continue
             sqT, e1T, e3T = self.gp[idx]
             ex = FIRES[idx][2]
@@ -356,7 +364,7 @@ class SqueezeFeatures:
                                                  _lib.ptr(scratch), _lib.stream_ptr()), "lpips_stem")
         return self.buf[2]
 
-    def __call__(self, x, out=None, from_pooled=False):
+    def __call__(self, x, out=None, from_pooled=False, argmax=False):
         """x: [n,3,h,w] in [-1,1] (un-scaled; ScalingLayer is folded).  Returns the list of 7 tap tensors
         (views of the internal workspace unless `out` -- a list of 7 preallocated tensors -- is given).
         from_pooled=True: `stem()` already produced the first pooled map; tap 0 is not materialised (entry 0 is None)."""
@@ -365,6 +373,7 @@ class SqueezeFeatures:
         st = _lib.stream_ptr()
         taps = []
         k = 0
+        self.have_argmax = bool(argmax) and not from_pooled and POOL_ARGMAX
 
         def dest(idx):
             nonlocal k
@@ -386,7 +395,15 @@ class SqueezeFeatures:
             if idx in POOLS:
                 y = self.buf[idx]
                 n, c, ih, iw = h.shape
-                _lib.check(L.mgf_maxpool3x3s2_ceil_f32(y.data_ptr(), h.data_ptr(), n * c, ih, iw, y.shape[2], y.shape[3], st), "maxpool")
+                if self.have_argmax:
+                    # gradient mode: the pool also stores each window's winning tap (one byte per output), so that its backward reads
+                    # neither the input map nor scans the windows again
+                    if idx not in self.pidx:
+                        self.pidx[idx] = torch.empty(y.shape, dtype=torch.uint8, device=y.device)
+                    _lib.check(L.mgf_maxpool3x3s2_ceil_idx_f32(y.data_ptr(), self.pidx[idx].data_ptr(), h.data_ptr(), n * c, ih, iw, y.shape[2],
+                                                               y.shape[3], st), "maxpool_idx")
+                else:
+                    _lib.check(L.mgf_maxpool3x3s2_ceil_f32(y.data_ptr(), h.data_ptr(), n * c, ih, iw, y.shape[2], y.shape[3], st), "maxpool")
                 h = y
             else:
                 (ps, bs), (p1, b1), (p3, b3) = self.fires[idx]
@@ -512,7 +529,7 @@ class PerceptualLoss(torch.nn.Module):
             f.stem(pred.contiguous(), feat_ref=self._target_taps[0], lin=self.lins[0], dist_out=out, scratch=self._scratch)
             taps = f(pred, from_pooled=True)
         else:
-            taps = f(pred)
+            taps = f(pred, argmax=True) if (keep_taps and self.net == "squeeze") else f(pred)
         L, st = _lib.lib(), _lib.stream_ptr()
         for i, (a, b, lin) in enumerate(zip(taps, self._target_taps, self.lins)):
             if a is None:

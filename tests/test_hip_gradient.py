@@ -351,6 +351,16 @@ def test_mse_grad_and_pool_bwd():
         _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_f32(dx.data_ptr(), dyd.data_ptr(), xd.data_ptr(), shape[0] * shape[1], shape[2], shape[3],
                                                    y.shape[2], y.shape[3], _lib.stream_ptr()))
         assert torch.equal(dx.cpu(), ref), shape
+        # the forward that stores each window's winning tap + the backward that reads those: same y as the plain forward, same dx
+        yd, yi = torch.empty_like(dyd), torch.empty_like(dyd)
+        taps = torch.full(dyd.shape, 255, dtype=torch.uint8, device="cuda")
+        pargs = (shape[0] * shape[1], shape[2], shape[3], y.shape[2], y.shape[3], _lib.stream_ptr())
+        _lib.check(L.mgf_maxpool3x3s2_ceil_f32(yd.data_ptr(), xd.data_ptr(), *pargs))
+        _lib.check(L.mgf_maxpool3x3s2_ceil_idx_f32(yi.data_ptr(), taps.data_ptr(), xd.data_ptr(), *pargs))
+        assert torch.equal(yd, yi) and torch.equal(yi.cpu(), y.detach()) and int(taps.max()) <= 8
+        dx2 = torch.full_like(xd, float("nan"))
+        _lib.check(L.mgf_maxpool3x3s2_ceil_bwd_idx_f32(dx2.data_ptr(), dyd.data_ptr(), taps.data_ptr(), *pargs))
+        assert torch.equal(dx2.cpu(), ref), shape
     # forward pooling, both entries, odd and even sides, wider than one wave's 128 columns: bit-exact
     for (c, hh, ww) in ((3, 15, 12), (2, 31, 301), (1, 8, 257), (5, 2, 3)):
         xf = torch.randn(2, c, hh, ww)
