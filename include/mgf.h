@@ -494,6 +494,14 @@ int mgf_lpips_layer_bwd_f32(float* df0, const float* f0, const float* f1_unit, c
 int mgf_lpips_layer_bwd_relu_f32(float* dz_a, float* dz_b, const float* dy, const float* f0, const float* f1_unit, const float* lin,
                                  int32_t n, int32_t c, int32_t c_split, int64_t hw, int64_t f1_batch_stride, float scale,
                                  mgf_stream_t stream);
+/* The pair that shares the per-pixel sums: mgf_lpips_layer_stats_f32 is mgf_lpips_layer_f32 that also writes stats [n][3][hw] =
+ * (sum_c f0^2, sum_c lin f0^2, sum_c lin f1_unit f0) (NULL: none); mgf_lpips_layer_bwd_relu_stats_f32 reads them instead of sweeping
+ * both feature maps for them (NULL: as mgf_lpips_layer_bwd_relu_f32). */
+int mgf_lpips_layer_stats_f32(float* out, float* stats, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c,
+                              int64_t hw, int64_t f1_batch_stride, int32_t accumulate, float* scratch, mgf_stream_t stream);
+int mgf_lpips_layer_bwd_relu_stats_f32(float* dz_a, float* dz_b, const float* dy, const float* f0, const float* f1_unit, const float* lin,
+                                       const float* stats, int32_t n, int32_t c, int32_t c_split, int64_t hw, int64_t f1_batch_stride,
+                                       float scale, mgf_stream_t stream);
 int mgf_relu_bwd_split_f32(float* dz_a, float* dz_b, const float* dy, const float* y, int32_t n, int32_t c, int32_t c_split, int64_t hw,
                            mgf_stream_t stream);
 /* The same gradient from tap indices stored by the forward (mgf_maxpool3x3s2_ceil_idx_f32: y as mgf_maxpool3x3s2_ceil_f32 plus, per

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void latent_grad_gather_kernel(float* dw, cons
 template <int PXB, bool RELU, int CPT>
 __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* oa, float* ob, const float* din, const float* f0, const float* f1u,
                                                               const float* lin, int c, int c_split, int64_t hw, int64_t f1_bs, float k,
-                                                              int accumulate) {
+                                                              int accumulate, const float* stats) {
     // a workgroup owns PXB consecutive pixels; its G = 256 / PXB lane groups split the channels and meet in LDS
     constexpr int G = 256 / PXB;
     constexpr int NV = CPT > 0 ? CPT : 1;
@@ -709,6 +709,11 @@ __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* oa, float* 
     const float* b = f1u + (int64_t)n * f1_bs + pc;
     float va[NV], vb[NV];
     float A = 0.f, B = 0.f, Cc = 0.f;
+    // stats: the per-pixel sums A, B, C of the forward (mgf_lpips_layer_stats_f32, [n][3][hw]) -- no first sweep, no meeting in LDS
+    if (CPT == 0 && stats) {
+        const float* sp = stats + (int64_t)n * 3 * hw + pc;
+        A = sp[0]; B = sp[hw]; Cc = sp[2 * hw];
+    } else {
     if (CPT > 0) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -738,6 +743,7 @@ __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* oa, float* 
     A = B = Cc = 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) { A += part[0][g][px]; B += part[1][g][px]; Cc += part[2][g][px]; }
+    }
     const float nrm = sqrtf(A);
     const float q = 1.f / (nrm + 1e-10f);
     const float dot = k * (q * B - Cc);
@@ -1168,18 +1174,18 @@ extern "C" int mgf_latent_grad_gather(float* dw, const float* dwg, int32_t n_sty
 // MGF_LPIPS_BWD_CACHE=0 turns the register-resident second sweep off (tuning).
 template <bool RELU>
 static void lpips_bwd_launch(float* oa, float* ob, const float* din, const float* f0, const float* f1u, const float* lin, int n, int c,
-                             int c_split, int64_t hw, int64_t f1_bs, float k, int accumulate, hipStream_t st) {
+                             int c_split, int64_t hw, int64_t f1_bs, float k, int accumulate, hipStream_t st, const float* stats = nullptr) {
     static const int env_pxb = [] { const char* e = getenv("MGF_LPIPS_BWD_PXB"); return e ? atoi(e) : 0; }();
     int pxb = mgf_cdiv(hw, 64) * n >= 512 ? 64 : mgf_cdiv(hw, 32) * n >= 256 ? 32 : 16;
     if (env_pxb == 16 || env_pxb == 32 || env_pxb == 64) pxb = env_pxb;
     static const bool no_cache = [] { const char* e = getenv("MGF_LPIPS_BWD_CACHE"); return e && e[0] == '0'; }();
     const dim3 grid((unsigned)mgf_cdiv(hw, pxb), n);
-#define MGF_LPB_LAUNCH(PX, CP) hipLaunchKernelGGL((lpips_layer_bwd_kernel<PX, RELU, CP>), grid, dim3(256), 0, st, oa, ob, din, f0, f1u, lin, c, c_split, hw, f1_bs, k, accumulate)
+#define MGF_LPB_LAUNCH(PX, CP) hipLaunchKernelGGL((lpips_layer_bwd_kernel<PX, RELU, CP>), grid, dim3(256), 0, st, oa, ob, din, f0, f1u, lin, c, c_split, hw, f1_bs, k, accumulate, stats)
     if (pxb == 64) {
-        if (c <= 64 && !no_cache) MGF_LPB_LAUNCH(64, 16);
+        if (c <= 64 && !no_cache && !stats) MGF_LPB_LAUNCH(64, 16);
         else MGF_LPB_LAUNCH(64, 0);
     } else if (pxb == 32) {
-        if (c <= 128 && !no_cache) MGF_LPB_LAUNCH(32, 16);
+        if (c <= 128 && !no_cache && !stats) MGF_LPB_LAUNCH(32, 16);
         else MGF_LPB_LAUNCH(32, 0);
     } else MGF_LPB_LAUNCH(16, 0);
 #undef MGF_LPB_LAUNCH
@@ -1198,11 +1204,17 @@ extern "C" int mgf_lpips_layer_bwd_f32(float* df0, const float* f0, const float*
 extern "C" int mgf_lpips_layer_bwd_relu_f32(float* dz_a, float* dz_b, const float* dy, const float* f0, const float* f1_unit,
                                             const float* lin, int32_t n, int32_t c, int32_t c_split, int64_t hw, int64_t f1_batch_stride,
                                             float scale, mgf_stream_t stream) {
+    return mgf_lpips_layer_bwd_relu_stats_f32(dz_a, dz_b, dy, f0, f1_unit, lin, nullptr, n, c, c_split, hw, f1_batch_stride, scale, stream);
+}
+
+extern "C" int mgf_lpips_layer_bwd_relu_stats_f32(float* dz_a, float* dz_b, const float* dy, const float* f0, const float* f1_unit,
+                                                  const float* lin, const float* stats, int32_t n, int32_t c, int32_t c_split, int64_t hw,
+                                                  int64_t f1_batch_stride, float scale, mgf_stream_t stream) {
     MGF_REQUIRE(dz_a && f0 && f1_unit && lin && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer_bwd_relu: bad arguments");
     MGF_REQUIRE(c_split >= 1 && c_split <= c && (dz_b || c_split == c), MGF_EINVAL, "lpips_layer_bwd_relu: bad split %d of %d channels", c_split, c);
     MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "lpips_layer_bwd_relu: n must be <= 65535");
     const float kk = 2.f * scale / (float)hw;
-    lpips_bwd_launch<true>(dz_a, dz_b, dy, f0, f1_unit, lin, n, c, c_split, hw, f1_batch_stride, kk, 0, (hipStream_t)stream);
+    lpips_bwd_launch<true>(dz_a, dz_b, dy, f0, f1_unit, lin, n, c, c_split, hw, f1_batch_stride, kk, 0, (hipStream_t)stream, stats);
     MGF_CHECK_LAUNCH("lpips_layer_bwd_relu");
     return MGF_OK;
 }

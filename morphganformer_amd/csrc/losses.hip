@@ -57,9 +57,10 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(float* scratch, const 
 template <int PXB, int CPT, bool UNIT_OUT>
 __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float* unit_out, const float* f0, const float* f1u,
                                                            const float* lin, int c, int64_t hw, int64_t f1_stride, int nsamp, int nblk,
-                                                           int xcd_per) {
+                                                           int xcd_per, float* stats) {
     constexpr int G = 256 / PXB;
     __shared__ float red[G][PXB];
+    __shared__ float redb[G][PXB], redc[G][PXB];      // stats only: the two other per-pixel sums the gradient needs
     __shared__ float sm[4];
     const int px = threadIdx.x % PXB, grp = threadIdx.x / PXB;
     // work order: XCD b % 8 walks a contiguous item range with the SAMPLE as the fastest index -- the n candidates of a pixel block read
@@ -91,10 +92,31 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
 #pragma unroll
     for (int j = 0; j < CPT; ++j) na += u[j] * u[j];
     red[grp][px] = na;
+    // stats (gradient mode): A = sum f0^2, B = sum lin f0^2, C = sum lin u1 f0 per pixel -> [n][3][hw]; the backward
+    // (mgf_lpips_layer_bwd_relu_f32) then skips its own sweep over both maps for them
+    if (!UNIT_OUT && stats) {
+        float nb = 0.f, nc = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int k = grp + j * G;
+            const float l = k < c ? lin[k] : 0.f;
+            nb += l * u[j] * u[j];
+            nc += l * v[UNIT_OUT ? 0 : j] * u[j];
+        }
+        redb[grp][px] = nb;
+        redc[grp][px] = nc;
+    }
     __syncthreads();
     na = 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) na += red[g][px];
+    if (!UNIT_OUT && stats && grp == 0 && valid) {
+        float nb = 0.f, nc = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) { nb += redb[g][px]; nc += redc[g][px]; }
+        float* so = stats + (int64_t)nn * 3 * hw + i;
+        so[0] = na; so[hw] = nb; so[2 * hw] = nc;
+    }
     const float ia = 1.f / (sqrtf(na) + 1e-10f);
     if (UNIT_OUT) {
         float* o = unit_out + (int64_t)nn * c * hw + pp;
@@ -123,7 +145,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
 
 template <bool UNIT_OUT>
 int launch_lpips_layer(float* scratch, float* unit_out, const float* f0, const float* f1u, const float* lin, int n, int c, int64_t hw,
-                       int64_t f1_stride, hipStream_t st, int* grid_out) {
+                       int64_t f1_stride, hipStream_t st, int* grid_out, float* stats = nullptr) {
     // 64 pixels per workgroup (256-byte segments) whenever that still yields >= 4 workgroups per CU, 16 for the small deep taps
     static const int pxb_env = [] { const char* e = getenv("MGF_LPIPS_PXB"); return e ? atoi(e) : 0; }();      // tuning hook: 16 | 32 | 64
     // (64-pixel blocks only up to 128 channels = 32 values per thread: with 64 values per thread the 256-channel tap at 127^2 ran at
@@ -140,7 +162,7 @@ int launch_lpips_layer(float* scratch, float* unit_out, const float* f0, const f
     const int xcd_per = (int)mgf_cdiv(grid64 * n, 8);
     const dim3 grid((unsigned)(xcd_per * 8));
     *grid_out = (int)grid64;
-#define MGF_LPIPS_LAUNCH(PXB, CPT) hipLaunchKernelGGL((lpips_layer_kernel<PXB, CPT, UNIT_OUT>), grid, dim3(256), 0, st, scratch, unit_out, f0, f1u, lin, c, hw, f1_stride, n, (int)grid64, xcd_per)
+#define MGF_LPIPS_LAUNCH(PXB, CPT) hipLaunchKernelGGL((lpips_layer_kernel<PXB, CPT, UNIT_OUT>), grid, dim3(256), 0, st, scratch, unit_out, f0, f1u, lin, c, hw, f1_stride, n, (int)grid64, xcd_per, stats)
     if (pxb == 64) {
         if (c <= 128) MGF_LPIPS_LAUNCH(64, 32); else if (c <= 256) MGF_LPIPS_LAUNCH(64, 64); else MGF_LPIPS_LAUNCH(64, 128);
     } else if (pxb == 32) {
@@ -364,10 +386,15 @@ extern "C" int mgf_lpips_unit_f32(float* out, const float* f, int32_t n, int32_t
 
 extern "C" int mgf_lpips_layer_f32(float* out, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c, int64_t hw,
                                    int64_t f1_batch_stride, int32_t accumulate, float* scratch, mgf_stream_t stream) {
+    return mgf_lpips_layer_stats_f32(out, nullptr, f0, f1_unit, lin, n, c, hw, f1_batch_stride, accumulate, scratch, stream);
+}
+
+extern "C" int mgf_lpips_layer_stats_f32(float* out, float* stats, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c,
+                                         int64_t hw, int64_t f1_batch_stride, int32_t accumulate, float* scratch, mgf_stream_t stream) {
     MGF_REQUIRE(out && f0 && f1_unit && lin && scratch && n >= 1 && n <= 65535 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
-    const int rc = launch_lpips_layer<false>(scratch, nullptr, f0, f1_unit, lin, n, c, hw, f1_batch_stride, st, &grid);
+    const int rc = launch_lpips_layer<false>(scratch, nullptr, f0, f1_unit, lin, n, c, hw, f1_batch_stride, st, &grid, stats);
     if (rc != MGF_OK) return rc;
     // spatial mean per sample (networks_basic.py:85-87)
     hipLaunchKernelGGL(finish_kernel, dim3(n), dim3(256), 0, st, out, scratch, grid, 1.0f / (float)hw, accumulate);

@@ -41,6 +41,8 @@ FUSE_TAP_RELU = os.environ.get("MGF_FUSE_TAP_RELU", "1") != "0"
 # gradient mode: SqueezeNet's pools store their winning taps in the forward and the backward reads those (0: argmax recomputed from the
 # input map in the backward; experiments / the equivalence test)
 POOL_ARGMAX = os.environ.get("MGF_POOL_ARGMAX", "1") != "0"
+# gradient mode: the tap distances also store their per-pixel sums and the tap gradients read them instead of sweeping both maps again
+TAP_STATS = os.environ.get("MGF_TAP_STATS", "1") != "0"
 
 
 def random_squeeze_backbone(seed=0):
@@ -198,9 +200,10 @@ class SequentialFeatures:
             fused = FUSE_TAP_RELU and i in tap_of and row[0] == "conv"
             if fused:
                 kk = tap_of[i]
-                _lib.check(L.mgf_lpips_layer_bwd_relu_f32(gh.data_ptr(), None, gh.data_ptr() if behind else None, h.data_ptr(),
-                                                          target_taps[kk].data_ptr(), lins[kk].data_ptr(), n, c, c, hh * ww,
-                                                          c * hh * ww if per_sample else 0, float(scale), st), "lpips_layer_bwd_relu")
+                _lib.check(L.mgf_lpips_layer_bwd_relu_stats_f32(gh.data_ptr(), None, gh.data_ptr() if behind else None, h.data_ptr(),
+                                                                target_taps[kk].data_ptr(), lins[kk].data_ptr(),
+                                                                _lib.ptr(getattr(self, "tap_stats", {}).get(kk)), n, c, c, hh * ww,
+                                                                c * hh * ww if per_sample else 0, float(scale), st), "lpips_layer_bwd_relu")
             elif i in tap_of:
                 kk = tap_of[i]
                 _lib.check(L.mgf_lpips_layer_bwd_f32(gh.data_ptr(), h.data_ptr(), target_taps[kk].data_ptr(), lins[kk].data_ptr(), n, c,
@@ -315,9 +318,10 @@ class SqueezeFeatures:
             if fused:
                 k = TAPS_AFTER.index(idx)
                 da, db, ex = (gh, None, c) if idx == 1 else (*self.gex[idx], FIRES[idx][2])
-                _lib.check(L.mgf_lpips_layer_bwd_relu_f32(da.data_ptr(), _lib.ptr(db), gh.data_ptr() if idx != 12 else None, h.data_ptr(),
-                                                          target_taps[k].data_ptr(), lins[k].data_ptr(), n, c, ex, hh * ww,
-                                                          c * hh * ww if per_sample else 0, float(scale), st), "lpips_layer_bwd_relu")
+                _lib.check(L.mgf_lpips_layer_bwd_relu_stats_f32(da.data_ptr(), _lib.ptr(db), gh.data_ptr() if idx != 12 else None, h.data_ptr(),
+                                                                target_taps[k].data_ptr(), lins[k].data_ptr(),
+                                                                _lib.ptr(getattr(self, "tap_stats", {}).get(k)), n, c, ex, hh * ww,
+                                                                c * hh * ww if per_sample else 0, float(scale), st), "lpips_layer_bwd_relu")
             elif idx in TAPS_AFTER:
                 k = TAPS_AFTER.index(idx)
                 _lib.check(L.mgf_lpips_layer_bwd_f32(gh.data_ptr(), h.data_ptr(), target_taps[k].data_ptr(), lins[k].data_ptr(), n, c,
@@ -456,6 +460,7 @@ class PerceptualLoss(torch.nn.Module):
         lin = np.load(os.path.join(WEIGHTS_DIR, f"lpips_lin_{net}.npz"))
         self.lins = [torch.as_tensor(lin[f"lin{i}"], dtype=torch.float32, device=self.device_) for i in range(len(self.chns))]
         self._feats = {}
+        self._stats = {}
         self._target_taps = None
         self._target_n = 1
         self._last, self._last_hw = None, None
@@ -525,6 +530,7 @@ class PerceptualLoss(torch.nn.Module):
         if self._scratch.numel() < need:
             self._scratch = torch.empty(need, dtype=torch.float32, device=self.device_)
         self._last, self._last_hw = (f, tuple(pred.shape[2:])) if keep_taps else (None, None)
+        f.tap_stats = {}                            # tap index -> per-pixel sums of this forward (keep_taps only)
         if self.fused_stem and not keep_taps and not per_sample:
             f.stem(pred.contiguous(), feat_ref=self._target_taps[0], lin=self.lins[0], dist_out=out, scratch=self._scratch)
             taps = f(pred, from_pooled=True)
@@ -535,9 +541,16 @@ class PerceptualLoss(torch.nn.Module):
             if a is None:
                 continue                            # tap 0 was consumed inside the stem kernel
             _, c, hh, ww = a.shape
-            _lib.check(L.mgf_lpips_layer_f32(out.data_ptr(), a.data_ptr(), b.data_ptr(), lin.data_ptr(), n, c, hh * ww,
-                                             c * hh * ww if per_sample else 0,
-                                             int(i > 0), self._scratch.data_ptr(), st), "lpips_layer")
+            stats = None
+            if keep_taps and TAP_STATS:
+                key = (i, n, hh * ww)
+                stats = self._stats.get(key)
+                if stats is None:
+                    stats = self._stats[key] = torch.empty(n, 3, hh * ww, dtype=torch.float32, device=self.device_)
+                f.tap_stats[i] = stats
+            _lib.check(L.mgf_lpips_layer_stats_f32(out.data_ptr(), _lib.ptr(stats), a.data_ptr(), b.data_ptr(), lin.data_ptr(), n, c, hh * ww,
+                                                   c * hh * ww if per_sample else 0,
+                                                   int(i > 0), self._scratch.data_ptr(), st), "lpips_layer")
         return out
 
     def forward(self, pred, target, normalize=False):

@@ -323,6 +323,19 @@ def test_lpips_tap_gradient_fused_with_relu_bwd_is_the_two_kernels_in_sequence(c
     _lib.check(L.mgf_lpips_layer_bwd_relu_f32(a1.data_ptr(), bp(b1), dy.data_ptr() if behind else None, f0.data_ptr(), f1.data_ptr(),
                                               lin.data_ptr(), n, c, split, hw, c * hw, 0.7, st))
     assert torch.equal(a0, a1) and (split == c or torch.equal(b0, b1))
+    # the per-pixel sums of the forward (mgf_lpips_layer_stats_f32) in place of the backward's own first sweep: the same sums in another
+    # order, so equal to rounding; and the sums themselves against torch
+    stats = torch.full((n, 3, hw), float("nan"), device="cuda")
+    dist = torch.zeros(n, device="cuda")
+    scratch = torch.empty(n * int(L.mgf_reduce_scratch_floats()), device="cuda")
+    _lib.check(L.mgf_lpips_layer_stats_f32(dist.data_ptr(), stats.data_ptr(), f0.data_ptr(), f1.data_ptr(), lin.data_ptr(), n, c, hw, c * hw, 0,
+                                           scratch.data_ptr(), st))
+    want = torch.stack([(f0 * f0).sum(1), (lin[None, :, None] * f0 * f0).sum(1), (lin[None, :, None] * f1 * f0).sum(1)], dim=1)
+    assert rel(stats, want) < 1e-5
+    a2, b2 = torch.empty_like(a0), torch.empty_like(b0)
+    _lib.check(L.mgf_lpips_layer_bwd_relu_stats_f32(a2.data_ptr(), bp(b2), dy.data_ptr() if behind else None, f0.data_ptr(), f1.data_ptr(),
+                                                    lin.data_ptr(), stats.data_ptr(), n, c, split, hw, c * hw, 0.7, st))
+    assert rel(a2, a0) < 1e-5 and (split == c or rel(b2, b0) < 1e-5)
     if split == c:                                                 # in place, as the sequential backbones call it
         _lib.check(L.mgf_lpips_layer_bwd_relu_f32(dy.data_ptr(), None, dy.data_ptr(), f0.data_ptr(), f1.data_ptr(), lin.data_ptr(), n, c, c, hw,
                                                   c * hw, 0.7, st))
