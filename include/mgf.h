@@ -424,8 +424,16 @@ int mgf_style_grad_f32(float* dot_part, float* dx, const float* x, const float* 
  * (conv_last -> conv1 of the last block): the activation is inverted on x - residual and s g is also written to dx, which the block's
  * skip branch reads. */
 int mgf_style_grad_act_bwd_f32(float* style_part, float* dot_part, float* dz, float* dx, const float* x, const float* g, const float* s,
-                               const float* residual, const float* bias, const float* noise, const float* noise_strength, int32_t noise_n,
-                               int32_t n, int32_t c, int64_t hw, float alpha, float gain, mgf_stream_t stream);
+                               const float* residual, const float* residual_low, int32_t w, const float* bias, const float* noise,
+                               const float* noise_strength, int32_t noise_n, int32_t n, int32_t c, int64_t hw, float alpha, float gain,
+                               mgf_stream_t stream);
+/* residual_low (here and in mgf_layer_act_bwd_low_f32; instead of `residual`, maps of row length w): the residual BEFORE its 2x FIR
+ * up-sampling, [n][c][h/2][w/2] -- the resnet skip branch as the form-3 Winograd epilogue consumes it in the forward
+ * (mgf_conv3x3_winograd3_f32's residual_low); it is up-sampled here with that epilogue's arithmetic, so the full-resolution skip
+ * tensor exists in neither pass. */
+int mgf_layer_act_bwd_low_f32(float* dz, float* dot_part, const float* dy, const float* y, const float* residual, const float* residual_low,
+                              int32_t w, const float* bias, const float* noise, const float* noise_strength, int32_t noise_n, int32_t n,
+                              int32_t c, int64_t hw, float alpha, float gain, mgf_stream_t stream);
 /* Backward of mgf_duplex_attention without its epilogue (apply mgf_layer_act_bwd_f32 first), same operands as the forward:
  *   dx[n,c,f]    gradient with respect to the attention input x
  *   dg[n,c,f]    = da * x * rsqrt(mean_c x^2 + 1e-8), scratch consumed by mgf_attn_values_grad (may be NULL)

@@ -35,12 +35,35 @@ struct ActBwdParams {
     int noise_n, c, nchunk;
     int64_t hw;
     float alpha, gain;
+    const float* res_low;   // LOW: the residual at half resolution [n][c][h/2][w/2] (res is null), up-sampled here
+    int w;                  // LOW: row length of the maps (w % 4 == 0, h = hw / w even)
 };
+
+// The residual given at HALF resolution (the resnet skip branch before its 2x FIR up-sampling: [1,3,3,1] x [1,3,3,1] / 64, gain 4, pad
+// (2,1,2,1)): the four values of row y from column x0 (x0 % 4 == 0), in the arithmetic of the form-3 Winograd epilogue that adds the
+// same up-sampled residual in the forward (csrc/wino3.hip: rows first -- (m-1, m) x (1/4, 3/4) for an even row 2m, (m, m+1) x (3/4, 1/4)
+// for an odd one -- then columns alike; samples outside the map count as zero).
+__device__ __forceinline__ float4 up2_residual4(const float* lowp, int lh, int lw, int y, int x0) {
+    const int orow = y & 1, ra = (y >> 1) - 1 + orow, rb = ra + 1;
+    const float wa = orow ? 0.75f : 0.25f, wb = 1.f - wa;
+    const bool ina = ra >= 0 && ra < lh, inb = rb >= 0 && rb < lh;
+    const int mc = x0 >> 1;
+    float cc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int col = mc - 1 + k;
+        const bool in = col >= 0 && col < lw;
+        const float a = (in && ina) ? lowp[ra * lw + col] : 0.f, b = (in && inb) ? lowp[rb * lw + col] : 0.f;
+        cc[k] = wa * a + wb * b;
+    }
+    return make_float4(0.25f * cc[0] + 0.75f * cc[1], 0.75f * cc[1] + 0.25f * cc[2], 0.25f * cc[1] + 0.75f * cc[2], 0.75f * cc[2] + 0.25f * cc[3]);
+}
 
 // grid (nchunk, c, n).  y = lrelu(z) * gain + res  with  z = cval + noise * strength + bias:
 //   dz = dy * gain * (y - res > 0 ? 1 : alpha);    part[n,c,chunk] = sum dz * cval   (cval recovered by inverting the activation)
-template <bool VEC>
+template <bool VEC, bool LOW = false>
 __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdParams p) {
+    static_assert(VEC || !LOW, "the half-resolution residual rides on the 16-byte path");
     __shared__ float red[4];
     const int chunk = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
     const int64_t base = ((int64_t)n * p.c + ch) * p.hw;
@@ -64,7 +87,13 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdParams p) {
         for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
             const float4 yv = *reinterpret_cast<const float4*>(p.y + base + i);
             const float4 dv = *reinterpret_cast<const float4*>(p.dy + base + i);
-            const float4 rv = p.res ? *reinterpret_cast<const float4*>(p.res + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 rv;
+            if (LOW) {
+                const int yy = (int)(i / p.w);
+                rv = up2_residual4(p.res_low + ((int64_t)n * p.c + ch) * (p.hw >> 2), (int)(p.hw / p.w) >> 1, p.w >> 1, yy, (int)(i - (int64_t)yy * p.w));
+            } else {
+                rv = p.res ? *reinterpret_cast<const float4*>(p.res + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             const float4 nv = nz ? *reinterpret_cast<const float4*>(nz + i) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 o;
             one(yv.x, rv.x, dv.x, nv.x, o.x); one(yv.y, rv.y, dv.y, nv.y, o.y);
@@ -946,14 +975,27 @@ extern "C" int32_t mgf_bwd_chunks(int64_t hw) { return (int32_t)mgf_cdiv(hw, BWD
 extern "C" int mgf_layer_act_bwd_f32(float* dz, float* dot_part, const float* dy, const float* y, const float* residual, const float* bias,
                                      const float* noise, const float* noise_strength, int32_t noise_n, int32_t n, int32_t c, int64_t hw,
                                      float alpha, float gain, mgf_stream_t stream) {
+    return mgf_layer_act_bwd_low_f32(dz, dot_part, dy, y, residual, nullptr, 0, bias, noise, noise_strength, noise_n, n, c, hw, alpha, gain, stream);
+}
+
+extern "C" int mgf_layer_act_bwd_low_f32(float* dz, float* dot_part, const float* dy, const float* y, const float* residual,
+                                         const float* residual_low, int32_t w, const float* bias, const float* noise,
+                                         const float* noise_strength, int32_t noise_n, int32_t n, int32_t c, int64_t hw, float alpha, float gain,
+                                         mgf_stream_t stream) {
     MGF_REQUIRE(dz && dy && y && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "layer_act_bwd: bad arguments");
     MGF_REQUIRE(alpha != 0.f && gain != 0.f, MGF_EINVAL, "layer_act_bwd: alpha and gain must be non-zero (the activation is inverted)");
     MGF_REQUIRE(n <= 65535 && c <= 65535, MGF_ETOOBIG, "layer_act_bwd: n and c must be <= 65535");
-    ActBwdParams p{dz, dot_part, dy, y, residual, bias, noise, noise_strength, noise_n, c, (int)mgf_cdiv(hw, BWD_CHUNK), hw, alpha, gain};
+    MGF_REQUIRE(!(residual && residual_low), MGF_EINVAL, "layer_act_bwd: the residual comes at full OR at half resolution");
+    ActBwdParams p{dz, dot_part, dy, y, residual, bias, noise, noise_strength, noise_n, c, (int)mgf_cdiv(hw, BWD_CHUNK), hw, alpha, gain,
+                   residual_low, w};
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
     const bool vec = hw % 4 == 0 && al16(dz) && al16(dy) && al16(y) && al16(residual) && al16(noise);
-    if (vec) hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
+    if (residual_low) {
+        MGF_REQUIRE(vec && w >= 4 && w % 4 == 0 && hw % w == 0 && (hw / w) % 2 == 0 && hw / w <= INT32_MAX, MGF_EUNSUPPORTED,
+                    "layer_act_bwd: the half-resolution residual needs 16-byte aligned maps with w %% 4 == 0 and an even height (w %d, hw %lld)", w, (long long)hw);
+        hipLaunchKernelGGL((act_bwd_kernel<true, true>), dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (vec) hipLaunchKernelGGL((act_bwd_kernel<true>), dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((act_bwd_kernel<false>), dim3(p.nchunk, c, n), dim3(256), 0, (hipStream_t)stream, p);
     MGF_CHECK_LAUNCH("layer_act_bwd");
     return MGF_OK;
 }
@@ -991,12 +1033,15 @@ struct StyleActParams {
     int noise_n, c, nchunk;
     int64_t hw;
     float alpha, gain;
+    const float* res_low;   // LOW: the residual at half resolution (res is null), see ActBwdParams
+    int w;
 };
 namespace {
 // RES: the earlier layer's output carries a residual (x = lrelu(..) gain + res: the activation is inverted on x - res) and s g is
 // also stored (dx: the block's skip branch reads it).
-template <bool VEC, bool RES>
+template <bool VEC, bool RES, bool LOW = false>
 __global__ __launch_bounds__(256) void style_grad_act_bwd_kernel(StyleActParams p) {
+    static_assert(!LOW || (VEC && RES), "the half-resolution residual rides on the 16-byte residual path");
     __shared__ float red[4];
     const int chunk = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
     const int64_t base = ((int64_t)n * p.c + ch) * p.hw;
@@ -1024,7 +1069,10 @@ __global__ __launch_bounds__(256) void style_grad_act_bwd_kernel(StyleActParams 
             const float4 xv = *reinterpret_cast<const float4*>(p.x + base + i);
             const float4 nv = nz ? *reinterpret_cast<const float4*>(nz + i) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (RES) rv = *reinterpret_cast<const float4*>(p.res + base + i);
+            if (LOW) {
+                const int yy = (int)(i / p.w);
+                rv = up2_residual4(p.res_low + ((int64_t)n * p.c + ch) * (p.hw >> 2), (int)(p.hw / p.w) >> 1, p.w >> 1, yy, (int)(i - (int64_t)yy * p.w));
+            } else if (RES) rv = *reinterpret_cast<const float4*>(p.res + base + i);
             acc_s += xv.x * gv.x + xv.y * gv.y + xv.z * gv.z + xv.w * gv.w;       // (the association of style_grad_kernel: bit-identical partials)
             float4 o, d;
             one(xv.x, rv.x, gv.x, nv.x, d.x, o.x); one(xv.y, rv.y, gv.y, nv.y, d.y, o.y);
@@ -1053,19 +1101,25 @@ __global__ __launch_bounds__(256) void style_grad_act_bwd_kernel(StyleActParams 
 }  // namespace
 
 extern "C" int mgf_style_grad_act_bwd_f32(float* style_part, float* dot_part, float* dz, float* dx, const float* x, const float* g,
-                                          const float* s, const float* residual, const float* bias, const float* noise,
-                                          const float* noise_strength, int32_t noise_n, int32_t n, int32_t c, int64_t hw, float alpha,
-                                          float gain, mgf_stream_t stream) {
+                                          const float* s, const float* residual, const float* residual_low, int32_t w, const float* bias,
+                                          const float* noise, const float* noise_strength, int32_t noise_n, int32_t n, int32_t c, int64_t hw,
+                                          float alpha, float gain, mgf_stream_t stream) {
     MGF_REQUIRE(style_part && dz && x && g && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "style_grad_act_bwd: bad arguments");
-    MGF_REQUIRE((dx != nullptr) == (residual != nullptr), MGF_EINVAL, "style_grad_act_bwd: dx and residual go together (both or neither)");
+    MGF_REQUIRE(!(residual && residual_low), MGF_EINVAL, "style_grad_act_bwd: the residual comes at full OR at half resolution");
+    MGF_REQUIRE((dx != nullptr) == (residual != nullptr || residual_low != nullptr), MGF_EINVAL,
+                "style_grad_act_bwd: dx and a residual go together (both or neither)");
     MGF_REQUIRE(alpha != 0.f && gain != 0.f, MGF_EINVAL, "style_grad_act_bwd: alpha and gain must be non-zero (the activation is inverted)");
     MGF_REQUIRE(n <= 65535 && c <= 65535, MGF_ETOOBIG, "style_grad_act_bwd: n and c must be <= 65535");
     StyleActParams p{style_part, dot_part, dz, dx, x, g, s, residual, bias, noise, noise_strength, noise_n, c, (int)mgf_cdiv(hw, BWD_CHUNK),
-                     hw, alpha, gain};
+                     hw, alpha, gain, residual_low, w};
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
     const bool vec = hw % 4 == 0 && al16(dz) && al16(x) && al16(g) && al16(noise) && al16(dx) && al16(residual);
     const dim3 grid(p.nchunk, c, n);
-    if (residual) {
+    if (residual_low) {
+        MGF_REQUIRE(vec && w >= 4 && w % 4 == 0 && hw % w == 0 && (hw / w) % 2 == 0 && hw / w <= INT32_MAX, MGF_EUNSUPPORTED,
+                    "style_grad_act_bwd: the half-resolution residual needs 16-byte aligned maps with w %% 4 == 0 and an even height (w %d, hw %lld)", w, (long long)hw);
+        hipLaunchKernelGGL((style_grad_act_bwd_kernel<true, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else if (residual) {
         if (vec) hipLaunchKernelGGL((style_grad_act_bwd_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((style_grad_act_bwd_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {

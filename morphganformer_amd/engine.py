@@ -223,6 +223,7 @@ class Generator:
         self._ws_cache = {}
         self.taps = None
         self.fuse_torgb = True
+        self.skip_fused = {}
         self.fuse_skip_up = os.environ.get("MGF_FUSE_SKIP_UP", "1") != "0"      # tuning hook: 0 = the skip branch's own 2x FIR pass everywhere
         self.last_noise = ("none", None)      # (noise_mode, noises) of the latest synthesis call, read by grad.SynthesisGrad
         self.side = torch.cuda.Stream(device=self.device)
@@ -450,6 +451,7 @@ class Generator:
                 # skip output itself -- no fir_up2 pass, no full-resolution skip tensor (one write + one read of the block's largest map)
                 fuse_up = (self.fuse_skip_up and P.fir_is_1331 and cv.WINOGRAD_FORM == 3 and l1.attn is None and l1.wino_u is not None
                            and l1.wino_u.ndim == 4 and res % 2 == 0 and cv.winograd_fills_chip(n, l1.cout, res, res))
+                self.skip_fused[res] = bool(fuse_up)         # (gradient mode's backward reads the skip tensor at the resolution it was consumed)
                 main = torch.cuda.current_stream(self.device)
                 if self.overlap_skip:
                     self.side.wait_stream(main)

@@ -26,6 +26,7 @@ from . import _lib
 from . import conv as cv
 from .engine import Generator
 
+GRAD_FUSE_SKIP = os.environ.get("MGF_GRAD_FUSE_SKIP", "1") != "0"
 FUSE_STYLE_ACT = os.environ.get("MGF_FUSE_STYLE_ACT", "1") != "0"      # tuning / test hook: 0 = style_grad and act_bwd as two launches
 
 
@@ -110,7 +111,11 @@ class GeneratorGrad:
                 raise _lib.MgfError("GeneratorGrad: per-layer ws (W+) has no backward pass; pass z, or a ws broadcast over the layer axis")
             w = (ws[:, :, 0] if ws.ndim == 4 else ws).contiguous().float()
         # the backward pass reads conv_last's activation and the full-resolution skip tensors: both fusions off for this forward
-        G.fuse_torgb, keep_up, G.fuse_skip_up = False, G.fuse_skip_up, False
+        # (the skip branch stays fused into conv1's Winograd epilogue where the engine does that -- G.skip_fused[res] -- and the backward
+        # up-samples the half-resolution skip tensor itself; MGF_GRAD_FUSE_SKIP=0: the full-resolution tensor in both passes)
+        G.fuse_torgb, keep_up = False, G.fuse_skip_up
+        if not GRAD_FUSE_SKIP:
+            G.fuse_skip_up = False
         if z is not None:
             # the mapping network's activations are kept for backward() (mgf_mapping_backward_saved) rather than recomputed there
             need = z.shape[0] * int(_lib.lib().mgf_mapping_bwd_scratch_floats(G.cfg.k, G.cfg.w_dim, G.cfg.mapping_layers // 2))
@@ -133,7 +138,7 @@ class GeneratorGrad:
         return img
 
     # ------------------------------------------------------------------ backward
-    def _act_bwd(self, lp, dy, y_out, residual):
+    def _act_bwd(self, lp, dy, y_out, residual, residual_low=None):
         """d(pre-activation) of one SynthesisLayer from the gradient dy of its output y_out = lrelu(c [attention] + noise + bias) * gain
         + residual (and, for a demodulated layer without attention, the <dz, c> partials of the demodulation gradient)."""
         G, L, st = self.G, _lib.lib(), _lib.stream_ptr()
@@ -144,10 +149,12 @@ class GeneratorGrad:
         want_dot = lp.demod and lp.attn is None
         # conv_last carries neither noise nor bias/activation (engine.synthesis): alpha = gain = 1 makes the kernel a plain copy + dot
         alpha, gain = (0.2, lp.act_gain) if lp.bias is not None else (1.0, 1.0)
-        _lib.check(L.mgf_layer_act_bwd_f32(dz.data_ptr(), self.dc_part[lp.name].data_ptr() if want_dot else None, dy.data_ptr(),
-                                           y_out.data_ptr(), _lib.ptr(residual), _lib.ptr(lp.bias), _lib.ptr(noise),
-                                           _lib.ptr(lp.noise_strength) if noise is not None else None, noise_n, n, c, h * w, alpha,
-                                           gain, st), "layer_act_bwd")
+        # residual_low: the skip branch at HALF resolution, as the forward's Winograd epilogue consumed it (engine fuse_skip_up): it is
+        # up-sampled inside the kernel and the full-resolution skip tensor exists in neither pass
+        _lib.check(L.mgf_layer_act_bwd_low_f32(dz.data_ptr(), self.dc_part[lp.name].data_ptr() if want_dot else None, dy.data_ptr(),
+                                               y_out.data_ptr(), _lib.ptr(residual), _lib.ptr(residual_low), w, _lib.ptr(lp.bias),
+                                               _lib.ptr(noise), _lib.ptr(lp.noise_strength) if noise is not None else None, noise_n, n, c,
+                                               h * w, alpha, gain, st), "layer_act_bwd")
         return dz
 
     def _conv_bwd(self, lp, dz, y_out, c_pre, x_in):
@@ -192,7 +199,7 @@ class GeneratorGrad:
                                         G._s(lp).data_ptr(), n, ci, hi, 0, st), "style_grad")
         return dx
 
-    def _style_act_bwd(self, lp, g, prev, y_prev, residual=None, dx_role=None):
+    def _style_act_bwd(self, lp, g, prev, y_prev, residual=None, dx_role=None, residual_low=None):
         """_style_bwd of `lp` fused with _act_bwd of the layer `prev` whose output y_prev is lp's input: one pass over (y_prev, g)
         (mgf_style_grad_act_bwd_f32).  conv1 -> conv0 of a block: prev has no residual and the intermediate s * g never reaches memory.
         conv_last -> conv1 of the last block: prev's residual is the block's skip tensor and s * g is stored too (dx_role: the skip
@@ -204,13 +211,14 @@ class GeneratorGrad:
         dz = self.buf("dz", y_prev.shape)
         want_dot = prev.demod and prev.attn is None
         alpha, gain = (0.2, prev.act_gain) if prev.bias is not None else (1.0, 1.0)
-        dx = self.buf(dx_role, y_prev.shape) if residual is not None else None
+        with_res = residual is not None or residual_low is not None
+        dx = self.buf(dx_role, y_prev.shape) if with_res else None
         _lib.check(L.mgf_style_grad_act_bwd_f32(self.ds_part[lp.name].data_ptr(), self.dc_part[prev.name].data_ptr() if want_dot else None,
                                                 dz.data_ptr(), _lib.ptr(dx), y_prev.data_ptr(), g.data_ptr(), G._s(lp).data_ptr(),
-                                                _lib.ptr(residual), _lib.ptr(prev.bias), _lib.ptr(noise),
+                                                _lib.ptr(residual), _lib.ptr(residual_low), w, _lib.ptr(prev.bias), _lib.ptr(noise),
                                                 _lib.ptr(prev.noise_strength) if noise is not None else None, noise_n,
                                                 n, c, h * w, alpha, gain, st), "style_grad_act_bwd")
-        return dz if residual is None else (dz, dx)
+        return (dz, dx) if with_res else dz
 
     def _layer_bwd(self, lp, dy, y_out, c_pre, residual, x_in, dx_role):
         """One SynthesisLayer.  dy: gradient wrt the layer output y_out (= lrelu(c [attention] + noise + bias) * gain + residual);
@@ -245,7 +253,9 @@ class GeneratorGrad:
             if R > 4:
                 # conv_last's input IS the last block's output (conv1's activation + the skip tensor): conv_last's style gradient and
                 # conv1's activation backward in one pass as well; s g is still stored, the skip branch's backward reads it
-                dz1_top, dx = self._style_act_bwd(ll, gl, layers[b + ".conv1"], out_of(R), residual=G.bufs[R]["skip"], dx_role="dxin")
+                low = G.skip_fused.get(R, False)
+                dz1_top, dx = self._style_act_bwd(ll, gl, layers[b + ".conv1"], out_of(R), dx_role="dxin",
+                                                  residual=None if low else G.bufs[R]["skip"], residual_low=G.bufs[R]["skip_low"] if low else None)
             else:
                 dx = self._style_bwd(ll, gl, out_of(R), "dxin")
         else:
@@ -269,7 +279,12 @@ class GeneratorGrad:
                 self.debug[f"synthesis.b{res}:dout"] = d_out.clone()
             # conv1 then conv0: conv1's input IS conv0's output y0, so conv1's style gradient and conv0's activation backward are one
             # pass over (y0, g) -- d(y0) = s g is never stored (MGF_FUSE_STYLE_ACT=0: the two kernels in sequence, bit-identical)
-            dz1 = dz1_top if res == R and dz1_top is not None else self._act_bwd(l1, d_out, y1, B["skip"])
+            if res == R and dz1_top is not None:
+                dz1 = dz1_top
+            elif G.skip_fused.get(res, False):
+                dz1 = self._act_bwd(l1, d_out, y1, None, residual_low=B["skip_low"])
+            else:
+                dz1 = self._act_bwd(l1, d_out, y1, B["skip"])
             g1 = self._conv_bwd(l1, dz1, y1, B["conv1"] if att else None, y0)
             if FUSE_STYLE_ACT and self.debug is None:
                 dz0 = self._style_act_bwd(l1, g1, l0, y0)

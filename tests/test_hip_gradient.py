@@ -152,15 +152,62 @@ def test_style_grad_fused_with_act_bwd_is_the_two_kernels_in_sequence(hw, with_d
                                        bias.data_ptr(), noise.data_ptr(), nstr.data_ptr(), n, n, c, hw, 0.2, 1.3, st))
     ps_b, pd_b, dz_b, dx_b = torch.empty_like(ps_a), torch.empty_like(pd_a), torch.empty_like(y), torch.empty_like(y)
     _lib.check(L.mgf_style_grad_act_bwd_f32(ps_b.data_ptr(), pd_b.data_ptr() if with_dot else None, dz_b.data_ptr(),
-                                            dx_b.data_ptr() if with_res else None, y.data_ptr(), g.data_ptr(), s.data_ptr(), rp,
+                                            dx_b.data_ptr() if with_res else None, y.data_ptr(), g.data_ptr(), s.data_ptr(), rp, None, 0,
                                             bias.data_ptr(), noise.data_ptr(), nstr.data_ptr(), n, n, c, hw, 0.2, 1.3, st))
     assert torch.equal(dz_a, dz_b) and torch.equal(ps_a, ps_b)
     if with_res:
         assert torch.equal(dmid, dx_b)
         assert L.mgf_style_grad_act_bwd_f32(ps_b.data_ptr(), None, dz_b.data_ptr(), dx_b.data_ptr(), y.data_ptr(), g.data_ptr(), s.data_ptr(),
-                                            None, None, None, None, 0, n, c, hw, 0.2, 1.3, st) != 0        # dx without residual
+                                            None, None, 0, None, None, None, 0, n, c, hw, 0.2, 1.3, st) != 0  # dx without residual
     if with_dot:
         assert torch.equal(pd_a, pd_b)
+
+
+@pytest.mark.parametrize("h,w", [(8, 8), (6, 12), (64, 128)])
+def test_activation_backward_with_the_residual_at_half_resolution(h, w):
+    """The skip branch consumed at HALF resolution (the forward's Winograd epilogue up-samples it: engine fuse_skip_up): both activation
+    backward kernels up-sample it themselves -- same dz / dx / partial sums as with the full-resolution tensor that upfirdn2d(up=2, pad
+    (2,1,2,1), gain 4) makes of it (to rounding: another summation order inside the 4-tap interpolation)."""
+    from morphganformer_amd import _lib, conv as cv
+    from morphganformer_amd.torch_utils.ops import upfirdn2d
+    L = _lib.lib()
+    torch.manual_seed(h * w)
+    n, c, hw = 2, 5, h * w
+    low = torch.randn(n, c, h // 2, w // 2, device="cuda")
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).cuda()
+    full = torch.empty(n, c, h, w, device="cuda")
+    cv.upfirdn_into(full, low, f, up=2, pad=(2, 1, 2, 1), gain=4.0)
+    ref_up = torch.nn.functional.conv_transpose2d(low.double().cpu().reshape(n * c, 1, h // 2, w // 2),
+                                                  (torch.outer(torch.tensor([1., 3, 3, 1]), torch.tensor([1., 3, 3, 1])).double() / 16)[None, None],
+                                                  stride=2, padding=1).reshape(n, c, h, w)
+    assert rel(full, ref_up) < 1e-6                              # (what "up-sampled" means here)
+    y = torch.randn(n, c, h, w, device="cuda") + full
+    dy, g = torch.randn_like(y), torch.randn_like(y)
+    s = torch.rand(n, c, device="cuda") + 0.5
+    bias, noise, nstr = torch.randn(c, device="cuda"), torch.randn(n, hw, device="cuda"), torch.tensor([0.3], device="cuda")
+    chunks = int(L.mgf_bwd_chunks(hw))
+    st = _lib.stream_ptr()
+    e = lambda: (torch.empty_like(y), torch.empty(n, c, chunks, device="cuda"))
+    (dz_a, pd_a), (dz_b, pd_b) = e(), e()
+    _lib.check(L.mgf_layer_act_bwd_low_f32(dz_a.data_ptr(), pd_a.data_ptr(), dy.data_ptr(), y.data_ptr(), full.data_ptr(), None, 0, bias.data_ptr(),
+                                           noise.data_ptr(), nstr.data_ptr(), n, n, c, hw, 0.2, 1.3, st))
+    _lib.check(L.mgf_layer_act_bwd_low_f32(dz_b.data_ptr(), pd_b.data_ptr(), dy.data_ptr(), y.data_ptr(), None, low.data_ptr(), w, bias.data_ptr(),
+                                           noise.data_ptr(), nstr.data_ptr(), n, n, c, hw, 0.2, 1.3, st))
+    decided = (y - full).abs() > 1e-5                              # (an element at the kink may take either slope)
+    assert torch.equal(dz_a[decided], dz_b[decided]) and rel(pd_a.sum(-1), pd_b.sum(-1)) < 1e-5
+    (dz_c, pd_c), (dz_d, pd_d) = e(), e()
+    ps_c, ps_d, dx_c, dx_d = torch.empty_like(pd_c), torch.empty_like(pd_c), torch.empty_like(y), torch.empty_like(y)
+    for dzv, pdv, psv, dxv, full_p, low_p, ww in ((dz_c, pd_c, ps_c, dx_c, full.data_ptr(), None, 0), (dz_d, pd_d, ps_d, dx_d, None, low.data_ptr(), w)):
+        _lib.check(L.mgf_style_grad_act_bwd_f32(psv.data_ptr(), pdv.data_ptr(), dzv.data_ptr(), dxv.data_ptr(), y.data_ptr(), g.data_ptr(),
+                                                s.data_ptr(), full_p, low_p, ww, bias.data_ptr(), noise.data_ptr(), nstr.data_ptr(), n, n, c, hw,
+                                                0.2, 1.3, st))
+    assert torch.equal(dz_c[decided], dz_d[decided]) and torch.equal(dx_c, dx_d) and torch.equal(ps_c, ps_d)
+    assert rel(pd_c.sum(-1), pd_d.sum(-1)) < 1e-5
+    # both at once / an odd width are refused
+    assert L.mgf_layer_act_bwd_low_f32(dz_a.data_ptr(), None, dy.data_ptr(), y.data_ptr(), full.data_ptr(), low.data_ptr(), w, None, None, None, 0,
+                                       n, c, hw, 0.2, 1.3, st) != 0
+    assert L.mgf_layer_act_bwd_low_f32(dz_a.data_ptr(), None, dy.data_ptr(), y.data_ptr(), None, low.data_ptr(), w - 1, None, None, None, 0,
+                                       n, c, hw, 0.2, 1.3, st) != 0
 
 
 @pytest.mark.parametrize("c,res", [(32, 8), (512, 4), (20, 6), (256, 32), (64, 16), (512, 8), (256, 8)])
