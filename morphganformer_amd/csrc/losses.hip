@@ -54,13 +54,13 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(float* scratch, const 
 // ONE sweep over HBM: each thread keeps its <= CPT channel values in registers, the squared norms meet in LDS in a fixed order
 // (bit-reproducible), then the registers are either written back unit-normalised (UNIT_OUT: the reference image's taps, once
 // per target) or compared with the stored unit-normalised reference taps and reduced to one partial per workgroup.
-template <int PXB, int CPT, bool UNIT_OUT>
+template <int PXB, int CPT, bool UNIT_OUT, bool STATS = false>
 __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float* unit_out, const float* f0, const float* f1u,
                                                            const float* lin, int c, int64_t hw, int64_t f1_stride, int nsamp, int nblk,
                                                            int xcd_per, float* stats) {
     constexpr int G = 256 / PXB;
     __shared__ float red[G][PXB];
-    __shared__ float redb[G][PXB], redc[G][PXB];      // stats only: the two other per-pixel sums the gradient needs
+    __shared__ float redb[STATS ? G : 1][PXB], redc[STATS ? G : 1][PXB];      // STATS: the two other per-pixel sums the gradient needs
     __shared__ float sm[4];
     const int px = threadIdx.x % PXB, grp = threadIdx.x / PXB;
     // work order: XCD b % 8 walks a contiguous item range with the SAMPLE as the fastest index -- the n candidates of a pixel block read
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
     red[grp][px] = na;
     // stats (gradient mode): A = sum f0^2, B = sum lin f0^2, C = sum lin u1 f0 per pixel -> [n][3][hw]; the backward
     // (mgf_lpips_layer_bwd_relu_f32) then skips its own sweep over both maps for them
-    if (!UNIT_OUT && stats) {
+    if (STATS) {
         float nb = 0.f, nc = 0.f;
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
     na = 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) na += red[g][px];
-    if (!UNIT_OUT && stats && grp == 0 && valid) {
+    if (STATS && grp == 0 && valid) {
         float nb = 0.f, nc = 0.f;
 #pragma unroll
         for (int g = 0; g < G; ++g) { nb += redb[g][px]; nc += redc[g][px]; }
@@ -162,7 +162,15 @@ int launch_lpips_layer(float* scratch, float* unit_out, const float* f0, const f
     const int xcd_per = (int)mgf_cdiv(grid64 * n, 8);
     const dim3 grid((unsigned)(xcd_per * 8));
     *grid_out = (int)grid64;
-#define MGF_LPIPS_LAUNCH(PXB, CPT) hipLaunchKernelGGL((lpips_layer_kernel<PXB, CPT, UNIT_OUT>), grid, dim3(256), 0, st, scratch, unit_out, f0, f1u, lin, c, hw, f1_stride, n, (int)grid64, xcd_per, stats)
+#define MGF_LPIPS_LAUNCH(PXB, CPT)                                                                                                            \
+    do {                                                                                                                                      \
+        if (!UNIT_OUT && stats)                                                                                                               \
+            hipLaunchKernelGGL((lpips_layer_kernel<PXB, CPT, false, true>), grid, dim3(256), 0, st, scratch, unit_out, f0, f1u, lin, c, hw,    \
+                               f1_stride, n, (int)grid64, xcd_per, stats);                                                                    \
+        else                                                                                                                                  \
+            hipLaunchKernelGGL((lpips_layer_kernel<PXB, CPT, UNIT_OUT>), grid, dim3(256), 0, st, scratch, unit_out, f0, f1u, lin, c, hw,      \
+                               f1_stride, n, (int)grid64, xcd_per, nullptr);                                                                  \
+    } while (0)
     if (pxb == 64) {
         if (c <= 128) MGF_LPIPS_LAUNCH(64, 32); else if (c <= 256) MGF_LPIPS_LAUNCH(64, 64); else MGF_LPIPS_LAUNCH(64, 128);
     } else if (pxb == 32) {
