@@ -4,7 +4,7 @@
 set -e
 D=$1; B=${2:-25}; R=${3:-r2}
 cd "$(dirname "$0")/.."
-DB=$(find $D/trace -name "*_results.db" | head -1)
+DB=$(ls -t $(find $D/trace -name "*_results.db") | head -1)      # the newest database: a re-used directory may hold an older one
 python tools/rocpd_stats.py $DB > profiles/${R}_bench_kernel_stats.txt
 python tools/rocpd_stats.py $DB --loop-only > profiles/${R}_bench_kernel_stats_loop.txt
 python tools/iter_trace.py $DB > profiles/${R}_iteration_trace.txt 2>&1
