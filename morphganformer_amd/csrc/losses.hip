@@ -428,6 +428,53 @@ extern "C" int mgf_adaptive_wing_loss_f64(double* out, const double* pred, const
     return MGF_OK;
 }
 
+namespace {
+// 3x3 / stride-2 ceil-mode pool through LDS: 64 x 8 outputs per workgroup from a 129 x 17 input patch loaded by rows (full 512-byte row
+// pieces per wave), two outputs per lane.  The row-per-wave form above issues five overlapping strided 4-byte loads per input row and
+// output pair -- with two non-overlapping ones (wrong results) it ran at 4.4 instead of 2.9 TB/s, its stores cost nothing -- yet this
+// form, which loads every element once, measures the same 2.9 TB/s on the 511^2 and 255^2 maps and 3.1 against 2.45 on 127^2
+// (tools/maxpool_fwd_micro.py); a 16-byte read-only stream reaches 6 TB/s (tools/probes/hbm_read.hip).  Not understood yet.
+__global__ __launch_bounds__(256) void maxpool3x3s2_tiled_kernel(float* __restrict__ y, const float* __restrict__ x, int in_h, int in_w, int out_h,
+                                                                 int out_w, int tiles_x, int tiles_y) {
+    constexpr int TW = 64, TH = 8, PW = 2 * TW + 1, PH = 2 * TH + 1;
+    __shared__ float patch[PH][PW + 1];
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
+    const int64_t pl = blockIdx.x / ((int64_t)tiles_x * tiles_y);
+    const int ox0 = tx * TW, oy0 = ty * TH, ix0 = 2 * ox0, iy0 = 2 * oy0;
+    const float* xp = x + pl * in_h * in_w;
+    const float NEG = -3.0e38f;
+    {
+        const int cc = tid & 127, ix = ix0 + cc;
+        const bool xin = ix < in_w;
+#pragma unroll
+        for (int r = tid >> 7; r < PH; r += 2) {
+            const int iy = iy0 + r;
+            patch[r][cc] = (xin && iy < in_h) ? xp[(int64_t)iy * in_w + ix] : NEG;
+        }
+        if (tid < PH) {                                              // the 129th column
+            const int iy = iy0 + tid, ix2 = ix0 + 128;
+            patch[tid][128] = (ix2 < in_w && iy < in_h) ? xp[(int64_t)iy * in_w + ix2] : NEG;
+        }
+    }
+    __syncthreads();
+    const int lx = tid & 63;
+    if (ox0 + lx >= out_w) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int ly = (tid >> 6) + 4 * q;
+        const int oy = oy0 + ly;
+        if (oy >= out_h) break;
+        float m = NEG;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, patch[2 * ly + dy][2 * lx + dx]);
+        y[(pl * out_h + oy) * out_w + ox0 + lx] = m;
+    }
+}
+}  // namespace
+
 extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                                          mgf_stream_t stream) {
     MGF_REQUIRE(y && x && nc >= 1 && in_h >= 1 && in_w >= 1, MGF_EINVAL, "maxpool: bad arguments");
@@ -436,6 +483,14 @@ extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, i
     MGF_REQUIRE(out_h == osz(in_h) && out_w == osz(in_w), MGF_EINVAL, "maxpool: output must be %dx%d (got %dx%d)", osz(in_h), osz(in_w),
                 out_h, out_w);
     MGF_REQUIRE((int64_t)nc * out_h <= INT32_MAX - 4, MGF_ETOOBIG, "maxpool: too many rows");
+    static const int tiled_env = [] { const char* e = getenv("MGF_POOL_TILED"); return e ? atoi(e) : -1; }();
+    const int64_t tiles = (int64_t)nc * mgf_cdiv(out_w, 64) * mgf_cdiv(out_h, 8);
+    if (tiled_env != 0 && out_w >= 32 && tiles <= INT32_MAX) {
+        hipLaunchKernelGGL(maxpool3x3s2_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, y, x, in_h, in_w, out_h, out_w,
+                           (int)mgf_cdiv(out_w, 64), (int)mgf_cdiv(out_h, 8));
+        MGF_CHECK_LAUNCH("maxpool");
+        return MGF_OK;
+    }
     hipLaunchKernelGGL(maxpool_kernel<3>, dim3((unsigned)mgf_cdiv((int64_t)nc * out_h, 4)), dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w,
                        out_h, out_w);
     MGF_CHECK_LAUNCH("maxpool");
