@@ -475,6 +475,41 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_tiled_kernel(float* __restri
 }
 }  // namespace
 
+namespace {
+// 3x3 / stride-2 ceil-mode pool, one wave per output row with every input element loaded ONCE per wave and fully coalesced: lane l holds
+// the column-wise maximum of the row's three input rows at columns l, l + 64, ... (S slots), the stride-2 three-wide windows are
+// then formed across lanes (two shuffles per slot; the last lanes of a slot take the next slot's first ones) and the even lanes store.
+template <int S>
+__global__ __launch_bounds__(256) void maxpool3x3s2_rows_kernel(float* __restrict__ y, const float* __restrict__ x, int nc, int in_h, int in_w,
+                                                                int out_h, int out_w) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);              // (plane, output row) flattened
+    if (row >= nc * out_h) return;
+    const int pl = row / out_h, oy = row - pl * out_h;
+    const int lane = threadIdx.x & 63;
+    const float* xp = x + (int64_t)pl * in_h * in_w + (int64_t)(2 * oy) * in_w;
+    const float NEG = -3.0e38f;
+    const bool r1 = 2 * oy + 1 < in_h, r2 = 2 * oy + 2 < in_h;
+    float v[S + 1];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int e = 64 * s + lane;
+        const bool in = e < in_w;
+        const float a = in ? xp[e] : NEG, b = (in && r1) ? xp[in_w + e] : NEG, c = (in && r2) ? xp[2 * in_w + e] : NEG;
+        v[s] = fmaxf(fmaxf(a, b), c);
+    }
+    v[S] = NEG;
+    float* yp = y + ((int64_t)pl * out_h + oy) * out_w;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const float t1 = __shfl(v[s], (lane + 1) & 63), n1 = __shfl(v[s + 1], (lane + 1) & 63);
+        const float t2 = __shfl(v[s], (lane + 2) & 63), n2 = __shfl(v[s + 1], (lane + 2) & 63);
+        const float m = fmaxf(fmaxf(v[s], lane < 63 ? t1 : n1), lane < 62 ? t2 : n2);
+        const int ox = 32 * s + (lane >> 1);
+        if (!(lane & 1) && ox < out_w) yp[ox] = m;
+    }
+}
+}  // namespace
+
 extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                                          mgf_stream_t stream) {
     MGF_REQUIRE(y && x && nc >= 1 && in_h >= 1 && in_w >= 1, MGF_EINVAL, "maxpool: bad arguments");
@@ -483,6 +518,19 @@ extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, i
     MGF_REQUIRE(out_h == osz(in_h) && out_w == osz(in_w), MGF_EINVAL, "maxpool: output must be %dx%d (got %dx%d)", osz(in_h), osz(in_w),
                 out_h, out_w);
     MGF_REQUIRE((int64_t)nc * out_h <= INT32_MAX - 4, MGF_ETOOBIG, "maxpool: too many rows");
+    static const int rows_env = [] { const char* e = getenv("MGF_POOL_ROWS"); return e ? atoi(e) : -1; }();
+    if (rows_env != 0 && in_w <= 512 && in_w >= 64) {
+        const dim3 grid((unsigned)mgf_cdiv((int64_t)nc * out_h, 4));
+        const int slots = (int)mgf_cdiv(in_w, 64);
+#define MGF_POOL_ROWS(SL) hipLaunchKernelGGL(maxpool3x3s2_rows_kernel<SL>, grid, dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w, out_h, out_w)
+        switch (slots) {
+            case 1: MGF_POOL_ROWS(1); break; case 2: MGF_POOL_ROWS(2); break; case 3: MGF_POOL_ROWS(3); break; case 4: MGF_POOL_ROWS(4); break;
+            case 5: MGF_POOL_ROWS(5); break; case 6: MGF_POOL_ROWS(6); break; case 7: MGF_POOL_ROWS(7); break; default: MGF_POOL_ROWS(8); break;
+        }
+#undef MGF_POOL_ROWS
+        MGF_CHECK_LAUNCH("maxpool");
+        return MGF_OK;
+    }
     static const int tiled_env = [] { const char* e = getenv("MGF_POOL_TILED"); return e ? atoi(e) : -1; }();
     const int64_t tiles = (int64_t)nc * mgf_cdiv(out_w, 64) * mgf_cdiv(out_h, 8);
     if (tiled_env != 0 && out_w >= 32 && tiles <= INT32_MAX) {
