@@ -479,9 +479,11 @@ namespace {
 // 3x3 / stride-2 ceil-mode pool, one wave per output row with every input element loaded ONCE per wave and fully coalesced: lane l holds
 // the column-wise maximum of the row's three input rows at columns l, l + 64, ... (S slots), the stride-2 three-wide windows are
 // then formed across lanes (two shuffles per slot; the last lanes of a slot take the next slot's first ones) and the even lanes store.
-template <int S>
+// IDX: also each window's first maximum in row-major order as a tap index (torch's gradient rule): the column maximum remembers its
+// first row, and among the window's columns with the maximal value the smallest row, then the smallest column, wins.
+template <int S, bool IDX = false>
 __global__ __launch_bounds__(256) void maxpool3x3s2_rows_kernel(float* __restrict__ y, const float* __restrict__ x, int nc, int in_h, int in_w,
-                                                                int out_h, int out_w) {
+                                                                int out_h, int out_w, uint8_t* __restrict__ idx = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);              // (plane, output row) flattened
     if (row >= nc * out_h) return;
     const int pl = row / out_h, oy = row - pl * out_h;
@@ -490,22 +492,42 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_rows_kernel(float* __restric
     const float NEG = -3.0e38f;
     const bool r1 = 2 * oy + 1 < in_h, r2 = 2 * oy + 2 < in_h;
     float v[S + 1];
+    int rw[IDX ? S + 1 : 1];                                         // IDX: first row of the column maximum
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int e = 64 * s + lane;
         const bool in = e < in_w;
         const float a = in ? xp[e] : NEG, b = (in && r1) ? xp[in_w + e] : NEG, c = (in && r2) ? xp[2 * in_w + e] : NEG;
-        v[s] = fmaxf(fmaxf(a, b), c);
+        if (IDX) {
+            float m = a; int r = 0;
+            if (b > m) { m = b; r = 1; }
+            if (c > m) { m = c; r = 2; }
+            v[s] = m; rw[s] = r;
+        } else {
+            v[s] = fmaxf(fmaxf(a, b), c);
+        }
     }
     v[S] = NEG;
+    if (IDX) rw[S] = 0;
     float* yp = y + ((int64_t)pl * out_h + oy) * out_w;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const float t1 = __shfl(v[s], (lane + 1) & 63), n1 = __shfl(v[s + 1], (lane + 1) & 63);
         const float t2 = __shfl(v[s], (lane + 2) & 63), n2 = __shfl(v[s + 1], (lane + 2) & 63);
-        const float m = fmaxf(fmaxf(v[s], lane < 63 ? t1 : n1), lane < 62 ? t2 : n2);
+        const float c1 = lane < 63 ? t1 : n1, c2 = lane < 62 ? t2 : n2;
         const int ox = 32 * s + (lane >> 1);
-        if (!(lane & 1) && ox < out_w) yp[ox] = m;
+        const bool st = !(lane & 1) && ox < out_w;
+        if (IDX) {
+            const int q1 = __shfl(rw[s], (lane + 1) & 63), p1 = __shfl(rw[s + 1], (lane + 1) & 63);
+            const int q2 = __shfl(rw[s], (lane + 2) & 63), p2 = __shfl(rw[s + 1], (lane + 2) & 63);
+            const int w1 = lane < 63 ? q1 : p1, w2 = lane < 62 ? q2 : p2;
+            float m = v[s]; int r = rw[s], dx = 0;
+            if (c1 > m || (c1 == m && w1 < r)) { m = c1; r = w1; dx = 1; }
+            if (c2 > m || (c2 == m && w2 < r)) { m = c2; r = w2; dx = 2; }
+            if (st) { yp[ox] = m; idx[((int64_t)pl * out_h + oy) * out_w + ox] = (uint8_t)(3 * r + dx); }
+        } else {
+            if (st) yp[ox] = fmaxf(fmaxf(v[s], c1), c2);
+        }
     }
 }
 }  // namespace
@@ -552,6 +574,18 @@ extern "C" int mgf_maxpool3x3s2_ceil_idx_f32(float* y, uint8_t* idx, const float
     MGF_REQUIRE(out_h == osz(in_h) && out_w == osz(in_w), MGF_EINVAL, "maxpool_idx: output must be %dx%d (got %dx%d)", osz(in_h), osz(in_w),
                 out_h, out_w);
     MGF_REQUIRE((int64_t)nc * out_h <= INT32_MAX - 4, MGF_ETOOBIG, "maxpool_idx: too many rows");
+    static const int rows_env = [] { const char* e = getenv("MGF_POOL_ROWS"); return e ? atoi(e) : -1; }();
+    if (rows_env != 0 && in_w <= 512 && in_w >= 64) {
+        const dim3 grid((unsigned)mgf_cdiv((int64_t)nc * out_h, 4));
+#define MGF_POOL_ROWS(SL) hipLaunchKernelGGL((maxpool3x3s2_rows_kernel<SL, true>), grid, dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w, out_h, out_w, idx)
+        switch ((int)mgf_cdiv(in_w, 64)) {
+            case 1: MGF_POOL_ROWS(1); break; case 2: MGF_POOL_ROWS(2); break; case 3: MGF_POOL_ROWS(3); break; case 4: MGF_POOL_ROWS(4); break;
+            case 5: MGF_POOL_ROWS(5); break; case 6: MGF_POOL_ROWS(6); break; case 7: MGF_POOL_ROWS(7); break; default: MGF_POOL_ROWS(8); break;
+        }
+#undef MGF_POOL_ROWS
+        MGF_CHECK_LAUNCH("maxpool_idx");
+        return MGF_OK;
+    }
     hipLaunchKernelGGL((maxpool_kernel<3, true>), dim3((unsigned)mgf_cdiv((int64_t)nc * out_h, 4)), dim3(256), 0, (hipStream_t)stream, y, x, nc,
                        in_h, in_w, out_h, out_w, idx);
     MGF_CHECK_LAUNCH("maxpool_idx");
