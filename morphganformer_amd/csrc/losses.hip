@@ -429,11 +429,9 @@ extern "C" int mgf_adaptive_wing_loss_f64(double* out, const double* pred, const
 }
 
 namespace {
-// 3x3 / stride-2 ceil-mode pool through LDS: 64 x 8 outputs per workgroup from a 129 x 17 input patch loaded by rows (full 512-byte row
-// pieces per wave), two outputs per lane.  The row-per-wave form above issues five overlapping strided 4-byte loads per input row and
-// output pair -- with two non-overlapping ones (wrong results) it ran at 4.4 instead of 2.9 TB/s, its stores cost nothing -- yet this
-// form, which loads every element once, measures the same 2.9 TB/s on the 511^2 and 255^2 maps and 3.1 against 2.45 on 127^2
-// (tools/maxpool_fwd_micro.py); a 16-byte read-only stream reaches 6 TB/s (tools/probes/hbm_read.hip).  Not understood yet.
+// 3x3 / stride-2 ceil-mode pool through LDS: 64 x 8 outputs per workgroup from a 129 x 17 input patch loaded by rows, two outputs per
+// lane -- for maps wider than the 512 columns maxpool3x3s2_rows_kernel keeps in registers.  Same 2.9 TB/s as the row-per-wave form on
+// the large maps (3.1 against 2.45 on 127^2): what the pool wants is neither -- see maxpool3x3s2_rows_kernel.
 __global__ __launch_bounds__(256) void maxpool3x3s2_tiled_kernel(float* __restrict__ y, const float* __restrict__ x, int in_h, int in_w, int out_h,
                                                                  int out_w, int tiles_x, int tiles_y) {
     constexpr int TW = 64, TH = 8, PW = 2 * TW + 1, PH = 2 * TH + 1;
@@ -476,6 +474,9 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_tiled_kernel(float* __restri
 }  // namespace
 
 namespace {
+// What the strided window costs (tools/maxpool_fwd_micro.py, 25 x 64 x 511^2): five overlapping 4-byte loads per row and output pair at
+// a lane stride of 8 bytes ran at 2.9 TB/s, two non-overlapping ones (wrong results) at 4.4, without the stores still 2.9; a read-only
+// stream reaches 6 TB/s (tools/probes/hbm_read.hip).  So:
 // 3x3 / stride-2 ceil-mode pool, one wave per output row with every input element loaded ONCE per wave and fully coalesced: lane l holds
 // the column-wise maximum of the row's three input rows at columns l, l + 64, ... (S slots), the stride-2 three-wide windows are
 // then formed across lanes (two shuffles per slot; the last lanes of a slot take the next slot's first ones) and the even lanes store.
