@@ -92,31 +92,10 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
 #pragma unroll
     for (int j = 0; j < CPT; ++j) na += u[j] * u[j];
     red[grp][px] = na;
-    // stats (gradient mode): A = sum f0^2, B = sum lin f0^2, C = sum lin u1 f0 per pixel -> [n][3][hw]; the backward
-    // (mgf_lpips_layer_bwd_relu_f32) then skips its own sweep over both maps for them
-    if (STATS) {
-        float nb = 0.f, nc = 0.f;
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int k = grp + j * G;
-            const float l = k < c ? lin[k] : 0.f;
-            nb += l * u[j] * u[j];
-            nc += l * v[UNIT_OUT ? 0 : j] * u[j];
-        }
-        redb[grp][px] = nb;
-        redc[grp][px] = nc;
-    }
     __syncthreads();
     na = 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) na += red[g][px];
-    if (STATS && grp == 0 && valid) {
-        float nb = 0.f, nc = 0.f;
-#pragma unroll
-        for (int g = 0; g < G; ++g) { nb += redb[g][px]; nc += redc[g][px]; }
-        float* so = stats + (int64_t)nn * 3 * hw + i;
-        so[0] = na; so[hw] = nb; so[2 * hw] = nc;
-    }
     const float ia = 1.f / (sqrtf(na) + 1e-10f);
     if (UNIT_OUT) {
         float* o = unit_out + (int64_t)nn * c * hw + pp;
@@ -127,7 +106,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
         }
         return;
     }
-    float d = 0.f;
+    float d = 0.f, nb = 0.f, nc = 0.f;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int k = grp + j * G;
@@ -136,7 +115,24 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
             // stored reference taps (u * ia above), so identical images give exactly zero
             const float ua = u[j] * ia;
             const float e = ua - v[UNIT_OUT ? 0 : j];
-            d += lin[k] * e * e;
+            const float l = lin[k];
+            d += l * e * e;
+            if (STATS) { nb += l * u[j] * u[j]; nc += l * v[UNIT_OUT ? 0 : j] * u[j]; }
+        }
+    }
+    // STATS (gradient mode): A = sum f0^2, B = sum lin f0^2, C = sum lin u1 f0 per pixel -> [n][3][hw]; the backward
+    // (mgf_lpips_layer_bwd_relu_stats_f32) then skips its own sweep over both maps for them.  Formed beside the distance (same operands, two
+    // more FMAs; as a loop of their own they cost the forward 75 % more time than they saved the backward)
+    if (STATS) {
+        redb[grp][px] = nb;
+        redc[grp][px] = nc;
+        __syncthreads();
+        if (grp == 0 && valid) {
+            float sb = 0.f, sc = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) { sb += redb[g][px]; sc += redc[g][px]; }
+            float* so = stats + (int64_t)nn * 3 * hw + i;
+            so[0] = na; so[hw] = sb; so[2 * hw] = sc;
         }
     }
     const float acc = block_sum_256(valid ? d : 0.f, sm);
