@@ -60,7 +60,12 @@ def build_parser():
                         "fetches with pretrained=True; required unless --no-lpips or --lpips-random-backbone")
     p.add_argument("--lpips-random-backbone", action="store_true",
                    help="score with SEEDED RANDOM backbone features (smoke runs only: the LPIPS term is then not a perceptual distance)")
-    p.add_argument("--batch", type=int, default=8, help="loop steps evaluated per generator forward (same result)")
+    p.add_argument("--batch", type=int, default=25,
+                   help="loop steps evaluated per generator forward in literal mode (same result; 25 = the benchmarked configuration, 40 GB of "
+                        "activations at 1024^2)")
+    p.add_argument("--keep-images", type=int, default=64,
+                   help="device slots for the scored image of every improvement (spilled to the host between launch sequences, so every "
+                        "improvement gets its PNG like the reference; raised to --batch if smaller)")
     p.add_argument("--mode", type=str, default="literal", choices=["literal", "gradient"],
                    help="literal = the loop as the reference executes it (best-of-N noisy sampling); gradient = back-propagate the loss "
                         "into the latent and let Adam move it")
@@ -122,8 +127,8 @@ def main(argv=None):
                                  allow_random_backbone=state is None)
     stem = os.path.splitext(os.path.basename(a.image))[0]
     res = drivers.project_image(G, target, lm_t, lm_s, args=args, percept=percept, batch=a.batch, seed=a.seed,
-                                out_prefix=os.path.join(a.path_to_gen, stem), mode=a.mode,
-                                path_to_gen=a.path_to_gen if a.mode == "literal" else None)
+                                out_prefix=os.path.join(a.path_to_gen, stem), mode=a.mode, path_to_gen=a.path_to_gen,
+                                keep_images=a.keep_images)
     print(f"best step {res['step']}  loss {res['loss']:.6f}")
     return 0
 

@@ -354,7 +354,10 @@ def conv_strided_dgrad(dy, w, stride, pad, in_hw, out=None):
 
     (py_, ky_), (px_, kx_) = geom(hq - hy), geom(wq - wy)
     key = (w.data_ptr(), tuple(w.shape), s, pad)
-    plan = _STRIDED_PLANS.get(key)
+    hit = _STRIDED_PLANS.get(key)
+    # the entry holds a reference to `w` itself: the address cannot be recycled for other weights while the plan lives, and a hit is
+    # only taken for the very same tensor object's storage (same version counter = not modified in place since)
+    plan = hit[0] if hit is not None and hit[1] is w and hit[2] == w._version else None
     if plan is None:                # the phase sub-kernels are a checkpoint constant: packed once
         plan = []
         for a in range(s):
@@ -366,7 +369,9 @@ def conv_strided_dgrad(dy, w, stride, pad, in_hw, out=None):
                 sub = torch.stack([w[:, :, ry + s * t, rx + s * u] for t in ts for u in us], dim=-1)        # [cout, cin, taps]
                 pc = pack_weights(sub.permute(1, 0, 2).reshape(cin, cout, 1, len(ts) * len(us)).contiguous())
                 plan.append((a, b, pc, [(qy - t, qx - u) for t in ts for u in us]))
-        _STRIDED_PLANS[key] = plan
+        if len(_STRIDED_PLANS) >= 8:                                 # a handful of stems at most: drop the oldest plan and its packs
+            _STRIDED_PLANS.pop(next(iter(_STRIDED_PLANS)))
+        _STRIDED_PLANS[key] = (plan, w, w._version)
     for a, b, pc, taps in plan:
         conv_forward(dy, pc, pad=(py_, px_), taps=taps, ksize=(ky_, kx_), out=phase)
         dst = out[:, :, a::s, b::s]

@@ -97,3 +97,22 @@ def gather_many(records: torch.Tensor, counts_max: int, group=None):
     keep = out[:, -1] >= 0
     out = out[keep]
     return out[torch.argsort(out[:, -1])]
+
+
+def run_sharded(n_items: int, work_fn, record_width: int, device, dynamic: bool = False, queue_name: str = "mgf_queue", group=None):
+    """The multi-GPU skeleton of `drivers.project_many`, free of any GPU work so that it runs under gloo on CPU: this rank takes its
+    items -- `items[rank::world]`, or with dynamic=True whatever the shared WorkQueue hands it (ragged per-item cost: targets whose
+    steps are skipped when no face is found) -- calls `work_fn(item) -> record [record_width] float64` (pack_result) for each, and ONE
+    ragged all_gather returns every item's record to every rank, ordered by item id.  Returns (records [n_items, width], mine) where
+    `mine` lists the items this rank worked on, in the order it did."""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
+    order = WorkQueue(n_items, name=queue_name) if dynamic else shard_items(n_items, rank, world)
+    recs, mine = [], []
+    for i in order:
+        recs.append(work_fn(i))
+        mine.append(i)
+    rows = torch.stack(recs) if recs else torch.empty([0, record_width], dtype=torch.float64, device=device)
+    assert rows.shape[1] == record_width, (tuple(rows.shape), record_width)
+    return gather_many(rows, n_items if dynamic else -(-n_items // world), group=group), mine

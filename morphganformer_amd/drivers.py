@@ -142,44 +142,70 @@ def merge_morph(G, w1, w2, alphas=(0.5,), truncation_psi=0.7, noise_mode="random
     return np.stack(lat), torch.stack(imgs)
 
 
+DEFAULT_BATCH = 25       # loop steps per generator forward in literal mode: the configuration bench.py times (1.6 GB of activations per step at 1024^2)
+
+
 def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None,
-                  eps=None, out_prefix=None, batch=1, use_graph=True, noise_mode="random", use_mse=True, seed=None,
-                  landmark_fn=None, mode="literal", weight_decay=0.0, path_to_gen=None, keep_images=32):
+                  eps=None, out_prefix=None, batch=DEFAULT_BATCH, use_graph=True, noise_mode="random", use_mse=True, seed=None,
+                  landmark_fn=None, mode="literal", weight_decay=0.0, path_to_gen=None, keep_images=64, engine=None,
+                  return_engine=False):
     """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and either
     `lm_steps` [steps,68,2] (injected landmark detections) or `landmark_fn` (host detector called on every generated image,
     see ProjectionEngine).  mode="literal" is the loop as the reference executes it (best-of-N noisy sampling, `batch` steps per
-    forward); mode="gradient" back-propagates the loss into the latent and lets Adam move it (GradientProjectionEngine; one
-    candidate per step; weight_decay=1e-4 is the 1024_example_MSE.py:117 optimizer).  Returns dict(w, step, loss, losses).
+    forward -- 25 by default, the benchmarked configuration; the result does not depend on it); mode="gradient" back-propagates the
+    loss into the latent and lets Adam move it (GradientProjectionEngine; one candidate per step; weight_decay=1e-4 is the
+    1024_example_MSE.py:117 optimizer).  Returns dict(w, step, loss, losses).
 
-    Outputs, like the drivers: with `path_to_gen` (literal mode) the SCORED image of every improvement -- the candidate as it was
-    generated and ranked, its random per-layer noise included -- is written as `{path_to_gen}/{step:06d}_{loss:04f}.png` (:190-195;
-    the images are kept on the device during the run, up to `keep_images` of them, and written afterwards).  `out_prefix` adds the
-    latent as `{out_prefix}.mat` (key 'w', :201-206 of the morph drivers)."""
+    Outputs, like the drivers: with `path_to_gen` the SCORED image of every improvement -- the candidate as it was generated and
+    ranked, its random per-layer noise included -- is written as `{path_to_gen}/{step:06d}_{loss:04f}.png` (:190-195; literal mode:
+    the images stay on the device during the run, `keep_images` slots that are spilled to the host between launch sequences, and are
+    written afterwards; gradient mode: the best latent's rendering under that name).  `out_prefix` adds the latent as
+    `{out_prefix}.mat` (key 'w', :201-206 of the morph drivers) and, when no `path_to_gen` trail is written, the best latent's
+    rendering as `{out_prefix}.png`.
+
+    engine: a ProjectionEngine from an earlier call with the same generator, objective, step count and batch (return_engine=True
+    hands it out) -- it is re-targeted in place (`ProjectionEngine.retarget`), which keeps its captured hipGraph and workspaces; this is
+    how `project_many` walks a list of targets."""
     args = args or ProjectionArgs()
+    if mode not in ("literal", "gradient"):
+        raise ValueError(f"mode must be 'literal' or 'gradient' (got {mode!r})")
+    if engine is not None and mode != "literal":
+        raise ValueError("engine= (re-targeting) is for literal mode")
     if latent_mean is None or latent_std is None:
         gen = None
         if seed is not None:
             gen = torch.Generator(device=G.device)
             gen.manual_seed(seed)
         latent_mean, latent_std = latent_stats(G, args.n_mean_latent, G.device, generator=gen)
-    if mode not in ("literal", "gradient"):
-        raise ValueError(f"mode must be 'literal' or 'gradient' (got {mode!r})")
-    if mode == "gradient":
+    keep = max(int(keep_images), int(batch)) if path_to_gen is not None and mode == "literal" else 0
+    if engine is not None:
+        if engine.G is not G or engine.batch != batch or engine.steps != args.step or engine.keep_images != keep:
+            raise ValueError("engine= was built for another generator / batch / step count / trail size")
+        eng = engine.retarget(target, lm_target=lm_target, lm_steps=lm_steps, eps=eps, seed=seed if eps is None else None,
+                              latent_mean=latent_mean, latent_std=float(latent_std))
+    elif mode == "gradient":
         eng = GradientProjectionEngine(G, target, latent_mean, float(latent_std), args, weight_decay=weight_decay, percept=percept,
                                        lm_target=lm_target, lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph,
-                                       use_mse=use_mse, landmark_fn=landmark_fn)
+                                       use_mse=use_mse, landmark_fn=landmark_fn, seed=0 if seed is None else seed)
     else:
         eng = ProjectionEngine(G, target, latent_mean, float(latent_std), args, percept=percept, lm_target=lm_target,
                                lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse,
-                               landmark_fn=landmark_fn, keep_images=keep_images if path_to_gen is not None else 0)
+                               landmark_fn=landmark_fn, keep_images=keep, seed=0 if seed is None else seed)
     w, step, loss, losses = eng.run().result()
     out = {"w": w, "step": step, "loss": loss, "losses": losses}
     if out_prefix is not None:
         save_latent_mat(f"{out_prefix}.mat", w)
+        if path_to_gen is None:                      # no improvement trail asked for: still leave an image of the result beside the latent
+            from .projection import save_best_png
+            out["image"] = save_best_png(G, w, f"{out_prefix}.png", args.ratio)
     if path_to_gen is not None:
-        if mode != "literal":
-            raise ValueError("path_to_gen (the per-improvement PNG trail) is kept by the literal-mode engine")
-        out["images"] = eng.save_improvements(path_to_gen, args.ratio)
+        if mode == "literal":
+            out["images"] = eng.save_improvements(path_to_gen, args.ratio)
+        else:
+            from .projection import save_best_png
+            out["images"] = [save_best_png(G, w, os.path.join(path_to_gen, "{:06d}_{:04f}.png".format(step, loss)), args.ratio)]
+    if return_engine:
+        out["engine"] = eng
     return out
 
 
@@ -189,30 +215,44 @@ def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):
     targets: list of [1,3,S,S] device tensors (or image paths); landmarks: optional list of (lm_target, lm_steps) per item.
     lockstep > 1 (gradient mode, static sharding): a rank advances that many of its items through one generator
     forward/backward per step (GradientProjectionEngine with B targets) instead of one after the other.
+    In literal mode the rank builds ONE engine (latent statistics, LPIPS workspaces, hipGraph capture) for its first item and
+    re-targets it for the others, as the reference keeps G / percept / latent statistics outside its per-image loop
+    (projection_example_v2_percept_morph.py:311-355).
     Returns dict(latents [N,k,D], losses [N], steps [N], items [N]) ordered by item id."""
     import torch.distributed as dist
-    from .distributed import WorkQueue, gather_many, pack_result, shard_items, unpack_results
+    from .distributed import gather_many, pack_result, run_sharded, shard_items, unpack_results
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
-    order = WorkQueue(len(targets)) if dynamic else shard_items(len(targets), rank, world)
     load = lambda t: t if isinstance(t, torch.Tensor) else image_transform(t, size=G.img_resolution, device=G.device)
-    recs = []
+    width = G.cfg.k * G.cfg.z_dim + 3
     if lockstep > 1:
         if dynamic or kw.get("mode") != "gradient":
             raise ValueError("lockstep groups need mode='gradient' and static sharding")
-        mine = list(order)
+        recs = []
+        mine = shard_items(len(targets), rank, world)
         for g0 in range(0, len(mine), lockstep):
             ids = mine[g0:g0 + lockstep]
             res = _project_group(G, [load(targets[i]) for i in ids], [landmarks[i] for i in ids] if landmarks is not None else None, **kw)
             recs += [pack_result(res["w"][j:j + 1].to(G.device), float(res["loss"][j]), int(res["step"][j]), item=i) for j, i in enumerate(ids)]
-    else:
-        for i in order:
-            lm_t, lm_s = landmarks[i] if landmarks is not None else (None, None)
-            r = project_image(G, load(targets[i]), lm_t, lm_s, **kw)
-            recs.append(pack_result(r["w"].to(G.device), r["loss"], r["step"], item=i))
-    width = G.cfg.k * G.cfg.z_dim + 3
-    mine = torch.stack(recs) if recs else torch.empty([0, width], dtype=torch.float64, device=G.device)
-    rows = gather_many(mine, len(targets) if dynamic else -(-len(targets) // world))
+        rows = torch.stack(recs) if recs else torch.empty([0, width], dtype=torch.float64, device=G.device)
+        return unpack_results(gather_many(rows, -(-len(targets) // world)), (G.cfg.k, G.cfg.z_dim))
+    reuse = kw.get("mode", "literal") == "literal" and kw.get("landmark_fn") is None and kw.get("eps") is None
+    if reuse and (kw.get("latent_mean") is None or kw.get("latent_std") is None):
+        a = kw.get("args") or ProjectionArgs()
+        gen = None
+        if kw.get("seed") is not None:
+            gen = torch.Generator(device=G.device)
+            gen.manual_seed(kw["seed"])
+        kw["latent_mean"], kw["latent_std"] = latent_stats(G, a.n_mean_latent, G.device, generator=gen)     # once per rank, not per item
+    state = {"eng": None}
+
+    def work(i):
+        lm_t, lm_s = landmarks[i] if landmarks is not None else (None, None)
+        r = project_image(G, load(targets[i]), lm_t, lm_s, engine=state["eng"], return_engine=reuse, **kw)
+        state["eng"] = r.get("engine")
+        return pack_result(r["w"].to(G.device), r["loss"], r["step"], item=i)
+
+    rows, _mine = run_sharded(len(targets), work, width, G.device, dynamic=dynamic)
     return unpack_results(rows, (G.cfg.k, G.cfg.z_dim))
 
 

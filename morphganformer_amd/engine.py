@@ -240,7 +240,7 @@ class Generator:
     # free them (it used to).  Engines `pin` the batch size they captured; only un-pinned workspaces are ever dropped, and only when
     # the total exceeds MGF_WORKSPACE_GB (default 160 of the 288 GB).
     _WS_FIELDS = ("n", "w_buf", "styles", "demods", "vtabs", "noise_rand", "bufs", "img", "const_in", "rgbw", "style_jobs", "n_style_jobs",
-                  "max_style_cin", "attn_jobs", "n_attn_jobs", "style_jobs_pl", "attn_jobs_pl", "ws_bytes")
+                  "max_style_cin", "attn_jobs", "n_attn_jobs", "style_jobs_pl", "attn_jobs_pl", "ws_bytes", "ws_gen")
 
     def _alloc(self, n):
         """Make the workspace of batch size n current (created on first use)."""
@@ -290,6 +290,10 @@ class Generator:
         cfg, dev, P = self.cfg, self.device, self.plan
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         self.n = n
+        # generation id: consumers that cache raw pointers into this workspace (grad.GeneratorGrad's job tables) rebuild them when a
+        # workspace of the same batch size was evicted and created anew
+        self._gen_counter = getattr(self, "_gen_counter", 0) + 1
+        self.ws_gen = self._gen_counter
         self.w_buf = e(n, cfg.k, cfg.w_dim)
         self.styles = e(n, P.s_total)
         self.demods = e(n, P.d_total)

@@ -49,6 +49,8 @@ class GeneratorGrad:
                 self.Tw[lp.name] = cv.winograd_pack(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), 1.0, lp.res)
         self._bufs = {}
         self._n = None
+        self._gen = None                  # generation id of the generator workspace the job tables below point into
+        self.per_layer = False
         self.map_scratch = None
         self.z = None
         self.psi = 1.0
@@ -67,7 +69,7 @@ class GeneratorGrad:
         """Per-batch-size reduction buffers and the device job tables of the latent-side kernels."""
         G, P, cfg, L = self.G, self.G.plan, self.G.cfg, _lib.lib()
         D, T = cfg.w_dim, cfg.k - 1
-        self._n = n
+        self._n, self._gen = n, G.ws_gen
         # per-slice partial sums of mgf_attn_values_grad_ws (allocated here, not at first use: never inside a captured launch sequence)
         cmax = max([lp.attn.c for lp in P.layers if lp.attn is not None] or [1])
         self.avg_ws = torch.empty(int(L.mgf_attn_values_grad_workspace_floats(n, cmax)), dtype=torch.float32, device=G.device)
@@ -98,6 +100,11 @@ class GeneratorGrad:
         self.dyc = e(n, max(len(aj), 1), T, D)
         self.dw = e(n, cfg.k, D)
         self.dz = e(n, cfg.k, D)
+        # W+ (per-layer latents, networks.py:1252-1253): layer j's style gradient belongs to slot lp.slot of the global component, its
+        # attention-value gradient to the same slot of the T local components -- index tables for the scatter of backward_ws
+        self.dws = e(n, cfg.k, cfg.num_ws, D)
+        self.style_slots = torch.tensor([lp.slot for lp in P.layers], dtype=torch.int64, device=G.device)
+        self.attn_slots = torch.tensor([lp.slot for lp in P.layers if lp.attn is not None], dtype=torch.int64, device=G.device)
         self.max_channels = max(max(lp.cin, lp.cout) for lp in P.layers)
 
     # ------------------------------------------------------------------ forward
@@ -105,11 +112,16 @@ class GeneratorGrad:
         """G(z)[0] (or G(ws=...)) with conv_last kept in memory (the fused conv_last+ToRGB kernel never writes it)."""
         G = self.G
         if ws is not None:
-            # the backward pass sums the layers' latent gradients into ONE latent set: a broadcast ws (what mapping() returns, an
-            # expanded view) is fine, distinct per-layer latents are not supported here
-            if ws.ndim == 4 and ws.stride(2) != 0:
-                raise _lib.MgfError("GeneratorGrad: per-layer ws (W+) has no backward pass; pass z, or a ws broadcast over the layer axis")
-            w = (ws[:, :, 0] if ws.ndim == 4 else ws).contiguous().float()
+            # ws [n, k, num_ws, D]: a broadcast VIEW (what mapping() returns: stride 0 over the layer axis) or [n, k, D] takes the shared
+            # tables; anything dense takes the per-layer tables -- always correct, also for a materialised broadcast (G.mapping(z, psi) /
+            # return_ws=True hand out dense copies): backward_w() then returns the SUM over the slots, i.e. the gradient with respect to
+            # one shared latent set, and backward_ws() the per-slot (W+) gradient
+            if ws.ndim == 4 and ws.stride(2) == 0:
+                ws = ws[:, :, 0]
+            w = ws.contiguous().float()
+            self.per_layer = w.ndim == 4
+        else:
+            self.per_layer = False
         # the backward pass reads conv_last's activation and the full-resolution skip tensors: both fusions off for this forward
         # (the skip branch stays fused into conv1's Winograd epilogue where the engine does that -- G.skip_fused[res] -- and the backward
         # up-samples the half-resolution skip tensor itself; MGF_GRAD_FUSE_SKIP=0: the full-resolution tensor in both passes)
@@ -133,8 +145,8 @@ class GeneratorGrad:
             G.fuse_torgb, G.fuse_skip_up, G.map_save = True, keep_up, None
         self.z = None if z is None else z.contiguous().float()
         self.psi = float(truncation_psi) if ws is None else 1.0
-        if self._n != G.n:            # after G: its style / demod arenas (pointed to by the job tables) are sized by then
-            self._alloc(G.n)
+        if (self._n, self._gen) != (G.n, G.ws_gen):     # after G: its style / demod arenas (pointed to by the job tables) are sized by then;
+            self._alloc(G.n)                            # a workspace evicted and re-created at the same batch size has a new generation id
         return img
 
     # ------------------------------------------------------------------ backward
@@ -228,7 +240,32 @@ class GeneratorGrad:
         return self._style_bwd(lp, g, x_in, dx_role)
 
     def backward_w(self, dimg):
-        """dimg [n,3,R,R] -> dw [n,k,D]: gradient of <img, dimg> with respect to the intermediate latent w."""
+        """dimg [n,3,R,R] -> dw [n,k,D]: gradient of <img, dimg> with respect to the intermediate latent w (after a forward with
+        per-layer ws: summed over the layer slots, i.e. with respect to a latent set shared by all layers)."""
+        G, cfg, L = self.G, self.G.cfg, _lib.lib()
+        self._backward_layers(dimg)
+        _lib.check(L.mgf_latent_grad_gather(self.dw.data_ptr(), self.dwg.data_ptr(), self.n_style_jobs, self.dyc.data_ptr(),
+                                            self.n_attn_jobs, G.n, cfg.k, cfg.w_dim, self.psi, _lib.stream_ptr()), "latent_grad_gather")
+        return self.dw
+
+    def backward_ws(self, dimg):
+        """dimg [n,3,R,R] -> dws [n,k,num_ws,D]: the W+ gradient -- every layer's latent gradient lands in its own slot (layer `slot`
+        reads ws[:, :, slot] for its style AND its attention values, networks.py:1022-1031,1252-1253; slots are unique per layer, so the
+        scatter has no collisions).  Valid after forward(ws=...) or forward(z): summed over axis 2 it equals backward_w()."""
+        G, cfg = self.G, self.G.cfg
+        self._backward_layers(dimg)
+        T = cfg.k - 1
+        self.dws.zero_()
+        self.dws[:, T].index_copy_(1, self.style_slots, self.dwg)                                  # [n, num_ws, D] <- [n, layers, D]
+        if self.n_attn_jobs:
+            self.dws[:, :T].index_copy_(2, self.attn_slots, self.dyc[:, :self.n_attn_jobs].permute(0, 2, 1, 3))     # [n, T, num_ws, D] <- [n, T, A, D]
+        if self.psi != 1.0:
+            self.dws.mul_(self.psi)
+        return self.dws
+
+    def _backward_layers(self, dimg):
+        """The synthesis network's backward pass down to the per-layer latent gradients: dwg [n, layers, D] (style path -> the global
+        component) and dyc [n, attention layers, T, D] (attention values -> the local components)."""
         G, P, cfg, L = self.G, self.G.plan, self.G.cfg, _lib.lib()
         _lib.require_gpu(dimg)
         n = G.n
@@ -305,9 +342,6 @@ class GeneratorGrad:
         if self.n_attn_jobs:
             _lib.check(L.mgf_attn_values_bwd_multi(self.dyc.data_ptr(), self.attn_jobs.data_ptr(), self.n_attn_jobs, n, T, D, st),
                        "attn_values_bwd_multi")
-        _lib.check(L.mgf_latent_grad_gather(self.dw.data_ptr(), self.dwg.data_ptr(), self.n_style_jobs, self.dyc.data_ptr(),
-                                            self.n_attn_jobs, n, cfg.k, D, self.psi, st), "latent_grad_gather")
-        return self.dw
 
     def backward(self, dimg):
         """dimg -> dz [n,k,D] (through the mapping network; forward() must have been called with z)."""

@@ -264,7 +264,12 @@ class BiometricLoss:
             self._tgt_net.__dict__.update({k: v for k, v in e.__dict__.items()
                                            if k not in ("bufs", "x112", "stem_out", "flat", "out") and not k.startswith("_g")})
             self._tgt_net._alloc(nt)
-        self._target = self._tgt_net.embed_image(target.float()).clone()
+        emb = self._tgt_net.embed_image(target.float())
+        old = getattr(self, "_target", None)
+        if old is not None and old.shape == emb.shape:
+            old.copy_(emb)            # in place: a captured hipGraph of the projection engine keeps reading this buffer (ProjectionEngine.retarget)
+        else:
+            self._target = emb.clone()
         self._target_stride = 512 if nt > 1 else 0
 
     def distance_into(self, out, pred, scale=1.0, accumulate=False):

@@ -490,8 +490,12 @@ class PerceptualLoss(torch.nn.Module):
         self._target_n = n
         f = self._features(n, h, w)
         keys = TAPS_AFTER if self.net == "squeeze" else range(len(self.chns))
-        outs = [torch.empty([n, c, *f.shapes[idx][1:]], dtype=torch.float32, device=self.device_)
-                for c, idx in zip(self.chns, keys)]
+        shapes = [(n, c, *f.shapes[idx][1:]) for c, idx in zip(self.chns, keys)]
+        old = getattr(self, "_target_taps", None)
+        if old is not None and [tuple(t.shape) for t in old] == shapes:
+            outs = old                # same geometry: rewrite the cached taps IN PLACE -- a captured hipGraph of the projection engine reads
+        else:                         # these buffers (ProjectionEngine.retarget); every element is overwritten below
+            outs = [torch.empty(sh, dtype=torch.float32, device=self.device_) for sh in shapes]
         if self.fused_stem and n == 1:
             # outs[0] holds the NORMALISED tap 0 (what the stem's distance mode compares against); the same kernel arithmetic
             # runs on both images, so identical images still give exactly zero

@@ -183,6 +183,12 @@ class ProjectionEngine:
             self.trail_losses = torch.zeros(self.keep_images, dtype=torch.float64, device=dev)
             self.trail_count = torch.zeros(1, dtype=torch.int32, device=dev)
             self.take_slot = torch.full([B], -1, dtype=torch.int32, device=dev)
+            if self.keep_images < B:
+                import warnings
+                warnings.warn(f"ProjectionEngine: keep_images={self.keep_images} < batch={B}: one launch sequence can improve more often than "
+                              "there are trail slots, and then only the latest improvement of the overflow keeps its image (the reference "
+                              "writes a PNG at every improvement); use keep_images >= batch", stacklevel=2)
+        self._spilled, self._seq_since_spill, self._trail_lost = [], 0, 0
         self.use_graph = use_graph
         self.graph = None
         self.pipeline = bool(pipeline) and landmark_fn is None
@@ -300,6 +306,7 @@ class ProjectionEngine:
             self._pipe_gen(self._parity)                                  # the first batch has no losses to overlap with
             self._primed = True
         for _ in range(n):
+            self._before_sequence()
             if self.use_graph:
                 self.graphs[self._parity].replay()
             else:
@@ -324,23 +331,56 @@ class ProjectionEngine:
             st += (self.trail_count, self.trail_steps, self.trail_losses)
         return st
 
+    def _spill_trail(self):
+        """Move the filled trail slots to host memory and empty the device trail (between launch sequences; one host sync).  `run()`
+        calls this whenever the NEXT launch sequence could overflow the K slots -- a sequence improves at most `batch` times -- so with
+        keep_images >= batch every improvement of a run of any length keeps its scored image, like the reference's PNG per improvement
+        (...sqz_MSE.py:186-195), for K x 12.6 MB of device memory instead of one slot per step."""
+        torch.cuda.synchronize(self.device)
+        total = int(self.trail_count.item())
+        n = min(total, self.keep_images)
+        self._trail_lost += total - n
+        if n:
+            steps, losses = self.trail_steps[:n].cpu().numpy(), self.trail_losses[:n].cpu().numpy()
+            imgs = self.trail_imgs[:n].cpu()
+            c, r = self.G.cfg.img_channels, self.G.cfg.img_resolution
+            self._spilled += [(int(steps[i]), float(losses[i]), imgs[i].view(c, r, r)) for i in range(n)]
+        self.trail_count.zero_()
+        self.trail_steps.fill_(-1)
+        self._seq_since_spill = 0
+
+    def _before_sequence(self):
+        """Trail bookkeeping in front of every launch sequence (see _spill_trail)."""
+        if self.keep_images > 0:
+            if self._seq_since_spill > 0 and (self._seq_since_spill + 1) * self.batch > self.keep_images:
+                self._spill_trail()
+            self._seq_since_spill += 1
+
     def improvements(self):
-        """The improvement trail of a keep_images=K engine: list of (step, loss, image [C,H,W] device tensor) in the order the
-        improvements happened -- the (step, min_loss, img_gen_raw) triples the drivers turn into PNG files (:186-195).  With more
-        than K improvements the list holds the first K-1 and the latest."""
+        """The improvement trail of a keep_images=K engine: list of (step, loss, image [C,H,W]) in the order the improvements
+        happened -- the (step, min_loss, img_gen_raw) triples the drivers turn into PNG files (:186-195).  Images still resident in the
+        device trail are device tensors, those already spilled to the host (see _spill_trail) CPU tensors.  With keep_images >= batch
+        the list is complete; otherwise a launch sequence with more than K improvements kept its first K-1 and its latest (a warning
+        says how many images were lost)."""
         assert self.keep_images > 0, "construct the engine with keep_images=K"
         torch.cuda.synchronize(self.device)
-        n = min(int(self.trail_count.item()), self.keep_images)
+        total = int(self.trail_count.item())
+        n = min(total, self.keep_images)
+        lost = self._trail_lost + total - n
+        if lost:
+            import warnings
+            warnings.warn(f"ProjectionEngine: {lost} improvement image(s) were overwritten: keep_images={self.keep_images} < batch={self.batch} "
+                          "(the reference writes one PNG per improvement)", stacklevel=2)
         c, r = self.G.cfg.img_channels, self.G.cfg.img_resolution
         steps, losses = self.trail_steps.cpu().numpy(), self.trail_losses.cpu().numpy()
-        return [(int(steps[i]), float(losses[i]), self.trail_imgs[i].view(c, r, r)) for i in range(n)]
+        return list(self._spilled) + [(int(steps[i]), float(losses[i]), self.trail_imgs[i].view(c, r, r)) for i in range(n)]
 
     def save_improvements(self, output_dir, ratio=1.0):
         """Write the trail as the drivers do: `{output_dir}/{step:06d}_{loss:04f}.png` of crop(to_pil(img), ratio) (:190-195)."""
         from .drivers import save_image
         paths = []
         for step, loss, img in self.improvements():
-            paths.append(save_image(self.G, img.unsqueeze(0), os.path.join(output_dir, "{:06d}_{:04f}.png".format(step, loss)), ratio))
+            paths.append(save_image(self.G, img.unsqueeze(0).to(self.device), os.path.join(output_dir, "{:06d}_{:04f}.png".format(step, loss)), ratio))
         return paths
 
     def _capture(self):
@@ -377,10 +417,77 @@ class ProjectionEngine:
         if self.use_graph and self.graph is None:
             self._capture()
         for _ in range(n):
+            self._before_sequence()
             if self.graph is not None:
                 self.graph.replay()
             else:
                 self._iteration()
+        return self
+
+    def retarget(self, target, lm_target=None, lm_steps=None, lm_valid=None, eps=None, seed=None, latent_mean=None, latent_std=None):
+        """Point this engine at ANOTHER target image and rewind the loop, keeping everything that was expensive to set up: the captured
+        hipGraph(s), the generator workspace, the LPIPS / embedder workspaces, the loss scratch.  Only data changes, in place, in the
+        buffers the graph already references: the target image and its cached LPIPS taps / embedding, the landmark tables, the noise
+        stream (`eps` given, or redrawn from `seed`), optionally the start latent and the noise schedule, and the loop state (step
+        counter, best-so-far, loss history, improvement trail).  A run after retarget() equals the run of a freshly constructed engine
+        on the same inputs bit for bit (tests/test_hip_drivers.py).  This is what the reference's serial per-image loop amortises by
+        keeping G / percept / latent statistics outside `projection()` (projection_example_v2_percept_morph.py:311-355); BASELINE
+        configs 3 and 5 are batches of targets."""
+        a, dev = self.args, self.device
+        _lib.require_gpu(target)
+        assert tuple(target.shape) == tuple(self.target.shape), (tuple(target.shape), tuple(self.target.shape))
+        torch.cuda.synchronize(dev)
+        self.target.copy_(target)
+        if self.percept is not None:
+            self.percept.set_target(self.target)                  # same shapes: rewrites the cached taps in place
+        if self.biometric is not None:
+            self.biometric.set_target(self.target)
+        if self.use_wing:
+            assert lm_target is not None, "this engine has a Wing term: pass the new target's landmarks"
+            self.lm_target.copy_(torch.as_tensor(lm_target, dtype=torch.float64).reshape(self.lm_target.shape))
+            if self.landmark_fn is not None or self.landmark_model is not None:
+                self.lm_steps.zero_()
+                self.valid.zero_()
+            else:
+                assert lm_steps is not None, "pass the per-step landmark table of the new target"
+                t = torch.as_tensor(lm_steps, dtype=torch.float64)
+                assert t.shape[0] >= a.step and tuple(t.shape[1:]) == tuple(self.lm_target.shape)
+                self.lm_steps[:a.step].copy_(t[:a.step])
+                if self.valid is not None:
+                    self.valid.copy_(torch.ones(self.valid.shape, dtype=torch.int32) if lm_valid is None
+                                     else torch.as_tensor(lm_valid, dtype=torch.int32).reshape(self.valid.shape))
+                else:
+                    assert lm_valid is None, "the engine was built without a `valid` table; construct it with lm_valid to use one"
+        if eps is not None:
+            assert eps.shape[0] >= a.step
+            self.eps[:a.step].copy_(eps[:a.step].reshape(a.step, *self.eps.shape[1:]))
+        elif seed is not None:
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(seed)
+            self.eps.copy_(torch.randn(self.eps.shape, device=dev, generator=gen))       # same draw as the constructor's
+        if latent_mean is not None:
+            self.latent_in.copy_(latent_mean.detach().reshape(self.latent_in.shape))
+        if latent_std is not None:
+            self.sigma.copy_(torch.as_tensor(noise_schedule(a.step, float(latent_std), a.noise, a.noise_ramp)))
+        self.rewind()
+        return self
+
+    def rewind(self):
+        """Loop state back to step 0 (graph, workspaces and inputs untouched)."""
+        a = self.args
+        self.step_ctr.zero_()
+        self.min_loss.fill_(float(a.min_loss_init))
+        self.best_latent.zero_()
+        self.best_step.fill_(-1)
+        self.losses.fill_(float("nan"))
+        if self.keep_images > 0:
+            self.trail_count.zero_()
+            self.trail_steps.fill_(-1)
+            self.trail_losses.zero_()
+        self._spilled, self._seq_since_spill, self._trail_lost = [], 0, 0
+        if self.pipeline:
+            self.gen_ctr.zero_()
+            self._parity, self._primed = 0, False
         return self
 
     def result(self):

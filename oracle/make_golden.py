@@ -292,7 +292,14 @@ def gold_wplus_tiny(ref):
     img_ws, att_ws = G(ws=ws, noise_mode="const", return_att=True)
     img_cut, ws_cut = G(z, None, truncation_psi=0.6, truncation_cutoff=5, noise_mode="const", return_ws=True)
     img_psi, ws_psi = G(z, None, truncation_psi=0.6, noise_mode="const", return_ws=True)
+    # gradient-mode oracle for W+: d(mean(img^2)) / d(ws) through the REFERENCE module's autograd, every layer slot its own gradient
+    wg = ws.clone().requires_grad_(True)
+    G.requires_grad_(False)
+    loss_ws = G(ws=wg, noise_mode="const")[0].square().mean()
+    (grad_ws,) = torch.autograd.grad(loss_ws, wg)
+    assert float(grad_ws.abs().amax(dim=(0, 1, 3)).min()) > 0          # every one of the num_ws slots receives a gradient
     np.savez_compressed(os.path.join(OUT, "wplus_tiny.npz"), z=z.numpy(), ws=ws.numpy(), img_ws=img_ws.numpy(),
+                        loss_ws=np.float32(loss_ws.item()), grad_ws=grad_ws.numpy(),
                         att_shape=np.array(att_ws.shape), att_sub=att_ws[:, :, :, 0, 3::8, 5::8].numpy(),
                         img_cut=img_cut.numpy(), ws_cut=ws_cut.numpy(), img_psi=img_psi.numpy(), ws_psi=ws_psi.numpy(),
                         img_synthesis_subnet=G(ws=ws, noise_mode="const", subnet="synthesis").numpy())

@@ -165,6 +165,54 @@ def test_improvement_trail_keeps_the_scored_images(golden):
     assert float((trail[1][2] - fresh).abs().max()) < 1e-5 * float(fresh.abs().max())
 
 
+def test_retargeted_engine_equals_fresh_engines(golden):
+    """ProjectionEngine.retarget: one engine (one captured hipGraph, one set of workspaces) walked over three targets gives, for every
+    target, the run of a freshly constructed engine bit for bit -- best latent, best step, loss history, improvement trail -- with the
+    full objective (LPIPS + Wing + MSE), graph replay, several steps per forward and the trail spilled to the host on the way."""
+    from morphganformer_amd.lpips import PerceptualLoss
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, synthetic_landmarks
+    from morphganformer_amd.synth_weights import TINY, synthetic_latents
+    g = golden("loop_tiny.npz")
+    G = _tiny_G()
+    steps, batch, keep = 40, 4, 8
+    mean, std = torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"])
+    targets = [G(torch.from_numpy(synthetic_latents(TINY, 1, 3000 + j)).cuda(), None, noise_mode="const")[0].clamp(-1, 1) for j in range(3)]
+    lms = [synthetic_landmarks(steps, 64, 20 + j) for j in range(3)]
+
+    def fresh(j):
+        P = PerceptualLoss(net="squeeze", allow_random_backbone=True)
+        return ProjectionEngine(G, targets[j], mean, std, ProjectionArgs(step=steps), percept=P, use_mse=True, lm_target=lms[j][0],
+                                lm_steps=lms[j][1], noise_mode="const", seed=100 + j, batch=batch, keep_images=keep, use_graph=True)
+
+    def outcome(eng):
+        lat, bstep, bloss, hist = eng.run().result()
+        trail = [(s_, l_, im.cpu().clone()) for s_, l_, im in eng.improvements()]
+        return lat, bstep, bloss, hist, trail
+
+    want = [outcome(fresh(j)) for j in range(3)]
+    eng = fresh(0)
+    graph = None
+    for j in range(3):
+        if j:
+            eng.retarget(targets[j], lm_target=lms[j][0], lm_steps=lms[j][1], seed=100 + j)
+        lat, bstep, bloss, hist, trail = outcome(eng)
+        if graph is None:
+            graph = eng.graph
+        assert eng.graph is graph and graph is not None                     # the captured graph is reused, never re-captured
+        w = want[j]
+        assert bstep == w[1] and bloss == w[2] and torch.equal(lat, w[0]) and np.array_equal(hist, w[3]), j
+        assert [(t[0], t[1]) for t in trail] == [(t[0], t[1]) for t in w[4]] and len(trail) >= 2
+        assert all(torch.equal(a[2], b[2]) for a, b in zip(trail, w[4])), j
+    assert not np.array_equal(want[0][3], want[1][3])                         # the targets really differ
+    # the trail of a long run is complete although it has fewer device slots than improvements: it spills between launch sequences
+    hist, best, impr = want[0][3], 100.0, []
+    for i, v in enumerate(hist):
+        if v < best:
+            best = v
+            impr.append(i)
+    assert [t[0] for t in want[0][4]] == impr
+
+
 def test_landmark_callback_mode_equals_injected_table(golden):
     """A host detector called on every generated image (the drivers' dlib step) gives the same run as the table it produces."""
     from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine

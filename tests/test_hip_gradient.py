@@ -296,6 +296,38 @@ def test_tiny_gradient_matches_reference_module(tiny, golden):
     assert rel(dz, g["grad_z"]) < GRAD_TOL
 
 
+def test_wplus_gradient_matches_reference_module(tiny, golden):
+    """W+ (per-layer latents, networks.py:1252-1253,1304-1331): d mean(img^2) / d ws [n, k, num_ws, D] by the REFERENCE module's
+    autograd (tests/golden/wplus_tiny.npz: grad_ws) vs GeneratorGrad.backward_ws -- every layer's style / attention-value gradient in
+    its own slot.  Summed over the slots it is backward_w(); a dense broadcast ws (what G.mapping(z, psi) / return_ws=True hand out)
+    is accepted and gives the shared-latent gradient."""
+    gg, tsd, cfg = tiny
+    g = golden("wplus_tiny.npz")
+    ws = torch.from_numpy(g["ws"]).cuda()
+    img = gg.forward(ws=ws, noise_mode="const")
+    assert rel(img, g["img_ws"]) < 1e-3
+    assert abs(float(img.square().mean()) - float(g["loss_ws"])) < 1e-3 * float(g["loss_ws"])
+    dimg = 2.0 * img / img.numel()
+    dws = gg.backward_ws(dimg).clone()
+    assert tuple(dws.shape) == tuple(g["grad_ws"].shape)
+    assert rel(dws, g["grad_ws"]) < GRAD_TOL
+    # per slot, not only overall: every layer slot's own gradient within tolerance of that slot's scale
+    for s in range(cfg.num_ws):
+        assert rel(dws[:, :, s], g["grad_ws"][:, :, s]) < 5 * GRAD_TOL, s
+    dw = gg.backward_w(dimg)
+    assert rel(dw, g["grad_ws"].sum(axis=2)) < GRAD_TOL
+    # a MATERIALISED broadcast (dense copy of mapping()'s view) is the ordinary shared-latent case
+    gt = golden("gen_tiny.npz")
+    z = torch.from_numpy(gt["z"]).cuda()
+    wsb = gg.G.mapping(z).contiguous()
+    assert wsb.stride(2) != 0
+    img_b = gg.forward(ws=wsb, noise_mode="const")
+    dw_b = gg.backward_w(2.0 * img_b / img_b.numel()).clone()
+    img_v = gg.forward(ws=gg.G.mapping(z), noise_mode="const")                     # the zero-stride view: shared tables
+    dw_v = gg.backward_w(2.0 * img_v / img_v.numel())
+    assert rel(img_b, img_v) < 1e-6 and rel(dw_b, dw_v) < 1e-4
+
+
 @pytest.mark.parametrize("net,size", [("squeeze", 65), ("squeeze", 128), ("vgg", 48), ("vgg", 70), ("alex", 96), ("alex", 131), ("alex", 224)])
 def test_lpips_gradient_matches_autograd(net, size):
     from morphganformer_amd.lpips import PerceptualLoss, random_backbone, WEIGHTS_DIR

@@ -215,6 +215,52 @@ def test_result_gather_gloo_world2(tmp_path):
         assert p.returncode == 0 and f"ok {r}" in o, o
 
 
+GLOO_WORKER_RAGGED = r"""
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from morphganformer_amd.distributed import pack_result, run_sharded, unpack_results
+world = int(sys.argv[4])
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=world)
+rank = dist.get_rank()
+N, K, D = 11, 17, 32
+# ragged per-item cost, as when "no face found" skips most steps of some targets (...sqz_MSE.py:165-166): item i costs cost[i]
+cost = [0.02, 0.30, 0.02, 0.02, 0.25, 0.02, 0.02, 0.02, 0.20, 0.02, 0.02]
+def work(i):
+    time.sleep(cost[i] * (1.0 + 0.5 * rank))                      # the ranks also run at different speeds
+    return pack_result(torch.full((1, K, D), float(i)), 10.0 + i, 100 + i, item=i)
+for dynamic in (True, False, True):                                 # (the second dynamic pass: a fresh queue epoch in the same group)
+    dist.barrier()
+    rows, mine = run_sharded(N, work, K * D + 3, "cpu", dynamic=dynamic)
+    res = unpack_results(rows, (K, D))
+    assert res["items"].tolist() == list(range(N)), res["items"].tolist()                 # every item exactly once, on every rank
+    assert res["steps"].tolist() == [100 + i for i in range(N)] and res["losses"].tolist() == [10.0 + i for i in range(N)]
+    assert all(float(res["latents"][i, 0, 0]) == float(i) for i in range(N))
+    cnt = torch.zeros(N); cnt[mine] = 1
+    dist.all_reduce(cnt)
+    assert cnt.tolist() == [1.0] * N
+    if not dynamic:
+        assert mine == list(range(rank, N, world))
+    else:
+        assert len(mine) >= 1                                       # nobody starves; who takes what depends on the interleaving
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_ragged_work_queue_gloo_world3(tmp_path):
+    """project_many's multi-GPU skeleton (distributed.run_sharded: dynamic WorkQueue / static shards + the ragged result gather) at
+    world size 3 with ragged per-item cost and ranks of different speed: every item is projected exactly once and every rank ends up
+    with all results in item order."""
+    script = tmp_path / "worker_ragged.py"
+    script.write_text(GLOO_WORKER_RAGGED)
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r), "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(3)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"ok {r}" in o, o
+
+
 def test_bench_self_launches_n_ranks():
     """`python bench.py --gpus 2` without a launcher starts two ranks itself (torch.distributed.run as a child of a parent that never
     imports torch), hands rank 0's JSON line through and fails when a rank fails -- rehearsed on CPU with the gloo dry-run leg."""

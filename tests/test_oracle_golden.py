@@ -319,3 +319,9 @@ def test_per_layer_ws_truncation_cutoff_and_att_tensor_vs_reference(golden):
         assert rel(wst, g[kws]) < TOL
         assert rel(generator_ref(sd, z, TINY, "const", truncation_psi=psi, truncation_cutoff=cut), g[kimg]) < 1e-5
     assert float((torch.from_numpy(g["ws_cut"])[:, :, 5:] - w[:, :, None]).abs().max()) < 1e-6          # slots >= cutoff untouched
+    # W+ gradient: the restatement's autograd with respect to per-layer latents against the reference module's (grad_ws)
+    wg = ws.clone().requires_grad_(True)
+    loss = synthesis_ref(sd, wg, TINY, "const").square().mean()
+    (gws,) = torch.autograd.grad(loss, wg)
+    assert abs(float(loss.detach()) - float(g["loss_ws"])) < 1e-5 * float(g["loss_ws"])
+    assert rel(gws, g["grad_ws"]) < 1e-4
