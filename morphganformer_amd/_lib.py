@@ -195,5 +195,10 @@ def dtype_id(dt: torch.dtype) -> int:
 
 
 def make_epilogue(bias=None, noise=None, noise_strength=None, noise_n=1, act="linear", alpha=0.2, gain=1.0, residual=None):
-    return Epilogue(ptr(bias), ptr(noise), ptr(noise_strength), int(noise_n), ACT_IDS[act], float(alpha), float(gain),
-                    ptr(residual))
+    ep = Epilogue(ptr(bias), ptr(noise), ptr(noise_strength), int(noise_n), ACT_IDS[act], float(alpha), float(gain),
+                  ptr(residual))
+    # the struct holds raw device pointers: keep the tensors alive as long as it lives, so that a temporary passed by the caller
+    # (`make_epilogue(bias=b.cuda())`) is not handed back to the caching allocator -- and reused for the launch's own output -- before
+    # the kernel that reads it has been enqueued (after that the allocator's stream ordering protects it)
+    ep._keep = (bias, noise, noise_strength, residual)
+    return ep

@@ -155,14 +155,14 @@ def test_improvement_trail_keeps_the_scored_images(golden):
             assert loss == losses[step]
             fresh = G(torch.from_numpy(g["latents_n"][step]).cuda(), None, noise_mode="const")[0]
             # (a fresh single-image rendering may take other kernel paths than the batch -- split-K, tile shapes: float32 rounding only)
-            assert float((img - fresh[0]).abs().max()) < 1e-5 * float(fresh.abs().max())
+            assert float((img.cuda() - fresh[0]).abs().max()) < 1e-5 * float(fresh.abs().max())   # (spilled trail images live on the host)
     # two slots, more improvements: first improvement in slot 0, the final best in slot 1 (also when several improve in one batch)
     eng = make(2, 50)
     eng.run()
     trail = eng.improvements()
     assert [t[0] for t in trail] == [want[0], want[-1]]
     fresh = G(torch.from_numpy(g["latents_n"][want[-1]]).cuda(), None, noise_mode="const")[0][0]
-    assert float((trail[1][2] - fresh).abs().max()) < 1e-5 * float(fresh.abs().max())
+    assert float((trail[1][2].cuda() - fresh).abs().max()) < 1e-5 * float(fresh.abs().max())
 
 
 def test_retargeted_engine_equals_fresh_engines(golden):
