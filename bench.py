@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", type=int, default=1024, help="debug only; the reported config is 1024")
-    ap.add_argument("--batch", type=int, default=25,
+    ap.add_argument("--batch", type=int, default=32,
                     help="loop steps evaluated per generator forward (exact in literal mode).  Fixed (not derived from --steps) so that every "
                          "run -- the driver's, the rocprofv3 trace, the PMC passes in profiles/ -- launches the same kernels on the same shapes")
     ap.add_argument("--min-seconds", type=float, default=1.0,

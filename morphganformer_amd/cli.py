@@ -60,8 +60,8 @@ def build_parser():
                         "fetches with pretrained=True; required unless --no-lpips or --lpips-random-backbone")
     p.add_argument("--lpips-random-backbone", action="store_true",
                    help="score with SEEDED RANDOM backbone features (smoke runs only: the LPIPS term is then not a perceptual distance)")
-    p.add_argument("--batch", type=int, default=25,
-                   help="loop steps evaluated per generator forward in literal mode (same result; 25 = the benchmarked configuration, 40 GB of "
+    p.add_argument("--batch", type=int, default=32,
+                   help="loop steps evaluated per generator forward in literal mode (same result; 32 = the benchmarked configuration, 51 GB of "
                         "activations at 1024^2)")
     p.add_argument("--keep-images", type=int, default=64,
                    help="device slots for the scored image of every improvement (spilled to the host between launch sequences, so every "

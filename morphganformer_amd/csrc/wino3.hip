@@ -54,6 +54,7 @@ struct Wino3Params {
     int64_t y_batch;          // elements between samples of y (y may be a channel slice of a wider concat buffer; residual likewise)
     int y_choff;              // channel offset into y
     int odd;                  // h or w odd: pixel pairs are stored / loaded element-wise with bounds checks
+    int strip_len, strips_x;  // persistent form (wino3p_conv_kernel): tiles per workgroup along x, strips per tile row
 };
 
 #ifndef MGF_W3X
@@ -523,12 +524,388 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Form 3, PERSISTENT, weights resident in registers: the shallow-K layers (cin = 32 / 64: conv1 of the 512^2 / 1024^2 blocks and
+// conv_last + ToRGB, 8 - 16 chunks per tile).  In the one-shot kernel above such a workgroup lives for 8 chunks: its time is the SUM of a
+// prologue (addresses, three chunks of loads from a cold start), a loop too short to pipeline anything, and an epilogue, and every
+// workgroup streams the whole 16 x cin x 32 weight slab from L2 -- 64 KB for 128 output pixels at 1024^2, more than its input footprint
+// (ablations in DESIGN 3.1c: at 1024^2 only 1.4 of 3.4 ms are matrix work).  Here a workgroup walks a STRIP of `strip_len` consecutive tiles
+// of one tile row:
+//   * a wave's A operands -- its 4 positions x all cin channels of its 32 output channels, 8 bytes per position and chunk -- are loaded
+//     ONCE and stay in 2 x 4 x NCK registers (64 at cin = 32), already multiplied by the sample's styles (the reference's w * s,
+//     networks.py:288-291; the one-shot kernel scales the input instead): the loop has no weight loads and no style work;
+//   * the chunk pipeline (load x three chunks ahead, park two ahead, transform one ahead) runs ACROSS tile boundaries: the next tile's
+//     first chunks are in flight while the current tile's last MFMAs and its epilogue run, so nothing starts cold after the first tile;
+//   * the epilogue's operands (half-resolution residual window, noise rows) come by LDS-DMA issued during the tile's second chunk
+//     through inline asm, i.e. invisible to the compiler's s_waitcnt bookkeeping (a DMA it knows of makes it wait for that DMA in front
+//     of the next LDS access of any kind).  Their completion is implied: vmcnt retires in issue order and every wave waits for the x
+//     loads it issues AFTER the DMAs (one chunk later), several barriers before the epilogue reads the window;
+//   * the exchange slots of the output transform have LDS of their own (the staging buffers are live across the epilogue).
+// 43 KB of LDS and <= 256 registers: two workgroups per CU.
+typedef int w3_v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ w3_v4i w3_make_rsrc(const void* ptr, unsigned bytes) {
+    const uint64_t a = (uint64_t)ptr;
+    w3_v4i r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((unsigned)(a >> 32) & 0xFFFFu);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+
+// buffer_load_dword ... lds outside the compiler's view: lane l writes its dword to LDS byte address lds_addr + 4 l (out of range =
+// 0).  M0 carries the LDS address and is compiler-reserved: saved and restored inside the statement (guide: inline asm, LDS-DMA recipe).
+__device__ __forceinline__ void w3_dma_b32(w3_v4i rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff)
+                 : "memory");
+}
+
+template <int NCK, bool RGB>
+__global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
+    static_assert(NCK % 2 == 0 && NCK >= 4, "the staging buffers alternate per chunk");
+    constexpr int FP = 6 * W3FW;                                   // footprint pixels per channel (6 rows x 34)
+    constexpr int CST = 256, RAW = W3CK * CST;
+    constexpr int NV = 16, NR = 8;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    extern __shared__ float lds[];
+    float* const raw0 = lds;
+    float* const raw1 = raw0 + RAW;
+    float* const xch = raw1 + RAW;                                 // [6 slots][NV][64 lanes]
+    float* const lowt = xch + 6 * NV * 64;                         // [32][4][18] half-resolution residual window (RGB: [3][32] projection weights)
+    float* const nzs = lowt + 2304;                                // [4 rows][64]
+    float* const obs = nzs + 256;                                  // [2][64]: out_scale, bias of the 32 channels
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int a = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tx = l31 & 15, ty = l31 >> 4;
+
+    int b_ = blockIdx.x;
+    if (p.xcd_per > 0) {
+        b_ = (b_ & 7) * p.xcd_per + (b_ >> 3);
+        if (b_ >= p.n * p.strips_x * p.tiles_y * p.co_tiles) return;
+    }
+    const int cot = b_ % p.co_tiles; b_ /= p.co_tiles;
+    const int sx = b_ % p.strips_x; b_ /= p.strips_x;
+    const int pty = b_ % p.tiles_y;
+    const int n = b_ / p.tiles_y;
+    const int co0 = cot * 32, oy0 = pty * 4, ox_s = sx * p.strip_len * 32;
+    const int ntiles = min(p.strip_len, p.tiles_x - sx * p.strip_len);
+    const int plane = p.h * p.w;
+    const float* xn = p.x + (int64_t)n * p.cin * plane;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, p.cin * plane * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, 16 * p.cin * p.cout * 4, 0x00020000);
+
+    // ---- resident A operands: position 4a + b, chunk c -> channels {half, half + 2} of the chunk, output channel co0 + l31; x style ----
+    v2f A[NCK][4];
+    {
+        const unsigned aoff = (unsigned)(((co0 + l31) * W3CK + half * 2) * 4);
+        const int upos = NCK * p.cout * W3CK * 4;                  // bytes between two positions
+        const int ubase = 4 * a * upos;
+#pragma unroll
+        for (int c = 0; c < NCK; ++c)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                A[c][b] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ru, aoff, ubase + c * p.cout * 16 + b * upos, 0));
+        if (p.in_scale) {
+            const float* sc = p.in_scale + (int64_t)n * p.cin;
+#pragma unroll
+            for (int c = 0; c < NCK; ++c) {
+                const float s0 = sc[4 * c + half], s1 = sc[4 * c + half + 2];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { A[c][b].x *= s0; A[c][b].y *= s1; }
+            }
+        }
+    }
+    // ---- per-workgroup constants of the epilogue into LDS (visible after the first barrier) ----
+    if (RGB) {
+        if (tid < 96) {
+            const int cc = tid >> 5, co = tid & 31;
+            float v = 0.f;
+            if (cc < p.rgb_channels)
+                v = p.rgb_w[((int64_t)n * p.rgb_channels + cc) * p.cout + co0 + co] * (p.out_scale ? p.out_scale[(int64_t)n * p.os_stride + co0 + co] : 1.f);
+            lowt[tid] = v;
+        }
+    } else if (tid < 32) {
+        obs[tid] = p.out_scale ? p.out_scale[(int64_t)n * p.os_stride + co0 + tid] : 1.f;
+        obs[64 + tid] = (p.has_ep && p.ep.bias) ? p.ep.bias[co0 + tid] : 0.f;
+    }
+
+    // ---- footprint addressing: thread = footprint pixel, channel in the scalar offset; the tile's x position enters per tile ----
+    const int fr = tid / W3FW, fq = tid - fr * W3FW;
+    const int fiy = oy0 - 1 + fr;
+    const bool frow_ok = tid < FP && fiy >= 0 && fiy < p.h;
+    const int fpix0 = fiy * p.w + ox_s - 1 + fq;                   // pixel of tile 0 (may be -1: masked below)
+    auto tile_voff = [&](int t) -> unsigned {
+        const int ix = ox_s + 32 * t - 1 + fq;
+        return (frow_ok && t < ntiles && ix >= 0 && ix < p.w) ? (unsigned)(fpix0 + 32 * t) * 4u : OOB;
+    };
+    auto load_x = [&](float (&dst)[W3CK], unsigned voff, int chunk) {
+#pragma unroll
+        for (int j = 0; j < W3CK; ++j)
+            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, (chunk * W3CK + j) * plane * 4, 0));
+    };
+    auto park_x = [&](float* R, const float (&src)[W3CK]) {
+#pragma unroll
+        for (int j = 0; j < W3CK; ++j) R[j * CST + tid] = src[j];
+    };
+    const int pr = a == 0 ? 0 : (a == 2 ? 2 : 1);
+    const int qr = a == 2 ? 1 : (a == 3 ? 3 : 2);
+    const float sg = a == 1 ? 1.f : -1.f;
+    const v2f sg2 = {sg, sg}, pm = {-1.f, 1.f}, sgpm = {-sg, sg};
+    auto transform = [&](float (&B)[2][4], const float* R) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const float* src = R + (half + 2 * kk) * CST + 2 * ty * W3FW + 2 * tx;
+            const v2f p01 = *reinterpret_cast<const v2f*>(src + pr * W3FW), p23 = *reinterpret_cast<const v2f*>(src + pr * W3FW + 2);
+            const v2f q01 = *reinterpret_cast<const v2f*>(src + qr * W3FW), q23 = *reinterpret_cast<const v2f*>(src + qr * W3FW + 2);
+            const v2f t01 = p01 + sg2 * q01, t23 = p23 + sg2 * q23;
+            const v2f p2b = {p23.x, p23.x}, q2b = {q23.x, q23.x}, t1b = {t01.y, t01.y};
+            const v2f b01 = q2b * sgpm + (p2b * pm + t01);
+            const v2f b23 = t23 - t1b;
+            B[kk][0] = b01.x;
+            B[kk][1] = b01.y;
+            B[kk][2] = b23.x;
+            B[kk][3] = b23.y;                                       // (= -B3: its accumulator carries -M3, the output transform adds it)
+        }
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    // ---- epilogue-operand DMA of one tile (non-RGB): half-resolution residual window + the tile's four noise rows ----
+    const bool has_low = !RGB && p.res_low != nullptr;
+    const bool has_nz = !RGB && p.has_ep && p.ep.noise != nullptr;
+    const int hl = p.h >> 1, wl = p.w >> 1, pl = hl * wl;
+    unsigned lowoff[9];                                            // window element tid + 256 j of tile 0, or OOB when its row is outside
+    unsigned lowflag = 0;                                          // bit j: window column 0, bit 9 + j: window column 17
+    w3_v4i rlow = {0, 0, 0, 0}, rnz = {0, 0, 0, 0};
+    if (has_low) {
+        rlow = w3_make_rsrc(p.res_low + ((int64_t)n * p.cout + co0) * pl, 32u * (unsigned)pl * 4u);
+        const int m0 = (oy0 >> 1) - 1, n0 = (ox_s >> 1) - 1;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int e = tid + 256 * j;
+            const int ch = e / 72, rem = e - ch * 72;
+            const int r = rem / 18, c = rem - r * 18;
+            const int my = m0 + r;
+            lowoff[j] = (my >= 0 && my < hl) ? (unsigned)(ch * pl + my * wl + n0 + c) * 4u : OOB;
+            lowflag |= (c == 0 ? 1u : 0u) << j;
+            lowflag |= (c == 17 ? 1u : 0u) << (9 + j);
+        }
+    }
+    if (has_nz) rnz = w3_make_rsrc(p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane, (unsigned)plane * 4u);
+    const unsigned lds_lowt = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lowt + 64 * a));
+    const unsigned lds_nzs = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(nzs + 64 * a));
+    auto issue_ep_dma = [&](int t) {
+        const int ox0 = ox_s + 32 * t;
+        if (has_low) {
+            // (branch-free per element: bit j of `edge` = this lane's element j is the window's column 0 of the row's first tile or its column 17 of the last one)
+            const unsigned edge = (ox0 == 0 ? lowflag : 0u) | (ox0 + 32 == p.w ? (lowflag >> 9) : 0u);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const unsigned off = (lowoff[j] == OOB || ((edge >> j) & 1u)) ? OOB : lowoff[j] + (unsigned)(64 * t);
+                w3_dma_b32(rlow, lds_lowt + 1024u * j, off, 0u);
+            }
+        }
+        if (has_nz) {
+            const int ny = oy0 + a, nx = ox0 + lane;
+            const unsigned off = (lane < 32 && ny < p.h && nx < p.w) ? (unsigned)(ny * p.w + nx) * 4u : OOB;
+            w3_dma_b32(rnz, lds_nzs, off, 0u);
+        }
+    };
+
+    // ---- epilogue of one tile: output transform, exchange of the four rows through LDS, fused epilogue / ToRGB, stores ----
+    const int blk = a & 1, orow = a >> 1;
+    const int w0s = a == 1 ? 1 : (a == 2 ? 3 : (a == 3 ? 5 : -1));   // slot receiving my unit 0
+    const int w1s = a == 0 ? 0 : (a == 1 ? 2 : (a == 2 ? 4 : -1));   // slot receiving my unit 1
+    const int sa = a == 0 ? 1 : (a == 1 ? 0 : (a == 2 ? 1 : 2)), sb = a == 0 ? 3 : (a == 2 ? 5 : 4);
+    const float sgn = a < 2 ? 1.f : -1.f;
+    const float* pa = xch + sa * (NV * 64) + lane;
+    const float* pb = xch + sb * (NV * 64) + lane;
+    const bool do_ep = p.has_ep != 0;
+    const float slope = !do_ep ? 1.f : (p.ep.act == MGF_ACT_LRELU ? p.ep.alpha : (p.ep.act == MGF_ACT_RELU ? 0.f : 1.f));
+    const float gain = do_ep ? p.ep.gain : 1.f;
+    const float ns = (do_ep && p.ep.noise) ? (p.ep.noise_strength ? *p.ep.noise_strength : 1.f) : 0.f;
+    auto epilogue = [&](int t) {
+        const int ox0 = ox_s + 32 * t;
+        float own[NV];
+        {
+            float val[2][NV];
+#pragma unroll
+            for (int un = 0; un < 2; ++un)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int r = RGB ? v : un * 8 + (v >> 1);
+                    const int jj = RGB ? un : (v & 1);
+                    const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
+                    val[un][v] = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;        // (m3 = -M3, see transform)
+                }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const unsigned m = 0u - (unsigned)blk, b0 = __builtin_bit_cast(unsigned, val[0][v]), b1 = __builtin_bit_cast(unsigned, val[1][v]);
+                own[v] = __builtin_bit_cast(float, (b1 & m) | (b0 & ~m));
+            }
+            if (w0s >= 0) {
+                float* dst = xch + w0s * (NV * 64) + lane;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) dst[v * 64] = val[0][v];
+            }
+            if (w1s >= 0) {
+                float* dst = xch + w1s * (NV * 64) + lane;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) dst[v * 64] = val[1][v];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        const int oy = oy0 + 2 * ty + orow, ox = ox0 + 2 * tx + (RGB ? blk : 0);
+        const bool ok_px = oy < p.h && ox < p.w;
+        if (RGB) {
+            const int rc = p.rgb_channels;
+            const float* wvs = lowt;
+            __syncthreads();
+            float sum[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float yv = pa[v * 64] + sgn * (own[v] + pb[v * 64]);
+                const int cl = 4 * half + (v & 3) + 8 * (v >> 2);
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) sum[cc] += yv * wvs[cc * 32 + cl];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) sum[cc] += __shfl_xor(sum[cc], 32, 64);
+            if (half == 0 && ok_px) {
+                for (int cc = 0; cc < rc; ++cc) {
+                    const float bb = p.rgb_bias ? p.rgb_bias[cc] : 0.f;
+                    p.rgb_out[((int64_t)n * rc + cc) * plane + (int64_t)oy * p.w + ox] = sum[cc] + bb;
+                }
+            }
+            return;
+        }
+        const int cob = co0 + blk * 16 + 4 * half;
+        const unsigned voff = ok_px ? (unsigned)(cob * plane + oy * p.w + ox) * 4u : OOB;
+        float2 rr[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) rr[k] = make_float2(0.f, 0.f);
+        if (do_ep && p.ep.residual) {
+            const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ep.residual + (int64_t)n * p.y_batch), 0, p.cout * plane * 4, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+                rr[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rres, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0));
+        }
+        __syncthreads();                                           // the exchange slots are complete (and, long since, the DMA'd operands)
+        const int chl = cob - co0;
+        float osv[NR], bvv[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int cl = chl + (k & 3) + 8 * (k >> 2);
+            osv[k] = obs[cl];
+            bvv[k] = obs[64 + cl];
+        }
+        float nz0 = 0.f, nz1 = 0.f;
+        if (has_nz) {
+            const float2 nv = *reinterpret_cast<const float2*>(nzs + 64 * (2 * ty + orow) + 2 * tx);
+            nz0 = nv.x * ns; nz1 = nv.y * ns;
+        }
+        if (has_low) {
+            const float wa = orow ? 0.75f : 0.25f, wb = 1.f - wa;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const float* lp = lowt + (chl + (k & 3) + 8 * (k >> 2)) * 72 + (ty + orow) * 18 + tx;
+                const float a0 = lp[0], a1 = lp[1], a2 = lp[2], b0 = lp[18], b1 = lp[19], b2 = lp[20];
+                const float c0 = wa * a0 + wb * b0, c1 = wa * a1 + wb * b1, c2 = wa * a2 + wb * b2;
+                rr[k].x = 0.25f * c0 + 0.75f * c1;
+                rr[k].y = 0.75f * c1 + 0.25f * c2;
+            }
+        }
+        float2 vout[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            float v[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float tt = (pa[(2 * k + q) * 64] + sgn * (own[2 * k + q] + pb[(2 * k + q) * 64])) * osv[k];
+                tt += q ? nz1 : nz0;
+                tt += bvv[k];
+                tt = tt > 0.f ? tt : tt * slope;
+                tt = tt * gain + (q ? rr[k].y : rr[k].x);
+                v[q] = tt;
+            }
+            vout[k] = make_float2(v[0], v[1]);
+        }
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (int64_t)n * p.y_batch), 0, p.cout * plane * 4, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vout[k]), ry, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0);
+    };
+
+    // ---- prologue: chunks 0 and 1 of tile 0 are parked, chunks 2 .. 1 + XD wait in the register ring ----
+    // The ring is what keeps memory busy: a workgroup's chunk is 3.2 KB, and with one chunk in flight per workgroup (two workgroups per
+    // CU) the whole chip has 1.6 MB outstanding -- 0.8 TB/s at 2 us of loaded latency, less than the layer reads.  XD chunks deep, a
+    // load has XD chunk bodies (~ 3 000 cycles) to land before it is parked.
+    constexpr int XD = 4;
+    static_assert(NCK % XD == 0, "ring slot = chunk index mod XD must be a compile-time value");
+    float xq[XD][W3CK];
+    float B[2][2][4];
+    unsigned voff_cur = tile_voff(0), voff_nxt = tile_voff(1);
+    {
+        float xa[W3CK], xb[W3CK];
+        load_x(xa, voff_cur, 0);
+        load_x(xb, voff_cur, 1);
+#pragma unroll
+        for (int d = 0; d < XD; ++d) {
+            if (2 + d < NCK) load_x(xq[d], voff_cur, 2 + d);
+            else load_x(xq[d], voff_nxt, 2 + d - NCK);
+        }
+        park_x(raw0, xa);
+        park_x(raw1, xb);
+        __syncthreads();
+        transform(B[0], raw0);
+        __syncthreads();                                           // chunk 0's body parks chunk 2 over raw0: every wave must have read chunk 0 from it
+    }
+    // ---- the strip: NCK chunk bodies + one epilogue per tile; the chunk pipeline does not stop at tile boundaries ----
+    for (int t = 0; t < ntiles; ++t) {
+#pragma unroll
+        for (int c = 0; c < NCK; ++c) {
+            __builtin_amdgcn_sched_barrier(0);
+            // (every wave passed the barrier of chunk 0: the previous tile's epilogue is over.  In FRONT of this body's loads: the compiler
+            // counts only its own loads, so a DMA younger than a load it waits for would be waited for as well)
+            if (!RGB && c == 1) issue_ep_dma(t);
+            transform(B[(c + 1) & 1], ((c + 1) & 1) ? raw1 : raw0);          // chunk c + 1 (of the next tile when c is the last)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[c][b].x, B[c & 1][0][b], acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[c][b].y, B[c & 1][1][b], acc[b], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            park_x((c & 1) ? raw1 : raw0, xq[c % XD]);                       // chunk c + 2, requested XD bodies ago
+            if (c + 2 + XD < NCK) load_x(xq[c % XD], voff_cur, c + 2 + XD);
+            else load_x(xq[c % XD], voff_nxt, c + 2 + XD - NCK);
+            __syncthreads();
+        }
+        epilogue(t);
+        voff_cur = voff_nxt;
+        voff_nxt = tile_voff(t + 2);
+    }
+}
+
 }  // namespace
 
 static int g_w3_forced_shape = 0;
 
 extern "C" int mgf_winograd3_force_shape(int32_t shape) {
-    MGF_REQUIRE(shape == 0 || shape == 21 || shape == 12 || shape == 11, MGF_EINVAL, "winograd3_force_shape: 0 (auto), 21, 12 or 11 (got %d)", shape);
+    MGF_REQUIRE(shape == 0 || shape == 21 || shape == 12 || shape == 11 || shape == 31, MGF_EINVAL,
+                "winograd3_force_shape: 0 (auto), 21, 12, 11 or 31 = the persistent form wherever the layer's structure admits it (got %d)", shape);
     g_w3_forced_shape = shape;
     return MGF_OK;
 }
@@ -573,6 +950,7 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
         (int64_t)n * mgf_cdiv(w, 32) * mgf_cdiv(h, 4) * (cout / 64) >= 8192) shape = 21;
     if (forced == 21 && cout % 64 == 0 && !rgb) shape = 21;
     if (forced == 12 || forced == 11) shape = forced;
+    const bool force_persist = forced == 31;
     const int cb = shape == 21 ? 2 : 1, tb = shape == 12 ? 2 : 1;
     Wino3Params p;
     p.y = y; p.x = x; p.u = u; p.in_scale = in_scale; p.out_scale = out_scale;
@@ -583,10 +961,45 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     p.rgb_w = rgb_w; p.rgb_bias = rgb_bias; p.rgb_out = rgb_out; p.rgb_channels = rgb_channels;
     p.res_low = res_low;
     p.y_batch = y_batch ? y_batch : (int64_t)cout * h * w; p.y_choff = y_choff; p.odd = odd;
+    p.strip_len = 0; p.strips_x = 0;
     if (res_low) {
         MGF_REQUIRE(ep && !ep->residual && !rgb, MGF_EINVAL, "conv3x3_winograd3_up2res: needs an epilogue without a full-resolution residual");
         MGF_REQUIRE(shape == 11, MGF_EUNSUPPORTED, "conv3x3_winograd3_up2res: only the 32x32-tile shape takes the half-resolution residual");
         MGF_REQUIRE((int64_t)32 * (h / 2) * (w / 2) * 4 <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd3_up2res: map too large");
+    }
+    // Persistent form (wino3p_conv_kernel): shallow K (cin 32 / 64), 32-channel tiles, even maps, whole strips of 16 tiles (or one tile row
+    // when it is shorter), a dense output, and enough strips to fill the chip's 512 workgroup slots several times over.
+    // MGF_W3_PERSIST=0 keeps the one-shot kernel (tuning / A-B runs).
+    static const bool persist_off = [] { const char* e = getenv("MGF_W3_PERSIST"); return e && e[0] == '0'; }();
+    static const int strip_env = [] { const char* e = getenv("MGF_W3_STRIP"); return e ? atoi(e) : 0; }();
+    const int strip_len = strip_env > 0 ? std::min(strip_env, p.tiles_x) : std::min(p.tiles_x, 16);
+    const bool persist = !persist_off && (!forced || force_persist) && shape == 11 && !odd && y_choff == 0 && p.y_batch == (int64_t)cout * h * w && cin == 32 &&
+                         w % 32 == 0 && h % 4 == 0 && p.tiles_x % strip_len == 0 && (!rgb || cout == 32) &&
+                         (force_persist || (int64_t)n * (p.tiles_x / strip_len) * p.tiles_y * p.co_tiles >= 2048);
+    if (persist) {
+        p.strip_len = strip_len;
+        p.strips_x = p.tiles_x / strip_len;
+        int64_t pblocks = (int64_t)n * p.strips_x * p.tiles_y * p.co_tiles;
+        p.xcd_per = (int)((pblocks + 7) / 8);                      // XCD-contiguous order: channel tiles, then strips of one row, share an L2
+        pblocks = (int64_t)p.xcd_per * 8;
+        const size_t plds = (size_t)(2 * 4 * 256 + 6 * 16 * 64 + 2304 + 256 + 128) * sizeof(float);
+        static bool pattr_set = false;
+        if (!pattr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)wino3p_conv_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino3p_conv_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            if (e != hipSuccess) { mgf_set_error("conv3x3_winograd3: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MGF_ELAUNCH; }
+            pattr_set = true;
+        }
+        const char* pname = rgb ? "wino3p_conv_kernel<8, true>" : "wino3p_conv_kernel<8, false>";
+        mgf_prof_external_begin((hipStream_t)stream, pname, 2.0 * 9 * cin * (double)cout * h * w * n,
+                                4.0 * ((double)n * cin * h * w + 9.0 * cin * cout + (double)n * (rgb ? rgb_channels : cout) * h * w));
+        const dim3 pgrid((unsigned)pblocks), pblk(256);
+        hipStream_t pst = (hipStream_t)stream;
+        if (rgb) hipLaunchKernelGGL((wino3p_conv_kernel<8, true>), pgrid, pblk, plds, pst, p);
+        else hipLaunchKernelGGL((wino3p_conv_kernel<8, false>), pgrid, pblk, plds, pst, p);
+        mgf_prof_external_end((hipStream_t)stream);
+        MGF_CHECK_LAUNCH("conv3x3_winograd3(persistent)");
+        return MGF_OK;
     }
     int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
     MGF_REQUIRE(blocks <= INT32_MAX - 8, MGF_ETOOBIG, "conv3x3_winograd3: too many workgroups");

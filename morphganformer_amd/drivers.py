@@ -142,7 +142,8 @@ def merge_morph(G, w1, w2, alphas=(0.5,), truncation_psi=0.7, noise_mode="random
     return np.stack(lat), torch.stack(imgs)
 
 
-DEFAULT_BATCH = 25       # loop steps per generator forward in literal mode: the configuration bench.py times (1.6 GB of activations per step at 1024^2)
+DEFAULT_BATCH = 32       # loop steps per generator forward in literal mode: the configuration bench.py times (1.6 GB of activations per step at 1024^2;
+                         # measured 20 .. 64: 32 is the fastest, 25 -- the round-2 figure -- 1.5 - 3 % behind)
 
 
 def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None,
@@ -152,7 +153,7 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
     """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and either
     `lm_steps` [steps,68,2] (injected landmark detections) or `landmark_fn` (host detector called on every generated image,
     see ProjectionEngine).  mode="literal" is the loop as the reference executes it (best-of-N noisy sampling, `batch` steps per
-    forward -- 25 by default, the benchmarked configuration; the result does not depend on it); mode="gradient" back-propagates the
+    forward -- 32 by default, the benchmarked configuration; the result does not depend on it); mode="gradient" back-propagates the
     loss into the latent and lets Adam move it (GradientProjectionEngine; one candidate per step; weight_decay=1e-4 is the
     1024_example_MSE.py:117 optimizer).  Returns dict(w, step, loss, losses).
 

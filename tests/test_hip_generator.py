@@ -116,23 +116,24 @@ def test_full_1024_matches_reference_samples(golden):
     assert float((img2 - ref_img).abs().max()) / amax < 1e-5
 
 
-def test_full_1024_batch25_equals_batch1(golden):
-    """The dispatch bench.py times: 25 candidates per forward at 1024^2 (204 800-workgroup Winograd grids in XCD-contiguous order, the
+def test_full_1024_bench_batch_equals_batch1(golden):
+    """The dispatch bench.py times: drivers.DEFAULT_BATCH (32) candidates per forward at 1024^2 (the persistent Winograd form on the 1024^2 layers, 100 000-workgroup grids in XCD-contiguous order, the
     `winograd_fills_chip` branches, the half-resolution skip fused into conv1's epilogue, 3.4 GB activation tensors behind 32-bit
     buffer offsets).  The reference's modulated conv treats the batch as groups (networks.py:300-303), so candidate j of a batched
-    forward must equal a batch-1 forward of the same latent and the same per-layer noise: checked on EVERY pixel of all 25 candidates
+    forward must equal a batch-1 forward of the same latent and the same per-layer noise: checked on EVERY pixel of all candidates
     (<= 1e-5 of max|img|; the two batch sizes may take different kernel shapes / split-K orders, hence not bit-equal), and candidate 0
     under noise_mode="const" against the reference module's own 1024^2 output (gen_full1024.npz, 1e-3)."""
+    from morphganformer_amd.drivers import DEFAULT_BATCH
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.synth_weights import FULL1024, make_state_dict, synthetic_latents
     g = golden("gen_full1024.npz")
-    cfg, B = FULL1024, 25
+    cfg, B = FULL1024, DEFAULT_BATCH
     G = Generator(make_state_dict(cfg, seed=0), cfg, "cuda", max_batch=B)
     idx = torch.from_numpy(g["idx"]).cuda()
     amax = float(g["img_absmax"])
     z = torch.from_numpy(synthetic_latents(cfg, B, seed=4242)).cuda()
     z[0] = torch.from_numpy(g["z"]).cuda()[0]
-    # (1) candidate 0 of a 25-candidate forward, const noise, against the reference's pixels
+    # (1) candidate 0 of a full-batch forward, const noise, against the reference's pixels
     img = G.forward_workspace(z, None, noise_mode="const")[0]
     assert tuple(img.shape) == (B, 3, 1024, 1024)
     pix = img[0].reshape(-1)[idx].cpu().numpy()
@@ -140,7 +141,7 @@ def test_full_1024_batch25_equals_batch1(golden):
     ds = torch.nn.functional.avg_pool2d(img[:1], 16).cpu().numpy()
     assert np.abs(ds - g["img_ds"]).max() / amax < PIX_TOL
     img_const0 = img[0].clone()                                       # (img is the workspace buffer: the next forward overwrites it)
-    # (2) injected per-layer noise, distinct per candidate: batch 25 == 25 x batch 1, every pixel
+    # (2) injected per-layer noise, distinct per candidate: one batched forward == B batch-1 forwards, every pixel
     gen = torch.Generator(device="cuda"); gen.manual_seed(11)
     noises = {lp.name: torch.randn(B, lp.res * lp.res, device="cuda", generator=gen) for lp in G.plan.layers if lp.noise_strength is not None}
     img25 = G.forward_workspace(z, None, noise_mode="inject", noises=noises)[0].clone()
@@ -156,7 +157,7 @@ def test_full_1024_batch25_equals_batch1(golden):
         assert float((img25[j].reshape(-1)[idx] - one[0].reshape(-1)[idx]).abs().max()) / m < 1e-5
     # distinct latents give distinct images (a stuck sample index would pass the equality above only for j = 0)
     assert float((img25[1] - img25[2]).abs().max()) > 1e-3 * amax
-    print(f"batch-25 vs batch-1 at 1024^2: worst relative pixel difference {worst:.2e}")
+    print(f"batch-{B} vs batch-1 at 1024^2: worst relative pixel difference {worst:.2e}")
 
 
 def test_list2tensor_matches_reference(tiny, golden):

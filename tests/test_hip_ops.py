@@ -517,6 +517,53 @@ def test_winograd3_half_resolution_residual(n, cin, cout, h, w):
     assert rel_err(out, two) < 2e-6
 
 
+@pytest.mark.parametrize("n,cout,h,w", [(2, 32, 64, 64), (1, 32, 100, 96), (3, 64, 32, 512), (1, 32, 16, 1024), (2, 32, 8, 2048)])
+def test_winograd3_persistent_form(n, cout, h, w):
+    """wino3p_conv_kernel (the form the literal loop runs on the 1024^2 layers at 25 - 32 candidates: a workgroup walks a strip of tiles with
+    its weights resident in registers, styles folded into them, the epilogue's operands by LDS-DMA) pinned through
+    mgf_winograd3_force_shape(31): against float64 torch for the plain / full-resolution-residual / half-resolution-residual / no-epilogue /
+    fused-ToRGB launches, and against the one-shot kernel (shape 11).  Strips of one, three and sixteen tiles, one and two strips per row,
+    first / interior / last tiles of a row, top and bottom tile rows."""
+    from morphganformer_amd import _lib, conv as cv
+    from oracle.ops_ref import bias_act_ref, setup_filter_ref, upfirdn2d_ref
+    L = _lib.lib()
+    cin = 32
+    torch.manual_seed(h + w + cout)
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+    s, d = 1 + 0.3 * torch.randn(n, cin), 0.5 + torch.rand(n, cout)
+    noise, bias = torch.randn(n, h, w), torch.randn(cout)
+    low, resid = torch.randn(n, cout, h // 2, w // 2), torch.randn(n, cout, h, w)
+    strength = torch.tensor([0.37])
+    conv = torch.nn.functional.conv2d((x * s[:, :, None, None]).double(), wt.double(), padding=1) * d[:, :, None, None].double()
+    act = bias_act_ref(conv.float() + noise[:, None] * strength, bias, act="lrelu", gain=1.3)
+    skip = upfirdn2d_ref(low, setup_filter_ref([1, 3, 3, 1]), up=2, padding=[2, 1, 2, 1], gain=4.0)
+    g = lambda t: t.cuda().contiguous()
+    xd, sd, dd, nd, bd, ld, rd, st = g(x), g(s), g(d), g(noise), g(bias), g(low), g(resid), strength.cuda()
+    u = cv.winograd2_weights(g(wt), gain=1.0)
+    ep = _lib.make_epilogue(bias=bd, noise=nd, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.3)
+    ep_r = _lib.make_epilogue(bias=bd, noise=nd, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.3, residual=rd)
+    cases = {"plain": (lambda: cv.winograd_forward(xd, u, in_scale=sd, out_scale=dd, epilogue=ep), act),
+             "residual": (lambda: cv.winograd_forward(xd, u, in_scale=sd, out_scale=dd, epilogue=ep_r), act + resid),
+             "half-resolution residual": (lambda: cv.winograd_forward(xd, u, in_scale=sd, out_scale=dd, epilogue=ep, residual_low=ld), act + skip),
+             "no epilogue": (lambda: cv.winograd_forward(xd, u, in_scale=sd, out_scale=dd), conv.float())}
+    if cout == 32:
+        rw, rb = torch.randn(n, 3, cout), torch.randn(3)
+        rgb_ref = torch.einsum("nco,nohw->nchw", rw.double(), conv) + rb.double()[None, :, None, None]
+        cases["ToRGB"] = (lambda: cv.winograd2_rgb_forward(xd, u, g(rw), g(rb), torch.empty(n, 3, h, w, device="cuda"), in_scale=sd, out_scale=dd),
+                          rgb_ref.float())
+    try:
+        for name, (fn, ref) in cases.items():
+            _lib.check(L.mgf_winograd3_force_shape(31))
+            got = fn().clone()
+            _lib.check(L.mgf_winograd3_force_shape(11))
+            one_shot = fn().clone()
+            assert rel_err(got, ref) < 2e-5, name
+            assert rel_err(got, one_shot) < 2e-6, name
+    finally:
+        _lib.check(L.mgf_winograd3_force_shape(0))
+
+
 @pytest.mark.parametrize("n,c,f,with_ep", [(2, 256, 128, True), (1, 512, 96, True), (2, 256, 64, False), (3, 64, 80, True), (1, 512, 1024, True)])
 def test_duplex_attention_forward_all_kernel_forms_vs_float64(n, c, f, with_ep):
     """mgf_duplex_attention against the folded layer written out in float64: S = x^T wqc + spos, P = softmax(S), y = x rsqrt(mean_c x^2

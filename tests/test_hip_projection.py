@@ -253,9 +253,9 @@ def test_full_size_loop_properties():
     assert torch.equal(lat.cuda(), expect)
 
 
-def test_full_size_loop_batch25_equals_batch1():
-    """configs[1] as bench.py runs it -- 1024^2, Wing + LPIPS(squeeze) + MSE, 25 loop steps per generator forward -- against the same
-    50 steps evaluated one per forward, on an injected eps stream and constant per-layer noise: same best step, bit-identical best
+def test_full_size_loop_bench_batch_equals_batch1():
+    """configs[1] as bench.py runs it -- 1024^2, Wing + LPIPS(squeeze) + MSE, drivers.DEFAULT_BATCH (32) loop steps per generator forward
+    -- against the same 70 steps (two full launch sequences and a ragged third) evaluated one per forward, on an injected eps stream and constant per-layer noise: same best step, bit-identical best
     latent, loss history within 1e-5 (the two batch sizes take different kernel shapes; the selection is in step order either way)."""
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.lpips import PerceptualLoss
@@ -265,16 +265,17 @@ def test_full_size_loop_batch25_equals_batch1():
     target = G(torch.from_numpy(synthetic_latents(FULL1024, 1, 1000)).cuda(), None, noise_mode="const")[0].clamp(-1, 1).clone()
     gen = torch.Generator(device="cuda"); gen.manual_seed(0)
     mean, std = latent_stats(G, 10000, "cuda", gen)
-    steps = 50
+    from morphganformer_amd.drivers import DEFAULT_BATCH
+    steps = 70
     lm_t, lm_s = synthetic_landmarks(steps, 1024, 7)
     eps = torch.randn(steps, 1, FULL1024.k, FULL1024.z_dim, device="cuda", generator=gen)
     out = {}
-    for batch in (25, 1):
+    for batch in (DEFAULT_BATCH, 1):
         P = PerceptualLoss(net="squeeze", allow_random_backbone=True)
         eng = ProjectionEngine(G, target, mean, std, ProjectionArgs(step=steps), percept=P, use_mse=True, lm_target=lm_t, lm_steps=lm_s,
                                eps=eps, noise_mode="const", use_graph=True, batch=batch)
         out[batch] = eng.run().result()
-    (lat_a, step_a, loss_a, hist_a), (lat_b, step_b, loss_b, hist_b) = out[25], out[1]
+    (lat_a, step_a, loss_a, hist_a), (lat_b, step_b, loss_b, hist_b) = out[DEFAULT_BATCH], out[1]
     assert not np.isnan(hist_a).any() and not np.isnan(hist_b).any()
     assert step_a == step_b == int(np.argmin(hist_b))
     assert torch.equal(lat_a, lat_b)
