@@ -29,6 +29,7 @@
 #include "mgf_common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -565,6 +566,12 @@ __device__ __forceinline__ void w3_dma_b32(w3_v4i rsrc, unsigned lds_addr, unsig
                  : "memory");
 }
 
+#ifndef W3P_SCALAR_T
+#define W3P_SCALAR_T 0        // same-box A/B at 32 x 1024^2 (us; conv1 + skip / conv1 / conv_last + ToRGB): packed 3889 / 3308 / 3235, scalar 3956 / 3363 / 3343
+#endif
+#ifndef W3P_OWN_BRANCH
+#define W3P_OWN_BRANCH 1      // (same series: 4019 / 3443 / 3246 with the run-time bit select)
+#endif
 template <int NCK, bool RGB>
 __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     static_assert(NCK % 2 == 0 && NCK >= 4, "the staging buffers alternate per chunk");
@@ -656,13 +663,23 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     const int pr = a == 0 ? 0 : (a == 2 ? 2 : 1);
     const int qr = a == 2 ? 1 : (a == 3 ? 3 : 2);
     const float sg = a == 1 ? 1.f : -1.f;
-    const v2f sg2 = {sg, sg}, pm = {-1.f, 1.f}, sgpm = {-sg, sg};
+    // Row a of B^T d B.  The packed form (5 packed instructions per pair, as in the one-shot kernel) measures FASTER than the plain scalar
+    // form with the minimum of 8 lane-operations per (tile, channel) (W3P_SCALAR_T=1: +1 - 3 %): beside FP32 MFMAs it is the number of
+    // VALU instructions that costs matrix time, not the number of lane-operations.
     auto transform = [&](float (&B)[2][4], const float* R) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const float* src = R + (half + 2 * kk) * CST + 2 * ty * W3FW + 2 * tx;
             const v2f p01 = *reinterpret_cast<const v2f*>(src + pr * W3FW), p23 = *reinterpret_cast<const v2f*>(src + pr * W3FW + 2);
             const v2f q01 = *reinterpret_cast<const v2f*>(src + qr * W3FW), q23 = *reinterpret_cast<const v2f*>(src + qr * W3FW + 2);
+#if W3P_SCALAR_T
+            const float t0 = p01.x + sg * q01.x, t1 = p01.y + sg * q01.y, t2 = p23.x + sg * q23.x, t3 = p23.y + sg * q23.y;
+            B[kk][0] = t0 - t2;
+            B[kk][1] = t1 + t2;
+            B[kk][2] = t2 - t1;
+            B[kk][3] = t3 - t1;                                     // (= -B3: its accumulator carries -M3, the output transform adds it)
+#else
+            const v2f sg2 = {sg, sg}, pm = {-1.f, 1.f}, sgpm = {-sg, sg};
             const v2f t01 = p01 + sg2 * q01, t23 = p23 + sg2 * q23;
             const v2f p2b = {p23.x, p23.x}, q2b = {q23.x, q23.x}, t1b = {t01.y, t01.y};
             const v2f b01 = q2b * sgpm + (p2b * pm + t01);
@@ -670,7 +687,8 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             B[kk][0] = b01.x;
             B[kk][1] = b01.y;
             B[kk][2] = b23.x;
-            B[kk][3] = b23.y;                                       // (= -B3: its accumulator carries -M3, the output transform adds it)
+            B[kk][3] = b23.y;
+#endif
         }
     };
     f32x16 acc[4];
@@ -733,9 +751,41 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     const float slope = !do_ep ? 1.f : (p.ep.act == MGF_ACT_LRELU ? p.ep.alpha : (p.ep.act == MGF_ACT_RELU ? 0.f : 1.f));
     const float gain = do_ep ? p.ep.gain : 1.f;
     const float ns = (do_ep && p.ep.noise) ? (p.ep.noise_strength ? *p.ep.noise_strength : 1.f) : 0.f;
+    // (the wave's own unit -- blk = a & 1 -- is a compile-time value of the two instantiations behind one wave-uniform branch: selected at
+    // run time it was 32 bit-select instructions per tile)
+    auto row_reduce = [&](auto own_unit, float (&own)[NV]) {
+        constexpr int OWN = decltype(own_unit)::value;
+        float other[NV];
+#pragma unroll
+        for (int un = 0; un < 2; ++un)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int r = RGB ? v : un * 8 + (v >> 1);
+                const int jj = RGB ? un : (v & 1);
+                const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
+                const float val = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;       // (m3 = -M3, see transform)
+                if (un == OWN) own[v] = val; else other[v] = val;
+            }
+        // unit 0 goes to slot w0s, unit 1 to slot w1s; the own unit is written too where another wave needs it (waves 1 and 2)
+        const int s_own = OWN == 0 ? w0s : w1s, s_oth = OWN == 0 ? w1s : w0s;
+        if (s_own >= 0) {
+            float* dst = xch + s_own * (NV * 64) + lane;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) dst[v * 64] = own[v];
+        }
+        if (s_oth >= 0) {
+            float* dst = xch + s_oth * (NV * 64) + lane;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) dst[v * 64] = other[v];
+        }
+    };
     auto epilogue = [&](int t) {
         const int ox0 = ox_s + 32 * t;
         float own[NV];
+#if W3P_OWN_BRANCH
+        if (blk) row_reduce(std::integral_constant<int, 1>{}, own);
+        else row_reduce(std::integral_constant<int, 0>{}, own);
+#else
         {
             float val[2][NV];
 #pragma unroll
@@ -745,7 +795,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
                     const int r = RGB ? v : un * 8 + (v >> 1);
                     const int jj = RGB ? un : (v & 1);
                     const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
-                    val[un][v] = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;        // (m3 = -M3, see transform)
+                    val[un][v] = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;
                 }
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -763,6 +813,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
                 for (int v = 0; v < NV; ++v) dst[v * 64] = val[1][v];
             }
         }
+#endif
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -946,8 +997,10 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     int shape = 11;
     // ... except where the 64-channel shape measures faster: deep K with enough workgroups left to fill the chip (the 128^2 x 256-channel
     // conv1 at 25 samples: 1969 vs 2097 us; at 64^2 x 512 its 6400 workgroups lose to 12800 of the small shape, 2151 vs 1998 us)
+    // (round 3, 32 samples: 64^2 x 512 -- 8192 workgroups of the wide shape -- 2653 vs 2502 us for the small one; 128^2 x 256 -- 16384 -- 2485 vs
+    // 2665: the wide shape needs ~ 12 800 workgroups, 25 rounds of the 512 the chip holds, before its smaller instruction count per MFMA wins)
     if (!forced && !rgb && !res_low && !odd && y_choff == 0 && cout % 64 == 0 && cin >= 256 &&
-        (int64_t)n * mgf_cdiv(w, 32) * mgf_cdiv(h, 4) * (cout / 64) >= 8192) shape = 21;
+        (int64_t)n * mgf_cdiv(w, 32) * mgf_cdiv(h, 4) * (cout / 64) >= 12800) shape = 21;
     if (forced == 21 && cout % 64 == 0 && !rgb) shape = 21;
     if (forced == 12 || forced == 11) shape = forced;
     const bool force_persist = forced == 31;
@@ -967,12 +1020,12 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
         MGF_REQUIRE(shape == 11, MGF_EUNSUPPORTED, "conv3x3_winograd3_up2res: only the 32x32-tile shape takes the half-resolution residual");
         MGF_REQUIRE((int64_t)32 * (h / 2) * (w / 2) * 4 <= INT32_MAX, MGF_ETOOBIG, "conv3x3_winograd3_up2res: map too large");
     }
-    // Persistent form (wino3p_conv_kernel): shallow K (cin 32 / 64), 32-channel tiles, even maps, whole strips of 16 tiles (or one tile row
+    // Persistent form (wino3p_conv_kernel): shallow K (cin 32 / 64), 32-channel tiles, even maps, whole strips of 32 tiles (or one tile row
     // when it is shorter), a dense output, and enough strips to fill the chip's 512 workgroup slots several times over.
     // MGF_W3_PERSIST=0 keeps the one-shot kernel (tuning / A-B runs).
     static const bool persist_off = [] { const char* e = getenv("MGF_W3_PERSIST"); return e && e[0] == '0'; }();
     static const int strip_env = [] { const char* e = getenv("MGF_W3_STRIP"); return e ? atoi(e) : 0; }();
-    const int strip_len = strip_env > 0 ? std::min(strip_env, p.tiles_x) : std::min(p.tiles_x, 16);
+    const int strip_len = strip_env > 0 ? std::min(strip_env, p.tiles_x) : std::min(p.tiles_x, 32);     // (1024^2 at 32 samples, us: strips of 4 / 8 / 16 / 32 tiles 3707 / 3536 / 3472 / 3428)
     const bool persist = !persist_off && (!forced || force_persist) && shape == 11 && !odd && y_choff == 0 && p.y_batch == (int64_t)cout * h * w && cin == 32 &&
                          w % 32 == 0 && h % 4 == 0 && p.tiles_x % strip_len == 0 && (!rgb || cout == 32) &&
                          (force_persist || (int64_t)n * (p.tiles_x / strip_len) * p.tiles_y * p.co_tiles >= 2048);

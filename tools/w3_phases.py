@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from morphganformer_amd import _lib, conv as cv
-n = 25
+n = int(os.environ.get("MGF_N", "25"))
 for res, c in ((64, 512), (128, 256), (256, 128), (512, 64), (1024, 32)):
     x = torch.randn(n, c, res, res, device="cuda")
     w = torch.randn(c, c, 3, 3, device="cuda") / (3 * c ** 0.5)

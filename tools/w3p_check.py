@@ -35,7 +35,7 @@ if "--time-only" not in sys.argv:
     print("worst", worst)
     if worst >= 2e-5:
         sys.exit(1)
-n, res, c = 25, 1024, 32
+n, res, c = int(os.environ.get("MGF_N", "25")), 1024, 32
 x = torch.randn(n, c, res, res, device="cuda")
 w = torch.randn(c, c, 3, 3, device="cuda") / (3 * c ** 0.5)
 s, d = torch.rand(n, c, device="cuda") + 0.5, torch.rand(n, c, device="cuda") + 0.5
