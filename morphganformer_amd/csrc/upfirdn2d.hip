@@ -443,6 +443,130 @@ __global__ __launch_bounds__(256) void fir_up1_sep(UFParams p) {
     }
 }
 
+// Streaming form of the same separable blur (+ fused noise / bias / activation) for wide maps: NO LDS and no barrier.  A wave owns a strip
+// of 256 output columns (lane = 4 consecutive outputs = one 16-byte load, one 16-byte store per row) and walks FS_ROWS output rows top
+// to bottom: the horizontal 4-tap pass needs x[ox - 1 .. ox + 5], i.e. the lane's own float4, the last element of its left neighbour and
+// the first two of its right neighbour -- three DPP wave shifts, the strip's two halo columns coming from one 8-byte load that only lanes 0
+// and 63 execute; the vertical pass runs on a ring of four horizontally filtered rows in registers.  The tiled kernel above (load window
+// -> barrier -> 176 FMAs per lane -> store) holds ~ 50 KB per CU in flight and streams at 4.4 - 4.8 TB/s; here every wave keeps two
+// groups of four rows (8 KB + its noise rows) in flight with nothing to wait for but its own loads.  Rows are re-read 3 / FS_ROWS times.
+#ifndef MGF_FS_ROWS
+#define MGF_FS_ROWS 64
+#endif
+constexpr int FS_ROWS = MGF_FS_ROWS;
+
+template <bool EP>
+__global__ __launch_bounds__(256) void fir_up1_stream(UFParams p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int strips = p.out_w >> 8, segs = (p.out_h + FS_ROWS - 1) / FS_ROWS;
+    int wv = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (tid >> 6));
+    const int strip = wv % strips; wv /= strips;
+    const int seg = wv % segs;
+    const int plane = wv / segs;
+    if (plane >= p.n * p.c) return;
+    const int n = plane / p.c, c = plane - n * p.c;
+    const float* xb = (const float*)p.x + (int64_t)n * p.sn + (int64_t)c * p.sc;
+    const float f00 = p.f[0];
+    float fx[4], fy[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = p.flip ? t : 3 - t;
+        fx[t] = p.f[k] / f00;
+        fy[t] = p.f[k * p.fw] * p.gain;
+    }
+    const int ox = strip * 256 + 4 * lane;
+    const int oy_begin = seg * FS_ROWS, ib = oy_begin - p.pady0;
+    // halo lanes: lane 0 reads x[ox - 2 .. ox - 1] (uses .y), lane 63 reads x[ox + 4 .. ox + 5]
+    const int hx = lane == 0 ? ox - 2 : ox + 4;
+    const bool h_on = (lane == 0 && ox > 0) || (lane == 63 && hx < p.in_w);
+    const bool m1 = ox + 1 < p.in_w, m2 = ox + 2 < p.in_w, m3 = ox + 3 < p.in_w, mh1 = hx + 1 < p.in_w;
+    const bool v_on = ox < p.in_w;
+    const float ns = (EP && p.ep.noise && p.ep.noise_strength) ? *p.ep.noise_strength : 1.0f;
+    const float bb = (EP && p.ep.bias) ? p.ep.bias[c] : 0.f;
+    const float* nzb = (EP && p.ep.noise) ? p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * p.out_h * p.out_w + ox : nullptr;
+    float* yb = (float*)p.y + (int64_t)n * p.yn + (int64_t)c * p.yc + ox;
+    const float* rb = (EP && p.ep.residual) ? p.ep.residual + (int64_t)n * p.yn + (int64_t)c * p.yc + ox : nullptr;
+
+    auto load_row = [&](int iy, float4& v, float2& h) {
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        h = make_float2(0.f, 0.f);
+        if (iy >= 0 && iy < p.in_h) {                                // (wave-uniform)
+            const float* row = xb + (int64_t)iy * p.sh;
+            if (v_on) v = *reinterpret_cast<const float4*>(row + ox);
+            if (h_on) h = *reinterpret_cast<const float2*>(row + hx);
+        }
+    };
+    auto hpass = [&](float (&hz)[4], float4 v, float2 h) {
+        if (!m1) v.y = 0.f;
+        if (!m2) v.z = 0.f;
+        if (!m3) v.w = 0.f;
+        if (!mh1) h.y = 0.f;
+        // lane i <- lane i - 1 (wave_shr:1, lane 0 keeps `old` = its halo), lane i <- lane i + 1 (wave_shl:1, lane 63 keeps its halo)
+        const float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h.y), __builtin_bit_cast(int, v.w), 0x138, 0xf, 0xf, false));
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h.x), __builtin_bit_cast(int, v.x), 0x130, 0xf, 0xf, false));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h.y), __builtin_bit_cast(int, v.y), 0x130, 0xf, 0xf, false));
+        const float w[7] = {l, v.x, v.y, v.z, v.w, r0, r1};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hz[e] = w[e] * fx[0] + w[e + 1] * fx[1] + w[e + 2] * fx[2] + w[e + 3] * fx[3];
+    };
+    float hz[4][4];
+    float4 va[4], vb[4], na[4], nb[4];
+    float2 ha[4], hb[4];
+    auto load_group = [&](int g, float4 (&v)[4], float2 (&h)[4], float4 (&nz)[4]) {      // input rows ib + 3 + 4 g + j, noise of output rows oy_begin + 4 g + j
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            load_row(ib + 3 + 4 * g + j, v[j], h[j]);
+            nz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int oy = oy_begin + 4 * g + j;
+            if (EP && nzb && oy < p.out_h) nz[j] = *reinterpret_cast<const float4*>(nzb + (int64_t)oy * p.out_w);
+        }
+    };
+    auto do_group = [&](int g, float4 (&v)[4], float2 (&h)[4], float4 (&nz)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hpass(hz[(3 + j) & 3], v[j], h[j]);
+            const int oy = oy_begin + 4 * g + j;
+            if (oy >= p.out_h) continue;                             // (wave-uniform)
+            float acc[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[e] = hz[j & 3][e] * fy[0] + hz[(j + 1) & 3][e] * fy[1] + hz[(j + 2) & 3][e] * fy[2] + hz[(j + 3) & 3][e] * fy[3];
+            if (EP) {
+                float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rb) rv = *reinterpret_cast<const float4*>(rb + (int64_t)oy * p.yh);
+                const float nzv[4] = {nz[j].x * ns, nz[j].y * ns, nz[j].z * ns, nz[j].w * ns};
+                const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[e] + nzv[e];
+                    t += bb;
+                    if (p.ep.act == MGF_ACT_LRELU) t = t > 0.f ? t : t * p.ep.alpha;
+                    else if (p.ep.act == MGF_ACT_RELU) t = t > 0.f ? t : 0.f;
+                    acc[e] = t * p.ep.gain + rr[e];
+                }
+            }
+            *reinterpret_cast<float4*>(yb + (int64_t)oy * p.yh) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    };
+    {   // rows ib .. ib + 2 prime the ring (slots 0 .. 2)
+        float4 v0[3];
+        float2 h0[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) load_row(ib + j, v0[j], h0[j]);
+        load_group(0, va, ha, na);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) hpass(hz[j], v0[j], h0[j]);
+    }
+    constexpr int NG = FS_ROWS / 4;
+    static_assert(NG % 2 == 0, "the row groups alternate between two register sets");
+    for (int g = 0; g < NG; g += 2) {
+        load_group(g + 1, vb, hb, nb);
+        do_group(g, va, ha, na);
+        if (g + 2 < NG) load_group(g + 2, va, ha, na);
+        do_group(g + 1, vb, hb, nb);
+    }
+}
+
 __global__ __launch_bounds__(256) void fir_up2_wide(UFParams p) {
     constexpr int TW = 64, TH = 16, WV = 10, IH = TH / 2 + 2;       // window: 10 float4 = 40 input columns, 10 input rows
     __shared__ float sx[IH][WV * 4 + 4];
@@ -542,7 +666,13 @@ extern "C" int mgf_upfirdn2d(void* y, const void* x, const float* f, int dtype, 
                          (!ep || ((!ep->noise || (uintptr_t)ep->noise % 16 == 0) && (!ep->residual || (uintptr_t)ep->residual % 16 == 0)));
     if (wide_ok && upx == 1 && padx0 == 1 && sh >= (int64_t)((in_w + 3) / 4) * 4 && pady0 >= 0 && pady0 <= 3) {
         static const char* sep_env = getenv("MGF_FIR_SEP");          // tuning hook (experiments only): 0 = never take the separable kernel
-        if (p.sep_ok && !(sep_env && sep_env[0] == '0')) {
+        static const char* stream_env = getenv("MGF_FIR_STREAM");    // tuning hook: 0 = the LDS-tiled separable kernel on wide maps too
+        const int64_t swaves = (int64_t)n * c * (out_w / 256) * mgf_cdiv(out_h, FS_ROWS);
+        if (p.sep_ok && out_w % 256 == 0 && out_h >= FS_ROWS && swaves >= 2048 && swaves <= INT32_MAX - 4 && !(stream_env && stream_env[0] == '0')) {
+            const int blocks = (int)mgf_cdiv(swaves, 4);
+            if (ep) hipLaunchKernelGGL((fir_up1_stream<true>), dim3(blocks), dim3(256), 0, stq, p);
+            else hipLaunchKernelGGL((fir_up1_stream<false>), dim3(blocks), dim3(256), 0, stq, p);
+        } else if (p.sep_ok && !(sep_env && sep_env[0] == '0')) {
             const int blocks = n * c * (int)mgf_cdiv(out_h, 64) * (out_w / 64);
             if (ep) hipLaunchKernelGGL((fir_up1_sep<true>), dim3(blocks), dim3(256), 0, stq, p);
             else hipLaunchKernelGGL((fir_up1_sep<false>), dim3(blocks), dim3(256), 0, stq, p);

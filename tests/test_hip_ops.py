@@ -517,6 +517,37 @@ def test_winograd3_half_resolution_residual(n, cin, cout, h, w):
     assert rel_err(out, two) < 2e-6
 
 
+@pytest.mark.parametrize("n,c,h,with_ep", [(8, 64, 128, True), (2, 32, 512, True), (4, 64, 256, False)])
+def test_fir_streaming_kernel_vs_float64(n, c, h, with_ep):
+    """fir_up1_stream (csrc/upfirdn2d.hip): the blur after the transposed conv on wide maps -- upfirdn2d(t, f, padding 1, gain 4) of the
+    (2h+1)^2 padded-pitch workspace, with the fused noise / bias / lrelu epilogue -- as the no-LDS streaming kernel (256-column strips,
+    DPP halo exchange, ring of four filtered rows) against float64 torch and against the LDS-tiled separable kernel it replaces (which
+    serves every call below 2048 strips-x-row-segments, e.g. one channel slice of the same tensors)."""
+    from morphganformer_amd import _lib, conv as cv
+    torch.manual_seed(h + c)
+    r = 2 * h
+    f1 = torch.tensor([1., 3., 3., 1.], dtype=torch.float64)
+    f2 = f1[:, None] * f1[None, :] / 64
+    tbuf = torch.full((n, c, r + 1, cv.tconv_pitch(h)), float("nan"), device="cuda")       # the pad columns hold garbage in the engine
+    t = tbuf[:, :, :, :r + 1]
+    t.copy_(torch.randn(n, c, r + 1, r + 1, device="cuda"))
+    noise, bias, st = torch.randn(n, r, r, device="cuda"), torch.randn(c, device="cuda"), torch.tensor([0.4], device="cuda")
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(t.double().reshape(n * c, 1, r + 1, r + 1), (1, 1, 1, 1)), (f2 * 4).cuda()[None, None])
+    ref = ref.reshape(n, c, r, r)
+    ep = None
+    if with_ep:
+        ep = _lib.make_epilogue(bias=bias, noise=noise, noise_strength=st, noise_n=n, act="lrelu", alpha=0.2, gain=1.3)
+        ref = torch.nn.functional.leaky_relu(ref + noise.double()[:, None] * 0.4 + bias.double()[None, :, None, None], 0.2) * 1.3
+    y = torch.full((n, c, r, r), float("nan"), device="cuda")
+    cv.upfirdn_into(y, t, f2.float().cuda(), up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=ep, separable=True)
+    assert rel_err(y, ref) < 5e-6
+    # one channel of one sample is far below the streaming threshold: the LDS-tiled kernel, same arithmetic
+    y1 = torch.empty(1, 1, r, r, device="cuda")
+    ep1 = _lib.make_epilogue(bias=bias[3:4].contiguous(), noise=noise[1:2].contiguous(), noise_strength=st, noise_n=1, act="lrelu", alpha=0.2, gain=1.3) if with_ep else None
+    cv.upfirdn_into(y1, t[1:2, 3:4], f2.float().cuda(), up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=ep1, separable=True)
+    assert rel_err(y[1:2, 3:4], y1) < 1e-6
+
+
 @pytest.mark.parametrize("n,cout,h,w", [(2, 32, 64, 64), (1, 32, 100, 96), (3, 64, 32, 512), (1, 32, 16, 1024), (2, 32, 8, 2048)])
 def test_winograd3_persistent_form(n, cout, h, w):
     """wino3p_conv_kernel (the form the literal loop runs on the 1024^2 layers at 25 - 32 candidates: a workgroup walks a strip of tiles with
