@@ -904,7 +904,12 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     // The ring is what keeps memory busy: a workgroup's chunk is 3.2 KB, and with one chunk in flight per workgroup (two workgroups per
     // CU) the whole chip has 1.6 MB outstanding -- 0.8 TB/s at 2 us of loaded latency, less than the layer reads.  XD chunks deep, a
     // load has XD chunk bodies (~ 3 000 cycles) to land before it is parked.
-    constexpr int XD = 4;
+    // (depth: the ToRGB variant has registers for 8 chunks -- 32 x 1024^2, same box: 3300 us with 4, 3085 with 8 -- the other one, whose
+    // epilogue holds more, spills beyond 4.  LDS-DMA staging into a ring of 8 LDS buffers with hand-counted vmcnt -- no staging registers, no
+    // LDS stores, a whole tile of prefetch distance -- was built and measured too: correct, and 3 - 5 % SLOWER than this register ring
+    // (4329 / 3749 / 3574 vs 4206 / 3675 / 3393 us on one box): four `buffer_load_dword ... lds` with their M0 hand-over per chunk body cost
+    // more issue time than four register loads and two 2-dword LDS stores)
+    constexpr int XD = RGB ? 8 : 4;
     static_assert(NCK % XD == 0, "ring slot = chunk index mod XD must be a compile-time value");
     float xq[XD][W3CK];
     float B[2][2][4];
