@@ -569,6 +569,12 @@ __device__ __forceinline__ void w3_dma_b32(w3_v4i rsrc, unsigned lds_addr, unsig
 #ifndef W3P_SCALAR_T
 #define W3P_SCALAR_T 0        // same-box A/B at 32 x 1024^2 (us; conv1 + skip / conv1 / conv_last + ToRGB): packed 3889 / 3308 / 3235, scalar 3956 / 3363 / 3343
 #endif
+#ifndef W3P_XD_PLAIN
+#define W3P_XD_PLAIN 4
+#endif
+#ifndef W3P_XD_RGB
+#define W3P_XD_RGB 8
+#endif
 #ifndef W3P_OWN_BRANCH
 #define W3P_OWN_BRANCH 1      // (same series: 4019 / 3443 / 3246 with the run-time bit select)
 #endif
@@ -755,28 +761,24 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     // run time it was 32 bit-select instructions per tile)
     auto row_reduce = [&](auto own_unit, float (&own)[NV]) {
         constexpr int OWN = decltype(own_unit)::value;
-        float other[NV];
+        // unit 0 goes to slot w0s, unit 1 to slot w1s; the own unit is written too where another wave needs it (waves 1 and 2).  Every value
+        // leaves for LDS as soon as it exists: the other unit is never held in registers (they are what bounds the prefetch ring's depth)
+        const int s_own = OWN == 0 ? w0s : w1s, s_oth = OWN == 0 ? w1s : w0s;
+        float* const d_own = xch + (s_own >= 0 ? s_own : 0) * (NV * 64) + lane;
+        float* const d_oth = xch + (s_oth >= 0 ? s_oth : 0) * (NV * 64) + lane;
 #pragma unroll
-        for (int un = 0; un < 2; ++un)
+        for (int v = 0; v < NV; ++v) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
+            for (int un = 0; un < 2; ++un) {
                 const int r = RGB ? v : un * 8 + (v >> 1);
                 const int jj = RGB ? un : (v & 1);
                 const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
                 const float val = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;       // (m3 = -M3, see transform)
-                if (un == OWN) own[v] = val; else other[v] = val;
+                if (un == OWN) {
+                    own[v] = val;
+                    if (s_own >= 0) d_own[v * 64] = val;
+                } else if (s_oth >= 0) d_oth[v * 64] = val;
             }
-        // unit 0 goes to slot w0s, unit 1 to slot w1s; the own unit is written too where another wave needs it (waves 1 and 2)
-        const int s_own = OWN == 0 ? w0s : w1s, s_oth = OWN == 0 ? w1s : w0s;
-        if (s_own >= 0) {
-            float* dst = xch + s_own * (NV * 64) + lane;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) dst[v * 64] = own[v];
-        }
-        if (s_oth >= 0) {
-            float* dst = xch + s_oth * (NV * 64) + lane;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) dst[v * 64] = other[v];
         }
     };
     auto epilogue = [&](int t) {
@@ -904,25 +906,28 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     // The ring is what keeps memory busy: a workgroup's chunk is 3.2 KB, and with one chunk in flight per workgroup (two workgroups per
     // CU) the whole chip has 1.6 MB outstanding -- 0.8 TB/s at 2 us of loaded latency, less than the layer reads.  XD chunks deep, a
     // load has XD chunk bodies (~ 3 000 cycles) to land before it is parked.
-    // (depth: the ToRGB variant has registers for 8 chunks -- 32 x 1024^2, same box: 3300 us with 4, 3085 with 8 -- the other one, whose
-    // epilogue holds more, spills beyond 4.  LDS-DMA staging into a ring of 8 LDS buffers with hand-counted vmcnt -- no staging registers, no
-    // LDS stores, a whole tile of prefetch distance -- was built and measured too: correct, and 3 - 5 % SLOWER than this register ring
-    // (4329 / 3749 / 3574 vs 4206 / 3675 / 3393 us on one box): four `buffer_load_dword ... lds` with their M0 hand-over per chunk body cost
-    // more issue time than four register loads and two 2-dword LDS stores)
-    constexpr int XD = RGB ? 8 : 4;
+    // (depth: 4 chunks; 8 in the ToRGB variant, whose epilogue leaves the registers -- 32 x 1024^2, same box, two runs each: 3243 / 3312 us
+    // with 8 against 3322 / 3348 with 4; in the other variant 8 measured no faster: 4135 / 3538 vs 4103 / 3498.  LDS-DMA staging into a ring of
+    // 8 LDS buffers with hand-counted vmcnt -- no staging registers, no LDS stores, a whole tile of prefetch distance -- was built and
+    // measured too: correct, and 3 - 5 % SLOWER than this register ring (4329 / 3749 / 3574 vs 4206 / 3675 / 3393 us on one box): four
+    // `buffer_load_dword ... lds` with their M0 hand-over per chunk body cost more issue time than four register loads and two 2-dword
+    // LDS stores)
+    constexpr int XD = RGB ? W3P_XD_RGB : W3P_XD_PLAIN;
     static_assert(NCK % XD == 0, "ring slot = chunk index mod XD must be a compile-time value");
     float xq[XD][W3CK];
     float B[2][2][4];
-    unsigned voff_cur = tile_voff(0), voff_nxt = tile_voff(1);
+    // (chunk g = c + 2 + XD of the flattened stream may lie in this tile, the next one or -- ring of 8 -- the one after: three tile offsets)
+    unsigned voff_cur = tile_voff(0), voff_nxt = tile_voff(1), voff_n2 = tile_voff(2);
+    auto load_ahead = [&](float (&dst)[W3CK], int g) {               // g: chunk index relative to the current tile's chunk 0 (compile-time)
+        load_x(dst, g < NCK ? voff_cur : (g < 2 * NCK ? voff_nxt : voff_n2), g % NCK);
+    };
+    static_assert(2 + XD + NCK - 1 < 3 * NCK, "the ring reaches at most two tiles ahead");
     {
         float xa[W3CK], xb[W3CK];
         load_x(xa, voff_cur, 0);
         load_x(xb, voff_cur, 1);
 #pragma unroll
-        for (int d = 0; d < XD; ++d) {
-            if (2 + d < NCK) load_x(xq[d], voff_cur, 2 + d);
-            else load_x(xq[d], voff_nxt, 2 + d - NCK);
-        }
+        for (int d = 0; d < XD; ++d) load_ahead(xq[d], 2 + d);
         park_x(raw0, xa);
         park_x(raw1, xb);
         __syncthreads();
@@ -945,13 +950,13 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             park_x((c & 1) ? raw1 : raw0, xq[c % XD]);                       // chunk c + 2, requested XD bodies ago
-            if (c + 2 + XD < NCK) load_x(xq[c % XD], voff_cur, c + 2 + XD);
-            else load_x(xq[c % XD], voff_nxt, c + 2 + XD - NCK);
+            load_ahead(xq[c % XD], c + 2 + XD);
             __syncthreads();
         }
         epilogue(t);
         voff_cur = voff_nxt;
-        voff_nxt = tile_voff(t + 2);
+        voff_nxt = voff_n2;
+        voff_n2 = tile_voff(t + 3);
     }
 }
 
