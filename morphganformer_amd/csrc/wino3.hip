@@ -569,6 +569,9 @@ __device__ __forceinline__ void w3_dma_b32(w3_v4i rsrc, unsigned lds_addr, unsig
 #ifndef W3P_SCALAR_T
 #define W3P_SCALAR_T 0        // same-box A/B at 32 x 1024^2 (us; conv1 + skip / conv1 / conv_last + ToRGB): packed 3889 / 3308 / 3235, scalar 3956 / 3363 / 3343
 #endif
+#ifndef W3P_ST_AUX
+#define W3P_ST_AUX 0
+#endif
 #ifndef W3P_XD_PLAIN
 #define W3P_XD_PLAIN 4
 #endif
@@ -899,7 +902,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (int64_t)n * p.y_batch), 0, p.cout * plane * 4, 0x00020000);
 #pragma unroll
         for (int k = 0; k < NR; ++k)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vout[k]), ry, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vout[k]), ry, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, W3P_ST_AUX);
     };
 
     // ---- prologue: chunks 0 and 1 of tile 0 are parked, chunks 2 .. 1 + XD wait in the register ring ----
