@@ -569,6 +569,9 @@ __device__ __forceinline__ void w3_dma_b32(w3_v4i rsrc, unsigned lds_addr, unsig
 #ifndef W3P_SCALAR_T
 #define W3P_SCALAR_T 0        // same-box A/B at 32 x 1024^2 (us; conv1 + skip / conv1 / conv_last + ToRGB): packed 3889 / 3308 / 3235, scalar 3956 / 3363 / 3343
 #endif
+#ifndef W3P_TIMING_NOX
+#define W3P_TIMING_NOX 0
+#endif
 #ifndef W3P_ST_AUX
 #define W3P_ST_AUX 0
 #endif
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     const int ntiles = min(p.strip_len, p.tiles_x - sx * p.strip_len);
     const int plane = p.h * p.w;
     const float* xn = p.x + (int64_t)n * p.cin * plane;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, p.cin * plane * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, W3P_TIMING_NOX ? 0 : p.cin * plane * 4, 0x00020000);       // (W3P_TIMING_NOX: timing-only build, no input traffic)
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, 16 * p.cin * p.cout * 4, 0x00020000);
 
     // ---- resident A operands: position 4a + b, chunk c -> channels {half, half + 2} of the chunk, output channel co0 + l31; x style ----
