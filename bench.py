@@ -470,17 +470,36 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if not launched:                                  # --force-dist without a launcher: a process group of one rank
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("LOCAL_RANK", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
         torch.cuda.set_device(0)
     device = torch.device("cuda", local_rank if world > 1 else 0)
     if dist is not None:
-        # one RCCL collective before anything is timed: every rank contributes its rank id; the count that comes back is what the line reports
-        ids = torch.empty(world, dtype=torch.int64, device=device)
-        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=device))
-        assert ids.tolist() == list(range(world)), ids.tolist()
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout must carry exactly one JSON line, so file
+        # descriptor 1 points at stderr while the group and its first collective are set up
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # one RCCL collective before anything is timed: every rank contributes its rank id; the count that comes back is what the line reports
+            ids = torch.empty(world, dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=device))
+            assert ids.tolist() == list(range(world)), ids.tolist()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         rccl_ranks = dist.get_world_size()
     from morphganformer_amd.synth_weights import GeneratorConfig
     cfg = GeneratorConfig(img_resolution=a.res)
