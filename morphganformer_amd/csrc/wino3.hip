@@ -473,15 +473,20 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     if (UMODE == 1 && p.res_low) {
         // this wave's output row is oy = oy0 + 2 trow + orow: low rows (m-1, m) with weights (1/4, 3/4) for orow = 0, (m, m+1) with
         // (3/4, 1/4) for orow = 1, i.e. window rows trow + orow and trow + orow + 1; window columns tx, tx + 1, tx + 2
+        // (two channel rows per step in packed fp32 -- k and k + 1 are neighbouring channels, planes 72 floats apart; round 3: the scalar
+        // form was 234 us of the persistent kernel's 4020 at 32 x 1024^2)
         const float wa = orow ? 0.75f : 0.25f, wb = 1.f - wa;
+        const v2f wa2 = {wa, wa}, wb2 = {wb, wb}, q25 = {0.25f, 0.25f}, q75 = {0.75f, 0.75f};
         const int chl = cob - co0;
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
+        for (int k = 0; k < NR; k += 2) {
             const float* lp = lowt + (chl + (k & 3) + 8 * (k >> 2)) * 72 + (trow + orow) * 18 + tx;
-            const float a0 = lp[0], a1 = lp[1], a2 = lp[2], b0 = lp[18], b1 = lp[19], b2 = lp[20];
-            const float c0 = wa * a0 + wb * b0, c1 = wa * a1 + wb * b1, c2 = wa * a2 + wb * b2;
-            rr[k].x = 0.25f * c0 + 0.75f * c1;
-            rr[k].y = 0.75f * c1 + 0.25f * c2;
+            const v2f a0 = {lp[0], lp[72]}, a1 = {lp[1], lp[73]}, a2 = {lp[2], lp[74]};
+            const v2f b0 = {lp[18], lp[90]}, b1 = {lp[19], lp[91]}, b2 = {lp[20], lp[92]};
+            const v2f c0 = wa2 * a0 + wb2 * b0, c1 = wa2 * a1 + wb2 * b1, c2 = wa2 * a2 + wb2 * b2;
+            const v2f rx2 = q25 * c0 + q75 * c1, ry2 = q75 * c1 + q25 * c2;
+            rr[k].x = rx2.x; rr[k + 1].x = rx2.y;
+            rr[k].y = ry2.x; rr[k + 1].y = ry2.y;
         }
     }
     {
@@ -566,6 +571,18 @@ __device__ __forceinline__ void w3_dma_b32(w3_v4i rsrc, unsigned lds_addr, unsig
                  : "memory");
 }
 
+// the 16-byte form (gfx950): lane l writes its four dwords to LDS byte address lds_addr + 16 l
+__device__ __forceinline__ void w3_dma_b128(w3_v4i rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff)
+                 : "memory");
+}
+
+#ifndef W3P_ABL
+#define W3P_ABL 0          // timing-only ablations of the fused skip: 1 = no window requests, 2 = no interpolation arithmetic
+#endif
 #ifndef W3P_SCALAR_T
 #define W3P_SCALAR_T 0        // same-box A/B at 32 x 1024^2 (us; conv1 + skip / conv1 / conv_last + ToRGB): packed 3889 / 3308 / 3235, scalar 3956 / 3363 / 3343
 #endif
@@ -595,8 +612,8 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     float* const raw0 = lds;
     float* const raw1 = raw0 + RAW;
     float* const xch = raw1 + RAW;                                 // [6 slots][NV][64 lanes]
-    float* const lowt = xch + 6 * NV * 64;                         // [32][4][18] half-resolution residual window (RGB: [3][32] projection weights)
-    float* const nzs = lowt + 2304;                                // [4 rows][64]
+    float* const lowt = xch + 6 * NV * 64;                         // [32][4][24] half-resolution residual window in 16-byte pieces (RGB: [3][32] projection weights)
+    float* const nzs = lowt + 3072;                                // [4 rows][64]
     float* const obs = nzs + 256;                                  // [2][64]: out_scale, bias of the 32 channels
     const int tid = threadIdx.x, lane = tid & 63;
     const int a = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -713,35 +730,40 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     const bool has_low = !RGB && p.res_low != nullptr;
     const bool has_nz = !RGB && p.has_ep && p.ep.noise != nullptr;
     const int hl = p.h >> 1, wl = p.w >> 1, pl = hl * wl;
-    unsigned lowoff[9];                                            // window element tid + 256 j of tile 0, or OOB when its row is outside
-    unsigned lowflag = 0;                                          // bit j: window column 0, bit 9 + j: window column 17
+    // The window as 16-byte pieces: [32 channels][4 rows][6 pieces] = 768 pieces, three per lane (nine 4-byte requests per lane and tile before:
+    // 4020 -> 3762 us without them, ablation W3P_ABL=1).  Low-resolution columns (ox0 >> 1) - 4 .. + 19 -- the 18 the tile needs are columns
+    // 3 .. 20 of them; the map width and every piece's first column are multiples of 4, so a piece is entirely inside the map or entirely
+    // outside (the row's first tile: piece 0; its last tile: piece 5).
+    unsigned lowoff[3];                                            // byte offset of piece tid + 256 j in tile 0
+    unsigned lowflag = 0;                                          // bit j: piece 0 of a row, bit 3 + j: piece 5, bit 6 + j: row outside the map
     w3_v4i rlow = {0, 0, 0, 0}, rnz = {0, 0, 0, 0};
     if (has_low) {
         rlow = w3_make_rsrc(p.res_low + ((int64_t)n * p.cout + co0) * pl, 32u * (unsigned)pl * 4u);
-        const int m0 = (oy0 >> 1) - 1, n0 = (ox_s >> 1) - 1;
+        const int m0 = (oy0 >> 1) - 1, n0 = (ox_s >> 1) - 4;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
+        for (int j = 0; j < 3; ++j) {
             const int e = tid + 256 * j;
-            const int ch = e / 72, rem = e - ch * 72;
-            const int r = rem / 18, c = rem - r * 18;
+            const int ch = e / 24, rem = e - ch * 24;
+            const int r = rem / 6, c = rem - r * 6;
             const int my = m0 + r;
-            lowoff[j] = (my >= 0 && my < hl) ? (unsigned)(ch * pl + my * wl + n0 + c) * 4u : OOB;
+            lowoff[j] = (unsigned)(ch * pl + my * wl + n0 + 4 * c) * 4u;           // (may wrap below zero for piece 0 of tile 0: masked by its edge bit)
             lowflag |= (c == 0 ? 1u : 0u) << j;
-            lowflag |= (c == 17 ? 1u : 0u) << (9 + j);
+            lowflag |= (c == 5 ? 1u : 0u) << (3 + j);
+            lowflag |= ((my >= 0 && my < hl) ? 0u : 1u) << (6 + j);                // row outside the map (a flag, not a sentinel offset: -16 is a real offset here)
         }
     }
     if (has_nz) rnz = w3_make_rsrc(p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane, (unsigned)plane * 4u);
-    const unsigned lds_lowt = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lowt + 64 * a));
+    const unsigned lds_lowt = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lowt + 256 * a));    // piece 64 a of a group of 256
     const unsigned lds_nzs = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(nzs + 64 * a));
     auto issue_ep_dma = [&](int t) {
         const int ox0 = ox_s + 32 * t;
-        if (has_low) {
-            // (branch-free per element: bit j of `edge` = this lane's element j is the window's column 0 of the row's first tile or its column 17 of the last one)
-            const unsigned edge = (ox0 == 0 ? lowflag : 0u) | (ox0 + 32 == p.w ? (lowflag >> 9) : 0u);
+        if (has_low && !(W3P_ABL & 1)) {
+            // (branch-free per piece: bit j of `edge` = this lane's piece j lies left of the row's first tile or right of its last one)
+            const unsigned edge = (ox0 == 0 ? lowflag : 0u) | (ox0 + 32 == p.w ? (lowflag >> 3) : 0u) | (lowflag >> 6);
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const unsigned off = (lowoff[j] == OOB || ((edge >> j) & 1u)) ? OOB : lowoff[j] + (unsigned)(64 * t);
-                w3_dma_b32(rlow, lds_lowt + 1024u * j, off, 0u);
+            for (int j = 0; j < 3; ++j) {
+                const unsigned off = ((edge >> j) & 1u) ? OOB : lowoff[j] + (unsigned)(64 * t);
+                w3_dma_b128(rlow, lds_lowt + 4096u * j, off, 0u);
             }
         }
         if (has_nz) {
@@ -875,15 +897,20 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             const float2 nv = *reinterpret_cast<const float2*>(nzs + 64 * (2 * ty + orow) + 2 * tx);
             nz0 = nv.x * ns; nz1 = nv.y * ns;
         }
-        if (has_low) {
+        if (has_low && !(W3P_ABL & 2)) {
+            // two channel rows per step in packed fp32 (k and k + 1 are neighbouring channels, planes 96 floats apart): 234 us of this kernel
+            // were interpolation arithmetic in scalar form (ablation W3P_ABL=2)
             const float wa = orow ? 0.75f : 0.25f, wb = 1.f - wa;
+            const v2f wa2 = {wa, wa}, wb2 = {wb, wb}, q25 = {0.25f, 0.25f}, q75 = {0.75f, 0.75f};
 #pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                const float* lp = lowt + (chl + (k & 3) + 8 * (k >> 2)) * 72 + (ty + orow) * 18 + tx;
-                const float a0 = lp[0], a1 = lp[1], a2 = lp[2], b0 = lp[18], b1 = lp[19], b2 = lp[20];
-                const float c0 = wa * a0 + wb * b0, c1 = wa * a1 + wb * b1, c2 = wa * a2 + wb * b2;
-                rr[k].x = 0.25f * c0 + 0.75f * c1;
-                rr[k].y = 0.75f * c1 + 0.25f * c2;
+            for (int k = 0; k < NR; k += 2) {
+                const float* lp = lowt + (chl + (k & 3) + 8 * (k >> 2)) * 96 + (ty + orow) * 24 + tx + 3;
+                const v2f a0 = {lp[0], lp[96]}, a1 = {lp[1], lp[97]}, a2 = {lp[2], lp[98]};
+                const v2f b0 = {lp[24], lp[120]}, b1 = {lp[25], lp[121]}, b2 = {lp[26], lp[122]};
+                const v2f c0 = wa2 * a0 + wb2 * b0, c1 = wa2 * a1 + wb2 * b1, c2 = wa2 * a2 + wb2 * b2;
+                const v2f rx2 = q25 * c0 + q75 * c1, ry2 = q75 * c1 + q25 * c2;
+                rr[k].x = rx2.x; rr[k + 1].x = rx2.y;
+                rr[k].y = ry2.x; rr[k + 1].y = ry2.y;
             }
         }
         float2 vout[NR];
@@ -1051,7 +1078,7 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
         int64_t pblocks = (int64_t)n * p.strips_x * p.tiles_y * p.co_tiles;
         p.xcd_per = (int)((pblocks + 7) / 8);                      // XCD-contiguous order: channel tiles, then strips of one row, share an L2
         pblocks = (int64_t)p.xcd_per * 8;
-        const size_t plds = (size_t)(2 * 4 * 256 + 6 * 16 * 64 + 2304 + 256 + 128) * sizeof(float);
+        const size_t plds = (size_t)(2 * 4 * 256 + 6 * 16 * 64 + 3072 + 256 + 128) * sizeof(float);
         static bool pattr_set = false;
         if (!pattr_set) {
             hipError_t e = hipFuncSetAttribute((const void*)wino3p_conv_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
