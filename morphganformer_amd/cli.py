@@ -51,7 +51,9 @@ def build_parser():
     p.add_argument("--ratio", type=float, default=1.0)
     p.add_argument("--truncation_psi", type=float, default=0.7)
     p.add_argument("--noise_regularize", type=float, default=1e5)       # accepted and unused, like the reference
-    p.add_argument("--w_plus", action="store_true")                     # accepted and unused, like the reference
+    p.add_argument("--w_plus", action="store_true",
+                   help="with --mode gradient: optimise the per-layer latent W+ [k, num_ws, D] instead of z (the reference accepts the flag "
+                        "and never reads it; in literal mode it stays unused here too)")
     p.add_argument("--percept_weight", type=float, default=1.0, help="coefficient of the LPIPS term (0.5 with --beta 0.5 = 1024_example_percept_MSE.py)")
     p.add_argument("--net", type=str, default="squeeze", choices=["squeeze", "vgg", "alex"], help="LPIPS backbone")
     p.add_argument("--no-lpips", action="store_true", help="MSE(+Wing) only, the 1024_example_MSE.py objective")
@@ -128,7 +130,7 @@ def main(argv=None):
     stem = os.path.splitext(os.path.basename(a.image))[0]
     res = drivers.project_image(G, target, lm_t, lm_s, args=args, percept=percept, batch=a.batch, seed=a.seed,
                                 out_prefix=os.path.join(a.path_to_gen, stem), mode=a.mode, path_to_gen=a.path_to_gen,
-                                keep_images=a.keep_images)
+                                keep_images=a.keep_images, latent_space="w+" if (a.w_plus and a.mode == "gradient") else "z")
     print(f"best step {res['step']}  loss {res['loss']:.6f}")
     return 0
 

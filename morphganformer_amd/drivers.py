@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .projection import GradientProjectionEngine, ProjectionArgs, ProjectionEngine, latent_stats
+from .projection import GradientProjectionEngine, ProjectionArgs, ProjectionEngine, latent_stats, latent_stats_w
 
 
 # ----------------------------------------------------------------------------------------------------------------- image I/O
@@ -149,13 +149,15 @@ DEFAULT_BATCH = 32       # loop steps per generator forward in literal mode: the
 def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None,
                   eps=None, out_prefix=None, batch=DEFAULT_BATCH, use_graph=True, noise_mode="random", use_mse=True, seed=None,
                   landmark_fn=None, mode="literal", weight_decay=0.0, path_to_gen=None, keep_images=64, engine=None,
-                  return_engine=False):
+                  return_engine=False, latent_space="z"):
     """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and either
     `lm_steps` [steps,68,2] (injected landmark detections) or `landmark_fn` (host detector called on every generated image,
     see ProjectionEngine).  mode="literal" is the loop as the reference executes it (best-of-N noisy sampling, `batch` steps per
     forward -- 32 by default, the benchmarked configuration; the result does not depend on it); mode="gradient" back-propagates the
     loss into the latent and lets Adam move it (GradientProjectionEngine; one candidate per step; weight_decay=1e-4 is the
-    1024_example_MSE.py:117 optimizer).  Returns dict(w, step, loss, losses).
+    1024_example_MSE.py:117 optimizer; latent_space="w+" optimises the per-layer intermediate latent [k, num_ws, D] instead of z -- the
+    statistics are then taken in w space, projection.latent_stats_w -- and `w` comes back as [1, k, num_ws, D]).  Returns dict(w, step,
+    loss, losses).
 
     Outputs, like the drivers: with `path_to_gen` the SCORED image of every improvement -- the candidate as it was generated and
     ranked, its random per-layer noise included -- is written as `{path_to_gen}/{step:06d}_{loss:04f}.png` (:190-195; literal mode:
@@ -172,12 +174,15 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
         raise ValueError(f"mode must be 'literal' or 'gradient' (got {mode!r})")
     if engine is not None and mode != "literal":
         raise ValueError("engine= (re-targeting) is for literal mode")
+    if latent_space not in ("z", "w+") or (latent_space == "w+" and mode != "gradient"):
+        raise ValueError("latent_space must be 'z', or 'w+' together with mode='gradient'")
     if latent_mean is None or latent_std is None:
         gen = None
         if seed is not None:
             gen = torch.Generator(device=G.device)
             gen.manual_seed(seed)
-        latent_mean, latent_std = latent_stats(G, args.n_mean_latent, G.device, generator=gen)
+        stats = latent_stats_w if latent_space == "w+" else latent_stats
+        latent_mean, latent_std = stats(G, args.n_mean_latent, G.device, generator=gen)
     keep = max(int(keep_images), int(batch)) if path_to_gen is not None and mode == "literal" else 0
     if engine is not None:
         if engine.G is not G or engine.batch != batch or engine.steps != args.step or engine.keep_images != keep:
@@ -187,7 +192,7 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
     elif mode == "gradient":
         eng = GradientProjectionEngine(G, target, latent_mean, float(latent_std), args, weight_decay=weight_decay, percept=percept,
                                        lm_target=lm_target, lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph,
-                                       use_mse=use_mse, landmark_fn=landmark_fn, seed=0 if seed is None else seed)
+                                       use_mse=use_mse, landmark_fn=landmark_fn, seed=0 if seed is None else seed, latent_space=latent_space)
     else:
         eng = ProjectionEngine(G, target, latent_mean, float(latent_std), args, percept=percept, lm_target=lm_target,
                                lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse,

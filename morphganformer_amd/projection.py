@@ -76,12 +76,31 @@ def latent_stats(G, n_mean_latent=10000, device="cuda", generator=None):
     return mean, std
 
 
+def _as_latent(latent_mean, shape):
+    """latent_mean as a tensor of `shape` = (k, D) or (k, num_ws, D): a [k, D] mean is broadcast over the layer slots of a W+ latent."""
+    t = latent_mean.detach().clone().float()
+    if len(shape) == 3 and t.numel() == shape[0] * shape[2]:
+        t = t.reshape(shape[0], 1, shape[2]).expand(*shape)
+    return t.reshape(*shape).contiguous()
+
+
+def latent_stats_w(G, n_mean_latent=10000, device="cuda", generator=None):
+    """Statistics of the INTERMEDIATE latent for a W+ search (what StyleGAN2-style projectors use: w_avg and w_std of mapped samples):
+    mean [k, D] and the scalar std of G.mapping(z)[:, :, 0] over z ~ N(0, I), with the drivers' formula (:251-255) applied to w."""
+    z = torch.randn(n_mean_latent, *G.input_shape[1:], device=device, generator=generator)
+    w = torch.cat([G.mapping(z[i:i + 2000])[:, :, 0].clone() for i in range(0, n_mean_latent, 2000)])
+    mean = w.mean(0)
+    std = ((w - mean).pow(2).sum() / n_mean_latent) ** 0.5
+    return mean, std
+
+
 class ProjectionEngine:
     """One target image <-> one latent search, replayable as a hipGraph."""
 
     def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True,
                  lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, batch=1,
-                 landmark_fn=None, biometric=None, gamma=1.0, wing_kind="wing", landmark_model=None, pipeline=False, keep_images=0):
+                 landmark_fn=None, biometric=None, gamma=1.0, wing_kind="wing", landmark_model=None, pipeline=False, keep_images=0,
+                 latent_shape=None):
         """batch = number of consecutive loop steps evaluated per generator forward.  In literal mode the steps do not depend
         on each other (latent_in never changes), so evaluating `batch` candidates at once and examining them in step order
         gives exactly the sequential loop's result while the small 4x4..64x64 layers, the mapping network and the LPIPS tail
@@ -128,16 +147,18 @@ class ProjectionEngine:
         self.use_wing = lm_target is not None
         self.noise_mode = noise_mode
         k, D = G.cfg.k, G.cfg.z_dim
-        self.numel = k * D
-        self.latent_in = latent_mean.detach().clone().reshape(1, k, D).contiguous().float()
+        # (k, D): the drivers' z latent.  GradientProjectionEngine(latent_space="w+") passes (k, num_ws, D)
+        self.latent_shape = ls = tuple(latent_shape) if latent_shape is not None else (k, D)
+        self.numel = int(np.prod(ls))
+        self.latent_in = _as_latent(latent_mean, ls).reshape(1, *ls).contiguous().float()
         sig = noise_schedule(a.step, float(latent_std), a.noise, a.noise_ramp)
         self.sigma = torch.as_tensor(sig, device=dev)
         if eps is None:
             gen = torch.Generator(device=dev)
             gen.manual_seed(seed)
-            eps = torch.randn(a.step, 1, k, D, device=dev, generator=gen)
+            eps = torch.randn(a.step, 1, *ls, device=dev, generator=gen)
         self.eps = eps.to(dev).contiguous().float()
-        assert self.eps.shape[0] >= a.step
+        assert self.eps.shape[0] >= a.step and self.eps[0].numel() == self.numel
         assert wing_kind in ("wing", "awing")
         self.wing_kind = wing_kind
         self.landmark_fn = landmark_fn
@@ -160,11 +181,11 @@ class ProjectionEngine:
         # device-resident loop state
         self.step_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
         self.min_loss = torch.full([1], float(a.min_loss_init), dtype=torch.float64, device=dev)
-        self.best_latent = torch.zeros(1, k, D, dtype=torch.float32, device=dev)
+        self.best_latent = torch.zeros(1, *ls, dtype=torch.float32, device=dev)
         self.best_step = torch.full([1], -1, dtype=torch.int32, device=dev)
         self.losses = torch.full([a.step], float("nan"), dtype=torch.float64, device=dev)
         B = self.batch
-        self.latent_n = torch.empty(B, k, D, dtype=torch.float32, device=dev)
+        self.latent_n = torch.empty(B, *ls, dtype=torch.float32, device=dev)
         self.p_loss = torch.zeros(B, dtype=torch.float32, device=dev)
         self.mse_loss = torch.zeros(B, dtype=torch.float32, device=dev)
         self.w_loss = torch.zeros(B, dtype=torch.float64, device=dev)
@@ -520,18 +541,28 @@ class GradientProjectionEngine(ProjectionEngine):
 
     def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True, lm_target=None,
                  lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, landmark_fn=None, biometric=None,
-                 gamma=1.0, wing_kind="wing", landmark_model=None, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=0.0, **ignored):
+                 gamma=1.0, wing_kind="wing", landmark_model=None, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=0.0,
+                 latent_space="z", **ignored):
+        """latent_space: "z" -- the drivers' parameter, the gradient runs on through the mapping network -- or "w+": the parameter is the
+        per-layer intermediate latent ws [k, num_ws, D] itself (north_star: "backprops into the k-component latent W+"; layer `slot` reads
+        ws[:, slot], networks.py:1252-1253), perturbed, descended by Adam and kept best-of exactly like z.  latent_mean is then a w-space
+        start -- [k, D] (broadcast over the slots, e.g. latent_stats_w's mean) or [k, num_ws, D] -- and latent_std a w-space scale.  The
+        reference has no such driver (its "W+" averages 18 copies of z, projection_example_v2_percept.py:133-162); the oracle is torch autograd
+        + Adam on ws through the CPU restatement (tests/test_hip_gradient.py)."""
         from .grad import GeneratorGrad
+        assert latent_space in ("z", "w+"), latent_space
+        self.latent_space = latent_space
+        ls = (G.cfg.k, G.cfg.num_ws, G.cfg.w_dim) if latent_space == "w+" else (G.cfg.k, G.cfg.z_dim)
         B = int(target.shape[0])
         if B == 1:
             super().__init__(G, target, latent_mean, latent_std, args, percept=percept, use_mse=use_mse, lm_target=lm_target,
                              lm_steps=lm_steps, lm_valid=lm_valid, eps=eps, noise_mode=noise_mode, seed=seed, use_graph=use_graph, batch=1,
                              landmark_fn=landmark_fn, biometric=biometric, gamma=gamma, wing_kind=wing_kind,
-                             landmark_model=landmark_model, pipeline=False)
+                             landmark_model=landmark_model, pipeline=False, latent_shape=ls)
             self.lm_tables = [self.lm_steps] if self.use_wing else None
         else:
             self._init_multi(G, target, latent_mean, latent_std, args, percept, use_mse, lm_target, lm_steps, lm_valid, eps, noise_mode,
-                             seed, use_graph, biometric, gamma, wing_kind)
+                             seed, use_graph, biometric, gamma, wing_kind, ls)
             assert landmark_fn is None and landmark_model is None, "landmark detectors are wired for one target per engine"
         self.targets = B
         a, dev = self.args, self.device
@@ -545,7 +576,7 @@ class GradientProjectionEngine(ProjectionEngine):
         self.dimg = torch.zeros_like(self.target)
 
     def _init_multi(self, G, target, latent_mean, latent_std, args, percept, use_mse, lm_target, lm_steps, lm_valid, eps, noise_mode,
-                    seed, use_graph, biometric, gamma, wing_kind):
+                    seed, use_graph, biometric, gamma, wing_kind, ls):
         """Loop state of B lockstep projections (the single-target layout of ProjectionEngine with a leading B axis)."""
         self.G, self.args = G, args or ProjectionArgs()
         a, dev = self.args, G.device
@@ -554,17 +585,18 @@ class GradientProjectionEngine(ProjectionEngine):
         _lib.require_gpu(target, latent_mean)
         self.target = target.contiguous().float()
         self.percept, self.use_mse, self.use_wing, self.noise_mode = percept, use_mse, lm_target is not None, noise_mode
-        k, D = G.cfg.k, G.cfg.z_dim
-        self.numel = k * D
-        lm0 = latent_mean.detach().float().reshape(-1, k, D)
-        self.latent_in = (lm0 if lm0.shape[0] == B else lm0.expand(B, -1, -1)).contiguous().clone()
+        self.latent_shape = ls
+        self.numel = int(np.prod(ls))
+        lm0 = latent_mean.detach().float()
+        lm0 = lm0.reshape(B, *ls) if lm0.numel() == B * self.numel else _as_latent(lm0, ls).reshape(1, *ls).expand(B, *ls)
+        self.latent_in = lm0.contiguous().clone()
         self.sigma = torch.as_tensor(noise_schedule(a.step, float(latent_std), a.noise, a.noise_ramp), device=dev)
         if eps is None:
             gen = torch.Generator(device=dev)
             gen.manual_seed(seed)
-            eps = torch.randn(a.step, B, k, D, device=dev, generator=gen)
+            eps = torch.randn(a.step, B, *ls, device=dev, generator=gen)
         self.eps = eps.to(dev).contiguous().float()
-        assert tuple(self.eps.shape) == (self.eps.shape[0], B, k, D) and self.eps.shape[0] >= a.step
+        assert tuple(self.eps.shape) == (self.eps.shape[0], B, *ls) and self.eps.shape[0] >= a.step
         assert wing_kind in ("wing", "awing")
         self.wing_kind, self.landmark_fn, self.landmark_model = wing_kind, None, None
         if self.use_wing:
@@ -577,10 +609,10 @@ class GradientProjectionEngine(ProjectionEngine):
         self.valid = None if lm_valid is None else torch.as_tensor(lm_valid, dtype=torch.int32, device=dev).reshape(B, -1).contiguous()
         self.step_ctr = torch.zeros(B, dtype=torch.int32, device=dev)              # one copy per target (select advances its own)
         self.min_loss = torch.full([B], float(a.min_loss_init), dtype=torch.float64, device=dev)
-        self.best_latent = torch.zeros(B, k, D, dtype=torch.float32, device=dev)
+        self.best_latent = torch.zeros(B, *ls, dtype=torch.float32, device=dev)
         self.best_step = torch.full([B], -1, dtype=torch.int32, device=dev)
         self.losses = torch.full([B, a.step], float("nan"), dtype=torch.float64, device=dev)
-        self.latent_n = torch.empty(B, k, D, dtype=torch.float32, device=dev)
+        self.latent_n = torch.empty(B, *ls, dtype=torch.float32, device=dev)
         self.p_loss = torch.zeros(B, dtype=torch.float32, device=dev)
         self.mse_loss = torch.zeros(B, dtype=torch.float32, device=dev)
         self.w_loss = torch.zeros(B, dtype=torch.float64, device=dev)
@@ -600,7 +632,10 @@ class GradientProjectionEngine(ProjectionEngine):
         # B targets: one flat parameter of B * numel floats, one noise row [B * numel] per step
         _lib.check(L.mgf_latent_perturb(self.latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(), self.sigma.data_ptr(),
                                         self.step_ctr.data_ptr(), 1, self.steps, B * self.numel, st), "latent_perturb")
-        img = self.gg.forward(self.latent_n, noise_mode=self.noise_mode)          # psi lands in `c` in the drivers: no truncation
+        if self.latent_space == "w+":
+            img = self.gg.forward(ws=self.latent_n, noise_mode=self.noise_mode)   # [B, k, num_ws, D]: every layer reads its own slot
+        else:
+            img = self.gg.forward(self.latent_n, noise_mode=self.noise_mode)      # psi lands in `c` in the drivers: no truncation
         if B == 1:
             self._landmarks(img)                                                  # before Adam: a "no face" step must not move the latent
         per = img.numel() // B
@@ -621,7 +656,7 @@ class GradientProjectionEngine(ProjectionEngine):
         if self.use_mse:
             _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), B, per, tstride, 1.0, 0,
                                      self.scratch.data_ptr(), st), "mse")
-        dz = self.gg.backward(self.dimg)
+        dz = self.gg.backward_ws(self.dimg) if self.latent_space == "w+" else self.gg.backward(self.dimg)
         has_p = self.percept is not None or self.biometric is not None
         for j in range(B):                   # per-target optimizer step, Wing term and best-of bookkeeping (tiny launches)
             ctr = self.step_ctr[j:]
@@ -672,7 +707,11 @@ class GradientProjectionEngine(ProjectionEngine):
 def save_best_png(G, latent, path, ratio=1.0, noise_mode="const"):
     """Write the image of `latent` as the drivers do (misc.to_pil + crop_max_rectangle, misc.py:94-130; :194-195)."""
     from PIL import Image
-    img = G.forward_workspace(latent.to(G.device), None, noise_mode=noise_mode)[0]
+    latent = latent.to(G.device)
+    if latent.ndim == 4:                       # a W+ result [1, k, num_ws, D] (GradientProjectionEngine(latent_space="w+"))
+        img = G.forward_workspace(ws=latent, noise_mode=noise_mode)[0]
+    else:
+        img = G.forward_workspace(latent, None, noise_mode=noise_mode)[0]
     c, h, w = img.shape[1:]
     out = torch.empty([h, w, c], dtype=torch.uint8, device=G.device)
     _lib.check(_lib.lib().mgf_to_uint8_hwc(out.data_ptr(), img.data_ptr(), c, h, w, _lib.stream_ptr()), "to_uint8")

@@ -469,6 +469,48 @@ def test_mse_grad_and_pool_bwd():
             assert torch.equal(got.cpu(), want)
 
 
+def test_wplus_gradient_projection_matches_autograd_adam(tiny):
+    """GradientProjectionEngine(latent_space="w+"): the parameter is the per-layer latent ws [k, num_ws, D] (north_star: "backprops into the
+    k-component latent W+") -- noise, Adam and the best-of bookkeeping act on all k * num_ws * D numbers -- against torch autograd +
+    torch.optim.Adam on ws through the CPU restatement's synthesis network: LPIPS + MSE, injected noise, hipGraph replay; the start is a
+    [k, D] mean broadcast over the slots, which must come apart (every slot gets its own gradient)."""
+    import os
+    from morphganformer_amd.lpips import PerceptualLoss, WEIGHTS_DIR
+    from morphganformer_amd.projection import GradientProjectionEngine, ProjectionArgs
+    from morphganformer_amd.synth_weights import synthetic_latents
+    from oracle.generator_ref import generator_ref, mapping_ref, synthesis_ref
+    from oracle.loss_ref import backbone_random, lpips_ref, mse_ref, projection_gradient_ref
+    gg, tsd, cfg = tiny
+    steps = 8
+    rng = np.random.Generator(np.random.PCG64(14))
+    w_mean = mapping_ref(tsd, torch.from_numpy(synthetic_latents(cfg, 1, 77)), cfg)[0].detach()              # [k, D], a point of w space
+    eps = torch.from_numpy(rng.standard_normal((steps, 1, cfg.k, cfg.num_ws, cfg.w_dim)).astype(np.float32))
+    target = generator_ref(tsd, torch.from_numpy(synthetic_latents(cfg, 1, 1001)), cfg, "const").clamp(-1, 1)
+    args = ProjectionArgs(step=steps, lr=0.05, lr_rampup=0.2)
+    w_std = float(w_mean.std()) * 4
+    bb = backbone_random("squeeze", 0)
+    lin = np.load(os.path.join(WEIGHTS_DIR, "lpips_lin_squeeze.npz"))
+    lins = [torch.from_numpy(lin[f"lin{i}"]).float().reshape(-1) for i in range(7)]
+    loss_fn = lambda i, img: lpips_ref(bb, lins, img, target).sum() + args.beta * mse_ref(img, target)
+    start = w_mean[:, None, :].expand(cfg.k, cfg.num_ws, cfg.w_dim).contiguous()
+    ref = projection_gradient_ref(lambda ws: synthesis_ref(tsd, ws, cfg, "const"), loss_fn, start, w_std, eps, steps, lr=args.lr,
+                                  rampdown=args.lr_rampdown, rampup=args.lr_rampup)
+    eng = GradientProjectionEngine(gg.G, target.cuda(), w_mean.cuda(), w_std, args, percept=PerceptualLoss(net="squeeze", allow_random_backbone=True),
+                                   eps=eps.cuda(), noise_mode="const", use_graph=True, latent_space="w+")
+    traj = []
+    for i in range(steps):
+        eng.run(1)
+        traj.append(eng.latent_in.cpu().clone())
+    lat, bstep, bloss, losses = eng.result()
+    assert tuple(lat.shape) == (1, cfg.k, cfg.num_ws, cfg.w_dim) and bstep == ref[1]
+    for i in range(steps):
+        assert float((traj[i] - ref[4][i]).abs().max()) < 0.05 * args.lr * (i + 1), i
+    assert np.abs(losses - np.array(ref[3])).max() < 1e-3 * np.abs(np.array(ref[3])).max()
+    assert rel(lat, ref[0]) < 0.02
+    spread = traj[-1][0].std(dim=1).max()                                # the slots started equal and moved apart
+    assert float(spread) > 0.2 * args.lr
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_gradient_projection_matches_autograd_adam(tiny, use_graph):
     """Gradient-mode loop vs torch autograd + torch.optim.Adam through the CPU oracle: LPIPS + lamda Wing + beta MSE, a skipped
