@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float u = acc[m][q] > 0.f ? acc[m][q] : 0.f;
+                const float u = fmaxf(acc[m][q], 0.f);        // (v_max_f32: written as `a > b ? a : b` the compiler must keep a compare + select for NaN's sake -- 2 of this kernel's ~ 14 VALU instructions per element went there)
                 v[m][q] = colvalid ? u : 0.f;
                 s += v[m][q] * v[m][q];
             }
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
             for (int q = 0; q < 16; ++q) {
                 const float s1 = wave_shl1(v[m][q]);
                 const float s2 = wave_shl1(s1);
-                float hmx = v[m][q] > s1 ? v[m][q] : s1;
-                hmx = hmx > s2 ? hmx : s2;
+                float hmx = fmaxf(v[m][q], s1);
+                hmx = fmaxf(hmx, s2);
                 v[m][q] = hmx;
             }
         if ((rr & 1) == 0) {                     // even row: closes window rr/2 - 1, opens window rr/2
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) P[m][q] = P[m][q] > v[m][q] ? P[m][q] : v[m][q];
+                    for (int q = 0; q < 16; ++q) P[m][q] = fmaxf(P[m][q], v[m][q]);
                 emit((r0 >> 1) + (rr >> 1) - 1);
             }
 #pragma unroll
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) P[m][q] = P[m][q] > v[m][q] ? P[m][q] : v[m][q];
+                for (int q = 0; q < 16; ++q) P[m][q] = fmaxf(P[m][q], v[m][q]);
         }
     }
     // ceil_mode: a map with an even number of rows ends on a two-row window
