@@ -19,6 +19,7 @@
 //     one strip for the distance sum.
 //   * distance: deterministic -- per-item partials in `scratch`, one finishing workgroup per sample adds them in index order.
 #include "mgf_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -39,12 +40,31 @@ struct StemParams {
     int n, h, w_in, ch, cw, ph, pw, tiles_x, strips, xcd_per;
 };
 
-__device__ __forceinline__ float wave_shl1(float v) {      // lane i <- lane i + 1 (DPP wave_shl:1)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+
+// v_max_f32 / v_max3_f32 issued as such.  `fmaxf` lowers to llvm.maxnum, whose IEEE semantics make the compiler put a canonicalising
+// `v_max x, x` in front of every operand it cannot prove quiet (MFMA results, DPP moves, loop-carried values): 128 of them per conv row
+// next to 96 real maxima.  NaNs do not occur here (finite weights, finite images), and for finite inputs the results are the same.
+__device__ __forceinline__ float vmax(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// Horizontal 3-max of four registers in place: x <- max(x[lane], x[lane + 1], x[lane + 2]) as two v_max_f32 whose first operand carries the
+// DPP shift (wave_shl:1; bound_ctrl: lane 63 reads 0, the identity for post-ReLU values).  One statement for four values so that every DPP
+// operand was written at least three instructions earlier: the two wait states a DPP read of a fresh VALU result needs are then free, and
+// the one s_nop in front covers whatever the compiler put before the statement (it does not look inside asm for that hazard).
+#define STEM_DPP " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void hmax3_x4(float& x0, float& x1, float& x2, float& x3) {
+    float m0, m1, m2, m3;
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %4, %0, %0" STEM_DPP "v_max_f32_dpp %5, %1, %1" STEM_DPP
+                 "v_max_f32_dpp %6, %2, %2" STEM_DPP "v_max_f32_dpp %7, %3, %3" STEM_DPP
+                 "v_max_f32_dpp %0, %4, %4" STEM_DPP "v_max_f32_dpp %1, %5, %5" STEM_DPP
+                 "v_max_f32_dpp %2, %6, %6" STEM_DPP "v_max_f32_dpp %3, %7, %7" STEM_DPP
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3));
 }
 
+#ifndef STEM_WAVES
+#define STEM_WAVES 2
+#endif
 template <bool FEAT>
-__global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STEM_WAVES, STEM_WAVES))) void lpips_stem_kernel(StemParams p) {
     __shared__ float lds[LDS_FLOATS];
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     // Work order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2); XCD b % 8 walks the contiguous item range
@@ -81,14 +101,19 @@ __global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
 #define STEM_CH(m, q) ((m) * 32 + ((q) & 3) + 8 * ((q) >> 2))
 
     // ---- input rows: global -> 4 registers per lane -> LDS ring slot (row & 3), even | odd columns apart ----
-    const float* xn = p.x + (int64_t)n * 3 * p.h * p.w_in;
-    const int64_t plane = (int64_t)p.h * p.w_in;
+    // (buffer addressing: the channel / row part of an address is wave-uniform and rides in the scalar offset; a row outside the image or
+    // a column past its end gets an offset beyond num_records and reads 0)
+    const int plane = p.h * p.w_in;                                          // host: 3 * h * w_in * 4 B < 2^32
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * 3 * plane), 0, (int)(12u * (unsigned)plane), 0x00020000);
+    const unsigned xoff_a = 2 * x0 + lane < p.w_in ? 4u * (2 * x0 + lane) : 0xFFFFFFF0u;
+    const unsigned xoff_b = (lane < 3 && 2 * x0 + 64 < p.w_in) ? 4u * (lane * plane + 2 * x0 + 64) : 0xFFFFFFF0u;
     auto load_row = [&](int ir, float (&g)[4]) {
         const bool rv = ir < p.h;
-        const int c0 = 2 * x0 + lane;
+        const int ro = ir * p.w_in;
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci) g[ci] = (rv && c0 < p.w_in) ? xn[ci * plane + (int64_t)ir * p.w_in + c0] : 0.f;
-        g[3] = (rv && lane < 3 && 2 * x0 + 64 < p.w_in) ? xn[lane * plane + (int64_t)ir * p.w_in + 2 * x0 + 64] : 0.f;
+        for (int ci = 0; ci < 3; ++ci)
+            g[ci] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, rv ? xoff_a : 0xFFFFFFF0u, (int)(4u * (unsigned)(ci * plane + ro)), 0));
+        g[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, rv ? xoff_b : 0xFFFFFFF0u, (int)(4u * (unsigned)ro), 0));
     };
     auto store_row = [&](int ir, const float (&g)[4]) {
         const int base = (ir & 3) * SLOT + ((lane & 1) ? ODD_OFF : 0) + (lane >> 1);
@@ -105,6 +130,7 @@ __global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
 
     const int xc = x0 + l31;
     const bool colvalid = xc < p.cw;
+    const bool edge_tile = x0 + 31 >= p.cw;
     const bool colown = colvalid && (l31 < TILE_COLS || last_tx);
     float P[2][16];
 #pragma unroll
@@ -112,36 +138,47 @@ __global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) P[m][q] = 0.f;
     float dsum = 0.f;
-    const int cplane = p.ch * p.cw;                                         // host guarantees 64 * ch * cw < 2^31
+    const int cplane = p.ch * p.cw;                                         // host guarantees 64 * ch * cw < 2^30
     const int pplane = p.ph * p.pw;
     const int lane_feat = 4 * half * cplane + (colvalid ? xc : p.cw - 1);    // per-lane part of a tap-0 address
     const int lane_pool = 4 * half * pplane + (x0 >> 1) + (l31 >> 1);        // per-lane part of a pooled address
+    // Buffer addressing: the per-channel plane offsets are wave-uniform, so they ride in the scalar offset operand and a row costs
+    // no vector address arithmetic (flat addressing spent one 64-bit vector add per element on it).  64 planes * 4 B < 2^32 (host).
+    const __amdgpu_buffer_rsrc_t rfeat = __builtin_amdgcn_make_buffer_rsrc(
+        FEAT ? (void*)(p.feat_out + (int64_t)n * 64 * cplane) : (void*)p.feat_ref, 0, (int)(256u * (unsigned)cplane), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc((void*)(p.pooled + (int64_t)n * 64 * pplane), 0, (int)(256u * (unsigned)pplane), 0x00020000);
 
-    auto emit = [&](int py) {          // pooled row py <- P (lanes on even columns; windows x .. x+2 stay inside the 31 good lanes)
+    auto emit = [&](const float (&E)[2][16], int py) {   // pooled row py <- E (lanes on even columns; windows x .. x+2 stay inside the 31 good lanes)
         const int px = (x0 >> 1) + (l31 >> 1);
         if (!(l31 & 1) && l31 <= 28 && px < p.pw && py < p.ph) {
-            float* o = p.pooled + (int64_t)n * 64 * pplane + (int64_t)py * p.pw;           // wave-uniform
+            const int o = py * p.pw;                                                       // wave-uniform
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) (o + (int64_t)STEM_CH(m, q) * pplane)[lane_pool] = P[m][q];
+                for (int q = 0; q < 16; ++q)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, E[m][q]), rpool, 4u * lane_pool, (int)(4u * (unsigned)(o + STEM_CH(m, q) * pplane)), 0);
         }
     };
 
-    for (int r = r0; r <= r_end; ++r) {
+    // One conv row.  EVEN (rows r0, r0 + 2, ...; r0 is even) is a compile-time tag and the loop below walks row PAIRS: with the parity known,
+    // "the even row opens the next window" (P = v) is a renaming instead of 32 register moves on three control-flow paths, and the LDS ring's
+    // odd-row flip is a constant.
+    auto row = [&](const int r, auto even_tag) {
+        constexpr bool EVEN = decltype(even_tag)::value;
         const int rr = r - r0;
         float gA[4], gB[4];
         if (r < r_end) { load_row(2 * r + 3, gA); load_row(2 * r + 4, gB); }
         float t[2][16];
         if (!FEAT) {
-            const float* tb = p.feat_ref + (int64_t)r * p.cw;                               // wave-uniform
+            const int tb = r * p.cw;                                                        // wave-uniform
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) t[m][q] = (tb + (int64_t)STEM_CH(m, q) * cplane)[lane_feat];
+                for (int q = 0; q < 16; ++q)
+                    t[m][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, 4u * lane_feat, (int)(4u * (unsigned)(tb + STEM_CH(m, q) * cplane)), 0));
         }
         // conv row r: rows 2r + dy sit in slots (dy + 2 (r & 1)) & 3
-        const int flip = (r & 1) ? 2 * SLOT : 0;
+        constexpr int flip = EVEN ? 0 : 2 * SLOT;
         f32x16 acc[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -164,20 +201,30 @@ __global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float u = fmaxf(acc[m][q], 0.f);        // (v_max_f32: written as `a > b ? a : b` the compiler must keep a compare + select for NaN's sake -- 2 of this kernel's ~ 14 VALU instructions per element went there)
-                v[m][q] = colvalid ? u : 0.f;
-                s += v[m][q] * v[m][q];
+                const float u = vmax(acc[m][q], 0.f);        // (v_max_f32: written as `a > b ? a : b` the compiler must keep a compare + select for NaN's sake -- 2 of this kernel's ~ 14 VALU instructions per element went there)
+                v[m][q] = u;
             }
+        if (edge_tile) {                         // wave-uniform: only a map's last column tile has lanes outside it
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[m][q] = colvalid ? v[m][q] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += v[m][q] * v[m][q];
         s += __shfl_xor(s, 32, 64);              // the other 32 channels of this pixel live in the other half of the wave
         const float inv = 1.f / (sqrtf(s) + 1e-10f);
         const bool own = colown && (rr < 2 * PR || last_st);
         if (FEAT) {
             if (own) {
-                float* fo = p.feat_out + (int64_t)n * 64 * cplane + (int64_t)r * p.cw;     // wave-uniform
+                const int fo = r * p.cw;                                                   // wave-uniform
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) (fo + (int64_t)STEM_CH(m, q) * cplane)[lane_feat] = v[m][q] * inv;
+                    for (int q = 0; q < 16; ++q)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[m][q] * inv), rfeat, 4u * lane_feat, (int)(4u * (unsigned)(fo + STEM_CH(m, q) * cplane)), 0);
             }
         } else {
             float d = 0.f;
@@ -185,32 +232,26 @@ __global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    // separate statements: the product is rounded before the subtraction, exactly like the stored reference
-                    // tap (v * inv above), so identical images give exactly zero
                     const float ua = v[m][q] * inv;
                     const float e = ua - t[m][q];
                     d += lds[LIN_OFF + STEM_CH(m, q) + 4 * half] * e * e;
                 }
-            if (own) dsum += d;
+            asm volatile("" : "+v"(d));
+            dsum += own ? d : 0.f;
         }
         // pool: horizontal 3-max, then the vertical window carried in P
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float s1 = wave_shl1(v[m][q]);
-                const float s2 = wave_shl1(s1);
-                float hmx = fmaxf(v[m][q], s1);
-                hmx = fmaxf(hmx, s2);
-                v[m][q] = hmx;
-            }
-        if ((rr & 1) == 0) {                     // even row: closes window rr/2 - 1, opens window rr/2
+            for (int q = 0; q < 16; q += 4) hmax3_x4(v[m][q], v[m][q + 1], v[m][q + 2], v[m][q + 3]);
+        if (EVEN) {                              // closes window rr/2 - 1, opens window rr/2
             if (rr > 0) {
+                float E[2][16];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) P[m][q] = fmaxf(P[m][q], v[m][q]);
-                emit((r0 >> 1) + (rr >> 1) - 1);
+                    for (int q = 0; q < 16; ++q) E[m][q] = vmax(P[m][q], v[m][q]);
+                emit(E, (r0 >> 1) + (rr >> 1) - 1);
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -220,11 +261,17 @@ __global__ __launch_bounds__(64) void lpips_stem_kernel(StemParams p) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) P[m][q] = fmaxf(P[m][q], v[m][q]);
+                for (int q = 0; q < 16; ++q) P[m][q] = vmax(P[m][q], v[m][q]);
         }
+    };
+    int r = r0;
+    for (; r < r_end; r += 2) {                  // (no branch inside the pair: a conditional odd row brings the moves back at its join)
+        row(r, std::true_type{});
+        row(r + 1, std::false_type{});
     }
+    if (r == r_end) row(r, std::true_type{});
     // ceil_mode: a map with an even number of rows ends on a two-row window
-    if ((r_end - r0) & 1) emit((r0 >> 1) + ((r_end - r0) >> 1));
+    if ((r_end - r0) & 1) emit(P, (r0 >> 1) + ((r_end - r0) >> 1));
 
     if (!FEAT) {
         dsum = wave_sum(dsum);
@@ -263,7 +310,7 @@ extern "C" int mgf_lpips_stem_f32(float* pooled, const float* x, const float* w,
     p.strips = (int)mgf_cdiv(p.ph, PR);
     const int64_t per_sample = (int64_t)p.tiles_x * p.strips;
     MGF_REQUIRE(per_sample <= STEM_RED && per_sample * n <= INT32_MAX, MGF_ETOOBIG, "lpips_stem: image too large (%d x %d)", h, w_in);
-    MGF_REQUIRE((int64_t)64 * p.ch * p.cw < (1LL << 31), MGF_ETOOBIG, "lpips_stem: image too large (%d x %d)", h, w_in);
+    MGF_REQUIRE((int64_t)64 * p.ch * p.cw < (1LL << 30), MGF_ETOOBIG, "lpips_stem: image too large (%d x %d)", h, w_in);
     hipStream_t stq = (hipStream_t)stream;
     p.xcd_per = (int)mgf_cdiv(per_sample * n, 8);
     const dim3 grid((unsigned)(p.xcd_per * 8));
