@@ -95,7 +95,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STEM_WAVES, 
         koff[kk] = k < 27 ? dy * SLOT + ci * CH_STRIDE + (dx == 1 ? ODD_OFF : 0) + l31 + (dx == 2 ? 1 : 0) : ONE_A;
     }
     if (lane == 0) { lds[ONE_A] = 1.0f; lds[ONE_B] = 1.0f; }
-    if (!FEAT) lds[LIN_OFF + lane] = p.lin[lane];
     // Channel of accumulator register q of M tile m: m*32 + (q&3) + 8*(q>>2) + 4*half.  The first three terms are wave-uniform,
     // so every per-channel address below is a scalar base (SGPR) plus ONE per-lane 32-bit offset that carries 4*half planes.
 #define STEM_CH(m, q) ((m) * 32 + ((q) & 3) + 8 * ((q) >> 2))
@@ -147,6 +146,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STEM_WAVES, 
     const __amdgpu_buffer_rsrc_t rfeat = __builtin_amdgcn_make_buffer_rsrc(
         FEAT ? (void*)(p.feat_out + (int64_t)n * 64 * cplane) : (void*)p.feat_ref, 0, (int)(256u * (unsigned)cplane), 0x00020000);
     const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc((void*)(p.pooled + (int64_t)n * 64 * pplane), 0, (int)(256u * (unsigned)pplane), 0x00020000);
+    // Four per-lane offsets (channel & 3 folded in) x eight scalar offsets per M tile, instead of one per-lane offset x 32 scalar ones: the
+    // compiler keeps every loop-invariant scalar offset in an SGPR, and 64 of them (tap + pooled) spill into VGPR lanes -- each use then
+    // costs a v_readlane and the VALU-writes-SGPR -> VMEM wait states.
+    unsigned vfeat[4], vpool[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { vfeat[j] = 4u * (unsigned)(lane_feat + j * cplane); vpool[j] = 4u * (unsigned)(lane_pool + j * pplane); }
+
+    // The 'lin' weights of this lane's 32 channels stay in registers: read from LDS at their use they cost one exposed LDS round trip per four
+    // channels (the distance is a serial chain, the compiler places each read right in front of its first use).
+    float linr[2][16];
+    if (!FEAT) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) linr[m][q] = p.lin[STEM_CH(m, q) + 4 * half];
+    }
 
     auto emit = [&](const float (&E)[2][16], int py) {   // pooled row py <- E (lanes on even columns; windows x .. x+2 stay inside the 31 good lanes)
         const int px = (x0 >> 1) + (l31 >> 1);
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STEM_WAVES, 
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, E[m][q]), rpool, 4u * lane_pool, (int)(4u * (unsigned)(o + STEM_CH(m, q) * pplane)), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, E[m][q]), rpool, vpool[q & 3], (int)(4u * (unsigned)(o + STEM_CH(m, q & ~3) * pplane)), 0);
         }
     };
 
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STEM_WAVES, 
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
-                    t[m][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, 4u * lane_feat, (int)(4u * (unsigned)(tb + STEM_CH(m, q) * cplane)), 0));
+                    t[m][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, vfeat[q & 3], (int)(4u * (unsigned)(tb + STEM_CH(m, q & ~3) * cplane)), 0));
         }
         // conv row r: rows 2r + dy sit in slots (dy + 2 (r & 1)) & 3
         constexpr int flip = EVEN ? 0 : 2 * SLOT;
@@ -184,11 +199,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STEM_WAVES, 
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
+        float bv[14];
+#pragma unroll
+        for (int kk = 0; kk < 14; ++kk) bv[kk] = lds[koff[kk] ^ flip];
 #pragma unroll
         for (int kk = 0; kk < 14; ++kk) {
-            const float bv = lds[koff[kk] ^ flip];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], bv, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][kk], bv, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], bv[kk], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][kk], bv[kk], acc[1], 0, 0, 0);
         }
         __syncthreads();                         // (one wave per workgroup: orders the LDS reads above before the overwrites below)
         if (r < r_end) { store_row(2 * r + 3, gA); store_row(2 * r + 4, gB); }
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STEM_WAVES, 
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[m][q] * inv), rfeat, 4u * lane_feat, (int)(4u * (unsigned)(fo + STEM_CH(m, q) * cplane)), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[m][q] * inv), rfeat, vfeat[q & 3], (int)(4u * (unsigned)(fo + STEM_CH(m, q & ~3) * cplane)), 0);
             }
         } else {
             float d = 0.f;
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STEM_WAVES, 
                 for (int q = 0; q < 16; ++q) {
                     const float ua = v[m][q] * inv;
                     const float e = ua - t[m][q];
-                    d += lds[LIN_OFF + STEM_CH(m, q) + 4 * half] * e * e;
+                    d += linr[m][q] * e * e;
                 }
             asm volatile("" : "+v"(d));
             dsum += own ? d : 0.f;
