@@ -140,6 +140,12 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         c.c_begin = c.ks * p.chunks_per_split * CK;
         c.c_end = c.c_begin + p.chunks_per_split * CK;
         if (c.c_end > d.cin) c.c_end = d.cin;
+        // The item index is wave-uniform, but its divisions by run-time values are expanded on the vector ALU and everything derived from
+        // them would then live in VGPRs -- loop bounds compared per lane, and a buffer descriptor built from them costs a
+        // readfirstlane "waterfall" loop around EVERY load.  Pin the decoded fields to scalar registers here.
+        c.n = __builtin_amdgcn_readfirstlane(c.n); c.ks = __builtin_amdgcn_readfirstlane(c.ks); c.co0 = __builtin_amdgcn_readfirstlane(c.co0);
+        c.ty0 = __builtin_amdgcn_readfirstlane(c.ty0); c.tx0 = __builtin_amdgcn_readfirstlane(c.tx0);
+        c.c_begin = __builtin_amdgcn_readfirstlane(c.c_begin); c.c_end = __builtin_amdgcn_readfirstlane(c.c_end);
     };
 
     // per-lane LDS base offset of each of this wave's WN pixel groups (tile independent)
@@ -169,14 +175,20 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     // padding (also the surplus slots past the footprint, which land in the padded LDS tail).  W slot j covers float4
     // i = tid + 256*j -> (t, ch, c4).
     constexpr int XS = Slots<WM, WN>::XS, WS = Slots<WM, WN>::WS;
-    int xoff[XS];
+    // Buffer addressing (round 3): the chunk's channel / weight-row offset is wave-uniform and rides in the scalar offset operand, the
+    // per-lane part is ONE 32-bit byte offset fixed for the tile, and a padding slot carries an offset past num_records -- the load returns
+    // 0 by itself.  Flat addressing spent ~ 50 vector instructions per chunk here (64-bit address adds, clamps, the zero-select at store
+    // time), and the modulation read through a may-be-either pointer became a FLAT load, which ties every LDS wait to global memory.
+    unsigned xoff[XS];                               // byte offset inside the chunk's channel block, 0xFFFFFFF0 = zero padding
     int woff[WS], wch[WS];
-    const float* xn_l = p.x;
-    const float* scp_l = g_ones.v;                   // no modulation: multiply by a table of ones (branch-free staging)
-    int scmask_l = 2047;
+    __amdgpu_buffer_rsrc_t rx_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, -1, 0x00020000);
+    // no modulation: multiply by a table of ones (branch-free staging)
+    __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)g_ones.v, 0, -1, 0x00020000);
+    const int sc_step = p.in_scale ? 4 : 0;          // bytes per channel in the modulation vector (the ones table is read at [0, CK))
     auto setup_slots = [&](const TileCtx& c) {
-        xn_l = p.x + (int64_t)c.n * d.cin * plane;
-        if (p.in_scale) { scp_l = p.in_scale + (int64_t)c.n * d.cin; scmask_l = ~0; }
+        rx_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)c.n * d.cin * plane), 0, (int)(4u * (unsigned)(d.cin * plane)), 0x00020000);
+        if (p.in_scale) rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in_scale + (int64_t)c.n * d.cin), 0, -1, 0x00020000);
 #pragma unroll
         for (int j = 0; j < WS; ++j) {
             int i = tid + 256 * j;
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         for (int j = 0; j < XS; ++j) {
             const int i = tid + 256 * j;
             const int iy = iy0 + r, ix = ix0 + q;
-            xoff[j] = (i < xs_floats && iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) ? ch * plane + iy * d.in_w + ix : -1;
+            xoff[j] = (i < xs_floats && iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) ? 4u * (unsigned)(ch * plane + iy * d.in_w + ix) : 0xFFFFFFF0u;
             q += dq; r += dr;
             if (q >= p.fw) { q -= p.fw; ++r; }
             if (r >= p.fh) { r -= p.fh; ++ch; }
@@ -210,25 +222,18 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     // instruction that consumes a loaded value -- and hence no s_waitcnt vmcnt -- sits between the loads and the MFMA phase.
     // The style modulation s[ci] is applied to the weight rows (the reference's w * s, networks.py:289) at store time.
     auto load_chunk = [&](int c0) {
-        const float* xc = xn_l + (int64_t)c0 * plane;
-        const float* wc = p.wp + (int64_t)c0 * d.cout_pad;
-#if defined(MGF_EXP) && (MGF_EXP == 4 || MGF_EXP == 6)      // experiment: no activation loads (everything else as is)
+        const int xso = (int)(4u * (unsigned)(c0 * plane)), wso = (int)(4u * (unsigned)(c0 * d.cout_pad)), sso = c0 * sc_step;
 #pragma unroll
-        for (int j = 0; j < XS; ++j) xr[j] = (float)xoff[j];
-        (void)xc;
-#else
-#pragma unroll
-        for (int j = 0; j < XS; ++j) xr[j] = xc[xoff[j] > 0 ? xoff[j] : 0];
-#endif
+        for (int j = 0; j < XS; ++j) xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_l, xoff[j], xso, 0));
 #pragma unroll
         for (int j = 0; j < WS; ++j) {
-            wr[j] = *reinterpret_cast<const float4*>(wc + woff[j]);
-            wsc[j] = scp_l[(c0 + wch[j]) & scmask_l];
+            wr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw_l, 4u * (unsigned)woff[j], wso, 0));
+            wsc[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_l, 4u * (unsigned)wch[j], sso, 0));
         }
     };
-    auto store_chunk = [&](float* buf) {              // registers -> LDS, branch-free (padded regions)
+    auto store_chunk = [&](float* buf) {              // registers -> LDS, branch-free (padded regions arrive as zeros)
 #pragma unroll
-        for (int j = 0; j < XS; ++j) buf[tid + 256 * j] = xoff[j] >= 0 ? xr[j] : 0.f;
+        for (int j = 0; j < XS; ++j) buf[tid + 256 * j] = xr[j];
         float* Wd = buf + xs_region;
 #pragma unroll
         for (int j = 0; j < WS; ++j) {
@@ -959,7 +964,9 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     MGF_REQUIRE(d.ngroups == 1 || d.ngroups == 4, MGF_EUNSUPPORTED, "conv_taps: ngroups must be 1 or 4");
     MGF_REQUIRE(d.istride >= 1 && d.ostride >= 1 && d.tile_h >= 1 && d.tile_w >= 1, MGF_EINVAL, "conv_taps: bad strides/tile");
     MGF_REQUIRE((int64_t)d.cin * d.in_h * d.in_w * d.n <= INT32_MAX, MGF_ETOOBIG, "conv_taps: input too large");
-    MGF_REQUIRE((int64_t)MGF_MAX_TAPS * d.cin * d.cout_pad <= INT32_MAX, MGF_ETOOBIG, "conv_taps: weight image too large");
+    MGF_REQUIRE((int64_t)MGF_MAX_TAPS * d.cin * d.cout_pad < (1LL << 30), MGF_ETOOBIG, "conv_taps: weight image too large");
+    // (the staging path addresses one sample's input and the weight image with 32-bit BYTE offsets)
+    MGF_REQUIRE((int64_t)d.cin * d.in_h * d.in_w < (1LL << 30), MGF_ETOOBIG, "conv_taps: one sample's input must stay below 4 GiB");
     MGF_REQUIRE(d.y_pitch >= d.out_w && d.y_plane >= (int64_t)d.out_h * d.y_pitch, MGF_EINVAL, "conv_taps: output strides too small");
     if (d.rgb_out) {
         MGF_REQUIRE(d.rgb_w && d.rgb_channels >= 1 && d.rgb_channels <= 4, MGF_EINVAL, "conv_taps: fused projection needs rgb_w and 1..4 channels");
