@@ -73,21 +73,22 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
     const int64_t i = (int64_t)blk * PXB + px;
     const bool valid = i < hw;
     const int64_t pp = valid ? i : hw - 1;
-    const float* a = f0 + (int64_t)nn * c * hw + pp;
+    // Buffer addressing: a thread's channels are G planes apart, so the channel part of every address is a wave-uniform scalar offset
+    // (j * G * hw) on ONE per-lane offset (grp * hw + pixel); a channel past c gets an offset beyond num_records and reads 0.  With flat
+    // addresses each of the 2 * CPT loads carried a 64-bit multiply-add (quarter-rate integer multiplies) and its own exec-mask branch.
+    const unsigned plane_bytes = 4u * (unsigned)hw;                                   // host: c * hw * 4 < 2^32
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(f0 + (int64_t)nn * c * hw), 0, (int)((unsigned)c * plane_bytes), 0x00020000);
+    const unsigned vo = (unsigned)grp * plane_bytes + 4u * (unsigned)pp;
     float u[CPT], v[UNIT_OUT ? 1 : CPT];
     float na = 0.f;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-        const int k = grp + j * G;
-        u[j] = k < c ? a[(int64_t)k * hw] : 0.f;
-    }
+    for (int j = 0; j < CPT; ++j)
+        u[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, grp + j * G < c ? vo : 0xFFFFFFF0u, (int)((unsigned)(j * G) * plane_bytes), 0));
     if (!UNIT_OUT) {                    // the reference taps are requested in the same burst: one memory round trip per workgroup
-        const float* b = f1u + (int64_t)nn * f1_stride + pp;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(f1u + (int64_t)nn * f1_stride), 0, (int)((unsigned)c * plane_bytes), 0x00020000);
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int k = grp + j * G;
-            v[j] = k < c ? b[(int64_t)k * hw] : 0.f;
-        }
+        for (int j = 0; j < CPT; ++j)
+            v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, grp + j * G < c ? vo : 0xFFFFFFF0u, (int)((unsigned)(j * G) * plane_bytes), 0));
     }
 #pragma unroll
     for (int j = 0; j < CPT; ++j) na += u[j] * u[j];
@@ -98,27 +99,25 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(float* scratch, float*
     for (int g = 0; g < G; ++g) na += red[g][px];
     const float ia = 1.f / (sqrtf(na) + 1e-10f);
     if (UNIT_OUT) {
-        float* o = unit_out + (int64_t)nn * c * hw + pp;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(unit_out + (int64_t)nn * c * hw), 0, (int)((unsigned)c * plane_bytes), 0x00020000);
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int k = grp + j * G;
-            if (valid && k < c) o[(int64_t)k * hw] = u[j] * ia;
-        }
+        for (int j = 0; j < CPT; ++j)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, u[j] * ia), ro, (valid && grp + j * G < c) ? vo : 0xFFFFFFF0u,
+                                                  (int)((unsigned)(j * G) * plane_bytes), 0);
         return;
     }
     float d = 0.f, nb = 0.f, nc = 0.f;
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)lin, 0, 4 * c, 0x00020000);
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        const int k = grp + j * G;
-        if (k < c) {
-            // separate statements: the product is rounded before the subtraction (build uses -ffp-contract=on) exactly like the
-            // stored reference taps (u * ia above), so identical images give exactly zero
-            const float ua = u[j] * ia;
-            const float e = ua - v[UNIT_OUT ? 0 : j];
-            const float l = lin[k];
-            d += l * e * e;
-            if (STATS) { nb += l * u[j] * u[j]; nc += l * v[UNIT_OUT ? 0 : j] * u[j]; }
-        }
+        // (no `k < c` branch: a channel past c arrived as u = v = 0 and its `lin` read is out of range, i.e. 0 as well)
+        // separate statements: the product is rounded before the subtraction (build uses -ffp-contract=on) exactly like the
+        // stored reference taps (u * ia above), so identical images give exactly zero
+        const float ua = u[j] * ia;
+        const float e = ua - v[UNIT_OUT ? 0 : j];
+        const float l = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, 4u * (unsigned)grp, 4 * j * G, 0));
+        d += l * e * e;
+        if (STATS) { nb += l * u[j] * u[j]; nc += l * v[UNIT_OUT ? 0 : j] * u[j]; }
     }
     // STATS (gradient mode): A = sum f0^2, B = sum lin f0^2, C = sum lin u1 f0 per pixel -> [n][3][hw]; the backward
     // (mgf_lpips_layer_bwd_relu_stats_f32) then skips its own sweep over both maps for them.  Formed beside the distance (same operands, two
@@ -154,6 +153,7 @@ int launch_lpips_layer(float* scratch, float* unit_out, const float* f0, const f
     MGF_REQUIRE(grid64 <= RED_BLOCKS, MGF_ETOOBIG, "lpips_layer: %lld pixels per sample need %lld scratch floats (have %d per sample)",
                 (long long)hw, (long long)grid64, RED_BLOCKS);
     MGF_REQUIRE(c <= 512, MGF_EUNSUPPORTED, "lpips_layer: at most 512 channels per tap (got %d)", c);
+    MGF_REQUIRE((int64_t)c * hw < (1LL << 30), MGF_ETOOBIG, "lpips_layer: one sample's tap must stay below 4 GiB");
     MGF_REQUIRE(grid64 * n <= INT32_MAX - 8, MGF_ETOOBIG, "lpips_layer: too many workgroups");
     const int xcd_per = (int)mgf_cdiv(grid64 * n, 8);
     const dim3 grid((unsigned)(xcd_per * 8));
