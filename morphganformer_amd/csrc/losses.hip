@@ -143,12 +143,12 @@ int launch_lpips_layer(float* scratch, float* unit_out, const float* f0, const f
                        int64_t f1_stride, hipStream_t st, int* grid_out, float* stats = nullptr) {
     // 64 pixels per workgroup (256-byte segments) whenever that still yields >= 4 workgroups per CU, 16 for the small deep taps
     static const int pxb_env = [] { const char* e = getenv("MGF_LPIPS_PXB"); return e ? atoi(e) : 0; }();      // tuning hook: 16 | 32 | 64
-    // (64-pixel blocks only up to 128 channels = 32 values per thread: with 64 values per thread the 256-channel tap at 127^2 ran at
-    // 1.6 TB/s, 2.35 TB/s on 16-pixel blocks -- tools/lpips_layer_micro.py)
-    // (32-pixel blocks for the 256-channel tap: 151 vs 176 us at 25 x 127^2; slower than 16 on the 384 / 512-channel taps at 63^2)
+    // (re-tuned on buffer addressing, 32 x {128 @ 255^2, 256 @ 127^2, 384 @ 63^2, 512 @ 63^2}, us for 64 / 32 / 16-pixel blocks:
+    // 264 / 306 / 386, 145 / 155 / 195, 100 / 60 / 58, 126 / 70 / 74 -- tools/lpips_layer_micro.py; with flat addressing 64 values per thread
+    // had been the slow case and the 256-channel tap ran on 32-pixel blocks)
     const int pxb = pxb_env ? pxb_env
-                  : (c <= 128 && (hw >= 65536 || (int64_t)n * mgf_cdiv(hw, 64) >= 1024)) ? 64
-                  : (c > 128 && c <= 256 && (int64_t)n * mgf_cdiv(hw, 32) >= 1024) ? 32 : 16;
+                  : (c <= 256 && (hw >= 65536 || (int64_t)n * mgf_cdiv(hw, 64) >= 1024)) ? 64
+                  : (c > 384 && (int64_t)n * mgf_cdiv(hw, 32) >= 1024) ? 32 : 16;
     const int64_t grid64 = mgf_cdiv(hw, pxb);
     MGF_REQUIRE(grid64 <= RED_BLOCKS, MGF_ETOOBIG, "lpips_layer: %lld pixels per sample need %lld scratch floats (have %d per sample)",
                 (long long)hw, (long long)grid64, RED_BLOCKS);

@@ -58,15 +58,24 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
     const int p0 = (pt * WPX + (WK > 1 ? 0 : wv / WCO)) * 128;
     if (p0 >= p.hw || co0 >= p.cout) return;                       // wave-uniform (workgroup-uniform with WK > 1: its barrier is safe)
 
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.cin * p.hw), 0, p.cin * p.hw * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.cin * p.cout_pad * 4, 0x00020000);
     // the style multiplies the WEIGHT operand (one dword per lane and k-step, next to the weight's own): w[ci][co] s[n][ci]
     const bool has_s = p.in_scale != nullptr;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(has_s ? p.in_scale + (int64_t)n * p.cin : p.x), 0, has_s ? p.cin * 4 : 0, 0x00020000);
-    // the channel part of every address rides in the VECTOR offset: the range check of a raw buffer access ignores the scalar offset
+    // The channel part of every address rides in the SCALAR offset (no vector add per load).  A raw buffer access range-checks only its
+    // vector offset, so a k-step past cin -- the tail of the last group -- switches to a descriptor with zero records and reads 0.
+    // (an odd cin ends on a k-step whose second channel does not exist: a descriptor that ends after ONE plane / weight row / style value
+    // rejects exactly the lanes of the upper half, whose vector offsets start one plane / row / value in.  Only num_records differs
+    // between the three cases, so the choice is one scalar select per operand.)
+    const float* xbase = p.x + (int64_t)n * p.cin * p.hw;
+    const float* sbase = has_s ? p.in_scale + (int64_t)n * p.cin : p.x;
     const unsigned xo = (unsigned)(half * p.hw + p0 + (VEC ? 4 * l31 : l31)) * 4u;
     const unsigned wo = (unsigned)(half * p.cout_pad + co0 + l31) * 4u;
+    const unsigned so = (unsigned)half * 4u;
     const unsigned xstep = (unsigned)p.hw * 8u, wstep = (unsigned)p.cout_pad * 8u;      // one k-step = 2 channels
+    unsigned xoj[4], woc[CB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xoj[j] = xo + 128u * j;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) woc[cb] = wo + 128u * cb;
 
     f32x16 acc[CB][4];
 #pragma unroll
@@ -76,49 +85,53 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cb][j][r] = 0.f;
 
-    float Ba[PWKU][4], Aa[PWKU][CB], Bb[PWKU][4], Ab[PWKU][CB];
-    auto load = [&](float (&B)[PWKU][4], float (&A)[PWKU][CB], int it) {
+    // S: the style of a k-step's two channels, multiplied into the weight operand when it is CONSUMED: multiplied where it is loaded, every
+    // group's loads ended in an s_waitcnt vmcnt(0) and the next group could not be in flight behind the MFMAs
+    float Ba[PWKU][4], Aa[PWKU][CB], Sa[PWKU], Bb[PWKU][4], Ab[PWKU][CB], Sb[PWKU];
+    auto load = [&](float (&B)[PWKU][4], float (&A)[PWKU][CB], float (&S)[PWKU], int it) {
 #pragma unroll
         for (int ks = 0; ks < PWKU; ++ks) {
-            const unsigned xv = xo + (unsigned)(it * PWKU + ks) * xstep, wvo = wo + (unsigned)(it * PWKU + ks) * wstep;
+            const int kk = it * PWKU + ks;                                   // wave-uniform
+            const bool live = 2 * kk + 2 <= p.cin, tail = 2 * kk + 1 == p.cin;
+            const __amdgpu_buffer_rsrc_t rxk = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, live ? p.cin * p.hw * 4 : (tail ? p.hw * 4 : 0), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rwk = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, live ? p.cin * p.cout_pad * 4 : (tail ? p.cout_pad * 4 : 0), 0x00020000);
+            const int xs = (int)((unsigned)kk * xstep), ws = (int)((unsigned)kk * wstep);
             if (VEC) {
-                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, xv, 0, 0));
+                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rxk, xo, xs, 0));
                 B[ks][0] = v.x; B[ks][1] = v.y; B[ks][2] = v.z; B[ks][3] = v.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) B[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xv + 128u * j, 0, 0));
+                for (int j = 0; j < 4; ++j) B[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxk, xoj[j], xs, 0));
             }
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) A[ks][cb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, wvo + 128u * cb, 0, 0));
-            if (has_s) {
-                const float sv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)((it * PWKU + ks) * 2 + half) * 4u, 0, 0));
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) A[ks][cb] *= sv;
-            }
+            for (int cb = 0; cb < CB; ++cb) A[ks][cb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwk, woc[cb], ws, 0));
+            if (has_s) S[ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, live ? p.cin * 4 : (tail ? 4 : 0), 0x00020000), so, kk * 8, 0));
         }
     };
-    auto mm = [&](const float (&B)[PWKU][4], const float (&A)[PWKU][CB]) {
+    auto mm = [&](const float (&B)[PWKU][4], const float (&A)[PWKU][CB], const float (&S)[PWKU]) {
 #pragma unroll
         for (int ks = 0; ks < PWKU; ++ks)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
+            for (int cb = 0; cb < CB; ++cb) {
+                const float a = has_s ? A[ks][cb] * S[ks] : A[ks][cb];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[cb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[ks][cb], B[ks][j], acc[cb][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[cb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B[ks][j], acc[cb][j], 0, 0, 0);
+            }
     };
     int nit = (p.cin + 2 * PWKU - 1) / (2 * PWKU), it0 = 0;
     // (an EVEN number of groups per wave: the loop below consumes them in pairs, and the odd one out would be the next wave's first;
     // groups past cin read zeros)
     if (WK > 1) { const int per = 2 * ((nit + 2 * WK - 1) / (2 * WK)); it0 = wv * per; nit = it0 + per; }
     // (scheduling fences: left alone, the compiler sinks each load group to just above its first use and waits for it there)
-    load(Ba, Aa, it0);
+    load(Ba, Aa, Sa, it0);
     for (int it = it0; it < nit; it += 2) {
-        load(Bb, Ab, it + 1);
+        load(Bb, Ab, Sb, it + 1);
         __builtin_amdgcn_sched_barrier(0);
-        mm(Ba, Aa);
+        mm(Ba, Aa, Sa);
         __builtin_amdgcn_sched_barrier(0);
-        load(Ba, Aa, it + 2);
+        load(Ba, Aa, Sa, it + 2);
         __builtin_amdgcn_sched_barrier(0);
-        mm(Bb, Ab);
+        mm(Bb, Ab, Sb);
         __builtin_amdgcn_sched_barrier(0);
     }
 
