@@ -187,23 +187,18 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
             }
     };
 
+    // (never cleared: the first chunk's MFMAs take the constant 0 as their C operand -- 64 * CB * TB v_mov per workgroup cost as much matrix
+    // time as 4 * CB * TB MFMAs, i.e. 6 % of an 8-chunk layer and 12 % of the 2-chunk Fire layers)
     f32x16 acc[4][CB][TB];
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[b][cb][tb][r] = 0.f;
-    auto mfma_chunk = [&](const v2f (&A)[4][CB], const float (&B)[TB][2][4]) {
+    auto mfma_chunk = [&](const v2f (&A)[4][CB], const float (&B)[TB][2][4], auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                 for (int tb = 0; tb < TB; ++tb) {
-                    acc[b][cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[b][cb].x, B[tb][0][b], acc[b][cb][tb], 0, 0, 0);
+                    acc[b][cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[b][cb].x, B[tb][0][b], FIRST ? f32x16{} : acc[b][cb][tb], 0, 0, 0);
                     acc[b][cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[b][cb].y, B[tb][1][b], acc[b][cb][tb], 0, 0, 0);
                 }
     };
@@ -280,7 +275,8 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     // ---- steady state, one barrier per chunk.  body(i): request A(i+1); transform chunk i+1 (parked during body(i-1)) into the other
     // B registers; the 16 MFMAs of chunk i; park x(i+2) -- loaded during body(i-1) -- over chunk i's footprint (its transform is
     // done and every wave passed the barrier since); request x(i+3). ----
-    auto body = [&](int i, v2f (&Acur)[4][CB], v2f (&Anxt)[4][CB], float (&Bcur)[TB][2][4], float (&Bnxt)[TB][2][4], float* raw_nxt, float* raw_park) {
+    auto body = [&](int i, v2f (&Acur)[4][CB], v2f (&Anxt)[4][CB], float (&Bcur)[TB][2][4], float (&Bnxt)[TB][2][4], float* raw_nxt, float* raw_park,
+                    auto first_tag) {
         // ONE basic block: nothing here is conditional (past the last chunk the loads go through the null resource, the transform and
         // the parking work on values nobody reads)
         // the fences keep the order written here: left alone, the scheduler hoists the parking -- and with it the wait for x(i+2),
@@ -295,7 +291,7 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         transform(Bnxt, raw_nxt);
 #endif
 #if !(MGF_W3X & 1)
-        mfma_chunk(Acur, Bcur);
+        mfma_chunk(Acur, Bcur, first_tag);
 #endif
         __builtin_amdgcn_sched_barrier(0);
 #if !(MGF_W3X & 4)
@@ -307,9 +303,11 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         __syncthreads();
 #endif
     };
-    for (int it = 0; it < nchunks; it += 2) {
-        body(it, A0, A1, B0, B1, raw1, raw0);
-        if (it + 1 < nchunks) body(it + 1, A1, A0, B1, B0, raw0, raw1);
+    body(0, A0, A1, B0, B1, raw1, raw0, std::true_type{});
+    if (1 < nchunks) body(1, A1, A0, B1, B0, raw0, raw1, std::false_type{});
+    for (int it = 2; it < nchunks; it += 2) {
+        body(it, A0, A1, B0, B1, raw1, raw0, std::false_type{});
+        if (it + 1 < nchunks) body(it + 1, A1, A0, B1, B0, raw0, raw1, std::false_type{});
     }
 
 #if MGF_W3X & 32
@@ -844,10 +842,6 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             }
         }
 #endif
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
         const int oy = oy0 + 2 * ty + orow, ox = ox0 + 2 * tx + (RGB ? blk : 0);
         const bool ok_px = oy < p.h && ox < p.w;
         if (RGB) {
@@ -978,7 +972,9 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             transform(B[(c + 1) & 1], ((c + 1) & 1) ? raw1 : raw0);          // chunk c + 1 (of the next tile when c is the last)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[c][b].x, B[c & 1][0][b], acc[b], 0, 0, 0);
+                // (a tile's first MFMA per accumulator takes the constant 0 as its C operand: clearing 64 accumulator registers per tile with
+                // v_mov costs as much matrix time as four of the tile's 64 MFMAs)
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[c][b].x, B[c & 1][0][b], c == 0 ? f32x16{} : acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[c][b].y, B[c & 1][1][b], acc[b], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
