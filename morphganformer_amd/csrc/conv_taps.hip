@@ -843,40 +843,38 @@ extern "C" int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs) {
 
 // Last row and last column of the stride-2 transposed 3x3 conv output t[2h+1][2w+1] (t[2i+kh][2j+kw] += w[kh][kw] x[i][j]): the
 // 4*in + 1 positions that do not belong to the in x in grid of 2x2 output quads the MFMA kernel tiles exactly.  The last column only
-// sees the taps kw = 2 (input column w-1), the last row only kh = 2 (input row h-1), so each part is a small GEMM
-//     out[pos][co] = sum_ci sum_{k<3} W[tap_k][ci][co] * X_k[ci][pos]          (X_k = the input sample tap k reads, or 0)
-// done on the VALU: workgroup = 16 positions x 64 output channels, K walked in chunks of 16 input channels staged in LDS (weights
-// coalesced along cout, the style modulation folded into the staged activations).
-constexpr int TB_POS = 16, TB_CK = 32;
+// sees the taps kw = 2 (input column w-1), the last row only kh = 2 (input row h-1): along its part, output position q = 2i gets
+// W[k=0] x[i] + W[k=2] x[i-1] and q = 2i + 1 gets W[k=1] x[i] -- two small GEMMs over the input's border line.
+// Round 3: on the matrix cores (the VALU version read 15 LDS words per 12 FMAs, multiplied half of its taps by zero and ran at a tenth of
+// what the layer's flops need: 0.94 ms per iteration for 2 % of the transposed convs' work).  A workgroup owns 64 consecutive positions
+// (32 even + 32 odd) x 64 output channels; K is walked in chunks of 32 input channels staged in LDS (weights coalesced along cout, the
+// border line -- 33 input samples per channel -- with the style folded in).  Waves 0 / 1: the even positions, one 32-channel block each,
+// k-step = (channel, tap 0 | tap 2 by lane half); wave 2: the odd positions, both channel blocks, k-step = channel pair; wave 3 only
+// stages.  32 MFMAs per wave and chunk in all three.
+constexpr int TB_POS = 64, TB_CK = 32, TB_LINE = TB_POS / 2 + 1, TB_LP = TB_LINE + 1;
 __global__ __launch_bounds__(256) void tconv_border_kernel(float* t, const float* x, const float* wp, const float* in_scale,
                                                            const float* out_scale, int cin, int h, int w, int cout, int cout_pad,
                                                            int64_t pitch, int64_t plane, int64_t batch, int64_t os_stride, int col_groups) {
     __shared__ float Ws[3][TB_CK][64];
-    __shared__ float Xs[TB_CK][3][TB_POS];
+    __shared__ float Xl[TB_CK][TB_LP];                                  // Xl[ci][jj] = s[ci] x[ci][i0 - 1 + jj] along the border line, 0 outside it
     const int tid = threadIdx.x, n = blockIdx.z, co0 = blockIdx.y * 64;
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool col = (int)blockIdx.x < col_groups;                      // column part (ox = 2w) or row part (oy = 2h)
     const int p0 = (col ? blockIdx.x : blockIdx.x - col_groups) * TB_POS;
     const int npos = col ? 2 * h + 1 : 2 * w;
+    const int lim = col ? h : w;
     const int tap0 = col ? 2 : 6, tapstep = col ? 3 : 1;               // packed tap index of k: (kh = k, kw = 2) or (kh = 2, kw = k)
     const float* xn = x + (int64_t)n * cin * h * w;
     const int64_t hw = (int64_t)h * w;
-    // staging role of this thread for X: (ci, k, pos) = 768 entries / 256 threads = 3 each; the source offset (or -1) is fixed
-    int xsrc[3];
+    // staging role of this thread for the line: entries (ci, jj) = 32 x 33 = 1056 over 256 threads; the source offset (or -1) is fixed
+    constexpr int XR = (TB_CK * TB_LINE + 255) / 256, WR = 3 * TB_CK * 64 / 256;
+    int xsrc[XR];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int e = tid + 256 * r, pos = e % TB_POS, k = (e / TB_POS) % 3;
-        const int q = p0 + pos;                                         // output coordinate along the part
-        int src = -1;
-        if (q < npos) {
-            const int i2 = q - k;                                       // q = 2*i + k
-            const int lim = col ? h : w;
-            if (i2 >= 0 && !(i2 & 1) && (i2 >> 1) < lim) src = col ? (i2 >> 1) * w + (w - 1) : (h - 1) * w + (i2 >> 1);
-        }
-        xsrc[r] = src;
+    for (int r = 0; r < XR; ++r) {
+        const int e = tid + 256 * r, jj = e % TB_LINE;
+        const int i = p0 / 2 - 1 + jj;
+        xsrc[r] = (e < TB_CK * TB_LINE && i >= 0 && i < lim) ? (col ? i * w + (w - 1) : (h - 1) * w + i) : -1;
     }
-    const int cl = tid & 63, pg = tid >> 6;                             // output channel lane, group of 4 positions
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    constexpr int WR = 3 * TB_CK * 64 / 256, XR = 3 * TB_CK * TB_POS / 256;
     float wreg[WR], xreg[XR];
     auto request = [&](int c0) {                                       // global -> registers for one K chunk (loads only)
 #pragma unroll
@@ -887,11 +885,16 @@ __global__ __launch_bounds__(256) void tconv_border_kernel(float* t, const float
         }
 #pragma unroll
         for (int r = 0; r < XR; ++r) {
-            const int e = tid + 256 * r, ci = e / (3 * TB_POS);
+            const int e = tid + 256 * r, ci = e / TB_LINE;
             const int cg = c0 + ci < cin ? c0 + ci : cin - 1;
-            xreg[r] = xn[cg * hw + (xsrc[r % 3] >= 0 ? xsrc[r % 3] : 0)] * (in_scale ? in_scale[(int64_t)n * cin + cg] : 1.0f);
+            xreg[r] = xn[cg * hw + (xsrc[r] >= 0 ? xsrc[r] : 0)] * (in_scale ? in_scale[(int64_t)n * cin + cg] : 1.0f);
         }
     };
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
     request(0);
     for (int c0 = 0; c0 < cin; c0 += TB_CK) {
         __syncthreads();
@@ -902,30 +905,39 @@ __global__ __launch_bounds__(256) void tconv_border_kernel(float* t, const float
         }
 #pragma unroll
         for (int r = 0; r < XR; ++r) {
-            const int e = tid + 256 * r, pos = e % TB_POS, k = (e / TB_POS) % 3, ci = e / (3 * TB_POS);
-            Xs[ci][k][pos] = (c0 + ci < cin && xsrc[r % 3] >= 0) ? xreg[r] : 0.f;
+            const int e = tid + 256 * r, jj = e % TB_LINE, ci = e / TB_LINE;
+            if (e < TB_CK * TB_LINE) Xl[ci][jj] = (c0 + ci < cin && xsrc[r] >= 0) ? xreg[r] : 0.f;
         }
         __syncthreads();
-        if (c0 + TB_CK < cin) request(c0 + TB_CK);                      // next chunk's loads fly during the FMAs below
+        if (c0 + TB_CK < cin) request(c0 + TB_CK);                      // next chunk's loads fly during the MFMAs below
+        if (wv < 2) {                                                  // even positions q = p0 + 2 j: tap 0 reads x[i], tap 2 reads x[i - 1]
 #pragma unroll 8
-        for (int ci = 0; ci < TB_CK; ++ci) {
-            const float w0 = Ws[0][ci][cl], w1 = Ws[1][ci][cl], w2 = Ws[2][ci][cl];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int pos = pg * 4 + j;
-                acc[j] += w0 * Xs[ci][0][pos] + w1 * Xs[ci][1][pos] + w2 * Xs[ci][2][pos];
+            for (int ci = 0; ci < TB_CK; ++ci)
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[2 * half][ci][wv * 32 + l31], Xl[ci][l31 + 1 - half], acc[0], 0, 0, 0);
+        } else if (wv == 2) {                                          // odd positions q = p0 + 2 j + 1: tap 1 reads x[i]
+#pragma unroll 8
+            for (int cp = 0; cp < TB_CK / 2; ++cp) {
+                const int ci = 2 * cp + half;
+                const float bv = Xl[ci][l31 + 1];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[1][ci][l31], bv, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[1][ci][32 + l31], bv, acc[1], 0, 0, 0);
             }
         }
     }
-    const int co = co0 + cl;
-    if (co >= cout) return;
-    const float os = out_scale ? out_scale[(int64_t)n * os_stride + co] : 1.0f;
+    if (wv > 2) return;
+    const int q = p0 + 2 * l31 + (wv == 2 ? 1 : 0);
+    if (q >= npos) return;
+    const int oy = col ? q : 2 * h, ox = col ? 2 * w : q;
+    float* tn = t + (int64_t)n * batch + (int64_t)oy * pitch + ox;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = p0 + pg * 4 + j;
-        if (q >= npos) continue;
-        const int oy = col ? q : 2 * h, ox = col ? 2 * w : q;
-        t[(int64_t)n * batch + (int64_t)co * plane + (int64_t)oy * pitch + ox] = acc[j] * os;
+    for (int m = 0; m < 2; ++m) {
+        if (m == 1 && wv != 2) break;
+        const int cb = wv == 2 ? m : wv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < cout) tn[(int64_t)co * plane] = acc[m][r] * (out_scale ? out_scale[(int64_t)n * os_stride + co] : 1.0f);
+        }
     }
 }
 

@@ -1,4 +1,4 @@
-"""Border kernel of the transposed conv on the generator's up-layers (GPU): python tools/border_micro.py   (MGF_BORDER_MFMA=0: the VALU form)"""
+"""Border kernel of the transposed conv on the generator's up-layers (GPU): python tools/border_micro.py"""
 import os, sys, math, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from morphganformer_amd import _lib, conv as cv
