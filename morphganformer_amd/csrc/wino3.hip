@@ -783,27 +783,28 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     const float slope = !do_ep ? 1.f : (p.ep.act == MGF_ACT_LRELU ? p.ep.alpha : (p.ep.act == MGF_ACT_RELU ? 0.f : 1.f));
     const float gain = do_ep ? p.ep.gain : 1.f;
     const float ns = (do_ep && p.ep.noise) ? (p.ep.noise_strength ? *p.ep.noise_strength : 1.f) : 0.f;
-    // (the wave's own unit -- blk = a & 1 -- is a compile-time value of the two instantiations behind one wave-uniform branch: selected at
-    // run time it was 32 bit-select instructions per tile)
-    auto row_reduce = [&](auto own_unit, float (&own)[NV]) {
-        constexpr int OWN = decltype(own_unit)::value;
-        // unit 0 goes to slot w0s, unit 1 to slot w1s; the own unit is written too where another wave needs it (waves 1 and 2).  Every value
+    // (the wave index a -- and with it the own unit a & 1 and the two exchange slots -- is a compile-time value of four instantiations behind
+    // one wave-uniform switch: with run-time slots every one of the 32 values carried its own scalar branch and a recomputed LDS address,
+    // ~ 100 instructions and 64 branches per tile; now each store is `ds_write_b32 base, v offset:imm`)
+    float* const xl = xch + lane;
+    auto row_reduce = [&](auto wave_tag, float (&own)[NV]) {
+        constexpr int A = decltype(wave_tag)::value, OWN = A & 1;
+        constexpr int W0 = A == 1 ? 1 : (A == 2 ? 3 : (A == 3 ? 5 : -1)), W1 = A == 0 ? 0 : (A == 1 ? 2 : (A == 2 ? 4 : -1));
+        // unit 0 goes to slot W0, unit 1 to slot W1; the own unit is written too where another wave needs it (waves 1 and 2).  Every value
         // leaves for LDS as soon as it exists: the other unit is never held in registers (they are what bounds the prefetch ring's depth)
-        const int s_own = OWN == 0 ? w0s : w1s, s_oth = OWN == 0 ? w1s : w0s;
-        float* const d_own = xch + (s_own >= 0 ? s_own : 0) * (NV * 64) + lane;
-        float* const d_oth = xch + (s_oth >= 0 ? s_oth : 0) * (NV * 64) + lane;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
 #pragma unroll
             for (int un = 0; un < 2; ++un) {
+                constexpr int dummy = 0;
+                (void)dummy;
                 const int r = RGB ? v : un * 8 + (v >> 1);
                 const int jj = RGB ? un : (v & 1);
                 const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
                 const float val = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;       // (m3 = -M3, see transform)
-                if (un == OWN) {
-                    own[v] = val;
-                    if (s_own >= 0) d_own[v * 64] = val;
-                } else if (s_oth >= 0) d_oth[v * 64] = val;
+                if (un == OWN) own[v] = val;
+                const int slot = un == 0 ? W0 : W1;
+                if (slot >= 0) xl[slot * (NV * 64) + v * 64] = val;
             }
         }
     };
@@ -811,8 +812,12 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
         const int ox0 = ox_s + 32 * t;
         float own[NV];
 #if W3P_OWN_BRANCH
-        if (blk) row_reduce(std::integral_constant<int, 1>{}, own);
-        else row_reduce(std::integral_constant<int, 0>{}, own);
+        switch (a) {
+            case 0: row_reduce(std::integral_constant<int, 0>{}, own); break;
+            case 1: row_reduce(std::integral_constant<int, 1>{}, own); break;
+            case 2: row_reduce(std::integral_constant<int, 2>{}, own); break;
+            default: row_reduce(std::integral_constant<int, 3>{}, own); break;
+        }
 #else
         {
             float val[2][NV];
