@@ -14,6 +14,7 @@
 // an interleaving of the tile, and the accumulators of a row leave as one 16-byte store).  Loads run one group of 8 channels ahead in a
 // second register set; reads past the last channel fall outside the buffer resources and return 0, so the loop has no tail code.
 #include "mgf_common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -186,37 +187,49 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
             pvo[j] = px < p.hw ? (unsigned)(4 * half * p.hw + px) * 4u : 0xFFFFFFF0u;
         }
     }
+    // (two instantiations behind one wave-uniform branch: without a residual the loop used to issue its 64 residual loads all the same --
+    // against the zero-size resource -- and every store waited for one of them)
+    auto store_rows = [&](auto res_tag) {
+        constexpr bool RES = decltype(res_tag)::value;
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
+        for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cor = co0 + 32 * cb + (r & 3) + 8 * (r >> 2);          // row of lane half 0 (wave-uniform); half 1: + 4
-            const bool in = rows8 ? cor < p.cout : cor + 4 * half < p.cout;    // (uniform when rows8)
-            const bool any = cor < p.cout;                                      // some lane of the row is inside (uniform)
-            const __amdgpu_buffer_rsrc_t ryr = any ? ry : rnone, rrr = any ? rres : rnone, rbr = any ? rbias : rnone;
-            const int soff = cor * p.hw * 4;
-            const unsigned lane_ok = (rows8 || in) ? 0u : 0xFFFFFFF0u;         // (per-lane only for ragged channel counts)
-            const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbr, (unsigned)(4 * half) * 4u | lane_ok, cor * 4, 0));
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = acc[cb][j][r] + bv;
-                t = t > 0.f ? t : t * slope;
-                v[j] = t * gain;
-            }
-            if (VEC) {
-                const float4 q = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrr, pvo[0] | lane_ok, soff, 0));
-                const float4 o = make_float4(v[0] + q.x, v[1] + q.y, v[2] + q.z, v[3] + q.w);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), ryr, pvo[0] | lane_ok, soff, 0);
-            } else {
+            for (int r = 0; r < 16; ++r) {
+                const int cor = co0 + 32 * cb + (r & 3) + 8 * (r >> 2);          // row of lane half 0 (wave-uniform); half 1: + 4
+                const bool in = rows8 ? cor < p.cout : cor + 4 * half < p.cout;    // (uniform when rows8)
+                const bool any = cor < p.cout;                                      // some lane of the row is inside (uniform)
+                const __amdgpu_buffer_rsrc_t ryr = any ? ry : rnone, rrr = any ? rres : rnone, rbr = any ? rbias : rnone;
+                const int soff = cor * p.hw * 4;
+                const unsigned lane_ok = (rows8 || in) ? 0u : 0xFFFFFFF0u;         // (per-lane only for ragged channel counts)
+                const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbr, (unsigned)(4 * half) * 4u | lane_ok, cor * 4, 0));
+                float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float q = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrr, pvo[j] | lane_ok, soff, 0));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j] + q), ryr, pvo[j] | lane_ok, soff, 0);
+                    const float t = acc[cb][j][r] + bv;
+                    float ts = t * slope, m;                                       // slope <= 1: leaky / plain ReLU / identity = max(t, slope t)
+                    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(t), "v"(ts));      // (as an instruction: `fmaxf` adds canonicalising v_max x, x)
+                    v[j] = m * gain;
+                }
+                if (VEC) {
+                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                    if (RES) {
+                        const float4 q = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrr, pvo[0] | lane_ok, soff, 0));
+                        o = make_float4(v[0] + q.x, v[1] + q.y, v[2] + q.z, v[3] + q.w);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), ryr, pvo[0] | lane_ok, soff, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float o = v[j];
+                        if (RES) o += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrr, pvo[j] | lane_ok, soff, 0));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ryr, pvo[j] | lane_ok, soff, 0);
+                    }
                 }
             }
         }
-    }
+    };
+    if (resp) store_rows(std::true_type{});
+    else store_rows(std::false_type{});
 }
 
 // cout <= 4 (ToRGB outside the fused conv_last launch: gradient mode, odd sizes): the layer is a weighted sum of the channel rows,
@@ -365,6 +378,8 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
         MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU, MGF_EUNSUPPORTED,
                     "conv1x1: epilogue activation %d unsupported", ep->act);
         MGF_REQUIRE(!ep->noise, MGF_EUNSUPPORTED, "conv1x1: no noise input (the tap-list kernel has it)");
+        MGF_REQUIRE(ep->act != MGF_ACT_LRELU || (ep->alpha >= 0.f && ep->alpha <= 1.f), MGF_EUNSUPPORTED,
+                    "conv1x1: leaky-ReLU slope %g outside [0, 1] (the epilogue forms max(t, slope t))", (double)ep->alpha);
     }
     PwParams p;
     p.y = y; p.x = x; p.w = w; p.in_scale = in_scale; p.n = n; p.cin = cin; p.hw = hw; p.cout = cout; p.cout_pad = cout_pad;
