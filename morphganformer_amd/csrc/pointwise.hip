@@ -417,7 +417,9 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
     // 32^2 142 / 145, 512->256 at 64^2 242 / 266, 256->128 at 128^2 250 / 272, Fire expand 16->64 at 255^2 152 / 192): residency hides
     // the load latency, the operand loads are L1 hits.  MGF_PW_CB = 2 or mgf_conv1x1_force_shape(2) select the wide shape (tuning, tests).
     static const int env_cb = [] { const char* e = getenv("MGF_PW_CB"); return e ? atoi(e) : 0; }();
-    int cb = 1;
+    // (round 3, after the epilogue lost its dummy residual loads: the wide shape wins where K is at most 32 -- the Fire expand layers 16 -> 64
+    // at 255^2, 163 -> 157 us, and 32 -> 128 at 127^2, 102 -> 88 us at 32 samples -- and still loses from 48 input channels on)
+    int cb = (cin <= 32 && cout_pad % 64 == 0 && cout >= 64) ? 2 : 1;
     const int forced = g_pw_forced_cb ? g_pw_forced_cb : env_cb;
     if ((forced == 1) || (forced == 2 && cout_pad % 64 == 0)) cb = forced;
     const int cw = cout_pad / (32 * cb);                           // wave columns needed
