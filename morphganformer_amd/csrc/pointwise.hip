@@ -61,13 +61,13 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
 
     // the style multiplies the WEIGHT operand (one dword per lane and k-step, next to the weight's own): w[ci][co] s[n][ci]
     const bool has_s = p.in_scale != nullptr;
-    // The channel part of every address rides in the SCALAR offset (no vector add per load).  A raw buffer access range-checks only its
-    // vector offset, so a k-step past cin -- the tail of the last group -- switches to a descriptor with zero records and reads 0.
-    // (an odd cin ends on a k-step whose second channel does not exist: a descriptor that ends after ONE plane / weight row / style value
-    // rejects exactly the lanes of the upper half, whose vector offsets start one plane / row / value in.  Only num_records differs
-    // between the three cases, so the choice is one scalar select per operand.)
-    const float* xbase = p.x + (int64_t)n * p.cin * p.hw;
-    const float* sbase = has_s ? p.in_scale + (int64_t)n * p.cin : p.x;
+    // The channel part of every address rides in the SCALAR offset (no vector add per load).  The range check of a raw buffer access
+    // covers vector + scalar offset (tools/buffer_load_probe.hip: offset + soffset >= num_records reads 0, without 32-bit wrap -- a sentinel
+    // vector offset stays out of range), so a k-step past cin -- or the second channel of an odd cin's last k-step, whose lanes start one
+    // plane / weight row / style value further in -- reads zeros through the ordinary descriptors.
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.cin * p.hw), 0, p.cin * p.hw * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.cin * p.cout_pad * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(has_s ? p.in_scale + (int64_t)n * p.cin : p.x), 0, has_s ? p.cin * 4 : 0, 0x00020000);
     const unsigned xo = (unsigned)(half * p.hw + p0 + (VEC ? 4 * l31 : l31)) * 4u;
     const unsigned wo = (unsigned)(half * p.cout_pad + co0 + l31) * 4u;
     const unsigned so = (unsigned)half * 4u;
@@ -93,20 +93,17 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
 #pragma unroll
         for (int ks = 0; ks < PWKU; ++ks) {
             const int kk = it * PWKU + ks;                                   // wave-uniform
-            const bool live = 2 * kk + 2 <= p.cin, tail = 2 * kk + 1 == p.cin;
-            const __amdgpu_buffer_rsrc_t rxk = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, live ? p.cin * p.hw * 4 : (tail ? p.hw * 4 : 0), 0x00020000);
-            const __amdgpu_buffer_rsrc_t rwk = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, live ? p.cin * p.cout_pad * 4 : (tail ? p.cout_pad * 4 : 0), 0x00020000);
             const int xs = (int)((unsigned)kk * xstep), ws = (int)((unsigned)kk * wstep);
             if (VEC) {
-                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rxk, xo, xs, 0));
+                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo, xs, 0));
                 B[ks][0] = v.x; B[ks][1] = v.y; B[ks][2] = v.z; B[ks][3] = v.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) B[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxk, xoj[j], xs, 0));
+                for (int j = 0; j < 4; ++j) B[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoj[j], xs, 0));
             }
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) A[ks][cb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwk, woc[cb], ws, 0));
-            if (has_s) S[ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, live ? p.cin * 4 : (tail ? 4 : 0), 0x00020000), so, kk * 8, 0));
+            for (int cb = 0; cb < CB; ++cb) A[ks][cb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woc[cb], ws, 0));
+            if (has_s) S[ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, kk * 8, 0));
         }
     };
     auto mm = [&](const float (&B)[PWKU][4], const float (&A)[PWKU][CB], const float (&S)[PWKU]) {

@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     // and drain the loads issued a moment ago, i.e. expose one L2 round trip per chunk)
     const __amdgpu_buffer_rsrc_t rnull = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, 0, 0x00020000);
     // A staging slot is ONE channel: slot j = channel j / SPC of the chunk, footprint pixel tid + 256 (j % SPC).  The pixel part of the
-    // address is the same for all channels (one VGPR per pixel slot; the channel rides in the scalar offset, which the range check ignores:
-    // a pixel outside the map stays out of range) and the style of a slot is wave-uniform: a scalar load, no LDS table.
+    // address is the same for all channels (one VGPR per pixel slot; the channel rides in the scalar offset -- the range check adds the two without
+    // 32-bit wrap, so a pixel outside the map, marked by a sentinel vector offset, stays out of range) and the style of a slot is wave-uniform: a scalar load, no LDS table.
     unsigned xoff[SPC];
 #pragma unroll
     for (int s = 0; s < SPC; ++s) {

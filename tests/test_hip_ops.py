@@ -239,6 +239,9 @@ def test_conv_taps_vs_torch(n, cin, cout, res, k, stride, pad):
     (2, 512, 512, 32, 32, 512, 0, "linear", False),   # resnet skip 512 -> 512: two channel tiles, XCD order, 16-byte path
     (2, 128, 64, 64, 64, 64, 0, "lrelu", True),       # residual, aligned
     (1, 6, 40, 9, 13, 50, 7, "linear", True),         # ragged everything: cin not a multiple of 8, residual on an odd slice
+    (2, 7, 40, 9, 13, 40, 0, "lrelu", False),         # ODD cin: the last k-step has one live channel (descriptor of one plane / weight row / style value)
+    (1, 31, 64, 12, 12, 64, 0, "relu", True),         # ... on the two-blocks-per-wave shape (K <= 32, 64 output channels)
+    (1, 33, 96, 5, 7, 96, 0, "linear", False),        # ... past one load group
     (1, 2, 3, 1, 1, 3, 0, "linear", False),           # one pixel
     (2, 32, 32, 8, 8, 32, 0, "linear", False),        # split-K workgroups with fewer channel groups than waves
     (1, 72, 40, 16, 12, 40, 0, "relu", True),         # ... and with an odd number of groups per wave
@@ -317,6 +320,33 @@ def test_narrow_stride2_convs_vs_torch_and_tap_list(n, narrow, wide, h, w, monke
         assert tuple(got_t.shape) == tuple(ref_t.shape) and rel_err(got_t, ref_t) < 2e-5
         outs.append(got_t.clone())
     assert rel_err(outs[0], outs[1]) < 2e-6
+
+
+def test_conv1x1_refuses_a_leaky_slope_outside_the_unit_interval():
+    """The 1x1 epilogue forms max(t, slope t), which is leaky ReLU only for 0 <= slope <= 1: anything else is an error, not a wrong answer."""
+    from morphganformer_amd import _lib, conv as cv
+    x = torch.randn(1, 16, 8, 8, device="cuda")
+    pc = cv.pack_weights(torch.randn(32, 16, 1, 1, device="cuda"))
+    for alpha in (1.5, -0.1):
+        with pytest.raises(_lib.MgfError, match="slope"):
+            cv.conv_forward(x, pc, epilogue=_lib.make_epilogue(act="lrelu", alpha=alpha))
+    cv.conv_forward(x, pc, epilogue=_lib.make_epilogue(act="lrelu", alpha=1.0))
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 40, 72, 20, 37), (1, 33, 130, 70, 16), (1, 5, 8, 16, 129)])
+def test_tconv_non_square_and_ragged_channels_vs_torch(n, cin, cout, h, w):
+    """Transposed conv on non-square maps with channel counts that fill neither the border kernel's 64-channel tile nor its 32-channel K
+    chunk: the MFMA border kernel's row part and column part have different lengths, its last position group and channel tile are ragged."""
+    from morphganformer_amd import conv as cv
+    torch.manual_seed(cin + cout + h + w)
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9)
+    s = 1 + 0.2 * torch.randn(n, cin)
+    d = 1 + 0.2 * torch.randn(n, cout)
+    ref = torch.nn.functional.conv_transpose2d(x * s[:, :, None, None], wt.transpose(0, 1), stride=2) * d[:, :, None, None]
+    out = cv.tconv3x3s2_forward(x.cuda(), cv.pack_weights(wt.cuda()), in_scale=s.cuda(), out_scale=d.cuda())
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert rel_err(out, ref) < 2e-5
 
 
 @pytest.mark.parametrize("n,cin,cout,res", [(1, 32, 32, 16), (2, 64, 32, 33), (1, 8, 40, 4), (1, 128, 64, 64), (3, 48, 96, 40), (1, 6, 20, 130)])
