@@ -55,7 +55,8 @@ struct Wino3Params {
     int64_t y_batch;          // elements between samples of y (y may be a channel slice of a wider concat buffer; residual likewise)
     int y_choff;              // channel offset into y
     int odd;                  // h or w odd: pixel pairs are stored / loaded element-wise with bounds checks
-    int strip_len, strips_x;  // persistent form (wino3p_conv_kernel): tiles per workgroup along x, strips per tile row
+    int strip_len, strips_x;  // persistent form (wino3p_conv_kernel): tiles per workgroup, strips per tile row
+    int vert, strips_y;       // ... vert: a strip walks DOWN a 32-pixel column (strips_x = tile columns, strips_y = strips per column)
 };
 
 #ifndef MGF_W3X
@@ -621,14 +622,23 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     int b_ = blockIdx.x;
     if (p.xcd_per > 0) {
         b_ = (b_ & 7) * p.xcd_per + (b_ >> 3);
-        if (b_ >= p.n * p.strips_x * p.tiles_y * p.co_tiles) return;
+        if (b_ >= p.n * p.strips_x * p.strips_y * p.co_tiles) return;
     }
+    // Strip direction.  Horizontal (round 3, first half): the strip walks along x, its tiles re-request two of the three 128-byte lines of
+    // every footprint row one tile later -- longer than an XCD's L2 keeps anything under this kernel's traffic -- and the launch fetched
+    // 2.9 x its input (15.7 GB against 5.5 at 32 x 1024^2: it ran at the memory system's 5.3 TB/s, not at its instruction rate).
+    // Vertical: the strip walks DOWN a 32-pixel column and the strips of neighbouring columns are consecutive work items, i.e. run side
+    // by side on one XCD: the shared lines are requested by both neighbours at about the same time (one L2 miss), and what a tile
+    // re-requests later is only its two halo ROWS of six.
     const int cot = b_ % p.co_tiles; b_ /= p.co_tiles;
     const int sx = b_ % p.strips_x; b_ /= p.strips_x;
-    const int pty = b_ % p.tiles_y;
-    const int n = b_ / p.tiles_y;
-    const int co0 = cot * 32, oy0 = pty * 4, ox_s = sx * p.strip_len * 32;
-    const int ntiles = min(p.strip_len, p.tiles_x - sx * p.strip_len);
+    const int sy = b_ % p.strips_y;
+    const int n = b_ / p.strips_y;
+    const int vert = p.vert;
+    const int co0 = cot * 32;
+    const int oy_s = (vert ? sy * p.strip_len : sy) * 4, ox_s = (vert ? sx : sx * p.strip_len) * 32;
+    const int tdx = vert ? 0 : 32, tdy = vert ? 4 : 0;             // position step per tile
+    const int ntiles = vert ? min(p.strip_len, p.tiles_y - sy * p.strip_len) : min(p.strip_len, p.tiles_x - sx * p.strip_len);
     const int plane = p.h * p.w;
     const float* xn = p.x + (int64_t)n * p.cin * plane;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, W3P_TIMING_NOX ? 0 : p.cin * plane * 4, 0x00020000);       // (W3P_TIMING_NOX: timing-only build, no input traffic)
@@ -671,12 +681,9 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
 
     // ---- footprint addressing: thread = footprint pixel, channel in the scalar offset; the tile's x position enters per tile ----
     const int fr = tid / W3FW, fq = tid - fr * W3FW;
-    const int fiy = oy0 - 1 + fr;
-    const bool frow_ok = tid < FP && fiy >= 0 && fiy < p.h;
-    const int fpix0 = fiy * p.w + ox_s - 1 + fq;                   // pixel of tile 0 (may be -1: masked below)
     auto tile_voff = [&](int t) -> unsigned {
-        const int ix = ox_s + 32 * t - 1 + fq;
-        return (frow_ok && t < ntiles && ix >= 0 && ix < p.w) ? (unsigned)(fpix0 + 32 * t) * 4u : OOB;
+        const int iy = oy_s + tdy * t - 1 + fr, ix = ox_s + tdx * t - 1 + fq;
+        return (tid < FP && t < ntiles && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) ? (unsigned)(iy * p.w + ix) * 4u : OOB;
     };
     auto load_x = [&](float (&dst)[W3CK], unsigned voff, int chunk) {
 #pragma unroll
@@ -733,11 +740,12 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     // 3 .. 20 of them; the map width and every piece's first column are multiples of 4, so a piece is entirely inside the map or entirely
     // outside (the row's first tile: piece 0; its last tile: piece 5).
     unsigned lowoff[3];                                            // byte offset of piece tid + 256 j in tile 0
-    unsigned lowflag = 0;                                          // bit j: piece 0 of a row, bit 3 + j: piece 5, bit 6 + j: row outside the map
+    unsigned lowflag = 0;                                          // bit j: piece 0 of a row, bit 3 + j: piece 5
+    int lowrow[3] = {0, 0, 0};
     w3_v4i rlow = {0, 0, 0, 0}, rnz = {0, 0, 0, 0};
     if (has_low) {
         rlow = w3_make_rsrc(p.res_low + ((int64_t)n * p.cout + co0) * pl, 32u * (unsigned)pl * 4u);
-        const int m0 = (oy0 >> 1) - 1, n0 = (ox_s >> 1) - 4;
+        const int m0 = (oy_s >> 1) - 1, n0 = (ox_s >> 1) - 4;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int e = tid + 256 * j;
@@ -745,22 +753,25 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             const int r = rem / 6, c = rem - r * 6;
             const int my = m0 + r;
             lowoff[j] = (unsigned)(ch * pl + my * wl + n0 + 4 * c) * 4u;           // (may wrap below zero for piece 0 of tile 0: masked by its edge bit)
+            lowrow[j] = my;                                                        // window row of tile 0; a tile further down: + 2 t
             lowflag |= (c == 0 ? 1u : 0u) << j;
             lowflag |= (c == 5 ? 1u : 0u) << (3 + j);
-            lowflag |= ((my >= 0 && my < hl) ? 0u : 1u) << (6 + j);                // row outside the map (a flag, not a sentinel offset: -16 is a real offset here)
         }
     }
     if (has_nz) rnz = w3_make_rsrc(p.ep.noise + (int64_t)(p.ep.noise_n > 1 ? n : 0) * plane, (unsigned)plane * 4u);
     const unsigned lds_lowt = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lowt + 256 * a));    // piece 64 a of a group of 256
     const unsigned lds_nzs = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(nzs + 64 * a));
     auto issue_ep_dma = [&](int t) {
-        const int ox0 = ox_s + 32 * t;
+        const int ox0 = ox_s + tdx * t, oy0 = oy_s + tdy * t;
         if (has_low && !(W3P_ABL & 1)) {
-            // (branch-free per piece: bit j of `edge` = this lane's piece j lies left of the row's first tile or right of its last one)
-            const unsigned edge = (ox0 == 0 ? lowflag : 0u) | (ox0 + 32 == p.w ? (lowflag >> 3) : 0u) | (lowflag >> 6);
+            // (branch-free per piece: bit j of `edge` = this lane's piece j lies left of the row's first tile or right of its last one; a
+            // window row outside the map is a flag too, not a sentinel offset: -16 is a real offset here)
+            const unsigned edge = (ox0 == 0 ? lowflag : 0u) | (ox0 + 32 == p.w ? (lowflag >> 3) : 0u);
+            const unsigned step = (unsigned)((tdx >> 1) * 4 + (tdy >> 1) * wl * 4) * (unsigned)t;       // bytes the window moves per tile
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const unsigned off = ((edge >> j) & 1u) ? OOB : lowoff[j] + (unsigned)(64 * t);
+                const int my = lowrow[j] + (tdy >> 1) * t;
+                const unsigned off = (((edge >> j) & 1u) || my < 0 || my >= hl) ? OOB : lowoff[j] + step;
                 w3_dma_b128(rlow, lds_lowt + 4096u * j, off, 0u);
             }
         }
@@ -809,7 +820,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
         }
     };
     auto epilogue = [&](int t) {
-        const int ox0 = ox_s + 32 * t;
+        const int ox0 = ox_s + tdx * t, oy0 = oy_s + tdy * t;
         float own[NV];
 #if W3P_OWN_BRANCH
         switch (a) {
@@ -1058,7 +1069,7 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     p.rgb_w = rgb_w; p.rgb_bias = rgb_bias; p.rgb_out = rgb_out; p.rgb_channels = rgb_channels;
     p.res_low = res_low;
     p.y_batch = y_batch ? y_batch : (int64_t)cout * h * w; p.y_choff = y_choff; p.odd = odd;
-    p.strip_len = 0; p.strips_x = 0;
+    p.strip_len = 0; p.strips_x = 0; p.vert = 0; p.strips_y = 0;
     if (res_low) {
         MGF_REQUIRE(ep && !ep->residual && !rgb, MGF_EINVAL, "conv3x3_winograd3_up2res: needs an epilogue without a full-resolution residual");
         MGF_REQUIRE(shape == 11, MGF_EUNSUPPORTED, "conv3x3_winograd3_up2res: only the 32x32-tile shape takes the half-resolution residual");
@@ -1074,9 +1085,13 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
                          w % 32 == 0 && h % 4 == 0 && p.tiles_x % strip_len == 0 && (!rgb || cout == 32) &&
                          (force_persist || (int64_t)n * (p.tiles_x / strip_len) * p.tiles_y * p.co_tiles >= 2048);
     if (persist) {
-        p.strip_len = strip_len;
-        p.strips_x = p.tiles_x / strip_len;
-        int64_t pblocks = (int64_t)n * p.strips_x * p.tiles_y * p.co_tiles;
+        // vertical strips where the tile rows divide into whole strips (MGF_W3_VERT=0: the horizontal walk, for A/B runs)
+        static const bool vert_off = [] { const char* e = getenv("MGF_W3_VERT"); return e && e[0] == '0'; }();
+        const int vlen = std::min(p.tiles_y, strip_env > 0 ? strip_env : 32);
+        p.vert = (!vert_off && p.tiles_y % vlen == 0) ? 1 : 0;
+        if (p.vert) { p.strip_len = vlen; p.strips_x = p.tiles_x; p.strips_y = p.tiles_y / vlen; }
+        else { p.strip_len = strip_len; p.strips_x = p.tiles_x / strip_len; p.strips_y = p.tiles_y; }
+        int64_t pblocks = (int64_t)n * p.strips_x * p.strips_y * p.co_tiles;
         p.xcd_per = (int)((pblocks + 7) / 8);                      // XCD-contiguous order: channel tiles, then strips of one row, share an L2
         pblocks = (int64_t)p.xcd_per * 8;
         const size_t plds = (size_t)(2 * 4 * 256 + 6 * 16 * 64 + 3072 + 256 + 128) * sizeof(float);
