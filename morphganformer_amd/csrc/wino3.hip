@@ -815,11 +815,15 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
                 const float val = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;       // (m3 = -M3, see transform)
                 if (un == OWN) own[v] = val;
                 const int slot = un == 0 ? W0 : W1;
-                if (slot >= 0) xl[slot * (NV * 64) + v * 64] = val;
+                if (slot >= 0 && !(W3P_ABL & 64)) xl[slot * (NV * 64) + v * 64] = val;       // (W3P_ABL & 64: timing ablation, no exchange stores)
             }
         }
     };
     auto epilogue = [&](int t) {
+        if (W3P_ABL & 4) {                                         // timing ablation: no epilogue at all (one lane keeps the accumulators alive)
+            if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.f) p.y[tid] = acc[0][5];
+            return;
+        }
         const int ox0 = ox_s + tdx * t, oy0 = oy_s + tdy * t;
         float own[NV];
 #if W3P_OWN_BRANCH
@@ -894,6 +898,10 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
                 rr[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rres, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0));
         }
         __syncthreads();                                           // the exchange slots are complete (and, long since, the DMA'd operands)
+        if (W3P_ABL & 32) {                                        // timing ablation: row reduction + exchange + barrier, nothing after it
+            if (own[0] + own[NV - 1] == 12345.f) p.y[tid] = own[1];
+            return;
+        }
         const int chl = cob - co0;
         float osv[NR], bvv[NR];
 #pragma unroll
@@ -942,7 +950,8 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (int64_t)n * p.y_batch), 0, p.cout * plane * 4, 0x00020000);
 #pragma unroll
         for (int k = 0; k < NR; ++k)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vout[k]), ry, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, W3P_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vout[k]), ry, ((W3P_ABL & 128) && vout[k].x != 12345.f) ? OOB : voff,
+                                                  ((k & 3) + 8 * (k >> 2)) * plane * 4, W3P_ST_AUX);      // (W3P_ABL & 128: timing ablation, stores out of range)
     };
 
     // ---- prologue: chunks 0 and 1 of tile 0 are parked, chunks 2 .. 1 + XD wait in the register ring ----
@@ -987,7 +996,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             if (!RGB && c == 1) issue_ep_dma(t);
             transform(B[(c + 1) & 1], ((c + 1) & 1) ? raw1 : raw0);          // chunk c + 1 (of the next tile when c is the last)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < 4 && !(W3P_ABL & 8); ++b) {          // (W3P_ABL & 8: timing ablation, no matrix work)
                 // (a tile's first MFMA per accumulator takes the constant 0 as its C operand: clearing 64 accumulator registers per tile with
                 // v_mov costs as much matrix time as four of the tile's 64 MFMAs)
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[c][b].x, B[c & 1][0][b], c == 0 ? f32x16{} : acc[b], 0, 0, 0);
@@ -996,7 +1005,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             __builtin_amdgcn_sched_barrier(0);
             park_x((c & 1) ? raw1 : raw0, xq[c % XD]);                       // chunk c + 2, requested XD bodies ago
             load_ahead(xq[c % XD], c + 2 + XD);
-            __syncthreads();
+            if (!(W3P_ABL & 16)) __syncthreads();                             // (W3P_ABL & 16: timing ablation, no chunk barrier -- results wrong)
         }
         epilogue(t);
         voff_cur = voff_nxt;
