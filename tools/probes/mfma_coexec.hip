@@ -23,7 +23,6 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters) {
         float a = lane * 1e-3f, b = 1.f + lane * 1e-4f;
         float v[8] = {a, b, a + 1, b + 1, a + 2, b + 2, a + 3, b + 3};
         const v2f* lp = reinterpret_cast<const v2f*>(lds) + lane;
-        unsigned sacc = 0;
         for (int i = 0; i < iters; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -31,14 +30,6 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters) {
                 if ((mode & 16)) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) if (k < fill) v[k] = v[k] + b;
-                }
-                if ((mode & 64)) {                       // k scalar adds (SALU) after each MFMA
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) if (k < fill) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
-                }
-                if ((mode & 128)) {                      // k x `s_nop 0`
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) if (k < fill) asm volatile("s_nop 0");
                 }
                 if ((mode & 32)) {
 #pragma unroll
@@ -48,7 +39,6 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters) {
         }
         for (int j = 0; j < 4; ++j) for (int k = 0; k < 16; ++k) r += acc[j][k];
         for (int k = 0; k < 8; ++k) r += v[k];
-        r += (float)sacc;
     } else {
         if (mode & 2) {
             float v[8];
@@ -111,8 +101,5 @@ int main() {
     printf("MFMA + LDS waves                                 : %.3f %.3f %.3f ms\n", R(5, 1), R(5, 2), R(5, 4));
     printf("same wave, 1/2/4/8 VALU adds after each MFMA     : %.3f %.3f %.3f %.3f ms\n", R(17, 1), R(17, 2), R(17, 4), R(17, 8));
     printf("same wave, 1/2/4/8 ds_read_b64 after each MFMA   : %.3f %.3f %.3f %.3f ms\n", R(33, 1), R(33, 2), R(33, 4), R(33, 8));
-    printf("same wave, 1/2/4/8 s_add_u32 after each MFMA     : %.3f %.3f %.3f %.3f ms\n", R(65, 1), R(65, 2), R(65, 4), R(65, 8));
-    printf("same wave, 1/2/4/8 s_nop 0 after each MFMA       : %.3f %.3f %.3f %.3f ms\n", R(129, 1), R(129, 2), R(129, 4), R(129, 8));
-    printf("same wave, 4 VALU + 4 s_add after each MFMA      : %.3f ms (4 VALU alone above)\n", R(81, 4));
     return 0;
 }

@@ -5,7 +5,7 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// FILL: 0 none, 1 `s_nop 0`, 2 `s_nop 1`, 3 `s_nop 3`, 4 `s_nop 7`, 5 `v_nop`, 6 s_add_u32, 7 two `s_nop 0`, 8 v_add_f32 (independent), 9 s_nop 0 after every 2nd MFMA
+// FILL: 0 none, 1 `s_nop 0`, 2 `s_nop 1`, 3 `s_nop 3`, 4 `s_nop 7`, 5 `v_nop`, 6 s_add_u32, 7 two `s_nop 0`, 8 v_add_f32 (independent), 9 s_nop 0 after every 2nd MFMA; 11 v_pk_add_f32, 12 ds_read_b32, 13 buffer_load_dword, 14 / 15 two / four v_add_f32, 16 s_waitcnt, 17 two s_cselect_b32 (scalar ALU)
 template <int FILL, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void probe(float* out, long long* cyc, int iters) {
     f32x16 acc[4];
@@ -30,8 +30,6 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* out, long long* cyc, 
             if (FILL == 3) asm volatile("s_nop 3");
             if (FILL == 4) asm volatile("s_nop 7");
             if (FILL == 5) asm volatile("v_nop");
-            if (FILL == 6) asm volatile("s_add_u32 s40, s40, 1" ::: "s40");
-            if (FILL == 10) asm volatile("s_add_u32 s40, s40, 1\n\ts_add_u32 s41, s41, 1\n\ts_add_u32 s42, s42, 1\n\ts_add_u32 s43, s43, 1" ::: "s40", "s41", "s42", "s43");
             if (FILL == 11) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(v2) : "v"(b2));
             if (FILL == 12) { float t; asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"(ldsa)); }
             if (FILL == 13) { float t; asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(t) : "v"(0), "s"(rs)); }
@@ -74,11 +72,9 @@ int main() {
     run<3, 4>("s_nop 3 after each", iters);
     run<4, 4>("s_nop 7 after each", iters);
     run<5, 4>("v_nop after each", iters);
-    run<6, 4>("s_add_u32 after each", iters);
     run<7, 4>("2 x s_nop 0 after each", iters);
     run<8, 4>("v_add_f32 after each", iters);
     run<9, 4>("s_nop 0 after every 2nd", iters);
-    run<10, 4>("4 x s_add_u32 after each", iters);
     run<17, 4>("2 x s_cselect_b32 after each", iters);
     run<11, 4>("v_pk_add_f32 after each", iters);
     run<14, 4>("2 x v_add_f32 after each", iters);
@@ -87,7 +83,6 @@ int main() {
     run<13, 4>("buffer_load_dword after each", iters);
     run<16, 4>("s_waitcnt vmcnt(0) after each", iters);
     run<0, 8>("back to back", iters);
-    run<10, 8>("4 x s_add_u32 after each", iters);
     run<15, 8>("4 x v_add_f32 after each", iters);
     run<12, 8>("ds_read_b32 after each", iters);
     run<13, 8>("buffer_load_dword after each", iters);
