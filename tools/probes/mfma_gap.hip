@@ -5,7 +5,7 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// FILL: 0 none, 1 `s_nop 0`, 2 `s_nop 1`, 3 `s_nop 3`, 4 `s_nop 7`, 5 `v_nop`, 6 s_add_u32, 7 two `s_nop 0`, 8 v_add_f32 (independent), 9 s_nop 0 after every 2nd MFMA; 11 v_pk_add_f32, 12 ds_read_b32, 13 buffer_load_dword, 14 / 15 two / four v_add_f32, 16 s_waitcnt, 17 two s_cselect_b32 (scalar ALU)
+// FILL: 0 none, 1 `s_nop 0`, 2 `s_nop 1`, 3 `s_nop 3`, 4 `s_nop 7`, 5 `v_nop`, 7 two `s_nop 0`, 8 v_add_f32 (independent), 9 s_nop 0 after every 2nd MFMA; 11 v_pk_add_f32, 12 ds_read_b32, 13 buffer_load_dword, 14 / 15 two / four v_add_f32, 16 s_waitcnt, 17 two s_cselect_b32 (scalar ALU)
 template <int FILL, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void probe(float* out, long long* cyc, int iters) {
     f32x16 acc[4];
