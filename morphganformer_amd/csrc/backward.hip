@@ -734,8 +734,20 @@ __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* oa, float* 
     const int64_t p = (int64_t)blockIdx.x * PXB + px;
     const bool valid = p < hw;
     const int64_t pc = valid ? p : hw - 1;
-    const float* a = f0 + (int64_t)n * c * hw + pc;
-    const float* b = f1u + (int64_t)n * f1_bs + pc;
+    // Buffer addressing (round 3, like the forward kernel): a thread's channels are G planes apart, so the channel part of every address is
+    // a scalar offset (j G hw) on one per-lane offset (grp hw + pixel); the range check covers both, so a channel past c -- or past
+    // c_split in the first output, before it in the second -- reads 0 / is not stored, without a per-lane test.  Host: c * hw * 4 < 2^32.
+    const unsigned plane_b = 4u * (unsigned)hw;
+    const unsigned vo = (unsigned)grp * plane_b + 4u * (unsigned)pc;
+    const unsigned cbytes = (unsigned)c * plane_b;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(f0 + (int64_t)n * c * hw), 0, (int)cbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(f1u + (int64_t)n * f1_bs), 0, (int)cbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)lin, 0, 4 * c, 0x00020000);
+    auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int j) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, (int)((unsigned)(j * G) * plane_b), 0));
+    };
+    auto ldlin = [&](int j) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, 4u * (unsigned)grp, 4 * j * G, 0)); };
+    const int nj = (c + G - 1) / G;                   // channel steps (a lane whose channel of the last step is past c reads zeros)
     float va[NV], vb[NV];
     float A = 0.f, B = 0.f, Cc = 0.f;
     // stats: the per-pixel sums A, B, C of the forward (mgf_lpips_layer_stats_f32, [n][3][hw]) -- no first sweep, no meeting in LDS
@@ -745,26 +757,21 @@ __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* oa, float* 
     } else {
     if (CPT > 0) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int ch = grp + j * G;
-            va[j] = ch < c ? a[(int64_t)ch * hw] : 0.f;
-            vb[j] = ch < c ? b[(int64_t)ch * hw] : 0.f;
-        }
+        for (int j = 0; j < NV; ++j) { va[j] = ld(ra, j); vb[j] = ld(rb, j); }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int ch = grp + j * G;
-            const float l = ch < c ? lin[ch] : 0.f;
+            const float l = ldlin(j);
             A += va[j] * va[j];
             B += l * va[j] * va[j];
             Cc += l * vb[j] * va[j];
         }
     } else {
 #pragma unroll 4
-        for (int ch = grp; ch < c; ch += G) {
-            const float v = a[(int64_t)ch * hw], l = lin[ch];
+        for (int j = 0; j < nj; ++j) {
+            const float v = ld(ra, j), l = ldlin(j);
             A += v * v;
             B += l * v * v;
-            Cc += l * b[(int64_t)ch * hw] * v;
+            Cc += l * ld(rb, j) * v;
         }
     }
     part[0][grp][px] = A; part[1][grp][px] = B; part[2][grp][px] = Cc;
@@ -777,30 +784,42 @@ __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* oa, float* 
     const float q = 1.f / (nrm + 1e-10f);
     const float dot = k * (q * B - Cc);
     const float coef = nrm > 0.f ? dot * q * q / nrm : 0.f;
-    if (!valid) return;
-    const float* di = (RELU && din) ? din + (int64_t)n * c * hw + pc : nullptr;
-    float* da = oa + (int64_t)n * (RELU ? c_split : c) * hw + pc;
-    float* db = (RELU && ob) ? ob + (int64_t)n * (c - c_split) * hw + pc : nullptr;
-    auto one = [&](int ch, float v, float u) {
-        float g = q * k * lin[ch] * (v * q - u) - coef * v;
+    // outputs: RELU -> channels [0, c_split) to oa, the rest to ob; else oa holds all c channels
+    const unsigned vst = valid ? vo : 0xFFFFFFF0u;
+    const int ca = RELU ? c_split : c;
+    const __amdgpu_buffer_rsrc_t rda = __builtin_amdgcn_make_buffer_rsrc((void*)(oa + (int64_t)n * ca * hw), 0, (int)((unsigned)ca * plane_b), 0x00020000);
+    const bool has_b = RELU && ob != nullptr && c > c_split;
+    const __amdgpu_buffer_rsrc_t rdb = __builtin_amdgcn_make_buffer_rsrc((void*)(has_b ? ob + (int64_t)n * (c - c_split) * hw : oa), 0,
+                                                                         has_b ? (int)((unsigned)(c - c_split) * plane_b) : 0, 0x00020000);
+    const bool has_di = RELU && din != nullptr;
+    const __amdgpu_buffer_rsrc_t rdi = __builtin_amdgcn_make_buffer_rsrc((void*)(has_di ? din + (int64_t)n * c * hw : f0), 0, has_di ? (int)cbytes : 0, 0x00020000);
+    auto one = [&](int j, float v, float u) {
+        const int so = (int)((unsigned)(j * G) * plane_b);
+        float g = q * k * ldlin(j) * (v * q - u) - coef * v;
         if (RELU) {
-            if (di) g = di[(int64_t)ch * hw] + g;
+            g = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdi, vo, so, 0)) + g;       // (no din: zero-size descriptor, reads 0)
             g = v > 0.f ? g : 0.f;
-            if (ch < c_split) da[(int64_t)ch * hw] = g;
-            else db[(int64_t)(ch - c_split) * hw] = g;
+            const int ch = grp + j * G, cb = j * G - c_split;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), rda, vst, so, 0);       // ch >= c_split: past rda's end
+            // second output: channel ch - c_split.  With c_split a multiple of G the step's channel base j G - c_split is wave-uniform (a
+            // negative one means this step lies in the first output); otherwise the whole offset is per lane.  (The range check adds
+            // vector and scalar offset WITHOUT 32-bit wrap: an offset that "wraps back" into range is still out of range.)
+            const bool even = c_split % G == 0;
+            const unsigned vsb = !valid ? 0xFFFFFFF0u
+                               : even ? (cb >= 0 ? vo : 0xFFFFFFF0u)
+                                      : (ch >= c_split ? (unsigned)(ch - c_split) * plane_b + 4u * (unsigned)pc : 0xFFFFFFF0u);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), rdb, vsb, (even && cb >= 0) ? (int)((unsigned)cb * plane_b) : 0, 0);
         } else {
-            da[(int64_t)ch * hw] = accumulate ? da[(int64_t)ch * hw] + g : g;
+            if (accumulate) g += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rda, vo, so, 0));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), rda, vst, so, 0);
         }
     };
     if (CPT > 0) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int ch = grp + j * G;
-            if (ch < c) one(ch, va[j], vb[j]);
-        }
+        for (int j = 0; j < NV; ++j) one(j, va[j], vb[j]);
     } else {
 #pragma unroll 4
-        for (int ch = grp; ch < c; ch += G) one(ch, a[(int64_t)ch * hw], b[(int64_t)ch * hw]);
+        for (int j = 0; j < nj; ++j) one(j, ld(ra, j), ld(rb, j));
     }
 }
 
@@ -1248,6 +1267,7 @@ static void lpips_bwd_launch(float* oa, float* ob, const float* din, const float
 extern "C" int mgf_lpips_layer_bwd_f32(float* df0, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c, int64_t hw,
                                        int64_t f1_batch_stride, float scale, int32_t accumulate, mgf_stream_t stream) {
     MGF_REQUIRE(df0 && f0 && f1_unit && lin && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer_bwd: bad arguments");
+    MGF_REQUIRE((int64_t)c * hw < (1LL << 30), MGF_ETOOBIG, "lpips_layer_bwd: one sample's tap must stay below 4 GiB (32-bit buffer offsets)");
     MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "lpips_layer_bwd: n must be <= 65535");
     const float kk = 2.f * scale / (float)hw;
     lpips_bwd_launch<false>(df0, nullptr, nullptr, f0, f1_unit, lin, n, c, c, hw, f1_batch_stride, kk, accumulate, (hipStream_t)stream);
@@ -1267,6 +1287,7 @@ extern "C" int mgf_lpips_layer_bwd_relu_stats_f32(float* dz_a, float* dz_b, cons
     MGF_REQUIRE(dz_a && f0 && f1_unit && lin && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer_bwd_relu: bad arguments");
     MGF_REQUIRE(c_split >= 1 && c_split <= c && (dz_b || c_split == c), MGF_EINVAL, "lpips_layer_bwd_relu: bad split %d of %d channels", c_split, c);
     MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "lpips_layer_bwd_relu: n must be <= 65535");
+    MGF_REQUIRE((int64_t)c * hw < (1LL << 30), MGF_ETOOBIG, "lpips_layer_bwd_relu: one sample's tap must stay below 4 GiB (32-bit buffer offsets)");
     const float kk = 2.f * scale / (float)hw;
     lpips_bwd_launch<true>(dz_a, dz_b, dy, f0, f1_unit, lin, n, c, c_split, hw, f1_batch_stride, kk, 0, (hipStream_t)stream, stats);
     MGF_CHECK_LAUNCH("lpips_layer_bwd_relu");
