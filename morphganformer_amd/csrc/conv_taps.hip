@@ -218,13 +218,18 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     float xr[XS];
     float4 wr[WS];
     float wsc[WS];
-    // load_chunk issues ONLY loads (every address is valid: padding slots read element 0 and are zeroed at store time), so no
+    // load_chunk issues ONLY loads (padding slots carry an out-of-range offset and arrive as zeros), so no
     // instruction that consumes a loaded value -- and hence no s_waitcnt vmcnt -- sits between the loads and the MFMA phase.
     // The style modulation s[ci] is applied to the weight rows (the reference's w * s, networks.py:289) at store time.
     auto load_chunk = [&](int c0) {
         const int xso = (int)(4u * (unsigned)(c0 * plane)), wso = (int)(4u * (unsigned)(c0 * d.cout_pad)), sso = c0 * sc_step;
+#if defined(MGF_EXP) && (MGF_EXP == 4 || MGF_EXP == 6)      // experiment: no activation traffic (a zero-record descriptor: same instructions, no bytes)
+        const __amdgpu_buffer_rsrc_t rx_e = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
+#else
+        const __amdgpu_buffer_rsrc_t rx_e = rx_l;
+#endif
 #pragma unroll
-        for (int j = 0; j < XS; ++j) xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_l, xoff[j], xso, 0));
+        for (int j = 0; j < XS; ++j) xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_e, xoff[j], xso, 0));
 #pragma unroll
         for (int j = 0; j < WS; ++j) {
             wr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw_l, 4u * (unsigned)woff[j], wso, 0));
@@ -471,7 +476,11 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                                 for (int a2 = 0; a2 < 2; ++a2) {
                                     const float v0 = acc[NG == 4 ? 2 * a2 : 0][m][g][hh * 8 + r8] * osv[r8];
                                     const float v1 = acc[NG == 4 ? 2 * a2 + 1 : 0][m][g][hh * 8 + r8] * osv[r8];
+#if defined(MGF_EXP) && (MGF_EXP == 5 || MGF_EXP == 6)      // experiment: no output stores (one lane keeps the values alive)
+                                    if (v0 == 12345.678f) *reinterpret_cast<float2*>(ybase + (og + cu * plane32 + a2 * pitch32)) = make_float2(v0, v1);
+#else
                                     *reinterpret_cast<float2*>(ybase + (og + cu * plane32 + a2 * pitch32)) = make_float2(v0, v1);
+#endif
                                 }
                             }
                         }
