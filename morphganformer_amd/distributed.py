@@ -29,14 +29,20 @@ class WorkQueue:
 
     _epochs: dict = {}
 
-    def __init__(self, n_items: int, name: str = "mgf_queue"):
+    def __init__(self, n_items: int, name: str = "mgf_queue", group=None):
+        """group: the process group whose ranks share this queue (default: all ranks).  The counter lives in the job's rendezvous
+        store whatever the group; a sub-group's key carries its global ranks, so disjoint sub-groups draw from separate counters and
+        the queue's population is exactly the group `run_sharded` gathers over."""
         import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized()
+        if on and group is not None:
+            name = f"{name}@{'-'.join(str(r) for r in dist.get_process_group_ranks(group))}"
         epoch = WorkQueue._epochs.get(name, 0)
         WorkQueue._epochs[name] = epoch + 1
         self.n_items, self.key = n_items, f"{name}/{epoch}/next"
         self.store = None
         self._local = 0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if on and dist.get_world_size(group) > 1:
             self.store = dist.distributed_c10d._get_default_store()
 
     def __iter__(self):
@@ -108,7 +114,7 @@ def run_sharded(n_items: int, work_fn, record_width: int, device, dynamic: bool 
     import torch.distributed as dist
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
-    order = WorkQueue(n_items, name=queue_name) if dynamic else shard_items(n_items, rank, world)
+    order = WorkQueue(n_items, name=queue_name, group=group) if dynamic else shard_items(n_items, rank, world)
     recs, mine = [], []
     for i in order:
         recs.append(work_fn(i))

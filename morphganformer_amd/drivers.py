@@ -187,6 +187,13 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
     if engine is not None:
         if engine.G is not G or engine.batch != batch or engine.steps != args.step or engine.keep_images != keep:
             raise ValueError("engine= was built for another generator / batch / step count / trail size")
+        # the objective is baked into the captured launch sequence: a re-targeted engine must score exactly what a fresh one would
+        diff = [name for name, ok in (("landmarks (Wing term)", engine.use_wing == (lm_target is not None)),
+                                      ("percept", engine.percept is percept), ("use_mse", engine.use_mse == bool(use_mse)),
+                                      ("noise_mode", engine.noise_mode == noise_mode), ("args", engine.args == args),
+                                      ("landmark_fn", engine.landmark_fn is landmark_fn)) if not ok]
+        if diff:
+            raise ValueError("engine= was built for another objective: " + ", ".join(diff) + " differ(s); build a fresh engine")
         eng = engine.retarget(target, lm_target=lm_target, lm_steps=lm_steps, eps=eps, seed=seed if eps is None else None,
                               latent_mean=latent_mean, latent_std=float(latent_std))
     elif mode == "gradient":
@@ -230,7 +237,11 @@ def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
     load = lambda t: t if isinstance(t, torch.Tensor) else image_transform(t, size=G.img_resolution, device=G.device)
-    width = G.cfg.k * G.cfg.z_dim + 3
+    w_plus = kw.get("latent_space", "z") == "w+"
+    lshape = (G.cfg.k, G.cfg.num_ws, G.cfg.w_dim) if w_plus else (G.cfg.k, G.cfg.z_dim)      # a W+ result is [k, num_ws, D] per item
+    width = int(np.prod(lshape)) + 3
+    if w_plus and kw.get("mode") != "gradient":
+        raise ValueError("latent_space='w+' needs mode='gradient'")
     if lockstep > 1:
         if dynamic or kw.get("mode") != "gradient":
             raise ValueError("lockstep groups need mode='gradient' and static sharding")
@@ -241,7 +252,7 @@ def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):
             res = _project_group(G, [load(targets[i]) for i in ids], [landmarks[i] for i in ids] if landmarks is not None else None, **kw)
             recs += [pack_result(res["w"][j:j + 1].to(G.device), float(res["loss"][j]), int(res["step"][j]), item=i) for j, i in enumerate(ids)]
         rows = torch.stack(recs) if recs else torch.empty([0, width], dtype=torch.float64, device=G.device)
-        return unpack_results(gather_many(rows, -(-len(targets) // world)), (G.cfg.k, G.cfg.z_dim))
+        return unpack_results(gather_many(rows, -(-len(targets) // world)), lshape)
     reuse = kw.get("mode", "literal") == "literal" and kw.get("landmark_fn") is None and kw.get("eps") is None
     if reuse and (kw.get("latent_mean") is None or kw.get("latent_std") is None):
         a = kw.get("args") or ProjectionArgs()
@@ -254,24 +265,31 @@ def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):
 
     def work(i):
         lm_t, lm_s = landmarks[i] if landmarks is not None else (None, None)
-        r = project_image(G, load(targets[i]), lm_t, lm_s, engine=state["eng"], return_engine=reuse, **kw)
+        eng = state["eng"]
+        if eng is not None and eng.use_wing != (lm_t is not None):
+            eng = None                     # an item with / without landmarks after one without / with: another objective, a fresh engine
+        r = project_image(G, load(targets[i]), lm_t, lm_s, engine=eng, return_engine=reuse, **kw)
         state["eng"] = r.get("engine")
         return pack_result(r["w"].to(G.device), r["loss"], r["step"], item=i)
 
     rows, _mine = run_sharded(len(targets), work, width, G.device, dynamic=dynamic)
-    return unpack_results(rows, (G.cfg.k, G.cfg.z_dim))
+    return unpack_results(rows, lshape)
 
 
 def _project_group(G, targets, landmarks, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None, eps=None,
-                   use_graph=True, noise_mode="random", use_mse=True, seed=None, weight_decay=0.0, mode="gradient", **unused):
-    """B targets through one lockstep GradientProjectionEngine; returns dict(w [B,k,D], step [B], loss [B], losses [B,steps])."""
+                   use_graph=True, noise_mode="random", use_mse=True, seed=None, weight_decay=0.0, mode="gradient", latent_space="z",
+                   **unused):
+    """B targets through one lockstep GradientProjectionEngine; returns dict(w [B,k,D] (W+: [B,k,num_ws,D]), step [B], loss [B],
+    losses [B,steps])."""
     args = args or ProjectionArgs()
+    if unused:
+        raise TypeError(f"project_many(lockstep=...): unsupported arguments {sorted(unused)}")
     if latent_mean is None or latent_std is None:
         gen = None
         if seed is not None:
             gen = torch.Generator(device=G.device)
             gen.manual_seed(seed)
-        latent_mean, latent_std = latent_stats(G, args.n_mean_latent, G.device, generator=gen)
+        latent_mean, latent_std = (latent_stats_w if latent_space == "w+" else latent_stats)(G, args.n_mean_latent, G.device, generator=gen)
     tg = torch.cat([t.reshape(1, *t.shape[-3:]) for t in targets]).contiguous()
     lm_t = lm_s = None
     if landmarks is not None:
@@ -280,7 +298,7 @@ def _project_group(G, targets, landmarks, args: ProjectionArgs = None, percept=N
         lm_t, lm_s = lm_t[0], lm_s[0]
     eng = GradientProjectionEngine(G, tg, latent_mean, float(latent_std), args, weight_decay=weight_decay, percept=percept,
                                    lm_target=lm_t, lm_steps=lm_s, eps=eps, noise_mode=noise_mode, use_graph=use_graph, use_mse=use_mse,
-                                   seed=0 if seed is None else seed)
+                                   seed=0 if seed is None else seed, latent_space=latent_space)
     w, step, loss, losses = eng.run().result()
     if len(targets) == 1:
         return {"w": w, "step": np.array([step]), "loss": np.array([loss]), "losses": losses[None]}

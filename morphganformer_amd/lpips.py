@@ -557,6 +557,34 @@ class PerceptualLoss(torch.nn.Module):
                                                    int(i > 0), self._scratch.data_ptr(), st), "lpips_layer")
         return out
 
+    def distance_per_tap(self, pred):
+        """[taps, n]: every tap's own contribution to `distance_into`'s sum -- PNetLin.forward(retPerLayer=True)'s `res` list
+        (networks_basic.py:85-92) -- through the SAME kernel dispatch as distance_into (fused stem included), each tap written to its
+        own row instead of accumulated."""
+        n = pred.shape[0]
+        f = self._features(n, pred.shape[2], pred.shape[3])
+        assert self._target_taps is not None, "call set_target first"
+        per_sample = self._target_n > 1
+        assert not per_sample or self._target_n == n
+        need = n * int(_lib.lib().mgf_reduce_scratch_floats())
+        if self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.float32, device=self.device_)
+        out = torch.zeros(len(self.chns), n, dtype=torch.float32, device=self.device_)
+        f.tap_stats = {}
+        if self.fused_stem and not per_sample:
+            f.stem(pred.contiguous(), feat_ref=self._target_taps[0], lin=self.lins[0], dist_out=out[0], scratch=self._scratch)
+            taps = f(pred, from_pooled=True)
+        else:
+            taps = f(pred)
+        L, st = _lib.lib(), _lib.stream_ptr()
+        for i, (a, b, lin) in enumerate(zip(taps, self._target_taps, self.lins)):
+            if a is None:
+                continue
+            _, c, hh, ww = a.shape
+            _lib.check(L.mgf_lpips_layer_stats_f32(out[i].data_ptr(), None, a.data_ptr(), b.data_ptr(), lin.data_ptr(), n, c, hh * ww,
+                                                   c * hh * ww if per_sample else 0, 0, self._scratch.data_ptr(), st), "lpips_layer")
+        return out
+
     def forward(self, pred, target, normalize=False):
         _lib.require_gpu(pred, target)
         if normalize:

@@ -84,11 +84,25 @@ def _as_latent(latent_mean, shape):
     return t.reshape(*shape).contiguous()
 
 
+def mapping_only(G, z):
+    """w [n, k, D] = the mapping network on z [n, k, D] for ANY n, without touching the generator's synthesis workspaces: the kernel
+    writes into a buffer of its own (G.mapping / G._mapping_into size the whole synthesis workspace for the batch -- 1.6 GB per sample at
+    1024^2 -- which a statistics pass over 10 000 samples must never do)."""
+    _lib.require_gpu(z)
+    cfg = G.cfg
+    assert tuple(z.shape[1:]) == (cfg.k, cfg.z_dim), tuple(z.shape)
+    z = z.contiguous().float()
+    w = torch.empty(z.shape[0], cfg.k, cfg.w_dim, dtype=torch.float32, device=z.device)
+    _lib.check(_lib.lib().mgf_mapping_forward(w.data_ptr(), z.data_ptr(), G.plan.mapping_blob.data_ptr(), z.shape[0], cfg.k, cfg.w_dim,
+                                              cfg.mapping_layers // 2, int(cfg.normalize_global), _lib.stream_ptr()), "mapping_forward")
+    return w
+
+
 def latent_stats_w(G, n_mean_latent=10000, device="cuda", generator=None):
     """Statistics of the INTERMEDIATE latent for a W+ search (what StyleGAN2-style projectors use: w_avg and w_std of mapped samples):
     mean [k, D] and the scalar std of G.mapping(z)[:, :, 0] over z ~ N(0, I), with the drivers' formula (:251-255) applied to w."""
     z = torch.randn(n_mean_latent, *G.input_shape[1:], device=device, generator=generator)
-    w = torch.cat([G.mapping(z[i:i + 2000])[:, :, 0].clone() for i in range(0, n_mean_latent, 2000)])
+    w = mapping_only(G, z)
     mean = w.mean(0)
     std = ((w - mean).pow(2).sum() / n_mean_latent) ** 0.5
     return mean, std

@@ -364,6 +364,67 @@ def test_project_many_gradient_lockstep_groups(golden):
         drivers.project_many(G, targets, lockstep=2, args=ProjectionArgs(step=6))
 
 
+def test_wplus_driver_statistics_never_size_a_synthesis_workspace(golden):
+    """project_image(mode='gradient', latent_space='w+') WITHOUT latent_mean: the w-space statistics pass (projection.latent_stats_w over
+    n_mean_latent mapped samples) runs the mapping network alone -- no generator workspace larger than the engine's batch is ever created
+    (round 3 sized the synthesis workspace for 2000 samples: 3.3 TB at 1024^2) -- and equals G.mapping on the same z; project_many carries
+    W+ records ([k, num_ws, D] per item) through the gather, one by one and in lockstep groups."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.projection import ProjectionArgs, latent_stats_w, mapping_only
+    g = golden("loop_tiny.npz")
+    G = _tiny_G()
+    cfg = G.cfg
+    t = torch.from_numpy(g["target"]).cuda()
+    z = torch.randn(7, cfg.k, cfg.z_dim, device="cuda")
+    assert torch.equal(mapping_only(G, z), G.mapping(z)[:, :, 0])
+    G2 = _tiny_G()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(4)
+    mean, std = latent_stats_w(G2, 4000, "cuda", gen)
+    assert tuple(mean.shape) == (cfg.k, cfg.w_dim) and float(std) > 0 and max(G2._workspaces) == 1
+    args = ProjectionArgs(step=5, lr=0.05, lr_rampup=0.3, n_mean_latent=3000)
+    r = drivers.project_image(G2, t, None, None, args=args, mode="gradient", latent_space="w+", noise_mode="const", seed=2)
+    assert tuple(r["w"].shape) == (1, cfg.k, cfg.num_ws, cfg.w_dim) and np.isfinite(r["losses"]).all()
+    assert max(G2._workspaces) == 1, sorted(G2._workspaces)
+    kw = dict(args=args, mode="gradient", latent_space="w+", noise_mode="const", seed=2)
+    many = drivers.project_many(G2, [t, (t * 0.9).contiguous()], **kw)
+    assert tuple(many["latents"].shape) == (2, cfg.k, cfg.num_ws, cfg.w_dim)
+    assert torch.equal(many["latents"][0].cpu(), r["w"][0])
+    grp = drivers.project_many(G2, [t, (t * 0.9).contiguous()], lockstep=2, **kw)
+    assert tuple(grp["latents"].shape) == (2, cfg.k, cfg.num_ws, cfg.w_dim) and max(G2._workspaces) == 2
+    with pytest.raises(ValueError):
+        drivers.project_many(G2, [t], latent_space="w+", args=args)
+
+
+def test_engine_reuse_checks_the_objective(golden):
+    """project_image(engine=...) re-targets a captured launch sequence: an engine built for another objective (no Wing term, another
+    percept / noise mode / ProjectionArgs) is refused instead of silently scoring the first item's objective; project_many builds a
+    fresh engine when an item with landmarks follows one without."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.projection import ProjectionArgs
+    g = golden("loop_tiny.npz")
+    G = _tiny_G()
+    t = torch.from_numpy(g["target"]).cuda()
+    steps = 6
+    args = ProjectionArgs(step=steps)
+    kw = dict(args=args, percept=None, latent_mean=torch.from_numpy(g["latent_mean"]).cuda(), latent_std=float(g["latent_std"]),
+              noise_mode="const", batch=2, seed=1)
+    first = drivers.project_image(G, t, None, None, return_engine=True, **kw)
+    eng = first["engine"]
+    with pytest.raises(ValueError, match="Wing"):
+        drivers.project_image(G, t, g["lm_target"], g["lm_steps"][:steps], engine=eng, **kw)
+    with pytest.raises(ValueError, match="args"):
+        drivers.project_image(G, t, None, None, engine=eng, **dict(kw, args=ProjectionArgs(step=steps, beta=0.5)))
+    with pytest.raises(ValueError, match="noise_mode"):
+        drivers.project_image(G, t, None, None, engine=eng, **dict(kw, noise_mode="none"))
+    again = drivers.project_image(G, t, None, None, engine=eng, **kw)
+    assert again["step"] == first["step"] and again["loss"] == first["loss"]
+    # mixed items: without landmarks, then with -- the second item's Wing term must be in ITS total
+    lms = [(None, None), (g["lm_target"], g["lm_steps"][:steps])]
+    many = drivers.project_many(G, [t, t], landmarks=lms, **kw)
+    alone = drivers.project_image(G, t, *lms[1], **kw)
+    assert float(many["losses"][0]) == first["loss"] and float(many["losses"][1]) == alone["loss"] and alone["loss"] != first["loss"]
+
+
 def test_gradient_entry_points_reject_bad_arguments():
     """The new C-ABI entry points validate on the host and report through mgf_last_error (no launch on bad input)."""
     from morphganformer_amd import _lib

@@ -578,7 +578,8 @@ def test_fir_streaming_kernel_vs_float64(n, c, h, with_ep):
     assert rel_err(y[1:2, 3:4], y1) < 1e-6
 
 
-@pytest.mark.parametrize("n,cout,h,w", [(2, 32, 64, 64), (1, 32, 100, 96), (3, 64, 32, 512), (1, 32, 16, 1024), (2, 32, 8, 2048)])
+@pytest.mark.parametrize("n,cout,h,w", [(2, 32, 64, 64), (1, 32, 100, 96), (3, 64, 32, 512), (1, 32, 16, 1024), (2, 32, 8, 2048),
+                                        (1, 32, 160, 64), (2, 32, 136, 96)])       # 40 / 34 tile rows: not whole 32-tile columns -> the HORIZONTAL strip walk
 def test_winograd3_persistent_form(n, cout, h, w):
     """wino3p_conv_kernel (the form the literal loop runs on the 1024^2 layers at 25 - 32 candidates: a workgroup walks a strip of tiles with
     its weights resident in registers, styles folded into them, the epilogue's operands by LDS-DMA) pinned through

@@ -283,6 +283,83 @@ def test_full_size_loop_bench_batch_equals_batch1():
     assert abs(loss_a - loss_b) <= 1e-5 * abs(loss_b)
 
 
+def test_full_size_loop_vs_oracle():
+    """configs[1] at FULL size against the CPU oracle, not against itself: 1024^2, Wing + LPIPS(squeeze) + MSE, drivers.DEFAULT_BATCH (32)
+    candidates per generator forward -- the kernel shapes bench.py times -- injected eps, constant per-layer noise, 4 loop steps.  Every loss of
+    the history <= 1e-3 of oracle.loss_ref.projection_literal_ref's (...sqz_MSE.py:171-184), best step exact, best latent bit-exact, and the
+    seven per-tap LPIPS contributions of candidate 0 (networks_basic.py:64-92, retPerLayer) <= 1e-3 each: the whole squeeze chain at 255^2 /
+    127^2 / 63^2 maps on the form-3 Winograd / pw_conv / max-pool / tap-distance kernels the 32-candidate dispatcher picks."""
+    from morphganformer_amd.drivers import DEFAULT_BATCH
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.lpips import PerceptualLoss, random_squeeze_backbone
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, latent_stats, synthetic_landmarks
+    from morphganformer_amd.synth_weights import FULL1024, make_state_dict, synthetic_latents
+    from oracle.generator_ref import generator_ref, to_torch_state
+    from oracle.loss_ref import lpips_ref, mse_ref, projection_literal_ref, squeeze_backbone_random, wing_loss_ref
+    cfg = FULL1024
+    sd = make_state_dict(cfg, seed=0)
+    G = Generator(sd, cfg, "cuda", max_batch=1)
+    target = G(torch.from_numpy(synthetic_latents(cfg, 1, 1000)).cuda(), None, noise_mode="const")[0].clamp(-1, 1).clone()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    mean, std = latent_stats(G, 10000, "cuda", gen)
+    steps = 4
+    lm_t, lm_s = synthetic_landmarks(steps, 1024, 7)
+    eps = torch.randn(steps, 1, cfg.k, cfg.z_dim, device="cuda", generator=gen)
+    P = PerceptualLoss(net="squeeze", backbone_state=random_squeeze_backbone(0))
+    eng = ProjectionEngine(G, target, mean, std, ProjectionArgs(step=steps), percept=P, use_mse=True, lm_target=lm_t, lm_steps=lm_s,
+                           eps=eps, noise_mode="const", use_graph=True, batch=DEFAULT_BATCH)
+    lat, bstep, bloss, losses = eng.run().result()
+    per_tap = P.distance_per_tap(G.img)[:, 0].cpu().numpy()          # the workspace still holds this launch sequence's candidates: row 0 = step 0
+    # ---- the oracle's loop on the host cores
+    tsd, bb = to_torch_state(sd), squeeze_backbone_random(0)
+    lins = [l.cpu() for l in P.lins]
+    tgt = target.cpu()
+    taps0 = {}
+
+    def loss_fn(i, img):
+        total, layers = lpips_ref(bb, lins, img, tgt, per_layer=True)
+        if i == 0:
+            taps0["v"] = np.array([float(v) for v in layers])
+        return float(total) + 0.01 * float(wing_loss_ref(torch.from_numpy(lm_s[i]), torch.from_numpy(lm_t))) + float(mse_ref(img, tgt))
+
+    with torch.no_grad():
+        ref = projection_literal_ref(lambda z: generator_ref(tsd, z, cfg, "const"), loss_fn, mean.cpu(), float(std), eps.cpu(), steps)
+    ref_losses = np.array(ref[3])
+    assert np.abs(losses - ref_losses).max() <= 1e-3 * np.abs(ref_losses).max(), (losses, ref_losses)
+    assert bstep == ref[1]
+    assert torch.equal(lat, ref[0])
+    assert abs(bloss - ref[2]) <= 1e-3 * abs(ref[2])
+    assert per_tap.shape == (7,)
+    assert (np.abs(per_tap - taps0["v"]) <= 1e-3 * np.abs(taps0["v"])).all(), (per_tap, taps0["v"])
+
+
+@pytest.mark.parametrize("net", ["vgg", "alex"])
+def test_lpips_vgg_alex_full_size_vs_oracle(net):
+    """LPIPS(vgg) -- the net 1024_example_percept_MSE.py:142-147 scores with -- and LPIPS(alex) on one 1024^2 pair: total and per-tap
+    contributions against the oracle (lpips/pretrained_networks.py:58-135 topology, networks_basic.py:64-92 distance), 1e-3 each."""
+    from morphganformer_amd.lpips import PerceptualLoss, random_backbone
+    from oracle.loss_ref import backbone_random, lpips_ref
+    torch.manual_seed(11)
+    res = 1024
+    x0 = (torch.rand(1, 3, res, res) * 2 - 1)
+    x0 = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x0, (2, 2, 2, 2), mode="reflect"), 5, 1) * 2.5      # some spatial correlation, like an image
+    x0 = x0.clamp(-1, 1)
+    x1 = (x0 + 0.2 * torch.randn(1, 3, res, res)).clamp(-1, 1)
+    bb_np, bb = random_backbone(net, 0), backbone_random(net, 0)
+    P = PerceptualLoss(model="net-lin", net=net, use_gpu=True, backbone_state=bb_np)
+    lins = [l.cpu() for l in P.lins]
+    P.set_target(x1.cuda())
+    out = torch.zeros(1, device="cuda")
+    P.distance_into(out, x0.cuda())
+    per_tap = P.distance_per_tap(x0.cuda())[:, 0].cpu().numpy()
+    with torch.no_grad():
+        total, layers = lpips_ref(bb, lins, x0, x1, per_layer=True, net=net)
+    ref_layers = np.array([float(v) for v in layers])
+    assert abs(float(out) - float(total)) <= 1e-3 * abs(float(total)), (float(out), float(total))
+    assert (np.abs(per_tap - ref_layers) <= 1e-3 * np.abs(ref_layers)).all(), (per_tap, ref_layers)
+    assert abs(per_tap.sum() - float(out)) <= 1e-5 * abs(float(out))
+
+
 def test_percept_mse_objective_variant(golden):
     """1024_example_percept_MSE.py:147: total = 0.5 * LPIPS(vgg) + 0.5 * MSE -- coefficient on the perceptual term and the VGG backbone
     inside the loop; every recorded loss equals the separately evaluated terms."""

@@ -99,6 +99,35 @@ def test_ops_refuse_cpu_tensors_and_missing_library(monkeypatch):
         _lib.lib()
 
 
+def test_build_cache_keys_objects_on_flags_compiler_and_source(tmp_path):
+    """morphganformer_amd/build.py names every object after a hash of the compiler banner, the full flag list, the source and the shared
+    headers: an object compiled with a timing-ablation macro (or by another compiler) has ANOTHER name and can never be linked into the
+    product; the experiment build keeps its objects in exp_build/_obj and never reads the product's cache."""
+    import inspect
+    import os
+    from morphganformer_amd import build as B
+    src = os.path.join(B.CSRC, "conv_taps.hip")
+    base = B.object_key(src, B.FLAGS)
+    assert base == B.object_key(src, list(B.FLAGS)) and len(base) == 16
+    assert B.object_key(src, B.FLAGS[:-2] + ["-DMGF_EXP=1"] + B.FLAGS[-2:]) != base
+    assert B.object_key(os.path.join(B.CSRC, "wino3.hip"), B.FLAGS) != base
+    saved = B._compiler_id
+    try:
+        B._compiler_id = (saved or B.compiler_id()) + " (another build)"
+        assert B.object_key(src, B.FLAGS) != base
+    finally:
+        B._compiler_id = saved
+    # the library on disk was linked from exactly the objects the current sources hash to
+    if os.path.exists(B.LIB + ".objs"):
+        want = [f"{s}.{B.object_key(os.path.join(B.CSRC, s), B.FLAGS)}.o" for s in B.SOURCES]
+        assert B._linked_from(B.LIB) == want
+    code = inspect.getsource(B.build_experiment)
+    assert "exp_build" in code and "OBJ" not in code.replace("_obj", "")
+    with open(os.path.join(B.ROOT, "tools", "build_exp.sh")) as f:
+        sh = f.read()
+    assert "cp -u" not in sh.split("set -e")[1] and "csrc/_obj" not in sh
+
+
 def test_product_package_never_imports_oracle():
     pkg = os.path.join(ROOT, "morphganformer_amd")
     for dirpath, _, files in os.walk(pkg):
