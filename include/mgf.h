@@ -29,7 +29,10 @@ enum { MGF_F32 = 0, MGF_F64 = 1, MGF_F16 = 2 };
 enum { MGF_FILTER_SEPARABLE = 2 };
 /* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:15-25) */
 enum { MGF_ACT_LINEAR = 1, MGF_ACT_RELU = 2, MGF_ACT_LRELU = 3, MGF_ACT_TANH = 4, MGF_ACT_SIGMOID = 5,
-       MGF_ACT_ELU = 6, MGF_ACT_SELU = 7, MGF_ACT_SOFTPLUS = 8, MGF_ACT_SWISH = 9 };
+       MGF_ACT_ELU = 6, MGF_ACT_SELU = 7, MGF_ACT_SOFTPLUS = 8, MGF_ACT_SWISH = 9,
+       /* mgf_conv1x1_f32 only: linear in front of the residual add, ReLU behind it -- y = relu((acc + bias) * gain + residual), the residual
+        * blocks of facenet_pytorch's InceptionResnetV1 (`out = relu(conv2d(cat) * scale + x)`) */
+       MGF_ACT_RELU_POST = 10 };
 
 const char* mgf_last_error(void);
 int mgf_version(void);
@@ -391,6 +394,12 @@ int mgf_linear_f32(float* y, const float* x, const float* w, const float* b, int
                    mgf_stream_t stream);
 int mgf_resize_bilinear_f32(float* y, const float* x, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                             mgf_stream_t stream);
+/* Head of the FaceNet embedder the biometric driver calls (facenet_pytorch.InceptionResnetV1, 1024_example_FaceNet_percept.py:30-32,
+ * 147-158; its convolutions are mgf_conv_taps_f32 / mgf_conv1x1_f32 / Winograd launches with eval-mode BatchNorm folded in):
+ *   spatial_mean:  y[p] = mean(x[p, 0:hw])                       (nn.AdaptiveAvgPool2d(1)), nc planes
+ *   l2_normalize:  y[r] = x[r] / max(||x[r]||_2, eps)            (F.normalize(x, p=2, dim=1)), n rows of d floats */
+int mgf_spatial_mean_f32(float* y, const float* x, int32_t nc, int64_t hw, mgf_stream_t stream);
+int mgf_l2_normalize_f32(float* y, const float* x, int32_t n, int32_t d, float eps, mgf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Gradient mode: dLoss/dlatent through the synthesis network -- what torch autograd does for the reference when the loss is

@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGF_LIB_PATH") or os.path.join(HERE, "libmgf_hip.so")     # env override: kernel experiments only
 
 MGF_F32, MGF_F64, MGF_F16 = 0, 1, 2
-ACT_IDS = {"linear": 1, "relu": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5, "elu": 6, "selu": 7, "softplus": 8, "swish": 9}
+ACT_IDS = {"linear": 1, "relu": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5, "elu": 6, "selu": 7, "softplus": 8, "swish": 9,
+           "relu_post": 10}      # mgf_conv1x1_f32 only: ReLU AFTER the residual add
 MAX_TAPS = 9
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
@@ -102,6 +103,8 @@ _SIGS = {
     "mgf_channel_affine_prelu_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),
     "mgf_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "mgf_resize_bilinear_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mgf_spatial_mean_f32": (C.c_int, [vp, vp, i32, i64, vp]),
+    "mgf_l2_normalize_f32": (C.c_int, [vp, vp, i32, i32, f32, vp]),
     "mgf_maxpool_s2_floor_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mgf_maxpool3x3s2_ceil_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "mgf_latent_perturb": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),

@@ -73,6 +73,31 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(float* y, const fl
     }
 }
 
+// y[p] = mean over the hw elements of plane p (nn.AdaptiveAvgPool2d(1) of the InceptionResnetV1 head): one wave per plane, fixed order
+__global__ __launch_bounds__(256) void spatial_mean_kernel(float* y, const float* x, int nc, int64_t hw) {
+    const int pl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pl >= nc) return;
+    const float* xp = x + (int64_t)pl * hw;
+    float a = 0.f;
+    for (int64_t i = lane; i < hw; i += 64) a += xp[i];
+    a = wave_sum(a);
+    if (lane == 0) y[pl] = a / (float)hw;
+}
+
+// y[r] = x[r] / max(||x[r]||_2, eps)  (F.normalize(x, p=2, dim=1)): one workgroup per row
+__global__ __launch_bounds__(256) void l2_normalize_kernel(float* y, const float* x, int d, float eps) {
+    __shared__ float sm[4];
+    const float* xr = x + (int64_t)blockIdx.x * d;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < d; i += 256) a += xr[i] * xr[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    const float nrm = sqrtf(sm[0] + sm[1] + sm[2] + sm[3]);
+    const float inv = 1.f / (nrm > eps ? nrm : eps);
+    for (int i = threadIdx.x; i < d; i += 256) y[(int64_t)blockIdx.x * d + i] = xr[i] * inv;
+}
+
 // ---- gradient mode ----
 // dx = dy * (y > 0 ? 1 : slope[c]) from the PReLU OUTPUT y (valid for positive slopes: sign(y) = sign(pre-activation))
 __global__ __launch_bounds__(256) void prelu_bwd_kernel(float* dx, const float* dy, const float* y, const float* slope, int c, int64_t hw,
@@ -130,6 +155,20 @@ __global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(float* dx, con
 }
 
 }  // namespace
+
+extern "C" int mgf_spatial_mean_f32(float* y, const float* x, int32_t nc, int64_t hw, mgf_stream_t stream) {
+    MGF_REQUIRE(y && x && nc >= 1 && hw >= 1, MGF_EINVAL, "spatial_mean: bad arguments");
+    hipLaunchKernelGGL(spatial_mean_kernel, dim3((unsigned)mgf_cdiv(nc, 4)), dim3(256), 0, (hipStream_t)stream, y, x, nc, hw);
+    MGF_CHECK_LAUNCH("spatial_mean");
+    return MGF_OK;
+}
+
+extern "C" int mgf_l2_normalize_f32(float* y, const float* x, int32_t n, int32_t d, float eps, mgf_stream_t stream) {
+    MGF_REQUIRE(y && x && n >= 1 && d >= 1 && eps > 0.f, MGF_EINVAL, "l2_normalize: bad arguments");
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, y, x, d, eps);
+    MGF_CHECK_LAUNCH("l2_normalize");
+    return MGF_OK;
+}
 
 extern "C" int mgf_prelu_bwd_f32(float* dx, const float* dy, const float* y, const float* slope, int32_t n, int32_t c, int64_t hw,
                                  mgf_stream_t stream) {

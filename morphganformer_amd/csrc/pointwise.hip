@@ -186,8 +186,12 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
     }
     // (two instantiations behind one wave-uniform branch: without a residual the loop used to issue its 64 residual loads all the same --
     // against the zero-size resource -- and every store waited for one of them)
-    auto store_rows = [&](auto res_tag) {
+    // MGF_ACT_RELU_POST: the ReLU comes AFTER the residual add, y = relu((acc + bias) * gain + residual) -- the residual blocks of
+    // InceptionResnetV1 (`out = relu(conv(cat) * scale + x)`); its own instantiation, so the other launches keep their instruction count
+    const bool post_relu = do_ep && p.ep.act == MGF_ACT_RELU_POST;
+    auto store_rows = [&](auto res_tag, auto post_tag) {
         constexpr bool RES = decltype(res_tag)::value;
+        constexpr bool POST = decltype(post_tag)::value;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
                     if (RES) {
                         const float4 q = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrr, pvo[0] | lane_ok, soff, 0));
                         o = make_float4(v[0] + q.x, v[1] + q.y, v[2] + q.z, v[3] + q.w);
+                        if (POST) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), ryr, pvo[0] | lane_ok, soff, 0);
                 } else {
@@ -219,14 +224,16 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
                     for (int j = 0; j < 4; ++j) {
                         float o = v[j];
                         if (RES) o += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrr, pvo[j] | lane_ok, soff, 0));
+                        if (RES && POST) o = fmaxf(o, 0.f);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ryr, pvo[j] | lane_ok, soff, 0);
                     }
                 }
             }
         }
     };
-    if (resp) store_rows(std::true_type{});
-    else store_rows(std::false_type{});
+    if (resp && post_relu) store_rows(std::true_type{}, std::true_type{});
+    else if (resp) store_rows(std::true_type{}, std::false_type{});
+    else store_rows(std::false_type{}, std::false_type{});
 }
 
 // cout <= 4 (ToRGB outside the fused conv_last launch: gradient mode, odd sizes): the layer is a weighted sum of the channel rows,
@@ -372,8 +379,10 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
     MGF_REQUIRE(((int64_t)cin + 4 * PWKU) * hw * 4 + 4096 <= (int64_t)UINT32_MAX && ((int64_t)cin + 4 * PWKU) * cout_pad * 4 + 4096 <= (int64_t)UINT32_MAX,
                 MGF_ETOOBIG, "conv1x1: one sample / the weight image must stay below 4 GiB (32-bit buffer offsets)");
     if (ep) {
-        MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU, MGF_EUNSUPPORTED,
-                    "conv1x1: epilogue activation %d unsupported", ep->act);
+        MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU || ep->act == MGF_ACT_RELU_POST,
+                    MGF_EUNSUPPORTED, "conv1x1: epilogue activation %d unsupported", ep->act);
+        MGF_REQUIRE(ep->act != MGF_ACT_RELU_POST || (ep->residual && cout > 4 && cin > 4), MGF_EUNSUPPORTED,
+                    "conv1x1: MGF_ACT_RELU_POST (ReLU after the residual add) needs a residual and the GEMM form (more than 4 channels on both sides)");
         MGF_REQUIRE(!ep->noise, MGF_EUNSUPPORTED, "conv1x1: no noise input (the tap-list kernel has it)");
         MGF_REQUIRE(ep->act != MGF_ACT_LRELU || (ep->alpha >= 0.f && ep->alpha <= 1.f), MGF_EUNSUPPORTED,
                     "conv1x1: leaky-ReLU slope %g outside [0, 1] (the epilogue forms max(t, slope t))", (double)ep->alpha);

@@ -101,6 +101,14 @@ class IResNetEmbedder:
         self.fc_w, self.fc_b = t32(wf), t32(np.asarray(sd["fc.bias"], dtype=np.float64) * sf + tf)
         self._alloc(n)
 
+    def clone_for(self, n):
+        """An instance sharing the packed weights but no mutable workspace (BiometricLoss keeps one for the target images)."""
+        other = IResNetEmbedder.__new__(IResNetEmbedder)
+        other.__dict__.update({k: v for k, v in self.__dict__.items()
+                               if k not in ("bufs", "x112", "stem_out", "flat", "out") and not k.startswith("_g")})
+        other._alloc(n)
+        return other
+
     def _alloc(self, n):
         self.n = n
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)
@@ -248,22 +256,29 @@ class BiometricLoss:
     """loss[i] = MSE(embed(pred[i]), embed(target)) like `MSE(img_gen_fea, img_fea)` (1024_example_FaceNet_percept.py:147-158);
     the target embedding is computed once per target (the reference recomputes it every step)."""
 
-    def __init__(self, embedder: IResNetEmbedder):
+    def __init__(self, embedder="iresnet50", **kw):
+        """embedder: an embedder object (IResNetEmbedder, facenet.InceptionResnetV1Embedder) or a name -- "facenet": the network the
+        driver scores with, on the un-resized image (1024_example_FaceNet_percept.py:30-32,147-158); "iresnet18/34/50/100": the vendored
+        ArcFace network on a 112x112 resize (backbones/iresnet.py).  kw (state=, n=, device=, seed=) go to the embedder's constructor."""
+        if isinstance(embedder, str):
+            if embedder == "facenet":
+                from .facenet import InceptionResnetV1Embedder
+                embedder = InceptionResnetV1Embedder(**kw)
+            elif embedder.startswith("iresnet"):
+                embedder = IResNetEmbedder(depth=int(embedder[len("iresnet"):]), **kw)
+            else:
+                raise ValueError(f"unknown embedder {embedder!r} (facenet, iresnet18/34/50/100)")
         self.embedder = embedder
         self._target = None
         self._target_stride = 0
-        self._tgt_net = None
+        self._tgt_net, self._tgt_nt = None, None
         self._scratch = None
 
     def set_target(self, target):
         """One target [1,3,H,W] shared by every candidate, or B targets that pair up with B candidates (lockstep projections)."""
         nt = int(target.shape[0])
-        if self._tgt_net is None or self._tgt_net.n != nt:       # an instance sharing nothing mutable with the candidates' workspace
-            e = self.embedder
-            self._tgt_net = IResNetEmbedder.__new__(IResNetEmbedder)
-            self._tgt_net.__dict__.update({k: v for k, v in e.__dict__.items()
-                                           if k not in ("bufs", "x112", "stem_out", "flat", "out") and not k.startswith("_g")})
-            self._tgt_net._alloc(nt)
+        if self._tgt_net is None or self._tgt_nt != nt:           # an instance sharing nothing mutable with the candidates' workspace
+            self._tgt_net, self._tgt_nt = self.embedder.clone_for(nt), nt
         emb = self._tgt_net.embed_image(target.float())
         old = getattr(self, "_target", None)
         if old is not None and old.shape == emb.shape:

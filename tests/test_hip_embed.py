@@ -86,3 +86,97 @@ def test_biometric_loss_vs_oracle_and_in_the_loop(golden, depth):
     with torch.no_grad():
         want0 = gamma * float(biometric_loss_ref({k: torch.from_numpy(v) for k, v in sd_np.items()}, img0, torch.from_numpy(g["target"]), 18))
     assert abs(extra[0] - want0) < 2e-3 * want0
+
+
+def test_facenet_head_ops_vs_torch():
+    """mgf_spatial_mean_f32 / mgf_l2_normalize_f32 (AdaptiveAvgPool2d(1), F.normalize) and the 1x1 GEMM's ReLU-behind-the-residual
+    epilogue (MGF_ACT_RELU_POST: the closing conv of an InceptionResnetV1 residual block) against torch in float64."""
+    from morphganformer_amd import _lib, conv as cv
+    L, st = _lib.lib(), _lib.stream_ptr()
+    torch.manual_seed(1)
+    x = torch.randn(3, 7, 30, 29)
+    xd, m = x.cuda(), torch.empty(21).cuda()
+    _lib.check(L.mgf_spatial_mean_f32(m.data_ptr(), xd.data_ptr(), 21, 30 * 29, st))
+    assert float((m.cpu().double() - x.double().mean((2, 3)).reshape(-1)).abs().max()) < 1e-6
+    v = torch.randn(5, 512)
+    v[3] = 0                                                              # a zero row: eps keeps it zero, like F.normalize
+    vd, o = v.cuda(), torch.empty(5, 512).cuda()
+    _lib.check(L.mgf_l2_normalize_f32(o.data_ptr(), vd.data_ptr(), 5, 512, 1e-12, st))
+    assert float((o.cpu().double() - torch.nn.functional.normalize(v.double(), p=2, dim=1)).abs().max()) < 1e-6
+    for (cin, cout, hw) in ((96, 256, (25, 25)), (256, 896, (14, 14)), (384, 1792, (6, 7))):
+        xx, w, b, r = torch.randn(2, cin, *hw), torch.randn(cout, cin, 1, 1) / cin ** 0.5, torch.randn(cout), torch.randn(2, cout, *hw)
+        pc = cv.pack_weights(w.cuda())
+        rd, bd = r.cuda(), b.cuda()
+        y = cv.conv_forward(xx.cuda(), pc, epilogue=_lib.make_epilogue(bias=bd, act="relu_post", residual=rd))
+        want = torch.relu(torch.nn.functional.conv2d(xx.double(), w.double(), b.double()) + r.double())
+        assert float((y.cpu().double() - want).abs().max()) < 2e-5 * float(want.abs().max()), (cin, cout)
+        assert float(y.min()) == 0.0
+    with pytest.raises(_lib.MgfError, match="RELU_POST"):
+        cv.conv_forward(xx.cuda(), pc, epilogue=_lib.make_epilogue(bias=bd, act="relu_post"))          # no residual: refused
+
+
+@pytest.mark.parametrize("n,size", [(2, 160), (3, (99, 131)), (1, 1024)])
+def test_facenet_inception_resnet_v1_vs_oracle(n, size):
+    """facenet.InceptionResnetV1Embedder -- the network 1024_example_FaceNet_percept.py:30-32 scores with, fed the UN-RESIZED image
+    (:147-158) -- against the oracle's restatement of the published facenet_pytorch topology on seeded weights: embedding <= 1e-3, the
+    stage outputs <= 1e-4 (160^2: all Winograd / tap-list / 1x1 / pool launches; an odd non-square size; the driver's 1024^2).
+    Parity with the real package is UNPINNED (absent offline)."""
+    from morphganformer_amd.facenet import InceptionResnetV1Embedder, random_state, conv_gflop
+    from oracle.embed_ref import inception_resnet_v1_ref
+    h, w = (size, size) if isinstance(size, int) else size
+    torch.manual_seed(h + w)
+    x = (torch.rand(n, 3, h, w) * 2 - 1)
+    x = (torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect"), 3, 1) * 1.7).clamp(-1, 1)
+    sd_np = random_state(3)
+    net = InceptionResnetV1Embedder(sd_np, n=n)
+    emb = net(x.cuda()).cpu()
+    taps = {}
+    with torch.no_grad():
+        want = inception_resnet_v1_ref({k: torch.from_numpy(v) for k, v in sd_np.items()}, x, taps)
+    assert tuple(emb.shape) == (n, 512)
+    assert float((emb.norm(dim=1) - 1).abs().max()) < 1e-5
+    got_taps = {"stem": net.bufs["stem"][-1], "repeat_1": net.bufs["stages"][0]["x"][0], "repeat_2": net.bufs["stages"][2]["x"][1],
+                "block8": net.bufs["stages"][4]["x"][1]}
+    for k, t in got_taps.items():
+        assert tuple(t.shape) == tuple(taps[k].shape), k
+        assert float((t.cpu() - taps[k]).abs().max()) < 1e-4 * float(taps[k].abs().max()), k
+    assert float((emb - want).abs().max()) < 1e-3 * float(want.abs().max())
+    if h == 1024:
+        assert 160 < conv_gflop(h, w) < 170                        # 164.6 GFLOP per 1024^2 image: what config 3's biometric term costs
+    # a second call with another batch size re-allocates and gives the same rows
+    if n > 1:
+        e1 = net(x[1:2].cuda()).cpu()
+        assert float((e1[0] - emb[1]).abs().max()) < 1e-5
+
+
+def test_facenet_biometric_term_in_the_loop(golden):
+    """BiometricLoss(embedder="facenet") inside the literal loop on the 256^2 generator (config 3's four-term objective with the embedder
+    the driver calls): every recorded loss against beta * MSE + gamma * facenet_loss_ref of the oracle, best step = argmin."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.facenet import random_state
+    from morphganformer_amd.iresnet import BiometricLoss
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    from morphganformer_amd.synth_weights import SMALL256, make_state_dict
+    from oracle.embed_ref import facenet_loss_ref
+    from oracle.loss_ref import mse_ref
+    g = golden("loop_config0_256.npz")
+    G = Generator(make_state_dict(SMALL256, seed=0), SMALL256, "cuda", max_batch=1)
+    target = torch.from_numpy(g["target_u8"]).float().div(255).sub(0.5).div(0.5)[None].cuda()
+    steps, gamma, batch = 5, 10.0, 3
+    sd_np = random_state(5)
+    bio = BiometricLoss("facenet", state=sd_np, n=batch)
+    eng = ProjectionEngine(G, target, torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]),
+                           ProjectionArgs(step=steps, min_loss_init=1e30), eps=torch.from_numpy(g["eps"][:steps]).cuda(),
+                           noise_mode="const", batch=batch, biometric=bio, gamma=gamma)
+    lat, bstep, bloss, losses = eng.run().result()
+    tsd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    for i in range(steps):
+        sigma = np.float32(np.float32(float(g["latent_std"])) * np.float32(0.05)) * np.float32(max(0, 1 - (i / steps) / 0.75) ** 2)
+        z = torch.from_numpy(g["latent_mean"])[None] + torch.from_numpy(g["eps"][i]) * float(sigma)
+        img = G(z.cuda(), None, noise_mode="const")[0].cpu()
+        with torch.no_grad():
+            want = float(mse_ref(img, target.cpu())) + gamma * float(facenet_loss_ref(tsd, img, target.cpu()))
+        assert abs(losses[i] - want) < 1e-3 * abs(want), (i, losses[i], want)
+    assert bstep == int(np.argmin(losses))
+    with pytest.raises(NotImplementedError):
+        bio.grad_into(torch.zeros_like(target))
