@@ -546,14 +546,19 @@ int mgf_linear_bwd_f32(float* dx, const float* dy, const float* w, int32_t n, in
 int mgf_resize_bilinear_bwd_f32(float* dx, const float* dy, int32_t nc, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                                 mgf_stream_t stream);
 
-/* Landmark-Delaunay warp post-process (1024_warp_morphs.py:78-113,163-210): every output pixel takes the LAST triangle of the list whose
- * integer polygon tri_xy[t] = {x0,y0,x1,y1,x2,y2} (the floor of the averaged-landmark mesh vertices, boundary included, as
- * cv2.fillConvexPoly(np.int32(...)) fills it) covers it, maps its coordinates through dst_to_src[t] = {a,b,tx, c,d,ty} (the inverse
- * of cv2.getAffineTransform(srcTri, dstTri)) and samples src [c,h,w] bilinearly with BORDER_REFLECT_101; pixels outside every
- * triangle get `background`.  Not reproduced (OpenCV is absent offline, parity with it is unpinned): warpAffine's 1/32-pixel fixed-point
- * coordinates, the LINE_AA blend along triangle edges, and the reflection at the per-triangle PATCH border instead of the image border. */
-int mgf_piecewise_affine_warp_f32(float* out, const float* src, const int32_t* tri_xy, const float* dst_to_src, int32_t ntri, int32_t c,
-                                  int32_t h, int32_t w, float background, mgf_stream_t stream);
+/* Landmark-Delaunay warp post-process (1024_warp_morphs.py:78-113,163-210): per triangle of the mesh the script pastes
+ * cv2.warpAffine(patch, INTER_LINEAR, BORDER_REFLECT_101) through a cv2.fillConvexPoly mask, later triangles over earlier ones.
+ *   label [h,w] int32:  the index of the triangle that wrote each pixel LAST, -1 = none (drivers.warp_plan rasterises OpenCV's polygon fill
+ *                       -- Bresenham outline + 16.16 scanline edges -- on the host: integer control flow over a few hundred scanlines);
+ *   triangles:          ntri records of mgf_cv_warp_triangle_bytes() bytes, 8-byte aligned: { double im[6] -- the INVERTED 2x3 matrix
+ *                       warpAffine works with; int32 dx, dy -- origin of the destination patch; int32 sx, sy, sw, sh -- the source patch };
+ *   out [c,h,w]:        every labelled pixel = OpenCV's value -- coordinates on the 1/1024 fixed-point grid rounded to 1/32 pixel
+ *                       (INTER_BITS 5, AB_BITS 10, round_delta 16), the 32 x 32 float weight table, four products summed left to right in float,
+ *                       BORDER_REFLECT_101 at the source PATCH -- the others `background` (the script's imgMorph starts at 0).
+ * OpenCV is absent offline: parity with the real library is unpinned; oracle/warp_ref.py transcribes the same published sources. */
+int64_t mgf_cv_warp_triangle_bytes(void);
+int mgf_cv_warp_triangles_f32(float* out, const float* src, const int32_t* label, const void* triangles, int32_t ntri, int32_t c, int32_t h,
+                              int32_t w, float background, mgf_stream_t stream);
 
 /* torch.optim.Adam.step() on the latent (1024_example_wing_loss_perceptual_sqz_MSE.py:146,181-184; defaults betas (0.9, 0.999),
  * eps 1e-8; weight_decay 1e-4 in 1024_example_MSE.py:117), device-resident: lr = lr_table[*step] (the get_lr schedule, :63-68),

@@ -137,7 +137,8 @@ _SIGS = {
     "mgf_prelu_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i64, vp]),
     "mgf_linear_bwd_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "mgf_resize_bilinear_bwd_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
-    "mgf_piecewise_affine_warp_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "mgf_cv_warp_triangle_bytes": (i64, []),
+    "mgf_cv_warp_triangles_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "mgf_adam_step_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, vp]),
     "mgf_mapping_bwd_scratch_floats": (i64, [i32, i32, i32]),
     "mgf_mapping_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -310,40 +310,185 @@ WARP_EXTRA_POINTS = [[0, 0], [0, 341], [0, 682], [0, 1023], [341, 0], [682, 0], 
                      [341, 1023], [682, 1023]]
 
 
-def warp_mesh(points_src, points_dst):
-    """Host side of the Delaunay warp (1024_warp_morphs.py:163-201): triangulate the DESTINATION points with scipy (as the reference
-    does), and per triangle return the integer polygon np.int32(dst triangle) that cv2.fillConvexPoly would fill and the affine map
-    destination -> source (the inverse of cv2.getAffineTransform(srcTri, dstTri)), solved in float64.
-    Returns (tri_xy int32 [T,6], dst_to_src float32 [T,6], simplices [T,3])."""
+# ---- host set-up of the warp: the OpenCV calls of morphTriangle that are integer / 6x6 control work, restated from OpenCV's published sources
+# (4.x: imgproc/src/shapedescr.cpp pointSetBoundingRect, imgwarp.cpp getAffineTransform / warpAffine, core LUImpl, drawing.cpp fillConvexPoly /
+# FillConvexPoly / Line / LineIterator) in closed form; the per-pixel work is the device kernel's (csrc/warp.hip)
+_XY_SHIFT = 16
+
+
+def _cv_bounding_rect(tri):
+    """cv2.boundingRect(np.float32([tri])): floor of the float32 extremes, both ends included."""
+    p = np.asarray(tri, np.float32)
+    lo, hi = np.floor(p.min(0)).astype(np.int64), np.floor(p.max(0)).astype(np.int64)
+    return int(lo[0]), int(lo[1]), int(hi[0] - lo[0] + 1), int(hi[1] - lo[1] + 1)
+
+
+def _cv_affine_inverse(src_tri, dst_tri):
+    """cv2.getAffineTransform(np.float32(src), np.float32(dst)) -- the 6x6 system solved by Gaussian elimination with partial pivoting in
+    double (core LUImpl), whole rows at a time -- followed by warpAffine's inversion of the matrix (no WARP_INVERSE_MAP).  -> iM [6]."""
+    s, d = np.asarray(src_tri, np.float32).astype(np.float64), np.asarray(dst_tri, np.float32).astype(np.float64)
+    a = np.zeros((6, 7))
+    a[0::2, 0:2], a[0::2, 2], a[1::2, 3:5], a[1::2, 5] = s, 1.0, s, 1.0
+    a[0::2, 6], a[1::2, 6] = d[:, 0], d[:, 1]
+    for i in range(6):
+        k = i + int(np.argmax(np.abs(a[i:, i])))              # first maximum, like the `>` scan
+        if abs(a[k, i]) < 1e-14:
+            raise ValueError("warp: degenerate source triangle")
+        if k != i:
+            a[[i, k], i:] = a[[k, i], i:]
+        alpha = a[i + 1:, i] * (-1.0 / a[i, i])
+        a[i + 1:, i + 1:] += alpha[:, None] * a[i, i + 1:][None, :]
+    x = np.zeros(6)
+    for i in range(5, -1, -1):
+        acc = a[i, 6]
+        for k in range(i + 1, 6):
+            acc -= a[i, k] * x[k]
+        x[i] = acc / a[i, i]
+    m = x.copy()
+    det = m[0] * m[4] - m[1] * m[3]
+    det = 1.0 / det if det != 0 else 0.0
+    a11, a22 = m[4] * det, m[0] * det
+    m[0], m[1], m[3], m[4] = a11, m[1] * -det, m[3] * -det, a22
+    b1 = -m[0] * m[2] - m[1] * m[5]
+    b2 = -m[3] * m[2] - m[4] * m[5]
+    m[2], m[5] = b1, b2
+    return m
+
+
+def _cv_line8(p, q):
+    """Pixels of Line(img, p, q, color, 8): LineIterator(connectivity 8, left_to_right) in closed form -- step k of the major axis has made
+    (2 dy k + dx - 1) // (2 dx) minor steps (the iterator's error term steps when the ideal minor coordinate exceeds the current one by MORE
+    than one half)."""
+    (x1, y1), (x2, y2) = (int(p[0]), int(p[1])), (int(q[0]), int(q[1]))
+    if x2 < x1:
+        x1, y1, x2, y2 = x2, y2, x1, y1
+    dx, dy = x2 - x1, y2 - y1
+    ys = -1 if dy < 0 else 1
+    dy = abs(dy)
+    steep = dy > dx
+    major, minor = (dy, dx) if steep else (dx, dy)
+    k = np.arange(major + 1, dtype=np.int64)
+    m = (2 * minor * k + major - 1) // (2 * major) if major > 0 else np.zeros(1, np.int64)
+    return (x1 + m, y1 + ys * k) if steep else (x1 + k, y1 + ys * m)
+
+
+def _cv_fill_convex_poly(height, width, pts):
+    """bool mask [height, width] of the pixels cv2.fillConvexPoly(mask, np.int32(pts), color, lineType=16, shift=0) writes on a non-8U image
+    (LINE_AA falls back to 8-connected there): the Bresenham outline plus FillConvexPoly's scanline spans.  The two edge walkers advance by a
+    constant 16.16 step between vertex rows, so every run of rows between two vertex events is filled at once."""
+    v = [(int(a), int(b)) for a, b in pts]
+    n = len(v)
+    mask = np.zeros((height, width), bool)
+    for i in range(n):
+        xs, ys = _cv_line8(v[i - 1], v[i])
+        mask[ys, xs] = True
+    ymin, ymax = min(p[1] for p in v), max(p[1] for p in v)
+    imin = min(range(n), key=lambda i: (v[i][1], i))
+    if n < 3 or max(p[0] for p in v) < 0 or ymax < 0 or min(p[0] for p in v) >= width or ymin >= height:
+        return mask
+    ymax = min(ymax, height - 1)
+    ed = [[imin, 1, -(1 << _XY_SHIFT), 0, ymin], [imin, n - 1, -(1 << _XY_SHIFT), 0, ymin]]         # idx, di, x, dx, ye
+    edges, y = n, ymin
+    cols = np.arange(width)
+    while y <= ymax:
+        for e in ed:
+            if y >= e[4]:
+                idx0, idx = e[0], (e[0] + e[1]) % n
+                while True:
+                    edges -= 1
+                    if edges < 0:
+                        break
+                    ty = v[idx][1]
+                    if ty > y:
+                        xs, xe = v[idx0][0] << _XY_SHIFT, v[idx][0] << _XY_SHIFT
+                        num, den = (xe - xs) * 2 + (ty - y), 2 * (ty - y)
+                        e[0], e[2], e[3], e[4] = idx, xs, (abs(num) // den) * (1 if num >= 0 else -1), ty      # C division: toward zero
+                        break
+                    idx0, idx = idx, (idx + e[1]) % n
+        if edges < 0:
+            break
+        y_next = min(ed[0][4], ed[1][4], ymax + 1)              # rows [y, y_next): both walkers keep their step
+        y_next = max(y_next, y + 1)
+        k = np.arange(y_next - y, dtype=np.int64)
+        xa, xb = ed[0][2] + k * ed[0][3], ed[1][2] + k * ed[1][3]
+        lo, hi = np.minimum(xa, xb), np.maximum(xa, xb)
+        xx1, xx2 = (lo + (1 << 15)) >> _XY_SHIFT, (hi + (1 << 15)) >> _XY_SHIFT
+        rows = np.arange(y, y_next)
+        ok = (rows >= 0) & (xx2 >= 0) & (xx1 < width)
+        span = (cols[None, :] >= np.maximum(xx1, 0)[:, None]) & (cols[None, :] <= np.minimum(xx2, width - 1)[:, None]) & ok[:, None]
+        mask[rows[ok]] |= span[ok]
+        steps = y_next - y
+        ed[0][2] += steps * ed[0][3]
+        ed[1][2] += steps * ed[1][3]
+        y = y_next
+    return mask
+
+
+def warp_plan(points_src, points_dst, height, width):
+    """Host side of the Delaunay warp (1024_warp_morphs.py:163-203): triangulate the DESTINATION points with scipy (as the script does) and,
+    per triangle in list order, do what morphTriangle does before any pixel is touched -- the two bounding rectangles, the fillConvexPoly
+    mask of np.int32(tRect), cv2.getAffineTransform(np.float32(t1Rect), np.float32(tRect)) inverted as warpAffine inverts it.
+    Returns (label int32 [height, width]: the triangle that writes each pixel LAST, -1 = none; records: one per triangle -- iM [6] float64,
+    destination patch origin, source patch origin and size; simplices)."""
     from scipy.spatial import Delaunay
     ps, pd = np.asarray(points_src, np.float64), np.asarray(points_dst, np.float64)
     simplices = Delaunay(pd).simplices
-    tri_xy = np.zeros((len(simplices), 6), np.int32)
-    maps = np.zeros((len(simplices), 6), np.float64)
+    label = np.full((height, width), -1, np.int32)
+    recs = []
     for t, idx in enumerate(simplices):
-        d, s_ = pd[idx], ps[idx]
-        tri_xy[t] = np.int32(d).reshape(-1)                               # truncation, like np.int32(tRect) (:101)
-        a = np.concatenate([d, np.ones((3, 1))], axis=1)                  # [x y 1] @ M^T = src
-        maps[t] = np.linalg.solve(a, s_).T.reshape(-1)
-    return tri_xy, maps.astype(np.float32), simplices
+        tg, ta = ps[idx], pd[idx]
+        r1, r = _cv_bounding_rect(tg), _cv_bounding_rect(ta)
+        if r[0] < 0 or r[1] < 0 or r[0] + r[2] > width or r[1] + r[3] > height or r1[0] < 0 or r1[1] < 0:
+            raise ValueError("warp: mesh points must lie inside the image (the script's numpy slices would not line up otherwise)")
+        t_rect, t1_rect = ta - np.array(r[:2], np.float64), tg - np.array(r1[:2], np.float64)
+        sw, sh = min(r1[0] + r1[2], width) - r1[0], min(r1[1] + r1[3], height) - r1[1]       # img_G[r1.y : r1.y + r1.h, ...]: numpy clips the slice
+        if sw < 1 or sh < 1:
+            raise ValueError("warp: a source triangle lies outside the image")
+        m = _cv_fill_convex_poly(r[3], r[2], np.int32(t_rect))
+        view = label[r[1]:r[1] + r[3], r[0]:r[0] + r[2]]
+        view[m] = t
+        recs.append((_cv_affine_inverse(np.float32(t1_rect), np.float32(t_rect)), r[0], r[1], r1[0], r1[1], sw, sh))
+    return label, recs, simplices
+
+
+def _pack_warp_records(recs):
+    """The device records of mgf_cv_warp_triangles_f32: { double im[6]; int32 dx, dy, sx, sy, sw, sh }."""
+    size = int(_lib.lib().mgf_cv_warp_triangle_bytes())
+    dt = np.dtype([("im", np.float64, 6), ("geo", np.int32, 6)])
+    assert dt.itemsize == size, (dt.itemsize, size)
+    arr = np.zeros(len(recs), dt)
+    for i, (im, *geo) in enumerate(recs):
+        arr["im"][i], arr["geo"][i] = im, geo
+    return arr
 
 
 def warp_morph(img, points_G, points_avg, background=0.0):
     """Warp the generated morph so that its landmarks `points_G` land on the averaged landmarks `points_avg` (both [P,2] in pixel
-    coordinates, frame points included), the post-process of 1024_warp_morphs.py:163-210 as one gather kernel.
-    img: [1,C,H,W] or [C,H,W] float32 device tensor in ANY value range (the reference works on the 0..255 float BGR image it reads
-    back from the PNG); returns a tensor of the same shape."""
+    coordinates, frame points included): the post-process of 1024_warp_morphs.py:163-210, every pixel computed as OpenCV computes it
+    (fixed-point 1/32-pixel coordinates, float weight table, BORDER_REFLECT_101 at the triangle's source patch, fillConvexPoly's pixel set).
+    img: [1,C,H,W] or [C,H,W] float32 device tensor in ANY value range -- the script works on the 0..255 float BGR image it reads back from
+    the PNG, for which every step is exact; returns imgMorph, a tensor of the same shape (`warp_morph_u8` gives the bytes the script writes)."""
     _lib.require_gpu(img)
     x = img.reshape(-1, *img.shape[-2:]).contiguous().float()
     c, h, w = x.shape
-    tri_xy, maps, _ = warp_mesh(points_G, points_avg)
+    label, recs, _ = warp_plan(points_G, points_avg, h, w)
     dev = x.device
-    t_d = torch.as_tensor(tri_xy, device=dev).contiguous()
-    m_d = torch.as_tensor(maps, device=dev).contiguous()
+    lab_d = torch.as_tensor(label, device=dev).contiguous()
+    rec_d = torch.as_tensor(_pack_warp_records(recs).view(np.uint8).reshape(-1), device=dev).contiguous()
     out = torch.empty_like(x)
-    _lib.check(_lib.lib().mgf_piecewise_affine_warp_f32(out.data_ptr(), x.data_ptr(), t_d.data_ptr(), m_d.data_ptr(), len(tri_xy), c, h, w,
-                                                        float(background), _lib.stream_ptr()), "piecewise_affine_warp")
+    _lib.check(_lib.lib().mgf_cv_warp_triangles_f32(out.data_ptr(), x.data_ptr(), lab_d.data_ptr(), rec_d.data_ptr(), len(recs), c, h, w,
+                                                    float(background), _lib.stream_ptr()), "cv_warp_triangles")
     return out.reshape(img.shape)
+
+
+def warp_morph_u8(img_u8_hwc, points_G, points_avg):
+    """uint8 [H,W,C] in -> uint8 [H,W,C] out, what the script does between cv2.imread and cv2.imwrite (:186-207): np.float32(image), the
+    triangle loop, np.uint8(imgMorph) (truncation)."""
+    a = np.asarray(img_u8_hwc)
+    assert a.dtype == np.uint8 and a.ndim == 3
+    x = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).to("cuda").float()
+    out = warp_morph(x, points_G, points_avg)
+    return out.to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy()           # values in [0, 255]: the cast truncates like np.uint8
 
 
 def second_stage(G, target, w_init, latent_std, lm_target, lm_steps, **kw):

@@ -448,27 +448,43 @@ def test_gradient_entry_points_reject_bad_arguments():
         _lib.check(L.mgf_linear_bwd_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), 17, 4, 4, None))
 
 
-def test_landmark_delaunay_warp_vs_oracle():
-    """the morph warp of 1024_warp_morphs.py as one gather kernel vs the numpy restatement (parity with OpenCV
-    itself is unpinned: cv2 is absent offline, see oracle/loss_ref.py).  Properties: identical point sets give the identity; every
-    pixel is covered (the frame points span the image)."""
+def _warp_points(rng, side, n_inner, jitter):
+    edge = side - 1
+    third = [0, edge // 3, 2 * edge // 3, edge]
+    frame = np.array([[0, v] for v in third] + [[v, 0] for v in third[1:]] + [[edge, v] for v in third[1:]] + [[v, edge] for v in third[1:3]], np.float64)
+    lm1 = rng.integers(side // 8, side - side // 8, (n_inner, 2)).astype(np.float64)
+    lm2 = lm1 + rng.integers(-jitter, jitter + 1, (n_inner, 2))
+    inner_avg = (lm1 + lm2) / 2                                          # averaged integer detections: halves, like torch.div(l1 + l2, 2)
+    inner_G = lm1 + rng.integers(-jitter, jitter + 1, (n_inner, 2))      # dlib detections on the morph: integers
+    return np.concatenate([inner_G, frame]), np.concatenate([inner_avg, frame])
+
+
+@pytest.mark.parametrize("side,n_inner,jitter", [(96, 20, 4), (1024, 68, 12)])
+def test_landmark_delaunay_warp_is_byte_exact_vs_the_opencv_restatement(side, n_inner, jitter):
+    """1024_warp_morphs.py:78-113,163-210 -- per triangle cv2.warpAffine(INTER_LINEAR, BORDER_REFLECT_101) of the
+    bounding-box patch pasted through cv2.fillConvexPoly -- as a host label map + one gather kernel, against oracle/warp_ref.py's literal
+    transcription of the OpenCV sources.  On the uint8 image the script reads back from its PNG every step is exact: imgMorph float values and
+    the written bytes are IDENTICAL (integer work: the bar is bit-exact).  Parity with the real OpenCV is unpinned (cv2 absent offline)."""
     from morphganformer_amd import drivers
-    from oracle.loss_ref import piecewise_affine_warp_ref
-    rng = np.random.Generator(np.random.PCG64(5))
-    h = w = 96
-    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
-    img = np.stack([127 + 100 * np.sin(xx / 7 + c) * np.cos(yy / 9 - c) for c in range(3)])[None].astype(np.float32)      # smooth, 0..255
-    frame = np.array([[0, 0], [0, 47], [0, 95], [47, 0], [95, 0], [95, 47], [95, 95], [47, 95]], np.float64)
-    inner_avg = rng.uniform(12, 84, (20, 2))
-    inner_G = inner_avg + rng.uniform(-4, 4, (20, 2))
-    p_avg, p_G = np.concatenate([inner_avg, frame]), np.concatenate([inner_G, frame])
-    out = drivers.warp_morph(torch.from_numpy(img).cuda(), p_G, p_avg, background=-1.0)
-    tri_xy, maps, simp = drivers.warp_mesh(p_G, p_avg)
-    ref = piecewise_affine_warp_ref(img[0].astype(np.float64), tri_xy, maps, background=-1.0)
-    assert out.shape == (1, 3, h, w)
-    assert np.abs(out[0].cpu().numpy() - ref).max() < 2e-2                   # float32 vs float64 coordinates on 0..255 data
-    assert float(out.min()) >= 0.0                                           # no background pixel: the mesh covers the frame
-    assert np.abs(out[0].cpu().numpy() - img[0]).max() > 5.0                 # ... and it did move something
-    same = drivers.warp_morph(torch.from_numpy(img).cuda(), p_avg, p_avg)
-    assert np.abs(same.cpu().numpy() - img).max() < 2e-2
-    assert len(drivers.WARP_EXTRA_POINTS) == 12 and tri_xy.shape == (len(simp), 6)
+    from oracle import warp_ref as W
+    rng = np.random.Generator(np.random.PCG64(side))
+    yy, xx = np.mgrid[0:side, 0:side].astype(np.float64)
+    img_u8 = np.stack([127 + 100 * np.sin(xx / (7 + c) + c) * np.cos(yy / 9 - c) + rng.integers(-20, 20, (side, side)) for c in range(3)],
+                      axis=-1).clip(0, 255).astype(np.uint8)
+    p_G, p_avg = _warp_points(rng, side, n_inner, jitter)
+    label, recs, simp = drivers.warp_plan(p_G, p_avg, side, side)
+    ref_fn = W.warp_morph_ref if side <= 128 else W.warp_morph_ref_rows
+    ref = ref_fn(img_u8.astype(np.float32), [tuple(p) for p in p_G], [tuple(p) for p in p_avg], simp)
+    src = torch.from_numpy(img_u8.transpose(2, 0, 1).copy()).float().cuda()
+    out = drivers.warp_morph(src, p_G, p_avg)
+    assert tuple(out.shape) == (3, side, side)
+    assert np.array_equal(out.cpu().numpy().transpose(1, 2, 0), ref)                       # imgMorph, float, bit for bit
+    got_u8 = drivers.warp_morph_u8(img_u8, p_G, p_avg)
+    assert got_u8.dtype == np.uint8 and np.array_equal(got_u8, np.uint8(ref))              # the bytes cv2.imwrite gets
+    assert (label >= 0).all() and len(recs) == len(simp)                                   # the frame points span the image: every pixel is written
+    assert np.abs(got_u8.astype(np.int32) - img_u8.astype(np.int32)).max() > 5             # ... and it did move something
+    # a float image in another value range takes the same path (products no longer exact: one rounding per operation, same order)
+    f = (src / 127.5 - 1.0).contiguous()
+    ref_f = ref_fn(f.cpu().numpy().transpose(1, 2, 0), [tuple(p) for p in p_G], [tuple(p) for p in p_avg], simp)
+    assert np.array_equal(drivers.warp_morph(f, p_G, p_avg, background=0.0).cpu().numpy().transpose(1, 2, 0), ref_f)
+    assert len(drivers.WARP_EXTRA_POINTS) == 12

@@ -325,3 +325,73 @@ def test_per_layer_ws_truncation_cutoff_and_att_tensor_vs_reference(golden):
     (gws,) = torch.autograd.grad(loss, wg)
     assert abs(float(loss.detach()) - float(g["loss_ws"])) < 1e-5 * float(g["loss_ws"])
     assert rel(gws, g["grad_ws"]) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ OpenCV warp restatement (oracle/warp_ref.py)
+def test_cv_warp_known_answers_by_hand():
+    """Hand-computed KATs of the OpenCV rules oracle/warp_ref.py restates (no cv2 offline: these pin the RULES, not the library):
+    a 1/64-pixel shift lands on the 1/32 grid by `+16 >> 5` (the tie goes UP), cvRound is half-to-even on the 1/1024 grid, the reflection is
+    BORDER_REFLECT_101 at the PATCH border, fillConvexPoly's pixel set on an axis-aligned right triangle is x + y <= 4 (the last scanline
+    comes from the outline only), np.uint8 truncates."""
+    from oracle import warp_ref as W
+    ramp = (32.0 * np.arange(8, dtype=np.float32))[None, :, None].repeat(3, 0).repeat(1, 2)        # [3, 8, 1]: S[x] = 32 x
+    # src -> dst translation by -1/64 px: dst x reads src x + 1/64 -> fixed point 16/1024 -> (16 + 16) >> 5 = 1/32 -> 32 x + 1 exactly
+    out = W.warp_affine_linear_reflect101(ramp, np.array([[1, 0, -1.0 / 64], [0, 1, 0]]), (6, 3))
+    assert np.array_equal(out[1, :, 0], 32.0 * np.arange(6) + 1)
+    # 15/1024 stays below the tie: (15 + 16) >> 5 = 0 -> the pixel itself
+    out = W.warp_affine_linear_reflect101(ramp, np.array([[1, 0, -15.0 / 1024], [0, 1, 0]]), (6, 3))
+    assert np.array_equal(out[1, :, 0], 32.0 * np.arange(6))
+    # cvRound half-to-even on the 1/1024 grid: 16.5/1024 -> 16 (tie up to 1/32), 15.5/1024 -> 16 as well (even), 14.5 -> 14 (stays)
+    for shift, want in ((16.5, 1.0), (15.5, 1.0), (14.5, 0.0)):
+        out = W.warp_affine_linear_reflect101(ramp, np.array([[1, 0, -shift / 1024], [0, 1, 0]]), (2, 1))
+        assert out[0, 0, 0] == want, (shift, out[0, 0, 0])
+    assert W.cv_round(0.5) == 0 and W.cv_round(1.5) == 2 and W.cv_round(2.5) == 2 and W.cv_round(-0.5) == 0
+    # BORDER_REFLECT_101 at the patch: a 4-wide patch [10 20 30 40], samples at 3.5 and -0.5
+    patch = np.array([10, 20, 30, 40], np.float32)[None, :, None]
+    out = W.warp_affine_linear_reflect101(patch, np.array([[1, 0, -3.5], [0, 1, 0]]), (1, 1))
+    assert out[0, 0, 0] == 35.0                                            # 40 * 1/2 + reflect(4) = 30 * 1/2
+    out = W.warp_affine_linear_reflect101(patch, np.array([[1, 0, 0.5], [0, 1, 0]]), (1, 1))
+    assert out[0, 0, 0] == 15.0                                            # reflect(-1) = 20 * 1/2 + 10 * 1/2
+    assert [W.border_reflect_101(p, 4) for p in (-2, -1, 0, 3, 4, 5, 7)] == [2, 1, 0, 3, 2, 1, 1] and W.border_reflect_101(9, 1) == 0
+    # fillConvexPoly: right triangle (0,0) (4,0) (0,4)
+    m = W.fill_convex_poly(6, 6, [(0, 0), (4, 0), (0, 4)])
+    yy, xx = np.mgrid[0:6, 0:6]
+    assert np.array_equal(m, xx + yy <= 4)
+    # Bresenham, left to right, tie rule: (0,0) -> (4,2) visits y = 0 0 1 1 2?  minor steps when the ideal exceeds by MORE than 1/2: k=1: 0.5 -> 0
+    assert W.line8((0, 0), (4, 2)) == [(0, 0), (1, 0), (2, 1), (3, 1), (4, 2)]
+    assert W.line8((4, 2), (0, 0)) == W.line8((0, 0), (4, 2))             # left_to_right: the same pixels from either end
+    assert W.line8((0, 0), (2, -4)) == [(0, 0), (0, -1), (1, -2), (1, -3), (2, -4)]
+    assert W.bounding_rect_f32([(10.5, 3.0), (12.0, 7.5), (11.25, 4.0)]) == (10, 3, 3, 5)
+    # getAffineTransform + inversion: a pure scale-and-shift has a closed form
+    M = W.get_affine_transform([(0, 0), (4, 0), (0, 4)], [(1, 2), (9, 2), (1, 10)])
+    assert np.allclose(M, [[2, 0, 1], [0, 2, 2]], atol=1e-15)
+    assert np.allclose(W.invert_affine(M), [0.5, 0, -0.5, 0, 0.5, -1.0], atol=1e-15)
+
+
+def test_cv_warp_host_plan_equals_the_literal_transcription():
+    """The product's closed-form host set-up (drivers: Bresenham by formula, scanline runs between vertex rows, row-wise LU) against the
+    oracle's literal one-step-at-a-time transcription: identical pixel sets, bit-identical matrices, on random and degenerate triangles;
+    and the oracle's vectorised patch warp equals its literal per-pixel loop bit for bit."""
+    from morphganformer_amd import drivers as D
+    from oracle import warp_ref as W
+    rng = np.random.Generator(np.random.PCG64(11))
+    for a in range(-6, 7):
+        for b in range(-6, 7):
+            xs, ys = D._cv_line8((3, 2), (3 + a, 2 + b))
+            assert list(zip(xs.tolist(), ys.tolist())) == W.line8((3, 2), (3 + a, 2 + b)), (a, b)
+    tris = [rng.integers(0, 40, (3, 2)) for _ in range(300)]
+    tris += [np.array(t) for t in ([(0, 0), (9, 0), (4, 0)], [(5, 5), (5, 5), (5, 5)], [(0, 3), (7, 3), (2, 9)], [(2, 0), (2, 8), (6, 8)],
+                                    [(0, 0), (39, 39), (0, 39)], [(10, 1), (11, 30), (12, 2)])]
+    for t in tris:
+        assert np.array_equal(D._cv_fill_convex_poly(40, 40, t), W.fill_convex_poly(40, 40, t)), t.tolist()
+    for _ in range(200):
+        s, d = rng.uniform(0, 200, (3, 2)), rng.uniform(0, 200, (3, 2))
+        if abs(np.linalg.det(np.c_[np.float32(s), np.ones(3)])) < 1.0:
+            continue
+        want = W.invert_affine(W.get_affine_transform(np.float32(s), np.float32(d)))
+        assert np.array_equal(D._cv_affine_inverse(np.float32(s), np.float32(d)), want)
+    assert D._cv_bounding_rect([(10.5, 3.0), (12.0, 7.5), (11.25, 4.0)]) == (10, 3, 3, 5)
+    src = rng.integers(0, 256, (9, 11, 3)).astype(np.float32)
+    for _ in range(20):
+        M = np.array([[1, 0, 0], [0, 1, 0]], np.float64) + rng.uniform(-0.6, 0.6, (2, 3)) * np.array([1, 1, 6.0])
+        assert np.array_equal(W.warp_affine_linear_reflect101(src, M, (13, 10)), W.warp_affine_linear_reflect101_rows(src, M, (13, 10)))
