@@ -85,6 +85,11 @@ def parse():
                          "this many 1024^2 targets with ONE engine re-targeted in place, timed end to end INCLUDING the set-up (latent statistics, "
                          "LPIPS workspaces, graph capture); rank 0, N=1 only; 0 = skip")
     ap.add_argument("--target-steps", type=int, default=1000, help="loop steps per target in the many-target leg (config 2: 1000)")
+    ap.add_argument("--landmark-callback", choices=["none", "stub"], default="stub",
+                    help="extra leg (rank 0, N=1): the same loop with a HOST landmark detector called on every generated image, as the drivers call "
+                         "dlib (...sqz_MSE.py:159-170) -- the detector is a no-op stub (dlib is closed / absent), so the figure is what the engine's "
+                         "host detour costs: the gray uint8 image built on the device, 1 MB per candidate to pinned host memory, one host->device "
+                         "copy of the landmark rows, two hipGraphs per launch sequence")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank (exercises the N>1 code path)")
     ap.add_argument("--force-launch", action="store_true", help="self-launch through torch.distributed.run even for --gpus 1 (exercises the launcher)")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)      # CPU/gloo dry run of the launcher (tests/)
@@ -323,6 +328,34 @@ def many_targets_leg(cfg, device, G, percept, batch, n_targets, steps):
             "best": res,
             "note": "first call = engine set-up (latent statistics, LPIPS workspaces + target taps, hipGraph capture) + the run; the others "
                     "re-target that engine in place (ProjectionEngine.retarget) and replay its graph"}
+
+
+def landmark_callback_leg(cfg, device, G, percept, target, latent_mean, latent_std, batch, headline):
+    """The loop with a host detector in it (ProjectionEngine(landmark_fn=, landmark_input="gray_u8")): iters/s with a no-op detector."""
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, synthetic_landmarks
+    steps = 64 * batch
+    lm_t, _ = synthetic_landmarks(1, cfg.img_resolution, seed=7)
+    calls = [0]
+
+    def stub(gray):                                    # stands where detector(gray, 1) + predictor(gray, rect) stand; touches the image once
+        calls[0] += 1
+        return lm_t + float(gray[0, 0] & 1)
+
+    eng = ProjectionEngine(G, target, latent_mean, latent_std, ProjectionArgs(step=steps), percept=percept, use_mse=True, lm_target=lm_t,
+                           noise_mode="random", seed=11, use_graph=True, batch=batch, landmark_fn=stub, landmark_input="gray_u8")
+    eng.run(2 * batch)
+    torch.cuda.synchronize()
+    timed = 24 * batch
+    t0 = time.perf_counter()
+    eng.run(timed)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.result()
+    v = timed / dt
+    return {"value": round(v, 2), "unit": "iters/s", "steps": timed, "ms_per_step": round(dt / timed * 1e3, 4), "detector": "no-op stub",
+            "callbacks": calls[0], "input": "gray uint8 [1024,1024] per candidate, built on the device (mgf_reference_gray_u8), pinned host memory",
+            "fraction_of_table_mode": round(v / headline, 4),
+            "note": "a real detector's own time comes on top (dlib: tens of ms per 1024^2 image on one core)"}
 
 
 def pmc_tables():
@@ -594,6 +627,13 @@ def main():
             except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                 out["many_targets"] = {"error": f"{type(exc).__name__}: {exc}"}
                 log(f"many-target leg failed: {exc}")
+        if world == 1 and a.landmark_callback == "stub" and not a.biometric and a.res == 1024:
+            try:
+                out["landmark_callback"] = landmark_callback_leg(cfg, device, G, percept, target, latent_mean, latent_std, a.batch, out["value"])
+                log(f"landmark-callback leg done: {out['landmark_callback']['value']} iters/s")
+            except Exception as exc:        # noqa: BLE001 -- reported in the line instead
+                out["landmark_callback"] = {"error": f"{type(exc).__name__}: {exc}"}
+                log(f"landmark-callback leg failed: {exc}")
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, a.cpu_iters)

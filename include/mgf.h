@@ -379,6 +379,13 @@ int mgf_keep_improvements(float* trail_imgs, const float* imgs, int64_t numel, c
                           mgf_stream_t stream);
 /* uint8 HWC image = clip(rint(x*127.5+127.5), 0, 255) from CHW float (misc.to_pil, misc.py:114-123) */
 int mgf_to_uint8_hwc(uint8_t* out, const float* img, int32_t c, int32_t h, int32_t w, mgf_stream_t stream);
+/* The gray uint8 image the drivers hand to dlib for every generated image (...sqz_MSE.py:159-163): cv2.normalize(img, None, 0, 255,
+ * NORM_MINMAX, CV_8U) over the whole float image -- u8 = clip(rint((double(x) - min) * (255.0 / (max - min)))), 0 for a flat image -- then
+ * cv2.cvtColor(COLOR_BGR2GRAY) applied to RGB-ordered data: gray = (c0 * 1868 + c1 * 9617 + c2 * 4899 + (1 << 13)) >> 14.
+ * img [n,3,h,w] float32 planar (16-byte aligned; a batch needs h*w % 4 == 0) -> gray [n,h,w]; scratch: n * mgf_reference_gray_scratch_floats()
+ * floats.  Per candidate its own min / max, like the per-image call of the driver.  1 MB instead of 12.6 MB per candidate crosses to the host. */
+int64_t mgf_reference_gray_scratch_floats(void);
+int mgf_reference_gray_u8(uint8_t* gray, const float* img, int32_t n, int32_t h, int32_t w, float* scratch, mgf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Biometric branch: the IResNet embedder (backbones/iresnet.py:28-161).  Its convolutions are mgf_conv_taps_f32 launches

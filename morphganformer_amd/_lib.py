@@ -111,6 +111,8 @@ _SIGS = {
     "mgf_select_best": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp, vp, f64, f32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp]),
     "mgf_keep_improvements": (C.c_int, [vp, vp, i64, vp, i32, vp]),
     "mgf_to_uint8_hwc": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "mgf_reference_gray_scratch_floats": (i64, []),
+    "mgf_reference_gray_u8": (C.c_int, [vp, vp, i32, i32, i32, vp, vp]),
     "mgf_bwd_chunks": (i32, [i64]),
     "mgf_layer_act_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, f32, f32, vp]),
     "mgf_channel_dot_f32": (C.c_int, [vp, vp, vp, i32, i32, i64, vp]),

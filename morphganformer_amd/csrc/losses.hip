@@ -362,7 +362,87 @@ __global__ __launch_bounds__(256) void to_uint8_kernel(uint8_t* out, const float
     }
 }
 
+// ---- the gray uint8 image the drivers hand to dlib (...sqz_MSE.py:159-163): cv2.normalize(img, None, 0, 255, NORM_MINMAX, CV_8U) over the
+// WHOLE float image, then cv2.cvtColor(COLOR_BGR2GRAY) on RGB-ordered data.  Two passes per candidate: partial minima / maxima, then the
+// conversion (every block of the second pass first folds the candidate's partials: min / max do not depend on the order).
+constexpr int GRAY_PARTS = 256;
+
+__global__ __launch_bounds__(256) void minmax_partial_kernel(float* part, const float* img, int64_t per) {
+    __shared__ float slo[4], shi[4];
+    const float* x = img + (int64_t)blockIdx.y * per;
+    float lo = INFINITY, hi = -INFINITY;
+    const int64_t n4 = per / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        lo = fminf(fminf(lo, fminf(v.x, v.y)), fminf(v.z, v.w));
+        hi = fmaxf(fmaxf(hi, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) { lo = fminf(lo, x[i]); hi = fmaxf(hi, x[i]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* p = part + ((int64_t)blockIdx.y * GRAY_PARTS + blockIdx.x) * 2;
+        p[0] = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+        p[1] = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+    }
+}
+
+// u8 = clip(rint((double(x) - lo) * (255.0 / (hi - lo)))), the scale 0 for a flat image, exactly the arithmetic of drivers.reference_gray_u8;
+// gray = (c0 * 1868 + c1 * 9617 + c2 * 4899 + (1 << 13)) >> 14: OpenCV's 8-bit BGR2GRAY coefficients (B 1868, G 9617, R 4899) with channel 0 -- RED
+// in the generator's RGB order -- in the blue slot, as the drivers call it.  img [n,3,h,w] planar -> gray [n,h,w]
+__global__ __launch_bounds__(256) void gray_u8_kernel(uint8_t* gray, const float* img, const float* part, int nparts, int64_t hw) {
+    __shared__ float slo[4], shi[4];
+    const int n = blockIdx.y;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < nparts; i += 256) { lo = fminf(lo, part[((int64_t)n * GRAY_PARTS + i) * 2]); hi = fmaxf(hi, part[((int64_t)n * GRAY_PARTS + i) * 2 + 1]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    const double dlo = (double)fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3])), dhi = (double)fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+    const double scale = dhi > dlo ? 255.0 / (dhi - dlo) : 0.0;
+    const float* x = img + (int64_t)n * 3 * hw;
+    uint8_t* g = gray + (int64_t)n * hw;
+    auto q = [&](float v) -> unsigned {
+        double t = rint(__dmul_rn(__dsub_rn((double)v, dlo), scale));
+        t = t < 0.0 ? 0.0 : (t > 255.0 ? 255.0 : t);
+        return (unsigned)t;
+    };
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < hw; i += (int64_t)gridDim.x * 1024) {
+        if (i + 4 <= hw && (hw & 3) == 0) {
+            const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(x + hw + i),
+                         c = *reinterpret_cast<const float4*>(x + 2 * hw + i);
+            const unsigned g0 = (q(a.x) * 1868u + q(b.x) * 9617u + q(c.x) * 4899u + (1u << 13)) >> 14;
+            const unsigned g1 = (q(a.y) * 1868u + q(b.y) * 9617u + q(c.y) * 4899u + (1u << 13)) >> 14;
+            const unsigned g2 = (q(a.z) * 1868u + q(b.z) * 9617u + q(c.z) * 4899u + (1u << 13)) >> 14;
+            const unsigned g3 = (q(a.w) * 1868u + q(b.w) * 9617u + q(c.w) * 4899u + (1u << 13)) >> 14;
+            *reinterpret_cast<uint32_t*>(g + i) = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+        } else {
+            for (int64_t j = i; j < hw && j < i + 4; ++j)
+                g[j] = (uint8_t)((q(x[j]) * 1868u + q(x[hw + j]) * 9617u + q(x[2 * hw + j]) * 4899u + (1u << 13)) >> 14);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int64_t mgf_reference_gray_scratch_floats(void) { return 2 * GRAY_PARTS; }
+
+extern "C" int mgf_reference_gray_u8(uint8_t* gray, const float* img, int32_t n, int32_t h, int32_t w, float* scratch, mgf_stream_t stream) {
+    MGF_REQUIRE(gray && img && scratch && n >= 1 && n <= 65535 && h >= 1 && w >= 1, MGF_EINVAL, "reference_gray_u8: bad arguments");
+    MGF_REQUIRE(((uintptr_t)img % 16) == 0 && ((uintptr_t)gray % 4) == 0, MGF_EINVAL, "reference_gray_u8: img must be 16-byte, gray 4-byte aligned");
+    const int64_t hw = (int64_t)h * w, per = 3 * hw;
+    MGF_REQUIRE(per % 4 == 0 || n == 1, MGF_EINVAL, "reference_gray_u8: a batch needs 16-byte aligned samples (3 h w a multiple of 4)");
+    const int parts = (int)(mgf_cdiv(per, 256 * 16) < GRAY_PARTS ? mgf_cdiv(per, 256 * 16) : GRAY_PARTS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(parts, n), dim3(256), 0, st, scratch, img, per);
+    const int blocks = (int)(mgf_cdiv(hw, 1024 * 4) < 1024 ? mgf_cdiv(hw, 1024 * 4) : 1024);
+    hipLaunchKernelGGL(gray_u8_kernel, dim3(blocks < 1 ? 1 : blocks, n), dim3(256), 0, st, gray, img, scratch, parts, hw);
+    MGF_CHECK_LAUNCH("reference_gray_u8");
+    return MGF_OK;
+}
 
 extern "C" int64_t mgf_reduce_scratch_floats(void) { return RED_BLOCKS; }
 

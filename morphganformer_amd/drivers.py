@@ -149,10 +149,10 @@ DEFAULT_BATCH = 32       # loop steps per generator forward in literal mode: the
 def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None,
                   eps=None, out_prefix=None, batch=DEFAULT_BATCH, use_graph=True, noise_mode="random", use_mse=True, seed=None,
                   landmark_fn=None, mode="literal", weight_decay=0.0, path_to_gen=None, keep_images=64, engine=None,
-                  return_engine=False, latent_space="z"):
+                  return_engine=False, latent_space="z", landmark_input="float"):
     """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and either
     `lm_steps` [steps,68,2] (injected landmark detections) or `landmark_fn` (host detector called on every generated image,
-    see ProjectionEngine).  mode="literal" is the loop as the reference executes it (best-of-N noisy sampling, `batch` steps per
+    see ProjectionEngine; landmark_input="gray_u8" hands it the drivers' gray uint8 image, built on the device).  mode="literal" is the loop as the reference executes it (best-of-N noisy sampling, `batch` steps per
     forward -- 32 by default, the benchmarked configuration; the result does not depend on it); mode="gradient" back-propagates the
     loss into the latent and lets Adam move it (GradientProjectionEngine; one candidate per step; weight_decay=1e-4 is the
     1024_example_MSE.py:117 optimizer; latent_space="w+" optimises the per-layer intermediate latent [k, num_ws, D] instead of z -- the
@@ -203,7 +203,7 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
     else:
         eng = ProjectionEngine(G, target, latent_mean, float(latent_std), args, percept=percept, lm_target=lm_target,
                                lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse,
-                               landmark_fn=landmark_fn, keep_images=keep, seed=0 if seed is None else seed)
+                               landmark_fn=landmark_fn, keep_images=keep, seed=0 if seed is None else seed, landmark_input=landmark_input)
     w, step, loss, losses = eng.run().result()
     out = {"w": w, "step": step, "loss": loss, "losses": losses}
     if out_prefix is not None:

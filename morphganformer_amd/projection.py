@@ -114,7 +114,7 @@ class ProjectionEngine:
     def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True,
                  lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, batch=1,
                  landmark_fn=None, biometric=None, gamma=1.0, wing_kind="wing", landmark_model=None, pipeline=False, keep_images=0,
-                 latent_shape=None):
+                 latent_shape=None, landmark_input="float"):
         """batch = number of consecutive loop steps evaluated per generator forward.  In literal mode the steps do not depend
         on each other (latent_in never changes), so evaluating `batch` candidates at once and examining them in step order
         gives exactly the sequential loop's result while the small 4x4..64x64 layers, the mapping network and the LPIPS tail
@@ -145,7 +145,14 @@ class ProjectionEngine:
         landmark_fn: optional host callback `f(img_hwc float32 numpy [H,W,3]) -> [68,2] array or None` standing where the
         drivers call dlib on every generated image (:159-170; `drivers.reference_gray_u8` reproduces their cv2 normalise +
         gray conversion).  With it the landmark table is filled step by step (None = "no face", the step is skipped) at
-        the price of one device->host image copy and a host call per candidate, and graph replay is off."""
+        the price of one device->host image copy and a host call per candidate, and graph replay is off.
+
+        landmark_input: what `landmark_fn` is handed.  "float": the float32 [H,W,3] image (12.6 MB per candidate at 1024^2 crosses to the
+        host, the caller converts it itself).  "gray_u8": the uint8 [H,W] gray image the drivers build for dlib (:159-163, cv2.normalize +
+        BGR2GRAY on RGB data), made ON THE DEVICE (mgf_reference_gray_u8, bit-identical to drivers.reference_gray_u8) and copied into
+        pinned host memory -- 1 MB per candidate -- and the launch sequence stays two captured hipGraphs with the host detour between
+        them: {perturb, generator, gray image, device->host copy} | callbacks, one host->device copy of the landmark rows | {losses,
+        selection}."""
         self.G, self.args = G, args or ProjectionArgs()
         self.batch = int(batch)
         assert self.batch >= 1
@@ -182,11 +189,16 @@ class ProjectionEngine:
             # + batch spare rows: the candidates of a ragged last batch that lie past the final step land there, not on real rows
             lm_steps = np.zeros((a.step + self.batch,) + tuple(np.shape(lm_target)), np.float64)
             lm_valid = np.zeros(a.step + self.batch, np.int32)
+        assert landmark_input in ("float", "gray_u8"), landmark_input
+        self.landmark_input = landmark_input
+        self.callback_graphs = landmark_fn is not None and landmark_input == "gray_u8"
         if landmark_fn is not None:
             assert lm_target is not None, "landmark_fn needs the target image's landmarks (lm_target)"
-            lm_steps = np.zeros((a.step,) + tuple(np.shape(lm_target)), np.float64)
-            lm_valid = np.zeros(a.step, np.int32)
-            use_graph = False
+            spare = self.batch if self.callback_graphs else 0          # (a ragged last batch's surplus candidates land on spare rows)
+            lm_steps = np.zeros((a.step + spare,) + tuple(np.shape(lm_target)), np.float64)
+            lm_valid = np.zeros(a.step + spare, np.int32)
+            if not self.callback_graphs:
+                use_graph = False
         if self.use_wing:
             self.lm_target = torch.as_tensor(lm_target, dtype=torch.float64, device=dev).contiguous()
             self.lm_steps = torch.as_tensor(lm_steps, dtype=torch.float64, device=dev).contiguous()
@@ -226,6 +238,19 @@ class ProjectionEngine:
         self._spilled, self._seq_since_spill, self._trail_lost = [], 0, 0
         self.use_graph = use_graph
         self.graph = None
+        if self.callback_graphs:
+            c, r = G.cfg.img_channels, G.cfg.img_resolution
+            assert c == 3, "the gray conversion is defined on 3-channel images"
+            lshape = tuple(self.lm_target.shape)
+            self.gray_dev = torch.empty(B, r, r, dtype=torch.uint8, device=dev)
+            self.gray_host = torch.empty(B, r, r, dtype=torch.uint8).pin_memory()
+            self.gray_scratch = torch.empty(B * int(_lib.lib().mgf_reference_gray_scratch_floats()), dtype=torch.float32, device=dev)
+            self.lm_stage_host = torch.zeros(B, *lshape, dtype=torch.float64).pin_memory()
+            self.ok_stage_host = torch.zeros(B, dtype=torch.int32).pin_memory()
+            self.lm_stage = torch.zeros(B, *lshape, dtype=torch.float64, device=dev)
+            self.ok_stage = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.cb_graphs = None
+            self._host_step = 0                     # host mirror of step_ctr (the callbacks need the step numbers without a device read)
         self.pipeline = bool(pipeline) and landmark_fn is None
         if self.pipeline:
             if G.n != B:
@@ -289,7 +314,12 @@ class ProjectionEngine:
     def _landmarks(self, img):
         """Fill this batch's rows of the landmark / valid tables when a detector is attached (host callback or device model)."""
         B = self.batch
-        if self.landmark_fn is not None:
+        if self.landmark_fn is not None and self.callback_graphs:
+            # the callbacks ran on the host between the two launch sequences (_run_callback); their rows wait in the device staging buffers
+            idx = self.step_ctr.long() + self._arange
+            self.lm_steps.index_copy_(0, idx, self.lm_stage)
+            self.valid.index_copy_(0, idx, self.ok_stage)
+        elif self.landmark_fn is not None:
             self._detect_landmarks(img)
         if self.landmark_model is not None:
             lm, ok = self.landmark_model(img)
@@ -347,6 +377,71 @@ class ProjectionEngine:
             else:
                 self._pipe_step(self._parity)
             self._parity ^= 1
+
+    # ------------------------------------------------------------------ callback mode on the gray uint8 image
+    def _cb_phase_a(self):
+        """perturb -> generator -> the drivers' gray uint8 image of every candidate -> pinned host memory (all asynchronous)."""
+        img = self._gen_phase(self.latent_n, self.step_ctr)
+        n, _, h, w = img.shape
+        _lib.check(_lib.lib().mgf_reference_gray_u8(self.gray_dev.data_ptr(), img.data_ptr(), n, h, w, self.gray_scratch.data_ptr(),
+                                                    _lib.stream_ptr()), "reference_gray_u8")
+        self.gray_host.copy_(self.gray_dev, non_blocking=True)
+        return img
+
+    def _cb_phase_b(self):
+        self._loss_phase(self.G.img, self.latent_n)
+
+    def _cb_capture(self):
+        state = [t.clone() for t in self._state()]
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self._cb_phase_a()
+            self._cb_phase_b()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self._cb_phase_a()
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            self._cb_phase_b()
+        for dst, src in zip(self._state(), state):
+            dst.copy_(src)
+        if self.use_wing:
+            self.lm_steps.zero_()
+            self.valid.zero_()
+        self.cb_graphs = (ga, gb)
+        self._pin_workspace()
+
+    def _run_callback(self, n):
+        """`n` launch sequences of the callback mode: phase A, one stream synchronisation, the host detector on every candidate's gray image
+        (in step order; None = "no face", the step is skipped, :165-166), ONE host->device copy of the batch's landmark rows, phase B."""
+        if self.use_graph and self.cb_graphs is None:
+            self._cb_capture()
+        B, st = self.batch, torch.cuda.current_stream(self.device)
+        for _ in range(n):
+            self._before_sequence()
+            if self.cb_graphs is not None:
+                self.cb_graphs[0].replay()
+            else:
+                self._cb_phase_a()
+            st.synchronize()
+            s0 = self._host_step
+            gray = self.gray_host.numpy()
+            self.ok_stage_host.zero_()
+            for j in range(min(B, self.steps - s0)):
+                lm = self.landmark_fn(gray[j])
+                if lm is None:
+                    continue
+                self.lm_stage_host[j].copy_(torch.as_tensor(np.asarray(lm, dtype=np.float64).reshape(self.lm_target.shape)))
+                self.ok_stage_host[j] = 1
+            self.lm_stage.copy_(self.lm_stage_host, non_blocking=True)
+            self.ok_stage.copy_(self.ok_stage_host, non_blocking=True)
+            if self.cb_graphs is not None:
+                self.cb_graphs[1].replay()
+            else:
+                self._cb_phase_b()
+            self._host_step = min(s0 + B, self.steps)
 
     def _detect_landmarks(self, img):
         """Host detour of the callback mode: hand every candidate image of this batch to `landmark_fn`, in step order."""
@@ -449,6 +544,9 @@ class ProjectionEngine:
         if self.pipeline:
             self._run_pipelined(n)
             return self
+        if self.callback_graphs:
+            self._run_callback(n)
+            return self
         if self.use_graph and self.graph is None:
             self._capture()
         for _ in range(n):
@@ -520,6 +618,8 @@ class ProjectionEngine:
             self.trail_steps.fill_(-1)
             self.trail_losses.zero_()
         self._spilled, self._seq_since_spill, self._trail_lost = [], 0, 0
+        if self.callback_graphs:
+            self._host_step = 0
         if self.pipeline:
             self.gen_ctr.zero_()
             self._parity, self._primed = 0, False
@@ -613,6 +713,7 @@ class GradientProjectionEngine(ProjectionEngine):
         assert tuple(self.eps.shape) == (self.eps.shape[0], B, *ls) and self.eps.shape[0] >= a.step
         assert wing_kind in ("wing", "awing")
         self.wing_kind, self.landmark_fn, self.landmark_model = wing_kind, None, None
+        self.landmark_input, self.callback_graphs = "float", False
         if self.use_wing:
             self.lm_target = torch.as_tensor(lm_target, dtype=torch.float64, device=dev).contiguous()           # [B,68,2]
             self.lm_steps = torch.as_tensor(lm_steps, dtype=torch.float64, device=dev).contiguous()             # [B,steps,68,2]

@@ -242,6 +242,73 @@ def test_landmark_callback_mode_equals_injected_table(golden):
     assert np.allclose(np.nan_to_num(hist1), np.nan_to_num(hist2), rtol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 64), (3, 96, 132), (2, 1024, 1024), (1, 5, 7)])
+def test_reference_gray_u8_on_the_device_is_bit_exact(shape):
+    """mgf_reference_gray_u8 -- cv2.normalize(NORM_MINMAX, CV_8U) + BGR2GRAY on RGB data, per candidate (...sqz_MSE.py:159-163) -- against
+    drivers.reference_gray_u8 (the numpy statement with its hand-checked KAT, tests/test_host_and_abi.py): every byte equal; a flat image -> 0."""
+    from morphganformer_amd import _lib, drivers
+    n, h, w = shape
+    torch.manual_seed(h * w)
+    img = torch.randn(n, 3, h, w) * torch.tensor([0.5, 1.0, 2.0][:n] if n <= 3 else 1.0).reshape(-1, 1, 1, 1)
+    img[0, :, 0, 0] = 0.0
+    if n > 1:
+        img[1] = 0.25                                                     # a flat candidate: max == min
+    x = img.cuda().contiguous()
+    gray = torch.empty(n, h, w, dtype=torch.uint8, device="cuda")
+    scratch = torch.empty(n * int(_lib.lib().mgf_reference_gray_scratch_floats()), device="cuda")
+    _lib.check(_lib.lib().mgf_reference_gray_u8(gray.data_ptr(), x.data_ptr(), n, h, w, scratch.data_ptr(), _lib.stream_ptr()))
+    for i in range(n):
+        want = drivers.reference_gray_u8(img[i].permute(1, 2, 0).numpy())
+        assert np.array_equal(gray[i].cpu().numpy(), want), i
+    # the KAT of the numpy statement, through the kernel
+    kat = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0], [1.0, -1.0, 0.0], [0.0, 0.0, 0.0]]).t().reshape(1, 3, 2, 2).contiguous().cuda()
+    g4 = torch.empty(1, 2, 2, dtype=torch.uint8, device="cuda")
+    _lib.check(_lib.lib().mgf_reference_gray_u8(g4.data_ptr(), kat.data_ptr(), 1, 2, 2, scratch.data_ptr(), _lib.stream_ptr()))
+    assert g4.cpu().reshape(-1).tolist()[:3] == [0, 255, 67]
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_landmark_callback_on_gray_u8_equals_injected_table(golden, use_graph):
+    """landmark_input="gray_u8": the detector gets the drivers' gray uint8 image, built on the device and copied to pinned host memory
+    between two captured launch sequences; the run equals the run on the table the callbacks produced, ragged last batch included, and
+    a re-targeted engine starts again at step 0."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    g = golden("loop_tiny.npz")
+    steps = 10
+    seen = []
+    G = _tiny_G()
+
+    def detector(gray):
+        assert gray.shape == (64, 64) and gray.dtype == np.uint8
+        k = len(seen)
+        seen.append(gray.copy())
+        if k % 10 in (2, 5):
+            return None
+        return g["lm_target"] + (gray[:34, :4].astype(np.float64) / 8).round().reshape(68, 2)
+
+    def make(**kw):
+        return ProjectionEngine(G, torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["latent_mean"]).cuda(),
+                                float(g["latent_std"]), ProjectionArgs(step=steps), use_mse=True, lm_target=g["lm_target"],
+                                eps=torch.from_numpy(g["eps"][:steps]).cuda(), noise_mode="const", **kw)
+    e1 = make(landmark_fn=detector, landmark_input="gray_u8", batch=4, use_graph=use_graph)
+    lat1, st1, loss1, hist1 = e1.run().result()
+    assert len(seen) == steps and (e1.cb_graphs is not None) == use_graph
+    table, valid = e1.lm_steps[:steps].cpu().numpy(), e1.valid[:steps].cpu().numpy()
+    assert valid.tolist() == [1, 1, 0, 1, 1, 0, 1, 1, 1, 1]
+    lat2, st2, loss2, hist2 = make(lm_steps=table, lm_valid=valid, batch=1).run().result()
+    assert st1 == st2 and torch.equal(lat1, lat2) and np.isnan(hist1[2]) and np.isnan(hist1[5])
+    assert np.allclose(np.nan_to_num(hist1), np.nan_to_num(hist2), rtol=1e-6)
+    # what the callback saw IS the numpy statement applied to the generated image of that step
+    sigma0 = np.float32(np.float32(float(g["latent_std"])) * np.float32(0.05))
+    img0 = G((torch.from_numpy(g["latent_mean"])[None] + torch.from_numpy(g["eps"][0]) * float(sigma0)).cuda(), None, noise_mode="const")[0]
+    assert np.array_equal(seen[0], drivers.reference_gray_u8(img0[0].permute(1, 2, 0).cpu().numpy()))
+    # re-target: same target again -> the same run, callbacks called afresh
+    e1.retarget(torch.from_numpy(g["target"]).cuda(), lm_target=g["lm_target"], eps=torch.from_numpy(g["eps"][:steps]).cuda())
+    lat3, st3, loss3, hist3 = e1.run().result()
+    assert len(seen) == 2 * steps and st3 == st1 and torch.equal(lat3, lat1) and loss3 == loss1
+
+
 def test_cli_generate_project_morph(tmp_path):
     from morphganformer_amd import cli, drivers
     from morphganformer_amd.projection import synthetic_landmarks
