@@ -73,6 +73,14 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--biometric", type=int, default=0, metavar="DEPTH",
                     help="add the IResNet-DEPTH embedding-MSE term (BASELINE config 3's full objective); 0 = the config-2 objective")
+    ap.add_argument("--lpips-net", choices=["squeeze", "vgg", "alex"], default="squeeze",
+                    help="LPIPS backbone of the timed workload: squeeze = configs[1] (...sqz_MSE.py:258-260, the headline); vgg = the net "
+                         "1024_example_percept_MSE.py:142-147 scores with; alex = 1024_example_percept_improved.py")
+    ap.add_argument("--objectives", type=int, default=1,
+                    help="1 = the extra `objectives` legs (rank 0, N=1): the same literal loop with LPIPS(vgg) and with BASELINE config 3's four-term "
+                         "objective Wing + FaceNet (InceptionResnetV1 on the un-resized 1024^2 image) + LPIPS(squeeze) + MSE -- iters/s, the "
+                         "dominant conv kernel and its executed fraction of the FP32-MFMA peak; 0 = skip")
+    ap.add_argument("--objective-batch", type=int, default=16, help="loop steps per generator forward in the `objectives` legs")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="1 = overlap the losses of batch i with the generator of batch i+1 on two streams (+3 %% iters/s; kernels of the two "
                          "streams then stretch each other, so per-kernel durations -- and the roofline object -- no longer describe a kernel "
@@ -105,7 +113,7 @@ def _late_imports():
         np, torch = numpy, _torch
 
 
-def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0, pipeline=False):
+def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0, pipeline=False, lpips_net="squeeze"):
     _late_imports()
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.lpips import PerceptualLoss
@@ -119,7 +127,7 @@ def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0, pipelin
     gen = torch.Generator(device=device)
     gen.manual_seed(0)
     latent_mean, latent_std = latent_stats(G, 10000, device, gen)
-    percept = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device, allow_random_backbone=True)
+    percept = PerceptualLoss(model="net-lin", net=lpips_net, use_gpu=True, device=device, allow_random_backbone=True)
     lm_t, lm_s = synthetic_landmarks(steps_total, cfg.img_resolution, seed=7 + rank)
     # (seeded random embedder weights give embedding distances far above the drivers' min_loss start of 100)
     args = ProjectionArgs(step=steps_total, min_loss_init=1e30 if biometric else 100.0)
@@ -328,6 +336,44 @@ def many_targets_leg(cfg, device, G, percept, batch, n_targets, steps):
             "best": res,
             "note": "first call = engine set-up (latent statistics, LPIPS workspaces + target taps, hipGraph capture) + the run; the others "
                     "re-target that engine in place (ProjectionEngine.retarget) and replay its graph"}
+
+
+def objective_leg(cfg, device, G, target, latent_mean, latent_std, batch, lpips_net="squeeze", facenet=False, min_seconds=0.6):
+    """One more objective of the north star through the SAME literal loop, timed like the headline (hipGraph replay, whole launch
+    sequences, >= min_seconds): iters/s, HBM in use, and the dominant MFMA conv kernel of its iteration with its executed fraction."""
+    from morphganformer_amd.lpips import PerceptualLoss
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, synthetic_landmarks
+    torch.cuda.reset_peak_memory_stats(device)
+    steps_total = 256 * batch
+    percept = PerceptualLoss(model="net-lin", net=lpips_net, use_gpu=True, device=device, allow_random_backbone=True)
+    bio = None
+    if facenet:
+        from morphganformer_amd.iresnet import BiometricLoss
+        bio = BiometricLoss("facenet", n=batch, device=device, seed=0)
+    lm_t, lm_s = synthetic_landmarks(steps_total, cfg.img_resolution, seed=17)
+    eng = ProjectionEngine(G, target, latent_mean, latent_std, ProjectionArgs(step=steps_total), percept=percept, use_mse=True, lm_target=lm_t,
+                           lm_steps=lm_s, noise_mode="random", seed=21, use_graph=True, batch=batch, biometric=bio, gamma=1.0)
+    eng.run(batch)                                   # capture + one replay
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(batch)
+    torch.cuda.synchronize()
+    per = time.perf_counter() - t0
+    n_seq = max(2, min(200, int(min_seconds / per) + 1))
+    t0 = time.perf_counter()
+    eng.run(n_seq * batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    roof = roofline_leg(eng, iters=1)
+    out = {"value": round(n_seq * batch / dt, 2), "unit": "iters/s", "steps": n_seq * batch, "ms_per_step": round(dt / (n_seq * batch) * 1e3, 4),
+           "steps_per_forward": batch, "hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
+           "dominant_kernel": roof["kernel"], "executed_tflops": roof["achieved"], "executed_frac": roof["frac"],
+           "algorithmic_tflops": roof["algorithmic_achieved"], "avg_launch_us": roof["avg_launch_us"],
+           "launches_per_iter": roof["launches_per_iter"], "conv_ms_per_iter": roof["conv_ms_per_iter"],
+           "mfma_busy": roof.get("mfma_busy")}
+    del eng, percept, bio
+    torch.cuda.empty_cache()
+    return out
 
 
 def landmark_callback_leg(cfg, device, G, percept, target, latent_mean, latent_std, batch, headline):
@@ -542,7 +588,7 @@ def main():
     rup = lambda v: -(-v // a.batch) * a.batch
     cap = max(rup(a.steps), 8192 if a.min_seconds > 0 else 0)            # room to extend the timed region to --min-seconds
     sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, cap + rup(a.warmup) + 3 * a.batch, not a.no_graph, a.batch,
-                                                                      a.biometric, bool(a.pipeline))
+                                                                      a.biometric, bool(a.pipeline), a.lpips_net)
 
     log(f"built generator/LPIPS/engine on {device}; warm-up {a.warmup} steps (includes graph capture)")
     eng.run(a.warmup)
@@ -601,12 +647,13 @@ def main():
         "unit": "iters/s", "n_gpus": world, "steps": steps, "steps_requested": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks, "timed_seconds": round(elapsed, 4), "ranks": rank_stats,
-        "config": {"workload": f"configs[1]: single {a.res}x{a.res} face per GPU, Wing+LPIPS(squeeze)+MSE literal-mode projection step, "
+        "hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
+        "config": {"workload": f"configs[1]: single {a.res}x{a.res} face per GPU, Wing+LPIPS({a.lpips_net})+MSE literal-mode projection step, "
                                "noise_mode=random, seeded synthetic weights/targets/landmarks"
                                + (f" + IResNet-{a.biometric} embedding MSE (config 3 objective)" if a.biometric else ""), "k": cfg.k, "z_dim": cfg.z_dim,
                    "targets_per_gpu": 1, "parallelism": f"pair-sharded x{world}", "graph_replay": not a.no_graph,
                    "loss_generator_overlap": bool(a.pipeline), "steps_per_forward": a.batch,
-                   "lpips_backbone": "seeded random SqueezeNet1.1 weights (torchvision's are a remote fetch) + the reference's vendored lin heads",
+                   "lpips_backbone": f"seeded random {a.lpips_net} weights (torchvision's are a remote fetch) + the reference's vendored lin heads",
                    "timed_region": f"{steps} steps = {steps // a.batch} graph replays (>= --min-seconds {a.min_seconds}; requested --steps {a.steps})"},
     }
     if rank == 0:
@@ -627,6 +674,18 @@ def main():
             except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                 out["many_targets"] = {"error": f"{type(exc).__name__}: {exc}"}
                 log(f"many-target leg failed: {exc}")
+        if world == 1 and a.objectives and not a.biometric and a.res == 1024 and a.lpips_net == "squeeze":
+            out["objectives"] = {}
+            legs = (("lpips_vgg", dict(lpips_net="vgg"), "Wing + LPIPS(vgg) + MSE (1024_example_percept_MSE.py:142-147's backbone in configs[1]'s loop)"),
+                    ("config3", dict(facenet=True), "Wing + FaceNet embedding MSE (InceptionResnetV1, un-resized 1024^2 image) + LPIPS(squeeze) + MSE: "
+                                                    "BASELINE config 3's objective (1024_example_FaceNet_percept.py:147-158 + ...sqz_MSE.py:171-179)"))
+            for name, kw, what in legs:
+                try:
+                    out["objectives"][name] = dict(objective_leg(cfg, device, G, target, latent_mean, latent_std, a.objective_batch, **kw), objective=what)
+                    log(f"objective leg {name}: {out['objectives'][name]['value']} iters/s")
+                except Exception as exc:        # noqa: BLE001 -- reported in the line instead
+                    out["objectives"][name] = {"error": f"{type(exc).__name__}: {exc}"}
+                    log(f"objective leg {name} failed: {exc}")
         if world == 1 and a.landmark_callback == "stub" and not a.biometric and a.res == 1024:
             try:
                 out["landmark_callback"] = landmark_callback_leg(cfg, device, G, percept, target, latent_mean, latent_std, a.batch, out["value"])

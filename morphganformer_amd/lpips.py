@@ -116,15 +116,21 @@ class SequentialFeatures:
         self.n = n
         t32 = lambda a: torch.as_tensor(np.ascontiguousarray(np.asarray(a), dtype=np.float32), device=dev)
         if share is not None:
-            self.convs, self.shift, self.scale, self.gp = share.convs, share.shift, share.scale, share.gp
+            self.convs, self.shift, self.scale, self.gp, self.wino = share.convs, share.shift, share.scale, share.gp, share.wino
         else:
             self.gp = {}                                   # channel-transposed packs of the backward pass, built on first use
             self.convs = {}
+            # 3x3 / stride-1 / pad-1 layers with whole 32-channel tiles (every VGG16 layer but the first, AlexNet's last three): Winograd
+            # F(2x2,3x3) form 3 when the launch fills the chip -- 4/9 of the matrix work of the tap-list kernel, which runs these layers at
+            # 0.80 of the FP32-MFMA peak and cannot get much closer (MGF_WINOGRAD_LPIPS=0: tap-list kernel everywhere)
+            self.wino = {}
             for row in self.spec:
                 if row[0] == "conv":
-                    _, idx, ci, co, k, _, _ = row
+                    _, idx, ci, co, k, st_, pd_ = row
                     wt, b = t32(backbone_state[f"features.{idx}.weight"]), t32(backbone_state[f"features.{idx}.bias"])
                     self.convs[idx] = (cv.pack_weights(wt) if k == 3 else wt, b)          # > 9 taps: packed per tap group at run time
+                    if USE_WINOGRAD_LPIPS and k == 3 and st_ == 1 and pd_ == 1 and ci % 4 == 0 and co % 32 == 0:
+                        self.wino[idx] = cv.winograd2_weights(wt)
             self.shift, self.scale = t32(SHIFT).reshape(1, 3, 1, 1), t32(SCALE).reshape(1, 3, 1, 1)
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         self.xs = e(n, 3, h, w)
@@ -157,7 +163,9 @@ class SequentialFeatures:
                 wt, b = self.convs[idx]
                 nxt = self.spec[pos + 1]
                 dst = out[len(taps)] if (out is not None and nxt[0] == "tap") else buf
-                if k == 3:
+                if idx in self.wino and min(h.shape[2:]) > 16 and cv.winograd_fills_chip(h.shape[0], co, h.shape[2], h.shape[3]):
+                    h = cv.winograd2_forward(h, self.wino[idx], epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dst)
+                elif k == 3:
                     h = cv.conv_forward(h, wt, stride=s, pad=(p, p), epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dst)
                 else:
                     h = cv.conv_large_forward(h, wt, b, s, p, act="relu", out=dst)
