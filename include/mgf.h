@@ -489,6 +489,11 @@ int mgf_style_demod_bwd_multi(float* dwg, const mgf_style_bwd_job* jobs_dev, int
                               mgf_stream_t stream);
 int mgf_attn_values_bwd_multi(float* dyc, const mgf_attn_bwd_job* jobs_dev, int32_t njobs, int32_t n, int32_t t, int32_t wdim,
                               mgf_stream_t stream);
+/* mgf_style_demod_bwd_multi and mgf_attn_values_bwd_multi in ONE launch (grid: style jobs + attention jobs): the two do not depend on each
+ * other and are single-workgroup latency chains at one sample */
+int mgf_latent_bwd_multi(float* dwg, const mgf_style_bwd_job* style_jobs_dev, int32_t n_style_jobs, float* dyc,
+                         const mgf_attn_bwd_job* attn_jobs_dev, int32_t n_attn_jobs, int32_t n, int32_t t, int32_t wdim, int32_t max_channels,
+                         mgf_stream_t stream);
 int mgf_latent_grad_gather(float* dw, const float* dwg, int32_t n_style_jobs, const float* dyc, int32_t n_attn_jobs, int32_t n, int32_t k,
                            int32_t wdim, float scale, mgf_stream_t stream);
 /* Backward of mgf_mapping_forward: dz[n,k,dim] from dw[n,k,dim].  The forward is recomputed; its per-layer activations go to

@@ -125,6 +125,7 @@ _SIGS = {
     "mgf_attn_values_grad_ws": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp, i64, vp]),
     "mgf_style_demod_bwd_multi": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mgf_attn_values_bwd_multi": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "mgf_latent_bwd_multi": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mgf_latent_grad_gather": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, i32, f32, vp]),
     "mgf_lpips_layer_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i64, i64, f32, i32, vp]),
     "mgf_lpips_layer_bwd_relu_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, f32, vp]),

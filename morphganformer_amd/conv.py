@@ -434,7 +434,9 @@ def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=Non
                                                        pitch, oh * pitch, pc.cout * oh * pitch, _lib.stream_ptr())
         _lib.check(rc, "tconv3x3s2_few_outputs")
         return out[:, :, :, :ow]
-    split = SPLIT_TCONV_BORDER and min(h, w) >= TCONV_SPLIT_MIN
+    # (one or two images -- gradient mode at a single target -- keep the single launch up to 64 px: the border kernel's few workgroups then
+    # cost more than the padded tiles, 6.76 -> 6.64 ms per gradient step; from four images on the split wins from 16 px, 686 vs 677 iters/s)
+    split = SPLIT_TCONV_BORDER and min(h, w) >= (TCONV_SPLIT_MIN if n >= 4 else max(TCONV_SPLIT_MIN, 128))
     os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, h if split else h + 1, w if split else w + 1, 1, 2, TCONV_TAPS, TCONV_GROUPS,
               [0, 0, 1, 1], [0, 1, 0, 1], oh, ow, pitch, oh * pitch, pc.cout * oh * pitch, 0, os_stride)

@@ -624,11 +624,8 @@ __device__ __forceinline__ void sum_chunk_partials(const float* part, int rows, 
     }
 }
 
-__global__ __launch_bounds__(256) void style_demod_bwd_kernel(float* dwg, const mgf_style_bwd_job* jobs, int njobs, int wdim) {
-    __shared__ float tl[2048];
-    __shared__ float dst[2048];
-    __shared__ float red[1024];
-    const mgf_style_bwd_job j = jobs[blockIdx.x];
+__device__ __forceinline__ void style_demod_bwd_body(float* dwg, const mgf_style_bwd_job& j, int job, int njobs, int wdim, float* tl, float* dst,
+                                                     float* red) {
     const int n = blockIdx.y, tid = threadIdx.x;
     const bool demod = j.wsq && j.d && j.dc_part;
     if (demod)
@@ -677,22 +674,63 @@ __global__ __launch_bounds__(256) void style_demod_bwd_kernel(float* dwg, const 
     if (tid < wdim) {
         float v = 0.f;
         for (int q = 0; q < nsl; ++q) v += red[q * wdim + tid];
-        dwg[((int64_t)n * njobs + blockIdx.x) * wdim + tid] = v * j.aff_gain * j.style_gain;
+        dwg[((int64_t)n * njobs + job) * wdim + tid] = v * j.aff_gain * j.style_gain;
     }
 }
 
-// grid (njobs, n): dyc[n, job, t, k] = sum_c dvwb[n,c,t] * wmv[c,k]
-__global__ __launch_bounds__(256) void attn_values_bwd_kernel(float* dyc, const mgf_attn_bwd_job* jobs, int njobs, int T, int wdim) {
-    const mgf_attn_bwd_job j = jobs[blockIdx.x];
-    const int n = blockIdx.y;
+__global__ __launch_bounds__(256) void style_demod_bwd_kernel(float* dwg, const mgf_style_bwd_job* jobs, int njobs, int wdim) {
+    __shared__ __attribute__((aligned(16))) float tl[2048];
+    __shared__ __attribute__((aligned(16))) float dst[2048];
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    style_demod_bwd_body(dwg, jobs[blockIdx.x], blockIdx.x, njobs, wdim, tl, dst, red);
+}
+
+// dyc[n, job, t, k] = sum_c dvwb[n,c,t] * wmv[c,k].  16 latents x 32 latent dimensions (every checkpoint of the drivers): the channels are
+// dealt round-robin to the four waves, a lane keeps one latent row and eight columns (one dvwb load + two 16-byte weight loads per eight
+// FMAs, c / 4 dependent steps instead of c: the chain of 512 dependent loads per lane was the whole 50 us), the waves meet in LDS in index
+// order.  Any other shape: one output per lane over all channels.
+__device__ __forceinline__ void attn_values_bwd_body(float* dyc, const mgf_attn_bwd_job& j, int job, int njobs, int T, int wdim, float* red) {
+    const int n = blockIdx.y, tid = threadIdx.x;
     const float* dv = j.dvwb + (int64_t)n * j.c * T;
-    for (int idx = threadIdx.x; idx < T * wdim; idx += 256) {
+    float* out = dyc + ((int64_t)n * njobs + job) * T * wdim;
+    if (T == 16 && wdim == 32 && ((uintptr_t)j.wmv % 16) == 0) {
+        const int g = tid >> 6, l = tid & 63, t = l >> 2, k0 = (l & 3) * 8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int c = g; c < j.c; c += 4) {
+            const float d = dv[c * 16 + t];
+            const float4 w0 = *reinterpret_cast<const float4*>(j.wmv + (int64_t)c * 32 + k0), w1 = *reinterpret_cast<const float4*>(j.wmv + (int64_t)c * 32 + k0 + 4);
+            acc[0] += d * w0.x; acc[1] += d * w0.y; acc[2] += d * w0.z; acc[3] += d * w0.w;
+            acc[4] += d * w1.x; acc[5] += d * w1.y; acc[6] += d * w1.z; acc[7] += d * w1.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) red[g * 512 + t * 32 + k0 + u] = acc[u];
+        __syncthreads();
+        for (int i = tid; i < 512; i += 256) out[i] = ((red[i] + red[512 + i]) + red[1024 + i]) + red[1536 + i];
+        return;
+    }
+    for (int idx = tid; idx < T * wdim; idx += 256) {
         const int t = idx / wdim, k = idx % wdim;
         float acc = 0.f;
 #pragma unroll 8
         for (int c = 0; c < j.c; ++c) acc += dv[(int64_t)c * T + t] * j.wmv[(int64_t)c * wdim + k];
-        dyc[(((int64_t)n * njobs + blockIdx.x) * T + t) * wdim + k] = acc;
+        out[idx] = acc;
     }
+}
+
+// grid (njobs, n)
+__global__ __launch_bounds__(256) void attn_values_bwd_kernel(float* dyc, const mgf_attn_bwd_job* jobs, int njobs, int T, int wdim) {
+    __shared__ float red[2048];
+    attn_values_bwd_body(dyc, jobs[blockIdx.x], blockIdx.x, njobs, T, wdim, red);
+}
+
+// Both latent-side reductions of the backward pass in ONE launch, grid (style jobs + attention jobs, n): the two kernels above are
+// single-workgroup latency chains of ~50 us each at one sample and do not depend on each other.
+__global__ __launch_bounds__(256) void latent_bwd_multi_kernel(float* dwg, const mgf_style_bwd_job* sjobs, int n_sjobs, float* dyc,
+                                                               const mgf_attn_bwd_job* ajobs, int n_ajobs, int T, int wdim) {
+    __shared__ __attribute__((aligned(16))) float sm[2048 + 2048 + 1024];
+    if ((int)blockIdx.x < n_sjobs) style_demod_bwd_body(dwg, sjobs[blockIdx.x], blockIdx.x, n_sjobs, wdim, sm, sm + 2048, sm + 4096);
+    else attn_values_bwd_body(dyc, ajobs[blockIdx.x - n_sjobs], blockIdx.x - n_sjobs, n_ajobs, T, wdim, sm);
 }
 
 // dw[n, t < T, :] = sum_jobs dyc ; dw[n, T, :] = sum_jobs dwg       (k = T + 1 rows), times `scale`
@@ -1229,6 +1267,20 @@ extern "C" int mgf_attn_values_bwd_multi(float* dyc, const mgf_attn_bwd_job* job
     MGF_REQUIRE(njobs <= 65535 && n <= 65535, MGF_ETOOBIG, "attn_values_bwd_multi: too many jobs/samples");
     hipLaunchKernelGGL(attn_values_bwd_kernel, dim3(njobs, n), dim3(256), 0, (hipStream_t)stream, dyc, jobs_dev, njobs, t, wdim);
     MGF_CHECK_LAUNCH("attn_values_bwd_multi");
+    return MGF_OK;
+}
+
+extern "C" int mgf_latent_bwd_multi(float* dwg, const mgf_style_bwd_job* style_jobs_dev, int32_t n_style_jobs, float* dyc,
+                                    const mgf_attn_bwd_job* attn_jobs_dev, int32_t n_attn_jobs, int32_t n, int32_t t, int32_t wdim,
+                                    int32_t max_channels, mgf_stream_t stream) {
+    MGF_REQUIRE(dwg && style_jobs_dev && n_style_jobs >= 1 && n >= 1, MGF_EINVAL, "latent_bwd_multi: bad arguments");
+    MGF_REQUIRE(n_attn_jobs == 0 || (dyc && attn_jobs_dev && t >= 1), MGF_EINVAL, "latent_bwd_multi: attention jobs need dyc, the job table and t");
+    MGF_REQUIRE(wdim >= 1 && wdim <= 256 && 256 % wdim == 0, MGF_EUNSUPPORTED, "latent_bwd_multi: wdim must divide 256 (got %d)", wdim);
+    MGF_REQUIRE(max_channels >= 1 && max_channels <= 2048, MGF_EUNSUPPORTED, "latent_bwd_multi: at most 2048 channels per layer (got %d)", max_channels);
+    MGF_REQUIRE(n_style_jobs + n_attn_jobs <= 65535 && n <= 65535, MGF_ETOOBIG, "latent_bwd_multi: too many jobs/samples");
+    hipLaunchKernelGGL(latent_bwd_multi_kernel, dim3(n_style_jobs + n_attn_jobs, n), dim3(256), 0, (hipStream_t)stream, dwg, style_jobs_dev,
+                       n_style_jobs, dyc, attn_jobs_dev, n_attn_jobs, t, wdim);
+    MGF_CHECK_LAUNCH("latent_bwd_multi");
     return MGF_OK;
 }
 

@@ -337,11 +337,9 @@ class GeneratorGrad:
             cv.upfirdn_into(dlow, d_out, P.fir, up=1, down=2, pad=(1, 1, 1, 1), gain=4.0, flip=True)
             cv.conv_forward(dlow, self.Tskip[res], epilogue=_lib.make_epilogue(residual=dxin), out=dxin)
             dx = dxin
-        _lib.check(L.mgf_style_demod_bwd_multi(self.dwg.data_ptr(), self.style_jobs.data_ptr(), self.n_style_jobs, n, D,
-                                               self.max_channels, st), "style_demod_bwd_multi")
-        if self.n_attn_jobs:
-            _lib.check(L.mgf_attn_values_bwd_multi(self.dyc.data_ptr(), self.attn_jobs.data_ptr(), self.n_attn_jobs, n, T, D, st),
-                       "attn_values_bwd_multi")
+        # d(styles) -> the global component and d(attention values) -> the local components: one launch (two independent latency chains)
+        _lib.check(L.mgf_latent_bwd_multi(self.dwg.data_ptr(), self.style_jobs.data_ptr(), self.n_style_jobs, self.dyc.data_ptr(),
+                                          _lib.ptr(self.attn_jobs), self.n_attn_jobs, n, T, D, self.max_channels, st), "latent_bwd_multi")
 
     def backward(self, dimg):
         """dimg -> dz [n,k,D] (through the mapping network; forward() must have been called with z)."""
