@@ -81,6 +81,13 @@ def parse():
                          "objective Wing + FaceNet (InceptionResnetV1 on the un-resized 1024^2 image) + LPIPS(squeeze) + MSE -- iters/s, the "
                          "dominant conv kernel and its executed fraction of the FP32-MFMA peak; 0 = skip")
     ap.add_argument("--objective-batch", type=int, default=16, help="loop steps per generator forward in the `objectives` legs")
+    ap.add_argument("--workload", choices=["configs1", "config3"], default="configs1",
+                    help="configs1 = the headline (configs[1], one target per rank, weak scaling).  config3 = BASELINE config 3's shape: a LIST of "
+                         "independent targets with the four-term objective Wing + FaceNet + LPIPS(squeeze) + MSE, sharded over the ranks by "
+                         "drivers.project_many through the dynamic work queue, one result gather at the end -- a weak pass (--config3-targets per "
+                         "rank) and a strong pass (--config3-targets in all), per-rank item counts and busy times in the line")
+    ap.add_argument("--config3-targets", type=int, default=16, help="targets per rank (weak pass) / in all (strong pass) of --workload config3")
+    ap.add_argument("--config3-steps", type=int, default=128, help="loop steps per target of --workload config3 (the drivers run 1000+)")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="1 = overlap the losses of batch i with the generator of batch i+1 on two streams (+3 %% iters/s; kernels of the two "
                          "streams then stretch each other, so per-kernel durations -- and the roofline object -- no longer describe a kernel "
@@ -513,6 +520,93 @@ def self_launch(a):
     return 0
 
 
+def sharded_passes(run_many, world, rank, per_rank, steps_per_item, barrier, sync, allgather_f64):
+    """The control flow of --workload config3, free of GPU work (tests rehearse it under gloo with a stub `run_many`): a WEAK pass over
+    per_rank * world items and a STRONG pass over per_rank items in all, each = barrier, run_many(n_items) (shards the items over the ranks,
+    works on them, gathers every record to every rank), barrier; every rank's own busy time and item count are all-gathered afterwards.
+    run_many(n) -> dict with `items` (all item ids, ordered) and `mine` (this rank's).  Returns the two result objects (rank-identical)."""
+    out = {}
+    for name, n_items in (("weak", per_rank * world), ("strong", per_rank)):
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        res = run_many(n_items)
+        sync()
+        busy = time.perf_counter() - t0
+        barrier()
+        wall = time.perf_counter() - t0
+        items = [int(v) for v in res["items"]]
+        assert items == list(range(n_items)), f"{name} pass: the gather must return every item exactly once, in order"
+        stats = allgather_f64([busy, float(len(res["mine"])), wall])                    # [world][3]
+        walls = [r[2] for r in stats]
+        total = max(walls)
+        counts = [int(r[1]) for r in stats]
+        assert sum(counts) == n_items, (counts, n_items)
+        out[name] = {"targets": n_items, "steps_per_target": steps_per_item, "seconds": round(total, 4),
+                     "projections_per_s": round(n_items / total, 4), "iters_per_s": round(n_items * steps_per_item / total, 2),
+                     "per_rank_targets": counts, "per_rank_busy_s": [round(r[0], 4) for r in stats],
+                     "rank_busy_min_s": round(min(r[0] for r in stats), 4), "rank_busy_max_s": round(max(r[0] for r in stats), 4)}
+    return out
+
+
+def config3_workload(a, cfg, device, rank, world, dist):
+    """--workload config3 on the GPUs: every rank builds the generator, LPIPS(squeeze), the FaceNet embedder once; items are synthetic
+    targets G(z_j) rendered when a rank takes them; drivers.project_many(dynamic=True) walks them with ONE re-targeted engine per rank."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.distributed import gather_results
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.iresnet import BiometricLoss
+    from morphganformer_amd.lpips import PerceptualLoss
+    from morphganformer_amd.projection import ProjectionArgs, latent_stats, synthetic_landmarks
+    from morphganformer_amd.synth_weights import make_state_dict, synthetic_latents
+    steps, per_rank, batch = a.config3_steps, a.config3_targets, a.objective_batch
+    G = Generator(make_state_dict(cfg, seed=0), cfg, device, max_batch=1)
+    percept = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device, allow_random_backbone=True)
+    bio = BiometricLoss("facenet", n=batch, device=device, seed=0)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0)
+    latent_mean, latent_std = latent_stats(G, 10000, device, gen)
+    n_max = per_rank * world
+    zs = torch.from_numpy(synthetic_latents(cfg, n_max, seed=7000)).to(device)
+    targets = [(lambda j=j: G(zs[j:j + 1], None, noise_mode="const")[0].clamp(-1, 1)) for j in range(n_max)]
+    lms = [synthetic_landmarks(steps, cfg.img_resolution, seed=900 + j) for j in range(n_max)]
+    kw = dict(args=ProjectionArgs(step=steps), percept=percept, biometric=bio, gamma=1.0, batch=batch, latent_mean=latent_mean,
+              latent_std=float(latent_std), seed=3, dynamic=True)
+    run_many = lambda n: drivers.project_many(G, targets[:n], landmarks=lms[:n], **kw)
+    run_many(min(2, n_max))                                   # warm-up: engine set-up and graph capture are not what the passes compare
+    barrier = dist.barrier if dist is not None else (lambda: None)
+
+    def allgather(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=device)
+        if dist is None:
+            return [t.tolist()]
+        out = torch.empty(world * len(vals), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(out, t)
+        return out.view(world, len(vals)).tolist()
+
+    passes = sharded_passes(run_many, world, rank, per_rank, steps, barrier, torch.cuda.synchronize, allgather)
+    gather_ms = None
+    if dist is not None:
+        lat = torch.zeros(1, cfg.k, cfg.z_dim, device=device)
+        gather_results(lat, 0.0, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gather_results(lat, 0.0, 0)
+        torch.cuda.synchronize()
+        gather_ms = round((time.perf_counter() - t0) * 1e3, 3)
+    w = passes["weak"]
+    return {"metric": "latent-projection iters/sec @1024^2, k=17 latents", "value": w["iters_per_s"], "unit": "iters/s", "n_gpus": world,
+            "steps": w["targets"] * steps, "warmup": 2 * steps, "ms_per_step": round(w["seconds"] / (w["targets"] * steps) * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1), "gather_ms": gather_ms,
+            "config": {"workload": f"config 3: {per_rank} independent {a.res}x{a.res} targets per GPU ({w['targets']} in all), Wing + FaceNet "
+                                   "(InceptionResnetV1, un-resized image) + LPIPS(squeeze) + MSE literal-mode projection, "
+                                   f"{steps} steps per target, pair-sharded by drivers.project_many through the dynamic work queue, one result "
+                                   "gather; seeded synthetic weights / targets / landmarks", "k": cfg.k, "z_dim": cfg.z_dim,
+                       "parallelism": f"pair-sharded x{world} (work queue)", "steps_per_forward": batch},
+            "weak": w, "strong": passes["strong"]}
+
+
 def launch_selftest(a):
     """CPU dry run of the launcher path (tests/): every rank joins a gloo group, the ranks all_gather their ids, rank 0 prints a
     line shaped like the real one.  MGF_SELFTEST_FAIL_RANK makes that rank exit non-zero (the parent must notice)."""
@@ -525,8 +619,31 @@ def launch_selftest(a):
     got = [th.zeros(1, dtype=th.int64) for _ in range(world)]
     dist.all_gather(got, th.tensor([rank]))
     dist.barrier()
+    line = {"metric": "launcher selftest", "n_gpus": world, "rccl_ranks": world, "ranks": [int(t) for t in got]}
+    if a.workload == "config3":
+        # the control flow of --workload config3 with a stub in place of the projection: distributed.run_sharded over the dynamic work
+        # queue, ragged per-item cost, slower odd ranks; the same sharded_passes() the GPU path runs
+        from morphganformer_amd.distributed import pack_result, run_sharded, unpack_results
+
+        def work(i):
+            time.sleep(0.002 * (1 + i % 3) * (1 + rank % 2))
+            return pack_result(th.full([1, 2, 3], float(i)), 0.5 * i, i, item=i)
+
+        def run_many(n):
+            rows, mine = run_sharded(n, work, 2 * 3 + 3, th.device("cpu"), dynamic=True)
+            res = unpack_results(rows, (2, 3))
+            assert all(float(res["latents"][j, 0, 0]) == j for j in range(n))
+            res["mine"] = mine
+            return res
+
+        def allgather(vals):
+            out = [th.zeros(len(vals), dtype=th.float64) for _ in range(world)]
+            dist.all_gather(out, th.tensor(vals, dtype=th.float64))
+            return [o.tolist() for o in out]
+
+        line.update(sharded_passes(run_many, world, rank, a.config3_targets, a.config3_steps, dist.barrier, lambda: None, allgather))
     if rank == 0:
-        print(json.dumps({"metric": "launcher selftest", "n_gpus": world, "rccl_ranks": world, "ranks": [int(t) for t in got]}), flush=True)
+        print(json.dumps(line), flush=True)
     dist.destroy_process_group()
     return 0
 
@@ -582,6 +699,15 @@ def main():
         rccl_ranks = dist.get_world_size()
     from morphganformer_amd.synth_weights import GeneratorConfig
     cfg = GeneratorConfig(img_resolution=a.res)
+    if a.workload == "config3":
+        line = config3_workload(a, cfg, device, rank, world, dist)
+        line["rccl_ranks"] = rccl_ranks
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
     assert a.batch >= 1
     # the engine advances `batch` loop steps per launch sequence: K and W are rounded UP to whole launches (more work inside the
     # timed region, never less), and the line reports the number of steps that were really timed

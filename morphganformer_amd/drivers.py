@@ -149,7 +149,7 @@ DEFAULT_BATCH = 32       # loop steps per generator forward in literal mode: the
 def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None,
                   eps=None, out_prefix=None, batch=DEFAULT_BATCH, use_graph=True, noise_mode="random", use_mse=True, seed=None,
                   landmark_fn=None, mode="literal", weight_decay=0.0, path_to_gen=None, keep_images=64, engine=None,
-                  return_engine=False, latent_space="z", landmark_input="float"):
+                  return_engine=False, latent_space="z", landmark_input="float", biometric=None, gamma=1.0):
     """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and either
     `lm_steps` [steps,68,2] (injected landmark detections) or `landmark_fn` (host detector called on every generated image,
     see ProjectionEngine; landmark_input="gray_u8" hands it the drivers' gray uint8 image, built on the device).  mode="literal" is the loop as the reference executes it (best-of-N noisy sampling, `batch` steps per
@@ -158,6 +158,9 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
     1024_example_MSE.py:117 optimizer; latent_space="w+" optimises the per-layer intermediate latent [k, num_ws, D] instead of z -- the
     statistics are then taken in w space, projection.latent_stats_w -- and `w` comes back as [1, k, num_ws, D]).  Returns dict(w, step,
     loss, losses).
+
+    biometric / gamma: an iresnet.BiometricLoss (embedder "facenet" or "iresnetNN") adds gamma * MSE(embed(img), embed(target)) to the objective
+    (BASELINE config 3; 1024_example_FaceNet_percept.py:147-158).
 
     Outputs, like the drivers: with `path_to_gen` the SCORED image of every improvement -- the candidate as it was generated and
     ranked, its random per-layer noise included -- is written as `{path_to_gen}/{step:06d}_{loss:04f}.png` (:190-195; literal mode:
@@ -191,7 +194,8 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
         diff = [name for name, ok in (("landmarks (Wing term)", engine.use_wing == (lm_target is not None)),
                                       ("percept", engine.percept is percept), ("use_mse", engine.use_mse == bool(use_mse)),
                                       ("noise_mode", engine.noise_mode == noise_mode), ("args", engine.args == args),
-                                      ("landmark_fn", engine.landmark_fn is landmark_fn)) if not ok]
+                                      ("landmark_fn", engine.landmark_fn is landmark_fn), ("biometric", engine.biometric is biometric),
+                                      ("gamma", biometric is None or engine.gamma == float(gamma))) if not ok]
         if diff:
             raise ValueError("engine= was built for another objective: " + ", ".join(diff) + " differ(s); build a fresh engine")
         eng = engine.retarget(target, lm_target=lm_target, lm_steps=lm_steps, eps=eps, seed=seed if eps is None else None,
@@ -199,11 +203,13 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
     elif mode == "gradient":
         eng = GradientProjectionEngine(G, target, latent_mean, float(latent_std), args, weight_decay=weight_decay, percept=percept,
                                        lm_target=lm_target, lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph,
-                                       use_mse=use_mse, landmark_fn=landmark_fn, seed=0 if seed is None else seed, latent_space=latent_space)
+                                       use_mse=use_mse, landmark_fn=landmark_fn, seed=0 if seed is None else seed, latent_space=latent_space,
+                                       biometric=biometric, gamma=gamma)
     else:
         eng = ProjectionEngine(G, target, latent_mean, float(latent_std), args, percept=percept, lm_target=lm_target,
                                lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse,
-                               landmark_fn=landmark_fn, keep_images=keep, seed=0 if seed is None else seed, landmark_input=landmark_input)
+                               landmark_fn=landmark_fn, keep_images=keep, seed=0 if seed is None else seed, landmark_input=landmark_input,
+                               biometric=biometric, gamma=gamma)
     w, step, loss, losses = eng.run().result()
     out = {"w": w, "step": step, "loss": loss, "losses": losses}
     if out_prefix is not None:
@@ -231,12 +237,13 @@ def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):
     In literal mode the rank builds ONE engine (latent statistics, LPIPS workspaces, hipGraph capture) for its first item and
     re-targets it for the others, as the reference keeps G / percept / latent statistics outside its per-image loop
     (projection_example_v2_percept_morph.py:311-355).
-    Returns dict(latents [N,k,D], losses [N], steps [N], items [N]) ordered by item id."""
+    Returns dict(latents [N,k,D], losses [N], steps [N], items [N]) ordered by item id, plus `mine`: the items this rank worked on."""
     import torch.distributed as dist
     from .distributed import gather_many, pack_result, run_sharded, shard_items, unpack_results
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
-    load = lambda t: t if isinstance(t, torch.Tensor) else image_transform(t, size=G.img_resolution, device=G.device)
+    # an item is a device tensor, an image path, or a callable that produces the tensor when the item is taken (a rank only ever touches its own)
+    load = lambda t: t if isinstance(t, torch.Tensor) else (t() if callable(t) else image_transform(t, size=G.img_resolution, device=G.device))
     w_plus = kw.get("latent_space", "z") == "w+"
     lshape = (G.cfg.k, G.cfg.num_ws, G.cfg.w_dim) if w_plus else (G.cfg.k, G.cfg.z_dim)      # a W+ result is [k, num_ws, D] per item
     width = int(np.prod(lshape)) + 3
@@ -252,7 +259,9 @@ def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):
             res = _project_group(G, [load(targets[i]) for i in ids], [landmarks[i] for i in ids] if landmarks is not None else None, **kw)
             recs += [pack_result(res["w"][j:j + 1].to(G.device), float(res["loss"][j]), int(res["step"][j]), item=i) for j, i in enumerate(ids)]
         rows = torch.stack(recs) if recs else torch.empty([0, width], dtype=torch.float64, device=G.device)
-        return unpack_results(gather_many(rows, -(-len(targets) // world)), lshape)
+        out = unpack_results(gather_many(rows, -(-len(targets) // world)), lshape)
+        out["mine"] = list(mine)
+        return out
     reuse = kw.get("mode", "literal") == "literal" and kw.get("landmark_fn") is None and kw.get("eps") is None
     if reuse and (kw.get("latent_mean") is None or kw.get("latent_std") is None):
         a = kw.get("args") or ProjectionArgs()
@@ -272,8 +281,10 @@ def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):
         state["eng"] = r.get("engine")
         return pack_result(r["w"].to(G.device), r["loss"], r["step"], item=i)
 
-    rows, _mine = run_sharded(len(targets), work, width, G.device, dynamic=dynamic)
-    return unpack_results(rows, lshape)
+    rows, mine = run_sharded(len(targets), work, width, G.device, dynamic=dynamic)
+    out = unpack_results(rows, lshape)
+    out["mine"] = mine                                       # the items THIS rank projected, in the order it took them
+    return out
 
 
 def _project_group(G, targets, landmarks, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None, eps=None,

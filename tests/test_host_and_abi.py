@@ -304,6 +304,16 @@ def test_bench_self_launches_n_ranks():
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2 and json.loads(lines[0])["ranks"] == [0, 1]
     bad = subprocess.run(cmd, env=dict(env, MGF_SELFTEST_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert bad.returncode != 0
+    # --workload config3: the sharded control flow (dynamic work queue over 16 * N items, weak + strong pass, per-rank statistics, one gather)
+    # with a stub projection, three ranks of different speed
+    c3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--selftest-launch", "--workload", "config3",
+                         "--config3-targets", "7", "--config3-steps", "10"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert c3.returncode == 0, c3.stderr.decode()[-2000:]
+    line = json.loads([ln for ln in c3.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert line["weak"]["targets"] == 21 and line["strong"]["targets"] == 7 and line["weak"]["steps_per_target"] == 10
+    assert sum(line["weak"]["per_rank_targets"]) == 21 and sum(line["strong"]["per_rank_targets"]) == 7 and len(line["weak"]["per_rank_busy_s"]) == 3
+    assert line["weak"]["per_rank_targets"][1] < line["weak"]["per_rank_targets"][0]          # the slow rank drew fewer items from the queue
+    assert line["weak"]["iters_per_s"] > 0 and line["weak"]["rank_busy_max_s"] >= line["weak"]["rank_busy_min_s"]
     # the parent decides to launch before anything GPU-related is imported
     src = open(os.path.join(ROOT, "bench.py")).read()
     head = src[:src.index("def main():")]
