@@ -203,12 +203,12 @@ def generator_leg(eng, iters=3):
     """The 1024^2 generator forward alone (mapping + synthesis of `batch` candidates, noise_mode="random"), HIP-event timed on
     the launch stream: north-star target ">= 40% of the MFMA roofline on the generator forward"."""
     G, a = eng.G, eng.args
-    G.forward_workspace(eng.latent_n, a.truncation_psi, noise_mode="random")
+    G.forward_workspace(eng.latent_n, a.truncation_psi, noise_mode="random", lean=True)       # (the workspace flavour the loop itself runs on)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        G.forward_workspace(eng.latent_n, a.truncation_psi, noise_mode="random")
+        G.forward_workspace(eng.latent_n, a.truncation_psi, noise_mode="random", lean=True)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters / eng.batch

@@ -235,61 +235,98 @@ class Generator:
         self._alloc(max_batch)
 
     # ------------------------------------------------------------------ workspace
-    # One workspace (activations, style / demod / value arenas, device job tables) per batch size, kept for the life of the
+    # One workspace (activations, style / demod / value arenas, device job tables) per (batch size, flavour), kept for the life of the
     # generator: hipGraphs captured by the projection engines bake these pointers in, so a call with another batch size must never
-    # free them (it used to).  Engines `pin` the batch size they captured; only un-pinned workspaces are ever dropped, and only when
+    # free them (it used to).  Engines `pin` the workspace they captured; only un-pinned workspaces are ever dropped, and only when
     # the total exceeds MGF_WORKSPACE_GB (default 160 of the 288 GB).
-    _WS_FIELDS = ("n", "w_buf", "styles", "demods", "vtabs", "noise_rand", "bufs", "img", "const_in", "rgbw", "style_jobs", "n_style_jobs",
+    # Two flavours.  FULL: every layer output of every sample has its own tensor (1.6 GB per sample at 1024^2) -- what the backward pass
+    # of gradient mode reads, what `taps` / return_att hand out.  LEAN: the literal loop has no backward pass and only ever needs a block's
+    # input, its transposed-conv workspace, its two layer outputs and its skip branch at the same time, so the layer outputs are views of
+    # seven arenas sized for the largest user and re-used block after block (0.47 GB per sample: 15 instead of 51 GB at 32 steps per forward).
+    _WS_FIELDS = ("n", "lean", "w_buf", "styles", "demods", "vtabs", "noise_rand", "bufs", "img", "const_in", "rgbw", "style_jobs", "n_style_jobs",
                   "max_style_cin", "attn_jobs", "n_attn_jobs", "style_jobs_pl", "attn_jobs_pl", "ws_bytes", "ws_gen")
 
-    def _alloc(self, n):
-        """Make the workspace of batch size n current (created on first use)."""
-        cur = getattr(self, "n", None)
-        if cur is not None and cur in self._workspaces:
+    def _alloc(self, n, lean=None):
+        """Make the workspace of batch size n current (created on first use); lean=None keeps the current flavour."""
+        cur = (getattr(self, "n", None), getattr(self, "lean", False))
+        lean = cur[1] if lean is None else bool(lean)
+        if cur[0] is not None and cur in self._workspaces:
             self._workspaces[cur]["noise_rand"] = self.noise_rand              # lazily allocated: remember it with its workspace
-        ws = self._workspaces.pop(n, None)
+        key = (n, lean)
+        ws = self._workspaces.pop(key, None)
         if ws is None:
-            self._evict_for(n)
-            self._create(n)
+            self._evict_for(n, lean)
+            self._create(n, lean)
             ws = {k: getattr(self, k) for k in self._WS_FIELDS}
-        self._workspaces[n] = ws                                               # most recently used last
+        self._workspaces[key] = ws                                             # most recently used last
         for k, v in ws.items():
             setattr(self, k, v)
 
-    def pin(self, n=None):
-        """Declare that a captured hipGraph references the workspace of batch size n (default: the current one)."""
-        n = self.n if n is None else n
-        self._pins[n] = self._pins.get(n, 0) + 1
-        return n
+    def pin(self, key=None):
+        """Declare that a captured hipGraph references a workspace (default: the current one).  Returns the key to `unpin` with."""
+        key = (self.n, self.lean) if key is None else key
+        self._pins[key] = self._pins.get(key, 0) + 1
+        return key
 
-    def unpin(self, n):
-        if self._pins.get(n, 0) > 0:
-            self._pins[n] -= 1
+    def unpin(self, key):
+        if self._pins.get(key, 0) > 0:
+            self._pins[key] -= 1
 
-    def _evict_for(self, n):
+    def _evict_for(self, n, lean):
         budget = float(os.environ.get("MGF_WORKSPACE_GB", "160")) * 2 ** 30
-        need = self._workspace_bytes(n)
+        need = self._workspace_bytes(n, lean)
         total = sum(w["ws_bytes"] for w in self._workspaces.values())
+        cur = (getattr(self, "n", None), getattr(self, "lean", False))
         for m in list(self._workspaces):                                       # least recently used first
             if total + need <= budget:
                 break
-            if self._pins.get(m, 0) == 0 and m != getattr(self, "n", None):
+            if self._pins.get(m, 0) == 0 and m != cur:
                 total -= self._workspaces.pop(m)["ws_bytes"]
 
-    def _workspace_bytes(self, n):
+    def _fuses_skip_up(self, l1, n):
+        """Does conv1 of this block up-sample the half-resolution skip tensor in its own (form-3 Winograd) epilogue at batch size n?"""
+        res = l1.res
+        return bool(self.fuse_skip_up and self.plan.fir_is_1331 and cv.WINOGRAD_FORM == 3 and l1.attn is None and l1.wino_u is not None
+                    and l1.wino_u.ndim == 4 and res % 2 == 0 and cv.winograd_fills_chip(n, l1.cout, res, res))
+
+    def _lean_arenas(self, n):
+        """Floats per sample of the lean flavour's arenas: T (transposed-conv workspace, also conv_last's output), U (conv0; conv1 before its
+        attention), V (conv0 after its attention), W0 / W1 (block outputs, alternating), S (full-resolution skip tensor of the blocks whose
+        conv1 does not up-sample it itself), SL (half-resolution skip tensor)."""
         cfg = self.cfg
+        conv1 = {lp.res: lp for lp in self.plan.layers if lp.name.endswith(".conv1")}
+        a = dict(T=0, U=0, V=0, W0=0, W1=0, S=0, SL=0)
+        for i, res in enumerate(cfg.block_resolutions):
+            c, px = cfg.channels(res), res * res
+            a["U"] = max(a["U"], c * px)
+            a["W%d" % (i & 1)] = max(a["W%d" % (i & 1)], c * px)
+            if res > 4:
+                a["T"] = max(a["T"], c * (res + 1) * cv.tconv_pitch(res // 2))
+                a["SL"] = max(a["SL"], c * px // 4)
+                if not self._fuses_skip_up(conv1[res], n):
+                    a["S"] = max(a["S"], c * px)
+                if cfg.has_attention(res):
+                    a["V"] = max(a["V"], c * px)
+            if res == cfg.img_resolution:
+                a["T"] = max(a["T"], c * px)
+        return a
+
+    def _workspace_bytes(self, n, lean=False):
+        cfg = self.cfg
+        if lean:
+            return 4 * n * (sum(self._lean_arenas(n).values()) + cfg.img_channels * cfg.img_resolution ** 2)
         per = 0
         for res in cfg.block_resolutions:
             c = cfg.channels(res)
-            planes = 2 + (4 if res > 4 else 0) + (1 if res > 4 and cfg.has_attention(res) else 0) + (1 if cfg.has_attention(res) else 0) \
+            planes = 1 + (4 if res > 4 else 0) + (1 if res > 4 and cfg.has_attention(res) else 0) + (1 if cfg.has_attention(res) else 0) \
                 + (1 if res == cfg.img_resolution else 0)
             per += planes * c * res * res
         return 4 * n * (per + cfg.img_channels * cfg.img_resolution ** 2)
 
-    def _create(self, n):
+    def _create(self, n, lean=False):
         cfg, dev, P = self.cfg, self.device, self.plan
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        self.n = n
+        self.n, self.lean = n, bool(lean)
         # generation id: consumers that cache raw pointers into this workspace (grad.GeneratorGrad's job tables) rebuild them when a
         # workspace of the same batch size was evicted and created anew
         self._gen_counter = getattr(self, "_gen_counter", 0) + 1
@@ -300,9 +337,29 @@ class Generator:
         self.vtabs = e(n, max(P.v_total, 1))
         self.noise_rand = None
         self.bufs = {}
-        for res in cfg.block_resolutions:
+        if lean:
+            arena = {k: e(n * v) for k, v in self._lean_arenas(n).items() if v}
+            conv1 = {lp.res: lp for lp in P.layers if lp.name.endswith(".conv1")}
+            view = lambda k, *shape: arena[k][:int(np.prod(shape))].view(*shape)
+            for i, res in enumerate(cfg.block_resolutions):
+                c, att, W = cfg.channels(res), cfg.has_attention(res), "W%d" % (i & 1)
+                b = {"conv1": view("U" if att else W, n, c, res, res)}
+                if att:
+                    b["conv1a"] = view(W, n, c, res, res)
+                if res > 4:
+                    b["skip_low"] = view("SL", n, c, res // 2, res // 2)
+                    b["t"] = view("T", n, c, res + 1, cv.tconv_pitch(res // 2))
+                    b["conv0"] = view("U", n, c, res, res)
+                    if att:
+                        b["conv0a"] = view("V", n, c, res, res)
+                    if not self._fuses_skip_up(conv1[res], n):
+                        b["skip"] = view("S", n, c, res, res)
+                if res == cfg.img_resolution:
+                    b["last"] = view("T", n, c, res, res)
+                self.bufs[res] = b
+        for res in ([] if lean else cfg.block_resolutions):
             c = cfg.channels(res)
-            b = {"conv1": e(n, c, res, res), "out": e(n, c, res, res)}
+            b = {"conv1": e(n, c, res, res)}
             if res > 4:
                 b["skip_low"] = e(n, c, res // 2, res // 2)
                 b["skip"] = e(n, c, res, res)
@@ -318,7 +375,7 @@ class Generator:
         self.img = e(n, cfg.img_channels, cfg.img_resolution, cfg.img_resolution)
         self.const_in = P.const.unsqueeze(0).repeat(n, 1, 1, 1).contiguous()            # networks.py:1147
         self.rgbw = e(n, cfg.img_channels, cfg.channels(cfg.img_resolution))
-        self.ws_bytes = self._workspace_bytes(n)
+        self.ws_bytes = self._workspace_bytes(n, lean)
         self._build_jobs(n)
 
     def _build_jobs(self, n):
@@ -453,8 +510,10 @@ class Generator:
                 l1 = layers[b + ".conv1"]
                 # conv1 on the form-3 Winograd kernel without attention (256^2 and larger): its epilogue up-samples the half-resolution
                 # skip output itself -- no fir_up2 pass, no full-resolution skip tensor (one write + one read of the block's largest map)
-                fuse_up = (self.fuse_skip_up and P.fir_is_1331 and cv.WINOGRAD_FORM == 3 and l1.attn is None and l1.wino_u is not None
-                           and l1.wino_u.ndim == 4 and res % 2 == 0 and cv.winograd_fills_chip(n, l1.cout, res, res))
+                fuse_up = self._fuses_skip_up(l1, n)
+                if not fuse_up and "skip" not in B:           # lean workspace: laid out with the same predicate, for the flag's value then
+                    raise _lib.MgfError(f"synthesis: the lean workspace has no full-resolution skip tensor for the {res}x{res} block "
+                                        "(fuse_skip_up changed after the workspace was created): use the full workspace")
                 self.skip_fused[res] = bool(fuse_up)         # (gradient mode's backward reads the skip tensor at the resolution it was consumed)
                 main = torch.cuda.current_stream(self.device)
                 if self.overlap_skip:
@@ -574,7 +633,7 @@ class Generator:
         return y
 
     def forward_workspace(self, z=None, c=None, ws=None, truncation_psi=1, truncation_cutoff=None, return_img=True, return_att=False,
-                          return_ws=False, subnet=None, noise_mode="random", noises=None, fused_modconv=None, att_format="tensor"):
+                          return_ws=False, subnet=None, noise_mode="random", noises=None, fused_modconv=None, att_format="tensor", lean=False):
         """Generator.forward (networks.py:1304-1331), zero-copy: the returned image IS the workspace buffer of this batch size and is
         overwritten by the next call (what the projection engines want; `__call__` hands out copies).
 
@@ -582,6 +641,10 @@ class Generator:
         truncation_cutoff act in the mapping network only, i.e. when `z` is given (:1317, :935-941).  return_att=True returns the
         stacked attention tensor [n, k-1, layers, 1, R, R] of list2tensor (:1262,1222-1242); att_format="maps" returns the per-layer
         dict {layer: (probs [n,F,k-1], argmax [n,F])} instead (the cheap form: the stacked tensor is 738 MB per image at 1024^2)."""
+        lean = bool(lean) and self.taps is None and not return_att      # (intermediate tensors are handed out: they need their own storage)
+        nb = (z if ws is None else ws)
+        if nb is not None and (nb.shape[0], lean) != (self.n, self.lean):
+            self._alloc(nb.shape[0], lean)
         return_tensor = False
         if subnet is not None:
             return_ws, return_img, return_att, return_tensor = subnet == "mapping", subnet == "synthesis", False, True

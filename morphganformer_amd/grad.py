@@ -136,8 +136,8 @@ class GeneratorGrad:
             G.map_save = self.map_scratch
         try:
             if ws is not None:
-                if w.shape[0] != G.n:
-                    G._alloc(w.shape[0])
+                if (w.shape[0], False) != (G.n, G.lean):        # the backward pass reads every layer output: the FULL workspace flavour
+                    G._alloc(w.shape[0], False)
                 img = G.synthesis(w, noise_mode=noise_mode, noises=noises)
             else:
                 img = G.forward_workspace(z, None, truncation_psi=truncation_psi, noise_mode=noise_mode, noises=noises)[0]

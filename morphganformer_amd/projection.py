@@ -253,8 +253,8 @@ class ProjectionEngine:
             self._host_step = 0                     # host mirror of step_ctr (the callbacks need the step numbers without a device read)
         self.pipeline = bool(pipeline) and landmark_fn is None
         if self.pipeline:
-            if G.n != B:
-                G._alloc(B)
+            if (G.n, G.lean) != (B, True):
+                G._alloc(B, True)
             self.latent_ns = [self.latent_n, torch.empty_like(self.latent_n)]
             self.imgs = [G.img, torch.empty_like(G.img)]
             self.gen_ctr = torch.zeros(1, dtype=torch.int32, device=dev)          # step counter of the generator side
@@ -274,7 +274,8 @@ class ProjectionEngine:
         L, st, a, B = _lib.lib(), _lib.stream_ptr(), self.args, self.batch
         _lib.check(L.mgf_latent_perturb(latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(),
                                         self.sigma.data_ptr(), ctr.data_ptr(), B, self.steps, self.numel, st), "latent_perturb")
-        return self.G.forward_workspace(latent_n, a.truncation_psi, noise_mode=self.noise_mode)[0]      # psi lands in `c`
+        # psi lands in `c`.  lean: the literal loop has no backward pass -- layer outputs share arenas block after block
+        return self.G.forward_workspace(latent_n, a.truncation_psi, noise_mode=self.noise_mode, lean=True)[0]
 
     def _loss_phase(self, img, latent_n):
         L, st, a, B = _lib.lib(), _lib.stream_ptr(), self.args, self.batch

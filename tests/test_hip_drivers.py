@@ -447,17 +447,17 @@ def test_wplus_driver_statistics_never_size_a_synthesis_workspace(golden):
     G2 = _tiny_G()
     gen = torch.Generator(device="cuda"); gen.manual_seed(4)
     mean, std = latent_stats_w(G2, 4000, "cuda", gen)
-    assert tuple(mean.shape) == (cfg.k, cfg.w_dim) and float(std) > 0 and max(G2._workspaces) == 1
+    assert tuple(mean.shape) == (cfg.k, cfg.w_dim) and float(std) > 0 and max(k[0] for k in G2._workspaces) == 1
     args = ProjectionArgs(step=5, lr=0.05, lr_rampup=0.3, n_mean_latent=3000)
     r = drivers.project_image(G2, t, None, None, args=args, mode="gradient", latent_space="w+", noise_mode="const", seed=2)
     assert tuple(r["w"].shape) == (1, cfg.k, cfg.num_ws, cfg.w_dim) and np.isfinite(r["losses"]).all()
-    assert max(G2._workspaces) == 1, sorted(G2._workspaces)
+    assert max(k[0] for k in G2._workspaces) == 1, sorted(G2._workspaces)
     kw = dict(args=args, mode="gradient", latent_space="w+", noise_mode="const", seed=2)
     many = drivers.project_many(G2, [t, (t * 0.9).contiguous()], **kw)
     assert tuple(many["latents"].shape) == (2, cfg.k, cfg.num_ws, cfg.w_dim)
     assert torch.equal(many["latents"][0].cpu(), r["w"][0])
     grp = drivers.project_many(G2, [t, (t * 0.9).contiguous()], lockstep=2, **kw)
-    assert tuple(grp["latents"].shape) == (2, cfg.k, cfg.num_ws, cfg.w_dim) and max(G2._workspaces) == 2
+    assert tuple(grp["latents"].shape) == (2, cfg.k, cfg.num_ws, cfg.w_dim) and max(k[0] for k in G2._workspaces) == 2
     with pytest.raises(ValueError):
         drivers.project_many(G2, [t], latent_space="w+", args=args)
 

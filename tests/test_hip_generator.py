@@ -227,7 +227,30 @@ def test_graph_replay_survives_other_batch_sizes(golden):
         eng.run(24)
         if disturb:
             junk = [G(torch.randn(n, TINY.k, TINY.z_dim, device="cuda"), None, noise_mode="const")[0] for n in (1, 7, 2)]
-            assert G._pins.get(4) == 1
+            assert G._pins.get((4, True)) == 1            # the engine pinned the LEAN workspace of its batch size
         eng.run(24)
         res.append(eng.result())
     assert res[0][1] == res[1][1] and torch.equal(res[0][0], res[1][0]) and np.array_equal(res[0][3], res[1][3])
+
+
+def test_lean_workspace_equals_full_workspace_and_is_a_third_of_it():
+    """forward_workspace(lean=True) -- what the literal loop runs on: layer outputs are views of seven arenas re-used block after block --
+    gives the image of the full workspace bit for bit (same kernels, same operands, other addresses), at 1024^2 and on the tiny config
+    (whose last block does NOT fuse the skip up-sampling: the lean layout keeps that block's full-resolution skip tensor), for a third of
+    the bytes; requests that hand out intermediate tensors (taps, return_att) fall back to the full flavour."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import FULL1024, TINY, make_state_dict, synthetic_latents
+    for cfg, n in ((TINY, 3), (FULL1024, 2)):
+        G = Generator(make_state_dict(cfg, seed=0), cfg, "cuda", max_batch=1)
+        z = torch.from_numpy(synthetic_latents(cfg, n, 77)).cuda()
+        full = G.forward_workspace(z, None, noise_mode="const")[0].clone()
+        lean = G.forward_workspace(z, None, noise_mode="const", lean=True)[0].clone()
+        assert torch.equal(full, lean) and G.lean and set(G._workspaces) >= {(n, False), (n, True)}
+        assert G._workspace_bytes(n, True) < 0.4 * G._workspace_bytes(n, False) or cfg is TINY
+        again = G.forward_workspace(z, None, noise_mode="const", lean=True, return_att=True, att_format="maps")
+        assert not G.lean and torch.equal(again[0], full)
+        G.taps = {}
+        G.forward_workspace(z, None, noise_mode="const", lean=True)
+        assert not G.lean and len(G.taps) > 4
+        G.taps = None
+    assert G._workspace_bytes(32, True) < 17 * 2 ** 30 < 40 * 2 ** 30 < G._workspace_bytes(32, False)       # 32 steps per forward: 15 vs 45 GiB
