@@ -4,29 +4,28 @@
                                                              children of a parent that never touches the GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (config 2 of BASELINE.json): one 1024x1024 synthetic target per GPU, literal-mode projection
+Workload (config 2 of BASELINE.json = configs[1]): one 1024x1024 synthetic target per GPU, literal-mode projection
 iteration = perturb latent -> GANformer generator forward (noise_mode="random", like the drivers) -> LPIPS(squeeze)
 + lamda*Wing(injected landmarks) + beta*MSE -> best-so-far selection, all resident on the device and replayed as a hipGraph.
-In literal mode the loop's steps do not depend on each other (the latent never receives a gradient), so the
-engine evaluates `--batch` consecutive steps per generator forward and examines them in step order: the result (best step,
-best latent, loss history) is the sequential loop's, bit for bit (tests/test_hip_projection.py), and every step's full work --
-its own noise draws, forward, three losses, selection -- is inside the timed region.  `steps` counts loop steps, not launches.
-The engine works in whole launch sequences of `--batch` (25) steps, and one sequence takes ~0.05 s, so the timed region is K rounded up
-to whole sequences and extended to at least `--min-seconds` (1 s): the line's `steps` is the number of steps that were really timed
-(`ms_per_step` and `value` are computed from it), `steps_requested` echoes K.
-With `--pipeline 1` the losses + selection of one batch run on a second stream while the generator already synthesises the next
-batch (separate buffers; same results; 496 vs 480 iters/s): every timed replay still contains one full generator batch and one
-full loss batch, the one generator batch that is in flight ahead of the losses is produced during warm-up.  It is off by default
-because concurrent kernels stretch each other: per-kernel durations would stop describing a kernel on its own.
-Weights are seeded synthetic tensors (no checkpoint exists offline); inputs are resident in HBM before the timed region.
-N > 1: one independent target per rank (pair-level sharding, no data-path collective) -> "weak" scaling; the only
-collective is the result gather after the timed region.
+In literal mode the loop's iterations do not depend on each other (the latent never receives a gradient), so the
+engine evaluates `--batch` (32) consecutive iterations per generator forward and examines them in order: the result (best step,
+best latent, loss history) is the sequential loop's, bit for bit (tests/test_hip_projection.py), and every iteration's full work --
+its own noise draws, forward, three losses, selection -- is inside the timed region.
 
-Rank 0 prints ONE JSON line.  Extra objects: "roofline" (the convolution kernel with the largest total time, algorithmic FLOPs /
-measured launch time vs the dense FP32-MFMA peak; Winograd launches are counted at the direct form's FLOPs), "generator_forward",
-"cpu_baseline" (the CPU oracle's port of the same iteration timed on the host cores, N=1 only) and "gradient_mode" (N=1 only,
---gradient-steps 0 skips it): the same objective with the loss back-propagated into the latent and Adam moving it, one target and
---gradient-lockstep targets per generator pass -- reported beside the metric, never in `value`.
+A bench STEP is one pass of the hot path over one batch: one launch sequence of `--batch` loop iterations (one hipGraph replay,
+0.045 s).  W untimed steps, then EXACTLY K timed steps; `steps` = K, `ms_per_step` = one launch sequence, `value` = loop iterations per
+second = K * batch / elapsed (`iters`, `iters_per_step`, `ms_per_iter` spell that out).  `--batch` is fixed, not derived from K, so the
+driver's run, the rocprofv3 trace and the PMC passes in profiles/ all launch the same kernels on the same shapes.
+Weights are seeded synthetic tensors (no checkpoint exists offline); inputs are resident in HBM before the timed region.
+N > 1: one independent target per rank (pair-level sharding, no data-path collective) -> "weak" scaling; the only collective is the
+result gather after the timed region.  `--workload config3` is the list-of-targets shape of BASELINE config 3 (see its help).
+
+Rank 0 prints ONE JSON line.  Extra objects (rank 0, N = 1): "roofline" (the MFMA conv kernel with the largest total time: executed
+FLOPs / event-measured launch time vs the dense FP32-MFMA peak, PMC traffic and mfma_busy from the committed passes),
+"generator_forward", "gradient_mode" (the loss back-propagated into the latent, Adam; one target and --gradient-lockstep targets),
+"many_targets" (projections/s set-up included), "objectives" (the LPIPS(vgg) loop and config 3's four-term loop with the FaceNet
+embedder), "landmark_callback" (a host detector in the loop), "cpu_baseline" (the CPU oracle's port of the same iteration on the host
+cores) -- all reported beside the metric, never in `value`.
 """
 import argparse
 import json
@@ -59,15 +58,14 @@ def host_cores():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20,
+                    help="timed STEPS: one step = one pass of the hot path over one batch = one launch sequence of --batch loop iterations "
+                         "(0.045 s at 1024^2); exactly this many are timed")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps before the timed region (graph capture included)")
     ap.add_argument("--res", type=int, default=1024, help="debug only; the reported config is 1024")
     ap.add_argument("--batch", type=int, default=32,
                     help="loop steps evaluated per generator forward (exact in literal mode).  Fixed (not derived from --steps) so that every "
                          "run -- the driver's, the rocprofv3 trace, the PMC passes in profiles/ -- launches the same kernels on the same shapes")
-    ap.add_argument("--min-seconds", type=float, default=1.0,
-                    help="the timed region is extended to at least this long (whole forwards; the line reports the real step count in `steps` "
-                         "and the request in `steps_requested`): one graph replay is 0.05 s, too short to time")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
@@ -148,7 +146,7 @@ def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0, pipelin
     return sd, G, percept, eng, target, latent_mean, float(latent_std), (lm_t, lm_s)
 
 
-def roofline_leg(eng, iters=3):
+def roofline_leg(eng, iters=3, pmc_tag=""):
     """Eager (un-graphed) iterations of the same step with every MFMA conv launch bracketed by HIP events on the launch
     stream, inside the library (mgf_conv_profile_begin/end): the main kernel only, so durations match rocprofv3's trace."""
     from morphganformer_amd import conv as cv
@@ -192,7 +190,7 @@ def roofline_leg(eng, iters=3):
     per_kernel = {k_: dict(v, executed_frac=round(v["tflops"] * (16 / 36 if k_.startswith("wino") else 1.0) / FP32_MFMA_PEAK_TFLOPS, 4))
                   for k_, v in per_kernel.items()}
     return {"bound": "mfma", "kernel": dom, "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4), **extra, **pmc_fields(dom, eng),
+            "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4), **extra, **pmc_fields(dom, eng, pmc_tag),
             "algorithmic_bytes_per_launch": round(nbytes / launches),
             "avg_launch_us": round(secs / launches * 1e6, 2), "launches_per_iter": launches // iters,
             "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
@@ -371,13 +369,13 @@ def objective_leg(cfg, device, G, target, latent_mean, latent_std, batch, lpips_
     eng.run(n_seq * batch)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    roof = roofline_leg(eng, iters=1)
+    roof = roofline_leg(eng, iters=1, pmc_tag="vgg_" if lpips_net == "vgg" else "config3_")
     out = {"value": round(n_seq * batch / dt, 2), "unit": "iters/s", "steps": n_seq * batch, "ms_per_step": round(dt / (n_seq * batch) * 1e3, 4),
            "steps_per_forward": batch, "hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
            "dominant_kernel": roof["kernel"], "executed_tflops": roof["achieved"], "executed_frac": roof["frac"],
            "algorithmic_tflops": roof["algorithmic_achieved"], "avg_launch_us": roof["avg_launch_us"],
            "launches_per_iter": roof["launches_per_iter"], "conv_ms_per_iter": roof["conv_ms_per_iter"],
-           "mfma_busy": roof.get("mfma_busy")}
+           "mfma_busy": roof.get("mfma_busy"), "mfma_busy_source": roof.get("mfma_busy_source")}
     del eng, percept, bio
     torch.cuda.empty_cache()
     return out
@@ -411,30 +409,30 @@ def landmark_callback_leg(cfg, device, G, percept, target, latent_mean, latent_s
             "note": "a real detector's own time comes on top (dlib: tens of ms per 1024^2 image on one core)"}
 
 
-def pmc_tables():
+def pmc_tables(tag=""):
     """The committed counter summaries of this workload (profiles/, newest round first): HBM-side bytes per launch and MFMA-pipe
     utilisation per kernel.  Counters cannot be read from inside the process (rocprofv3 --pmc is a separate run, and gpurun forbids
     mixing it with tracing), so bench.py reports the figures of the committed passes and says which file they come from."""
     out = {"traffic": None, "mfma": None}
-    for rnd in ("r3", "r2", "r1"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+    for rnd in ("r4", "r3", "r2", "r1"):                  # `tag` selects the passes of another workload ("vgg_": the LPIPS(vgg) loop)
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}pmc_traffic.json")
         if out["traffic"] is None and os.path.exists(path):
             with open(path) as fh:
-                out["traffic"] = (f"profiles/{rnd}_pmc_traffic.json", json.load(fh))
-        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_mfma.json")
+                out["traffic"] = (f"profiles/{rnd}_{tag}pmc_traffic.json", json.load(fh))
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}pmc_mfma.json")
         if out["mfma"] is None and os.path.exists(path):
             with open(path) as fh:
-                out["mfma"] = (f"profiles/{rnd}_pmc_mfma.json", json.load(fh))
+                out["mfma"] = (f"profiles/{rnd}_{tag}pmc_mfma.json", json.load(fh))
     return out
 
 
-def pmc_fields(kernel, eng):
+def pmc_fields(kernel, eng, tag=""):
     """`traffic` = HBM-side bytes per launch of `kernel` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this same
     workload, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled on gfx950, WRITE_SIZE as read; profiles/README.md).
     The passes are taken at `steps_per_forward` candidates per launch; for another count the bytes are scaled by the ratio (every
     operand of these kernels except the weights -- < 1 % of the bytes -- is per candidate) and the line says so.
     `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x SIMDs) of the same kernel from the committed MFMA pass."""
-    t = pmc_tables()
+    t = pmc_tables(tag)
     out = {"traffic": None}
     if eng.G.cfg.img_resolution != 1024:
         return out
@@ -708,30 +706,19 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return 0
-    assert a.batch >= 1
-    # the engine advances `batch` loop steps per launch sequence: K and W are rounded UP to whole launches (more work inside the
-    # timed region, never less), and the line reports the number of steps that were really timed
-    rup = lambda v: -(-v // a.batch) * a.batch
-    cap = max(rup(a.steps), 8192 if a.min_seconds > 0 else 0)            # room to extend the timed region to --min-seconds
-    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, cap + rup(a.warmup) + 3 * a.batch, not a.no_graph, a.batch,
+    assert a.batch >= 1 and a.steps >= 1 and a.warmup >= 0
+    # A bench STEP is one pass of the hot path over one batch: one launch sequence = `--batch` consecutive loop iterations of the
+    # projection (perturb, generator forward, three losses, in-order selection -- each iteration's full work).  W untimed steps, then
+    # EXACTLY K timed steps; `value` stays loop iterations per second (K * batch / elapsed).
+    seqs, warm = a.steps, a.warmup
+    steps = seqs * a.batch                             # loop iterations inside the timed region
+    sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, (seqs + warm + 4) * a.batch, not a.no_graph, a.batch,
                                                                       a.biometric, bool(a.pipeline), a.lpips_net)
 
-    log(f"built generator/LPIPS/engine on {device}; warm-up {a.warmup} steps (includes graph capture)")
-    eng.run(a.warmup)
+    log(f"built generator/LPIPS/engine on {device}; warm-up {warm} steps of {a.batch} loop iterations (+ graph capture)")
+    eng.run(max(warm, 1) * a.batch)                    # (graph capture needs one launch sequence even with --warmup 0)
     torch.cuda.synchronize()
-    # calibration (part of the warm-up): one more launch sequence, timed, to size the timed region
-    t0 = time.perf_counter()
-    eng.run(a.batch)
-    torch.cuda.synchronize()
-    per_launch = time.perf_counter() - t0
-    steps = rup(a.steps)
-    if a.min_seconds > 0:
-        steps = min(max(steps, rup(int(a.min_seconds / per_launch * a.batch) + 1)), cap)
-    if dist is not None:                               # every rank times the same number of steps
-        t = torch.tensor([steps], dtype=torch.int64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        steps = int(t.item())
-    log(f"warm-up done ({per_launch * 1e3:.1f} ms per launch sequence of {a.batch} steps); timing {steps} steps (requested {a.steps})")
+    log(f"warm-up done; timing {seqs} steps = {steps} loop iterations")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -742,7 +729,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    log(f"timed {steps} steps in {elapsed:.3f} s ({a.batch} steps per forward, {torch.cuda.max_memory_allocated(device) / 2 ** 30:.1f} GiB of HBM in use)")
+    log(f"timed {seqs} steps ({steps} loop iterations) in {elapsed:.3f} s ({a.batch} iterations per forward, {torch.cuda.max_memory_allocated(device) / 2 ** 30:.1f} GiB of HBM in use)")
     own_elapsed = elapsed
     rank_stats = {"per_rank_iters_per_s": [round(steps / own_elapsed, 3)], "gather_ms": None}
     if dist is not None:
@@ -770,8 +757,9 @@ def main():
 
     out = {
         "metric": "latent-projection iters/sec @1024^2, k=17 latents", "value": round(world * steps / elapsed, 3),
-        "unit": "iters/s", "n_gpus": world, "steps": steps, "steps_requested": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "unit": "iters/s", "n_gpus": world, "steps": seqs, "warmup": warm,
+        "ms_per_step": round(elapsed / seqs * 1e3, 4), "iters_per_step": a.batch, "iters": steps, "ms_per_iter": round(elapsed / steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks, "timed_seconds": round(elapsed, 4), "ranks": rank_stats,
         "hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
         "config": {"workload": f"configs[1]: single {a.res}x{a.res} face per GPU, Wing+LPIPS({a.lpips_net})+MSE literal-mode projection step, "
@@ -780,7 +768,7 @@ def main():
                    "targets_per_gpu": 1, "parallelism": f"pair-sharded x{world}", "graph_replay": not a.no_graph,
                    "loss_generator_overlap": bool(a.pipeline), "steps_per_forward": a.batch,
                    "lpips_backbone": f"seeded random {a.lpips_net} weights (torchvision's are a remote fetch) + the reference's vendored lin heads",
-                   "timed_region": f"{steps} steps = {steps // a.batch} graph replays (>= --min-seconds {a.min_seconds}; requested --steps {a.steps})"},
+                   "timed_region": f"{seqs} steps = {seqs} hipGraph replays of {a.batch} loop iterations each = {steps} iterations"},
     }
     if rank == 0:
         out["roofline"] = roofline_leg(eng)

@@ -609,15 +609,15 @@ def test_legacy_tf_conversion_matches_the_reference_converter():
 
 
 def test_bench_fixed_batch_and_torch_free_launcher():
-    """bench.py evaluates a FIXED 32 steps per generator forward (every run -- the driver's, the rocprofv3 trace, the PMC passes --
-    launches the same shapes), and parsing its arguments / deciding to self-launch must not import torch (the launcher parent stays
-    off the GPU)."""
+    """bench.py evaluates a FIXED 32 loop iterations per generator forward (every run -- the driver's, the rocprofv3 trace, the PMC passes --
+    launches the same shapes); a bench step is one such launch sequence and exactly --steps of them are timed (no extension of the timed
+    region); parsing its arguments / deciding to self-launch must not import torch (the launcher parent stays off the GPU)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys, importlib.util; sys.argv = ['bench.py', '--steps', '97']; "
             f"spec = importlib.util.spec_from_file_location('bench_mod', {os.path.join(root, 'bench.py')!r}); "
             "mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod); a = mod.parse(); "
-            "assert a.batch == 32 and a.steps == 97 and a.min_seconds == 1.0 and a.gpus == 1; "
+            "assert a.batch == 32 and a.steps == 97 and a.warmup == 5 and a.gpus == 1 and not hasattr(a, 'min_seconds'); "
             "assert 'torch' not in sys.modules and 'numpy' not in sys.modules; print('ok')")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]

@@ -5,12 +5,12 @@ set -e
 D=$1; LS=${2:-8}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$D"
-rocprofv3 --kernel-trace -d $D/gtrace1 -- python3 bench.py --steps 32 --warmup 32 --no-cpu-baseline --gradient-steps 6 --gradient-lockstep 0 --targets 0 --landmark-callback none > $D/g1.json 2> $D/g1.err
+rocprofv3 --kernel-trace -d $D/gtrace1 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --gradient-steps 6 --gradient-lockstep 0 --targets 0 --landmark-callback none --objectives 0 > $D/g1.json 2> $D/g1.err
 DB1=$(ls -t $(find $D/gtrace1 -name "*_results.db") | head -1)
 python3 tools/grad_step_trace.py $DB1 70 > $D/g1_totals.txt
 python3 tools/grad_step_trace.py $DB1 --ordered > $D/g1_ordered.txt
 if [ "$LS" != "0" ]; then
-rocprofv3 --kernel-trace -d $D/gtraceN -- python3 bench.py --steps 32 --warmup 32 --no-cpu-baseline --gradient-steps 6 --gradient-lockstep $LS --targets 0 --landmark-callback none > $D/gN.json 2> $D/gN.err
+rocprofv3 --kernel-trace -d $D/gtraceN -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --gradient-steps 6 --gradient-lockstep $LS --targets 0 --landmark-callback none --objectives 0 > $D/gN.json 2> $D/gN.err
 DBN=$(ls -t $(find $D/gtraceN -name "*_results.db") | head -1)
 python3 tools/grad_step_trace.py $DBN 70 > $D/gN_totals.txt
 python3 tools/grad_step_trace.py $DBN --ordered > $D/gN_ordered.txt
