@@ -739,7 +739,7 @@ int launch_conv(const ConvParams& p_in, hipStream_t st) {
     // persistent kernels: as many workgroups as the chip holds at once (2 per CU; 3 for the small-register variant)
     static const char* res_env = getenv("MGF_RESIDENT");      // tuning hook (experiments only): workgroups per CU
     const int64_t resident = (int64_t)MGF_NUM_CU * (res_env ? atoi(res_env) : ((WM == 1 && WN == 2 && MODE == 0) ? 3 : 2));
-    dim3 grid((unsigned)(pipe && (p.d.ntaps == 9 || (p.d.ntaps == 1 && MODE == 0)) ? (items < resident ? items : resident) : items));
+    dim3 grid((unsigned)(pipe && (p.d.ntaps == 9 || ((p.d.ntaps == 1 || p.d.ntaps == 7 || p.d.ntaps == 3) && MODE == 0)) ? (items < resident ? items : resident) : items));
     // XCD-aware order needs a grid that is a multiple of the 8 XCDs (a grid of ceil(items/8)*8 workgroups otherwise)
     static const char* xcd_env = getenv("MGF_XCD");            // tuning hook (experiments only): 0 disables the XCD-aware order
     p.xcd_per = 0;
@@ -757,6 +757,11 @@ int launch_conv(const ConvParams& p_in, hipStream_t st) {
     } else if (pipe && nt == 9) {
         ProfScope ps(st, WM, WN, MODE, 1, 9, p);
         hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE, true, 9>), grid, dim3(256), lds, st, p);
+    } else if (pipe && (nt == 7 || nt == 3) && MODE == 0) {
+        // 1x7 / 7x1 and 1x3 / 3x1 layers (InceptionResnetV1's Block17 / Block8): the pipelined, persistent form with the tap loop unrolled
+        ProfScope ps(st, WM, WN, MODE, 1, nt, p);
+        if (nt == 7) hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE == 1 ? 0 : MODE, true, 7>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE == 1 ? 0 : MODE, true, 3>), grid, dim3(256), lds, st, p);
     } else if (pipe && nt == 1 && MODE == 0) {
         ProfScope ps(st, WM, WN, MODE, 1, 1, p);
         hipLaunchKernelGGL((conv_taps_kernel<WM, WN, MODE == 1 ? 0 : MODE, true, 1>), grid, dim3(256), lds, st, p);

@@ -131,9 +131,17 @@ class SequentialFeatures:
                     self.convs[idx] = (cv.pack_weights(wt) if k == 3 else wt, b)          # > 9 taps: packed per tap group at run time
                     if USE_WINOGRAD_LPIPS and k == 3 and st_ == 1 and pd_ == 1 and ci % 4 == 0 and co % 32 == 0:
                         self.wino[idx] = cv.winograd2_weights(wt)
+                    elif USE_WINOGRAD_LPIPS and k == 3 and st_ == 1 and pd_ == 1 and ci == 3 and co % 32 == 0 and row is self.spec[0]:
+                        # VGG16's first layer (3 -> 64 at the full image size: 4.3 GB of output per 16 images, 58 GFLOP): a FOURTH, all-zero
+                        # input channel makes it a Winograd launch (the tap-list kernel stages 3 channels synchronously: 2.85 ms per 16 images)
+                        self.wino[idx] = cv.winograd2_weights(torch.cat([wt, torch.zeros_like(wt[:, :1])], dim=1).contiguous())
             self.shift, self.scale = t32(SHIFT).reshape(1, 3, 1, 1), t32(SCALE).reshape(1, 3, 1, 1)
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         self.xs = e(n, 3, h, w)
+        # the scaled input with a fourth, zero channel: what the first layer's Winograd form reads (see above)
+        first = self.spec[0]
+        self.xs4 = (torch.zeros(n, 4, h, w, dtype=torch.float32, device=dev)
+                    if first[1] in self.wino and first[2] == 3 and min(h, w) > 16 and cv.winograd_fills_chip(n, first[3], h, w) else None)
         self.bufs, self.shapes = [], {}
         c, hh, ww, tap = 3, h, w, 0
         for row in self.spec:
@@ -163,7 +171,10 @@ class SequentialFeatures:
                 wt, b = self.convs[idx]
                 nxt = self.spec[pos + 1]
                 dst = out[len(taps)] if (out is not None and nxt[0] == "tap") else buf
-                if idx in self.wino and min(h.shape[2:]) > 16 and cv.winograd_fills_chip(h.shape[0], co, h.shape[2], h.shape[3]):
+                if pos == 0 and self.xs4 is not None:
+                    self.xs4[:, :3].copy_(h)                          # channel 3 stays zero
+                    h = cv.winograd2_forward(self.xs4, self.wino[idx], epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dst)
+                elif idx in self.wino and ci % 4 == 0 and min(h.shape[2:]) > 16 and cv.winograd_fills_chip(h.shape[0], co, h.shape[2], h.shape[3]):
                     h = cv.winograd2_forward(h, self.wino[idx], epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dst)
                 elif k == 3:
                     h = cv.conv_forward(h, wt, stride=s, pad=(p, p), epilogue=_lib.make_epilogue(bias=b, act="relu"), out=dst)
