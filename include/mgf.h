@@ -407,6 +407,16 @@ int mgf_resize_bilinear_f32(float* y, const float* x, int32_t nc, int32_t in_h, 
  *   l2_normalize:  y[r] = x[r] / max(||x[r]||_2, eps)            (F.normalize(x, p=2, dim=1)), n rows of d floats */
 int mgf_spatial_mean_f32(float* y, const float* x, int32_t nc, int64_t hw, mgf_stream_t stream);
 int mgf_l2_normalize_f32(float* y, const float* x, int32_t n, int32_t d, float eps, mgf_stream_t stream);
+/* gradient mode of the same network (what autograd runs through the package's Block35 / Block17 / Block8 / Mixed_6a / Mixed_7a modules):
+ *   l2_normalize_bwd:  dx = (dy - y <y, dy>) / max(||x||, eps), y = x / max(||x||, eps)
+ *   spatial_mean_bwd:  dx[p, i] = dy[p] / hw
+ *   relu_bwd_slice:    dx[n, c, p] = y[n, y_choff + c, p] > 0 ? dy[n, dy_choff + c, p] : 0 -- the ReLU backward of ONE branch of a concat
+ *                      buffer: dy / y are channel slices of [n, dy_channels | y_channels, hw] tensors, dx is dense [n, c, hw]
+ * its convolution gradients are mgf_conv_taps_f32 / mgf_conv1x1_f32 launches on transposed taps. */
+int mgf_l2_normalize_bwd_f32(float* dx, const float* dy, const float* x, int32_t n, int32_t d, float eps, mgf_stream_t stream);
+int mgf_spatial_mean_bwd_f32(float* dx, const float* dy, int32_t nc, int64_t hw, mgf_stream_t stream);
+int mgf_relu_bwd_slice_f32(float* dx, const float* dy, int32_t dy_channels, int32_t dy_choff, const float* y, int32_t y_channels,
+                           int32_t y_choff, int32_t n, int32_t c, int64_t hw, mgf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Gradient mode: dLoss/dlatent through the synthesis network -- what torch autograd does for the reference when the loss is

@@ -105,6 +105,9 @@ _SIGS = {
     "mgf_resize_bilinear_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "mgf_spatial_mean_f32": (C.c_int, [vp, vp, i32, i64, vp]),
     "mgf_l2_normalize_f32": (C.c_int, [vp, vp, i32, i32, f32, vp]),
+    "mgf_l2_normalize_bwd_f32": (C.c_int, [vp, vp, vp, i32, i32, f32, vp]),
+    "mgf_spatial_mean_bwd_f32": (C.c_int, [vp, vp, i32, i64, vp]),
+    "mgf_relu_bwd_slice_f32": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i64, vp]),
     "mgf_maxpool_s2_floor_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mgf_maxpool3x3s2_ceil_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "mgf_latent_perturb": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),

@@ -98,6 +98,44 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(float* y, const float
     for (int i = threadIdx.x; i < d; i += 256) y[(int64_t)blockIdx.x * d + i] = xr[i] * inv;
 }
 
+// ---- gradient mode of the FaceNet head and its concat buffers ----
+// y = x / max(||x||, eps):  dx = (dy - y <y, dy>) / max(||x||, eps)   (the clamped branch ||x|| <= eps: dx = dy / eps)
+__global__ __launch_bounds__(256) void l2_normalize_bwd_kernel(float* dx, const float* dy, const float* x, int d, float eps) {
+    __shared__ float sm[8];
+    const float* xr = x + (int64_t)blockIdx.x * d;
+    const float* gr = dy + (int64_t)blockIdx.x * d;
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < d; i += 256) { a += xr[i] * xr[i]; b += xr[i] * gr[i]; }
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = a; sm[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    const float nrm = sqrtf(sm[0] + sm[1] + sm[2] + sm[3]), xg = sm[4] + sm[5] + sm[6] + sm[7];
+    if (nrm > eps) {
+        const float inv = 1.f / nrm, k = xg * inv * inv * inv;             // <y, dy> / ||x|| * (1 / ||x||) folded: dx = dy / r - x <x, dy> / r^3
+        for (int i = threadIdx.x; i < d; i += 256) dx[(int64_t)blockIdx.x * d + i] = gr[i] * inv - xr[i] * k;
+    } else {
+        for (int i = threadIdx.x; i < d; i += 256) dx[(int64_t)blockIdx.x * d + i] = gr[i] / eps;
+    }
+}
+
+// dx[p, i] = dy[p] / hw  (adjoint of spatial_mean_kernel)
+__global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(float* dx, const float* dy, int64_t hw, int64_t total) {
+    const float inv = 1.f / (float)hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) dx[i] = dy[i / hw] * inv;
+}
+
+// dx[n, c, p] = y[n, y_choff + c, p] > 0 ? dy[n, dy_choff + c, p] : 0 -- the ReLU backward of a BRANCH of a concat buffer: dy and y are
+// channel slices [choff, choff + c) of tensors with dy_ctot / y_ctot channels, dx is dense [n, c, hw]
+__global__ __launch_bounds__(256) void relu_bwd_slice_kernel(float* dx, const float* dy, int dy_ctot, int dy_choff, const float* y, int y_ctot,
+                                                             int y_choff, int c, int64_t hw, int64_t total) {
+    const int64_t per = (int64_t)c * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / per, r = i - n * per;
+        const float yv = y[(n * y_ctot + y_choff) * hw + r];
+        dx[i] = yv > 0.f ? dy[(n * dy_ctot + dy_choff) * hw + r] : 0.f;
+    }
+}
+
 // ---- gradient mode ----
 // dx = dy * (y > 0 ? 1 : slope[c]) from the PReLU OUTPUT y (valid for positive slopes: sign(y) = sign(pre-activation))
 __global__ __launch_bounds__(256) void prelu_bwd_kernel(float* dx, const float* dy, const float* y, const float* slope, int c, int64_t hw,
@@ -167,6 +205,34 @@ extern "C" int mgf_l2_normalize_f32(float* y, const float* x, int32_t n, int32_t
     MGF_REQUIRE(y && x && n >= 1 && d >= 1 && eps > 0.f, MGF_EINVAL, "l2_normalize: bad arguments");
     hipLaunchKernelGGL(l2_normalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, y, x, d, eps);
     MGF_CHECK_LAUNCH("l2_normalize");
+    return MGF_OK;
+}
+
+extern "C" int mgf_l2_normalize_bwd_f32(float* dx, const float* dy, const float* x, int32_t n, int32_t d, float eps, mgf_stream_t stream) {
+    MGF_REQUIRE(dx && dy && x && n >= 1 && d >= 1 && eps > 0.f, MGF_EINVAL, "l2_normalize_bwd: bad arguments");
+    hipLaunchKernelGGL(l2_normalize_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, dx, dy, x, d, eps);
+    MGF_CHECK_LAUNCH("l2_normalize_bwd");
+    return MGF_OK;
+}
+
+extern "C" int mgf_spatial_mean_bwd_f32(float* dx, const float* dy, int32_t nc, int64_t hw, mgf_stream_t stream) {
+    MGF_REQUIRE(dx && dy && nc >= 1 && hw >= 1, MGF_EINVAL, "spatial_mean_bwd: bad arguments");
+    const int64_t total = (int64_t)nc * hw;
+    hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(mgf_stream_grid(total, 256, 4)), dim3(256), 0, (hipStream_t)stream, dx, dy, hw, total);
+    MGF_CHECK_LAUNCH("spatial_mean_bwd");
+    return MGF_OK;
+}
+
+extern "C" int mgf_relu_bwd_slice_f32(float* dx, const float* dy, int32_t dy_channels, int32_t dy_choff, const float* y, int32_t y_channels,
+                                      int32_t y_choff, int32_t n, int32_t c, int64_t hw, mgf_stream_t stream) {
+    MGF_REQUIRE(dx && dy && y && n >= 1 && c >= 1 && hw >= 1, MGF_EINVAL, "relu_bwd_slice: bad arguments");
+    MGF_REQUIRE(dy_choff >= 0 && dy_choff + c <= dy_channels && y_choff >= 0 && y_choff + c <= y_channels, MGF_EINVAL,
+                "relu_bwd_slice: channel slice [%d, %d) / [%d, %d) outside its tensor (%d / %d channels)", dy_choff, dy_choff + c, y_choff,
+                y_choff + c, dy_channels, y_channels);
+    const int64_t total = (int64_t)n * c * hw;
+    hipLaunchKernelGGL(relu_bwd_slice_kernel, dim3(mgf_stream_grid(total, 256, 4)), dim3(256), 0, (hipStream_t)stream, dx, dy, dy_channels,
+                       dy_choff, y, y_channels, y_choff, c, hw, total);
+    MGF_CHECK_LAUNCH("relu_bwd_slice");
     return MGF_OK;
 }
 

@@ -21,7 +21,9 @@ Every convolution runs on the library's MFMA kernels: eval-mode BatchNorm is fol
 into the epilogue; branch outputs are written straight into their channel slice of the concat buffer; the residual blocks' closing 1x1 is
 ONE mgf_conv1x1_f32 launch whose epilogue adds the block input and applies the ReLU behind the add (MGF_ACT_RELU_POST), the block scale
 folded into its weights and bias; the 3x3 / stride-1 / pad-1 layers take the Winograd form-3 kernel when the launch fills the chip.
-Weights are injectable (`state`: facenet_pytorch's state_dict); offline they are seeded random (`random_state`).  PARITY IS UNPINNED:
+Gradient mode: `keep_activations = True` before the forward pass, then `backward(demb)` (data gradients on the same kernels with
+transposed taps, ReLU masks off the stored outputs).  Weights are injectable (`state`: facenet_pytorch's state_dict); offline they are
+seeded random (`random_state`).  PARITY IS UNPINNED:
 no golden vector of the real package can exist here; the oracle (oracle/embed_ref.py: inception_resnet_v1_ref) restates the same
 published topology with torch's own conv ops and the tests compare against it on seeded weights.
 """
@@ -211,14 +213,15 @@ class InceptionResnetV1Embedder:
         self.fc_b = t32(g("last_bn.bias") - g("last_bn.running_mean") * sb)
         self.n, self.hw = None, None
         self._n0 = n
+        self.keep_activations = False              # gradient mode sets this before the forward pass: backward() reads every layer output
         self.out = torch.empty(n, EMB, dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------ workspace
     def clone_for(self, n):
         """An instance sharing the packed weights but no mutable workspace (BiometricLoss keeps one for the target images)."""
         other = InceptionResnetV1Embedder.__new__(InceptionResnetV1Embedder)
-        other.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("bufs", "out", "n", "hw")})
-        other.n, other.hw, other._n0 = None, None, n
+        other.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("bufs", "out", "n", "hw", "_g", "_kept", "_x_in")})
+        other.n, other.hw, other._n0, other.keep_activations = None, None, n, False
         other.out = torch.empty(n, EMB, dtype=torch.float32, device=self.device)
         return other
 
@@ -230,31 +233,48 @@ class InceptionResnetV1Embedder:
                 return
             h, w = self.hw
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)
-        self.n, self.hw = n, (h, w)
+        keep = self.keep_activations                          # gradient mode: every layer output keeps its own tensor for backward()
+        self.n, self.hw, self._kept = n, (h, w), keep
+        self._g = None                                        # backward workspace (built on first use)
         B = {"stem": []}
         hh, ww, c = h, w, 3
+        out_hw = lambda L, hh, ww: ((hh + 2 * L.pad[0] - L.k[0]) // L.stride + 1, (ww + 2 * L.pad[1] - L.k[1]) // L.stride + 1)
         for name, L in self.stem:
             if L is None:
                 hh, ww = (hh - 3) // 2 + 1, (ww - 3) // 2 + 1
             else:
-                hh, ww = (hh + 2 * L.pad[0] - L.k[0]) // L.stride + 1, (ww + 2 * L.pad[1] - L.k[1]) // L.stride + 1
-                c = L.cout
+                (hh, ww), c = out_hw(L, hh, ww), L.cout
             if hh < 1 or ww < 1:
                 raise _lib.MgfError(f"InceptionResnetV1: a {h}x{w} image is too small")
             B["stem"].append(e(n, c, hh, ww))
         B["stages"] = []
+
+        def inter_bufs(branches, hh, ww, shared):
+            """{(branch, layer): tensor} for the non-final layers of every branch: own tensors (keep) or views of two ping-pong buffers."""
+            out = {}
+            for bi, br in enumerate(branches):
+                ih, iw = hh, ww
+                for li, L in enumerate(br[:-1]):
+                    ih, iw = out_hw(L, ih, iw)
+                    out[(bi, li)] = e(n, L.cout, ih, iw) if shared is None else shared[li & 1][:n * L.cout * ih * iw].view(n, L.cout, ih, iw)
+            return out
+
         for kind, c, body in self.stages:
             if kind == "res":
                 ccat = body[0][1].cin
                 tmp = max(max(L.cout for L in br[:-1]) if len(br) > 1 else 0 for br in body[0][0])
-                B["stages"].append(dict(cat=e(n, ccat, hh, ww), t=[e(n, tmp, hh, ww), e(n, tmp, hh, ww)], x=[e(n, c, hh, ww), e(n, c, hh, ww)]))
+                shared_t = None if keep else [e(n * tmp * hh * ww), e(n * tmp * hh * ww)]
+                shared_cat, shared_x = (None, None) if keep else (e(n, ccat, hh, ww), [e(n, c, hh, ww), e(n, c, hh, ww)])
+                blocks = [dict(cat=e(n, ccat, hh, ww) if keep else shared_cat, t=inter_bufs(brs, hh, ww, shared_t),
+                               x=e(n, c, hh, ww) if keep else shared_x[bi & 1]) for bi, (brs, _, _) in enumerate(body)]
+                B["stages"].append(dict(blocks=blocks, hw=(hh, ww)))
             else:
                 oh, ow = (hh - 3) // 2 + 1, (ww - 3) // 2 + 1
                 if oh < 1 or ow < 1:
                     raise _lib.MgfError(f"InceptionResnetV1: a {h}x{w} image is too small")
                 tmp = max(L.cout for br in body for L in br[:-1])
-                cin = body[0][0].cin
-                B["stages"].append(dict(cat=e(n, c, oh, ow), t=[e(n, tmp, hh, ww), e(n, tmp, hh, ww)], pool=e(n, cin, oh, ow)))
+                shared_t = None if keep else [e(n * tmp * hh * ww), e(n * tmp * hh * ww)]
+                B["stages"].append(dict(cat=e(n, c, oh, ow), t=inter_bufs(body, hh, ww, shared_t), pool=e(n, body[0][0].cin, oh, ow), hw=(hh, ww)))
                 hh, ww = oh, ow
         B["mean"] = e(n, 1792)
         B["pre"] = e(n, EMB)
@@ -277,44 +297,38 @@ class InceptionResnetV1Embedder:
         _lib.check(_lib.lib().mgf_maxpool_s2_floor_f32(y.data_ptr(), x.data_ptr(), n * c, h, w, 3, _lib.stream_ptr()), "maxpool")
         return y
 
-    def _branch(self, x, br, tmps, cat, choff):
-        """A chain of BasicConv2d: intermediate results ping-pong through `tmps`, the last layer writes its slice of the concat buffer."""
+    def _branch(self, x, br, bi, inter, cat, choff):
+        """A chain of BasicConv2d: intermediate results go to `inter[(branch, layer)]`, the last layer writes its slice of the concat buffer."""
         h = x
         for li, L in enumerate(br):
-            last = li == len(br) - 1
-            if last:
+            if li == len(br) - 1:
                 self._conv(h, L, cat, choff)
             else:
-                t = tmps[li & 1]
-                oh = (h.shape[2] + 2 * L.pad[0] - L.k[0]) // L.stride + 1
-                ow = (h.shape[3] + 2 * L.pad[1] - L.k[1]) // L.stride + 1
-                dst = t.view(-1)[:h.shape[0] * L.cout * oh * ow].view(h.shape[0], L.cout, oh, ow)
-                h = self._conv(h, L, dst)
+                h = self._conv(h, L, inter[(bi, li)])
         return br[-1].cout
 
     def embed_image(self, img, out=None):
         _lib.require_gpu(img, out)
         n, c, h, w = img.shape
         assert c == 3 and img.dtype == torch.float32
-        if (self.n, self.hw) != (n, (h, w)):
+        if (self.n, self.hw, getattr(self, "_kept", None)) != (n, (h, w), self.keep_activations):
             self._alloc(n, h, w)
         B = self.bufs
-        x = img.contiguous()
+        x = self._x_in = img.contiguous()
         for (name, L), buf in zip(self.stem, B["stem"]):
             x = self._pool(buf, x) if L is None else self._conv(x, L, buf)
         for (kind, c, body), S in zip(self.stages, B["stages"]):
             if kind == "res":
-                for bi, (brs, close, relu) in enumerate(body):
+                for (brs, close, relu), K in zip(body, S["blocks"]):
                     off = 0
-                    for br in brs:
-                        off += self._branch(x, br, S["t"], S["cat"], off)
-                    dst = S["x"][bi & 1]
+                    for bi, br in enumerate(brs):
+                        off += self._branch(x, br, bi, K["t"], K["cat"], off)
                     # out = [relu](conv2d(cat) * scale + x): scale folded into the weights / bias, the add and the ReLU in the epilogue
-                    x = self._conv(S["cat"], close, dst, act="relu_post" if relu else "linear", residual=x)
+                    x = self._conv(K["cat"], close, K["x"], act="relu_post" if relu else "linear", residual=x)
             else:
                 off = 0
-                for br in body:
-                    off += self._branch(x, br, S["t"], S["cat"], off)
+                for bi, br in enumerate(body):
+                    off += self._branch(x, br, bi, S["t"], S["cat"], off)
                 self._pool(S["pool"], x)
                 S["cat"][:, off:].copy_(S["pool"])                          # the max-pool branch: last slice of the concat buffer
                 x = S["cat"]
@@ -328,7 +342,152 @@ class InceptionResnetV1Embedder:
         _lib.check(L_.mgf_l2_normalize_f32(out.data_ptr(), B["pre"].data_ptr(), n, EMB, 1e-12, st), "l2_normalize")
         return out
 
-    __call__ = embed_image
+    # ------------------------------------------------------------------ backward (gradient mode)
+    def _gpack(self, L):
+        """Transposed taps of a layer's data gradient, built once: stride 1 -> the flipped, channel-transposed kernel (a correlation's
+        gradient is a true convolution), stride 2 -> the same taps for the transposed-conv kernel."""
+        gp = getattr(self, "_gpacks", None)
+        if gp is None:
+            gp = self._gpacks = {}
+        t = gp.get(id(L))
+        if t is None:
+            t = gp[id(L)] = cv.transpose_packed(L.pc, flip=(L.stride == 1 and L.k != (1, 1)))
+        return t
+
+    def _gbuf(self, key, shape):
+        t = self._g.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._g[key] = torch.empty(shape, dtype=torch.float32, device=self.device)
+        return t
+
+    def _mask(self, key, dy, y, c, dy_off=0, y_off=0):
+        """dx = dy[:, dy_off : dy_off + c] where y[:, y_off : y_off + c] > 0 else 0 (ReLU backward off the layer OUTPUT), dense."""
+        n, hw = dy.shape[0], dy.shape[2] * dy.shape[3]
+        dx = self._gbuf(key, (n, c, dy.shape[2], dy.shape[3]))
+        _lib.check(_lib.lib().mgf_relu_bwd_slice_f32(dx.data_ptr(), dy.data_ptr(), dy.shape[1], dy_off, y.data_ptr(), y.shape[1], y_off, n, c, hw,
+                                                     _lib.stream_ptr()), "relu_bwd_slice")
+        return dx
+
+    def _dgrad(self, key, g, L, in_shape, accumulate_into=None):
+        """d(input) of one (already ReLU-masked) BasicConv2d / closing conv: g [n, cout, oh, ow] -> [n, cin, H, W].  accumulate_into: add the
+        result to that tensor in place (stride-1 layers: through the conv epilogue's residual port) and return it."""
+        n, cin, H, W = in_shape
+        T = self._gpack(L)
+        if L.stride == 1:
+            pad = (L.k[0] - 1 - L.pad[0], L.k[1] - 1 - L.pad[1])
+            if accumulate_into is not None:
+                return cv.conv_forward(g, T, pad=pad, epilogue=_lib.make_epilogue(residual=accumulate_into), out=accumulate_into)
+            return cv.conv_forward(g, T, pad=pad, out=self._gbuf(key, in_shape))
+        # 3x3 / stride 2 / no padding: x[2i + k] += w[k] g[i] = the transposed-conv kernel; rows / columns past 2 oh (an even input side) get nothing
+        oh, ow = g.shape[2:]
+        t = cv.tconv3x3s2_forward(g.contiguous(), T, out=self._gbuf(key + ("t",), (n, cin, 2 * oh + 1, cv.tconv_pitch(ow))))
+        if accumulate_into is not None:
+            accumulate_into[:, :, :2 * oh + 1, :2 * ow + 1].add_(t)
+            return accumulate_into
+        dx = self._gbuf(key, in_shape)
+        if (H, W) != (2 * oh + 1, 2 * ow + 1):
+            dx.zero_()
+        dx[:, :, :2 * oh + 1, :2 * ow + 1].copy_(t)
+        return dx
+
+    def _branch_bwd(self, key, g, br, bi, inter, x_in, dxin):
+        """Backward of one branch: g = the masked gradient of its LAST layer's output; intermediate outputs from `inter`; the first layer's
+        input is the block input x_in, whose gradient accumulates into dxin."""
+        for li in range(len(br) - 1, -1, -1):
+            L = br[li]
+            if li == 0:
+                self._dgrad(key + (bi, li), g, L, tuple(x_in.shape), accumulate_into=dxin)
+            else:
+                y_prev = inter[(bi, li - 1)]
+                gp = self._dgrad(key + (bi, li), g, L, tuple(y_prev.shape))
+                g = self._mask(key + (bi, li, "m"), gp, y_prev, y_prev.shape[1])
 
     def backward(self, demb, dimg=None, accumulate=False):
-        raise NotImplementedError("InceptionResnetV1Embedder has no backward pass yet: gradient mode takes the IResNet embedder (iresnet.py)")
+        """demb [n, 512] -> the gradient with respect to the image of the latest embed_image() call (keep_activations must have been set
+        before that call).  With `dimg` the result is written (added, when `accumulate`) there; otherwise a [n, 3, H, W] tensor is returned."""
+        _lib.require_gpu(demb, dimg)
+        if not getattr(self, "_kept", False):
+            raise _lib.MgfError("InceptionResnetV1Embedder.backward: set keep_activations = True before the forward pass (gradient mode)")
+        if self._g is None:
+            self._g = {}
+        L_, st, n, B = _lib.lib(), _lib.stream_ptr(), self.n, self.bufs
+        dpre = self._gbuf(("dpre",), (n, EMB))
+        _lib.check(L_.mgf_l2_normalize_bwd_f32(dpre.data_ptr(), demb.contiguous().data_ptr(), B["pre"].data_ptr(), n, EMB, 1e-12, st), "l2_normalize_bwd")
+        dmean = self._gbuf(("dmean",), (n, 1792))
+        for r0 in range(0, n, 16):
+            rows = min(16, n - r0)
+            _lib.check(L_.mgf_linear_bwd_f32(dmean[r0:].data_ptr(), dpre[r0:].data_ptr(), self.fc_w.data_ptr(), rows, 1792, EMB, st), "linear_bwd")
+        last = B["stages"][-1]["blocks"][-1]["x"]
+        dx = self._gbuf(("dx", len(self.stages), 0), tuple(last.shape))
+        _lib.check(L_.mgf_spatial_mean_bwd_f32(dx.data_ptr(), dmean.data_ptr(), n * 1792, last.shape[2] * last.shape[3], st), "spatial_mean_bwd")
+        # the input of stage i: the output of stage i - 1 (the last block's x, or the mixed stage's concat buffer), the stem's output for i = 0
+        stage_in = [B["stem"][-1]] + [(S["blocks"][-1]["x"] if "blocks" in S else S["cat"]) for S in B["stages"][:-1]]
+        for si in range(len(self.stages) - 1, -1, -1):
+            (kind, c, body), S = self.stages[si], B["stages"][si]
+            if kind == "res":
+                for bi in range(len(body) - 1, -1, -1):
+                    (brs, close, relu), K = body[bi], S["blocks"][bi]
+                    x_in = S["blocks"][bi - 1]["x"] if bi > 0 else stage_in[si]
+                    # out = [relu](conv2d(cat) + x): d(pre) = dx masked by the block OUTPUT; it is also the residual path's d(x_in)
+                    dxin = self._mask(("dx", si, bi), dx, K["x"], c) if relu else dx
+                    # (the closing conv's gradient needs d(pre) BEFORE the branches add to it: keep a copy)
+                    dpre_blk = self._gbuf(("dpre_blk", si), tuple(dxin.shape))
+                    dpre_blk.copy_(dxin)
+                    off = 0
+                    for b, br in enumerate(brs):
+                        cb = br[-1].cout
+                        gcat = cv.conv_forward(dpre_blk, self._closing_slice(close, off, cb), out=self._gbuf(("gcat", si, b), (n, cb, *K["cat"].shape[2:])))
+                        g = self._mask(("gm", si, b), gcat, K["cat"], cb, 0, off)
+                        self._branch_bwd(("br", si), g, br, b, K["t"], x_in, dxin)
+                        off += cb
+                    dx = dxin
+            else:
+                x_in = stage_in[si]
+                dxin = self._gbuf(("dx", si, 0), tuple(x_in.shape))
+                off = sum(br[-1].cout for br in body)
+                cpool = x_in.shape[1]
+                gpool = self._gbuf(("gpool", si), tuple(S["pool"].shape))
+                gpool.copy_(dx[:, off:off + cpool])
+                _lib.check(L_.mgf_maxpool_s2_floor_bwd_f32(dxin.data_ptr(), gpool.data_ptr(), x_in.data_ptr(), n * cpool, x_in.shape[2], x_in.shape[3],
+                                                           3, st), "maxpool_bwd")
+                off = 0
+                for b, br in enumerate(body):
+                    cb = br[-1].cout
+                    g = self._mask(("gm", si, b), dx, S["cat"], cb, off, off)
+                    self._branch_bwd(("br", si), g, br, b, S["t"], x_in, dxin)
+                    off += cb
+                dx = dxin
+        # stem, in reverse: every BasicConv2d output is a ReLU output
+        stem_in = [self._x_in] + B["stem"][:-1]
+        for i in range(len(self.stem) - 1, -1, -1):
+            (name, L), y, x_in = self.stem[i], B["stem"][i], stem_in[i]
+            if L is None:
+                dxi = self._gbuf(("stem", i), tuple(x_in.shape))
+                _lib.check(L_.mgf_maxpool_s2_floor_bwd_f32(dxi.data_ptr(), dx.contiguous().data_ptr(), x_in.data_ptr(), n * x_in.shape[1], x_in.shape[2],
+                                                           x_in.shape[3], 3, st), "maxpool_bwd")
+            else:
+                g = self._mask(("stem", i, "m"), dx, y, L.cout)
+                dxi = self._dgrad(("stem", i), g, L, tuple(x_in.shape))
+            dx = dxi
+        if dimg is None:
+            return dx
+        if accumulate:
+            dimg.add_(dx)
+        else:
+            dimg.copy_(dx)
+        return dimg
+
+    def _closing_slice(self, close, off, cb):
+        """The data-gradient weights of a residual block's closing 1x1 for ONE branch of its concat input: out channels [off, off + cb)
+        of the transposed kernel, as a packed 1x1 conv c -> cb (so that each branch's gradient leaves as a dense tensor)."""
+        cache = getattr(self, "_cslices", None)
+        if cache is None:
+            cache = self._cslices = {}
+        key = (id(close), off, cb)
+        t = cache.get(key)
+        if t is None:
+            w = close.pc.wp[0, off:off + cb, :close.cout]                     # packed [tap = 1][cin = ccat][cout_pad]: rows = cat channels
+            t = cache[key] = cv.pack_weights(w.reshape(cb, close.cout, 1, 1).contiguous())
+        return t
+
+    __call__ = embed_image

@@ -681,6 +681,8 @@ class GradientProjectionEngine(ProjectionEngine):
             assert landmark_fn is None and landmark_model is None, "landmark detectors are wired for one target per engine"
         self.targets = B
         a, dev = self.args, self.device
+        if biometric is not None and hasattr(biometric.embedder, "keep_activations"):
+            biometric.embedder.keep_activations = True          # (the FaceNet embedder re-uses its buffers block after block otherwise)
         self.gg = GeneratorGrad(G)
         self.betas, self.adam_eps, self.weight_decay = betas, float(adam_eps), float(weight_decay)
         self.lr_table = torch.as_tensor(np.array([get_lr(i / a.step, a.lr, a.lr_rampdown, a.lr_rampup) for i in range(a.step)],

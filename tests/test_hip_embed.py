@@ -135,8 +135,8 @@ def test_facenet_inception_resnet_v1_vs_oracle(n, size):
         want = inception_resnet_v1_ref({k: torch.from_numpy(v) for k, v in sd_np.items()}, x, taps)
     assert tuple(emb.shape) == (n, 512)
     assert float((emb.norm(dim=1) - 1).abs().max()) < 1e-5
-    got_taps = {"stem": net.bufs["stem"][-1], "repeat_1": net.bufs["stages"][0]["x"][0], "repeat_2": net.bufs["stages"][2]["x"][1],
-                "block8": net.bufs["stages"][4]["x"][1]}
+    got_taps = {"stem": net.bufs["stem"][-1], "repeat_1": net.bufs["stages"][0]["blocks"][-1]["x"], "repeat_2": net.bufs["stages"][2]["blocks"][-1]["x"],
+                "block8": net.bufs["stages"][4]["blocks"][-1]["x"]}
     for k, t in got_taps.items():
         assert tuple(t.shape) == tuple(taps[k].shape), k
         assert float((t.cpu() - taps[k]).abs().max()) < 1e-4 * float(taps[k].abs().max()), k
@@ -178,5 +178,66 @@ def test_facenet_biometric_term_in_the_loop(golden):
             want = float(mse_ref(img, target.cpu())) + gamma * float(facenet_loss_ref(tsd, img, target.cpu()))
         assert abs(losses[i] - want) < 1e-3 * abs(want), (i, losses[i], want)
     assert bstep == int(np.argmin(losses))
-    with pytest.raises(NotImplementedError):
-        bio.grad_into(torch.zeros_like(target))
+
+
+@pytest.mark.parametrize("n,size", [(2, 160), (1, (99, 131))])
+def test_facenet_gradient_matches_autograd(n, size):
+    """d(scale * MSE(embed(pred), embed(target)))/d(pred) through the InceptionResnetV1 embedder vs FLOAT64 autograd through the oracle's
+    restatement.  ~130 ReLU layers make the gradient piecewise: a pre-activation within float32 rounding of zero takes the other branch in
+    any float32 implementation, so the gate is on the bulk of the error distribution (median, rms), like the IResNet test."""
+    from morphganformer_amd.facenet import random_state
+    from morphganformer_amd.iresnet import BiometricLoss
+    from oracle.embed_ref import facenet_loss_ref
+    h, w = (size, size) if isinstance(size, int) else size
+    torch.manual_seed(h * w + n)
+    sd_np = random_state(9)
+    pred = (torch.rand(n, 3, h, w, dtype=torch.float64) * 2 - 1).requires_grad_(True)
+    target = torch.rand(1, 3, h, w, dtype=torch.float64) * 2 - 1
+    val = facenet_loss_ref({k: torch.from_numpy(v).double() for k, v in sd_np.items()}, pred, target.expand(n, -1, -1, -1))
+    (ref,) = torch.autograd.grad(val.sum() * 3e6, pred)          # (unit-norm embeddings of random nets: the raw gradient is ~1e-7)
+    bio = BiometricLoss("facenet", state=sd_np, n=n)
+    bio.embedder.keep_activations = True
+    bio.set_target(target.float().cuda())
+    out = torch.empty(n, device="cuda")
+    bio.distance_into(out, pred.detach().float().cuda())
+    assert float((out.cpu().double() - val.detach()).abs().max()) < 1e-3 * float(val.detach().abs().max())
+    dimg = torch.full((n, 3, h, w), 0.5, device="cuda")
+    bio.grad_into(dimg, scale=3e6, accumulate=True)
+    first = dimg.clone()
+    bio.grad_into(dimg, scale=3e6)
+    assert torch.allclose(first - 0.5, dimg, rtol=0, atol=1e-5 * float(ref.abs().max()))      # accumulate adds to what was there
+    err = (dimg.double().cpu() - ref).abs() / ref.abs().max()
+    assert float(err.median()) < 2e-5 and float(err.square().mean().sqrt()) < 2e-3, (float(err.median()), float(err.square().mean().sqrt()))
+    # without keep_activations the buffers were re-used block after block: the backward refuses
+    plain = BiometricLoss("facenet", state=sd_np, n=n)
+    plain.set_target(target.float().cuda())
+    plain.distance_into(out, pred.detach().float().cuda())
+    from morphganformer_amd import _lib
+    with pytest.raises(_lib.MgfError, match="keep_activations"):
+        plain.grad_into(dimg)
+
+
+def test_gradient_projection_with_the_facenet_term():
+    """Gradient mode with BASELINE config 3's embedder: GradientProjectionEngine(biometric=BiometricLoss("facenet")) on the 256^2 generator
+    runs as a replayed graph, its first loss equals the literal engine's loss of the same candidate, and Adam moves the latent."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.iresnet import BiometricLoss
+    from morphganformer_amd.projection import GradientProjectionEngine, ProjectionArgs, ProjectionEngine
+    from morphganformer_amd.synth_weights import SMALL256, make_state_dict
+    cfg = SMALL256
+    G = Generator(make_state_dict(cfg, seed=0), cfg, "cuda", max_batch=1)
+    steps = 5
+    torch.manual_seed(4)
+    latent_mean = torch.randn(cfg.k, cfg.z_dim, device="cuda")
+    eps = torch.randn(steps, 1, cfg.k, cfg.z_dim, device="cuda")
+    target = G(torch.randn(1, cfg.k, cfg.z_dim, device="cuda"), None, noise_mode="const")[0].clamp(-1, 1).clone()
+    args = ProjectionArgs(step=steps, lr=0.05, lr_rampup=0.2, min_loss_init=1e30)
+    mk = lambda cls, **kw: cls(G, target, latent_mean, 1.0, args, percept=None, eps=eps, noise_mode="const",
+                               biometric=BiometricLoss("facenet", n=1, seed=2), gamma=10.0, **kw)
+    lit = mk(ProjectionEngine, batch=1, use_graph=False).run(1)
+    first_literal = float(lit.losses[0])
+    eng = mk(GradientProjectionEngine, use_graph=True).run()
+    lat, bstep, bloss, losses = eng.result()
+    assert np.isfinite(losses).all()
+    assert abs(losses[0] - first_literal) < 1e-4 * abs(first_literal)       # step 0: lr = 0, same candidate, same objective
+    assert float((eng.latent_in[0] - latent_mean).abs().max()) > 0.01
