@@ -295,6 +295,14 @@ int mgf_attn_values(const mgf_attn_job* job, const float* ws, int64_t ws_stride_
 int mgf_attn_values_multi(const mgf_attn_job* jobs_dev, int32_t njobs, const float* ws, int64_t ws_stride_n, int64_t ws_stride_t,
                           int32_t n, int32_t t, int32_t wdim, mgf_stream_t stream);
 
+/* Per-layer noise maps of noise_mode="random" (networks.py:1016-1017: torch.randn per layer and call) and the per-sample ToRGB weights of
+ * the fused conv_last epilogue (networks.py:1056-1063), so that the captured launch sequence holds hand-written kernels only.
+ *   randn:       out[0:n] ~ N(0,1): Philox4x32-10 keyed by `seed`, Box-Muller; `state` = 16 zero-initialised device bytes {uint64 stream
+ *                position, uint32 ticket, pad} that the launch advances itself -- a replayed hipGraph draws fresh numbers every time
+ *   rgb_weights: out[n, c, co] = w[c, co] * s[n, co] */
+int mgf_randn_f32(float* out, int64_t n, uint64_t seed, void* state, mgf_stream_t stream);
+int mgf_rgb_weights_f32(float* out, const float* w, const float* s, int32_t n, int32_t c, int32_t cout, mgf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Mapping network z -> w  (MappingNetwork.forward, training/networks.py:894-942 with MLP/ResnetLayer :154-221 and the
  * latent self-attention TransformerLayer :748-822).  One workgroup per sample.

@@ -91,6 +91,8 @@ _SIGS = {
     "mgf_att_map_upsample_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mgf_attn_values": (C.c_int, [C.POINTER(AttnJob), vp, i64, i64, i32, i32, i32, vp]),
     "mgf_attn_values_multi": (C.c_int, [vp, i32, vp, i64, i64, i32, i32, i32, vp]),
+    "mgf_randn_f32": (C.c_int, [vp, i64, C.c_uint64, vp, vp]),
+    "mgf_rgb_weights_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "mgf_mapping_param_floats": (i64, [i32, i32, i32]),
     "mgf_mapping_forward": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mgf_reduce_scratch_floats": (i64, []),

@@ -1095,7 +1095,8 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     int ksplit = 1;
     static const int splitk_below = [] { const char* e = getenv("MGF_SPLITK_BELOW"); return e ? atoi(e) : 256; }();   // tuning hook (512 / 256 / 128: 99.6 / 100.4 / 101.1 single-target gradient iters/s, 542 / 548 / 545 literal)
     if (d.workspace && base_wgs < splitk_below && nchunks >= 4 && !d.rgb_out) {
-        ksplit = (int)mgf_cdiv(1024, base_wgs);
+        static const int splitk_target = [] { const char* e = getenv("MGF_SPLITK_TARGET"); return e ? atoi(e) : 1024; }();      // tuning hook: workgroups wanted
+        ksplit = (int)mgf_cdiv(splitk_target, base_wgs);
         if (ksplit > nchunks / 2) ksplit = nchunks / 2;
         const int64_t slice = (int64_t)d.n * d.cout * d.out_h * d.y_pitch;
         while (ksplit > 1 && slice * ksplit > d.workspace_floats) --ksplit;

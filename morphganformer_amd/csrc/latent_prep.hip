@@ -696,6 +696,76 @@ extern "C" int mgf_mapping_backward(float* dz, const float* dw, const float* z, 
     return MGF_OK;
 }
 
+namespace {
+// N(0, 1) draws for the per-layer noise maps of noise_mode="random" (networks.py:1016-1017 draws them with torch.randn per layer and call):
+// Philox4x32-10 keyed by `seed`, counter = *counter + lane index, four normals per counter value through two Box-Muller pairs.  The
+// stream position lives in DEVICE memory and the launch advances it itself (the last workgroup to finish adds the number of counter
+// values used), so a replayed hipGraph draws fresh numbers every time without any host involvement.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* out, int64_t n, uint64_t seed, unsigned long long* counter, unsigned* ticket) {
+    const unsigned long long base = *counter;                       // (every workgroup reads it before the last one to finish advances it)
+    const int64_t quads = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256) {
+        const unsigned long long ctr = base + (unsigned long long)q;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;          // (0, 1]: + 0.5 keeps the logarithm finite
+            const float u2 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+            const float r = sqrtf(-2.f * logf(u1 < 1.f ? u1 : 0.99999994f));
+            float sn, cs;
+            sincospif(2.f * u2, &sn, &cs);
+            z[2 * h] = r * cs; z[2 * h + 1] = r * sn;
+        }
+        if (4 * q + 4 <= n && (((uintptr_t)out) & 15) == 0) *reinterpret_cast<float4*>(out + 4 * q) = make_float4(z[0], z[1], z[2], z[3]);
+        else for (int e = 0; e < 4 && 4 * q + e < n; ++e) out[4 * q + e] = z[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {                                  // the last workgroup: every other one has read `base` by now
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(counter, base + (unsigned long long)quads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// rgbw[n, c, co] = w[c, co] * s[n, co]: the per-sample ToRGB weights the fused conv_last epilogue projects with (networks.py:1056-1063)
+__global__ __launch_bounds__(256) void rgb_weights_kernel(float* out, const float* w, const float* s, int c, int co, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int o = i % co, n = i / (c * co);
+    out[i] = w[i % (c * co)] * s[n * co + o];
+}
+}  // namespace
+
+extern "C" int mgf_randn_f32(float* out, int64_t n, uint64_t seed, void* state, mgf_stream_t stream) {
+    MGF_REQUIRE(out && state && n >= 1, MGF_EINVAL, "randn: bad arguments");
+    MGF_REQUIRE(((uintptr_t)state % 8) == 0, MGF_EINVAL, "randn: the 16-byte state {uint64 counter, uint32 ticket, pad} must be 8-byte aligned");
+    const int grid = mgf_stream_grid((n + 3) / 4, 256, 4);
+    hipLaunchKernelGGL(randn_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, n, seed, reinterpret_cast<unsigned long long*>(state),
+                       reinterpret_cast<unsigned*>(reinterpret_cast<char*>(state) + 8));
+    MGF_CHECK_LAUNCH("randn");
+    return MGF_OK;
+}
+
+extern "C" int mgf_rgb_weights_f32(float* out, const float* w, const float* s, int32_t n, int32_t c, int32_t cout, mgf_stream_t stream) {
+    MGF_REQUIRE(out && w && s && n >= 1 && c >= 1 && cout >= 1 && (int64_t)n * c * cout <= INT32_MAX, MGF_EINVAL, "rgb_weights: bad arguments");
+    const int total = n * c * cout;
+    hipLaunchKernelGGL(rgb_weights_kernel, dim3((unsigned)mgf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out, w, s, c, cout, total);
+    MGF_CHECK_LAUNCH("rgb_weights");
+    return MGF_OK;
+}
+
 extern "C" int mgf_mapping_forward_save(float* w, const float* z, const float* params, float* scratch, int32_t n, int32_t k, int32_t dim,
                                         int32_t n_res_layers, int32_t normalize_global, mgf_stream_t stream) {
     MGF_REQUIRE(w && z && params && scratch, MGF_EINVAL, "mapping_forward_save: null pointer");

@@ -232,6 +232,8 @@ class Generator:
         # roofline leg -- so per-kernel durations would no longer agree between bench.py and a rocprofv3 trace.
         self.overlap_skip = os.environ.get("MGF_OVERLAP_SKIP", "0") != "0"
         self._workspaces, self._pins = {}, {}
+        self.noise_seed, self._noise_epoch = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, None
+        self.noise_state = torch.zeros(2, dtype=torch.int64, device=self.device)          # {stream position, ticket}: advanced on the device
         self._alloc(max_batch)
 
     # ------------------------------------------------------------------ workspace
@@ -540,7 +542,8 @@ class Generator:
                 lt = layers[b + ".torgb"]
                 if self.taps is None and self.fuse_torgb and lp.cout <= 32:
                     # conv_last + ToRGB in one kernel: the [n,32,R,R] conv_last activation never goes to HBM
-                    torch.mul(lt.w_raw.unsqueeze(0), self._s(lt).unsqueeze(1), out=self.rgbw)      # W[c,co] * s[n,co]
+                    _lib.check(L.mgf_rgb_weights_f32(self.rgbw.data_ptr(), lt.w_raw.data_ptr(), self._s(lt).data_ptr(), n, lt.w_raw.shape[0],
+                                                     lt.w_raw.shape[1], st), "rgb_weights")                       # W[c,co] * s[n,co]
                     if lp.wino_u is not None and lp.wino_u.ndim == 4 and lp.cout == 32 and cv.winograd_fills_chip(n, lp.cout, res, res):
                         cv.winograd2_rgb_forward(x, lp.wino_u, self.rgbw, lt.bias, self.img, in_scale=self._s(lp), out_scale=self._d(lp))
                     else:
@@ -584,13 +587,26 @@ class Generator:
         return t, t.shape[0]
 
     def _draw_noise(self, n):
-        """Fresh N(0,1) maps per layer and call (networks.py:1016-1017): ONE torch.randn launch fills a flat buffer that is
+        """Fresh N(0,1) maps per layer and call (networks.py:1016-1017): ONE mgf_randn_f32 launch fills a flat buffer that is
         laid out layer-major ([layer][n][r*r]), so every layer sees a dense [n, r, r] view without copies."""
         sizes = [(lp.name, lp.res) for lp in self.plan.layers if lp.noise_strength is not None]
         total = sum(r * r for _, r in sizes)
         if self.noise_rand is None or self.noise_rand.numel() != n * total:
             self.noise_rand = torch.empty(n * total, dtype=torch.float32, device=self.device)
-        self.noise_rand.normal_()
+        # The library's own Philox / Box-Muller kernel: its stream position lives on the device and every launch -- every replay of a
+        # captured graph -- advances it.  torch.manual_seed still governs it, like the reference's torch.randn: outside graph capture the
+        # call looks at torch's CUDA generator -- (seed, offset) other than what the previous draw left behind means the user re-seeded (or
+        # drew elsewhere): the stream restarts under a key derived from that pair -- and leaves its own mark (offset + 4) behind.
+        if not torch.cuda.is_current_stream_capturing():
+            gen = torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()]
+            seed, off = int(gen.initial_seed()), int(gen.get_offset())
+            if (seed, off) != self._noise_epoch:
+                self.noise_seed = (seed ^ (off * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+                self.noise_state.zero_()
+            gen.set_offset(off + 4)
+            self._noise_epoch = (seed, off + 4)
+        _lib.check(_lib.lib().mgf_randn_f32(self.noise_rand.data_ptr(), self.noise_rand.numel(), self.noise_seed, self.noise_state.data_ptr(),
+                                            _lib.stream_ptr()), "randn")
         out, off = {}, 0
         for name, r in sizes:
             out[name] = self.noise_rand[off * n:(off + r * r) * n].view(n, r * r)

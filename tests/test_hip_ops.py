@@ -667,3 +667,49 @@ def test_duplex_attention_forward_all_kernel_forms_vs_float64(n, c, f, with_ep):
     _lib.check(L.mgf_duplex_attention(out2.data_ptr(), xd.data_ptr(), wd.data_ptr(), sd_.data_ptr(), vd.data_ptr(), n, c, f, T,
                                       C.byref(ep) if ep is not None else None, 0, None, None, _lib.stream_ptr()))
     assert torch.equal(out, out2)
+
+
+def test_randn_and_rgb_weights_kernels():
+    """mgf_randn_f32 (the per-layer noise maps of noise_mode="random"): Philox4x32-10 + Box-Muller with the stream position on the device --
+    standard normal statistics, the same (seed, position) reproduces, consecutive launches and REPLAYS of a captured graph continue the
+    stream; odd lengths and unaligned tails.  mgf_rgb_weights_f32 = W[c,co] * s[n,co] exactly."""
+    from morphganformer_amd import _lib
+    L, st = _lib.lib(), _lib.stream_ptr()
+    n = 1 << 22
+    state = torch.zeros(2, dtype=torch.int64, device="cuda")
+    a, b = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    _lib.check(L.mgf_randn_f32(a.data_ptr(), n, 1234, state.data_ptr(), st))
+    assert int(state[0]) == n // 4 and int(state[1]) == 0
+    _lib.check(L.mgf_randn_f32(b.data_ptr(), n, 1234, state.data_ptr(), st))
+    assert int(state[0]) == n // 2
+    x = torch.cat([a, b]).double().cpu()
+    assert abs(float(x.mean())) < 2e-3 and abs(float(x.var()) - 1) < 4e-3 and abs(float((x ** 3).mean())) < 1e-2 and abs(float((x ** 4).mean()) - 3) < 3e-2
+    assert torch.isfinite(x).all() and float(x.abs().max()) > 4.5 and not torch.equal(a, b)
+    assert abs(float((a[:-1] * a[1:]).mean())) < 2e-3                      # neighbours are uncorrelated
+    state.zero_()
+    c = torch.empty(n, device="cuda")
+    _lib.check(L.mgf_randn_f32(c.data_ptr(), n, 1234, state.data_ptr(), st))
+    assert torch.equal(a, c)                                               # same seed, same position: same numbers
+    _lib.check(L.mgf_randn_f32(c.data_ptr(), n, 1235, state.data_ptr(), st))
+    assert not torch.equal(b, c)                                           # another key
+    # odd length into an unaligned tail: exactly n values written, the stream advances by ceil(n / 4)
+    state.zero_()
+    buf = torch.full([1003], 7.0, device="cuda")
+    _lib.check(L.mgf_randn_f32(buf[1:].data_ptr(), 1001, 1234, state.data_ptr(), st))
+    assert float(buf[0]) == 7.0 and float(buf[1002]) == 7.0 and int(state[0]) == 251 and torch.equal(buf[1:1001], a[:1000])
+    # under graph replay every replay draws fresh numbers
+    state.zero_()
+    g, out = torch.cuda.CUDAGraph(), torch.empty(4096, device="cuda")
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        _lib.check(L.mgf_randn_f32(out.data_ptr(), 4096, 99, state.data_ptr(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        _lib.check(L.mgf_randn_f32(out.data_ptr(), 4096, 99, state.data_ptr(), _lib.stream_ptr()))
+    g.replay(); first = out.clone(); g.replay(); second = out.clone()
+    assert not torch.equal(first, second) and int(state[0]) == 3 * 1024
+    w, s = torch.randn(3, 32), torch.randn(5, 32)
+    o = torch.empty(5, 3, 32, device="cuda")
+    wd, sd = w.cuda(), s.cuda()
+    _lib.check(L.mgf_rgb_weights_f32(o.data_ptr(), wd.data_ptr(), sd.data_ptr(), 5, 3, 32, st))
+    assert torch.equal(o.cpu(), w[None] * s[:, None])
