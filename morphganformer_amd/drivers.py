@@ -289,11 +289,11 @@ def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):
 
 def _project_group(G, targets, landmarks, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None, eps=None,
                    use_graph=True, noise_mode="random", use_mse=True, seed=None, weight_decay=0.0, mode="gradient", latent_space="z",
-                   **unused):
+                   biometric=None, gamma=1.0, batch=None, **unused):
     """B targets through one lockstep GradientProjectionEngine; returns dict(w [B,k,D] (W+: [B,k,num_ws,D]), step [B], loss [B],
     losses [B,steps])."""
     args = args or ProjectionArgs()
-    if unused:
+    if unused:                                      # (`batch` is literal mode's steps per forward: gradient mode evaluates one candidate per step)
         raise TypeError(f"project_many(lockstep=...): unsupported arguments {sorted(unused)}")
     if latent_mean is None or latent_std is None:
         gen = None
@@ -309,7 +309,7 @@ def _project_group(G, targets, landmarks, args: ProjectionArgs = None, percept=N
         lm_t, lm_s = lm_t[0], lm_s[0]
     eng = GradientProjectionEngine(G, tg, latent_mean, float(latent_std), args, weight_decay=weight_decay, percept=percept,
                                    lm_target=lm_t, lm_steps=lm_s, eps=eps, noise_mode=noise_mode, use_graph=use_graph, use_mse=use_mse,
-                                   seed=0 if seed is None else seed, latent_space=latent_space)
+                                   seed=0 if seed is None else seed, latent_space=latent_space, biometric=biometric, gamma=gamma)
     w, step, loss, losses = eng.run().result()
     if len(targets) == 1:
         return {"w": w, "step": np.array([step]), "loss": np.array([loss]), "losses": losses[None]}
