@@ -512,6 +512,16 @@ int mgf_attn_values_bwd_multi(float* dyc, const mgf_attn_bwd_job* jobs_dev, int3
 int mgf_latent_bwd_multi(float* dwg, const mgf_style_bwd_job* style_jobs_dev, int32_t n_style_jobs, float* dyc,
                          const mgf_attn_bwd_job* attn_jobs_dev, int32_t n_attn_jobs, int32_t n, int32_t t, int32_t wdim, int32_t max_channels,
                          mgf_stream_t stream);
+/* The per-attention-layer by-products of the backward pass that nothing on the critical path waits for -- the value gradient
+ * dvwb[c][t] = sum_f dg[c][f] P[f][t] (mgf_attn_values_grad_ws) and the demodulation partials <dc, c> (mgf_channel_dot_f32) -- for ALL attention
+ * layers in two launches at the end of the pass instead of three small launches per layer (33 -> 2 at 1024^2).  jobs_dev: njobs records of
+ * mgf_attn_grad_job_bytes() bytes { const float* dg, probs, dc, cpre; float* part, dvwb, dc_part; int32 c, f, slices, nchunk, blk_grad, blk_dot,
+ * blk_red, pad } (dc_part NULL: no demodulation; slices from mgf_attn_values_grad_slices, > 0 required; part: n * slices * c * 16 floats;
+ * blk_*: the layer's first workgroup in the flat grids of grad_blocks / dot_blocks / reduce_blocks workgroups). */
+int32_t mgf_attn_values_grad_slices(int32_t n, int32_t c, int32_t f, int32_t t);
+int64_t mgf_attn_grad_job_bytes(void);
+int mgf_attn_grad_multi(const void* jobs_dev, int32_t njobs, int32_t n, int32_t grad_blocks, int32_t dot_blocks, int32_t reduce_blocks,
+                        mgf_stream_t stream);
 int mgf_latent_grad_gather(float* dw, const float* dwg, int32_t n_style_jobs, const float* dyc, int32_t n_attn_jobs, int32_t n, int32_t k,
                            int32_t wdim, float scale, mgf_stream_t stream);
 /* Backward of mgf_mapping_forward: dz[n,k,dim] from dw[n,k,dim].  The forward is recomputed; its per-layer activations go to

@@ -54,6 +54,11 @@ class StyleBwdJob(C.Structure):
                 ("s_chunks", i32), ("d_chunks", i32), ("aff_gain", f32), ("style_gain", f32)]
 
 
+class AttnGradJob(C.Structure):
+    _fields_ = [("dg", vp), ("probs", vp), ("dc", vp), ("cpre", vp), ("part", vp), ("dvwb", vp), ("dc_part", vp), ("c", i32), ("f", i32),
+                ("slices", i32), ("nchunk", i32), ("blk_grad", i32), ("blk_dot", i32), ("blk_red", i32), ("pad_", i32)]
+
+
 class AttnBwdJob(C.Structure):
     _fields_ = [("wmv", vp), ("dvwb", vp), ("c", i32), ("pad_", i32)]
 
@@ -130,6 +135,9 @@ _SIGS = {
     "mgf_attn_values_grad_ws": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp, i64, vp]),
     "mgf_style_demod_bwd_multi": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mgf_attn_values_bwd_multi": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "mgf_attn_values_grad_slices": (i32, [i32, i32, i32, i32]),
+    "mgf_attn_grad_job_bytes": (i64, []),
+    "mgf_attn_grad_multi": (C.c_int, [vp, i32, i32, i32, i32, i32, vp]),
     "mgf_latent_bwd_multi": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mgf_latent_grad_gather": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, i32, f32, vp]),
     "mgf_lpips_layer_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i64, i64, f32, i32, vp]),

@@ -114,9 +114,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdParams p) {
 }
 
 // part[n,c,chunk] = sum a * b over the chunk
-__global__ __launch_bounds__(256) void channel_dot_kernel(float* part, const float* a, const float* b, int c, int64_t hw, int nchunk) {
-    __shared__ float red[4];
-    const int chunk = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
+__device__ __forceinline__ void channel_dot_body(float* part, const float* a, const float* b, int c, int64_t hw, int nchunk, int chunk, int ch, int n,
+                                                 float* red) {
     const int64_t base = ((int64_t)n * c + ch) * hw;
     const int64_t i0 = (int64_t)chunk * BWD_CHUNK;
     const int64_t i1 = min(hw, i0 + (int64_t)BWD_CHUNK);
@@ -124,6 +123,11 @@ __global__ __launch_bounds__(256) void channel_dot_kernel(float* part, const flo
     for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) acc += a[base + i] * b[base + i];
     const float tot = block_sum(acc, red);
     if (threadIdx.x == 0) part[((int64_t)n * c + ch) * nchunk + chunk] = tot;
+}
+
+__global__ __launch_bounds__(256) void channel_dot_kernel(float* part, const float* a, const float* b, int c, int64_t hw, int nchunk) {
+    __shared__ float red[4];
+    channel_dot_body(part, a, b, c, hw, nchunk, blockIdx.x, blockIdx.y, blockIdx.z, red);
 }
 
 // part[n,c,chunk] = sum x * g ;  dx (+)= s[n,c] * g
@@ -534,11 +538,12 @@ __global__ __launch_bounds__(256) void attn_values_grad_kernel(float* dvwb, cons
 // attn_values_reduce_kernel adds the slices in index order (bit-reproducible).  The VALU kernel above gave every workgroup 4 channels and
 // ALL pixels: 64 workgroups for a 128^2 x 256-channel layer at one sample, each re-reading the 1 MB probability map: 150 us.
 typedef float avg_f32x16 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void attn_values_grad_mfma_kernel(float* part, const float* dg, const float* probs, int c, int f, int slices) {
+__device__ __forceinline__ void attn_values_grad_mfma_body(float* part, const float* dg, const float* probs, int c, int f, int slices, int sl,
+                                                           int cbq, int n) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int sl = blockIdx.x, cb = blockIdx.y * 4 + wv, n = blockIdx.z;
+    const int cb = cbq * 4 + wv;
     if (cb * 32 >= c) return;
     const int fs = f / slices, f0 = sl * fs;                      // pixels of this slice (host: a multiple of 8)
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dg + (int64_t)n * c * f), 0, c * f * 4, 0x00020000);
@@ -579,6 +584,68 @@ __global__ __launch_bounds__(256) void attn_values_grad_mfma_kernel(float* part,
         *reinterpret_cast<float4*>(o + 4 * half) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         *reinterpret_cast<float4*>(o + 8 + 4 * half) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
+}
+
+__global__ __launch_bounds__(256) void attn_values_grad_mfma_kernel(float* part, const float* dg, const float* probs, int c, int f, int slices) {
+    attn_values_grad_mfma_body(part, dg, probs, c, f, slices, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// One record per attention layer of the deferred passes below (mgf_attn_grad_multi): the layer's value-gradient GEMM over its pixel slices,
+// its demodulation dot products, then the slice sums.  blk_* = first workgroup of the layer in the flat grids.
+struct AttnGradJob {
+    const float* dg; const float* probs; const float* dc; const float* cpre;
+    float* part; float* dvwb; float* dc_part;
+    int32_t c, f, slices, nchunk, blk_grad, blk_dot, blk_red, pad_;
+};
+static_assert(sizeof(AttnGradJob) == 88, "AttnGradJob layout (morphganformer_amd/_lib.py mirrors it)");
+
+// launch 1 of 2: the value-gradient GEMMs of ALL attention layers and (no dependency between them) their <dc, c> demodulation partials
+__global__ __launch_bounds__(256) void attn_grad_multi_kernel(const AttnGradJob* jobs, int njobs, int n_samples, int grad_blocks) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const bool dot = b >= grad_blocks;
+    const int local = dot ? b - grad_blocks : b;
+    int j = 0;
+    for (int q = 1; q < njobs; ++q) j = ((dot ? jobs[q].blk_dot : jobs[q].blk_grad) <= local) ? q : j;       // (tables are sorted: the last job that starts at or before)
+    const AttnGradJob J = jobs[j];
+    if (!dot) {
+        int r = local - J.blk_grad;
+        const int sl = r % J.slices; r /= J.slices;
+        const int cbq4 = (int)((J.c + 127) / 128);
+        const int cbq = r % cbq4, n = r / cbq4;
+        if (n < n_samples) attn_values_grad_mfma_body(J.part, J.dg, J.probs, J.c, J.f, J.slices, sl, cbq, n);
+    } else if (J.dc_part) {
+        int r = local - J.blk_dot;
+        const int chunk = r % J.nchunk; r /= J.nchunk;
+        const int ch = r % J.c, n = r / J.c;
+        if (n < n_samples) channel_dot_body(J.dc_part, J.dc, J.cpre, J.c, (int64_t)J.f, J.nchunk, chunk, ch, n, red);
+    }
+}
+
+// launch 2 of 2: dvwb = the slices of `part` added in index order, all layers
+__global__ __launch_bounds__(256) void attn_reduce_multi_kernel(const AttnGradJob* jobs, int njobs, int n_samples) {
+    const int b = blockIdx.x;
+    int j = 0;
+    for (int q = 1; q < njobs; ++q) j = (jobs[q].blk_red <= b) ? q : j;
+    const AttnGradJob J = jobs[j];
+    const int64_t per_sample = (int64_t)J.c * TMAX;
+    const int64_t bps = (per_sample + 255) / 256;                       // workgroups per sample
+    const int64_t r = b - J.blk_red;
+    const int n = (int)(r / bps);
+    const int64_t i = (r % bps) * 256 + threadIdx.x;
+    if (n >= n_samples || i >= per_sample) return;
+    const float* pp = J.part + (int64_t)n * J.slices * per_sample + i;
+    float a = 0.f;
+    int s = 0;
+    for (; s + 8 <= J.slices; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pp[(int64_t)(s + u) * per_sample];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; s < J.slices; ++s) a += pp[(int64_t)s * per_sample];
+    J.dvwb[(int64_t)n * per_sample + i] = a;
 }
 
 __global__ __launch_bounds__(256) void attn_values_reduce_kernel(float* dvwb, const float* part, int64_t per_sample, int slices) {
@@ -1229,17 +1296,41 @@ extern "C" int64_t mgf_attn_values_grad_workspace_floats(int32_t n, int32_t c) {
     return (int64_t)128 * (n > 0 ? n : 1) * (c > 0 ? c : 1) * TMAX;         // at most 128 pixel slices
 }
 
+// pixel slices of the MFMA value-gradient form for one layer (0: the layer's shape does not take that form)
+static int attn_grad_slices(int n, int c, int f, int t) {
+    int slices = 1;
+    const int cblocks = (int)mgf_cdiv(c, 32);
+    while (slices < 128 && (int64_t)n * slices * cblocks < 1024 && f % (slices * 2 * 8) == 0 && f / (slices * 2) >= 32) slices *= 2;
+    const bool ok = t == TMAX && f % (8 * slices) == 0 && (int64_t)c * f * 4 < (1LL << 31);
+    return ok ? slices : 0;
+}
+
+extern "C" int32_t mgf_attn_values_grad_slices(int32_t n, int32_t c, int32_t f, int32_t t) { return attn_grad_slices(n, c, f, t); }
+
+extern "C" int64_t mgf_attn_grad_job_bytes(void) { return (int64_t)sizeof(AttnGradJob); }
+
+extern "C" int mgf_attn_grad_multi(const void* jobs_dev, int32_t njobs, int32_t n, int32_t grad_blocks, int32_t dot_blocks, int32_t reduce_blocks,
+                                   mgf_stream_t stream) {
+    MGF_REQUIRE(jobs_dev && njobs >= 1 && njobs <= 64 && n >= 1 && grad_blocks >= 1 && dot_blocks >= 0 && reduce_blocks >= 1, MGF_EINVAL,
+                "attn_grad_multi: bad arguments");
+    MGF_REQUIRE(((uintptr_t)jobs_dev % 8) == 0, MGF_EINVAL, "attn_grad_multi: the job table must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_grad_multi_kernel, dim3(grad_blocks + dot_blocks), dim3(256), 0, st, reinterpret_cast<const AttnGradJob*>(jobs_dev), njobs, n,
+                       grad_blocks);
+    hipLaunchKernelGGL(attn_reduce_multi_kernel, dim3(reduce_blocks), dim3(256), 0, st, reinterpret_cast<const AttnGradJob*>(jobs_dev), njobs, n);
+    MGF_CHECK_LAUNCH("attn_grad_multi");
+    return MGF_OK;
+}
+
 extern "C" int mgf_attn_values_grad_ws(float* dvwb, const float* dg, const float* probs, int32_t n, int32_t c, int32_t f, int32_t t,
                                        float* workspace, int64_t workspace_floats, mgf_stream_t stream) {
     MGF_REQUIRE(dvwb && dg && probs && n >= 1 && c >= 1 && f >= 1, MGF_EINVAL, "attn_values_grad: bad arguments");
     MGF_REQUIRE(t >= 1 && t <= TMAX, MGF_EUNSUPPORTED, "attn_values_grad: supports 1..%d latent components (got %d)", TMAX, t);
     MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "attn_values_grad: n must be <= 65535");
     // the MFMA form: 16 latents, pixel count a multiple of 8, 32-bit offsets inside a sample; pixel slices so that ~1024 waves run
-    int slices = 1;
+    const int slices = attn_grad_slices(n, c, f, t);
     const int cblocks = (int)mgf_cdiv(c, 32);
-    while (slices < 128 && (int64_t)n * slices * cblocks < 1024 && f % (slices * 2 * 8) == 0 && f / (slices * 2) >= 32) slices *= 2;
-    const bool ok = t == TMAX && f % (8 * slices) == 0 && (int64_t)c * f * 4 < (1LL << 31) && workspace &&
-                    workspace_floats >= (int64_t)n * slices * c * TMAX && ((uintptr_t)workspace % 16) == 0;
+    const bool ok = slices > 0 && workspace && workspace_floats >= (int64_t)n * slices * c * TMAX && ((uintptr_t)workspace % 16) == 0;
     static const char* mf_env = getenv("MGF_ATTN_GRAD_MFMA");     // tuning hook (experiments, tests): 0 = the VALU kernel
     if (!ok || (mf_env && mf_env[0] == '0')) return mgf_attn_values_grad(dvwb, dg, probs, n, c, f, t, stream);
     hipStream_t st = (hipStream_t)stream;

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import math
 import os
+from ctypes import sizeof as ctypes_sizeof
 
 import torch
 
@@ -28,6 +29,9 @@ from .engine import Generator
 
 GRAD_FUSE_SKIP = os.environ.get("MGF_GRAD_FUSE_SKIP", "1") != "0"
 FUSE_STYLE_ACT = os.environ.get("MGF_FUSE_STYLE_ACT", "1") != "0"      # tuning / test hook: 0 = style_grad and act_bwd as two launches
+# the attention layers' value gradients and demodulation dot products -- by-products nothing on the critical path waits for -- for all layers
+# in two launches at the end of the pass (0: three small launches per layer where they arise; tuning / equivalence test)
+DEFER_ATTN_GRADS = os.environ.get("MGF_DEFER_ATTN_GRADS", "1") != "0"
 
 
 class GeneratorGrad:
@@ -89,6 +93,7 @@ class GeneratorGrad:
             if lp.attn is not None:
                 self.dvwb[lp.name] = e(n, lp.attn.c, T)
                 aj.append(_lib.AttnBwdJob(lp.attn.wmv.data_ptr(), self.dvwb[lp.name].data_ptr(), lp.attn.c, 0))
+        self._build_deferred_attention(n)
         arr = (_lib.StyleBwdJob * len(sj))(*sj)
         self.style_jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(G.device)
         self.n_style_jobs = len(sj)
@@ -106,6 +111,49 @@ class GeneratorGrad:
         self.style_slots = torch.tensor([lp.slot for lp in P.layers], dtype=torch.int64, device=G.device)
         self.attn_slots = torch.tensor([lp.slot for lp in P.layers if lp.attn is not None], dtype=torch.int64, device=G.device)
         self.max_channels = max(max(lp.cin, lp.cout) for lp in P.layers)
+
+    def _build_deferred_attention(self, n):
+        """Per-layer buffers (dc, dg, probabilities, slice partials) and the device job table of mgf_attn_grad_multi.  The buffers must
+        outlive their layer's step of the pass -- 2 x the attention layers' activations (110 MB per sample at 1024^2) instead of one shared
+        set -- which buys 33 small launches for 2."""
+        G, P, L = self.G, self.G.plan, _lib.lib()
+        T = G.cfg.k - 1
+        self.attn_defer = None
+        layers = [lp for lp in P.layers if lp.attn is not None]
+        if not (DEFER_ATTN_GRADS and layers):
+            return
+        assert ctypes_sizeof(_lib.AttnGradJob) == int(L.mgf_attn_grad_job_bytes())
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=G.device)
+        jobs, bufs, g0, d0, r0 = [], {}, 0, 0, 0
+        for lp in layers:
+            a = lp.attn
+            side = lp.res
+            slices = int(L.mgf_attn_values_grad_slices(n, a.c, a.f, T))
+            if slices <= 0:
+                return                                  # a shape the MFMA form does not take: keep the per-layer launches for all
+            nchunk = int(L.mgf_bwd_chunks(a.f))
+            b = dict(dc=e(n, a.c, side, side), dg=e(n, a.c, side, side), probs=e(n, a.f, T), part=e(n * slices * a.c * 16))
+            bufs[lp.name] = b
+            jobs.append(_lib.AttnGradJob(b["dg"].data_ptr(), b["probs"].data_ptr(), b["dc"].data_ptr(), 0, b["part"].data_ptr(),
+                                         self.dvwb[lp.name].data_ptr(), self.dc_part[lp.name].data_ptr() if lp.demod else 0, a.c, a.f, slices,
+                                         nchunk, g0, d0, r0, 0))
+            g0 += slices * -(-a.c // 128) * n
+            d0 += (nchunk * a.c * n) if lp.demod else 0
+            r0 += -(-(a.c * 16) // 256) * n
+        self.attn_defer = dict(jobs=jobs, bufs=bufs, blocks=(g0, d0, r0), table=None, cpre={})
+
+    def _deferred_attention_launch(self):
+        """The two launches of the deferred attention by-products (after the last layer of the pass)."""
+        D = self.attn_defer
+        if D["table"] is None or D["cpre_ptrs"] != tuple(D["cpre"][j.dg] for j in D["jobs"]):
+            # (the conv outputs c_pre live in the generator's workspace: their addresses are known once the pass has walked the layers)
+            for j in D["jobs"]:
+                j.cpre = D["cpre"][j.dg]
+            D["cpre_ptrs"] = tuple(j.cpre for j in D["jobs"])
+            arr = (_lib.AttnGradJob * len(D["jobs"]))(*D["jobs"])
+            D["table"] = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.G.device)
+        g, d, r = D["blocks"]
+        _lib.check(_lib.lib().mgf_attn_grad_multi(D["table"].data_ptr(), len(D["jobs"]), self.G.n, g, d, r, _lib.stream_ptr()), "attn_grad_multi")
 
     # ------------------------------------------------------------------ forward
     def forward(self, z=None, ws=None, truncation_psi=1, noise_mode="const", noises=None):
@@ -176,7 +224,18 @@ class GeneratorGrad:
         n, c, h, w = y_out.shape
         hw = h * w
         dc = dz
-        if lp.attn is not None:
+        if lp.attn is not None and self.attn_defer is not None and self.debug is None:
+            # deferred form: this layer's dc / dg / probabilities stay in buffers of their own; the value gradient and the demodulation
+            # dot products of ALL attention layers are two launches at the end of the pass (_deferred_attention_launch)
+            a = lp.attn
+            T = G.cfg.k - 1
+            b = self.attn_defer["bufs"][lp.name]
+            dc = b["dc"]
+            _lib.check(L.mgf_duplex_attention_bwd(dc.data_ptr(), b["dg"].data_ptr(), b["probs"].data_ptr(), dz.data_ptr(), c_pre.data_ptr(),
+                                                  a.wqc.data_ptr(), a.spos.data_ptr(), G._v(lp).data_ptr(), n, a.c, a.f, T, st),
+                       "duplex_attention_bwd")
+            self.attn_defer["cpre"][b["dg"].data_ptr()] = c_pre.data_ptr()
+        elif lp.attn is not None:
             a = lp.attn
             T = G.cfg.k - 1
             dc, dg, probs = self.buf("dc", y_out.shape), self.buf("dg", y_out.shape), self.buf("probs", (n, a.f, T))
@@ -337,6 +396,8 @@ class GeneratorGrad:
             cv.upfirdn_into(dlow, d_out, P.fir, up=1, down=2, pad=(1, 1, 1, 1), gain=4.0, flip=True)
             cv.conv_forward(dlow, self.Tskip[res], epilogue=_lib.make_epilogue(residual=dxin), out=dxin)
             dx = dxin
+        if self.attn_defer is not None and self.debug is None:
+            self._deferred_attention_launch()
         # d(styles) -> the global component and d(attention values) -> the local components: one launch (two independent latency chains)
         _lib.check(L.mgf_latent_bwd_multi(self.dwg.data_ptr(), self.style_jobs.data_ptr(), self.n_style_jobs, self.dyc.data_ptr(),
                                           _lib.ptr(self.attn_jobs), self.n_attn_jobs, n, T, D, self.max_channels, st), "latent_bwd_multi")

@@ -285,6 +285,32 @@ def test_tiny_generator_gradient_wrt_z(tiny):
     assert rel(dz1, dz_ref[:1]) < GRAD_TOL
 
 
+def test_deferred_attention_by_products_equal_the_per_layer_launches(monkeypatch):
+    """The attention layers' value gradients and demodulation dot products as two launches at the end of the pass (mgf_attn_grad_multi: job
+    table over all layers, per-layer buffers) against the three small launches per layer where they arise: the same arithmetic in the same
+    order -- dz bit-identical -- at one and at three samples, and again after a workspace of another batch size was used in between."""
+    from morphganformer_amd import grad
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    sd = make_state_dict(TINY, seed=0)
+    torch.manual_seed(5)
+    out = {}
+    for defer in (True, False):
+        monkeypatch.setattr(grad, "DEFER_ATTN_GRADS", defer)
+        gg = grad.GeneratorGrad(Generator(sd, TINY, "cuda", max_batch=1))
+        res = []
+        for n in (1, 3, 1):
+            torch.manual_seed(n)
+            z = torch.randn(n, TINY.k, TINY.z_dim, device="cuda")
+            img = gg.forward(z, noise_mode="const")
+            res.append(gg.backward(torch.sin(img * 3.0)).clone())
+            assert (gg.attn_defer is not None) == defer
+        out[defer] = res
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
+    assert torch.equal(out[True][0], out[True][2])
+
+
 def test_tiny_gradient_matches_reference_module(tiny, golden):
     """d mean(img^2)/dz computed by the REFERENCE module's autograd (gen_tiny.npz, oracle/make_golden.py) vs the HIP backward."""
     gg, tsd, cfg = tiny
