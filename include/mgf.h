@@ -556,6 +556,13 @@ int mgf_lpips_layer_bwd_relu_f32(float* dz_a, float* dz_b, const float* dy, cons
  * both feature maps for them (NULL: as mgf_lpips_layer_bwd_relu_f32). */
 int mgf_lpips_layer_stats_f32(float* out, float* stats, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c,
                               int64_t hw, int64_t f1_batch_stride, int32_t accumulate, float* scratch, mgf_stream_t stream);
+/* ... and the same tap WITHOUT its finish launch: the partial sums stay in `scratch` (one set of n * mgf_reduce_scratch_floats() floats per tap,
+ * *nparts_out partials per sample; a HOST pointer), and mgf_lpips_finish_taps_f32 adds up to 8 taps to out in tap order -- the same sums in the
+ * same order as one finish per tap, in one launch (nparts / scales are host arrays; scale = 1 / hw of the tap) */
+int mgf_lpips_layer_defer_f32(float* scratch, float* stats, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c, int64_t hw,
+                              int64_t f1_batch_stride, int32_t* nparts_out, mgf_stream_t stream);
+int mgf_lpips_finish_taps_f32(float* out, const float* scratch, int64_t set_stride_floats, int32_t ntaps, const int32_t* nparts, const float* scales,
+                              int32_t n, int32_t accumulate, mgf_stream_t stream);
 int mgf_lpips_layer_bwd_relu_stats_f32(float* dz_a, float* dz_b, const float* dy, const float* f0, const float* f1_unit, const float* lin,
                                        const float* stats, int32_t n, int32_t c, int32_t c_split, int64_t hw, int64_t f1_batch_stride,
                                        float scale, mgf_stream_t stream);

@@ -143,6 +143,8 @@ _SIGS = {
     "mgf_lpips_layer_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i64, i64, f32, i32, vp]),
     "mgf_lpips_layer_bwd_relu_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, f32, vp]),
     "mgf_lpips_layer_stats_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, i64, i32, vp, vp]),
+    "mgf_lpips_layer_defer_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, i64, C.POINTER(i32), vp]),
+    "mgf_lpips_finish_taps_f32": (C.c_int, [vp, vp, i64, i32, C.POINTER(i32), C.POINTER(f32), i32, i32, vp]),
     "mgf_lpips_layer_bwd_relu_stats_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, f32, vp]),
     "mgf_relu_bwd_split_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i64, vp]),
     "mgf_maxpool3x3s2_ceil_idx_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -27,6 +27,23 @@ __global__ __launch_bounds__(256) void finish_kernel(float* out, const float* sc
     if (threadIdx.x == 0) out[blockIdx.x] = (accumulate ? out[blockIdx.x] : 0.f) + v * scale;
 }
 
+// the same finish for up to 8 partial sets at once (the taps of one LPIPS evaluation), added to out[s] in set order with the arithmetic of
+// that many finish_kernel launches: out = (accumulate ? out : 0) + v_0 * scale_0; out += v_1 * scale_1; ...
+struct FinishSets { int nparts[8]; float scale[8]; };
+__global__ __launch_bounds__(256) void finish_multi_kernel(float* out, const float* scratch, int64_t set_stride, int nsets, FinishSets fs, int accumulate) {
+    __shared__ float sm[4];
+    float acc = accumulate ? out[blockIdx.x] : 0.f;
+    for (int t = 0; t < nsets; ++t) {
+        const float* sc = scratch + (int64_t)t * set_stride + (int64_t)blockIdx.x * RED_BLOCKS;
+        float v = 0.f;
+        for (int i = threadIdx.x; i < fs.nparts[t]; i += 256) v += sc[i];
+        v = block_sum_256(v, sm);
+        acc = acc + v * fs.scale[t];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
 // grid = (blocks, n)
 __global__ __launch_bounds__(256) void mse_partial_kernel(float* scratch, const float* a, const float* b, int64_t numel, int64_t b_stride) {
     __shared__ float sm[4];
@@ -483,6 +500,31 @@ extern "C" int mgf_lpips_layer_stats_f32(float* out, float* stats, const float* 
     // spatial mean per sample (networks_basic.py:85-87)
     hipLaunchKernelGGL(finish_kernel, dim3(n), dim3(256), 0, st, out, scratch, grid, 1.0f / (float)hw, accumulate);
     MGF_CHECK_LAUNCH("lpips_layer");
+    return MGF_OK;
+}
+
+/* mgf_lpips_layer_stats_f32 without its finish launch: the tap's partial sums stay in `scratch` (n * mgf_reduce_scratch_floats() floats: one
+ * set per tap) and *nparts_out says how many there are per sample; mgf_lpips_finish_taps_f32 then adds all taps to out in tap order -- the
+ * same sums in the same order as one finish per tap, in ONE launch (the loss VALUE is a by-product in gradient mode: nothing waits for it). */
+extern "C" int mgf_lpips_layer_defer_f32(float* scratch, float* stats, const float* f0, const float* f1_unit, const float* lin, int32_t n, int32_t c,
+                                         int64_t hw, int64_t f1_batch_stride, int32_t* nparts_out, mgf_stream_t stream) {
+    MGF_REQUIRE(scratch && f0 && f1_unit && lin && nparts_out && n >= 1 && n <= 65535 && c >= 1 && hw >= 1, MGF_EINVAL, "lpips_layer_defer: bad arguments");
+    int grid = 0;
+    const int rc = launch_lpips_layer<false>(scratch, nullptr, f0, f1_unit, lin, n, c, hw, f1_batch_stride, (hipStream_t)stream, &grid, stats);
+    if (rc != MGF_OK) return rc;
+    *nparts_out = grid;
+    MGF_CHECK_LAUNCH("lpips_layer_defer");
+    return MGF_OK;
+}
+
+extern "C" int mgf_lpips_finish_taps_f32(float* out, const float* scratch, int64_t set_stride_floats, int32_t ntaps, const int32_t* nparts,
+                                         const float* scales, int32_t n, int32_t accumulate, mgf_stream_t stream) {
+    MGF_REQUIRE(out && scratch && nparts && scales && ntaps >= 1 && ntaps <= 8 && n >= 1 && n <= 65535, MGF_EINVAL, "lpips_finish_taps: bad arguments (1..8 taps)");
+    FinishSets fs;
+    for (int t = 0; t < 8; ++t) { fs.nparts[t] = t < ntaps ? nparts[t] : 0; fs.scale[t] = t < ntaps ? scales[t] : 0.f; }
+    for (int t = 0; t < ntaps; ++t) MGF_REQUIRE(nparts[t] >= 1 && nparts[t] <= RED_BLOCKS, MGF_EINVAL, "lpips_finish_taps: bad partial count");
+    hipLaunchKernelGGL(finish_multi_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, out, scratch, set_stride_floats, ntaps, fs, accumulate);
+    MGF_CHECK_LAUNCH("lpips_finish_taps");
     return MGF_OK;
 }
 

@@ -560,9 +560,18 @@ class PerceptualLoss(torch.nn.Module):
         else:
             taps = f(pred, argmax=True) if (keep_taps and self.net == "squeeze") else f(pred)
         L, st = _lib.lib(), _lib.stream_ptr()
+        # every tap leaves its partial sums in a scratch set of its own; ONE finish launch adds them to `out` in tap order (the same sums
+        # in the same order as a finish per tap: the value is a by-product nothing waits for)
+        red = int(L.mgf_reduce_scratch_floats())
+        ntaps = len(self.lins)
+        if self._scratch.numel() < ntaps * n * red:
+            self._scratch = torch.empty(ntaps * n * red, dtype=torch.float32, device=self.device_)
+        import ctypes as C
+        nparts, scales, k, first_done = (C.c_int32 * 8)(), (C.c_float * 8)(), 0, False
         for i, (a, b, lin) in enumerate(zip(taps, self._target_taps, self.lins)):
             if a is None:
-                continue                            # tap 0 was consumed inside the stem kernel
+                first_done = True                   # tap 0 was consumed inside the stem kernel, which wrote out itself
+                continue
             _, c, hh, ww = a.shape
             stats = None
             if keep_taps and TAP_STATS:
@@ -571,9 +580,13 @@ class PerceptualLoss(torch.nn.Module):
                 if stats is None:
                     stats = self._stats[key] = torch.empty(n, 3, hh * ww, dtype=torch.float32, device=self.device_)
                 f.tap_stats[i] = stats
-            _lib.check(L.mgf_lpips_layer_stats_f32(out.data_ptr(), _lib.ptr(stats), a.data_ptr(), b.data_ptr(), lin.data_ptr(), n, c, hh * ww,
-                                                   c * hh * ww if per_sample else 0,
-                                                   int(i > 0), self._scratch.data_ptr(), st), "lpips_layer")
+            got = C.c_int32(0)
+            _lib.check(L.mgf_lpips_layer_defer_f32(self._scratch[k * n * red:].data_ptr(), _lib.ptr(stats), a.data_ptr(), b.data_ptr(), lin.data_ptr(),
+                                                   n, c, hh * ww, c * hh * ww if per_sample else 0, C.byref(got), st), "lpips_layer")
+            nparts[k], scales[k] = got.value, 1.0 / float(hh * ww)
+            k += 1
+        _lib.check(L.mgf_lpips_finish_taps_f32(out.data_ptr(), self._scratch.data_ptr(), n * red, k, nparts, scales, n, int(first_done), st),
+                   "lpips_finish_taps")
         return out
 
     def distance_per_tap(self, pred):
