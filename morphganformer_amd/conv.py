@@ -305,7 +305,8 @@ def conv_large_forward(x, w, bias, stride, pad, act="relu", out=None):
     _lib.require_gpu(x, w, bias)
     cout, cin, kh, kw = w.shape
     n, _, h, wd = x.shape
-    oh, ow = (h + 2 * pad - kh) // stride + 1, (wd + 2 * pad - kw) // stride + 1
+    py, px = (pad, pad) if isinstance(pad, int) else pad
+    oh, ow = (h + 2 * py - kh) // stride + 1, (wd + 2 * px - kw) // stride + 1
     if out is None:
         out = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
     taps = [(a, b) for a in range(kh) for b in range(kw)]
@@ -314,7 +315,7 @@ def conv_large_forward(x, w, bias, stride, pad, act="relu", out=None):
         grp = taps[g0:g0 + 9]
         pc = pack_weights(wf[:, :, g0:g0 + len(grp)].reshape(cout, cin, 1, len(grp)).contiguous())
         ep = None if g0 == 0 else _lib.make_epilogue(residual=out)
-        conv_forward(x, pc, stride=stride, pad=(pad, pad), epilogue=ep, out=out, taps=[(a - pad, b - pad) for a, b in grp],
+        conv_forward(x, pc, stride=stride, pad=(py, px), epilogue=ep, out=out, taps=[(a - py, b - px) for a, b in grp],
                      ksize=(kh, kw))
     if bias is None and act == "linear":
         return out

@@ -341,16 +341,20 @@ def _cv_affine_inverse(src_tri, dst_tri):
     a = np.zeros((6, 7))
     a[0::2, 0:2], a[0::2, 2], a[1::2, 3:5], a[1::2, 5] = s, 1.0, s, 1.0
     a[0::2, 6], a[1::2, 6] = d[:, 0], d[:, 1]
+    singular = False
     for i in range(6):
         k = i + int(np.argmax(np.abs(a[i:, i])))              # first maximum, like the `>` scan
-        if abs(a[k, i]) < 1e-14:
-            raise ValueError("warp: degenerate source triangle")
+        if abs(a[k, i]) < np.finfo(np.float64).eps * 100:     # LU64f's threshold: cv::solve then returns false and zeroes X,
+            singular = True                                   # getAffineTransform does not look at the result -- a collinear source
+            break                                             # triangle gets the all-zero matrix, and warpAffine's inverse of it is zero
         if k != i:
             a[[i, k], i:] = a[[k, i], i:]
         alpha = a[i + 1:, i] * (-1.0 / a[i, i])
         a[i + 1:, i + 1:] += alpha[:, None] * a[i, i + 1:][None, :]
     x = np.zeros(6)
     for i in range(5, -1, -1):
+        if singular:
+            break
         acc = a[i, 6]
         for k in range(i + 1, 6):
             acc -= a[i, k] * x[k]

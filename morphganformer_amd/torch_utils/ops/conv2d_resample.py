@@ -16,6 +16,11 @@ from . import upfirdn2d as _up
 
 def _conv2d(x, w, stride=1, padding=(0, 0), flip_weight=True, in_scale=None, out_scale=None):
     """flip_weight=True is correlation (torch.nn.functional.conv2d), False is true convolution (conv2d_resample.py:27-28)."""
+    if w.shape[2] * w.shape[3] > _lib.MAX_TAPS:
+        # more taps than one launch carries (the generator has none; the contract takes any kernel): chained <= 9-tap launches
+        if in_scale is not None or out_scale is not None:
+            raise _lib.MgfError("conv2d_resample: modulation with a kernel of more than 9 taps is not supported by the HIP path")
+        return _conv.conv_large_forward(x.contiguous(), w if flip_weight else w.flip([2, 3]), None, stride, tuple(padding), act="linear")
     pc = _conv.pack_weights(w, flip=not flip_weight)
     return _conv.conv_forward(x.contiguous(), pc, stride=stride, pad=padding, in_scale=in_scale, out_scale=out_scale)
 

@@ -56,7 +56,7 @@ def lu_solve(a, b):
             if abs(a[j, i]) > abs(a[k, i]):
                 k = j
         if abs(a[k, i]) < np.finfo(np.float64).eps * 100:
-            raise np.linalg.LinAlgError("singular")
+            return None                                  # LUImpl returns 0: "singular"
         if k != i:
             for j in range(i, m):
                 a[i, j], a[k, j] = a[k, j], a[i, j]
@@ -84,7 +84,10 @@ def get_affine_transform(src, dst):
         a[2 * i, 0:3] = (float(s[i, 0]), float(s[i, 1]), 1.0)
         a[2 * i + 1, 3:6] = (float(s[i, 0]), float(s[i, 1]), 1.0)
         b[2 * i], b[2 * i + 1] = float(d[i, 0]), float(d[i, 1])
-    return lu_solve(a, b).reshape(2, 3)
+    x = lu_solve(a, b)
+    if x is None:                                        # cv::solve: `if( !result ) dst = Scalar(0);` -- and getAffineTransform ignores the result
+        x = np.zeros(6)
+    return x.reshape(2, 3)
 
 
 def invert_affine(M):

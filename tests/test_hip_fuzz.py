@@ -1,0 +1,302 @@
+"""Seeded random sweeps of the operator-level boundary (the reference's plugin / operator API: upfirdn2d, bias_act, conv2d_resample,
+modulated_conv2d) against the CPU oracle: shapes, strides, paddings and filter sizes nobody picked by hand -- ragged tile edges, negative
+padding (cropping), single-pixel maps, channel counts off every block size.  Each case is cheap; a failure prints its parameters.
+Tolerances as in test_hip_ops.py: element-wise / FIR ops 1e-5 relative to max|y|, MFMA convolutions 2e-4 (re-associated float32 sums).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu().numpy()
+    b = b.detach().double().cpu().numpy()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def test_upfirdn2d_random_geometry():
+    """up / down 1..3 per axis, 1-D and 2-D filters of 1..7 taps, per-side padding -3..5 (negative = crop), float32 / float64 / float16,
+    contiguous and channels_last."""
+    from morphganformer_amd.torch_utils.ops import upfirdn2d
+    from oracle.ops_ref import upfirdn2d_ref
+    r = _rng(101)
+    done = 0
+    for case in range(400):
+        n, c = int(r.integers(1, 4)), int(r.integers(1, 9))
+        h, w = int(r.integers(1, 48)), int(r.integers(1, 80))
+        if case % 7 == 0:
+            h, w = int(r.integers(60, 140)), int(r.integers(60, 140))
+        upx, upy = (int(v) for v in r.integers(1, 4, 2))
+        dnx, dny = (int(v) for v in r.integers(1, 4, 2))
+        fh, fw = (int(v) for v in r.integers(1, 8, 2))
+        one_d = bool(r.integers(0, 2))
+        if one_d:
+            fh = fw
+        pad = [int(v) for v in r.integers(-3, 6, 4)]
+        oh = (h * upy + pad[2] + pad[3] - fh + dny) // dny
+        ow = (w * upx + pad[0] + pad[1] - fw + dnx) // dnx
+        if h * upy + pad[2] + pad[3] < fh or w * upx + pad[0] + pad[1] < fw or oh < 1 or ow < 1:
+            continue
+        # (the reference crops before filtering: a crop larger than the up-sampled map is not a defined case)
+        if max(-pad[2], 0) + max(-pad[3], 0) >= h * upy or max(-pad[0], 0) + max(-pad[1], 0) >= w * upx:
+            continue
+        flip, gain = bool(r.integers(0, 2)), float(r.uniform(0.5, 4.0))
+        dtype = [torch.float32, torch.float32, torch.float64, torch.float16][int(r.integers(0, 4))]
+        torch.manual_seed(case)
+        x = torch.randn(n, c, h, w)
+        f = torch.rand(fw) + 0.1 if one_d else torch.rand(fh, fw) + 0.1
+        ref = upfirdn2d_ref(x.double(), f.double(), up=(upx, upy), down=(dnx, dny), padding=pad, flip_filter=flip, gain=gain)
+        xin = x.to(dtype).cuda()
+        if case % 3 == 0 and c > 1:
+            xin = xin.to(memory_format=torch.channels_last)
+        out = upfirdn2d.upfirdn2d(xin, f.cuda(), up=[upx, upy], down=[dnx, dny], padding=pad, flip_filter=flip, gain=gain)
+        tag = f"case {case}: x {tuple(x.shape)} {dtype} up ({upx},{upy}) down ({dnx},{dny}) f {'1-D ' if one_d else ''}{fh}x{fw} pad {pad} flip {flip}"
+        assert tuple(out.shape) == tuple(ref.shape), tag
+        tol = 4e-3 if dtype == torch.float16 else 1e-5
+        assert rel_err(out, ref) < tol, tag
+        done += 1
+    assert done > 250
+
+
+def test_upfirdn2d_random_gradients():
+    """The autograd of the operator is the operator applied to the gradient with up / down swapped (upfirdn2d.py:237-256): checked against
+    the oracle's autograd on random geometry."""
+    from morphganformer_amd.torch_utils.ops import upfirdn2d
+    from oracle.ops_ref import upfirdn2d_ref
+    r = _rng(202)
+    done = 0
+    for case in range(120):
+        n, c = int(r.integers(1, 3)), int(r.integers(1, 5))
+        h, w = int(r.integers(2, 40)), int(r.integers(2, 70))
+        up, down = int(r.integers(1, 3)), int(r.integers(1, 3))
+        ft = int(r.integers(1, 6))
+        pad = [int(v) for v in r.integers(0, 4, 4)]
+        if h * up + pad[2] + pad[3] < ft or w * up + pad[0] + pad[1] < ft:
+            continue
+        flip = bool(r.integers(0, 2))
+        torch.manual_seed(1000 + case)
+        x = torch.randn(n, c, h, w)
+        f = torch.rand(ft, ft) + 0.1
+        xr = x.double().requires_grad_(True)
+        yr = upfirdn2d_ref(xr, f.double(), up=up, down=down, padding=pad, flip_filter=flip, gain=2.0)
+        gy = torch.randn(yr.shape, dtype=torch.float64)
+        (gr,) = torch.autograd.grad((yr * gy).sum(), xr)
+        xg = x.cuda().requires_grad_(True)
+        yg = upfirdn2d.upfirdn2d(xg, f.cuda(), up=up, down=down, padding=pad, flip_filter=flip, gain=2.0)
+        (gx,) = torch.autograd.grad((yg * gy.float().cuda()).sum(), xg)
+        tag = f"case {case}: x {tuple(x.shape)} up {up} down {down} f {ft} pad {pad} flip {flip}"
+        assert rel_err(gx, gr) < 1e-5, tag
+        done += 1
+    assert done > 80
+
+
+def test_bias_act_random():
+    """Every activation x dim x dtype on random ranks 1..4, with and without bias / clamp, forward and first-order gradient."""
+    from morphganformer_amd.torch_utils.ops import bias_act
+    from oracle.ops_ref import bias_act_ref
+    acts = ["linear", "relu", "lrelu", "tanh", "sigmoid", "elu", "selu", "softplus", "swish"]
+    r = _rng(303)
+    for case in range(200):
+        rank = int(r.integers(1, 5))
+        shape = [int(v) for v in r.integers(1, 9, rank)]
+        if case % 5 == 0:
+            shape[-1] = int(r.integers(100, 300))
+        dim = int(r.integers(0, rank))
+        act = acts[int(r.integers(0, len(acts)))]
+        alpha = None if r.integers(0, 2) else float(r.uniform(0.05, 0.5))
+        gain = None if r.integers(0, 2) else float(r.uniform(0.5, 2.0))
+        clamp = None if r.integers(0, 3) else float(r.uniform(0.2, 1.5))
+        has_b = bool(r.integers(0, 2))
+        dtype = [torch.float32, torch.float64, torch.float16][int(r.integers(0, 3))]
+        torch.manual_seed(2000 + case)
+        x = torch.randn(*shape)
+        b = torch.randn(shape[dim]) if has_b else None
+        xr = x.double().requires_grad_(True)
+        yr = bias_act_ref(xr, None if b is None else b.double(), dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        gy = torch.randn(yr.shape, dtype=torch.float64)
+        (gr,) = torch.autograd.grad((yr * gy).sum(), xr)
+        xg = x.to(dtype).cuda().requires_grad_(True)
+        yg = bias_act.bias_act(xg, None if b is None else b.to(dtype).cuda(), dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        (gx,) = torch.autograd.grad((yg * gy.to(dtype).cuda()).sum(), xg)
+        tag = f"case {case}: {shape} dim {dim} {act} alpha {alpha} gain {gain} clamp {clamp} bias {has_b} {dtype}"
+        tol = 4e-3 if dtype == torch.float16 else 1e-5
+        assert yg.dtype == dtype and tuple(yg.shape) == tuple(shape), tag
+        assert rel_err(yg, yr) < tol, tag
+        if clamp is None:                                # (at a clamp boundary the two sides may round to different sides of it)
+            assert rel_err(gx, gr) < (2e-2 if dtype == torch.float16 else 1e-5), tag
+
+
+def test_conv2d_resample_random():
+    """1x1 / 3x3 / 5x5 kernels, up / down 1..2 with the 4-tap filter or none, padding 0..3, both weight orientations, channel counts off the
+    32-wide blocks: the operator's branches (conv2d_resample.py:87-146) against the oracle's restatement."""
+    from morphganformer_amd.torch_utils.ops import conv2d_resample as cr
+    from oracle.ops_ref import conv2d_resample_ref, setup_filter_ref
+    r = _rng(404)
+    done = 0
+    for case in range(220):
+        n = int(r.integers(1, 4))
+        cin, cout = int(r.integers(1, 80)), int(r.integers(1, 80))
+        if case % 9 == 0:
+            cin, cout = int(r.integers(100, 300)), int(r.integers(100, 200))
+        k = [1, 3, 3, 3, 5][int(r.integers(0, 5))]
+        h, w = int(r.integers(k, 40)), int(r.integers(k, 56))
+        up, down = int(r.integers(1, 3)), int(r.integers(1, 3))
+        if up > 1 and down > 1:
+            down = 1
+        if up == 2 and k == 5:
+            k = 3
+        use_f = (up > 1 or down > 1) or bool(r.integers(0, 2))
+        f = setup_filter_ref([1, 3, 3, 1]) if use_f else None
+        pad = int(r.integers(0, 4))
+        flip_w = bool(r.integers(0, 2))
+        torch.manual_seed(3000 + case)
+        x = torch.randn(n, cin, h, w)
+        wt = torch.randn(cout, cin, k, k) / (k * cin ** 0.5)
+        try:
+            ref = conv2d_resample_ref(x.double(), wt.double(), None if f is None else f.double(), up=up, down=down, padding=pad, flip_weight=flip_w)
+        except RuntimeError:
+            continue                                     # (kernel larger than the padded map)
+        if min(ref.shape[2:]) < 1:
+            continue
+        out = cr.conv2d_resample(x.cuda(), wt.cuda(), None if f is None else f.cuda(), up=up, down=down, padding=pad, flip_weight=flip_w)
+        tag = f"case {case}: x {tuple(x.shape)} w {tuple(wt.shape)} up {up} down {down} pad {pad} f {use_f} flip_weight {flip_w}"
+        assert tuple(out.shape) == tuple(ref.shape), tag
+        assert rel_err(out, ref) < 2e-4, tag
+        done += 1
+    assert done > 150
+
+
+def test_modulated_conv2d_random():
+    """Per-sample styles, with and without demodulation / noise, up 1 and 2 (networks.py:253-328)."""
+    from morphganformer_amd.torch_utils.ops import conv2d_resample as cr
+    from oracle.ops_ref import modulated_conv2d_ref, setup_filter_ref
+    r = _rng(505)
+    f = setup_filter_ref([1, 3, 3, 1])
+    for case in range(120):
+        n = int(r.integers(1, 5))
+        cin, cout = int(r.integers(1, 72)), int(r.integers(1, 72))
+        k = [1, 3, 3][int(r.integers(0, 3))]
+        up = int(r.integers(1, 3)) if k == 3 else 1
+        res = int(r.integers(4, 36))
+        if case % 6 == 0:
+            res = int(r.integers(40, 80))
+        demod, has_noise = bool(r.integers(0, 2)), bool(r.integers(0, 2))
+        torch.manual_seed(4000 + case)
+        x = torch.randn(n, cin, res, res)
+        wt = torch.randn(cout, cin, k, k)
+        s = torch.randn(n, cin) + 1.0
+        noise = torch.randn(n, 1, res * up, res * up) * 0.1 if has_noise else None
+        ref = modulated_conv2d_ref(x.double(), wt.double(), s.double(), None if noise is None else noise.double(), up=up, padding=k // 2,
+                                   resample_kernel=f.double(), demodulate=demod)
+        out = cr.modulated_conv2d(x.cuda(), wt.cuda(), s.cuda(), None if noise is None else noise.cuda(), up=up, padding=k // 2,
+                                  resample_kernel=f.cuda(), demodulate=demod)
+        tag = f"case {case}: x {tuple(x.shape)} w {tuple(wt.shape)} up {up} demod {demod} noise {has_noise}"
+        assert tuple(out.shape) == tuple(ref.shape), tag
+        assert rel_err(out, ref) < 2e-4, tag
+
+
+def test_conv_forward_random_epilogues():
+    """The engine-level convolution entry (tap list / 1x1 GEMM / narrow streaming kernels, chosen by shape) with every epilogue piece --
+    per-sample input and output scales, bias, noise, activation, gain, residual, a channel slice of a wider output buffer -- on random shapes,
+    against float64 torch."""
+    import torch.nn.functional as F
+    from morphganformer_amd import _lib, conv as cv
+    r = _rng(606)
+    for case in range(160):
+        n = int(r.integers(1, 4))
+        cin, cout = int(r.integers(1, 100)), int(r.integers(1, 100))
+        k = [1, 1, 3][int(r.integers(0, 3))]
+        stride = 1 if k == 1 else int(r.integers(1, 3))
+        pad = 0 if k == 1 else int(r.integers(0, 2))
+        h, w = int(r.integers(k, 45)), int(r.integers(k, 61))
+        act = ["linear", "relu", "lrelu"][int(r.integers(0, 3))]
+        has_bias, has_noise, has_res = bool(r.integers(0, 2)), bool(r.integers(0, 2)), bool(r.integers(0, 2))
+        has_is, has_os = bool(r.integers(0, 2)), bool(r.integers(0, 2))
+        choff = int(r.integers(0, 9)) if r.integers(0, 2) else 0
+        ctotal = cout + choff + (int(r.integers(0, 5)) if choff else 0)
+        gain = float(r.uniform(0.5, 2.0))
+        torch.manual_seed(5000 + case)
+        x = torch.randn(n, cin, h, w)
+        wt = torch.randn(cout, cin, k, k) / (k * cin ** 0.5)
+        oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        b = torch.randn(cout) if has_bias else None
+        nz = torch.randn(n, oh * ow) if has_noise else None
+        ns = torch.tensor([0.3])
+        s_in = torch.rand(n, cin) + 0.5 if has_is else None
+        s_out = torch.rand(n, cout) + 0.5 if has_os else None
+        base = torch.randn(n, ctotal, oh, ow)
+        ref = F.conv2d((x * s_in[:, :, None, None] if has_is else x).double(), wt.double(), stride=stride, padding=pad)
+        if has_os:
+            ref = ref * s_out[:, :, None, None].double()
+        if has_noise:
+            ref = ref + (nz.double() * 0.3).reshape(n, 1, oh, ow)
+        if has_bias:
+            ref = ref + b.double().reshape(1, -1, 1, 1)
+        ref = {"linear": ref, "relu": ref.clamp(min=0), "lrelu": torch.where(ref > 0, ref, 0.2 * ref)}[act] * gain
+        if has_res:
+            ref = ref + base[:, choff:choff + cout].double()
+        out = base.clone().cuda()
+        ep = _lib.make_epilogue(bias=None if b is None else b.cuda(), noise=None if nz is None else nz.cuda(),
+                                noise_strength=ns.cuda() if has_noise else None, noise_n=n, act=act, alpha=0.2, gain=gain,
+                                residual=out if has_res else None)
+        cv.conv_forward(x.cuda(), cv.pack_weights(wt.cuda()), stride=stride, pad=(pad, pad), in_scale=None if s_in is None else s_in.cuda(),
+                        out_scale=None if s_out is None else s_out.cuda(), epilogue=ep, out=out, out_choff=choff)
+        tag = (f"case {case}: x {tuple(x.shape)} w {tuple(wt.shape)} stride {stride} pad {pad} {act} bias {has_bias} noise {has_noise} "
+               f"residual {has_res} in_scale {has_is} out_scale {has_os} slice {choff}/{ctotal}")
+        assert rel_err(out[:, choff:choff + cout], ref) < 2e-4, tag
+        keep = torch.ones(ctotal, dtype=torch.bool)
+        keep[choff:choff + cout] = False
+        assert torch.equal(out.cpu()[:, keep], base[:, keep]), tag      # the rest of the wider buffer is untouched
+
+
+@pytest.mark.parametrize("net", ["squeeze", "alex", "vgg"])
+def test_lpips_random_non_square_sizes(net):
+    """lpips.PerceptualLoss on image sizes nobody tuned a kernel for: non-square, odd, just above each backbone's minimum."""
+    from morphganformer_amd.lpips import PerceptualLoss, random_backbone, random_squeeze_backbone
+    from oracle.loss_ref import backbone_random, lpips_ref, squeeze_backbone_random
+    r = _rng({"squeeze": 707, "alex": 708, "vgg": 709}[net])
+    bb_np = random_squeeze_backbone(0) if net == "squeeze" else random_backbone(net, 0)
+    bb = squeeze_backbone_random(0) if net == "squeeze" else backbone_random(net, 0)
+    P = PerceptualLoss(model="net-lin", net=net, use_gpu=True, backbone_state=bb_np)
+    lins = [l.cpu() for l in P.lins]
+    lo = {"squeeze": 35, "alex": 70, "vgg": 33}[net]
+    for case in range(6):
+        h, w = int(r.integers(lo, 150)), int(r.integers(lo, 150))
+        n = int(r.integers(1, 4))
+        torch.manual_seed(6000 + case)
+        x0 = torch.rand(n, 3, h, w) * 2 - 1
+        x1 = (x0[:1] + 0.3 * torch.randn(1, 3, h, w)).clamp(-1, 1)
+        P.set_target(x1.cuda())
+        out = torch.zeros(n, device="cuda")
+        P.distance_into(out, x0.cuda())
+        for i in range(n):
+            ref = float(lpips_ref(bb, lins, x0[i:i + 1], x1, net=net))
+            assert abs(float(out[i]) - ref) < 1e-3 * abs(ref), (net, h, w, n, i, float(out[i]), ref)
+
+
+def test_warp_random_point_sets_are_byte_exact():
+    """drivers.warp_morph on random landmark sets (random counts, jitters, image sides, non-square images) against the literal OpenCV
+    transcription: integer / byte work, the bar is bit-exact."""
+    from morphganformer_amd import drivers
+    from oracle import warp_ref as W
+    for case in range(8):
+        rng = np.random.Generator(np.random.PCG64(900 + case))
+        hh, ww = int(rng.integers(40, 120)), int(rng.integers(40, 120))
+        n_inner = int(rng.integers(3, 30))
+        img = rng.integers(0, 256, (hh, ww, 3)).astype(np.uint8)
+        inner = np.stack([rng.integers(4, ww - 4, n_inner), rng.integers(4, hh - 4, n_inner)], axis=1)
+        inner = np.unique(inner, axis=0)
+        frame = np.array([[0, 0], [ww // 2, 0], [ww - 1, 0], [0, hh // 2], [ww - 1, hh // 2], [0, hh - 1], [ww // 2, hh - 1], [ww - 1, hh - 1]])
+        jit = int(rng.integers(1, 6))
+        p_src = np.concatenate([(inner + rng.integers(-jit, jit + 1, inner.shape)).clip(0, [ww - 1, hh - 1]), frame])
+        p_dst = np.concatenate([inner, frame])
+        label, recs, simp = drivers.warp_plan(p_src, p_dst, hh, ww)
+        ref = W.warp_morph_ref(img.astype(np.float32), [tuple(p) for p in p_src], [tuple(p) for p in p_dst], simp)
+        got = drivers.warp_morph_u8(img, p_src, p_dst)
+        assert np.array_equal(got, np.uint8(ref)), (case, hh, ww, n_inner, jit)

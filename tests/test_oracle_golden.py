@@ -390,6 +390,13 @@ def test_cv_warp_host_plan_equals_the_literal_transcription():
             continue
         want = W.invert_affine(W.get_affine_transform(np.float32(s), np.float32(d)))
         assert np.array_equal(D._cv_affine_inverse(np.float32(s), np.float32(d)), want)
+    # a collinear SOURCE triangle: LU64f reports "singular", cv::solve zeroes X, getAffineTransform returns the zero matrix without
+    # looking, warpAffine's inverse of it is zero too -- every pixel of the patch then samples source pixel (0, 0)
+    for s in ([(0, 22), (0, 0), (0, 20)], [(1, 1), (3, 3), (7, 7)], [(4, 4), (4, 4), (9, 2)]):
+        d = [(0, 15), (2, 0), (4, 19)]
+        assert np.array_equal(W.get_affine_transform(np.float32(s), np.float32(d)), np.zeros((2, 3)))
+        assert np.array_equal(D._cv_affine_inverse(np.float32(s), np.float32(d)), np.zeros(6))
+        assert np.array_equal(W.invert_affine(np.zeros((2, 3))), np.zeros(6))
     assert D._cv_bounding_rect([(10.5, 3.0), (12.0, 7.5), (11.25, 4.0)]) == (10, 3, 3, 5)
     src = rng.integers(0, 256, (9, 11, 3)).astype(np.float32)
     for _ in range(20):
