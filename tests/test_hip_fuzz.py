@@ -300,3 +300,49 @@ def test_warp_random_point_sets_are_byte_exact():
         ref = W.warp_morph_ref(img.astype(np.float32), [tuple(p) for p in p_src], [tuple(p) for p in p_dst], simp)
         got = drivers.warp_morph_u8(img, p_src, p_dst)
         assert np.array_equal(got, np.uint8(ref)), (case, hh, ww, n_inner, jit)
+
+
+@pytest.mark.parametrize("res,base,cmax,att,norm_g", [
+    (32, 256, 16, 8, True), (64, 1024, 64, 6, False), (128, 2048, 48, 8, True), (256, 4096, 128, 7, True), (64, 512, 32, 3, True),
+    (128, 16384, 256, 8, False), (16, 512, 64, 8, True)])
+def test_generator_random_configurations_vs_oracle(res, base, cmax, att, norm_g):
+    """Generator configurations besides the two the goldens pin (run_network.py:61-77,243-283: resolution, channel_base / channel_max,
+    the attention range, normalize_global): image, latents and every noise mode's plumbing against the CPU oracle."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import GeneratorConfig, make_state_dict
+    from oracle.generator_ref import generator_ref, to_torch_state
+    cfg = GeneratorConfig(img_resolution=res, channel_base=base, channel_max=cmax, attn_max_log2res=att, normalize_global=norm_g)
+    sd = make_state_dict(cfg, seed=res + cmax)
+    G = Generator(sd, cfg, "cuda", max_batch=3)
+    torch.manual_seed(res * 7 + cmax)
+    z = torch.randn(3, cfg.k, cfg.z_dim)
+    ref = generator_ref(to_torch_state(sd), z, cfg, "const")
+    img = G(z.cuda(), None, noise_mode="const")[0]
+    assert tuple(img.shape) == (3, 3, res, res)
+    assert rel_err(img, ref) < 1e-3
+    ref0 = generator_ref(to_torch_state(sd), z[:2], cfg, "none", truncation_psi=0.6)
+    img0 = G(z[:2].cuda(), None, noise_mode="none", truncation_psi=0.6)[0]
+    assert rel_err(img0, ref0) < 1e-3
+
+
+@pytest.mark.parametrize("res,base,cmax,att,norm_g", [(32, 256, 16, 8, True), (128, 2048, 48, 6, False), (256, 4096, 96, 8, True),
+                                                       (64, 16384, 256, 4, True)])
+def test_generator_gradient_random_configurations_vs_autograd(res, base, cmax, att, norm_g):
+    """d(loss)/dz through other generator configurations than the goldens' (gradient mode) against torch autograd
+    through the CPU oracle; gate as in test_hip_gradient.py: 1e-3 of max |gradient|."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.grad import GeneratorGrad
+    from morphganformer_amd.synth_weights import GeneratorConfig, make_state_dict
+    from oracle.generator_ref import generator_ref, to_torch_state
+    cfg = GeneratorConfig(img_resolution=res, channel_base=base, channel_max=cmax, attn_max_log2res=att, normalize_global=norm_g)
+    sd = make_state_dict(cfg, seed=res + cmax + 1)
+    gg = GeneratorGrad(Generator(sd, cfg, "cuda", max_batch=2))
+    torch.manual_seed(res + 3 * cmax)
+    z = torch.randn(2, cfg.k, cfg.z_dim, requires_grad=True)
+    target = torch.randn(2, 3, res, res) * 0.5
+    img_ref = generator_ref(to_torch_state(sd), z, cfg, "const")
+    (dz_ref,) = torch.autograd.grad((img_ref - target).square().mean(dim=(1, 2, 3)).sum(), z)
+    img = gg.forward(z.detach().cuda(), noise_mode="const")
+    assert rel_err(img, img_ref) < 1e-3
+    dz = gg.backward(2.0 * (img - target.cuda()) / target[0].numel())
+    assert rel_err(dz, dz_ref) < 1e-3
