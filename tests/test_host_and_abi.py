@@ -621,3 +621,17 @@ def test_bench_fixed_batch_and_torch_free_launcher():
             "assert 'torch' not in sys.modules and 'numpy' not in sys.modules; print('ok')")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
+
+
+def test_facenet_topology_parameter_count_and_work():
+    """The InceptionResnetV1 tables (facenet.py) against the one public known answer that needs no weights: the package's model summary
+    counts 27 910 327 parameters with the 8631-way vggface2 classifier head, i.e. 23 482 624 without it (`classify=False`, what
+    1024_example_FaceNet_percept.py:30-32 builds).  Plus the work the bench prices the config-3 term with."""
+    from morphganformer_amd import facenet as F
+    st = F.random_state(0)
+    buffers = sum(v.size for k, v in st.items() if "running" in k)
+    params = sum(v.size for v in st.values()) - buffers
+    assert params == 27_910_327 - (512 * 8631 + 8631) == 23_482_624
+    assert len(F.layer_table()) == sum(1 for k in st if k.endswith("conv.weight")) == 111              # BasicConv2d layers (conv + BN + ReLU)
+    assert len(F.residual_table()) == sum(1 for k in st if k.endswith("conv2d.weight")) == 21          # the blocks' closing 1x1 convs
+    assert abs(F.conv_gflop(160, 160) - 2.833) < 1e-3 and abs(F.conv_gflop(1024, 1024) - 164.62) < 1e-2
