@@ -635,3 +635,13 @@ def test_facenet_topology_parameter_count_and_work():
     assert len(F.layer_table()) == sum(1 for k in st if k.endswith("conv.weight")) == 111              # BasicConv2d layers (conv + BN + ReLU)
     assert len(F.residual_table()) == sum(1 for k in st if k.endswith("conv2d.weight")) == 21          # the blocks' closing 1x1 convs
     assert abs(F.conv_gflop(160, 160) - 2.833) < 1e-3 and abs(F.conv_gflop(1024, 1024) - 164.62) < 1e-2
+
+
+def test_lpips_backbone_topologies_against_published_parameter_counts():
+    """The three torchvision `.features` stacks LPIPS cuts its taps from (pretrained_networks.py:6-135), restated from the published
+    architectures -- weight-free known answers: squeezenet1_1 has 1 235 496 parameters, 513 000 of them in its classifier conv; AlexNet's five
+    convolutions 2 469 696; VGG-16's thirteen 14 714 688."""
+    from morphganformer_amd.lpips import random_backbone, random_squeeze_backbone
+    assert sum(v.size for v in random_squeeze_backbone(0).values()) == 1_235_496 - (512 * 1000 + 1000)
+    assert sum(v.size for v in random_backbone("alex", 0).values()) == 2_469_696
+    assert sum(v.size for v in random_backbone("vgg", 0).values()) == 14_714_688
