@@ -569,7 +569,7 @@ def config3_workload(a, cfg, device, rank, world, dist):
     targets = [(lambda j=j: G(zs[j:j + 1], None, noise_mode="const")[0].clamp(-1, 1)) for j in range(n_max)]
     lms = [synthetic_landmarks(steps, cfg.img_resolution, seed=900 + j) for j in range(n_max)]
     kw = dict(args=ProjectionArgs(step=steps), percept=percept, biometric=bio, gamma=1.0, batch=batch, latent_mean=latent_mean,
-              latent_std=float(latent_std), seed=3, dynamic=True)
+              latent_std=float(latent_std), seed=3, dynamic=True, use_graph=not a.no_graph)
     run_many = lambda n: drivers.project_many(G, targets[:n], landmarks=lms[:n], **kw)
     run_many(min(2, n_max))                                   # warm-up: engine set-up and graph capture are not what the passes compare
     barrier = dist.barrier if dist is not None else (lambda: None)

@@ -21,6 +21,7 @@ rocprofv3 --kernel-trace --stats -d $D/trace_vgg -- python3 bench.py $VARGS --st
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $D/pmc_mfma_vgg -- python3 bench.py $VARGS --no-graph --steps 1 --warmup 1 > $D/pmc_mfma_vgg.json 2> $D/pmc_mfma_vgg.err
 echo "[measure] config 3 (Wing + FaceNet + LPIPS + MSE over a list of targets): kernel trace"
 rocprofv3 --kernel-trace --stats -d $D/trace_c3 -- python3 bench.py --workload config3 --config3-targets 2 --config3-steps 64 > $D/c3_bench.json 2> $D/c3_trace.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $D/pmc_mfma_c3 -- python3 bench.py --workload config3 --config3-targets 1 --config3-steps 16 --no-graph > $D/pmc_mfma_c3.json 2> $D/pmc_mfma_c3.err
 echo "[measure] reduce"
 bash tools/refresh_profiles.sh $D $B $R
 { echo "== one target (n = 1), the last step of the gradient-mode leg: python tools/grad_step_trace.py <rocprofv3 --kernel-trace db>";
@@ -32,6 +33,7 @@ python3 tools/pmc_mfma.py $D/pmc_mfma_vgg --json profiles/${R}_vgg_pmc_mfma.json
 cp $D/vgg_bench.json profiles/${R}_vgg_bench.json
 python3 tools/rocpd_stats.py $(ls -t $(find $D/trace_c3 -name "*_results.db") | head -1) > profiles/${R}_config3_kernel_stats.txt
 cp $D/c3_bench.json profiles/${R}_config3_bench.json
+python3 tools/pmc_mfma.py $D/pmc_mfma_c3 --json profiles/${R}_config3_pmc_mfma.json > profiles/${R}_config3_pmc_mfma.txt
 mkdir -p $D/profiles && cp profiles/${R}_* $D/profiles/
-rm -rf $D/trace $D/pmc_fetch $D/pmc_write $D/pmc_mfma $D/gtrace1 $D/gtrace8 $D/trace_vgg $D/pmc_mfma_vgg $D/trace_c3          # raw output: too large to travel back
+rm -rf $D/trace $D/pmc_fetch $D/pmc_write $D/pmc_mfma $D/gtrace1 $D/gtrace8 $D/trace_vgg $D/pmc_mfma_vgg $D/trace_c3 $D/pmc_mfma_c3          # raw output: too large to travel back
 echo "[measure] done"; ls -la $D/profiles
