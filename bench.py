@@ -448,6 +448,12 @@ def pmc_fields(kernel, eng, tag=""):
     if t["mfma"] is not None:
         src, table = t["mfma"]
         rec = table.get(kernel)
+        if rec is None and kernel.endswith(">"):
+            # the engine's record names a kernel by its leading template arguments (`pw_conv_kernel<1, 4>`); the counter table has one row per
+            # full instantiation (`..., 1, true>`, `..., 1, false>`): busy cycles over cycles of all of them = the time-weighted mean
+            rows = [v for k, v in table.items() if k.startswith(kernel[:-1] + ", ") and isinstance(v, dict) and "total_ms" in v]
+            if rows:
+                rec = {"mfma_busy": round(sum(v["mfma_busy"] * v["total_ms"] for v in rows) / sum(v["total_ms"] for v in rows), 4)}
         if rec is not None:
             out["mfma_busy"] = rec["mfma_busy"]
             out["mfma_busy_source"] = f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs), {src}"
