@@ -27,7 +27,7 @@ def test_upfirdn2d_random_geometry():
     from oracle.ops_ref import upfirdn2d_ref
     r = _rng(101)
     done = 0
-    for case in range(400):
+    for case in range(260):
         n, c = int(r.integers(1, 4)), int(r.integers(1, 9))
         h, w = int(r.integers(1, 48)), int(r.integers(1, 80))
         if case % 7 == 0:
@@ -61,7 +61,7 @@ def test_upfirdn2d_random_geometry():
         tol = 4e-3 if dtype == torch.float16 else 1e-5
         assert rel_err(out, ref) < tol, tag
         done += 1
-    assert done > 250
+    assert done > 160
 
 
 def test_upfirdn2d_random_gradients():
@@ -102,7 +102,7 @@ def test_bias_act_random():
     from oracle.ops_ref import bias_act_ref
     acts = ["linear", "relu", "lrelu", "tanh", "sigmoid", "elu", "selu", "softplus", "swish"]
     r = _rng(303)
-    for case in range(200):
+    for case in range(140):
         rank = int(r.integers(1, 5))
         shape = [int(v) for v in r.integers(1, 9, rank)]
         if case % 5 == 0:
@@ -139,7 +139,7 @@ def test_conv2d_resample_random():
     from oracle.ops_ref import conv2d_resample_ref, setup_filter_ref
     r = _rng(404)
     done = 0
-    for case in range(220):
+    for case in range(160):
         n = int(r.integers(1, 4))
         cin, cout = int(r.integers(1, 80)), int(r.integers(1, 80))
         if case % 9 == 0:
@@ -169,7 +169,7 @@ def test_conv2d_resample_random():
         assert tuple(out.shape) == tuple(ref.shape), tag
         assert rel_err(out, ref) < 2e-4, tag
         done += 1
-    assert done > 150
+    assert done > 110
 
 
 def test_modulated_conv2d_random():
@@ -208,7 +208,7 @@ def test_conv_forward_random_epilogues():
     import torch.nn.functional as F
     from morphganformer_amd import _lib, conv as cv
     r = _rng(606)
-    for case in range(160):
+    for case in range(120):
         n = int(r.integers(1, 4))
         cin, cout = int(r.integers(1, 100)), int(r.integers(1, 100))
         k = [1, 1, 3][int(r.integers(0, 3))]
