@@ -61,7 +61,7 @@ def test_upfirdn2d_random_geometry():
         tol = 4e-3 if dtype == torch.float16 else 1e-5
         assert rel_err(out, ref) < tol, tag
         done += 1
-    assert done > 160
+    assert done > 140
 
 
 def test_upfirdn2d_random_gradients():
@@ -169,7 +169,7 @@ def test_conv2d_resample_random():
         assert tuple(out.shape) == tuple(ref.shape), tag
         assert rel_err(out, ref) < 2e-4, tag
         done += 1
-    assert done > 110
+    assert done > 90
 
 
 def test_modulated_conv2d_random():
