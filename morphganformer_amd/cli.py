@@ -82,6 +82,15 @@ def build_parser():
     m.add_argument("--gpus", type=str, default="0")
     m.add_argument("--ratio", type=float, default=1.0)
     m.add_argument("--truncation_psi", type=float, default=0.7)
+    w = sub.add_parser("warp", help="Morph two projected latents and warp the morph onto the averaged landmarks (1024_warp_morphs.py)")
+    w.add_argument("--model", type=str, required=True)
+    w.add_argument("--w1", type=str, required=True, help=".mat latent of the first bona fide image")
+    w.add_argument("--w2", type=str, required=True)
+    w.add_argument("--landmarks", type=str, required=True,
+                   help=".npz with `lm1`, `lm2` [68,2] (detections on the two source images) and `lm_G` [68,2] (on the morph)")
+    w.add_argument("--out", type=str, required=True, help="output directory: morph_G.png, Morph_final.png")
+    w.add_argument("--gpus", type=str, default="0")
+    w.add_argument("--truncation_psi", type=float, default=0.7)
     return ap
 
 
@@ -98,6 +107,12 @@ def main(argv=None):
     if a.cmd == "generate":
         print("Generate and save images...")
         drivers.generate_images(G, a.images_num, a.truncation_psi, a.output_dir, a.ratio, seed=a.seed)
+        return 0
+    if a.cmd == "warp":
+        lm = np.load(a.landmarks)
+        drivers.warp_morphs(G, drivers.load_latent_mat(a.w1), drivers.load_latent_mat(a.w2), lm["lm1"], lm["lm2"], landmark_G=lm["lm_G"],
+                            out_dir=a.out, truncation_psi=a.truncation_psi)
+        print("done")
         return 0
     if a.cmd == "morph":
         alphas = [float(v) for v in a.alphas.split(",")]

@@ -506,6 +506,59 @@ def warp_morph_u8(img_u8_hwc, points_G, points_avg):
     return out.to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy()           # values in [0, 255]: the cast truncates like np.uint8
 
 
+def frame_points(size: int):
+    """The 12 frame points of 1024_warp_morphs.py:130-132 for a `size` x `size` image (0, 341, 682, 1023 at 1024)."""
+    q = [(size - 1) * i // 3 for i in range(4)]
+    return [[q[0], q[0]], [q[0], q[1]], [q[0], q[2]], [q[0], q[3]], [q[1], q[0]], [q[2], q[0]], [q[3], q[0]], [q[3], q[1]], [q[3], q[2]],
+            [q[3], q[3]], [q[1], q[3]], [q[2], q[3]]]
+
+
+def gray_u8_device(img):
+    """[n,3,H,W] float32 device images -> [n,H,W] uint8 numpy: the gray image `get_landmarks_G` hands to dlib (1024_warp_morphs.py:61-66,
+    the same two cv2 calls as the projection drivers), made on the device (mgf_reference_gray_u8)."""
+    _lib.require_gpu(img)
+    x = img.contiguous().float()
+    n, c, h, w = x.shape
+    assert c == 3
+    out = torch.empty(n, h, w, dtype=torch.uint8, device=x.device)
+    scratch = torch.empty(n * int(_lib.lib().mgf_reference_gray_scratch_floats()), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().mgf_reference_gray_u8(out.data_ptr(), x.data_ptr(), n, h, w, scratch.data_ptr(), _lib.stream_ptr()), "reference_gray_u8")
+    return out.cpu().numpy()
+
+
+def warp_morphs(G, w1, w2, landmark1, landmark2, landmark_G=None, landmark_fn=None, out_dir=None, truncation_psi=0.7, noise_mode="random"):
+    """The whole of 1024_warp_morphs.py's main (:128-210): the 0.5 / 0.5 latent morph rendered with `G(W, truncation_psi)` (:153-156),
+    the averaged landmarks of the two bona fide images + the 12 frame points triangulated (scipy Delaunay, :160-164), the morph's own
+    landmarks (:166-168: `get_landmarks_G` -- here `landmark_G` [68,2], or `landmark_fn(gray uint8 [H,W])` called on the drivers' gray image
+    of the morph), then every triangle of the morph warped onto the averaged mesh (:186-200) and written as bytes (:203-206).
+    landmark1 / landmark2: [68,2] detections on the two source images (dlib is the caller's; `get_landmarks_img`, :46-56).
+    Writes morph_G.png and Morph_final.png under `out_dir` when given.  Returns dict(latent [1,k,D], morph uint8 [H,W,3] (what the script
+    reads back from morph_G.png), warped uint8 [H,W,3] (Morph_final.png), points_G, points_avg)."""
+    lat, imgs = merge_morph(G, w1, w2, (0.5,), truncation_psi, noise_mode=noise_mode)
+    img = imgs[0:1]
+    size = int(img.shape[-1])
+    morph_u8 = to_uint8_image(G, img)                       # the bytes misc.to_pil writes and cv2.imread reads back (channel order does not matter: per-channel work)
+    if landmark_G is None:
+        if landmark_fn is None:
+            raise ValueError("warp_morphs: pass the morph's landmarks (landmark_G) or a detector (landmark_fn)")
+        landmark_G = landmark_fn(gray_u8_device(img)[0])
+        if landmark_G is None:                              # (the script would fail on `None.detach()` two lines later)
+            raise _lib.MgfError("warp_morphs: the detector found no face in the morph")
+    l1, l2, lg = (np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v, dtype=np.float64).reshape(-1, 2) for v in (landmark1, landmark2, landmark_G))
+    if not (l1.shape == l2.shape == lg.shape):
+        raise ValueError(f"warp_morphs: landmark sets differ in shape: {l1.shape}, {l2.shape}, {lg.shape}")
+    extra = np.asarray(frame_points(size), dtype=np.float64)
+    points_avg = np.concatenate([(l1 + l2) / 2, extra])    # torch.div(landmark1.add(landmark2), 2) on DoubleTensors
+    points_G = np.concatenate([lg, extra])
+    warped = warp_morph_u8(morph_u8, points_G, points_avg)
+    if out_dir is not None:
+        from PIL import Image
+        os.makedirs(out_dir, exist_ok=True)
+        Image.fromarray(morph_u8, "RGB").save(os.path.join(out_dir, "morph_G.png"))
+        Image.fromarray(warped, "RGB").save(os.path.join(out_dir, "Morph_final.png"))
+    return {"latent": lat[0], "morph": morph_u8, "warped": warped, "points_G": points_G, "points_avg": points_avg}
+
+
 def second_stage(G, target, w_init, latent_std, lm_target, lm_steps, **kw):
     """A second projection whose noisy candidates are drawn around an earlier result instead of the latent mean
     (edit_MSE.py: `latent_in = w1` pattern; BASELINE config 5)."""

@@ -555,3 +555,68 @@ def test_landmark_delaunay_warp_is_byte_exact_vs_the_opencv_restatement(side, n_
     ref_f = ref_fn(f.cpu().numpy().transpose(1, 2, 0), [tuple(p) for p in p_G], [tuple(p) for p in p_avg], simp)
     assert np.array_equal(drivers.warp_morph(f, p_G, p_avg, background=0.0).cpu().numpy().transpose(1, 2, 0), ref_f)
     assert len(drivers.WARP_EXTRA_POINTS) == 12
+
+
+def test_warp_morphs_driver_mirrors_the_script(tmp_path):
+    """1024_warp_morphs.py:128-210 end to end on the tiny generator: 0.5 / 0.5 latent morph -> bytes -> landmarks of the two sources averaged and
+    triangulated with the frame points -> the morph's own landmarks (injected, or a detector called on the drivers' gray uint8 image) -> every
+    triangle warped -> Morph_final.png.  Against the literal OpenCV transcription applied to the same bytes: byte-exact."""
+    from scipy.spatial import Delaunay
+    from morphganformer_amd import cli, drivers
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from oracle import warp_ref as W
+    from test_host_and_abi import _tiny_snapshot
+    from PIL import Image
+    assert drivers.frame_points(1024) == drivers.WARP_EXTRA_POINTS
+    G = Generator(make_state_dict(TINY, seed=0), TINY, "cuda", max_batch=1)
+    S = TINY.img_resolution
+    rng = np.random.Generator(np.random.PCG64(77))
+    w1, w2 = (rng.standard_normal((1, TINY.k, TINY.z_dim)).astype(np.float32) for _ in range(2))
+    base = np.stack([rng.integers(8, S - 8, 68), rng.integers(8, S - 8, 68)], axis=1)
+    base = np.unique(base, axis=0)
+    lm1, lm2 = base + rng.integers(-2, 3, base.shape), base + rng.integers(-2, 3, base.shape)
+    lm_G = base + rng.integers(-3, 4, base.shape)
+    r = drivers.warp_morphs(G, w1, w2, lm1, lm2, landmark_G=lm_G, out_dir=str(tmp_path / "o"), noise_mode="const")
+    assert np.array_equal(r["latent"], 0.5 * w1 + 0.5 * w2)
+    img = G(torch.from_numpy(r["latent"]).cuda(), 0.7, noise_mode="const")[0]            # (the script's call: the 0.7 lands on `c`)
+    want_u8 = np.clip(np.rint((img[0].permute(1, 2, 0).cpu().numpy().astype(np.float64) + 1) * 127.5), 0, 255).astype(np.uint8)
+    assert np.array_equal(r["morph"], want_u8)
+    extra = np.asarray(drivers.frame_points(S), np.float64)
+    p_avg = np.concatenate([(lm1.astype(np.float64) + lm2) / 2, extra])
+    p_G = np.concatenate([lm_G.astype(np.float64), extra])
+    assert np.array_equal(r["points_avg"], p_avg) and np.array_equal(r["points_G"], p_G)
+    simp = Delaunay(p_avg).simplices.tolist()
+    ref = W.warp_morph_ref(r["morph"].astype(np.float32), [tuple(p) for p in p_G], [tuple(p) for p in p_avg], simp)
+    assert np.array_equal(r["warped"], np.uint8(ref))
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "o" / "Morph_final.png")), r["warped"])
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "o" / "morph_G.png")), r["morph"])
+    # the detector variant: it sees the drivers' gray uint8 image of the morph (get_landmarks_G, :61-66)
+    seen = []
+
+    def detector(gray):
+        seen.append(gray.copy())
+        return lm_G
+
+    r2 = drivers.warp_morphs(G, w1, w2, lm1, lm2, landmark_fn=detector, noise_mode="const")
+    assert np.array_equal(r2["warped"], r["warped"])
+    assert np.array_equal(seen[0], drivers.reference_gray_u8(img[0].permute(1, 2, 0).cpu().numpy()))
+    with pytest.raises(_lib_error()):
+        drivers.warp_morphs(G, w1, w2, lm1, lm2, landmark_fn=lambda gray: None, noise_mode="const")
+    with pytest.raises(ValueError):
+        drivers.warp_morphs(G, w1, w2, lm1, lm2[:10], landmark_G=lm_G, noise_mode="const")
+    # the command line
+    pkl = str(tmp_path / "net.pkl")
+    _tiny_snapshot(pkl, seed=3)
+    drivers.save_latent_mat(str(tmp_path / "a.mat"), w1)
+    drivers.save_latent_mat(str(tmp_path / "b.mat"), w2)
+    np.savez(tmp_path / "lm.npz", lm1=lm1, lm2=lm2, lm_G=lm_G)
+    assert cli.main(["warp", "--model", pkl, "--w1", str(tmp_path / "a.mat"), "--w2", str(tmp_path / "b.mat"), "--landmarks", str(tmp_path / "lm.npz"),
+                     "--out", str(tmp_path / "w")]) == 0
+    assert sorted(os.listdir(tmp_path / "w")) == ["Morph_final.png", "morph_G.png"]
+    assert np.asarray(Image.open(tmp_path / "w" / "Morph_final.png")).shape == (S, S, 3)
+
+
+def _lib_error():
+    from morphganformer_amd import _lib
+    return _lib.MgfError
