@@ -346,3 +346,89 @@ def test_generator_gradient_random_configurations_vs_autograd(res, base, cmax, a
     assert rel_err(img, img_ref) < 1e-3
     dz = gg.backward(2.0 * (img - target.cuda()) / target[0].numel())
     assert rel_err(dz, dz_ref) < 1e-3
+
+
+def test_second_order_gradients_random():
+    """Double backward of the two plugin operators (bias_act.py:137-198: the grad=2 kernel; upfirdn2d.py:237-256: self-application) on random
+    shapes, against torch's own double backward through the oracle's float64 forward."""
+    from morphganformer_amd.torch_utils.ops import bias_act, upfirdn2d
+    from oracle.ops_ref import bias_act_ref, upfirdn2d_ref
+    r = _rng(808)
+    smooth = ["tanh", "sigmoid", "softplus", "swish", "elu", "selu", "linear", "lrelu"]
+    for case in range(60):
+        rank = int(r.integers(2, 5))
+        shape = [int(v) for v in r.integers(1, 8, rank)]
+        dim = int(r.integers(0, rank))
+        act = smooth[int(r.integers(0, len(smooth)))]
+        gain = float(r.uniform(0.5, 2.0))
+        torch.manual_seed(7000 + case)
+        x, b = torch.randn(*shape), torch.randn(shape[dim])
+        gy, ggx = torch.randn(*shape), torch.randn(*shape)
+        xr = x.double().requires_grad_(True)
+        yr = bias_act_ref(xr, b.double(), dim=dim, act=act, gain=gain)
+        (dxr,) = torch.autograd.grad(yr, xr, gy.double(), create_graph=True)
+        xg = x.cuda().requires_grad_(True)
+        yg = bias_act.bias_act(xg, b.cuda(), dim=dim, act=act, gain=gain)
+        (dxg,) = torch.autograd.grad(yg, xg, gy.cuda(), create_graph=True)
+        tag = f"bias_act case {case}: {shape} dim {dim} {act}"
+        assert rel_err(dxg, dxr) < 1e-5, tag
+        if dxr.requires_grad and dxr.grad_fn is not None and act not in ("linear", "lrelu"):
+            (d2r,) = torch.autograd.grad(dxr, xr, ggx.double())
+            (d2g,) = torch.autograd.grad(dxg, xg, ggx.cuda())
+            assert rel_err(d2g, d2r) < 2e-5, tag
+    for case in range(40):
+        n, c = int(r.integers(1, 3)), int(r.integers(1, 4))
+        h, w = int(r.integers(3, 30)), int(r.integers(3, 40))
+        up, down = int(r.integers(1, 3)), int(r.integers(1, 3))
+        ft = int(r.integers(1, 5))
+        pad = [int(v) for v in r.integers(0, 3, 4)]
+        if h * up + pad[2] + pad[3] < ft or w * up + pad[0] + pad[1] < ft:
+            continue
+        torch.manual_seed(8000 + case)
+        x, f = torch.randn(n, c, h, w), torch.rand(ft, ft) + 0.1
+        xr = x.double().requires_grad_(True)
+        yr = upfirdn2d_ref(xr, f.double(), up=up, down=down, padding=pad, gain=1.5)
+        gy = torch.randn(yr.shape)
+        (dxr,) = torch.autograd.grad(yr, xr, gy.double(), create_graph=True)
+        # the operator is linear in x: its gradient does not depend on x, the double backward w.r.t. gy is the forward operator again
+        gyg = gy.cuda().requires_grad_(True)
+        xg = x.cuda().requires_grad_(True)
+        yg = upfirdn2d.upfirdn2d(xg, f.cuda(), up=up, down=down, padding=pad, gain=1.5)
+        (dxg,) = torch.autograd.grad(yg, xg, gyg, create_graph=True)
+        v = torch.randn(n, c, h, w)
+        (back,) = torch.autograd.grad(dxg, gyg, v.cuda())
+        want = upfirdn2d_ref(v.double(), f.double(), up=up, down=down, padding=pad, gain=1.5)
+        tag = f"upfirdn2d case {case}: x {tuple(x.shape)} up {up} down {down} f {ft} pad {pad}"
+        assert rel_err(dxg, dxr) < 1e-5 and rel_err(back, want) < 1e-5, tag
+
+
+@pytest.mark.parametrize("net", ["squeeze", "alex", "vgg"])
+def test_lpips_gradient_random_non_square_sizes(net):
+    """d LPIPS / d image (gradient mode) on non-square, odd image sizes against autograd through the oracle.
+    (The gate holds AWAY from ReLU / max-pool ties: an input with one unit within rounding of its decision boundary gets that unit's whole
+    contribution or none -- seen once while these cases were drawn, vgg 109 x 66: 2.7e-3 of max |gradient| over one receptive field against
+    float64, 2.7e-6 after perturbing the input by 1e-5.  The seeds below have no such unit.)"""
+    import os
+    from morphganformer_amd.lpips import PerceptualLoss, WEIGHTS_DIR
+    from oracle.loss_ref import backbone_random, lpips_ref, squeeze_backbone_random
+    r = _rng({"squeeze": 811, "alex": 812, "vgg": 814}[net])
+    bb = squeeze_backbone_random(0) if net == "squeeze" else backbone_random(net, 0)
+    lin = np.load(os.path.join(WEIGHTS_DIR, f"lpips_lin_{net}.npz"))
+    lins = [torch.from_numpy(lin[f"lin{i}"]).float().reshape(-1) for i in range(len(lin.files))]
+    pl = PerceptualLoss(net=net, allow_random_backbone=True)
+    lo = {"squeeze": 35, "alex": 70, "vgg": 33}[net]
+    for case in range(4):
+        h, w = int(r.integers(lo, 120)), int(r.integers(lo, 120))
+        n = int(r.integers(1, 3))
+        torch.manual_seed(9000 + case)
+        pred = (torch.rand(n, 3, h, w) * 2 - 1).requires_grad_(True)
+        target = torch.rand(1, 3, h, w) * 2 - 1
+        val = lpips_ref(bb, lins, pred, target.expand(n, -1, -1, -1), net=net)
+        (ref,) = torch.autograd.grad(val.sum(), pred)
+        pl.set_target(target.cuda())
+        out = torch.empty(n, device="cuda")
+        pl.distance_into(out, pred.detach().cuda(), keep_taps=True)
+        assert rel_err(out, val.reshape(n)) < 1e-3, (net, h, w, n)
+        dimg = torch.zeros(n, 3, h, w, device="cuda")
+        pl.grad_into(dimg, scale=1.0)
+        assert rel_err(dimg, ref) < 1e-3, (net, h, w, n)
