@@ -432,3 +432,26 @@ def test_lpips_gradient_random_non_square_sizes(net):
         dimg = torch.zeros(n, 3, h, w, device="cuda")
         pl.grad_into(dimg, scale=1.0)
         assert rel_err(dimg, ref) < 1e-3, (net, h, w, n)
+
+
+def test_facenet_random_non_square_sizes():
+    """The InceptionResnetV1 embedder on random image sizes from just above its minimum (75) upwards, non-square and odd: every stride-2 /
+    valid-padding stage hits different ragged edges.  Embedding <= 1e-3 against the oracle (unit norm), seeded weights."""
+    from morphganformer_amd.facenet import InceptionResnetV1Embedder, random_state
+    from oracle.embed_ref import inception_resnet_v1_ref
+    r = _rng(909)
+    sd_np = random_state(5)
+    sd_t = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    net = InceptionResnetV1Embedder(sd_np, n=1)
+    for case in range(5):
+        h, w = int(r.integers(75, 240)), int(r.integers(75, 240))
+        n = int(r.integers(1, 3))
+        torch.manual_seed(9500 + case)
+        x = torch.rand(n, 3, h, w) * 2 - 1
+        emb = net(x.cuda()).cpu()
+        with torch.no_grad():
+            want = inception_resnet_v1_ref(sd_t, x, {})
+        assert tuple(emb.shape) == (n, 512), (h, w, n)
+        assert float((emb - want).abs().max()) < 1e-3 * float(want.abs().max()), (h, w, n)
+    with pytest.raises(Exception):
+        net(torch.zeros(1, 3, 60, 60, device="cuda"))            # below the network's minimum: refused, not garbage
