@@ -82,6 +82,13 @@ def build_parser():
     m.add_argument("--gpus", type=str, default="0")
     m.add_argument("--ratio", type=float, default=1.0)
     m.add_argument("--truncation_psi", type=float, default=0.7)
+    t = sub.add_parser("morph-tree", help="Morph every latent pair of every id folder (the directory walk of 1024_merge_morph_2.py)")
+    t.add_argument("--model", type=str, required=True)
+    t.add_argument("--src", type=str, required=True, help="<src>/<id>/<name>/*.mat: two name folders per id")
+    t.add_argument("--dst", type=str, required=True, help="<dst>/<id>/<stem1>+<stem2>.jpg / .mat")
+    t.add_argument("--gpus", type=str, default="0")
+    t.add_argument("--ratio", type=float, default=1.0)
+    t.add_argument("--truncation_psi", type=float, default=0.7)
     w = sub.add_parser("warp", help="Morph two projected latents and warp the morph onto the averaged landmarks (1024_warp_morphs.py)")
     w.add_argument("--model", type=str, required=True)
     w.add_argument("--w1", type=str, required=True, help=".mat latent of the first bona fide image")
@@ -107,6 +114,10 @@ def main(argv=None):
     if a.cmd == "generate":
         print("Generate and save images...")
         drivers.generate_images(G, a.images_num, a.truncation_psi, a.output_dir, a.ratio, seed=a.seed)
+        return 0
+    if a.cmd == "morph-tree":
+        for stem in drivers.merge_morph_tree(G, a.src, a.dst, a.truncation_psi, a.ratio):
+            print(stem)
         return 0
     if a.cmd == "warp":
         lm = np.load(a.landmarks)

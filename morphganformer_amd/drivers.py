@@ -142,6 +142,36 @@ def merge_morph(G, w1, w2, alphas=(0.5,), truncation_psi=0.7, noise_mode="random
     return np.stack(lat), torch.stack(imgs)
 
 
+def merge_morph_tree(G, src_path, dst_path, truncation_psi=0.7, ratio=1.0, noise_mode="random"):
+    """The directory walk of 1024_merge_morph_2.py:53-92: `src_path/<id>/<name>/` holds the projected latents (`.mat`, beside their `.png`s) of
+    one bona fide image; every id folder has two such name folders (entries with a dot are skipped, :61-63; the first two are used, :64-65), and
+    every latent of the first is morphed with every latent of the second -- `0.5 * w1 + 0.5 * w2`, rendered with `G(W, truncation_psi)` -- into
+    `dst_path/<id>/<stem1>+<stem2>.jpg / .mat` (:77-92); pairs whose image already exists are skipped (:80).  Returns the list of written stems."""
+    done = []
+    for ident in sorted(os.listdir(src_path)):
+        id_dir = os.path.join(src_path, ident)
+        if not os.path.isdir(id_dir):
+            continue
+        names = [nm for nm in sorted(os.listdir(id_dir)) if len(nm.split(".")) == 1]
+        if len(names) < 2:
+            raise ValueError(f"{id_dir}: needs the latent folders of two bona fide images, found {names}")
+        dst_id = os.path.join(dst_path, ident)
+        os.makedirs(dst_id, exist_ok=True)
+        mats = [[f for f in sorted(os.listdir(os.path.join(id_dir, nm))) if f.endswith(".mat")] for nm in names[:2]]
+        for im1 in mats[0]:
+            w1 = load_latent_mat(os.path.join(id_dir, names[0], im1))
+            for im2 in mats[1]:
+                stem = im1[:-4] + "+" + im2[:-4]
+                if os.path.exists(os.path.join(dst_id, stem + ".jpg")):
+                    continue
+                w2 = load_latent_mat(os.path.join(id_dir, names[1], im2))
+                lat, imgs = merge_morph(G, w1, w2, (0.5,), truncation_psi, noise_mode=noise_mode)
+                save_image(G, imgs[0:1], os.path.join(dst_id, stem + ".jpg"), ratio)
+                save_latent_mat(os.path.join(dst_id, stem + ".mat"), lat[0])
+                done.append(os.path.join(ident, stem))
+    return done
+
+
 DEFAULT_BATCH = 32       # loop steps per generator forward in literal mode: the configuration bench.py times (1.6 GB of activations per step at 1024^2;
                          # measured 20 .. 64: 32 is the fastest, 25 -- the round-2 figure -- 1.5 - 3 % behind)
 

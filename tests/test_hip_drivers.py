@@ -620,3 +620,37 @@ def test_warp_morphs_driver_mirrors_the_script(tmp_path):
 def _lib_error():
     from morphganformer_amd import _lib
     return _lib.MgfError
+
+
+def test_merge_morph_tree_walks_the_directories_like_the_script(tmp_path):
+    """1024_merge_morph_2.py:53-92: ids -> the two latent folders -> every pair of `.mat` files -> `<stem1>+<stem2>.jpg / .mat`; existing
+    images are skipped; the blended latent is `0.5 * w1 + 0.5 * w2` on the loadmat arrays."""
+    from morphganformer_amd import cli, drivers
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from test_host_and_abi import _tiny_snapshot
+    from PIL import Image
+    G = Generator(make_state_dict(TINY, seed=0), TINY, "cuda", max_batch=1)
+    rng = np.random.Generator(np.random.PCG64(5))
+    src, lat = tmp_path / "src", {}
+    for ident in ("0001", "0002"):
+        for name, files in (("personA", ["000003_0.812345", "000007_0.701234"]), ("personB", ["000001_0.912345"])):
+            os.makedirs(src / ident / name)
+            for f in files:
+                lat[(ident, name, f)] = rng.standard_normal((1, TINY.k, TINY.z_dim)).astype(np.float32)
+                drivers.save_latent_mat(str(src / ident / name / (f + ".mat")), lat[(ident, name, f)])
+                Image.new("RGB", (8, 8)).save(src / ident / name / (f + ".png"))          # the projections' images lie beside the latents
+        (src / ident / "notes.txt").write_text("x")                                        # entries with a dot are not latent folders
+    done = drivers.merge_morph_tree(G, str(src), str(tmp_path / "dst"), noise_mode="const")
+    assert sorted(done) == [os.path.join(i, s) for i in ("0001", "0002") for s in ("000003_0.812345+000001_0.912345", "000007_0.701234+000001_0.912345")]
+    for ident in ("0001", "0002"):
+        assert sorted(os.listdir(tmp_path / "dst" / ident)) == sorted(s + e for s in ("000003_0.812345+000001_0.912345", "000007_0.701234+000001_0.912345")
+                                                                       for e in (".jpg", ".mat"))
+        w = drivers.load_latent_mat(str(tmp_path / "dst" / ident / "000003_0.812345+000001_0.912345.mat"))
+        assert np.array_equal(w, 0.5 * lat[(ident, "personA", "000003_0.812345")] + 0.5 * lat[(ident, "personB", "000001_0.912345")])
+        assert Image.open(tmp_path / "dst" / ident / "000003_0.812345+000001_0.912345.jpg").size == (TINY.img_resolution, TINY.img_resolution)
+    assert drivers.merge_morph_tree(G, str(src), str(tmp_path / "dst"), noise_mode="const") == []      # everything exists: nothing is redone
+    pkl = str(tmp_path / "net.pkl")
+    _tiny_snapshot(pkl, seed=3)
+    assert cli.main(["morph-tree", "--model", pkl, "--src", str(src), "--dst", str(tmp_path / "dst2")]) == 0
+    assert len(os.listdir(tmp_path / "dst2" / "0002")) == 4
