@@ -19,24 +19,9 @@ import os
 import sys
 
 
-def build_parser():
-    ap = argparse.ArgumentParser(prog="morphganformer_amd", description="MI355X latent-projection / GANformer drivers")
-    sub = ap.add_subparsers(dest="cmd", required=True)
-
-    g = sub.add_parser("generate", help="Generate images using a pretrained network pickle")
-    g.add_argument("--model", type=str, required=True)
-    g.add_argument("--gpus", type=str, default="0")
-    g.add_argument("--output-dir", type=str, default="images")
-    g.add_argument("--images-num", type=int, default=32)
-    g.add_argument("--truncation-psi", type=float, default=0.7)
-    g.add_argument("--ratio", type=float, default=1.0)
-    g.add_argument("--seed", type=int, default=None)
-
-    p = sub.add_parser("project", help="Project one face image into the latent space")
+def _loop_arguments(p):
+    """The projection loop's arguments, shared by `project` and `morph-pairs` (1024_example_wing_loss_perceptual_sqz_MSE.py:222-245)."""
     p.add_argument("--model", type=str, default="models/ffhq-snapshot-1024_v2.pkl")
-    p.add_argument("--image", type=str, required=True)
-    p.add_argument("--landmarks", type=str, default=None)
-    p.add_argument("--path_to_gen", type=str, default="images/projection/")
     p.add_argument("--gpus", type=str, default="0")
     p.add_argument("--size", type=int, default=1024)
     p.add_argument("--n_mean_latent", type=int, default=10000)
@@ -73,6 +58,36 @@ def build_parser():
                         "into the latent and let Adam move it")
     p.add_argument("--seed", type=int, default=None)
 
+
+def build_parser():
+    ap = argparse.ArgumentParser(prog="morphganformer_amd", description="MI355X latent-projection / GANformer drivers")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+
+    g = sub.add_parser("generate", help="Generate images using a pretrained network pickle")
+    g.add_argument("--model", type=str, required=True)
+    g.add_argument("--gpus", type=str, default="0")
+    g.add_argument("--output-dir", type=str, default="images")
+    g.add_argument("--images-num", type=int, default=32)
+    g.add_argument("--truncation-psi", type=float, default=0.7)
+    g.add_argument("--ratio", type=float, default=1.0)
+    g.add_argument("--seed", type=int, default=None)
+
+    p = sub.add_parser("project", help="Project one face image into the latent space")
+    p.add_argument("--image", type=str, required=True)
+    p.add_argument("--landmarks", type=str, default=None)
+    p.add_argument("--path_to_gen", type=str, default="images/projection/")
+    _loop_arguments(p)
+
+    q = sub.add_parser("morph-pairs", help="Project both images of every CSV pair and render their latent morph "
+                                           "(projection_example_v2_percept_morph.py:330-365; BASELINE config 3's outer loop)")
+    q.add_argument("--csv", type=str, required=True, help="rows `img1,img2,similarity`; the header row and rows below --threshold are skipped")
+    q.add_argument("--threshold", type=float, default=0.5)
+    q.add_argument("--src", type=str, required=True, help="directory of the bona fide images")
+    q.add_argument("--dst-raw", type=str, required=True, help="<a>_<b>_A.png / _B.png: the two projections")
+    q.add_argument("--dst-morph", type=str, required=True, help="<a>_<b>.png: the 0.5 / 0.5 latent morph")
+    q.add_argument("--dynamic", action="store_true", help="ranks pull images from a shared work queue instead of images[rank::world]")
+    _loop_arguments(q)
+
     m = sub.add_parser("morph", help="Render linear morphs of two projected latents")
     m.add_argument("--model", type=str, required=True)
     m.add_argument("--w1", type=str, required=True)
@@ -103,9 +118,13 @@ def build_parser():
 
 def main(argv=None):
     a = build_parser().parse_args(argv)
-    os.environ.setdefault("CUDA_VISIBLE_DEVICES", a.gpus)
+    launched = int(os.environ.get("WORLD_SIZE", "1")) > 1 and "LOCAL_RANK" in os.environ
+    if not launched:
+        os.environ.setdefault("CUDA_VISIBLE_DEVICES", a.gpus)
     import numpy as np
     import torch
+    if launched:                                              # one process per GPU (torch.distributed.run): rank r works on device LOCAL_RANK
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
     from . import drivers, loader
     from .projection import ProjectionArgs
 
@@ -135,17 +154,10 @@ def main(argv=None):
     args = ProjectionArgs(step=a.step, lamda=a.lamda, beta=a.beta, lr=a.lr, lr_rampup=a.lr_rampup, lr_rampdown=a.lr_rampdown,
                           noise=a.noise, noise_ramp=a.noise_ramp, truncation_psi=a.truncation_psi, n_mean_latent=a.n_mean_latent,
                           ratio=a.ratio, percept_weight=a.percept_weight)
-    target = drivers.image_transform(a.image, size=a.size, device=G.device)
-    lm_t = lm_s = None
-    if a.landmarks:
-        lm = np.load(a.landmarks)
-        lm_t, lm_s = lm["target"], lm["steps"]
-        if lm_s.shape[0] < a.step:
-            raise SystemExit(f"--landmarks holds {lm_s.shape[0]} steps, --step is {a.step}")
     percept = None
     if not a.no_lpips:
         if a.lpips_backbone is None and not a.lpips_random_backbone:
-            raise SystemExit("project: the LPIPS term needs the torchvision backbone weights: --lpips-backbone <state dict> "
+            raise SystemExit(f"{a.cmd}: the LPIPS term needs the torchvision backbone weights: --lpips-backbone <state dict> "
                              "(or --no-lpips / --lpips-random-backbone)")
         from .lpips import load_backbone_state
         state = load_backbone_state(a.lpips_backbone) if a.lpips_backbone else None
@@ -153,10 +165,36 @@ def main(argv=None):
             print("WARNING: LPIPS runs on seeded random backbone weights (--lpips-random-backbone); the term is not a perceptual distance")
         percept = PerceptualLoss(model="net-lin", net=a.net, use_gpu=True, device=G.device, backbone_state=state,
                                  allow_random_backbone=state is None)
+    space = "w+" if (a.w_plus and a.mode == "gradient") else "z"
+    if a.cmd == "morph-pairs":
+        # one process per GPU under `python -m torch.distributed.run --nproc-per-node N -m morphganformer_amd.cli morph-pairs ...`: the
+        # 2 x pairs projections are sharded over the ranks, one all_gather returns the latents, the renderings are dealt pairs[rank::world]
+        import torch.distributed as dist
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        kw = dict(args=args, percept=percept, batch=a.batch, seed=a.seed, mode=a.mode, latent_space=space, keep_images=a.keep_images)
+        if a.mode == "literal":
+            kw["dynamic"] = a.dynamic
+        res = drivers.morph_pairs(G, drivers.read_pair_csv(a.csv, a.threshold), a.src, a.dst_raw, a.dst_morph,
+                                  truncation_psi=a.truncation_psi, ratio=a.ratio, **kw)
+        for path in res["written"]:
+            print(path)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+    target = drivers.image_transform(a.image, size=a.size, device=G.device)
+    lm_t = lm_s = None
+    if a.landmarks:
+        lm = np.load(a.landmarks)
+        lm_t, lm_s = lm["target"], lm["steps"]
+        if lm_s.shape[0] < a.step:
+            raise SystemExit(f"--landmarks holds {lm_s.shape[0]} steps, --step is {a.step}")
     stem = os.path.splitext(os.path.basename(a.image))[0]
     res = drivers.project_image(G, target, lm_t, lm_s, args=args, percept=percept, batch=a.batch, seed=a.seed,
                                 out_prefix=os.path.join(a.path_to_gen, stem), mode=a.mode, path_to_gen=a.path_to_gen,
-                                keep_images=a.keep_images, latent_space="w+" if (a.w_plus and a.mode == "gradient") else "z")
+                                keep_images=a.keep_images, latent_space=space)
     print(f"best step {res['step']}  loss {res['loss']:.6f}")
     return 0
 

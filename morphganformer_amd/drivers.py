@@ -317,6 +317,53 @@ def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):
     return out
 
 
+def read_pair_csv(path, threshold=0.5):
+    """The pair list of projection_example_v2_percept_morph.py:337-343: rows `img1, img2, similarity`; the header row (`img1`) and rows below the
+    similarity threshold are skipped.  -> [(img1, img2), ...]"""
+    import csv
+    pairs = []
+    with open(path, "r", newline="") as fh:
+        for row in csv.reader(fh):
+            if not row or row[0] == "img1":
+                continue
+            if float(row[2]) < threshold:
+                continue
+            pairs.append((row[0], row[1]))
+    return pairs
+
+
+def morph_pairs(G, pairs, src_dir, dst_raw, dst_morph, landmarks=None, truncation_psi=0.7, ratio=1.0, noise_mode="random", **project_kw):
+    """BASELINE config 3's outer loop (projection_example_v2_percept_morph.py:330-365): for every pair of bona fide images, project both into the
+    latent space, render them (`<a>_<b>_A.png`, `_B.png` under dst_raw) and their 0.5 / 0.5 latent morph (`<a>_<b>.png` under dst_morph); pairs
+    whose morph exists are skipped (:352).  The 2 x len(pairs) projections are independent: `project_many` shards them over the ranks of the
+    process group (static or, with dynamic=True, through the work queue) and gathers every latent to every rank; the renderings are then
+    dealt `pairs[rank::world]`.  pairs: [(img1, img2)] file names under src_dir (read_pair_csv); landmarks: optional {file name: (lm_target,
+    lm_steps)}; project_kw: project_image's arguments (args, percept, biometric, gamma, batch, seed, mode, dynamic, ...).
+    Returns dict(pairs (the ones worked on), latents [2P,k,D], losses, steps, written (this rank's morph paths))."""
+    import torch.distributed as dist
+    from .distributed import shard_items
+    stem = lambda f: f.split(".")[0]                          # (`img1.split('.')[0]`, :347)
+    todo = [(a, b) for a, b in pairs if not os.path.exists(os.path.join(dst_morph, f"{stem(a)}_{stem(b)}.png"))]
+    if not todo:
+        return {"pairs": [], "latents": None, "losses": None, "steps": None, "written": []}
+    files = [f for pr in todo for f in pr]
+    lms = None if landmarks is None else [landmarks[f] for f in files]
+    res = project_many(G, [os.path.join(src_dir, f) for f in files], landmarks=lms, **project_kw)
+    on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+    written = []
+    for pi in shard_items(len(todo), rank, world):
+        a, b = todo[pi]
+        name = f"{stem(a)}_{stem(b)}"
+        w1, w2 = res["latents"][2 * pi:2 * pi + 1], res["latents"][2 * pi + 1:2 * pi + 2]
+        for w, tag in ((w1, "_A"), (w2, "_B")):
+            save_image(G, G(w.to(G.device), truncation_psi, noise_mode=noise_mode)[0], os.path.join(dst_raw, name + tag + ".png"), ratio)
+        _, imgs = merge_morph(G, w1, w2, (0.5,), truncation_psi, noise_mode=noise_mode)
+        save_image(G, imgs[0:1], os.path.join(dst_morph, name + ".png"), ratio)
+        written.append(os.path.join(dst_morph, name + ".png"))
+    return {"pairs": todo, "latents": res["latents"], "losses": res["losses"], "steps": res["steps"], "written": written}
+
+
 def _project_group(G, targets, landmarks, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None, eps=None,
                    use_graph=True, noise_mode="random", use_mse=True, seed=None, weight_decay=0.0, mode="gradient", latent_space="z",
                    biometric=None, gamma=1.0, batch=None, **unused):

@@ -654,3 +654,53 @@ def test_merge_morph_tree_walks_the_directories_like_the_script(tmp_path):
     _tiny_snapshot(pkl, seed=3)
     assert cli.main(["morph-tree", "--model", pkl, "--src", str(src), "--dst", str(tmp_path / "dst2")]) == 0
     assert len(os.listdir(tmp_path / "dst2" / "0002")) == 4
+
+
+def test_morph_pairs_projects_renders_and_skips_like_the_script(tmp_path):
+    """projection_example_v2_percept_morph.py:330-365 (BASELINE config 3's outer loop): CSV rows -> both images projected -> `_A.png`, `_B.png`,
+    the 0.5 / 0.5 morph; header and low-similarity rows skipped, existing morphs skipped; the morph IS G(0.5 w1 + 0.5 w2) of the returned latents."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.projection import ProjectionArgs
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from PIL import Image
+    G = Generator(make_state_dict(TINY, seed=0), TINY, "cuda", max_batch=1)
+    drivers.generate_images(G, 3, output_dir=str(tmp_path / "src"), seed=4, noise_mode="const")
+    for i, nm in enumerate(("anna.png", "ben.png", "cleo.png")):
+        os.rename(tmp_path / "src" / f"sample_{i:06d}.png", tmp_path / "src" / nm)
+    (tmp_path / "pairs.csv").write_text("img1,img2,simi\nanna.png,ben.png,0.81\nanna.png,cleo.png,0.31\nben.png,cleo.png,0.5\n")
+    pairs = drivers.read_pair_csv(str(tmp_path / "pairs.csv"))
+    assert pairs == [("anna.png", "ben.png"), ("ben.png", "cleo.png")]                      # header and the 0.31 row are gone (`re < 0.5`)
+    kw = dict(args=ProjectionArgs(step=8, n_mean_latent=200), percept=None, batch=4, seed=2, noise_mode="const")
+    r = drivers.morph_pairs(G, pairs, str(tmp_path / "src"), str(tmp_path / "raw"), str(tmp_path / "morph"), **kw)
+    assert sorted(os.listdir(tmp_path / "morph")) == ["anna_ben.png", "ben_cleo.png"]
+    assert sorted(os.listdir(tmp_path / "raw")) == ["anna_ben_A.png", "anna_ben_B.png", "ben_cleo_A.png", "ben_cleo_B.png"]
+    assert tuple(r["latents"].shape) == (4, TINY.k, TINY.z_dim) and len(r["written"]) == 2
+    w = 0.5 * r["latents"][0:1].cpu().numpy() + 0.5 * r["latents"][1:2].cpu().numpy()
+    want = drivers.to_uint8_image(G, G(torch.from_numpy(w).cuda(), 0.7, noise_mode="const")[0])
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "morph" / "anna_ben.png")), want)
+    want_b = drivers.to_uint8_image(G, G(r["latents"][1:2].cuda(), 0.7, noise_mode="const")[0])
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "raw" / "anna_ben_B.png")), want_b)
+    # everything exists: nothing is projected again; one morph removed: only that pair is redone
+    assert drivers.morph_pairs(G, pairs, str(tmp_path / "src"), str(tmp_path / "raw"), str(tmp_path / "morph"), **kw)["pairs"] == []
+    os.remove(tmp_path / "morph" / "ben_cleo.png")
+    r2 = drivers.morph_pairs(G, pairs, str(tmp_path / "src"), str(tmp_path / "raw"), str(tmp_path / "morph"), **kw)
+    assert r2["pairs"] == [("ben.png", "cleo.png")] and tuple(r2["latents"].shape) == (2, TINY.k, TINY.z_dim)
+    assert torch.equal(r2["latents"], r["latents"][2:4])                                  # same seed, same targets: the same projections
+
+
+def test_cli_morph_pairs(tmp_path):
+    from morphganformer_amd import cli
+    from test_host_and_abi import _tiny_snapshot
+    pkl = str(tmp_path / "net.pkl")
+    _tiny_snapshot(pkl, seed=3)
+    assert cli.main(["generate", "--model", pkl, "--output-dir", str(tmp_path / "src"), "--images-num", "2", "--seed", "1"]) == 0
+    (tmp_path / "pairs.csv").write_text("img1,img2,simi\nsample_000000.png,sample_000001.png,0.9\n")
+    argv = ["morph-pairs", "--model", pkl, "--csv", str(tmp_path / "pairs.csv"), "--src", str(tmp_path / "src"), "--dst-raw", str(tmp_path / "raw"),
+            "--dst-morph", str(tmp_path / "morph"), "--size", "64", "--step", "6", "--n_mean_latent", "200", "--batch", "3", "--seed", "0"]
+    with pytest.raises(SystemExit, match="lpips-backbone"):
+        cli.main(argv)
+    assert cli.main(argv + ["--no-lpips"]) == 0
+    assert os.listdir(tmp_path / "morph") == ["sample_000000_sample_000001.png"]
+    assert sorted(os.listdir(tmp_path / "raw")) == ["sample_000000_sample_000001_A.png", "sample_000000_sample_000001_B.png"]
+    assert cli.main(argv + ["--no-lpips", "--mode", "gradient"]) == 0              # everything exists: nothing to do

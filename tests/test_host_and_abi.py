@@ -426,6 +426,8 @@ def test_cli_arguments_mirror_the_reference_scripts():
     assert p.mode == "literal" and ap.parse_args(["project", "--image", "x.png", "--mode", "gradient"]).mode == "gradient"
     m = ap.parse_args(["morph", "--model", "m.pkl", "--w1", "a.mat", "--w2", "b.mat", "--out", "o"])
     assert m.alphas == "0.5" and m.truncation_psi == 0.7
+    q = ap.parse_args(["morph-pairs", "--csv", "p.csv", "--src", "s", "--dst-raw", "r", "--dst-morph", "m"])
+    assert (q.threshold, q.step, q.truncation_psi, q.model, q.dynamic) == (0.5, 5000, 0.7, "models/ffhq-snapshot-1024_v2.pkl", False)
     w = ap.parse_args(["warp", "--model", "m.pkl", "--w1", "a.mat", "--w2", "b.mat", "--landmarks", "lm.npz", "--out", "o"])
     assert w.truncation_psi == 0.7 and w.gpus == "0"                 # 1024_warp_morphs.py:127 (`truncation_psi = 0.7`)
 
