@@ -57,6 +57,15 @@ def _loop_arguments(p):
                    help="literal = the loop as the reference executes it (best-of-N noisy sampling); gradient = back-propagate the loss "
                         "into the latent and let Adam move it")
     p.add_argument("--seed", type=int, default=None)
+    p.add_argument("--biometric", type=str, default="none", choices=["none", "facenet", "iresnet18", "iresnet34", "iresnet50", "iresnet100"],
+                   help="add gamma * MSE(embed(img), embed(target)): facenet = InceptionResnetV1 on the un-resized image, the term "
+                        "1024_example_FaceNet_percept.py:147-158 scores with (alone: --no-lpips --no-mse); iresnetNN = the vendored ArcFace network")
+    p.add_argument("--gamma", type=float, default=1.0, help="coefficient of the biometric term")
+    p.add_argument("--biometric-weights", type=str, default=None, metavar="STATE_DICT",
+                   help="the embedder's state dict (.pth / .npz; facenet_pytorch's vggface2 weights, an insightface iresnet checkpoint) -- what the "
+                        "reference fetches by name; required with --biometric unless --biometric-random")
+    p.add_argument("--biometric-random", action="store_true", help="seeded random embedder weights (smoke runs only)")
+    p.add_argument("--no-mse", action="store_true", help="drop the MSE term (beta * MSE)")
 
 
 def build_parser():
@@ -165,6 +174,23 @@ def main(argv=None):
             print("WARNING: LPIPS runs on seeded random backbone weights (--lpips-random-backbone); the term is not a perceptual distance")
         percept = PerceptualLoss(model="net-lin", net=a.net, use_gpu=True, device=G.device, backbone_state=state,
                                  allow_random_backbone=state is None)
+    biometric = None
+    if a.biometric != "none":
+        if a.biometric_weights is None and not a.biometric_random:
+            raise SystemExit(f"{a.cmd}: --biometric {a.biometric} needs the embedder's weights: --biometric-weights <state dict> (or --biometric-random)")
+        from .iresnet import BiometricLoss
+        state = None
+        if a.biometric_weights:
+            if a.biometric_weights.endswith(".npz"):
+                state = dict(np.load(a.biometric_weights))
+            else:
+                state = torch.load(a.biometric_weights, map_location="cpu", weights_only=True)
+                state = state.get("state_dict", state)
+        else:
+            print(f"WARNING: the biometric term runs on seeded random {a.biometric} weights (--biometric-random); it is not a face embedding")
+        biometric = BiometricLoss(a.biometric, state=state, n=a.batch if a.mode == "literal" else 1, device=G.device)
+    if percept is None and a.no_mse and biometric is None and not getattr(a, "landmarks", None):
+        raise SystemExit(f"{a.cmd}: every term of the objective is switched off")
     space = "w+" if (a.w_plus and a.mode == "gradient") else "z"
     if a.cmd == "morph-pairs":
         # one process per GPU under `python -m torch.distributed.run --nproc-per-node N -m morphganformer_amd.cli morph-pairs ...`: the
@@ -173,7 +199,8 @@ def main(argv=None):
         if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
-        kw = dict(args=args, percept=percept, batch=a.batch, seed=a.seed, mode=a.mode, latent_space=space, keep_images=a.keep_images)
+        kw = dict(args=args, percept=percept, batch=a.batch, seed=a.seed, mode=a.mode, latent_space=space, keep_images=a.keep_images,
+                  biometric=biometric, gamma=a.gamma, use_mse=not a.no_mse)
         if a.mode == "literal":
             kw["dynamic"] = a.dynamic
         res = drivers.morph_pairs(G, drivers.read_pair_csv(a.csv, a.threshold), a.src, a.dst_raw, a.dst_morph,
@@ -194,7 +221,7 @@ def main(argv=None):
     stem = os.path.splitext(os.path.basename(a.image))[0]
     res = drivers.project_image(G, target, lm_t, lm_s, args=args, percept=percept, batch=a.batch, seed=a.seed,
                                 out_prefix=os.path.join(a.path_to_gen, stem), mode=a.mode, path_to_gen=a.path_to_gen,
-                                keep_images=a.keep_images, latent_space=space)
+                                keep_images=a.keep_images, latent_space=space, biometric=biometric, gamma=a.gamma, use_mse=not a.no_mse)
     print(f"best step {res['step']}  loss {res['loss']:.6f}")
     return 0
 

@@ -704,3 +704,12 @@ def test_cli_morph_pairs(tmp_path):
     assert os.listdir(tmp_path / "morph") == ["sample_000000_sample_000001.png"]
     assert sorted(os.listdir(tmp_path / "raw")) == ["sample_000000_sample_000001_A.png", "sample_000000_sample_000001_B.png"]
     assert cli.main(argv + ["--no-lpips", "--mode", "gradient"]) == 0              # everything exists: nothing to do
+    # the biometric term from the command line (1024_example_FaceNet_percept.py's objective is this term alone: --no-lpips --no-mse)
+    proj = ["project", "--model", pkl, "--image", str(tmp_path / "src" / "sample_000000.png"), "--path_to_gen", str(tmp_path / "b"), "--size", "64",
+            "--step", "4", "--n_mean_latent", "200", "--batch", "2", "--seed", "0", "--no-lpips"]
+    with pytest.raises(SystemExit, match="biometric-weights"):
+        cli.main(proj + ["--biometric", "iresnet18"])
+    assert cli.main(proj + ["--biometric", "iresnet18", "--biometric-random", "--gamma", "1e-12"]) == 0
+    assert cli.main(proj + ["--biometric", "iresnet18", "--biometric-random", "--gamma", "1e-12", "--no-mse", "--path_to_gen", str(tmp_path / "b2")]) == 0
+    with pytest.raises(SystemExit, match="switched off"):
+        cli.main(proj + ["--no-mse"])
