@@ -410,6 +410,11 @@ def test_driver_host_helpers(tmp_path):
     sio.savemat(str(tmp_path / "bad.mat"), {"w": np.zeros(4, np.float32)})
     with pytest.raises(ValueError):
         drivers.load_latent_mat(str(tmp_path / "bad.mat"))
+    # the pair list of projection_example_v2_percept_morph.py:337-343: header and rows below the similarity threshold are skipped
+    (tmp_path / "p.csv").write_text("img1,img2,simi\na.png,b.png,0.5\na.png,c.png,0.49\nc.png,b.png,0.93\n")
+    assert drivers.read_pair_csv(str(tmp_path / "p.csv")) == [("a.png", "b.png"), ("c.png", "b.png")]
+    assert drivers.read_pair_csv(str(tmp_path / "p.csv"), threshold=0.9) == [("c.png", "b.png")]
+    assert drivers.frame_points(1024) == drivers.WARP_EXTRA_POINTS and drivers.frame_points(64)[3] == [0, 63]
 
 
 def test_cli_arguments_mirror_the_reference_scripts():
