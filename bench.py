@@ -616,7 +616,8 @@ def launch_selftest(a):
     line shaped like the real one.  MGF_SELFTEST_FAIL_RANK makes that rank exit non-zero (the parent must notice)."""
     import torch as th
     import torch.distributed as dist
-    dist.init_process_group("gloo")
+    from morphganformer_amd.distributed import init_process_group
+    init_process_group("gloo")                            # (keeps the store for the work queue: no private torch API)
     rank, world = dist.get_rank(), dist.get_world_size()
     if os.environ.get("MGF_SELFTEST_FAIL_RANK") == str(rank):
         sys.exit(3)
@@ -690,7 +691,8 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            from morphganformer_amd.distributed import init_process_group
+            init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             # one RCCL collective before anything is timed: every rank contributes its rank id; the count that comes back is what the line reports
             ids = torch.empty(world, dtype=torch.int64, device=device)
             dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=device))

@@ -128,6 +128,9 @@ def build_parser():
 def main(argv=None):
     a = build_parser().parse_args(argv)
     launched = int(os.environ.get("WORLD_SIZE", "1")) > 1 and "LOCAL_RANK" in os.environ
+    # read by the HSA runtime when it starts, i.e. at the first GPU call (loader.load_network below): set here, before torch is imported,
+    # like bench.py does -- the host driver only supports dmabuf IPC, RCCL fails without it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not launched:
         os.environ.setdefault("CUDA_VISIBLE_DEVICES", a.gpus)
     import numpy as np
@@ -197,8 +200,8 @@ def main(argv=None):
         # 2 x pairs projections are sharded over the ranks, one all_gather returns the latents, the renderings are dealt pairs[rank::world]
         import torch.distributed as dist
         if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+            from .distributed import init_process_group
+            init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
         kw = dict(args=args, percept=percept, batch=a.batch, seed=a.seed, mode=a.mode, latent_space=space, keep_images=a.keep_images,
                   biometric=biometric, gamma=a.gamma, use_mse=not a.no_mse)
         if a.mode == "literal":

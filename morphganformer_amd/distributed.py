@@ -10,7 +10,50 @@ single all_gather over RCCL/xGMI (backend "nccl" on ROCm) or gloo in CPU tests.
 """
 from __future__ import annotations
 
+import os
+
 import torch
+
+_STORE = None          # the key-value store the work queues count in: handed in by whoever created the process group (set_store / init_process_group)
+
+
+def make_store(rank: int = None, world_size: int = None, host: str = None, port: int = None, timeout_s: float = 1800.0):
+    """A `torch.distributed.TCPStore` on the job's rendezvous address (MASTER_ADDR / MASTER_PORT, or host / port): rank 0 serves it, the
+    others connect -- or, under `torch.distributed.run`, whose agent already serves a store on that port (TORCHELASTIC_USE_AGENT_STORE),
+    every rank connects to the agent's.  This is the store `init_process_group` below hands to torch AND keeps for the work queues."""
+    import datetime
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"]) if rank is None else int(rank)
+    world_size = int(os.environ["WORLD_SIZE"]) if world_size is None else int(world_size)
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1") if host is None else host
+    port = int(os.environ["MASTER_PORT"]) if port is None else int(port)
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    return dist.TCPStore(host, port, world_size, is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=timeout_s))
+
+
+def set_store(store):
+    """Hand the module the store shared by all ranks of the job (any torch.distributed.Store: the one passed to
+    `torch.distributed.init_process_group(store=...)`, a TCPStore / FileStore of the caller's own)."""
+    global _STORE
+    _STORE = store
+    return store
+
+
+def get_store():
+    return _STORE
+
+
+def init_process_group(backend: str, rank: int = None, world_size: int = None, host: str = None, port: int = None, store=None, **kw):
+    """`torch.distributed.init_process_group(backend, store=..., rank=..., world_size=...)` on a store this module keeps a handle to
+    (`make_store` unless one is passed in), so that `WorkQueue` never has to reach into torch's private state for it.  The drivers' entry
+    points (bench.py, cli.py) create their process group through this call; a caller with a group of its own uses `set_store`."""
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"]) if rank is None else int(rank)
+    world_size = int(os.environ["WORLD_SIZE"]) if world_size is None else int(world_size)
+    if store is None:
+        store = make_store(rank, world_size, host, port)
+    dist.init_process_group(backend, store=store, rank=rank, world_size=world_size, **kw)
+    return set_store(store)
 
 
 def shard_items(n_items: int, rank: int, world: int):
@@ -29,10 +72,11 @@ class WorkQueue:
 
     _epochs: dict = {}
 
-    def __init__(self, n_items: int, name: str = "mgf_queue", group=None):
+    def __init__(self, n_items: int, name: str = "mgf_queue", group=None, store=None):
         """group: the process group whose ranks share this queue (default: all ranks).  The counter lives in the job's rendezvous
         store whatever the group; a sub-group's key carries its global ranks, so disjoint sub-groups draw from separate counters and
-        the queue's population is exactly the group `run_sharded` gathers over."""
+        the queue's population is exactly the group `run_sharded` gathers over.
+        store: the key-value store shared by the ranks (default: the one this module was handed, `set_store` / `init_process_group`)."""
         import torch.distributed as dist
         on = dist.is_available() and dist.is_initialized()
         if on and group is not None:
@@ -43,7 +87,11 @@ class WorkQueue:
         self.store = None
         self._local = 0
         if on and dist.get_world_size(group) > 1:
-            self.store = dist.distributed_c10d._get_default_store()
+            self.store = store if store is not None else _STORE
+            if self.store is None:
+                raise RuntimeError("WorkQueue: more than one rank but no shared store: create the process group with "
+                                   "morphganformer_amd.distributed.init_process_group(...), or hand the store over with set_store(store) / "
+                                   "WorkQueue(..., store=store)")
 
     def __iter__(self):
         return self
@@ -105,7 +153,7 @@ def gather_many(records: torch.Tensor, counts_max: int, group=None):
     return out[torch.argsort(out[:, -1])]
 
 
-def run_sharded(n_items: int, work_fn, record_width: int, device, dynamic: bool = False, queue_name: str = "mgf_queue", group=None):
+def run_sharded(n_items: int, work_fn, record_width: int, device, dynamic: bool = False, queue_name: str = "mgf_queue", group=None, store=None):
     """The multi-GPU skeleton of `drivers.project_many`, free of any GPU work so that it runs under gloo on CPU: this rank takes its
     items -- `items[rank::world]`, or with dynamic=True whatever the shared WorkQueue hands it (ragged per-item cost: targets whose
     steps are skipped when no face is found) -- calls `work_fn(item) -> record [record_width] float64` (pack_result) for each, and ONE
@@ -114,7 +162,7 @@ def run_sharded(n_items: int, work_fn, record_width: int, device, dynamic: bool 
     import torch.distributed as dist
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
-    order = WorkQueue(n_items, name=queue_name, group=group) if dynamic else shard_items(n_items, rank, world)
+    order = WorkQueue(n_items, name=queue_name, group=group, store=store) if dynamic else shard_items(n_items, rank, world)
     recs, mine = [], []
     for i in order:
         recs.append(work_fn(i))

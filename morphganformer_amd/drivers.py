@@ -98,8 +98,8 @@ def save_latent_mat(path, w):
 def load_latent_mat(path):
     import scipy.io as sio
     w = np.asarray(sio.loadmat(path)["w"], dtype=np.float32)
-    if w.ndim != 3:
-        raise ValueError(f"{path}: 'w' has shape {w.shape}, expected [1,k,D]")
+    if w.ndim not in (3, 4):
+        raise ValueError(f"{path}: 'w' has shape {w.shape}, expected [1,k,D] (or a W+ latent [1,k,num_ws,D])")
     return w
 
 
@@ -120,19 +120,33 @@ def generate_images(G, images_num=32, truncation_psi=0.7, output_dir=None, ratio
     return zs
 
 
-def merge_morph(G, w1, w2, alphas=(0.5,), truncation_psi=0.7, noise_mode="random", out_prefix=None, ratio=1.0):
+def render_latent(G, w, truncation_psi=0.7, noise_mode="random"):
+    """The image of a projected latent as the morph drivers render it: `G(w, truncation_psi)` for a z latent [n,k,D] (the 0.7 lands in `c`,
+    SURVEY 0.2) and `G(ws=w)` for a W+ latent [n,k,num_ws,D] (gradient mode, latent_space="w+": every layer reads its own slot;
+    truncation acts in the mapping network only, networks.py:935-941, so there is none to apply).  -> [n,3,R,R], the caller's own tensor."""
+    w = (w if isinstance(w, torch.Tensor) else torch.from_numpy(np.asarray(w, dtype=np.float32))).to(G.device)
+    if w.ndim == 4:
+        return G(ws=w, noise_mode=noise_mode)[0]
+    return G(w, truncation_psi, noise_mode=noise_mode)[0]
+
+
+def merge_morph(G, w1, w2, alphas=(0.5,), truncation_psi=0.7, noise_mode="random", out_prefix=None, ratio=1.0, batched=False):
     """Linear latent morphs `dw = (1-a) w1 + a w2` rendered with G(dw, psi) (1024_merge_morph_2.py:83-92).
-    w1/w2: numpy or tensors [1,k,D] (what the `.mat` files hold).  Returns (latents [A,1,k,D] numpy, images [A,3,H,W] device).
-    The blend is done in numpy float32 exactly like the reference (`0.5 * w1 + 0.5 * w2` on loadmat arrays)."""
+    w1/w2: numpy or tensors [1,k,D] (what the `.mat` files hold), or two W+ results [1,k,num_ws,D] -- blended slot by slot and rendered
+    through `G(ws=...)` (render_latent).  Returns (latents [A,1,k,D] numpy, images [A,3,H,W] device).
+    The blend is done in numpy float32 exactly like the reference (`0.5 * w1 + 0.5 * w2` on loadmat arrays).
+    batched=True renders the whole sweep with ONE generator forward of len(alphas) images (BASELINE config 4's 11-alpha sweep as one
+    batch-11 forward) instead of one forward per alpha like the script; the images agree to float32 rounding (other kernel shapes)."""
     a1 = np.asarray(w1.detach().cpu() if isinstance(w1, torch.Tensor) else w1, dtype=np.float32)
     a2 = np.asarray(w2.detach().cpu() if isinstance(w2, torch.Tensor) else w2, dtype=np.float32)
+    if a1.shape != a2.shape:
+        raise ValueError(f"merge_morph: the two latents differ in shape: {a1.shape} vs {a2.shape}")
+    blend = lambda a: (0.5 * a1 + 0.5 * a2) if a == 0.5 else (np.float32(1.0 - a) * a1 + np.float32(a) * a2)
     lat, imgs = [], []
-    for a in alphas:
-        if a == 0.5:
-            dw = 0.5 * a1 + 0.5 * a2
-        else:
-            dw = np.float32(1.0 - a) * a1 + np.float32(a) * a2
-        img = G(torch.from_numpy(dw).to(G.device), truncation_psi, noise_mode=noise_mode)[0]
+    sweep = render_latent(G, np.concatenate([blend(a) for a in alphas]), truncation_psi, noise_mode) if batched and len(alphas) > 1 else None
+    for j, a in enumerate(alphas):
+        dw = blend(a)
+        img = sweep[j:j + 1] if sweep is not None else render_latent(G, dw, truncation_psi, noise_mode)
         if out_prefix is not None:
             tag = f"{out_prefix}_a{a:.2f}"
             save_image(G, img, tag + ".jpg", ratio)
@@ -339,25 +353,32 @@ def morph_pairs(G, pairs, src_dir, dst_raw, dst_morph, landmarks=None, truncatio
     process group (static or, with dynamic=True, through the work queue) and gathers every latent to every rank; the renderings are then
     dealt `pairs[rank::world]`.  pairs: [(img1, img2)] file names under src_dir (read_pair_csv); landmarks: optional {file name: (lm_target,
     lm_steps)}; project_kw: project_image's arguments (args, percept, biometric, gamma, batch, seed, mode, dynamic, ...).
-    Returns dict(pairs (the ones worked on), latents [2P,k,D], losses, steps, written (this rank's morph paths))."""
+    Returns dict(pairs (the ones worked on), latents [2P,k,D] (W+: [2P,k,num_ws,D]), losses, steps, written (this rank's morph paths))."""
     import torch.distributed as dist
     from .distributed import shard_items
     stem = lambda f: f.split(".")[0]                          # (`img1.split('.')[0]`, :347)
-    todo = [(a, b) for a, b in pairs if not os.path.exists(os.path.join(dst_morph, f"{stem(a)}_{stem(b)}.png"))]
+    on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+    # ONE rank looks at dst_morph and tells the others: the static shards and the size of the result gather are derived from this list, so
+    # every rank must hold the same one (node-local scratch or a lagging network file system would otherwise let them disagree -- and an
+    # empty list on some ranks only would let those skip the collective the others wait in)
+    todo = [(a, b) for a, b in pairs if not os.path.exists(os.path.join(dst_morph, f"{stem(a)}_{stem(b)}.png"))] if rank == 0 else None
+    if on and world > 1:
+        box = [todo]
+        dist.broadcast_object_list(box, src=0)
+        todo = [tuple(pr) for pr in box[0]]
     if not todo:
         return {"pairs": [], "latents": None, "losses": None, "steps": None, "written": []}
     files = [f for pr in todo for f in pr]
     lms = None if landmarks is None else [landmarks[f] for f in files]
     res = project_many(G, [os.path.join(src_dir, f) for f in files], landmarks=lms, **project_kw)
-    on = dist.is_available() and dist.is_initialized()
-    rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
     written = []
     for pi in shard_items(len(todo), rank, world):
         a, b = todo[pi]
         name = f"{stem(a)}_{stem(b)}"
         w1, w2 = res["latents"][2 * pi:2 * pi + 1], res["latents"][2 * pi + 1:2 * pi + 2]
-        for w, tag in ((w1, "_A"), (w2, "_B")):
-            save_image(G, G(w.to(G.device), truncation_psi, noise_mode=noise_mode)[0], os.path.join(dst_raw, name + tag + ".png"), ratio)
+        for w, tag in ((w1, "_A"), (w2, "_B")):                 # (a W+ result [1,k,num_ws,D] renders through G(ws=...): render_latent)
+            save_image(G, render_latent(G, w, truncation_psi, noise_mode), os.path.join(dst_raw, name + tag + ".png"), ratio)
         _, imgs = merge_morph(G, w1, w2, (0.5,), truncation_psi, noise_mode=noise_mode)
         save_image(G, imgs[0:1], os.path.join(dst_morph, name + ".png"), ratio)
         written.append(os.path.join(dst_morph, name + ".png"))

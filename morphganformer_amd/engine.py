@@ -474,6 +474,10 @@ class Generator:
         n = w.shape[0]
         if n != self.n:
             raise _lib.MgfError("synthesis: batch size changed; call through __call__ / mapping first")
+        if self.lean and (self.taps is not None or return_att):
+            # the lean flavour's layer outputs are views of shared arenas that later blocks overwrite: tensors that are handed out need their
+            # own storage (forward_workspace makes the same choice before it gets here; this is the direct-call path)
+            self._alloc(n, False)
         st = _lib.stream_ptr()
         D, T = cfg.w_dim, cfg.k - 1
         _lib.require_gpu(w)
@@ -586,9 +590,25 @@ class Generator:
         t = noises[lp.name]
         return t, t.shape[0]
 
+    def seed_noise(self, seed: int):
+        """Restart the per-layer noise stream of noise_mode="random" under an explicit key, independent of torch's global CUDA generator
+        (see _draw_noise for how torch.manual_seed governs it otherwise).  Captured launch sequences read the key at capture time and the
+        stream position from the device: seed before capture; replays then continue the device-side stream."""
+        self.noise_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.noise_state.zero_()
+        gen = torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()]
+        self._noise_epoch = (int(gen.initial_seed()), int(gen.get_offset()))       # "nothing happened since": the next draw keeps this key
+
     def _draw_noise(self, n):
         """Fresh N(0,1) maps per layer and call (networks.py:1016-1017): ONE mgf_randn_f32 launch fills a flat buffer that is
-        laid out layer-major ([layer][n][r*r]), so every layer sees a dense [n, r, r] view without copies."""
+        laid out layer-major ([layer][n][r*r]), so every layer sees a dense [n, r, r] view without copies.
+
+        Relation to torch's global CUDA generator, chosen to match what the reference's `torch.randn` calls do to it: a draw outside graph
+        capture advances the global offset (as torch.randn would: later torch draws shift, like after the reference's forward), and
+        `torch.manual_seed(s)` -- or any foreign draw -- in front of a call re-keys the stream, so `manual_seed(s); G(z)` is reproducible
+        call for call.  Replays of a captured graph cannot see the host generator: they continue the device-side stream of the key the
+        capture saw (an eager loop and a replayed loop of one engine therefore draw different, equally distributed noise).  `seed_noise`
+        gives the stream a key of its own."""
         sizes = [(lp.name, lp.res) for lp in self.plan.layers if lp.noise_strength is not None]
         total = sum(r * r for _, r in sizes)
         if self.noise_rand is None or self.noise_rand.numel() != n * total:

@@ -197,8 +197,8 @@ def _free_port():
 GLOO_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from morphganformer_amd.distributed import shard_items, pack_result, gather_results, gather_many, WorkQueue
-dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+from morphganformer_amd.distributed import shard_items, pack_result, gather_results, gather_many, WorkQueue, init_process_group
+init_process_group("gloo", rank=int(sys.argv[3]), world_size=2, host="127.0.0.1", port=int(sys.argv[2]))
 rank = dist.get_rank()
 mine = shard_items(5, rank, 2)
 assert mine == ([0, 2, 4] if rank == 0 else [1, 3])
@@ -247,9 +247,12 @@ def test_result_gather_gloo_world2(tmp_path):
 GLOO_WORKER_RAGGED = r"""
 import os, sys, time, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from morphganformer_amd.distributed import pack_result, run_sharded, unpack_results
+from morphganformer_amd.distributed import pack_result, run_sharded, unpack_results, make_store, set_store
 world = int(sys.argv[4])
-dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=world)
+# a caller with a process group of its own: it creates the store, gives it to torch and hands it to the module (set_store)
+store = make_store(int(sys.argv[3]), world, "127.0.0.1", int(sys.argv[2]))
+dist.init_process_group("gloo", store=store, rank=int(sys.argv[3]), world_size=world)
+set_store(store)
 rank = dist.get_rank()
 N, K, D = 11, 17, 32
 # ragged per-item cost, as when "no face found" skips most steps of some targets (...sqz_MSE.py:165-166): item i costs cost[i]
