@@ -27,6 +27,10 @@ enum { MGF_F32 = 0, MGF_F64 = 1, MGF_F16 = 2 };
  * upfirdn2d.setup_filter builds from a 1-D tap list is): lets the 4x4 blur take its separable kernel.  Without the hint the
  * general kernel runs; a wrong hint gives wrong results (the filter lives in device memory and is not inspected). */
 enum { MGF_FILTER_SEPARABLE = 2 };
+/* OR-ed into `flip` by the engine-internal caller (conv.upfirdn_into): tensors of more than INT32_MAX elements are accepted wherever the
+ * dispatcher picks one of the tiled / streaming kernels (64-bit plane addressing); without it the plug-in contract of the reference holds
+ * (upfirdn2d.cpp:14-15,28: numel <= INT_MAX) and such a call is refused with MGF_ETOOBIG. */
+enum { MGF_FILTER_LARGE = 4 };
 /* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:15-25) */
 enum { MGF_ACT_LINEAR = 1, MGF_ACT_RELU = 2, MGF_ACT_LRELU = 3, MGF_ACT_TANH = 4, MGF_ACT_SIGMOID = 5,
        MGF_ACT_ELU = 6, MGF_ACT_SELU = 7, MGF_ACT_SOFTPLUS = 8, MGF_ACT_SWISH = 9,

@@ -20,13 +20,7 @@ namespace {
 typedef float v2f __attribute__((ext_vector_type(2)));
 // The two 16-wide inner products of the register kernels in PACKED fp32 (v_pk_fma_f32: two lanes of math per issue slot; the scalar form
 // issued 16 v_fmac per channel and phase): scores  s[0..15] += x * row,  gain  g = <s, row>.  `row` = 16 floats of an LDS table.
-#ifndef MGF_ATTX
-#define MGF_ATTX 0          // timing ablations (tools/build_exp.sh; results wrong by construction): 1 no score FMAs, 2 no gain dot product,
-#endif                      // 4 both read ONE table row (LDS reads hoisted out of the channel loops)
 __device__ __forceinline__ void att_fma_row(v2f (&s2)[8], float xv, const float4* w4) {
-#if MGF_ATTX & 1
-    s2[0] += v2f{xv, xv}; return;
-#endif
     const v2f x2 = {xv, xv};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -37,9 +31,6 @@ __device__ __forceinline__ void att_fma_row(v2f (&s2)[8], float xv, const float4
     }
 }
 __device__ __forceinline__ float att_dot_row(const v2f (&s2)[8], const float4* w4) {
-#if MGF_ATTX & 2
-    return s2[0].x + w4[0].x;
-#endif
     v2f g2 = {0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -312,7 +303,7 @@ __global__ __launch_bounds__(256) void duplex_attention_reg_kernel(AttnParams p)
         const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
         const float xv = xreg[k];
         sq += xv * xv;
-        att_fma_row(s2, xv, reinterpret_cast<const float4*>(tab + ((MGF_ATTX & 4) ? 0 : c) * TMAX));
+        att_fma_row(s2, xv, reinterpret_cast<const float4*>(tab + c * TMAX));
     }
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) part[(grp * (TMAX + 1) + t) * PXB + px] = (t & 1) ? s2[t >> 1].y : s2[t >> 1].x;
@@ -365,7 +356,7 @@ __global__ __launch_bounds__(256) void duplex_attention_reg_kernel(AttnParams p)
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
-        const float g = att_dot_row(s2, reinterpret_cast<const float4*>(tab + ((MGF_ATTX & 4) ? 0 : c) * TMAX));
+        const float g = att_dot_row(s2, reinterpret_cast<const float4*>(tab + c * TMAX));
         float v = xreg[k] * g;
         if (p.has_ep) {
             v += nz;
@@ -453,7 +444,7 @@ __global__ __launch_bounds__(256) void duplex_attention_blocks_kernel(AttnParams
             const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
             const float xv = xk[k];
             sq += xv * xv;
-            att_fma_row(s2, xv, reinterpret_cast<const float4*>(tab + ((MGF_ATTX & 4) ? 0 : c) * TMAX));
+            att_fma_row(s2, xv, reinterpret_cast<const float4*>(tab + c * TMAX));
         }
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) part[(grp * (TMAX + 1) + t) * PXB + px] = (t & 1) ? s2[t >> 1].y : s2[t >> 1].x;
@@ -505,7 +496,7 @@ __global__ __launch_bounds__(256) void duplex_attention_blocks_kernel(AttnParams
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c = (k / UNR) * G * UNR + grp * UNR + (k % UNR);
-            const float g = att_dot_row(s2, reinterpret_cast<const float4*>(tabv + ((MGF_ATTX & 4) ? 0 : c) * TMAX));
+            const float g = att_dot_row(s2, reinterpret_cast<const float4*>(tabv + c * TMAX));
             float v = xk[k] * g;
             if (p.has_ep) {
                 v += nzk;
@@ -692,7 +683,7 @@ void launch_attention(const AttnParams& p, size_t lds, hipStream_t st) {
     if (p.t == TMAX && (nch == 16 || nch == 32 || nch == 64) && (nch * G) % 64 == 0) {
         const size_t lds_r = ((size_t)p.c * TMAX + (size_t)(G + 1) * (TMAX + 1) * PXB) * sizeof(float);
         // large maps with few channels (the 128x128 x 256 layers): 4 pixel blocks per workgroup, both tables resident
-        static const char* nb_env = getenv("MGF_ATTN_NBLK");      // tuning hook (experiments only): 1 = one block per workgroup
+        static const char* nb_env = mgf_knob("MGF_ATTN_NBLK");      // tuning hook (experiments only): 1 = one block per workgroup
         constexpr int NBLK = 4;
         if (PXB == 16 && nch == 16 && p.f >= 4096 && p.f % (PXB * NBLK) == 0 && !(nb_env && nb_env[0] == '1')) {
             const size_t lds_2 = ((size_t)2 * p.c * TMAX + (size_t)(G + 1) * (TMAX + 1) * PXB) * sizeof(float);
@@ -728,7 +719,7 @@ extern "C" int mgf_duplex_attention(float* y, const float* x, const float* wqc, 
     MGF_REQUIRE(((uintptr_t)wqc % 16 == 0) && ((uintptr_t)vwb % 16 == 0), MGF_EINVAL, "duplex_attention: tables must be 16-byte aligned");
     // the generator's layers (256 / 512 channels, 16 latents, whole 32-pixel tiles): the MFMA form.  MGF_ATTN_MFMA=0 keeps the register
     // kernels (tuning hook, tests).
-    static const char* mf_env = getenv("MGF_ATTN_MFMA");
+    static const char* mf_env = mgf_knob("MGF_ATTN_MFMA");
     if (t == TMAX && (c == 256 || c == 512) && f % 32 == 0 && !(mf_env && mf_env[0] == '0')) {
         hipStream_t st0 = (hipStream_t)stream;
         if (c == 256) hipLaunchKernelGGL((duplex_attention_mfma_kernel<4>), dim3((unsigned)(f / 32), n), dim3(256), 0, st0, p);
@@ -736,7 +727,7 @@ extern "C" int mgf_duplex_attention(float* y, const float* x, const float* wqc, 
         MGF_CHECK_LAUNCH("duplex_attention");
         return MGF_OK;
     }
-    static const char* pxb_env = getenv("MGF_ATTN_PXB");      // tuning hook (experiments only)
+    static const char* pxb_env = mgf_knob("MGF_ATTN_PXB");      // tuning hook (experiments only)
     const int pxb = pxb_env ? atoi(pxb_env) : (f > 16384 ? 64 : 16);
     const int g = 256 / pxb;
     p.c_pad = (int)(mgf_cdiv(c, UNR * g) * UNR * g);

@@ -1264,7 +1264,7 @@ extern "C" int mgf_duplex_attention_bwd(float* dx, float* dg, float* probs, cons
     constexpr int PXB = 16, G = 256 / PXB;
     AttnBwdParams p{dx, dg, probs, da, x, wqc, spos, vwb, n, c, f, t, (int)(mgf_cdiv(c, 4) * 4)};
     // the generator's layers: the MFMA form (MGF_ATTN_BWD_MFMA=0 keeps the register kernel: tuning hook, tests)
-    static const char* mf_env = getenv("MGF_ATTN_BWD_MFMA");
+    static const char* mf_env = mgf_knob("MGF_ATTN_BWD_MFMA");
     if (t == TMAX && (c == 256 || c == 512) && f % 32 == 0 && !(mf_env && mf_env[0] == '0')) {
         if (c == 256) hipLaunchKernelGGL((duplex_attention_bwd_mfma_kernel<4>), dim3((unsigned)(f / 32), n), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((duplex_attention_bwd_mfma_kernel<8>), dim3((unsigned)(f / 32), n), dim3(512), 0, (hipStream_t)stream, p);
@@ -1331,7 +1331,7 @@ extern "C" int mgf_attn_values_grad_ws(float* dvwb, const float* dg, const float
     const int slices = attn_grad_slices(n, c, f, t);
     const int cblocks = (int)mgf_cdiv(c, 32);
     const bool ok = slices > 0 && workspace && workspace_floats >= (int64_t)n * slices * c * TMAX && ((uintptr_t)workspace % 16) == 0;
-    static const char* mf_env = getenv("MGF_ATTN_GRAD_MFMA");     // tuning hook (experiments, tests): 0 = the VALU kernel
+    static const char* mf_env = mgf_knob("MGF_ATTN_GRAD_MFMA");     // tuning hook (experiments, tests): 0 = the VALU kernel
     if (!ok || (mf_env && mf_env[0] == '0')) return mgf_attn_values_grad(dvwb, dg, probs, n, c, f, t, stream);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_values_grad_mfma_kernel, dim3(slices, (unsigned)mgf_cdiv(cblocks, 4), n), dim3(256), 0, st, workspace, dg, probs, c, f, slices);
@@ -1391,10 +1391,10 @@ extern "C" int mgf_latent_grad_gather(float* dw, const float* dwg, int32_t n_sty
 template <bool RELU>
 static void lpips_bwd_launch(float* oa, float* ob, const float* din, const float* f0, const float* f1u, const float* lin, int n, int c,
                              int c_split, int64_t hw, int64_t f1_bs, float k, int accumulate, hipStream_t st, const float* stats = nullptr) {
-    static const int env_pxb = [] { const char* e = getenv("MGF_LPIPS_BWD_PXB"); return e ? atoi(e) : 0; }();
+    static const int env_pxb = [] { const char* e = mgf_knob("MGF_LPIPS_BWD_PXB"); return e ? atoi(e) : 0; }();
     int pxb = mgf_cdiv(hw, 64) * n >= 512 ? 64 : mgf_cdiv(hw, 32) * n >= 256 ? 32 : 16;
     if (env_pxb == 16 || env_pxb == 32 || env_pxb == 64) pxb = env_pxb;
-    static const bool no_cache = [] { const char* e = getenv("MGF_LPIPS_BWD_CACHE"); return e && e[0] == '0'; }();
+    static const bool no_cache = [] { const char* e = mgf_knob("MGF_LPIPS_BWD_CACHE"); return e && e[0] == '0'; }();
     const dim3 grid((unsigned)mgf_cdiv(hw, pxb), n);
 #define MGF_LPB_LAUNCH(PX, CP) hipLaunchKernelGGL((lpips_layer_bwd_kernel<PX, RELU, CP>), grid, dim3(256), 0, st, oa, ob, din, f0, f1u, lin, c, c_split, hw, f1_bs, k, accumulate, stats)
     if (pxb == 64) {

@@ -223,13 +223,8 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     // The style modulation s[ci] is applied to the weight rows (the reference's w * s, networks.py:289) at store time.
     auto load_chunk = [&](int c0) {
         const int xso = (int)(4u * (unsigned)(c0 * plane)), wso = (int)(4u * (unsigned)(c0 * d.cout_pad)), sso = c0 * sc_step;
-#if defined(MGF_EXP) && (MGF_EXP == 4 || MGF_EXP == 6)      // experiment: no activation traffic (a zero-record descriptor: same instructions, no bytes)
-        const __amdgpu_buffer_rsrc_t rx_e = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
-#else
-        const __amdgpu_buffer_rsrc_t rx_e = rx_l;
-#endif
 #pragma unroll
-        for (int j = 0; j < XS; ++j) xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_e, xoff[j], xso, 0));
+        for (int j = 0; j < XS; ++j) xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_l, xoff[j], xso, 0));
 #pragma unroll
         for (int j = 0; j < WS; ++j) {
             wr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw_l, 4u * (unsigned)woff[j], wso, 0));
@@ -316,16 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                     for (int m = 0; m < WM; ++m)
 #pragma unroll
                         for (int g = 0; g < WN; ++g)
-#if defined(MGF_EXP) && MGF_EXP == 1      // experiment: no matrix work (operands kept live), measures everything else
-                            asm volatile("" ::"v"(fa[t & 1][kk][m]), "v"(fb[t & 1][kk][g]));
-#elif defined(MGF_EXP) && MGF_EXP == 2    // experiment: twice the matrix work
-                        {
                             acc[q][m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][kk][m], fb[t & 1][kk][g], acc[q][m][g], 0, 0, 0);
-                            acc[q][m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][kk][m], fb[t & 1][kk][g], acc[q][m][g], 0, 0, 0);
-                        }
-#else
-                            acc[q][m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][kk][m], fb[t & 1][kk][g], acc[q][m][g], 0, 0, 0);
-#endif
             }
         } else {
             for (int t = 0; t < T; ++t) {                         // generic tap count (e.g. 2x2, 1x3): not pipelined
@@ -460,11 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                                     else if (p.ep.act == MGF_ACT_RELU) v = v > 0.f ? v : 0.f;
                                     v = v * p.ep.gain + rv[r8];
                                 }
-#if defined(MGF_EXP) && (MGF_EXP == 5 || MGF_EXP == 6)      // experiment: no output stores (one lane keeps the value alive)
-                                if (v == 12345.678f) ybase[og + cu * plane32] = v;
-#else
                                 ybase[og + cu * plane32] = v;
-#endif
                             }
                         } else {
                             // parity sets: q = 2*a + b -> row 2*ty + a, cols 2*tx + {0,1} written as an aligned pair
@@ -476,11 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
                                 for (int a2 = 0; a2 < 2; ++a2) {
                                     const float v0 = acc[NG == 4 ? 2 * a2 : 0][m][g][hh * 8 + r8] * osv[r8];
                                     const float v1 = acc[NG == 4 ? 2 * a2 + 1 : 0][m][g][hh * 8 + r8] * osv[r8];
-#if defined(MGF_EXP) && (MGF_EXP == 5 || MGF_EXP == 6)      // experiment: no output stores (one lane keeps the values alive)
-                                    if (v0 == 12345.678f) *reinterpret_cast<float2*>(ybase + (og + cu * plane32 + a2 * pitch32)) = make_float2(v0, v1);
-#else
                                     *reinterpret_cast<float2*>(ybase + (og + cu * plane32 + a2 * pitch32)) = make_float2(v0, v1);
-#endif
                                 }
                             }
                         }
@@ -594,54 +572,30 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         TileCtx cur;
         decode(wbase + slot, cur);
         int b = 0;
-#if defined(MGF_EXP) && MGF_EXP == 3      // experiment: per-phase shader-clock totals of every workgroup -> workspace
-        unsigned long long tPro = 0, tLoop = 0, tEpi = 0, tMfma = 0, tiles_done = 0;
-#define MGF_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#else
-#define MGF_STAMP(var)
-#endif
         for (;;) {
             // first chunk of this tile: global -> registers -> LDS (latency covered by the co-resident workgroup and by the
             // previous tile's stores, which are still draining)
-            MGF_STAMP(s0);
             setup_slots(cur);
             load_chunk(cur.c_begin);
             store_chunk(lds + b * buf_floats);
             __syncthreads();
-            MGF_STAMP(s1);
             const int nch = (cur.c_end - cur.c_begin) / CK;
             for (int c = 0; c < nch; ++c) {
                 float* curb = lds + b * buf_floats;
                 float* nxtb = lds + (b ^ 1) * buf_floats;
                 const bool more = c + 1 < nch;
                 if (more) load_chunk(cur.c_begin + (c + 1) * CK);             // in flight behind the MFMAs below
-                MGF_STAMP(m0);
                 mfma_chunk(curb);
-                MGF_STAMP(m1);
-#if defined(MGF_EXP) && MGF_EXP == 3
-                tMfma += m1 - m0;
-#endif
                 if (more) store_chunk(nxtb);
                 __syncthreads();
                 b ^= 1;
             }
-            MGF_STAMP(s2);
             epilogue(cur);                                                     // stores drain behind the next tile's work
             zero_acc();
-            MGF_STAMP(s3);
-#if defined(MGF_EXP) && MGF_EXP == 3
-            tPro += s1 - s0; tLoop += s2 - s1; tEpi += s3 - s2; ++tiles_done;
-#endif
             slot += slot_step;
             if (slot >= slot_end) break;
             decode(wbase + slot, cur);
         }
-#if defined(MGF_EXP) && MGF_EXP == 3
-        if (tid == 0 && d.workspace) {
-            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(d.workspace) + (size_t)blockIdx.x * 8;
-            dbg[0] = tPro; dbg[1] = tLoop; dbg[2] = tEpi; dbg[3] = tMfma; dbg[4] = tiles_done;
-        }
-#endif
     } else {
         const int w = p.xcd_per > 0 ? (int)(blockIdx.x & 7) * p.xcd_per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
         if (w >= total_items || (p.xcd_per > 0 && (int)(blockIdx.x >> 3) >= p.xcd_per)) return;
@@ -737,11 +691,11 @@ int launch_conv(const ConvParams& p_in, hipStream_t st) {
     if (lds > 160 * 1024) { mgf_set_error("conv_taps: tile needs %zu bytes of LDS (> 160 KiB)", lds); return MGF_EUNSUPPORTED; }
     const int64_t items = (int64_t)p.tiles_x * p.tiles_y * p.co_tiles * p.d.n * p.ksplit;
     // persistent kernels: as many workgroups as the chip holds at once (2 per CU; 3 for the small-register variant)
-    static const char* res_env = getenv("MGF_RESIDENT");      // tuning hook (experiments only): workgroups per CU
+    static const char* res_env = mgf_knob("MGF_RESIDENT");      // tuning hook (experiments only): workgroups per CU
     const int64_t resident = (int64_t)MGF_NUM_CU * (res_env ? atoi(res_env) : ((WM == 1 && WN == 2 && MODE == 0) ? 3 : 2));
     dim3 grid((unsigned)(pipe && (p.d.ntaps == 9 || ((p.d.ntaps == 1 || p.d.ntaps == 7 || p.d.ntaps == 3) && MODE == 0)) ? (items < resident ? items : resident) : items));
     // XCD-aware order needs a grid that is a multiple of the 8 XCDs (a grid of ceil(items/8)*8 workgroups otherwise)
-    static const char* xcd_env = getenv("MGF_XCD");            // tuning hook (experiments only): 0 disables the XCD-aware order
+    static const char* xcd_env = mgf_knob("MGF_XCD");            // tuning hook (experiments only): 0 disables the XCD-aware order
     p.xcd_per = 0;
     if (!(xcd_env && xcd_env[0] == '0') && items >= 16) {
         p.xcd_per = (int)((items + 7) / 8);
@@ -1030,7 +984,7 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     int wm = 1, wn = 2;
     // maps of at most 128 positions (4x4, 8x8 and the 5x5 / 9x9 parity grids of the first transposed convs): 128-lane pixel tiles,
     // half the padded MFMA work of the 256-lane ones
-    static const char* small_env = getenv("MGF_SMALL_TILES");    // tuning hook (experiments only): 0 = always 256-lane tiles
+    static const char* small_env = mgf_knob("MGF_SMALL_TILES");    // tuning hook (experiments only): 0 = always 256-lane tiles
     const bool small = (int64_t)d.tile_h * d.tile_w <= 128 && !(small_env && small_env[0] == '0');
     if (mode == 1 && small) wn = 1;
     if (mode == 0) {
@@ -1042,10 +996,10 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
         // four times that of a stride-1 tile and does not fit the pipeline's register slots, so these launches stage synchronously --
         // with 128-lane tiles (4 x 32 outputs, 9 x 65 footprint: 37 KB of LDS, four workgroups per CU instead of two) the workgroups
         // cover each other's staging phases
-        static const char* s2_env = getenv("MGF_S2_SMALL");          // tuning hook (experiments only): 0 keeps the 256-lane tile
+        static const char* s2_env = mgf_knob("MGF_S2_SMALL");          // tuning hook (experiments only): 0 keeps the 256-lane tile
         if (d.istride == 2 && !(s2_env && s2_env[0] == '0')) wn = 1;
         // tuning hook (experiments only): MGF_CONV_TILE=wm,wn forces the tile of MODE-0 launches
-        static const char* force = getenv("MGF_CONV_TILE");
+        static const char* force = mgf_knob("MGF_CONV_TILE");
         if (force && force[0] && force[1] == ',' && force[2]) {
             const int fm = force[0] - '0', fn = force[2] - '0';
             if ((fm == 2 && fn == 2 && d.cout_pad % 64 == 0) || (fm == 1 && (fn == 2 || fn == 3 || fn == 4))) { wm = fm; wn = fn; }
@@ -1057,7 +1011,7 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
         // The parity grids of the transposed conv are (in+1) wide -- 33, 65, 129 ...: one column more than a whole number of
         // 32-wide tiles.  Any width works for the lane -> (row, column) map, so take the one that needs the fewest tiles
         // (rows * tw may leave a few of the 256 pixel lanes idle).
-        static const char* tw_env = getenv("MGF_TCONV_TW");      // tuning hook (experiments only): 0 keeps 32-wide tiles
+        static const char* tw_env = mgf_knob("MGF_TCONV_TW");      // tuning hook (experiments only): 0 keeps 32-wide tiles
         // an odd width costs the predicated epilogue and some idle lanes: it has to save at least 10% of the tiles
         int64_t best = mgf_cdiv(d.tile_w, TW) * mgf_cdiv(d.tile_h, rows) * 9;       // in tenths of a tile
         for (int tw = 8; tw <= 64 && !(tw_env && tw_env[0] == '0'); ++tw) {
@@ -1078,14 +1032,14 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
         p.fixed_geo = 1;
         for (int t = 0; t < 9; ++t)
             if (d.dy[t] != ((t / 3) == 2 ? -1 : 0) || d.dx[t] != ((t % 3) == 2 ? -1 : 0)) p.fixed_geo = 0;
-        static const char* fg_env = getenv("MGF_TCONV_FIXED");       // tuning hook (experiments only): 0 = run-time geometry
+        static const char* fg_env = mgf_knob("MGF_TCONV_FIXED");       // tuning hook (experiments only): 0 = run-time geometry
         if (fg_env && fg_env[0] == '0') p.fixed_geo = 0;
     }
     if (mode == 0 && d.ntaps == 9 && d.istride == 2 && p.fh == 9 && p.fw == 65) {
         p.fixed_geo = 2;
         for (int t = 0; t < 9; ++t)
             if (d.dy[t] - dy_min != t / 3 || d.dx[t] - dx_min != t % 3) p.fixed_geo = 0;
-        static const char* fg_env = getenv("MGF_TCONV_FIXED");
+        static const char* fg_env = mgf_knob("MGF_TCONV_FIXED");
         if (fg_env && fg_env[0] == '0') p.fixed_geo = 0;
     }
     p.co_tiles = d.cout_pad / (32 * wm);
@@ -1093,9 +1047,9 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     const int64_t base_wgs = (int64_t)p.tiles_x * p.tiles_y * p.co_tiles * d.n;
     const int nchunks = (int)mgf_cdiv(d.cin, CK);
     int ksplit = 1;
-    static const int splitk_below = [] { const char* e = getenv("MGF_SPLITK_BELOW"); return e ? atoi(e) : 256; }();   // tuning hook (512 / 256 / 128: 99.6 / 100.4 / 101.1 single-target gradient iters/s, 542 / 548 / 545 literal)
+    static const int splitk_below = [] { const char* e = mgf_knob("MGF_SPLITK_BELOW"); return e ? atoi(e) : 256; }();   // tuning hook (512 / 256 / 128: 99.6 / 100.4 / 101.1 single-target gradient iters/s, 542 / 548 / 545 literal)
     if (d.workspace && base_wgs < splitk_below && nchunks >= 4 && !d.rgb_out) {
-        static const int splitk_target = [] { const char* e = getenv("MGF_SPLITK_TARGET"); return e ? atoi(e) : 1024; }();      // tuning hook: workgroups wanted
+        static const int splitk_target = [] { const char* e = mgf_knob("MGF_SPLITK_TARGET"); return e ? atoi(e) : 1024; }();      // tuning hook: workgroups wanted
         ksplit = (int)mgf_cdiv(splitk_target, base_wgs);
         if (ksplit > nchunks / 2) ksplit = nchunks / 2;
         const int64_t slice = (int64_t)d.n * d.cout * d.out_h * d.y_pitch;

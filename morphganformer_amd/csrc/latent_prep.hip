@@ -631,10 +631,10 @@ extern "C" int mgf_style_demod_multi(const mgf_style_job* jobs_dev, int32_t njob
         hipLaunchKernelGGL(style_demod_multi_kernel, dim3(1, njobs, n), dim3(256), 0, (hipStream_t)stream, jobs_dev, ws, ws_stride_n, wdim, 1);
         // 64 workgroups per job (8 rows of a 512-channel table each): 157 -> 54 us for the 19 layers at 25 samples against 16 -- each
         // wave walks its rows one after the other, so the launch wants many short walks.  MGF_SD_BLOCKS overrides (tuning)
-        static const int sdb_env = [] { const char* e = getenv("MGF_SD_BLOCKS"); return e ? atoi(e) : 0; }();
+        static const int sdb_env = [] { const char* e = mgf_knob("MGF_SD_BLOCKS"); return e ? atoi(e) : 0; }();
         hipLaunchKernelGGL(style_demod_batched_kernel, dim3(sdb_env > 0 ? sdb_env : 64, njobs), dim3(256), lds, (hipStream_t)stream, jobs_dev, ws, ws_stride_n, wdim, n);
     } else {
-        static const int sdm_env = [] { const char* e = getenv("MGF_SD_BLOCKS"); return e ? atoi(e) : 0; }();
+        static const int sdm_env = [] { const char* e = mgf_knob("MGF_SD_BLOCKS"); return e ? atoi(e) : 0; }();
         hipLaunchKernelGGL(style_demod_multi_kernel, dim3(sdm_env > 0 ? sdm_env : 16, njobs, n), dim3(256), 0, (hipStream_t)stream, jobs_dev, ws, ws_stride_n, wdim, 0);
     }
     MGF_CHECK_LAUNCH("style_demod_multi");

@@ -159,7 +159,7 @@ template <bool UNIT_OUT>
 int launch_lpips_layer(float* scratch, float* unit_out, const float* f0, const float* f1u, const float* lin, int n, int c, int64_t hw,
                        int64_t f1_stride, hipStream_t st, int* grid_out, float* stats = nullptr) {
     // 64 pixels per workgroup (256-byte segments) whenever that still yields >= 4 workgroups per CU, 16 for the small deep taps
-    static const int pxb_env = [] { const char* e = getenv("MGF_LPIPS_PXB"); return e ? atoi(e) : 0; }();      // tuning hook: 16 | 32 | 64
+    static const int pxb_env = [] { const char* e = mgf_knob("MGF_LPIPS_PXB"); return e ? atoi(e) : 0; }();      // tuning hook: 16 | 32 | 64
     // (re-tuned on buffer addressing, 32 x {128 @ 255^2, 256 @ 127^2, 384 @ 63^2, 512 @ 63^2}, us for 64 / 32 / 16-pixel blocks:
     // 264 / 306 / 386, 145 / 155 / 195, 100 / 60 / 58, 126 / 70 / 74 -- tools/lpips_layer_micro.py; with flat addressing 64 values per thread
     // had been the slow case and the 256-channel tap ran on 32-pixel blocks)
@@ -659,7 +659,7 @@ extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, i
     MGF_REQUIRE(out_h == osz(in_h) && out_w == osz(in_w), MGF_EINVAL, "maxpool: output must be %dx%d (got %dx%d)", osz(in_h), osz(in_w),
                 out_h, out_w);
     MGF_REQUIRE((int64_t)nc * out_h <= INT32_MAX - 4, MGF_ETOOBIG, "maxpool: too many rows");
-    static const int rows_env = [] { const char* e = getenv("MGF_POOL_ROWS"); return e ? atoi(e) : -1; }();
+    static const int rows_env = [] { const char* e = mgf_knob("MGF_POOL_ROWS"); return e ? atoi(e) : -1; }();
     if (rows_env != 0 && in_w <= 512 && in_w >= 64) {
         const dim3 grid((unsigned)mgf_cdiv((int64_t)nc * out_h, 4));
         const int slots = (int)mgf_cdiv(in_w, 64);
@@ -672,7 +672,7 @@ extern "C" int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, i
         MGF_CHECK_LAUNCH("maxpool");
         return MGF_OK;
     }
-    static const int tiled_env = [] { const char* e = getenv("MGF_POOL_TILED"); return e ? atoi(e) : -1; }();
+    static const int tiled_env = [] { const char* e = mgf_knob("MGF_POOL_TILED"); return e ? atoi(e) : -1; }();
     const int64_t tiles = (int64_t)nc * mgf_cdiv(out_w, 64) * mgf_cdiv(out_h, 8);
     if (tiled_env != 0 && out_w >= 32 && tiles <= INT32_MAX) {
         hipLaunchKernelGGL(maxpool3x3s2_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, y, x, in_h, in_w, out_h, out_w,
@@ -693,7 +693,7 @@ extern "C" int mgf_maxpool3x3s2_ceil_idx_f32(float* y, uint8_t* idx, const float
     MGF_REQUIRE(out_h == osz(in_h) && out_w == osz(in_w), MGF_EINVAL, "maxpool_idx: output must be %dx%d (got %dx%d)", osz(in_h), osz(in_w),
                 out_h, out_w);
     MGF_REQUIRE((int64_t)nc * out_h <= INT32_MAX - 4, MGF_ETOOBIG, "maxpool_idx: too many rows");
-    static const int rows_env = [] { const char* e = getenv("MGF_POOL_ROWS"); return e ? atoi(e) : -1; }();
+    static const int rows_env = [] { const char* e = mgf_knob("MGF_POOL_ROWS"); return e ? atoi(e) : -1; }();
     if (rows_env != 0 && in_w <= 512 && in_w >= 64) {
         const dim3 grid((unsigned)mgf_cdiv((int64_t)nc * out_h, 4));
 #define MGF_POOL_ROWS(SL) hipLaunchKernelGGL((maxpool3x3s2_rows_kernel<SL, true>), grid, dim3(256), 0, (hipStream_t)stream, y, x, nc, in_h, in_w, out_h, out_w, idx)

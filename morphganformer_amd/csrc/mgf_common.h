@@ -31,6 +31,17 @@ void mgf_set_error(const char* fmt, ...);
 
 static inline int64_t mgf_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Dispatch knobs (tile shapes, split-K thresholds, kernel choices).  In the product library every knob IS its measured default:
+// mgf_knob() returns nullptr at compile time and the `static const` it initialises folds to the constant -- nothing reads the environment.
+// Only the experiment library of tools/build_exp.sh (-DMGF_TUNING_HOOKS, exp_build/, never the product's object cache) looks the name up,
+// so that tools/*_micro.py can sweep a knob without a rebuild.
+#ifdef MGF_TUNING_HOOKS
+#include <stdlib.h>
+static inline const char* mgf_knob(const char* name) { return getenv(name); }
+#else
+static inline constexpr const char* mgf_knob(const char*) { return nullptr; }
+#endif
+
 // Grid size for a grid-stride streaming kernel: enough workgroups to fill 256 CUs x 8, no more.
 static inline int mgf_stream_grid(int64_t work_items, int block, int per_thread) {
     int64_t g = mgf_cdiv(work_items, (int64_t)block * per_thread);

@@ -395,7 +395,7 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
     // 16-byte accesses: every row of x, y and the residual starts 16-byte aligned
     const bool vec = hw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (p.y_batch % 4) == 0 &&
                      (!ep || !ep->residual || ((uintptr_t)ep->residual % 16) == 0);
-    static const bool narrow_off = [] { const char* e = getenv("MGF_PW_NARROW"); return e && e[0] == '0'; }();
+    static const bool narrow_off = [] { const char* e = mgf_knob("MGF_PW_NARROW"); return e && e[0] == '0'; }();
     if (cout <= 4 && !narrow_off && n <= 65535) {
         hipStream_t st = (hipStream_t)stream;
         mgf_prof_external_begin(st, "pw_narrow_kernel", 2.0 * cin * (double)cout * hw * n,
@@ -422,7 +422,7 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
     // per CU) halve the B-operand loads but were never faster (tools/pw_micro.py, 25 samples, us for 1 / 2 blocks: skip 512->512 at
     // 32^2 142 / 145, 512->256 at 64^2 242 / 266, 256->128 at 128^2 250 / 272, Fire expand 16->64 at 255^2 152 / 192): residency hides
     // the load latency, the operand loads are L1 hits.  MGF_PW_CB = 2 or mgf_conv1x1_force_shape(2) select the wide shape (tuning, tests).
-    static const int env_cb = [] { const char* e = getenv("MGF_PW_CB"); return e ? atoi(e) : 0; }();
+    static const int env_cb = [] { const char* e = mgf_knob("MGF_PW_CB"); return e ? atoi(e) : 0; }();
     // (round 3, after the epilogue lost its dummy residual loads: the wide shape wins where K is at most 32 -- the Fire expand layers 16 -> 64
     // at 255^2, 163 -> 157 us, and 32 -> 128 at 127^2, 102 -> 88 us at 32 samples -- and still loses from 48 input channels on)
     int cb = (cin <= 32 && cout_pad % 64 == 0 && cout >= 64) ? 2 : 1;
@@ -433,7 +433,7 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
     // (tools/pw_micro.py, 1 / 8 / 25 samples): a gain below ~800 waves (512 -> 512 at 4^2, 25 samples: 39 -> 26 us; 512 -> 64 at 63^2,
     // one sample: 49 -> 24 us), a loss above (512 -> 512 at 16^2, 25 samples = 800 waves: 42 -> 50 us).
     // MGF_PW_SPLITK_WAVES = the wave count below which it is used (tuning; 0 = never).
-    static const int64_t splitk_below = [] { const char* e = getenv("MGF_PW_SPLITK_WAVES"); return e ? atoll(e) : (int64_t)768; }();
+    static const int64_t splitk_below = [] { const char* e = mgf_knob("MGF_PW_SPLITK_WAVES"); return e ? atoll(e) : (int64_t)768; }();
     const bool splitk = cb == 1 && cin >= 32 && (int64_t)n * mgf_cdiv(hw, 128) * cw < splitk_below;
     const int wco = splitk ? 1 : (cw >= 3 ? 4 : cw);               // 1, 2 or 4 waves of a workgroup side by side over the channels
     p.co_tiles = (cw + wco - 1) / wco;

@@ -682,7 +682,10 @@ extern "C" int mgf_upfirdn2d(void* y, const void* x, const float* f, int dtype, 
     MGF_REQUIRE(eh >= 1 && ew >= 1, MGF_EINVAL, "upfirdn2d: output would be empty (%lld x %lld)", (long long)eh, (long long)ew);
     MGF_REQUIRE(eh == out_h && ew == out_w, MGF_EINVAL, "upfirdn2d: output shape mismatch: expected %lldx%lld, got %dx%d",
                 (long long)eh, (long long)ew, out_h, out_w);
-    MGF_REQUIRE((int64_t)n * c * in_h * in_w <= INT32_MAX && (int64_t)n * c * out_h * out_w <= INT32_MAX, MGF_ETOOBIG,
+    // the reference's contract (upfirdn2d.cpp:14-15,28): numel <= INT_MAX.  MGF_FILTER_LARGE (the engine's own calls) lifts it for the
+    // kernels that address a plane through a 64-bit base: every tiled / streaming kernel below; the element-indexed ones refuse
+    const bool big = (int64_t)n * c * in_h * in_w > INT32_MAX || (int64_t)n * c * out_h * out_w > INT32_MAX;
+    MGF_REQUIRE(!big || ((flip & MGF_FILTER_LARGE) && (int64_t)in_h * in_w <= INT32_MAX && (int64_t)out_h * out_w <= INT32_MAX), MGF_ETOOBIG,
                 "upfirdn2d: tensor too large");
     if (n == 0 || c == 0) return MGF_OK;
     MGF_REQUIRE(x && y && f, MGF_EINVAL, "upfirdn2d: null pointer");
@@ -706,8 +709,8 @@ extern "C" int mgf_upfirdn2d(void* y, const void* x, const float* f, int dtype, 
                          yh % 4 == 0 && yc % 4 == 0 && yn % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
                          (!ep || ((!ep->noise || (uintptr_t)ep->noise % 16 == 0) && (!ep->residual || (uintptr_t)ep->residual % 16 == 0)));
     if (wide_ok && upx == 1 && padx0 == 1 && sh >= (int64_t)((in_w + 3) / 4) * 4 && pady0 >= 0 && pady0 <= 3) {
-        static const char* sep_env = getenv("MGF_FIR_SEP");          // tuning hook (experiments only): 0 = never take the separable kernel
-        static const char* stream_env = getenv("MGF_FIR_STREAM");    // tuning hook: 0 = the LDS-tiled separable kernel on wide maps too
+        static const char* sep_env = mgf_knob("MGF_FIR_SEP");          // tuning hook (experiments only): 0 = never take the separable kernel
+        static const char* stream_env = mgf_knob("MGF_FIR_STREAM");    // tuning hook: 0 = the LDS-tiled separable kernel on wide maps too
         const int64_t swaves = (int64_t)n * c * (out_w / 256) * mgf_cdiv(out_h, FS_ROWS);
         if (p.sep_ok && out_w % 256 == 0 && out_h >= FS_ROWS && swaves >= 2048 && swaves <= INT32_MAX - 4 && !(stream_env && stream_env[0] == '0')) {
             const int blocks = (int)mgf_cdiv(swaves, 4);
@@ -747,6 +750,7 @@ extern "C" int mgf_upfirdn2d(void* y, const void* x, const float* f, int dtype, 
         else if (downx == 2) hipLaunchKernelGGL((upfirdn_small4<1, 2>), dim3(blocks), dim3(256), 0, stq, p);
         else hipLaunchKernelGGL((upfirdn_small4<1, 1>), dim3(blocks), dim3(256), 0, stq, p);
     } else {
+        MGF_REQUIRE(!big, MGF_ETOOBIG, "upfirdn2d: tensor too large for the general kernel (32-bit element indices)");
         const int64_t total = (int64_t)n * c * out_h * out_w;
         const int grid = mgf_stream_grid(total, 256, 4);
         const size_t lds = (size_t)fh * fw * sizeof(float);

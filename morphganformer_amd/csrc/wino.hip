@@ -434,18 +434,12 @@ __global__ __launch_bounds__(256, 2) void wino2_conv_kernel(WinoParams p) {
     auto body = [&](int i, float* Ucur, float* Vcur, float* Unxt, float* Vnxt, float* raw_in, float* raw_out, bool lx, bool lu) {
         // matrix work first in program order: its operands are ready, so the wave's MFMAs start at once and the parking /
         // transform instructions below issue in the slots between them (all five LDS regions are distinct compile-time buffers)
-#if !defined(MGF_W2EXP) || MGF_W2EXP != 1         // experiment 1: no matrix work
         mfma_chunk(Ucur, Vcur);
-#endif
-#if !defined(MGF_W2EXP) || MGF_W2EXP != 3         // experiment 3: no global loads / register parking
         store_x(raw_out);                            // X(i+2), loaded during the previous chunk
         store_u(Unxt, chunk0(i + 1));                // U(i+1)
         if (lx) load_x(chunk0(i + 3));
         if (lu) load_u(chunk0(i + 2));
-#endif
-#if !defined(MGF_W2EXP) || MGF_W2EXP != 2         // experiment 2: no input transform
         transform(raw_in, Vnxt);
-#endif
         __syncthreads();
     };
     for (int it = 0; it < nchunks; it += 2) {

@@ -59,9 +59,6 @@ struct Wino3Params {
     int vert, strips_y;       // ... vert: a strip walks DOWN a 32-pixel column (strips_x = tile columns, strips_y = strips per column)
 };
 
-#ifndef MGF_W3X
-#define MGF_W3X 0
-#endif
 #ifndef W3_OCC1
 #define W3_OCC1 4                        // workgroups per CU the one-block shapes are compiled for (3 -> 4: conv_last + ToRGB 3.64 -> 3.26 ms)
 #endif
@@ -282,27 +279,15 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         // the parking work on values nobody reads)
         // the fences keep the order written here: left alone, the scheduler hoists the parking -- and with it the wait for x(i+2),
         // requested only one chunk ago -- in front of the MFMAs
-        // (MGF_W3X: bit mask of timing ablations built by tools/build_exp.sh, results wrong by construction -- 1 no matrix work, 2 no
-        // input transform, 4 no footprint staging, 8 no weight loads, 16 no barrier, 32 no epilogue at all)
-#if !(MGF_W3X & 8)
         load_a(Anxt, chunk0(i + 1), i + 1 < nchunks);
-#endif
         __builtin_amdgcn_sched_barrier(0);
-#if !(MGF_W3X & 2)
         transform(Bnxt, raw_nxt);
-#endif
-#if !(MGF_W3X & 1)
         mfma_chunk(Acur, Bcur, first_tag);
-#endif
         __builtin_amdgcn_sched_barrier(0);
-#if !(MGF_W3X & 4)
         park_x(raw_park, xr, sv);
         load_x(xr, chunk0(i + 3), i + 3 < nchunks);
         load_s(sv, chunk0(i + 3));                   // (requested here, a whole chunk before their use: scalar loads share the LDS counter)
-#endif
-#if !(MGF_W3X & 16)
         __syncthreads();
-#endif
     };
     body(0, A0, A1, B0, B1, raw1, raw0, std::true_type{});
     if (1 < nchunks) body(1, A1, A0, B1, B0, raw0, raw1, std::false_type{});
@@ -311,10 +296,6 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         if (it + 1 < nchunks) body(it + 1, A1, A0, B1, B0, raw0, raw1, std::false_type{});
     }
 
-#if MGF_W3X & 32
-    if (acc[0][0][0][0] + acc[1][0][0][1] + acc[2][0][0][2] + acc[3][0][0][3] == 12345.f) p.y[tid] = B0[0][0][0] + A0[0][0].x;
-    return;
-#endif
     // ---- output transform.  R[j] = row a of M times A: R0 = M0 + M1 + M2, R1 = M1 - M2 - M3 per accumulator register; then over the
     // rows (= waves): Y0 = R[0] + R[1] + R[2], Y1 = R[1] - R[2] - R[3].  The work is cut in two UNITS and wave w finishes output row
     // (w >> 1) of unit (w & 1):
@@ -579,26 +560,11 @@ __device__ __forceinline__ void w3_dma_b128(w3_v4i rsrc, unsigned lds_addr, unsi
                  : "memory");
 }
 
-#ifndef W3P_ABL
-#define W3P_ABL 0          // timing-only ablations of the fused skip: 1 = no window requests, 2 = no interpolation arithmetic
-#endif
-#ifndef W3P_SCALAR_T
-#define W3P_SCALAR_T 0        // same-box A/B at 32 x 1024^2 (us; conv1 + skip / conv1 / conv_last + ToRGB): packed 3889 / 3308 / 3235, scalar 3956 / 3363 / 3343
-#endif
-#ifndef W3P_TIMING_NOX
-#define W3P_TIMING_NOX 0
-#endif
-#ifndef W3P_ST_AUX
-#define W3P_ST_AUX 0
-#endif
 #ifndef W3P_XD_PLAIN
 #define W3P_XD_PLAIN 4
 #endif
 #ifndef W3P_XD_RGB
 #define W3P_XD_RGB 8
-#endif
-#ifndef W3P_OWN_BRANCH
-#define W3P_OWN_BRANCH 1      // (same series: 4019 / 3443 / 3246 with the run-time bit select)
 #endif
 template <int NCK, bool RGB>
 __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
@@ -641,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     const int ntiles = vert ? min(p.strip_len, p.tiles_y - sy * p.strip_len) : min(p.strip_len, p.tiles_x - sx * p.strip_len);
     const int plane = p.h * p.w;
     const float* xn = p.x + (int64_t)n * p.cin * plane;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, W3P_TIMING_NOX ? 0 : p.cin * plane * 4, 0x00020000);       // (W3P_TIMING_NOX: timing-only build, no input traffic)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, p.cin * plane * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, 16 * p.cin * p.cout * 4, 0x00020000);
 
     // ---- resident A operands: position 4a + b, chunk c -> channels {half, half + 2} of the chunk, output channel co0 + l31; x style ----
@@ -706,13 +672,6 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             const float* src = R + (half + 2 * kk) * CST + 2 * ty * W3FW + 2 * tx;
             const v2f p01 = *reinterpret_cast<const v2f*>(src + pr * W3FW), p23 = *reinterpret_cast<const v2f*>(src + pr * W3FW + 2);
             const v2f q01 = *reinterpret_cast<const v2f*>(src + qr * W3FW), q23 = *reinterpret_cast<const v2f*>(src + qr * W3FW + 2);
-#if W3P_SCALAR_T
-            const float t0 = p01.x + sg * q01.x, t1 = p01.y + sg * q01.y, t2 = p23.x + sg * q23.x, t3 = p23.y + sg * q23.y;
-            B[kk][0] = t0 - t2;
-            B[kk][1] = t1 + t2;
-            B[kk][2] = t2 - t1;
-            B[kk][3] = t3 - t1;                                     // (= -B3: its accumulator carries -M3, the output transform adds it)
-#else
             const v2f sg2 = {sg, sg}, pm = {-1.f, 1.f}, sgpm = {-sg, sg};
             const v2f t01 = p01 + sg2 * q01, t23 = p23 + sg2 * q23;
             const v2f p2b = {p23.x, p23.x}, q2b = {q23.x, q23.x}, t1b = {t01.y, t01.y};
@@ -722,7 +681,6 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             B[kk][1] = b01.y;
             B[kk][2] = b23.x;
             B[kk][3] = b23.y;
-#endif
         }
     };
     f32x16 acc[4];
@@ -763,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
     const unsigned lds_nzs = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(nzs + 64 * a));
     auto issue_ep_dma = [&](int t) {
         const int ox0 = ox_s + tdx * t, oy0 = oy_s + tdy * t;
-        if (has_low && !(W3P_ABL & 1)) {
+        if (has_low) {
             // (branch-free per piece: bit j of `edge` = this lane's piece j lies left of the row's first tile or right of its last one; a
             // window row outside the map is a flag too, not a sentinel offset: -16 is a real offset here)
             const unsigned edge = (ox0 == 0 ? lowflag : 0u) | (ox0 + 32 == p.w ? (lowflag >> 3) : 0u);
@@ -815,53 +773,19 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
                 const float val = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;       // (m3 = -M3, see transform)
                 if (un == OWN) own[v] = val;
                 const int slot = un == 0 ? W0 : W1;
-                if (slot >= 0 && !(W3P_ABL & 64)) xl[slot * (NV * 64) + v * 64] = val;       // (W3P_ABL & 64: timing ablation, no exchange stores)
+                if (slot >= 0) xl[slot * (NV * 64) + v * 64] = val;
             }
         }
     };
     auto epilogue = [&](int t) {
-        if (W3P_ABL & 4) {                                         // timing ablation: no epilogue at all (one lane keeps the accumulators alive)
-            if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.f) p.y[tid] = acc[0][5];
-            return;
-        }
         const int ox0 = ox_s + tdx * t, oy0 = oy_s + tdy * t;
         float own[NV];
-#if W3P_OWN_BRANCH
         switch (a) {
             case 0: row_reduce(std::integral_constant<int, 0>{}, own); break;
             case 1: row_reduce(std::integral_constant<int, 1>{}, own); break;
             case 2: row_reduce(std::integral_constant<int, 2>{}, own); break;
             default: row_reduce(std::integral_constant<int, 3>{}, own); break;
         }
-#else
-        {
-            float val[2][NV];
-#pragma unroll
-            for (int un = 0; un < 2; ++un)
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const int r = RGB ? v : un * 8 + (v >> 1);
-                    const int jj = RGB ? un : (v & 1);
-                    const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
-                    val[un][v] = jj == 0 ? m0 + m1 + m2 : m1 - m2 + m3;
-                }
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const unsigned m = 0u - (unsigned)blk, b0 = __builtin_bit_cast(unsigned, val[0][v]), b1 = __builtin_bit_cast(unsigned, val[1][v]);
-                own[v] = __builtin_bit_cast(float, (b1 & m) | (b0 & ~m));
-            }
-            if (w0s >= 0) {
-                float* dst = xch + w0s * (NV * 64) + lane;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) dst[v * 64] = val[0][v];
-            }
-            if (w1s >= 0) {
-                float* dst = xch + w1s * (NV * 64) + lane;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) dst[v * 64] = val[1][v];
-            }
-        }
-#endif
         const int oy = oy0 + 2 * ty + orow, ox = ox0 + 2 * tx + (RGB ? blk : 0);
         const bool ok_px = oy < p.h && ox < p.w;
         if (RGB) {
@@ -898,10 +822,6 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
                 rr[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rres, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0));
         }
         __syncthreads();                                           // the exchange slots are complete (and, long since, the DMA'd operands)
-        if (W3P_ABL & 32) {                                        // timing ablation: row reduction + exchange + barrier, nothing after it
-            if (own[0] + own[NV - 1] == 12345.f) p.y[tid] = own[1];
-            return;
-        }
         const int chl = cob - co0;
         float osv[NR], bvv[NR];
 #pragma unroll
@@ -915,9 +835,9 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             const float2 nv = *reinterpret_cast<const float2*>(nzs + 64 * (2 * ty + orow) + 2 * tx);
             nz0 = nv.x * ns; nz1 = nv.y * ns;
         }
-        if (has_low && !(W3P_ABL & 2)) {
+        if (has_low) {
             // two channel rows per step in packed fp32 (k and k + 1 are neighbouring channels, planes 96 floats apart): 234 us of this kernel
-            // were interpolation arithmetic in scalar form (ablation W3P_ABL=2)
+            // were interpolation arithmetic in scalar form
             const float wa = orow ? 0.75f : 0.25f, wb = 1.f - wa;
             const v2f wa2 = {wa, wa}, wb2 = {wb, wb}, q25 = {0.25f, 0.25f}, q75 = {0.75f, 0.75f};
 #pragma unroll
@@ -950,8 +870,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (int64_t)n * p.y_batch), 0, p.cout * plane * 4, 0x00020000);
 #pragma unroll
         for (int k = 0; k < NR; ++k)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vout[k]), ry, ((W3P_ABL & 128) && vout[k].x != 12345.f) ? OOB : voff,
-                                                  ((k & 3) + 8 * (k >> 2)) * plane * 4, W3P_ST_AUX);      // (W3P_ABL & 128: timing ablation, stores out of range)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vout[k]), ry, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0);
     };
 
     // ---- prologue: chunks 0 and 1 of tile 0 are parked, chunks 2 .. 1 + XD wait in the register ring ----
@@ -996,7 +915,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             if (!RGB && c == 1) issue_ep_dma(t);
             transform(B[(c + 1) & 1], ((c + 1) & 1) ? raw1 : raw0);          // chunk c + 1 (of the next tile when c is the last)
 #pragma unroll
-            for (int b = 0; b < 4 && !(W3P_ABL & 8); ++b) {          // (W3P_ABL & 8: timing ablation, no matrix work)
+            for (int b = 0; b < 4; ++b) {
                 // (a tile's first MFMA per accumulator takes the constant 0 as its C operand: clearing 64 accumulator registers per tile with
                 // v_mov costs as much matrix time as four of the tile's 64 MFMAs)
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[c][b].x, B[c & 1][0][b], c == 0 ? f32x16{} : acc[b], 0, 0, 0);
@@ -1005,7 +924,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             __builtin_amdgcn_sched_barrier(0);
             park_x((c & 1) ? raw1 : raw0, xq[c % XD]);                       // chunk c + 2, requested XD bodies ago
             load_ahead(xq[c % XD], c + 2 + XD);
-            if (!(W3P_ABL & 16)) __syncthreads();                             // (W3P_ABL & 16: timing ablation, no chunk barrier -- results wrong)
+            __syncthreads();
         }
         epilogue(t);
         voff_cur = voff_nxt;
@@ -1056,7 +975,7 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     // at 25 samples (tools/w3_phases.py; shapes 21 / 12 / 11, us): 64^2 2412 / 2297 / 2138, 128^2 2273 / 2408 / 2254, 256^2 2543 /
     // 2681 / 2525, 512^2 3078 / 3303 / 3011, 1024^2 - / 4376 / 3940 -- residency (latency hiding across workgroups) is worth more than
     // the instructions the wider shapes save.  MGF_W3_SHAPE = 21 | 12 | 11 or mgf_winograd3_force_shape pin a shape (tuning, tests).
-    static const int env_forced = [] { const char* e = getenv("MGF_W3_SHAPE"); return e ? atoi(e) : 0; }();
+    static const int env_forced = [] { const char* e = mgf_knob("MGF_W3_SHAPE"); return e ? atoi(e) : 0; }();
     const int forced = g_w3_forced_shape ? g_w3_forced_shape : env_forced;
     int shape = 11;
     // ... except where the 64-channel shape measures faster: deep K with enough workgroups left to fill the chip (the 128^2 x 256-channel
@@ -1087,15 +1006,15 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     // Persistent form (wino3p_conv_kernel): shallow K (cin 32 / 64), 32-channel tiles, even maps, whole strips of 32 tiles (or one tile row
     // when it is shorter), a dense output, and enough strips to fill the chip's 512 workgroup slots several times over.
     // MGF_W3_PERSIST=0 keeps the one-shot kernel (tuning / A-B runs).
-    static const bool persist_off = [] { const char* e = getenv("MGF_W3_PERSIST"); return e && e[0] == '0'; }();
-    static const int strip_env = [] { const char* e = getenv("MGF_W3_STRIP"); return e ? atoi(e) : 0; }();
+    static const bool persist_off = [] { const char* e = mgf_knob("MGF_W3_PERSIST"); return e && e[0] == '0'; }();
+    static const int strip_env = [] { const char* e = mgf_knob("MGF_W3_STRIP"); return e ? atoi(e) : 0; }();
     const int strip_len = strip_env > 0 ? std::min(strip_env, p.tiles_x) : std::min(p.tiles_x, 32);     // (1024^2 at 32 samples, us: strips of 4 / 8 / 16 / 32 tiles 3707 / 3536 / 3472 / 3428)
     const bool persist = !persist_off && (!forced || force_persist) && shape == 11 && !odd && y_choff == 0 && p.y_batch == (int64_t)cout * h * w && cin == 32 &&
                          w % 32 == 0 && h % 4 == 0 && p.tiles_x % strip_len == 0 && (!rgb || cout == 32) &&
                          (force_persist || (int64_t)n * (p.tiles_x / strip_len) * p.tiles_y * p.co_tiles >= 2048);
     if (persist) {
         // vertical strips where the tile rows divide into whole strips (MGF_W3_VERT=0: the horizontal walk, for A/B runs)
-        static const bool vert_off = [] { const char* e = getenv("MGF_W3_VERT"); return e && e[0] == '0'; }();
+        static const bool vert_off = [] { const char* e = mgf_knob("MGF_W3_VERT"); return e && e[0] == '0'; }();
         const int vlen = std::min(p.tiles_y, strip_env > 0 ? strip_env : 32);
         p.vert = (!vert_off && p.tiles_y % vlen == 0) ? 1 : 0;
         if (p.vert) { p.strip_len = vlen; p.strips_x = p.tiles_x; p.strips_y = p.tiles_y / vlen; }
@@ -1124,7 +1043,7 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     }
     int64_t blocks = (int64_t)n * p.tiles_x * p.tiles_y * p.co_tiles;
     MGF_REQUIRE(blocks <= INT32_MAX - 8, MGF_ETOOBIG, "conv3x3_winograd3: too many workgroups");
-    static const char* xcd_env = getenv("MGF_XCD");             // tuning hook (experiments only): 0 disables the XCD-aware order
+    static const char* xcd_env = mgf_knob("MGF_XCD");             // tuning hook (experiments only): 0 disables the XCD-aware order
     p.xcd_per = 0;
     // (also with ONE channel tile: a footprint row is 34 floats around a 32-float = 128-byte line, so its two halo floats pull in the
     // neighbours' lines; with horizontally adjacent tiles on one XCD those are L2 hits instead of a 3x fetch from fabric)
@@ -1134,7 +1053,7 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     }
     // main loop: two footprint buffers + the styles; epilogue: 6 exchange slots (+ the ToRGB weights) over the same memory
     const size_t nv = cb * tb == 2 ? 32 : 16;
-    static const size_t lds_pad = [] { const char* e = getenv("MGF_W3_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();   // tuning: fewer workgroups per CU
+    static const size_t lds_pad = [] { const char* e = mgf_knob("MGF_W3_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();   // tuning: fewer workgroups per CU
     const size_t lds = std::max<size_t>((size_t)(2 * 256 * (tb == 2 ? 8 : 4)) * sizeof(float),
                                         (size_t)(6 * nv * 64 + (res_low ? 2304 : 0) + 256 + 128) * sizeof(float)) + lds_pad;
     static bool attr_set = false;

@@ -19,7 +19,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, misc
 from .projection import GradientProjectionEngine, ProjectionArgs, ProjectionEngine, latent_stats, latent_stats_w
 
 
@@ -63,24 +63,15 @@ def reference_gray_u8(img_hwc):
 
 def to_uint8_image(G, img):
     """[1,C,H,W] float32 device image in [-1,1] -> uint8 HWC numpy (misc.to_pil's rint+clip, misc.py:114-130) on the device."""
-    c, h, w = img.shape[1:]
-    out = torch.empty([h, w, c], dtype=torch.uint8, device=img.device)
-    _lib.check(_lib.lib().mgf_to_uint8_hwc(out.data_ptr(), img.contiguous().data_ptr(), c, h, w, _lib.stream_ptr()), "to_uint8")
-    return out.cpu().numpy()
+    return misc.to_uint8(img)
 
 
-def _crop_max_rectangle(im, ratio):
-    if ratio is None:
-        return im
-    w, h = im.size
-    s = min(w, h / ratio)
-    cw, ch = s, ratio * s
-    return im.crop((int((w - cw) // 2), int((h - ch) // 2), int((w + cw) // 2), int((h + ch) // 2)))
+_crop_max_rectangle = misc.crop_max_rectangle        # (the reference's name lives in morphganformer_amd.misc)
 
 
 def save_image(G, img, path, ratio=1.0):
-    from PIL import Image
-    im = _crop_max_rectangle(Image.fromarray(to_uint8_image(G, img), "RGB"), ratio)
+    """`crop(misc.to_pil(img[0]), ratio).save(path)` of the drivers (...sqz_MSE.py:190-195)."""
+    im = misc.crop_max_rectangle(misc.to_pil(img), ratio)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     im.save(path)
     return path

@@ -824,20 +824,13 @@ class GradientProjectionEngine(ProjectionEngine):
 
 def save_best_png(G, latent, path, ratio=1.0, noise_mode="const"):
     """Write the image of `latent` as the drivers do (misc.to_pil + crop_max_rectangle, misc.py:94-130; :194-195)."""
-    from PIL import Image
+    from . import misc
     latent = latent.to(G.device)
     if latent.ndim == 4:                       # a W+ result [1, k, num_ws, D] (GradientProjectionEngine(latent_space="w+"))
         img = G.forward_workspace(ws=latent, noise_mode=noise_mode)[0]
     else:
         img = G.forward_workspace(latent, None, noise_mode=noise_mode)[0]
-    c, h, w = img.shape[1:]
-    out = torch.empty([h, w, c], dtype=torch.uint8, device=G.device)
-    _lib.check(_lib.lib().mgf_to_uint8_hwc(out.data_ptr(), img.data_ptr(), c, h, w, _lib.stream_ptr()), "to_uint8")
-    im = Image.fromarray(out.cpu().numpy(), "RGB")
-    if ratio is not None:
-        s = min(im.size[0], im.size[1] / ratio)
-        cw, ch = s, ratio * s
-        im = im.crop((int((w - cw) // 2), int((h - ch) // 2), int((w + cw) // 2), int((h + ch) // 2)))
+    im = misc.crop_max_rectangle(misc.to_pil(img), ratio)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     im.save(path)
     return path

@@ -689,6 +689,55 @@ def test_morph_pairs_projects_renders_and_skips_like_the_script(tmp_path):
     assert torch.equal(r2["latents"], r["latents"][2:4])                                  # same seed, same targets: the same projections
 
 
+def test_morph_pairs_gradient_mode_w_plus(tmp_path):
+    """morph_pairs(mode="gradient", latent_space="w+") used to run every projection and then die in the render step (a 4-D
+    latent passed on as z).  W+ results [1,k,num_ws,D] render through G(ws=...), blend slot by slot, and round-trip through the .mat format."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.projection import ProjectionArgs
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from PIL import Image
+    G = Generator(make_state_dict(TINY, seed=0), TINY, "cuda", max_batch=1)
+    drivers.generate_images(G, 2, output_dir=str(tmp_path / "src"), seed=4, noise_mode="const")
+    pairs = [("sample_000000.png", "sample_000001.png")]
+    kw = dict(args=ProjectionArgs(step=6, n_mean_latent=200, lr=0.05, min_loss_init=1e30), percept=None, seed=2, noise_mode="const", mode="gradient",
+              latent_space="w+")
+    r = drivers.morph_pairs(G, pairs, str(tmp_path / "src"), str(tmp_path / "raw"), str(tmp_path / "morph"), **kw)
+    assert tuple(r["latents"].shape) == (2, TINY.k, TINY.num_ws, TINY.w_dim)
+    assert sorted(os.listdir(tmp_path / "raw")) == ["sample_000000_sample_000001_A.png", "sample_000000_sample_000001_B.png"]
+    w1, w2 = r["latents"][0:1], r["latents"][1:2]
+    want = drivers.to_uint8_image(G, G(ws=(0.5 * w1 + 0.5 * w2).cuda(), noise_mode="const")[0])
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "morph" / "sample_000000_sample_000001.png")), want)
+    want_a = drivers.to_uint8_image(G, G(ws=w1.cuda(), noise_mode="const")[0])
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "raw" / "sample_000000_sample_000001_A.png")), want_a)
+    lat, imgs = drivers.merge_morph(G, w1, w2, (0.0, 0.5), noise_mode="const", out_prefix=str(tmp_path / "m" / "ab"))
+    assert lat.shape == (2, 1, TINY.k, TINY.num_ws, TINY.w_dim) and torch.equal(imgs[0], G(ws=w1.cuda(), noise_mode="const")[0][0])
+    assert np.array_equal(drivers.load_latent_mat(str(tmp_path / "m" / "ab_a0.50.mat")), lat[1])
+    with pytest.raises(ValueError, match="differ in shape"):
+        drivers.merge_morph(G, w1, w2[:, :, 0], (0.5,))
+
+
+def test_misc_to_pil_and_crop_under_the_reference_names():
+    """morphganformer_amd.misc.to_pil / crop_max_rectangle (misc.py:94-130) -- the calls `crop(misc.to_pil(img_gen_raw[0]), ratio)` of the drivers
+    -- on a numpy CHW image as the drivers pass it and on a device tensor: the bytes equal the reference's float32 adjust_range + rint + clip."""
+    from morphganformer_amd import misc
+    rng = np.random.Generator(np.random.PCG64(5))
+    img = (rng.standard_normal((3, 37, 52)) * 0.8).astype(np.float32)
+    img[0, 0, :6] = [-1.0, 1.0, -1.00001, 1.00001, 0.0, -0.0039215689]       # range ends, just outside, a .5 tie candidate
+    scale = (np.float32(255) - np.float32(0)) / (np.float32(1) - np.float32(-1))
+    bias = np.float32(0) - np.float32(-1) * scale
+    want = np.rint(img.transpose(1, 2, 0) * scale + bias).clip(0, 255).astype(np.uint8)     # misc.py:103-124
+    im = misc.to_pil(img)
+    assert im.mode == "RGB" and im.size == (52, 37) and np.array_equal(np.asarray(im), want)
+    assert np.array_equal(np.asarray(misc.to_pil(torch.from_numpy(img).cuda())), want)
+    gray = misc.to_pil(img[:1])
+    assert gray.mode == "L" and np.array_equal(np.asarray(gray), want[:, :, 0])
+    assert misc.crop_max_rectangle(im, None) is im
+    assert misc.crop_max_rectangle(im, 1.0).size == (37, 37) and misc.crop_max_rectangle(im, 0.5).size == (52, 26)
+    with pytest.raises(ValueError, match="drange"):
+        misc.to_pil(img, drange=[0, 1])
+
+
 def test_cli_morph_pairs(tmp_path):
     from morphganformer_amd import cli
     from test_host_and_abi import _tiny_snapshot

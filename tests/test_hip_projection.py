@@ -283,6 +283,37 @@ def test_full_size_loop_bench_batch_equals_batch1():
     assert abs(loss_a - loss_b) <= 1e-5 * abs(loss_b)
 
 
+def test_full_size_loop_64_candidates_per_forward():
+    """64 loop steps per generator forward at 1024^2: the blur's input [64, 32, 1025, 1025] exceeds the 2^31 elements of the plug-in
+    contract (upfirdn2d.cpp:14-15), which the engine-internal FIR path used to inherit -- a silent wall at 32.  The
+    engine's own calls carry MGF_FILTER_LARGE now; the run equals the 32-per-forward run: same best step, bit-identical latent, history to
+    1e-5.  The plug-in entry still refuses such a tensor."""
+    from morphganformer_amd import _lib
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, latent_stats
+    from morphganformer_amd.synth_weights import FULL1024, make_state_dict, synthetic_latents
+    from morphganformer_amd.torch_utils.ops import upfirdn2d
+    G = Generator(make_state_dict(FULL1024, seed=0), FULL1024, "cuda", max_batch=1)
+    target = G(torch.from_numpy(synthetic_latents(FULL1024, 1, 1000)).cuda(), None, noise_mode="const")[0].clamp(-1, 1).clone()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    mean, std = latent_stats(G, 10000, "cuda", gen)
+    steps = 64
+    eps = torch.randn(steps, 1, FULL1024.k, FULL1024.z_dim, device="cuda", generator=gen)
+    out = {}
+    for batch in (64, 32):
+        eng = ProjectionEngine(G, target, mean, std, ProjectionArgs(step=steps), percept=None, use_mse=True, eps=eps, noise_mode="const",
+                               use_graph=False, batch=batch)
+        out[batch] = eng.run().result()
+        del eng
+    (lat_a, step_a, loss_a, hist_a), (lat_b, step_b, loss_b, hist_b) = out[64], out[32]
+    assert not np.isnan(hist_a).any()
+    assert step_a == step_b and torch.equal(lat_a, lat_b)
+    assert np.abs(hist_a - hist_b).max() <= 1e-5 * np.abs(hist_b).max()
+    big = torch.empty(33, 64, 1025, 1025, device="cuda")                # 2.2e9 elements through the reference-signature operator
+    with pytest.raises((_lib.MgfError, RuntimeError), match="too large"):
+        upfirdn2d.upfirdn2d(big, upfirdn2d.setup_filter([1, 3, 3, 1], device="cuda"), padding=1)
+
+
 def test_full_size_loop_vs_oracle():
     """configs[1] at FULL size against the CPU oracle, not against itself: 1024^2, Wing + LPIPS(squeeze) + MSE, drivers.DEFAULT_BATCH (32)
     candidates per generator forward -- the kernel shapes bench.py times -- injected eps, constant per-layer noise, 4 loop steps.  Every loss of

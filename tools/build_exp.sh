@@ -4,4 +4,4 @@
 # nothing is copied from -- or can leak into -- the product's object cache)
 set -e
 cd "$(dirname "$0")/.."
-exec python -m morphganformer_amd.build --exp "$1" --flags "$2" --source "${3:-conv_taps.hip}"
+exec python -m morphganformer_amd.build --exp "$1" --flags "-DMGF_TUNING_HOOKS $2" --source "${3:-conv_taps.hip}"
