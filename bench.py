@@ -55,6 +55,19 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+def cpu_model():
+    """The host CPU's model string (SURVEY 8d asks for model and core count beside the CPU baseline)."""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,7 +81,7 @@ def parse():
                          "run -- the driver's, the rocprofv3 trace, the PMC passes in profiles/ -- launches the same kernels on the same shapes")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=3, help="timed iterations of the CPU oracle's port (+1 warm-up), about 3 s each on 64 threads")
     ap.add_argument("--biometric", type=int, default=0, metavar="DEPTH",
                     help="add the IResNet-DEPTH embedding-MSE term (BASELINE config 3's full objective); 0 = the config-2 objective")
     ap.add_argument("--lpips-net", choices=["squeeze", "vgg", "alex"], default="squeeze",
@@ -92,7 +105,18 @@ def parse():
                          "running alone); 0 = one stream (default: keeps roofline and rocprofv3 per-kernel figures clean)")
     ap.add_argument("--gradient-steps", type=int, default=20,
                     help="steps of the extra gradient-mode leg (loss back-propagated into the latent, Adam; rank 0, N=1 only); 0 = skip")
-    ap.add_argument("--gradient-lockstep", type=int, default=8, help="targets advanced in lockstep in the second half of the gradient-mode leg")
+    ap.add_argument("--gradient-lockstep", type=str, default="8,16,32",
+                    help="targets advanced in lockstep in the second half of the gradient-mode leg: a comma-separated list, one sub-leg each (the first "
+                         "is reported as `lockstep`, all of them under `lockstep_sweep`); 0 = skip")
+    ap.add_argument("--objective-batches", type=str, default="16,32",
+                    help="candidates per forward of the config-3 objective leg: the first is `objectives.config3`, the others `objectives.config3_bNN`")
+    ap.add_argument("--config4", type=int, default=1,
+                    help="1 = the `config4` leg (rank 0, N=1): BASELINE config 4 -- two --target-steps-step projections (one re-targeted engine) and the "
+                         "11-alpha sweep of their latents as ONE batch-11 generator forward: projections/s and sweep ms; 0 = skip")
+    ap.add_argument("--config5-targets", type=int, default=32,
+                    help="targets of the `config5` leg (rank 0, N=1): BASELINE config 5's batch of second-stage projections started from a stage-1 "
+                         "latent (edit_MSE.py:229-231), MSE objective like the script, through drivers.project_many on one GPU; 0 = skip")
+    ap.add_argument("--config5-steps", type=int, default=500, help="loop steps per second-stage projection of the config5 leg (stated in the line)")
     ap.add_argument("--targets", type=int, default=3,
                     help="targets of the many-target leg (BASELINE configs 3 and 5 are batches of targets): drivers.project_image walked over "
                          "this many 1024^2 targets with ONE engine re-targeted in place, timed end to end INCLUDING the set-up (latent statistics, "
@@ -190,7 +214,7 @@ def roofline_leg(eng, iters=3, pmc_tag=""):
     per_kernel = {k_: dict(v, executed_frac=round(v["tflops"] * (16 / 36 if k_.startswith("wino") else 1.0) / FP32_MFMA_PEAK_TFLOPS, 4))
                   for k_, v in per_kernel.items()}
     return {"bound": "mfma", "kernel": dom, "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4), **extra, **pmc_fields(dom, eng, pmc_tag),
+            "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4), **extra, **pmc_fields(dom, eng, pmc_tag, launched=tuple(agg)),
             "algorithmic_bytes_per_launch": round(nbytes / launches),
             "avg_launch_us": round(secs / launches * 1e6, 2), "launches_per_iter": launches // iters,
             "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
@@ -213,6 +237,25 @@ def generator_leg(eng, iters=3):
     gf = G.cfg.conv_gflop()
     return {"gflop_per_image": round(gf, 1), "ms_per_image": round(ms, 4), "tflops": round(gf / ms, 2),
             "frac_of_fp32_mfma_peak": round(gf / ms / FP32_MFMA_PEAK_TFLOPS, 4), "images_per_forward": eng.batch}
+
+
+def graph_kernel_nodes(graph):
+    """Kernel launches per replay of a captured torch.cuda.CUDAGraph (None when it cannot be counted): the debug dump of the graph, one
+    `label=...` node per kernel."""
+    if graph is None:
+        return None
+    import re
+    import tempfile
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "g.dot")
+            graph.debug_dump(path)
+            with open(path) as fh:
+                txt = fh.read()
+        n = len(re.findall(r"KERNEL|kernel", txt))
+        return n or None
+    except Exception:          # noqa: BLE001 -- a count beside the metric, never a reason to fail
+        return None
 
 
 def gradient_roofline(ge):
@@ -244,7 +287,37 @@ def gradient_roofline(ge):
             "all_convs_tflops": round(sum(v[0] for v in agg.values()) / conv_s / 1e12, 2)}
 
 
-def gradient_leg(sd, cfg, device, eng, steps, lockstep=8):
+def lockstep_leg(sd, cfg, device, eng, steps, total, B, conv_gf):
+    """B independent targets advanced in lockstep through one generator forward/backward per step."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.lpips import PerceptualLoss
+    from morphganformer_amd.projection import GradientProjectionEngine, ProjectionArgs, synthetic_landmarks
+    from morphganformer_amd.synth_weights import synthetic_latents
+    torch.cuda.reset_peak_memory_stats(device)
+    GB = Generator(sd, cfg, device, max_batch=B)
+    zt = torch.from_numpy(synthetic_latents(cfg, B, seed=2000)).to(device)
+    tg = torch.cat([GB(zt[j:j + 1], None, noise_mode="const")[0].clamp(-1, 1) for j in range(B)]).contiguous()
+    lm = [synthetic_landmarks(total, cfg.img_resolution, seed=50 + j) for j in range(B)]
+    gb = GradientProjectionEngine(GB, tg, eng.latent_in[0], 1.0, ProjectionArgs(step=total),
+                                  percept=PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device, allow_random_backbone=True), use_mse=True,
+                                  lm_target=np.stack([l[0] for l in lm]), lm_steps=np.stack([l[1] for l in lm]), noise_mode="random",
+                                  seed=6, use_graph=True)
+    gb.sigma.copy_(eng.sigma[:1].expand(total))
+    gb.run(4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gb.run(steps)
+    torch.cuda.synchronize()
+    dtb = time.perf_counter() - t0
+    out = {"targets": B, "value": round(B * steps / dtb, 2), "unit": "iters/s (all targets)", "ms_per_step": round(dtb / steps * 1e3, 3),
+           "step_tflops": round(2 * conv_gf * B * steps / dtb / 1e3, 2), "hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
+           "roofline": gradient_roofline(gb)}
+    del gb, GB, tg
+    torch.cuda.empty_cache()
+    return out
+
+
+def gradient_leg(sd, cfg, device, eng, steps, lockstep=(8,)):
     """Extra (not the headline metric): the same objective with the loss back-propagated into the latent and Adam moving it
     (projection.GradientProjectionEngine) -- one candidate per step, forward + LPIPS + backward + Adam as one hipGraph."""
     from morphganformer_amd.engine import Generator
@@ -255,6 +328,7 @@ def gradient_leg(sd, cfg, device, eng, steps, lockstep=8):
                                   lm_target=eng.lm_target.cpu().numpy(), lm_steps=eng.lm_steps[:total].cpu().numpy(), noise_mode="random",
                                   seed=5, use_graph=True)
     ge.sigma.copy_(eng.sigma[:1].expand(total))                    # the run's initial noise level at every step of this short leg
+    ge.graph_debug = True                                          # (only so that the launches per step can be counted afterwards)
     ge.run(4)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -275,32 +349,21 @@ def gradient_leg(sd, cfg, device, eng, steps, lockstep=8):
     torch.cuda.synchronize()
     conv_gf = cfg.conv_gflop()
     roof = gradient_roofline(ge)
-    # B independent targets advanced in lockstep through one generator forward/backward per step
-    lock = None
-    if lockstep > 1:
-        from morphganformer_amd.lpips import PerceptualLoss
-        from morphganformer_amd.projection import synthetic_landmarks
-        from morphganformer_amd.synth_weights import synthetic_latents
-        B = lockstep
-        GB = Generator(sd, cfg, device, max_batch=B)
-        zt = torch.from_numpy(synthetic_latents(cfg, B, seed=2000)).to(device)
-        tg = GB(zt, None, noise_mode="const")[0].clamp(-1, 1).clone()
-        lm = [synthetic_landmarks(total, cfg.img_resolution, seed=50 + j) for j in range(B)]
-        gb = GradientProjectionEngine(GB, tg, eng.latent_in[0], 1.0, ProjectionArgs(step=total),
-                                      percept=PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device, allow_random_backbone=True), use_mse=True,
-                                      lm_target=np.stack([l[0] for l in lm]), lm_steps=np.stack([l[1] for l in lm]), noise_mode="random",
-                                      seed=6, use_graph=True)
-        gb.sigma.copy_(eng.sigma[:1].expand(total))
-        gb.run(4)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        gb.run(steps)
-        torch.cuda.synchronize()
-        dtb = time.perf_counter() - t0
-        lock = {"targets": B, "value": round(B * steps / dtb, 2), "unit": "iters/s (all targets)", "ms_per_step": round(dtb / steps * 1e3, 3),
-                "step_tflops": round(2 * conv_gf * B * steps / dtb / 1e3, 2), "roofline": gradient_roofline(gb)}
+    launches = graph_kernel_nodes(ge.graph)
+    del ge
+    torch.cuda.empty_cache()
+    sweep = []
+    for B in lockstep:
+        if B > 1:
+            try:
+                sweep.append(lockstep_leg(sd, cfg, device, eng, steps, total, B, conv_gf))
+                log(f"gradient lockstep {B}: {sweep[-1]['value']} iters/s")
+            except Exception as exc:        # noqa: BLE001 -- reported in the line instead
+                sweep.append({"targets": B, "error": f"{type(exc).__name__}: {exc}"})
+    lock = sweep[0] if sweep else None
     return {"value": round(steps / dt, 2), "unit": "iters/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
-            "candidates_per_step": 1, "lockstep": lock, "generator_forward_ms": round(ev[0].elapsed_time(ev[1]), 3),
+            "candidates_per_step": 1, "launches_per_step": launches, "lockstep": lock,
+            "lockstep_sweep": [{k: v for k, v in r.items() if k != "roofline"} for r in sweep], "generator_forward_ms": round(ev[0].elapsed_time(ev[1]), 3),
             "lpips_forward_backward_ms": round(ev[1].elapsed_time(ev[2]), 3), "generator_backward_ms": round(ev[2].elapsed_time(ev[3]), 3),
             "conv_gflop_forward_plus_dgrad": round(2 * conv_gf, 1),
             "generator_forward_frac_of_fp32_mfma_peak": round(conv_gf / ev[0].elapsed_time(ev[1]) / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -341,6 +404,72 @@ def many_targets_leg(cfg, device, G, percept, batch, n_targets, steps):
             "best": res,
             "note": "first call = engine set-up (latent statistics, LPIPS workspaces + target taps, hipGraph capture) + the run; the others "
                     "re-target that engine in place (ProjectionEngine.retarget) and replay its graph"}
+
+
+def config4_leg(cfg, device, G, percept, batch, steps, latent_mean, latent_std):
+    """BASELINE config 4 (1024_merge_morph_2.py:83-92 after two `projection()` calls): two literal-mode projections of `steps` steps with
+    configs[1]'s objective through ONE engine (built for the first target, re-targeted for the second), then the 11-alpha sweep
+    `(1-a) w1 + a w2`, a = 0, 0.1 .. 1, rendered as ONE batch-11 generator forward.  Timed end to end, engine set-up included."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.projection import ProjectionArgs, synthetic_landmarks
+    from morphganformer_amd.synth_weights import synthetic_latents
+    zs = torch.from_numpy(synthetic_latents(cfg, 2, seed=6000)).to(device)
+    targets = [G(zs[j:j + 1], None, noise_mode="const")[0].clamp(-1, 1) for j in range(2)]
+    lms = [synthetic_landmarks(steps, cfg.img_resolution, seed=600 + j) for j in range(2)]
+    alphas = [round(0.1 * i, 1) for i in range(11)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng, ws, tp = None, [], []
+    for j in range(2):
+        t1 = time.perf_counter()
+        r = drivers.project_image(G, targets[j], lms[j][0], lms[j][1], args=ProjectionArgs(step=steps), percept=percept, batch=batch, seed=60 + j,
+                                  latent_mean=latent_mean, latent_std=latent_std, engine=eng, return_engine=True)
+        torch.cuda.synchronize()
+        tp.append(time.perf_counter() - t1)
+        eng = r["engine"]
+        ws.append(r["w"])
+    t2 = time.perf_counter()
+    lat, imgs = drivers.merge_morph(G, ws[0], ws[1], alphas, truncation_psi=0.7, noise_mode="random", batched=True)
+    torch.cuda.synchronize()
+    first_sweep = time.perf_counter() - t2
+    total = time.perf_counter() - t0
+    t3 = time.perf_counter()
+    drivers.merge_morph(G, ws[0], ws[1], alphas, truncation_psi=0.7, noise_mode="random", batched=True)       # (workspace of 11 exists now)
+    torch.cuda.synchronize()
+    sweep = time.perf_counter() - t3
+    assert tuple(imgs.shape) == (11, cfg.img_channels, cfg.img_resolution, cfg.img_resolution) and bool(torch.isfinite(imgs).all())
+    del eng
+    return {"value": round(2 / (tp[0] + tp[1]), 4), "unit": "projections/s (engine set-up included)", "steps_per_projection": steps,
+            "projection_s": [round(t, 3) for t in tp], "iters_per_s_retargeted": round(-(-steps // batch) * batch / tp[1], 2),
+            "sweep_alphas": 11, "sweep_ms": round(sweep * 1e3, 3), "first_sweep_ms": round(first_sweep * 1e3, 3),
+            "sweep_images_per_s": round(11 / sweep, 1), "total_s": round(total, 3),
+            "note": "two projections + the 11-alpha sweep as one batch-11 forward (drivers.merge_morph(batched=True)); first_sweep_ms includes "
+                    "allocating the batch-11 workspace"}
+
+
+def config5_leg(cfg, device, G, batch, n_targets, steps, latent_std):
+    """BASELINE config 5 on one GPU: `n_targets` second-stage projections (edit_MSE.py:229-231 -- candidates drawn around a stage-1 latent
+    instead of the latent mean; MSE objective and no landmarks, like the script) through drivers.project_many: ONE engine, re-targeted per
+    item, results gathered by item id.  Timed end to end after a one-item warm-up (set-up is config 4's and many_targets' figure)."""
+    from morphganformer_amd import drivers
+    from morphganformer_amd.projection import ProjectionArgs
+    from morphganformer_amd.synth_weights import synthetic_latents
+    zs = torch.from_numpy(synthetic_latents(cfg, n_targets + 1, seed=8000)).to(device)
+    w1 = zs[n_targets] * 0.5                              # the stage-1 result every second stage starts from (`w = w1.reshape([17, 32])`)
+    targets = [(lambda j=j: G(zs[j:j + 1], None, noise_mode="const")[0].clamp(-1, 1)) for j in range(n_targets)]
+    kw = dict(args=ProjectionArgs(step=steps), percept=None, batch=batch, latent_mean=w1, latent_std=float(latent_std), seed=9)
+    drivers.project_many(G, targets[:1], **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = drivers.project_many(G, targets, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert [int(v) for v in res["items"]] == list(range(n_targets))
+    rup = -(-steps // batch) * batch
+    return {"value": round(n_targets / dt, 4), "unit": "projections/s", "targets": n_targets, "steps_per_target": steps, "seconds": round(dt, 3),
+            "iters_per_s": round(n_targets * rup / dt, 2), "objective": "MSE (edit_MSE.py:143)", "steps_per_forward": batch,
+            "note": "second-stage projections started from one stage-1 latent, drivers.project_many on one GPU (BASELINE config 5 shards 32 "
+                    "of them over 4 GPUs: the same call under torch.distributed)"}
 
 
 def objective_leg(cfg, device, G, target, latent_mean, latent_std, batch, lpips_net="squeeze", facenet=False, min_seconds=0.6):
@@ -426,7 +555,7 @@ def pmc_tables(tag=""):
     return out
 
 
-def pmc_fields(kernel, eng, tag=""):
+def pmc_fields(kernel, eng, tag="", launched=()):
     """`traffic` = HBM-side bytes per launch of `kernel` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this same
     workload, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled on gfx950, WRITE_SIZE as read; profiles/README.md).
     The passes are taken at `steps_per_forward` candidates per launch; for another count the bytes are scaled by the ratio (every
@@ -436,6 +565,17 @@ def pmc_fields(kernel, eng, tag=""):
     out = {"traffic": None}
     if eng.G.cfg.img_resolution != 1024:
         return out
+    # The counters are look-ups of committed passes, not measurements of this run: they are only reported while the passes still describe
+    # this build -- every MFMA conv kernel the leg just launched must have a row in the table (a renamed, re-templated or new kernel means
+    # the passes are stale: re-take them with tools/refresh_profiles.sh).
+    for which in ("traffic", "mfma"):
+        if t[which] is not None and launched:
+            src, table = t[which]
+            known = lambda k_: k_ in table or (k_.endswith(">") and any(r.startswith(k_[:-1] + ", ") for r in table))
+            missing = sorted(k_ for k_ in launched if not known(k_))
+            if missing:
+                out["pmc_stale"] = f"{src} has no row for {missing}: counters not reported (re-take the PMC passes)"
+                return out
     if t["traffic"] is not None:
         src, table = t["traffic"]
         rec = table.get(kernel)
@@ -489,7 +629,8 @@ def cpu_baseline_leg(sd, cfg, target, latent_mean, latent_std, lms, iters):
             times.append(time.perf_counter() - t0)
             log(f"cpu_baseline iteration {i}: {times[-1]:.2f} s (loss {total:.4f})")
     per = float(np.mean(times[1:]))
-    return {"value": round(1.0 / per, 4), "unit": "iters/s", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / per, 4), "unit": "iters/s", "cores": cores, "cpu_model": cpu_model(), "host_cores": host_cores(), "kind": "port",
+            "s_per_iter": [round(t, 3) for t in times[1:]],
             "sample": f"{iters} timed iterations (+1 warm-up) of the same 1024^2 Wing+LPIPS(squeeze)+MSE step, torch-CPU fp32 oracle, "
                       f"{cores} threads; {per:.2f} s/iter"}
 
@@ -784,7 +925,7 @@ def main():
         log(f"roofline leg done: {out['roofline']['kernel']} {out['roofline']['achieved']} TFLOP/s executed")
         if world == 1 and a.gradient_steps > 0 and not a.biometric:
             try:            # an extra beside the metric: never let it take the JSON line down
-                out["gradient_mode"] = gradient_leg(sd, cfg, device, eng, a.gradient_steps, a.gradient_lockstep)
+                out["gradient_mode"] = gradient_leg(sd, cfg, device, eng, a.gradient_steps, [int(v) for v in str(a.gradient_lockstep).split(",") if int(v) > 1])
                 log(f"gradient-mode leg done: {out['gradient_mode']['value']} iters/s")
             except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                 out["gradient_mode"] = {"error": f"{type(exc).__name__}: {exc}"}
@@ -796,14 +937,30 @@ def main():
             except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                 out["many_targets"] = {"error": f"{type(exc).__name__}: {exc}"}
                 log(f"many-target leg failed: {exc}")
+        if world == 1 and a.config4 and not a.biometric and a.res == 1024:
+            try:
+                out["config4"] = config4_leg(cfg, device, G, percept, a.batch, a.target_steps, latent_mean, latent_std)
+                log(f"config4 leg done: {out['config4']['value']} projections/s, sweep {out['config4']['sweep_ms']} ms")
+            except Exception as exc:        # noqa: BLE001 -- reported in the line instead
+                out["config4"] = {"error": f"{type(exc).__name__}: {exc}"}
+                log(f"config4 leg failed: {exc}")
+        if world == 1 and a.config5_targets > 0 and not a.biometric and a.res == 1024:
+            try:
+                out["config5"] = config5_leg(cfg, device, G, a.batch, a.config5_targets, a.config5_steps, latent_std)
+                log(f"config5 leg done: {out['config5']['value']} projections/s")
+            except Exception as exc:        # noqa: BLE001 -- reported in the line instead
+                out["config5"] = {"error": f"{type(exc).__name__}: {exc}"}
+                log(f"config5 leg failed: {exc}")
         if world == 1 and a.objectives and not a.biometric and a.res == 1024 and a.lpips_net == "squeeze":
             out["objectives"] = {}
-            legs = (("lpips_vgg", dict(lpips_net="vgg"), "Wing + LPIPS(vgg) + MSE (1024_example_percept_MSE.py:142-147's backbone in configs[1]'s loop)"),
-                    ("config3", dict(facenet=True), "Wing + FaceNet embedding MSE (InceptionResnetV1, un-resized 1024^2 image) + LPIPS(squeeze) + MSE: "
-                                                    "BASELINE config 3's objective (1024_example_FaceNet_percept.py:147-158 + ...sqz_MSE.py:171-179)"))
-            for name, kw, what in legs:
+            c3 = ("Wing + FaceNet embedding MSE (InceptionResnetV1, un-resized 1024^2 image) + LPIPS(squeeze) + MSE: BASELINE config 3's objective "
+                  "(1024_example_FaceNet_percept.py:147-158 + ...sqz_MSE.py:171-179)")
+            obs = [int(v) for v in str(a.objective_batches).split(",")] if a.objective_batches else [a.objective_batch]
+            legs = [("lpips_vgg", obs[0], dict(lpips_net="vgg"), "Wing + LPIPS(vgg) + MSE (1024_example_percept_MSE.py:142-147's backbone in configs[1]'s loop)"),
+                    ("config3", obs[0], dict(facenet=True), c3)] + [(f"config3_b{b}", b, dict(facenet=True), c3) for b in obs[1:]]
+            for name, ob, kw, what in legs:
                 try:
-                    out["objectives"][name] = dict(objective_leg(cfg, device, G, target, latent_mean, latent_std, a.objective_batch, **kw), objective=what)
+                    out["objectives"][name] = dict(objective_leg(cfg, device, G, target, latent_mean, latent_std, ob, **kw), objective=what)
                     log(f"objective leg {name}: {out['objectives'][name]['value']} iters/s")
                 except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                     out["objectives"][name] = {"error": f"{type(exc).__name__}: {exc}"}

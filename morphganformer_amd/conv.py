@@ -465,7 +465,8 @@ def upfirdn_into(y, x, f2d, up=1, pad=(0, 0, 0, 0), gain=1.0, flip=False, epilog
     sx, sy = x.stride(), y.stride()
     rc = _lib.lib().mgf_upfirdn2d(y.data_ptr(), x.data_ptr(), f2d.data_ptr(), _lib.MGF_F32, n, c, h, w, sx[0], sx[1], sx[2],
                                   sx[3], oh, ow, sy[0], sy[1], sy[2], sy[3], fh, fw, up, up, down, down, px0, px1, py0, py1,
-                                  int(flip) | (2 if separable else 0) | 4, float(gain),      # 4 = MGF_FILTER_LARGE: the engine's own calls C.byref(epilogue) if epilogue is not None else None,
+                                  int(flip) | (2 if separable else 0) | 4,      # 4 = MGF_FILTER_LARGE: the engine's own calls
+                                  float(gain), C.byref(epilogue) if epilogue is not None else None,
                                   _lib.stream_ptr())
     _lib.check(rc, "upfirdn2d")
     return y

@@ -524,6 +524,8 @@ class ProjectionEngine:
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
+        if getattr(self, "graph_debug", False):          # keeps the hipGraph_t behind the executable graph: graph.debug_dump(path) can list its nodes
+            g.enable_debug_mode()
         with torch.cuda.graph(g):
             self._iteration()
         for dst, src in zip(self._state(), state):
