@@ -465,6 +465,15 @@ int mgf_style_grad_act_bwd_f32(float* style_part, float* dot_part, float* dz, fl
                                const float* residual, const float* residual_low, int32_t w, const float* bias, const float* noise,
                                const float* noise_strength, int32_t noise_n, int32_t n, int32_t c, int64_t hw, float alpha, float gain,
                                mgf_stream_t stream);
+/* The same pair followed by the ADJOINT OF THE 4x4 RESAMPLE BLUR (upfirdn2d with pad 2, upfirdn2d.py:237-256) in one pass, for an earlier
+ * layer that is an up-sampling layer without attention and without residual: dt [n, c, h + 1, w + 1] = upfirdn2d(dz, f, pad 2, gain
+ * fir_gain, flip) -- the map the stride-2 data-gradient convolution reads; dz itself never reaches memory.  f: the 4x4 OUTER-PRODUCT filter
+ * (device, as upfirdn2d.setup_filter builds it).  The dot-product partials come one per 64 x 64 output tile: style_part / dot_part are
+ * [n, c, mgf_style_act_fir_tiles(h, w)] (dot_part may be NULL). */
+int32_t mgf_style_act_fir_tiles(int32_t h, int32_t w);
+int mgf_style_act_fir_bwd_f32(float* style_part, float* dot_part, float* dt, const float* x, const float* g, const float* s, const float* bias,
+                              const float* noise, const float* noise_strength, int32_t noise_n, const float* f, int32_t flip, float fir_gain,
+                              int32_t n, int32_t c, int32_t h, int32_t w, float alpha, float gain, mgf_stream_t stream);
 /* residual_low (here and in mgf_layer_act_bwd_low_f32; instead of `residual`, maps of row length w): the residual BEFORE its 2x FIR
  * up-sampling, [n][c][h/2][w/2] -- the resnet skip branch as the form-3 Winograd epilogue consumes it in the forward
  * (mgf_conv3x3_winograd3_f32's residual_low); it is up-sampled here with that epilogue's arithmetic, so the full-resolution skip

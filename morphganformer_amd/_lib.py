@@ -128,6 +128,8 @@ _SIGS = {
     "mgf_channel_dot_f32": (C.c_int, [vp, vp, vp, i32, i32, i64, vp]),
     "mgf_style_grad_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, i32, vp]),
     "mgf_style_grad_act_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i64, f32, f32, vp]),
+    "mgf_style_act_fir_tiles": (i32, [i32, i32]),
+    "mgf_style_act_fir_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, f32, i32, i32, i32, i32, f32, f32, vp]),
     "mgf_layer_act_bwd_low_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i64, f32, f32, vp]),
     "mgf_duplex_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mgf_attn_values_grad": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),

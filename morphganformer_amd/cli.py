@@ -40,6 +40,11 @@ def _loop_arguments(p):
                    help="with --mode gradient: optimise the per-layer latent W+ [k, num_ws, D] instead of z (the reference accepts the flag "
                         "and never reads it; in literal mode it stays unused here too)")
     p.add_argument("--percept_weight", type=float, default=1.0, help="coefficient of the LPIPS term (0.5 with --beta 0.5 = 1024_example_percept_MSE.py)")
+    p.add_argument("--pixel-term", choices=["mse", "psnr"], default="mse",
+                   help="psnr = the pixel term of 1024_example_PSNR.py (10 log10(255^2 / MSE), minimised like the script does; use with --no-lpips)")
+    p.add_argument("--pool-above", type=int, default=0,
+                   help="projection_example_v1.py:150-155: block-average generated images taller than this (256 there) by height // N before the "
+                        "image-space losses; the target image is then transformed to that size")
     p.add_argument("--net", type=str, default="squeeze", choices=["squeeze", "vgg", "alex"], help="LPIPS backbone")
     p.add_argument("--no-lpips", action="store_true", help="MSE(+Wing) only, the 1024_example_MSE.py objective")
     p.add_argument("--lpips-backbone", type=str, default=None, metavar="STATE_DICT",
@@ -165,7 +170,7 @@ def main(argv=None):
     from .lpips import PerceptualLoss
     args = ProjectionArgs(step=a.step, lamda=a.lamda, beta=a.beta, lr=a.lr, lr_rampup=a.lr_rampup, lr_rampdown=a.lr_rampdown,
                           noise=a.noise, noise_ramp=a.noise_ramp, truncation_psi=a.truncation_psi, n_mean_latent=a.n_mean_latent,
-                          ratio=a.ratio, percept_weight=a.percept_weight)
+                          ratio=a.ratio, percept_weight=a.percept_weight, pixel_term=a.pixel_term, pool_above=a.pool_above)
     percept = None
     if not a.no_lpips:
         if a.lpips_backbone is None and not a.lpips_random_backbone:
@@ -214,7 +219,8 @@ def main(argv=None):
             dist.barrier()
             dist.destroy_process_group()
         return 0
-    target = drivers.image_transform(a.image, size=a.size, device=G.device)
+    tsize = a.size // (a.size // a.pool_above) if (a.pool_above and a.size > a.pool_above) else a.size       # the size the image-space losses see
+    target = drivers.image_transform(a.image, size=tsize, device=G.device)
     lm_t = lm_s = None
     if a.landmarks:
         lm = np.load(a.landmarks)

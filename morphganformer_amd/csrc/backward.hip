@@ -1254,6 +1254,135 @@ extern "C" int mgf_style_grad_act_bwd_f32(float* style_part, float* dot_part, fl
     return MGF_OK;
 }
 
+// The pair above followed by the blur's gradient, in one pass: layer L is an up-sampling layer without attention (256^2 and larger), so its
+// dz goes through nothing but the adjoint of the 4x4 resample filter (upfirdn2d with pad 2: the [h+1, w+1] map the stride-2 dgrad convolution
+// reads) -- dz itself is never needed in memory.  A workgroup produces a 64 x 64 tile of that map from a 67-row x 72-column window of (x, g):
+// dz is computed element-wise while the window is staged into LDS (every element of the window; the two dot products only over the elements
+// the tile OWNS, rows / columns [tile origin, + 64): every element of the plane is owned by exactly one tile), then the separable blur of
+// csrc/upfirdn2d.hip's fir_up1_sep runs on it.  Traffic per element: 2 x 4 B x 1.18 in, 4 B out, against 12 B + 8.7 B for the two launches.
+struct StyleActFirParams {
+    float* part_s; float* part_dc; float* dt;
+    const float* x; const float* g; const float* s; const float* bias; const float* noise; const float* nstr; const float* f;
+    int noise_n, n, c, h, w, flip, ntiles, tiles_x;
+    float alpha, gain, fir_gain;
+};
+namespace {
+__global__ __launch_bounds__(256) void style_act_fir_bwd_kernel(StyleActFirParams p) {
+    constexpr int T = 64, WV = 18, IH = T + 3, RS = T + 4;
+    __shared__ float4 sx[IH][WV + 1];
+    __shared__ float sfx[4], sfy[4];
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    if (tid < 4) {                                                   // f[jy][jx] = fy[jy] * fx[jx]; the gain goes with fy (fir_up1_sep)
+        const int k = p.flip ? tid : 3 - tid;
+        const float f00 = p.f[0];
+        sfx[tid] = p.f[k] / f00;
+        sfy[tid] = p.f[k * 4] * p.fir_gain;
+    }
+    const int tile = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
+    const int ox0 = (tile % p.tiles_x) * T, oy0 = (tile / p.tiles_x) * T;
+    const int out_h = p.h + 1, out_w = p.w + 1;
+    const int64_t plane = (int64_t)p.h * p.w;
+    const int64_t base = ((int64_t)n * p.c + ch) * plane;
+    const float sv = p.s ? p.s[(int64_t)n * p.c + ch] : 1.f;
+    const float b = p.bias ? p.bias[ch] : 0.f;
+    const float ns = p.noise ? (p.nstr ? *p.nstr : 1.f) : 0.f;
+    const float* nz = p.noise ? p.noise + (int64_t)(p.noise_n > 1 ? n : 0) * plane : nullptr;
+    const float inv_gain = 1.f / p.gain, inv_alpha = 1.f / p.alpha;
+    float acc_s = 0.f, acc_c = 0.f;
+    const int xa = ox0 - 4, iy0 = oy0 - 2;                          // pad 2: output (oy, ox) reads input rows oy - 2 .. oy + 1
+    for (int i = tid; i < IH * WV; i += 256) {
+        const int r = i / WV, v4 = i - r * WV;
+        const int iy = iy0 + r, ix = xa + 4 * v4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {            // (w % 4 == 0: a float4 is inside the row or outside it)
+            const int64_t off = (int64_t)iy * p.w + ix;
+            const float4 gv = *reinterpret_cast<const float4*>(p.g + base + off);
+            const float4 xv = *reinterpret_cast<const float4*>(p.x + base + off);
+            const float4 nv = nz ? *reinterpret_cast<const float4*>(nz + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool own = iy >= oy0 && iy < oy0 + T && ix >= ox0 && ix < ox0 + T;
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, nn[4] = {nv.x, nv.y, nv.z, nv.w};
+            float dz[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dv = sv * gs[e];                         // (what style_grad would have stored: rounded before it is used)
+                const bool pos = xs[e] > 0.f;
+                dz[e] = dv * p.gain * (pos ? 1.f : p.alpha);
+                if (own) {
+                    acc_s += xs[e] * gs[e];
+                    if (p.part_dc) {
+                        const float zv = (pos ? xs[e] : xs[e] * inv_alpha) * inv_gain;
+                        acc_c += dz[e] * (zv - b - nn[e] * ns);
+                    }
+                }
+            }
+            o = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        }
+        sx[r][v4] = o;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    const float fx0 = sfx[0], fx1 = sfx[1], fx2 = sfx[2], fx3 = sfx[3];
+    float hz[7][4];                                                  // horizontal pass: rows 4 ly .. 4 ly + 6, outputs e = 0 .. 3
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const float4 a = sx[4 * ly + r][lx], bq = sx[4 * ly + r][lx + 1], cc = sx[4 * ly + r][lx + 2];
+        const float w[12] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w, cc.x, cc.y, cc.z, cc.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hz[r][e] = w[2 + e] * fx0 + w[3 + e] * fx1 + w[4 + e] * fx2 + w[5 + e] * fx3;
+    }
+    const float fy0 = sfy[0], fy1 = sfy[1], fy2 = sfy[2], fy3 = sfy[3];
+    // rows of w + 1 floats start at any alignment: the tile goes back through LDS and leaves as whole 256-byte row segments
+    float* so = reinterpret_cast<float*>(&sx[0][0]);
+    static_assert(T * RS <= IH * (WV + 1) * 4, "output tile must fit in the input window's LDS");
+    __syncthreads();                                                 // every lane has read its window rows
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float4 o;
+        o.x = hz[a][0] * fy0 + hz[a + 1][0] * fy1 + hz[a + 2][0] * fy2 + hz[a + 3][0] * fy3;
+        o.y = hz[a][1] * fy0 + hz[a + 1][1] * fy1 + hz[a + 2][1] * fy2 + hz[a + 3][1] * fy3;
+        o.z = hz[a][2] * fy0 + hz[a + 1][2] * fy1 + hz[a + 2][2] * fy2 + hz[a + 3][2] * fy3;
+        o.w = hz[a][3] * fy0 + hz[a + 1][3] * fy1 + hz[a + 2][3] * fy2 + hz[a + 3][3] * fy3;
+        *reinterpret_cast<float4*>(so + (4 * ly + a) * RS + 4 * lx) = o;
+    }
+    __syncthreads();
+    const int col = tid & 63, r0 = tid >> 6;
+    if (ox0 + col < out_w) {
+        float* yb = p.dt + ((int64_t)n * p.c + ch) * ((int64_t)out_h * out_w) + ox0 + col;
+#pragma unroll
+        for (int k = 0; k < T / 4; ++k) {
+            const int row = r0 + 4 * k;
+            if (oy0 + row < out_h) yb[(int64_t)(oy0 + row) * out_w] = so[row * RS + col];
+        }
+    }
+    const float ts = block_sum(acc_s, red);
+    if (tid == 0) p.part_s[((int64_t)n * p.c + ch) * p.ntiles + tile] = ts;
+    if (p.part_dc) {
+        __syncthreads();
+        const float tc = block_sum(acc_c, red);
+        if (tid == 0) p.part_dc[((int64_t)n * p.c + ch) * p.ntiles + tile] = tc;
+    }
+}
+}  // namespace
+
+extern "C" int32_t mgf_style_act_fir_tiles(int32_t h, int32_t w) { return (int32_t)(mgf_cdiv(h + 1, 64) * mgf_cdiv(w + 1, 64)); }
+
+extern "C" int mgf_style_act_fir_bwd_f32(float* style_part, float* dot_part, float* dt, const float* x, const float* g, const float* s,
+                                         const float* bias, const float* noise, const float* noise_strength, int32_t noise_n, const float* f,
+                                         int32_t flip, float fir_gain, int32_t n, int32_t c, int32_t h, int32_t w, float alpha, float gain,
+                                         mgf_stream_t stream) {
+    MGF_REQUIRE(style_part && dt && x && g && f && n >= 1 && c >= 1 && h >= 1 && w >= 4, MGF_EINVAL, "style_act_fir_bwd: bad arguments");
+    MGF_REQUIRE(alpha != 0.f && gain != 0.f, MGF_EINVAL, "style_act_fir_bwd: alpha and gain must be non-zero (the activation is inverted)");
+    MGF_REQUIRE(w % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)g % 16) == 0 && (!noise || ((uintptr_t)noise % 16) == 0), MGF_EUNSUPPORTED,
+                "style_act_fir_bwd: needs 16-byte aligned maps with w %% 4 == 0 (w = %d)", w);
+    MGF_REQUIRE(n <= 65535 && c <= 65535, MGF_ETOOBIG, "style_act_fir_bwd: n and c must be <= 65535");
+    StyleActFirParams p{style_part, dot_part, dt, x, g, s, bias, noise, noise_strength, f, noise_n, n, c, h, w, flip & 1,
+                        mgf_style_act_fir_tiles(h, w), (int)mgf_cdiv(w + 1, 64), alpha, gain, fir_gain};
+    hipLaunchKernelGGL(style_act_fir_bwd_kernel, dim3(p.ntiles, c, n), dim3(256), 0, (hipStream_t)stream, p);
+    MGF_CHECK_LAUNCH("style_act_fir_bwd");
+    return MGF_OK;
+}
+
 extern "C" int mgf_duplex_attention_bwd(float* dx, float* dg, float* probs, const float* da, const float* x, const float* wqc,
                                         const float* spos, const float* vwb, int32_t n, int32_t c, int32_t f, int32_t t,
                                         mgf_stream_t stream) {

@@ -1009,14 +1009,20 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     static const bool persist_off = [] { const char* e = mgf_knob("MGF_W3_PERSIST"); return e && e[0] == '0'; }();
     static const int strip_env = [] { const char* e = mgf_knob("MGF_W3_STRIP"); return e ? atoi(e) : 0; }();
     const int strip_len = strip_env > 0 ? std::min(strip_env, p.tiles_x) : std::min(p.tiles_x, 32);     // (1024^2 at 32 samples, us: strips of 4 / 8 / 16 / 32 tiles 3707 / 3536 / 3472 / 3428)
+    // vertical strips where the tile rows divide into whole strips (MGF_W3_VERT=0: the horizontal walk, for A/B runs).  A strip is as long
+    // as the launch can afford: 32 tiles when that still gives the chip's 512 workgroup slots four rounds of work (2048 workgroups), else 16,
+    // 8 or 4 -- a single 1024^2 image (gradient mode, one target) is 2048 strips of 4 tiles, and the persistent form's resident weights and
+    // cross-tile prefetch still beat the one-shot kernel there (strips of 4 / 8 / 16 / 32 at 32 samples: 3707 / 3536 / 3472 / 3428 us)
+    static const bool vert_off = [] { const char* e = mgf_knob("MGF_W3_VERT"); return e && e[0] == '0'; }();
+    int vlen = std::min(p.tiles_y, strip_env > 0 ? strip_env : 32);
+    if (strip_env <= 0)
+        while (vlen > 4 && vlen % 2 == 0 && p.tiles_y % vlen == 0 && (int64_t)n * p.tiles_x * (p.tiles_y / vlen) * p.co_tiles < 2048) vlen /= 2;
+    const bool vert_ok = !vert_off && p.tiles_y % vlen == 0;
+    const int64_t pcount = vert_ok ? (int64_t)n * p.tiles_x * (p.tiles_y / vlen) * p.co_tiles : (int64_t)n * (p.tiles_x / strip_len) * p.tiles_y * p.co_tiles;
     const bool persist = !persist_off && (!forced || force_persist) && shape == 11 && !odd && y_choff == 0 && p.y_batch == (int64_t)cout * h * w && cin == 32 &&
-                         w % 32 == 0 && h % 4 == 0 && p.tiles_x % strip_len == 0 && (!rgb || cout == 32) &&
-                         (force_persist || (int64_t)n * (p.tiles_x / strip_len) * p.tiles_y * p.co_tiles >= 2048);
+                         w % 32 == 0 && h % 4 == 0 && p.tiles_x % strip_len == 0 && (!rgb || cout == 32) && (force_persist || pcount >= 2048);
     if (persist) {
-        // vertical strips where the tile rows divide into whole strips (MGF_W3_VERT=0: the horizontal walk, for A/B runs)
-        static const bool vert_off = [] { const char* e = mgf_knob("MGF_W3_VERT"); return e && e[0] == '0'; }();
-        const int vlen = std::min(p.tiles_y, strip_env > 0 ? strip_env : 32);
-        p.vert = (!vert_off && p.tiles_y % vlen == 0) ? 1 : 0;
+        p.vert = vert_ok ? 1 : 0;
         if (p.vert) { p.strip_len = vlen; p.strips_x = p.tiles_x; p.strips_y = p.tiles_y / vlen; }
         else { p.strip_len = strip_len; p.strips_x = p.tiles_x / strip_len; p.strips_y = p.tiles_y; }
         int64_t pblocks = (int64_t)n * p.strips_x * p.strips_y * p.co_tiles;

@@ -278,7 +278,9 @@ def project_many(G, targets, landmarks=None, dynamic=False, lockstep=1, **kw):
     on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
     # an item is a device tensor, an image path, or a callable that produces the tensor when the item is taken (a rank only ever touches its own)
-    load = lambda t: t if isinstance(t, torch.Tensor) else (t() if callable(t) else image_transform(t, size=G.img_resolution, device=G.device))
+    pa = getattr(kw.get("args"), "pool_above", 0) or 0           # (projection_example_v1.py: the target at the size the losses see)
+    tsize = G.img_resolution // (G.img_resolution // pa) if (pa and G.img_resolution > pa) else G.img_resolution
+    load = lambda t: t if isinstance(t, torch.Tensor) else (t() if callable(t) else image_transform(t, size=tsize, device=G.device))
     w_plus = kw.get("latent_space", "z") == "w+"
     lshape = (G.cfg.k, G.cfg.num_ws, G.cfg.w_dim) if w_plus else (G.cfg.k, G.cfg.z_dim)      # a W+ result is [k, num_ws, D] per item
     width = int(np.prod(lshape)) + 3

@@ -32,6 +32,14 @@ FUSE_STYLE_ACT = os.environ.get("MGF_FUSE_STYLE_ACT", "1") != "0"      # tuning 
 # the attention layers' value gradients and demodulation dot products -- by-products nothing on the critical path waits for -- for all layers
 # in two launches at the end of the pass (0: three small launches per layer where they arise; tuning / equivalence test)
 DEFER_ATTN_GRADS = os.environ.get("MGF_DEFER_ATTN_GRADS", "1") != "0"
+# the resnet skip branch's gradient (2x FIR down-sampling + 1x1 conv on transposed weights: memory bound, depends only on the block's output
+# gradient) on the generator's side stream next to the block's main chain, from this map size up; it then writes d(x_in) first and the main
+# chain's style-gradient kernel accumulates into it.  0 = in line, after the main chain (a forked graph branch costs ~10 us on this runtime:
+# it only pays where the branch is long)
+SKIP_STREAM_MIN_RES = int(os.environ.get("MGF_GRAD_SKIP_STREAM", "0"))
+# up-sampling layers without attention (256^2 and larger): conv1's style gradient, conv0's activation backward AND the adjoint of conv0's blur in
+# one pass (mgf_style_act_fir_bwd_f32) -- conv0's dz never reaches memory; 0 = the blur's gradient as its own upfirdn2d launch (equivalence test)
+FUSE_ACT_FIR = os.environ.get("MGF_FUSE_ACT_FIR", "1") != "0"
 
 
 class GeneratorGrad:
@@ -74,15 +82,23 @@ class GeneratorGrad:
         G, P, cfg, L = self.G, self.G.plan, self.G.cfg, _lib.lib()
         D, T = cfg.w_dim, cfg.k - 1
         self._n, self._gen = n, G.ws_gen
+        self._fir_mode = self._want_fir_mode()
         # per-slice partial sums of mgf_attn_values_grad_ws (allocated here, not at first use: never inside a captured launch sequence)
         cmax = max([lp.attn.c for lp in P.layers if lp.attn is not None] or [1])
         self.avg_ws = torch.empty(int(L.mgf_attn_values_grad_workspace_floats(n, cmax)), dtype=torch.float32, device=G.device)
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=G.device)
         self.ds_part, self.dc_part, self.dvwb = {}, {}, {}
         sj, aj = [], []
+        by_name = {lp.name: lp for lp in P.layers}
         for lp in P.layers:
             in_res = lp.res // lp.up
             sc, dc = int(L.mgf_bwd_chunks(in_res * in_res)), int(L.mgf_bwd_chunks(lp.res * lp.res))
+            # the fused style / activation / blur-gradient pass leaves one partial per 64 x 64 tile instead of one per 4096-element chunk:
+            # conv1's <x, g> partials and conv0's <dz, c> partials of the blocks it serves
+            if self._fir_mode and lp.name.endswith(".conv1") and self._fir_block(by_name.get(lp.name[:-1] + "0"), lp):
+                sc = int(L.mgf_style_act_fir_tiles(lp.res, lp.res))
+            if self._fir_mode and lp.name.endswith(".conv0") and self._fir_block(lp, by_name.get(lp.name[:-1] + "1")):
+                dc = int(L.mgf_style_act_fir_tiles(lp.res, lp.res))
             self.ds_part[lp.name] = e(n, lp.cin, sc)
             if lp.demod:
                 self.dc_part[lp.name] = e(n, lp.cout, dc)
@@ -111,6 +127,16 @@ class GeneratorGrad:
         self.style_slots = torch.tensor([lp.slot for lp in P.layers], dtype=torch.int64, device=G.device)
         self.attn_slots = torch.tensor([lp.slot for lp in P.layers if lp.attn is not None], dtype=torch.int64, device=G.device)
         self.max_channels = max(max(lp.cin, lp.cout) for lp in P.layers)
+
+    def _want_fir_mode(self):
+        return bool(FUSE_ACT_FIR and FUSE_STYLE_ACT and self.debug is None)
+
+    @staticmethod
+    def _fir_block(l0, l1):
+        """Does the (conv0, conv1) pair of a block take the fused style / activation / blur-gradient pass?  conv0 an up-sampling layer with
+        bias / activation and no attention, 16-byte rows."""
+        return (l0 is not None and l1 is not None and l0.kind == "tconv" and l0.attn is None and l1.attn is None and l0.bias is not None
+                and l0.res % 4 == 0 and l0.res >= 64)
 
     def _build_deferred_attention(self, n):
         """Per-layer buffers (dc, dg, probabilities, slice partials) and the device job table of mgf_attn_grad_multi.  The buffers must
@@ -193,8 +219,10 @@ class GeneratorGrad:
             G.fuse_torgb, G.fuse_skip_up, G.map_save = True, keep_up, None
         self.z = None if z is None else z.contiguous().float()
         self.psi = float(truncation_psi) if ws is None else 1.0
-        if (self._n, self._gen) != (G.n, G.ws_gen):     # after G: its style / demod arenas (pointed to by the job tables) are sized by then;
-            self._alloc(G.n)                            # a workspace evicted and re-created at the same batch size has a new generation id
+        if (self._n, self._gen, getattr(self, "_fir_mode", None)) != (G.n, G.ws_gen, self._want_fir_mode()):
+            # after G: its style / demod arenas (pointed to by the job tables) are sized by then; a workspace evicted and re-created at the same
+            # batch size has a new generation id; the partial-sum layout depends on which fused passes run
+            self._alloc(G.n)
         return img
 
     # ------------------------------------------------------------------ backward
@@ -217,12 +245,15 @@ class GeneratorGrad:
                                                h * w, alpha, gain, st), "layer_act_bwd")
         return dz
 
-    def _conv_bwd(self, lp, dz, y_out, c_pre, x_in):
+    def _conv_bwd(self, lp, dz, y_out, c_pre, x_in, dT=None):
         """dz -> g = the data gradient of the layer's convolution BEFORE the style scale (d(x_in) = s * g): attention backward when the
-        layer has one, then the convolution on the transposed taps."""
+        layer has one, then the convolution on the transposed taps.  dT: the blur's adjoint of dz, already computed by the fused pass
+        (_style_act_fir_bwd; dz is then None)."""
         G, L, st = self.G, _lib.lib(), _lib.stream_ptr()
         n, c, h, w = y_out.shape
         hw = h * w
+        if dT is not None:
+            return cv.conv_forward(dT, self.T[lp.name], stride=2, pad=(0, 0), in_scale=G._d(lp) if lp.demod else None, out=self.buf("g", x_in.shape))
         dc = dz
         if lp.attn is not None and self.attn_defer is not None and self.debug is None:
             # deferred form: this layer's dc / dg / probabilities stay in buffers of their own; the value gradient and the demodulation
@@ -260,14 +291,14 @@ class GeneratorGrad:
             return cv.winograd_forward(dc, self.Tw[lp.name], in_scale=d, out=self.buf("g", x_in.shape))
         return cv.conv_forward(dc, self.T[lp.name], pad=pad, in_scale=d, out=self.buf("g", x_in.shape))
 
-    def _style_bwd(self, lp, g, x_in, dx_role):
-        """<x_in, g> partials of the style gradient and d(x_in) = s * g."""
+    def _style_bwd(self, lp, g, x_in, dx_role, accumulate=False):
+        """<x_in, g> partials of the style gradient and d(x_in) (+)= s * g."""
         G, L, st = self.G, _lib.lib(), _lib.stream_ptr()
         n = x_in.shape[0]
         dx = self.buf(dx_role, x_in.shape)
         ci, hi = x_in.shape[1], x_in.shape[2] * x_in.shape[3]
         _lib.check(L.mgf_style_grad_f32(self.ds_part[lp.name].data_ptr(), dx.data_ptr(), x_in.data_ptr(), g.data_ptr(),
-                                        G._s(lp).data_ptr(), n, ci, hi, 0, st), "style_grad")
+                                        G._s(lp).data_ptr(), n, ci, hi, int(accumulate), st), "style_grad")
         return dx
 
     def _style_act_bwd(self, lp, g, prev, y_prev, residual=None, dx_role=None, residual_low=None):
@@ -290,6 +321,20 @@ class GeneratorGrad:
                                                 _lib.ptr(prev.noise_strength) if noise is not None else None, noise_n,
                                                 n, c, h * w, alpha, gain, st), "style_grad_act_bwd")
         return (dz, dx) if with_res else dz
+
+    def _style_act_fir_bwd(self, lp, g, prev, y_prev):
+        """_style_act_bwd of (lp, prev) followed by the adjoint of prev's blur, in one pass (mgf_style_act_fir_bwd_f32): returns
+        dT [n, c, h + 1, w + 1], the map prev's stride-2 data-gradient convolution reads."""
+        G, L, st = self.G, _lib.lib(), _lib.stream_ptr()
+        n, c, h, w = y_prev.shape
+        mode, noises = G.last_noise
+        noise, noise_n = G._noise_for(prev, mode, noises)
+        dT = self.buf("dT", (n, c, h + 1, w + 1))
+        _lib.check(L.mgf_style_act_fir_bwd_f32(self.ds_part[lp.name].data_ptr(), self.dc_part[prev.name].data_ptr() if prev.demod else None,
+                                               dT.data_ptr(), y_prev.data_ptr(), g.data_ptr(), G._s(lp).data_ptr(), _lib.ptr(prev.bias),
+                                               _lib.ptr(noise), _lib.ptr(prev.noise_strength) if noise is not None else None, noise_n,
+                                               G.plan.fir.data_ptr(), 1, 4.0, n, c, h, w, 0.2, prev.act_gain, st), "style_act_fir_bwd")
+        return dT
 
     def _layer_bwd(self, lp, dy, y_out, c_pre, residual, x_in, dx_role):
         """One SynthesisLayer.  dy: gradient wrt the layer output y_out (= lrelu(c [attention] + noise + bias) * gain + residual);
@@ -373,6 +418,16 @@ class GeneratorGrad:
             d_out = dx
             if self.debug is not None:
                 self.debug[f"synthesis.b{res}:dout"] = d_out.clone()
+            side = bool(SKIP_STREAM_MIN_RES) and res >= SKIP_STREAM_MIN_RES and self.debug is None
+            if side:
+                # skip branch first, on the side stream: y = upfirdn(conv1x1(x), up=2)  ->  d(x) = conv1x1^T(upfirdn(dy, down=2)) written
+                # into d(x_in); the main chain's style-gradient kernel adds its s g to it after the join
+                main = torch.cuda.current_stream(G.device)
+                G.side.wait_stream(main)
+                with torch.cuda.stream(G.side):
+                    dlow = self.buf("dlow", B["skip_low"].shape)
+                    cv.upfirdn_into(dlow, d_out, P.fir, up=1, down=2, pad=(1, 1, 1, 1), gain=4.0, flip=True)
+                    cv.conv_forward(dlow, self.Tskip[res], out=self.buf("dxin", x_prev.shape))
             # conv1 then conv0: conv1's input IS conv0's output y0, so conv1's style gradient and conv0's activation backward are one
             # pass over (y0, g) -- d(y0) = s g is never stored (MGF_FUSE_STYLE_ACT=0: the two kernels in sequence, bit-identical)
             if res == R and dz1_top is not None:
@@ -382,19 +437,27 @@ class GeneratorGrad:
             else:
                 dz1 = self._act_bwd(l1, d_out, y1, B["skip"])
             g1 = self._conv_bwd(l1, dz1, y1, B["conv1"] if att else None, y0)
-            if FUSE_STYLE_ACT and self.debug is None:
+            dT0 = None
+            if self._fir_mode and self._fir_block(l0, l1):
+                dT0 = self._style_act_fir_bwd(l1, g1, l0, y0)       # conv0's dz goes straight through the blur's adjoint: never stored
+                dz0 = None
+            elif FUSE_STYLE_ACT and self.debug is None:
                 dz0 = self._style_act_bwd(l1, g1, l0, y0)
             else:
                 dmid = self._style_bwd(l1, g1, y0, "dmid")
                 if self.debug is not None:
                     self.debug[f"synthesis.b{res}:dmid"] = dmid.clone()
                 dz0 = self._act_bwd(l0, dmid, y0, None)
-            g0 = self._conv_bwd(l0, dz0, y0, B["conv0"] if att else None, x_prev)
-            dxin = self._style_bwd(l0, g0, x_prev, "dxin")
-            # skip branch: y = upfirdn(conv1x1(x), up=2, pad (2,1,2,1), gain 4)  ->  conv1x1^T(upfirdn(dy, down=2, pad (1,1,1,1)))
-            dlow = self.buf("dlow", B["skip_low"].shape)
-            cv.upfirdn_into(dlow, d_out, P.fir, up=1, down=2, pad=(1, 1, 1, 1), gain=4.0, flip=True)
-            cv.conv_forward(dlow, self.Tskip[res], epilogue=_lib.make_epilogue(residual=dxin), out=dxin)
+            g0 = self._conv_bwd(l0, dz0, y0, B["conv0"] if att else None, x_prev, dT=dT0)
+            if side:
+                main.wait_stream(G.side)
+                dxin = self._style_bwd(l0, g0, x_prev, "dxin", accumulate=True)
+            else:
+                dxin = self._style_bwd(l0, g0, x_prev, "dxin")
+                # skip branch: y = upfirdn(conv1x1(x), up=2, pad (2,1,2,1), gain 4)  ->  conv1x1^T(upfirdn(dy, down=2, pad (1,1,1,1)))
+                dlow = self.buf("dlow", B["skip_low"].shape)
+                cv.upfirdn_into(dlow, d_out, P.fir, up=1, down=2, pad=(1, 1, 1, 1), gain=4.0, flip=True)
+                cv.conv_forward(dlow, self.Tskip[res], epilogue=_lib.make_epilogue(residual=dxin), out=dxin)
             dx = dxin
         if self.attn_defer is not None and self.debug is None:
             self._deferred_attention_launch()

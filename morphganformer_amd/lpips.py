@@ -43,6 +43,11 @@ FUSE_TAP_RELU = os.environ.get("MGF_FUSE_TAP_RELU", "1") != "0"
 POOL_ARGMAX = os.environ.get("MGF_POOL_ARGMAX", "1") != "0"
 # gradient mode: the tap distances also store their per-pixel sums and the tap gradients read them instead of sweeping both maps again
 TAP_STATS = os.environ.get("MGF_TAP_STATS", "1") != "0"
+# ONE image per forward (gradient mode with a single target): a Fire's two expand branches run as ONE 3x3 launch -- expand1x1's weights sit in
+# the centre tap of 2 x ex output channels' worth of 3x3 kernels -- and their data gradients as one 3x3 launch over the concatenated gradient.
+# At one image these layers sit on their launch latency (8 - 25 us each), so the extra matrix work of the 1x1 computed as a 3x3 is free and a
+# launch per Fire and direction disappears; from two images on the separate launches are kept (0: always separate; the equivalence test)
+MERGE_FIRE = os.environ.get("MGF_LPIPS_MERGE_FIRE", "1") != "0"
 
 
 def random_squeeze_backbone(seed=0):
@@ -261,6 +266,7 @@ class SqueezeFeatures:
         dev = self.device
         if share is not None:
             self.c0, self.fires, self.wino3 = share.c0, share.fires, share.wino3          # packed weights are size independent
+            self.merged, self.wino3m = share.merged, share.wino3m
             self.stem_w, self.stem_b = share.stem_w, share.stem_b
             self.gp, self.gpw = share.gp, share.gpw
         else:
@@ -281,7 +287,20 @@ class SqueezeFeatures:
                                         for nm in ("squeeze", "expand1x1", "expand3x3"))
                 if USE_WINOGRAD_LPIPS:
                     self.wino3[idx] = cv.winograd2_weights(t32(g(f"{p}.expand3x3.weight")))
+            # the merged expand launch of the one-image path (MERGE_FIRE): [2 ex, sq, 3, 3], expand1x1 in the centre tap of the first ex kernels
+            self.merged, self.wino3m = {}, {}
+            for idx in FIRES:
+                p = f"features.{idx}"
+                w1, w3 = g(f"{p}.expand1x1.weight"), g(f"{p}.expand3x3.weight")
+                wm = np.zeros((2 * w1.shape[0], w1.shape[1], 3, 3))
+                wm[:w1.shape[0], :, 1, 1] = w1[:, :, 0, 0]
+                wm[w1.shape[0]:] = w3
+                bm = np.concatenate([g(f"{p}.expand1x1.bias"), g(f"{p}.expand3x3.bias")])
+                self.merged[idx] = (cv.pack_weights(t32(wm)), t32(bm))
+                if USE_WINOGRAD_LPIPS:
+                    self.wino3m[idx] = cv.winograd2_weights(t32(wm))
         self.n = n
+        self.merge = MERGE_FIRE and n == 1
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         hh, ww = (h - 3) // 2 + 1, (w - 3) // 2 + 1
         self.shapes = {1: (64, hh, ww)}
@@ -312,12 +331,24 @@ class SqueezeFeatures:
                     w = p3.wp[:, :, :p3.cout].reshape(3, 3, p3.cin, p3.cout).permute(3, 2, 0, 1)        # [E, S, kh, kw]
                     # (the form-3 image whatever this instance's map size: the packs are shared between sizes)
                     self.gpw[idx] = cv.winograd2_weights(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), 1.0)
+            for idx, (pm, _) in self.merged.items():
+                # the merged data gradient: one true convolution over the concatenated gradient [d expand1x1 | d expand3x3] (2 ex -> sq channels)
+                self.gp[("m", idx)] = cv.transpose_packed(pm, True)
+                if USE_WINOGRAD_LPIPS and pm.cin % 32 == 0:
+                    w = pm.wp[:, :, :pm.cout].reshape(3, 3, pm.cin, pm.cout).permute(3, 2, 0, 1)        # [2 ex, sq, kh, kw]
+                    self.gpw[("m", idx)] = cv.winograd2_weights(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), 1.0)
         if getattr(self, "gbuf", None) is None:
             e = lambda t: torch.empty_like(t)
             self.gbuf = {idx: e(t) for idx, t in self.buf.items()}
             self.gsq = {idx: e(t) for idx, t in self.sq.items()}
-            self.gex = {idx: (e(self.buf[idx][:, :FIRES[idx][2]].contiguous()), e(self.buf[idx][:, FIRES[idx][2]:].contiguous()))
-                        for idx in FIRES}
+            if self.merge:
+                # one image: the two halves of ONE [1, 2 ex, h, w] tensor are dense blocks, so the kernels that write the split gradient
+                # fill the merged launch's input in place
+                self.gcat = {idx: e(self.buf[idx]) for idx in FIRES}
+                self.gex = {idx: (self.gcat[idx][:, :FIRES[idx][2]], self.gcat[idx][:, FIRES[idx][2]:]) for idx in FIRES}
+            else:
+                self.gex = {idx: (e(self.buf[idx][:, :FIRES[idx][2]].contiguous()), e(self.buf[idx][:, FIRES[idx][2]:].contiguous()))
+                            for idx in FIRES}
             n, _, h1, w1 = self.buf[1].shape
             self.gimg = torch.empty([n, 3, 2 * h1 + 1, cv.tconv_pitch(w1)], dtype=torch.float32, device=self.device)
 
@@ -366,8 +397,17 @@ class SqueezeFeatures:
                 _lib.check(L.mgf_relu_bwd_split_f32(da.data_ptr(), db.data_ptr(), gh.data_ptr(), h.data_ptr(), n, c, ex, hh * ww, st),
                            "relu_bwd_split")
             s, gs = self.sq[idx], self.gsq[idx]
-            cv.conv_forward(da, e1T, out=gs)
-            if idx in self.gpw and cv.winograd_fills_chip(n, gs.shape[1], hh, ww):
+            if self.merge:
+                gc = self.gcat[idx]
+                if ("m", idx) in self.gpw and min(hh, ww) > 16 and cv.winograd_fills_chip(n, gs.shape[1], hh, ww):
+                    cv.winograd_forward(gc, self.gpw[("m", idx)], out=gs)
+                else:
+                    cv.conv_forward(gc, self.gp[("m", idx)], pad=(1, 1), out=gs)
+            else:
+                cv.conv_forward(da, e1T, out=gs)
+            if self.merge:
+                pass
+            elif idx in self.gpw and cv.winograd_fills_chip(n, gs.shape[1], hh, ww):
                 cv.winograd_forward(db, self.gpw[idx], epilogue=_lib.make_epilogue(residual=gs), out=gs)
             else:
                 cv.conv_forward(db, e3T, pad=(1, 1), epilogue=_lib.make_epilogue(residual=gs), out=gs)
@@ -433,6 +473,16 @@ class SqueezeFeatures:
                 s = cv.conv_forward(h, ps, epilogue=_lib.make_epilogue(bias=bs, act="relu"), out=self.sq[idx])
                 y = dest(idx)
                 ex = p1.cout
+                if self.merge:
+                    pm, bm = self.merged[idx]
+                    if idx in self.wino3m and min(s.shape[2:]) > 16 and cv.winograd_fills_chip(s.shape[0], 2 * ex, s.shape[2], s.shape[3]):
+                        cv.winograd2_forward(s, self.wino3m[idx], epilogue=_lib.make_epilogue(bias=bm, act="relu"), out=y)
+                    else:
+                        cv.conv_forward(s, pm, pad=(1, 1), epilogue=_lib.make_epilogue(bias=bm, act="relu"), out=y)
+                    h = y
+                    if idx in TAPS_AFTER:
+                        taps.append(h)
+                    continue
                 cv.conv_forward(s, p1, epilogue=_lib.make_epilogue(bias=b1, act="relu"), out=y, out_choff=0)
                 # Winograd when its grid (no split-K) fills the chip: the 25-candidate literal iteration, not a single small image
                 if idx in self.wino3 and min(s.shape[2:]) > 16 and cv.winograd_fills_chip(s.shape[0], ex, s.shape[2], s.shape[3]):

@@ -50,6 +50,13 @@ class ProjectionArgs:
     ratio: float = 1.0
     percept_weight: float = 1.0     # coefficient of the LPIPS term: 1 in the Wing/LPIPS/MSE drivers, 0.5 in 1024_example_percept_MSE.py:147
     min_loss_init: float = 100.0
+    # "mse": beta * MSE(img, target), the drivers' pixel term.  "psnr": the pixel term of 1024_example_PSNR.py:113-114,158 --
+    # 10 log10(255^2 / mean((img - target)^2)) on the [-1, 1] float images, MINIMISED like every other loss of these loops (:173-175 keeps
+    # the candidate with the smallest value; the script's objective as written, not a claim that it is a sensible one)
+    pixel_term: str = "mse"
+    # projection_example_v1.py:150-155: a generated image taller than `pool_above` pixels is block-averaged by height // pool_above before
+    # the image-space losses (the target is then given at the pooled size, :84-92 resize it to 256); 0 = off (the 1024 drivers)
+    pool_above: int = 0
 
 
 def get_lr(t, initial_lr, rampdown=0.25, rampup=0.05):
@@ -217,6 +224,8 @@ class ProjectionEngine:
         self.w_loss = torch.zeros(B, dtype=torch.float64, device=dev)
         self.scratch = torch.empty(B * int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=dev)
         self._arange = torch.arange(B, dtype=torch.int64, device=dev)
+        assert a.pixel_term in ("mse", "psnr"), a.pixel_term
+        self._init_pool(B)
         if self.percept is not None:
             self.percept.set_target(self.target)
         self.biometric, self.gamma = biometric, float(gamma)
@@ -263,6 +272,28 @@ class ProjectionEngine:
             self._parity = 0
             self._primed = False
 
+    def _init_pool(self, B):
+        """projection_example_v1.py:150-155: images above `pool_above` pixels are block-averaged by height // pool_above in front of the
+        image-space losses; the target comes at the pooled size."""
+        a, G = self.args, self.G
+        r = G.cfg.img_resolution
+        self.pool_factor = r // a.pool_above if (a.pool_above and r > a.pool_above) else 1
+        want = r // self.pool_factor
+        if tuple(self.target.shape[-2:]) != (want, want):
+            raise _lib.MgfError(f"projection: the target is {tuple(self.target.shape[-2:])}, the image-space losses see {want}x{want} "
+                                f"(generator {r}x{r}, pool_above={a.pool_above})")
+        if self.pool_factor > 1:
+            f = self.pool_factor
+            # the block mean as the library's own upfirdn2d: an f x f box filter of weight 1 / f^2, down-sampling by f, no padding
+            self.pool_box = torch.full([f, f], 1.0 / (f * f), dtype=torch.float32, device=self.device)
+            self.pooled = torch.empty(B, G.cfg.img_channels, want, want, dtype=torch.float32, device=self.device)
+
+    def _pooled(self, img):
+        if self.pool_factor == 1:
+            return img
+        from . import conv as cv
+        return cv.upfirdn_into(self.pooled[:img.shape[0]], img, self.pool_box, up=1, down=self.pool_factor, pad=(0, 0, 0, 0), gain=1.0)
+
     # ------------------------------------------------------------------ one iteration
     def _iteration(self):
         """`batch` consecutive steps of the loop: perturb -> generator -> losses -> in-order best-so-far selection."""
@@ -279,6 +310,7 @@ class ProjectionEngine:
 
     def _loss_phase(self, img, latent_n):
         L, st, a, B = _lib.lib(), _lib.stream_ptr(), self.args, self.batch
+        full_img, img = img, self._pooled(img)              # (the improvement trail keeps the image as generated)
         if self.percept is not None:
             self.percept.distance_into(self.p_loss, img)
             if a.percept_weight != 1.0:
@@ -289,7 +321,10 @@ class ProjectionEngine:
             per = img.numel() // B
             _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), B, per, 0, 1.0, 0,
                                      self.scratch.data_ptr(), st), "mse")
-        self._landmarks(img)
+            if a.pixel_term == "psnr":
+                # 10 * np.log10(peak ** 2 / np.mean(d ** 2)) with peak = 255., in float32 like the script's numpy (1024_example_PSNR.py:113-114)
+                self.mse_loss.reciprocal_().mul_(65025.0).log10_().mul_(10.0)
+        self._landmarks(full_img)
         if self.use_wing and self.wing_kind == "wing":
             _lib.check(L.mgf_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), B,
                                            self.lm_target.numel(), 10.0, 2.0, self.step_ctr.data_ptr(), self.lm_steps.shape[0] - 1, st),
@@ -309,7 +344,7 @@ class ProjectionEngine:
                                      self.keep_images, _lib.ptr(self.trail_steps if keep else None),
                                      _lib.ptr(self.trail_losses if keep else None), st), "select_best")
         if keep:
-            _lib.check(L.mgf_keep_improvements(self.trail_imgs.data_ptr(), img.data_ptr(), self.trail_imgs.shape[1],
+            _lib.check(L.mgf_keep_improvements(self.trail_imgs.data_ptr(), full_img.data_ptr(), self.trail_imgs.shape[1],
                                                self.take_slot.data_ptr(), B, st), "keep_improvements")
 
     def _landmarks(self, img):
@@ -683,6 +718,9 @@ class GradientProjectionEngine(ProjectionEngine):
             assert landmark_fn is None and landmark_model is None, "landmark detectors are wired for one target per engine"
         self.targets = B
         a, dev = self.args, self.device
+        if a.pixel_term != "mse" or a.pool_above:
+            raise _lib.MgfError("GradientProjectionEngine: pixel_term='psnr' / pool_above are literal-mode objectives (the PSNR / v1 drivers "
+                                "sever the gradient like every other driver; only the Wing / LPIPS / MSE / biometric terms have backward passes)")
         if biometric is not None and hasattr(biometric.embedder, "keep_activations"):
             biometric.embedder.keep_activations = True          # (the FaceNet embedder re-uses its buffers block after block otherwise)
         self.gg = GeneratorGrad(G)
@@ -743,6 +781,7 @@ class GradientProjectionEngine(ProjectionEngine):
         if biometric is not None:
             biometric.set_target(self.target)                 # one embedding per target
         self.use_graph, self.graph, self.pipeline, self.keep_images = use_graph, None, False, 0
+        self.pool_factor = 1
 
     def _state(self):
         return super()._state() + (self.latent_in, self.exp_avg, self.exp_avg_sq, self.adam_t)

@@ -52,6 +52,25 @@ def mse_ref(a, b):
     return (a - b).square().mean()
 
 
+def psnr_ref(p0, p1, peak=255.0):
+    """1024_example_PSNR.py:113-114: `10*np.log10(peak**2/np.mean((1.*p0-1.*p1)**2))` on the flattened float32 images (the driver passes
+    the [-1, 1] images and keeps the default peak of 255, :158)."""
+    import numpy as np
+    a, b = np.asarray(p0, dtype=np.float32).reshape(-1), np.asarray(p1, dtype=np.float32).reshape(-1)
+    return 10 * np.log10(peak ** 2 / np.mean((1. * a - 1. * b) ** 2))
+
+
+def pool_above_ref(img, above=256):
+    """projection_example_v1.py:148-155: an image taller than `above` is averaged over factor x factor blocks, factor = height // above."""
+    import numpy as np
+    x = np.asarray(img)
+    batch, channel, height, width = x.shape
+    if height > above:
+        factor = height // above
+        x = x.reshape(batch, channel, height // factor, factor, width // factor, factor).mean((3, 5))
+    return x
+
+
 def get_lr_ref(t, initial_lr, rampdown=0.25, rampup=0.05):
     ramp = min(1.0, (1.0 - t) / rampdown)
     ramp = 0.5 - 0.5 * math.cos(ramp * math.pi)

@@ -311,6 +311,36 @@ def test_deferred_attention_by_products_equal_the_per_layer_launches(monkeypatch
     assert torch.equal(out[True][0], out[True][2])
 
 
+@pytest.mark.parametrize("res,cmax,attn", [(256, 512, 8), (128, 64, 5)])
+def test_fused_style_act_blur_gradient_pass_equals_the_separate_launches(monkeypatch, res, cmax, attn):
+    """Up-sampling layers without attention: conv1's style gradient, conv0's activation backward and the adjoint of conv0's blur as ONE pass
+    (mgf_style_act_fir_bwd_f32: conv0's dz never reaches memory, dot-product partials per 64 x 64 tile) against the two launches it replaces
+    (mgf_style_grad_act_bwd_f32 + upfirdn2d with pad 2): d/dz to 1e-5 -- the same arithmetic per element, another summation order of the
+    partials -- at one and at two samples, random per-layer noise, on the 256^2 generator (its top block) and on a 128^2 one whose blocks from
+    32^2 up have no attention (three fused blocks, 32^2 / 64^2 / 128^2 maps: tiles cut by the map edge)."""
+    from morphganformer_amd import grad
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import GeneratorConfig, make_state_dict
+    cfg = GeneratorConfig(img_resolution=res, channel_max=cmax, attn_max_log2res=attn)
+    sd = make_state_dict(cfg, seed=0)
+    out = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(grad, "FUSE_ACT_FIR", fuse)
+        G = Generator(sd, cfg, "cuda", max_batch=1)
+        gg = grad.GeneratorGrad(G)
+        res_ = []
+        for n in (1, 2):
+            torch.manual_seed(n)
+            z = torch.randn(n, cfg.k, cfg.z_dim, device="cuda")
+            noises = {lp.name: torch.randn(n, lp.res * lp.res, device="cuda") for lp in G.plan.layers if lp.noise_strength is not None}
+            img = gg.forward(z, noise_mode="inject", noises=noises)
+            res_.append(gg.backward(torch.sin(img * 3.0)).clone())
+            assert gg._fir_mode == fuse
+        out[fuse] = res_
+    for a, b in zip(out[True], out[False]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
+
+
 def test_tiny_gradient_matches_reference_module(tiny, golden):
     """d mean(img^2)/dz computed by the REFERENCE module's autograd (gen_tiny.npz, oracle/make_golden.py) vs the HIP backward."""
     gg, tsd, cfg = tiny
