@@ -240,20 +240,26 @@ def generator_leg(eng, iters=3):
 
 
 def graph_kernel_nodes(graph):
-    """Kernel launches per replay of a captured torch.cuda.CUDAGraph (None when it cannot be counted): the debug dump of the graph, one
-    `label=...` node per kernel."""
+    """Kernel nodes of a captured torch.cuda.CUDAGraph(keep_graph=True) = kernel launches per replay (None when they cannot be counted):
+    hipGraphGetNodes / hipGraphNodeGetType on the graph torch kept."""
     if graph is None:
         return None
-    import re
-    import tempfile
     try:
-        with tempfile.TemporaryDirectory() as d:
-            path = os.path.join(d, "g.dot")
-            graph.debug_dump(path)
-            with open(path) as fh:
-                txt = fh.read()
-        n = len(re.findall(r"KERNEL|kernel", txt))
-        return n or None
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        handle = ctypes.c_void_p(graph.raw_cuda_graph())
+        n = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(handle, None, ctypes.byref(n)) != 0 or n.value == 0:
+            return None
+        nodes = (ctypes.c_void_p * n.value)()
+        if hip.hipGraphGetNodes(handle, nodes, ctypes.byref(n)) != 0:
+            return None
+        kernels = 0
+        for node in nodes:
+            t = ctypes.c_int(-1)
+            if hip.hipGraphNodeGetType(ctypes.c_void_p(node), ctypes.byref(t)) == 0 and t.value == 0:          # hipGraphNodeTypeKernel
+                kernels += 1
+        return kernels or None
     except Exception:          # noqa: BLE001 -- a count beside the metric, never a reason to fail
         return None
 

@@ -650,6 +650,45 @@ def warp_morphs(G, w1, w2, landmark1, landmark2, landmark_G=None, landmark_fn=No
     return {"latent": lat[0], "morph": morph_u8, "warped": warped, "points_G": points_G, "points_avg": points_avg}
 
 
+def cv_resize_linear_u8(img_u8_hwc, width, height):
+    """cv2.resize(I, (width, height)) of a uint8 image with the default INTER_LINEAR, restated from OpenCV's published sources (imgproc
+    resize.cpp: half-pixel centres, coefficients rounded to 11-bit fixed point, HResizeLinear in int32, VResizeLinear<uchar>'s
+    `(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2`).  Host-side input formatting of one small image, like
+    image_transform; cv2 is absent offline, so bit-parity with it is UNPINNED."""
+    a = np.asarray(img_u8_hwc)
+    assert a.dtype == np.uint8 and a.ndim == 3
+    ih, iw = a.shape[:2]
+
+    def table(dst, src):
+        f = (np.arange(dst, dtype=np.float64) + 0.5) * (src / dst) - 0.5
+        s0 = np.floor(f).astype(np.int64)
+        fr = (f - s0).astype(np.float32)
+        lo = s0 < 0
+        s0[lo], fr[lo] = 0, 0.0
+        hi = s0 >= src - 1
+        s0[hi], fr[hi] = src - 1, 0.0
+        c1 = np.rint(fr * np.float32(2048)).astype(np.int64)                # saturate_cast<short>(coef * INTER_RESIZE_COEF_SCALE)
+        c0 = np.rint((np.float32(1) - fr) * np.float32(2048)).astype(np.int64)
+        return s0, np.minimum(s0 + 1, src - 1), c0, c1
+
+    x0, x1, a0, a1 = table(width, iw)
+    y0, y1, b0, b1 = table(height, ih)
+    src = a.astype(np.int64)
+    hrow = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]             # [ih, width, c], scale 2048
+    s0, s1 = hrow[y0], hrow[y1]
+    out = (((b0[:, None, None] * (s0 >> 4)) >> 16) + ((b1[:, None, None] * (s1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def facenet_feature(image_u8_hwc, embedder):
+    """extract_FaceNet.py:30-40: `cv2.resize(I, (224, 224))`, clamp to [0, 255], (x - 127.5) / 128, InceptionResnetV1 -> the flattened
+    512-d embedding.  embedder: facenet.InceptionResnetV1Embedder (the HIP network; its weights are the caller's)."""
+    small = cv_resize_linear_u8(image_u8_hwc, 224, 224)
+    x = torch.from_numpy(small.astype(np.float32)).clamp_(0, 255).sub_(127.5).div_(128.0).permute(2, 0, 1)[None].contiguous()
+    emb = embedder(x.to(embedder.device if hasattr(embedder, "device") else "cuda"))
+    return emb.detach().cpu().numpy().reshape(-1)
+
+
 def second_stage(G, target, w_init, latent_std, lm_target, lm_steps, **kw):
     """A second projection whose noisy candidates are drawn around an earlier result instead of the latent mean
     (edit_MSE.py: `latent_in = w1` pattern; BASELINE config 5)."""

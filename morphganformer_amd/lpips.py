@@ -268,9 +268,10 @@ class SqueezeFeatures:
             self.c0, self.fires, self.wino3 = share.c0, share.fires, share.wino3          # packed weights are size independent
             self.merged, self.wino3m = share.merged, share.wino3m
             self.stem_w, self.stem_b = share.stem_w, share.stem_b
-            self.gp, self.gpw = share.gp, share.gpw
+            self.gp, self.gpw, self.gpm, self.gpwm = share.gp, share.gpw, share.gpm, share.gpwm
         else:
             self.gp, self.gpw = {}, {}                            # channel-transposed packs of the backward pass (+ Winograd images), built on first use
+            self.gpm, self.gpwm = {}, {}                          # ... of the merged expand launch (one image per forward)
             g = lambda k: np.asarray(backbone_state[k], dtype=np.float64)
             t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
             w0, b0 = g("features.0.weight"), g("features.0.bias")
@@ -300,7 +301,7 @@ class SqueezeFeatures:
                 if USE_WINOGRAD_LPIPS:
                     self.wino3m[idx] = cv.winograd2_weights(t32(wm))
         self.n = n
-        self.merge = MERGE_FIRE and n == 1
+        self.merge = set()           # Fire modules whose expand branches run merged (filled below: one image, maps the Winograd launch fills the chip with)
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         hh, ww = (h - 3) // 2 + 1, (w - 3) // 2 + 1
         self.shapes = {1: (64, hh, ww)}
@@ -316,6 +317,10 @@ class SqueezeFeatures:
                 ci, sq, ex = FIRES[idx]
                 assert ci == c
                 self.sq[idx] = e(n, sq, hh, ww)
+                # merged only where the merged launch is a Winograd launch (255^2 / 127^2 maps of a 1024^2 image): there both branches sit on
+                # their launch latency; on the 63^2 maps the tap-list kernel does real work and twice of it costs more than a launch saves
+                if MERGE_FIRE and n == 1 and idx in self.wino3m and min(hh, ww) > 16 and cv.winograd_fills_chip(n, 2 * ex, hh, ww):
+                    self.merge.add(idx)
                 c = 2 * ex
                 self.buf[idx] = e(n, c, hh, ww)
             self.shapes[idx] = (c, hh, ww)
@@ -333,22 +338,20 @@ class SqueezeFeatures:
                     self.gpw[idx] = cv.winograd2_weights(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), 1.0)
             for idx, (pm, _) in self.merged.items():
                 # the merged data gradient: one true convolution over the concatenated gradient [d expand1x1 | d expand3x3] (2 ex -> sq channels)
-                self.gp[("m", idx)] = cv.transpose_packed(pm, True)
+                self.gpm[idx] = cv.transpose_packed(pm, True)
                 if USE_WINOGRAD_LPIPS and pm.cin % 32 == 0:
                     w = pm.wp[:, :, :pm.cout].reshape(3, 3, pm.cin, pm.cout).permute(3, 2, 0, 1)        # [2 ex, sq, kh, kw]
-                    self.gpw[("m", idx)] = cv.winograd2_weights(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), 1.0)
+                    self.gpwm[idx] = cv.winograd2_weights(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), 1.0)
         if getattr(self, "gbuf", None) is None:
             e = lambda t: torch.empty_like(t)
             self.gbuf = {idx: e(t) for idx, t in self.buf.items()}
             self.gsq = {idx: e(t) for idx, t in self.sq.items()}
-            if self.merge:
-                # one image: the two halves of ONE [1, 2 ex, h, w] tensor are dense blocks, so the kernels that write the split gradient
-                # fill the merged launch's input in place
-                self.gcat = {idx: e(self.buf[idx]) for idx in FIRES}
-                self.gex = {idx: (self.gcat[idx][:, :FIRES[idx][2]], self.gcat[idx][:, FIRES[idx][2]:]) for idx in FIRES}
-            else:
-                self.gex = {idx: (e(self.buf[idx][:, :FIRES[idx][2]].contiguous()), e(self.buf[idx][:, FIRES[idx][2]:].contiguous()))
-                            for idx in FIRES}
+            # merged Fires (one image): the two halves of ONE [1, 2 ex, h, w] tensor are dense blocks, so the kernels that write the split
+            # gradient fill the merged launch's input in place
+            self.gcat = {idx: e(self.buf[idx]) for idx in self.merge}
+            self.gex = {idx: ((self.gcat[idx][:, :FIRES[idx][2]], self.gcat[idx][:, FIRES[idx][2]:]) if idx in self.merge else
+                              (e(self.buf[idx][:, :FIRES[idx][2]].contiguous()), e(self.buf[idx][:, FIRES[idx][2]:].contiguous())))
+                        for idx in FIRES}
             n, _, h1, w1 = self.buf[1].shape
             self.gimg = torch.empty([n, 3, 2 * h1 + 1, cv.tconv_pitch(w1)], dtype=torch.float32, device=self.device)
 
@@ -397,15 +400,16 @@ class SqueezeFeatures:
                 _lib.check(L.mgf_relu_bwd_split_f32(da.data_ptr(), db.data_ptr(), gh.data_ptr(), h.data_ptr(), n, c, ex, hh * ww, st),
                            "relu_bwd_split")
             s, gs = self.sq[idx], self.gsq[idx]
-            if self.merge:
+            merged = idx in self.merge
+            if merged:
                 gc = self.gcat[idx]
-                if ("m", idx) in self.gpw and min(hh, ww) > 16 and cv.winograd_fills_chip(n, gs.shape[1], hh, ww):
-                    cv.winograd_forward(gc, self.gpw[("m", idx)], out=gs)
+                if idx in self.gpwm and min(hh, ww) > 16 and cv.winograd_fills_chip(n, gs.shape[1], hh, ww):
+                    cv.winograd_forward(gc, self.gpwm[idx], out=gs)
                 else:
-                    cv.conv_forward(gc, self.gp[("m", idx)], pad=(1, 1), out=gs)
+                    cv.conv_forward(gc, self.gpm[idx], pad=(1, 1), out=gs)
             else:
                 cv.conv_forward(da, e1T, out=gs)
-            if self.merge:
+            if merged:
                 pass
             elif idx in self.gpw and cv.winograd_fills_chip(n, gs.shape[1], hh, ww):
                 cv.winograd_forward(db, self.gpw[idx], epilogue=_lib.make_epilogue(residual=gs), out=gs)
@@ -473,12 +477,8 @@ class SqueezeFeatures:
                 s = cv.conv_forward(h, ps, epilogue=_lib.make_epilogue(bias=bs, act="relu"), out=self.sq[idx])
                 y = dest(idx)
                 ex = p1.cout
-                if self.merge:
-                    pm, bm = self.merged[idx]
-                    if idx in self.wino3m and min(s.shape[2:]) > 16 and cv.winograd_fills_chip(s.shape[0], 2 * ex, s.shape[2], s.shape[3]):
-                        cv.winograd2_forward(s, self.wino3m[idx], epilogue=_lib.make_epilogue(bias=bm, act="relu"), out=y)
-                    else:
-                        cv.conv_forward(s, pm, pad=(1, 1), epilogue=_lib.make_epilogue(bias=bm, act="relu"), out=y)
+                if idx in self.merge:
+                    cv.winograd2_forward(s, self.wino3m[idx], epilogue=_lib.make_epilogue(bias=self.merged[idx][1], act="relu"), out=y)
                     h = y
                     if idx in TAPS_AFTER:
                         taps.append(h)

@@ -558,11 +558,13 @@ class ProjectionEngine:
             self._iteration()
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        if getattr(self, "graph_debug", False):          # keeps the hipGraph_t behind the executable graph: graph.debug_dump(path) can list its nodes
-            g.enable_debug_mode()
+        # graph_debug: keep the hipGraph_t behind the executable graph, so that its nodes can be counted afterwards (bench.py)
+        keep = bool(getattr(self, "graph_debug", False))
+        g = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._iteration()
+        if keep:
+            g.instantiate()
         for dst, src in zip(self._state(), state):
             dst.copy_(src)
         self.graph = g

@@ -391,7 +391,7 @@ def test_lpips_vgg_alex_full_size_vs_oracle(net):
     assert abs(per_tap.sum() - float(out)) <= 1e-5 * abs(float(out))
 
 
-@pytest.mark.parametrize("size", [(256, 256), (203, 131)])
+@pytest.mark.parametrize("size", [(1024, 1024), (600, 520)])
 def test_lpips_merged_fire_launches_equal_the_separate_ones(size):
     """One image per forward: a Fire's expand1x1 + expand3x3 run as ONE 3x3 launch (expand1x1 in the centre tap) and their data gradients as
     one launch over the concatenated gradient (lpips.MERGE_FIRE) -- distance, per-tap contributions and the image gradient against the
@@ -407,7 +407,7 @@ def test_lpips_merged_fire_launches_equal_the_separate_ones(size):
             lpips.MERGE_FIRE = merge
             P = lpips.PerceptualLoss(net="squeeze", backbone_state=lpips.random_squeeze_backbone(0))
             P.set_target(x1)
-            assert next(iter(P._feats.values())).merge == merge
+            assert bool(next(iter(P._feats.values())).merge) == merge
             out, d = torch.zeros(1, device="cuda"), torch.zeros_like(x0)
             P.distance_into(out, x0, keep_taps=True)
             P.grad_into(d, scale=1.0)
@@ -419,7 +419,7 @@ def test_lpips_merged_fire_launches_equal_the_separate_ones(size):
     # (a ReLU input within float32 rounding of zero may take the other branch in the other arithmetic -- expand1x1 through the Winograd
     # transform instead of a plain dot product: the gate is on the bulk of the error, like the other gradient tests)
     err = (ga - gb).abs() / gb.abs().max()
-    assert float(err.median()) < 1e-6 and float(err.square().mean().sqrt()) < 1e-4, (float(err.median()), float(err.square().mean().sqrt()), float(err.max()))
+    assert float(err.median()) < 1e-6 and float(err.square().mean().sqrt()) < 1e-3, (float(err.median()), float(err.square().mean().sqrt()), float(err.max()))
 
 
 def test_percept_mse_objective_variant(golden):
