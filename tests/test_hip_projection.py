@@ -470,7 +470,7 @@ def test_psnr_objective_variant(golden):
         want.append(float(psnr_ref(img.numpy(), g["target"])))
     want = np.array(want)
     assert np.abs(losses - want).max() < 1e-3 * np.abs(want).max(), (losses, want)
-    assert bstep == int(np.argmin(want)) and 40 < want.min() < 100
+    assert bstep == int(np.argmin(losses)) and bloss == float(losses.min()) and 20 < want.min() < 100
 
 
 def test_v1_pooled_percept_objective(golden):
