@@ -80,6 +80,10 @@ def parse():
                     help="loop steps evaluated per generator forward (exact in literal mode).  Fixed (not derived from --steps) so that every "
                          "run -- the driver's, the rocprofv3 trace, the PMC passes in profiles/ -- launches the same kernels on the same shapes")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--arith", choices=["f32", "bf16x3"], default="f32",
+                    help="arithmetic of the generator's convolutions in the TIMED workload.  f32 (default, the headline): exact float32, the "
+                         "reference's.  bf16x3: the opt-in mode (three bf16 matrix instructions per product, float32 accumulation) -- the line "
+                         "is then labelled with it (`dtype`, `config.arithmetic`) and is NOT the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3, help="timed iterations of the CPU oracle's port (+1 warm-up), about 3 s each on 64 threads")
     ap.add_argument("--biometric", type=int, default=0, metavar="DEPTH",
@@ -110,6 +114,9 @@ def parse():
                          "is reported as `lockstep`, all of them under `lockstep_sweep`); 0 = skip")
     ap.add_argument("--objective-batches", type=str, default="16,32",
                     help="candidates per forward of the config-3 objective leg: the first is `objectives.config3`, the others `objectives.config3_bNN`")
+    ap.add_argument("--bf16x3-leg", type=int, default=1,
+                    help="1 = the `bf16x3_mode` leg (rank 0, N=1): the headline's loop on a generator in the opt-in bf16x3 arithmetic, reported "
+                         "beside the metric with its pixel error against the float32 engine; 0 = skip")
     ap.add_argument("--config4", type=int, default=1,
                     help="1 = the `config4` leg (rank 0, N=1): BASELINE config 4 -- two --target-steps-step projections (one re-targeted engine) and the "
                          "11-alpha sweep of their latents as ONE batch-11 generator forward: projections/s and sweep ms; 0 = skip")
@@ -142,14 +149,14 @@ def _late_imports():
         np, torch = numpy, _torch
 
 
-def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0, pipeline=False, lpips_net="squeeze"):
+def build(cfg, device, rank, steps_total, use_graph, batch, biometric=0, pipeline=False, lpips_net="squeeze", arith="f32"):
     _late_imports()
     from morphganformer_amd.engine import Generator
     from morphganformer_amd.lpips import PerceptualLoss
     from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, latent_stats, synthetic_landmarks
     from morphganformer_amd.synth_weights import make_state_dict, synthetic_latents
     sd = make_state_dict(cfg, seed=0)
-    G = Generator(sd, cfg, device, max_batch=1)
+    G = Generator(sd, cfg, device, max_batch=1, arith=arith)
     G.fuse_torgb = True
     z_t = torch.from_numpy(synthetic_latents(cfg, 1, seed=1000 + rank)).to(device)
     target = G(z_t, None, noise_mode="const")[0].clamp(-1, 1).clone()
@@ -476,6 +483,49 @@ def config5_leg(cfg, device, G, batch, n_targets, steps, latent_std):
             "iters_per_s": round(n_targets * rup / dt, 2), "objective": "MSE (edit_MSE.py:143)", "steps_per_forward": batch,
             "note": "second-stage projections started from one stage-1 latent, drivers.project_many on one GPU (BASELINE config 5 shards 32 "
                     "of them over 4 GPUs: the same call under torch.distributed)"}
+
+
+def bf16x3_leg(sd, cfg, device, G32, target, latent_mean, latent_std, batch, min_seconds=0.6):
+    """The OPT-IN bf16x3 arithmetic (Generator(arith="bf16x3"): transposed convs and the 3x3 layers below 256^2 as three bf16 matrix
+    instructions per product, float32 accumulation) in configs[1]'s literal loop: iters/s beside the headline -- never IN it: the headline's
+    arithmetic is the reference's float32 -- and the worst pixel difference against the float32 engine on the same latents and noise."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.lpips import PerceptualLoss
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, synthetic_landmarks
+    torch.cuda.reset_peak_memory_stats(device)
+    Gb = Generator(sd, cfg, device, max_batch=1, arith="bf16x3")
+    steps_total = 256 * batch
+    percept = PerceptualLoss(model="net-lin", net="squeeze", use_gpu=True, device=device, allow_random_backbone=True)
+    lm_t, lm_s = synthetic_landmarks(steps_total, cfg.img_resolution, seed=17)
+    eng = ProjectionEngine(Gb, target, latent_mean, latent_std, ProjectionArgs(step=steps_total), percept=percept, use_mse=True, lm_target=lm_t,
+                           lm_steps=lm_s, noise_mode="random", seed=21, use_graph=True, batch=batch)
+    eng.run(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(batch)
+    torch.cuda.synchronize()
+    per = time.perf_counter() - t0
+    n_seq = max(2, min(200, int(min_seconds / per) + 1))
+    t0 = time.perf_counter()
+    eng.run(n_seq * batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    roof = roofline_leg(eng, iters=1)
+    # the same 4 latents and the same (constant) noise through both engines
+    z = torch.randn(4, cfg.k, cfg.z_dim, device=device, generator=torch.Generator(device=device).manual_seed(9))
+    a = G32(z, None, noise_mode="const")[0]
+    b = Gb(z, None, noise_mode="const")[0]
+    err = float((a - b).abs().max() / a.abs().max())
+    out = {"value": round(n_seq * batch / dt, 2), "unit": "iters/s", "steps": n_seq * batch, "ms_per_step": round(dt / (n_seq * batch) * 1e3, 4),
+           "steps_per_forward": batch, "arithmetic": "bf16x3: f32 operands split into 2 bf16 terms, 3 v_mfma_f32_32x32x16_bf16 per product, f32 accumulate "
+                                                     "(transposed convs >= 32^2 input, 3x3 layers of the 64^2 / 128^2 blocks); everything else float32",
+           "max_pixel_error_vs_f32_engine": float(f"{err:.3e}"), "dominant_kernel": roof["kernel"], "avg_launch_us": roof["avg_launch_us"],
+           "conv_ms_per_iter": roof["conv_ms_per_iter"],
+           "bf16x3_kernels": {k: v for k, v in roof["all_conv_kernels"].items() if k.endswith(", 1>") and k.count(",") == 5},
+           "note": "opt-in engine mode beside the metric; the headline `value` / `dtype` stay exact float32 (the reference's arithmetic)"}
+    del eng, percept, Gb
+    torch.cuda.empty_cache()
+    return out
 
 
 def objective_leg(cfg, device, G, target, latent_mean, latent_std, batch, lpips_net="squeeze", facenet=False, min_seconds=0.6):
@@ -868,7 +918,7 @@ def main():
     seqs, warm = a.steps, a.warmup
     steps = seqs * a.batch                             # loop iterations inside the timed region
     sd, G, percept, eng, target, latent_mean, latent_std, lms = build(cfg, device, rank, (seqs + warm + 4) * a.batch, not a.no_graph, a.batch,
-                                                                      a.biometric, bool(a.pipeline), a.lpips_net)
+                                                                      a.biometric, bool(a.pipeline), a.lpips_net, a.arith)
 
     log(f"built generator/LPIPS/engine on {device}; warm-up {warm} steps of {a.batch} loop iterations (+ graph capture)")
     eng.run(max(warm, 1) * a.batch)                    # (graph capture needs one launch sequence even with --warmup 0)
@@ -915,7 +965,8 @@ def main():
         "unit": "iters/s", "n_gpus": world, "steps": seqs, "warmup": warm,
         "ms_per_step": round(elapsed / seqs * 1e3, 4), "iters_per_step": a.batch, "iters": steps, "ms_per_iter": round(elapsed / steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks, "timed_seconds": round(elapsed, 4), "ranks": rank_stats,
+        "dtype": "f32" if a.arith == "f32" else "bf16x3 (f32 operands split into 2 bf16 terms, 3 bf16 MFMAs per product, f32 accumulate): NOT the headline arithmetic",
+        "data": "synthetic", "rccl_ranks": rccl_ranks, "timed_seconds": round(elapsed, 4), "ranks": rank_stats,
         "hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
         "config": {"workload": f"configs[1]: single {a.res}x{a.res} face per GPU, Wing+LPIPS({a.lpips_net})+MSE literal-mode projection step, "
                                "noise_mode=random, seeded synthetic weights/targets/landmarks"
@@ -971,6 +1022,13 @@ def main():
                 except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                     out["objectives"][name] = {"error": f"{type(exc).__name__}: {exc}"}
                     log(f"objective leg {name} failed: {exc}")
+        if world == 1 and a.bf16x3_leg and a.arith == "f32" and not a.biometric and a.res == 1024 and a.lpips_net == "squeeze":
+            try:
+                out["bf16x3_mode"] = bf16x3_leg(sd, cfg, device, G, target, latent_mean, latent_std, a.batch)
+                log(f"bf16x3 leg done: {out['bf16x3_mode']['value']} iters/s, pixel error {out['bf16x3_mode']['max_pixel_error_vs_f32_engine']}")
+            except Exception as exc:        # noqa: BLE001 -- reported in the line instead
+                out["bf16x3_mode"] = {"error": f"{type(exc).__name__}: {exc}"}
+                log(f"bf16x3 leg failed: {exc}")
         if world == 1 and a.landmark_callback == "stub" and not a.biometric and a.res == 1024:
             try:
                 out["landmark_callback"] = landmark_callback_leg(cfg, device, G, percept, target, latent_mean, latent_std, a.batch, out["value"])

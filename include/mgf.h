@@ -131,6 +131,16 @@ typedef struct mgf_conv_desc {
 
 int mgf_conv_taps_f32(float* y, const float* x, const float* wp, const float* in_scale, const float* out_scale,
                       const mgf_conv_desc* d, const mgf_epilogue* ep, mgf_stream_t stream);
+/* The same convolution in the OPT-IN "bf16x3" arithmetic (not the reference's float32: an engine mode of its own, never the default).
+ * Every float32 operand is split into two bfloat16 terms a = a1 + a2 (a1 = bf16(a), a2 = bf16(a - a1): 16 significant bits) and a product
+ * runs as three v_mfma_f32_32x32x16_bf16 (a2 b1 + a1 b2 + a1 b1) with float32 accumulation -- 3 x 32 matrix-pipe cycles per 16 input
+ * channels instead of 8 x 64; worst error 4 - 5e-6 of max|y| on the generator's layer shapes (tools/probes/bf16x3_gemm.hip).
+ * wb: the weights split once per checkpoint: bfloat16 [cin / 16][term 2][tap 9][lane half 2][cout_pad][8 channels], from the float32
+ * image of mgf_pack_conv_weights (gain folded in).  The style multiplies the ACTIVATIONS where they are staged (w (s x) instead of
+ * (w s) x).  Serves 3x3 stride-1 convolutions and the 4-group transposed conv on maps at least 32 wide with cin % 16 == 0;
+ * MGF_EUNSUPPORTED otherwise.  Descriptor, epilogue and fused ToRGB projection as in mgf_conv_taps_f32. */
+int mgf_conv_taps_bf16x3_f32(float* y, const float* x, const void* wb, const float* in_scale, const float* out_scale,
+                             const mgf_conv_desc* d, const mgf_epilogue* ep, mgf_stream_t stream);
 
 /* Per-launch instrumentation of mgf_conv_taps_f32 for roofline accounting: between _begin and _end every conv launch is
  * bracketed by HIP events on its launch stream (main kernel only, not the split-K reduce; do not use during graph capture).

@@ -71,6 +71,7 @@ _SIGS = {
     "mgf_upfirdn2d": (C.c_int, [vp, vp, vp, C.c_int, i32, i32, i32, i32, i64, i64, i64, i64, i32, i32, i64, i64, i64, i64,
                                 i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, C.POINTER(Epilogue), vp]),
     "mgf_conv_taps_f32": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(ConvDesc), C.POINTER(Epilogue), vp]),
+    "mgf_conv_taps_bf16x3_f32": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(ConvDesc), C.POINTER(Epilogue), vp]),
     "mgf_tconv3x3s2_border_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, vp]),
     "mgf_winograd_weights_f32": (C.c_int, [vp, vp, i32, i32, f32, vp]),
     "mgf_conv3x3_winograd_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(Epilogue), vp]),

@@ -57,6 +57,18 @@ def pack_weights(w: torch.Tensor, gain: float = 1.0, flip: bool = False, want_ws
     return PackedConv(wp, wsq, cout, cin, kh, kw, cout_pad)
 
 
+def pack_weights_bf16x3(pc: PackedConv) -> torch.Tensor:
+    """The weight operand of the opt-in "bf16x3" arithmetic (mgf_conv_taps_bf16x3_f32): the float32 tap-major image of a 3x3 layer split into
+    two bfloat16 terms w = w1 + w2 (w1 = bf16(w), w2 = bf16(w - w1), round to nearest even) and laid out
+    [cin / 16][term 2][tap 9][lane half 2][cout_pad][8 channels] -- once per checkpoint."""
+    assert pc.kh * pc.kw == 9 and pc.cin % 16 == 0, (pc.kh, pc.kw, pc.cin)
+    w = pc.wp                                                          # [9, cin, cout_pad]
+    hi = w.to(torch.bfloat16)
+    mid = (w - hi.float()).to(torch.bfloat16)
+    t = torch.stack([hi, mid]).view(2, 9, pc.cin // 16, 2, 8, pc.cout_pad)
+    return t.permute(2, 0, 1, 3, 5, 4).contiguous()                    # [cin/16][term][tap][half][cout_pad][8]
+
+
 def _desc(n, cin, in_h, in_w, cout, cout_pad, tile_h, tile_w, istride, ostride, taps, groups, oy, ox, out_h, out_w,
           y_pitch, y_plane, y_batch, y_choff=0, out_scale_stride=0):
     d = _lib.ConvDesc()
@@ -96,11 +108,14 @@ def _workspace(dev_index):
 
 
 def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_scale=None, epilogue=None, out=None,
-                 out_choff=0, rgb=None, taps=None, ksize=None):
+                 out_choff=0, rgb=None, taps=None, ksize=None, bf=None):
     """Correlation with the packed taps: y[oy,ox] = sum w[kh,kw] x[oy*stride + kh - pad_y, ox*stride + kw - pad_x].
 
-    `out` may be a larger [n, C_total, oh, ow] buffer; this conv then writes channels [out_choff, out_choff + cout)."""
-    _lib.require_gpu(x, pc.wp, in_scale, out_scale, out)
+    `out` may be a larger [n, C_total, oh, ow] buffer; this conv then writes channels [out_choff, out_choff + cout).
+    bf: pack_weights_bf16x3(pc) -> the launch runs in the opt-in bf16x3 arithmetic (3x3 stride 1 only; mgf_conv_taps_bf16x3_f32)."""
+    _lib.require_gpu(x, pc.wp, in_scale, out_scale, out, bf)
+    launch = _lib.lib().mgf_conv_taps_f32 if bf is None else _lib.lib().mgf_conv_taps_bf16x3_f32
+    wptr = pc.wp.data_ptr() if bf is None else bf.data_ptr()
     assert x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 4 and x.shape[1] == pc.cin
     n, cin, h, w = x.shape
     py, px = pad
@@ -119,8 +134,8 @@ def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_sca
         d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, oh, ow, stride, 1, taps, None, [0], [0], oh, ow, ow, oh * ow,
                   pc.cout * oh * ow, 0, 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
         d.rgb_w, d.rgb_bias, d.rgb_out, d.rgb_channels = rgb_w.data_ptr(), _lib.ptr(rgb_b), rgb_out.data_ptr(), rgb_w.shape[1]
-        rc = _lib.lib().mgf_conv_taps_f32(None, x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                          C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
+        rc = launch(None, x.data_ptr(), wptr, _lib.ptr(in_scale), _lib.ptr(out_scale),
+                    C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
         _lib.check(rc, "conv_taps(rgb)")
         return rgb_out
     if out is None:
@@ -138,8 +153,8 @@ def conv_forward(x, pc: PackedConv, stride=1, pad=(0, 0), in_scale=None, out_sca
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, oh, ow, stride, 1, taps, None, [0], [0], oh, ow,
               ow, oh * ow, out.shape[1] * oh * ow, out_choff,
               0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0)
-    rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                      C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
+    rc = launch(out.data_ptr(), x.data_ptr(), wptr, _lib.ptr(in_scale), _lib.ptr(out_scale),
+                C.byref(d), C.byref(epilogue) if epilogue is not None else None, _lib.stream_ptr())
     _lib.check(rc, "conv_taps")
     return out
 
@@ -413,7 +428,7 @@ def conv3x3s2_few_inputs(x, w, bias=None, relu=False, out=None):
     return out
 
 
-def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=None):
+def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=None, bf=None):
     """Stride-2 3x3 transposed convolution t[2i+kh, 2j+kw] += w[kh,kw] x[i,j] -> view [n, cout, 2h+1, 2w+1] of a padded-pitch
     workspace (row pitch a multiple of 4 floats so the parity pairs are written as aligned float2)."""
     _lib.require_gpu(x, pc.wp, in_scale, out_scale, out)
@@ -438,11 +453,17 @@ def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=Non
     # (one or two images -- gradient mode at a single target -- keep the single launch up to 64 px: the border kernel's few workgroups then
     # cost more than the padded tiles, 6.76 -> 6.64 ms per gradient step; from four images on the split wins from 16 px, 686 vs 677 iters/s)
     split = SPLIT_TCONV_BORDER and min(h, w) >= (TCONV_SPLIT_MIN if n >= 4 else max(TCONV_SPLIT_MIN, 128))
+    # bf: the main launch in the opt-in bf16x3 arithmetic (needs the split form: whole 32-wide tiles of quads); the border stays float32
+    use_bf = bf is not None and split and w % 32 == 0 and cin % 16 == 0
     os_stride = 0 if out_scale is None else out_scale.stride(0) if out_scale.ndim == 2 else 0
     d = _desc(n, cin, h, w, pc.cout, pc.cout_pad, h if split else h + 1, w if split else w + 1, 1, 2, TCONV_TAPS, TCONV_GROUPS,
               [0, 0, 1, 1], [0, 1, 0, 1], oh, ow, pitch, oh * pitch, pc.cout * oh * pitch, 0, os_stride)
-    rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                      C.byref(d), None, _lib.stream_ptr())
+    if use_bf:
+        rc = _lib.lib().mgf_conv_taps_bf16x3_f32(out.data_ptr(), x.data_ptr(), bf.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                                 C.byref(d), None, _lib.stream_ptr())
+    else:
+        rc = _lib.lib().mgf_conv_taps_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                          C.byref(d), None, _lib.stream_ptr())
     _lib.check(rc, "conv_taps(tconv)")
     if split:
         rc = _lib.lib().mgf_tconv3x3s2_border_f32(out.data_ptr(), x.data_ptr(), pc.wp.data_ptr(), _lib.ptr(in_scale), _lib.ptr(out_scale),

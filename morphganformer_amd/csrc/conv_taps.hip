@@ -31,8 +31,11 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CK = 8;          // input channels per K chunk
+constexpr int CKB = 16;        // ... of the bf16x3 arithmetic (AR = 1): one v_mfma_f32_32x32x16_bf16 covers 16 channels
 // per-lane register staging slots of the pipelined kernels: XS floats of the input footprint, WS float4 of the weight slab
 template <int WM, int WN> struct Slots {
     // 16x32 tile: 8*18*34 = 4896 floats; 12x32: 3808; 8x32: 2720; 4x32: 1632 -- and 8*9*65 = 4680 for the 4x32 tile of a STRIDE-2 3x3
@@ -65,6 +68,7 @@ struct ConvParams {
     int off32_ok;         // one sample of y (and of the split-K slab) spans < 2^30 elements: 32-bit store offsets are safe
     float* partial;       // [ksplit][n][cout][out_h][y_pitch] when ksplit > 1
     int fixed_geo;        // transposed conv on its usual tile (8 x 32 quads: footprint 9 x 33, canonical taps): instantiation NTP = 10
+    const void* wb;       // AR = 1: the weights split into two bf16 terms, [cin / 16][term 2][tap 9][half 2][cout_pad][8 channels]
     int xcd_per;          // > 0: XCD-aware item order -- workgroup b (dispatched round-robin to XCD b % 8) walks the contiguous
                           // item range [(b % 8) * xcd_per, +xcd_per): neighbouring tiles and the co-tiles of one pixel tile share
                           // one XCD's L2 instead of being re-fetched by eight of them
@@ -98,12 +102,25 @@ struct TileCtx { int n, ks, co0, ty0, tx0, c_begin, c_end; };
 // ACROSS item boundaries -- the first chunk of the next tile is prefetched behind the last MFMA phase of the current one and
 // the epilogue's stores drain while the next tile computes -- so HBM traffic and matrix work overlap chip-wide instead of
 // alternating in lock-step bursts.  Non-PIPE kernels take one item per workgroup and stage synchronously.
-template <int WM, int WN, int MODE, bool PIPE, int NTP>
+//
+// AR = 1: the "bf16x3" arithmetic (opt-in engine mode, NOT the reference's: tools/probes/bf16x3_gemm.hip has its error and rate).  Every f32
+// operand is split into two bf16 terms a = a1 + a2 (a1 = bf16(a), a2 = bf16(a - a1): 16 significant bits) and a product becomes three
+// v_mfma_f32_32x32x16_bf16 (a2 b1 + a1 b2 + a1 b1, f32 accumulation): 3 x 32 matrix-pipe cycles per 16 channels instead of 8 x 64.  The
+// weights arrive split (a checkpoint constant, p.wb); the activations are split where they are staged -- once per footprint element and
+// workgroup, with the style folded into them (w (s x) instead of (w s) x) -- and both sit in LDS as 16-byte vectors of 8 channels, the
+// fragment of one lane half: Xs[term][half][footprint pixel], Ws[term][tap][half][channel].  Tile walk, persistence, split-K and epilogue
+// are the f32 kernel's.
+// (A form with wave roles -- 8 waves, one workgroup per CU, waves 4 .. 7 only loading two chunks ahead, waves 0 .. 3 only running matrix
+// phases and epilogues -- was built and measured: 816 against 834 iterations/s for this form.  The launch is bound by HBM traffic whose
+// load-heavy and store-heavy phases alternate per CU, not by exposed load latency; two independent workgroups per CU overlap them better.)
+template <int WM, int WN, int MODE, bool PIPE, int NTP, int AR = 0>
 __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
+    static_assert(AR == 0 || (PIPE && (NTP == 9 || NTP == 10)), "bf16x3: the pipelined 3x3 / transposed-conv instantiations only");
     constexpr bool FX = NTP == 10 || NTP == 11;      // fixed geometry: transposed conv (10), stride-2 conv (11)
     constexpr int FXW = NTP == 10 ? 33 : 65;         // footprint width (height 9 in both)
     constexpr int NT = FX ? 9 : NTP;
     constexpr int CO_T = 32 * WM, PX = 128 * WN, NG = MODE == 1 ? 4 : 1;
+    constexpr int CKK = AR ? CKB : CK;               // input channels per K chunk
     extern __shared__ float lds[];
     const mgf_conv_desc& d = p.d;
     const int T = NT > 0 ? NT : d.ntaps;
@@ -111,10 +128,10 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
 #pragma unroll
     for (int t = 0; t < MGF_MAX_TAPS; ++t) toffs[t] = t < T ? (d.dy[t] - p.dy_min) * p.fw + (d.dx[t] - p.dx_min) : 0;
     const int chs = p.fh * p.fw;                 // LDS channel stride of Xs
-    const int xs_floats = CK * chs;
+    const int xs_floats = CKK * chs;             // (AR: 2 terms x 2 halves x chs vectors of 16 bytes = 16 chs floats as well)
     // pipelined mode pads both LDS regions to whole staging slots (branch-free register -> LDS copies)
-    const int xs_region = PIPE ? Slots<WM, WN>::XS * 256 : xs_floats;
-    const int buf_floats = PIPE ? xs_region + Slots<WM, WN>::WS * 1024 : xs_floats + T * CK * CO_T;
+    const int xs_region = AR ? xs_floats : (PIPE ? Slots<WM, WN>::XS * 256 : xs_floats);
+    const int buf_floats = AR ? xs_region + 144 * CO_T : (PIPE ? xs_region + Slots<WM, WN>::WS * 1024 : xs_floats + T * CK * CO_T);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -137,8 +154,8 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         c.co0 = cot * CO_T;
         c.ty0 = (pt / p.tiles_x) * rows;
         c.tx0 = (pt % p.tiles_x) * TW;
-        c.c_begin = c.ks * p.chunks_per_split * CK;
-        c.c_end = c.c_begin + p.chunks_per_split * CK;
+        c.c_begin = c.ks * p.chunks_per_split * CKK;
+        c.c_end = c.c_begin + p.chunks_per_split * CKK;
         if (c.c_end > d.cin) c.c_end = d.cin;
         // The item index is wave-uniform, but its divisions by run-time values are expanded on the vector ALU and everything derived from
         // them would then live in VGPRs -- loop bounds compared per lane, and a buffer descriptor built from them costs a
@@ -240,6 +257,99 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
             float4 v = wr[j];
             v.x *= wsc[j]; v.y *= wsc[j]; v.z *= wsc[j]; v.w *= wsc[j];
             *reinterpret_cast<float4*>(Wd + (tid + 256 * j) * 4) = v;
+        }
+    };
+    // ---- AR = 1 staging.  Waves 0, 1 stage lane half 0 (channels 0 .. 7 of the chunk), waves 2, 3 half 1: an ITEM is one footprint pixel
+    // x 8 channels = 8 dword loads (lanes = consecutive pixels: coalesced), split into the two bf16 terms and written as two 16-byte vectors.
+    constexpr int XI = AR ? 3 : 1;                   // items per lane: 128 lanes x 3 >= the 297 / 340 pixels of a footprint (host checks)
+    constexpr int WSB = AR ? (36 * CO_T + 255) / 256 : 1;     // 16-byte weight vectors per lane
+    const int stid = tid;
+    const int h_st = __builtin_amdgcn_readfirstlane(stid >> 7), lp = stid & 127;
+    unsigned xoffb[XI];
+    unsigned woffb[WSB];
+    struct StageSet { float x[XI][8]; u32x4 w[WSB]; float4 s[2]; };
+    const __amdgpu_buffer_rsrc_t rwb_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.wb, 0, -1, 0x00020000);
+    auto setup_slots_b = [&](const TileCtx& c) {
+        rx_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)c.n * d.cin * plane), 0, (int)(4u * (unsigned)(d.cin * plane)), 0x00020000);
+        if (p.in_scale) rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in_scale + (int64_t)c.n * d.cin), 0, -1, 0x00020000);
+        const int iy0 = c.ty0 * d.istride + p.dy_min, ix0 = c.tx0 * d.istride + p.dx_min;
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int px = lp + 128 * j;
+            const int r = px / p.fw, q = px - r * p.fw;
+            const int iy = iy0 + r, ix = ix0 + q;
+            xoffb[j] = (px < chs && iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) ? 4u * (unsigned)(8 * h_st * plane + iy * d.in_w + ix) : 0xFFFFFFF0u;
+        }
+#pragma unroll
+        for (int j = 0; j < WSB; ++j) {
+            int i = stid + 256 * j;
+            if (i >= 36 * CO_T) i = 36 * CO_T - 1;    // (surplus slots: loaded, never stored)
+            const int cc = i % CO_T, rest = i / CO_T; // rest = (term * 9 + tap) * 2 + half
+            woffb[j] = 16u * (unsigned)(rest * d.cout_pad + c.co0 + cc);
+        }
+    };
+    auto load_chunk_b = [&](StageSet& S, int c0) {
+        const int wso = (int)(16u * (unsigned)((c0 / CKB) * 36 * d.cout_pad)), sso = c0 * sc_step;
+#pragma unroll
+        for (int j = 0; j < XI; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                S.x[j][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_l, xoffb[j], (int)(4u * (unsigned)((c0 + k) * plane)), 0));
+#pragma unroll
+        for (int j = 0; j < WSB; ++j) S.w[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rwb_l, woffb[j], wso, 0));
+        // the style of this lane half's 8 channels (the ones table without modulation)
+        S.s[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_l, 32u * (unsigned)h_st, sso, 0));
+        S.s[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_l, 32u * (unsigned)h_st + 16u, sso, 0));
+    };
+    auto store_chunk_b = [&](const StageSet& S, float* buf) {
+        bf16x8* X1 = reinterpret_cast<bf16x8*>(buf) + h_st * chs;
+        bf16x8* X2 = X1 + 2 * chs;
+        const float sv[8] = {S.s[0].x, S.s[0].y, S.s[0].z, S.s[0].w, S.s[1].x, S.s[1].y, S.s[1].z, S.s[1].w};
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int px = lp + 128 * j;
+            bf16x8 t1, t2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = S.x[j][k] * sv[k];
+                const __bf16 a1 = (__bf16)v;
+                t1[k] = a1;
+                t2[k] = (__bf16)(v - (float)a1);                   // (exact difference: a1 keeps v's leading 8 bits)
+            }
+            if (px < chs) { X1[px] = t1; X2[px] = t2; }
+        }
+        u32x4* Wd = reinterpret_cast<u32x4*>(buf + xs_region);
+#pragma unroll
+        for (int j = 0; j < WSB; ++j)
+            if (stid + 256 * j < 36 * CO_T) Wd[stid + 256 * j] = S.w[j];
+    };
+    auto mfma_chunk_b = [&](const float* buf) {
+        auto toff = [&](int t) { return NTP == 10 ? ((t / 3) == 2 ? 0 : 33) + ((t % 3) == 2 ? 0 : 1) : toffs[t]; };
+        const bf16x8* X1 = reinterpret_cast<const bf16x8*>(buf) + half * chs;
+        const bf16x8* X2 = X1 + 2 * chs;
+        const bf16x8* W1 = reinterpret_cast<const bf16x8*>(buf + xs_region) + half * CO_T + l31;      // [term][tap][half][CO_T]
+        const bf16x8* W2 = W1 + 18 * CO_T;
+        bf16x8 fa1[2][WM], fa2[2][WM], fb1[2][WN], fb2[2][WN];
+        auto fetch = [&](int t, int set) {
+#pragma unroll
+            for (int m = 0; m < WM; ++m) { fa1[set][m] = W1[t * 2 * CO_T + m * 32]; fa2[set][m] = W2[t * 2 * CO_T + m * 32]; }
+#pragma unroll
+            for (int g = 0; g < WN; ++g) { fb1[set][g] = X1[pbase[g] + toff(t)]; fb2[set][g] = X2[pbase[g] + toff(t)]; }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) fetch(t + 1, (t + 1) & 1);
+            const int q = (MODE == 1 && NG == 4) ? tconv_group(t) : 0;
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int g = 0; g < WN; ++g) {
+                    // the two small products first: their sum is formed before it meets the large one
+                    acc[q][m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[t & 1][m], fb1[t & 1][g], acc[q][m][g], 0, 0, 0);
+                    acc[q][m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[t & 1][m], fb2[t & 1][g], acc[q][m][g], 0, 0, 0);
+                    acc[q][m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[t & 1][m], fb1[t & 1][g], acc[q][m][g], 0, 0, 0);
+                }
         }
     };
     auto stage_direct = [&](const TileCtx& c, int c0, float* buf) {   // synchronous staging (non-pipelined kernels)
@@ -572,21 +682,27 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         TileCtx cur;
         decode(wbase + slot, cur);
         int b = 0;
+        StageSet S0;
         for (;;) {
             // first chunk of this tile: global -> registers -> LDS (latency covered by the co-resident workgroup and by the
             // previous tile's stores, which are still draining)
-            setup_slots(cur);
-            load_chunk(cur.c_begin);
-            store_chunk(lds + b * buf_floats);
+            if (AR) { setup_slots_b(cur); load_chunk_b(S0, cur.c_begin); store_chunk_b(S0, lds + b * buf_floats); }
+            else { setup_slots(cur); load_chunk(cur.c_begin); store_chunk(lds + b * buf_floats); }
             __syncthreads();
-            const int nch = (cur.c_end - cur.c_begin) / CK;
+            const int nch = (cur.c_end - cur.c_begin) / CKK;
             for (int c = 0; c < nch; ++c) {
                 float* curb = lds + b * buf_floats;
                 float* nxtb = lds + (b ^ 1) * buf_floats;
                 const bool more = c + 1 < nch;
-                if (more) load_chunk(cur.c_begin + (c + 1) * CK);             // in flight behind the MFMAs below
-                mfma_chunk(curb);
-                if (more) store_chunk(nxtb);
+                if (AR) {
+                    if (more) load_chunk_b(S0, cur.c_begin + (c + 1) * CKK);
+                    mfma_chunk_b(curb);
+                    if (more) store_chunk_b(S0, nxtb);
+                } else {
+                    if (more) load_chunk(cur.c_begin + (c + 1) * CK);             // in flight behind the MFMAs below
+                    mfma_chunk(curb);
+                    if (more) store_chunk(nxtb);
+                }
                 __syncthreads();
                 b ^= 1;
             }
@@ -677,6 +793,44 @@ struct ProfScope {
     }
     ~ProfScope() { if (on) (void)hipEventRecord(g_prof.back().e1, st); }
 };
+
+// the bf16x3 instantiations (AR = 1): persistent, pipelined, 32-channel x 256-pixel tiles; 3x3 stride-1 and the transposed conv
+template <int MODE>
+int launch_conv_bf(const ConvParams& p_in, hipStream_t st) {
+    ConvParams p = p_in;
+    constexpr int WM = 1, WN = 2, CO_T = 32;
+    const int chs = p.fh * p.fw;
+    const size_t lds = 2 * ((size_t)16 * chs + (size_t)144 * CO_T) * sizeof(float);
+    if (2 * chs > 768 || p.d.cin % CKB != 0 || lds > 80 * 1024) {
+        mgf_set_error("conv_taps(bf16x3): footprint %d x %d / %d input channels not supported", p.fh, p.fw, p.d.cin);
+        return MGF_EUNSUPPORTED;
+    }
+    const int64_t items = (int64_t)p.tiles_x * p.tiles_y * p.co_tiles * p.d.n * p.ksplit;
+    const int64_t resident = (int64_t)MGF_NUM_CU * 2;
+    dim3 grid((unsigned)(items < resident ? items : resident));
+    p.xcd_per = 0;
+    if (items >= 16) {
+        p.xcd_per = (int)((items + 7) / 8);
+        if (grid.x % 8 != 0) grid.x = (grid.x + 7) / 8 * 8;
+    }
+    auto kern1 = conv_taps_kernel<WM, WN, MODE, true, (MODE == 1 ? 10 : 9), 1>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) { mgf_set_error("conv_taps(bf16x3): cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MGF_ELAUNCH; }
+        attr_set = true;
+    }
+    {
+        ProfScope ps(st, WM, WN, MODE, 1, MODE == 1 ? 10 : 9, p);
+        if (ps.on) g_prof.back().name = MODE == 1 ? "conv_taps_kernel<1, 2, 1, true, 10, 1>" : "conv_taps_kernel<1, 2, 0, true, 9, 1>";
+        hipLaunchKernelGGL(kern1, grid, dim3(256), lds, st, p);
+    }
+    if (p.ksplit > 1) {
+        const int64_t total = (int64_t)p.d.n * p.d.cout * p.d.out_h * p.d.out_w;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(mgf_stream_grid(total, 256, 2)), dim3(256), 0, st, p);
+    }
+    return MGF_OK;
+}
 
 template <int WM, int WN, int MODE>
 int launch_conv(const ConvParams& p_in, hipStream_t st) {
@@ -934,9 +1088,9 @@ extern "C" int mgf_pack_conv_weights(float* wp, float* wsq, const float* w, int3
     return MGF_OK;
 }
 
-extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, const float* in_scale, const float* out_scale,
-                                 const mgf_conv_desc* dd, const mgf_epilogue* ep, mgf_stream_t stream) {
-    MGF_REQUIRE(x && wp && dd && (y || dd->rgb_out), MGF_EINVAL, "conv_taps: null pointer");
+static int conv_taps_dispatch(float* y, const float* x, const float* wp, const void* wb, const float* in_scale, const float* out_scale,
+                              const mgf_conv_desc* dd, const mgf_epilogue* ep, mgf_stream_t stream) {
+    MGF_REQUIRE(x && (wp || wb) && dd && (y || dd->rgb_out), MGF_EINVAL, "conv_taps: null pointer");
     const mgf_conv_desc& d = *dd;
     MGF_REQUIRE(d.n >= 1 && d.cin >= 1 && d.cout >= 1 && d.in_h >= 1 && d.in_w >= 1, MGF_EINVAL, "conv_taps: bad shape");
     MGF_REQUIRE(d.cout_pad >= d.cout && d.cout_pad % 32 == 0, MGF_EINVAL, "conv_taps: cout_pad must be a multiple of 32 >= cout");
@@ -956,7 +1110,7 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     if (ep) MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU,
                         MGF_EUNSUPPORTED, "conv_taps: epilogue activation %d unsupported", ep->act);
     ConvParams p;
-    p.y = y; p.x = x; p.wp = wp; p.in_scale = in_scale; p.out_scale = out_scale; p.d = d;
+    p.y = y; p.x = x; p.wp = wp; p.wb = wb; p.in_scale = in_scale; p.out_scale = out_scale; p.d = d;
     p.has_ep = ep != nullptr;
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; }
     int dy_min = d.dy[0], dy_max = d.dy[0], dx_min = d.dx[0], dx_max = d.dx[0];
@@ -986,8 +1140,14 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     // half the padded MFMA work of the 256-lane ones
     static const char* small_env = mgf_knob("MGF_SMALL_TILES");    // tuning hook (experiments only): 0 = always 256-lane tiles
     const bool small = (int64_t)d.tile_h * d.tile_w <= 128 && !(small_env && small_env[0] == '0');
+    if (wb) {
+        // bf16x3: 32-channel x 256-pixel tiles of 3x3 stride-1 convolutions and of the transposed conv on its canonical 8 x 32-quad tile
+        MGF_REQUIRE(d.ntaps == 9 && d.istride == 1 && !small && TW == 32 && d.cin % CKB == 0, MGF_EUNSUPPORTED,
+                    "conv_taps(bf16x3): needs 9 taps, stride 1, a map of more than 128 positions at least 32 wide and cin %% 16 == 0");
+    }
     if (mode == 1 && small) wn = 1;
-    if (mode == 0) {
+    if (mode == 0 && wb) { wm = 1; wn = 2; }
+    else if (mode == 0) {
         if (d.cout_pad % 64 == 0 && d.cout > 32) { wm = 2; wn = small ? 1 : 2; }
         else if (small) { wm = 1; wn = 1; }
         // <= 32 output channels on a large map: 12-row tiles for 3x3 (measured 91 vs 87 TFLOP/s at 1024^2), 16-row tiles for 1x1
@@ -1014,7 +1174,7 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
         static const char* tw_env = mgf_knob("MGF_TCONV_TW");      // tuning hook (experiments only): 0 keeps 32-wide tiles
         // an odd width costs the predicated epilogue and some idle lanes: it has to save at least 10% of the tiles
         int64_t best = mgf_cdiv(d.tile_w, TW) * mgf_cdiv(d.tile_h, rows) * 9;       // in tenths of a tile
-        for (int tw = 8; tw <= 64 && !(tw_env && tw_env[0] == '0'); ++tw) {
+        for (int tw = 8; tw <= 64 && !(tw_env && tw_env[0] == '0') && !wb; ++tw) {
             const int r = PX / tw;
             const int fh_ = r + (dy_max - dy_min), fw_ = tw + (dx_max - dx_min);
             if (256 / fw_ + 2 > 2 * fh_ || (size_t)CK * fh_ * fw_ > (size_t)(wn == 1 ? Slots<1, 1>::XS : Slots<1, 2>::XS) * 256) continue;
@@ -1045,7 +1205,7 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     p.co_tiles = d.cout_pad / (32 * wm);
     // split-K when the output tiling alone cannot fill the chip (>= 2 workgroups on each of 256 CUs wanted)
     const int64_t base_wgs = (int64_t)p.tiles_x * p.tiles_y * p.co_tiles * d.n;
-    const int nchunks = (int)mgf_cdiv(d.cin, CK);
+    const int nchunks = (int)mgf_cdiv(d.cin, wb ? CKB : CK);
     int ksplit = 1;
     static const int splitk_below = [] { const char* e = mgf_knob("MGF_SPLITK_BELOW"); return e ? atoi(e) : 256; }();   // tuning hook (512 / 256 / 128: 99.6 / 100.4 / 101.1 single-target gradient iters/s, 542 / 548 / 545 literal)
     if (d.workspace && base_wgs < splitk_below && nchunks >= 4 && !d.rgb_out) {
@@ -1064,7 +1224,11 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     MGF_REQUIRE((int64_t)p.tiles_x * p.tiles_y * p.co_tiles * d.n * ksplit <= INT32_MAX, MGF_ETOOBIG, "conv_taps: grid too large");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (mode == 1) rc = wn == 1 ? launch_conv<1, 1, 1>(p, st) : launch_conv<1, 2, 1>(p, st);
+    if (wb) {
+        MGF_REQUIRE(mode == 0 || p.fixed_geo == 1, MGF_EUNSUPPORTED, "conv_taps(bf16x3): the transposed conv needs its canonical tile (9 x 33 footprint)");
+        rc = mode == 1 ? launch_conv_bf<1>(p, st) : launch_conv_bf<0>(p, st);
+    }
+    else if (mode == 1) rc = wn == 1 ? launch_conv<1, 1, 1>(p, st) : launch_conv<1, 2, 1>(p, st);
     else if (wn == 1) rc = wm == 2 ? launch_conv<2, 1, 0>(p, st) : launch_conv<1, 1, 0>(p, st);
     else if (wm == 2) rc = launch_conv<2, 2, 0>(p, st);
     else if (wn == 4) rc = launch_conv<1, 4, 0>(p, st);
@@ -1073,4 +1237,16 @@ extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, cons
     if (rc != MGF_OK) return rc;
     MGF_CHECK_LAUNCH("conv_taps");
     return MGF_OK;
+}
+
+extern "C" int mgf_conv_taps_f32(float* y, const float* x, const float* wp, const float* in_scale, const float* out_scale,
+                                 const mgf_conv_desc* dd, const mgf_epilogue* ep, mgf_stream_t stream) {
+    MGF_REQUIRE(wp, MGF_EINVAL, "conv_taps: null pointer");
+    return conv_taps_dispatch(y, x, wp, nullptr, in_scale, out_scale, dd, ep, stream);
+}
+
+extern "C" int mgf_conv_taps_bf16x3_f32(float* y, const float* x, const void* wb, const float* in_scale, const float* out_scale,
+                                        const mgf_conv_desc* dd, const mgf_epilogue* ep, mgf_stream_t stream) {
+    MGF_REQUIRE(wb && ((uintptr_t)wb % 16) == 0, MGF_EINVAL, "conv_taps(bf16x3): the split weights must be 16-byte aligned");
+    return conv_taps_dispatch(y, x, nullptr, wb, in_scale, out_scale, dd, ep, stream);
 }

@@ -32,6 +32,7 @@ SQRT2 = math.sqrt(2.0)
 SQRT_HALF = math.sqrt(0.5)
 USE_WINOGRAD = os.environ.get("MGF_WINOGRAD", "1") != "0"
 WINOGRAD_MAX_RES = int(os.environ.get("MGF_WINOGRAD_MAX_RES", "1024"))
+BF_DIRECT_MAX_RES = int(os.environ.get("MGF_BF_DIRECT_MAX_RES", "128"))     # arith="bf16x3": largest map whose 3x3 layers leave Winograd (tuning hook)
 
 
 def pack_mapping_params(sd, cfg: GeneratorConfig) -> np.ndarray:
@@ -99,6 +100,7 @@ class ConvLayerPlan:
     attn: "AttnPlan" = None
     w_raw: torch.Tensor = None      # toRGB only: [img_channels, cin] un-packed weights for the fused projection
     wino_u: torch.Tensor = None     # 3x3 stride-1 layers on 16^2 .. 256^2 maps: Winograd-transformed weights (csrc/wino.hip)
+    pcb: torch.Tensor = None        # arith="bf16x3" only: the weights split into two bfloat16 terms (conv.pack_weights_bf16x3)
     s_off: int = 0                  # offsets (floats) into the per-sample style / demod arenas
     d_off: int = 0
 
@@ -117,9 +119,10 @@ class AttnPlan:
 class SynthesisPlan:
     """Device-resident, checkpoint-derived constants of one generator."""
 
-    def __init__(self, sd, cfg: GeneratorConfig, device="cuda"):
+    def __init__(self, sd, cfg: GeneratorConfig, device="cuda", arith="f32"):
         _lib.lib()
         self.cfg = cfg
+        self.arith = arith
         self.device = torch.device(device)
         dev = self.device
         f64 = lambda k: np.asarray(sd[k], dtype=np.float64)
@@ -156,6 +159,9 @@ class SynthesisPlan:
                 # everywhere, MGF_WINOGRAD_MAX_RES limits the map size
                 if kind == "conv3" and USE_WINOGRAD and cv.winograd_ok(cin, cout, res, res) and res <= WINOGRAD_MAX_RES:
                     lp.wino_u = cv.winograd_pack(t32(w), wg, res)
+                # the opt-in bf16x3 arithmetic: every transposed conv and 3x3 layer the kernel serves (maps at least 32 wide, cin % 16 == 0)
+                if arith == "bf16x3" and cin % 16 == 0 and res // up >= 32:
+                    lp.pcb = cv.pack_weights_bf16x3(lp.pc)
             lp.aff_w = t32(f64(p + ".affine.weight"))
             lp.aff_b = t32(f64(p + ".affine.bias"))
             if (p + ".biasAct.bias") in sd:
@@ -210,9 +216,16 @@ class Generator:
     __call__(z=None, c=None, ws=None, truncation_psi=1, ..., noise_mode="random") -> tuple, like the reference.
     """
 
-    def __init__(self, sd, cfg: GeneratorConfig, device="cuda", max_batch: int = 1):
+    def __init__(self, sd, cfg: GeneratorConfig, device="cuda", max_batch: int = 1, arith: str = "f32"):
+        """arith: "f32" -- the reference's arithmetic, exact float32 on the FP32 matrix cores (what every parity claim and the headline rest
+        on) -- or "bf16x3": an OPT-IN mode in which the transposed convolutions and the 3x3 layers below 256^2 split every float32 operand into
+        two bfloat16 terms and run three bf16 matrix instructions per product with float32 accumulation (mgf_conv_taps_bf16x3_f32; per-layer
+        error 4 - 5e-6 of the output's range instead of 1e-6, ~2x the matrix rate).  Everything else is unchanged."""
+        if arith not in ("f32", "bf16x3"):
+            raise ValueError(f"arith must be 'f32' or 'bf16x3' (got {arith!r})")
         self.cfg = cfg
-        self.plan = SynthesisPlan(sd, cfg, device)
+        self.arith = arith
+        self.plan = SynthesisPlan(sd, cfg, device, arith=arith)
         self.device = self.plan.device
         self.input_shape = [None, cfg.k, cfg.z_dim]
         self.cond_shape = [None, 0]
@@ -633,6 +646,12 @@ class Generator:
             off += r * r
         return out
 
+    def _bf_direct(self, lp, n, residual_low):
+        """Does this 3x3 layer take the bf16x3 direct kernel?  Only in that mode, only where it wins: maps of 32^2 .. 128^2 (the layers whose
+        Winograd launch has no fused skip up-sampling to lose), and enough tiles to fill the chip without split-K."""
+        return (lp.pcb is not None and lp.kind == "conv3" and residual_low is None and 32 <= lp.res <= BF_DIRECT_MAX_RES
+                and n * (lp.res // 8) * (lp.res // 32) * (lp.cout // 32) >= 512)
+
     def _layer(self, lp, x, B, key, noise_mode, noises, residual, residual_low=None):
         """One SynthesisLayer (networks.py:1010-1042): modulated conv (+FIR) -> [attention] -> noise -> bias/lrelu."""
         n = x.shape[0]
@@ -642,10 +661,13 @@ class Generator:
         has_att = lp.attn is not None
         s, d = self._s(lp), self._d(lp)
         if lp.kind == "tconv":
-            t = cv.tconv3x3s2_forward(x, lp.pc, in_scale=s, out_scale=d, out=B["t"])
+            t = cv.tconv3x3s2_forward(x, lp.pc, in_scale=s, out_scale=d, out=B["t"], bf=lp.pcb)
             # plan.fir is the outer product of the 1-D resample kernel (networks.py:1113 / upfirdn2d.setup_filter): separable
             y = cv.upfirdn_into(B[key], t, self.plan.fir, up=1, pad=(1, 1, 1, 1), gain=4.0, epilogue=None if has_att else ep,
                                 separable=True)
+        elif self._bf_direct(lp, n, residual_low):
+            # bf16x3 mode: the direct 3x3 form at three bf16 matrix instructions per 16 channels beats float32 Winograd below 256^2
+            y = cv.conv_forward(x, lp.pc, pad=(1, 1), in_scale=s, out_scale=d, epilogue=None if has_att else ep, out=B[key], bf=lp.pcb)
         elif lp.wino_u is not None and cv.winograd_fills_chip(n, lp.cout, lp.res, lp.res):
             y = cv.winograd_forward(x, lp.wino_u, in_scale=s, out_scale=d, epilogue=None if has_att else ep, out=B[key],
                                     residual_low=residual_low)

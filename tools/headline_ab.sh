@@ -10,7 +10,7 @@ except Exception as e:
     print("HEADLINE", sys.argv[2], "failed", e)
 PY
 }
-X="--no-cpu-baseline --gradient-steps 0 --targets 0 --objectives 0 --landmark-callback none --config4 0 --config5-targets 0"
+X="--bf16x3-leg 0 --no-cpu-baseline --gradient-steps 0 --targets 0 --objectives 0 --landmark-callback none --config4 0 --config5-targets 0"
 run b32      MGF_D=0 python bench.py $X
 run b48      MGF_D=0 python bench.py $X --batch 48 --steps 14
 run b64      MGF_D=0 python bench.py $X --batch 64 --steps 10
