@@ -953,7 +953,7 @@ extern "C" int mgf_conv_profile_end(mgf_conv_prof_rec* out, int32_t max_recs) {
         if (out && n < max_recs) {
             mgf_conv_prof_rec& o = out[n];
             if (r.name) snprintf(o.kernel, sizeof(o.kernel), "%s", r.name);
-            else snprintf(o.kernel, sizeof(o.kernel), "conv_taps_kernel<%d, %d, %d, %s, %d>", r.wm, r.wn, r.mode, r.pipe ? "true" : "false", r.nt);
+            else snprintf(o.kernel, sizeof(o.kernel), "conv_taps_kernel<%d, %d, %d, %s, %d, 0>", r.wm, r.wn, r.mode, r.pipe ? "true" : "false", r.nt);
             o.flops = r.flops; o.bytes = r.bytes; o.seconds = ms * 1e-3; o.ksplit = r.ksplit;
         }
         ++n;

@@ -2,7 +2,7 @@
 # Reduce one measurement pass (gpurun_out/<dir> with bench.json, trace/, pmc_fetch/, pmc_write/, pmc_mfma/) into profiles/<round>_*.
 # usage: tools/refresh_profiles.sh gpurun_out/r2m [steps_per_forward] [round]
 set -e
-D=$1; B=${2:-25}; R=${3:-r2}
+D=$1; B=${2:-32}; R=${3:-r5}
 cd "$(dirname "$0")/.."
 DB=$(ls -t $(find $D/trace -name "*_results.db") | head -1)      # the newest database: a re-used directory may hold an older one
 python tools/rocpd_stats.py $DB > profiles/${R}_bench_kernel_stats.txt
