@@ -406,8 +406,11 @@ SPLIT_TCONV_BORDER = os.environ.get("MGF_TCONV_BORDER", "1") != "0"       # tuni
 TCONV_SPLIT_MIN = int(os.environ.get("MGF_TCONV_SPLIT_MIN", "16"))         # smallest map side that takes the split (tuning hook)
 
 
-def tconv_pitch(w: int) -> int:
-    return round_up(2 * w + 1, 4)
+def tconv_pitch(w: int, align: int = 4) -> int:
+    """Row pitch (floats) of the transposed conv's [2h+1, 2w+1] workspace: a multiple of 4 (aligned float2 / float4 accesses).  align=32
+    starts every row on a 128-byte line: the 256-byte row segments a tile stores are then whole lines -- nothing for the float32 kernel,
+    whose stores hide under matrix work, but 22 % of the 512 -> 1024 launch in the bf16x3 mode, whose stores do not (2310 -> 1806 us)."""
+    return round_up(2 * w + 1, align)
 
 
 def conv3x3s2_few_inputs(x, w, bias=None, relu=False, out=None):
@@ -435,10 +438,10 @@ def tconv3x3s2_forward(x, pc: PackedConv, in_scale=None, out_scale=None, out=Non
     assert pc.kh == 3 and pc.kw == 3 and x.dtype == torch.float32 and x.is_contiguous()
     n, cin, h, w = x.shape
     oh, ow = 2 * h + 1, 2 * w + 1
-    pitch = tconv_pitch(w)
     if out is None:
-        out = torch.empty([n, pc.cout, oh, pitch], dtype=torch.float32, device=x.device)
-    assert out.is_contiguous() and tuple(out.shape) == (n, pc.cout, oh, pitch)
+        out = torch.empty([n, pc.cout, oh, tconv_pitch(w)], dtype=torch.float32, device=x.device)
+    pitch = out.shape[3]                               # (the caller's workspace decides: tconv_pitch(w) or a 128-byte aligned one)
+    assert out.is_contiguous() and tuple(out.shape) == (n, pc.cout, oh, pitch) and pitch >= ow and pitch % 4 == 0
     # The MFMA launch tiles the h x w grid of 2x2 output quads exactly (rows/columns 0 .. 2h-1 / 2w-1); the last row and column
     # -- 4*in + 1 positions with at most two taps each -- come from a small border kernel.  Tiling (h+1) x (w+1) instead would
     # spend 7-20 % of the MFMA work on padding (33-wide parity grids over 32-wide tiles) -- and half of it on a 16 px map, whose 17 x 17

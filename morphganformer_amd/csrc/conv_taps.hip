@@ -268,6 +268,26 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
     unsigned xoffb[XI];
     unsigned woffb[WSB];
     struct StageSet { float x[XI][8]; u32x4 w[WSB]; float4 s[2]; };
+    // tile-invariant parts of the slot addresses, once per kernel (no integer division on the per-tile path): footprint row / column of
+    // each item, and the weight vector's offset inside a channel tile's slab
+    int itr[XI], itq[XI];
+    unsigned wbase0[WSB];
+    if (AR) {
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int px = lp + 128 * j;
+            itr[j] = px / p.fw;
+            itq[j] = px - itr[j] * p.fw;
+            if (px >= chs) itr[j] = 1 << 20;           // (past the footprint: out of every map)
+        }
+#pragma unroll
+        for (int j = 0; j < WSB; ++j) {
+            int i = stid + 256 * j;
+            if (i >= 36 * CO_T) i = 36 * CO_T - 1;    // (surplus slots: loaded, never stored)
+            const int cc = i % CO_T, rest = i / CO_T; // rest = (term * 9 + tap) * 2 + half
+            wbase0[j] = 16u * (unsigned)(rest * d.cout_pad + cc);
+        }
+    }
     const __amdgpu_buffer_rsrc_t rwb_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.wb, 0, -1, 0x00020000);
     auto setup_slots_b = [&](const TileCtx& c) {
         rx_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)c.n * d.cin * plane), 0, (int)(4u * (unsigned)(d.cin * plane)), 0x00020000);
@@ -275,18 +295,11 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         const int iy0 = c.ty0 * d.istride + p.dy_min, ix0 = c.tx0 * d.istride + p.dx_min;
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
-            const int px = lp + 128 * j;
-            const int r = px / p.fw, q = px - r * p.fw;
-            const int iy = iy0 + r, ix = ix0 + q;
-            xoffb[j] = (px < chs && iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) ? 4u * (unsigned)(8 * h_st * plane + iy * d.in_w + ix) : 0xFFFFFFF0u;
+            const int iy = iy0 + itr[j], ix = ix0 + itq[j];
+            xoffb[j] = (iy >= 0 && iy < d.in_h && ix >= 0 && ix < d.in_w) ? 4u * (unsigned)(8 * h_st * plane + iy * d.in_w + ix) : 0xFFFFFFF0u;
         }
 #pragma unroll
-        for (int j = 0; j < WSB; ++j) {
-            int i = stid + 256 * j;
-            if (i >= 36 * CO_T) i = 36 * CO_T - 1;    // (surplus slots: loaded, never stored)
-            const int cc = i % CO_T, rest = i / CO_T; // rest = (term * 9 + tap) * 2 + half
-            woffb[j] = 16u * (unsigned)(rest * d.cout_pad + c.co0 + cc);
-        }
+        for (int j = 0; j < WSB; ++j) woffb[j] = wbase0[j] + 16u * (unsigned)c.co0;
     };
     auto load_chunk_b = [&](StageSet& S, int c0) {
         const int wso = (int)(16u * (unsigned)((c0 / CKB) * 36 * d.cout_pad)), sso = c0 * sc_step;

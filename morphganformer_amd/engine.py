@@ -225,6 +225,7 @@ class Generator:
             raise ValueError(f"arith must be 'f32' or 'bf16x3' (got {arith!r})")
         self.cfg = cfg
         self.arith = arith
+        self.tpitch_align = 32 if arith == "bf16x3" else 4         # transposed-conv workspace rows on 128-byte lines in the bf16x3 mode (conv.tconv_pitch)
         self.plan = SynthesisPlan(sd, cfg, device, arith=arith)
         self.device = self.plan.device
         self.input_shape = [None, cfg.k, cfg.z_dim]
@@ -316,7 +317,7 @@ class Generator:
             a["U"] = max(a["U"], c * px)
             a["W%d" % (i & 1)] = max(a["W%d" % (i & 1)], c * px)
             if res > 4:
-                a["T"] = max(a["T"], c * (res + 1) * cv.tconv_pitch(res // 2))
+                a["T"] = max(a["T"], c * (res + 1) * cv.tconv_pitch(res // 2, self.tpitch_align))
                 a["SL"] = max(a["SL"], c * px // 4)
                 if not self._fuses_skip_up(conv1[res], n):
                     a["S"] = max(a["S"], c * px)
@@ -363,7 +364,7 @@ class Generator:
                     b["conv1a"] = view(W, n, c, res, res)
                 if res > 4:
                     b["skip_low"] = view("SL", n, c, res // 2, res // 2)
-                    b["t"] = view("T", n, c, res + 1, cv.tconv_pitch(res // 2))
+                    b["t"] = view("T", n, c, res + 1, cv.tconv_pitch(res // 2, self.tpitch_align))
                     b["conv0"] = view("U", n, c, res, res)
                     if att:
                         b["conv0a"] = view("V", n, c, res, res)
@@ -378,7 +379,7 @@ class Generator:
             if res > 4:
                 b["skip_low"] = e(n, c, res // 2, res // 2)
                 b["skip"] = e(n, c, res, res)
-                b["t"] = e(n, c, res + 1, cv.tconv_pitch(res // 2))
+                b["t"] = e(n, c, res + 1, cv.tconv_pitch(res // 2, self.tpitch_align))
                 b["conv0"] = e(n, c, res, res)
                 if cfg.has_attention(res):
                     b["conv0a"] = e(n, c, res, res)
