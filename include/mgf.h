@@ -346,6 +346,15 @@ int mgf_mapping_forward(float* w, const float* z, const float* params, int32_t n
 int64_t mgf_reduce_scratch_floats(void);
 int mgf_mse_f32(float* out, const float* a, const float* b, int32_t n, int64_t numel, int64_t b_batch_stride, float scale,
                 int32_t accumulate, float* scratch, mgf_stream_t stream);
+/* dssim: out[i] (+)= scale * (1 - SSIM(u8(img[i]), u8(target))) / 2 as float32 -- `dssim`, 1024_example_SSIM.py:115-117 (the same function as
+ *        lpips/__init__.py:54-55): skimage's compare_ssim(data_range, multichannel=True) with its defaults (7x7 uniform window, sample
+ *        covariance, K1 0.01, K2 0.03, the window positions whole inside the image, mean over positions, then over channels).
+ *        u8(x) = clip(rint(x * 127.5 + 127.5), 0, 255): the image the drivers save (misc.to_pil, misc.py:115-116).  img [n,c,h,w] in [-1, 1],
+ *        target [c,h,w] (t_batch_stride 0) or one per sample; h, w >= 7; scratch: mgf_dssim_scratch_bytes(n,c,h,w) bytes, 8-byte aligned.
+ *        The window sums are exact integers, everything above them float64 in a fixed order (bit-reproducible). */
+int64_t mgf_dssim_scratch_bytes(int32_t n, int32_t c, int32_t h, int32_t w);
+int mgf_dssim_u8_f32(float* out, const float* img, const float* target, int32_t n, int32_t c, int32_t h, int32_t w, int64_t t_batch_stride,
+                     float data_range, float scale, int32_t accumulate, void* scratch, mgf_stream_t stream);
 int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int32_t n, int64_t numel, double omega, double epsilon,
                       const int32_t* pred_step, int32_t max_row, mgf_stream_t stream);
 /* AdaptiveWingLoss(omega=14, theta=0.5, epsilon=1, alpha=2.1) of adaptive_wing_loss.py:12-39, same row addressing as the wing loss */

@@ -40,7 +40,7 @@ def _loop_arguments(p):
                    help="with --mode gradient: optimise the per-layer latent W+ [k, num_ws, D] instead of z (the reference accepts the flag "
                         "and never reads it; in literal mode it stays unused here too)")
     p.add_argument("--percept_weight", type=float, default=1.0, help="coefficient of the LPIPS term (0.5 with --beta 0.5 = 1024_example_percept_MSE.py)")
-    p.add_argument("--pixel-term", choices=["mse", "psnr"], default="mse",
+    p.add_argument("--pixel-term", choices=["mse", "psnr", "dssim"], default="mse",
                    help="psnr = the pixel term of 1024_example_PSNR.py (10 log10(255^2 / MSE), minimised like the script does; use with --no-lpips)")
     p.add_argument("--pool-above", type=int, default=0,
                    help="projection_example_v1.py:150-155: block-average generated images taller than this (256 there) by height // N before the "

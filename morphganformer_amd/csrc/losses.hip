@@ -765,3 +765,119 @@ extern "C" int mgf_to_uint8_hwc(uint8_t* out, const float* img, int32_t c, int32
     MGF_CHECK_LAUNCH("to_uint8");
     return MGF_OK;
 }
+
+// ---- DSSIM of the uint8 images (`dssim`, 1024_example_SSIM.py:115-117 = lpips/__init__.py:54-55: (1 - compare_ssim(p0, p1, data_range=255,
+// multichannel=True)) / 2, skimage's defaults: 7x7 uniform window, sample covariance, K1 = 0.01, K2 = 0.03, the window positions that lie
+// whole inside the image, mean over positions then over channels).  Both images are quantised like the image the drivers save
+// (misc.to_pil:115-116: rint(x * 127.5 + 127.5) clipped to 0..255), so the five window sums (x, y, xx, yy, xy over 49 pixels) are exact
+// integers (< 2^22); the SSIM quotient and every sum above it are float64 in a fixed order.
+// grid = (tiles, c, n); a workgroup owns 32 x 32 window positions of one channel plane and reads the 38 x 38 pixels under them.
+constexpr int DS_T = 32, DS_W = 7, DS_R = DS_T + DS_W - 1;
+__device__ __forceinline__ int ds_quant(float v) {
+    v = rintf(v * 127.5f + 127.5f);
+    return (int)fminf(fmaxf(v, 0.f), 255.f);
+}
+__global__ __launch_bounds__(256) void dssim_partial_kernel(double* part, const float* img, const float* tgt, int h, int w, int64_t t_stride,
+                                                            int tiles_x, double c1, double c2) {
+    __shared__ int xs[DS_R][DS_R + 1], ys[DS_R][DS_R + 1];
+    __shared__ int hs[5][DS_R][DS_T + 1];
+    __shared__ double red[256];
+    const int tile = blockIdx.x, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int c = gridDim.y;
+    const int64_t plane = (int64_t)h * w;
+    const float* a = img + ((int64_t)blockIdx.z * c + blockIdx.y) * plane;
+    const float* b = tgt + (int64_t)blockIdx.z * t_stride + (int64_t)blockIdx.y * plane;
+    const int r0 = ty * DS_T, q0 = tx * DS_T;
+    for (int i = threadIdx.x; i < DS_R * DS_R; i += 256) {
+        const int r = i / DS_R, q = i - r * DS_R;
+        const int rr = r0 + r, qq = q0 + q;
+        int xv = 0, yv = 0;
+        if (rr < h && qq < w) { xv = ds_quant(a[(int64_t)rr * w + qq]); yv = ds_quant(b[(int64_t)rr * w + qq]); }
+        xs[r][q] = xv; ys[r][q] = yv;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < DS_R * DS_T; i += 256) {
+        const int r = i / DS_T, q = i - r * DS_T;
+        int sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+        for (int t = 0; t < DS_W; ++t) {
+            const int xv = xs[r][q + t], yv = ys[r][q + t];
+            sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+        }
+        hs[0][r][q] = sx; hs[1][r][q] = sy; hs[2][r][q] = sxx; hs[3][r][q] = syy; hs[4][r][q] = sxy;
+    }
+    __syncthreads();
+    double acc = 0.0;
+    const int vh = h - (DS_W - 1), vw = w - (DS_W - 1);         // window positions per plane
+    for (int i = threadIdx.x; i < DS_T * DS_T; i += 256) {
+        const int r = i / DS_T, q = i - r * DS_T;
+        if (r0 + r >= vh || q0 + q >= vw) continue;
+        int s[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int v = 0;
+#pragma unroll
+            for (int t = 0; t < DS_W; ++t) v += hs[k][r + t][q];
+            s[k] = v;
+        }
+        constexpr double inv = 1.0 / (DS_W * DS_W), cov = (double)(DS_W * DS_W) / (DS_W * DS_W - 1);
+        const double ux = s[0] * inv, uy = s[1] * inv, uxx = s[2] * inv, uyy = s[3] * inv, uxy = s[4] * inv;
+        const double vx = cov * (uxx - ux * ux), vy = cov * (uyy - uy * uy), vxy = cov * (uxy - ux * uy);
+        const double a1 = 2.0 * ux * uy + c1, a2 = 2.0 * vxy + c2, b1 = ux * ux + uy * uy + c1, b2 = vx + vy + c2;
+        acc += (a1 * a2) / (b1 * b2);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[((int64_t)blockIdx.z * c + blockIdx.y) * gridDim.x + tile] = red[0];
+}
+
+// grid = n: out = (accumulate ? out : 0) + scale * (1 - mean_c mean_positions S) / 2, the value as float32 like the script's FloatTensor (:159)
+__global__ __launch_bounds__(256) void dssim_finish_kernel(float* out, const double* part, int c, int tiles, double positions, float scale,
+                                                           int accumulate) {
+    __shared__ double red[256];
+    double m = 0.0;
+    for (int ch = 0; ch < c; ++ch) {
+        const double* p = part + ((int64_t)blockIdx.x * c + ch) * tiles;
+        double v = 0.0;
+        for (int i = threadIdx.x; i < tiles; i += 256) v += p[i];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+            if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+            __syncthreads();
+        }
+        m += red[0] / positions;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = (float)((1.0 - m / c) / 2.0) * scale;
+        out[blockIdx.x] = accumulate ? out[blockIdx.x] + v : v;
+    }
+}
+
+extern "C" int64_t mgf_dssim_scratch_bytes(int32_t n, int32_t c, int32_t h, int32_t w) {
+    if (n < 1 || c < 1 || h < DS_W || w < DS_W) return 0;
+    const int64_t tiles = (int64_t)mgf_cdiv(h - (DS_W - 1), DS_T) * mgf_cdiv(w - (DS_W - 1), DS_T);
+    return (int64_t)n * c * tiles * (int64_t)sizeof(double);
+}
+
+extern "C" int mgf_dssim_u8_f32(float* out, const float* img, const float* target, int32_t n, int32_t c, int32_t h, int32_t w,
+                                int64_t t_batch_stride, float data_range, float scale, int32_t accumulate, void* scratch,
+                                mgf_stream_t stream) {
+    MGF_REQUIRE(out && img && target && scratch && n >= 1 && n <= 65535 && c >= 1 && c <= 65535, MGF_EINVAL, "dssim: bad arguments");
+    MGF_REQUIRE(h >= DS_W && w >= DS_W, MGF_EINVAL, "dssim: the image is smaller than the 7x7 window (skimage raises here)");
+    MGF_REQUIRE(data_range > 0.f && (uintptr_t)scratch % 8 == 0, MGF_EINVAL, "dssim: data_range must be positive, scratch 8-byte aligned");
+    const int tiles_y = (int)mgf_cdiv(h - (DS_W - 1), DS_T), tiles_x = (int)mgf_cdiv(w - (DS_W - 1), DS_T);
+    const double c1 = (0.01 * (double)data_range) * (0.01 * (double)data_range), c2 = (0.03 * (double)data_range) * (0.03 * (double)data_range);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dssim_partial_kernel, dim3(tiles_x * tiles_y, c, n), dim3(256), 0, st, (double*)scratch, img, target, h, w,
+                       t_batch_stride, tiles_x, c1, c2);
+    hipLaunchKernelGGL(dssim_finish_kernel, dim3(n), dim3(256), 0, st, out, (const double*)scratch, c, tiles_x * tiles_y,
+                       (double)(h - (DS_W - 1)) * (double)(w - (DS_W - 1)), scale, accumulate);
+    MGF_CHECK_LAUNCH("dssim");
+    return MGF_OK;
+}

@@ -53,6 +53,9 @@ class ProjectionArgs:
     # "mse": beta * MSE(img, target), the drivers' pixel term.  "psnr": the pixel term of 1024_example_PSNR.py:113-114,158 --
     # 10 log10(255^2 / mean((img - target)^2)) on the [-1, 1] float images, MINIMISED like every other loss of these loops (:173-175 keeps
     # the candidate with the smallest value; the script's objective as written, not a claim that it is a sensible one)
+    # "dssim": `dssim` of 1024_example_SSIM.py:115-117 (= lpips/__init__.py:54-55), (1 - SSIM) / 2 with skimage's defaults, on the uint8
+    # images (the generated image as the drivers save it, misc.to_pil) -- the function as defined; the script's own call site (:158) passes
+    # flattened float arrays, which compare_ssim rejects
     pixel_term: str = "mse"
     # projection_example_v1.py:150-155: a generated image taller than `pool_above` pixels is block-averaged by height // pool_above before
     # the image-space losses (the target is then given at the pooled size, :84-92 resize it to 256); 0 = off (the 1024 drivers)
@@ -224,8 +227,14 @@ class ProjectionEngine:
         self.w_loss = torch.zeros(B, dtype=torch.float64, device=dev)
         self.scratch = torch.empty(B * int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=dev)
         self._arange = torch.arange(B, dtype=torch.int64, device=dev)
-        assert a.pixel_term in ("mse", "psnr"), a.pixel_term
+        assert a.pixel_term in ("mse", "psnr", "dssim"), a.pixel_term
         self._init_pool(B)
+        if a.pixel_term == "dssim" and use_mse:
+            c, h, w = self.target.shape[-3:]
+            nbytes = int(_lib.lib().mgf_dssim_scratch_bytes(B, c, h, w))
+            if nbytes <= 0:
+                raise _lib.MgfError(f"projection: pixel_term='dssim' needs images of at least 7x7 pixels, got {h}x{w}")
+            self.dssim_scratch = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
         if self.percept is not None:
             self.percept.set_target(self.target)
         self.biometric, self.gamma = biometric, float(gamma)
@@ -317,7 +326,11 @@ class ProjectionEngine:
                 self.p_loss.mul_(float(a.percept_weight))
         if self.biometric is not None:      # rides in the p_loss slot: p_loss = LPIPS + gamma * embedding MSE
             self.biometric.distance_into(self.p_loss, img, scale=self.gamma, accumulate=self.percept is not None)
-        if self.use_mse:
+        if self.use_mse and a.pixel_term == "dssim":
+            c, h, w = img.shape[1:]
+            _lib.check(L.mgf_dssim_u8_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), B, c, h, w, 0, 255.0, 1.0, 0,
+                                          self.dssim_scratch.data_ptr(), st), "dssim")
+        elif self.use_mse:
             per = img.numel() // B
             _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), B, per, 0, 1.0, 0,
                                      self.scratch.data_ptr(), st), "mse")
@@ -721,7 +734,7 @@ class GradientProjectionEngine(ProjectionEngine):
         self.targets = B
         a, dev = self.args, self.device
         if a.pixel_term != "mse" or a.pool_above:
-            raise _lib.MgfError("GradientProjectionEngine: pixel_term='psnr' / pool_above are literal-mode objectives (the PSNR / v1 drivers "
+            raise _lib.MgfError("GradientProjectionEngine: pixel_term='psnr' / 'dssim' / pool_above are literal-mode objectives (the PSNR / v1 drivers "
                                 "sever the gradient like every other driver; only the Wing / LPIPS / MSE / biometric terms have backward passes)")
         if biometric is not None and hasattr(biometric.embedder, "keep_activations"):
             biometric.embedder.keep_activations = True          # (the FaceNet embedder re-uses its buffers block after block otherwise)

@@ -60,6 +60,54 @@ def psnr_ref(p0, p1, peak=255.0):
     return 10 * np.log10(peak ** 2 / np.mean((1. * a - 1. * b) ** 2))
 
 
+def to_u8_ref(img):
+    """misc.py:115-116 (`to_pil`): adjust_range([-1, 1] -> [0, 255]) in float32, np.rint, clip, uint8 -- the image the drivers save."""
+    import numpy as np
+    x = np.asarray(img, dtype=np.float32)
+    scale = (np.float32(255) - np.float32(0)) / (np.float32(1) - np.float32(-1))
+    bias = np.float32(0) - np.float32(-1) * scale
+    return np.rint(x * scale + bias).clip(0, 255).astype(np.uint8)
+
+
+def ssim_ref(X, Y, data_range=255.0, win_size=7, K1=0.01, K2=0.03):
+    """skimage.measure.compare_ssim(X, Y, data_range=..., multichannel=True) with its defaults, restated from the published source
+    (scikit-image 0.14-0.16, skimage/measure/_structural_similarity.py; Wang, Bovik, Sheikh, Simoncelli 2004) -- scikit-image is NOT in this
+    image, so this half is UNPINNED against the library itself and held by hand-computed known answers (tests/test_oracle.py) instead.
+    X, Y: [H, W, C] arrays of one dtype.  Per channel: uniform_filter means / second moments over win_size x win_size, sample covariance
+    (cov_norm = NP / (NP - 1)), S = (2 ux uy + C1)(2 vxy + C2) / ((ux^2 + uy^2 + C1)(vx + vy + C2)), mean of S over the positions whose
+    window lies inside the image (crop by (win_size - 1) // 2); then the mean over channels."""
+    import numpy as np
+    from scipy.ndimage import uniform_filter
+    X, Y = np.asarray(X), np.asarray(Y)
+    assert X.shape == Y.shape and X.dtype == Y.dtype and X.ndim == 3
+    if min(X.shape[:2]) < win_size:
+        raise ValueError("win_size exceeds image extent")        # what compare_ssim raises (and what :158's flattened call runs into)
+    per = []
+    for ch in range(X.shape[-1]):
+        x, y = X[..., ch].astype(np.float64), Y[..., ch].astype(np.float64)
+        NP = win_size ** 2
+        cov_norm = NP / (NP - 1)
+        ux, uy = uniform_filter(x, size=win_size), uniform_filter(y, size=win_size)
+        uxx, uyy, uxy = uniform_filter(x * x, size=win_size), uniform_filter(y * y, size=win_size), uniform_filter(x * y, size=win_size)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+        S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+        pad = (win_size - 1) // 2
+        per.append(S[pad:S.shape[0] - pad, pad:S.shape[1] - pad].mean())
+    return float(np.mean(per))
+
+
+def dssim_ref(img, target, data_range=255.0):
+    """`dssim` (1024_example_SSIM.py:115-117 = lpips/__init__.py:54-55): (1 - compare_ssim(p0, p1, data_range=255, multichannel=True)) / 2
+    of the uint8 HWC images; img, target: [C, H, W] float images in [-1, 1], quantised like the saved image (to_u8_ref).  float32 like the
+    script's torch.FloatTensor (:159).  The script itself hands compare_ssim FLATTENED float arrays (:158), which compare_ssim rejects
+    (a 1-D array is narrower than the window): this is the function as defined, on the images the function is documented for."""
+    import numpy as np
+    a = to_u8_ref(img).transpose(1, 2, 0)
+    b = to_u8_ref(target).transpose(1, 2, 0)
+    return np.float32((1 - ssim_ref(a, b, data_range=data_range)) / 2.)
+
+
 def pool_above_ref(img, above=256):
     """projection_example_v1.py:148-155: an image taller than `above` is averaged over factor x factor blocks, factor = height // above."""
     import numpy as np

@@ -473,6 +473,73 @@ def test_psnr_objective_variant(golden):
     assert bstep == int(np.argmin(losses)) and bloss == float(losses.min()) and 20 < want.min() < 100
 
 
+def test_dssim_kernel_vs_oracle_and_full_size():
+    """mgf_dssim_u8_f32 (`dssim`, 1024_example_SSIM.py:115-117 = lpips/__init__.py:54-55) against oracle.loss_ref.dssim_ref on the same float
+    images: window-edge sizes (7x7 = one position, one past a tile, ragged), 1 and 3 channels, a shared target and one target per sample,
+    scale / accumulate; identical images give exactly 0; one 1024^2 pair (the reference's size) against the oracle."""
+    from morphganformer_amd import _lib
+    from oracle.loss_ref import dssim_ref
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+
+    def run(img, tgt, shared, scale=1.0, acc=None):
+        n, c, h, w = img.shape
+        out = torch.zeros(n, dtype=torch.float32, device="cuda") if acc is None else acc.clone()
+        scratch = torch.empty(int(L.mgf_dssim_scratch_bytes(n, c, h, w)) // 8, dtype=torch.float64, device="cuda")
+        _lib.check(L.mgf_dssim_u8_f32(out.data_ptr(), img.data_ptr(), tgt.data_ptr(), n, c, h, w, 0 if shared else c * h * w, 255.0, scale,
+                                      0 if acc is None else 1, scratch.data_ptr(), _lib.stream_ptr()), "dssim")
+        return out.cpu().numpy()
+
+    for (n, c, h, w) in [(1, 1, 7, 7), (2, 3, 7, 40), (3, 3, 38, 39), (2, 1, 39, 71), (2, 3, 64, 64), (1, 3, 101, 133)]:
+        base = rng.uniform(-1.2, 1.2, (c, h, w)).astype(np.float32)
+        img = (base[None] + rng.normal(0, 0.2, (n, c, h, w))).astype(np.float32)
+        tgts = (base[None] + rng.normal(0, 0.05, (n, c, h, w))).astype(np.float32)
+        got = run(torch.from_numpy(img).cuda(), torch.from_numpy(base).cuda(), True)
+        want = np.array([dssim_ref(img[i], base) for i in range(n)])
+        assert np.abs(got - want).max() < 2e-7, (n, c, h, w, got, want)
+        got = run(torch.from_numpy(img).cuda(), torch.from_numpy(tgts).cuda(), False, scale=0.5, acc=torch.full([n], 2.0, device="cuda"))
+        want = np.array([2.0 + 0.5 * dssim_ref(img[i], tgts[i]) for i in range(n)], dtype=np.float32)
+        assert np.abs(got - want).max() < 5e-7, (n, c, h, w, got, want)
+        same = run(torch.from_numpy(img).cuda(), torch.from_numpy(img).cuda(), False)
+        assert (same == 0).all()
+    with pytest.raises(_lib.MgfError):
+        run(torch.zeros(1, 3, 6, 9, device="cuda"), torch.zeros(3, 6, 9, device="cuda"), True)
+    # the reference's size: smooth images with noise (the statistics of a face, not of white noise)
+    yy, xx = np.mgrid[0:1024, 0:1024].astype(np.float32) / 1024
+    base = np.stack([np.sin(6 * xx + 3 * yy), np.cos(5 * yy) * xx, xx * yy * 2 - 1]).astype(np.float32)
+    img = (base[None] + rng.normal(0, 0.08, (2, 3, 1024, 1024))).astype(np.float32)
+    got = run(torch.from_numpy(img).cuda(), torch.from_numpy(base).cuda(), True)
+    want = np.array([dssim_ref(img[i], base) for i in range(2)])
+    assert np.abs(got - want).max() < 2e-7 and 0.05 < want.min() < 0.5, (got, want)
+
+
+def test_dssim_objective_variant(golden):
+    """1024_example_SSIM.py:115-117,173-175: the loop keeps the candidate with the smallest (1 - SSIM) / 2 of the uint8 images -- every
+    recorded loss against the oracle's dssim on the oracle's image (a pixel within 1e-3 of a rounding boundary may quantise one level apart:
+    1e-3 on a loss of order 0.3), best step = argmin."""
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from oracle.generator_ref import generator_ref, to_torch_state
+    from oracle.loss_ref import dssim_ref
+    g = golden("loop_tiny.npz")
+    steps = 7
+    tsd = to_torch_state(make_state_dict(TINY, seed=0))
+    eng = ProjectionEngine(_tiny_gen(), torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]),
+                           ProjectionArgs(step=steps, pixel_term="dssim"), percept=None, use_mse=True, eps=torch.from_numpy(g["eps"][:steps]).cuda(),
+                           noise_mode="const", batch=3)
+    lat, bstep, bloss, losses = eng.run().result()
+    want = []
+    for i in range(steps):
+        sigma = np.float32(np.float32(float(g["latent_std"])) * np.float32(0.05)) * np.float32(max(0, 1 - (i / steps) / 0.75) ** 2)
+        z = torch.from_numpy(g["latent_mean"])[None] + torch.from_numpy(g["eps"][i]) * float(sigma)
+        with torch.no_grad():
+            img = generator_ref(tsd, z, TINY, "const")
+        want.append(float(dssim_ref(img.numpy()[0], g["target"].reshape(img.shape[1:]))))
+    want = np.array(want)
+    assert np.abs(losses - want).max() < 1e-3, (losses, want)
+    assert bstep == int(np.argmin(losses)) and bloss == float(losses.min()) and 0 < want.min() < 0.5
+
+
 def test_v1_pooled_percept_objective(golden):
     """projection_example_v1.py:148-160: a generated image taller than 256 px is block-averaged by height // 256 before LPIPS, against a
     target given at the pooled size -- here the 64^2 generator with pool_above=32 (factor 2), LPIPS(squeeze) only: every recorded loss against

@@ -402,3 +402,35 @@ def test_cv_warp_host_plan_equals_the_literal_transcription():
     for _ in range(20):
         M = np.array([[1, 0, 0], [0, 1, 0]], np.float64) + rng.uniform(-0.6, 0.6, (2, 3)) * np.array([1, 1, 6.0])
         assert np.array_equal(W.warp_affine_linear_reflect101(src, M, (13, 10)), W.warp_affine_linear_reflect101_rows(src, M, (13, 10)))
+
+
+def test_ssim_ref_known_answers_by_hand():
+    """oracle.loss_ref.ssim_ref restates skimage's compare_ssim (absent here, so unpinned against the library): held by answers that follow
+    from the published formula -- identical images 1; two constant images (2ab + C1) / (a^2 + b^2 + C1) (both variances and the covariance
+    vanish, so the contrast term is C2 / C2); a window-by-window evaluation with numpy's own sample moments on a small random pair; a
+    1-D (flattened) input is refused like compare_ssim refuses it (what 1024_example_SSIM.py:158 runs into)."""
+    from oracle.loss_ref import dssim_ref, ssim_ref, to_u8_ref
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (13, 17, 3)).astype(np.uint8)
+    b = rng.integers(0, 256, (13, 17, 3)).astype(np.uint8)
+    assert ssim_ref(a, a) == 1.0
+    x, y = np.full((9, 11, 1), 100, np.uint8), np.full((9, 11, 1), 50, np.uint8)
+    c1 = (0.01 * 255) ** 2
+    assert abs(ssim_ref(x, y) - (2 * 100 * 50 + c1) / (100 ** 2 + 50 ** 2 + c1)) < 1e-14
+    c2 = (0.03 * 255) ** 2
+    per = []
+    for ch in range(3):
+        vals = []
+        for i in range(13 - 6):
+            for j in range(17 - 6):
+                p, q = a[i:i + 7, j:j + 7, ch].astype(np.float64).ravel(), b[i:i + 7, j:j + 7, ch].astype(np.float64).ravel()
+                cov = np.cov(p, q, ddof=1)
+                vals.append((2 * p.mean() * q.mean() + c1) * (2 * cov[0, 1] + c2) / ((p.mean() ** 2 + q.mean() ** 2 + c1) * (cov[0, 0] + cov[1, 1] + c2)))
+        per.append(np.mean(vals))
+    assert abs(ssim_ref(a, b) - np.mean(per)) < 1e-12
+    with pytest.raises((ValueError, AssertionError)):
+        ssim_ref(a.reshape(-1), b.reshape(-1))
+    # the quantisation of the saved image: rint, not truncation (misc.py:115-116)
+    assert to_u8_ref(np.array([-1.0, -0.9961, 0.0, 0.0039, 1.0, 1.5], np.float32)).tolist() == [0, 0, 128, 128, 255, 255]
+    f = (a.transpose(2, 0, 1).astype(np.float32) / 127.5 - 1)
+    assert dssim_ref(f, f) == 0 and dssim_ref(f, f).dtype == np.float32
