@@ -127,7 +127,41 @@ def build_parser():
     w.add_argument("--out", type=str, required=True, help="output directory: morph_G.png, Morph_final.png")
     w.add_argument("--gpus", type=str, default="0")
     w.add_argument("--truncation_psi", type=float, default=0.7)
+    e = sub.add_parser("extract-facenet", help="The FaceNet feature of image files (`facenet_feature`, extract_FaceNet.py:30-40): 224x224 "
+                                               "cv2-style resize, (x - 127.5) / 128, InceptionResnetV1 -> 512 numbers per image")
+    e.add_argument("images", nargs="+", help="image files")
+    e.add_argument("--out", type=str, required=True, help=".mat (scipy.io.savemat: `names`, `features` [N, 512]) or .npy ([N, 512])")
+    e.add_argument("--biometric-weights", type=str, default=None, metavar="STATE_DICT",
+                   help="facenet_pytorch's InceptionResnetV1 state dict (.pth / .npz) -- what the reference fetches with pretrained='vggface2'")
+    e.add_argument("--biometric-random", action="store_true", help="seeded random embedder weights (smoke runs only)")
+    e.add_argument("--gpus", type=str, default="0")
     return ap
+
+
+def _extract_facenet(a):
+    import numpy as np
+    import torch
+    from PIL import Image
+    from . import drivers
+    from .facenet import InceptionResnetV1Embedder, random_state
+    if a.biometric_weights is None and not a.biometric_random:
+        raise SystemExit("extract-facenet: the embedder's weights are needed: --biometric-weights <state dict> (or --biometric-random)")
+    if a.biometric_weights:
+        state = dict(np.load(a.biometric_weights)) if a.biometric_weights.endswith(".npz") else \
+            {k: v.numpy() for k, v in torch.load(a.biometric_weights, map_location="cpu", weights_only=True).items()}
+    else:
+        print("WARNING: seeded random InceptionResnetV1 weights (--biometric-random); the output is not a face embedding")
+        state = random_state(0)
+    net = InceptionResnetV1Embedder(state, n=1, device="cuda")
+    feats = [drivers.facenet_feature(np.asarray(Image.open(f).convert("RGB")), net) for f in a.images]
+    feats = np.stack(feats).astype(np.float32)
+    if a.out.endswith(".npy"):
+        np.save(a.out, feats)
+    else:
+        import scipy.io as sio
+        sio.savemat(a.out, {"names": np.array(a.images, dtype=object), "features": feats})
+    print(f"{len(a.images)} feature(s) -> {a.out}")
+    return 0
 
 
 def main(argv=None):
@@ -142,6 +176,8 @@ def main(argv=None):
     import torch
     if launched:                                              # one process per GPU (torch.distributed.run): rank r works on device LOCAL_RANK
         torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+    if a.cmd == "extract-facenet":                          # no generator involved
+        return _extract_facenet(a)
     from . import drivers, loader
     from .projection import ProjectionArgs
 

@@ -762,3 +762,45 @@ def test_cli_morph_pairs(tmp_path):
     assert cli.main(proj + ["--biometric", "iresnet18", "--biometric-random", "--gamma", "1e-12", "--no-mse", "--path_to_gen", str(tmp_path / "b2")]) == 0
     with pytest.raises(SystemExit, match="switched off"):
         cli.main(proj + ["--no-mse"])
+
+
+@pytest.mark.gpu
+def test_facenet_feature_and_its_cli_verb(tmp_path):
+    """`facenet_feature` (extract_FaceNet.py:30-40): cv2.resize to 224 x 224, clamp, (x - 127.5) / 128, InceptionResnetV1, flatten -- the driver
+    against the oracle's network on the same resized input (seeded weights: parity with facenet_pytorch itself is unpinned), and the
+    `extract-facenet` verb writing the same numbers for two files."""
+    from PIL import Image
+    import scipy.io as sio
+    from morphganformer_amd import cli, drivers
+    from morphganformer_amd.facenet import InceptionResnetV1Embedder, random_state
+    from oracle.embed_ref import inception_resnet_v1_ref
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:300, 0:280].astype(np.float32)
+    imgs = []
+    for k in range(2):
+        base = np.stack([np.sin(xx / (17 + k)) + np.cos(yy / 23), np.sin((xx + yy) / 31), np.cos(xx / 11) * np.sin(yy / (13 + k))], -1)
+        imgs.append(np.clip(127.5 + 60 * base + rng.normal(0, 6, base.shape), 0, 255).astype(np.uint8))
+    sd = random_state(0)
+    net = InceptionResnetV1Embedder(sd, n=1)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    feats = []
+    for im in imgs:
+        got = drivers.facenet_feature(im, net)
+        small = drivers.cv_resize_linear_u8(im, 224, 224)
+        x = ((torch.from_numpy(small.astype(np.float32)) - 127.5) / 128.0).permute(2, 0, 1)[None]
+        with torch.no_grad():
+            want = inception_resnet_v1_ref(tsd, x).numpy().reshape(-1)
+        assert got.shape == (512,) and np.abs(got - want).max() < 1e-3 * np.abs(want).max()
+        feats.append(got)
+    assert np.abs(feats[0] - feats[1]).max() > 1e-4                 # two different faces, two different features
+    files = []
+    for k, im in enumerate(imgs):
+        files.append(str(tmp_path / f"f{k}.png"))
+        Image.fromarray(im, "RGB").save(files[-1])
+    with pytest.raises(SystemExit):
+        cli.main(["extract-facenet", *files, "--out", str(tmp_path / "f.mat")])
+    assert cli.main(["extract-facenet", *files, "--out", str(tmp_path / "f.mat"), "--biometric-random"]) == 0
+    m = sio.loadmat(str(tmp_path / "f.mat"))
+    assert m["features"].shape == (2, 512) and np.abs(m["features"] - np.stack(feats)).max() < 1e-6
+    assert cli.main(["extract-facenet", files[1], "--out", str(tmp_path / "f.npy"), "--biometric-random"]) == 0
+    assert np.abs(np.load(str(tmp_path / "f.npy"))[0] - feats[1]).max() < 1e-6

@@ -657,3 +657,20 @@ def test_lpips_backbone_topologies_against_published_parameter_counts():
     assert sum(v.size for v in random_squeeze_backbone(0).values()) == 1_235_496 - (512 * 1000 + 1000)
     assert sum(v.size for v in random_backbone("alex", 0).values()) == 2_469_696
     assert sum(v.size for v in random_backbone("vgg", 0).values()) == 14_714_688
+
+
+def test_cv_resize_linear_u8_known_answers_by_hand():
+    """drivers.cv_resize_linear_u8 restates cv2.resize's INTER_LINEAR on uint8 (cv2 is absent: unpinned against the library): answers that
+    follow from the published fixed-point scheme -- the same size is the identity; halving an even image is the rounded mean of each 2 x 2
+    block ((a + b + c + d + 2) >> 2); doubling [0, 255] gives the half-pixel-centred ramp 0, 64, 191, 255 (63.75 / 191.25 rounded)."""
+    from morphganformer_amd.drivers import cv_resize_linear_u8
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, (10, 14, 3)).astype(np.uint8)
+    assert (cv_resize_linear_u8(a, 14, 10) == a).all()
+    half = cv_resize_linear_u8(a, 7, 5)
+    blocks = a.astype(np.int64).reshape(5, 2, 7, 2, 3).sum((1, 3))
+    assert (half == ((blocks + 2) >> 2)).all()
+    ramp = cv_resize_linear_u8(np.array([[[0], [255]]], np.uint8), 4, 1)
+    assert ramp.reshape(-1).tolist() == [0, 64, 191, 255]
+    col = cv_resize_linear_u8(np.array([[[0]], [[255]]], np.uint8), 1, 4)
+    assert col.reshape(-1).tolist() == [0, 64, 191, 255]
