@@ -302,6 +302,8 @@ class Generator:
     def _fuses_skip_up(self, l1, n):
         """Does conv1 of this block up-sample the half-resolution skip tensor in its own (form-3 Winograd) epilogue at batch size n?"""
         res = l1.res
+        if l1.pcb is not None and res <= BF_DIRECT_MAX_RES:       # bf16x3 mode: this layer takes the direct kernel (full-resolution residual)
+            return False
         return bool(self.fuse_skip_up and self.plan.fir_is_1331 and cv.WINOGRAD_FORM == 3 and l1.attn is None and l1.wino_u is not None
                     and l1.wino_u.ndim == 4 and res % 2 == 0 and cv.winograd_fills_chip(n, l1.cout, res, res))
 
