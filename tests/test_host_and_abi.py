@@ -674,3 +674,21 @@ def test_cv_resize_linear_u8_known_answers_by_hand():
     assert ramp.reshape(-1).tolist() == [0, 64, 191, 255]
     col = cv_resize_linear_u8(np.array([[[0]], [[255]]], np.uint8), 1, 4)
     assert col.reshape(-1).tolist() == [0, 64, 191, 255]
+
+
+def test_c_consumer_builds_and_links_against_the_header_and_library(tmp_path):
+    """examples/abi_consumer.c compiles as C99 with -Wall -Werror against include/mgf.h and links against the built library; without a GPU it
+    stops at mgf_device_ok() with exit code 3 (tests/test_hip_ops.py runs it on the device)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/lib/libamdhip64.so"):
+        pytest.skip("gcc / the HIP runtime are not installed")
+    libdir = os.path.join(ROOT, "morphganformer_amd")
+    exe = str(tmp_path / "abi_consumer")
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "abi_consumer.c"),
+                    "-o", exe, "-L", libdir, "-lmgf_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm"], check=True)
+    import torch
+    if not torch.cuda.is_available():
+        env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+        r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 3 and "no usable gfx950 device" in r.stdout, (r.returncode, r.stdout, r.stderr)
