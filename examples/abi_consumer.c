@@ -7,7 +7,8 @@
  *   LD_LIBRARY_PATH=morphganformer_amd:/opt/rocm/lib ./abi_consumer
  *
  * Entry points exercised: mgf_bias_act (bias_act.cpp:24), mgf_upfirdn2d (upfirdn2d.cpp:8), mgf_mse_f32 (torch.nn.MSELoss of the drivers),
- * mgf_dssim_u8_f32 (`dssim`, 1024_example_SSIM.py:115-117).  Exit code 0 = every result within its stated tolerance.
+ * mgf_dssim_u8_f32 (`dssim`, 1024_example_SSIM.py:115-117), mgf_winograd2_weights_f32 + mgf_conv3x3_winograd3_f32 (modulated_conv2d,
+ * training/networks.py:288-303: the FP32-MFMA kernel of the hot path).  Exit code 0 = every result within its stated tolerance.
  */
 #include <math.h>
 #include <stdio.h>
@@ -134,10 +135,60 @@ static int test_pixel_terms(void) {
     return 0;
 }
 
+/* ---- the hot path's matrix kernel: modulated 3x3 convolution (modulated_conv2d, training/networks.py:288-303) through the Winograd form the
+ * engine uses -- y[n, co] = lrelu(d[n, co] * sum_ci (s[n, ci] w[co, ci]) (*) x[n, ci] + bias[co]) * gain, pad 1 -- against direct loops ---- */
+static int test_modulated_conv(void) {
+    enum { N = 2, CI = 8, CO = 32, H = 32, W = 32 };
+    static float x[N * CI * H * W], w[CO * CI * 9], s[N * CI], d[N * CO], bias[CO], y[N * CO * H * W];
+    unsigned sd = 11;
+    for (int i = 0; i < N * CI * H * W; ++i) x[i] = frand(&sd);
+    for (int i = 0; i < CO * CI * 9; ++i) w[i] = frand(&sd);
+    for (int i = 0; i < N * CI; ++i) s[i] = 1.0f + 0.5f * frand(&sd);
+    for (int i = 0; i < CO; ++i) bias[i] = 0.1f * frand(&sd);
+    const float wgain = 1.0f / sqrtf((float)(CI * 9));
+    for (int n = 0; n < N; ++n)                       /* demodulation d = rsqrt(sum (w s)^2 + 1e-8) (:291-293) */
+        for (int co = 0; co < CO; ++co) {
+            double acc = 0;
+            for (int ci = 0; ci < CI; ++ci)
+                for (int t = 0; t < 9; ++t) { const double v = (double)w[(co * CI + ci) * 9 + t] * wgain * s[n * CI + ci]; acc += v * v; }
+            d[n * CO + co] = (float)(1.0 / sqrt(acc + 1e-8));
+        }
+    float *dx = to_device(x, sizeof x), *dw = to_device(w, sizeof w), *ds = to_device(s, sizeof s), *dd = to_device(d, sizeof d);
+    float *db = to_device(bias, sizeof bias), *dy = to_device(NULL, sizeof y), *du = to_device(NULL, 16 * CI * CO * sizeof(float));
+    MGF(mgf_winograd2_weights_f32(du, dw, CO, CI, wgain, NULL));
+    mgf_epilogue ep;
+    memset(&ep, 0, sizeof ep);
+    ep.bias = db; ep.act = MGF_ACT_LRELU; ep.alpha = 0.2f; ep.gain = 1.41421356f; ep.noise_n = 1;
+    MGF(mgf_conv3x3_winograd3_f32(dy, dx, du, ds, dd, N, CI, H, W, CO, CO, &ep, NULL));
+    to_host(y, dy, sizeof y);
+    double worst = 0, scale = 0;
+    for (int n = 0; n < N; ++n)
+        for (int co = 0; co < CO; ++co)
+            for (int oy = 0; oy < H; ++oy)
+                for (int ox = 0; ox < W; ++ox) {
+                    double acc = 0;
+                    for (int ci = 0; ci < CI; ++ci)
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const int iy = oy + ky - 1, ix = ox + kx - 1;
+                                if (iy < 0 || ix < 0 || iy >= H || ix >= W) continue;
+                                acc += (double)w[(co * CI + ci) * 9 + ky * 3 + kx] * wgain * s[n * CI + ci] * x[((n * CI + ci) * H + iy) * W + ix];
+                            }
+                    double t = acc * d[n * CO + co] + bias[co];
+                    t = (t > 0 ? t : 0.2 * t) * 1.41421356;
+                    const double e = fabs(y[((n * CO + co) * H + oy) * W + ox] - t);
+                    if (e > worst) worst = e;
+                    if (fabs(t) > scale) scale = fabs(t);
+                }
+    CHECK(worst <= 1e-5 * scale, "modulated 3x3 conv: worst error %g of max |y| %g", worst, scale);
+    hipFree(dx); hipFree(dw); hipFree(ds); hipFree(dd); hipFree(db); hipFree(dy); hipFree(du);
+    return 0;
+}
+
 int main(void) {
     if (!mgf_device_ok()) { printf("abi_consumer: no usable gfx950 device\n"); return 3; }
-    if (test_bias_act() || test_upfirdn2d() || test_pixel_terms()) return 1;
+    if (test_bias_act() || test_upfirdn2d() || test_pixel_terms() || test_modulated_conv()) return 1;
     if (failures) { printf("abi_consumer: %d check(s) failed\n", failures); return 1; }
-    printf("abi_consumer: OK (mgf_bias_act, mgf_upfirdn2d, mgf_mse_f32, mgf_dssim_u8_f32; library version %d)\n", mgf_version());
+    printf("abi_consumer: OK (mgf_bias_act, mgf_upfirdn2d, mgf_mse_f32, mgf_dssim_u8_f32, mgf_conv3x3_winograd3_f32; library version %d)\n", mgf_version());
     return 0;
 }
