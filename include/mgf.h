@@ -355,6 +355,24 @@ int mgf_mse_f32(float* out, const float* a, const float* b, int32_t n, int64_t n
 int64_t mgf_dssim_scratch_bytes(int32_t n, int32_t c, int32_t h, int32_t w);
 int mgf_dssim_u8_f32(float* out, const float* img, const float* target, int32_t n, int32_t c, int32_t h, int32_t w, int64_t t_batch_stride,
                      float data_range, float scale, int32_t accumulate, void* scratch, mgf_stream_t stream);
+/* The LBP matching distance of 1024_example_LBP_percept.py:34-58,162-166 per candidate, in three steps (csrc/lbp.hip):
+ *   lbp_gray224:  gray [n,224,224] u8 = cv2.resize(cv2.cvtColor(to_pil(img), COLOR_BGR2GRAY), (224, 224)) of img [n,3,h,w] in [-1, 1]: misc.to_pil's
+ *                 rint quantisation (misc.py:115-116), OpenCV's 8-bit gray weights (1868, 9617, 4899, >> 14) with the FIRST channel in the blue
+ *                 slot -- the scripts hand an RGB array to a BGR conversion (:48) -- or, true_rgb_order != 0, in the red slot (what
+ *                 cv2.imread(IMREAD_GRAYSCALE) does to the target file, :41); INTER_LINEAR in OpenCV's 11-bit fixed point.
+ *                 tables: int32 [2][224][4] {index 0, index 1, coefficient 0, coefficient 1} for the 224 columns, then the 224 rows
+ *                 (half-pixel centres; host-side, drivers.cv_resize_tables)
+ *   lbp_codes:    codes [n,224,224] u8 = skimage.feature.local_binary_pattern(gray, 24, 3, 'uniform') (values 0..25), float64 in skimage's
+ *                 expression order; offsets: float64 [2][24] = the sample offsets {rp, cp} rounded to 5 decimals (host-side)
+ *   lbp_distance: out[i] = 1 - dot(x_i, y) / (sqrt(dot(x_i, x_i)) * sqrt(dot(y, y))), x_i the code map of gray[i], y = target_codes
+ *                 [224*224] u8; float64, the dots exact integers.  scratch: mgf_lbp_scratch_bytes(n) bytes.
+ * OpenCV and scikit-image are not part of the reference tree: their published algorithms are restated. */
+int64_t mgf_lbp_scratch_bytes(int32_t n);
+int mgf_lbp_gray224_u8(uint8_t* gray, const float* img, const int32_t* tables, int32_t n, int32_t h, int32_t w, int32_t true_rgb_order,
+                       mgf_stream_t stream);
+int mgf_lbp_codes_u8(uint8_t* codes, const uint8_t* gray, const double* offsets, int32_t n, mgf_stream_t stream);
+int mgf_lbp_distance_f64(double* out, const uint8_t* gray, const uint8_t* target_codes, const double* offsets, int32_t n, void* scratch,
+                         mgf_stream_t stream);
 int mgf_wing_loss_f64(double* out, const double* pred, const double* target, int32_t n, int64_t numel, double omega, double epsilon,
                       const int32_t* pred_step, int32_t max_row, mgf_stream_t stream);
 /* AdaptiveWingLoss(omega=14, theta=0.5, epsilon=1, alpha=2.1) of adaptive_wing_loss.py:12-39, same row addressing as the wing loss */

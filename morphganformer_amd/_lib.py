@@ -105,6 +105,10 @@ _SIGS = {
     "mgf_mse_f32": (C.c_int, [vp, vp, vp, i32, i64, i64, f32, i32, vp, vp]),
     "mgf_dssim_scratch_bytes": (i64, [i32, i32, i32, i32]),
     "mgf_dssim_u8_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i64, f32, f32, i32, vp, vp]),
+    "mgf_lbp_scratch_bytes": (i64, [i32]),
+    "mgf_lbp_gray224_u8": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mgf_lbp_codes_u8": (C.c_int, [vp, vp, vp, i32, vp]),
+    "mgf_lbp_distance_f64": (C.c_int, [vp, vp, vp, vp, i32, vp, vp]),
     "mgf_wing_loss_f64": (C.c_int, [vp, vp, vp, i32, i64, f64, f64, vp, i32, vp]),
     "mgf_adaptive_wing_loss_f64": (C.c_int, [vp, vp, vp, i32, i64, f64, f64, f64, f64, vp, i32, vp]),
     "mgf_lpips_unit_f32": (C.c_int, [vp, vp, i32, i32, i64, vp]),

@@ -25,7 +25,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmgf_hip.so")
 SOURCES = ["capi.cpp", "bias_act.hip", "upfirdn2d.hip", "conv_taps.hip", "latent_prep.hip", "attention.hip", "losses.hip", "lpips_stem.hip",
-           "embed.hip", "backward.hip", "wino.hip", "wino3.hip", "pointwise.hip", "narrow_conv.hip", "warp.hip"]
+           "embed.hip", "backward.hip", "wino.hip", "wino3.hip", "pointwise.hip", "narrow_conv.hip", "warp.hip", "lbp.hip"]
 HEADERS = [os.path.join(CSRC, "mgf_common.h"), os.path.join(ROOT, "include", "mgf.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=on: fma only inside one source expression (so `acc += a * b` still fuses) and never across statements --

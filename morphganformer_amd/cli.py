@@ -40,8 +40,10 @@ def _loop_arguments(p):
                    help="with --mode gradient: optimise the per-layer latent W+ [k, num_ws, D] instead of z (the reference accepts the flag "
                         "and never reads it; in literal mode it stays unused here too)")
     p.add_argument("--percept_weight", type=float, default=1.0, help="coefficient of the LPIPS term (0.5 with --beta 0.5 = 1024_example_percept_MSE.py)")
-    p.add_argument("--pixel-term", choices=["mse", "psnr", "dssim"], default="mse",
-                   help="psnr = the pixel term of 1024_example_PSNR.py (10 log10(255^2 / MSE), minimised like the script does; use with --no-lpips)")
+    p.add_argument("--pixel-term", choices=["mse", "psnr", "dssim", "lbp"], default="mse",
+                   help="psnr = the pixel term of 1024_example_PSNR.py (10 log10(255^2 / MSE), minimised like the script does; use with --no-lpips); "
+                        "dssim = (1 - SSIM) / 2 of the uint8 images (1024_example_SSIM.py's `dssim`); lbp = the LBP matching distance of "
+                        "1024_example_LBP_percept.py, the whole objective of that script (use with --no-lpips; literal mode)")
     p.add_argument("--pool-above", type=int, default=0,
                    help="projection_example_v1.py:150-155: block-average generated images taller than this (256 there) by height // N before the "
                         "image-space losses; the target image is then transformed to that size")
@@ -233,8 +235,10 @@ def main(argv=None):
         else:
             print(f"WARNING: the biometric term runs on seeded random {a.biometric} weights (--biometric-random); it is not a face embedding")
         biometric = BiometricLoss(a.biometric, state=state, n=a.batch if a.mode == "literal" else 1, device=G.device)
-    if percept is None and a.no_mse and biometric is None and not getattr(a, "landmarks", None):
+    if percept is None and a.no_mse and biometric is None and not getattr(a, "landmarks", None) and a.pixel_term != "lbp":
         raise SystemExit(f"{a.cmd}: every term of the objective is switched off")
+    if a.pixel_term == "lbp" and (a.cmd != "project" or a.mode != "literal"):
+        raise SystemExit("--pixel-term lbp is the objective of the single-image literal loop (project --mode literal)")
     space = "w+" if (a.w_plus and a.mode == "gradient") else "z"
     if a.cmd == "morph-pairs":
         # one process per GPU under `python -m torch.distributed.run --nproc-per-node N -m morphganformer_amd.cli morph-pairs ...`: the
@@ -264,9 +268,16 @@ def main(argv=None):
         if lm_s.shape[0] < a.step:
             raise SystemExit(f"--landmarks holds {lm_s.shape[0]} steps, --step is {a.step}")
     stem = os.path.splitext(os.path.basename(a.image))[0]
+    lbp_target = None
+    if a.pixel_term == "lbp":          # LBP_feature(path): the file's own pixels (1024_example_LBP_percept.py:40-45,140); min_distance starts at 1 (:151)
+        from PIL import Image
+        from . import lbp
+        lbp_target = lbp.target_feature(np.asarray(Image.open(a.image).convert("RGB")), G.device)
+        args.min_loss_init = 1.0
     res = drivers.project_image(G, target, lm_t, lm_s, args=args, percept=percept, batch=a.batch, seed=a.seed,
                                 out_prefix=os.path.join(a.path_to_gen, stem), mode=a.mode, path_to_gen=a.path_to_gen,
-                                keep_images=a.keep_images, latent_space=space, biometric=biometric, gamma=a.gamma, use_mse=not a.no_mse)
+                                keep_images=a.keep_images, latent_space=space, biometric=biometric, gamma=a.gamma, use_mse=not a.no_mse,
+                                lbp_target=lbp_target)
     print(f"best step {res['step']}  loss {res['loss']:.6f}")
     return 0
 

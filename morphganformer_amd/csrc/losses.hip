@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void to_uint8_kernel(uint8_t* out, const float
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ch = (int)(i % c);
         const int64_t px = i / c;
-        float v = img[(int64_t)ch * hw + px] * 127.5f + 127.5f;
+        float v = __fadd_rn(__fmul_rn(img[(int64_t)ch * hw + px], 127.5f), 127.5f);      // two roundings like numpy's `data * scale + bias` (misc.py:103-104)
         v = rintf(v);
         v = fminf(fmaxf(v, 0.f), 255.f);
         out[i] = (uint8_t)v;
@@ -774,7 +774,7 @@ extern "C" int mgf_to_uint8_hwc(uint8_t* out, const float* img, int32_t c, int32
 // grid = (tiles, c, n); a workgroup owns 32 x 32 window positions of one channel plane and reads the 38 x 38 pixels under them.
 constexpr int DS_T = 32, DS_W = 7, DS_R = DS_T + DS_W - 1;
 __device__ __forceinline__ int ds_quant(float v) {
-    v = rintf(v * 127.5f + 127.5f);
+    v = rintf(__fadd_rn(__fmul_rn(v, 127.5f), 127.5f));
     return (int)fminf(fmaxf(v, 0.f), 255.f);
 }
 __global__ __launch_bounds__(256) void dssim_partial_kernel(double* part, const float* img, const float* tgt, int h, int w, int64_t t_stride,

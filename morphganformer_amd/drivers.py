@@ -184,7 +184,7 @@ DEFAULT_BATCH = 32       # loop steps per generator forward in literal mode: the
 def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None,
                   eps=None, out_prefix=None, batch=DEFAULT_BATCH, use_graph=True, noise_mode="random", use_mse=True, seed=None,
                   landmark_fn=None, mode="literal", weight_decay=0.0, path_to_gen=None, keep_images=64, engine=None,
-                  return_engine=False, latent_space="z", landmark_input="float", biometric=None, gamma=1.0):
+                  return_engine=False, latent_space="z", landmark_input="float", biometric=None, gamma=1.0, lbp_target=None):
     """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and either
     `lm_steps` [steps,68,2] (injected landmark detections) or `landmark_fn` (host detector called on every generated image,
     see ProjectionEngine; landmark_input="gray_u8" hands it the drivers' gray uint8 image, built on the device).  mode="literal" is the loop as the reference executes it (best-of-N noisy sampling, `batch` steps per
@@ -195,7 +195,8 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
     loss, losses).
 
     biometric / gamma: an iresnet.BiometricLoss (embedder "facenet" or "iresnetNN") adds gamma * MSE(embed(img), embed(target)) to the objective
-    (BASELINE config 3; 1024_example_FaceNet_percept.py:147-158).
+    (BASELINE config 3; 1024_example_FaceNet_percept.py:147-158).  lbp_target: with args.pixel_term="lbp" the target FILE's LBP code map
+    (lbp.target_feature; 1024_example_LBP_percept.py:140).
 
     Outputs, like the drivers: with `path_to_gen` the SCORED image of every improvement -- the candidate as it was generated and
     ranked, its random per-layer noise included -- is written as `{path_to_gen}/{step:06d}_{loss:04f}.png` (:190-195; literal mode:
@@ -234,7 +235,7 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
         if diff:
             raise ValueError("engine= was built for another objective: " + ", ".join(diff) + " differ(s); build a fresh engine")
         eng = engine.retarget(target, lm_target=lm_target, lm_steps=lm_steps, eps=eps, seed=seed if eps is None else None,
-                              latent_mean=latent_mean, latent_std=float(latent_std))
+                              latent_mean=latent_mean, latent_std=float(latent_std), lbp_target=lbp_target)
     elif mode == "gradient":
         eng = GradientProjectionEngine(G, target, latent_mean, float(latent_std), args, weight_decay=weight_decay, percept=percept,
                                        lm_target=lm_target, lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph,
@@ -244,7 +245,7 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
         eng = ProjectionEngine(G, target, latent_mean, float(latent_std), args, percept=percept, lm_target=lm_target,
                                lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse,
                                landmark_fn=landmark_fn, keep_images=keep, seed=0 if seed is None else seed, landmark_input=landmark_input,
-                               biometric=biometric, gamma=gamma)
+                               biometric=biometric, gamma=gamma, lbp_target=lbp_target)
     w, step, loss, losses = eng.run().result()
     out = {"w": w, "step": step, "loss": loss, "losses": losses}
     if out_prefix is not None:
@@ -659,17 +660,7 @@ def cv_resize_linear_u8(img_u8_hwc, width, height):
     assert a.dtype == np.uint8 and a.ndim == 3
     ih, iw = a.shape[:2]
 
-    def table(dst, src):
-        f = (np.arange(dst, dtype=np.float64) + 0.5) * (src / dst) - 0.5
-        s0 = np.floor(f).astype(np.int64)
-        fr = (f - s0).astype(np.float32)
-        lo = s0 < 0
-        s0[lo], fr[lo] = 0, 0.0
-        hi = s0 >= src - 1
-        s0[hi], fr[hi] = src - 1, 0.0
-        c1 = np.rint(fr * np.float32(2048)).astype(np.int64)                # saturate_cast<short>(coef * INTER_RESIZE_COEF_SCALE)
-        c0 = np.rint((np.float32(1) - fr) * np.float32(2048)).astype(np.int64)
-        return s0, np.minimum(s0 + 1, src - 1), c0, c1
+    from .lbp import resize_table as table
 
     x0, x1, a0, a1 = table(width, iw)
     y0, y1, b0, b1 = table(height, ih)

@@ -56,6 +56,9 @@ class ProjectionArgs:
     # "dssim": `dssim` of 1024_example_SSIM.py:115-117 (= lpips/__init__.py:54-55), (1 - SSIM) / 2 with skimage's defaults, on the uint8
     # images (the generated image as the drivers save it, misc.to_pil) -- the function as defined; the script's own call site (:158) passes
     # flattened float arrays, which compare_ssim rejects
+    # "lbp": the matching distance of 1024_example_LBP_percept.py:34-58,162-166 -- 1 - cos(LBP(24, 3, 'uniform') code map of the saved image at
+    # 224 x 224, the target file's code map) in float64 -- in place of every other term (the script scores nothing else); needs
+    # ProjectionEngine(lbp_target=lbp.target_feature(file pixels))
     pixel_term: str = "mse"
     # projection_example_v1.py:150-155: a generated image taller than `pool_above` pixels is block-averaged by height // pool_above before
     # the image-space losses (the target is then given at the pooled size, :84-92 resize it to 256); 0 = off (the 1024 drivers)
@@ -124,7 +127,7 @@ class ProjectionEngine:
     def __init__(self, G, target, latent_mean, latent_std, args: ProjectionArgs = None, percept=None, use_mse=True,
                  lm_target=None, lm_steps=None, lm_valid=None, eps=None, noise_mode="random", seed=0, use_graph=True, batch=1,
                  landmark_fn=None, biometric=None, gamma=1.0, wing_kind="wing", landmark_model=None, pipeline=False, keep_images=0,
-                 latent_shape=None, landmark_input="float"):
+                 latent_shape=None, landmark_input="float", lbp_target=None):
         """batch = number of consecutive loop steps evaluated per generator forward.  In literal mode the steps do not depend
         on each other (latent_in never changes), so evaluating `batch` candidates at once and examining them in step order
         gives exactly the sequential loop's result while the small 4x4..64x64 layers, the mapping network and the LPIPS tail
@@ -174,8 +177,12 @@ class ProjectionEngine:
         self.target = target.contiguous().float()
         assert self.target.shape[0] == 1, "one target per engine (the drivers process images serially)"
         self.percept = percept
-        self.use_mse = use_mse
+        self.use_lbp = a.pixel_term == "lbp"
+        self.use_mse = use_mse and not self.use_lbp
         self.use_wing = lm_target is not None
+        if self.use_lbp and (lbp_target is None or self.use_wing or percept is not None or biometric is not None):
+            raise _lib.MgfError("projection: pixel_term='lbp' is the whole objective of 1024_example_LBP_percept.py -- pass lbp_target "
+                                "(lbp.target_feature of the target file) and no landmark / LPIPS / biometric term")
         self.noise_mode = noise_mode
         k, D = G.cfg.k, G.cfg.z_dim
         # (k, D): the drivers' z latent.  GradientProjectionEngine(latent_space="w+") passes (k, num_ws, D)
@@ -227,7 +234,13 @@ class ProjectionEngine:
         self.w_loss = torch.zeros(B, dtype=torch.float64, device=dev)
         self.scratch = torch.empty(B * int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=dev)
         self._arange = torch.arange(B, dtype=torch.int64, device=dev)
-        assert a.pixel_term in ("mse", "psnr", "dssim"), a.pixel_term
+        assert a.pixel_term in ("mse", "psnr", "dssim", "lbp"), a.pixel_term
+        if self.use_lbp:
+            from . import lbp
+            r = G.cfg.img_resolution
+            self.lbp_ws = lbp.LbpWorkspace(B, r, r, dev)
+            self.lbp_codes = torch.as_tensor(lbp_target, dtype=torch.uint8, device=dev).reshape(-1).contiguous()
+            assert self.lbp_codes.numel() == lbp.SIDE * lbp.SIDE, "lbp_target: the 224 x 224 code map of lbp.target_feature"
         self._init_pool(B)
         if a.pixel_term == "dssim" and use_mse:
             c, h, w = self.target.shape[-3:]
@@ -338,6 +351,8 @@ class ProjectionEngine:
                 # 10 * np.log10(peak ** 2 / np.mean(d ** 2)) with peak = 255., in float32 like the script's numpy (1024_example_PSNR.py:113-114)
                 self.mse_loss.reciprocal_().mul_(65025.0).log10_().mul_(10.0)
         self._landmarks(full_img)
+        if self.use_lbp:        # rides in the float64 slot (the script compares float64 distances, :166-172), coefficient 1
+            self.lbp_ws.distance_into(self.w_loss, full_img, self.lbp_codes)
         if self.use_wing and self.wing_kind == "wing":
             _lib.check(L.mgf_wing_loss_f64(self.w_loss.data_ptr(), self.lm_steps.data_ptr(), self.lm_target.data_ptr(), B,
                                            self.lm_target.numel(), 10.0, 2.0, self.step_ctr.data_ptr(), self.lm_steps.shape[0] - 1, st),
@@ -350,8 +365,8 @@ class ProjectionEngine:
         _lib.check(L.mgf_select_best(self.min_loss.data_ptr(), self.best_latent.data_ptr(), self.best_step.data_ptr(),
                                      self.losses.data_ptr(), latent_n.data_ptr(), self.numel,
                                      _lib.ptr(self.p_loss if (self.percept is not None or self.biometric is not None) else None),
-                                     _lib.ptr(self.w_loss if self.use_wing else None),
-                                     _lib.ptr(self.mse_loss if self.use_mse else None), float(a.lamda), float(a.beta),
+                                     _lib.ptr(self.w_loss if (self.use_wing or self.use_lbp) else None),
+                                     _lib.ptr(self.mse_loss if self.use_mse else None), 1.0 if self.use_lbp else float(a.lamda), float(a.beta),
                                      self.step_ctr.data_ptr(), _lib.ptr(self.valid), B, self.steps,
                                      _lib.ptr(self.take_slot if keep else None), _lib.ptr(self.trail_count if keep else None),
                                      self.keep_images, _lib.ptr(self.trail_steps if keep else None),
@@ -610,7 +625,8 @@ class ProjectionEngine:
                 self._iteration()
         return self
 
-    def retarget(self, target, lm_target=None, lm_steps=None, lm_valid=None, eps=None, seed=None, latent_mean=None, latent_std=None):
+    def retarget(self, target, lm_target=None, lm_steps=None, lm_valid=None, eps=None, seed=None, latent_mean=None, latent_std=None,
+                 lbp_target=None):
         """Point this engine at ANOTHER target image and rewind the loop, keeping everything that was expensive to set up: the captured
         hipGraph(s), the generator workspace, the LPIPS / embedder workspaces, the loss scratch.  Only data changes, in place, in the
         buffers the graph already references: the target image and its cached LPIPS taps / embedding, the landmark tables, the noise
@@ -628,6 +644,9 @@ class ProjectionEngine:
             self.percept.set_target(self.target)                  # same shapes: rewrites the cached taps in place
         if self.biometric is not None:
             self.biometric.set_target(self.target)
+        if self.use_lbp:
+            assert lbp_target is not None, "this engine scores the LBP distance: pass the new target's code map (lbp.target_feature)"
+            self.lbp_codes.copy_(torch.as_tensor(lbp_target, dtype=torch.uint8).reshape(-1))
         if self.use_wing:
             assert lm_target is not None, "this engine has a Wing term: pass the new target's landmarks"
             self.lm_target.copy_(torch.as_tensor(lm_target, dtype=torch.float64).reshape(self.lm_target.shape))
@@ -734,7 +753,7 @@ class GradientProjectionEngine(ProjectionEngine):
         self.targets = B
         a, dev = self.args, self.device
         if a.pixel_term != "mse" or a.pool_above:
-            raise _lib.MgfError("GradientProjectionEngine: pixel_term='psnr' / 'dssim' / pool_above are literal-mode objectives (the PSNR / v1 drivers "
+            raise _lib.MgfError("GradientProjectionEngine: pixel_term='psnr' / 'dssim' / 'lbp' / pool_above are literal-mode objectives (the PSNR / v1 drivers "
                                 "sever the gradient like every other driver; only the Wing / LPIPS / MSE / biometric terms have backward passes)")
         if biometric is not None and hasattr(biometric.embedder, "keep_activations"):
             biometric.embedder.keep_activations = True          # (the FaceNet embedder re-uses its buffers block after block otherwise)

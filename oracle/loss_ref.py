@@ -108,6 +108,100 @@ def dssim_ref(img, target, data_range=255.0):
     return np.float32((1 - ssim_ref(a, b, data_range=data_range)) / 2.)
 
 
+def cv_bgr2gray_u8_ref(img_u8, blue_first=True):
+    """cv2.cvtColor(im, COLOR_BGR2GRAY) on uint8 as OpenCV's 8-bit path publishes it: (B 1868 + G 9617 + R 4899 + 2^13) >> 14.  The scripts
+    hand it an RGB array (1024_example_LBP_percept.py:48), so with blue_first=True channel 0 -- red -- takes the blue weight;
+    blue_first=False is what cv2.imread(IMREAD_GRAYSCALE) does to a file's true colours (:41).  OpenCV is absent: UNPINNED against it."""
+    import numpy as np
+    a = np.asarray(img_u8).astype(np.int64)
+    c0, c2 = (a[..., 0], a[..., 2]) if blue_first else (a[..., 2], a[..., 0])
+    return ((c0 * 1868 + a[..., 1] * 9617 + c2 * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def cv_resize_linear_gray_ref(gray_u8, width, height):
+    """cv2.resize(gray, (width, height)), INTER_LINEAR on uint8, pixel by pixel from OpenCV's published scheme (imgproc/resize.cpp): source
+    coordinate (d + 0.5) * scale - 0.5, clamped at both ends, float32 weights rounded to 11-bit fixed point (cvRound: half to even), the
+    horizontal pass in int32, the vertical pass (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  UNPINNED against OpenCV."""
+    import numpy as np
+    g = np.asarray(gray_u8)
+    assert g.dtype == np.uint8 and g.ndim == 2
+    ih, iw = g.shape
+
+    def axis(dst, src):
+        out = []
+        for d in range(dst):
+            f = (d + 0.5) * (src / dst) - 0.5
+            s = int(math.floor(f))
+            fr = np.float32(f - s)
+            if s < 0:
+                s, fr = 0, np.float32(0)
+            if s >= src - 1:
+                s, fr = src - 1, np.float32(0)
+            out.append((s, min(s + 1, src - 1), int(np.rint((np.float32(1) - fr) * np.float32(2048))), int(np.rint(fr * np.float32(2048)))))
+        return out
+
+    xs, ys = axis(width, iw), axis(height, ih)
+    out = np.zeros((height, width), np.uint8)
+    gi = g.astype(np.int64)
+    for oy, (y0, y1, b0, b1) in enumerate(ys):
+        for ox, (x0, x1, a0, a1) in enumerate(xs):
+            s0 = int(gi[y0, x0]) * a0 + int(gi[y0, x1]) * a1
+            s1 = int(gi[y1, x0]) * a0 + int(gi[y1, x1]) * a1
+            out[oy, ox] = min(255, max(0, (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2))
+    return out
+
+
+def lbp_uniform_ref(image, P=24, R=3):
+    """skimage.feature.local_binary_pattern(image, P, R, 'uniform') restated from the published source (skimage/feature/_texture.pyx,
+    _local_binary_pattern, and skimage/_shared/interpolation.pxd): the image as float64; sample offsets rp = round(-R sin(2 pi p / P), 5),
+    cp = round(R cos(2 pi p / P), 5); texture[p] = bilinear_interpolation(r + rp, c + cp) with mode 'C' (0 outside the image) in exactly
+    `top = (1 - dc) * tl + dc * tr; bottom = (1 - dc) * bl + dc * br; (1 - dr) * top + dr * bottom`; signed[p] = texture[p] - centre >= 0;
+    changes = number of p < P - 1 with signed[p] != signed[p + 1] (not circular); code = sum(signed) if changes <= 2 else P + 1.
+    Returns float64 like skimage.  scikit-image is absent: UNPINNED against it, held by hand-computed answers (tests/test_oracle_golden.py)."""
+    import numpy as np
+    img = np.ascontiguousarray(image, dtype=np.double)
+    rows, cols = img.shape
+    ang = 2 * np.pi * np.arange(P, dtype=np.double) / P
+    rp, cp = np.round(-R * np.sin(ang), 5), np.round(R * np.cos(ang), 5)
+    r = np.arange(rows, dtype=np.double)[:, None] + np.zeros((1, cols))
+    c = np.arange(cols, dtype=np.double)[None, :] + np.zeros((rows, 1))
+
+    def px(rr, cc):
+        ok = (rr >= 0) & (rr < rows) & (cc >= 0) & (cc < cols)
+        return np.where(ok, img[np.clip(rr, 0, rows - 1), np.clip(cc, 0, cols - 1)], 0.0)
+
+    signed = np.zeros((P, rows, cols), np.int64)
+    for p in range(P):
+        y, x = r + rp[p], c + cp[p]
+        minr, minc = np.floor(y).astype(np.int64), np.floor(x).astype(np.int64)
+        maxr, maxc = np.ceil(y).astype(np.int64), np.ceil(x).astype(np.int64)
+        dr, dc = y - minr, x - minc
+        top = (1 - dc) * px(minr, minc) + dc * px(minr, maxc)
+        bottom = (1 - dc) * px(maxr, minc) + dc * px(maxr, maxc)
+        signed[p] = ((1 - dr) * top + dr * bottom) - img >= 0
+    changes = (signed[:-1] != signed[1:]).sum(0)
+    return np.where(changes <= 2, signed.sum(0), P + 1).astype(np.double)
+
+
+def lbp_cosine_distance_ref(x, y):
+    """`cosine_distance` (1024_example_LBP_percept.py:54-55) on the flattened float64 features."""
+    import numpy as np
+    x, y = np.asarray(x, np.double).reshape(-1), np.asarray(y, np.double).reshape(-1)
+    return 1 - np.dot(x, y) / (np.sqrt(np.dot(x, x)) * np.sqrt(np.dot(y, y)))
+
+
+def lbp_feature_im_ref(img):
+    """`LBP_feature_im(np.asarray(misc.to_pil(img)))` (:47-52,162-164): img [3, H, W] float in [-1, 1] -> the saved uint8 RGB image -> BGR2GRAY
+    (on RGB data) -> 224 x 224 -> local_binary_pattern(24, 3, 'uniform') -> flattened float64."""
+    u8 = to_u8_ref(img).transpose(1, 2, 0)
+    return lbp_uniform_ref(cv_resize_linear_gray_ref(cv_bgr2gray_u8_ref(u8, blue_first=True), 224, 224)).reshape(-1)
+
+
+def lbp_feature_file_ref(image_u8_rgb):
+    """`LBP_feature(path)` (:40-45): cv2.imread(path, IMREAD_GRAYSCALE) of the file's own pixels (true colour order), 224 x 224, the same feature."""
+    return lbp_uniform_ref(cv_resize_linear_gray_ref(cv_bgr2gray_u8_ref(image_u8_rgb, blue_first=False), 224, 224)).reshape(-1)
+
+
 def pool_above_ref(img, above=256):
     """projection_example_v1.py:148-155: an image taller than `above` is averaged over factor x factor blocks, factor = height // above."""
     import numpy as np

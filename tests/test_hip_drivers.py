@@ -804,3 +804,23 @@ def test_facenet_feature_and_its_cli_verb(tmp_path):
     assert m["features"].shape == (2, 512) and np.abs(m["features"] - np.stack(feats)).max() < 1e-6
     assert cli.main(["extract-facenet", files[1], "--out", str(tmp_path / "f.npy"), "--biometric-random"]) == 0
     assert np.abs(np.load(str(tmp_path / "f.npy"))[0] - feats[1]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_cli_project_with_the_lbp_objective(tmp_path):
+    """`project --pixel-term lbp --no-lpips --no-mse`: 1024_example_LBP_percept.py as a command -- the target file's LBP feature is taken from the
+    file's own pixels, the loop keeps the smallest distance, the latent and the improvement images are written under the scripts' names."""
+    from morphganformer_amd import cli, drivers
+    from test_host_and_abi import _tiny_snapshot
+    pkl = str(tmp_path / "net.pkl")
+    _tiny_snapshot(pkl, seed=3)
+    assert cli.main(["generate", "--model", pkl, "--output-dir", str(tmp_path / "g"), "--images-num", "1", "--seed", "2"]) == 0
+    img = str(tmp_path / "g" / "sample_000000.png")
+    argv = ["project", "--model", pkl, "--image", img, "--path_to_gen", str(tmp_path / "p"), "--size", "64", "--step", "6", "--n_mean_latent", "200",
+            "--batch", "4", "--seed", "0", "--no-lpips", "--no-mse", "--pixel-term", "lbp"]
+    assert cli.main(argv) == 0
+    files = sorted(os.listdir(tmp_path / "p"))
+    assert "sample_000000.mat" in files and any(f.endswith(".png") for f in files)
+    assert drivers.load_latent_mat(str(tmp_path / "p" / "sample_000000.mat")).shape[-2:] == (17, 32)
+    with pytest.raises(SystemExit):
+        cli.main(argv + ["--mode", "gradient"])

@@ -540,6 +540,87 @@ def test_dssim_objective_variant(golden):
     assert bstep == int(np.argmin(losses)) and bloss == float(losses.min()) and 0 < want.min() < 0.5
 
 
+def test_lbp_kernels_bit_exact_vs_oracle():
+    """csrc/lbp.hip against oracle.loss_ref step by step and bit for bit: the 224 x 224 gray image (to_pil quantisation, BGR2GRAY weights in
+    both channel orders, fixed-point resize) from an odd-sized and from a 1024^2 image, the LBP(24, 3, 'uniform') code map -- smooth,
+    noisy and SATURATED (flat) regions, where skimage's interpolation ties at the ulp level decide the code --, and the float64 cosine
+    distance; the target feature of a file's pixels (lbp.target_feature)."""
+    from morphganformer_amd import lbp
+    from oracle.loss_ref import (cv_bgr2gray_u8_ref, cv_resize_linear_gray_ref, lbp_cosine_distance_ref, lbp_feature_file_ref,
+                                 lbp_feature_im_ref, lbp_uniform_ref, to_u8_ref)
+    rng = np.random.default_rng(21)
+    for (n, h, w) in ((3, 300, 280), (1, 1024, 1024), (2, 64, 64)):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        img = np.stack([np.stack([1.4 * np.sin(xx / (9 + 3 * k + c)) * np.cos(yy / (13 + c)) for c in range(3)]) for k in range(n)]).astype(np.float32)
+        img += rng.normal(0, 0.05, img.shape).astype(np.float32)              # |1.4 sin| > 1 in places: clipped to 0 / 255, i.e. flat patches
+        ws = lbp.LbpWorkspace(n, h, w, "cuda")
+        x = torch.from_numpy(img).cuda()
+        for true_order in (False, True):
+            g = ws.gray224(x, true_rgb_order=true_order).cpu().numpy().reshape(n, 224, 224)
+            for i in range(n):
+                want = cv_resize_linear_gray_ref(cv_bgr2gray_u8_ref(to_u8_ref(img[i]).transpose(1, 2, 0), blue_first=not true_order), 224, 224)
+                assert np.array_equal(g[i], want), (n, h, w, true_order, i)
+        gray = ws.gray224(x)
+        codes = ws.codes(gray).cpu().numpy().reshape(n, 224, 224)
+        feats = [lbp_feature_im_ref(img[i]) for i in range(n)]
+        for i in range(n):
+            assert np.array_equal(codes[i].reshape(-1).astype(np.float64), feats[i]), (n, h, w, i, int((codes[i].reshape(-1) != feats[i]).sum()))
+        assert len(np.unique(codes)) > 20
+        tgt = torch.from_numpy(codes[0].reshape(-1)).cuda()
+        out = torch.zeros(n, dtype=torch.float64, device="cuda")
+        ws.distance_into(out, x, tgt)
+        want = np.array([lbp_cosine_distance_ref(feats[i], feats[0]) for i in range(n)])
+        assert np.array_equal(out.cpu().numpy(), want), (out.cpu().numpy(), want)
+        assert n == 1 or want[1] > 1e-3
+    # the target side: a file's own pixels, true colour order, any size
+    u8 = rng.integers(0, 256, (150, 131, 3)).astype(np.uint8)
+    u8[20:60, 30:90] = 255
+    got = lbp.target_feature(u8).cpu().numpy().astype(np.float64)
+    assert np.array_equal(got, lbp_feature_file_ref(u8))
+
+
+def test_lbp_objective_variant(golden):
+    """1024_example_LBP_percept.py:151-172: the loop keeps the candidate with the smallest float64 LBP matching distance to the target
+    file's feature.  One batch of candidates: every recorded loss EQUALS the oracle's distance on the image the engine generated (the
+    same latents through the same generator call), differs from the oracle's on the oracle generator's image only by what a pixel near
+    a rounding boundary can move, and the best step is the argmin; a re-targeted engine scores the new feature."""
+    from morphganformer_amd import lbp
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from oracle.generator_ref import generator_ref, to_torch_state
+    from oracle.loss_ref import lbp_cosine_distance_ref, lbp_feature_file_ref, lbp_feature_im_ref, to_u8_ref
+    from morphganformer_amd import _lib
+    g = golden("loop_tiny.npz")
+    steps = 4
+    tsd = to_torch_state(make_state_dict(TINY, seed=0))
+    file_px = to_u8_ref(g["target"][0]).transpose(1, 2, 0)                   # "the target file": the golden target as saved pixels
+    feat_t = lbp_feature_file_ref(file_px)
+    G = _tiny_gen()
+    args = ProjectionArgs(step=steps, pixel_term="lbp", min_loss_init=1.0)
+    mk = lambda **kw: ProjectionEngine(G, torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]), args,
+                                       percept=None, eps=torch.from_numpy(g["eps"][:steps]).cuda(), noise_mode="const", batch=steps, **kw)
+    with pytest.raises(_lib.MgfError):
+        mk()                                                                 # the feature of the target file is the objective: it must be given
+    eng = mk(lbp_target=lbp.target_feature(file_px))
+    lat, bstep, bloss, losses = eng.run().result()
+    sig = [np.float32(np.float32(float(g["latent_std"])) * np.float32(0.05)) * np.float32(max(0, 1 - (i / steps) / 0.75) ** 2) for i in range(steps)]
+    z = torch.cat([torch.from_numpy(g["latent_mean"])[None] + torch.from_numpy(g["eps"][i]) * float(sig[i]) for i in range(steps)]).cuda()
+    own = G.forward_workspace(z, args.truncation_psi, noise_mode="const", lean=True)[0].cpu().numpy()
+    want_own = np.array([lbp_cosine_distance_ref(lbp_feature_im_ref(own[i]), feat_t) for i in range(steps)])
+    assert np.array_equal(losses, want_own), (losses, want_own)
+    with torch.no_grad():
+        ref_img = generator_ref(tsd, z.cpu(), TINY, "const").numpy()
+    want_ref = np.array([lbp_cosine_distance_ref(lbp_feature_im_ref(ref_img[i]), feat_t) for i in range(steps)])
+    assert np.abs(losses - want_ref).max() < 2e-2 and 0 < want_ref.min() < 1, (losses, want_ref)
+    assert bstep == int(np.argmin(losses)) and bloss == float(losses.min())
+    # re-target: another file -> another feature, same launch sequence
+    other = np.ascontiguousarray(file_px[::-1])
+    eng.retarget(torch.from_numpy(g["target"]).cuda(), eps=torch.from_numpy(g["eps"][:steps]).cuda(), lbp_target=lbp.target_feature(other))
+    l2 = eng.run().result()[3]
+    f2 = lbp_feature_file_ref(other)
+    assert np.array_equal(l2, np.array([lbp_cosine_distance_ref(lbp_feature_im_ref(own[i]), f2) for i in range(steps)]))
+
+
 def test_v1_pooled_percept_objective(golden):
     """projection_example_v1.py:148-160: a generated image taller than 256 px is block-averaged by height // 256 before LPIPS, against a
     target given at the pooled size -- here the 64^2 generator with pool_above=32 (factor 2), LPIPS(squeeze) only: every recorded loss against

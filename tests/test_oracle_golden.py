@@ -434,3 +434,57 @@ def test_ssim_ref_known_answers_by_hand():
     assert to_u8_ref(np.array([-1.0, -0.9961, 0.0, 0.0039, 1.0, 1.5], np.float32)).tolist() == [0, 0, 128, 128, 255, 255]
     f = (a.transpose(2, 0, 1).astype(np.float32) / 127.5 - 1)
     assert dssim_ref(f, f) == 0 and dssim_ref(f, f).dtype == np.float32
+
+
+def test_lbp_ref_known_answers_by_hand():
+    """oracle.loss_ref restates OpenCV's BGR2GRAY / INTER_LINEAR resize and skimage's local_binary_pattern(24, 3, 'uniform') (both absent:
+    unpinned against the libraries).  Held by answers that follow from the published algorithms: a flat image -- every interior sample
+    equals the centre or misses it by an ulp, so the interior code is whatever a SCALAR walk through skimage's expressions gives, the corner
+    sees the 7 samples with non-negative offsets, an edge 13; a bright pixel on black is code 0, a black pixel on white 24; the vectorised
+    restatement equals that scalar walk on a random image; gray weights and the two resize implementations (product host code, oracle)."""
+    from oracle.loss_ref import cv_bgr2gray_u8_ref, cv_resize_linear_gray_ref, lbp_cosine_distance_ref, lbp_uniform_ref
+    from morphganformer_amd.drivers import cv_resize_linear_u8
+    P, R = 24, 3
+    ang = 2 * np.pi * np.arange(P, dtype=np.double) / P
+    rp, cp = np.round(-R * np.sin(ang), 5), np.round(R * np.cos(ang), 5)
+
+    def scalar(img):                       # _texture.pyx line by line, one pixel at a time
+        rows, cols = img.shape
+        f = img.astype(np.double)
+        out = np.zeros((rows, cols))
+        px = lambda r, c: float(f[r, c]) if (0 <= r < rows and 0 <= c < cols) else 0.0
+        for r in range(rows):
+            for c in range(cols):
+                s = []
+                for p in range(P):
+                    y, x = r + float(rp[p]), c + float(cp[p])
+                    minr, minc, maxr, maxc = math.floor(y), math.floor(x), math.ceil(y), math.ceil(x)
+                    dr, dc = y - minr, x - minc
+                    top = (1 - dc) * px(minr, minc) + dc * px(minr, maxc)
+                    bottom = (1 - dc) * px(maxr, minc) + dc * px(maxr, maxc)
+                    s.append(1 if ((1 - dr) * top + dr * bottom) - float(f[r, c]) >= 0 else 0)
+                changes = sum(s[i] != s[i + 1] for i in range(P - 1))
+                out[r, c] = sum(s) if changes <= 2 else P + 1
+        return out
+
+    flat = np.full((12, 13), 64, np.uint8)                      # 64 is a power of two: (1 - dc) * 64 + dc * 64 == 64 exactly
+    got = lbp_uniform_ref(flat)
+    assert got[6, 6] == 24 and got[0, 0] == 7 and got[0, 6] == 13 and got[11, 12] == 7
+    spot = np.zeros((11, 11), np.uint8); spot[5, 5] = 200
+    assert lbp_uniform_ref(spot)[5, 5] == 0
+    hole = np.full((11, 11), 255, np.uint8); hole[5, 5] = 0
+    assert lbp_uniform_ref(hole)[5, 5] == 24
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (14, 15)).astype(np.uint8)
+    img[3:9, 4:11] = 77                                          # a flat patch: the ulp-level ties of the interpolation are part of the answer
+    assert np.array_equal(lbp_uniform_ref(img), scalar(img))
+    v = lbp_uniform_ref(img)
+    assert v.dtype == np.float64 and v.min() >= 0 and v.max() <= 25
+    rgb = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 20, 30]]], np.uint8)
+    assert cv_bgr2gray_u8_ref(rgb, blue_first=True).tolist() == [[29, 150, 76, (10 * 1868 + 20 * 9617 + 30 * 4899 + 8192) >> 14]]
+    assert cv_bgr2gray_u8_ref(rgb, blue_first=False).tolist() == [[76, 150, 29, (30 * 1868 + 20 * 9617 + 10 * 4899 + 8192) >> 14]]
+    g = rng.integers(0, 256, (61, 47)).astype(np.uint8)
+    for (w, h) in ((224, 224), (30, 20), (47, 61)):
+        assert np.array_equal(cv_resize_linear_gray_ref(g, w, h), cv_resize_linear_u8(g[..., None], w, h)[..., 0])
+    assert abs(lbp_cosine_distance_ref(v, v)) < 1e-15 and abs(lbp_cosine_distance_ref(v, 2 * v)) < 1e-15
+    assert abs(lbp_cosine_distance_ref([1, 0], [0, 1]) - 1) < 1e-15
