@@ -653,6 +653,10 @@ def pmc_fields(kernel, eng, tag="", launched=()):
         if rec is not None:
             out["mfma_busy"] = rec["mfma_busy"]
             out["mfma_busy_source"] = f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs), {src}"
+            if "clock_ghz" in rec:
+                # the shader clock the kernel actually ran at (GRBM_GUI_ACTIVE / 8 / duration): under FP32-MFMA load the part settles near
+                # 2.1 GHz, below the 2.4 GHz the 157.3 TFLOP/s peak is quoted at -- frac ~= mfma_busy x clock / 2.4
+                out["clock_ghz"] = rec["clock_ghz"]
     return out
 
 
