@@ -1195,6 +1195,17 @@ static int conv_taps_dispatch(float* y, const float* x, const float* wp, const v
             if (tiles * 10 < best) { best = tiles * 10; TW = tw; rows = r; }
         }
     }
+    if (mode == 0 && !wb && d.istride == 1 && TW == 32 && d.tile_w > 16) {
+        // A tall tap pattern (InceptionResnetV1's 7x1 layers: 7 rows x 1 column) makes the footprint of the 8 x 32 tile -- 14 x 32 x 8 channels --
+        // overflow the pipeline's staging slots, and the launch used to fall back to the synchronous kernel (mfma_busy 0.39 against 0.61 for
+        // the 1x7 twin).  A 16 x 16 tile covers the same 256 pixels with a 22 x 16 footprint, which fits.
+        const size_t cap = (size_t)(wn == 4 ? Slots<1, 4>::XS : (wn == 3 ? Slots<1, 3>::XS : (wn == 1 ? Slots<1, 1>::XS : Slots<1, 2>::XS))) * 256;
+        auto fits = [&](int tw) {
+            const int r = PX / tw, fh_ = r + (dy_max - dy_min), fw_ = tw + (dx_max - dx_min);
+            return (size_t)CK * fh_ * fw_ <= cap && 256 / fw_ + 2 <= 2 * fh_;
+        };
+        if (!fits(32) && fits(16)) { TW = 16; rows = PX / 16; }
+    }
     p.tw = TW; p.rows = rows; p.tw_magic = (65536 + TW - 1) / TW;
     p.tiles_x = (int)mgf_cdiv(d.tile_w, TW);
     p.tiles_y = (int)mgf_cdiv(d.tile_h, rows);
