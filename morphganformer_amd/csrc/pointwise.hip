@@ -11,8 +11,9 @@
 // (lane -> co = lane % 32, ci = lane / 32: two 128-byte rows of the [cin][cout_pad] weight image, L2-resident) and B[2 ci][32 px] as
 // one dword per lane -- so a lane loads exactly its own operand slots, 4 pixel blocks per k-step, and 4 CB MFMAs follow from 4 + CB
 // loaded dwords (one 16-byte load + CB dwords when the map is 4-pixel aligned: lane -> 4 CONSECUTIVE pixels, the four pixel blocks are
-// an interleaving of the tile, and the accumulators of a row leave as one 16-byte store).  Loads run one group of 8 channels ahead in a
-// second register set; reads past the last channel fall outside the buffer resources and return 0, so the loop has no tail code.
+// an interleaving of the tile, and the accumulators of a row leave as one 16-byte store).  Loads run through a ring of register sets (8 groups of one k-step: a
+// group is requested seven groups of MFMAs before its use); reads past the last channel fall outside the buffer resources and return 0, so the
+// loop has no tail code.
 #include "mgf_common.h"
 #include <type_traits>
 #include <cstdlib>
@@ -35,7 +36,18 @@ struct PwParams {
     int has_ep;
 };
 
-constexpr int PWKU = 4;       // k-steps (of 2 channels) per load group
+// Ring geometry (tools/pw_ring_micro.py, 14 layer shapes at 16 samples, same box, us in all: 4 k-steps x 2 groups -- the double buffer of
+// rounds 3-4 -- 2114; 2 x 4: 2033; 2 x 3: 2048; 1 x 8: 2000; 4 x 3 and 2 x 6, whose extra registers cost a resident workgroup: 2623 / 2761).
+// The same 48 staging registers cut into 8 groups of one k-step put a load 7 x 256 matrix-pipe cycles ahead of its use instead of 1024:
+// FaceNet's 1792 -> 192 layer 160 -> 127 us, fire9's squeeze 71 -> 60.
+#ifndef PW_KU
+#define PW_KU 1
+#endif
+#ifndef PW_NR
+#define PW_NR 8
+#endif
+constexpr int PWKU = PW_KU;   // k-steps (of 2 channels) per load group
+constexpr int PWNR = PW_NR;   // load groups in the register ring: a group is requested PWNR - 1 groups of MFMAs before its use
 
 // WK = 4: the four waves of a workgroup share ONE tile and split the input channels (layers with too few tiles to fill the chip, where a
 // wave's serial walk over K at one load group in flight is the whole run time); their accumulators meet in LDS and wave 0 stores.
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
 
     // S: the style of a k-step's two channels, multiplied into the weight operand when it is CONSUMED: multiplied where it is loaded, every
     // group's loads ended in an s_waitcnt vmcnt(0) and the next group could not be in flight behind the MFMAs
-    float Ba[PWKU][4], Aa[PWKU][CB], Sa[PWKU], Bb[PWKU][4], Ab[PWKU][CB], Sb[PWKU];
+    float Br[PWNR][PWKU][4], Ar[PWNR][PWKU][CB], Sr[PWNR][PWKU];
     auto load = [&](float (&B)[PWKU][4], float (&A)[PWKU][CB], float (&S)[PWKU], int it) {
 #pragma unroll
         for (int ks = 0; ks < PWKU; ++ks) {
@@ -117,20 +129,20 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
             }
     };
     int nit = (p.cin + 2 * PWKU - 1) / (2 * PWKU), it0 = 0;
-    // (an EVEN number of groups per wave: the loop below consumes them in pairs, and the odd one out would be the next wave's first;
+    // (a multiple of PWNR groups per wave: the loop below consumes them PWNR at a time, and a remainder would be the next wave's first;
     // groups past cin read zeros)
-    if (WK > 1) { const int per = 2 * ((nit + 2 * WK - 1) / (2 * WK)); it0 = wv * per; nit = it0 + per; }
+    if (WK > 1) { const int per = PWNR * ((nit + PWNR * WK - 1) / (PWNR * WK)); it0 = wv * per; nit = it0 + per; }
     // (scheduling fences: left alone, the compiler sinks each load group to just above its first use and waits for it there)
-    load(Ba, Aa, Sa, it0);
-    for (int it = it0; it < nit; it += 2) {
-        load(Bb, Ab, Sb, it + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(Ba, Aa, Sa);
-        __builtin_amdgcn_sched_barrier(0);
-        load(Ba, Aa, Sa, it + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(Bb, Ab, Sb);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < PWNR - 1; ++r) load(Br[r], Ar[r], Sr[r], it0 + r);
+    for (int it = it0; it < nit; it += PWNR) {
+#pragma unroll
+        for (int r = 0; r < PWNR; ++r) {
+            load(Br[(r + PWNR - 1) % PWNR], Ar[(r + PWNR - 1) % PWNR], Sr[(r + PWNR - 1) % PWNR], it + r + PWNR - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(Br[r], Ar[r], Sr[r]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     if (WK > 1) {
@@ -376,7 +388,7 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
                 cout_pad, cout);
     MGF_REQUIRE(y_choff >= 0 && (y_batch == 0 || y_batch >= (int64_t)(y_choff + cout) * hw), MGF_EINVAL, "conv1x1: bad output slice");
     // 32-bit byte offsets inside one sample / the weight image, with room for the reads past the last channel (they must not wrap)
-    MGF_REQUIRE(((int64_t)cin + 4 * PWKU) * hw * 4 + 4096 <= (int64_t)UINT32_MAX && ((int64_t)cin + 4 * PWKU) * cout_pad * 4 + 4096 <= (int64_t)UINT32_MAX,
+    MGF_REQUIRE(((int64_t)cin + 4 * PWKU * PWNR) * hw * 4 + 4096 <= (int64_t)UINT32_MAX && ((int64_t)cin + 4 * PWKU * PWNR) * cout_pad * 4 + 4096 <= (int64_t)UINT32_MAX,
                 MGF_ETOOBIG, "conv1x1: one sample / the weight image must stay below 4 GiB (32-bit buffer offsets)");
     if (ep) {
         MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU || ep->act == MGF_ACT_RELU_POST,
