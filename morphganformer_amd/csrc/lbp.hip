@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void lbp_gray224_kernel(uint8_t* out, const fl
     const float* c0 = swap_rb ? x + 2 * hw : x;                          // the channel in OpenCV's BLUE slot (weight 1868)
     const float* c2 = swap_rb ? x : x + 2 * hw;
     auto gray = [&](int yy, int xx) -> int {
+        yy = min(max(yy, 0), h - 1); xx = min(max(xx, 0), w - 1);       // (the tables are the caller's: a wrong index must not leave the image)
         const int64_t o = (int64_t)yy * w + xx;
         return (int)((lbp_quant(c0[o]) * 1868u + lbp_quant(x[hw + o]) * 9617u + lbp_quant(c2[o]) * 4899u + (1u << 13)) >> 14);
     };
