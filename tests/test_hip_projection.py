@@ -572,6 +572,12 @@ def test_lbp_kernels_bit_exact_vs_oracle():
         want = np.array([lbp_cosine_distance_ref(feats[i], feats[0]) for i in range(n)])
         assert np.array_equal(out.cpu().numpy(), want), (out.cpu().numpy(), want)
         assert n == 1 or want[1] > 1e-3
+    # argument checks happen on the host, before any launch
+    from morphganformer_amd import _lib
+    Lh = _lib.lib()
+    assert Lh.mgf_lbp_scratch_bytes(0) == 0 and Lh.mgf_lbp_scratch_bytes(3) == 3 * 196 * 16
+    assert Lh.mgf_lbp_codes_u8(None, gray.data_ptr(), ws.off.data_ptr(), 1, None) != 0 and b"lbp_codes" in Lh.mgf_last_error()
+    assert Lh.mgf_lbp_distance_f64(out.data_ptr(), gray.data_ptr(), tgt.data_ptr(), ws.off.data_ptr(), 0, ws.scratch.data_ptr(), None) != 0
     # the target side: a file's own pixels, true colour order, any size
     u8 = rng.integers(0, 256, (150, 131, 3)).astype(np.uint8)
     u8[20:60, 30:90] = 255
