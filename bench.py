@@ -854,9 +854,23 @@ def launch_selftest(a):
     return 0
 
 
+def visible_gpus():
+    """How many GPUs this process may use, WITHOUT initialising one: torch.cuda.device_count() reads the driver's device list (it honours
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES) and makes no HIP context on this image, so the launcher parent stays exec-safe."""
+    import torch as _t
+    return int(_t.cuda.device_count())
+
+
 def main():
     a = parse()
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not a.selftest_launch:
+        have = visible_gpus()
+        if a.gpus < 1 or a.gpus > have:
+            # said once, by the launcher parent or by every rank the driver's own launcher started, before any rank touches a GPU or
+            # waits in a rendezvous for ranks that can never come up
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but {have} GPU(s) are visible to this process "
+                             f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}): nothing was launched")
     if not launched and (a.gpus > 1 or a.force_launch):
         return self_launch(a)
     if a.selftest_launch:

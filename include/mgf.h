@@ -269,6 +269,12 @@ typedef struct mgf_style_job {
     int32_t w_offset;
     float aff_gain, style_gain;
 } mgf_style_job;
+/* Demodulation alone, for callers that hold the styles as a tensor (the operator-level modulated_conv2d, networks.py:253-328, whose
+ * `styles` argument is computed by the caller):  d[n,co] = rsqrt(sum_ci wsq[co,ci] s[n,ci]^2 + 1e-8), wsq from mgf_pack_conv_weights;
+ * and its adjoint  ds[n,ci] = -s[n,ci] sum_co dd[n,co] d[n,co]^3 wsq[co,ci]  (what autograd runs through networks.py:288-291). */
+int mgf_demod_f32(float* d, const float* s, const float* wsq, int32_t n, int32_t cin, int32_t cout, mgf_stream_t stream);
+int mgf_demod_bwd_f32(float* ds, const float* dd, const float* d, const float* s, const float* wsq, int32_t n, int32_t cin, int32_t cout,
+                      mgf_stream_t stream);
 int mgf_style_demod(const mgf_style_job* job, const float* ws, int64_t ws_stride_n, int32_t n, int32_t wdim, mgf_stream_t stream);
 int mgf_style_demod_multi(const mgf_style_job* jobs_dev, int32_t njobs, const float* ws, int64_t ws_stride_n,
                           int32_t n, int32_t wdim, int32_t max_cin, mgf_stream_t stream);

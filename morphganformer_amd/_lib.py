@@ -91,6 +91,8 @@ _SIGS = {
     "mgf_pack_conv_weights": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
     "mgf_conv_profile_begin": (C.c_int, []),
     "mgf_conv_profile_end": (C.c_int, [C.POINTER(ConvProfRec), i32]),
+    "mgf_demod_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+    "mgf_demod_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "mgf_style_demod": (C.c_int, [C.POINTER(StyleJob), vp, i64, i32, i32, vp]),
     "mgf_style_demod_multi": (C.c_int, [vp, i32, vp, i64, i32, i32, i32, vp]),
     "mgf_duplex_attention": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(Epilogue), i32, vp, vp, vp]),

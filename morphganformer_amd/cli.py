@@ -41,9 +41,13 @@ def _loop_arguments(p):
                         "and never reads it; in literal mode it stays unused here too)")
     p.add_argument("--percept_weight", type=float, default=1.0, help="coefficient of the LPIPS term (0.5 with --beta 0.5 = 1024_example_percept_MSE.py)")
     p.add_argument("--pixel-term", choices=["mse", "psnr", "dssim", "lbp"], default="mse",
-                   help="psnr = the pixel term of 1024_example_PSNR.py (10 log10(255^2 / MSE), minimised like the script does; use with --no-lpips); "
+                   help="psnr = the pixel term of 1024_example_PSNR.py (10 log10(255^2 / MSE), minimised like the script does, and -- see --psnr-layout -- "
+                        "with the script's element order; use with --no-lpips); "
                         "dssim = (1 - SSIM) / 2 of the uint8 images (1024_example_SSIM.py's `dssim`); lbp = the LBP matching distance of "
                         "1024_example_LBP_percept.py, the whole objective of that script (use with --no-lpips; literal mode)")
+    p.add_argument("--psnr-layout", choices=["script", "aligned"], default="script",
+                   help="script = 1024_example_PSNR.py:150-158 as written: the candidate's C-H-W stream against the target's H-W-C stream (different pixels "
+                        "are paired); aligned = the PSNR of corresponding pixels (a deviation from the script)")
     p.add_argument("--pool-above", type=int, default=0,
                    help="projection_example_v1.py:150-155: block-average generated images taller than this (256 there) by height // N before the "
                         "image-space losses; the target image is then transformed to that size")
@@ -208,7 +212,7 @@ def main(argv=None):
     from .lpips import PerceptualLoss
     args = ProjectionArgs(step=a.step, lamda=a.lamda, beta=a.beta, lr=a.lr, lr_rampup=a.lr_rampup, lr_rampdown=a.lr_rampdown,
                           noise=a.noise, noise_ramp=a.noise_ramp, truncation_psi=a.truncation_psi, n_mean_latent=a.n_mean_latent,
-                          ratio=a.ratio, percept_weight=a.percept_weight, pixel_term=a.pixel_term, pool_above=a.pool_above)
+                          ratio=a.ratio, percept_weight=a.percept_weight, pixel_term=a.pixel_term, psnr_layout=a.psnr_layout, pool_above=a.pool_above)
     percept = None
     if not a.no_lpips:
         if a.lpips_backbone is None and not a.lpips_random_backbone:

@@ -349,13 +349,17 @@ def conv_large_dgrad(dy, w, pad, out=None):
     return conv_large_forward(dy, wt, None, 1, kh - 1 - pad, act="linear", out=out)
 
 
-def conv_strided_dgrad(dy, w, stride, pad, in_hw, out=None):
+def conv_strided_dgrad(dy, w, stride, pad, in_hw, out=None, in_scale=None, out_scale=None):
     """Data gradient of a strided convolution y = conv(x, w, stride, pad) with a large kernel (AlexNet's 11x11 / stride 4 stem):
     dx[s i + kh - pad] += w[co, ci, kh, kw] dy[co, i].  The stride^2 output phases are independent stride-1 correlations of dy with the
     sub-kernels w[.., r + s t, r' + s u] (<= 9 taps each for 11x11 / 4), run as tap-list launches into a phase-planar buffer that one
-    strided copy interleaves into dx [n, cin, H, W]."""
-    _lib.require_gpu(dy, w)
+    strided copy interleaves into dx [n, cin, H, W].  pad: p or (py, px); in_scale [n, cout] / out_scale [n, cin]: per-sample channel scales of
+    dy / dx inside the launches (the modulated form of torch_utils.ops.conv2d_resample)."""
+    _lib.require_gpu(dy, w, in_scale, out_scale)
     cout, cin, kh, kw = w.shape
+    pad_y, pad_x = (pad, pad) if isinstance(pad, int) else pad
+    if -(-kh // stride) * -(-kw // stride) > _lib.MAX_TAPS:
+        raise _lib.MgfError(f"conv_strided_dgrad: a {kh}x{kw} kernel at stride {stride} has more than {_lib.MAX_TAPS} taps per output phase")
     n, _, hy, wy = dy.shape
     H, W = in_hw
     s = stride
@@ -369,7 +373,7 @@ def conv_strided_dgrad(dy, w, stride, pad, in_hw, out=None):
         return ((diff + 1) // 2, 2) if diff % 2 else (diff // 2, 1)
 
     (py_, ky_), (px_, kx_) = geom(hq - hy), geom(wq - wy)
-    key = (w.data_ptr(), tuple(w.shape), s, pad)
+    key = (w.data_ptr(), tuple(w.shape), s, pad_y, pad_x)
     hit = _STRIDED_PLANS.get(key)
     # the entry holds a reference to `w` itself: the address cannot be recycled for other weights while the plan lives, and a hit is
     # only taken for the very same tensor object's storage (same version counter = not modified in place since)
@@ -377,11 +381,14 @@ def conv_strided_dgrad(dy, w, stride, pad, in_hw, out=None):
     if plan is None:                # the phase sub-kernels are a checkpoint constant: packed once
         plan = []
         for a in range(s):
-            ry, qy = (a + pad) % s, (a + pad) // s
+            ry, qy = (a + pad_y) % s, (a + pad_y) // s
             ts = [t for t in range(-(-kh // s)) if ry + s * t < kh]
             for b in range(s):
-                rx, qx = (b + pad) % s, (b + pad) // s
+                rx, qx = (b + pad_x) % s, (b + pad_x) // s
                 us = [u for u in range(-(-kw // s)) if rx + s * u < kw]
+                if not ts or not us:                                 # a phase no tap reaches (kernel narrower than the stride): zeros
+                    plan.append((a, b, None, None))
+                    continue
                 sub = torch.stack([w[:, :, ry + s * t, rx + s * u] for t in ts for u in us], dim=-1)        # [cout, cin, taps]
                 pc = pack_weights(sub.permute(1, 0, 2).reshape(cin, cout, 1, len(ts) * len(us)).contiguous())
                 plan.append((a, b, pc, [(qy - t, qx - u) for t in ts for u in us]))
@@ -389,7 +396,10 @@ def conv_strided_dgrad(dy, w, stride, pad, in_hw, out=None):
             _STRIDED_PLANS.pop(next(iter(_STRIDED_PLANS)))
         _STRIDED_PLANS[key] = (plan, w, w._version)
     for a, b, pc, taps in plan:
-        conv_forward(dy, pc, pad=(py_, px_), taps=taps, ksize=(ky_, kx_), out=phase)
+        if pc is None:
+            out[:, :, a::s, b::s].zero_()
+            continue
+        conv_forward(dy, pc, pad=(py_, px_), taps=taps, ksize=(ky_, kx_), out=phase, in_scale=in_scale, out_scale=out_scale)
         dst = out[:, :, a::s, b::s]
         dst.copy_(phase[:, :, :dst.shape[2], :dst.shape[3]])
     return out

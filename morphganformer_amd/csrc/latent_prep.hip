@@ -89,6 +89,34 @@ __global__ __launch_bounds__(256) void style_demod_single_kernel(mgf_style_job j
     style_demod_body(j, ws, ws_stride_n, wdim, blockIdx.z, s_lds);
 }
 
+// ------------------------------------------------------------------------------------------ demodulation alone (operator API)
+// torch_utils.ops.conv2d_resample.modulated_conv2d receives the styles as a tensor (networks.py:253-328 computes them outside): only the
+// demodulation coefficients are left to do, d[n,co] = rsqrt(sum_ci wsq[co,ci] s[n,ci]^2 + 1e-8), and their adjoint
+// ds[n,ci] = -s[n,ci] sum_co dd[n,co] d[n,co]^3 wsq[co,ci].  grid = (blocks, n).
+__global__ __launch_bounds__(256) void demod_kernel(float* __restrict__ d, const float* __restrict__ s, const float* __restrict__ wsq, int cin, int cout) {
+    const int n = blockIdx.y, lane = threadIdx.x & 63;
+    const float* sn = s + (int64_t)n * cin;
+    for (int co = blockIdx.x * 4 + (threadIdx.x >> 6); co < cout; co += gridDim.x * 4) {
+        const float* row = wsq + (int64_t)co * cin;
+        float acc = 0.f;
+        for (int ci = lane; ci < cin; ci += 64) { const float sv = sn[ci]; acc += row[ci] * sv * sv; }
+        acc = wave_sum(acc);
+        if (lane == 0) d[(int64_t)n * cout + co] = rsqrtf(acc + 1e-8f);
+    }
+}
+
+__global__ __launch_bounds__(256) void demod_bwd_kernel(float* __restrict__ ds, const float* __restrict__ dd, const float* __restrict__ d,
+                                                        const float* __restrict__ s, const float* __restrict__ wsq, int cin, int cout) {
+    const int n = blockIdx.y;
+    const int ci = blockIdx.x * 256 + threadIdx.x;
+    if (ci >= cin) return;
+    const float* ddn = dd + (int64_t)n * cout;
+    const float* dn = d + (int64_t)n * cout;
+    float acc = 0.f;
+    for (int co = 0; co < cout; ++co) { const float dv = dn[co]; acc += ddn[co] * dv * dv * dv * wsq[(int64_t)co * cin + ci]; }
+    ds[(int64_t)n * cin + ci] = -s[(int64_t)n * cin + ci] * acc;
+}
+
 // ------------------------------------------------------------------------------------------ attention value tables
 // vwb[n][c][t] (t fastest: 16 contiguous scalars per channel for the attention kernel's scalar loads)
 //   = sum_j ycomp[n,t,j] * wmv[c,j] + bmv[c]
@@ -615,6 +643,24 @@ __global__ __launch_bounds__(MAP_BLOCK) void mapping_backward_kernel(float* dz, 
 }
 
 }  // namespace
+
+extern "C" int mgf_demod_f32(float* d, const float* s, const float* wsq, int32_t n, int32_t cin, int32_t cout, mgf_stream_t stream) {
+    MGF_REQUIRE(d && s && wsq && n >= 1 && cin >= 1 && cout >= 1, MGF_EINVAL, "demod: bad arguments");
+    MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "demod: too many samples (%d)", n);
+    hipLaunchKernelGGL(demod_kernel, dim3((unsigned)mgf_cdiv(cout, 4) < 1024u ? (unsigned)mgf_cdiv(cout, 4) : 1024u, n), dim3(256), 0, (hipStream_t)stream,
+                       d, s, wsq, cin, cout);
+    MGF_CHECK_LAUNCH("demod");
+    return MGF_OK;
+}
+
+extern "C" int mgf_demod_bwd_f32(float* ds, const float* dd, const float* d, const float* s, const float* wsq, int32_t n, int32_t cin,
+                                 int32_t cout, mgf_stream_t stream) {
+    MGF_REQUIRE(ds && dd && d && s && wsq && n >= 1 && cin >= 1 && cout >= 1, MGF_EINVAL, "demod_bwd: bad arguments");
+    MGF_REQUIRE(n <= 65535, MGF_ETOOBIG, "demod_bwd: too many samples (%d)", n);
+    hipLaunchKernelGGL(demod_bwd_kernel, dim3((unsigned)mgf_cdiv(cin, 256), n), dim3(256), 0, (hipStream_t)stream, ds, dd, d, s, wsq, cin, cout);
+    MGF_CHECK_LAUNCH("demod_bwd");
+    return MGF_OK;
+}
 
 extern "C" int mgf_style_demod_multi(const mgf_style_job* jobs_dev, int32_t njobs, const float* ws, int64_t ws_stride_n,
                                      int32_t n, int32_t wdim, int32_t max_cin, mgf_stream_t stream) {

@@ -387,8 +387,12 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
     MGF_REQUIRE(cout_pad >= cout && cout_pad % 32 == 0, MGF_EINVAL, "conv1x1: the weight image must be [cin][cout_pad], cout_pad a multiple of 32 (got %d for %d)",
                 cout_pad, cout);
     MGF_REQUIRE(y_choff >= 0 && (y_batch == 0 || y_batch >= (int64_t)(y_choff + cout) * hw), MGF_EINVAL, "conv1x1: bad output slice");
-    // 32-bit byte offsets inside one sample / the weight image, with room for the reads past the last channel (they must not wrap)
-    MGF_REQUIRE(((int64_t)cin + 4 * PWKU * PWNR) * hw * 4 + 4096 <= (int64_t)UINT32_MAX && ((int64_t)cin + 4 * PWKU * PWNR) * cout_pad * 4 + 4096 <= (int64_t)UINT32_MAX,
+    // 32-bit byte offsets inside one sample / the weight image, with room for the reads past the last channel (they must not wrap: a wrapped
+    // offset would fetch in-range data where the buffer rule returns zeros).  The furthest read: with split-K (4 waves) every wave's share
+    // is rounded up to a multiple of PWNR load groups and the ring runs PWNR - 1 groups ahead -- group index < 4 PWNR ceil(nit / 4 PWNR) +
+    // PWNR - 1 <= nit + 5 PWNR, at 2 PWKU channels per group
+    constexpr int64_t PW_OVERREAD = 2LL * PWKU * (5 * PWNR + 1);
+    MGF_REQUIRE(((int64_t)cin + PW_OVERREAD) * hw * 4 + 4096 <= (int64_t)UINT32_MAX && ((int64_t)cin + PW_OVERREAD) * cout_pad * 4 + 4096 <= (int64_t)UINT32_MAX,
                 MGF_ETOOBIG, "conv1x1: one sample / the weight image must stay below 4 GiB (32-bit buffer offsets)");
     if (ep) {
         MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU || ep->act == MGF_ACT_RELU_POST,

@@ -33,9 +33,16 @@ def make_store(rank: int = None, world_size: int = None, host: str = None, port:
 
 def set_store(store):
     """Hand the module the store shared by all ranks of the job (any torch.distributed.Store: the one passed to
-    `torch.distributed.init_process_group(store=...)`, a TCPStore / FileStore of the caller's own)."""
+    `torch.distributed.init_process_group(store=...)`, a TCPStore / FileStore of the caller's own; None forgets it).  The queues count
+    under a prefix of their own that carries the launcher's restart count: the keys never collide with the rendezvous keys the same store
+    may hold (under torch.distributed.run it is the agent's store), and after an elastic restart (max_restarts > 0) the new attempt does
+    not see the counters the failed one left behind -- torch's own env rendezvous separates attempts the same way."""
     global _STORE
-    _STORE = store
+    if store is None:
+        _STORE = None
+        return None
+    import torch.distributed as dist
+    _STORE = dist.PrefixStore(f"mgf/attempt_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}", store)
     return store
 
 

@@ -440,13 +440,42 @@ class Generator:
         return self.vtabs.view(-1)[a.v_off * self.n:(a.v_off + a.c * T) * self.n]
 
     # ------------------------------------------------------------------ API
-    def to(self, device):
+    def to(self, *args, **kwargs):
+        """nn.Module.to as the drivers use it (`G = ...["Gs"].to(device)`, ...sqz_MSE.py:249).  This generator's weights, packed tables and
+        workspaces live on the device it was built on: that device (or float32) is a no-op, anything else RAISES -- a request to move is never
+        silently ignored (build the Generator / call loader.load_network with device= instead)."""
+        device = kwargs.get("device")
+        dtype = kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif isinstance(a, (str, int, torch.device)):
+                device = a
+            elif isinstance(a, torch.Tensor):
+                device, dtype = a.device, a.dtype
+        if dtype is not None and dtype != torch.float32:
+            raise _lib.MgfError(f"Generator.to: the HIP generator is float32 only (got {dtype})")
+        if device is not None:
+            want = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+            index = lambda d: d.index if d.index is not None else torch.cuda.current_device()
+            if want.type != "cuda" or index(want) != index(self.device):
+                raise _lib.MgfError(f"Generator.to: this generator was built on {self.device} (index {index(self.device)}) and cannot move to {want}; "
+                                    "construct it on the target device (Generator(sd, cfg, device=...) / loader.load_network(path, device=...))")
         return self
 
     def eval(self):
         return self
 
+    def train(self, mode=True):
+        if mode:
+            raise _lib.MgfError("Generator.train: the HIP generator is inference-only (its weights are constants); use eval()")
+        return self
+
     def requires_grad_(self, flag=False):
+        """The reference drivers call .requires_grad_(False); the weights here never carry gradients, so True is refused."""
+        if flag:
+            raise _lib.MgfError("Generator.requires_grad_(True): the HIP generator's weights are constants (gradient mode differentiates "
+                                "with respect to the latent: grad.GeneratorGrad / GradientProjectionEngine)")
         return self
 
     def mapping(self, z, truncation_psi=1, truncation_cutoff=None):

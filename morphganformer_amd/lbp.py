@@ -4,7 +4,9 @@ the cosine distance -- is csrc/lbp.hip (mgf_lbp_gray224_u8 / mgf_lbp_codes_u8 / 
 
 OpenCV and scikit-image are third-party packages outside the reference tree (and absent offline): what is restated here is their
 published algorithm -- cv2.resize's INTER_LINEAR on uint8 (imgproc/resize.cpp: half-pixel centres, coefficients rounded to 11-bit
-fixed point) and skimage/feature/_texture.pyx's sample offsets (rounded to 5 decimals)."""
+fixed point) and skimage/feature/_texture.pyx's sample offsets (rounded to 5 decimals).  UNPINNED against the real packages; one known
+difference outside this restatement's reach: `cv2.imread(path, IMREAD_GRAYSCALE)` of a JPEG takes libjpeg's own luma plane, not the
+BGR2GRAY fixed-point weights `target_feature` applies to decoded RGB pixels (identical for PNG / BMP targets)."""
 import numpy as np
 import torch
 
@@ -16,9 +18,12 @@ SIDE, POINTS, RADIUS = 224, 24, 3          # settings of the script (:34-37; cv2
 def resize_table(dst, src):
     """cv2.resize INTER_LINEAR, one axis: (index 0, index 1, coefficient 0, coefficient 1) per destination position, coefficients at scale
     2048 (saturate_cast<short>(c * INTER_RESIZE_COEF_SCALE), i.e. round-half-even of the float32 product)."""
-    f = (np.arange(dst, dtype=np.float64) + 0.5) * (src / dst) - 0.5
-    s0 = np.floor(f).astype(np.int64)
-    fr = (f - s0).astype(np.float32)
+    # resize.cpp: scale = 1. / ((double)dst / src); fx = (float)((dx + 0.5) * scale - 0.5); sx = cvFloor(fx); fx -= sx -- float32 BEFORE the
+    # floor and the fraction (in float64 the index or an 11-bit coefficient can differ by one for some size ratios)
+    f = ((np.arange(dst, dtype=np.float64) + 0.5) * (1.0 / (dst / src)) - 0.5).astype(np.float32)
+    s0f = np.floor(f)
+    s0 = s0f.astype(np.int64)
+    fr = (f - s0f).astype(np.float32)
     lo = s0 < 0
     s0[lo], fr[lo] = 0, 0.0
     hi = s0 >= src - 1

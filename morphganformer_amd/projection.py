@@ -51,8 +51,12 @@ class ProjectionArgs:
     percept_weight: float = 1.0     # coefficient of the LPIPS term: 1 in the Wing/LPIPS/MSE drivers, 0.5 in 1024_example_percept_MSE.py:147
     min_loss_init: float = 100.0
     # "mse": beta * MSE(img, target), the drivers' pixel term.  "psnr": the pixel term of 1024_example_PSNR.py:113-114,158 --
-    # 10 log10(255^2 / mean((img - target)^2)) on the [-1, 1] float images, MINIMISED like every other loss of these loops (:173-175 keeps
-    # the candidate with the smallest value; the script's objective as written, not a claim that it is a sensible one)
+    # 10 log10(255^2 / mean((p0 - p1)^2)) on the [-1, 1] float images, MINIMISED like every other loss of these loops (:173-175 keeps
+    # the candidate with the smallest value; the script's objective as written, not a claim that it is a sensible one).  AS WRITTEN also
+    # covers the element order (`psnr_layout="script"`, the default): :150-153 permute the generated image and tensor2np it back into
+    # C-H-W order, tensor2np the target into H-W-C order, and :158 compares the two FLATTENED arrays -- element i of the candidate's
+    # CHW stream against element i of the target's HWC stream, i.e. different pixels and channels.  `psnr_layout="aligned"` is the PSNR the
+    # function defines on corresponding pixels (a deliberate deviation from the script; ranks candidates by their MSE)
     # "dssim": `dssim` of 1024_example_SSIM.py:115-117 (= lpips/__init__.py:54-55), (1 - SSIM) / 2 with skimage's defaults, on the uint8
     # images (the generated image as the drivers save it, misc.to_pil) -- the function as defined; the script's own call site (:158) passes
     # flattened float arrays, which compare_ssim rejects
@@ -60,6 +64,7 @@ class ProjectionArgs:
     # 224 x 224, the target file's code map) in float64 -- in place of every other term (the script scores nothing else); needs
     # ProjectionEngine(lbp_target=lbp.target_feature(file pixels))
     pixel_term: str = "mse"
+    psnr_layout: str = "script"
     # projection_example_v1.py:150-155: a generated image taller than `pool_above` pixels is block-averaged by height // pool_above before
     # the image-space losses (the target is then given at the pooled size, :84-92 resize it to 256); 0 = off (the 1024 drivers)
     pool_above: int = 0
@@ -174,7 +179,7 @@ class ProjectionEngine:
         self.device = dev
         _lib.require_gpu(target, latent_mean)
         self.steps = a.step
-        self.target = target.contiguous().float()
+        self.target = target.detach().float().clone(memory_format=torch.contiguous_format)     # the engine's OWN copy: retarget() rewrites it in place
         assert self.target.shape[0] == 1, "one target per engine (the drivers process images serially)"
         self.percept = percept
         self.use_lbp = a.pixel_term == "lbp"
@@ -235,6 +240,10 @@ class ProjectionEngine:
         self.scratch = torch.empty(B * int(_lib.lib().mgf_reduce_scratch_floats()), dtype=torch.float32, device=dev)
         self._arange = torch.arange(B, dtype=torch.int64, device=dev)
         assert a.pixel_term in ("mse", "psnr", "dssim", "lbp"), a.pixel_term
+        assert a.psnr_layout in ("script", "aligned"), a.psnr_layout
+        # what the pixel term reads as "the target": the image itself, or -- the PSNR script's element order -- its H-W-C stream under the
+        # candidate's C-H-W indexing (one permuted copy, refreshed by retarget(); the kernel is the same aligned sum)
+        self.pix_target = self._script_order(self.target) if (a.pixel_term == "psnr" and a.psnr_layout == "script") else self.target
         if self.use_lbp:
             from . import lbp
             r = G.cfg.img_resolution
@@ -345,7 +354,7 @@ class ProjectionEngine:
                                           self.dssim_scratch.data_ptr(), st), "dssim")
         elif self.use_mse:
             per = img.numel() // B
-            _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.target.data_ptr(), B, per, 0, 1.0, 0,
+            _lib.check(L.mgf_mse_f32(self.mse_loss.data_ptr(), img.data_ptr(), self.pix_target.data_ptr(), B, per, 0, 1.0, 0,
                                      self.scratch.data_ptr(), st), "mse")
             if a.pixel_term == "psnr":
                 # 10 * np.log10(peak ** 2 / np.mean(d ** 2)) with peak = 255., in float32 like the script's numpy (1024_example_PSNR.py:113-114)
@@ -625,6 +634,11 @@ class ProjectionEngine:
                 self._iteration()
         return self
 
+    @staticmethod
+    def _script_order(target):
+        """[1, C, H, W] tensor whose C-H-W stream is the target's H-W-C stream (`tensor2np(imgs).flatten()`, 1024_example_PSNR.py:122,153,158)."""
+        return target.permute(0, 2, 3, 1).contiguous().view(target.shape)
+
     def retarget(self, target, lm_target=None, lm_steps=None, lm_valid=None, eps=None, seed=None, latent_mean=None, latent_std=None,
                  lbp_target=None):
         """Point this engine at ANOTHER target image and rewind the loop, keeping everything that was expensive to set up: the captured
@@ -640,6 +654,8 @@ class ProjectionEngine:
         assert tuple(target.shape) == tuple(self.target.shape), (tuple(target.shape), tuple(self.target.shape))
         torch.cuda.synchronize(dev)
         self.target.copy_(target)
+        if self.pix_target is not self.target:
+            self.pix_target.copy_(self._script_order(self.target))
         if self.percept is not None:
             self.percept.set_target(self.target)                  # same shapes: rewrites the cached taps in place
         if self.biometric is not None:
@@ -774,7 +790,7 @@ class GradientProjectionEngine(ProjectionEngine):
         B = int(target.shape[0])
         self.device, self.batch, self.steps = dev, 1, a.step
         _lib.require_gpu(target, latent_mean)
-        self.target = target.contiguous().float()
+        self.target = target.detach().float().clone(memory_format=torch.contiguous_format)     # the engine's OWN copy: retarget() rewrites it in place
         self.percept, self.use_mse, self.use_wing, self.noise_mode = percept, use_mse, lm_target is not None, noise_mode
         self.latent_shape = ls
         self.numel = int(np.prod(ls))

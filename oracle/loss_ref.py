@@ -60,6 +60,23 @@ def psnr_ref(p0, p1, peak=255.0):
     return 10 * np.log10(peak ** 2 / np.mean((1. * a - 1. * b) ** 2))
 
 
+def psnr_script_ref(img_gen, imgs, peak=255.0):
+    """The PSNR driver's loss exactly as 1024_example_PSNR.py:150-158 forms it, transcribed step by step from [1, C, H, W] tensors:
+        img_gen_raw2 = img_gen.permute(0, 3, 1, 2);  pre = tensor2np(img_gen_raw2);  trg = tensor2np(imgs)
+        psnr(pre.flatten(), trg.flatten())       with tensor2np(t) = t[0].numpy().transpose((1, 2, 0))  (:120-122)
+    `pre` comes back in C-H-W order (the permute and the transpose cancel), `trg` is H-W-C: the flattened streams pair element i of one
+    with element i of the other, i.e. different pixels and channels.  This function IS the script's arithmetic; whether the product
+    follows it (`psnr_layout="script"`) or the aligned definition (`psnr_ref`) is ProjectionArgs' choice."""
+    import numpy as np
+    import torch
+    tensor2np = lambda t: t[0].cpu().float().numpy().transpose((1, 2, 0))
+    img_gen, imgs = torch.as_tensor(img_gen), torch.as_tensor(imgs)
+    pre = tensor2np(img_gen.permute(0, 3, 1, 2))
+    trg = tensor2np(imgs)
+    assert pre.shape == tuple(img_gen.shape[1:]) and trg.shape == (imgs.shape[2], imgs.shape[3], imgs.shape[1])
+    return psnr_ref(pre.flatten(), trg.flatten(), peak)
+
+
 def to_u8_ref(img):
     """misc.py:115-116 (`to_pil`): adjust_range([-1, 1] -> [0, 255]) in float32, np.rint, clip, uint8 -- the image the drivers save."""
     import numpy as np
@@ -120,7 +137,8 @@ def cv_bgr2gray_u8_ref(img_u8, blue_first=True):
 
 def cv_resize_linear_gray_ref(gray_u8, width, height):
     """cv2.resize(gray, (width, height)), INTER_LINEAR on uint8, pixel by pixel from OpenCV's published scheme (imgproc/resize.cpp): source
-    coordinate (d + 0.5) * scale - 0.5, clamped at both ends, float32 weights rounded to 11-bit fixed point (cvRound: half to even), the
+    coordinate (d + 0.5) * scale - 0.5, clamped at both ends, the coordinate cast to float32 BEFORE its floor and fraction are taken (as resize.cpp does), float32 weights rounded to 11-bit
+    fixed point (cvRound: half to even), the
     horizontal pass in int32, the vertical pass (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  UNPINNED against OpenCV."""
     import numpy as np
     g = np.asarray(gray_u8)
@@ -130,9 +148,10 @@ def cv_resize_linear_gray_ref(gray_u8, width, height):
     def axis(dst, src):
         out = []
         for d in range(dst):
-            f = (d + 0.5) * (src / dst) - 0.5
+            # resize.cpp: scale_x = 1. / ((double)dsize.width / ssize.width); fx = (float)((dx + 0.5) * scale_x - 0.5); sx = cvFloor(fx); fx -= sx
+            f = np.float32((d + 0.5) * (1.0 / (dst / src)) - 0.5)
             s = int(math.floor(f))
-            fr = np.float32(f - s)
+            fr = np.float32(f - np.float32(s))
             if s < 0:
                 s, fr = 0, np.float32(0)
             if s >= src - 1:

@@ -239,8 +239,20 @@ def gold_loop_tiny(ref, G):
                         latents_n=np.stack(latents_n))
 
 
+def _attention_layer_names(cfg):
+    """The synthesis layers that carry a TransformerLayer, in execution order (conv0 before conv1 inside a block)."""
+    names = []
+    for res in cfg.block_resolutions:
+        if cfg.has_attention(res):
+            names += ([f"b{res}.conv0"] if res > 4 else []) + [f"b{res}.conv1"]
+    return names
+
+
 def gold_generator_full(ref):
-    """Full-size 1024^2 generator: 4096 sampled pixels + per-block checksums."""
+    """Full-size 1024^2 generator: 4096 sampled pixels + per-block checksums -> gen_full1024.npz, and the
+    integer gate of SURVEY 8d at full size -> att_full1024.npz: for each of the 11 TransformerLayers of the 1024^2 model
+    (networks.py:505-524,776-792) the per-pixel argmax latent assignment (uint8), the mask of pixels whose top-2 probability margin
+    exceeds 1e-4 ("decided": an f32 kernel cannot be asked to reproduce a tie) and 256 sampled probability rows, for two latents."""
     from morphganformer_amd.synth_weights import FULL1024, make_state_dict, synthetic_latents
     sd = make_state_dict(FULL1024, seed=0)
     G = build_reference_generator(ref, FULL1024, sd)
@@ -248,15 +260,44 @@ def gold_generator_full(ref):
     G.synthesis.list2tensor = lambda att_list, device: torch.zeros([1])
     z = torch.from_numpy(synthetic_latents(FULL1024, 1, seed=1000))
     stats = {}
+    probs = {}
     hooks = []
     for res in FULL1024.block_resolutions:
         blk = getattr(G.synthesis, f"b{res}")
         hooks.append(blk.register_forward_hook(
             lambda m, i, o, r=res: stats.__setitem__(r, (float(o[0].double().mean()), float(o[0].double().square().mean().sqrt())))))
+    att_names = _attention_layer_names(FULL1024)
+    for key in att_names:
+        b, name = key.split(".")
+        tr = getattr(getattr(G.synthesis, b), name).transformer
+        hooks.append(tr.register_forward_hook(lambda m, i, o, k=key: probs.__setitem__(k, o[1].detach().clone())))
     torch.set_num_threads(8)
     img = G(z, None, noise_mode="const")[0]
+    T = FULL1024.k - 1
+    att = {"z": [z.numpy()], "layers": np.array(att_names)}
+    rng_att = np.random.Generator(np.random.PCG64(515))
+    rows = {key: np.sort(rng_att.choice(probs[key].numel() // T, size=min(256, probs[key].numel() // T), replace=False)) for key in att_names}
+
+    def keep_att(slot):
+        for key in att_names:
+            p = probs[key].reshape(-1, T).numpy()                       # [F, T] of the one sample
+            top2 = np.sort(p, axis=-1)[:, -2:]
+            att.setdefault("argmax_" + key, []).append(p.argmax(-1).astype(np.uint8))
+            att.setdefault("decided_" + key, []).append(np.packbits((top2[:, 1] - top2[:, 0]) > 1e-4))
+            att.setdefault("probs_" + key, []).append(p[rows[key]])
+    keep_att(0)
+    for h in hooks[:len(FULL1024.block_resolutions)]:
+        h.remove()
+    z2 = torch.from_numpy(synthetic_latents(FULL1024, 1, seed=1001))
+    att["z"].append(z2.numpy())
+    G(z2, None, noise_mode="const")
+    keep_att(1)
     for h in hooks:
         h.remove()
+    for key in att_names:
+        att["rows_" + key] = rows[key]
+    np.savez_compressed(os.path.join(OUT, "att_full1024.npz"), **{k_: (np.concatenate(v) if k_ == "z" else np.stack(v) if isinstance(v, list) else v)
+                                                                   for k_, v in att.items()})
     rng = np.random.Generator(np.random.PCG64(99))
     idx = rng.integers(0, 3 * 1024 * 1024, size=4096)
     flat = img.reshape(-1).numpy()
@@ -574,6 +615,8 @@ def main():
             gold_wplus_tiny(ref)
         if "gradfull" in only:
             gold_grad_full(ref)
+        if "full" in only:
+            gold_generator_full(ref)
         if "iresnet" in only:
             gold_iresnet()
         if "morph" in only:

@@ -358,7 +358,56 @@ def test_project_many_shards_and_gathers(golden):
     single = drivers.project_image(G, targets[1], None, None, **kw)
     assert torch.equal(res["latents"][1].cpu(), single["w"][0]) and int(res["steps"][1]) == single["step"]
     dyn = drivers.project_many(G, targets, dynamic=True, **kw)
-    assert torch.equal(dyn["latents"], res["latents"])
+    assert torch.equal(dyn["latents"], res["latents"]) and torch.equal(dyn["losses"], res["losses"]) and torch.equal(dyn["steps"], res["steps"])
+    # a re-targeted engine rewrites ITS copy of the target, never the caller's tensor (it used to alias item 0 and leave the last item's
+    # pixels in it: a second pass over the same list then scored item 0 against the wrong image)
+    assert torch.equal(targets[0], torch.from_numpy(g["target"]).cuda())
+
+
+def test_project_many_under_an_rccl_process_group_of_one_rank(golden):
+    """First contact with RCCL happens HERE, not in the driver's scaling run: in this process (no re-exec, no child after GPU
+    initialisation) a world-size-1 "nccl" process group is created through `distributed.init_process_group` (which makes the TCPStore, hands
+    it to torch and keeps it for the work queues), `drivers.project_many(dynamic=True)` runs its three tiny targets through the queue and
+    the ragged float64 `all_gather_into_tensor` on DEVICE tensors, `gather_results` gathers one record, and the group is destroyed.  The
+    N > 1 control flow is the gloo tests' (tests/test_host_and_abi.py); the job's shape is projection_example_v2_percept_morph.py:329-365."""
+    import socket
+    import torch.distributed as dist
+    from morphganformer_amd import distributed, drivers
+    from morphganformer_amd.projection import ProjectionArgs
+    assert not dist.is_initialized()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    g = golden("loop_tiny.npz")
+    G = _tiny_G()
+    t = torch.from_numpy(g["target"]).cuda()
+    targets = [t, (t * 0.9).contiguous(), (t * 0.8).contiguous()]
+    kw = dict(args=ProjectionArgs(step=6, n_mean_latent=300), seed=0, batch=3, noise_mode="const")
+    ref = drivers.project_many(G, targets, **kw)                          # no process group: the plain loop
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    before = distributed.get_store()
+    try:
+        store = distributed.init_process_group("nccl", rank=0, world_size=1, host="127.0.0.1", port=port,
+                                               device_id=torch.device("cuda", torch.cuda.current_device()))
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        qs = distributed.get_store()                               # the queues' view of the same store (own prefix, restart count in it)
+        assert qs is not None and qs.add("mgf_test/counter", 1) == 1 and qs.add("mgf_test/counter", 1) == 2 and store.num_keys() >= 1
+        ids = torch.empty(1, dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(ids, torch.tensor([7], dtype=torch.int64, device="cuda"))       # one raw RCCL collective
+        assert ids.tolist() == [7]
+        dyn = drivers.project_many(G, targets, dynamic=True, **kw)
+        assert dyn["items"].tolist() == [0, 1, 2] and dyn["mine"] == [0, 1, 2] and dyn["latents"].is_cuda
+        assert torch.equal(dyn["latents"], ref["latents"]) and torch.equal(dyn["steps"], ref["steps"]) and torch.equal(dyn["losses"], ref["losses"])
+        sta = drivers.project_many(G, targets, **kw)
+        assert torch.equal(sta["latents"], ref["latents"])
+        one = distributed.gather_results(ref["latents"][1:2].cuda(), float(ref["losses"][1]), int(ref["steps"][1]), item=1)
+        assert torch.equal(one["latents"][0], ref["latents"][1]) and one["items"].tolist() == [1] and float(one["losses"][0]) == float(ref["losses"][1])
+        dist.barrier()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        distributed._STORE = before
+    assert not dist.is_initialized()
 
 
 def test_device_landmark_model_in_the_graph(golden):

@@ -68,6 +68,27 @@ def test_tiny_attention_assignments(tiny, golden):
         assert np.array_equal(argmax.cpu().numpy()[decided], ref.argmax(-1)[decided]), key
 
 
+def test_generator_to_refuses_to_be_ignored(tiny):
+    """`G = load_network(...)["Gs"].to(device)` (...sqz_MSE.py:249): the device the generator lives on is accepted in every spelling, any other
+    device, dtype or a request for trainable weights RAISES instead of being silently ignored."""
+    from morphganformer_amd import _lib
+    G, sd, cfg = tiny
+    cur = torch.cuda.current_device()
+    for dev_ in ("cuda", f"cuda:{cur}", torch.device("cuda", cur), cur):
+        assert G.to(dev_) is G
+    assert G.to(device=f"cuda:{cur}", dtype=torch.float32) is G and G.to(torch.float32) is G and G.to(torch.zeros(1, device="cuda")) is G
+    assert G.eval() is G and G.requires_grad_(False) is G and G.train(False) is G
+    for bad in ("cpu", f"cuda:{cur + 3}", torch.device("cuda", cur + 1), cur + 1):
+        with pytest.raises(_lib.MgfError, match="cannot move"):
+            G.to(bad)
+    with pytest.raises(_lib.MgfError, match="float32"):
+        G.to(torch.float16)
+    with pytest.raises(_lib.MgfError):
+        G.requires_grad_(True)
+    with pytest.raises(_lib.MgfError):
+        G.train()
+
+
 def test_tiny_vs_oracle_fresh_latents(tiny):
     from oracle.generator_ref import generator_ref, to_torch_state
     G, sd, cfg = tiny
@@ -114,6 +135,55 @@ def test_full_1024_matches_reference_samples(golden):
     pix2 = img2.reshape(-1)[torch.from_numpy(g["idx"]).cuda()].cpu().numpy()
     assert np.abs(pix2 - g["pixels"]).max() / amax < PIX_TOL
     assert float((img2 - ref_img).abs().max()) / amax < 1e-5
+
+
+def _check_att_full(att, g, slot, sample):
+    for key in g["layers"]:
+        key = str(key)
+        probs, argmax = att["synthesis." + key]
+        F = g["argmax_" + key].shape[1]
+        assert tuple(argmax.shape[1:]) == (F,), key
+        dec = np.unpackbits(g["decided_" + key][slot])[:F].astype(bool)
+        assert dec.mean() > 0.99, key
+        am = argmax[sample].cpu().numpy()
+        assert np.array_equal(am[dec], g["argmax_" + key][slot][dec]), (key, int((am[dec] != g["argmax_" + key][slot][dec]).sum()))
+        pr = probs[sample].cpu().numpy()
+        assert np.abs(pr[g["rows_" + key]] - g["probs_" + key][slot]).max() < 1e-4, key
+        # the handed-out argmax is the argmax of the handed-out probabilities wherever those are decided
+        top2 = np.sort(pr, axis=-1)[:, -2:]
+        own = (top2[:, 1] - top2[:, 0]) > 1e-6
+        assert np.array_equal(am[own], pr.argmax(-1)[own]), key
+
+
+def test_full_1024_attention_assignments_batch1(golden):
+    """SURVEY 8d's integer gate at FULL size: the per-pixel argmax latent assignment of every one of the 1024^2 model's 11 attention
+    layers (F up to 16 384, C = 512 / 256) against the reference module's own (att_full1024.npz, networks.py:505-524,776-792) --
+    exact on every pixel the reference decides by more than 1e-4, probabilities <= 1e-4 on 256 sampled rows -- at batch 1."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import FULL1024, make_state_dict
+    g = golden("att_full1024.npz")
+    G = Generator(make_state_dict(FULL1024, seed=0), FULL1024, "cuda", max_batch=1)
+    for slot in range(2):
+        img, att = G(torch.from_numpy(g["z"][slot:slot + 1]).cuda(), None, noise_mode="const", return_att=True, att_format="maps")
+        assert len(att) == 11
+        _check_att_full(att, g, slot, 0)
+
+
+def test_full_1024_attention_assignments_bench_dispatch(golden):
+    """The same gate in the dispatch bench.py times: drivers.DEFAULT_BATCH (32) candidates per forward (the wide attention launches, the
+    batched conv kernels in front of them).  Candidates 0 / 31 carry the fixture's first latent, 1 / 30 its second, the rest are other
+    latents; the 738 MB-per-image stacked tensor is not built (att_format="maps")."""
+    from morphganformer_amd.drivers import DEFAULT_BATCH
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.synth_weights import FULL1024, make_state_dict, synthetic_latents
+    g = golden("att_full1024.npz")
+    B = DEFAULT_BATCH
+    G = Generator(make_state_dict(FULL1024, seed=0), FULL1024, "cuda", max_batch=B)
+    z = torch.from_numpy(synthetic_latents(FULL1024, B, seed=4000)).clone()
+    z[0], z[B - 1], z[1], z[B - 2] = (torch.from_numpy(g["z"][i]) for i in (0, 0, 1, 1))
+    img, att = G.forward_workspace(z.cuda(), None, noise_mode="const", return_att=True, att_format="maps")
+    for slot, sample in ((0, 0), (0, B - 1), (1, 1), (1, B - 2)):
+        _check_att_full(att, g, slot, sample)
 
 
 def test_full_1024_bench_batch_equals_batch1(golden):

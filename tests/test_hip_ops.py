@@ -212,6 +212,105 @@ def test_modulated_conv_golden(golden):
     assert rel_err(y, g["y_skip_up2"]) < 1e-5
 
 
+@pytest.mark.parametrize("up,down,k,flip_w", [(1, 1, 3, True), (1, 1, 3, False), (1, 1, 1, True), (2, 1, 3, False), (2, 1, 3, True), (2, 1, 1, True),
+                                               (1, 2, 3, True), (1, 2, 1, True), (2, 2, 3, True), (1, 1, 5, True)])
+def test_conv2d_resample_gradient_vs_oracle_autograd(up, down, k, flip_w):
+    """The operator is differentiable like the reference's (conv2d_gradfix.py:50-162 under conv2d_resample.py:51-146): first-order dL/dx against
+    float64 autograd through the oracle's restatement for up / down in {1, 2}, 1x1 / 3x3 (+ a 25-tap kernel on the chained launches), and
+    the second-order piece a gradient penalty needs -- d<dx, v>/d(dy) = the forward applied to v."""
+    from morphganformer_amd.torch_utils.ops import conv2d_resample as cr
+    from oracle.ops_ref import conv2d_resample_ref, setup_filter_ref
+    torch.manual_seed(up * 100 + down * 10 + k)
+    n, ci, co, h = 2, 12, 20, 14
+    x = torch.randn(n, ci, h, h)
+    w = torch.randn(co, ci, k, k) / math.sqrt(ci * k * k)
+    f = setup_filter_ref([1, 3, 3, 1]) if (up > 1 or down > 1) else None
+    pad = k // 2
+    xr = x.double().requires_grad_(True)
+    ref = conv2d_resample_ref(xr, w.double(), None if f is None else f.double(), up=up, down=down, padding=pad, flip_weight=flip_w)
+    gy = torch.randn(ref.shape, dtype=torch.float64)
+    (dx_ref,) = torch.autograd.grad(ref, xr, gy)
+    xd = x.cuda().requires_grad_(True)
+    y = cr.conv2d_resample(xd, w.cuda(), None if f is None else f.cuda(), up=up, down=down, padding=pad, flip_weight=flip_w)
+    assert y.requires_grad and y.grad_fn is not None
+    assert rel_err(y, ref) < 2e-5
+    gyd = gy.float().cuda().requires_grad_(True)
+    (dx,) = torch.autograd.grad(y, xd, gyd, create_graph=True)
+    assert tuple(dx.shape) == tuple(x.shape) and rel_err(dx, dx_ref) < 2e-5, (up, down, k)
+    v = torch.randn(x.shape)
+    (d2,) = torch.autograd.grad((dx * v.cuda()).sum(), gyd)
+    ref_v = conv2d_resample_ref(v.double(), w.double(), None if f is None else f.double(), up=up, down=down, padding=pad, flip_weight=flip_w)
+    assert rel_err(d2, ref_v) < 2e-5, (up, down, k)
+
+
+@pytest.mark.parametrize("up,demod", [(1, True), (1, False), (2, True), (2, False)])
+def test_modulated_conv2d_gradients_vs_oracle_autograd(up, demod):
+    """networks.py:253-328 differentiated with respect to x AND the styles (through the modulation and the demodulation, :288-291) against float64
+    autograd through the oracle's grouped-conv restatement; with noise, whose add must not cut the graph."""
+    from morphganformer_amd.torch_utils.ops import conv2d_resample as cr
+    from oracle.ops_ref import modulated_conv2d_ref, setup_filter_ref
+    torch.manual_seed(7 + up + int(demod))
+    n, ci, co, h = 3, 16, 24, 10
+    x, s = torch.randn(n, ci, h, h), torch.randn(n, ci) + 1.0
+    w = torch.randn(co, ci, 3, 3)
+    f = setup_filter_ref([1, 3, 3, 1])
+    noise = torch.randn(n, 1, h * up, h * up)
+    xr, sr = x.double().requires_grad_(True), s.double().requires_grad_(True)
+    ref = modulated_conv2d_ref(xr, w.double(), sr, noise.double(), up=up, padding=1, resample_kernel=f.double(), demodulate=demod, flip_weight=(up == 1))
+    gy = torch.randn(ref.shape, dtype=torch.float64)
+    dx_ref, ds_ref = torch.autograd.grad(ref, (xr, sr), gy)
+    xd, sd = x.cuda().requires_grad_(True), s.cuda().requires_grad_(True)
+    y = cr.modulated_conv2d(xd, w.cuda(), sd, noise.cuda(), up=up, padding=1, resample_kernel=f.cuda(), demodulate=demod, flip_weight=(up == 1))
+    assert rel_err(y, ref) < 2e-5
+    dx, ds = torch.autograd.grad(y, (xd, sd), gy.float().cuda())
+    assert rel_err(dx, dx_ref) < 5e-5 and rel_err(ds, ds_ref) < 5e-5, (up, demod)
+    # without a graph the noise add is the library's own pass (upfirdn2d's epilogue port), same numbers
+    with torch.no_grad():
+        y2 = cr.modulated_conv2d(x.cuda(), w.cuda(), s.cuda(), noise.cuda(), up=up, padding=1, resample_kernel=f.cuda(), demodulate=demod,
+                                 flip_weight=(up == 1))
+    assert not y2.requires_grad and rel_err(y2, ref) < 2e-5
+
+
+def test_conv2d_resample_refuses_what_it_cannot_differentiate():
+    """Never a silently detached tensor: trainable weights, groups > 1 and second-order style gradients raise."""
+    from morphganformer_amd import _lib
+    from morphganformer_amd.torch_utils.ops import conv2d_resample as cr
+    x = torch.randn(1, 4, 8, 8).cuda().requires_grad_(True)
+    w = torch.randn(6, 4, 3, 3).cuda()
+    with pytest.raises(_lib.MgfError, match="constants"):
+        cr.conv2d_resample(x, w.clone().requires_grad_(True), padding=1)
+    with pytest.raises(_lib.MgfError, match="constants"):
+        cr.modulated_conv2d(x, w.clone().requires_grad_(True), torch.ones(1, 4).cuda(), padding=1)
+    with pytest.raises(_lib.MgfError, match="groups"):
+        cr.conv2d_resample(x, w[:, :2].contiguous(), padding=1, groups=2)
+    with torch.no_grad():                                          # inference with a trainable module's weights is fine
+        cr.conv2d_resample(x, w.clone().requires_grad_(True), padding=1)
+    s = torch.ones(1, 4).cuda().requires_grad_(True)
+    y = cr.modulated_conv2d(x, w, s, padding=1)
+    (ds,) = torch.autograd.grad(y.sum(), s, create_graph=False)
+    assert ds.shape == s.shape
+    y = cr.modulated_conv2d(x, w, s, padding=1)
+    with pytest.raises(_lib.MgfError, match="second-order"):
+        torch.autograd.grad(y.sum(), s, create_graph=True)
+
+
+def test_fma_matches_reference_semantics_and_gradients():
+    """fma(a, b, c) = a * b + c with broadcasting and the reference's custom backward (fma.py:12-37: products un-broadcast to each operand)."""
+    from morphganformer_amd.torch_utils.ops import fma
+    torch.manual_seed(3)
+    a, b, c = torch.randn(2, 5, 7, 3), torch.randn(5, 1, 3), torch.randn(1, 5, 1, 1)
+    ar, br, cr_ = (t.double().requires_grad_(True) for t in (a, b, c))
+    ref = ar * br + cr_
+    g = torch.randn(ref.shape, dtype=torch.float64)
+    refs = torch.autograd.grad(ref, (ar, br, cr_), g)
+    ad, bd, cd = (t.cuda().requires_grad_(True) for t in (a, b, c))
+    y = fma.fma(ad, bd, cd)
+    assert rel_err(y, ref) < 1e-6
+    outs = torch.autograd.grad(y, (ad, bd, cd), g.float().cuda())
+    for o, r, t in zip(outs, refs, (a, b, c)):
+        assert tuple(o.shape) == tuple(t.shape) and rel_err(o, r) < 1e-5
+
+
 @pytest.mark.parametrize("n,cin,cout,res,k,stride,pad", [
     (1, 32, 32, 64, 3, 1, 1), (2, 64, 96, 40, 3, 1, 1), (1, 3, 64, 67, 3, 2, 0), (1, 16, 64, 31, 1, 1, 0),
     (1, 48, 192, 17, 3, 1, 1), (3, 8, 3, 36, 1, 1, 0), (1, 128, 64, 8, 3, 1, 1), (1, 512, 512, 4, 3, 1, 1)])

@@ -447,19 +447,26 @@ def test_percept_mse_objective_variant(golden):
     assert bstep == int(np.argmin(losses))
 
 
-def test_psnr_objective_variant(golden):
-    """1024_example_PSNR.py:113-114,158,173-175: the loss is 10 log10(255^2 / mean((img - target)^2)) of the [-1, 1] images and the loop keeps
-    the SMALLEST value -- every recorded loss against the script's numpy expression on the oracle's image, best step = argmin."""
+@pytest.mark.parametrize("layout", ["script", "aligned"])
+def test_psnr_objective_variant(golden, layout):
+    """1024_example_PSNR.py:113-114,150-158,173-175: the loss is 10 log10(255^2 / mean((p0 - p1)^2)) of the [-1, 1] images and the loop keeps
+    the SMALLEST value -- every recorded loss against the script's numpy pipeline on the oracle's image (`psnr_script_ref`: the permute /
+    tensor2np / flatten steps transcribed, which pair the candidate's C-H-W stream with the target's H-W-C stream; the default) or against
+    the aligned definition (`psnr_layout="aligned"`, a declared deviation), best step = argmin; and a re-targeted engine follows suit."""
     from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
     from morphganformer_amd.synth_weights import TINY, make_state_dict
     from oracle.generator_ref import generator_ref, to_torch_state
-    from oracle.loss_ref import psnr_ref
+    from oracle.loss_ref import psnr_ref as psnr_aligned, psnr_script_ref
+    psnr_ref = (lambda img, tgt: psnr_script_ref(img, tgt)) if layout == "script" else psnr_aligned
     g = golden("loop_tiny.npz")
     steps = 7
     tsd = to_torch_state(make_state_dict(TINY, seed=0))
-    eng = ProjectionEngine(_tiny_gen(), torch.from_numpy(g["target"]).cuda(), torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]),
-                           ProjectionArgs(step=steps, pixel_term="psnr"), percept=None, use_mse=True, eps=torch.from_numpy(g["eps"][:steps]).cuda(),
-                           noise_mode="const", batch=3)
+    assert ProjectionArgs().psnr_layout == "script"
+    eng = ProjectionEngine(_tiny_gen(), torch.from_numpy(g["target"]).cuda() * 0.5, torch.from_numpy(g["latent_mean"]).cuda(), float(g["latent_std"]),
+                           ProjectionArgs(step=steps, pixel_term="psnr", psnr_layout=layout), percept=None, use_mse=True,
+                           eps=torch.from_numpy(g["eps"][:steps]).cuda(), noise_mode="const", batch=3)
+    eng.run()
+    eng.retarget(torch.from_numpy(g["target"]).cuda(), eps=torch.from_numpy(g["eps"][:steps]).cuda())
     lat, bstep, bloss, losses = eng.run().result()
     want = []
     for i in range(steps):
@@ -471,6 +478,8 @@ def test_psnr_objective_variant(golden):
     want = np.array(want)
     assert np.abs(losses - want).max() < 1e-3 * np.abs(want).max(), (losses, want)
     assert bstep == int(np.argmin(losses)) and bloss == float(losses.min()) and 20 < want.min() < 100
+    if layout == "script":          # the two layouts are different numbers on any image that is not constant across channels and positions
+        assert abs(float(psnr_aligned(g["target"] * 0.5, g["target"])) - float(psnr_script_ref(g["target"] * 0.5, g["target"]))) > 1e-3
 
 
 def test_dssim_kernel_vs_oracle_and_full_size():

@@ -323,6 +323,22 @@ def test_bench_self_launches_n_ranks():
     assert not re.search(r"^(import|from) (torch|numpy)", head, re.M)
 
 
+def test_bench_refuses_more_ranks_than_visible_gpus():
+    """`bench.py --gpus N` with N above the number of visible devices exits non-zero with a message BEFORE anything is launched or any
+    GPU is touched -- as the launcher parent and as a rank the driver's own torch.distributed.run started (which would otherwise sit in
+    the rendezvous or fail inside set_device)."""
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"--gpus 8 but 0 GPU(s) are visible" in r.stderr and not r.stdout.strip(), r.stderr.decode()[-2000:]
+    assert b"self-launch" not in r.stderr                                   # nothing was started
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1",
+                                                                                                MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"GPU(s) are visible" in r.stderr, r.stderr.decode()[-2000:]
+
+
 # ----------------------------------------------------------------------------------------------------------------- callers
 def _tiny_snapshot(path, seed=3):
     from morphganformer_amd import loader

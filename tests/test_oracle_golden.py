@@ -173,6 +173,31 @@ def test_generator_ref_full_vs_reference(golden):
         assert abs(float(t.mean()) - m) < 1e-5 * r and abs(float(t.square().mean().sqrt()) - r) < 1e-5 * r
 
 
+def _att_decided(g, key, slot):
+    F = g["argmax_" + key].shape[1]
+    return np.unpackbits(g["decided_" + key][slot])[:F].astype(bool)
+
+
+@pytest.mark.slow
+def test_attention_assignments_full_vs_reference(golden):
+    """SURVEY 8d's integer gate at FULL size for the restatement: the per-pixel argmax latent assignment of all 11 attention layers of
+    the 1024^2 model (networks.py:505-524,776-792) against the reference module's own (att_full1024.npz: forward hooks on its
+    TransformerLayers), exact wherever the reference's top-2 margin exceeds 1e-4, and 256 sampled probability rows per layer."""
+    g = golden("att_full1024.npz")
+    sd = to_torch_state(make_state_dict(FULL1024, 0))
+    assert len(g["layers"]) == 11
+    for slot in range(2):
+        taps = {}
+        with torch.no_grad():
+            generator_ref(sd, torch.from_numpy(g["z"][slot:slot + 1]), FULL1024, "const", taps=taps)
+        for key in g["layers"]:
+            p = taps[f"synthesis.{key}:probs"].reshape(-1, FULL1024.k - 1).numpy()
+            dec = _att_decided(g, key, slot)
+            assert dec.mean() > 0.99, key
+            assert np.array_equal(p.argmax(-1)[dec], g["argmax_" + key][slot][dec]), key
+            assert np.abs(p[g["rows_" + key]] - g["probs_" + key][slot]).max() < 1e-5, key
+
+
 def test_morph_ref_vs_reference(golden):
     """BASELINE config 4's rendering half: the oracle generator on the 11 blended latents the reference rendered."""
     g = golden("morph_tiny.npz")
@@ -225,6 +250,22 @@ def test_generator_ref_gradient_full_vs_reference(golden):
     (gz,) = torch.autograd.grad(loss, z)
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * float(g["loss"])
     assert rel(gz, g["grad_z"]) < 1e-4
+
+
+def test_psnr_script_pipeline_known_answer_by_hand():
+    """1024_example_PSNR.py:150-158 transcribed (oracle.loss_ref.psnr_script_ref): the candidate reaches `psnr` in C-H-W order, the target in
+    H-W-C order.  x = arange(12) as [1,3,2,2] against ITSELF: the aligned PSNR is infinite (MSE 0); the script pairs the streams
+    [0..11] and [0,4,8,1,5,9,2,6,10,3,7,11]: squared differences 0+9+36+4+1+16+16+1+4+36+9+0 = 132, mean 11 -> 10 log10(255^2 / 11)."""
+    x = torch.arange(12, dtype=torch.float32).reshape(1, 3, 2, 2)
+    got = float(loss_ref.psnr_script_ref(x, x))
+    assert abs(got - 10 * math.log10(65025.0 / 11.0)) < 1e-5, got
+    with np.errstate(divide="ignore"):
+        assert np.isinf(loss_ref.psnr_ref(x.numpy(), x.numpy()))
+    # the same pairing expressed as one permuted copy of the target (what the engine does): aligned PSNR against the H-W-C stream re-read as C-H-W
+    t = torch.randn(1, 3, 5, 4)
+    y = torch.randn(1, 3, 5, 4)
+    t_script = t.permute(0, 2, 3, 1).contiguous().view(t.shape)
+    assert abs(float(loss_ref.psnr_script_ref(y, t)) - float(loss_ref.psnr_ref(y.numpy(), t_script.numpy()))) < 1e-5
 
 
 def test_winograd_f2x2_3x3_identity():

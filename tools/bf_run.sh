@@ -1,3 +1,6 @@
+#!/bin/bash
+# float32 / bf16x3 / bf16x3 with the direct kernel up to 512^2: three bench.py passes on one box -> gpurun_out/r5i
+mkdir -p gpurun_out/r5i
 X="--bf16x3-leg 0 --no-cpu-baseline --gradient-steps 0 --targets 0 --objectives 0 --landmark-callback none --config4 0 --config5-targets 0"
 python bench.py $X > gpurun_out/r5i/f32.json 2>gpurun_out/r5i/f32.err
 python bench.py $X --arith bf16x3 > gpurun_out/r5i/bf.json 2>gpurun_out/r5i/bf.err

@@ -11,15 +11,3 @@ run skip_s64     MGF_GRAD_SKIP_STREAM=64
 B=16 STEPS=12 run b16_no_fir MGF_FUSE_ACT_FIR=0
 B=16 STEPS=12 run b16_defaults MGF_DUMMY=0
 B=16 STEPS=12 run b16_skip256 MGF_GRAD_SKIP_STREAM=256
-python - <<'PY' 2>>$D/err.log | head -40 > $D/dot_head.txt
-import torch, tempfile, os
-g = torch.cuda.CUDAGraph(); g.enable_debug_mode()
-x = torch.zeros(1024, device="cuda")
-s = torch.cuda.Stream()
-with torch.cuda.stream(s):
-    x.add_(1); torch.cuda.synchronize()
-with torch.cuda.graph(g):
-    x.add_(1); x.mul_(2)
-g.debug_dump("/tmp/g.dot")
-print(open("/tmp/g.dot").read()[:3000])
-PY
