@@ -3,7 +3,7 @@ up-sampled in the epilogue) and conv_last + ToRGB -- for ablation builds (tools/
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from morphganformer_amd import _lib, conv as cv
-n, res, c = 25, 1024, 32
+n, res, c = int(os.environ.get("MGF_N", "32")), 1024, 32
 x = torch.randn(n, c, res, res, device="cuda")
 w = torch.randn(c, c, 3, 3, device="cuda") / (3 * c ** 0.5)
 s, d = torch.rand(n, c, device="cuda") + 0.5, torch.rand(n, c, device="cuda") + 0.5
