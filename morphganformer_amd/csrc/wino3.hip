@@ -873,6 +873,52 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vout[k]), ry, voff, ((k & 3) + 8 * (k >> 2)) * plane * 4, 0);
     };
 
+    // ToRGB variant (round 6): the projection behind the row exchange is cut into NCK parts, part c riding in chunk body c of the NEXT tile
+    // between that body's MFMAs (its slot reads and their waits pass under matrix work of the same wave); only the row reduction and its
+    // barrier stay at the tile's end, the last tile's parts run after the loop.  Measured on one box (tools/w3_top_micro.py, 32 x 1024^2):
+    // 3034 / 3021 us against 3159 for the epilogue in one piece (-4 %).  The same split of the OTHER variant's epilogue (skip interpolation,
+    // noise / bias / activation, 16 stores; operands double-buffered by tile parity) is correct and measures 1 - 2 % SLOWER (4035 / 3383
+    // against 3967 / 3350 us with / without the fused skip): that stream's 200 vector instructions cost the same issue time wherever they
+    // stand (profiles/r6_w3p_ablation.txt), and the compiler's interleaving puts LDS waits between the MFMAs.  Not adopted there.
+    float own_d[NV];
+    float rgb_b[3] = {0.f, 0.f, 0.f};
+    if (RGB && p.rgb_bias)
+        for (int cc = 0; cc < p.rgb_channels; ++cc) rgb_b[cc] = p.rgb_bias[cc];
+    unsigned ep_voff = OOB;                                        // output offset of the tile whose parts are pending (out of range: none yet)
+    float ep_sum[3] = {0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rrgb = __builtin_amdgcn_make_buffer_rsrc((void*)(RGB ? p.rgb_out + (int64_t)n * p.rgb_channels * plane : p.y), 0,
+                                                                          RGB ? p.rgb_channels * plane * 4 : 0, 0x00020000);
+    auto tile_reduce_rgb = [&](int t) {
+        const int ox0 = ox_s + tdx * t, oy0 = oy_s + tdy * t;
+        switch (a) {
+            case 0: row_reduce(std::integral_constant<int, 0>{}, own_d); break;
+            case 1: row_reduce(std::integral_constant<int, 1>{}, own_d); break;
+            case 2: row_reduce(std::integral_constant<int, 2>{}, own_d); break;
+            default: row_reduce(std::integral_constant<int, 3>{}, own_d); break;
+        }
+        const int oy = oy0 + 2 * ty + orow, ox = ox0 + 2 * tx + blk;
+        ep_voff = (oy < p.h && ox < p.w) ? (unsigned)(oy * p.w + ox) * 4u : OOB;
+        __syncthreads();                                           // the exchange slots are complete
+    };
+    auto ep_part_rgb = [&](const int k) {                          // k is a constant after unrolling; branch-free (see the call site)
+        if (k == 0) { ep_sum[0] = 0.f; ep_sum[1] = 0.f; ep_sum[2] = 0.f; }
+#pragma unroll
+        for (int v = 2 * k; v < 2 * k + 2; ++v) {
+            const float yv = pa[v * 64] + sgn * (own_d[v] + pb[v * 64]);
+            const int cl = 4 * half + (v & 3) + 8 * (v >> 2);
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) ep_sum[cc] += yv * lowt[cc * 32 + cl];
+        }
+        if (k == NR - 1) {
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) ep_sum[cc] += __shfl_xor(ep_sum[cc], 32, 64);
+            const unsigned so = half == 0 ? ep_voff : OOB;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)          // (a plane past rgb_channels lies beyond the resource's records: the store is dropped)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ep_sum[cc] + rgb_b[cc]), rrgb, so, cc * plane * 4, 0);
+        }
+    };
+
     // ---- prologue: chunks 0 and 1 of tile 0 are parked, chunks 2 .. 1 + XD wait in the register ring ----
     // The ring is what keeps memory busy: a workgroup's chunk is 3.2 KB, and with one chunk in flight per workgroup (two workgroups per
     // CU) the whole chip has 1.6 MB outstanding -- 0.8 TB/s at 2 us of loaded latency, less than the layer reads.  XD chunks deep, a
@@ -921,15 +967,25 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[c][b].x, B[c & 1][0][b], c == 0 ? f32x16{} : acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[c][b].y, B[c & 1][1][b], acc[b], 0, 0, 0);
             }
+            // ToRGB: the previous tile's projection, part c.  Unconditional -- in the strip's first tile the parts run on whatever the
+            // registers hold and store through the out-of-range offset ep_voff starts with: a branch here would make the compiler merge its
+            // vmcnt bookkeeping over both paths and drain the prefetch ring in every body
+            if constexpr (RGB) ep_part_rgb(c);
             __builtin_amdgcn_sched_barrier(0);
             park_x((c & 1) ? raw1 : raw0, xq[c % XD]);                       // chunk c + 2, requested XD bodies ago
             load_ahead(xq[c % XD], c + 2 + XD);
             __syncthreads();
         }
-        epilogue(t);
+        if constexpr (RGB) tile_reduce_rgb(t); else epilogue(t);
         voff_cur = voff_nxt;
         voff_nxt = voff_n2;
         voff_n2 = tile_voff(t + 3);
+    }
+    if constexpr (RGB) {                                           // the last tile's parts (nothing left to hide them under)
+        if (ntiles > 0) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) ep_part_rgb(k);
+        }
     }
 }
 
