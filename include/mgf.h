@@ -425,6 +425,11 @@ int mgf_maxpool3x3s2_ceil_f32(float* y, const float* x, int32_t nc, int32_t in_h
  */
 int mgf_latent_perturb(float* latent_n, const float* latent_in, const float* eps, const float* sigma, const int32_t* step,
                        int32_t batch, int32_t steps_total, int64_t numel, mgf_stream_t stream);
+/* projection_example_v2_percept.py:131-166: `copies` noisy copies of the latent per step, averaged before the generator sees them --
+ * latent_n[j, i] = torch.mean over c of (latent_in[i] + eps[s, c, i] * sigma[s]), s = *step + j, eps [steps, copies, numel]; the sum in
+ * torch's CPU order (blocks of 16 rows, then the tail; 1 <= copies <= 255) so that the kept latent equals the script's bit for bit. */
+int mgf_latent_perturb_mean(float* latent_n, const float* latent_in, const float* eps, const float* sigma, const int32_t* step,
+                            int32_t batch, int32_t steps_total, int64_t numel, int32_t copies, mgf_stream_t stream);
 int mgf_select_best(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out,
                     const float* latent_n, int64_t numel, const float* p_loss, const double* w_loss, const float* mse_loss,
                     double lamda, float beta, int32_t* step, const int32_t* valid, int32_t batch, int32_t steps_total,

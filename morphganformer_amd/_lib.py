@@ -127,6 +127,7 @@ _SIGS = {
     "mgf_maxpool_s2_floor_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "mgf_maxpool3x3s2_ceil_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "mgf_latent_perturb": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp]),
+    "mgf_latent_perturb_mean": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, i32, vp]),
     "mgf_select_best": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp, vp, f64, f32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp]),
     "mgf_keep_improvements": (C.c_int, [vp, vp, i64, vp, i32, vp]),
     "mgf_to_uint8_hwc": (C.c_int, [vp, vp, i32, i32, i32, vp]),

@@ -48,6 +48,10 @@ def _loop_arguments(p):
     p.add_argument("--psnr-layout", choices=["script", "aligned"], default="script",
                    help="script = 1024_example_PSNR.py:150-158 as written: the candidate's C-H-W stream against the target's H-W-C stream (different pixels "
                         "are paired); aligned = the PSNR of corresponding pixels (a deviation from the script)")
+    p.add_argument("--latent-copies", type=int, default=1,
+                   help="projection_example_v2_percept.py:131-166: this many noisy copies of the latent per step, averaged (torch.mean order) before the "
+                        "generator (18 there, with --min-loss-init 1.0 --net vgg --no-mse --pool-above 256); literal mode")
+    p.add_argument("--min-loss-init", type=float, default=100.0, help="the loop's starting min_loss (100 in the 1024 drivers, 1.0 in the v2 drivers)")
     p.add_argument("--pool-above", type=int, default=0,
                    help="projection_example_v1.py:150-155: block-average generated images taller than this (256 there) by height // N before the "
                         "image-space losses; the target image is then transformed to that size")
@@ -212,7 +216,8 @@ def main(argv=None):
     from .lpips import PerceptualLoss
     args = ProjectionArgs(step=a.step, lamda=a.lamda, beta=a.beta, lr=a.lr, lr_rampup=a.lr_rampup, lr_rampdown=a.lr_rampdown,
                           noise=a.noise, noise_ramp=a.noise_ramp, truncation_psi=a.truncation_psi, n_mean_latent=a.n_mean_latent,
-                          ratio=a.ratio, percept_weight=a.percept_weight, pixel_term=a.pixel_term, psnr_layout=a.psnr_layout, pool_above=a.pool_above)
+                          ratio=a.ratio, percept_weight=a.percept_weight, pixel_term=a.pixel_term, psnr_layout=a.psnr_layout, pool_above=a.pool_above,
+                          latent_copies=a.latent_copies, min_loss_init=a.min_loss_init)
     percept = None
     if not a.no_lpips:
         if a.lpips_backbone is None and not a.lpips_random_backbone:

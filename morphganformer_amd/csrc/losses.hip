@@ -300,6 +300,35 @@ __global__ __launch_bounds__(256) void perturb_kernel(float* latent_n, const flo
     }
 }
 
+// projection_example_v2_percept.py:131-166: the optimised latent is [1, copies = 18, k D], every copy gets its own noise, and the generator
+// sees `torch.mean(latent_n, 1)`.  The mean must come out bit for bit (the kept latent IS that mean): torch's CPU sum over an outer dimension
+// (SumKernel.cpp, cascade_sum / multi_row_sum) adds the rows in blocks of 16 -- each block sequentially from zero, the block sums sequentially
+// into a second accumulator -- adds the remaining rows sequentially from zero, then tail + blocks; the mean divides by the count.  Same
+// order here, every step of it a separate float32 rounding (no fma: the products are two roundings like torch's `randn_like(..) * strength`).
+__global__ __launch_bounds__(256) void perturb_mean_kernel(float* latent_n, const float* latent_in, const float* eps, const float* sigma,
+                                                           const int32_t* step, int batch, int steps_total, int64_t numel, int copies) {
+    const int64_t total = (int64_t)batch * numel;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int j = (int)(idx / numel);
+        const int64_t i = idx - (int64_t)j * numel;
+        int s = *step + j;
+        if (s > steps_total - 1) s = steps_total - 1;
+        const float sg = sigma[s], base = latent_in[i];
+        const float* e = eps + ((int64_t)s * copies) * numel + i;
+        float blocks = 0.f, run = 0.f;
+        for (int c = 0; c < copies; ++c) {
+            float prod = e[(int64_t)c * numel] * sg;
+            asm volatile("" : "+v"(prod));                 // opaque to the fma combiner
+            float v = base + prod;
+            asm volatile("" : "+v"(v));
+            run = run + v;
+            asm volatile("" : "+v"(run));
+            if ((c & 15) == 15) { blocks = blocks + run; asm volatile("" : "+v"(blocks)); run = 0.f; }
+        }
+        latent_n[idx] = (run + blocks) / (float)copies;
+    }
+}
+
 // candidates j = 0 .. batch-1 are examined in step order, exactly as the sequential loop would
 __global__ __launch_bounds__(256) void select_kernel(double* min_loss, float* best_latent, int32_t* best_step, double* losses_out,
                                                      const float* latent_n, int64_t numel, const float* p_loss, const double* w_loss,
@@ -729,6 +758,17 @@ extern "C" int mgf_latent_perturb(float* latent_n, const float* latent_in, const
     hipLaunchKernelGGL(perturb_kernel, dim3((unsigned)mgf_cdiv(numel * batch, 256)), dim3(256), 0, (hipStream_t)stream, latent_n, latent_in,
                        eps, sigma, step, batch, steps_total, numel);
     MGF_CHECK_LAUNCH("latent_perturb");
+    return MGF_OK;
+}
+
+extern "C" int mgf_latent_perturb_mean(float* latent_n, const float* latent_in, const float* eps, const float* sigma, const int32_t* step,
+                                       int32_t batch, int32_t steps_total, int64_t numel, int32_t copies, mgf_stream_t stream) {
+    MGF_REQUIRE(latent_n && latent_in && eps && sigma && step && numel >= 1 && batch >= 1 && steps_total >= 1, MGF_EINVAL,
+                "latent_perturb_mean: bad arguments");
+    MGF_REQUIRE(copies >= 1 && copies <= 255, MGF_EUNSUPPORTED, "latent_perturb_mean: 1 .. 255 copies (torch's two-level summation order; got %d)", copies);
+    hipLaunchKernelGGL(perturb_mean_kernel, dim3((unsigned)mgf_cdiv(numel * batch, 256)), dim3(256), 0, (hipStream_t)stream, latent_n, latent_in,
+                       eps, sigma, step, batch, steps_total, numel, copies);
+    MGF_CHECK_LAUNCH("latent_perturb_mean");
     return MGF_OK;
 }
 

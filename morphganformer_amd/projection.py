@@ -65,6 +65,10 @@ class ProjectionArgs:
     # ProjectionEngine(lbp_target=lbp.target_feature(file pixels))
     pixel_term: str = "mse"
     psnr_layout: str = "script"
+    # projection_example_v2_percept.py:131-166: the optimised latent holds `latent_copies` (18 there) copies of the start latent, every copy
+    # receives its own noise each step and the generator sees their mean (`torch.mean(latent_n, 1)`, reproduced in torch's summation order:
+    # the kept latent -- that mean -- is bit-exact); 1 = the other drivers' single latent.  Literal mode; eps is then [steps, 1, copies, k, D]
+    latent_copies: int = 1
     # projection_example_v1.py:150-155: a generated image taller than `pool_above` pixels is block-averaged by height // pool_above before
     # the image-space losses (the target is then given at the pooled size, :84-92 resize it to 256); 0 = off (the 1024 drivers)
     pool_above: int = 0
@@ -196,12 +200,20 @@ class ProjectionEngine:
         self.latent_in = _as_latent(latent_mean, ls).reshape(1, *ls).contiguous().float()
         sig = noise_schedule(a.step, float(latent_std), a.noise, a.noise_ramp)
         self.sigma = torch.as_tensor(sig, device=dev)
+        self.copies = int(a.latent_copies)
+        if not 1 <= self.copies <= 255:
+            raise ValueError(f"latent_copies must be 1 .. 255 (got {a.latent_copies})")
+        if self.copies > 1 and self.numel % 32:
+            # (torch reduces a width's last numel % 32 columns on another path with another summation order: the bit-exact mean is only
+            # claimed for widths it reduces four vector registers at a time -- k D = 17 x 32 = 544 is one)
+            raise ValueError(f"latent_copies > 1 needs a latent of a multiple of 32 elements (got {self.numel})")
         if eps is None:
             gen = torch.Generator(device=dev)
             gen.manual_seed(seed)
-            eps = torch.randn(a.step, 1, *ls, device=dev, generator=gen)
+            eps = torch.randn(a.step, 1, *(((self.copies,) if self.copies > 1 else ()) + ls), device=dev, generator=gen)
         self.eps = eps.to(dev).contiguous().float()
-        assert self.eps.shape[0] >= a.step and self.eps[0].numel() == self.numel
+        assert self.eps.shape[0] >= a.step and self.eps[0].numel() == self.numel * self.copies, \
+            f"eps must be [steps, 1{', copies' if self.copies > 1 else ''}, *latent shape] (got {tuple(self.eps.shape)})"
         assert wing_kind in ("wing", "awing")
         self.wing_kind = wing_kind
         self.landmark_fn = landmark_fn
@@ -334,8 +346,12 @@ class ProjectionEngine:
 
     def _gen_phase(self, latent_n, ctr):
         L, st, a, B = _lib.lib(), _lib.stream_ptr(), self.args, self.batch
-        _lib.check(L.mgf_latent_perturb(latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(),
-                                        self.sigma.data_ptr(), ctr.data_ptr(), B, self.steps, self.numel, st), "latent_perturb")
+        if self.copies > 1:       # the v2 driver's averaged copies (projection_example_v2_percept.py:147-159)
+            _lib.check(L.mgf_latent_perturb_mean(latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(), self.sigma.data_ptr(),
+                                                 ctr.data_ptr(), B, self.steps, self.numel, self.copies, st), "latent_perturb_mean")
+        else:
+            _lib.check(L.mgf_latent_perturb(latent_n.data_ptr(), self.latent_in.data_ptr(), self.eps.data_ptr(),
+                                            self.sigma.data_ptr(), ctr.data_ptr(), B, self.steps, self.numel, st), "latent_perturb")
         # psi lands in `c`.  lean: the literal loop has no backward pass -- layer outputs share arenas block after block
         return self.G.forward_workspace(latent_n, a.truncation_psi, noise_mode=self.noise_mode, lean=True)[0]
 
@@ -768,6 +784,9 @@ class GradientProjectionEngine(ProjectionEngine):
             assert landmark_fn is None and landmark_model is None, "landmark detectors are wired for one target per engine"
         self.targets = B
         a, dev = self.args, self.device
+        if a.latent_copies != 1:
+            raise _lib.MgfError("GradientProjectionEngine: latent_copies is the literal-mode v2 driver's averaged latent (projection_example_v2_percept.py); "
+                                "gradient mode optimises one latent")
         if a.pixel_term != "mse" or a.pool_above:
             raise _lib.MgfError("GradientProjectionEngine: pixel_term='psnr' / 'dssim' / 'lbp' / pool_above are literal-mode objectives (the PSNR / v1 drivers "
                                 "sever the gradient like every other driver; only the Wing / LPIPS / MSE / biometric terms have backward passes)")

@@ -385,22 +385,53 @@ def lpips_ref(bb, lins, img0, img1, per_layer=False, net="squeeze"):
 # --------------------------------------------------------------------------------------------
 # Projection loop, literal semantics
 
+def mean_rows_torch_order_ref(rows):
+    """`torch.mean(x, 1)` of a float32 [copies, m] block as torch's CPU kernel forms it (SumKernel.cpp: cascade_sum -> multi_row_sum for an
+    outer reduction): rows in blocks of 16, each block summed sequentially from zero, the block sums summed sequentially, the remaining
+    rows summed sequentially from zero, tail + blocks, then divided by the count -- every step one float32 rounding.  Restated in numpy so
+    that the device kernel's order (mgf_latent_perturb_mean) can be held against it AND it against torch itself (1 <= copies <= 255).
+    Holds for the columns torch reduces four vector registers at a time, i.e. all of them when m is a multiple of 32 (k D = 544 is;
+    checked on this container's AVX-512 build); the remainder columns of other widths take another path (row_sum's four interleaved
+    partial sums) that the product does not need and refuses (ProjectionEngine: numel % 32)."""
+    import numpy as np
+    x = np.asarray(rows, dtype=np.float32)
+    n = x.shape[0]
+    assert 1 <= n <= 255
+    blocks = np.zeros(x.shape[1:], np.float32)
+    run = np.zeros(x.shape[1:], np.float32)
+    for c in range(n):
+        run = (run + x[c]).astype(np.float32)
+        if (c & 15) == 15:
+            blocks = (blocks + run).astype(np.float32)
+            run = np.zeros(x.shape[1:], np.float32)
+    return ((run + blocks).astype(np.float32) / np.float32(n)).astype(np.float32)
+
+
 def projection_literal_ref(gen_fn, loss_fn, latent_mean, latent_std, eps_stream, steps,
-                           noise=0.05, noise_ramp=0.75, min_loss_init=100.0, total_steps=None):
+                           noise=0.05, noise_ramp=0.75, min_loss_init=100.0, total_steps=None, copies=1):
     """Best-of-N noisy sampling around latent_mean.
 
     gen_fn(latent [1,k,D]) -> image; loss_fn(step, image) -> python float or None (= 'no face', step skipped);
     eps_stream[i] is the injected randn_like draw of step i.  Returns (best_latent, best_step, best_loss, losses).
     `total_steps` (default = steps) is args.step of the schedule when only a prefix of the run is evaluated.
+    copies > 1: projection_example_v2_percept.py:131-166 -- `latent_in` is the flattened start latent repeated `copies` times
+    ([1, copies, k D], :133-140), eps_stream[i] is [1, copies, k, D], and the generator sees (and the loop keeps, :193) `torch.mean(latent_n, 1)`
+    reshaped to [1, k, D] (:157-158).
     """
     total_steps = total_steps or steps
     latent_in = latent_mean[None].clone()
+    if copies > 1:
+        latent_in = latent_mean.reshape(1, -1).unsqueeze(1).repeat(1, copies, 1)
     best, best_step, min_loss = None, -1, float(min_loss_init)
     losses = []
     for i in range(steps):
         t = i / total_steps
         sigma = float(noise_strength_ref(t, float(latent_std), noise, noise_ramp))
-        latent_n = latent_in + eps_stream[i] * sigma
+        if copies > 1:
+            latent_c = latent_in + eps_stream[i].reshape(1, copies, -1) * sigma
+            latent_n = torch.mean(latent_c, 1).reshape([1, *latent_mean.shape])
+        else:
+            latent_n = latent_in + eps_stream[i] * sigma
         img = gen_fn(latent_n)
         val = loss_fn(i, img)
         losses.append(val)

@@ -239,6 +239,46 @@ def gold_loop_tiny(ref, G):
                         latents_n=np.stack(latents_n))
 
 
+def gold_loop_copies_tiny(ref, G):
+    """projection_example_v2_percept.py:131-203 on the tiny generator: the latent as 18 noisy copies averaged by torch.mean before the
+    generator (the script's own tensor statements, :133-140,154-159, on its [1, 18, k D] layout), min_loss starting at 1.0 (:146), best
+    latent = that mean (:193).  The script scores LPIPS(vgg) alone; the fixture scores 0.01 x the pixel MSE against a near target so that it needs
+    no backbone -- what it pins is the copies' arithmetic, the averaged latents of every step and the selection."""
+    from morphganformer_amd.synth_weights import TINY, synthetic_latents
+    steps, n_latent = 24, 18
+    rng = np.random.Generator(np.random.PCG64(1818))
+    numel = TINY.k * TINY.z_dim
+    samples = torch.from_numpy(rng.standard_normal((1000, numel)).astype(np.float32))
+    latent_mean = samples.mean(0)                                                       # [k D]: the script flattens the latent (:244-249)
+    latent_std = ((samples - latent_mean).pow(2).sum() / samples.shape[0]) ** 0.5
+    # (a target near the start latent: the script's min_loss starts at 1.0, far below the pixel MSE of an unrelated image)
+    z_t = latent_mean.reshape(1, TINY.k, TINY.z_dim) + torch.from_numpy(rng.standard_normal((1, TINY.k, TINY.z_dim)).astype(np.float32)) * 0.1
+    target = G(z_t, None, noise_mode="const")[0].clamp(-1, 1)
+    eps = rng.standard_normal((steps, 1, n_latent, numel)).astype(np.float32)
+    mse = torch.nn.MSELoss()
+    latent_in = latent_mean.detach().clone().unsqueeze(0).repeat(1, 1)                  # :133
+    latent_in = latent_in.unsqueeze(1).repeat(1, n_latent, 1)                           # :140
+    min_loss, best, best_step = 1.0, None, -1
+    losses = np.zeros(steps, np.float64)
+    ims = []
+    for i in range(steps):
+        t = i / steps
+        noise_strength = latent_std * 0.05 * max(0, 1 - t / 0.75) ** 2
+        latent_n = latent_in + torch.from_numpy(eps[i]) * noise_strength.item()         # latent_noise, :70-72 with the draw injected
+        im_latent = torch.mean(latent_n, 1)
+        im_latent = im_latent.reshape([1, TINY.k, TINY.z_dim])
+        ims.append(im_latent.numpy().copy())
+        img = G(im_latent, 0.7, noise_mode="const")[0]
+        total = 0.01 * mse(img, target)          # (a coefficient like the drivers' beta: the tiny generator's images are not in [-1, 1] at this latent)
+        losses[i] = float(total)
+        if float(total) < min_loss:
+            min_loss, best, best_step = float(total), im_latent.clone(), i
+    assert best_step >= 0
+    np.savez_compressed(os.path.join(OUT, "loop_copies_tiny.npz"), latent_mean=latent_mean.numpy(), latent_std=np.float32(latent_std.item()),
+                        target=target.numpy(), eps=eps, losses=losses, best_latent=best.numpy(), best_step=np.int64(best_step),
+                        best_loss=np.float64(min_loss), im_latents=np.stack(ims), copies=np.int64(n_latent))
+
+
 def _attention_layer_names(cfg):
     """The synthesis layers that carry a TransformerLayer, in execution order (conv0 before conv1 inside a block)."""
     names = []
@@ -611,6 +651,9 @@ def main():
             gold_loop_tiny(ref, build_reference_generator(ref, TINY, make_state_dict(TINY, seed=0)))
         if "att" in only:
             gold_att_tiny(ref)
+        if "copies" in only:
+            from morphganformer_amd.synth_weights import TINY, make_state_dict
+            gold_loop_copies_tiny(ref, build_reference_generator(ref, TINY, make_state_dict(TINY, seed=0)))
         if "wplus" in only:
             gold_wplus_tiny(ref)
         if "gradfull" in only:
@@ -630,6 +673,7 @@ def main():
     gold_lin_heads()
     G, _ = gold_generator_tiny(ref)
     gold_loop_tiny(ref, G)
+    gold_loop_copies_tiny(ref, G)
     gold_morph_tiny(ref, G)
     gold_att_tiny(ref)
     gold_wplus_tiny(ref)

@@ -216,7 +216,7 @@ def test_loop_no_face_and_never_improves(golden):
     lat, bstep, bloss, losses = eng.run().result()
     want = 3 if g["losses"][3] <= g["losses"][7] else 7
     assert bstep == want and np.isnan(losses[0]) and not np.isnan(losses[3])
-    # min_loss_init below every loss -> the reference raises IndexError (latent_path[-1] on an empty list, :208)
+    # min_loss_init below every loss -> the reference raises IndexError (latent_path[-1] on an empty list, :224)
     eng = _engine_from_golden(g, False)
     eng.min_loss.fill_(1e-9)
     with pytest.raises(IndexError):
@@ -445,6 +445,44 @@ def test_percept_mse_objective_variant(golden):
         want = 0.5 * float(P(img, tgt)) + 0.5 * float(torch.nn.functional.mse_loss(img, tgt))
         assert abs(losses[i] - want) < 1e-5 * abs(want), (i, losses[i], want)
     assert bstep == int(np.argmin(losses))
+
+
+@pytest.mark.parametrize("batch", [1, 5])
+def test_latent_copies_variant_vs_reference_run(golden, batch):
+    """projection_example_v2_percept.py:131-203 (`ProjectionArgs(latent_copies=18)`): 18 noisy copies of the latent per step, averaged like
+    torch.mean before the generator; min_loss starts at 1.0 and the kept latent is the mean.  Against the run of the script's tensor
+    statements on the reference generator (loop_copies_tiny.npz): every step's averaged latent BIT-exact (the kernel alone), best step
+    exact, best latent bit-exact, losses 1e-3; and the kernel's summation order against torch.mean for other copy counts."""
+    from morphganformer_amd import _lib
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine
+    g = golden("loop_copies_tiny.npz")
+    steps, copies = g["eps"].shape[0], int(g["copies"])
+    lm = torch.from_numpy(g["latent_mean"]).reshape(17, 32)
+    eng = ProjectionEngine(_tiny_gen(), torch.from_numpy(g["target"]).cuda(), lm.cuda(), float(g["latent_std"]),
+                           ProjectionArgs(step=steps, beta=0.01, min_loss_init=1.0, latent_copies=copies), percept=None, use_mse=True,
+                           eps=torch.from_numpy(g["eps"]).cuda(), noise_mode="const", batch=batch)
+    lat, bstep, bloss, losses = eng.run().result()
+    assert bstep == int(g["best_step"]) and torch.equal(lat, torch.from_numpy(g["best_latent"]))
+    assert np.abs(losses - g["losses"]).max() < 1e-3 * np.abs(g["losses"]).max() and abs(bloss - float(g["best_loss"])) < 1e-3 * float(g["best_loss"])
+    # the kernel on its own, all steps in one call
+    out = torch.empty(steps, 17 * 32, device="cuda")
+    ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().mgf_latent_perturb_mean(out.data_ptr(), eng.latent_in.data_ptr(), eng.eps.data_ptr(), eng.sigma.data_ptr(), ctr.data_ptr(),
+                                                  steps, steps, 17 * 32, copies, _lib.stream_ptr()), "latent_perturb_mean")
+    assert np.array_equal(out.cpu().numpy().reshape(steps, 1, 17, 32), g["im_latents"])
+    rng = np.random.Generator(np.random.PCG64(11))
+    for n in (1, 2, 15, 16, 17, 31, 32, 33, 100, 255):
+        e = torch.from_numpy(rng.standard_normal((3, n, 224)).astype(np.float32))
+        base = torch.from_numpy(rng.standard_normal(224).astype(np.float32))
+        sig = torch.tensor([0.5, 1.25, 0.0], dtype=torch.float32)
+        want = torch.stack([torch.mean((base[None, None] + e[s][None] * float(sig[s])), 1)[0] for s in range(3)])
+        got = torch.empty(3, 224, device="cuda")
+        base_d, e_d, sig_d = base.cuda(), e.cuda(), sig.cuda()             # (named: a temporary's memory would be recycled by the next .cuda())
+        _lib.check(_lib.lib().mgf_latent_perturb_mean(got.data_ptr(), base_d.data_ptr(), e_d.data_ptr(), sig_d.data_ptr(), ctr.data_ptr(),
+                                                      3, 3, 224, n, _lib.stream_ptr()), "latent_perturb_mean")
+        assert torch.equal(got.cpu(), want), n
+    with pytest.raises(_lib.MgfError):
+        _lib.check(_lib.lib().mgf_latent_perturb_mean(got.data_ptr(), got.data_ptr(), got.data_ptr(), got.data_ptr(), ctr.data_ptr(), 1, 1, 8, 256, _lib.stream_ptr()))
 
 
 @pytest.mark.parametrize("layout", ["script", "aligned"])

@@ -268,6 +268,33 @@ def test_psnr_script_pipeline_known_answer_by_hand():
     assert abs(float(loss_ref.psnr_script_ref(y, t)) - float(loss_ref.psnr_ref(y.numpy(), t_script.numpy()))) < 1e-5
 
 
+def test_latent_copies_loop_vs_reference_run(golden):
+    """projection_example_v2_percept.py:131-203 (18 noisy copies of the latent averaged by torch.mean, min_loss from 1.0): the restated loop
+    against the run of the script's own tensor statements on the reference generator (loop_copies_tiny.npz) -- every step's averaged latent
+    bit for bit, every loss, the selection; and the numpy restatement of torch's summation order against torch.mean itself for 1..40 and
+    255 rows (the order the device kernel follows)."""
+    g = golden("loop_copies_tiny.npz")
+    sd = to_torch_state(make_state_dict(TINY, 0))
+    steps, copies = g["eps"].shape[0], int(g["copies"])
+    target = torch.from_numpy(g["target"])
+    seen = []
+
+    def gen(z):
+        seen.append(z.numpy().copy())
+        with torch.no_grad():
+            return generator_ref(sd, z, TINY, "const")
+    lat, bstep, bloss, losses = loss_ref.projection_literal_ref(
+        gen, lambda i, img: float(0.01 * loss_ref.mse_ref(img, target)), torch.from_numpy(g["latent_mean"]).reshape(TINY.k, TINY.z_dim),
+        float(g["latent_std"]), torch.from_numpy(g["eps"]), steps, min_loss_init=1.0, copies=copies)
+    assert np.array_equal(np.stack(seen), g["im_latents"])
+    assert bstep == int(g["best_step"]) and np.array_equal(lat.numpy(), g["best_latent"])
+    assert rel(np.array(losses), g["losses"]) < 1e-5
+    rng = np.random.Generator(np.random.PCG64(7))
+    for n in list(range(1, 41)) + [255]:
+        x = (rng.standard_normal((n, 96)) * 3 + 0.7).astype(np.float32)      # (a multiple of the vector width: see mean_rows_torch_order_ref)
+        assert np.array_equal(loss_ref.mean_rows_torch_order_ref(x), torch.mean(torch.from_numpy(x)[None], 1)[0].numpy()), n
+
+
 def test_winograd_f2x2_3x3_identity():
     """The transform matrices csrc/wino.hip hard-codes (Lavin & Gray F(2x2,3x3)): A^T [(G g G^T) . (B^T d B)] A equals the 3x3
     correlation of a 4x4 patch, in float64, for random data -- pins the algebra the HIP kernels implement."""
