@@ -201,6 +201,13 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
     // MGF_ACT_RELU_POST: the ReLU comes AFTER the residual add, y = relu((acc + bias) * gain + residual) -- the residual blocks of
     // InceptionResnetV1 (`out = relu(conv(cat) * scale + x)`); its own instantiation, so the other launches keep their instruction count
     const bool post_relu = do_ep && p.ep.act == MGF_ACT_RELU_POST;
+    // 16-byte accesses on rows that are NOT a multiple of four pixels long (FaceNet's 125^2 maps, SqueezeNet's 255^2 / 127^2 / 63^2; round 6):
+    // the rows then start at 4-byte alignment only -- a raw buffer access takes that at full width -- and the vector over a row's END would
+    // spill into the next channel's row.  Harmless for the loads of x (those accumulator columns are never stored); for the stores and the
+    // residual loads the row's LAST pixel tile (wave-uniform) goes through a resource that ends at the row's end, one lane half at a time
+    // (the halves write different rows): the range check of a 16-byte access is per dword on this part (tools/probes/buffer_b128_unaligned.hip:
+    // the in-range dwords are read / written, the others return 0 / are dropped), so the ragged vector needs no element path.
+    const bool rag = VEC && (p.hw & 3) != 0 && p0 + 128 > p.hw;
     auto store_rows = [&](auto res_tag, auto post_tag) {
         constexpr bool RES = decltype(res_tag)::value;
         constexpr bool POST = decltype(post_tag)::value;
@@ -223,7 +230,26 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
                     asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(t), "v"(ts));      // (as an instruction: `fmaxf` adds canonicalising v_max x, x)
                     v[j] = m * gain;
                 }
-                if (VEC) {
+                if (VEC && rag) {
+                    const int px = p0 + 4 * l31;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int row = cor + 4 * h;                               // (wave-uniform)
+                        const bool row_in = row < p.cout;
+                        const __amdgpu_buffer_rsrc_t ryh = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + ybase + (int64_t)(row_in ? row : 0) * p.hw), 0,
+                                                                                             row_in ? p.hw * 4 : 0, 0x00020000);
+                        const unsigned off = (half == h && px < p.hw) ? (unsigned)px * 4u : 0xFFFFFFF0u;
+                        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                        if (RES) {
+                            const __amdgpu_buffer_rsrc_t rrh = __builtin_amdgcn_make_buffer_rsrc((void*)(resp + (int64_t)(row_in ? row : 0) * p.hw), 0,
+                                                                                                 row_in ? p.hw * 4 : 0, 0x00020000);
+                            const float4 q = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrh, off, 0, 0));
+                            o = make_float4(v[0] + q.x, v[1] + q.y, v[2] + q.z, v[3] + q.w);
+                            if (POST) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), ryh, off, 0, 0);
+                    }
+                } else if (VEC) {
                     float4 o = make_float4(v[0], v[1], v[2], v[3]);
                     if (RES) {
                         const float4 q = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrr, pvo[0] | lane_ok, soff, 0));
@@ -408,9 +434,13 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
     p.y_batch = y_batch ? y_batch : (int64_t)cout * hw; p.y_choff = y_choff;
     p.has_ep = ep != nullptr;
     if (ep) { p.ep = *ep; if (p.ep.act == 0) p.ep.act = MGF_ACT_LINEAR; } else { p.ep = mgf_epilogue{}; p.ep.gain = 1.f; p.ep.act = MGF_ACT_LINEAR; }
-    // 16-byte accesses: every row of x, y and the residual starts 16-byte aligned
+    // 16-byte accesses.  The streaming kernels for <= 4 channels on one side (plain pointers) want every row of x, y and the residual
+    // 16-byte aligned; the GEMM kernel's raw buffer accesses take any 4-byte alignment and any row length (see `rag` in the kernel), so it
+    // always runs its vector form -- MGF_PW_VEC=0 (tuning hook) brings the element form back for A/B runs
     const bool vec = hw % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (p.y_batch % 4) == 0 &&
                      (!ep || !ep->residual || ((uintptr_t)ep->residual % 16) == 0);
+    static const bool gemm_vec_off = [] { const char* e = mgf_knob("MGF_PW_VEC"); return e && e[0] == '0'; }();
+    const bool gemm_vec = vec || !gemm_vec_off;
     static const bool narrow_off = [] { const char* e = mgf_knob("MGF_PW_NARROW"); return e && e[0] == '0'; }();
     if (cout <= 4 && !narrow_off && n <= 65535) {
         hipStream_t st = (hipStream_t)stream;
@@ -464,11 +494,11 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
     mgf_prof_external_begin(st, splitk ? "pw_conv_kernel<1, 1, 4>" : names[cb - 1][wco == 4 ? 2 : wco - 1], 2.0 * cin * (double)cout * hw * n,
                             4.0 * ((double)n * cin * hw + (double)cin * cout + (double)n * cout * hw * ((ep && ep->residual) ? 2 : 1)));
     const dim3 grid((unsigned)blocks);
-    if (splitk) pw_launch<1, 1, 4>(p, vec, grid, st);
+    if (splitk) pw_launch<1, 1, 4>(p, gemm_vec, grid, st);
     else if (cb == 2) {
-        if (wco == 4) pw_launch<2, 4>(p, vec, grid, st); else if (wco == 2) pw_launch<2, 2>(p, vec, grid, st); else pw_launch<2, 1>(p, vec, grid, st);
+        if (wco == 4) pw_launch<2, 4>(p, gemm_vec, grid, st); else if (wco == 2) pw_launch<2, 2>(p, gemm_vec, grid, st); else pw_launch<2, 1>(p, gemm_vec, grid, st);
     } else {
-        if (wco == 4) pw_launch<1, 4>(p, vec, grid, st); else if (wco == 2) pw_launch<1, 2>(p, vec, grid, st); else pw_launch<1, 1>(p, vec, grid, st);
+        if (wco == 4) pw_launch<1, 4>(p, gemm_vec, grid, st); else if (wco == 2) pw_launch<1, 2>(p, gemm_vec, grid, st); else pw_launch<1, 1>(p, gemm_vec, grid, st);
     }
     mgf_prof_external_end(st);
     MGF_CHECK_LAUNCH("conv1x1");
