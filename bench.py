@@ -611,7 +611,7 @@ def pmc_tables(tag=""):
     utilisation per kernel.  Counters cannot be read from inside the process (rocprofv3 --pmc is a separate run, and gpurun forbids
     mixing it with tracing), so bench.py reports the figures of the committed passes and says which file they come from."""
     out = {"traffic": None, "mfma": None}
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):                  # `tag` selects the passes of another workload ("vgg_": the LPIPS(vgg) loop)
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):                  # `tag` selects the passes of another workload ("vgg_": the LPIPS(vgg) loop)
         path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}pmc_traffic.json")
         if out["traffic"] is None and os.path.exists(path):
             with open(path) as fh:
