@@ -876,6 +876,7 @@ def visible_gpus():
 def main():
     a = parse()
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (before anything can bring the HSA runtime up: RCCL needs dmabuf IPC on this pool)
     if not a.selftest_launch:
         have = visible_gpus()
         if a.gpus < 1 or a.gpus > have:
