@@ -254,13 +254,26 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         if (cc < p.rgb_channels)
             wv_pre = p.rgb_w[((int64_t)n * p.rgb_channels + cc) * p.cout + co0 + co] * (p.out_scale ? p.out_scale[(int64_t)n * p.os_stride + co0 + co] : 1.f);
     }
+    // The two-block shapes (128 accumulators, TWO workgroups per CU: two waves per SIMD to cover a load's latency, and registers to spare)
+    // request their operands one chunk EARLIER (round 6): weights two chunks ahead in a ring of three operand sets, the footprint two bodies
+    // ahead in a ring of two -- 2516-2528 -> 2400-2413 us for the 256-channel 128^2 layer at 32 samples (tools/w3_layers_micro.py).  The
+    // one-block shape sits at exactly 128 registers for its four workgroups per CU: the same ring there spills (2640 -> 2960-2990 us) or, compiled
+    // for three workgroups, loses more residency than it gains distance (2640 -> 2690-2720 at 64^2, 3400 -> 3540-3570 at 512^2).
+    constexpr bool DEEP = NB == 2;
+    v2f A2[4][CB];
+    float xr1[XS], sv1[W3CK];
     {
         float xa[XS], xb[XS], sa_[W3CK], sb_[W3CK];
         load_s(sv, chunk0(2));
         load_x(xa, 0);
         load_a(A0, 0);
         load_x(xb, chunk0(1));
+        if constexpr (DEEP) load_a(A1, chunk0(1), 1 < nchunks);
         load_x(xr, chunk0(2));
+        if constexpr (DEEP) {
+            load_x(xr1, chunk0(3), 3 < nchunks);
+            load_s(sv1, chunk0(3));
+        }
         load_s(sa_, 0);
         load_s(sb_, chunk0(1));
         park_x(raw0, xa, sa_);
@@ -289,11 +302,37 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         load_s(sv, chunk0(i + 3));                   // (requested here, a whole chunk before their use: scalar loads share the LDS counter)
         __syncthreads();
     };
-    body(0, A0, A1, B0, B1, raw1, raw0, std::true_type{});
-    if (1 < nchunks) body(1, A1, A0, B1, B0, raw0, raw1, std::false_type{});
-    for (int it = 2; it < nchunks; it += 2) {
-        body(it, A0, A1, B0, B1, raw1, raw0, std::false_type{});
-        if (it + 1 < nchunks) body(it + 1, A1, A0, B1, B0, raw0, raw1, std::false_type{});
+    // body2(i): the same with the deeper rings -- request A(i+2) into the set chunk i-1 used; park x(i+2) from ring slot i % 2, request x(i+4) into it
+    auto body2 = [&](int i, v2f (&Acur)[4][CB], v2f (&Afar)[4][CB], float (&Bcur)[TB][2][4], float (&Bnxt)[TB][2][4], float* raw_nxt, float* raw_park,
+                     float (&xq)[XS], float (&sq)[W3CK], auto first_tag) {
+        load_a(Afar, chunk0(i + 2), i + 2 < nchunks);
+        __builtin_amdgcn_sched_barrier(0);
+        transform(Bnxt, raw_nxt);
+        mfma_chunk(Acur, Bcur, first_tag);
+        __builtin_amdgcn_sched_barrier(0);
+        park_x(raw_park, xq, sq);
+        load_x(xq, chunk0(i + 4), i + 4 < nchunks);
+        load_s(sq, chunk0(i + 4));
+        __syncthreads();
+    };
+    if constexpr (DEEP) {
+        body2(0, A0, A2, B0, B1, raw1, raw0, xr, sv, std::true_type{});
+        if (1 < nchunks) body2(1, A1, A0, B1, B0, raw0, raw1, xr1, sv1, std::false_type{});
+        for (int it = 2; it < nchunks; it += 6) {        // (operand set = chunk % 3, B / staging buffer = chunk % 2: the pattern repeats every six)
+            body2(it, A2, A1, B0, B1, raw1, raw0, xr, sv, std::false_type{});
+            if (it + 1 < nchunks) body2(it + 1, A0, A2, B1, B0, raw0, raw1, xr1, sv1, std::false_type{});
+            if (it + 2 < nchunks) body2(it + 2, A1, A0, B0, B1, raw1, raw0, xr, sv, std::false_type{});
+            if (it + 3 < nchunks) body2(it + 3, A2, A1, B1, B0, raw0, raw1, xr1, sv1, std::false_type{});
+            if (it + 4 < nchunks) body2(it + 4, A0, A2, B0, B1, raw1, raw0, xr, sv, std::false_type{});
+            if (it + 5 < nchunks) body2(it + 5, A1, A0, B1, B0, raw0, raw1, xr1, sv1, std::false_type{});
+        }
+    } else {
+        body(0, A0, A1, B0, B1, raw1, raw0, std::true_type{});
+        if (1 < nchunks) body(1, A1, A0, B1, B0, raw0, raw1, std::false_type{});
+        for (int it = 2; it < nchunks; it += 2) {
+            body(it, A0, A1, B0, B1, raw1, raw0, std::false_type{});
+            if (it + 1 < nchunks) body(it + 1, A1, A0, B1, B0, raw0, raw1, std::false_type{});
+        }
     }
 
     // ---- output transform.  R[j] = row a of M times A: R0 = M0 + M1 + M2, R1 = M1 - M2 - M3 per accumulator register; then over the
