@@ -1077,8 +1077,13 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     // conv1 at 25 samples: 1969 vs 2097 us; at 64^2 x 512 its 6400 workgroups lose to 12800 of the small shape, 2151 vs 1998 us)
     // (round 3, 32 samples: 64^2 x 512 -- 8192 workgroups of the wide shape -- 2653 vs 2502 us for the small one; 128^2 x 256 -- 16384 -- 2485 vs
     // 2665: the wide shape needs ~ 12 800 workgroups, 25 rounds of the 512 the chip holds, before its smaller instruction count per MFMA wins)
+    // (round 6: with its operands requested one chunk earlier -- the DEEP rings of the kernel -- the wide shape wins from ONE round of the chip's 512
+    // two-per-CU slots on: tools/w3_shape_ab.py, us for shapes 21 / 11 at 512 channels 64^2: 296-306 / 322 at 4 samples (1024 workgroups), 588-591 /
+    // 618-631 at 8, 1161-1172 / 1222-1231 at 16, 2253-2266 / 2423-2509 at 32; 32^2: 149 / 164 at 8 (512 workgroups), 286-295 / 309-315 at 16, 610-664 /
+    // 657-777 at 32, but 107 / 99 at 4 (256 workgroups); 256 channels 128^2: 85 / 94 at one sample (512 workgroups) .. 2394-2432 / 2573-2583 at 32.
+    // The threshold was 12 800 workgroups for the kernel that requested them one chunk ahead.)
     if (!forced && !rgb && !res_low && !odd && y_choff == 0 && cout % 64 == 0 && cin >= 256 &&
-        (int64_t)n * mgf_cdiv(w, 32) * mgf_cdiv(h, 4) * (cout / 64) >= 12800) shape = 21;
+        (int64_t)n * mgf_cdiv(w, 32) * mgf_cdiv(h, 4) * (cout / 64) >= 512) shape = 21;
     if (forced == 21 && cout % 64 == 0 && !rgb) shape = 21;
     if (forced == 12 || forced == 11) shape = forced;
     const bool force_persist = forced == 31;
