@@ -696,34 +696,80 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvParams p) {
         decode(wbase + slot, cur);
         int b = 0;
         StageSet S0;
-        for (;;) {
-            // first chunk of this tile: global -> registers -> LDS (latency covered by the co-resident workgroup and by the
-            // previous tile's stores, which are still draining)
-            if (AR) { setup_slots_b(cur); load_chunk_b(S0, cur.c_begin); store_chunk_b(S0, lds + b * buf_floats); }
-            else { setup_slots(cur); load_chunk(cur.c_begin); store_chunk(lds + b * buf_floats); }
+        constexpr bool XTILE = !AR && WN <= 2;       // (the three- and four-group shapes have no registers left for it: they spill)
+        if (XTILE) {
+            // Round 6: ONE chunk stream across the tile boundaries.  During a tile's LAST chunk -- where the staging registers used to idle --
+            // the NEXT tile's first chunk is requested (its slot set-up included) and, behind the MFMAs, stored into the free staging buffer
+            // like any other chunk, so the epilogue runs with no staging register live and the next tile starts on data that is already in
+            // LDS (a tile used to start cold: slot set-up, one HBM round trip, an LDS store and a barrier with nothing to do); the loop over
+            // a tile's other chunks has no condition left.  Same-box A/B at 32 samples (tools/conv_micro.py, us, before / after): transposed
+            // convs 1384-1391 / 1365-1389, 2464-2474 / 2431, 2476-2480 / 2446-2449, 2598-2613 / 2579, 2998-3002 / 3003-3028 (32^2 .. 512^2
+            // input); 3x3 at 32^2 1183-1192 / 1178-1179 -- 1 - 1.5 % on the middle layers, nothing on the last: the other resident workgroup
+            // had covered most of the cold start.  (Held across the epilogue instead of stored in front of it, the prefetched chunk spilled:
+            // +5 %; with the tile switch as a branch inside one chunk loop the whole loop lost 10 %.)
+            setup_slots(cur);
+            load_chunk(cur.c_begin);
+            store_chunk(lds + b * buf_floats);
             __syncthreads();
-            const int nch = (cur.c_end - cur.c_begin) / CKK;
-            for (int c = 0; c < nch; ++c) {
-                float* curb = lds + b * buf_floats;
-                float* nxtb = lds + (b ^ 1) * buf_floats;
-                const bool more = c + 1 < nch;
-                if (AR) {
-                    if (more) load_chunk_b(S0, cur.c_begin + (c + 1) * CKK);
-                    mfma_chunk_b(curb);
-                    if (more) store_chunk_b(S0, nxtb);
-                } else {
-                    if (more) load_chunk(cur.c_begin + (c + 1) * CK);             // in flight behind the MFMAs below
-                    mfma_chunk(curb);
-                    if (more) store_chunk(nxtb);
+            for (;;) {
+                const int nch = (cur.c_end - cur.c_begin) / CKK;
+                const int nslot = slot + slot_step;
+                const bool have_next = nslot < slot_end;
+                // every chunk but the last: the next chunk of this tile in flight behind the MFMAs -- no condition left in this loop
+                for (int c = 0; c + 1 < nch; ++c) {
+                    load_chunk(cur.c_begin + (c + 1) * CK);
+                    mfma_chunk(lds + b * buf_floats);
+                    store_chunk(lds + (b ^ 1) * buf_floats);
+                    __syncthreads();
+                    b ^= 1;
                 }
+                // the last chunk: the next tile's first chunk behind it
+                if (have_next) {
+                    TileCtx nx;                                                      // (decoded here and again behind the epilogue: nothing of it lives across either)
+                    decode(wbase + nslot, nx);
+                    setup_slots(nx);
+                    load_chunk(nx.c_begin);
+                }
+                mfma_chunk(lds + b * buf_floats);
+                if (have_next) store_chunk(lds + (b ^ 1) * buf_floats);
                 __syncthreads();
                 b ^= 1;
+                epilogue(cur);                                                 // stores drain behind the next tile's work
+                zero_acc();
+                if (!have_next) break;
+                slot = nslot;
+                decode(wbase + slot, cur);
             }
-            epilogue(cur);                                                     // stores drain behind the next tile's work
-            zero_acc();
-            slot += slot_step;
-            if (slot >= slot_end) break;
-            decode(wbase + slot, cur);
+        } else {
+            for (;;) {
+                // first chunk of this tile: global -> registers -> LDS (latency covered by the co-resident workgroup and by the
+                // previous tile's stores, which are still draining)
+                if (AR) { setup_slots_b(cur); load_chunk_b(S0, cur.c_begin); store_chunk_b(S0, lds + b * buf_floats); }
+                else { setup_slots(cur); load_chunk(cur.c_begin); store_chunk(lds + b * buf_floats); }
+                __syncthreads();
+                const int nch = (cur.c_end - cur.c_begin) / CKK;
+                for (int c = 0; c < nch; ++c) {
+                    float* curb = lds + b * buf_floats;
+                    float* nxtb = lds + (b ^ 1) * buf_floats;
+                    const bool more = c + 1 < nch;
+                    if (AR) {
+                        if (more) load_chunk_b(S0, cur.c_begin + (c + 1) * CKK);
+                        mfma_chunk_b(curb);
+                        if (more) store_chunk_b(S0, nxtb);
+                    } else {
+                        if (more) load_chunk(cur.c_begin + (c + 1) * CK);
+                        mfma_chunk(curb);
+                        if (more) store_chunk(nxtb);
+                    }
+                    __syncthreads();
+                    b ^= 1;
+                }
+                epilogue(cur);
+                zero_acc();
+                slot += slot_step;
+                if (slot >= slot_end) break;
+                decode(wbase + slot, cur);
+            }
         }
     } else {
         const int w = p.xcd_per > 0 ? (int)(blockIdx.x & 7) * p.xcd_per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
