@@ -55,6 +55,7 @@ struct Wino3Params {
     int64_t y_batch;          // elements between samples of y (y may be a channel slice of a wider concat buffer; residual likewise)
     int y_choff;              // channel offset into y
     int odd;                  // h or w odd: pixel pairs are stored / loaded element-wise with bounds checks
+    int low_pieces;           // the half-resolution residual's rows are whole 16-byte pieces (one-shot kernel: three 16-byte DMAs per lane instead of nine 4-byte ones)
     int strip_len, strips_x;  // persistent form (wino3p_conv_kernel): tiles per workgroup, strips per tile row
     int vert, strips_y;       // ... vert: a strip walks DOWN a 32-pixel column (strips_x = tile columns, strips_y = strips per column)
 };
@@ -216,23 +217,43 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
     // lanes write zeros.  These are the oldest loads in flight, so the first ordinary wait below retires them too.
     constexpr int UMODE = NB == 2 ? 0 : (RGB ? 2 : 1);
     constexpr int NV = UMODE == 0 ? 32 : 16;         // values per lane and exchange slot
-    float* const lowt = lds + 6 * NV * 64;           // [32 channels][4 rows][18 columns] half-resolution residual window (2304 floats)
-    float* const nzs = lowt + (p.res_low ? 2304 : 0);    // [4 rows][64]: noise of the tile's rows (32 px used)
+    // half-resolution residual window of the tile's 32 channels: as 16-byte pieces [32][4 rows][24 columns] -- low-resolution columns
+    // (ox0 >> 1) - 4 .. + 19, the 18 the tile needs are columns 3 .. 20 of them; 768 pieces, three 16-byte DMAs per lane (round 6; the nine 4-byte
+    // requests per lane before were 5 % of the 512^2 layer, profiles/r6_w3_oneshot_ablation.txt) -- where the low map's rows are whole pieces
+    // (width a multiple of 4, 16-byte aligned base: a piece is then entirely inside the map or entirely outside), else element-wise [32][4][18]
+    float* const lowt = lds + 6 * NV * 64;
+    const bool low_pieces = p.low_pieces != 0;                     // (uniform; decided by the host: low map width a multiple of 4, 16-byte aligned base)
+    const int low_ch = low_pieces ? 96 : 72, low_row = low_pieces ? 24 : 18, low_col = low_pieces ? 3 : 0;
+    float* const nzs = lowt + (p.res_low ? 3072 : 0);    // [4 rows][64]: noise of the tile's rows (32 px used)
     float* const obs = nzs + 256;                    // [2][64]: out_scale, bias of the 32 channels
     const bool pre_ep = UMODE == 1 && !p.odd;        // (uniform)
     if (pre_ep) {
         if (p.res_low) {
             const int hl = p.h >> 1, wl = p.w >> 1, pl = hl * wl;
             const __amdgpu_buffer_rsrc_t rlow = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res_low + ((int64_t)n * p.cout + co0) * pl), 0, 32 * pl * 4, 0x00020000);
-            const int m0 = (oy0 >> 1) - 1, n0 = (ox0 >> 1) - 1;
+            const int m0 = (oy0 >> 1) - 1;
+            if (low_pieces) {
+                const int n0 = (ox0 >> 1) - 4;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const int e = tid + 256 * j;
-                const int ch = e / 72, rem = e - ch * 72;
-                const int r = rem / 18, c = rem - r * 18;
-                const int my = m0 + r, nx = n0 + c;
-                const unsigned off = (my >= 0 && my < hl && nx >= 0 && nx < wl) ? (unsigned)(ch * pl + my * wl + nx) * 4u : 0xFFFFFFF0u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rlow, lowt + 256 * j + 64 * a, 4, off, 0, 0, 0);
+                for (int j = 0; j < 3; ++j) {
+                    const int e = tid + 256 * j;                         // piece: channel e / 24, row (e % 24) / 6, columns 4 c .. 4 c + 3
+                    const int ch = e / 24, rem = e - ch * 24;
+                    const int r = rem / 6, c = rem - r * 6;
+                    const int my = m0 + r, nx = n0 + 4 * c;
+                    const unsigned off = (my >= 0 && my < hl && nx >= 0 && nx < wl) ? (unsigned)(ch * pl + my * wl + nx) * 4u : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rlow, lowt + 4 * (256 * j + 64 * a), 16, off, 0, 0, 0);
+                }
+            } else {
+                const int n0 = (ox0 >> 1) - 1;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const int e = tid + 256 * j;
+                    const int ch = e / 72, rem = e - ch * 72;
+                    const int r = rem / 18, c = rem - r * 18;
+                    const int my = m0 + r, nx = n0 + c;
+                    const unsigned off = (my >= 0 && my < hl && nx >= 0 && nx < wl) ? (unsigned)(ch * pl + my * wl + nx) * 4u : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rlow, lowt + 256 * j + 64 * a, 4, off, 0, 0, 0);
+                }
             }
         }
         if (p.has_ep && p.ep.noise) {                // wave a: row a of the tile, lanes 0..31 its 32 pixels
@@ -499,9 +520,10 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
         const int chl = cob - co0;
 #pragma unroll
         for (int k = 0; k < NR; k += 2) {
-            const float* lp = lowt + (chl + (k & 3) + 8 * (k >> 2)) * 72 + (trow + orow) * 18 + tx;
-            const v2f a0 = {lp[0], lp[72]}, a1 = {lp[1], lp[73]}, a2 = {lp[2], lp[74]};
-            const v2f b0 = {lp[18], lp[90]}, b1 = {lp[19], lp[91]}, b2 = {lp[20], lp[92]};
+            const float* lp = lowt + (chl + (k & 3) + 8 * (k >> 2)) * low_ch + (trow + orow) * low_row + tx + low_col;
+            const float* lq = lp + low_ch;                        // the neighbouring channel
+            const v2f a0 = {lp[0], lq[0]}, a1 = {lp[1], lq[1]}, a2 = {lp[2], lq[2]};
+            const v2f b0 = {lp[low_row], lq[low_row]}, b1 = {lp[low_row + 1], lq[low_row + 1]}, b2 = {lp[low_row + 2], lq[low_row + 2]};
             const v2f c0 = wa2 * a0 + wb2 * b0, c1 = wa2 * a1 + wb2 * b1, c2 = wa2 * a2 + wb2 * b2;
             const v2f rx2 = q25 * c0 + q75 * c1, ry2 = q75 * c1 + q25 * c2;
             rr[k].x = rx2.x; rr[k + 1].x = rx2.y;
@@ -1098,6 +1120,8 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     p.res_low = res_low;
     p.y_batch = y_batch ? y_batch : (int64_t)cout * h * w; p.y_choff = y_choff; p.odd = odd;
     p.strip_len = 0; p.strips_x = 0; p.vert = 0; p.strips_y = 0;
+    static const bool pieces_off = [] { const char* e = mgf_knob("MGF_W3_LOW_PIECES"); return e && e[0] == '0'; }();   // tuning hook (A/B runs)
+    p.low_pieces = (res_low && !pieces_off && ((w >> 1) & 3) == 0 && ((uintptr_t)res_low & 15) == 0) ? 1 : 0;
     if (res_low) {
         MGF_REQUIRE(ep && !ep->residual && !rgb, MGF_EINVAL, "conv3x3_winograd3_up2res: needs an epilogue without a full-resolution residual");
         MGF_REQUIRE(shape == 11, MGF_EUNSUPPORTED, "conv3x3_winograd3_up2res: only the 32x32-tile shape takes the half-resolution residual");
@@ -1161,7 +1185,7 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     const size_t nv = cb * tb == 2 ? 32 : 16;
     static const size_t lds_pad = [] { const char* e = mgf_knob("MGF_W3_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();   // tuning: fewer workgroups per CU
     const size_t lds = std::max<size_t>((size_t)(2 * 256 * (tb == 2 ? 8 : 4)) * sizeof(float),
-                                        (size_t)(6 * nv * 64 + (res_low ? 2304 : 0) + 256 + 128) * sizeof(float)) + lds_pad;
+                                        (size_t)(6 * nv * 64 + (res_low ? 3072 : 0) + 256 + 128) * sizeof(float)) + lds_pad;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)wino3_conv_kernel<2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);

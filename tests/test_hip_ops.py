@@ -617,7 +617,7 @@ def test_winograd_odd_maps_and_channel_slices(n, cin, cout, h, w, ctotal, choff,
     assert bool((out[:, mask.cuda()] == 7.0).all())
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 32, 32, 64, 64), (1, 16, 64, 20, 36), (3, 8, 96, 8, 2)])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 32, 32, 64, 64), (1, 16, 64, 20, 36), (3, 8, 96, 8, 2), (2, 16, 32, 12, 40), (1, 8, 32, 6, 104)])
 def test_winograd3_half_resolution_residual(n, cin, cout, h, w):
     """Form 3 with the resnet skip branch given at half resolution: the epilogue's in-place 2x up-sampling ([1,3,3,1] filter, padding
     [2,1,2,1], gain 4) against the reference-pinned upfirdn2d oracle, and against the two-launch path (FIR pass + full-size residual)."""
