@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256, (CB * TB == 2 ? 2 : W3_OCC1)) void wino3_conv_
                 float t = (pa[(2 * k + q) * 64] + sgn * (own[2 * k + q] + pb[(2 * k + q) * 64])) * osv[k];
                 t += nzq[q];
                 t += do_ep ? bvv[k] : 0.f;
-                t = t > 0.f ? t : t * slope;
+                { float ts = t * slope, m; asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(t), "v"(ts)); t = m; }   // slope in [0, 1] (host-checked): leaky / plain ReLU / identity = max(t, slope t); as an instruction: `fmaxf` adds a canonicalising v_max x, x
                 t = t * gain + (q ? rr[k].y : rr[k].x);
                 v[q] = t;
             }
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(256, 2) void wino3p_conv_kernel(Wino3Params p) {
                 float tt = (pa[(2 * k + q) * 64] + sgn * (own[2 * k + q] + pb[(2 * k + q) * 64])) * osv[k];
                 tt += q ? nz1 : nz0;
                 tt += bvv[k];
-                tt = tt > 0.f ? tt : tt * slope;
+                { float ts = tt * slope, m; asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(tt), "v"(ts)); tt = m; }   // (slope in [0, 1]: max(t, slope t), one instruction instead of compare + select)
                 tt = tt * gain + (q ? rr[k].y : rr[k].x);
                 v[q] = tt;
             }
@@ -1081,6 +1081,8 @@ static int launch_wino3(float* y, const float* x, const float* u, const float* i
     if (ep) {
         MGF_REQUIRE(ep->act == 0 || ep->act == MGF_ACT_LINEAR || ep->act == MGF_ACT_LRELU || ep->act == MGF_ACT_RELU, MGF_EUNSUPPORTED,
                     "conv3x3_winograd3: epilogue activation %d unsupported", ep->act);
+        MGF_REQUIRE(ep->act != MGF_ACT_LRELU || (ep->alpha >= 0.f && ep->alpha <= 1.f), MGF_EUNSUPPORTED,
+                    "conv3x3_winograd3: leaky-ReLU slope %g outside [0, 1] (the epilogue forms max(t, slope t))", (double)ep->alpha);
         MGF_REQUIRE(odd || !ep->residual || ((uintptr_t)ep->residual % 8) == 0, MGF_EINVAL, "conv3x3_winograd3: the residual must be 8-byte aligned");
         MGF_REQUIRE(odd || !ep->noise || ((uintptr_t)ep->noise % 8) == 0, MGF_EINVAL, "conv3x3_winograd3: the noise map must be 8-byte aligned");
     }
