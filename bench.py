@@ -844,7 +844,7 @@ def launch_selftest(a):
         from morphganformer_amd.distributed import pack_result, run_sharded, unpack_results
 
         def work(i):
-            time.sleep(0.002 * (1 + i % 3) * (1 + rank % 2))
+            time.sleep(0.01 * (1 + i % 3) * (1 + 2 * (rank % 2)))       # (odd ranks three times slower: far outside scheduling jitter on a loaded host)
             return pack_result(th.full([1, 2, 3], float(i)), 0.5 * i, i, item=i)
 
         def run_many(n):
