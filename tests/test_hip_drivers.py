@@ -410,6 +410,30 @@ def test_project_many_under_an_rccl_process_group_of_one_rank(golden):
     assert not dist.is_initialized()
 
 
+def test_bench_force_dist_runs_the_rccl_path():
+    """`bench.py --force-dist` in a CHILD process (never an exec from this one): the N > 1 code path of the benchmark with one rank -- the TCPStore
+    hand-over through distributed.init_process_group("nccl", device_id=...), the warm-up all_gather, the barriers around the timed region, the
+    per-rank time gather and the timed result gather (`gather_results` on device tensors), destroy -- and the JSON line says so (`rccl_ranks` 1,
+    `ranks.gather_ms` measured).  What the driver's scaling run exercises first, minus the other ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--gradient-steps", "0",
+           "--targets", "0", "--objectives", "0", "--landmark-callback", "none", "--config4", "0", "--config5-targets", "0", "--bf16x3-leg", "0"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]                      # RCCL's banner went to stderr: stdout carries exactly the JSON line
+    d = json.loads(lines[0])
+    assert d["rccl_ranks"] == 1 and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["ranks"]["gather_ms"] is not None and len(d["ranks"]["per_rank_iters_per_s"]) == 1
+    assert d["roofline"]["frac"] > 0.3
+
+
 def test_device_landmark_model_in_the_graph(golden):
     """GPU landmark-regressor interface: a device callable produces the landmarks of every candidate inside the captured launch
     sequence; the run equals the one driven by the table it produced (batch 3 over 8 steps: ragged last batch)."""
