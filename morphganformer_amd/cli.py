@@ -121,6 +121,9 @@ def build_parser():
     m.add_argument("--gpus", type=str, default="0")
     m.add_argument("--ratio", type=float, default=1.0)
     m.add_argument("--truncation_psi", type=float, default=0.7)
+    mf = sub.add_parser("merge-files", help="Fold a results tree <src>/<version>/<variant>/<id>/<name>/ over its variants (1024_merge_files.py); no model, no GPU")
+    mf.add_argument("--src", type=str, required=True)
+    mf.add_argument("--dst", type=str, required=True)
     t = sub.add_parser("morph-tree", help="Morph every latent pair of every id folder (the directory walk of 1024_merge_morph_2.py)")
     t.add_argument("--model", type=str, required=True)
     t.add_argument("--src", type=str, required=True, help="<src>/<id>/<name>/*.mat: two name folders per id")
@@ -176,6 +179,11 @@ def _extract_facenet(a):
 
 def main(argv=None):
     a = build_parser().parse_args(argv)
+    if a.cmd == "merge-files":                              # file bookkeeping only (1024_merge_files.py): no generator, no GPU
+        from . import drivers
+        files = drivers.merge_files(a.src, a.dst)
+        print(f"copied {len(files)} files")
+        return 0
     launched = int(os.environ.get("WORLD_SIZE", "1")) > 1 and "LOCAL_RANK" in os.environ
     # read by the HSA runtime when it starts, i.e. at the first GPU call (loader.load_network below): set here, before torch is imported,
     # like bench.py does -- the host driver only supports dmabuf IPC, RCCL fails without it

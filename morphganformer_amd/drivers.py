@@ -177,6 +177,33 @@ def merge_morph_tree(G, src_path, dst_path, truncation_psi=0.7, ratio=1.0, noise
     return done
 
 
+def merge_files(src_path, dst_path):
+    """1024_merge_files.py:20-45, the step in front of the morph walk above ("combine all bonafides from different results"): a results tree
+    `src_path/<version>/<variant>/<id>/<name>/<file>` is folded over its variants into `dst_path/<version>/<id>/<name>/<file>` -- the per-image
+    folders of every variant of a version land side by side under one id; entries of an id folder that carry a dot are skipped (:36), files
+    are copied with `shutil.copy` (a later variant's file of the same name overwrites an earlier one, as in the script, which walks
+    `os.listdir` order; here sorted, so the result does not depend on the file system).  Host-side file bookkeeping: no tensor is touched.
+    Returns the list of destination files."""
+    import shutil
+    out = []
+    for version in sorted(os.listdir(src_path)):
+        v_dir = os.path.join(src_path, version)
+        if not os.path.isdir(v_dir):
+            continue
+        os.makedirs(os.path.join(dst_path, version), exist_ok=True)          # (:23-25: made even when the version holds no variant)
+        for variant in sorted(os.listdir(v_dir)):
+            for ident in sorted(os.listdir(os.path.join(v_dir, variant))):
+                id_dir = os.path.join(v_dir, variant, ident)
+                for name in sorted(os.listdir(id_dir)):
+                    if len(name.split(".")) > 1:
+                        continue
+                    dst_fold = os.path.join(dst_path, version, ident, name)
+                    os.makedirs(dst_fold, exist_ok=True)
+                    for img in sorted(os.listdir(os.path.join(id_dir, name))):
+                        out.append(shutil.copy(os.path.join(id_dir, name, img), os.path.join(dst_fold, img)))
+    return out
+
+
 DEFAULT_BATCH = 32       # loop steps per generator forward in literal mode: the configuration bench.py times (1.6 GB of activations per step at 1024^2;
                          # measured 20 .. 64: 32 is the fastest, 25 -- the round-2 figure -- 1.5 - 3 % behind)
 

@@ -636,6 +636,29 @@ def test_legacy_tf_conversion_matches_the_reference_converter():
     assert set(want) - set(got) == set() or all("num_batches" in k for k in set(want) - set(got))
 
 
+def test_merge_files_folds_the_variants_like_the_script(tmp_path):
+    """1024_merge_files.py:20-45: <src>/<version>/<variant>/<id>/<name>/<file> -> <dst>/<version>/<id>/<name>/<file>; dotted entries of an id folder are
+    skipped; the CLI verb needs neither a model nor a GPU."""
+    from morphganformer_amd import cli, drivers
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    layout = {("v1", "hog", "0001", "a"): ["a_000010_0.1.png", "a.mat"], ("v1", "dlib", "0001", "b"): ["b.mat"],
+              ("v1", "dlib", "0002", "c"): ["c.png"], ("v2", "hog", "0001", "a"): ["x.png"]}
+    for (ver, var, ident, name), files in layout.items():
+        d = src / ver / var / ident / name
+        d.mkdir(parents=True)
+        for f in files:
+            (d / f).write_text(f"{ver}/{var}/{ident}/{name}/{f}")
+    (src / "v1" / "hog" / "0001" / "notes.txt").write_text("skipped: carries a dot")
+    (src / "v3").mkdir()
+    out = drivers.merge_files(str(src), str(dst))
+    assert len(out) == 5
+    assert sorted(os.listdir(dst / "v1" / "0001")) == ["a", "b"] and os.listdir(dst / "v1" / "0002") == ["c"] and os.listdir(dst / "v3") == []
+    assert (dst / "v1" / "0001" / "b" / "b.mat").read_text() == "v1/dlib/0001/b/b.mat" and (dst / "v2" / "0001" / "a" / "x.png").exists()
+    assert not (dst / "v1" / "0001" / "notes.txt").exists()
+    assert cli.main(["merge-files", "--src", str(src), "--dst", str(tmp_path / "dst2")]) == 0
+    assert sorted(os.listdir(tmp_path / "dst2")) == ["v1", "v2", "v3"]
+
+
 def test_bench_fixed_batch_and_torch_free_launcher():
     """bench.py evaluates a FIXED 32 loop iterations per generator forward (every run -- the driver's, the rocprofv3 trace, the PMC passes --
     launches the same shapes); a bench step is one such launch sequence and exactly --steps of them are timed (no extension of the timed
