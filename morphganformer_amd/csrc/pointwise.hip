@@ -51,9 +51,13 @@ constexpr int PWNR = PW_NR;   // load groups in the register ring: a group is re
 
 // WK = 4: the four waves of a workgroup share ONE tile and split the input channels (layers with too few tiles to fill the chip, where a
 // wave's serial walk over K at one load group in flight is the whole run time); their accumulators meet in LDS and wave 0 stores.
-template <int CB, int WCO, int WK, bool VEC>
+// NJ = 32-pixel blocks per wave: 4 (a 128-pixel tile) or -- small maps under split-K, where the launch has too few waves to fill the chip and a wave's
+// serial walk over its K share is the whole run time (512 -> 512 at 32^2, one sample: 128 workgroups, 64 k-steps x 4 MFMAs per wave) -- 1: a quarter
+// of the matrix work per wave, four times the waves.
+template <int CB, int WCO, int WK, bool VEC, int NJ = 4>
 __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_kernel(PwParams p) {
     static_assert(WK == 1 || (WK == 4 && WCO == 1), "split-K workgroups put all four waves on one tile");
+    static_assert(NJ == 4 || (NJ == 1 && !VEC && WK == 4 && CB == 1), "the one-block tile is the split-K form's, with element loads");
     constexpr int WPX = 4 / (WCO * WK);
     __shared__ float red[WK > 1 ? 3 * 64 * CB * 64 : 1];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
     const int pt = b_ % p.px_tiles;
     const int n = b_ / p.px_tiles;
     const int co0 = (cot * WCO + wv % WCO) * 32 * CB;
-    const int p0 = (pt * WPX + (WK > 1 ? 0 : wv / WCO)) * 128;
+    const int p0 = (pt * WPX + (WK > 1 ? 0 : wv / WCO)) * (32 * NJ);
     if (p0 >= p.hw || co0 >= p.cout) return;                       // wave-uniform (workgroup-uniform with WK > 1: its barrier is safe)
 
     // the style multiplies the WEIGHT operand (one dword per lane and k-step, next to the weight's own): w[ci][co] s[n][ci]
@@ -84,48 +88,48 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
     const unsigned wo = (unsigned)(half * p.cout_pad + co0 + l31) * 4u;
     const unsigned so = (unsigned)half * 4u;
     const unsigned xstep = (unsigned)p.hw * 8u, wstep = (unsigned)p.cout_pad * 8u;      // one k-step = 2 channels
-    unsigned xoj[4], woc[CB];
+    unsigned xoj[NJ], woc[CB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xoj[j] = xo + 128u * j;
+    for (int j = 0; j < NJ; ++j) xoj[j] = xo + 128u * j;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) woc[cb] = wo + 128u * cb;
 
-    f32x16 acc[CB][4];
+    f32x16 acc[CB][NJ];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cb][j][r] = 0.f;
 
     // S: the style of a k-step's two channels, multiplied into the weight operand when it is CONSUMED: multiplied where it is loaded, every
     // group's loads ended in an s_waitcnt vmcnt(0) and the next group could not be in flight behind the MFMAs
-    float Br[PWNR][PWKU][4], Ar[PWNR][PWKU][CB], Sr[PWNR][PWKU];
-    auto load = [&](float (&B)[PWKU][4], float (&A)[PWKU][CB], float (&S)[PWKU], int it) {
+    float Br[PWNR][PWKU][NJ], Ar[PWNR][PWKU][CB], Sr[PWNR][PWKU];
+    auto load = [&](float (&B)[PWKU][NJ], float (&A)[PWKU][CB], float (&S)[PWKU], int it) {
 #pragma unroll
         for (int ks = 0; ks < PWKU; ++ks) {
             const int kk = it * PWKU + ks;                                   // wave-uniform
             const int xs = (int)((unsigned)kk * xstep), ws = (int)((unsigned)kk * wstep);
-            if (VEC) {
+            if constexpr (VEC) {
                 const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo, xs, 0));
                 B[ks][0] = v.x; B[ks][1] = v.y; B[ks][2] = v.z; B[ks][3] = v.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) B[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoj[j], xs, 0));
+                for (int j = 0; j < NJ; ++j) B[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoj[j], xs, 0));
             }
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) A[ks][cb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woc[cb], ws, 0));
             if (has_s) S[ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, so, kk * 8, 0));
         }
     };
-    auto mm = [&](const float (&B)[PWKU][4], const float (&A)[PWKU][CB], const float (&S)[PWKU]) {
+    auto mm = [&](const float (&B)[PWKU][NJ], const float (&A)[PWKU][CB], const float (&S)[PWKU]) {
 #pragma unroll
         for (int ks = 0; ks < PWKU; ++ks)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 const float a = has_s ? A[ks][cb] * S[ks] : A[ks][cb];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[cb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B[ks][j], acc[cb][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[cb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B[ks][j], acc[cb][j], 0, 0, 0);
             }
     };
     int nit = (p.cin + 2 * PWKU - 1) / (2 * PWKU), it0 = 0;
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) red[(((wv - 1) * CB + cb) * 64 + j * 16 + r) * 64 + lane] = acc[cb][j][r];
         }
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[cb][j][r] += red[((k * CB + cb) * 64 + j * 16 + r) * 64 + lane];
     }
@@ -184,14 +188,14 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
     const bool rows8 = (p.cout & 7) == 0;             // rows of both lane halves are inside / outside together
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     // per-lane pixel offsets (bytes) inside a channel row; the half's 4 rows ride along
-    unsigned pvo[4];
-    if (VEC) {
+    unsigned pvo[NJ > 1 ? NJ : 4];
+    if constexpr (VEC) {
         const int px = p0 + 4 * l31;
         pvo[0] = px < p.hw ? (unsigned)(4 * half * p.hw + px) * 4u : 0xFFFFFFF0u;
         pvo[1] = pvo[2] = pvo[3] = 0xFFFFFFF0u;
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int px = p0 + l31 + 32 * j;
             pvo[j] = px < p.hw ? (unsigned)(4 * half * p.hw + px) * 4u : 0xFFFFFFF0u;
         }
@@ -222,15 +226,15 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
                 const int soff = cor * p.hw * 4;
                 const unsigned lane_ok = (rows8 || in) ? 0u : 0xFFFFFFF0u;         // (per-lane only for ragged channel counts)
                 const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbr, (unsigned)(4 * half) * 4u | lane_ok, cor * 4, 0));
-                float v[4];
+                float v[NJ];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const float t = acc[cb][j][r] + bv;
                     float ts = t * slope, m;                                       // slope <= 1: leaky / plain ReLU / identity = max(t, slope t)
                     asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(t), "v"(ts));      // (as an instruction: `fmaxf` adds canonicalising v_max x, x)
                     v[j] = m * gain;
                 }
-                if (VEC && rag) {
+                if constexpr (VEC) { if (rag) {
                     const int px = p0 + 4 * l31;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
                         }
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), ryh, off, 0, 0);
                     }
-                } else if (VEC) {
+                } else {
                     float4 o = make_float4(v[0], v[1], v[2], v[3]);
                     if (RES) {
                         const float4 q = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrr, pvo[0] | lane_ok, soff, 0));
@@ -257,9 +261,9 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : (WK > 1 ? 3 : 4)) void pw_conv_k
                         if (POST) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), ryr, pvo[0] | lane_ok, soff, 0);
-                } else {
+                } } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         float o = v[j];
                         if (RES) o += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrr, pvo[j] | lane_ok, soff, 0));
                         if (RES && POST) o = fmaxf(o, 0.f);
@@ -396,6 +400,7 @@ void pw_launch(const PwParams& p, bool vec, dim3 grid, hipStream_t st) {
     if (vec) hipLaunchKernelGGL((pw_conv_kernel<CB, WCO, WK, true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((pw_conv_kernel<CB, WCO, WK, false>), grid, dim3(256), 0, st, p);
 }
+void pw_launch_narrow(const PwParams& p, dim3 grid, hipStream_t st) { hipLaunchKernelGGL((pw_conv_kernel<1, 1, 4, false, 1>), grid, dim3(256), 0, st, p); }
 
 }  // namespace
 
@@ -481,9 +486,13 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
     // MGF_PW_SPLITK_WAVES = the wave count below which it is used (tuning; 0 = never).
     static const int64_t splitk_below = [] { const char* e = mgf_knob("MGF_PW_SPLITK_WAVES"); return e ? atoll(e) : (int64_t)768; }();
     const bool splitk = cb == 1 && cin >= 32 && (int64_t)n * mgf_cdiv(hw, 128) * cw < splitk_below;
+    // ... and with few of THOSE workgroups (<= 32^2 maps at one sample: the gradient mode's skips and transformer projections) one 32-pixel block per
+    // wave: four times the workgroups, a quarter of the serial k walk each.  MGF_PW_NARROW_WGS = the 128-pixel workgroup count below which (0 = never).
+    static const int64_t narrow_below = [] { const char* e = mgf_knob("MGF_PW_NARROW_WGS"); return e ? atoll(e) : (int64_t)256; }();
+    const bool narrow = splitk && (int64_t)n * mgf_cdiv(hw, 128) * cw < narrow_below;
     const int wco = splitk ? 1 : (cw >= 3 ? 4 : cw);               // 1, 2 or 4 waves of a workgroup side by side over the channels
     p.co_tiles = (cw + wco - 1) / wco;
-    p.px_tiles = (int)mgf_cdiv(hw, splitk ? 128 : 128 * (4 / wco));
+    p.px_tiles = (int)mgf_cdiv(hw, narrow ? 32 : splitk ? 128 : 128 * (4 / wco));
     int64_t blocks = (int64_t)n * p.px_tiles * p.co_tiles;
     MGF_REQUIRE(blocks <= INT32_MAX - 8, MGF_ETOOBIG, "conv1x1: too many workgroups");
     p.xcd_per = 0;
@@ -491,10 +500,11 @@ extern "C" int mgf_conv1x1_f32(float* y, const float* x, const float* w, const f
     static const char* names[2][3] = {{"pw_conv_kernel<1, 1>", "pw_conv_kernel<1, 2>", "pw_conv_kernel<1, 4>"},
                                       {"pw_conv_kernel<2, 1>", "pw_conv_kernel<2, 2>", "pw_conv_kernel<2, 4>"}};
     hipStream_t st = (hipStream_t)stream;
-    mgf_prof_external_begin(st, splitk ? "pw_conv_kernel<1, 1, 4>" : names[cb - 1][wco == 4 ? 2 : wco - 1], 2.0 * cin * (double)cout * hw * n,
+    mgf_prof_external_begin(st, narrow ? "pw_conv_kernel<1, 1, 4, 1>" : splitk ? "pw_conv_kernel<1, 1, 4>" : names[cb - 1][wco == 4 ? 2 : wco - 1], 2.0 * cin * (double)cout * hw * n,
                             4.0 * ((double)n * cin * hw + (double)cin * cout + (double)n * cout * hw * ((ep && ep->residual) ? 2 : 1)));
     const dim3 grid((unsigned)blocks);
-    if (splitk) pw_launch<1, 1, 4>(p, gemm_vec, grid, st);
+    if (narrow) pw_launch_narrow(p, grid, st);
+    else if (splitk) pw_launch<1, 1, 4>(p, gemm_vec, grid, st);
     else if (cb == 2) {
         if (wco == 4) pw_launch<2, 4>(p, gemm_vec, grid, st); else if (wco == 2) pw_launch<2, 2>(p, gemm_vec, grid, st); else pw_launch<2, 1>(p, gemm_vec, grid, st);
     } else {

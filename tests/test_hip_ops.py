@@ -344,6 +344,8 @@ def test_conv_taps_vs_torch(n, cin, cout, res, k, stride, pad):
     (1, 2, 3, 1, 1, 3, 0, "linear", False),           # one pixel
     (2, 32, 32, 8, 8, 32, 0, "linear", False),        # split-K workgroups with fewer channel groups than waves
     (1, 72, 40, 16, 12, 40, 0, "relu", True),         # ... and with an odd number of groups per wave
+    (1, 512, 512, 32, 32, 512, 0, "lrelu", False),    # ... one 32-pixel block per wave (few workgroups): the gradient mode's skip at one sample
+    (1, 40, 72, 5, 9, 80, 8, "lrelu", True),          # ... its ragged second pixel tile, ragged channels, residual on a slice
     (1, 256, 128, 128, 128, 128, 0, "linear", False),
     (2, 32, 3, 64, 64, 3, 0, "linear", False),        # ToRGB outside the fused launch: the narrow-output streaming kernel, 16-byte path
     (2, 13, 3, 9, 13, 8, 2, "lrelu", True),           # ... scalar path, cin not a multiple of its 8-row sweep, residual on a slice
