@@ -1279,7 +1279,7 @@ static int conv_taps_dispatch(float* y, const float* x, const float* wp, const v
     int ksplit = 1;
     static const int splitk_below = [] { const char* e = mgf_knob("MGF_SPLITK_BELOW"); return e ? atoi(e) : 256; }();   // tuning hook (512 / 256 / 128: 99.6 / 100.4 / 101.1 single-target gradient iters/s, 542 / 548 / 545 literal)
     if (d.workspace && base_wgs < splitk_below && nchunks >= 4 && !d.rgb_out) {
-        static const int splitk_target = [] { const char* e = mgf_knob("MGF_SPLITK_TARGET"); return e ? atoi(e) : 1024; }();      // tuning hook: workgroups wanted
+        static const int splitk_target = [] { const char* e = mgf_knob("MGF_SPLITK_TARGET"); return e ? atoi(e) : 1024; }();      // tuning hook: workgroups wanted (256 / 512 / 768 / 1024: 157.8 / 158.7 / 157.5 / 157.0 single-target gradient iters/s, headline and config 3 unchanged: tools/splitk_target_ab.sh)
         ksplit = (int)mgf_cdiv(splitk_target, base_wgs);
         if (ksplit > nchunks / 2) ksplit = nchunks / 2;
         const int64_t slice = (int64_t)d.n * d.cout * d.out_h * d.y_pitch;
