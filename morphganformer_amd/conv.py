@@ -196,6 +196,7 @@ def winograd2_weights(w: torch.Tensor, gain: float = 1.0) -> torch.Tensor:
 # Which kernel serves the [16, cin/4, cout, 4] weight layout on even maps: form 3 (csrc/wino3.hip, the transformed input stays in
 # registers) unless MGF_WINOGRAD_FORM=2 (tuning hook: form 2, csrc/wino.hip, which also takes odd maps and channel slices)
 WINOGRAD_FORM = int(os.environ.get("MGF_WINOGRAD_FORM", "3"))
+WINOGRAD3_MIN_WGS = int(os.environ.get("MGF_WINOGRAD3_MIN_WGS", "128"))      # tuning hook: fewest form-3 workgroups that still beat the split-K tap-list launch (one target, gradient mode: 512 / 256 / 128 / 64 -> 157.4 / 157.9 / 159.4 / 158.0 iters/s, tools/wino3_min_wgs_ab.sh)
 
 
 def winograd3_ok(x, out, out_choff):
@@ -284,7 +285,7 @@ def winograd_fills_chip(n, cout, h, w):
     if WINOGRAD_FORM == 3:
         # form 3: 32 channels x (32 x 4 outputs) per workgroup, four workgroups per CU.  Half a wave of workgroups (512 of the 1024 the
         # chip holds: a single 64x64 x 512-channel image, gradient mode) is still faster than the split-K tap-list launch + its reduce
-        return n * -(-h // 4) * -(-w // 32) * (cout // 32) >= 512
+        return n * -(-h // 4) * -(-w // 32) * (cout // 32) >= WINOGRAD3_MIN_WGS
     return n * -(-h // 8) * -(-w // 32) * (cout // 32) >= 512
 
 
