@@ -113,12 +113,12 @@ def build(verbose: bool = False, force: bool = False) -> str:
 
 
 def build_experiment(name: str, extra_flags, source: str = "conv_taps.hip", verbose: bool = False) -> str:
-    """exp_build/libmgf_<name>.so: the library with `extra_flags` applied to `source` only (timing ablations, instruction-mix probes).
+    """exp_build/libmgf_<name>.so: the library with `extra_flags` applied to `source` only -- or to every source with "all" -- (timing ablations, instruction-mix probes).
     Its objects live in exp_build/_obj, keyed like the product's -- the flagged object has its own name, the others are compiled there
     once and shared between experiments -- and nothing is read from or written to the product's cache."""
-    assert source in SOURCES, source
+    assert source == "all" or source in SOURCES, source
     out_dir = os.path.join(ROOT, "exp_build")
-    objs, _ = _compile_all(os.path.join(out_dir, "_obj"), lambda src: FLAGS[:-2] + list(extra_flags) + FLAGS[-2:] if src == source else list(FLAGS),
+    objs, _ = _compile_all(os.path.join(out_dir, "_obj"), lambda src: FLAGS[:-2] + list(extra_flags) + FLAGS[-2:] if (src == source or source == "all") else list(FLAGS),
                            verbose, False, prune=False)
     lib = os.path.join(out_dir, f"libmgf_{name}.so")
     _link(lib, objs, verbose)
