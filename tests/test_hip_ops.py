@@ -73,6 +73,21 @@ def test_bias_act_dim0_alpha_gain_and_dtypes(golden):
     assert rel_err(bias_act.bias_act(x, torch.ones(3).cuda(), act="relu"), bias_act_ref(x.cpu(), torch.ones(3), act="relu")) < 2e-6
 
 
+def test_bias_act_small_arguments_and_the_kink_at_zero():
+    """Per-ELEMENT relative accuracy where the exponential formulas cancel (found by tools/fuzz_soak.sh on a one-element tensor: the plugin's
+    (e^x - e^-x) / (e^x + e^-x) is 2e-5 off at |x| ~ 1e-2 in float32) and the gradient at exactly zero (relu: 0, like the reference and its plugin)."""
+    from morphganformer_amd.torch_utils.ops import bias_act
+    x = torch.cat([torch.logspace(-6, 0, 61), -torch.logspace(-6, 0, 61)]).float()
+    for act, fn in (("tanh", torch.tanh), ("elu", torch.nn.functional.elu), ("selu", torch.nn.functional.selu), ("softplus", torch.nn.functional.softplus),
+                    ("sigmoid", torch.sigmoid)):
+        y = bias_act.bias_act(x.cuda(), None, act=act).cpu().double()
+        want = fn(x.double())
+        assert float(((y - want).abs() / want.abs().clamp_min(1e-30)).max()) < 1e-6, act
+    xz = torch.tensor([[0.0, -1.0, 2.0, 0.0]], device="cuda", requires_grad=True)
+    (g,) = torch.autograd.grad(bias_act.bias_act(xz, torch.zeros(4, device="cuda"), act="relu").sum(), xz)
+    assert g.cpu().tolist() == [[0.0, 0.0, float(np.float32(np.sqrt(2))), 0.0]]
+
+
 def test_bias_act_errors():
     from morphganformer_amd import _lib
     from morphganformer_amd.torch_utils.ops import bias_act

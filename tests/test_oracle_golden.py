@@ -40,6 +40,15 @@ def test_bias_act_ref_vs_reference(golden, clamp):
     assert rel(bias_act_ref(torch.from_numpy(g["x2"]), torch.from_numpy(g["b2"]), dim=0, act="lrelu", alpha=0.3, gain=1.7), g["y2"]) < TOL
 
 
+def test_bias_act_ref_relu_gradient_at_exactly_zero():
+    """bias_act.py:17 is `torch.nn.functional.relu`: autograd gives it (and the plugin's `y > 0` test, bias_act.cu) the gradient 0 AT zero -- `clamp_min`,
+    which the restatement used until a round-6 soak run drew x + b == 0 in float16, gives 1."""
+    x = torch.tensor([0.0, -1.0, 2.0, 0.0], dtype=torch.float64, requires_grad=True)
+    b = torch.tensor([0.0, 0.0, 0.0, 0.0], dtype=torch.float64)
+    (g,) = torch.autograd.grad(bias_act_ref(x.reshape(1, 4), b, dim=1, act="relu").sum(), x)
+    assert g.tolist() == [0.0, 0.0, math.sqrt(2), 0.0]
+
+
 def test_upfirdn2d_ref_vs_reference(golden):
     from oracle.make_golden import UPFIRDN_CASES
     g = golden("ops_upfirdn2d.npz")
