@@ -87,7 +87,8 @@ template <typename S> struct Act<MGF_ACT_SWISH, S> {
     }
 };
 
-template <typename T> __device__ __forceinline__ float to_s(T v) { return (float)v; }
+// (element -> compute type: float for float / half, DOUBLE for double -- this used to return float for every T, which gave the float64 path float32 inputs)
+template <typename T> __device__ __forceinline__ typename Compute<T>::type to_s(T v) { return (typename Compute<T>::type)v; }
 template <> __device__ __forceinline__ float to_s<__half>(__half v) { return __half2float(v); }
 template <typename T, typename S> __device__ __forceinline__ T from_s(S v) { return (T)v; }
 template <> __device__ __forceinline__ __half from_s<__half, float>(float v) { return __float2half(v); }

@@ -8,6 +8,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Soak runs (tools/suite_soak.sh): MGF_SOAK_OFFSET=k shifts every torch seed a test sets -- other random inputs for every HIP-vs-oracle comparison.  Tests that
+# re-draw the inputs of a committed fixture by seed are expected to fail under it (they fail on EVERY offset, by a lot); 0 / unset = the committed cases.
+_SOAK = int(os.environ.get("MGF_SOAK_OFFSET", "0")) * 1000003
+if _SOAK:
+    import torch as _torch
+    _ms = _torch.manual_seed
+    _torch.manual_seed = lambda s: _ms(int(s) + _SOAK)              # (torch.Generator.manual_seed is a C method and stays as it is)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

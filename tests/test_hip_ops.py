@@ -57,10 +57,12 @@ def test_bias_act_dim0_alpha_gain_and_dtypes(golden):
     for dt, tol in ((torch.float64, 1e-7), (torch.float16, 2e-3)):
         x = torch.randn(3, 8, 5, 6, dtype=torch.float64).to(dt)
         b = torch.randn(8, dtype=torch.float64).to(dt)
-        for act in ("lrelu", "swish", "tanh", "softplus"):
+        for act in ("lrelu", "swish", "tanh", "softplus", "sigmoid", "elu"):
             ref = bias_act_ref(x.double(), b.double(), act=act)
             out = bias_act.bias_act(x.cuda(), b.cuda(), act=act)
-            assert out.dtype == dt and rel_err(out, ref) < tol, (dt, act)
+            # (activations without a float alpha / gain are double all the way: a suite soak found the float64 path converting its INPUTS to float)
+            tol_a = 1e-14 if (dt == torch.float64 and act in ("tanh", "softplus", "sigmoid", "elu")) else tol
+            assert out.dtype == dt and rel_err(out, ref) < tol_a, (dt, act)
     # channels_last input keeps its layout and values
     x = torch.randn(2, 6, 5, 7).cuda().to(memory_format=torch.channels_last)
     b = torch.randn(6).cuda()

@@ -103,10 +103,11 @@ def test_mapping_ref_properties():
     w = mapping_ref(sd, z, TINY)
     assert tuple(w.shape) == (3, TINY.k, TINY.w_dim)
     # samples are independent: evaluating one alone gives the same row
-    assert torch.allclose(mapping_ref(sd, z[1:2], TINY), w[1:2], atol=1e-6)
+    wmax = float(w.abs().max())                       # (~ 18: the gates are relative to it -- float32 rounding of the restatement itself is 1e-6 of that)
+    assert float((mapping_ref(sd, z[1:2], TINY) - w[1:2]).abs().max()) < 5e-7 * wmax
     # the joint normalisation makes the local path invariant to a positive rescale of the local components
     z2 = z.clone(); z2[:, :-1] *= 3.0
-    assert torch.allclose(mapping_ref(sd, z2, TINY)[:, :-1], w[:, :-1], atol=1e-5)
+    assert float((mapping_ref(sd, z2, TINY)[:, :-1] - w[:, :-1]).abs().max()) < 5e-6 * wmax
 
 
 def test_loss_kats(golden):
