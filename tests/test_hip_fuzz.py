@@ -317,7 +317,7 @@ def test_generator_random_configurations_vs_oracle(res, base, cmax, att, norm_g)
     from morphganformer_amd.synth_weights import GeneratorConfig, make_state_dict
     from oracle.generator_ref import generator_ref, to_torch_state
     cfg = GeneratorConfig(img_resolution=res, channel_base=base, channel_max=cmax, attn_max_log2res=att, normalize_global=norm_g)
-    sd = make_state_dict(cfg, seed=res + cmax)
+    sd = make_state_dict(cfg, seed=res + cmax + _OFFSET % 9973)          # (soak: other weights too)
     G = Generator(sd, cfg, "cuda", max_batch=3)
     torch.manual_seed(res * 7 + cmax + _OFFSET)
     z = torch.randn(3, cfg.k, cfg.z_dim)
@@ -340,7 +340,7 @@ def test_generator_gradient_random_configurations_vs_autograd(res, base, cmax, a
     from morphganformer_amd.synth_weights import GeneratorConfig, make_state_dict
     from oracle.generator_ref import generator_ref, to_torch_state
     cfg = GeneratorConfig(img_resolution=res, channel_base=base, channel_max=cmax, attn_max_log2res=att, normalize_global=norm_g)
-    sd = make_state_dict(cfg, seed=res + cmax + 1)
+    sd = make_state_dict(cfg, seed=res + cmax + 1 + _OFFSET % 9973)
     gg = GeneratorGrad(Generator(sd, cfg, "cuda", max_batch=2))
     torch.manual_seed(res + 3 * cmax + _OFFSET)
     z = torch.randn(2, cfg.k, cfg.z_dim, requires_grad=True)

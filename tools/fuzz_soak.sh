@@ -5,7 +5,7 @@
 D=${1:-gpurun_out/soak}; mkdir -p $D
 for k in ${2:-1 2 3}; do
   echo "== MGF_FUZZ_OFFSET=$k"
-  MGF_FUZZ_OFFSET=$k python -m pytest tests/test_hip_fuzz.py -m gpu -q --no-header -p no:cacheprovider $3 $4 > $D/soak_$k.log 2>&1; rc=$?
+  MGF_FUZZ_OFFSET=$k python -m pytest tests/test_hip_fuzz.py -m gpu -q --no-header -p no:cacheprovider "${@:3}" > $D/soak_$k.log 2>&1; rc=$?
   tail -1 $D/soak_$k.log
   if [ $rc -ne 0 ]; then grep -n "Error\|assert\|FAILED" $D/soak_$k.log | head -20; fi
 done
