@@ -259,6 +259,79 @@ def test_conv_forward_random_epilogues():
         keep[choff:choff + cout] = False
         assert torch.equal(out.cpu()[:, keep], base[:, keep]), tag      # the rest of the wider buffer is untouched
 
+def test_winograd3_and_pointwise_random_shapes():
+    """The two MFMA convolutions whose dispatch has the most branches, on shapes nobody picked: form-3 Winograd under each workgroup shape (11 / 21 / 12:
+    the one-shot kernel's one-block and two-block forms with their different operand rings), K from one chunk to 80, ragged maps, every epilogue piece,
+    channel slices; the 1x1 register-operand GEMM over its split-K / one-block-per-wave / 16-byte / ragged-row branches.  Against float64 torch convolutions."""
+    from morphganformer_amd import _lib, conv as cv
+    from oracle.ops_ref import bias_act_ref
+    r = _rng(1212)
+    f = lambda t: t.cuda().contiguous()
+    try:
+        for case in range(36):
+            shape = (11, 21, 12)[case % 3]
+            n = int(r.integers(1, 4))
+            cin = 4 * int(r.integers(1, 41)) if case % 4 else int(r.choice([256, 288, 320]))
+            cout = 32 * int(r.integers(1, 6)) * (2 if shape == 21 else 1)
+            h, w = int(r.integers(3, 60)), int(r.integers(3, 100))
+            torch.manual_seed(12000 + case + _OFFSET)
+            x = torch.randn(n, cin, h, w)
+            wt = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+            s, d = 1 + 0.3 * torch.randn(n, cin), 0.5 + torch.rand(n, cout)
+            ref = torch.nn.functional.conv2d((x * s[:, :, None, None]).double(), wt.double(), padding=1) * d[:, :, None, None].double()
+            kw, ep = {}, {}
+            if r.integers(0, 2):
+                bias = torch.randn(cout); ep["bias"] = f(bias)
+            else:
+                bias = None
+            act = ["linear", "lrelu", "relu"][int(r.integers(0, 3))]
+            alpha = float(r.uniform(0.05, 0.9)) if act == "lrelu" else None
+            gain = float(r.uniform(0.5, 2.0))
+            noise = torch.randn(n, h, w) if r.integers(0, 2) else None
+            resid = torch.randn(n, cout, h, w) if r.integers(0, 2) else None
+            want = ref.float()
+            if noise is not None:
+                strength = torch.tensor([float(r.uniform(0.1, 1.0))])
+                want = want + noise[:, None] * strength
+                ep.update(noise=f(noise), noise_strength=strength.cuda(), noise_n=n)
+            want = bias_act_ref(want, bias, act=act, alpha=alpha, gain=gain)
+            if resid is not None:
+                want = want + resid
+                ep["residual"] = f(resid)
+            _lib.check(_lib.lib().mgf_winograd3_force_shape(shape))
+            out = cv.winograd_forward(f(x), cv.winograd2_weights(f(wt), gain=1.0), in_scale=f(s), out_scale=f(d),
+                                      epilogue=_lib.make_epilogue(act=act, alpha=0.0 if alpha is None else alpha, gain=gain, **ep))
+            assert rel_err(out, want) < 3e-5, (case, shape, n, cin, cout, h, w, act, sorted(ep))
+    finally:
+        _lib.lib().mgf_winograd3_force_shape(0)
+    for case in range(60):
+        n = int(r.integers(1, 5))
+        cin, cout = int(r.integers(1, 600)), int(r.integers(1, 300))
+        if case % 3 == 0:
+            cin, cout = int(r.choice([256, 384, 512])), int(r.choice([32, 64, 256, 512]))
+        h, w = int(r.integers(1, 40)), int(r.integers(1, 70))
+        if case % 7 == 0:
+            h, w = int(r.integers(60, 130)), int(r.integers(60, 130))
+        extra = int(r.integers(0, 3)) * 8
+        choff = int(r.integers(0, extra + 1))
+        torch.manual_seed(13000 + case + _OFFSET)
+        x = torch.randn(n, cin, h, w)
+        wt = torch.randn(cout, cin, 1, 1) / cin ** 0.5
+        bias = torch.randn(cout)
+        act = ["linear", "lrelu", "relu"][int(r.integers(0, 3))]
+        want = bias_act_ref(torch.nn.functional.conv2d(x.double(), wt.double()).float(), bias, act=act, alpha=0.3 if act == "lrelu" else None, gain=1.0)
+        out = torch.full((n, cout + extra, h, w), 5.0, device="cuda")
+        kw = {}
+        if r.integers(0, 2):
+            resid = torch.randn(n, cout + extra, h, w)
+            want = want + resid[:, choff:choff + cout]
+            kw["residual"] = f(resid)
+        cv.conv_forward(f(x), cv.pack_weights(f(wt)), out=out, out_choff=choff,
+                        epilogue=_lib.make_epilogue(bias=f(bias), act=act, alpha=0.3 if act == "lrelu" else 0.0, gain=1.0, **kw))
+        assert rel_err(out[:, choff:choff + cout], want) < 3e-5, (case, n, cin, cout, h, w, act, extra, choff)
+        rest = torch.ones(cout + extra, dtype=torch.bool); rest[choff:choff + cout] = False
+        assert bool((out[:, rest.cuda()] == 5.0).all()), (case, "wrote outside its channel slice")
+
 
 @pytest.mark.parametrize("net", ["squeeze", "alex", "vgg"])
 def test_lpips_random_non_square_sizes(net):
