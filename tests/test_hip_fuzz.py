@@ -332,6 +332,28 @@ def test_winograd3_and_pointwise_random_shapes():
         rest = torch.ones(cout + extra, dtype=torch.bool); rest[choff:choff + cout] = False
         assert bool((out[:, rest.cuda()] == 5.0).all()), (case, "wrote outside its channel slice")
 
+def test_transposed_and_strided_conv_random_shapes():
+    """The stride-2 transposed 3x3 convolution of the up-sampling layers (persistent tap-list kernel with one chunk stream across tiles, its border launch,
+    the single-launch form of small maps and few images) on random channel counts and map sizes at 1 .. 5 images -- the n >= 4 / n < 4 and 16 px / 128 px
+    dispatch boundaries included -- against float64 torch.  (Its adjoint, the stride-2 convolution of the data gradient, has its cases in test_hip_ops.py.)"""
+    import math
+    from morphganformer_amd import conv as cv
+    r = _rng(1414)
+    for case in range(40):
+        n = int(r.integers(1, 6))
+        cin = 8 * int(r.integers(1, 33)) if case % 3 else int(r.integers(1, 70))
+        cout = int(r.integers(1, 140))
+        h, w = int(r.integers(2, 48)), int(r.integers(2, 72))
+        if case % 8 == 0:
+            h, w, cin, cout = int(r.integers(128, 150)), int(r.integers(128, 140)), 8 * int(r.integers(1, 5)), int(r.integers(1, 40))
+        torch.manual_seed(14000 + case + _OFFSET)
+        x = torch.randn(n, cin, h, w)
+        wt = torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9)
+        s, d = 1 + 0.2 * torch.randn(n, cin), 1 + 0.2 * torch.randn(n, cout)
+        ref = torch.nn.functional.conv_transpose2d((x * s[:, :, None, None]).double(), wt.transpose(0, 1).double(), stride=2) * d[:, :, None, None].double()
+        out = cv.tconv3x3s2_forward(x.cuda(), cv.pack_weights(wt.cuda()), in_scale=s.cuda(), out_scale=d.cuda())
+        assert tuple(out.shape) == tuple(ref.shape) and rel_err(out, ref) < 2e-5, (case, "tconv", n, cin, cout, h, w)
+
 
 @pytest.mark.parametrize("net", ["squeeze", "alex", "vgg"])
 def test_lpips_random_non_square_sizes(net):
