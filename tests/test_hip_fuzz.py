@@ -332,7 +332,7 @@ def test_winograd3_and_pointwise_random_shapes():
         rest = torch.ones(cout + extra, dtype=torch.bool); rest[choff:choff + cout] = False
         assert bool((out[:, rest.cuda()] == 5.0).all()), (case, "wrote outside its channel slice")
 
-def test_transposed_and_strided_conv_random_shapes():
+def test_transposed_conv_random_shapes():
     """The stride-2 transposed 3x3 convolution of the up-sampling layers (persistent tap-list kernel with one chunk stream across tiles, its border launch,
     the single-launch form of small maps and few images) on random channel counts and map sizes at 1 .. 5 images -- the n >= 4 / n < 4 and 16 px / 128 px
     dispatch boundaries included -- against float64 torch.  (Its adjoint, the stride-2 convolution of the data gradient, has its cases in test_hip_ops.py.)"""
