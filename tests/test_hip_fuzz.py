@@ -51,11 +51,17 @@ def test_upfirdn2d_random_geometry():
         # (the reference crops before filtering: a crop larger than the up-sampled map is not a defined case)
         if max(-pad[2], 0) + max(-pad[3], 0) >= h * upy or max(-pad[0], 0) + max(-pad[1], 0) >= w * upx:
             continue
-        flip, gain = bool(r.integers(0, 2)), float(r.uniform(0.5, 4.0))
+        flip, gain = bool(r.integers(0, 2)), float(np.float32(r.uniform(0.5, 4.0)))       # (the plugin's gain is a C float, upfirdn2d.cpp:8: a float32 value, so that the float64 gate can be tight)
         dtype = [torch.float32, torch.float32, torch.float64, torch.float16][int(r.integers(0, 4))]
         torch.manual_seed(case + _OFFSET)
         x = torch.randn(n, c, h, w)
         f = torch.rand(fw) + 0.1 if one_d else torch.rand(fh, fw) + 0.1
+        if dtype == torch.float64:
+            # dyadic taps and a power-of-FOUR gain: every float32 value the filter set-up may form (outer product of a 1-D filter, gain folded into the taps,
+            # sqrt(gain) per pass of a separable filter -- the reference's implementations differ there, upfirdn2d.py:161-200, :222-232 / upfirdn2d.cpp:8) is
+            # exact, so the float64 gate below can be tight
+            f = torch.round(f * 8) / 8 + 0.125
+            gain = float(4.0 ** int(r.integers(-1, 2)))
         ref = upfirdn2d_ref(x.double(), f.double(), up=(upx, upy), down=(dnx, dny), padding=pad, flip_filter=flip, gain=gain)
         xin = x.to(dtype).cuda()
         if case % 3 == 0 and c > 1:
@@ -63,7 +69,7 @@ def test_upfirdn2d_random_geometry():
         out = upfirdn2d.upfirdn2d(xin, f.cuda(), up=[upx, upy], down=[dnx, dny], padding=pad, flip_filter=flip, gain=gain)
         tag = f"case {case}: x {tuple(x.shape)} {dtype} up ({upx},{upy}) down ({dnx},{dny}) f {'1-D ' if one_d else ''}{fh}x{fw} pad {pad} flip {flip}"
         assert tuple(out.shape) == tuple(ref.shape), tag
-        tol = 4e-3 if dtype == torch.float16 else 1e-5
+        tol = {torch.float16: 4e-3, torch.float32: 1e-5, torch.float64: 1e-12}[dtype]     # (float64 accumulates in double: anything above rounding is a float path)
         assert rel_err(out, ref) < tol, tag
         done += 1
     assert done > 140
@@ -131,6 +137,9 @@ def test_bias_act_random():
         (gx,) = torch.autograd.grad((yg * gy.to(dtype).cuda()).sum(), xg)
         tag = f"case {case}: {shape} dim {dim} {act} alpha {alpha} gain {gain} clamp {clamp} bias {has_b} {dtype}"
         tol = 4e-3 if dtype == torch.float16 else 1e-5
+        if dtype == torch.float64:                       # double all the way, except that alpha / gain / clamp cross the ABI as floats (bias_act.cpp:24)
+            exact = gain is None and clamp is None and act in ("linear", "tanh", "sigmoid", "elu", "selu", "softplus")
+            tol = 1e-13 if exact else 2e-7
         assert yg.dtype == dtype and tuple(yg.shape) == tuple(shape), tag
         assert rel_err(yg, yr) < tol, tag
         if clamp is None:                                # (at a clamp boundary the two sides may round to different sides of it)
