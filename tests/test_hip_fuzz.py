@@ -363,6 +363,91 @@ def test_transposed_conv_random_shapes():
         out = cv.tconv3x3s2_forward(x.cuda(), cv.pack_weights(wt.cuda()), in_scale=s.cuda(), out_scale=d.cuda())
         assert tuple(out.shape) == tuple(ref.shape) and rel_err(out, ref) < 2e-5, (case, "tconv", n, cin, cout, h, w)
 
+def test_projection_engine_random_option_combinations():
+    """The literal loop's plumbing under option COMBINATIONS nobody wrote a test for (candidates per forward that do not divide the step count, graph replay
+    and the two-stream pipeline, wing / adaptive wing with "no face" steps, LPIPS on or off with its coefficient, each pixel term, the v2 driver's averaged
+    latent copies): every recorded loss against the same terms evaluated one candidate at a time through the public modules, the best
+    step by the drivers' rule (strictly smaller than everything before, skipped steps never), the kept latent bit-exact."""
+    from morphganformer_amd.engine import Generator
+    from morphganformer_amd.lpips import PerceptualLoss
+    from morphganformer_amd.projection import ProjectionArgs, ProjectionEngine, synthetic_landmarks
+    from morphganformer_amd.synth_weights import TINY, make_state_dict
+    from oracle.loss_ref import adaptive_wing_loss_ref, dssim_ref, psnr_ref, psnr_script_ref, wing_loss_ref
+    cfg = TINY
+    G = Generator(make_state_dict(TINY, seed=0), TINY, "cuda", max_batch=1)
+    P = PerceptualLoss(net="squeeze", allow_random_backbone=True)
+    r = _rng(1515)
+    for case in range(14):
+        steps = int(r.integers(3, 13))
+        batch = int(r.choice([1, 2, 3, 4, 5, 7]))
+        use_graph, pipeline = bool(r.integers(0, 2)), bool(r.integers(0, 2))
+        copies = int(r.choice([1, 1, 3]))
+        pixel = str(r.choice(["mse", "mse", "psnr", "dssim", "none"]))
+        layout = str(r.choice(["script", "aligned"]))
+        use_percept = bool(r.integers(0, 2)) or pixel == "none"
+        wing = str(r.choice(["none", "wing", "awing"]))
+        a = ProjectionArgs(step=steps, lamda=float(r.uniform(1e-3, 2e-2)) if wing != "awing" else 1e-5, beta=float(r.uniform(0.2, 2.0)),
+                           percept_weight=float(r.uniform(0.3, 1.5)), min_loss_init=float(r.choice([1e9, 1e12])),      # (the tiny generator's images reach MSE 200: the drivers' 100 would end in the reference's IndexError)
+                           pixel_term="mse" if pixel == "none" else pixel, psnr_layout=layout, latent_copies=copies)
+        torch.manual_seed(15000 + case + _OFFSET)
+        latent_mean = torch.randn(cfg.k, cfg.z_dim)
+        latent_std = float(r.uniform(0.5, 2.0))
+        eps = torch.randn(steps, 1, copies, cfg.k, cfg.z_dim) if copies > 1 else torch.randn(steps, 1, cfg.k, cfg.z_dim)
+        target = G(torch.randn(1, cfg.k, cfg.z_dim).cuda(), None, noise_mode="const")[0].clamp(-1, 1).clone()
+        kw = {}
+        valid = np.ones(steps, np.int32)
+        if wing != "none":
+            lm_t, lm_s = synthetic_landmarks(steps, 64, 50 + case)
+            if wing == "awing":
+                lm_t, lm_s = lm_t / 64.0, lm_s / 64.0
+            valid[r.integers(0, steps, int(r.integers(0, 3)))] = 0
+            valid[int(r.integers(0, steps))] = 1
+            kw.update(lm_target=lm_t, lm_steps=lm_s, lm_valid=valid, wing_kind=wing)
+        tag = (case, steps, batch, use_graph, pipeline, copies, pixel, layout, use_percept, wing, valid.tolist())
+        eng = ProjectionEngine(G, target, latent_mean.cuda(), latent_std, a, percept=P if use_percept else None, use_mse=pixel != "none",
+                               eps=eps.cuda(), noise_mode="const", use_graph=use_graph, batch=batch, pipeline=pipeline, **kw)
+        try:
+            lat, bstep, bloss, losses = eng.run().result()
+        except IndexError:
+            raise AssertionError((tag, "no step improved", eng.losses.cpu().numpy(), a))
+        want, zs = [], []
+        tgt_np = target.cpu().numpy()
+        for i in range(steps):
+            sigma = np.float32(np.float32(latent_std) * np.float32(a.noise)) * np.float32(max(0, 1 - (i / steps) / a.noise_ramp) ** 2)
+            if copies > 1:
+                z = torch.mean(latent_mean[None, None].expand(1, copies, -1, -1) + eps[i] * float(sigma), 1)      # torch.mean over the copies (v2 driver :166)
+            else:
+                z = latent_mean[None] + eps[i] * float(sigma)
+            zs.append(z)
+            if not valid[i]:
+                want.append(np.nan)
+                continue
+            img = G(z.cuda(), None, noise_mode="const")[0]
+            v = 0.0
+            if wing == "wing":
+                v += a.lamda * float(wing_loss_ref(torch.from_numpy(lm_s[i]), torch.from_numpy(lm_t)))
+            elif wing == "awing":
+                v += a.lamda * float(adaptive_wing_loss_ref(torch.from_numpy(lm_s[i]), torch.from_numpy(lm_t)))
+            if use_percept:
+                v += a.percept_weight * float(P(img, target))
+            if pixel == "mse":
+                v += a.beta * float(torch.nn.functional.mse_loss(img, target))
+            elif pixel == "psnr":
+                v += a.beta * float((psnr_script_ref if layout == "script" else psnr_ref)(img.cpu().numpy(), tgt_np))
+            elif pixel == "dssim":
+                v += a.beta * float(dssim_ref(img.cpu().numpy()[0], tgt_np[0]))
+            want.append(v)
+        want = np.array(want)
+        assert np.array_equal(np.isnan(losses), np.isnan(want)), tag
+        ok = ~np.isnan(want)
+        assert np.abs(losses[ok] - want[ok]).max() < 2e-4 * np.abs(want[ok]).max() + (1e-3 if pixel == "dssim" else 0.0), (tag, losses, want)
+        best, cur = -1, a.min_loss_init
+        for i in range(steps):
+            if ok[i] and losses[i] < cur:
+                best, cur = i, losses[i]
+        assert bstep == best and bloss == float(losses[best]), (tag, bstep, best)
+        assert torch.equal(lat.reshape(-1), zs[best].reshape(-1)), tag
+
 
 @pytest.mark.parametrize("net", ["squeeze", "alex", "vgg"])
 def test_lpips_random_non_square_sizes(net):
