@@ -510,10 +510,21 @@ def test_generator_random_configurations_vs_oracle(res, base, cmax, att, norm_g)
     G = Generator(sd, cfg, "cuda", max_batch=3)
     torch.manual_seed(res * 7 + cmax + _OFFSET)
     z = torch.randn(3, cfg.k, cfg.z_dim)
-    ref = generator_ref(to_torch_state(sd), z, cfg, "const")
-    img = G(z.cuda(), None, noise_mode="const")[0]
+    taps = {}
+    ref = generator_ref(to_torch_state(sd), z, cfg, "const", taps=taps)
+    img, att = G(z.cuda(), None, noise_mode="const", return_att=True, att_format="maps")
     assert tuple(img.shape) == (3, 3, res, res)
     assert rel_err(img, ref) < 1e-3
+    # the integer gate on every attention layer of the configuration: the latent a pixel is assigned to, exact wherever the oracle's top two are 1e-4 apart
+    layers = [k[:-len(":probs")] for k in taps if k.endswith(":probs")]
+    assert sorted(layers) == sorted(att) and len(layers) >= 1
+    for key in layers:
+        probs, argmax = att[key]
+        want = taps[key + ":probs"].detach().numpy().reshape(probs.shape)
+        assert np.abs(probs.cpu().numpy() - want).max() < 1e-4, key
+        top2 = np.sort(want, axis=-1)[..., -2:]
+        decided = (top2[..., 1] - top2[..., 0]) > 1e-4
+        assert decided.mean() > 0.97 and np.array_equal(argmax.cpu().numpy()[decided], want.argmax(-1)[decided]), key
     ref0 = generator_ref(to_torch_state(sd), z[:2], cfg, "none", truncation_psi=0.6)
     img0 = G(z[:2].cuda(), None, noise_mode="none", truncation_psi=0.6)[0]
     assert rel_err(img0, ref0) < 1e-3
