@@ -103,10 +103,10 @@ def parse():
                          "rank) and a strong pass (--config3-targets in all), per-rank item counts and busy times in the line")
     ap.add_argument("--config3-targets", type=int, default=16, help="targets per rank (weak pass) / in all (strong pass) of --workload config3")
     ap.add_argument("--config3-steps", type=int, default=128, help="loop steps per target of --workload config3 (the drivers run 1000+)")
-    ap.add_argument("--pipeline", type=int, default=0,
-                    help="1 = overlap the losses of batch i with the generator of batch i+1 on two streams (+3 %% iters/s; kernels of the two "
-                         "streams then stretch each other, so per-kernel durations -- and the roofline object -- no longer describe a kernel "
-                         "running alone); 0 = one stream (default: keeps roofline and rocprofv3 per-kernel figures clean)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="1 (default since round 6) = the losses and the selection of batch i run on a side stream while the generator synthesises batch "
+                         "i+1 (ProjectionEngine(pipeline=True): the same result bit for bit, +1.5-2 %% iters/s; the roofline leg and a rocprofv3 trace of "
+                         "this command see the same two-stream schedule, so their per-kernel durations still agree with each other); 0 = one stream")
     ap.add_argument("--gradient-steps", type=int, default=20,
                     help="steps of the extra gradient-mode leg (loss back-propagated into the latent, Adam; rank 0, N=1 only); 0 = skip")
     ap.add_argument("--gradient-lockstep", type=str, default="8,16,32",
@@ -385,7 +385,7 @@ def gradient_leg(sd, cfg, device, eng, steps, lockstep=(8,)):
                     "the reference loop severs this gradient, so the headline metric stays the literal loop"}
 
 
-def many_targets_leg(cfg, device, G, percept, batch, n_targets, steps):
+def many_targets_leg(cfg, device, G, percept, batch, n_targets, steps, pipeline=False):
     """Projections per second over a list of targets, set-up included (missing #3): the reference's serial per-image
     loop (projection_example_v2_percept_morph.py:329-365) through drivers.project_image, the first call building the engine (latent
     statistics over 10 000 samples, LPIPS target taps, hipGraph capture), the others re-targeting it in place."""
@@ -402,7 +402,7 @@ def many_targets_leg(cfg, device, G, percept, batch, n_targets, steps):
     for j in range(n_targets):
         t0 = time.perf_counter()
         r = drivers.project_image(G, targets[j], lms[j][0], lms[j][1], args=args, percept=percept, batch=batch, seed=40 + j,
-                                  engine=eng, return_engine=True)
+                                  engine=eng, return_engine=True, pipeline=pipeline)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
         eng = r["engine"]
@@ -431,7 +431,7 @@ def many_targets_leg(cfg, device, G, percept, batch, n_targets, steps):
                     "re-target that engine in place (ProjectionEngine.retarget) and replay its graph"}
 
 
-def config4_leg(cfg, device, G, percept, batch, steps, latent_mean, latent_std):
+def config4_leg(cfg, device, G, percept, batch, steps, latent_mean, latent_std, pipeline=False):
     """BASELINE config 4 (1024_merge_morph_2.py:83-92 after two `projection()` calls): two literal-mode projections of `steps` steps with
     configs[1]'s objective through ONE engine (built for the first target, re-targeted for the second), then the 11-alpha sweep
     `(1-a) w1 + a w2`, a = 0, 0.1 .. 1, rendered as ONE batch-11 generator forward.  Timed end to end, engine set-up included."""
@@ -448,7 +448,7 @@ def config4_leg(cfg, device, G, percept, batch, steps, latent_mean, latent_std):
     for j in range(2):
         t1 = time.perf_counter()
         r = drivers.project_image(G, targets[j], lms[j][0], lms[j][1], args=ProjectionArgs(step=steps), percept=percept, batch=batch, seed=60 + j,
-                                  latent_mean=latent_mean, latent_std=latent_std, engine=eng, return_engine=True)
+                                  latent_mean=latent_mean, latent_std=latent_std, engine=eng, return_engine=True, pipeline=pipeline)
         torch.cuda.synchronize()
         tp.append(time.perf_counter() - t1)
         eng = r["engine"]
@@ -472,7 +472,7 @@ def config4_leg(cfg, device, G, percept, batch, steps, latent_mean, latent_std):
                     "allocating the batch-11 workspace"}
 
 
-def config5_leg(cfg, device, G, batch, n_targets, steps, latent_std):
+def config5_leg(cfg, device, G, batch, n_targets, steps, latent_std, pipeline=False):
     """BASELINE config 5 on one GPU: `n_targets` second-stage projections (edit_MSE.py:229-231 -- candidates drawn around a stage-1 latent
     instead of the latent mean; MSE objective and no landmarks, like the script) through drivers.project_many: ONE engine, re-targeted per
     item, results gathered by item id.  Timed end to end after a one-item warm-up (set-up is config 4's and many_targets' figure)."""
@@ -482,7 +482,7 @@ def config5_leg(cfg, device, G, batch, n_targets, steps, latent_std):
     zs = torch.from_numpy(synthetic_latents(cfg, n_targets + 1, seed=8000)).to(device)
     w1 = zs[n_targets] * 0.5                              # the stage-1 result every second stage starts from (`w = w1.reshape([17, 32])`)
     targets = [(lambda j=j: G(zs[j:j + 1], None, noise_mode="const")[0].clamp(-1, 1)) for j in range(n_targets)]
-    kw = dict(args=ProjectionArgs(step=steps), percept=None, batch=batch, latent_mean=w1, latent_std=float(latent_std), seed=9)
+    kw = dict(args=ProjectionArgs(step=steps), percept=None, batch=batch, latent_mean=w1, latent_std=float(latent_std), seed=9, pipeline=pipeline)
     drivers.project_many(G, targets[:1], **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -540,7 +540,7 @@ def bf16x3_leg(sd, cfg, device, G32, target, latent_mean, latent_std, batch, min
     return out
 
 
-def objective_leg(cfg, device, G, target, latent_mean, latent_std, batch, lpips_net="squeeze", facenet=False, min_seconds=0.6):
+def objective_leg(cfg, device, G, target, latent_mean, latent_std, batch, lpips_net="squeeze", facenet=False, min_seconds=0.6, pipeline=False):
     """One more objective of the north star through the SAME literal loop, timed like the headline (hipGraph replay, whole launch
     sequences, >= min_seconds): iters/s, HBM in use, and the dominant MFMA conv kernel of its iteration with its executed fraction."""
     from morphganformer_amd.lpips import PerceptualLoss
@@ -554,7 +554,7 @@ def objective_leg(cfg, device, G, target, latent_mean, latent_std, batch, lpips_
         bio = BiometricLoss("facenet", n=batch, device=device, seed=0)
     lm_t, lm_s = synthetic_landmarks(steps_total, cfg.img_resolution, seed=17)
     eng = ProjectionEngine(G, target, latent_mean, latent_std, ProjectionArgs(step=steps_total), percept=percept, use_mse=True, lm_target=lm_t,
-                           lm_steps=lm_s, noise_mode="random", seed=21, use_graph=True, batch=batch, biometric=bio, gamma=1.0)
+                           lm_steps=lm_s, noise_mode="random", seed=21, use_graph=True, batch=batch, biometric=bio, gamma=1.0, pipeline=pipeline)
     eng.run(batch)                                   # capture + one replay
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -1020,21 +1020,21 @@ def main():
                 log(f"gradient-mode leg failed: {exc}")
         if world == 1 and a.targets > 0 and not a.biometric and a.res == 1024:
             try:
-                out["many_targets"] = many_targets_leg(cfg, device, G, percept, a.batch, a.targets, a.target_steps)
+                out["many_targets"] = many_targets_leg(cfg, device, G, percept, a.batch, a.targets, a.target_steps, bool(a.pipeline))
                 log(f"many-target leg done: {out['many_targets']['value']} projections/s")
             except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                 out["many_targets"] = {"error": f"{type(exc).__name__}: {exc}"}
                 log(f"many-target leg failed: {exc}")
         if world == 1 and a.config4 and not a.biometric and a.res == 1024:
             try:
-                out["config4"] = config4_leg(cfg, device, G, percept, a.batch, a.target_steps, latent_mean, latent_std)
+                out["config4"] = config4_leg(cfg, device, G, percept, a.batch, a.target_steps, latent_mean, latent_std, bool(a.pipeline))
                 log(f"config4 leg done: {out['config4']['value']} projections/s, sweep {out['config4']['sweep_ms']} ms")
             except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                 out["config4"] = {"error": f"{type(exc).__name__}: {exc}"}
                 log(f"config4 leg failed: {exc}")
         if world == 1 and a.config5_targets > 0 and not a.biometric and a.res == 1024:
             try:
-                out["config5"] = config5_leg(cfg, device, G, a.batch, a.config5_targets, a.config5_steps, latent_std)
+                out["config5"] = config5_leg(cfg, device, G, a.batch, a.config5_targets, a.config5_steps, latent_std, bool(a.pipeline))
                 log(f"config5 leg done: {out['config5']['value']} projections/s")
             except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                 out["config5"] = {"error": f"{type(exc).__name__}: {exc}"}
@@ -1048,7 +1048,7 @@ def main():
                     ("config3", obs[0], dict(facenet=True), c3)] + [(f"config3_b{b}", b, dict(facenet=True), c3) for b in obs[1:]]
             for name, ob, kw, what in legs:
                 try:
-                    out["objectives"][name] = dict(objective_leg(cfg, device, G, target, latent_mean, latent_std, ob, **kw), objective=what)
+                    out["objectives"][name] = dict(objective_leg(cfg, device, G, target, latent_mean, latent_std, ob, **kw), objective=what)   # (one stream: the heavy loss phases lose 1 - 1.5 % to the pipeline, tools/pipeline_legs_ab.sh)
                     log(f"objective leg {name}: {out['objectives'][name]['value']} iters/s")
                 except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                     out["objectives"][name] = {"error": f"{type(exc).__name__}: {exc}"}

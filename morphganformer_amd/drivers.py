@@ -211,7 +211,7 @@ DEFAULT_BATCH = 32       # loop steps per generator forward in literal mode: the
 def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None,
                   eps=None, out_prefix=None, batch=DEFAULT_BATCH, use_graph=True, noise_mode="random", use_mse=True, seed=None,
                   landmark_fn=None, mode="literal", weight_decay=0.0, path_to_gen=None, keep_images=64, engine=None,
-                  return_engine=False, latent_space="z", landmark_input="float", biometric=None, gamma=1.0, lbp_target=None):
+                  return_engine=False, latent_space="z", landmark_input="float", biometric=None, gamma=1.0, lbp_target=None, pipeline=None):
     """One full `projection(...)` call (:135-208).  `target`: [1,3,S,S] from image_transform; `lm_target` [68,2] and either
     `lm_steps` [steps,68,2] (injected landmark detections) or `landmark_fn` (host detector called on every generated image,
     see ProjectionEngine; landmark_input="gray_u8" hands it the drivers' gray uint8 image, built on the device).  mode="literal" is the loop as the reference executes it (best-of-N noisy sampling, `batch` steps per
@@ -232,6 +232,12 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
     `{out_prefix}.mat` (key 'w', :201-206 of the morph drivers) and, when no `path_to_gen` trail is written, the best latent's
     rendering as `{out_prefix}.png`.
 
+    pipeline: literal mode without a host landmark callback -- the losses and the selection of one batch of candidates run on a side stream while the
+    generator already synthesises the next batch (ProjectionEngine(pipeline=True): same result, bit for bit; one more image batch of memory).  None
+    (default) = where it was measured to pay: the light objectives -- no perceptual term or LPIPS(squeeze), no embedder (+1.9 % on a 1000-step
+    projection at 1024^2 and 32 candidates per forward; LPIPS(vgg) and the FaceNet term, whose own matrix work then competes with the generator's,
+    lose 1 - 1.5 % and stay on one stream).
+
     engine: a ProjectionEngine from an earlier call with the same generator, objective, step count and batch (return_engine=True
     hands it out) -- it is re-targeted in place (`ProjectionEngine.retarget`), which keeps its captured hipGraph and workspaces; this is
     how `project_many` walks a list of targets."""
@@ -249,10 +255,13 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
             gen.manual_seed(seed)
         stats = latent_stats_w if latent_space == "w+" else latent_stats
         latent_mean, latent_std = stats(G, args.n_mean_latent, G.device, generator=gen)
+    if pipeline is None:
+        pipeline = mode == "literal" and landmark_fn is None and biometric is None and getattr(percept, "net", "squeeze") == "squeeze"
     keep = max(int(keep_images), int(batch)) if path_to_gen is not None and mode == "literal" else 0
     if engine is not None:
-        if engine.G is not G or engine.batch != batch or engine.steps != args.step or engine.keep_images != keep:
-            raise ValueError("engine= was built for another generator / batch / step count / trail size")
+        if (engine.G is not G or engine.batch != batch or engine.steps != args.step or engine.keep_images != keep or
+                engine.pipeline != (bool(pipeline) and landmark_fn is None)):
+            raise ValueError("engine= was built for another generator / batch / step count / trail size / pipeline mode")
         # the objective is baked into the captured launch sequence: a re-targeted engine must score exactly what a fresh one would
         diff = [name for name, ok in (("landmarks (Wing term)", engine.use_wing == (lm_target is not None)),
                                       ("percept", engine.percept is percept), ("use_mse", engine.use_mse == bool(use_mse)),
@@ -272,7 +281,7 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
         eng = ProjectionEngine(G, target, latent_mean, float(latent_std), args, percept=percept, lm_target=lm_target,
                                lm_steps=lm_steps, eps=eps, noise_mode=noise_mode, use_graph=use_graph, batch=batch, use_mse=use_mse,
                                landmark_fn=landmark_fn, keep_images=keep, seed=0 if seed is None else seed, landmark_input=landmark_input,
-                               biometric=biometric, gamma=gamma, lbp_target=lbp_target)
+                               biometric=biometric, gamma=gamma, lbp_target=lbp_target, pipeline=pipeline)
     w, step, loss, losses = eng.run().result()
     out = {"w": w, "step": step, "loss": loss, "losses": losses}
     if out_prefix is not None:
@@ -408,11 +417,12 @@ def morph_pairs(G, pairs, src_dir, dst_raw, dst_morph, landmarks=None, truncatio
 
 def _project_group(G, targets, landmarks, args: ProjectionArgs = None, percept=None, latent_mean=None, latent_std=None, eps=None,
                    use_graph=True, noise_mode="random", use_mse=True, seed=None, weight_decay=0.0, mode="gradient", latent_space="z",
-                   biometric=None, gamma=1.0, batch=None, **unused):
+                   biometric=None, gamma=1.0, batch=None, pipeline=None, **unused):
     """B targets through one lockstep GradientProjectionEngine; returns dict(w [B,k,D] (W+: [B,k,num_ws,D]), step [B], loss [B],
     losses [B,steps])."""
     args = args or ProjectionArgs()
-    if unused:                                      # (`batch` is literal mode's steps per forward: gradient mode evaluates one candidate per step)
+    if unused or pipeline:                          # (`batch` is literal mode's steps per forward: gradient mode evaluates one candidate per step; `pipeline` is literal mode's too)
+        unused = dict(unused, **({"pipeline": pipeline} if pipeline else {}))
         raise TypeError(f"project_many(lockstep=...): unsupported arguments {sorted(unused)}")
     if latent_mean is None or latent_std is None:
         gen = None

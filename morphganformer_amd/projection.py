@@ -148,8 +148,8 @@ class ProjectionEngine:
         pipeline: software-pipeline consecutive batches over two streams -- while the losses and the selection of batch i run
         on a side stream, the generator already synthesises batch i+1 (its own latent / image buffers and step counter).  The
         literal loop's steps are independent, and selection still happens in step order, so results are unchanged; one extra
-        generator batch is in flight at any time (an engine that is `run()` to its last step has synthesised one batch more
-        than it scored).
+        generator batch is in flight at any time, and the run's last launch sequence scores its batch with nothing beside it (the
+        first generator batch and the last loss phase are the two un-overlapped ends: B generator forwards for B scored batches).
 
         keep_images: K > 0 keeps the SCORED image of every improvement on the device (the drivers write `{step:06d}_{loss:04f}.png`
         of exactly that image -- random per-layer noise included -- at every improvement, :186-195): a trail of up to K images with
@@ -312,8 +312,10 @@ class ProjectionEngine:
             self.gen_ctr = torch.zeros(1, dtype=torch.int32, device=dev)          # step counter of the generator side
             self.loss_stream = torch.cuda.Stream(device=dev)
             self.graphs = [None, None]
+            self.tail_graphs = [None, None]                                       # losses only: the run's LAST launch sequence has no next batch to synthesise
             self._parity = 0
             self._primed = False
+            self._seq_launched = 0                                                # host count of launch sequences since the last rewind
 
     def _init_pool(self, B):
         """projection_example_v1.py:150-155: images above `pool_above` pixels are block-averaged by height // pool_above in front of the
@@ -434,6 +436,10 @@ class ProjectionEngine:
         self._pipe_gen(p ^ 1)
         main.wait_stream(self.loss_stream)
 
+    def _pipe_tail(self, p):
+        """The run's last launch sequence: losses + selection of the batch in buffers p, nothing left to synthesise beside them."""
+        self._loss_phase(self.imgs[p], self.latent_ns[p])
+
     def _pipe_capture(self):
         tensors = self._state() + (self.gen_ctr,)
         state = [t.clone() for t in tensors]
@@ -449,6 +455,10 @@ class ProjectionEngine:
             with torch.cuda.graph(g):
                 self._pipe_step(p)
             self.graphs[p] = g
+            t = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(t, pool=g.pool()):
+                self._pipe_tail(p)
+            self.tail_graphs[p] = t
         for dst, src in zip(tensors, state):
             dst.copy_(src)
         self._pin_workspace()
@@ -459,13 +469,18 @@ class ProjectionEngine:
         if not self._primed:
             self._pipe_gen(self._parity)                                  # the first batch has no losses to overlap with
             self._primed = True
+        last = -(-self.steps // self.batch) - 1                          # index of the sequence that scores the run's last candidates
         for _ in range(n):
             self._before_sequence()
+            final = self._seq_launched >= last                            # (and anything a caller launches past the end: nothing left to score)
             if self.use_graph:
-                self.graphs[self._parity].replay()
+                (self.tail_graphs if final else self.graphs)[self._parity].replay()
+            elif final:
+                self._pipe_tail(self._parity)
             else:
                 self._pipe_step(self._parity)
             self._parity ^= 1
+            self._seq_launched += 1
 
     # ------------------------------------------------------------------ callback mode on the gray uint8 image
     def _cb_phase_a(self):
@@ -726,7 +741,7 @@ class ProjectionEngine:
             self._host_step = 0
         if self.pipeline:
             self.gen_ctr.zero_()
-            self._parity, self._primed = 0, False
+            self._parity, self._primed, self._seq_launched = 0, False, 0
         return self
 
     def result(self):

@@ -165,6 +165,46 @@ def test_improvement_trail_keeps_the_scored_images(golden):
     assert float((trail[1][2].cuda() - fresh).abs().max()) < 1e-5 * float(fresh.abs().max())
 
 
+def test_project_image_pipeline_option_equals_the_plain_loop(tmp_path):
+    """drivers.project_image(pipeline=True): the losses of one batch of candidates on a side stream beside the generator of the next, the run's last
+    launch sequence scoring alone -- the same latent, step, loss history and the same improvement PNGs (names and bytes) as the one-stream loop, also
+    through a re-targeted engine, with a step count the batch does not divide and the improvement trail spilled on the way; and an engine built for one
+    mode is refused for the other."""
+    import glob
+    from morphganformer_amd import drivers
+    from morphganformer_amd.lpips import PerceptualLoss
+    from morphganformer_amd.projection import ProjectionArgs, synthetic_landmarks
+    from morphganformer_amd.synth_weights import TINY, synthetic_latents
+    G = _tiny_G()
+    P = PerceptualLoss(net="squeeze", allow_random_backbone=True)
+    steps, batch = 37, 5
+    zs = torch.from_numpy(synthetic_latents(TINY, 2, seed=77)).cuda()
+    targets = [G(zs[j:j + 1], None, noise_mode="const")[0].clamp(-1, 1).clone() for j in range(2)]
+    lms = [synthetic_landmarks(steps, 64, 600 + j) for j in range(2)]
+    torch.manual_seed(9)
+    latent_mean = torch.randn(TINY.k, TINY.z_dim, device="cuda")
+    runs = {}
+    for pipe in (False, True):
+        eng, res = None, []
+        for j in range(2):
+            d = tmp_path / f"pipe{int(pipe)}_{j}"
+            r = drivers.project_image(G, targets[j], lms[j][0], lms[j][1], args=ProjectionArgs(step=steps, min_loss_init=1e9), percept=P, batch=batch,
+                                      seed=40 + j, latent_mean=latent_mean, latent_std=1.5, path_to_gen=str(d), keep_images=6, engine=eng,
+                                      return_engine=True, pipeline=pipe, noise_mode="const")      # (random per-layer noise is drawn in launch order, which the two modes' set-up passes advance differently)
+            eng = r["engine"]
+            files = {os.path.basename(f): open(f, "rb").read() for f in sorted(glob.glob(str(d / "*.png")))}
+            res.append((r["w"].clone(), r["step"], r["loss"], np.array(r["losses"]), files))
+        assert eng.pipeline == pipe
+        runs[pipe] = (res, eng)
+    for (w0, s0, l0, h0, f0), (w1, s1, l1, h1, f1) in zip(runs[False][0], runs[True][0]):
+        assert torch.equal(w0, w1) and s0 == s1 and l0 == l1 and np.array_equal(h0, h1)
+        assert len(f0) >= 2 and f0 == f1
+    with pytest.raises(ValueError, match="pipeline"):
+        drivers.project_image(G, targets[0], lms[0][0], lms[0][1], args=ProjectionArgs(step=steps, min_loss_init=1e9), percept=P, batch=batch, seed=40,
+                              latent_mean=latent_mean, latent_std=1.5, path_to_gen=str(tmp_path / "x"), keep_images=6, engine=runs[False][1], pipeline=True,
+                              noise_mode="const")
+
+
 def test_retargeted_engine_equals_fresh_engines(golden):
     """ProjectionEngine.retarget: one engine (one captured hipGraph, one set of workspaces) walked over three targets gives, for every
     target, the run of a freshly constructed engine bit for bit -- best latent, best step, loss history, improvement trail -- with the
