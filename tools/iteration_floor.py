@@ -2,7 +2,7 @@
     time per iteration (rocprofv3 kernel trace, loop only), the time its matrix pipes were busy (mfma_busy x time, MFMA counter pass) and the time
     its HBM-side traffic needs at the rate a copy reaches on this part (2 x FETCH + WRITE over HBM_TBS),
 and what is left when the larger of the two is taken away:   python tools/iteration_floor.py [round tag, default r4] [HBM TB/s, default 5.0]
-Reads profiles/<tag>_bench_kernel_stats_loop.txt, <tag>_pmc_mfma.json, <tag>_pmc_traffic.json."""
+Reads profiles/<tag>_bench_kernel_stats_one_stream_loop.txt (or <tag>_bench_kernel_stats_loop.txt), <tag>_pmc_mfma.json, <tag>_pmc_traffic.json."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
@@ -10,7 +10,8 @@ tbs = float(sys.argv[2]) if len(sys.argv) > 2 else 5.0
 short = lambda n: n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
 rows = {}
 iters = None
-for line in open(os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats_loop.txt")):
+one = os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats_one_stream_loop.txt")          # (round 6 on: the default run is two-stream, the floors need kernels running alone)
+for line in open(one if os.path.exists(one) else os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats_loop.txt")):
     m = re.match(r"^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
     if not m:
         continue

@@ -9,7 +9,11 @@ rm -rf "$D"; mkdir -p "$D"
 echo "[measure] bench"; python3 bench.py > $D/bench.json 2> $D/bench.err
 echo "[measure] kernel trace"; LEAN="--no-cpu-baseline --gradient-steps 0 --targets 0 --landmark-callback none --objectives 0 --config4 0 --config5-targets 0 --bf16x3-leg 0"
 rocprofv3 --kernel-trace --stats -d $D/trace -- python3 bench.py --steps 20 --warmup 2 $LEAN > $D/trace_bench.json 2> $D/trace.err
-ARGS="--steps 1 --warmup 1 --batch $B --no-graph $LEAN"
+# the same on ONE stream (--pipeline 0): kernels running alone, for the per-iteration analyses (iteration trace / floor) and the counter passes -- in the
+# default two-stream schedule the loss phase's kernels run beside the generator's and their durations (and per-kernel busy counters) describe the pair
+echo "[measure] kernel trace, one stream"
+rocprofv3 --kernel-trace --stats -d $D/trace1 -- python3 bench.py --steps 20 --warmup 2 --pipeline 0 $LEAN > $D/trace1_bench.json 2> $D/trace1.err
+ARGS="--steps 1 --warmup 1 --batch $B --no-graph --pipeline 0 $LEAN"
 echo "[measure] pmc fetch"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -- python3 bench.py $ARGS > $D/pmc_fetch.json 2> $D/pmc_fetch.err
 echo "[measure] pmc write"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -- python3 bench.py $ARGS > $D/pmc_write.json 2> $D/pmc_write.err
 echo "[measure] pmc mfma"; rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $D/pmc_mfma -- python3 bench.py $ARGS > $D/pmc_mfma.json 2> $D/pmc_mfma.err
@@ -45,5 +49,5 @@ python3 tools/rocpd_stats.py $(ls -t $(find $D/trace_c3 -name "*_results.db") | 
 cp $D/c3_bench.json profiles/${R}_config3_bench.json
 python3 tools/pmc_mfma.py $D/pmc_mfma_c3 --json profiles/${R}_config3_pmc_mfma.json > profiles/${R}_config3_pmc_mfma.txt
 mkdir -p $D/profiles && cp profiles/${R}_* $D/profiles/
-rm -rf $D/trace $D/pmc_fetch $D/pmc_write $D/pmc_mfma $D/gtrace1 $D/gtrace8 $D/trace_vgg $D/pmc_mfma_vgg $D/trace_c3 $D/pmc_mfma_c3 $D/trace_bf $D/pmc_mfma_bf          # raw output: too large to travel back
+rm -rf $D/trace $D/trace1 $D/pmc_fetch $D/pmc_write $D/pmc_mfma $D/gtrace1 $D/gtrace8 $D/trace_vgg $D/pmc_mfma_vgg $D/trace_c3 $D/pmc_mfma_c3 $D/trace_bf $D/pmc_mfma_bf          # raw output: too large to travel back
 echo "[measure] done"; ls -la $D/profiles

@@ -7,7 +7,9 @@ cd "$(dirname "$0")/.."
 DB=$(ls -t $(find $D/trace -name "*_results.db") | head -1)      # the newest database: a re-used directory may hold an older one
 python tools/rocpd_stats.py $DB > profiles/${R}_bench_kernel_stats.txt
 python tools/rocpd_stats.py $DB --loop-only > profiles/${R}_bench_kernel_stats_loop.txt
-python tools/iter_trace.py $DB > profiles/${R}_iteration_trace.txt 2>&1
+DB1=$DB; if [ -d $D/trace1 ]; then DB1=$(ls -t $(find $D/trace1 -name "*_results.db") | head -1); fi      # one-stream trace (measure_pass.sh) for the per-iteration analysis
+python tools/rocpd_stats.py $DB1 --loop-only > profiles/${R}_bench_kernel_stats_one_stream_loop.txt
+python tools/iter_trace.py $DB1 > profiles/${R}_iteration_trace.txt 2>&1
 python tools/pmc_mfma.py $D/pmc_mfma --json profiles/${R}_pmc_mfma.json > profiles/${R}_pmc_mfma.txt
 cp $D/bench.json profiles/${R}_bench.json
 CAL=$(sed -n '/^calibration/,$p' profiles/r1_pmc_traffic.txt)
