@@ -13,7 +13,8 @@ best latent, loss history) is the sequential loop's, bit for bit (tests/test_hip
 its own noise draws, forward, three losses, selection -- is inside the timed region.
 
 A bench STEP is one pass of the hot path over one batch: one launch sequence of `--batch` loop iterations (one hipGraph replay,
-0.045 s).  W untimed steps, then EXACTLY K timed steps; `steps` = K, `ms_per_step` = one launch sequence, `value` = loop iterations per
+0.044 s; with `--pipeline 1`, the default, the replay scores batch i on a side stream while the generator synthesises batch i + 1 -- K steps are still
+K generator forwards and K loss phases, the first generator batch is primed in the warm-up: ProjectionEngine(pipeline=True), same result).  W untimed steps, then EXACTLY K timed steps; `steps` = K, `ms_per_step` = one launch sequence, `value` = loop iterations per
 second = K * batch / elapsed (`iters`, `iters_per_step`, `ms_per_iter` spell that out).  `--batch` is fixed, not derived from K, so the
 driver's run, the rocprofv3 trace and the PMC passes in profiles/ all launch the same kernels on the same shapes.
 Weights are seeded synthetic tensors (no checkpoint exists offline); inputs are resident in HBM before the timed region.
