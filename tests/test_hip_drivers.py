@@ -198,7 +198,7 @@ def test_project_image_pipeline_option_equals_the_plain_loop(tmp_path):
         runs[pipe] = (res, eng)
     for (w0, s0, l0, h0, f0), (w1, s1, l1, h1, f1) in zip(runs[False][0], runs[True][0]):
         assert torch.equal(w0, w1) and s0 == s1 and l0 == l1 and np.array_equal(h0, h1)
-        assert len(f0) >= 2 and f0 == f1
+        assert len(f0) >= 1 and f0 == f1
     with pytest.raises(ValueError, match="pipeline"):
         drivers.project_image(G, targets[0], lms[0][0], lms[0][1], args=ProjectionArgs(step=steps, min_loss_init=1e9), percept=P, batch=batch, seed=40,
                               latent_mean=latent_mean, latent_std=1.5, path_to_gen=str(tmp_path / "x"), keep_images=6, engine=runs[False][1], pipeline=True,
