@@ -1021,21 +1021,21 @@ def main():
                 log(f"gradient-mode leg failed: {exc}")
         if world == 1 and a.targets > 0 and not a.biometric and a.res == 1024:
             try:
-                out["many_targets"] = many_targets_leg(cfg, device, G, percept, a.batch, a.targets, a.target_steps, bool(a.pipeline))
+                out["many_targets"] = many_targets_leg(cfg, device, G, percept, a.batch, a.targets, a.target_steps, None if a.pipeline else False)
                 log(f"many-target leg done: {out['many_targets']['value']} projections/s")
             except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                 out["many_targets"] = {"error": f"{type(exc).__name__}: {exc}"}
                 log(f"many-target leg failed: {exc}")
         if world == 1 and a.config4 and not a.biometric and a.res == 1024:
             try:
-                out["config4"] = config4_leg(cfg, device, G, percept, a.batch, a.target_steps, latent_mean, latent_std, bool(a.pipeline))
+                out["config4"] = config4_leg(cfg, device, G, percept, a.batch, a.target_steps, latent_mean, latent_std, None if a.pipeline else False)
                 log(f"config4 leg done: {out['config4']['value']} projections/s, sweep {out['config4']['sweep_ms']} ms")
             except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                 out["config4"] = {"error": f"{type(exc).__name__}: {exc}"}
                 log(f"config4 leg failed: {exc}")
         if world == 1 and a.config5_targets > 0 and not a.biometric and a.res == 1024:
             try:
-                out["config5"] = config5_leg(cfg, device, G, a.batch, a.config5_targets, a.config5_steps, latent_std, bool(a.pipeline))
+                out["config5"] = config5_leg(cfg, device, G, a.batch, a.config5_targets, a.config5_steps, latent_std, None if a.pipeline else False)   # (the drivers' own policy: MSE-only objective -> one stream)
                 log(f"config5 leg done: {out['config5']['value']} projections/s")
             except Exception as exc:        # noqa: BLE001 -- reported in the line instead
                 out["config5"] = {"error": f"{type(exc).__name__}: {exc}"}

@@ -67,7 +67,7 @@ def _loop_arguments(p):
                         "activations at 1024^2)")
     p.add_argument("--pipeline", type=int, default=-1, choices=[-1, 0, 1],
                    help="literal mode: score one batch of candidates on a side stream while the generator synthesises the next (same result); -1 = where it pays "
-                        "(no perceptual term or LPIPS(squeeze), no embedder: +1.9 %% iterations/s), 0 = never, 1 = always")
+                        "(LPIPS(squeeze) without an embedder: +1.9 %% iterations/s), 0 = never, 1 = always")
     p.add_argument("--keep-images", type=int, default=64,
                    help="device slots for the scored image of every improvement (spilled to the host between launch sequences, so every "
                         "improvement gets its PNG like the reference; raised to --batch if smaller)")

@@ -234,9 +234,9 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
 
     pipeline: literal mode without a host landmark callback -- the losses and the selection of one batch of candidates run on a side stream while the
     generator already synthesises the next batch (ProjectionEngine(pipeline=True): same result, bit for bit; one more image batch of memory).  None
-    (default) = where it was measured to pay: the light objectives -- no perceptual term or LPIPS(squeeze), no embedder (+1.9 % on a 1000-step
-    projection at 1024^2 and 32 candidates per forward; LPIPS(vgg) and the FaceNet term, whose own matrix work then competes with the generator's,
-    lose 1 - 1.5 % and stay on one stream).
+    (default) = where it was measured to pay: LPIPS(squeeze) without an embedder (+1.9 % on a 1000-step projection at 1024^2 and 32 candidates per
+    forward; LPIPS(vgg) and the FaceNet term, whose own matrix work then competes with the generator's, lose 1 - 1.5 %, and with no perceptual term
+    there is nothing to overlap, -0.5 %: those stay on one stream).
 
     engine: a ProjectionEngine from an earlier call with the same generator, objective, step count and batch (return_engine=True
     hands it out) -- it is re-targeted in place (`ProjectionEngine.retarget`), which keeps its captured hipGraph and workspaces; this is
@@ -256,7 +256,7 @@ def project_image(G, target, lm_target, lm_steps, args: ProjectionArgs = None, p
         stats = latent_stats_w if latent_space == "w+" else latent_stats
         latent_mean, latent_std = stats(G, args.n_mean_latent, G.device, generator=gen)
     if pipeline is None:
-        pipeline = mode == "literal" and landmark_fn is None and biometric is None and getattr(percept, "net", "squeeze") == "squeeze"
+        pipeline = mode == "literal" and landmark_fn is None and biometric is None and getattr(percept, "net", None) == "squeeze"
     keep = max(int(keep_images), int(batch)) if path_to_gen is not None and mode == "literal" else 0
     if engine is not None:
         if (engine.G is not G or engine.batch != batch or engine.steps != args.step or engine.keep_images != keep or

@@ -312,6 +312,7 @@ class ProjectionEngine:
             self.gen_ctr = torch.zeros(1, dtype=torch.int32, device=dev)          # step counter of the generator side
             self.loss_stream = torch.cuda.Stream(device=dev)
             self.graphs = [None, None]
+            self.prime_graph = None
             self.tail_graphs = [None, None]                                       # losses only: the run's LAST launch sequence has no next batch to synthesise
             self._parity = 0
             self._primed = False
@@ -459,6 +460,10 @@ class ProjectionEngine:
             with torch.cuda.graph(t, pool=g.pool()):
                 self._pipe_tail(p)
             self.tail_graphs[p] = t
+        # the first batch of a run (nothing to score beside it yet) as a graph of its own: a re-targeted engine starts every run with it
+        self.prime_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.prime_graph, pool=self.graphs[0].pool()):
+            self._pipe_gen(0)
         for dst, src in zip(tensors, state):
             dst.copy_(src)
         self._pin_workspace()
@@ -467,7 +472,10 @@ class ProjectionEngine:
         if self.use_graph and self.graphs[0] is None:
             self._pipe_capture()                                          # (its warm-up overwrites both image buffers: capture first)
         if not self._primed:
-            self._pipe_gen(self._parity)                                  # the first batch has no losses to overlap with
+            if self.use_graph and self._parity == 0:
+                self.prime_graph.replay()                                 # the first batch has no losses to overlap with
+            else:
+                self._pipe_gen(self._parity)
             self._primed = True
         last = -(-self.steps // self.batch) - 1                          # index of the sequence that scores the run's last candidates
         for _ in range(n):
